@@ -1,0 +1,79 @@
+// tests/host_algos.cpp — compiles the product's per-work-item device algorithms (lexicmap_amd/csrc/lm_algos.h) for
+// the HOST so that the CPU test-suite can check the device logic against the oracle without a GPU.
+// TEST INFRASTRUCTURE ONLY: the product library never runs these on the host.
+#include "../lexicmap_amd/csrc/lm_algos.h"
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+extern "C" {
+
+uint64_t ha_revcomp(uint64_t x, int k) { return lm_revcomp(x, k); }
+uint64_t ha_reverse(uint64_t x, int k) { return lm_reverse(x, k); }
+int ha_dust(uint64_t x, int k) { return lm_dust(x, k); }
+int ha_low_complexity(uint64_t x, int k) { return lm_low_complexity(x, k); }
+int ha_base2bit(int c) { return lm_base2bit((uint8_t)c); }
+
+uint64_t ha_xor_argmin(const uint64_t *a, int n, uint64_t m, int *lo, int *hi) { return lm_xor_argmin(a, n, m, lo, hi); }
+
+uint64_t ha_pack_anchor(int qb, int len, int tb, int qrc, int trc) { return lm_pack_anchor(qb, len, tb, qrc, trc); }
+void ha_unpack_anchor(uint64_t v, LmSub *out) { *out = lm_unpack_anchor(v); }
+
+int ha_clear_sorted(LmSub *subs, int n, int k) {
+    std::vector<uint8_t> marks(n + 1);
+    return lm_clear_sorted(subs, n, k, marks.data());
+}
+
+float ha_chain1(const LmSub *subs, int n, float max_gap, float min_score, float max_distance, int top_chains,
+                const float *gap_lut, int gap_lut_n, int32_t *chain_off, int32_t *chain_idx, int *nchains) {
+    std::vector<uint64_t> msi(n + 1), s2i(n + 1);
+    std::vector<int8_t> dirs(n + 1);
+    std::vector<uint8_t> vis(n + 1);
+    LmChainOpt o;
+    o.max_gap = max_gap;
+    o.min_score = min_score;
+    o.max_distance = max_distance;
+    o.top_chains = top_chains;
+    o.gap_lut = gap_lut;
+    o.gap_lut_n = gap_lut_n;
+    return lm_chain1(subs, n, o, msi.data(), s2i.data(), dirs.data(), vis.data(), chain_off, chain_idx, nchains);
+}
+
+int ha_trim(const LmSub *subs, int n, float min_dist, int *start) { return lm_trim(subs, n, min_dist, start); }
+
+int ha_chain2(const LmSub *subs, int n, int max_gap, int min_score, int min_align_len, int band_count, int band_base,
+              double hpt, LmChain2 *out) {
+    std::vector<uint64_t> msi(n + 1);
+    std::vector<int32_t> stack(2 * (n + 2));
+    LmChain2Opt o;
+    o.max_gap = max_gap;
+    o.min_score = min_score;
+    o.min_align_len = min_align_len;
+    o.band_count = band_count;
+    o.band_base = band_base;
+    o.heuristic_pident = hpt;
+    return lm_chain2(subs, n, o, msi.data(), stack.data(), out);
+}
+
+void ha_extend_match(const uint8_t *seq1, int len1, const uint8_t *seq2, int len2, int start1, int end1, int start2,
+                     int end2, int ext_len, int tbegin, int max_ext_len, int rc, int *o) {
+    int cap = 200 * 200;
+    std::vector<LmSub> subs(cap);
+    std::vector<int64_t> msi(cap);
+    lm_extend_match(seq1, len1, seq2, len2, start1, end1, start2, end2, ext_len, tbegin, max_ext_len, rc != 0,
+                    subs.data(), msi.data(), cap, &o[0], &o[1], &o[2], &o[3], &o[4], &o[5], &o[6], &o[7]);
+}
+
+int ha_tree_search_range(const uint64_t *keys, int n, uint64_t key, int p, int K, int *lo, int *hi) {
+    return lm_tree_search_range(keys, n, key, p, K, lo, hi) ? 1 : 0;
+}
+
+// returns status; ops copied out
+int ha_wfa(const uint8_t *q, int plen, const uint8_t *t, int tlen, int max_score, int64_t arena_cap, uint64_t *ops,
+           int ops_cap, LmWfaOut *out) {
+    std::vector<int32_t> hdr((size_t)9 * max_score + 9);
+    std::vector<int32_t> arena((size_t)arena_cap);
+    lm_wfa_align(q, plen, t, tlen, hdr.data(), max_score, arena.data(), arena_cap, ops, ops_cap, out);
+    return out->status;
+}
+}

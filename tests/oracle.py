@@ -89,6 +89,10 @@ class CmpOpt(C.Structure):
                 ("min_identity", C.c_double)]
 
 
+class TreeSr(C.Structure):
+    _fields_ = [("kmer", C.c_uint64), ("len_prefix", C.c_uint8), ("vals", C.POINTER(C.c_uint32)), ("nvals", C.c_int)]
+
+
 _lib = None
 
 
@@ -152,6 +156,17 @@ def lib():
                                       C.POINTER(C.POINTER(Chain2)), C.POINTER(C.POINTER(Sub)), C.POINTER(C.c_int)]
         L.lmo_extend_match.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int] + [C.c_int] * 8 + \
             [C.POINTER(C.c_int)] * 8
+        L.lmo_tree_new.restype = C.c_void_p
+        L.lmo_tree_new.argtypes = [C.c_int]
+        L.lmo_tree_free.argtypes = [C.c_void_p]
+        L.lmo_tree_insert.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32]
+        L.lmo_tree_search.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.POINTER(TreeSr)), C.POINTER(C.c_int)]
+        L.lmo_trim_subs.argtypes = [C.POINTER(Sub), C.c_int, C.c_int, C.c_float, C.POINTER(C.c_int)]
+        L.lmo_lh_new.restype = C.c_void_p
+        L.lmo_lh_new.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.c_int]
+        L.lmo_lh_free.argtypes = [C.c_void_p]
+        L.lmo_lh_mask.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int,
+                                  C.POINTER(C.c_uint64), C.POINTER(C.POINTER(C.c_int)), C.POINTER(C.POINTER(C.c_int))]
         L.free = C.CDLL(None).free
         L.free.argtypes = [C.c_void_p]
         _lib = L
