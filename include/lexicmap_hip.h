@@ -1,0 +1,217 @@
+/*
+ * lexicmap_hip.h — C-ABI of the MI355X-native `lexicmap search` hot path (liblexicmap_hip.so).
+ *
+ * The reference (shenwei356/LexicMap) is pure Go built with CGO_ENABLED=0 and has no FFI of its own
+ * (lexicmap/build.sh:7); this header is the seam a cgo shim in lexicmap/cmd would bind (INTEGRATION.md shows it).
+ * Each entry point names the reference interface it replaces (paths relative to lexicmap/cmd/).
+ *
+ * Conventions
+ *   - plain C types only; every function returns lm_status (0 = LM_OK) unless noted; lm_last_error() gives the text.
+ *   - inputs are borrowed for the duration of the call (Go may move memory afterwards); outputs are callee-allocated
+ *     and released with the matching *_free (mirrors the reference's Recycle* hand-back, lib-index-search.go:1170).
+ *   - "no hit" is success with zero rows (the reference returns (nil,nil): lib-index-search.go:1669-1672).
+ *   - the library needs a gfx950 GPU: every entry point that computes fails with LM_ERR_NO_DEVICE otherwise. There
+ *     is no CPU fallback.
+ */
+#ifndef LEXICMAP_HIP_H
+#define LEXICMAP_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int lm_status;
+enum {
+    LM_OK = 0,
+    LM_ERR_IO = 1,        /* missing / broken index file (reference: checkError -> exit, util-cli.go:35) */
+    LM_ERR_FORMAT = 2,    /* magic / version mismatch (kv-data.go:54-64, genome.go:58-71) */
+    LM_ERR_OPTION = 3,    /* option out of range (search.go:159-229, lib-index-search.go:483-485) */
+    LM_ERR_NO_DEVICE = 4, /* no HIP device / not gfx950 */
+    LM_ERR_HIP = 5,       /* HIP runtime error */
+    LM_ERR_NOMEM = 6,
+    LM_ERR_ARG = 7
+};
+
+/* Search options: IndexSearchingOptions (lib-index-search.go:57-106) + SeqComparatorOptions as wired by
+ * search.go:305-382.  Defaults = the flag defaults of search.go:631-731. */
+typedef struct lm_options {
+    int32_t min_prefix;          /* -p/--seed-min-prefix 15 */
+    int32_t min_single_prefix;   /* -P/--seed-min-single-prefix 17 */
+    int32_t top_n_genomes;       /* -n 0 */
+    int32_t top_n_chains;        /* -N 0 */
+    double max_gap;              /* --seed-max-gap 50 */
+    double max_distance;         /* --seed-max-dist 1000 */
+    int32_t ext_len;             /* --align-ext-len 1000 */
+    int32_t ext_len2;            /* 50, hard-coded at search.go:325 */
+    double min_qcov_per_genome;  /* -Q 0 */
+    double max_evalue;           /* -e 10 */
+    int32_t output_seq;          /* -a/--all */
+    int32_t align_max_gap;       /* --align-max-gap 20 */
+    int32_t align_band;          /* --align-band 100 */
+    int32_t align_min_match_len; /* -l 50 */
+    double align_min_pident;     /* -i 70 */
+    double min_qcov_per_hsp;     /* -q 0 */
+    /* sharding of the genome set across ranks: this process loads genomes with
+     * (dense genome number % shard_count) == shard_rank. shard_count <= 1 loads everything. */
+    int32_t shard_rank, shard_count;
+    int64_t total_bases_override; /* >0: e-value database size shared by all shards (info.toml input-bases) */
+} lm_options;
+
+typedef struct lm_index lm_index;
+
+typedef struct lm_index_info {
+    int32_t k, masks, mask_prefix, anchor_prefix;
+    int64_t total_bases;   /* info.toml input-bases: the e-value database size (lib-index-search.go:1918) */
+    int64_t genomes;       /* genomes resident on this device */
+    int64_t seeds;         /* (k-mer,value) pairs resident on this device */
+    int64_t genome_bases;  /* concatenated bases resident on this device */
+    int64_t hbm_bytes;     /* device memory held by the index image */
+} lm_index_info;
+
+/* search.go:631-731 flag defaults */
+void lm_options_default(lm_options *opt);
+
+/* Replaces NewIndexSearcher(dir, opt) + SetSeqCompareOptions (lib-index-search.go:237-757, :217): reads info.toml,
+ * masks.bin, seeds/chunk_*.bin(.idx), genomes/batch_NNNN/genomes.bin(.idx), genomes.map.bin and builds the HBM image on
+ * HIP device `device`. */
+lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_index **out);
+/* Replaces (*Index).Close (lib-index-search.go:760) */
+void lm_index_close(lm_index *idx);
+lm_status lm_index_get_info(const lm_index *idx, lm_index_info *info);
+/* masks of the index (lexichash.LexicHash.Masks), borrowed until close */
+const uint64_t *lm_index_masks(const lm_index *idx);
+/* text of the last error on this handle, or of the last failed lm_index_open when idx == NULL */
+const char *lm_last_error(const lm_index *idx);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Whole-path entry point: replaces the per-query goroutines calling (*Index).Search (search.go:548-608,
+ * lib-index-search.go:1191-2940) with one batched call. */
+typedef struct lm_query {
+    const uint8_t *seq; /* upper-case bases (the host upper-cases, search.go:580-587) */
+    uint32_t len;
+} lm_query;
+
+/* One HSP row = what the TSV printer consumes (search.go:468-523); coordinates 0-based inclusive. */
+typedef struct lm_hsp {
+    uint32_t query;        /* index into the batch */
+    uint32_t hits;         /* number of subject genomes of this query ("hits" column) */
+    uint64_t batch_genome; /* batch<<17 | genome index (key of genomes.map.bin) */
+    double qcov_genome;    /* qcovGnm */
+    int32_t cls, hsp;      /* 1-based counters as printed */
+    int32_t seq_idx, nseqs, seq_len, nchunks, chunk_idx;
+    int32_t rc;            /* subject strand '-' */
+    double qcov_hsp;
+    int32_t aligned_length;
+    double pident;
+    int32_t gaps;
+    int32_t qbegin, qend, tbegin, tend;
+    double evalue;
+    int32_t bitscore, score, matched_bases;
+    const char *genome_id, *seq_id;          /* borrowed from the index, valid until lm_index_close */
+    const char *cigar, *qseq, *sseq, *align; /* only with output_seq; owned by the result batch */
+} lm_hsp;
+
+typedef struct lm_stage_stats { /* measured work per batch (H, A, C ...) */
+    int64_t query_bases, query_kmers;
+    int64_t seed_lookups;      /* (query,mask,direction) probes issued */
+    int64_t seed_values;       /* H: seed values returned */
+    int64_t anchors_raw;       /* anchors assembled (values x query locations) */
+    int64_t genome_pairs;      /* (query,genome) pairs chained */
+    int64_t anchors_cleared;   /* A: anchors after de-duplication */
+    int64_t chains;            /* C: chains sent to alignment */
+    int64_t window_bases;      /* sum of target window lengths */
+    int64_t pa_anchors;        /* pseudo-alignment anchors */
+    int64_t hsps_aligned;      /* WFA problems */
+    int64_t wfa_retries;
+    int64_t rows;              /* HSP rows emitted */
+    int64_t aligned_bases;     /* sum of alenHSP over emitted rows */
+    double ms_mask, ms_lookup, ms_chain, ms_window, ms_pseudo, ms_glue, ms_extend_wfa, ms_finalize, ms_total;
+} lm_stage_stats;
+
+typedef struct lm_result lm_result;
+
+/* queries resident in HBM (so that a timed region can exclude the PCIe upload) */
+typedef struct lm_qbatch lm_qbatch;
+lm_status lm_qbatch_upload(lm_index *idx, const lm_query *queries, size_t nq, lm_qbatch **out);
+void lm_qbatch_free(lm_qbatch *qb);
+lm_status lm_search_resident(lm_index *idx, lm_qbatch *qb, lm_result **out);
+/* = upload + search_resident */
+lm_status lm_search_batch(lm_index *idx, const lm_query *queries, size_t nq, lm_result **out);
+size_t lm_result_rows(const lm_result *res, const lm_hsp **rows); /* rows grouped by query, in output order */
+void lm_result_stats(const lm_result *res, lm_stage_stats *stats);
+void lm_result_free(lm_result *res); /* RecycleSearchResults, lib-index-search.go:1170 */
+/* search.go:468-523: one TSV line (no newline); returns the length that was/would be written */
+int lm_format_row(const lm_hsp *row, const char *query_id, uint32_t qlen, int more_columns, char *buf, size_t buflen);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Stage-level entry points (inner seams) used by the parity tests. All outputs are host arrays owned
+ * by the returned lm_stage object. */
+typedef struct lm_stage lm_stage;
+void lm_stage_free(lm_stage *s);
+
+/* lexichash MaskKnownDistinctPrefixes + low-complexity zeroing (lib-index-search.go:1212-1238):
+ * kmers[nq*M]; loc_off[nq*M+1] CSR into locs[] (pos<<1|strand ascending). */
+lm_status lm_mask_batch(lm_index *idx, const lm_query *queries, size_t nq, lm_stage **out, const uint64_t **kmers,
+                        const int64_t **loc_off, const int32_t **locs);
+
+/* reverse re-bucketing + seed lookup + anchor assembly (lib-index-search.go:1268-1569) and, per (query,genome),
+ * ClearSubstrPairs + Chainer.Chain (:1702-1775).
+ * pairs: npairs records sorted by (query, batch_genome); raw anchors and cleared anchors as CSR. */
+typedef struct lm_anchor {
+    int32_t qbegin, tbegin;
+    uint8_t len, trc, qrc, pad;
+} lm_anchor;
+typedef struct lm_pair {
+    uint32_t query;
+    uint64_t batch_genome;
+    int64_t raw_off, raw_n;         /* into raw anchors (sorted in the ClearSubstrPairs order) */
+    int64_t clr_off, clr_n;         /* into cleared anchors */
+    float score;                    /* Chainer.Chain best score */
+    int64_t chain_off, chain_n;     /* chains of this pair: chain_ptr[chain_off .. chain_off+chain_n] */
+} lm_pair;
+lm_status lm_seed_chain_batch(lm_index *idx, const lm_query *queries, size_t nq, lm_stage **out, size_t *npairs,
+                              const lm_pair **pairs, const lm_anchor **raw, const lm_anchor **cleared,
+                              const int64_t **chain_ptr, const int32_t **chain_idx);
+
+/* SeqComparator.Index + Compare (lib-seq_compare.go:115-159,335-522) for explicit (query, target window) problems:
+ * problem i compares queries[qidx[i]] over [qbegin[i], qend[i]] with targets[i]. Results CSR by problem. */
+typedef struct lm_chain2 {
+    int32_t qbegin, qend, tbegin, tend;
+    int32_t nanchors, matched_bases, aligned_bases_q, aligned_bases_t;
+    double pident;
+} lm_chain2;
+lm_status lm_pseudoalign_batch(lm_index *idx, const lm_query *queries, size_t nq, const lm_query *targets,
+                               const uint32_t *qidx, const uint32_t *qbegin, const uint32_t *qend, size_t nproblems,
+                               lm_stage **out, const int64_t **res_off, const lm_chain2 **res);
+
+/* wfa.Aligner.Align(q,t) with DefaultPenalties, global, AdaptiveReduction(DefaultAdaptiveOption)
+ * (lib-index-search.go:1910-1911,2261,2528). ops CSR: op<<32|n in forward order. */
+typedef struct lm_wfa {
+    int32_t status; /* 0 ok, 2 no match op */
+    int32_t score;  /* WFA penalty score */
+    int32_t qbegin, qend, tbegin, tend;
+    uint32_t align_len, matches, gaps, gap_regions;
+    int64_t ops_off;
+    int32_t nops;
+} lm_wfa;
+lm_status lm_wfa_batch(lm_index *idx, const lm_query *q, const lm_query *t, size_t n, lm_stage **out,
+                       const lm_wfa **res, const uint64_t **ops);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Measurement support: per-kernel HIP-event timing on the library's own stream. */
+typedef struct lm_kernel_time {
+    const char *name;
+    int64_t launches;
+    double total_ms;
+    int64_t bytes;   /* algorithmic bytes accounted by the host for these launches */
+} lm_kernel_time;
+void lm_profile_enable(lm_index *idx, int on);
+void lm_profile_reset(lm_index *idx);
+size_t lm_profile_get(lm_index *idx, const lm_kernel_time **out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -11,7 +11,7 @@
 
 #if defined(__HIPCC__)
 #define LM_HD __host__ __device__ __forceinline__
-#define LM_HDN __host__ __device__
+#define LM_HDN __host__ __device__ inline
 #else
 #define LM_HD inline
 #define LM_HDN inline
@@ -255,7 +255,7 @@ struct LmChainOpt {       // ChainingOptions, lib-index-search.go:739-746
 // Chainer.Chain, lib-chaining.go:122-633.
 // scratch: msi[n], s2i[n] (u64); dirs[n] (i8); visited[n] (u8).
 // out: chain_off[0..nchains] (capacity n+2), chain_idx (capacity 2n+2). returns best score.
-LM_HDN float lm_chain1(const LmSub *subs, int n, const LmChainOpt &opt, uint64_t *msi, uint64_t *s2i, int8_t *dirs,
+LM_HDN float lm_run_chain1(const LmSub *subs, int n, const LmChainOpt &opt, uint64_t *msi, uint64_t *s2i, int8_t *dirs,
                        uint8_t *visited, int32_t *chain_off, int32_t *chain_idx, int *nchains_out) {
     int nchains = 0, nidx = 0;
     chain_off[0] = 0;
@@ -462,7 +462,7 @@ struct LmChain2 { // the fields of Chain2Result produced by chaining
 
 // scratch: msi[n] (u64), stack[2*(n+1)] (i32). out: chains (capacity n). returns #chains in emission order
 // (chain, then right region, then left region — the recursion order of chainARegion).
-LM_HDN int lm_chain2(const LmSub *subs, int n, const LmChain2Opt &opt, uint64_t *msi, int32_t *stack, LmChain2 *out) {
+LM_HDN int lm_run_chain2(const LmSub *subs, int n, const LmChain2Opt &opt, uint64_t *msi, int32_t *stack, LmChain2 *out) {
     if (n <= 0) return 0;
     if (n == 1) { // :155-180
         int slen = subs[0].len;
@@ -634,7 +634,7 @@ LM_HDN int lm_chain2(const LmSub *subs, int n, const LmChain2Opt &opt, uint64_t 
 
 // ---------------------------------------------------------------------------------------------------------------
 // Chainer3 (lib-chaining3.go:111-299) with DefaultChaining3Options. scratch msi[n] (i64). returns found.
-LM_HDN bool lm_chain3(const LmSub *subs, int n, int64_t *msi, int *qend_out, int *tend_out) {
+LM_HDN bool lm_run_chain3(const LmSub *subs, int n, int64_t *msi, int *qend_out, int *tend_out) {
     const int32_t band_base = 10;
     const int band_count = 20;
     const int64_t max_gap = 5, max_distance = 10, min_score = 1;
@@ -744,7 +744,7 @@ LM_HDN void lm_extend_right(const uint8_t *s1, int n1, const uint8_t *s2, int n2
     }
     if (n == 0) return;
     int qe, te;
-    if (lm_chain3(subs, n, msi, &qe, &te)) {
+    if (lm_run_chain3(subs, n, msi, &qe, &te)) {
         *o1 = qe + 1;
         *o2 = te + 1;
     }

@@ -1,0 +1,331 @@
+// lm_format.cpp — see lm_format.h
+#include "lm_format.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <dirent.h>
+#include <map>
+
+namespace lm {
+
+namespace {
+
+struct File {
+    FILE *f = nullptr;
+    explicit File(const std::string &p) { f = fopen(p.c_str(), "rb"); }
+    ~File() {
+        if (f) fclose(f);
+    }
+    bool ok() const { return f != nullptr; }
+    bool read(void *dst, size_t n) { return fread(dst, 1, n, f) == n; }
+};
+
+inline uint64_t be64(const uint8_t *b) {
+    uint64_t v = 0;
+    for (int i = 0; i < 8; i++) v = (v << 8) | b[i];
+    return v;
+}
+inline uint64_t be56(const uint8_t *b) {
+    uint64_t v = 0;
+    for (int i = 0; i < 7; i++) v = (v << 8) | b[i];
+    return v;
+}
+inline uint32_t be32(const uint8_t *b) { return ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | b[3]; }
+inline uint32_t be16(const uint8_t *b) { return ((uint32_t)b[0] << 8) | b[1]; }
+
+bool read_all(const std::string &path, std::vector<uint8_t> &buf) {
+    File f(path);
+    if (!f.ok()) return false;
+    fseek(f.f, 0, SEEK_END);
+    long n = ftell(f.f);
+    fseek(f.f, 0, SEEK_SET);
+    buf.resize((size_t)n);
+    return n == 0 || f.read(buf.data(), (size_t)n);
+}
+
+long long toml_int(const std::string &text, const char *key, long long dflt) {
+    size_t kl = strlen(key), pos = 0;
+    while (pos < text.size()) {
+        size_t eol = text.find('\n', pos);
+        if (eol == std::string::npos) eol = text.size();
+        if (text.compare(pos, kl, key) == 0) {
+            size_t q = pos + kl;
+            while (q < eol && text[q] == ' ') q++;
+            if (q < eol && text[q] == '=') return atoll(text.c_str() + q + 1);
+        }
+        pos = eol + 1;
+    }
+    return dflt;
+}
+
+// group varint of two uint64 (util/varint-GB.go:88-113)
+inline int gv2(uint8_t ctrl, const uint8_t *p, uint64_t &a, uint64_t &b) {
+    int l1 = ((ctrl >> 3) & 7) + 1, l2 = (ctrl & 7) + 1;
+    a = b = 0;
+    for (int i = 0; i < l1; i++) a = (a << 8) | *p++;
+    for (int i = 0; i < l2; i++) b = (b << 8) | *p++;
+    return l1 + l2;
+}
+
+} // namespace
+
+// Decodes one seeds chunk (kv-data.go:66-89 layout) and appends every (k-mer,value) whose genome passes `keep`.
+static std::string load_chunk(const std::string &path, HostIndex &idx, const std::vector<int64_t> &batch_first,
+                              std::vector<std::vector<uint64_t>> &km, std::vector<std::vector<uint64_t>> &vv,
+                              int &status) {
+    std::vector<uint8_t> buf;
+    if (!read_all(path, buf)) {
+        status = 1;
+        return "cannot read " + path;
+    }
+    if (buf.size() < 32 || memcmp(buf.data(), ".kv-data", 8) != 0) {
+        status = 2;
+        return "k-mer-value data: invalid binary format: " + path;
+    }
+    if (buf[8] != 1) {
+        status = 2;
+        return "k-mer-value data: version mismatch: " + path;
+    }
+    const bool use7 = (buf[11] & 1) != 0;
+    const int nvb = use7 ? 7 : 8;
+    int64_t mask0 = (int64_t)be64(&buf[16]), nmask = (int64_t)be64(&buf[24]);
+    // anchor prefix from the .idx header (the data itself does not need the index)
+    {
+        File fi(path + ".idx");
+        uint8_t h[32];
+        if (!fi.ok() || !fi.read(h, 32) || memcmp(h, ".kvindex", 8) != 0) {
+            status = 2;
+            return "k-mer-value index: invalid binary format: " + path + ".idx";
+        }
+        if ((int)h[11] != idx.mask_prefix) {
+            status = 2;
+            return "lengths of mask prefix mismatch between info.toml and the seed data";
+        }
+        idx.anchor_prefix = h[12]; // users might have run 'utils reindex-seeds' (lib-index-search.go:611)
+    }
+    size_t p = 32;
+    const size_t n = buf.size();
+    const int sc = idx.shard_count, sr = idx.shard_rank;
+    for (int64_t im = 0; im < nmask; im++) {
+        if (p + 8 > n) {
+            status = 2;
+            return "k-mer-value data: broken file: " + path;
+        }
+        uint64_t nk = be64(&buf[p]);
+        p += 8;
+        if (nk == 0) continue;
+        std::vector<uint64_t> &K = km[(size_t)(mask0 + im)];
+        std::vector<uint64_t> &V = vv[(size_t)(mask0 + im)];
+        uint64_t off = 0;
+        for (;;) {
+            if (p + 1 > n) {
+                status = 2;
+                return "k-mer-value data: broken file: " + path;
+            }
+            uint8_t ctrl = buf[p++];
+            bool last_pair = (ctrl & 128) != 0, has2 = (ctrl & 64) == 0;
+            ctrl &= 63;
+            uint64_t d1, d2, l1, l2;
+            p += gv2(ctrl, &buf[p], d1, d2);
+            uint64_t k1 = d1 + off, k2 = k1 + d2;
+            off = k2;
+            ctrl = buf[p++];
+            p += gv2(ctrl, &buf[p], l1, l2);
+            for (int w = 0; w < 2; w++) {
+                if (w == 1 && last_pair && !has2) break;
+                uint64_t kmer = w == 0 ? k1 : k2, lv = w == 0 ? l1 : l2;
+                if (p + lv * nvb > n) {
+                    status = 2;
+                    return "k-mer-value data: broken file: " + path;
+                }
+                for (uint64_t j = 0; j < lv; j++) {
+                    uint64_t v = use7 ? be56(&buf[p]) : be64(&buf[p]);
+                    p += nvb;
+                    if (sc > 1) {
+                        uint64_t bg = v >> 30;
+                        uint64_t batch = bg >> 17, gi = bg & 0x1ffff;
+                        int64_t g = (batch < batch_first.size() ? batch_first[batch] : 0) + (int64_t)gi;
+                        if ((int)(g % sc) != sr) continue;
+                    }
+                    K.push_back(kmer);
+                    V.push_back(v);
+                }
+            }
+            if (last_pair) break;
+        }
+    }
+    return "";
+}
+
+std::string load_index(const std::string &dir, int shard_rank, int shard_count, HostIndex &out, int &status) {
+    status = 0;
+    if (shard_count < 1) shard_count = 1;
+    out.shard_rank = shard_rank;
+    out.shard_count = shard_count;
+    std::vector<uint8_t> buf;
+    if (!read_all(dir + "/info.toml", buf)) {
+        status = 1;
+        return "failed to read index info file: " + dir + "/info.toml";
+    }
+    std::string text((const char *)buf.data(), buf.size());
+    out.main_version = (int)toml_int(text, "main-version", -1);
+    out.minor_version = (int)toml_int(text, "minor-version", 0);
+    if (out.main_version != 3) { // lib-index-search.go:290-292
+        status = 2;
+        return "index main versions do not match";
+    }
+    out.total_bases = toml_int(text, "input-bases", 0);
+    out.contig_interval = (int)toml_int(text, "contig-interval", 1000);
+    out.genome_batches = (int)toml_int(text, "genome-batches", 1);
+    int partitions = (int)toml_int(text, "index-partitions", 4096);
+
+    // masks.bin (own layout, written by this build's index writers)
+    if (!read_all(dir + "/masks.bin", buf) || buf.size() < 24 || memcmp(buf.data(), "LMMASKS1", 8) != 0) {
+        status = buf.empty() ? 1 : 2;
+        return "failed to read masks: " + dir + "/masks.bin";
+    }
+    out.k = buf[8];
+    out.M = (int)be32(&buf[12]);
+    if (buf.size() < 24 + (size_t)out.M * 8 || out.k < 1 || out.k > 32) {
+        status = 2;
+        return "broken masks file";
+    }
+    out.masks.resize(out.M);
+    for (int i = 0; i < out.M; i++) out.masks[i] = be64(&buf[24 + (size_t)i * 8]);
+    {   // lib-index-search.go:467-469
+        int p = (int)(std::log2((double)out.M) / 2);
+        out.mask_prefix = p < 1 ? 1 : p;
+        int a = (int)(std::log2((double)partitions) / 2);
+        out.anchor_prefix = a < 1 ? 1 : a;
+    }
+
+    // genomes: batch_NNNN/genomes.bin + .idx
+    out.batch_first.assign(out.genome_batches + 1, 0);
+    std::map<uint64_t, std::string> id_of;
+    if (read_all(dir + "/genomes.map.bin", buf)) {
+        size_t p = 0;
+        while (p + 2 <= buf.size()) {
+            uint32_t l = be16(&buf[p]);
+            p += 2;
+            if (p + l + 8 > buf.size()) break;
+            std::string id((const char *)&buf[p], l);
+            p += l;
+            id_of[be64(&buf[p])] = id;
+            p += 8;
+        }
+    } else {
+        status = 1;
+        return "failed to read " + dir + "/genomes.map.bin";
+    }
+    int64_t global = 0;
+    for (int b = 0; b < out.genome_batches; b++) {
+        char name[64];
+        snprintf(name, sizeof name, "/genomes/batch_%04d/genomes.bin", b);
+        std::vector<uint8_t> ib, gb;
+        if (!read_all(dir + name + ".idx", ib) || ib.size() < 24 || memcmp(ib.data(), ".genomei", 8) != 0) {
+            status = ib.empty() ? 1 : 2;
+            return std::string("genome data: invalid binary format: ") + name + ".idx";
+        }
+        uint32_t nrec = be32(&ib[20]);
+        out.batch_first[b] = global;
+        if (!read_all(dir + name, gb) || gb.size() < 16 || memcmp(gb.data(), ".genomes", 8) != 0 || gb[8] != 0) {
+            status = gb.empty() ? 1 : 2;
+            return std::string("genome data: invalid binary format: ") + name;
+        }
+        for (uint32_t r = 0; r < nrec; r++, global++) {
+            if ((int)(global % shard_count) != shard_rank) continue;
+            if (24 + (size_t)r * 12 + 12 > ib.size()) {
+                status = 2;
+                return "genome data: broken file (index)";
+            }
+            size_t p = (size_t)be64(&ib[24 + (size_t)r * 12]);
+            HostGenome g;
+            g.bg = ((uint64_t)b << 17) | r;
+            g.global = global;
+            auto it = id_of.find(g.bg);
+            if (it != id_of.end()) g.id = it->second;
+            if (p + 2 > gb.size()) {
+                status = 2;
+                return "genome data: broken file";
+            }
+            uint32_t idl = be16(&gb[p]);
+            p += 2 + idl;
+            if (p + 12 > gb.size()) {
+                status = 2;
+                return "genome data: broken file";
+            }
+            g.genome_size = (int32_t)be32(&gb[p]);
+            g.len = (int32_t)be32(&gb[p + 4]);
+            g.nseqs = (int32_t)be32(&gb[p + 8]);
+            p += 12;
+            for (int s = 0; s < g.nseqs; s++) {
+                if (p + 6 > gb.size()) {
+                    status = 2;
+                    return "genome data: broken file";
+                }
+                g.seq_sizes.push_back((int32_t)be32(&gb[p]));
+                uint32_t l = be16(&gb[p + 4]);
+                p += 6;
+                g.seq_ids.emplace_back((const char *)&gb[p], l);
+                p += l;
+            }
+            if (p + 8 > gb.size()) {
+                status = 2;
+                return "genome data: broken file";
+            }
+            uint32_t nbytes = be32(&gb[p]);
+            p += 8;
+            if (p + nbytes > gb.size()) {
+                status = 2;
+                return "genome data: broken file";
+            }
+            g.bits_off = (int64_t)out.gbits.size();
+            out.gbits.insert(out.gbits.end(), gb.begin() + p, gb.begin() + p + nbytes);
+            // pad so that 8-byte loads near the end of a genome stay inside the buffer
+            size_t padded = (out.gbits.size() + 15) & ~(size_t)7;
+            out.gbits.resize(padded, 0);
+            out.genomes.push_back(std::move(g));
+        }
+    }
+    out.batch_first[out.genome_batches] = global;
+
+    // seeds
+    std::vector<std::string> files;
+    {
+        DIR *d = opendir((dir + "/seeds").c_str());
+        if (!d) {
+            status = 1;
+            return "seeds file not found in: " + dir + "/seeds";
+        }
+        while (dirent *de = readdir(d)) {
+            std::string nm = de->d_name;
+            if (nm.size() > 4 && nm.compare(nm.size() - 4, 4, ".bin") == 0) files.push_back(nm);
+        }
+        closedir(d);
+        std::sort(files.begin(), files.end());
+    }
+    if (files.empty()) {
+        status = 1;
+        return "seeds file not found in: " + dir + "/seeds";
+    }
+    std::vector<std::vector<uint64_t>> km(out.M), vv(out.M);
+    for (auto &f : files) {
+        std::string e = load_chunk(dir + "/seeds/" + f, out, out.batch_first, km, vv, status);
+        if (!e.empty()) return e;
+    }
+    out.mask_off.assign(out.M + 1, 0);
+    for (int i = 0; i < out.M; i++) out.mask_off[i + 1] = out.mask_off[i] + (int64_t)km[i].size();
+    out.seed_kmers.resize((size_t)out.mask_off[out.M]);
+    out.seed_vals.resize((size_t)out.mask_off[out.M]);
+    for (int i = 0; i < out.M; i++) {
+        std::copy(km[i].begin(), km[i].end(), out.seed_kmers.begin() + out.mask_off[i]);
+        std::copy(vv[i].begin(), vv[i].end(), out.seed_vals.begin() + out.mask_off[i]);
+        std::vector<uint64_t>().swap(km[i]);
+        std::vector<uint64_t>().swap(vv[i]);
+    }
+    return "";
+}
+
+} // namespace lm

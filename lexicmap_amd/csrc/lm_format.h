@@ -1,0 +1,43 @@
+// lm_format.h — host-side readers of the reference on-disk index (format 3.x) used to build the HBM image.
+// Reference: info.toml (lib-index-build.go:1914-1932), seeds/chunk_NNN.bin(.idx) (kv/kv-data.go:66-125,394-562;
+// kv/kv-reader.go:762-1021), genomes/batch_NNNN/genomes.bin(.idx) (genome/genome.go:184-358,388-474),
+// genomes.map.bin (lib-index-build.go:649-655,1969-2016).  masks.bin uses this build's own layout (the upstream
+// lexichash layout is not available).
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+namespace lm {
+
+struct HostGenome {
+    uint64_t bg = 0;        // batch<<17 | index in batch
+    int64_t global = 0;     // dense number over the whole index
+    std::string id;         // from genomes.map.bin
+    int32_t genome_size = 0, len = 0, nseqs = 0;
+    std::vector<int32_t> seq_sizes;
+    std::vector<std::string> seq_ids;
+    int64_t bits_off = 0;   // byte offset of the packed sequence in HostIndex::gbits
+};
+
+struct HostIndex {
+    int k = 0, M = 0, mask_prefix = 0, anchor_prefix = 0;
+    int main_version = 0, minor_version = 0;
+    int64_t total_bases = 0;
+    int contig_interval = 1000;
+    int genome_batches = 0;
+    std::vector<uint64_t> masks;
+    // seeds: per mask sorted by k-mer; SoA
+    std::vector<int64_t> mask_off; // [M+1]
+    std::vector<uint64_t> seed_kmers, seed_vals;
+    // genomes of this shard
+    std::vector<HostGenome> genomes;
+    std::vector<uint8_t> gbits;    // 2-bit packed, first base in bits 7-6; each genome padded to 8 bytes
+    std::vector<int64_t> batch_first; // [batches+1] global dense number of the first genome of each batch
+    int shard_rank = 0, shard_count = 1;
+};
+
+// returns empty string on success, else the error text. status: 1 io, 2 format
+std::string load_index(const std::string &dir, int shard_rank, int shard_count, HostIndex &out, int &status);
+
+} // namespace lm

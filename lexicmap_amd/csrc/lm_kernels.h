@@ -1,0 +1,103 @@
+// lm_kernels.h — device-side record types and kernel launchers (see lm_kernels.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lm_algos.h"
+
+namespace lm {
+
+// HBM image of the index (DESIGN.md §HBM layout)
+struct DevIndexView {
+    int K, M, mask_prefix;
+    const uint64_t *masks;      // [M] sorted
+    const int32_t *pfx_first;   // [4^p + 1] masks sharing each p-base prefix
+    const uint64_t *seed_kmers; // [N] per mask sorted ascending
+    const uint64_t *seed_vals;  // [N] batch:17|genome:17|pos:28|rc:1|reversed:1 (lib-index-build.go:412-455)
+    const int64_t *mask_off;    // [M+1]
+    const uint8_t *gbits;       // 2-bit genomes, first base in bits 7-6 (genome.go:1480)
+    const int64_t *g_off;       // [G] byte offset
+    const int32_t *g_len;       // [G] concatenated length in bases
+    const int64_t *batch_first; // [nbatches+1]
+    int nbatches;
+    int64_t ngenomes;           // local
+    int shard_rank, shard_count;
+};
+
+struct Task { // one lexichash chain of one (query, genome): the pseudo-alignment problem
+    uint32_t seg, q;
+    int32_t g, rc;
+    int32_t tBegin, tEnd, qBegin, qEnd;
+    int32_t nseeds, wlen;
+    int64_t woff;
+};
+
+struct HspIn { // extendMatch input (lib-index-search.go:2255,2522)
+    uint32_t q;
+    int32_t rc;
+    int64_t woff;
+    int32_t len1, len2;
+    int32_t start1, end1, start2, end2;
+    int32_t ext_len, tbegin, max_ext_len, pad;
+};
+struct HspExt {
+    int32_t qs, qe, ts, te, s1, e1, s2, e2;
+};
+
+struct WfaIn {
+    const uint8_t *q, *t;
+    int32_t qlen, tlen;
+    int64_t hdr_off, arena_off, arena_cap, ops_off;
+    int32_t max_score, ops_cap;
+};
+struct WfaOut {
+    LmWfaOut r;
+    int32_t blast_score;
+};
+
+void launch_extract_kmers(hipStream_t st, const uint8_t *qseq, const int64_t *qoff, const int64_t *posoff, int nq, int K,
+                          int64_t total_pos, uint64_t *keys_all, uint32_t *vals_all, uint64_t *keys_cmp,
+                          uint32_t *vals_cmp, int32_t *nvalid);
+void launch_fill_u32(hipStream_t st, uint32_t *p, int64_t n, uint32_t v);
+void launch_mask(hipStream_t st, const uint64_t *keys_all, const int64_t *posoff, int nq, int M, int K,
+                 const uint64_t *masks, uint64_t *out_kmers, int64_t *out_lo, int64_t *out_hi, uint32_t *first_mask);
+void launch_lookup_count(hipStream_t st, DevIndexView ix, const uint64_t *kmers, const int64_t *klo, const int64_t *khi,
+                         const uint32_t *first_mask, int64_t nqm, int min_prefix, uint32_t *counts, int64_t *starts,
+                         int32_t *nscan, unsigned long long *stat_values);
+void launch_lookup_emit(hipStream_t st, DevIndexView ix, const uint64_t *kmers, const int64_t *klo, const int64_t *khi,
+                        const uint32_t *vals_all, int64_t nqm, const uint32_t *counts, const int64_t *offs,
+                        const int64_t *starts, const int32_t *nscan, uint64_t *outA, uint64_t *outB);
+void launch_chain1(hipStream_t st, const uint64_t *B, const int64_t *seg_off, int nseg, LmChainOpt opt, int K, LmSub *subs,
+                   uint8_t *marks, uint64_t *msi, uint64_t *s2i, int8_t *dirs, uint8_t *visited, int32_t *chain_off_pool,
+                   int32_t *chain_idx_pool, int32_t *seg_n, float *seg_score, int32_t *seg_nch);
+void launch_task_count(hipStream_t st, const float *seg_score, const int32_t *seg_nch, const uint8_t *keep, int nseg,
+                       float min_score, int32_t *ntask);
+void launch_make_tasks(hipStream_t st, DevIndexView ix, const uint64_t *segA, const int64_t *seg_off, int nseg,
+                       const LmSub *subs, const int32_t *chain_off_pool, const int32_t *chain_idx_pool,
+                       const int32_t *ntask, const int64_t *task_off, const int64_t *qoff, int ext_len,
+                       int32_t *order_scratch, Task *tasks);
+void launch_task_wlen(hipStream_t st, const Task *tasks, int64_t ntasks, int32_t *wlen);
+void launch_task_set_woff(hipStream_t st, Task *tasks, int64_t ntasks, const int64_t *woff);
+void launch_extract_windows(hipStream_t st, DevIndexView ix, const Task *tasks, int64_t ntasks, uint8_t *wbuf);
+void launch_pa_count(hipStream_t st, const Task *tasks, int64_t ntasks, const uint8_t *wbuf, const uint64_t *keys_cmp,
+                     const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid, int K, int min_prefix,
+                     uint32_t *counts);
+void launch_pa_emit(hipStream_t st, const Task *tasks, int64_t ntasks, const uint8_t *wbuf, const uint64_t *keys_cmp,
+                    const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid, int K, int min_prefix,
+                    const uint32_t *counts, const int64_t *offs, uint64_t *outA, uint64_t *outB);
+void launch_pa_task_off(hipStream_t st, const Task *tasks, int64_t ntasks, const int64_t *offs, int64_t total_pos,
+                        int64_t total_anchors, int64_t *pa_off);
+void launch_pa_chain(hipStream_t st, const uint64_t *B, const int64_t *pa_off, int64_t ntasks, int K, LmChain2Opt opt,
+                     LmSub *subs, uint8_t *marks, uint64_t *msi, int32_t *stack, LmChain2 *out, int32_t *out_n,
+                     int32_t *clr_n);
+void launch_gather_chain2(hipStream_t st, const LmChain2 *in, const int64_t *pa_off, const int32_t *out_n,
+                          const int64_t *res_off, int64_t ntasks, LmChain2 *out);
+void launch_extend_count(hipStream_t st, const HspIn *hsps, int64_t n, const uint8_t *qseq, const int64_t *qoff,
+                         const uint8_t *wbuf, int32_t *cap);
+void launch_extend(hipStream_t st, const HspIn *hsps, int64_t n, const uint8_t *qseq, const int64_t *qoff,
+                   const uint8_t *wbuf, const int32_t *cap, const int64_t *scratch_off, LmSub *subs, int64_t *msi,
+                   HspExt *out);
+void launch_wfa(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int32_t *hdr_pool,
+                int32_t *arena_pool, uint64_t *ops_pool, WfaOut *out);
+
+} // namespace lm

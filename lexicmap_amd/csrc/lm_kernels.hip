@@ -1,0 +1,714 @@
+// lm_kernels.hip — gfx950 kernels of the `lexicmap search` hot path.
+//
+// Work decomposition:
+//   k_extract_kmers   one lane per query position       -> 2-bit k-mers of both strands (+ filtered copy)
+//   k_mask            one lane per (query, mask)         -> LexicHash capture over the sorted k-mer array
+//   k_lookup_count/emit one lane per (query, mask, dir)  -> prefix/suffix range query in the HBM seed arrays
+//   k_chain1          one lane per (query, genome)       -> ClearSubstrPairs + Chainer.Chain
+//   k_make_tasks      one lane per (query, genome)       -> chain windows
+//   k_extract_windows one workgroup per chain            -> 2-bit genome -> ASCII window (rc applied)
+//   k_pa_count/emit   one workgroup per chain            -> SeqComparator.Compare anchor generation
+//   k_pa_chain        one lane per chain                 -> Clear + Trim + Chainer2
+//   k_extend_count/k_extend one lane per HSP             -> extendMatch
+//   k_wfa             one lane per HSP                   -> WFA + backtrace + BLAST-style score
+// Radix sorts / scans / run-length encodes between kernels are rocPRIM device primitives (plumbing).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lm_algos.h"
+#include "lm_kernels.h"
+
+namespace lm {
+
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int find_segment(const int64_t *off, int n, int64_t x) {
+    // largest s with off[s] <= x  (off[0]=0, off[n]=total)
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (off[mid] <= x)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ uint64_t encode_kmer(const uint8_t *s, int k) {
+    uint64_t c = 0;
+    for (int i = 0; i < k; i++) c = (c << 2) | lm_base2bit(s[i]);
+    return c;
+}
+
+// posoff[q] = number of k-mer positions before query q; keys of query q live at [2*posoff[q], 2*posoff[q+1])
+__global__ void k_extract_kmers(const uint8_t *__restrict__ qseq, const int64_t *__restrict__ qoff,
+                                const int64_t *__restrict__ posoff, int nq, int K, uint64_t *__restrict__ keys_all,
+                                uint32_t *__restrict__ vals_all, uint64_t *__restrict__ keys_cmp,
+                                uint32_t *__restrict__ vals_cmp, int32_t *__restrict__ nvalid) {
+    int64_t total = posoff[nq];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int q = find_segment(posoff, nq, i);
+        int pos = (int)(i - posoff[q]);
+        uint64_t fwd = encode_kmer(qseq + qoff[q] + pos, K);
+        uint64_t rc = lm_revcomp(fwd, K);
+        keys_all[2 * i] = fwd;
+        keys_all[2 * i + 1] = rc;
+        vals_all[2 * i] = (uint32_t)pos << 1;
+        vals_all[2 * i + 1] = ((uint32_t)pos << 1) | 1u;
+        // SeqComparator.Index filter (lib-seq_compare.go:143): both strands of a position are dropped together
+        bool filtered = fwd == 0 || lm_low_complexity(fwd, K);
+        keys_cmp[2 * i] = filtered ? (1ull << 63) : fwd;
+        keys_cmp[2 * i + 1] = filtered ? (1ull << 63) : rc;
+        vals_cmp[2 * i] = (uint32_t)pos << 1;
+        vals_cmp[2 * i + 1] = ((uint32_t)pos << 1) | 1u;
+        if (!filtered) atomicAdd(&nvalid[q], 2);
+    }
+}
+
+__global__ void k_fill_u32(uint32_t *p, int64_t n, uint32_t v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// lexichash masking (lib-index-search.go:1212-1238)
+__global__ void k_mask(const uint64_t *__restrict__ keys_all, const int64_t *__restrict__ posoff, int nq, int M, int K,
+                       const uint64_t *__restrict__ masks, uint64_t *__restrict__ out_kmers,
+                       int64_t *__restrict__ out_lo, int64_t *__restrict__ out_hi, uint32_t *__restrict__ first_mask) {
+    int64_t total = (int64_t)nq * M;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        int q = (int)(t / M), m = (int)(t % M);
+        int64_t base = 2 * posoff[q];
+        int n = (int)(2 * (posoff[q + 1] - posoff[q]));
+        uint64_t kmer = 0;
+        int lo = 0, hi = 0;
+        if (n > 0) {
+            kmer = lm_xor_argmin(keys_all + base, n, masks[m], &lo, &hi);
+            if (kmer != 0 && lm_low_complexity(kmer, K)) kmer = 0;
+            if (kmer != 0) atomicMin(&first_mask[base + lo], (uint32_t)m);
+        }
+        out_kmers[t] = kmer;
+        out_lo[t] = base + lo;
+        out_hi[t] = base + hi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// seed lookup (kv-searcher2.go:105-549 semantics over the flat HBM arrays) + anchor assembly (:1398-1562)
+__device__ __forceinline__ int argmin_mask(const uint64_t *masks, const int32_t *pfx_first, int K, int p, uint64_t kmer) {
+    uint64_t pf = kmer >> ((K - p) << 1);
+    int minj = -1;
+    uint64_t minh = ~0ull;
+    for (int j = pfx_first[pf]; j < pfx_first[pf + 1]; j++) {
+        uint64_t h = masks[j] ^ kmer;
+        if (h < minh) {
+            minh = h;
+            minj = j;
+        }
+    }
+    return minj;
+}
+
+__device__ __forceinline__ bool lookup_setup(const DevIndexView &ix, const uint64_t *kmers, const int64_t *klo,
+                                             const uint32_t *first_mask, int64_t t, int min_prefix, int *dir_out,
+                                             uint64_t *key_out, int64_t *b_out, int64_t *e_out, uint64_t *right_out,
+                                             int64_t *qm_out) {
+    int dir = (int)(t & 1);
+    int64_t qm = t >> 1;
+    uint64_t kmer = kmers[qm];
+    *dir_out = dir;
+    *qm_out = qm;
+    if (kmer == 0) return false;
+    int m = (int)(qm % ix.M);
+    int list = m;
+    uint64_t key = kmer;
+    if (dir == 1) {
+        if (first_mask[klo[qm]] != (uint32_t)m) return false; // de-duplicated reversed k-mer (:1288-1298)
+        key = lm_reverse(kmer, ix.K);
+        list = argmin_mask(ix.masks, ix.pfx_first, ix.K, ix.mask_prefix, key);
+        if (list < 0) return false;
+    }
+    uint64_t left, right;
+    if (min_prefix < ix.K) {
+        int s2 = (ix.K - min_prefix) << 1;
+        uint64_t low = (1ull << s2) - 1;
+        left = key & ~low;
+        right = key | low;
+    } else {
+        left = right = key;
+    }
+    int64_t b = ix.mask_off[list], e = ix.mask_off[list + 1];
+    // lower_bound(left)
+    int64_t lo = b, hi = e;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (ix.seed_kmers[mid] < left)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    *key_out = key;
+    *b_out = lo;
+    *e_out = e;
+    *right_out = right;
+    return true;
+}
+
+__global__ void k_lookup_count(DevIndexView ix, const uint64_t *__restrict__ kmers, const int64_t *__restrict__ klo,
+                               const int64_t *__restrict__ khi, const uint32_t *__restrict__ first_mask, int64_t nqm,
+                               int min_prefix, uint32_t *__restrict__ counts, int64_t *__restrict__ starts,
+                               int32_t *__restrict__ nscan, unsigned long long *__restrict__ stat_values) {
+    int64_t total = nqm * 2;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        int dir;
+        uint64_t key, right;
+        int64_t b, e, qm;
+        uint32_t cnt = 0;
+        int32_t ns = 0;
+        int64_t st = 0;
+        if (lookup_setup(ix, kmers, klo, first_mask, t, min_prefix, &dir, &key, &b, &e, &right, &qm)) {
+            uint32_t nv = 0;
+            int64_t i = b;
+            while (i < e && ix.seed_kmers[i] <= right) {
+                if ((ix.seed_vals[i] & 1ull) == (uint64_t)dir) nv++;
+                i++;
+            }
+            ns = (int32_t)(i - b);
+            st = b;
+            cnt = nv * (uint32_t)(khi[qm] - klo[qm]);
+            if (nv) atomicAdd(stat_values, (unsigned long long)nv);
+        }
+        counts[t] = cnt;
+        starts[t] = st;
+        nscan[t] = ns;
+    }
+}
+
+__global__ void k_lookup_emit(DevIndexView ix, const uint64_t *__restrict__ kmers, const int64_t *__restrict__ klo,
+                              const int64_t *__restrict__ khi, const uint32_t *__restrict__ vals_all, int64_t nqm,
+                              const uint32_t *__restrict__ counts, const int64_t *__restrict__ offs,
+                              const int64_t *__restrict__ starts, const int32_t *__restrict__ nscan,
+                              uint64_t *__restrict__ outA, uint64_t *__restrict__ outB) {
+    int64_t total = nqm * 2;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        if (counts[t] == 0) continue;
+        int dir = (int)(t & 1);
+        int64_t qm = t >> 1;
+        uint64_t q = (uint64_t)(qm / ix.M);
+        uint64_t key = kmers[qm];
+        if (dir) key = lm_reverse(key, ix.K);
+        int64_t o = offs[t];
+        int64_t b = starts[t];
+        for (int32_t s = 0; s < nscan[t]; s++) {
+            uint64_t v = ix.seed_vals[b + s];
+            if ((v & 1ull) != (uint64_t)dir) continue;
+            int kprefix = lm_lcp(key, ix.seed_kmers[b + s], ix.K);
+            uint64_t A = (q << 34) | (v >> 30);
+            for (int64_t li = klo[qm]; li < khi[qm]; li++) {
+                uint32_t loc = vals_all[li];
+                int bq, bt;
+                bool rct;
+                lm_anchor_coords(v, (int)(loc >> 1), (loc & 1u) != 0, kprefix, ix.K, &bq, &bt, &rct);
+                outA[o] = A;
+                outB[o] = lm_pack_anchor(bq, kprefix, bt, (loc & 1u) != 0, rct);
+                o++;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// per (query,genome): ClearSubstrPairs + Chainer.Chain (lib-index-search.go:1702-1775)
+__global__ void k_chain1(const uint64_t *__restrict__ B, const int64_t *__restrict__ seg_off, int nseg, LmChainOpt opt,
+                         int K, LmSub *__restrict__ subs, uint8_t *__restrict__ marks, uint64_t *__restrict__ msi,
+                         uint64_t *__restrict__ s2i, int8_t *__restrict__ dirs, uint8_t *__restrict__ visited,
+                         int32_t *__restrict__ chain_off_pool, int32_t *__restrict__ chain_idx_pool,
+                         int32_t *__restrict__ seg_n, float *__restrict__ seg_score, int32_t *__restrict__ seg_nch) {
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += gridDim.x * blockDim.x) {
+        int64_t o = seg_off[s];
+        int n = (int)(seg_off[s + 1] - o);
+        LmSub *sb = subs + o;
+        for (int i = 0; i < n; i++) sb[i] = lm_unpack_anchor(B[o + i]);
+        if (n > 1) n = lm_clear_sorted(sb, n, K, marks + o);
+        int nch = 0;
+        float sc = lm_run_chain1(sb, n, opt, msi + o, s2i + o, dirs + o, visited + o, chain_off_pool + o + 4ll * s,
+                             chain_idx_pool + 2 * o + 8ll * s, &nch);
+        seg_n[s] = n;
+        seg_score[s] = sc;
+        seg_nch[s] = nch;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// chain windows (lib-index-search.go:1966-2051)
+__device__ __forceinline__ int local_genome(const DevIndexView &ix, uint64_t bg) {
+    uint64_t batch = bg >> 17, gi = bg & 0x1ffff;
+    if (batch >= (uint64_t)ix.nbatches) return -1;
+    int64_t g = ix.batch_first[batch] + (int64_t)gi;
+    if (ix.shard_count > 1) {
+        if ((int)(g % ix.shard_count) != ix.shard_rank) return -1;
+        g /= ix.shard_count;
+    }
+    if (g >= ix.ngenomes) return -1;
+    return (int)g;
+}
+
+__global__ void k_task_count(const float *__restrict__ seg_score, const int32_t *__restrict__ seg_nch,
+                             const uint8_t *__restrict__ keep, int nseg, float min_score, int32_t *__restrict__ ntask) {
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += gridDim.x * blockDim.x)
+        ntask[s] = (seg_score[s] >= min_score && (!keep || keep[s])) ? seg_nch[s] : 0;
+}
+
+__global__ void k_make_tasks(DevIndexView ix, const uint64_t *__restrict__ segA, const int64_t *__restrict__ seg_off,
+                             int nseg, const LmSub *__restrict__ subs, const int32_t *__restrict__ chain_off_pool,
+                             const int32_t *__restrict__ chain_idx_pool, const int32_t *__restrict__ ntask,
+                             const int64_t *__restrict__ task_off, const int64_t *__restrict__ qoff, int ext_len,
+                             int32_t *__restrict__ order_scratch, Task *__restrict__ tasks) {
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += gridDim.x * blockDim.x) {
+        int nch = ntask[s];
+        if (nch == 0) continue;
+        int64_t o = seg_off[s];
+        const LmSub *sb = subs + o;
+        const int32_t *coff = chain_off_pool + o + 4ll * s;
+        const int32_t *cidx = chain_idx_pool + 2 * o + 8ll * s;
+        int32_t *order = order_scratch + o + 4ll * s;
+        // stable sort of chains by TBegin of the first anchor (:1967-1974)
+        for (int i = 0; i < nch; i++) {
+            int32_t tx = sb[cidx[coff[i]]].tbegin;
+            int j = i - 1;
+            while (j >= 0 && sb[cidx[coff[order[j]]]].tbegin > tx) {
+                order[j + 1] = order[j];
+                j--;
+            }
+            order[j + 1] = i;
+        }
+        uint64_t A = segA[s];
+        uint32_t q = (uint32_t)(A >> 34);
+        uint64_t bg = A & ((1ull << 34) - 1);
+        int g = local_genome(ix, bg);
+        int qlen = (int)(qoff[q + 1] - qoff[q]);
+        int glen = g >= 0 ? ix.g_len[g] : 0;
+        for (int ci = 0; ci < nch; ci++) {
+            int c = order[ci];
+            const int32_t *chain = cidx + coff[c];
+            int nseeds = coff[c + 1] - coff[c];
+            LmSub first = sb[chain[0]], last = sb[chain[nseeds - 1]];
+            int qb = first.qbegin, tb = first.tbegin;
+            int qe = last.qbegin + last.len - 1, te = last.tbegin + last.len - 1;
+            bool rc = nseeds == 1 ? (last.qrc != last.trc) : (tb > last.tbegin);
+            int tBegin, tEnd;
+            if (rc) {
+                tBegin = last.tbegin - ext_len;
+                if (tBegin < 0) tBegin = 0;
+                tEnd = tb + last.len - 1 + ext_len;
+            } else {
+                tBegin = tb - ext_len;
+                if (tBegin < 0) tBegin = 0;
+                tEnd = te + ext_len;
+            }
+            int qBegin = qb - (qb < ext_len ? qb : ext_len);
+            int qEnd = qe + (qlen - qe - 1 < ext_len ? qlen - qe - 1 : ext_len);
+            // SubSeq3 clamping (genome.go:944-952) and the tEnd fix-up (:2045-2047)
+            int st = tBegin, en = tEnd;
+            if (en >= glen - 1) en = glen - 1;
+            if (en < st) en = st;
+            int wlen = g >= 0 && glen > 0 && st < glen ? en - st + 1 : 0;
+            if (wlen < tEnd - tBegin + 1) tEnd -= tEnd - tBegin + 1 - wlen;
+            Task t;
+            t.seg = (uint32_t)s;
+            t.q = q;
+            t.g = g;
+            t.rc = rc ? 1 : 0;
+            t.tBegin = tBegin;
+            t.tEnd = tEnd;
+            t.qBegin = qBegin;
+            t.qEnd = qEnd;
+            t.nseeds = nseeds;
+            t.wlen = wlen;
+            t.woff = 0;
+            tasks[task_off[s] + ci] = t;
+        }
+    }
+}
+
+__global__ void k_task_wlen(const Task *__restrict__ tasks, int64_t ntasks, int32_t *__restrict__ wlen) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ntasks; i += (int64_t)gridDim.x * blockDim.x)
+        wlen[i] = tasks[i].wlen;
+}
+__global__ void k_task_set_woff(Task *__restrict__ tasks, int64_t ntasks, const int64_t *__restrict__ woff) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ntasks; i += (int64_t)gridDim.x * blockDim.x)
+        tasks[i].woff = woff[i];
+}
+
+// genome.SubSeq3 (genome.go:931-1143) + RC (:2943) — one workgroup per chain window
+__global__ void k_extract_windows(DevIndexView ix, const Task *__restrict__ tasks, int64_t ntasks,
+                                  uint8_t *__restrict__ wbuf) {
+    for (int64_t ti = blockIdx.x; ti < ntasks; ti += gridDim.x) {
+        const Task t = tasks[ti];
+        if (t.wlen <= 0 || t.g < 0) continue;
+        const uint8_t *gb = ix.gbits + ix.g_off[t.g];
+        uint8_t *w = wbuf + t.woff;
+        for (int i = threadIdx.x; i < t.wlen; i += blockDim.x) {
+            int pos = t.rc ? (t.tBegin + t.wlen - 1 - i) : (t.tBegin + i);
+            uint32_t code = (gb[pos >> 2] >> ((3 - (pos & 3)) << 1)) & 3u;
+            if (t.rc) code = 3u - code;
+            w[i] = (uint8_t)("ACGT"[code]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// SeqComparator.Compare anchor generation (lib-seq_compare.go:335-445)
+__device__ __forceinline__ int pa_min_prefix(int base, int wlen) {
+    if (wlen >= 1000000) return base + 8;
+    if (wlen >= 250000) return base + 6;
+    if (wlen >= 50000) return base + 4;
+    if (wlen >= 10000) return base + 2;
+    return base;
+}
+
+template <bool EMIT>
+__device__ __forceinline__ uint32_t pa_position(const uint64_t *keys, const uint32_t *vals, int n, uint64_t kmer, int K,
+                                                int m, uint32_t begin, uint32_t end, int idx, uint64_t A,
+                                                uint64_t *outA, uint64_t *outB, int64_t o) {
+    uint32_t cnt = 0;
+    if (kmer == 0 || kmer == lm_ns(1, K) || kmer == lm_ns(2, K) || kmer == lm_kmer_mask(K)) return 0;
+    int lo, hi;
+    if (lm_tree_search_range(keys, n, kmer, m, K, &lo, &hi)) {
+        for (int j = lo; j < hi; j++) {
+            uint32_t v = vals[j];
+            uint32_t lp = (uint32_t)lm_lcp(keys[j], kmer, K);
+            uint32_t p = v >> 1;
+            if ((v & 1u) == 1u || p < begin || p + lp > end) continue;
+            if (EMIT) {
+                outA[o + cnt] = A;
+                outB[o + cnt] = lm_pack_anchor((int)p, (int)lp, idx, false, false);
+            }
+            cnt++;
+        }
+    }
+    uint64_t rc = lm_revcomp(kmer, K);
+    if (lm_tree_search_range(keys, n, rc, m, K, &lo, &hi)) {
+        for (int j = lo; j < hi; j++) {
+            uint32_t v = vals[j];
+            uint32_t lp = (uint32_t)lm_lcp(keys[j], rc, K);
+            uint32_t p = (v >> 1) + (uint32_t)K - lp;
+            if ((v & 1u) == 0u || p + lp < begin || p > end) continue;
+            if (EMIT) {
+                outA[o + cnt] = A;
+                outB[o + cnt] = lm_pack_anchor((int)p, (int)lp, idx + K - (int)lp, true, true);
+            }
+            cnt++;
+        }
+    }
+    return cnt;
+}
+
+__global__ void k_pa_count(const Task *__restrict__ tasks, int64_t ntasks, const uint8_t *__restrict__ wbuf,
+                           const uint64_t *__restrict__ keys_cmp, const uint32_t *__restrict__ vals_cmp,
+                           const int64_t *__restrict__ posoff, const int32_t *__restrict__ nvalid, int K,
+                           int min_prefix, uint32_t *__restrict__ counts) {
+    for (int64_t ti = blockIdx.x; ti < ntasks; ti += gridDim.x) {
+        const Task t = tasks[ti];
+        const uint8_t *w = wbuf + t.woff;
+        const uint64_t *keys = keys_cmp + 2 * posoff[t.q];
+        const uint32_t *vals = vals_cmp + 2 * posoff[t.q];
+        int n = nvalid[t.q];
+        int m = pa_min_prefix(min_prefix, t.wlen);
+        for (int i = threadIdx.x; i < t.wlen; i += blockDim.x) {
+            uint32_t c = 0;
+            if (i + K <= t.wlen && n > 0) {
+                uint64_t kmer = encode_kmer(w + i, K);
+                c = pa_position<false>(keys, vals, n, kmer, K, m, (uint32_t)t.qBegin, (uint32_t)t.qEnd, i, 0, nullptr,
+                                       nullptr, 0);
+            }
+            counts[t.woff + i] = c;
+        }
+    }
+}
+
+__global__ void k_pa_emit(const Task *__restrict__ tasks, int64_t ntasks, const uint8_t *__restrict__ wbuf,
+                          const uint64_t *__restrict__ keys_cmp, const uint32_t *__restrict__ vals_cmp,
+                          const int64_t *__restrict__ posoff, const int32_t *__restrict__ nvalid, int K, int min_prefix,
+                          const uint32_t *__restrict__ counts, const int64_t *__restrict__ offs,
+                          uint64_t *__restrict__ outA, uint64_t *__restrict__ outB) {
+    for (int64_t ti = blockIdx.x; ti < ntasks; ti += gridDim.x) {
+        const Task t = tasks[ti];
+        const uint8_t *w = wbuf + t.woff;
+        const uint64_t *keys = keys_cmp + 2 * posoff[t.q];
+        const uint32_t *vals = vals_cmp + 2 * posoff[t.q];
+        int n = nvalid[t.q];
+        int m = pa_min_prefix(min_prefix, t.wlen);
+        for (int i = threadIdx.x; i < t.wlen; i += blockDim.x) {
+            if (counts[t.woff + i] == 0) continue;
+            uint64_t kmer = encode_kmer(w + i, K);
+            pa_position<true>(keys, vals, n, kmer, K, m, (uint32_t)t.qBegin, (uint32_t)t.qEnd, i, (uint64_t)ti, outA,
+                              outB, offs[t.woff + i]);
+        }
+    }
+}
+
+__global__ void k_pa_task_off(const Task *__restrict__ tasks, int64_t ntasks, const int64_t *__restrict__ offs,
+                              int64_t total_pos, int64_t total_anchors, int64_t *__restrict__ pa_off) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= ntasks; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i == ntasks) {
+            pa_off[i] = total_anchors;
+        } else {
+            int64_t w = tasks[i].woff;
+            pa_off[i] = w < total_pos ? offs[w] : total_anchors;
+        }
+    }
+}
+
+// Clear + Trim + Chainer2 per chain (lib-seq_compare.go:447-508)
+__global__ void k_pa_chain(const uint64_t *__restrict__ B, const int64_t *__restrict__ pa_off, int64_t ntasks, int K,
+                           LmChain2Opt opt, LmSub *__restrict__ subs, uint8_t *__restrict__ marks,
+                           uint64_t *__restrict__ msi, int32_t *__restrict__ stack, LmChain2 *__restrict__ out,
+                           int32_t *__restrict__ out_n, int32_t *__restrict__ clr_n) {
+    for (int64_t ti = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ti < ntasks; ti += (int64_t)gridDim.x * blockDim.x) {
+        int64_t o = pa_off[ti];
+        int n = (int)(pa_off[ti + 1] - o);
+        int nout = 0;
+        if (n > 0) {
+            LmSub *sb = subs + o;
+            for (int i = 0; i < n; i++) sb[i] = lm_unpack_anchor(B[o + i]);
+            if (n > 1) n = lm_clear_sorted(sb, n, K, marks + o);
+            int start = 0;
+            n = lm_trim(sb, n, 100.0f, &start);
+            clr_n[ti] = n;
+            if (n > 0) {
+                LmChain2 *res = out + o;
+                nout = lm_run_chain2(sb + start, n, opt, msi + o, stack + 2 * o + 4 * ti, res);
+                // "very important": sort by QBegin (:501-508), stable
+                for (int i = 1; i < nout; i++) {
+                    LmChain2 x = res[i];
+                    int j = i - 1;
+                    while (j >= 0 && res[j].qbegin > x.qbegin) {
+                        res[j + 1] = res[j];
+                        j--;
+                    }
+                    res[j + 1] = x;
+                }
+            }
+        } else {
+            clr_n[ti] = 0;
+        }
+        out_n[ti] = nout;
+    }
+}
+
+__global__ void k_gather_chain2(const LmChain2 *__restrict__ in, const int64_t *__restrict__ pa_off,
+                                const int32_t *__restrict__ out_n, const int64_t *__restrict__ res_off, int64_t ntasks,
+                                LmChain2 *__restrict__ out) {
+    for (int64_t ti = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ti < ntasks; ti += (int64_t)gridDim.x * blockDim.x) {
+        const LmChain2 *src = in + pa_off[ti];
+        LmChain2 *dst = out + res_off[ti];
+        for (int i = 0; i < out_n[ti]; i++) dst[i] = src[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// extendMatch (lib-index-search-util.go:34-96) — scratch sizing pass + run pass
+__device__ __forceinline__ void ext_flanks(const HspIn &h, int len1, int len2, int *r_n1, int *r_n2, int *l_n1, int *l_n2) {
+    *r_n1 = *r_n2 = *l_n1 = *l_n2 = 0;
+    const int m = 2;
+    if (h.end1 + m < len1 && h.end2 + m < len2) {
+        int e = h.rc ? (h.ext_len < h.tbegin ? h.ext_len : h.tbegin) : (h.ext_len < h.max_ext_len ? h.ext_len : h.max_ext_len);
+        if (e > 2) {
+            *r_n1 = (h.end1 + e < len1 ? h.end1 + e : len1) - h.end1;
+            *r_n2 = (h.end2 + e < len2 ? h.end2 + e : len2) - h.end2;
+        }
+    }
+    if (h.start1 > m && h.start2 > m) {
+        int e = h.rc ? (h.ext_len < h.max_ext_len ? h.ext_len : h.max_ext_len) : (h.ext_len < h.tbegin ? h.ext_len : h.tbegin);
+        if (e > 2) {
+            *l_n1 = h.start1 - (h.start1 - e > 0 ? h.start1 - e : 0);
+            *l_n2 = h.start2 - (h.start2 - e > 0 ? h.start2 - e : 0);
+        }
+    }
+}
+
+__device__ __forceinline__ int count_2mer_pairs(const uint8_t *a, int n1, const uint8_t *b, int n2) {
+    if (n1 < 2 || n2 < 2) return 0;
+    int c1[16], c2[16];
+    for (int i = 0; i < 16; i++) c1[i] = c2[i] = 0;
+    for (int i = 0; i + 1 < n1; i++) c1[(lm_base2bit(a[i]) << 2) | lm_base2bit(a[i + 1])]++;
+    for (int i = 0; i + 1 < n2; i++) c2[(lm_base2bit(b[i]) << 2) | lm_base2bit(b[i + 1])]++;
+    int s = 0;
+    for (int i = 0; i < 16; i++) s += c1[i] * c2[i];
+    return s;
+}
+
+__global__ void k_extend_count(const HspIn *__restrict__ hsps, int64_t n, const uint8_t *__restrict__ qseq,
+                               const int64_t *__restrict__ qoff, const uint8_t *__restrict__ wbuf,
+                               int32_t *__restrict__ cap) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const HspIn h = hsps[i];
+        const uint8_t *s1 = qseq + qoff[h.q];
+        const uint8_t *s2 = wbuf + h.woff;
+        int rn1, rn2, ln1, ln2;
+        ext_flanks(h, h.len1, h.len2, &rn1, &rn2, &ln1, &ln2);
+        int a = count_2mer_pairs(s1 + h.end1, rn1, s2 + h.end2, rn2);
+        int b = count_2mer_pairs(s1 + h.start1 - ln1, ln1, s2 + h.start2 - ln2, ln2); // reversal keeps 2-mer pair counts
+        cap[i] = (a > b ? a : b) + 1;
+    }
+}
+
+__global__ void k_extend(const HspIn *__restrict__ hsps, int64_t n, const uint8_t *__restrict__ qseq,
+                         const int64_t *__restrict__ qoff, const uint8_t *__restrict__ wbuf,
+                         const int32_t *__restrict__ cap, const int64_t *__restrict__ scratch_off,
+                         LmSub *__restrict__ subs, int64_t *__restrict__ msi, HspExt *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const HspIn h = hsps[i];
+        HspExt e;
+        lm_extend_match(qseq + qoff[h.q], h.len1, wbuf + h.woff, h.len2, h.start1, h.end1, h.start2, h.end2, h.ext_len,
+                        h.tbegin, h.max_ext_len, h.rc != 0, subs + scratch_off[i], msi + scratch_off[i], cap[i], &e.qs,
+                        &e.qe, &e.ts, &e.te, &e.s1, &e.e1, &e.s2, &e.e2);
+        out[i] = e;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// WFA + BLAST-style score (lib-index-search-util.go:260-304: 2/-3/5/2 over the M-trimmed ops)
+__global__ void k_wfa(const WfaIn *__restrict__ in, int64_t n, const int32_t *__restrict__ todo, int64_t ntodo,
+                      int32_t *__restrict__ hdr_pool, int32_t *__restrict__ arena_pool, uint64_t *__restrict__ ops_pool,
+                      WfaOut *__restrict__ out) {
+    for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < ntodo; x += (int64_t)gridDim.x * blockDim.x) {
+        int64_t i = todo ? todo[x] : x;
+        if (i >= n) continue;
+        const WfaIn w = in[i];
+        LmWfaOut r;
+        lm_wfa_align(w.q, w.qlen, w.t, w.tlen, hdr_pool + w.hdr_off, w.max_score, arena_pool + w.arena_off, w.arena_cap,
+                     ops_pool + w.ops_off, w.ops_cap, &r);
+        WfaOut o;
+        o.r = r;
+        o.blast_score = 0;
+        if (r.status == 0) {
+            const uint64_t *ops = ops_pool + w.ops_off;
+            int first = -1, last = -1;
+            for (int j = 0; j < r.nops; j++)
+                if ((ops[j] >> 32) == 'M') {
+                    if (first < 0) first = j;
+                    last = j;
+                }
+            int score = 0;
+            for (int j = first; j >= 0 && j <= last; j++) {
+                int nn = (int)(ops[j] & 0xffffffffu);
+                char op = (char)(ops[j] >> 32);
+                if (op == 'M')
+                    score += nn * 2;
+                else if (op == 'X')
+                    score += nn * -3;
+                else
+                    score -= 5 + nn * 2;
+            }
+            o.blast_score = score;
+        }
+        out[i] = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host-callable launchers
+static inline int grid_for(int64_t n, int block, int maxb = 2048 * 8) {
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > maxb) g = maxb;
+    return (int)g;
+}
+
+#define LM_LAUNCH_1D(kernel, n, stream, ...) \
+    hipLaunchKernelGGL(kernel, dim3(grid_for((n), 256)), dim3(256), 0, stream, __VA_ARGS__)
+
+void launch_extract_kmers(hipStream_t st, const uint8_t *qseq, const int64_t *qoff, const int64_t *posoff, int nq, int K,
+                          int64_t total_pos, uint64_t *keys_all, uint32_t *vals_all, uint64_t *keys_cmp,
+                          uint32_t *vals_cmp, int32_t *nvalid) {
+    LM_LAUNCH_1D(k_extract_kmers, total_pos, st, qseq, qoff, posoff, nq, K, keys_all, vals_all, keys_cmp, vals_cmp, nvalid);
+}
+void launch_fill_u32(hipStream_t st, uint32_t *p, int64_t n, uint32_t v) { LM_LAUNCH_1D(k_fill_u32, n, st, p, n, v); }
+void launch_mask(hipStream_t st, const uint64_t *keys_all, const int64_t *posoff, int nq, int M, int K,
+                 const uint64_t *masks, uint64_t *out_kmers, int64_t *out_lo, int64_t *out_hi, uint32_t *first_mask) {
+    LM_LAUNCH_1D(k_mask, (int64_t)nq * M, st, keys_all, posoff, nq, M, K, masks, out_kmers, out_lo, out_hi, first_mask);
+}
+void launch_lookup_count(hipStream_t st, DevIndexView ix, const uint64_t *kmers, const int64_t *klo, const int64_t *khi,
+                         const uint32_t *first_mask, int64_t nqm, int min_prefix, uint32_t *counts, int64_t *starts,
+                         int32_t *nscan, unsigned long long *stat_values) {
+    LM_LAUNCH_1D(k_lookup_count, nqm * 2, st, ix, kmers, klo, khi, first_mask, nqm, min_prefix, counts, starts, nscan,
+                 stat_values);
+}
+void launch_lookup_emit(hipStream_t st, DevIndexView ix, const uint64_t *kmers, const int64_t *klo, const int64_t *khi,
+                        const uint32_t *vals_all, int64_t nqm, const uint32_t *counts, const int64_t *offs,
+                        const int64_t *starts, const int32_t *nscan, uint64_t *outA, uint64_t *outB) {
+    LM_LAUNCH_1D(k_lookup_emit, nqm * 2, st, ix, kmers, klo, khi, vals_all, nqm, counts, offs, starts, nscan, outA, outB);
+}
+void launch_chain1(hipStream_t st, const uint64_t *B, const int64_t *seg_off, int nseg, LmChainOpt opt, int K, LmSub *subs,
+                   uint8_t *marks, uint64_t *msi, uint64_t *s2i, int8_t *dirs, uint8_t *visited, int32_t *chain_off_pool,
+                   int32_t *chain_idx_pool, int32_t *seg_n, float *seg_score, int32_t *seg_nch) {
+    hipLaunchKernelGGL(k_chain1, dim3(grid_for(nseg, 64)), dim3(64), 0, st, B, seg_off, nseg, opt, K, subs, marks, msi, s2i,
+                       dirs, visited, chain_off_pool, chain_idx_pool, seg_n, seg_score, seg_nch);
+}
+void launch_task_count(hipStream_t st, const float *seg_score, const int32_t *seg_nch, const uint8_t *keep, int nseg,
+                       float min_score, int32_t *ntask) {
+    LM_LAUNCH_1D(k_task_count, nseg, st, seg_score, seg_nch, keep, nseg, min_score, ntask);
+}
+void launch_make_tasks(hipStream_t st, DevIndexView ix, const uint64_t *segA, const int64_t *seg_off, int nseg,
+                       const LmSub *subs, const int32_t *chain_off_pool, const int32_t *chain_idx_pool,
+                       const int32_t *ntask, const int64_t *task_off, const int64_t *qoff, int ext_len,
+                       int32_t *order_scratch, Task *tasks) {
+    hipLaunchKernelGGL(k_make_tasks, dim3(grid_for(nseg, 64)), dim3(64), 0, st, ix, segA, seg_off, nseg, subs,
+                       chain_off_pool, chain_idx_pool, ntask, task_off, qoff, ext_len, order_scratch, tasks);
+}
+void launch_task_wlen(hipStream_t st, const Task *tasks, int64_t ntasks, int32_t *wlen) {
+    LM_LAUNCH_1D(k_task_wlen, ntasks, st, tasks, ntasks, wlen);
+}
+void launch_task_set_woff(hipStream_t st, Task *tasks, int64_t ntasks, const int64_t *woff) {
+    LM_LAUNCH_1D(k_task_set_woff, ntasks, st, tasks, ntasks, woff);
+}
+void launch_extract_windows(hipStream_t st, DevIndexView ix, const Task *tasks, int64_t ntasks, uint8_t *wbuf) {
+    int g = (int)(ntasks < 1 ? 1 : (ntasks > 1048576 ? 1048576 : ntasks));
+    hipLaunchKernelGGL(k_extract_windows, dim3(g), dim3(256), 0, st, ix, tasks, ntasks, wbuf);
+}
+void launch_pa_count(hipStream_t st, const Task *tasks, int64_t ntasks, const uint8_t *wbuf, const uint64_t *keys_cmp,
+                     const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid, int K, int min_prefix,
+                     uint32_t *counts) {
+    int g = (int)(ntasks < 1 ? 1 : (ntasks > 1048576 ? 1048576 : ntasks));
+    hipLaunchKernelGGL(k_pa_count, dim3(g), dim3(256), 0, st, tasks, ntasks, wbuf, keys_cmp, vals_cmp, posoff, nvalid, K,
+                       min_prefix, counts);
+}
+void launch_pa_emit(hipStream_t st, const Task *tasks, int64_t ntasks, const uint8_t *wbuf, const uint64_t *keys_cmp,
+                    const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid, int K, int min_prefix,
+                    const uint32_t *counts, const int64_t *offs, uint64_t *outA, uint64_t *outB) {
+    int g = (int)(ntasks < 1 ? 1 : (ntasks > 1048576 ? 1048576 : ntasks));
+    hipLaunchKernelGGL(k_pa_emit, dim3(g), dim3(256), 0, st, tasks, ntasks, wbuf, keys_cmp, vals_cmp, posoff, nvalid, K,
+                       min_prefix, counts, offs, outA, outB);
+}
+void launch_pa_task_off(hipStream_t st, const Task *tasks, int64_t ntasks, const int64_t *offs, int64_t total_pos,
+                        int64_t total_anchors, int64_t *pa_off) {
+    LM_LAUNCH_1D(k_pa_task_off, ntasks + 1, st, tasks, ntasks, offs, total_pos, total_anchors, pa_off);
+}
+void launch_pa_chain(hipStream_t st, const uint64_t *B, const int64_t *pa_off, int64_t ntasks, int K, LmChain2Opt opt,
+                     LmSub *subs, uint8_t *marks, uint64_t *msi, int32_t *stack, LmChain2 *out, int32_t *out_n,
+                     int32_t *clr_n) {
+    hipLaunchKernelGGL(k_pa_chain, dim3(grid_for(ntasks, 64)), dim3(64), 0, st, B, pa_off, ntasks, K, opt, subs, marks, msi,
+                       stack, out, out_n, clr_n);
+}
+void launch_gather_chain2(hipStream_t st, const LmChain2 *in, const int64_t *pa_off, const int32_t *out_n,
+                          const int64_t *res_off, int64_t ntasks, LmChain2 *out) {
+    LM_LAUNCH_1D(k_gather_chain2, ntasks, st, in, pa_off, out_n, res_off, ntasks, out);
+}
+void launch_extend_count(hipStream_t st, const HspIn *hsps, int64_t n, const uint8_t *qseq, const int64_t *qoff,
+                         const uint8_t *wbuf, int32_t *cap) {
+    hipLaunchKernelGGL(k_extend_count, dim3(grid_for(n, 64)), dim3(64), 0, st, hsps, n, qseq, qoff, wbuf, cap);
+}
+void launch_extend(hipStream_t st, const HspIn *hsps, int64_t n, const uint8_t *qseq, const int64_t *qoff,
+                   const uint8_t *wbuf, const int32_t *cap, const int64_t *scratch_off, LmSub *subs, int64_t *msi,
+                   HspExt *out) {
+    hipLaunchKernelGGL(k_extend, dim3(grid_for(n, 64)), dim3(64), 0, st, hsps, n, qseq, qoff, wbuf, cap, scratch_off, subs,
+                       msi, out);
+}
+void launch_wfa(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int32_t *hdr_pool,
+                int32_t *arena_pool, uint64_t *ops_pool, WfaOut *out) {
+    hipLaunchKernelGGL(k_wfa, dim3(grid_for(ntodo, 64)), dim3(64), 0, st, in, n, todo, ntodo, hdr_pool, arena_pool, ops_pool,
+                       out);
+}
+
+} // namespace lm

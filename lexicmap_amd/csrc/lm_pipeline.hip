@@ -1,0 +1,1858 @@
+// lm_pipeline.hip — host orchestration of the batched `lexicmap search` pipeline and the C-ABI (include/lexicmap_hip.h).
+//
+// The host does bookkeeping only: buffer management, rocPRIM sorts/scans between kernels, the contig/coordinate glue of
+// lib-index-search.go:2083-2468, BLAST statistics (lib-index-search-util.go:260-304) and result ordering
+// (:2701-2749,2919-2932).  All of §8(a) rows a1-a12,a14,a15 run in the kernels of lm_kernels.hip.  There is no CPU path:
+// without a HIP device every entry point fails with LM_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <tuple>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/lexicmap_hip.h"
+#include "lm_format.h"
+#include "lm_kernels.h"
+
+namespace lm {
+
+struct HipError : std::runtime_error {
+    explicit HipError(const std::string &m) : std::runtime_error(m) {}
+};
+#define HIPCHK(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t _e = (expr);                                                                              \
+        if (_e != hipSuccess)                                                                                \
+            throw HipError(std::string(#expr) + ": " + hipGetErrorString(_e) + " at " + __FILE__ + ":" +     \
+                           std::to_string(__LINE__));                                                        \
+    } while (0)
+
+template <typename T> struct DBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    DBuf() = default;
+    DBuf(const DBuf &) = delete;
+    DBuf &operator=(const DBuf &) = delete;
+    ~DBuf() {
+        if (p) (void)hipFree(p);
+    }
+    void ensure(size_t n) {
+        if (n <= cap && p) return;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        size_t want = std::max<size_t>(n + n / 8, 64);
+        HIPCHK(hipMalloc((void **)&p, want * sizeof(T)));
+        cap = want;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+static double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct ProfEntry {
+    std::string name;
+    int64_t launches = 0;
+    double ms = 0;
+    int64_t bytes = 0;
+};
+
+} // namespace lm
+
+using namespace lm;
+
+struct lm_index {
+    HostIndex host;
+    lm_options opt;
+    int device = 0;
+    hipStream_t st = nullptr;
+    std::string err;
+    // HBM image
+    DBuf<uint64_t> d_masks, d_seed_kmers, d_seed_vals;
+    DBuf<int32_t> d_pfx_first, d_g_len;
+    DBuf<int64_t> d_mask_off, d_g_off, d_batch_first;
+    DBuf<uint8_t> d_gbits;
+    DBuf<float> d_gap_lut;
+    int gap_lut_n = 0;
+    DevIndexView view;
+    int64_t hbm_bytes = 0;
+    // scratch
+    DBuf<uint8_t> tmp; // rocPRIM temporary storage
+    // profiling
+    bool prof = false;
+    std::vector<ProfEntry> prof_entries;
+    std::vector<lm_kernel_time> prof_out;
+    struct Pending {
+        int entry;
+        hipEvent_t a, b;
+    };
+    std::vector<Pending> pending;
+    // genome lookup
+    std::unordered_map<uint64_t, int> bg2local;
+};
+
+static thread_local std::string g_open_error;
+
+namespace lm {
+
+// ---- profiling: HIP events on the library's stream around each named launch ---------------------------------
+struct Prof {
+    lm_index *ix;
+    int entry = -1;
+    hipEvent_t a = nullptr, b = nullptr;
+    Prof(lm_index *ix_, const char *name, int64_t bytes = 0) : ix(ix_) {
+        if (!ix->prof) return;
+        for (size_t i = 0; i < ix->prof_entries.size(); i++)
+            if (ix->prof_entries[i].name == name) entry = (int)i;
+        if (entry < 0) {
+            ProfEntry e;
+            e.name = name;
+            ix->prof_entries.push_back(e);
+            entry = (int)ix->prof_entries.size() - 1;
+        }
+        ix->prof_entries[entry].bytes += bytes;
+        ix->prof_entries[entry].launches++;
+        HIPCHK(hipEventCreate(&a));
+        HIPCHK(hipEventCreate(&b));
+        HIPCHK(hipEventRecord(a, ix->st));
+    }
+    ~Prof() {
+        if (entry < 0) return;
+        (void)hipEventRecord(b, ix->st);
+        ix->pending.push_back({entry, a, b});
+    }
+};
+
+static void prof_resolve(lm_index *ix) {
+    for (auto &p : ix->pending) {
+        (void)hipEventSynchronize(p.b);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, p.a, p.b);
+        ix->prof_entries[p.entry].ms += ms;
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    ix->pending.clear();
+}
+
+// Go math.Log (pure Go / FreeBSD e_log.c) and math.Log2, for the gapScore table (lib-chaining.go:662-667):
+// gapScore(g) = 0.1*g + 0.5*float32(math.Log2(float64(g))) in float32.
+static double go_log(double x) {
+    const double Ln2Hi = 6.93147180369123816490e-01, Ln2Lo = 1.90821492927058770002e-10, L1 = 6.666666666666735130e-01,
+                 L2 = 3.999999999940941908e-01, L3 = 2.857142874366239149e-01, L4 = 2.222219843214978396e-01,
+                 L5 = 1.818357216161805012e-01, L6 = 1.531383769920937332e-01, L7 = 1.479819860511658591e-01;
+    int ki;
+    double f1 = std::frexp(x, &ki);
+    if (f1 < 0.70710678118654752440084436210484903928483593768847) {
+        f1 *= 2;
+        ki--;
+    }
+    double f = f1 - 1, k = (double)ki;
+    double s = f / (2 + f), s2 = s * s, s4 = s2 * s2;
+    double t1 = s2 * (L1 + s4 * (L3 + s4 * (L5 + s4 * L7)));
+    double t2 = s4 * (L2 + s4 * (L4 + s4 * L6));
+    double R = t1 + t2, hfsq = 0.5 * f * f;
+    return k * Ln2Hi - ((hfsq - (s * (hfsq + R) + k * Ln2Lo)) - f);
+}
+static double go_log2(double x) {
+    int e;
+    double frac = std::frexp(x, &e);
+    if (frac == 0.5) return (double)(e - 1);
+    return go_log(frac) * 1.44269504088896340735992468100189214 + (double)e;
+}
+static float gap_score(float gap) {
+    if (gap == 0) return 0;
+    float a = 0.1f * gap;
+    float b = 0.5f * (float)go_log2((double)gap);
+    return a + b;
+}
+
+template <typename T> static void h2d(lm_index *ix, DBuf<T> &d, const std::vector<T> &h) {
+    d.ensure(std::max<size_t>(h.size(), 1));
+    if (!h.empty()) HIPCHK(hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, ix->st));
+}
+template <typename T> static void d2h(lm_index *ix, std::vector<T> &h, const T *d, size_t n) {
+    h.resize(n);
+    if (n) HIPCHK(hipMemcpyAsync(h.data(), d, n * sizeof(T), hipMemcpyDeviceToHost, ix->st));
+}
+static void sync(lm_index *ix) { HIPCHK(hipStreamSynchronize(ix->st)); }
+
+// exclusive scan of n+1 uint32 counts (counts[n] must be 0) into int64 offsets; returns total after sync
+struct CastU32 {
+    __host__ __device__ int64_t operator()(const uint32_t &x) const { return (int64_t)x; }
+};
+struct CastI32 {
+    __host__ __device__ int64_t operator()(const int32_t &x) const { return (int64_t)x; }
+};
+template <typename InT, typename Cast>
+static int64_t scan_to_i64(lm_index *ix, const InT *counts, int64_t n, int64_t *offs) {
+    hipcub::TransformInputIterator<int64_t, Cast, const InT *> it(counts, Cast());
+    size_t bytes = 0;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, it, offs, (int)(n + 1), ix->st));
+    ix->tmp.ensure(bytes);
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(ix->tmp.p, bytes, it, offs, (int)(n + 1), ix->st));
+    int64_t total = 0;
+    HIPCHK(hipMemcpyAsync(&total, offs + n, sizeof(int64_t), hipMemcpyDeviceToHost, ix->st));
+    sync(ix);
+    return total;
+}
+
+static void sort_pairs_u64(lm_index *ix, uint64_t *k_in, uint64_t *k_out, uint64_t *v_in, uint64_t *v_out, int64_t n,
+                           int begin_bit, int end_bit) {
+    size_t bytes = 0;
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k_in, k_out, v_in, v_out, (int)n, begin_bit, end_bit, ix->st));
+    ix->tmp.ensure(bytes);
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(ix->tmp.p, bytes, k_in, k_out, v_in, v_out, (int)n, begin_bit, end_bit, ix->st));
+}
+
+// sort anchors by (A, B): LSD — stable sort by B, then by A. Result lands in (A0,B0).
+static void sort_anchors(lm_index *ix, uint64_t *A0, uint64_t *B0, uint64_t *A1, uint64_t *B1, int64_t n, int a_bits) {
+    if (n <= 0) return;
+    sort_pairs_u64(ix, B0, B1, A0, A1, n, 0, 64);
+    sort_pairs_u64(ix, A1, A0, B1, B0, n, 0, a_bits);
+}
+
+// ---- query batch ---------------------------------------------------------------------------------------------
+} // namespace lm
+
+struct lm_qbatch {
+    lm_index *ix = nullptr;
+    int nq = 0;
+    std::vector<uint8_t> h_seq;
+    std::vector<int64_t> h_qoff, h_posoff;
+    int64_t total_len = 0, total_pos = 0;
+    DBuf<uint8_t> d_seq;
+    DBuf<int64_t> d_qoff, d_posoff, d_segoff;
+};
+
+struct lm_result {
+    std::vector<lm_hsp> rows;
+    std::vector<std::string *> strings; // owned cigar/qseq/sseq/align
+    lm_stage_stats stats;
+    ~lm_result() {
+        for (auto *s : strings) delete s;
+    }
+};
+
+struct lm_stage {
+    std::vector<uint64_t> u64a, u64b;
+    std::vector<int64_t> i64a, i64b;
+    std::vector<int32_t> i32a, i32b;
+    std::vector<lm_pair> pairs;
+    std::vector<lm_anchor> raw, cleared;
+    std::vector<lm_chain2> chains2;
+    std::vector<lm_wfa> wfa;
+};
+
+namespace lm {
+
+// everything a batch keeps on the device between stages
+struct Work {
+    lm_index *ix;
+    lm_qbatch *qb;
+    // stage A
+    DBuf<uint64_t> keys_all, keys_all2, keys_cmp, keys_cmp2;
+    DBuf<uint32_t> vals_all, vals_all2, vals_cmp, vals_cmp2, first_mask;
+    DBuf<int32_t> nvalid;
+    uint64_t *k_all = nullptr, *k_cmp = nullptr; // sorted
+    uint32_t *v_all = nullptr, *v_cmp = nullptr;
+    // stage B
+    DBuf<uint64_t> kmers;
+    DBuf<int64_t> klo, khi;
+    // stage C
+    DBuf<uint32_t> lk_counts;
+    DBuf<int64_t> lk_offs, lk_starts;
+    DBuf<int32_t> lk_nscan;
+    DBuf<unsigned long long> stat;
+    DBuf<uint64_t> A0, B0, A1, B1;
+    int64_t n_anchors = 0;
+    DBuf<uint64_t> segA;
+    DBuf<int32_t> seg_len;
+    DBuf<int64_t> seg_off;
+    DBuf<int32_t> nseg_d;
+    int nseg = 0;
+    // stage D
+    DBuf<LmSub> subs;
+    DBuf<uint8_t> marks, visited;
+    DBuf<uint64_t> msi, s2i;
+    DBuf<int8_t> dirs;
+    DBuf<int32_t> chain_off_pool, chain_idx_pool, seg_n, seg_nch, order_scratch;
+    DBuf<float> seg_score;
+    // stage E
+    DBuf<int32_t> ntask;
+    DBuf<int64_t> task_off;
+    DBuf<uint8_t> keep;
+    DBuf<Task> tasks;
+    int64_t ntasks = 0;
+    explicit Work(lm_index *i, lm_qbatch *q) : ix(i), qb(q) {}
+};
+
+static void stage_kmers(Work &w) {
+    lm_index *ix = w.ix;
+    lm_qbatch *qb = w.qb;
+    int64_t P = qb->total_pos;
+    size_t n2 = (size_t)std::max<int64_t>(2 * P, 1);
+    w.keys_all.ensure(n2);
+    w.keys_all2.ensure(n2);
+    w.keys_cmp.ensure(n2);
+    w.keys_cmp2.ensure(n2);
+    w.vals_all.ensure(n2);
+    w.vals_all2.ensure(n2);
+    w.vals_cmp.ensure(n2);
+    w.vals_cmp2.ensure(n2);
+    w.nvalid.ensure(qb->nq + 1);
+    HIPCHK(hipMemsetAsync(w.nvalid.p, 0, sizeof(int32_t) * (qb->nq + 1), ix->st));
+    w.k_all = w.keys_all.p;
+    w.v_all = w.vals_all.p;
+    w.k_cmp = w.keys_cmp.p;
+    w.v_cmp = w.vals_cmp.p;
+    if (P == 0) return;
+    {
+        Prof p(ix, "k_extract_kmers", qb->total_len + 2 * P * 24);
+        launch_extract_kmers(ix->st, qb->d_seq.p, qb->d_qoff.p, qb->d_posoff.p, qb->nq, ix->host.k, P, w.keys_all.p,
+                             w.vals_all.p, w.keys_cmp.p, w.vals_cmp.p, w.nvalid.p);
+    }
+    {
+        Prof p(ix, "segmented_sort_kmers");
+        size_t bytes = 0;
+        int end_bit = std::min(64, 2 * ix->host.k);
+        HIPCHK(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, bytes, w.keys_all.p, w.keys_all2.p, w.vals_all.p,
+                                                           w.vals_all2.p, (int)(2 * P), qb->nq, qb->d_segoff.p,
+                                                           qb->d_segoff.p + 1, 0, end_bit, ix->st));
+        ix->tmp.ensure(bytes);
+        HIPCHK(hipcub::DeviceSegmentedRadixSort::SortPairs(ix->tmp.p, bytes, w.keys_all.p, w.keys_all2.p, w.vals_all.p,
+                                                           w.vals_all2.p, (int)(2 * P), qb->nq, qb->d_segoff.p,
+                                                           qb->d_segoff.p + 1, 0, end_bit, ix->st));
+        HIPCHK(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, bytes, w.keys_cmp.p, w.keys_cmp2.p, w.vals_cmp.p,
+                                                           w.vals_cmp2.p, (int)(2 * P), qb->nq, qb->d_segoff.p,
+                                                           qb->d_segoff.p + 1, 0, 64, ix->st));
+        ix->tmp.ensure(bytes);
+        HIPCHK(hipcub::DeviceSegmentedRadixSort::SortPairs(ix->tmp.p, bytes, w.keys_cmp.p, w.keys_cmp2.p, w.vals_cmp.p,
+                                                           w.vals_cmp2.p, (int)(2 * P), qb->nq, qb->d_segoff.p,
+                                                           qb->d_segoff.p + 1, 0, 64, ix->st));
+    }
+    w.k_all = w.keys_all2.p;
+    w.v_all = w.vals_all2.p;
+    w.k_cmp = w.keys_cmp2.p;
+    w.v_cmp = w.vals_cmp2.p;
+}
+
+static void stage_mask(Work &w) {
+    lm_index *ix = w.ix;
+    lm_qbatch *qb = w.qb;
+    int M = ix->host.M;
+    int64_t nqm = (int64_t)qb->nq * M;
+    w.kmers.ensure((size_t)nqm + 1);
+    w.klo.ensure((size_t)nqm + 1);
+    w.khi.ensure((size_t)nqm + 1);
+    w.first_mask.ensure((size_t)std::max<int64_t>(2 * qb->total_pos, 1));
+    launch_fill_u32(ix->st, w.first_mask.p, 2 * qb->total_pos, 0xffffffffu);
+    Prof p(ix, "k_mask", nqm * 32);
+    launch_mask(ix->st, w.k_all, qb->d_posoff.p, qb->nq, M, ix->host.k, ix->view.masks, w.kmers.p, w.klo.p, w.khi.p,
+                w.first_mask.p);
+}
+
+static void stage_lookup(Work &w, lm_stage_stats &stats) {
+    lm_index *ix = w.ix;
+    lm_qbatch *qb = w.qb;
+    int M = ix->host.M;
+    int64_t nqm = (int64_t)qb->nq * M;
+    int64_t n = nqm * 2;
+    w.lk_counts.ensure((size_t)n + 1);
+    w.lk_offs.ensure((size_t)n + 1);
+    w.lk_starts.ensure((size_t)n + 1);
+    w.lk_nscan.ensure((size_t)n + 1);
+    w.stat.ensure(4);
+    HIPCHK(hipMemsetAsync(w.stat.p, 0, 4 * sizeof(unsigned long long), ix->st));
+    HIPCHK(hipMemsetAsync(w.lk_counts.p + n, 0, sizeof(uint32_t), ix->st));
+    {
+        Prof p(ix, "k_lookup_count");
+        launch_lookup_count(ix->st, ix->view, w.kmers.p, w.klo.p, w.khi.p, w.first_mask.p, nqm, ix->opt.min_prefix,
+                            w.lk_counts.p, w.lk_starts.p, w.lk_nscan.p, w.stat.p);
+    }
+    int64_t T;
+    {
+        Prof p(ix, "scan");
+        T = scan_to_i64<uint32_t, CastU32>(ix, w.lk_counts.p, n, w.lk_offs.p);
+    }
+    unsigned long long hv = 0;
+    HIPCHK(hipMemcpyAsync(&hv, w.stat.p, sizeof hv, hipMemcpyDeviceToHost, ix->st));
+    sync(ix);
+    stats.seed_lookups += n;
+    stats.seed_values += (int64_t)hv;
+    stats.anchors_raw += T;
+    w.n_anchors = T;
+    w.nseg = 0;
+    if (T == 0) return;
+    if (T >= (int64_t)1 << 31) throw HipError("too many anchors in one batch; use a smaller query batch");
+    w.A0.ensure((size_t)T);
+    w.B0.ensure((size_t)T);
+    w.A1.ensure((size_t)T);
+    w.B1.ensure((size_t)T);
+    {
+        Prof p(ix, "k_lookup_emit", T * 16);
+        launch_lookup_emit(ix->st, ix->view, w.kmers.p, w.klo.p, w.khi.p, w.v_all, nqm, w.lk_counts.p, w.lk_offs.p,
+                           w.lk_starts.p, w.lk_nscan.p, w.A0.p, w.B0.p);
+    }
+    {
+        Prof p(ix, "sort_anchors");
+        sort_anchors(ix, w.A0.p, w.B0.p, w.A1.p, w.B1.p, T, 64);
+    }
+    // segments = runs of equal A
+    w.segA.ensure((size_t)T + 1);
+    w.seg_len.ensure((size_t)T + 2);
+    w.nseg_d.ensure(2);
+    {
+        Prof p(ix, "rle");
+        size_t bytes = 0;
+        HIPCHK(hipcub::DeviceRunLengthEncode::Encode(nullptr, bytes, w.A0.p, w.segA.p, w.seg_len.p, w.nseg_d.p, (int)T, ix->st));
+        ix->tmp.ensure(bytes);
+        HIPCHK(hipcub::DeviceRunLengthEncode::Encode(ix->tmp.p, bytes, w.A0.p, w.segA.p, w.seg_len.p, w.nseg_d.p, (int)T, ix->st));
+    }
+    int32_t nseg = 0;
+    HIPCHK(hipMemcpyAsync(&nseg, w.nseg_d.p, sizeof nseg, hipMemcpyDeviceToHost, ix->st));
+    sync(ix);
+    w.nseg = nseg;
+    HIPCHK(hipMemsetAsync(w.seg_len.p + nseg, 0, sizeof(int32_t), ix->st));
+    w.seg_off.ensure((size_t)nseg + 2);
+    scan_to_i64<int32_t, CastI32>(ix, w.seg_len.p, nseg, w.seg_off.p);
+    stats.genome_pairs += nseg;
+}
+
+static LmChainOpt chain_opt(lm_index *ix) {
+    LmChainOpt o;
+    o.max_gap = (float)ix->opt.max_gap;
+    o.min_score = lm_seed_weight((float)(uint8_t)ix->opt.min_single_prefix); // lib-index-search.go:742
+    o.max_distance = (float)ix->opt.max_distance;
+    o.top_chains = ix->opt.top_n_chains;
+    o.gap_lut = ix->d_gap_lut.p;
+    o.gap_lut_n = ix->gap_lut_n;
+    return o;
+}
+
+static void stage_chain1(Work &w) {
+    lm_index *ix = w.ix;
+    int64_t T = w.n_anchors;
+    int nseg = w.nseg;
+    if (nseg == 0) return;
+    w.subs.ensure((size_t)T);
+    w.marks.ensure((size_t)T);
+    w.visited.ensure((size_t)T);
+    w.msi.ensure((size_t)T);
+    w.s2i.ensure((size_t)T);
+    w.dirs.ensure((size_t)T);
+    w.chain_off_pool.ensure((size_t)T + 4 * (size_t)nseg + 8);
+    w.chain_idx_pool.ensure(2 * (size_t)T + 8 * (size_t)nseg + 8);
+    w.order_scratch.ensure((size_t)T + 4 * (size_t)nseg + 8);
+    w.seg_n.ensure(nseg);
+    w.seg_nch.ensure((size_t)nseg + 1);
+    w.seg_score.ensure(nseg);
+    Prof p(ix, "k_chain1", T * 8 * 3);
+    launch_chain1(ix->st, w.B0.p, w.seg_off.p, nseg, chain_opt(ix), ix->host.k, w.subs.p, w.marks.p, w.msi.p, w.s2i.p,
+                  w.dirs.p, w.visited.p, w.chain_off_pool.p, w.chain_idx_pool.p, w.seg_n.p, w.seg_score.p, w.seg_nch.p);
+}
+
+// ---- host-side result assembly types ---------------------------------------------------------------------------
+struct HChain { // Chain2Result (lib-chaining2.go:106-135) as it moves through falin
+    int qbegin, qend, tbegin, tend;
+    int aligned_bases_q, matched_bases, aligned_length = 0, gaps = 0;
+    double pident, aligned_fraction = 0, evalue = 0;
+    int score = 0, bitscore = 0;
+    int max_ext_len = 0, tpos_offset_begin = 0;
+    bool alive = true;
+    int64_t hsp = -1; // index into the HSP arrays of the current chunk
+    std::string *cigar = nullptr, *qseq = nullptr, *tseq = nullptr, *align = nullptr;
+};
+struct HCluster { // SimilarityDetail (:1099-1120)
+    bool rc = false, variant_a = false, has_result = false;
+    int nseeds = 0, seq_idx = 0;
+    double sim = 0;
+    int tBegin = 0, tEnd = 0; // chain window
+    int64_t task = -1;
+    std::vector<HChain> chains;
+};
+struct HGenome { // SearchResult (:1023-1040)
+    uint32_t q = 0;
+    uint64_t bg = 0;
+    int g = -1;
+    std::vector<HCluster> sds;
+    double aligned_fraction = 0;
+    bool alive = true;
+};
+
+struct AKey {
+    int qb, qe, tb, te, seq, rc;
+    bool operator<(const AKey &o) const {
+        return std::tie(qb, qe, tb, te, seq, rc) < std::tie(o.qb, o.qe, o.tb, o.te, o.seq, o.rc);
+    }
+};
+
+// lib-seq_compare.go:270-308
+static int coverage_len(std::vector<std::pair<int, int>> &r) {
+    if (r.empty()) return 0;
+    if (r.size() == 1) return r[0].second - r[0].first + 1;
+    std::stable_sort(r.begin(), r.end(), [](const std::pair<int, int> &a, const std::pair<int, int> &b) { return a.first < b.first; });
+    int tot = 0, start = r[0].first, end = r[0].second;
+    for (size_t i = 1; i < r.size(); i++) {
+        if (r[i].first > end) {
+            tot += end - start + 1;
+            start = r[i].first;
+            end = r[i].second;
+            continue;
+        }
+        if (r[i].second <= end) continue;
+        end = r[i].second;
+    }
+    return tot + end - start + 1;
+}
+
+// The contig-resolution / coordinate-conversion / dedup glue of falin for ONE lexichash chain (task) of a genome:
+// lib-index-search.go:2079-2470. Appends clusters (with pre-WFA HSPs) to `gen`.
+static void glue_task(const lm_index *ix, HGenome &gen, std::map<AKey, bool> &keys, const Task &t, int64_t task_id,
+                      const LmChain2 *cr, int ncr) {
+    if (ncr == 0) return;
+    const HostGenome &G = ix->host.genomes[t.g];
+    const int K = ix->host.k, contig_interval = ix->host.contig_interval;
+    const bool rc = t.rc != 0;
+    const int tBegin = t.tBegin, tEnd = t.tEnd, seqlen_w = t.wlen;
+    int iSeqPre = -1, iSeq = 0, tPosOffsetBegin = 0, tPosOffsetEnd = 0;
+    HCluster cur;
+    auto new_cluster = [&](bool variant_a) {
+        cur = HCluster();
+        cur.rc = rc;
+        cur.nseeds = t.nseeds;
+        cur.tBegin = tBegin;
+        cur.tEnd = tEnd;
+        cur.task = task_id;
+        cur.variant_a = variant_a;
+    };
+    new_cluster(false);
+    auto convert = [&](HChain &c, int qb, int qe, int tb, int te, int iseq) {
+        c.qbegin = qb;
+        c.qend = qe;
+        c.tpos_offset_begin = tPosOffsetBegin;
+        if (rc) {
+            c.tbegin = tBegin - tPosOffsetBegin + (seqlen_w - te - 1);
+            if (c.tbegin < 0) {
+                c.qend += c.tbegin;
+                c.aligned_bases_q += c.tbegin;
+                c.tbegin = 0;
+            }
+            c.tend = tBegin - tPosOffsetBegin + (seqlen_w - tb - 1);
+            if (c.tend > G.seq_sizes[iseq] - 1) {
+                c.qbegin += c.tend - (G.seq_sizes[iseq] - 1);
+                c.tend = G.seq_sizes[iseq] - 1;
+            }
+        } else {
+            c.tbegin = tBegin - tPosOffsetBegin + tb;
+            if (c.tbegin < 0) {
+                c.qbegin -= c.tbegin;
+                c.aligned_bases_q += c.tbegin;
+                c.tbegin = 0;
+            }
+            c.tend = tBegin - tPosOffsetBegin + te;
+            if (c.tend > G.seq_sizes[iseq] - 1) {
+                c.qend -= c.tend - (G.seq_sizes[iseq] - 1);
+                c.tend = G.seq_sizes[iseq] - 1;
+            }
+        }
+        c.max_ext_len = G.seq_sizes[iseq] - 1 - c.tend;
+    };
+    for (int _i = 0; _i < ncr; _i++) {
+        const LmChain2 &s = cr[_i];
+        HChain c;
+        c.aligned_bases_q = s.aligned_bases_q;
+        c.matched_bases = s.matched_bases;
+        c.pident = s.pident;
+        int qb = s.qbegin, qe = s.qend, tb = s.tbegin, te = s.tend;
+        iSeq = 0;
+        tPosOffsetBegin = 0;
+        tPosOffsetEnd = 0;
+        if (G.nseqs > 1) {
+            iSeq = -1;
+            int _begin, _end;
+            if (rc) {
+                _begin = tEnd - te + K;
+                _end = tEnd - tb - K;
+            } else {
+                _begin = tBegin + tb + K;
+                _end = tBegin + te - K;
+            }
+            if (_begin >= _end) {
+                if (rc) {
+                    _begin = tEnd - te;
+                    _end = tEnd - tb;
+                } else {
+                    _begin = tBegin + tb;
+                    _end = tBegin + te;
+                }
+            }
+            for (int j = 0; j < G.nseqs; j++) {
+                int l = G.seq_sizes[j];
+                tPosOffsetEnd += l - 1;
+                if (_begin + K >= tPosOffsetBegin && _end - K <= tPosOffsetEnd) {
+                    iSeq = j;
+                    break;
+                } else if (_end < tPosOffsetBegin) {
+                    iSeq = -1;
+                    break;
+                }
+                tPosOffsetEnd += contig_interval + 1;
+                tPosOffsetBegin = tPosOffsetEnd;
+            }
+            if (iSeq < 0) continue;
+            if (iSeqPre >= 0 && iSeq != iSeqPre) { // the HSP fragment belongs to another contig (:2156-2415)
+                int iSeq0 = iSeq;
+                iSeq = iSeqPre;
+                convert(c, qb, qe, tb, te, iSeq);
+                if (!cur.chains.empty()) {
+                    cur.variant_a = true;
+                    cur.seq_idx = iSeq;
+                    gen.sds.push_back(std::move(cur));
+                }
+                new_cluster(false);
+                iSeqPre = -1;
+                AKey key{c.qbegin, c.qend, c.tbegin, c.tend, iSeq, rc ? 1 : 0};
+                if (!keys.count(key)) {
+                    keys[key] = true;
+                    cur.chains.push_back(c);
+                }
+                iSeq = iSeq0;
+                continue;
+            }
+        }
+        iSeqPre = iSeq;
+        convert(c, qb, qe, tb, te, iSeq);
+        AKey key{c.qbegin, c.qend, c.tbegin, c.tend, iSeq, rc ? 1 : 0};
+        if (!keys.count(key)) {
+            keys[key] = true;
+            cur.chains.push_back(c);
+        }
+    }
+    if (iSeq >= 0 && !cur.chains.empty()) {
+        cur.seq_idx = iSeq;
+        gen.sds.push_back(std::move(cur));
+    }
+}
+
+} // namespace lm
+
+// ================================================================================================================
+// C-ABI
+// ================================================================================================================
+extern "C" {
+
+void lm_options_default(lm_options *o) {
+    memset(o, 0, sizeof *o);
+    o->min_prefix = 15;
+    o->min_single_prefix = 17;
+    o->top_n_genomes = 0;
+    o->top_n_chains = 0;
+    o->max_gap = 50;
+    o->max_distance = 1000;
+    o->ext_len = 1000;
+    o->ext_len2 = 50;
+    o->min_qcov_per_genome = 0;
+    o->max_evalue = 10;
+    o->output_seq = 0;
+    o->align_max_gap = 20;
+    o->align_band = 100;
+    o->align_min_match_len = 50;
+    o->align_min_pident = 70;
+    o->min_qcov_per_hsp = 0;
+    o->shard_rank = 0;
+    o->shard_count = 1;
+    o->total_bases_override = 0;
+}
+
+const char *lm_last_error(const lm_index *idx) { return idx ? idx->err.c_str() : g_open_error.c_str(); }
+
+static lm_status check_options(const lm_options &o, int k, int mask_prefix, int anchor_prefix, std::string &err) {
+    // search.go:159-229 and lib-index-search.go:483-485
+    if (o.min_prefix < 5 || o.min_prefix > 32) {
+        err = "the value of flag -p/--seed-min-prefix should be in the range of [5, 32]";
+        return LM_ERR_OPTION;
+    }
+    if (o.min_prefix > k || o.min_prefix < mask_prefix + anchor_prefix) {
+        err = "MinPrefix (" + std::to_string(o.min_prefix) + ") should be in the range of [" +
+              std::to_string(mask_prefix + anchor_prefix) + ", " + std::to_string(k) + "]";
+        return LM_ERR_OPTION;
+    }
+    if (o.min_single_prefix < o.min_prefix || o.min_single_prefix > 32) {
+        err = "the value of flag -P/--seed-min-single-prefix should be >= -p and <= 32";
+        return LM_ERR_OPTION;
+    }
+    if (o.align_band < o.align_max_gap) {
+        err = "the value of flag --align-band should be >= --align-max-gap";
+        return LM_ERR_OPTION;
+    }
+    if (o.align_min_match_len < o.min_single_prefix) {
+        err = "the value of flag -l/--align-min-match-len should be >= -P/--seed-min-single-prefix";
+        return LM_ERR_OPTION;
+    }
+    if (o.align_min_pident < 60 || o.align_min_pident > 100) {
+        err = "the value of flag -i/--align-min-match-pident should be in range of [60, 100]";
+        return LM_ERR_OPTION;
+    }
+    if (o.max_gap <= 0 || o.max_distance <= 0 || o.ext_len < 0) {
+        err = "seed-max-gap / seed-max-dist / align-ext-len out of range";
+        return LM_ERR_OPTION;
+    }
+    return LM_OK;
+}
+
+lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_index **out) {
+    *out = nullptr;
+    g_open_error.clear();
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        g_open_error = "no HIP device available (this library has no CPU path)";
+        return LM_ERR_NO_DEVICE;
+    }
+    lm_index *ix = new lm_index();
+    try {
+        ix->opt = *opt;
+        ix->device = device;
+        int status = 0;
+        std::string e = load_index(dir, opt->shard_count > 1 ? opt->shard_rank : 0,
+                                   opt->shard_count > 1 ? opt->shard_count : 1, ix->host, status);
+        if (!e.empty()) {
+            g_open_error = e;
+            delete ix;
+            return status == 2 ? LM_ERR_FORMAT : LM_ERR_IO;
+        }
+        if (opt->total_bases_override > 0) ix->host.total_bases = opt->total_bases_override;
+        lm_status st = check_options(*opt, ix->host.k, ix->host.mask_prefix, ix->host.anchor_prefix, g_open_error);
+        if (st != LM_OK) {
+            delete ix;
+            return st;
+        }
+        HIPCHK(hipSetDevice(device));
+        HIPCHK(hipStreamCreate(&ix->st));
+        HostIndex &h = ix->host;
+        // mask prefix table
+        int p = h.mask_prefix;
+        std::vector<int32_t> pfx((size_t)(1ull << (2 * p)) + 1, 0);
+        for (int i = 0; i < h.M; i++) pfx[(size_t)(h.masks[i] >> ((h.k - p) << 1)) + 1]++;
+        for (size_t i = 1; i < pfx.size(); i++) pfx[i] += pfx[i - 1];
+        h2d(ix, ix->d_masks, h.masks);
+        h2d(ix, ix->d_pfx_first, pfx);
+        h2d(ix, ix->d_seed_kmers, h.seed_kmers);
+        h2d(ix, ix->d_seed_vals, h.seed_vals);
+        h2d(ix, ix->d_mask_off, h.mask_off);
+        h2d(ix, ix->d_gbits, h.gbits);
+        std::vector<int64_t> goff;
+        std::vector<int32_t> glen;
+        for (size_t i = 0; i < h.genomes.size(); i++) {
+            goff.push_back(h.genomes[i].bits_off);
+            glen.push_back(h.genomes[i].len);
+            ix->bg2local[h.genomes[i].bg] = (int)i;
+        }
+        h2d(ix, ix->d_g_off, goff);
+        h2d(ix, ix->d_g_len, glen);
+        h2d(ix, ix->d_batch_first, h.batch_first);
+        // gapScore table for integer gaps 0..ceil(max_gap)
+        ix->gap_lut_n = (int)std::ceil(opt->max_gap) + 2;
+        std::vector<float> lut(ix->gap_lut_n);
+        for (int g = 0; g < ix->gap_lut_n; g++) lut[g] = gap_score((float)g);
+        h2d(ix, ix->d_gap_lut, lut);
+        sync(ix);
+        DevIndexView &v = ix->view;
+        v.K = h.k;
+        v.M = h.M;
+        v.mask_prefix = h.mask_prefix;
+        v.masks = ix->d_masks.p;
+        v.pfx_first = ix->d_pfx_first.p;
+        v.seed_kmers = ix->d_seed_kmers.p;
+        v.seed_vals = ix->d_seed_vals.p;
+        v.mask_off = ix->d_mask_off.p;
+        v.gbits = ix->d_gbits.p;
+        v.g_off = ix->d_g_off.p;
+        v.g_len = ix->d_g_len.p;
+        v.batch_first = ix->d_batch_first.p;
+        v.nbatches = h.genome_batches;
+        v.ngenomes = (int64_t)h.genomes.size();
+        v.shard_rank = h.shard_rank;
+        v.shard_count = h.shard_count;
+        ix->hbm_bytes = (int64_t)(h.masks.size() * 8 + pfx.size() * 4 + h.seed_kmers.size() * 16 + h.mask_off.size() * 8 +
+                                  h.gbits.size() + goff.size() * 12 + h.batch_first.size() * 8);
+        // the packed host copies are no longer needed
+        std::vector<uint64_t>().swap(h.seed_kmers);
+        std::vector<uint64_t>().swap(h.seed_vals);
+        std::vector<uint8_t>().swap(h.gbits);
+    } catch (const std::exception &e) {
+        g_open_error = e.what();
+        delete ix;
+        return LM_ERR_HIP;
+    }
+    *out = ix;
+    return LM_OK;
+}
+
+void lm_index_close(lm_index *ix) {
+    if (!ix) return;
+    prof_resolve(ix);
+    if (ix->st) (void)hipStreamDestroy(ix->st);
+    delete ix;
+}
+
+lm_status lm_index_get_info(const lm_index *ix, lm_index_info *info) {
+    if (!ix || !info) return LM_ERR_ARG;
+    info->k = ix->host.k;
+    info->masks = ix->host.M;
+    info->mask_prefix = ix->host.mask_prefix;
+    info->anchor_prefix = ix->host.anchor_prefix;
+    info->total_bases = ix->host.total_bases;
+    info->genomes = (int64_t)ix->host.genomes.size();
+    info->seeds = ix->host.mask_off.empty() ? 0 : ix->host.mask_off.back();
+    int64_t gb = 0;
+    for (auto &g : ix->host.genomes) gb += g.len;
+    info->genome_bases = gb;
+    info->hbm_bytes = ix->hbm_bytes;
+    return LM_OK;
+}
+
+const uint64_t *lm_index_masks(const lm_index *ix) { return ix ? ix->host.masks.data() : nullptr; }
+
+void lm_profile_enable(lm_index *ix, int on) { ix->prof = on != 0; }
+void lm_profile_reset(lm_index *ix) {
+    prof_resolve(ix);
+    ix->prof_entries.clear();
+}
+size_t lm_profile_get(lm_index *ix, const lm_kernel_time **out) {
+    prof_resolve(ix);
+    ix->prof_out.clear();
+    for (auto &e : ix->prof_entries) ix->prof_out.push_back({e.name.c_str(), e.launches, e.ms, e.bytes});
+    *out = ix->prof_out.data();
+    return ix->prof_out.size();
+}
+
+// ---- query upload ---------------------------------------------------------------------------------------------
+lm_status lm_qbatch_upload(lm_index *ix, const lm_query *queries, size_t nq, lm_qbatch **out) {
+    *out = nullptr;
+    if (!ix) return LM_ERR_ARG;
+    try {
+        HIPCHK(hipSetDevice(ix->device));
+        lm_qbatch *qb = new lm_qbatch();
+        qb->ix = ix;
+        qb->nq = (int)nq;
+        qb->h_qoff.assign(nq + 1, 0);
+        qb->h_posoff.assign(nq + 1, 0);
+        int K = ix->host.k;
+        for (size_t i = 0; i < nq; i++) {
+            qb->h_qoff[i + 1] = qb->h_qoff[i] + queries[i].len;
+            int64_t np = (int64_t)queries[i].len - K + 1;
+            qb->h_posoff[i + 1] = qb->h_posoff[i] + (np > 0 ? np : 0);
+        }
+        qb->total_len = qb->h_qoff[nq];
+        qb->total_pos = qb->h_posoff[nq];
+        if (2 * qb->total_pos >= ((int64_t)1 << 31) || nq >= ((size_t)1 << 30)) {
+            ix->err = "query batch too large (more than 2^30 k-mers); split the batch";
+            delete qb;
+            return LM_ERR_ARG;
+        }
+        qb->h_seq.resize((size_t)qb->total_len + 64, 'A');
+        for (size_t i = 0; i < nq; i++)
+            if (queries[i].len) memcpy(&qb->h_seq[(size_t)qb->h_qoff[i]], queries[i].seq, queries[i].len);
+        std::vector<int64_t> segoff(nq + 1);
+        for (size_t i = 0; i <= nq; i++) segoff[i] = 2 * qb->h_posoff[i];
+        h2d(ix, qb->d_seq, qb->h_seq);
+        h2d(ix, qb->d_qoff, qb->h_qoff);
+        h2d(ix, qb->d_posoff, qb->h_posoff);
+        h2d(ix, qb->d_segoff, segoff);
+        sync(ix);
+        *out = qb;
+        return LM_OK;
+    } catch (const std::exception &e) {
+        ix->err = e.what();
+        return LM_ERR_HIP;
+    }
+}
+
+void lm_qbatch_free(lm_qbatch *qb) { delete qb; }
+
+} // extern "C"
+
+namespace lm {
+
+// ---- alignment half of the pipeline: tasks -> windows -> pseudo-alignment -> glue -> extend -> WFA -> finalize ----
+struct AlignCtx {
+    lm_index *ix;
+    lm_qbatch *qb;
+    Work *w;
+    lm_stage_stats *stats;
+    // per chunk device buffers
+    DBuf<int32_t> wlen;
+    DBuf<int64_t> woff;
+    DBuf<uint8_t> wbuf;
+    DBuf<uint32_t> pa_counts;
+    DBuf<int64_t> pa_offs, pa_off;
+    DBuf<uint64_t> A0, B0, A1, B1;
+    DBuf<LmSub> subs;
+    DBuf<uint8_t> marks;
+    DBuf<uint64_t> msi;
+    DBuf<int32_t> stack, out_n, clr_n;
+    DBuf<LmChain2> out, out_compact;
+    DBuf<int64_t> res_off;
+    DBuf<Task> tasks;
+    DBuf<HspIn> hsp_in;
+    DBuf<HspExt> hsp_ext;
+    DBuf<int32_t> ext_cap;
+    DBuf<int64_t> ext_off, ext_msi;
+    DBuf<LmSub> ext_subs;
+    DBuf<WfaIn> wfa_in;
+    DBuf<WfaOut> wfa_out;
+    DBuf<int32_t> wfa_todo, hdr_pool, arena_pool;
+    DBuf<uint64_t> ops_pool;
+};
+
+struct HspMeta { // host-side view of one WFA problem
+    int64_t task;
+    uint32_t q;
+    HspIn in;
+    HspExt ext;
+    WfaOut out;
+    std::vector<uint64_t> ops;
+};
+
+// Runs pseudo-alignment for tasks[t0,t1) (host copy `ht`), returns per task the Chain2 results.
+static void run_pseudo(AlignCtx &a, const std::vector<Task> &ht, std::vector<int64_t> &res_off_h,
+                       std::vector<LmChain2> &res_h) {
+    lm_index *ix = a.ix;
+    lm_qbatch *qb = a.qb;
+    int64_t nt = (int64_t)ht.size();
+    res_off_h.assign(nt + 1, 0);
+    res_h.clear();
+    if (nt == 0) return;
+    int64_t W = ht.back().woff + ht.back().wlen;
+    a.wbuf.ensure((size_t)W + 64);
+    a.tasks.ensure((size_t)nt);
+    HIPCHK(hipMemcpyAsync(a.tasks.p, ht.data(), sizeof(Task) * nt, hipMemcpyHostToDevice, ix->st));
+    {
+        Prof p(ix, "k_extract_windows", W + W / 4);
+        launch_extract_windows(ix->st, ix->view, a.tasks.p, nt, a.wbuf.p);
+    }
+    a.stats->window_bases += W;
+    a.pa_counts.ensure((size_t)W + 1);
+    a.pa_offs.ensure((size_t)W + 1);
+    HIPCHK(hipMemsetAsync(a.pa_counts.p + W, 0, sizeof(uint32_t), ix->st));
+    {
+        Prof p(ix, "k_pa_count", W);
+        launch_pa_count(ix->st, a.tasks.p, nt, a.wbuf.p, a.w->k_cmp, a.w->v_cmp, qb->d_posoff.p, a.w->nvalid.p,
+                        ix->host.k, 11, a.pa_counts.p);
+    }
+    int64_t TP = scan_to_i64<uint32_t, CastU32>(ix, a.pa_counts.p, W, a.pa_offs.p);
+    a.stats->pa_anchors += TP;
+    if (TP >= (int64_t)1 << 31) throw HipError("too many pseudo-alignment anchors in one chunk");
+    a.pa_off.ensure((size_t)nt + 2);
+    a.out_n.ensure((size_t)nt + 1);
+    a.clr_n.ensure((size_t)nt + 1);
+    HIPCHK(hipMemsetAsync(a.out_n.p, 0, sizeof(int32_t) * (nt + 1), ix->st));
+    if (TP > 0) {
+        a.A0.ensure((size_t)TP);
+        a.B0.ensure((size_t)TP);
+        a.A1.ensure((size_t)TP);
+        a.B1.ensure((size_t)TP);
+        {
+            Prof p(ix, "k_pa_emit", TP * 16);
+            launch_pa_emit(ix->st, a.tasks.p, nt, a.wbuf.p, a.w->k_cmp, a.w->v_cmp, qb->d_posoff.p, a.w->nvalid.p,
+                           ix->host.k, 11, a.pa_counts.p, a.pa_offs.p, a.A0.p, a.B0.p);
+        }
+        {
+            Prof p(ix, "sort_pa_anchors");
+            int abits = 1;
+            while (((int64_t)1 << abits) < nt + 1) abits++;
+            sort_anchors(ix, a.A0.p, a.B0.p, a.A1.p, a.B1.p, TP, abits);
+        }
+        launch_pa_task_off(ix->st, a.tasks.p, nt, a.pa_offs.p, W, TP, a.pa_off.p);
+        a.subs.ensure((size_t)TP);
+        a.marks.ensure((size_t)TP);
+        a.msi.ensure((size_t)TP);
+        a.stack.ensure(2 * (size_t)TP + 4 * (size_t)nt + 8);
+        a.out.ensure((size_t)TP);
+        LmChain2Opt o2; // search.go:364-378
+        o2.max_gap = ix->opt.align_max_gap;
+        o2.min_score = (int)((double)ix->opt.align_min_match_len * ix->opt.align_min_pident / 100);
+        o2.min_align_len = ix->opt.align_min_match_len;
+        o2.band_base = ix->opt.align_band;
+        o2.band_count = ix->opt.align_band / 2;
+        o2.heuristic_pident = 15;
+        {
+            Prof p(ix, "k_pa_chain", TP * 32);
+            launch_pa_chain(ix->st, a.B0.p, a.pa_off.p, nt, ix->host.k, o2, a.subs.p, a.marks.p, a.msi.p, a.stack.p,
+                            a.out.p, a.out_n.p, a.clr_n.p);
+        }
+        a.res_off.ensure((size_t)nt + 2);
+        int64_t NR = scan_to_i64<int32_t, CastI32>(ix, a.out_n.p, nt, a.res_off.p);
+        if (NR > 0) {
+            a.out_compact.ensure((size_t)NR);
+            launch_gather_chain2(ix->st, a.out.p, a.pa_off.p, a.out_n.p, a.res_off.p, nt, a.out_compact.p);
+            d2h(ix, res_h, a.out_compact.p, (size_t)NR);
+        }
+        d2h(ix, res_off_h, a.res_off.p, (size_t)nt + 1);
+        sync(ix);
+    }
+}
+
+// WFA for a list of problems already described by device pointers; retries with more memory on overflow.
+static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &out, std::vector<uint64_t> &ops_h,
+                    std::vector<int64_t> &ops_off_h, bool want_ops) {
+    lm_index *ix = a.ix;
+    int64_t n = (int64_t)in.size();
+    out.assign(n, WfaOut());
+    ops_off_h.assign(n + 1, 0);
+    ops_h.clear();
+    if (n == 0) return;
+    std::vector<int32_t> todo(n);
+    for (int64_t i = 0; i < n; i++) todo[i] = (int32_t)i;
+    std::vector<int32_t> level(n, 0);
+    const int64_t budget = (int64_t)6 << 30; // bytes of scratch per launch
+    a.wfa_out.ensure((size_t)n);
+    std::vector<std::vector<uint64_t>> ops_keep(want_ops ? n : 0);
+    while (!todo.empty()) {
+        // take a prefix of todo that fits the scratch budget
+        std::vector<int32_t> cur;
+        int64_t hdr_tot = 0, arena_tot = 0, ops_tot = 0;
+        size_t taken = 0;
+        for (; taken < todo.size(); taken++) {
+            int32_t i = todo[taken];
+            WfaIn &w = in[i];
+            int64_t L = (int64_t)w.qlen + w.tlen;
+            int64_t ms = (64 + L / 8) << (2 * level[i]);
+            if (ms > 8 * L + 64) ms = 8 * L + 64; // a global alignment never exceeds this penalty
+            int64_t ar = std::max<int64_t>(4096, ms * 96) << level[i];
+            int64_t oc = std::min<int64_t>(L + 2, (64 + L / 8) << (2 * level[i]));
+            int64_t need = (ms * 9 + ar) * 4 + oc * 8;
+            if (!cur.empty() && (hdr_tot * 9 + arena_tot) * 4 + ops_tot * 8 + need > budget) break;
+            w.max_score = (int32_t)std::min<int64_t>(ms, 2000000000);
+            w.hdr_off = hdr_tot * 9;
+            w.arena_off = arena_tot;
+            w.arena_cap = ar;
+            w.ops_off = ops_tot;
+            w.ops_cap = (int32_t)oc;
+            hdr_tot += ms;
+            arena_tot += ar;
+            ops_tot += oc;
+            cur.push_back(i);
+        }
+        todo.erase(todo.begin(), todo.begin() + taken);
+        a.hdr_pool.ensure((size_t)hdr_tot * 9 + 16);
+        a.arena_pool.ensure((size_t)arena_tot + 16);
+        a.ops_pool.ensure((size_t)ops_tot + 16);
+        a.wfa_in.ensure((size_t)n);
+        a.wfa_todo.ensure(cur.size());
+        HIPCHK(hipMemcpyAsync(a.wfa_in.p, in.data(), sizeof(WfaIn) * n, hipMemcpyHostToDevice, ix->st));
+        HIPCHK(hipMemcpyAsync(a.wfa_todo.p, cur.data(), sizeof(int32_t) * cur.size(), hipMemcpyHostToDevice, ix->st));
+        {
+            Prof p(ix, "k_wfa");
+            launch_wfa(ix->st, a.wfa_in.p, n, a.wfa_todo.p, (int64_t)cur.size(), a.hdr_pool.p, a.arena_pool.p,
+                       a.ops_pool.p, a.wfa_out.p);
+        }
+        std::vector<WfaOut> tmp;
+        d2h(ix, tmp, a.wfa_out.p, (size_t)n);
+        std::vector<uint64_t> ops_tmp;
+        if (want_ops) d2h(ix, ops_tmp, a.ops_pool.p, (size_t)ops_tot);
+        sync(ix);
+        for (int32_t i : cur) {
+            if (tmp[i].r.status == 1) {
+                level[i]++;
+                a.stats->wfa_retries++;
+                if (level[i] > 12) throw HipError("WFA scratch overflow after 12 retries");
+                todo.push_back(i);
+            } else {
+                out[i] = tmp[i];
+                if (want_ops && tmp[i].r.nops > 0)
+                    ops_keep[i].assign(ops_tmp.begin() + in[i].ops_off, ops_tmp.begin() + in[i].ops_off + tmp[i].r.nops);
+            }
+        }
+    }
+    if (want_ops) {
+        for (int64_t i = 0; i < n; i++) {
+            ops_off_h[i] = (int64_t)ops_h.size();
+            ops_h.insert(ops_h.end(), ops_keep[i].begin(), ops_keep[i].end());
+        }
+        ops_off_h[n] = (int64_t)ops_h.size();
+    }
+}
+
+// scoreAndEvalue (lib-index-search-util.go:260-304) from the kernel's integer score
+static void score_evalue(int score, int qlen, int64_t total_bases, int *bitscore, double *evalue) {
+    int _score = score;
+    if ((_score & 1) == 1) _score--;
+    const double lnK = std::log(0.41);
+    double bit = (0.625 * (double)_score - lnK) / 0.693147180559945309417232121458176568;
+    *evalue = (double)total_bases * std::pow(2, -bit) * (double)qlen;
+    *bitscore = (int)bit;
+}
+
+static std::string *fmt_cigar(const std::vector<uint64_t> &ops) { // :2327-2340
+    int start = -1, end = -1;
+    for (size_t i = 0; i < ops.size(); i++)
+        if ((ops[i] >> 32) == 'M') {
+            if (start < 0) start = (int)i;
+            end = (int)i;
+        }
+    std::string *s = new std::string();
+    for (int i = start; i >= 0 && i <= end; i++) {
+        char op = (char)(ops[i] >> 32);
+        if (op == 'D')
+            op = 'I';
+        else if (op == 'I')
+            op = 'D';
+        *s += std::to_string((unsigned)(ops[i] & 0xffffffffu));
+        *s += op;
+    }
+    return s;
+}
+
+static void fmt_alignment(const std::vector<uint64_t> &ops, const uint8_t *q, const uint8_t *t, std::string *Q,
+                          std::string *A, std::string *T) {
+    int start = -1, end = -1;
+    for (size_t i = 0; i < ops.size(); i++)
+        if ((ops[i] >> 32) == 'M') {
+            if (start < 0) start = (int)i;
+            end = (int)i;
+        }
+    int qp = 0, tp = 0;
+    for (int i = 0; i < (int)ops.size(); i++) {
+        char op = (char)(ops[i] >> 32);
+        int cnt = (int)(ops[i] & 0xffffffffu);
+        bool in = start >= 0 && i >= start && i <= end;
+        for (int j = 0; j < cnt; j++) {
+            if (op == 'M' || op == 'X') {
+                if (in) {
+                    Q->push_back((char)q[qp]);
+                    T->push_back((char)t[tp]);
+                    A->push_back(op == 'M' ? '|' : ' ');
+                }
+                qp++;
+                tp++;
+            } else if (op == 'I') {
+                if (in) {
+                    Q->push_back('-');
+                    T->push_back((char)t[tp]);
+                    A->push_back(' ');
+                }
+                tp++;
+            } else {
+                if (in) {
+                    Q->push_back((char)q[qp]);
+                    T->push_back('-');
+                    A->push_back(' ');
+                }
+                qp++;
+            }
+        }
+    }
+}
+
+static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
+    lm_stage_stats &st = res->stats;
+    memset(&st, 0, sizeof st);
+    HIPCHK(hipSetDevice(ix->device));
+    double t0 = now_ms(), t1;
+    st.query_bases = qb->total_len;
+    st.query_kmers = 2 * qb->total_pos;
+    Work w(ix, qb);
+    stage_kmers(w);
+    stage_mask(w);
+    sync(ix);
+    t1 = now_ms();
+    st.ms_mask = t1 - t0;
+    t0 = t1;
+    stage_lookup(w, st);
+    t1 = now_ms();
+    st.ms_lookup = t1 - t0;
+    t0 = t1;
+    if (w.nseg == 0) {
+        st.ms_total = st.ms_mask + st.ms_lookup;
+        return;
+    }
+    stage_chain1(w);
+    int nseg = w.nseg;
+    // ---- top-N genomes per query (lib-index-search.go:1781-1805), host selection on (score desc, genome asc)
+    std::vector<uint64_t> segA_h;
+    std::vector<float> score_h;
+    std::vector<int32_t> segn_h, nch_h;
+    d2h(ix, segA_h, w.segA.p, (size_t)nseg);
+    d2h(ix, score_h, w.seg_score.p, (size_t)nseg);
+    d2h(ix, segn_h, w.seg_n.p, (size_t)nseg);
+    d2h(ix, nch_h, w.seg_nch.p, (size_t)nseg);
+    sync(ix);
+    for (int s = 0; s < nseg; s++) st.anchors_cleared += segn_h[s];
+    const float min_score = chain_opt(ix).min_score;
+    const uint8_t *keep_d = nullptr;
+    if (ix->opt.top_n_genomes > 0) {
+        std::vector<uint8_t> keep(nseg, 0);
+        int s = 0;
+        while (s < nseg) {
+            int e = s;
+            uint64_t q = segA_h[s] >> 34;
+            while (e < nseg && (segA_h[e] >> 34) == q) e++;
+            std::vector<int> cand;
+            for (int i = s; i < e; i++)
+                if (score_h[i] >= min_score) cand.push_back(i);
+            std::stable_sort(cand.begin(), cand.end(), [&](int x, int y) { return score_h[x] > score_h[y]; });
+            for (size_t i = 0; i < cand.size() && (int)i < ix->opt.top_n_genomes; i++) keep[cand[i]] = 1;
+            s = e;
+        }
+        w.keep.ensure(nseg);
+        HIPCHK(hipMemcpyAsync(w.keep.p, keep.data(), nseg, hipMemcpyHostToDevice, ix->st));
+        keep_d = w.keep.p;
+    }
+    w.ntask.ensure((size_t)nseg + 1);
+    w.task_off.ensure((size_t)nseg + 2);
+    HIPCHK(hipMemsetAsync(w.ntask.p + nseg, 0, sizeof(int32_t), ix->st));
+    launch_task_count(ix->st, w.seg_score.p, w.seg_nch.p, keep_d, nseg, min_score, w.ntask.p);
+    int64_t NT = scan_to_i64<int32_t, CastI32>(ix, w.ntask.p, nseg, w.task_off.p);
+    st.chains += NT;
+    t1 = now_ms();
+    st.ms_chain = t1 - t0;
+    t0 = t1;
+    if (NT == 0) {
+        st.ms_total = st.ms_mask + st.ms_lookup + st.ms_chain;
+        return;
+    }
+    w.tasks.ensure((size_t)NT);
+    launch_make_tasks(ix->st, ix->view, w.segA.p, w.seg_off.p, nseg, w.subs.p, w.chain_off_pool.p, w.chain_idx_pool.p,
+                      w.ntask.p, w.task_off.p, qb->d_qoff.p, ix->opt.ext_len, w.order_scratch.p, w.tasks.p);
+    std::vector<Task> tasks_h;
+    d2h(ix, tasks_h, w.tasks.p, (size_t)NT);
+    sync(ix);
+    t1 = now_ms();
+    st.ms_window = t1 - t0;
+    t0 = t1;
+
+    // ---- alignment in chunks of whole segments ----
+    AlignCtx a;
+    a.ix = ix;
+    a.qb = qb;
+    a.w = &w;
+    a.stats = &st;
+    const int64_t max_window_bytes = (int64_t)192 << 20;
+    std::vector<HGenome> genomes; // in (query, genome) order
+    const int K = ix->host.k;
+    const bool want_seq = ix->opt.output_seq != 0;
+    int64_t tpos = 0;
+    while (tpos < NT) {
+        // chunk [tpos, tend): whole segments, bounded window bytes
+        int64_t tend = tpos, wb = 0;
+        while (tend < NT) {
+            int64_t e = tend;
+            uint32_t seg = tasks_h[tend].seg;
+            int64_t segw = 0;
+            while (e < NT && tasks_h[e].seg == seg) segw += tasks_h[e++].wlen;
+            if (tend > tpos && wb + segw > max_window_bytes) break;
+            wb += segw;
+            tend = e;
+        }
+        std::vector<Task> ht(tasks_h.begin() + tpos, tasks_h.begin() + tend);
+        int64_t off = 0;
+        for (auto &t : ht) {
+            t.woff = off;
+            off += t.wlen;
+        }
+        std::vector<int64_t> res_off;
+        std::vector<LmChain2> resv;
+        double ta = now_ms();
+        run_pseudo(a, ht, res_off, resv);
+        double tb = now_ms();
+        st.ms_pseudo += tb - ta;
+        // glue per segment
+        size_t g0 = genomes.size();
+        std::vector<HspMeta> hsps;
+        {
+            size_t i = 0;
+            while (i < ht.size()) {
+                size_t e = i;
+                while (e < ht.size() && ht[e].seg == ht[i].seg) e++;
+                HGenome gen;
+                gen.q = ht[i].q;
+                gen.bg = segA_h[ht[i].seg] & ((1ull << 34) - 1);
+                gen.g = ht[i].g;
+                std::map<AKey, bool> keys;
+                if (gen.g >= 0)
+                    for (size_t t = i; t < e; t++)
+                        glue_task(ix, gen, keys, ht[t], (int64_t)t, resv.data() + res_off[t],
+                                  (int)(res_off[t + 1] - res_off[t]));
+                if (!gen.sds.empty()) genomes.push_back(std::move(gen));
+                i = e;
+            }
+        }
+        // HSP list (Update2 + the start of the finalisation loops :2223-2255 / :2490-2522)
+        for (size_t gi = g0; gi < genomes.size(); gi++) {
+            HGenome &gen = genomes[gi];
+            int qlen = (int)(qb->h_qoff[gen.q + 1] - qb->h_qoff[gen.q]);
+            for (auto &cl : gen.sds) {
+                const Task &t = ht[cl.task];
+                for (auto &c : cl.chains) {
+                    c.aligned_fraction = (double)c.aligned_bases_q / (double)qlen * 100;
+                    if (c.qbegin >= c.qend + 1) {
+                        c.alive = false;
+                        continue;
+                    }
+                    int start, end;
+                    if (cl.rc) {
+                        start = cl.tEnd - c.tend - c.tpos_offset_begin;
+                        end = cl.tEnd - c.tbegin - c.tpos_offset_begin + 1;
+                    } else {
+                        start = c.tpos_offset_begin + c.tbegin - cl.tBegin;
+                        end = c.tpos_offset_begin + c.tend - cl.tBegin + 1;
+                    }
+                    if (start >= end) {
+                        c.alive = false;
+                        continue;
+                    }
+                    int ext2 = ix->opt.ext_len2;
+                    if (c.aligned_bases_q > 1000000)
+                        ext2 += 80;
+                    else if (c.aligned_bases_q > 250000)
+                        ext2 += 40;
+                    else if (c.aligned_bases_q > 50000)
+                        ext2 += 20;
+                    else if (c.aligned_bases_q > 10000)
+                        ext2 += 10;
+                    HspMeta h;
+                    h.task = cl.task;
+                    h.q = gen.q;
+                    h.in.q = gen.q;
+                    h.in.rc = cl.rc ? 1 : 0;
+                    h.in.woff = t.woff;
+                    h.in.len1 = qlen;
+                    h.in.len2 = t.wlen;
+                    h.in.start1 = c.qbegin;
+                    h.in.end1 = c.qend + 1;
+                    h.in.start2 = start;
+                    h.in.end2 = end;
+                    h.in.ext_len = ext2;
+                    h.in.tbegin = c.tbegin;
+                    h.in.max_ext_len = c.max_ext_len;
+                    h.in.pad = 0;
+                    c.hsp = (int64_t)hsps.size();
+                    hsps.push_back(std::move(h));
+                }
+            }
+        }
+        double tc = now_ms();
+        st.ms_glue += tc - tb;
+        int64_t NH = (int64_t)hsps.size();
+        st.hsps_aligned += NH;
+        std::vector<WfaOut> wout;
+        std::vector<uint64_t> ops_h;
+        std::vector<int64_t> ops_off_h;
+        std::vector<uint8_t> wbuf_h;
+        if (NH > 0) {
+            std::vector<HspIn> hin(NH);
+            for (int64_t i = 0; i < NH; i++) hin[i] = hsps[i].in;
+            a.hsp_in.ensure((size_t)NH);
+            a.hsp_ext.ensure((size_t)NH);
+            a.ext_cap.ensure((size_t)NH + 1);
+            a.ext_off.ensure((size_t)NH + 2);
+            HIPCHK(hipMemcpyAsync(a.hsp_in.p, hin.data(), sizeof(HspIn) * NH, hipMemcpyHostToDevice, ix->st));
+            HIPCHK(hipMemsetAsync(a.ext_cap.p + NH, 0, sizeof(int32_t), ix->st));
+            launch_extend_count(ix->st, a.hsp_in.p, NH, qb->d_seq.p, qb->d_qoff.p, a.wbuf.p, a.ext_cap.p);
+            int64_t ES = scan_to_i64<int32_t, CastI32>(ix, a.ext_cap.p, NH, a.ext_off.p);
+            a.ext_subs.ensure((size_t)ES + 16);
+            a.ext_msi.ensure((size_t)ES + 16);
+            {
+                Prof p(ix, "k_extend");
+                launch_extend(ix->st, a.hsp_in.p, NH, qb->d_seq.p, qb->d_qoff.p, a.wbuf.p, a.ext_cap.p, a.ext_off.p,
+                              a.ext_subs.p, a.ext_msi.p, a.hsp_ext.p);
+            }
+            std::vector<HspExt> hext;
+            d2h(ix, hext, a.hsp_ext.p, (size_t)NH);
+            sync(ix);
+            std::vector<WfaIn> win(NH);
+            for (int64_t i = 0; i < NH; i++) {
+                hsps[i].ext = hext[i];
+                win[i].q = qb->d_seq.p + qb->h_qoff[hsps[i].q] + hext[i].qs;
+                win[i].t = a.wbuf.p + hsps[i].in.woff + hext[i].ts;
+                win[i].qlen = hext[i].qe - hext[i].qs;
+                win[i].tlen = hext[i].te - hext[i].ts;
+            }
+            run_wfa(a, win, wout, ops_h, ops_off_h, want_seq);
+            if (want_seq) {
+                d2h(ix, wbuf_h, a.wbuf.p, (size_t)off);
+                sync(ix);
+            }
+        }
+        double td = now_ms();
+        st.ms_extend_wfa += td - tc;
+        // ---- finalisation of this chunk's genomes (:2266-2357 / :2533-2626, then :2684-2749) ----
+        for (size_t gi = g0; gi < genomes.size(); gi++) {
+            HGenome &gen = genomes[gi];
+            int qlen = (int)(qb->h_qoff[gen.q + 1] - qb->h_qoff[gen.q]);
+            for (auto &cl : gen.sds) {
+                double max_sim = 0;
+                bool has = false;
+                for (auto &c : cl.chains) {
+                    if (!c.alive || c.hsp < 0) {
+                        c.alive = false;
+                        continue;
+                    }
+                    const HspMeta &h = hsps[c.hsp];
+                    const WfaOut &wo = wout[c.hsp];
+                    const LmWfaOut &cg = wo.r;
+                    int lq = h.ext.qe - h.ext.qs, lt = h.ext.te - h.ext.ts;
+                    c.score = wo.blast_score;
+                    if (cg.status != 0) { // no 'M' op: scoreAndEvalue returns MaxFloat64 -> filtered by evalue
+                        c.alive = false;
+                        continue;
+                    }
+                    score_evalue(c.score, lq, ix->host.total_bases, &c.bitscore, &c.evalue);
+                    if (c.evalue > ix->opt.max_evalue) {
+                        c.alive = false;
+                        continue;
+                    }
+                    c.qbegin -= h.ext.s1;
+                    c.qend += h.ext.e1;
+                    c.qbegin = c.qbegin + cg.qbegin - 1;
+                    c.qend = c.qend - (lq - cg.qend);
+                    if (cl.rc) {
+                        c.tbegin -= h.ext.e2;
+                        c.tend += h.ext.s2;
+                        c.tbegin = c.tbegin + (lt - cg.tend);
+                        if (cl.variant_a)
+                            c.tend = c.tend - cg.tbegin - 1; // :2285 as written in the contig-switch copy
+                        else
+                            c.tend = c.tend - (cg.tbegin - 1); // :2552
+                    } else {
+                        c.tbegin -= h.ext.s2;
+                        c.tend += h.ext.e2;
+                        c.tbegin = c.tbegin + cg.tbegin - 1;
+                        c.tend = c.tend - (lt - cg.tend);
+                    }
+                    c.aligned_bases_q = c.qend - c.qbegin + 1;
+                    c.aligned_length = (int)cg.align_len;
+                    c.matched_bases = (int)cg.matches;
+                    c.gaps = (int)cg.gaps;
+                    c.aligned_fraction = (double)c.aligned_bases_q / (double)qlen * 100;
+                    if (c.aligned_fraction > 100) c.aligned_fraction = 100;
+                    c.pident = (double)c.matched_bases / (double)cg.align_len * 100;
+                    if (c.aligned_fraction < ix->opt.min_qcov_per_hsp || c.pident < ix->opt.align_min_pident) {
+                        c.alive = false;
+                        continue;
+                    }
+                    if (want_seq) {
+                        std::vector<uint64_t> ops(ops_h.begin() + ops_off_h[c.hsp], ops_h.begin() + ops_off_h[c.hsp + 1]);
+                        c.cigar = fmt_cigar(ops);
+                        c.qseq = new std::string();
+                        c.tseq = new std::string();
+                        c.align = new std::string();
+                        fmt_alignment(ops, qb->h_seq.data() + qb->h_qoff[h.q] + h.ext.qs,
+                                      wbuf_h.data() + h.in.woff + h.ext.ts, c.qseq, c.align, c.tseq);
+                        res->strings.push_back(c.cigar);
+                        res->strings.push_back(c.qseq);
+                        res->strings.push_back(c.tseq);
+                        res->strings.push_back(c.align);
+                    }
+                    double sim = (double)c.bitscore * c.pident;
+                    if (sim > max_sim) max_sim = sim;
+                    has = true;
+                }
+                cl.has_result = has;
+                cl.sim = max_sim;
+            }
+            // drop clusters without results (:2359-2391, :2628-2659)
+            std::vector<HCluster> kept;
+            for (auto &cl : gen.sds)
+                if (cl.has_result) kept.push_back(std::move(cl));
+            gen.sds.swap(kept);
+            if (gen.sds.empty()) {
+                gen.alive = false;
+                continue;
+            }
+            std::vector<std::pair<int, int>> regions;
+            for (auto &cl : gen.sds)
+                for (auto &c : cl.chains)
+                    if (c.alive) regions.push_back({c.qbegin, c.qend});
+            int ab = coverage_len(regions);
+            gen.aligned_fraction = (double)ab / (double)qlen * 100;
+            if (gen.aligned_fraction > 100) gen.aligned_fraction = 100;
+            if (gen.aligned_fraction < ix->opt.min_qcov_per_genome) {
+                gen.alive = false;
+                continue;
+            }
+            std::stable_sort(gen.sds.begin(), gen.sds.end(), [](const HCluster &x, const HCluster &y) { return x.sim > y.sim; });
+        }
+        st.ms_finalize += now_ms() - td;
+        tpos = tend;
+    }
+    // ---- per query: sort genomes by best cluster (:2919-2921, ties by genome key), regroup by sseqid, emit rows ----
+    double te0 = now_ms();
+    {
+        size_t i = 0;
+        while (i < genomes.size()) {
+            size_t e = i;
+            while (e < genomes.size() && genomes[e].q == genomes[i].q) e++;
+            std::vector<HGenome *> gs;
+            for (size_t j = i; j < e; j++)
+                if (genomes[j].alive) gs.push_back(&genomes[j]);
+            std::stable_sort(gs.begin(), gs.end(), [](const HGenome *x, const HGenome *y) {
+                if (x->sds[0].sim != y->sds[0].sim) return x->sds[0].sim > y->sds[0].sim;
+                return x->bg < y->bg;
+            });
+            for (HGenome *g : gs) {
+                const HostGenome &G = ix->host.genomes[g->g];
+                // SortBySeqID (:1042-1096): group clusters by sseqid keeping first-seen order
+                std::vector<HCluster *> order;
+                std::vector<bool> used(g->sds.size(), false);
+                for (size_t x = 0; x < g->sds.size(); x++) {
+                    if (used[x]) continue;
+                    for (size_t y = x; y < g->sds.size(); y++)
+                        if (!used[y] && G.seq_ids[g->sds[y].seq_idx] == G.seq_ids[g->sds[x].seq_idx]) {
+                            order.push_back(&g->sds[y]);
+                            used[y] = true;
+                        }
+                }
+                int cls = 1, hspn = 1;
+                for (HCluster *cl : order) {
+                    for (auto &c : cl->chains) {
+                        if (!c.alive) continue;
+                        lm_hsp r;
+                        memset(&r, 0, sizeof r);
+                        r.query = g->q;
+                        r.hits = (uint32_t)gs.size();
+                        r.batch_genome = g->bg;
+                        r.qcov_genome = g->aligned_fraction;
+                        r.cls = cls;
+                        r.hsp = hspn++;
+                        r.seq_idx = cl->seq_idx;
+                        r.nseqs = G.nseqs;
+                        r.seq_len = G.seq_sizes[cl->seq_idx];
+                        r.nchunks = 1;
+                        r.chunk_idx = 0;
+                        r.rc = cl->rc ? 1 : 0;
+                        r.qcov_hsp = c.aligned_fraction;
+                        r.aligned_length = c.aligned_length;
+                        r.pident = c.pident;
+                        r.gaps = c.gaps;
+                        r.qbegin = c.qbegin;
+                        r.qend = c.qend;
+                        r.tbegin = c.tbegin;
+                        r.tend = c.tend;
+                        r.evalue = c.evalue;
+                        r.bitscore = c.bitscore;
+                        r.score = c.score;
+                        r.matched_bases = c.matched_bases;
+                        r.genome_id = G.id.c_str();
+                        r.seq_id = G.seq_ids[cl->seq_idx].c_str();
+                        r.cigar = c.cigar ? c.cigar->c_str() : nullptr;
+                        r.qseq = c.qseq ? c.qseq->c_str() : nullptr;
+                        r.sseq = c.tseq ? c.tseq->c_str() : nullptr;
+                        r.align = c.align ? c.align->c_str() : nullptr;
+                        res->rows.push_back(r);
+                        st.rows++;
+                        st.aligned_bases += c.aligned_length;
+                    }
+                    cls++;
+                }
+            }
+            i = e;
+        }
+    }
+    st.ms_finalize += now_ms() - te0;
+    st.ms_total = st.ms_mask + st.ms_lookup + st.ms_chain + st.ms_window + st.ms_pseudo + st.ms_glue + st.ms_extend_wfa +
+                  st.ms_finalize;
+}
+
+} // namespace lm
+
+extern "C" {
+
+lm_status lm_search_resident(lm_index *ix, lm_qbatch *qb, lm_result **out) {
+    *out = nullptr;
+    if (!ix || !qb) return LM_ERR_ARG;
+    lm_result *res = new lm_result();
+    try {
+        search_impl(ix, qb, res);
+    } catch (const std::exception &e) {
+        ix->err = e.what();
+        delete res;
+        return LM_ERR_HIP;
+    }
+    *out = res;
+    return LM_OK;
+}
+
+lm_status lm_search_batch(lm_index *ix, const lm_query *queries, size_t nq, lm_result **out) {
+    *out = nullptr;
+    lm_qbatch *qb = nullptr;
+    lm_status s = lm_qbatch_upload(ix, queries, nq, &qb);
+    if (s != LM_OK) return s;
+    s = lm_search_resident(ix, qb, out);
+    lm_qbatch_free(qb);
+    return s;
+}
+
+size_t lm_result_rows(const lm_result *res, const lm_hsp **rows) {
+    *rows = res->rows.data();
+    return res->rows.size();
+}
+void lm_result_stats(const lm_result *res, lm_stage_stats *stats) { *stats = res->stats; }
+void lm_result_free(lm_result *res) { delete res; }
+
+int lm_format_row(const lm_hsp *h, const char *query_id, uint32_t qlen, int more_columns, char *buf, size_t buflen) {
+    int n = snprintf(buf, buflen, "%s\t%u\t%u\t%s\t%s\t%.3f\t%d\t%d\t%.3f\t%d\t%.3f\t%d\t%d\t%d\t%d\t%d\t%c\t%d\t%.2e\t%d",
+                     query_id, qlen, h->hits, h->genome_id, h->seq_id, h->qcov_genome, h->cls, h->hsp, h->qcov_hsp,
+                     h->aligned_length, h->pident, h->gaps, h->qbegin + 1, h->qend + 1, h->tbegin + 1, h->tend + 1,
+                     h->rc ? '-' : '+', h->seq_len, h->evalue, h->bitscore);
+    if (more_columns && n > 0) {
+        int m = snprintf((size_t)n < buflen ? buf + n : nullptr, (size_t)n < buflen ? buflen - n : 0, "\t%s\t%s\t%s\t%s",
+                         h->cigar ? h->cigar : "", h->qseq ? h->qseq : "", h->sseq ? h->sseq : "",
+                         h->align ? h->align : "");
+        n += m;
+    }
+    return n;
+}
+
+void lm_stage_free(lm_stage *s) { delete s; }
+
+// ---- stage-level entry points ----------------------------------------------------------------------------------
+lm_status lm_mask_batch(lm_index *ix, const lm_query *queries, size_t nq, lm_stage **out, const uint64_t **kmers,
+                        const int64_t **loc_off, const int32_t **locs) {
+    *out = nullptr;
+    lm_qbatch *qb = nullptr;
+    lm_status s = lm_qbatch_upload(ix, queries, nq, &qb);
+    if (s != LM_OK) return s;
+    lm_stage *sg = new lm_stage();
+    try {
+        Work w(ix, qb);
+        stage_kmers(w);
+        stage_mask(w);
+        int64_t nqm = (int64_t)nq * ix->host.M;
+        std::vector<int64_t> lo, hi;
+        std::vector<uint32_t> vals;
+        d2h(ix, sg->u64a, w.kmers.p, (size_t)nqm);
+        d2h(ix, lo, w.klo.p, (size_t)nqm);
+        d2h(ix, hi, w.khi.p, (size_t)nqm);
+        d2h(ix, vals, (const uint32_t *)w.v_all, (size_t)(2 * qb->total_pos));
+        sync(ix);
+        sg->i64a.assign(nqm + 1, 0);
+        for (int64_t i = 0; i < nqm; i++) sg->i64a[i + 1] = sg->i64a[i] + (hi[i] - lo[i]);
+        sg->i32a.resize((size_t)sg->i64a[nqm]);
+        for (int64_t i = 0; i < nqm; i++)
+            for (int64_t j = lo[i]; j < hi[i]; j++) sg->i32a[sg->i64a[i] + (j - lo[i])] = (int32_t)vals[j];
+    } catch (const std::exception &e) {
+        ix->err = e.what();
+        delete sg;
+        lm_qbatch_free(qb);
+        return LM_ERR_HIP;
+    }
+    lm_qbatch_free(qb);
+    *kmers = sg->u64a.data();
+    *loc_off = sg->i64a.data();
+    *locs = sg->i32a.data();
+    *out = sg;
+    return LM_OK;
+}
+
+lm_status lm_seed_chain_batch(lm_index *ix, const lm_query *queries, size_t nq, lm_stage **out, size_t *npairs,
+                              const lm_pair **pairs, const lm_anchor **raw, const lm_anchor **cleared,
+                              const int64_t **chain_ptr, const int32_t **chain_idx) {
+    *out = nullptr;
+    *npairs = 0;
+    lm_qbatch *qb = nullptr;
+    lm_status s = lm_qbatch_upload(ix, queries, nq, &qb);
+    if (s != LM_OK) return s;
+    lm_stage *sg = new lm_stage();
+    try {
+        lm_stage_stats st;
+        memset(&st, 0, sizeof st);
+        Work w(ix, qb);
+        stage_kmers(w);
+        stage_mask(w);
+        stage_lookup(w, st);
+        sg->i64a.assign(1, 0);
+        if (w.nseg > 0) {
+            stage_chain1(w);
+            int nseg = w.nseg;
+            int64_t T = w.n_anchors;
+            std::vector<uint64_t> segA, B;
+            std::vector<int64_t> seg_off;
+            std::vector<int32_t> seg_n, seg_nch, coff, cidx;
+            std::vector<float> score;
+            std::vector<LmSub> subs;
+            d2h(ix, segA, w.segA.p, (size_t)nseg);
+            d2h(ix, B, w.B0.p, (size_t)T);
+            d2h(ix, seg_off, w.seg_off.p, (size_t)nseg + 1);
+            d2h(ix, seg_n, w.seg_n.p, (size_t)nseg);
+            d2h(ix, seg_nch, w.seg_nch.p, (size_t)nseg);
+            d2h(ix, score, w.seg_score.p, (size_t)nseg);
+            d2h(ix, subs, w.subs.p, (size_t)T);
+            d2h(ix, coff, w.chain_off_pool.p, (size_t)T + 4 * (size_t)nseg);
+            d2h(ix, cidx, w.chain_idx_pool.p, 2 * (size_t)T + 8 * (size_t)nseg);
+            sync(ix);
+            sg->raw.resize((size_t)T);
+            for (int64_t i = 0; i < T; i++) {
+                LmSub x = lm_unpack_anchor(B[i]);
+                sg->raw[i] = {x.qbegin, x.tbegin, x.len, x.trc, x.qrc, 0};
+            }
+            for (int sidx = 0; sidx < nseg; sidx++) {
+                lm_pair p;
+                p.query = (uint32_t)(segA[sidx] >> 34);
+                p.batch_genome = segA[sidx] & ((1ull << 34) - 1);
+                p.raw_off = seg_off[sidx];
+                p.raw_n = seg_off[sidx + 1] - seg_off[sidx];
+                p.clr_off = (int64_t)sg->cleared.size();
+                p.clr_n = seg_n[sidx];
+                for (int i = 0; i < seg_n[sidx]; i++) {
+                    const LmSub &x = subs[seg_off[sidx] + i];
+                    sg->cleared.push_back({x.qbegin, x.tbegin, x.len, x.trc, x.qrc, 0});
+                }
+                p.score = score[sidx];
+                p.chain_off = (int64_t)sg->i64a.size() - 1;
+                p.chain_n = seg_nch[sidx];
+                const int32_t *co = coff.data() + seg_off[sidx] + 4ll * sidx;
+                const int32_t *ci = cidx.data() + 2 * seg_off[sidx] + 8ll * sidx;
+                for (int c = 0; c < seg_nch[sidx]; c++) {
+                    for (int j = co[c]; j < co[c + 1]; j++) sg->i32a.push_back(ci[j]);
+                    sg->i64a.push_back((int64_t)sg->i32a.size());
+                }
+                sg->pairs.push_back(p);
+            }
+        }
+    } catch (const std::exception &e) {
+        ix->err = e.what();
+        delete sg;
+        lm_qbatch_free(qb);
+        return LM_ERR_HIP;
+    }
+    lm_qbatch_free(qb);
+    *npairs = sg->pairs.size();
+    *pairs = sg->pairs.data();
+    *raw = sg->raw.data();
+    *cleared = sg->cleared.data();
+    *chain_ptr = sg->i64a.data();
+    *chain_idx = sg->i32a.data();
+    *out = sg;
+    return LM_OK;
+}
+
+lm_status lm_pseudoalign_batch(lm_index *ix, const lm_query *queries, size_t nq, const lm_query *targets,
+                               const uint32_t *qidx, const uint32_t *qbegin, const uint32_t *qend, size_t nproblems,
+                               lm_stage **out, const int64_t **res_off, const lm_chain2 **resv) {
+    *out = nullptr;
+    lm_qbatch *qb = nullptr;
+    lm_status s = lm_qbatch_upload(ix, queries, nq, &qb);
+    if (s != LM_OK) return s;
+    lm_stage *sg = new lm_stage();
+    try {
+        lm_stage_stats st;
+        memset(&st, 0, sizeof st);
+        Work w(ix, qb);
+        stage_kmers(w);
+        AlignCtx a;
+        a.ix = ix;
+        a.qb = qb;
+        a.w = &w;
+        a.stats = &st;
+        // explicit windows: upload targets as the window buffer, build tasks on the host
+        std::vector<Task> ht(nproblems);
+        int64_t off = 0;
+        for (size_t i = 0; i < nproblems; i++) {
+            Task t;
+            memset(&t, 0, sizeof t);
+            t.seg = (uint32_t)i;
+            t.q = qidx[i];
+            t.g = -1; // windows come from the caller, k_extract_windows skips them
+            t.qBegin = (int32_t)qbegin[i];
+            t.qEnd = (int32_t)qend[i];
+            t.wlen = (int32_t)targets[i].len;
+            t.woff = off;
+            off += t.wlen;
+            ht[i] = t;
+        }
+        std::vector<uint8_t> wb((size_t)off + 64, 'A');
+        for (size_t i = 0; i < nproblems; i++)
+            if (targets[i].len) memcpy(&wb[(size_t)ht[i].woff], targets[i].seq, targets[i].len);
+        a.wbuf.ensure(wb.size());
+        HIPCHK(hipMemcpyAsync(a.wbuf.p, wb.data(), wb.size(), hipMemcpyHostToDevice, ix->st));
+        std::vector<int64_t> ro;
+        std::vector<LmChain2> rv;
+        run_pseudo(a, ht, ro, rv);
+        sg->i64a = ro;
+        sg->chains2.resize(rv.size());
+        for (size_t i = 0; i < rv.size(); i++)
+            sg->chains2[i] = {rv[i].qbegin, rv[i].qend, rv[i].tbegin, rv[i].tend, rv[i].nanchors, rv[i].matched_bases,
+                              rv[i].aligned_bases_q, rv[i].aligned_bases_t, rv[i].pident};
+    } catch (const std::exception &e) {
+        ix->err = e.what();
+        delete sg;
+        lm_qbatch_free(qb);
+        return LM_ERR_HIP;
+    }
+    lm_qbatch_free(qb);
+    *res_off = sg->i64a.data();
+    *resv = sg->chains2.data();
+    *out = sg;
+    return LM_OK;
+}
+
+lm_status lm_wfa_batch(lm_index *ix, const lm_query *q, const lm_query *t, size_t n, lm_stage **out, const lm_wfa **resv,
+                       const uint64_t **ops) {
+    *out = nullptr;
+    if (!ix) return LM_ERR_ARG;
+    lm_stage *sg = new lm_stage();
+    try {
+        HIPCHK(hipSetDevice(ix->device));
+        lm_stage_stats st;
+        memset(&st, 0, sizeof st);
+        AlignCtx a;
+        a.ix = ix;
+        a.qb = nullptr;
+        a.w = nullptr;
+        a.stats = &st;
+        std::vector<uint8_t> buf;
+        std::vector<int64_t> qo(n), to(n);
+        for (size_t i = 0; i < n; i++) {
+            qo[i] = (int64_t)buf.size();
+            buf.insert(buf.end(), q[i].seq, q[i].seq + q[i].len);
+            to[i] = (int64_t)buf.size();
+            buf.insert(buf.end(), t[i].seq, t[i].seq + t[i].len);
+        }
+        buf.resize(buf.size() + 64, 'A');
+        a.wbuf.ensure(buf.size());
+        HIPCHK(hipMemcpyAsync(a.wbuf.p, buf.data(), buf.size(), hipMemcpyHostToDevice, ix->st));
+        std::vector<WfaIn> win(n);
+        for (size_t i = 0; i < n; i++) {
+            win[i].q = a.wbuf.p + qo[i];
+            win[i].t = a.wbuf.p + to[i];
+            win[i].qlen = (int32_t)q[i].len;
+            win[i].tlen = (int32_t)t[i].len;
+        }
+        std::vector<WfaOut> wout;
+        std::vector<int64_t> ops_off;
+        run_wfa(a, win, wout, sg->u64a, ops_off, true);
+        sg->wfa.resize(n);
+        for (size_t i = 0; i < n; i++) {
+            const LmWfaOut &r = wout[i].r;
+            sg->wfa[i] = {r.status, r.score, r.qbegin, r.qend, r.tbegin, r.tend, r.align_len, r.matches, r.gaps,
+                          r.gap_regions, ops_off[i], r.nops};
+        }
+    } catch (const std::exception &e) {
+        ix->err = e.what();
+        delete sg;
+        return LM_ERR_HIP;
+    }
+    *resv = sg->wfa.data();
+    *ops = sg->u64a.data();
+    *out = sg;
+    return LM_OK;
+}
+
+} // extern "C"

@@ -36,7 +36,7 @@ float ha_chain1(const LmSub *subs, int n, float max_gap, float min_score, float 
     o.top_chains = top_chains;
     o.gap_lut = gap_lut;
     o.gap_lut_n = gap_lut_n;
-    return lm_chain1(subs, n, o, msi.data(), s2i.data(), dirs.data(), vis.data(), chain_off, chain_idx, nchains);
+    return lm_run_chain1(subs, n, o, msi.data(), s2i.data(), dirs.data(), vis.data(), chain_off, chain_idx, nchains);
 }
 
 int ha_trim(const LmSub *subs, int n, float min_dist, int *start) { return lm_trim(subs, n, min_dist, start); }
@@ -52,7 +52,7 @@ int ha_chain2(const LmSub *subs, int n, int max_gap, int min_score, int min_alig
     o.band_count = band_count;
     o.band_base = band_base;
     o.heuristic_pident = hpt;
-    return lm_chain2(subs, n, o, msi.data(), stack.data(), out);
+    return lm_run_chain2(subs, n, o, msi.data(), stack.data(), out);
 }
 
 void ha_extend_match(const uint8_t *seq1, int len1, const uint8_t *seq2, int len2, int start1, int end1, int start2,
