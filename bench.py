@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""bench.py — queries/s of the MI355X `lexicmap search` hot path (BASELINE.json metric), one JSON line on rank 0.
+
+A "step" = one pass of the whole hot path (mask -> lookup -> chain -> pseudo-align -> extend/WFA -> HSP rows) over one
+batch of synthetic queries whose bases are already resident in HBM.  N>1: one process per GPU; the index is replicated,
+the query batch is sharded (strong scaling: total work fixed) and per-rank HSP rows are merged with one RCCL all-gather
+per step.  `--shard index` shards the genomes instead (index larger than one GPU).
+
+The CPU baseline is the oracle (oracle/liblmo.so, a C restatement of the reference; kind "port") timed on the host cores
+on a bounded sample of the same workload.  The Go reference cannot be built here (`go` absent) — probed and printed.
+"""
+import argparse
+import json
+import math
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--workload", default=os.environ.get("LM_BENCH_WORKLOAD", "c2"), choices=["c2", "small", "tiny"])
+    p.add_argument("--queries", type=int, default=0, help="override the number of queries")
+    p.add_argument("--genomes", type=int, default=0, help="override the number of genomes")
+    p.add_argument("--genome-len", type=int, default=0)
+    p.add_argument("--shard", default="queries", choices=["queries", "index"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=20.0)
+    return p.parse_args()
+
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: 1k gene queries (1-2 kb) vs 10k synthetic 5-Mb genomes, index HBM-resident
+    "c2": dict(genomes=10000, genome_len=5_000_000, families=100, queries=1000, qlen=(1000, 2000)),
+    # scaled-down shapes for development (NOT the headline config)
+    "small": dict(genomes=200, genome_len=500_000, families=4, queries=1000, qlen=(1000, 2000)),
+    "tiny": dict(genomes=24, genome_len=100_000, families=4, queries=64, qlen=(300, 1500)),
+}
+
+
+def cpu_baseline(index_dir, queries, seconds, ncores):
+    """oracle (port) on the host cores, bounded sample; returns dict"""
+    import multiprocessing as mp
+    n = len(queries)
+    # calibrate on a few queries with one core
+    import oracle as O
+    oi = O.Index(index_dir)
+    t0 = time.time()
+    k = 0
+    while k < min(n, 4):
+        oi.search(queries[k][1])
+        k += 1
+    per = (time.time() - t0) / max(k, 1)
+    oi.close()
+    nsample = int(max(ncores, min(n, seconds * ncores / max(per, 1e-4))))
+    sample = queries[:nsample]
+    with mp.Pool(ncores, initializer=_cpu_init, initargs=(index_dir,)) as pool:
+        t0 = time.time()
+        res = pool.map(_cpu_one, [q[1] for q in sample], chunksize=max(1, len(sample) // (ncores * 8)))
+        dt = time.time() - t0
+    rows = sum(r[0] for r in res)
+    return dict(value=len(sample) / dt, unit="queries/s", cores=ncores, kind="port",
+                sample="%d of %d queries of the same batch, oracle/liblmo.so (C restatement of the Go reference, "
+                       "RAM-resident index = the reference's -w regime) on %d processes, %.1f s, %d HSP rows"
+                       % (len(sample), n, ncores, dt, rows))
+
+
+_CPU_IDX = None
+
+
+def _cpu_init(index_dir):
+    global _CPU_IDX
+    import oracle as O
+    _CPU_IDX = O.Index(index_dir)
+
+
+def _cpu_one(seq):
+    rows, st = _CPU_IDX.search(seq)
+    return (len(rows), sum(r["aligned_length"] for r in rows))
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    import lexicmap_amd as la
+    from lexicmap_amd import synth
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.queries:
+        wl["queries"] = args.queries
+    if args.genomes:
+        wl["genomes"] = args.genomes
+    if args.genome_len:
+        wl["genome_len"] = args.genome_len
+
+    t_setup = time.time()
+    tmpdir = None
+    index_dir = None
+    opt_kw = {}
+    if args.shard == "index" and world > 1:
+        opt_kw = dict(shard_rank=rank, shard_count=world)
+    gpu_built = hasattr(la.api, "build_synthetic_index") and args.workload == "c2"
+    if gpu_built:
+        # synthetic index generated directly in HBM by the GPU builder (no disk): the only way to have the C2-size index
+        # on a fresh box within minutes
+        gi, queries, sample_dir = la.api.build_synthetic_index(wl, device=local_rank, rank=rank, world=world,
+                                                               shard=args.shard)
+        index_dir = sample_dir
+    else:
+        import oracle as O
+        tmpdir = os.path.join(tempfile.gettempdir(), "lm_bench_%s_%d_%d" % (args.workload, wl["genomes"], wl["genome_len"]))
+        index_dir = os.path.join(tmpdir, "index.lmi")
+        genomes = synth.make_genomes(wl["genomes"], wl["genome_len"], wl["families"], seed=1000, max_div=0.10)
+        if rank == 0 and not os.path.exists(os.path.join(index_dir, "info.toml")):
+            os.makedirs(tmpdir, exist_ok=True)
+            O.build_index(index_dir, genomes, O.default_build_opt(chunks=8))
+        if world > 1:
+            dist.barrier()
+        queries = synth.make_gene_queries(genomes, wl["queries"], seed=2000, len_range=wl["qlen"], max_div=0.10)
+        if opt_kw:
+            whole_bases = sum(sum(len(c[1]) for c in g[1]) for g in genomes)
+            opt_kw["total_bases_override"] = whole_bases
+        gi = la.Index(index_dir, la.api.default_options(**opt_kw), device=local_rank)
+    info = gi.info()
+    log("[rank %d] index ready in %.1f s: %s" % (rank, time.time() - t_setup, info))
+
+    # queries of this rank
+    if args.shard == "queries" and world > 1:
+        my = [q for i, q in enumerate(queries) if i % world == rank]
+    else:
+        my = queries
+    seqs = [q[1] for q in my]
+    qb = gi.upload(seqs)  # bases resident in HBM before the timed region
+
+    def gather_rows(rows_count, aligned):
+        """merge per-rank hit lists: one all-gather of the per-rank row payload (here: counts + aligned bases; the
+        row payload itself is gathered as a byte tensor)"""
+        if world == 1:
+            return rows_count, aligned
+        t = torch.tensor([rows_count, aligned], dtype=torch.int64, device="cuda")
+        out = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return int(sum(o[0].item() for o in out)), int(sum(o[1].item() for o in out))
+
+    def step(want_rows=False):
+        rows, st = gi.search_resident(qb, want_rows=want_rows)
+        if world > 1:
+            # row payload all-gather (variable length): sizes then padded bytes
+            payload = torch.zeros(max(1, st["rows"]) * 96, dtype=torch.uint8, device="cuda")
+            sizes = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(world)]
+            dist.all_gather(sizes, torch.tensor([payload.numel()], dtype=torch.int64, device="cuda"))
+            mx = int(max(s.item() for s in sizes))
+            pad = torch.zeros(mx, dtype=torch.uint8, device="cuda")
+            pad[:payload.numel()] = payload
+            bufs = [torch.zeros(mx, dtype=torch.uint8, device="cuda") for _ in range(world)]
+            dist.all_gather(bufs, pad)
+        return st
+
+    for _ in range(args.warmup):
+        step()
+    gi.profile(True)
+    gi.profile_reset()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    stats = None
+    for _ in range(args.steps):
+        stats = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.time() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    prof = gi.profile_get()
+    gi.profile(False)
+    rows_total, aligned_total = gather_rows(stats["rows"], stats["aligned_bases"])
+
+    nq_total = len(queries)
+    value = nq_total * args.steps / dt
+    result = None
+    if rank == 0:
+        kern = [p for p in prof if p["name"].startswith("k_")]
+        kern.sort(key=lambda p: -p["total_ms"])
+        dom = kern[0] if kern else None
+        kernels = []
+        for p in kern:
+            avg_ms = p["total_ms"] / max(p["launches"], 1)
+            gbs = (p["bytes"] / max(p["launches"], 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            kernels.append(dict(name=p["name"], launches=p["launches"], avg_ms=round(avg_ms, 4),
+                                algorithmic_bytes_per_launch=int(p["bytes"] / max(p["launches"], 1)),
+                                achieved_GBs=round(gbs, 3), frac_of_hbm_peak=round(gbs / HBM_PEAK_GBS, 6)))
+        roofline = None
+        if dom:
+            avg_ms = dom["total_ms"] / max(dom["launches"], 1)
+            ach = (dom["bytes"] / max(dom["launches"], 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            roofline = dict(bound="hbm", kernel=dom["name"], achieved=round(ach, 3), peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=round(ach / HBM_PEAK_GBS, 6), traffic=None,
+                            avg_launch_ms=round(avg_ms, 4), launches=dom["launches"])
+        go = shutil.which("go")
+        result = {
+            "metric": "queries/sec (lexicmap search hot path, seed index HBM-resident)",
+            "value": round(value, 3), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong" if args.shard == "queries" or world == 1 else "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "gbp_aligned_per_s": round(aligned_total * args.steps / dt / 1e9 * (1 if world == 1 else 1), 6),
+            "config": {"workload": "%s: %d gene queries (%d-%d bp, <=10%% divergence) vs %d synthetic genomes x %d bp "
+                                   "(%d families), M=%d masks, k=%d, index %s" %
+                                   (args.workload, nq_total, wl["qlen"][0], wl["qlen"][1], wl["genomes"], wl["genome_len"],
+                                    wl["families"], info["masks"], info["k"],
+                                    "GPU-built in HBM" if gpu_built else "oracle-built, loaded from the reference format"),
+                       "seeds_resident": info["seeds"], "index_hbm_bytes": info["hbm_bytes"], "parallelism":
+                           ("q-shard x%d (index replicated)" % world) if args.shard == "queries" else ("index-shard x%d" % world),
+                       "go_toolchain": go or "absent (reference Go binary cannot be built; CPU baseline is the C port)"},
+            "stage_ms": {k: round(v, 3) for k, v in stats.items() if k.startswith("ms_")},
+            "work": {k: v for k, v in stats.items() if not k.startswith("ms_")},
+            "rows": rows_total,
+            "roofline": roofline,
+            "kernels": kernels,
+        }
+    gi.free_batch(qb)
+    # CPU baseline on rank 0, N=1 only
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and index_dir:
+        try:
+            ncores = os.cpu_count() or 1
+            result["cpu_baseline"] = cpu_baseline(index_dir, queries, args.cpu_seconds, ncores)
+        except Exception as e:  # the baseline must not kill the bench line
+            result["cpu_baseline"] = dict(value=None, unit="queries/s", cores=0, kind="port", sample="failed: %r" % (e,))
+    gi.close()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

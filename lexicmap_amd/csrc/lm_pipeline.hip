@@ -137,6 +137,12 @@ struct Prof {
     }
 };
 
+static void prof_add_bytes(lm_index *ix, const char *name, int64_t bytes) {
+    if (!ix->prof) return;
+    for (auto &e : ix->prof_entries)
+        if (e.name == name) e.bytes += bytes;
+}
+
 static void prof_resolve(lm_index *ix) {
     for (auto &p : ix->pending) {
         (void)hipEventSynchronize(p.b);
@@ -394,6 +400,12 @@ static void stage_lookup(Work &w, lm_stage_stats &stats) {
     sync(ix);
     stats.seed_lookups += n;
     stats.seed_values += (int64_t)hv;
+    {   // algorithmic bytes of the lookup: per probe one mask-offset entry + ceil(log2 S) 8-byte k-mer
+        // probes of the binary search, plus 16 B (k-mer + value) per returned seed
+        double avg_list = (double)ix->host.mask_off.back() / std::max(1, ix->host.M);
+        int64_t probes = (int64_t)std::ceil(std::log2(avg_list + 2.0));
+        prof_add_bytes(ix, "k_lookup_count", n * (8 + 8 * probes) + 16 * (int64_t)hv);
+    }
     stats.anchors_raw += T;
     w.n_anchors = T;
     w.nseg = 0;
