@@ -935,8 +935,161 @@ LM_HD void lm_wf_trim(int32_t *hdr, const int32_t *arena, int comp, int s, int p
     h[1] = hi;
 }
 
-// ops: output buffer of packed (op<<32|n) runs, capacity ops_cap; built backwards from the end of the buffer and
-// then moved to the front.
+// Backtrace (WFA2 wavefront_backtrace_affine) + statistics over the stored wavefronts; `s` = final score.
+// ops: output buffer of packed (op<<32|n) runs, capacity ops_cap; built backwards from the end of the buffer and then
+// moved to the front.
+LM_HDN void lm_wfa_backtrace(const int32_t *hdr, const int32_t *arena, int s, int plen, int tlen, uint64_t *ops,
+                             int ops_cap, LmWfaOut *out) {
+    const int X = 4, OE = 8, E = 2;
+    const int ak = tlen - plen;
+    out->status = 0;
+    out->nops = 0;
+    out->qbegin = out->qend = out->tbegin = out->tend = 0;
+    out->align_len = out->matches = out->gaps = out->gap_regions = 0;
+    out->score = s;
+    int wp = ops_cap; // next write slot is wp-1
+    char cur_op = 0;
+    uint32_t cur_n = 0;
+    bool overflow = false;
+#define LM_PUSH(OP, N)                                                     \
+    do {                                                                   \
+        int _n = (N);                                                      \
+        if (_n > 0) {                                                      \
+            if (cur_op == (OP)) {                                          \
+                cur_n += (uint32_t)_n;                                     \
+            } else {                                                       \
+                if (cur_n) {                                               \
+                    if (wp <= 0) overflow = true;                          \
+                    else ops[--wp] = ((uint64_t)(uint8_t)cur_op << 32) | cur_n; \
+                }                                                          \
+                cur_op = (OP);                                             \
+                cur_n = (uint32_t)_n;                                      \
+            }                                                              \
+        }                                                                  \
+    } while (0)
+    int score = s, k = ak;
+    int32_t offset = tlen;
+    int v = offset - k, h = offset;
+    int matrix = 0;
+    const int64_t NEG = (int64_t)LM_NULL_OFF * 16;
+    while (v > 0 && h > 0 && score > 0) {
+        int s_mis = score - X, s_open = score - OE, s_ext = score - E;
+        int64_t c_mis = NEG, c_io = NEG, c_ie = NEG, c_do = NEG, c_de = NEG;
+        if (matrix == 0) {
+            int64_t o;
+            o = (int64_t)lm_wf_get(hdr, arena, LM_WF_M, s_mis, k) + 1;
+            if (o >= 0) c_mis = (o << 4) | 9;
+            o = (int64_t)lm_wf_get(hdr, arena, LM_WF_M, s_open, k - 1) + 1;
+            if (o >= 0) c_io = (o << 4) | 1;
+            o = (int64_t)lm_wf_get(hdr, arena, LM_WF_M, s_open, k + 1);
+            if (o >= 0) c_do = (o << 4) | 3;
+            o = (int64_t)lm_wf_get(hdr, arena, LM_WF_I, s_ext, k - 1) + 1;
+            if (o >= 0) c_ie = (o << 4) | 2;
+            o = (int64_t)lm_wf_get(hdr, arena, LM_WF_D, s_ext, k + 1);
+            if (o >= 0) c_de = (o << 4) | 4;
+        } else if (matrix == 1) {
+            int64_t o;
+            o = (int64_t)lm_wf_get(hdr, arena, LM_WF_M, s_open, k - 1) + 1;
+            if (o >= 0) c_io = (o << 4) | 1;
+            o = (int64_t)lm_wf_get(hdr, arena, LM_WF_I, s_ext, k - 1) + 1;
+            if (o >= 0) c_ie = (o << 4) | 2;
+        } else {
+            int64_t o;
+            o = (int64_t)lm_wf_get(hdr, arena, LM_WF_M, s_open, k + 1);
+            if (o >= 0) c_do = (o << 4) | 3;
+            o = (int64_t)lm_wf_get(hdr, arena, LM_WF_D, s_ext, k + 1);
+            if (o >= 0) c_de = (o << 4) | 4;
+        }
+        int64_t mx = c_mis;
+        if (c_io > mx) mx = c_io;
+        if (c_ie > mx) mx = c_ie;
+        if (c_do > mx) mx = c_do;
+        if (c_de > mx) mx = c_de;
+        if (mx < 0) break;
+        if (matrix == 0) {
+            int32_t max_off = (int32_t)(mx >> 4);
+            LM_PUSH('M', offset - max_off);
+            offset = max_off;
+            v = offset - k;
+            h = offset;
+            if (v <= 0 || h <= 0) break;
+        }
+        int bt = (int)(mx & 15);
+        if (bt == 9) {
+            score = s_mis; matrix = 0; LM_PUSH('X', 1); --offset;
+        } else if (bt == 1) {
+            score = s_open; matrix = 0; LM_PUSH('I', 1); --k; --offset;
+        } else if (bt == 2) {
+            score = s_ext; matrix = 1; LM_PUSH('I', 1); --k; --offset;
+        } else if (bt == 3) {
+            score = s_open; matrix = 0; LM_PUSH('D', 1); ++k;
+        } else {
+            score = s_ext; matrix = 2; LM_PUSH('D', 1); ++k;
+        }
+        v = offset - k;
+        h = offset;
+    }
+    if (v > 0 && h > 0) {
+        int nm = v < h ? v : h;
+        LM_PUSH('M', nm);
+        v -= nm;
+        h -= nm;
+    }
+    if (v > 0) LM_PUSH('D', v);
+    if (h > 0) LM_PUSH('I', h);
+    if (cur_n) {
+        if (wp <= 0) overflow = true;
+        else ops[--wp] = ((uint64_t)(uint8_t)cur_op << 32) | cur_n;
+    }
+#undef LM_PUSH
+    if (overflow) {
+        out->status = 1;
+        return;
+    }
+    int nops = ops_cap - wp;
+    for (int i = 0; i < nops; i++) ops[i] = ops[wp + i];
+    out->nops = nops;
+    int first = -1, last = -1;
+    for (int i = 0; i < nops; i++)
+        if ((ops[i] >> 32) == 'M') {
+            if (first < 0) first = i;
+            last = i;
+        }
+    if (first < 0) {
+        out->status = 2;
+        return;
+    }
+    int qpos = 0, tpos = 0;
+    for (int i = 0; i < nops; i++) {
+        char op = (char)(ops[i] >> 32);
+        int nn = (int)(ops[i] & 0xffffffffu);
+        if (i == first) {
+            out->qbegin = qpos + 1;
+            out->tbegin = tpos + 1;
+        }
+        if (op == 'M' || op == 'X') {
+            qpos += nn;
+            tpos += nn;
+        } else if (op == 'I') {
+            tpos += nn;
+        } else {
+            qpos += nn;
+        }
+        if (i >= first && i <= last) {
+            out->align_len += (uint32_t)nn;
+            if (op == 'M') out->matches += (uint32_t)nn;
+            if (op == 'I' || op == 'D') {
+                out->gaps += (uint32_t)nn;
+                out->gap_regions++;
+            }
+        }
+        if (i == last) {
+            out->qend = qpos;
+            out->tend = tpos;
+        }
+    }
+}
+
 LM_HDN void lm_wfa_align(const uint8_t *q, int plen, const uint8_t *t, int tlen, int32_t *hdr, int max_score,
                          int32_t *arena, int64_t arena_cap, uint64_t *ops, int ops_cap, LmWfaOut *out) {
     const int X = 4, OE = 8, E = 2;
@@ -1110,147 +1263,6 @@ LM_HDN void lm_wfa_align(const uint8_t *q, int plen, const uint8_t *t, int tlen,
         lm_wf_trim(hdr, arena, LM_WF_I, s, plen, tlen, lo);
         lm_wf_trim(hdr, arena, LM_WF_D, s, plen, tlen, lo);
     }
-    out->score = s;
-    // ---- backtrace: write runs backwards from the end of ops[] ----
-    int wp = ops_cap; // next write slot is wp-1
-    char cur_op = 0;
-    uint32_t cur_n = 0;
-    bool overflow = false;
-#define LM_PUSH(OP, N)                                                     \
-    do {                                                                   \
-        int _n = (N);                                                      \
-        if (_n > 0) {                                                      \
-            if (cur_op == (OP)) {                                          \
-                cur_n += (uint32_t)_n;                                     \
-            } else {                                                       \
-                if (cur_n) {                                               \
-                    if (wp <= 0) overflow = true;                          \
-                    else ops[--wp] = ((uint64_t)(uint8_t)cur_op << 32) | cur_n; \
-                }                                                          \
-                cur_op = (OP);                                             \
-                cur_n = (uint32_t)_n;                                      \
-            }                                                              \
-        }                                                                  \
-    } while (0)
-    int score = s, k = ak;
-    int32_t offset = tlen;
-    int v = offset - k, h = offset;
-    int matrix = 0;
-    const int64_t NEG = (int64_t)LM_NULL_OFF * 16;
-    while (v > 0 && h > 0 && score > 0) {
-        int s_mis = score - X, s_open = score - OE, s_ext = score - E;
-        int64_t c_mis = NEG, c_io = NEG, c_ie = NEG, c_do = NEG, c_de = NEG;
-        if (matrix == 0) {
-            int64_t o;
-            o = (int64_t)lm_wf_get(hdr, arena, LM_WF_M, s_mis, k) + 1;
-            if (o >= 0) c_mis = (o << 4) | 9;
-            o = (int64_t)lm_wf_get(hdr, arena, LM_WF_M, s_open, k - 1) + 1;
-            if (o >= 0) c_io = (o << 4) | 1;
-            o = (int64_t)lm_wf_get(hdr, arena, LM_WF_M, s_open, k + 1);
-            if (o >= 0) c_do = (o << 4) | 3;
-            o = (int64_t)lm_wf_get(hdr, arena, LM_WF_I, s_ext, k - 1) + 1;
-            if (o >= 0) c_ie = (o << 4) | 2;
-            o = (int64_t)lm_wf_get(hdr, arena, LM_WF_D, s_ext, k + 1);
-            if (o >= 0) c_de = (o << 4) | 4;
-        } else if (matrix == 1) {
-            int64_t o;
-            o = (int64_t)lm_wf_get(hdr, arena, LM_WF_M, s_open, k - 1) + 1;
-            if (o >= 0) c_io = (o << 4) | 1;
-            o = (int64_t)lm_wf_get(hdr, arena, LM_WF_I, s_ext, k - 1) + 1;
-            if (o >= 0) c_ie = (o << 4) | 2;
-        } else {
-            int64_t o;
-            o = (int64_t)lm_wf_get(hdr, arena, LM_WF_M, s_open, k + 1);
-            if (o >= 0) c_do = (o << 4) | 3;
-            o = (int64_t)lm_wf_get(hdr, arena, LM_WF_D, s_ext, k + 1);
-            if (o >= 0) c_de = (o << 4) | 4;
-        }
-        int64_t mx = c_mis;
-        if (c_io > mx) mx = c_io;
-        if (c_ie > mx) mx = c_ie;
-        if (c_do > mx) mx = c_do;
-        if (c_de > mx) mx = c_de;
-        if (mx < 0) break;
-        if (matrix == 0) {
-            int32_t max_off = (int32_t)(mx >> 4);
-            LM_PUSH('M', offset - max_off);
-            offset = max_off;
-            v = offset - k;
-            h = offset;
-            if (v <= 0 || h <= 0) break;
-        }
-        int bt = (int)(mx & 15);
-        if (bt == 9) {
-            score = s_mis; matrix = 0; LM_PUSH('X', 1); --offset;
-        } else if (bt == 1) {
-            score = s_open; matrix = 0; LM_PUSH('I', 1); --k; --offset;
-        } else if (bt == 2) {
-            score = s_ext; matrix = 1; LM_PUSH('I', 1); --k; --offset;
-        } else if (bt == 3) {
-            score = s_open; matrix = 0; LM_PUSH('D', 1); ++k;
-        } else {
-            score = s_ext; matrix = 2; LM_PUSH('D', 1); ++k;
-        }
-        v = offset - k;
-        h = offset;
-    }
-    if (v > 0 && h > 0) {
-        int nm = v < h ? v : h;
-        LM_PUSH('M', nm);
-        v -= nm;
-        h -= nm;
-    }
-    if (v > 0) LM_PUSH('D', v);
-    if (h > 0) LM_PUSH('I', h);
-    if (cur_n) {
-        if (wp <= 0) overflow = true;
-        else ops[--wp] = ((uint64_t)(uint8_t)cur_op << 32) | cur_n;
-    }
-#undef LM_PUSH
-    if (overflow) {
-        out->status = 1;
-        return;
-    }
-    int nops = ops_cap - wp;
-    for (int i = 0; i < nops; i++) ops[i] = ops[wp + i];
-    out->nops = nops;
-    int first = -1, last = -1;
-    for (int i = 0; i < nops; i++)
-        if ((ops[i] >> 32) == 'M') {
-            if (first < 0) first = i;
-            last = i;
-        }
-    if (first < 0) {
-        out->status = 2;
-        return;
-    }
-    int qpos = 0, tpos = 0;
-    for (int i = 0; i < nops; i++) {
-        char op = (char)(ops[i] >> 32);
-        int nn = (int)(ops[i] & 0xffffffffu);
-        if (i == first) {
-            out->qbegin = qpos + 1;
-            out->tbegin = tpos + 1;
-        }
-        if (op == 'M' || op == 'X') {
-            qpos += nn;
-            tpos += nn;
-        } else if (op == 'I') {
-            tpos += nn;
-        } else {
-            qpos += nn;
-        }
-        if (i >= first && i <= last) {
-            out->align_len += (uint32_t)nn;
-            if (op == 'M') out->matches += (uint32_t)nn;
-            if (op == 'I' || op == 'D') {
-                out->gaps += (uint32_t)nn;
-                out->gap_regions++;
-            }
-        }
-        if (i == last) {
-            out->qend = qpos;
-            out->tend = tpos;
-        }
-    }
+    lm_wfa_backtrace(hdr, arena, s, plen, tlen, ops, ops_cap, out);
 }
+

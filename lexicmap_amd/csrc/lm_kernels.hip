@@ -607,6 +607,271 @@ __global__ void k_wfa(const WfaIn *__restrict__ in, int64_t n, const int32_t *__
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Wave-cooperative WFA: one wavefront (64 lanes) per alignment; lanes own diagonals k = lo + lane (+64 j).
+// Same recurrence, trimming, wf-adaptive cut-off and storage layout as lm_wfa_align (lm_algos.h), which is the
+// CPU-checked statement of the device logic; the backtrace is the shared lm_wfa_backtrace run by lane 0.
+__device__ __forceinline__ int wave_min_i32(int v) {
+    for (int o = 32; o > 0; o >>= 1) {
+        int x = __shfl_xor(v, o, 64);
+        v = x < v ? x : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int32_t wf_val(const int32_t *arena, int lo, int hi, int base, int k) {
+    return (k < lo || k > hi) ? LM_NULL_OFF : arena[base + (k - lo)];
+}
+
+__device__ __forceinline__ int wf_dist(int32_t off, int k, int plen, int tlen) {
+    if (off < 0) return 1073741824;
+    int lv = plen - (off - k), lh = tlen - off;
+    return lv > lh ? lv : lh;
+}
+
+// first k in [a, b) (ascending) with pred, else b.  All lanes must call; result uniform.
+template <typename F> __device__ __forceinline__ int wave_find_first(int a, int b, int lane, F pred) {
+    for (int c = a; c < b; c += 64) {
+        int k = c + lane;
+        bool p = k < b && pred(k);
+        unsigned long long m = __ballot(p);
+        if (m) return c + (int)__ffsll((long long)m) - 1;
+    }
+    return b;
+}
+// last k in (b, a] (descending from a) with pred, else b.
+template <typename F> __device__ __forceinline__ int wave_find_last(int a, int b, int lane, F pred) {
+    for (int c = a; c > b; c -= 64) {
+        int k = c - lane;
+        bool p = k > b && pred(k);
+        unsigned long long m = __ballot(p);
+        if (m) return c - ((int)__ffsll((long long)m) - 1);
+    }
+    return b;
+}
+
+__device__ __forceinline__ void wave_trim(int32_t *h, const int32_t *arena, int alo, int plen, int tlen, int lane) {
+    // h = {lo, hi, base} freshly computed over [lo,hi] with base addressing alo==lo
+    int lo = h[0], hi = h[1], base = h[2];
+    auto valid = [&](int k) {
+        int32_t off = arena[base + (k - alo)];
+        return (uint32_t)off <= (uint32_t)tlen && (uint32_t)(off - k) <= (uint32_t)plen;
+    };
+    int nhi = wave_find_last(hi, lo - 1, lane, valid);     // lo-1 when nothing is valid
+    int nlo = wave_find_first(lo, nhi + 1, lane, valid);   // == nhi+1 when empty
+    if (nhi < lo) nlo = lo;                                  // sequential code leaves lo untouched in that case
+    __syncthreads();
+    if (lane == 0) {
+        h[2] = base + (nlo - alo);
+        h[0] = nlo;
+        h[1] = nhi;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_wfa_wave(const WfaIn *__restrict__ in, int64_t n, const int32_t *__restrict__ todo,
+                                                  int64_t ntodo, int32_t *__restrict__ hdr_pool,
+                                                  int32_t *__restrict__ arena_pool, uint64_t *__restrict__ ops_pool,
+                                                  WfaOut *__restrict__ out) {
+    const int lane = threadIdx.x;
+    const int X = 4, OE = 8, E = 2;
+    for (int64_t x = blockIdx.x; x < ntodo; x += gridDim.x) {
+        int64_t i = todo ? todo[x] : x;
+        if (i >= n) continue;
+        const WfaIn w = in[i];
+        const uint8_t *__restrict__ q = w.q;
+        const uint8_t *__restrict__ t = w.t;
+        const int plen = w.qlen, tlen = w.tlen;
+        int32_t *hdr = hdr_pool + w.hdr_off;
+        int32_t *arena = arena_pool + w.arena_off;
+        const int64_t arena_cap = w.arena_cap;
+        const int max_score = w.max_score;
+        const int ak = tlen - plen;
+        int status = 0;
+        int64_t used = 1;
+        __syncthreads();
+        if (max_score < 1 || arena_cap < 1) {
+            status = 1;
+        } else if (lane == 0) {
+            hdr[0] = 0; hdr[1] = 0; hdr[2] = 0;
+            hdr[3] = 1; hdr[4] = -1; hdr[5] = 0;
+            hdr[6] = 1; hdr[7] = -1; hdr[8] = 0;
+            arena[0] = 0;
+        }
+        int s = 0;
+        while (status == 0) {
+            __syncthreads();
+            int32_t *hm = hdr + s * 9;
+            int mlo = hm[0], mhi = hm[1], mbase = hm[2];
+            if (mlo <= mhi) {
+                // ---- extend along each diagonal (8 bases per compare) ----
+                for (int k = mlo + lane; k <= mhi; k += 64) {
+                    int32_t off = arena[mbase + (k - mlo)];
+                    if (off < 0) continue;
+                    int v = off - k, h = off;
+                    while (v + 8 <= plen && h + 8 <= tlen) {
+                        uint64_t a, b;
+                        __builtin_memcpy(&a, q + v, 8);
+                        __builtin_memcpy(&b, t + h, 8);
+                        uint64_t d = a ^ b;
+                        if (d) {
+                            int nb = __builtin_ctzll(d) >> 3;
+                            v += nb;
+                            h += nb;
+                            goto extended;
+                        }
+                        v += 8;
+                        h += 8;
+                    }
+                    while (v < plen && h < tlen && q[v] == t[h]) {
+                        v++;
+                        h++;
+                    }
+                extended:
+                    arena[mbase + (k - mlo)] = h;
+                }
+                __syncthreads();
+                if (mlo <= ak && ak <= mhi && arena[mbase + (ak - mlo)] >= tlen) break;
+                // ---- wf-adaptive cut-off (min wavefront length 10, max distance diff 50) ----
+                int nlo = mlo, nhi = mhi;
+                if (mhi - mlo + 1 >= 10) {
+                    int dmin = 2147483647;
+                    for (int k = mlo + lane; k <= mhi; k += 64) {
+                        int d = wf_dist(arena[mbase + (k - mlo)], k, plen, tlen);
+                        dmin = d < dmin ? d : dmin;
+                    }
+                    dmin = wave_min_i32(dmin);
+                    auto keep = [&](int k) { return wf_dist(arena[mbase + (k - mlo)], k, plen, tlen) - dmin <= 50; };
+                    int top = ak < mhi ? ak : mhi;
+                    if (mlo < top) nlo = wave_find_first(mlo, top, lane, keep);
+                    int bottom = ak > nlo ? ak : nlo;
+                    if (mhi > bottom) nhi = wave_find_last(mhi, bottom, lane, keep);
+                }
+                __syncthreads();
+                if (lane == 0) {
+                    hm[2] = mbase + (nlo - mlo);
+                    hm[0] = nlo;
+                    hm[1] = nhi;
+                    for (int c = 1; c <= 2; c++) {
+                        int32_t *hc = hm + c * 3;
+                        if (hc[0] > hc[1]) continue;
+                        if (nlo > hc[0]) {
+                            hc[2] += nlo - hc[0];
+                            hc[0] = nlo;
+                        }
+                        if (nhi < hc[1]) hc[1] = nhi;
+                    }
+                }
+            }
+            s++;
+            if (s >= max_score) {
+                status = 1;
+                break;
+            }
+            __syncthreads();
+            // ---- compute wavefronts of score s ----
+            int32_t *ho = hdr + s * 9;
+            int mm_lo = 1, mm_hi = -1, mm_b = 0, mo_lo = 1, mo_hi = -1, mo_b = 0, ie_lo = 1, ie_hi = -1, ie_b = 0, de_lo = 1,
+                de_hi = -1, de_b = 0;
+            if (s - X >= 0) {
+                const int32_t *h = hdr + (s - X) * 9;
+                mm_lo = h[0]; mm_hi = h[1]; mm_b = h[2];
+            }
+            if (s - OE >= 0) {
+                const int32_t *h = hdr + (s - OE) * 9;
+                mo_lo = h[0]; mo_hi = h[1]; mo_b = h[2];
+            }
+            if (s - E >= 0) {
+                const int32_t *h = hdr + (s - E) * 9;
+                ie_lo = h[3]; ie_hi = h[4]; ie_b = h[5];
+                de_lo = h[6]; de_hi = h[7]; de_b = h[8];
+            }
+            int lo = 2147483647, hi = -2147483647;
+            bool any = false;
+            if (mm_lo <= mm_hi) { any = true; lo = mm_lo < lo ? mm_lo : lo; hi = mm_hi > hi ? mm_hi : hi; }
+            if (mo_lo <= mo_hi) { any = true; lo = mo_lo - 1 < lo ? mo_lo - 1 : lo; hi = mo_hi + 1 > hi ? mo_hi + 1 : hi; }
+            if (ie_lo <= ie_hi) { any = true; lo = ie_lo + 1 < lo ? ie_lo + 1 : lo; hi = ie_hi + 1 > hi ? ie_hi + 1 : hi; }
+            if (de_lo <= de_hi) { any = true; lo = de_lo - 1 < lo ? de_lo - 1 : lo; hi = de_hi - 1 > hi ? de_hi - 1 : hi; }
+            if (!any || lo > hi) {
+                if (lane == 0) {
+                    ho[0] = 1; ho[1] = -1; ho[2] = 0;
+                    ho[3] = 1; ho[4] = -1; ho[5] = 0;
+                    ho[6] = 1; ho[7] = -1; ho[8] = 0;
+                }
+                continue;
+            }
+            int wd = hi - lo + 1;
+            if (used + 3ll * wd > arena_cap) {
+                status = 1;
+                break;
+            }
+            int bm = (int)used, bi = (int)(used + wd), bd = (int)(used + 2ll * wd);
+            used += 3ll * wd;
+            for (int k = lo + lane; k <= hi; k += 64) {
+                int32_t a = wf_val(arena, mo_lo, mo_hi, mo_b, k - 1), b = wf_val(arena, ie_lo, ie_hi, ie_b, k - 1);
+                int32_t ins = (a > b ? a : b) + 1;
+                a = wf_val(arena, mo_lo, mo_hi, mo_b, k + 1);
+                b = wf_val(arena, de_lo, de_hi, de_b, k + 1);
+                int32_t del = a > b ? a : b;
+                int32_t mis = wf_val(arena, mm_lo, mm_hi, mm_b, k) + 1;
+                int32_t mx = mis > ins ? mis : ins;
+                if (del > mx) mx = del;
+                uint32_t hh = (uint32_t)mx, vv = (uint32_t)(mx - k);
+                if (hh > (uint32_t)tlen) mx = LM_NULL_OFF;
+                if (vv > (uint32_t)plen) mx = LM_NULL_OFF;
+                arena[bi + (k - lo)] = ins;
+                arena[bd + (k - lo)] = del;
+                arena[bm + (k - lo)] = mx;
+            }
+            if (lane == 0) {
+                ho[0] = lo; ho[1] = hi; ho[2] = bm;
+                ho[3] = lo; ho[4] = hi; ho[5] = bi;
+                ho[6] = lo; ho[7] = hi; ho[8] = bd;
+            }
+            __syncthreads();
+            wave_trim(ho + 0, arena, lo, plen, tlen, lane);
+            wave_trim(ho + 3, arena, lo, plen, tlen, lane);
+            wave_trim(ho + 6, arena, lo, plen, tlen, lane);
+        }
+        __syncthreads();
+        if (lane == 0) {
+            WfaOut o;
+            o.blast_score = 0;
+            if (status != 0) {
+                o.r.status = 1;
+                o.r.score = 0;
+                o.r.nops = 0;
+                o.r.qbegin = o.r.qend = o.r.tbegin = o.r.tend = 0;
+                o.r.align_len = o.r.matches = o.r.gaps = o.r.gap_regions = 0;
+            } else {
+                uint64_t *ops = ops_pool + w.ops_off;
+                lm_wfa_backtrace(hdr, arena, s, plen, tlen, ops, w.ops_cap, &o.r);
+                if (o.r.status == 0) {
+                    int first = -1, last = -1;
+                    for (int j = 0; j < o.r.nops; j++)
+                        if ((ops[j] >> 32) == 'M') {
+                            if (first < 0) first = j;
+                            last = j;
+                        }
+                    int score = 0;
+                    for (int j = first; j >= 0 && j <= last; j++) {
+                        int nn = (int)(ops[j] & 0xffffffffu);
+                        char op = (char)(ops[j] >> 32);
+                        if (op == 'M')
+                            score += nn * 2;
+                        else if (op == 'X')
+                            score += nn * -3;
+                        else
+                            score -= 5 + nn * 2;
+                    }
+                    o.blast_score = score;
+                }
+            }
+            out[i] = o;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // host-callable launchers
 static inline int grid_for(int64_t n, int block, int maxb = 2048 * 8) {
@@ -707,6 +972,12 @@ void launch_extend(hipStream_t st, const HspIn *hsps, int64_t n, const uint8_t *
 }
 void launch_wfa(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int32_t *hdr_pool,
                 int32_t *arena_pool, uint64_t *ops_pool, WfaOut *out) {
+    // one wavefront per alignment; enough workgroups to fill 256 CUs x 32 waves
+    int g = (int)(ntodo < 1 ? 1 : (ntodo > 65536 ? 65536 : ntodo));
+    hipLaunchKernelGGL(k_wfa_wave, dim3(g), dim3(64), 0, st, in, n, todo, ntodo, hdr_pool, arena_pool, ops_pool, out);
+}
+void launch_wfa_lane(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int32_t *hdr_pool,
+                     int32_t *arena_pool, uint64_t *ops_pool, WfaOut *out) {
     hipLaunchKernelGGL(k_wfa, dim3(grid_for(ntodo, 64)), dim3(64), 0, st, in, n, todo, ntodo, hdr_pool, arena_pool, ops_pool,
                        out);
 }

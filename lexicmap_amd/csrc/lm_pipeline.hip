@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <stdexcept>
 #include <tuple>
 #include <string>
@@ -75,7 +76,15 @@ struct ProfEntry {
 
 using namespace lm;
 
+namespace lm {
+struct Work;
+struct AlignCtx;
+} // namespace lm
+
 struct lm_index {
+    lm::Work *work = nullptr;       // device scratch reused across calls (grow-only)
+    lm::AlignCtx *actx = nullptr;
+    std::mutex mu;                  // one in-flight call per handle
     HostIndex host;
     lm_options opt;
     int device = 0;
@@ -305,6 +314,12 @@ struct Work {
     DBuf<Task> tasks;
     int64_t ntasks = 0;
     explicit Work(lm_index *i, lm_qbatch *q) : ix(i), qb(q) {}
+    void rebind(lm_qbatch *q) {
+        qb = q;
+        n_anchors = 0;
+        nseg = 0;
+        ntasks = 0;
+    }
 };
 
 static void stage_kmers(Work &w) {
@@ -818,6 +833,8 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
 void lm_index_close(lm_index *ix) {
     if (!ix) return;
     prof_resolve(ix);
+    delete ix->work;
+    delete ix->actx;
     if (ix->st) (void)hipStreamDestroy(ix->st);
     delete ix;
 }
@@ -1032,7 +1049,7 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
     std::vector<int32_t> todo(n);
     for (int64_t i = 0; i < n; i++) todo[i] = (int32_t)i;
     std::vector<int32_t> level(n, 0);
-    const int64_t budget = (int64_t)6 << 30; // bytes of scratch per launch
+    const int64_t budget = (int64_t)32 << 30; // bytes of scratch per launch
     a.wfa_out.ensure((size_t)n);
     std::vector<std::vector<uint64_t>> ops_keep(want_ops ? n : 0);
     while (!todo.empty()) {
@@ -1044,10 +1061,11 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
             int32_t i = todo[taken];
             WfaIn &w = in[i];
             int64_t L = (int64_t)w.qlen + w.tlen;
-            int64_t ms = (64 + L / 8) << (2 * level[i]);
+            // first guess covers ~15% divergence; every retry quadruples the scratch
+            int64_t ms = (96 + L / 3) << (2 * level[i]);
             if (ms > 8 * L + 64) ms = 8 * L + 64; // a global alignment never exceeds this penalty
-            int64_t ar = std::max<int64_t>(4096, ms * 96) << level[i];
-            int64_t oc = std::min<int64_t>(L + 2, (64 + L / 8) << (2 * level[i]));
+            int64_t ar = std::max<int64_t>(4096, ms * 420) << (2 * level[i]);
+            int64_t oc = std::min<int64_t>(L + 2, (128 + L / 4) << (2 * level[i]));
             int64_t need = (ms * 9 + ar) * 4 + oc * 8;
             if (!cur.empty() && (hdr_tot * 9 + arena_tot) * 4 + ops_tot * 8 + need > budget) break;
             w.max_score = (int32_t)std::min<int64_t>(ms, 2000000000);
@@ -1172,14 +1190,30 @@ static void fmt_alignment(const std::vector<uint64_t> &ops, const uint8_t *q, co
     }
 }
 
+static Work &get_work(lm_index *ix, lm_qbatch *qb) {
+    if (!ix->work) ix->work = new Work(ix, qb);
+    ix->work->rebind(qb);
+    return *ix->work;
+}
+static AlignCtx &get_actx(lm_index *ix, lm_qbatch *qb, Work *w, lm_stage_stats *st) {
+    if (!ix->actx) ix->actx = new AlignCtx();
+    AlignCtx &a = *ix->actx;
+    a.ix = ix;
+    a.qb = qb;
+    a.w = w;
+    a.stats = st;
+    return a;
+}
+
 static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
+    std::lock_guard<std::mutex> lock(ix->mu);
     lm_stage_stats &st = res->stats;
     memset(&st, 0, sizeof st);
     HIPCHK(hipSetDevice(ix->device));
     double t0 = now_ms(), t1;
     st.query_bases = qb->total_len;
     st.query_kmers = 2 * qb->total_pos;
-    Work w(ix, qb);
+    Work &w = get_work(ix, qb);
     stage_kmers(w);
     stage_mask(w);
     sync(ix);
@@ -1250,11 +1284,7 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
     t0 = t1;
 
     // ---- alignment in chunks of whole segments ----
-    AlignCtx a;
-    a.ix = ix;
-    a.qb = qb;
-    a.w = &w;
-    a.stats = &st;
+    AlignCtx &a = get_actx(ix, qb, &w, &st);
     const int64_t max_window_bytes = (int64_t)192 << 20;
     std::vector<HGenome> genomes; // in (query, genome) order
     const int K = ix->host.k;
