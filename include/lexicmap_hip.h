@@ -77,6 +77,25 @@ void lm_options_default(lm_options *opt);
  * masks.bin, seeds/chunk_*.bin(.idx), genomes/batch_NNNN/genomes.bin(.idx), genomes.map.bin and builds the HBM image on
  * HIP device `device`. */
 lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_index **out);
+/* Synthetic genome set + seed index generated directly in HBM (benchmark input; nothing in the reference corresponds to
+ * it — index building is out of the hot-path scope).  Genome g belongs to family g % families; genomes >= families are
+ * mutated copies (substitution rate U(0,max_div), indel shifts at a tenth of that) of the family ancestor.  Honors
+ * opt->shard_rank/shard_count.  See lexicmap_amd/csrc/lm_builder.hip for what is exact and what is simplified. */
+typedef struct lm_synth_spec {
+    int32_t k;            /* 31 */
+    int32_t masks;        /* 20000 (index.go:560) */
+    int64_t mask_seed;
+    int64_t genomes;      /* genomes in the whole set */
+    int32_t genome_len;   /* bases per genome (one contig) */
+    int32_t families;
+    double max_div;
+    int64_t seed;
+    int32_t max_desert;   /* 100 (index.go:582) */
+    int32_t seed_dist;    /* 50 (index.go:584) */
+} lm_synth_spec;
+lm_status lm_index_build_synthetic(const lm_synth_spec *spec, const lm_options *opt, int device, lm_index **out);
+/* bases [start, start+len) of local genome `local_genome` as ASCII (used to derive synthetic queries) */
+lm_status lm_index_fetch(lm_index *idx, int64_t local_genome, int64_t start, int64_t len, uint8_t *out);
 /* Replaces (*Index).Close (lib-index-search.go:760) */
 void lm_index_close(lm_index *idx);
 lm_status lm_index_get_info(const lm_index *idx, lm_index_info *info);

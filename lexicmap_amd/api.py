@@ -75,6 +75,12 @@ class Wfa(C.Structure):
                 ("gaps", C.c_uint32), ("gap_regions", C.c_uint32), ("ops_off", C.c_int64), ("nops", C.c_int32)]
 
 
+class SynthSpec(C.Structure):
+    _fields_ = [("k", C.c_int32), ("masks", C.c_int32), ("mask_seed", C.c_int64), ("genomes", C.c_int64),
+                ("genome_len", C.c_int32), ("families", C.c_int32), ("max_div", C.c_double), ("seed", C.c_int64),
+                ("max_desert", C.c_int32), ("seed_dist", C.c_int32)]
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char_p), ("launches", C.c_int64), ("total_ms", C.c_double), ("bytes", C.c_int64)]
 
@@ -129,6 +135,8 @@ def lib():
                                        C.POINTER(C.POINTER(C.c_int64)), C.POINTER(C.POINTER(Chain2))]
     L.lm_wfa_batch.argtypes = [vp, C.POINTER(Query), C.POINTER(Query), C.c_size_t, C.POINTER(vp),
                                C.POINTER(C.POINTER(Wfa)), C.POINTER(C.POINTER(C.c_uint64))]
+    L.lm_index_build_synthetic.argtypes = [C.POINTER(SynthSpec), C.POINTER(Options), C.c_int, C.POINTER(vp)]
+    L.lm_index_fetch.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64, C.c_char_p]
     L.lm_profile_enable.argtypes = [vp, C.c_int]
     L.lm_profile_reset.argtypes = [vp]
     L.lm_profile_get.argtypes = [vp, C.POINTER(C.POINTER(KernelTime))]
@@ -159,14 +167,36 @@ def default_options(**kw):
 class Index:
     """lm_index handle (replaces cmd.NewIndexSearcher / Index.Search / Index.Close of the reference)."""
 
-    def __init__(self, path, options=None, device=0):
+    def __init__(self, path, options=None, device=0, _handle=None):
         L = lib()
         self.opt = options or default_options()
+        if _handle is not None:
+            self.h = _handle
+            return
         h = C.c_void_p()
         st = L.lm_index_open(path.encode(), C.byref(self.opt), device, C.byref(h))
         if st != 0:
             raise RuntimeError("lm_index_open failed (%d): %s" % (st, L.lm_last_error(None).decode()))
         self.h = h
+
+    @classmethod
+    def synthetic(cls, genomes, genome_len, families, seed=1000, max_div=0.10, masks=20000, options=None, device=0):
+        """genomes + seed index generated directly in HBM by lm_index_build_synthetic (bench input)"""
+        L = lib()
+        opt = options or default_options()
+        sp = SynthSpec(31, masks, 1, genomes, genome_len, families, max_div, seed, 100, 50)
+        h = C.c_void_p()
+        st = L.lm_index_build_synthetic(C.byref(sp), C.byref(opt), device, C.byref(h))
+        if st != 0:
+            raise RuntimeError("lm_index_build_synthetic failed (%d): %s" % (st, L.lm_last_error(None).decode()))
+        return cls(None, opt, device, _handle=h)
+
+    def fetch(self, local_genome, start, length):
+        buf = C.create_string_buffer(length)
+        st = lib().lm_index_fetch(self.h, local_genome, start, length, buf)
+        if st != 0:
+            self._err(st)
+        return buf.raw
 
     def close(self):
         if self.h:

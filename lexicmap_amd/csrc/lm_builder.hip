@@ -1,0 +1,649 @@
+// lm_builder.hip — synthetic genome set + seed index generated directly in HBM (bench / large-scale test input).
+//
+// Index BUILDING is outside the hot-path scope; this exists because the benchmark configurations
+// (10k x 5 Mb genomes and up) cannot be built by any CPU tool on a fresh box within minutes, and nothing persists on
+// the GPU box.  What it produces has the same structure as a reference-built index (lib-index-build.go):
+//   * genomes: procedural i.i.d. ACGT ancestors per family; members are substituted (rate U(0,max_div)) and
+//     indel-shifted copies; single contig; stored 2-bit MSB-first like genome/genome.go:1471-1508
+//   * normal seeds: EXACT LexicHash capture per genome — for every mask the argmin of mask^kmer over both strands, all
+//     occurrences, low-complexity captures dropped (lib-index-build.go:1028-1046)
+//   * seed-desert filling: every gap >= max_desert between neighbouring seeds is filled every seed_dist bases with the
+//     nearest non-low-complexity k-mer (scan 25 up-, then 24 downstream, + strand before - strand), stored under the
+//     closest mask sharing its p-base prefix.  SIMPLIFICATION vs lib-index-build.go:1094-1407: the reference also
+//     requires the k-mer to be the capture of that mask within the +-1000 bp window.  Seed density and the
+//     prefix-structure of every mask's list are the same; which k-mer near a step is picked may differ.
+//   * reversed (suffix) seeds for every normal and desert seed (lib-index-build.go:776-890)
+//   * seed values batch:17|genome:17|pos:28|strand:1|reversed:1, per-mask arrays sorted by k-mer
+// The search kernels and the parity tests never depend on this file: parity uses indexes written in the reference's
+// on-disk format by the oracle's writer.
+#include <hipcub/hipcub.hpp>
+
+#include <cmath>
+#include <cstring>
+
+#include "lm_internal.h"
+
+namespace lm {
+
+static inline void bsync(lm_index *ix) {
+    hipError_t e = hipStreamSynchronize(ix->st);
+    if (e != hipSuccess) throw HipError(std::string("builder sync: ") + hipGetErrorString(e));
+}
+
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__host__ __device__ __forceinline__ uint64_t hash3(uint64_t a, uint64_t b, uint64_t c) {
+    return mix64(mix64(mix64(a) ^ b) ^ c);
+}
+
+struct SynthDev {
+    uint64_t seed;
+    int64_t genomes;  // whole set
+    int32_t genome_len, families;
+    double max_div;
+    int32_t shard_rank, shard_count;
+    int64_t nlocal;
+    int32_t nblk;     // 512-base blocks per genome
+    int64_t gbytes;   // padded bytes per genome
+};
+
+__device__ __forceinline__ int64_t global_genome(const SynthDev &sp, int64_t local) {
+    return sp.shard_count > 1 ? local * sp.shard_count + sp.shard_rank : local;
+}
+__device__ __forceinline__ double genome_div(const SynthDev &sp, int64_t g) {
+    if (g < sp.families) return 0.0;
+    return sp.max_div * ((double)(hash3(sp.seed, 0xD1Full, (uint64_t)g) >> 11) * (1.0 / 9007199254740992.0));
+}
+
+// cumulative indel shift per 512-base block
+__global__ void k_synth_shifts(SynthDev sp, int16_t *__restrict__ shifts) {
+    for (int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; l < sp.nlocal; l += (int64_t)gridDim.x * blockDim.x) {
+        int64_t g = global_genome(sp, l);
+        double d = genome_div(sp, g);
+        // indel events at a tenth of the substitution rate: 8 trials per block
+        uint32_t thr = (uint32_t)(fmin(1.0, d * 0.1 * 512.0 / 8.0) * 4294967295.0);
+        int sh = 0;
+        for (int b = 0; b < sp.nblk; b++) {
+            if (g >= sp.families) {
+                uint64_t h = hash3(sp.seed, 0x5117ull + (uint64_t)g, (uint64_t)b);
+                for (int t = 0; t < 8; t++) {
+                    uint64_t hh = mix64(h + t);
+                    if ((uint32_t)hh < thr) sh += (hh >> 63) ? 1 : -1;
+                }
+                if (sh > 30000) sh = 30000;
+                if (sh < -30000) sh = -30000;
+            }
+            shifts[l * sp.nblk + b] = (int16_t)sh;
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t synth_base(const SynthDev &sp, int64_t g, int64_t i, int sh, uint32_t sub_thr) {
+    uint64_t f = (uint64_t)(g % sp.families);
+    uint32_t anc = (uint32_t)(hash3(sp.seed, 0xA11Cull + f, (uint64_t)(i + sh)) >> 17) & 3u;
+    if (g >= sp.families) {
+        uint64_t h = hash3(sp.seed, 0x5B5ull + (uint64_t)g, (uint64_t)i);
+        if ((uint32_t)h < sub_thr) anc = (anc + 1u + (uint32_t)((h >> 40) % 3u)) & 3u;
+    }
+    return anc;
+}
+
+// one lane per packed byte (4 bases, first base in bits 7-6)
+__global__ void k_synth_genomes(SynthDev sp, const int16_t *__restrict__ shifts, uint8_t *__restrict__ gbits) {
+    int64_t nb = ((int64_t)sp.genome_len + 3) >> 2;
+    int64_t total = sp.nlocal * nb;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t l = t / nb, by = t % nb;
+        int64_t g = global_genome(sp, l);
+        uint32_t thr = (uint32_t)(genome_div(sp, g) * 4294967295.0);
+        uint32_t v = 0;
+        for (int j = 0; j < 4; j++) {
+            int64_t i = by * 4 + j;
+            uint32_t b = 0;
+            if (i < sp.genome_len) b = synth_base(sp, g, i, shifts[l * sp.nblk + (i >> 9)], thr);
+            v = (v << 2) | b;
+        }
+        gbits[l * sp.gbytes + by] = (uint8_t)v;
+    }
+}
+
+// 31-mer at base position pos of a packed genome (needs 16 readable bytes from pos>>2)
+__device__ __forceinline__ uint64_t packed_kmer(const uint8_t *gb, int64_t pos, int K) {
+    const uint8_t *p = gb + (pos >> 2);
+    uint64_t hi, lo;
+    __builtin_memcpy(&hi, p, 8);
+    __builtin_memcpy(&lo, p + 8, 8);
+    hi = __builtin_bswap64(hi);
+    lo = __builtin_bswap64(lo);
+    int s = (int)(pos & 3) << 1;
+    uint64_t x = s ? ((hi << s) | (lo >> (64 - s))) : hi;
+    return x >> (64 - (K << 1));
+}
+
+struct MaskTab {
+    const uint64_t *masks;
+    const int32_t *pfx_first;
+    int K, p, M;
+};
+
+// pass A: per genome of the chunk, argmin hash per mask
+__global__ void k_cap_argmin(SynthDev sp, MaskTab mt, const uint8_t *__restrict__ gbits, int64_t l0, int nchunk,
+                             unsigned long long *__restrict__ hashes) {
+    int64_t npos = (int64_t)sp.genome_len - mt.K + 1;
+    int64_t total = (int64_t)nchunk * npos;
+    int shift = (mt.K - mt.p) << 1;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        int c = (int)(t / npos);
+        int64_t pos = t % npos;
+        const uint8_t *gb = gbits + (l0 + c) * sp.gbytes;
+        uint64_t fwd = packed_kmer(gb, pos, mt.K);
+        uint64_t rc = lm_revcomp(fwd, mt.K);
+        unsigned long long *hs = hashes + (int64_t)c * mt.M;
+        for (int s = 0; s < 2; s++) {
+            uint64_t x = s ? rc : fwd;
+            uint64_t pf = x >> shift;
+            for (int j = mt.pfx_first[pf]; j < mt.pfx_first[pf + 1]; j++) {
+                unsigned long long h = mt.masks[j] ^ x;
+                if (h < hs[j]) atomicMin(&hs[j], h);
+            }
+        }
+    }
+}
+
+// pass B: emit every occurrence of every captured k-mer
+__global__ void k_cap_emit(SynthDev sp, MaskTab mt, const uint8_t *__restrict__ gbits, int64_t l0, int nchunk,
+                           const unsigned long long *__restrict__ hashes, uint16_t *__restrict__ s_mask,
+                           uint64_t *__restrict__ s_kmer, uint64_t *__restrict__ s_val, unsigned long long *__restrict__ counter,
+                           unsigned long long cap, uint64_t *__restrict__ pos_keys, unsigned long long *__restrict__ pos_counter,
+                           unsigned long long pos_cap) {
+    int64_t npos = (int64_t)sp.genome_len - mt.K + 1;
+    int64_t total = (int64_t)nchunk * npos;
+    int shift = (mt.K - mt.p) << 1;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        int c = (int)(t / npos);
+        int64_t pos = t % npos;
+        const uint8_t *gb = gbits + (l0 + c) * sp.gbytes;
+        uint64_t fwd = packed_kmer(gb, pos, mt.K);
+        uint64_t rc = lm_revcomp(fwd, mt.K);
+        const unsigned long long *hs = hashes + (int64_t)c * mt.M;
+        int64_t g = global_genome(sp, l0 + c);
+        uint64_t bg = ((uint64_t)(g / 5000) << 17) | (uint64_t)(g % 5000);
+        for (int s = 0; s < 2; s++) {
+            uint64_t x = s ? rc : fwd;
+            uint64_t pf = x >> shift;
+            bool lc_known = false, lc = false;
+            for (int j = mt.pfx_first[pf]; j < mt.pfx_first[pf + 1]; j++) {
+                if ((mt.masks[j] ^ x) != hs[j]) continue;
+                if (!lc_known) {
+                    lc = x == 0 || lm_low_complexity(x, mt.K);
+                    lc_known = true;
+                }
+                if (lc) continue;
+                unsigned long long o = atomicAdd(counter, 1ull);
+                if (o < cap) {
+                    s_mask[o] = (uint16_t)j;
+                    s_kmer[o] = x;
+                    s_val[o] = (bg << 30) | ((uint64_t)pos << 2) | ((uint64_t)s << 1);
+                }
+                unsigned long long po = atomicAdd(pos_counter, 1ull);
+                if (po < pos_cap) pos_keys[po] = ((uint64_t)c << 32) | ((uint64_t)pos << 1) | (uint64_t)s;
+            }
+        }
+    }
+}
+
+__global__ void k_pseudo_pos(int nchunk, int32_t last_pos, uint64_t *__restrict__ pos_keys, unsigned long long base) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < nchunk) pos_keys[base + c] = ((uint64_t)c << 32) | ((uint64_t)(uint32_t)last_pos << 1) | 1ull; // sorts last
+}
+
+__device__ __forceinline__ int closest_mask(const MaskTab &mt, uint64_t x) {
+    uint64_t pf = x >> ((mt.K - mt.p) << 1);
+    int minj = -1;
+    uint64_t minh = ~0ull;
+    for (int j = mt.pfx_first[pf]; j < mt.pfx_first[pf + 1]; j++) {
+        uint64_t h = mt.masks[j] ^ x;
+        if (h < minh) {
+            minh = h;
+            minj = j;
+        }
+    }
+    return minj;
+}
+
+// desert filling: one lane per neighbouring seed pair of a genome (sorted position keys)
+__global__ void k_desert_fill(SynthDev sp, MaskTab mt, const uint8_t *__restrict__ gbits, int64_t l0,
+                              const uint64_t *__restrict__ pos_keys, int64_t npk, int max_desert, int seed_dist,
+                              uint16_t *__restrict__ s_mask, uint64_t *__restrict__ s_kmer, uint64_t *__restrict__ s_val,
+                              unsigned long long *__restrict__ counter, unsigned long long cap) {
+    const int seed_pos_r = seed_dist / 2;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < npk; t += (int64_t)gridDim.x * blockDim.x) {
+        uint64_t key = pos_keys[t];
+        int c = (int)(key >> 32);
+        int64_t pos = (int64_t)((key & 0xffffffffu) >> 1);
+        int64_t pre = 0;
+        if (t > 0 && (int)(pos_keys[t - 1] >> 32) == c) pre = (int64_t)((pos_keys[t - 1] & 0xffffffffu) >> 1);
+        if (pos - pre < max_desert) continue;
+        const uint8_t *gb = gbits + (l0 + c) * sp.gbytes;
+        int64_t g = global_genome(sp, l0 + c);
+        uint64_t bg = ((uint64_t)(g / 5000) << 17) | (uint64_t)(g % 5000);
+        int64_t j = pre + seed_dist;
+        while (j < pos) {
+            int64_t start_dn = j + 1, end_up = j - seed_pos_r;
+            bool ok = false;
+            uint64_t kmer = 0;
+            int strand = 0;
+            int64_t at = j;
+            for (; at > end_up; at--) {
+                if (at < 0) continue;
+                uint64_t f = packed_kmer(gb, at, mt.K);
+                if (f != 0 && !lm_low_complexity(f, mt.K)) {
+                    kmer = f;
+                    strand = 0;
+                    ok = true;
+                    break;
+                }
+                uint64_t r = lm_revcomp(f, mt.K);
+                if (r != 0 && !lm_low_complexity(r, mt.K)) {
+                    kmer = r;
+                    strand = 1;
+                    ok = true;
+                    break;
+                }
+            }
+            if (!ok) {
+                if (start_dn >= pos) break;
+                int64_t end_dn = start_dn + seed_pos_r;
+                if (end_dn >= pos) end_dn = pos - 1;
+                for (at = start_dn; at < end_dn; at++) {
+                    uint64_t f = packed_kmer(gb, at, mt.K);
+                    if (f != 0 && !lm_low_complexity(f, mt.K)) {
+                        kmer = f;
+                        strand = 0;
+                        ok = true;
+                        break;
+                    }
+                    uint64_t r = lm_revcomp(f, mt.K);
+                    if (r != 0 && !lm_low_complexity(r, mt.K)) {
+                        kmer = r;
+                        strand = 1;
+                        ok = true;
+                        break;
+                    }
+                }
+            }
+            if (ok) {
+                int m = closest_mask(mt, kmer);
+                unsigned long long o = atomicAdd(counter, 1ull);
+                if (o < cap && m >= 0) {
+                    s_mask[o] = (uint16_t)m;
+                    s_kmer[o] = kmer;
+                    s_val[o] = (bg << 30) | ((uint64_t)at << 2) | ((uint64_t)strand << 1);
+                }
+            }
+            j = at + seed_dist;
+        }
+    }
+}
+
+// reversed copies of seeds [from, to)
+__global__ void k_reverse_seeds(MaskTab mt, unsigned long long from, unsigned long long to, uint16_t *__restrict__ s_mask,
+                                uint64_t *__restrict__ s_kmer, uint64_t *__restrict__ s_val,
+                                unsigned long long *__restrict__ counter, unsigned long long cap) {
+    for (unsigned long long t = from + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < to;
+         t += (unsigned long long)gridDim.x * blockDim.x) {
+        uint64_t rev = lm_reverse(s_kmer[t], mt.K);
+        int m = closest_mask(mt, rev);
+        unsigned long long o = atomicAdd(counter, 1ull);
+        if (o < cap && m >= 0) {
+            s_mask[o] = (uint16_t)m;
+            s_kmer[o] = rev;
+            s_val[o] = s_val[t] | 1ull;
+        }
+    }
+}
+
+__global__ void k_mask_hist(const uint16_t *__restrict__ s_mask, unsigned long long n, unsigned long long *__restrict__ counts) {
+    for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < n;
+         t += (unsigned long long)gridDim.x * blockDim.x)
+        atomicAdd(&counts[s_mask[t]], 1ull);
+}
+
+__global__ void k_mask_scatter(const uint16_t *__restrict__ s_mask, const uint64_t *__restrict__ s_kmer,
+                               const uint64_t *__restrict__ s_val, unsigned long long n, const int64_t *__restrict__ mask_off,
+                               unsigned long long *__restrict__ cursor, uint64_t *__restrict__ out_k,
+                               uint64_t *__restrict__ out_v) {
+    for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < n;
+         t += (unsigned long long)gridDim.x * blockDim.x) {
+        int m = s_mask[t];
+        unsigned long long o = (unsigned long long)mask_off[m] + atomicAdd(&cursor[m], 1ull);
+        out_k[o] = s_kmer[t];
+        out_v[o] = s_val[t];
+    }
+}
+
+__global__ void k_fill_u64(unsigned long long *p, int64_t n, unsigned long long v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+__global__ void k_fetch_bases(const uint8_t *__restrict__ gb, int64_t start, int64_t len, uint8_t *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t p = start + i;
+        out[i] = (uint8_t)("ACGT"[(gb[p >> 2] >> ((3 - (p & 3)) << 1)) & 3]);
+    }
+}
+
+static int gridn(int64_t n, int block = 256) {
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > 262144) g = 262144;
+    return (int)g;
+}
+
+// host-side mask set with the structure of lexicmap masks (docs/content/usage/utils/masks.md:69-110): all p-prefixes
+// present, M-4^p extra masks on distinct prefixes differing from their twin at base p+1, sorted.
+static void gen_masks(int k, int M, uint64_t seed, std::vector<uint64_t> &out) {
+    int p = std::max(1, (int)(std::log2((double)M) / 2));
+    int64_t np = (int64_t)1 << (2 * p);
+    int lowbits = (k - p) << 1;
+    uint64_t lowmask = (1ull << lowbits) - 1;
+    uint64_t st = seed * 0x2545F4914F6CDD1Dull + 0x9E37ull;
+    auto next = [&]() {
+        st += 0x9E3779B97F4A7C15ull;
+        return mix64(st);
+    };
+    out.clear();
+    for (int64_t i = 0; i < np && (int)out.size() < M; i++) {
+        uint64_t m;
+        do m = ((uint64_t)i << lowbits) | (next() & lowmask);
+        while (lm_dust(m, k));
+        out.push_back(m);
+    }
+    int extra = M - (int)out.size();
+    std::vector<int64_t> perm(np);
+    for (int64_t i = 0; i < np; i++) perm[i] = i;
+    for (int j = 0; j < extra; j++) {
+        int64_t r = j + (int64_t)(next() % (uint64_t)(np - j));
+        std::swap(perm[j], perm[r]);
+        uint64_t twin_base = (out[perm[j]] >> (lowbits - 2)) & 3;
+        uint64_t m;
+        do m = ((uint64_t)perm[j] << lowbits) | (next() & lowmask);
+        while (((m >> (lowbits - 2)) & 3) == twin_base || lm_dust(m, k));
+        out.push_back(m);
+    }
+    std::sort(out.begin(), out.end());
+}
+
+} // namespace lm
+
+extern "C" {
+
+lm_status lm_index_build_synthetic(const lm_synth_spec *spec, const lm_options *opt, int device, lm_index **out) {
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        g_open_error = "no HIP device available (this library has no CPU path)";
+        return LM_ERR_NO_DEVICE;
+    }
+    if (spec->k != 31 || spec->masks < 4 || spec->masks > 65535 || spec->genome_len < 64 || spec->genomes < 1 ||
+        spec->genome_len >= (1 << 28) || spec->families < 1) {
+        g_open_error = "lm_index_build_synthetic: unsupported spec (k must be 31, masks in [4,65535])";
+        return LM_ERR_ARG;
+    }
+    lm_index *ix = new lm_index();
+    try {
+        ix->opt = *opt;
+        ix->device = device;
+        HIPCHK(hipSetDevice(device));
+        HIPCHK(hipStreamCreate(&ix->st));
+        HostIndex &h = ix->host;
+        const int K = spec->k, M = spec->masks;
+        h.k = K;
+        h.M = M;
+        h.main_version = 3;
+        h.minor_version = 5;
+        h.mask_prefix = std::max(1, (int)(std::log2((double)M) / 2));
+        h.anchor_prefix = 6;
+        h.contig_interval = 1000;
+        h.shard_rank = opt->shard_count > 1 ? opt->shard_rank : 0;
+        h.shard_count = opt->shard_count > 1 ? opt->shard_count : 1;
+        h.total_bases = opt->total_bases_override > 0 ? opt->total_bases_override : spec->genomes * (int64_t)spec->genome_len;
+        gen_masks(K, M, (uint64_t)spec->mask_seed, h.masks);
+        const int p = h.mask_prefix;
+        std::vector<int32_t> pfx((size_t)(1ull << (2 * p)) + 1, 0);
+        for (int i = 0; i < M; i++) pfx[(size_t)(h.masks[i] >> ((K - p) << 1)) + 1]++;
+        for (size_t i = 1; i < pfx.size(); i++) pfx[i] += pfx[i - 1];
+        {
+            if (opt->min_prefix > K || opt->min_prefix < p + h.anchor_prefix) {
+                g_open_error = "MinPrefix out of range for this index";
+                delete ix;
+                return LM_ERR_OPTION;
+            }
+        }
+        // local genomes
+        int64_t nlocal = 0;
+        for (int64_t g = 0; g < spec->genomes; g++)
+            if ((int)(g % h.shard_count) == h.shard_rank) nlocal++;
+        SynthDev sp;
+        sp.seed = (uint64_t)spec->seed;
+        sp.genomes = spec->genomes;
+        sp.genome_len = spec->genome_len;
+        sp.families = (int32_t)std::min<int64_t>(spec->families, spec->genomes);
+        sp.max_div = spec->max_div;
+        sp.shard_rank = h.shard_rank;
+        sp.shard_count = h.shard_count;
+        sp.nlocal = nlocal;
+        sp.nblk = (spec->genome_len + 511) >> 9;
+        sp.gbytes = ((((int64_t)spec->genome_len + 3) >> 2) + 16 + 7) & ~(int64_t)7;
+        h.genome_batches = (int)((spec->genomes + 4999) / 5000);
+        h.batch_first.assign(h.genome_batches + 1, 0);
+        for (int b = 0; b <= h.genome_batches; b++) h.batch_first[b] = std::min<int64_t>((int64_t)b * 5000, spec->genomes);
+
+        auto copy_up = [&](auto &dbuf, const auto &vec) {
+            dbuf.ensure(std::max<size_t>(vec.size(), 1));
+            HIPCHK(hipMemcpyAsync(dbuf.p, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice, ix->st));
+        };
+        copy_up(ix->d_masks, h.masks);
+        copy_up(ix->d_pfx_first, pfx);
+        copy_up(ix->d_batch_first, h.batch_first);
+        // genomes
+        ix->d_gbits.ensure((size_t)(nlocal * sp.gbytes) + 64);
+        HIPCHK(hipMemsetAsync(ix->d_gbits.p, 0, (size_t)(nlocal * sp.gbytes) + 64, ix->st));
+        DBuf<int16_t> shifts;
+        shifts.ensure((size_t)(nlocal * sp.nblk) + 1);
+        hipLaunchKernelGGL(k_synth_shifts, dim3(gridn(nlocal, 64)), dim3(64), 0, ix->st, sp, shifts.p);
+        hipLaunchKernelGGL(k_synth_genomes, dim3(gridn(nlocal * (((int64_t)spec->genome_len + 3) >> 2))), dim3(256), 0, ix->st,
+                           sp, shifts.p, ix->d_gbits.p);
+        bsync(ix);
+        shifts.release();
+        MaskTab mt{ix->d_masks.p, ix->d_pfx_first.p, K, p, M};
+        // seed buffer
+        double per_genome = 2.0 * (1.45 * M + (double)spec->genome_len / 42.0) + 1024;
+        unsigned long long cap = (unsigned long long)(per_genome * (double)nlocal) + 65536;
+        DBuf<uint16_t> s_mask;
+        DBuf<uint64_t> s_kmer, s_val;
+        s_mask.ensure(cap);
+        s_kmer.ensure(cap);
+        s_val.ensure(cap);
+        DBuf<unsigned long long> counters;
+        counters.ensure(8);
+        HIPCHK(hipMemsetAsync(counters.p, 0, 8 * sizeof(unsigned long long), ix->st));
+        const int CH = (int)std::min<int64_t>(nlocal, std::max<int64_t>(1, (int64_t)(256ll << 20) / ((int64_t)M * 8)));
+        DBuf<unsigned long long> hashes;
+        hashes.ensure((size_t)CH * M);
+        unsigned long long pos_cap = (unsigned long long)((1.45 * M + 64) * CH) + CH + 64;
+        DBuf<uint64_t> pos_keys, pos_keys2;
+        pos_keys.ensure(pos_cap);
+        pos_keys2.ensure(pos_cap);
+        unsigned long long seeds_done = 0; // seeds already reversed
+        const int64_t npos = (int64_t)spec->genome_len - K + 1;
+        for (int64_t l0 = 0; l0 < nlocal; l0 += CH) {
+            int nch = (int)std::min<int64_t>(CH, nlocal - l0);
+            hipLaunchKernelGGL(k_fill_u64, dim3(gridn((int64_t)nch * M)), dim3(256), 0, ix->st, hashes.p, (int64_t)nch * M,
+                               ~0ull);
+            HIPCHK(hipMemsetAsync(counters.p + 1, 0, sizeof(unsigned long long), ix->st));
+            hipLaunchKernelGGL(k_cap_argmin, dim3(gridn((int64_t)nch * npos)), dim3(256), 0, ix->st, sp, mt, ix->d_gbits.p, l0,
+                               nch, hashes.p);
+            hipLaunchKernelGGL(k_cap_emit, dim3(gridn((int64_t)nch * npos)), dim3(256), 0, ix->st, sp, mt, ix->d_gbits.p, l0,
+                               nch, hashes.p, s_mask.p, s_kmer.p, s_val.p, counters.p, cap, pos_keys.p, counters.p + 1,
+                               pos_cap - CH - 1);
+            unsigned long long hc[2];
+            HIPCHK(hipMemcpyAsync(hc, counters.p, sizeof hc, hipMemcpyDeviceToHost, ix->st));
+            bsync(ix);
+            if (hc[0] >= cap || hc[1] >= pos_cap - CH - 1) throw HipError("synthetic builder: seed buffer too small");
+            unsigned long long npk = hc[1];
+            hipLaunchKernelGGL(k_pseudo_pos, dim3((nch + 63) / 64), dim3(64), 0, ix->st, nch, (int32_t)(spec->genome_len - K),
+                               pos_keys.p, npk);
+            npk += nch;
+            {
+                size_t bytes = 0;
+                HIPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, pos_keys.p, pos_keys2.p, (int)npk, 0, 64, ix->st));
+                ix->tmp.ensure(bytes);
+                HIPCHK(hipcub::DeviceRadixSort::SortKeys(ix->tmp.p, bytes, pos_keys.p, pos_keys2.p, (int)npk, 0, 64, ix->st));
+            }
+            hipLaunchKernelGGL(k_desert_fill, dim3(gridn((int64_t)npk, 64)), dim3(64), 0, ix->st, sp, mt, ix->d_gbits.p, l0,
+                               pos_keys2.p, (int64_t)npk, spec->max_desert, spec->seed_dist, s_mask.p, s_kmer.p, s_val.p,
+                               counters.p, cap);
+            HIPCHK(hipMemcpyAsync(hc, counters.p, sizeof hc, hipMemcpyDeviceToHost, ix->st));
+            bsync(ix);
+            if (hc[0] >= cap) throw HipError("synthetic builder: seed buffer too small (desert)");
+            unsigned long long upto = hc[0];
+            hipLaunchKernelGGL(k_reverse_seeds, dim3(gridn((int64_t)(upto - seeds_done))), dim3(256), 0, ix->st, mt, seeds_done,
+                               upto, s_mask.p, s_kmer.p, s_val.p, counters.p, cap);
+            HIPCHK(hipMemcpyAsync(hc, counters.p, sizeof hc, hipMemcpyDeviceToHost, ix->st));
+            bsync(ix);
+            if (hc[0] >= cap) throw HipError("synthetic builder: seed buffer too small (reversed)");
+            seeds_done = hc[0];
+        }
+        hashes.release();
+        pos_keys.release();
+        pos_keys2.release();
+        unsigned long long N = seeds_done;
+        // bucket by mask
+        DBuf<unsigned long long> counts, cursor;
+        counts.ensure(M + 1);
+        cursor.ensure(M + 1);
+        HIPCHK(hipMemsetAsync(counts.p, 0, (M + 1) * sizeof(unsigned long long), ix->st));
+        HIPCHK(hipMemsetAsync(cursor.p, 0, (M + 1) * sizeof(unsigned long long), ix->st));
+        hipLaunchKernelGGL(k_mask_hist, dim3(gridn((int64_t)N)), dim3(256), 0, ix->st, s_mask.p, N, counts.p);
+        std::vector<unsigned long long> hcounts(M);
+        HIPCHK(hipMemcpyAsync(hcounts.data(), counts.p, M * sizeof(unsigned long long), hipMemcpyDeviceToHost, ix->st));
+        bsync(ix);
+        h.mask_off.assign(M + 1, 0);
+        for (int i = 0; i < M; i++) h.mask_off[i + 1] = h.mask_off[i] + (int64_t)hcounts[i];
+        copy_up(ix->d_mask_off, h.mask_off);
+        DBuf<uint64_t> bk, bv;
+        bk.ensure((size_t)N + 1);
+        bv.ensure((size_t)N + 1);
+        hipLaunchKernelGGL(k_mask_scatter, dim3(gridn((int64_t)N)), dim3(256), 0, ix->st, s_mask.p, s_kmer.p, s_val.p, N,
+                           ix->d_mask_off.p, cursor.p, bk.p, bv.p);
+        bsync(ix);
+        s_mask.release();
+        s_kmer.release();
+        s_val.release();
+        ix->d_seed_kmers.ensure((size_t)N + 1);
+        ix->d_seed_vals.ensure((size_t)N + 1);
+        // per-mask sort by k-mer, in groups of masks below 2^31 items
+        {
+            int m0 = 0;
+            DBuf<int64_t> rel;
+            while (m0 < M) {
+                int m1 = m0;
+                while (m1 < M && h.mask_off[m1 + 1] - h.mask_off[m0] < ((int64_t)1 << 31) - 1) m1++;
+                if (m1 == m0) throw HipError("synthetic builder: a single mask list exceeds 2^31 seeds");
+                int64_t base = h.mask_off[m0], items = h.mask_off[m1] - base;
+                std::vector<int64_t> relh(m1 - m0 + 1);
+                for (int i = m0; i <= m1; i++) relh[i - m0] = h.mask_off[i] - base;
+                rel.ensure(relh.size());
+                HIPCHK(hipMemcpyAsync(rel.p, relh.data(), relh.size() * sizeof(int64_t), hipMemcpyHostToDevice, ix->st));
+                size_t bytes = 0;
+                HIPCHK(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, bytes, bk.p + base, ix->d_seed_kmers.p + base,
+                                                                   bv.p + base, ix->d_seed_vals.p + base, (int)items, m1 - m0,
+                                                                   rel.p, rel.p + 1, 0, 2 * K, ix->st));
+                ix->tmp.ensure(bytes);
+                HIPCHK(hipcub::DeviceSegmentedRadixSort::SortPairs(ix->tmp.p, bytes, bk.p + base, ix->d_seed_kmers.p + base,
+                                                                   bv.p + base, ix->d_seed_vals.p + base, (int)items, m1 - m0,
+                                                                   rel.p, rel.p + 1, 0, 2 * K, ix->st));
+                bsync(ix);
+                m0 = m1;
+            }
+        }
+        bk.release();
+        bv.release();
+        // genome tables + host metadata
+        std::vector<int64_t> goff(nlocal);
+        std::vector<int32_t> glen(nlocal, spec->genome_len);
+        h.genomes.resize(nlocal);
+        for (int64_t l = 0; l < nlocal; l++) {
+            int64_t g = h.shard_count > 1 ? l * h.shard_count + h.shard_rank : l;
+            HostGenome &G = h.genomes[l];
+            G.bg = ((uint64_t)(g / 5000) << 17) | (uint64_t)(g % 5000);
+            G.global = g;
+            char nm[64];
+            snprintf(nm, sizeof nm, "SYN_%09lld.1", (long long)g);
+            G.id = nm;
+            G.genome_size = spec->genome_len;
+            G.len = spec->genome_len;
+            G.nseqs = 1;
+            G.seq_sizes = {spec->genome_len};
+            snprintf(nm, sizeof nm, "syn%09lld_c1", (long long)g);
+            G.seq_ids = {std::string(nm)};
+            G.bits_off = l * sp.gbytes;
+            goff[l] = G.bits_off;
+            ix->bg2local[G.bg] = (int)l;
+        }
+        copy_up(ix->d_g_off, goff);
+        copy_up(ix->d_g_len, glen);
+        lm_fill_gap_lut(ix); // same table as lm_index_open (lib-chaining.go:662-667)
+        bsync(ix);
+        DevIndexView &v = ix->view;
+        v.K = K;
+        v.M = M;
+        v.mask_prefix = p;
+        v.masks = ix->d_masks.p;
+        v.pfx_first = ix->d_pfx_first.p;
+        v.seed_kmers = ix->d_seed_kmers.p;
+        v.seed_vals = ix->d_seed_vals.p;
+        v.mask_off = ix->d_mask_off.p;
+        v.gbits = ix->d_gbits.p;
+        v.g_off = ix->d_g_off.p;
+        v.g_len = ix->d_g_len.p;
+        v.batch_first = ix->d_batch_first.p;
+        v.nbatches = h.genome_batches;
+        v.ngenomes = nlocal;
+        v.shard_rank = h.shard_rank;
+        v.shard_count = h.shard_count;
+        ix->hbm_bytes = (int64_t)(N * 16 + (uint64_t)(nlocal * sp.gbytes) + (uint64_t)M * 16 + pfx.size() * 4 + nlocal * 12);
+    } catch (const std::exception &e) {
+        g_open_error = e.what();
+        delete ix;
+        return LM_ERR_HIP;
+    }
+    *out = ix;
+    return LM_OK;
+}
+
+lm_status lm_index_fetch(lm_index *ix, int64_t local_genome, int64_t start, int64_t len, uint8_t *out) {
+    if (!ix || local_genome < 0 || local_genome >= (int64_t)ix->host.genomes.size()) return LM_ERR_ARG;
+    const HostGenome &G = ix->host.genomes[local_genome];
+    if (start < 0 || len < 0 || start + len > G.len) return LM_ERR_ARG;
+    try {
+        std::lock_guard<std::mutex> lock(ix->mu);
+        HIPCHK(hipSetDevice(ix->device));
+        DBuf<uint8_t> d;
+        d.ensure((size_t)len + 1);
+        hipLaunchKernelGGL(k_fetch_bases, dim3(gridn(len)), dim3(256), 0, ix->st, ix->d_gbits.p + G.bits_off, start, len, d.p);
+        HIPCHK(hipMemcpyAsync(out, d.p, (size_t)len, hipMemcpyDeviceToHost, ix->st));
+        bsync(ix);
+    } catch (const std::exception &e) {
+        ix->err = e.what();
+        return LM_ERR_HIP;
+    }
+    return LM_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,110 @@
+// lm_internal.h — shared host-side internals of liblexicmap_hip (handle layout, device buffers, HIP error handling)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/lexicmap_hip.h"
+#include "lm_format.h"
+#include "lm_kernels.h"
+
+namespace lm {
+
+struct HipError : std::runtime_error {
+    explicit HipError(const std::string &m) : std::runtime_error(m) {}
+};
+#define HIPCHK(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t _e = (expr);                                                                              \
+        if (_e != hipSuccess)                                                                                \
+            throw HipError(std::string(#expr) + ": " + hipGetErrorString(_e) + " at " + __FILE__ + ":" +     \
+                           std::to_string(__LINE__));                                                        \
+    } while (0)
+
+template <typename T> struct DBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    DBuf() = default;
+    DBuf(const DBuf &) = delete;
+    DBuf &operator=(const DBuf &) = delete;
+    ~DBuf() {
+        if (p) (void)hipFree(p);
+    }
+    void ensure(size_t n) {
+        if (n <= cap && p) return;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        size_t want = std::max<size_t>(n + n / 8, 64);
+        HIPCHK(hipMalloc((void **)&p, want * sizeof(T)));
+        cap = want;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+static double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct ProfEntry {
+    std::string name;
+    int64_t launches = 0;
+    double ms = 0;
+    int64_t bytes = 0;
+};
+
+} // namespace lm
+
+using namespace lm;
+
+extern thread_local std::string g_open_error; // text of the last failed open/build (lm_last_error(NULL))
+struct lm_index;
+void lm_fill_gap_lut(lm_index *ix);
+
+namespace lm {
+struct Work;
+struct AlignCtx;
+} // namespace lm
+
+struct lm_index {
+    lm::Work *work = nullptr;       // device scratch reused across calls (grow-only)
+    lm::AlignCtx *actx = nullptr;
+    std::mutex mu;                  // one in-flight call per handle
+    HostIndex host;
+    lm_options opt;
+    int device = 0;
+    hipStream_t st = nullptr;
+    std::string err;
+    // HBM image
+    DBuf<uint64_t> d_masks, d_seed_kmers, d_seed_vals;
+    DBuf<int32_t> d_pfx_first, d_g_len;
+    DBuf<int64_t> d_mask_off, d_g_off, d_batch_first;
+    DBuf<uint8_t> d_gbits;
+    DBuf<float> d_gap_lut;
+    int gap_lut_n = 0;
+    DevIndexView view;
+    int64_t hbm_bytes = 0;
+    // scratch
+    DBuf<uint8_t> tmp; // rocPRIM temporary storage
+    // profiling
+    bool prof = false;
+    std::vector<ProfEntry> prof_entries;
+    std::vector<lm_kernel_time> prof_out;
+    struct Pending {
+        int entry;
+        hipEvent_t a, b;
+    };
+    std::vector<Pending> pending;
+    // genome lookup
+    std::unordered_map<uint64_t, int> bg2local;
+};
+

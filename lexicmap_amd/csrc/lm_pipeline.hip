@@ -24,97 +24,9 @@
 #include "lm_format.h"
 #include "lm_kernels.h"
 
-namespace lm {
+#include "lm_internal.h"
 
-struct HipError : std::runtime_error {
-    explicit HipError(const std::string &m) : std::runtime_error(m) {}
-};
-#define HIPCHK(expr)                                                                                         \
-    do {                                                                                                     \
-        hipError_t _e = (expr);                                                                              \
-        if (_e != hipSuccess)                                                                                \
-            throw HipError(std::string(#expr) + ": " + hipGetErrorString(_e) + " at " + __FILE__ + ":" +     \
-                           std::to_string(__LINE__));                                                        \
-    } while (0)
-
-template <typename T> struct DBuf {
-    T *p = nullptr;
-    size_t cap = 0;
-    DBuf() = default;
-    DBuf(const DBuf &) = delete;
-    DBuf &operator=(const DBuf &) = delete;
-    ~DBuf() {
-        if (p) (void)hipFree(p);
-    }
-    void ensure(size_t n) {
-        if (n <= cap && p) return;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        size_t want = std::max<size_t>(n + n / 8, 64);
-        HIPCHK(hipMalloc((void **)&p, want * sizeof(T)));
-        cap = want;
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-};
-
-static double now_ms() {
-    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-
-struct ProfEntry {
-    std::string name;
-    int64_t launches = 0;
-    double ms = 0;
-    int64_t bytes = 0;
-};
-
-} // namespace lm
-
-using namespace lm;
-
-namespace lm {
-struct Work;
-struct AlignCtx;
-} // namespace lm
-
-struct lm_index {
-    lm::Work *work = nullptr;       // device scratch reused across calls (grow-only)
-    lm::AlignCtx *actx = nullptr;
-    std::mutex mu;                  // one in-flight call per handle
-    HostIndex host;
-    lm_options opt;
-    int device = 0;
-    hipStream_t st = nullptr;
-    std::string err;
-    // HBM image
-    DBuf<uint64_t> d_masks, d_seed_kmers, d_seed_vals;
-    DBuf<int32_t> d_pfx_first, d_g_len;
-    DBuf<int64_t> d_mask_off, d_g_off, d_batch_first;
-    DBuf<uint8_t> d_gbits;
-    DBuf<float> d_gap_lut;
-    int gap_lut_n = 0;
-    DevIndexView view;
-    int64_t hbm_bytes = 0;
-    // scratch
-    DBuf<uint8_t> tmp; // rocPRIM temporary storage
-    // profiling
-    bool prof = false;
-    std::vector<ProfEntry> prof_entries;
-    std::vector<lm_kernel_time> prof_out;
-    struct Pending {
-        int entry;
-        hipEvent_t a, b;
-    };
-    std::vector<Pending> pending;
-    // genome lookup
-    std::unordered_map<uint64_t, int> bg2local;
-};
-
-static thread_local std::string g_open_error;
+thread_local std::string g_open_error;
 
 namespace lm {
 
@@ -195,6 +107,20 @@ static float gap_score(float gap) {
     float b = 0.5f * (float)go_log2((double)gap);
     return a + b;
 }
+
+} // namespace lm
+
+// gapScore table for integer gaps 0..ceil(max_gap) (shared with lm_builder.hip)
+void lm_fill_gap_lut(lm_index *ix) {
+    ix->gap_lut_n = (int)std::ceil(ix->opt.max_gap) + 2;
+    std::vector<float> lut(ix->gap_lut_n);
+    for (int g = 0; g < ix->gap_lut_n; g++) lut[g] = lm::gap_score((float)g);
+    ix->d_gap_lut.ensure(lut.size());
+    HIPCHK(hipMemcpyAsync(ix->d_gap_lut.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice, ix->st));
+    HIPCHK(hipStreamSynchronize(ix->st));
+}
+
+namespace lm {
 
 template <typename T> static void h2d(lm_index *ix, DBuf<T> &d, const std::vector<T> &h) {
     d.ensure(std::max<size_t>(h.size(), 1));
@@ -792,11 +718,7 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
         h2d(ix, ix->d_g_off, goff);
         h2d(ix, ix->d_g_len, glen);
         h2d(ix, ix->d_batch_first, h.batch_first);
-        // gapScore table for integer gaps 0..ceil(max_gap)
-        ix->gap_lut_n = (int)std::ceil(opt->max_gap) + 2;
-        std::vector<float> lut(ix->gap_lut_n);
-        for (int g = 0; g < ix->gap_lut_n; g++) lut[g] = gap_score((float)g);
-        h2d(ix, ix->d_gap_lut, lut);
+        lm_fill_gap_lut(ix);
         sync(ix);
         DevIndexView &v = ix->view;
         v.K = h.k;
