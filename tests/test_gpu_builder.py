@@ -28,7 +28,8 @@ def test_synthetic_genomes_family_structure(synth_index):
     assert all(abs((a == x).mean() - 0.25) < 0.01 for x in b"ACGT")
     ident_c = (a[:5000] == c[:5000]).mean()
     assert 0.2 < ident_c < 0.3                                      # unrelated
-    ident_b = (a[:400] == b[:400]).mean()                           # before the first indel shift
+    # members are substituted + indel-shifted copies: some small shift aligns the first block
+    ident_b = max((a[8 + sh:408 + sh] == b[8:408]).mean() for sh in range(-8, 9))
     assert ident_b > 0.85
 
 
