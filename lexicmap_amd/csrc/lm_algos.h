@@ -825,20 +825,10 @@ LM_HD int lm_upper_bound_u64(const uint64_t *a, int lo, int hi, uint64_t x) {
     }
     return lo;
 }
-LM_HDN bool lm_tree_search_range(const uint64_t *keys, int n, uint64_t key, int p, int K, int *lo_out, int *hi_out) {
-    if (n <= 0) return false;
-    if (p < 1) p = 1;
-    if (p > K) p = K;
+// The "no key shares p bases" half of tree.Search: decides whether the partial-prefix quirk returns a subtree.
+// lo = insertion point of (key & ~low) in keys[0..n).
+LM_HDN bool lm_tree_search_miss(const uint64_t *keys, int n, uint64_t key, int p, int K, int lo, int *lo_out, int *hi_out) {
     const int sh = (K - p) << 1;
-    const uint64_t low = sh >= 64 ? ~0ull : ((1ull << sh) - 1);
-    const uint64_t left = key & ~low, right = key | low;
-    int lo = lm_lower_bound_u64(keys, 0, n, left);
-    int hi = lm_upper_bound_u64(keys, lo, n, right);
-    if (lo < hi) {
-        *lo_out = lo;
-        *hi_out = hi;
-        return true;
-    }
     // No key shares p bases. The quirk needs bases [d,p) of `key` to be all A for some node depth d <= L, where
     // L = longest prefix shared with any key; cheap necessary test first: bases [L,p) all A.
     int L = 0;
@@ -887,6 +877,44 @@ LM_HDN bool lm_tree_search_range(const uint64_t *keys, int n, uint64_t key, int 
         }
         return false;
     }
+}
+
+
+LM_HDN bool lm_tree_search_range(const uint64_t *keys, int n, uint64_t key, int p, int K, int *lo_out, int *hi_out) {
+    if (n <= 0) return false;
+    if (p < 1) p = 1;
+    if (p > K) p = K;
+    const int sh = (K - p) << 1;
+    const uint64_t low = sh >= 64 ? ~0ull : ((1ull << sh) - 1);
+    const uint64_t left = key & ~low, right = key | low;
+    int lo = lm_lower_bound_u64(keys, 0, n, left);
+    int hi = lm_upper_bound_u64(keys, lo, n, right);
+    if (lo < hi) {
+        *lo_out = lo;
+        *hi_out = hi;
+        return true;
+    }
+    return lm_tree_search_miss(keys, n, key, p, K, lo, lo_out, hi_out);
+}
+
+// Same, with the two binary searches narrowed by a bucket table over the leading `tab_bits/2` bases:
+// tab[b] = first index whose leading bits are >= b, tab[nbuckets] = n.  Requires 2*p >= tab_bits.
+LM_HD bool lm_tree_search_range_tab(const uint64_t *keys, int n, uint64_t key, int p, int K, const uint32_t *tab,
+                                    int tab_bits, int *lo_out, int *hi_out) {
+    if (n <= 0) return false;
+    if (p > K) p = K;
+    const int sh = (K - p) << 1;
+    const uint64_t low = sh >= 64 ? ~0ull : ((1ull << sh) - 1);
+    const uint64_t left = key & ~low, right = key | low;
+    const uint32_t b = (uint32_t)(key >> ((K << 1) - tab_bits));
+    int lo = lm_lower_bound_u64(keys, (int)tab[b], (int)tab[b + 1], left);
+    int hi = lm_upper_bound_u64(keys, lo, (int)tab[b + 1], right);
+    if (lo < hi) {
+        *lo_out = lo;
+        *hi_out = hi;
+        return true;
+    }
+    return lm_tree_search_miss(keys, n, key, p, K, lo, lo_out, hi_out);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -79,12 +79,15 @@ void launch_make_tasks(hipStream_t st, DevIndexView ix, const uint64_t *segA, co
 void launch_task_wlen(hipStream_t st, const Task *tasks, int64_t ntasks, int32_t *wlen);
 void launch_task_set_woff(hipStream_t st, Task *tasks, int64_t ntasks, const int64_t *woff);
 void launch_extract_windows(hipStream_t st, DevIndexView ix, const Task *tasks, int64_t ntasks, uint8_t *wbuf);
+#define LM_TAB_BITS 12 /* bucket table over the first 6 bases of the query's sorted k-mers */
+void launch_build_cmp_tab(hipStream_t st, const uint64_t *keys_cmp, const int64_t *posoff, const int32_t *nvalid, int nq,
+                          int K, uint32_t *tab);
 void launch_pa_count(hipStream_t st, const Task *tasks, int64_t ntasks, const uint8_t *wbuf, const uint64_t *keys_cmp,
-                     const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid, int K, int min_prefix,
-                     uint32_t *counts);
+                     const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_tab, int K,
+                     int min_prefix, uint32_t *counts);
 void launch_pa_emit(hipStream_t st, const Task *tasks, int64_t ntasks, const uint8_t *wbuf, const uint64_t *keys_cmp,
-                    const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid, int K, int min_prefix,
-                    const uint32_t *counts, const int64_t *offs, uint64_t *outA, uint64_t *outB);
+                    const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_tab, int K,
+                    int min_prefix, const uint32_t *counts, const int64_t *offs, uint64_t *outA, uint64_t *outB);
 void launch_pa_task_off(hipStream_t st, const Task *tasks, int64_t ntasks, const int64_t *offs, int64_t total_pos,
                         int64_t total_anchors, int64_t *pa_off);
 void launch_pa_chain(hipStream_t st, const uint64_t *B, const int64_t *pa_off, int64_t ntasks, int K, LmChain2Opt opt,
@@ -99,5 +102,9 @@ void launch_extend(hipStream_t st, const HspIn *hsps, int64_t n, const uint8_t *
                    HspExt *out);
 void launch_wfa(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int32_t *hdr_pool,
                 int32_t *arena_pool, uint64_t *ops_pool, WfaOut *out);
+
+// wavefronts wider than the LDS ring (status 3 from launch_wfa): same algorithm with the ring in global memory
+void launch_wfa_wide(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int32_t *hdr_pool,
+                     int32_t *arena_pool, uint64_t *ops_pool, WfaOut *out);
 
 } // namespace lm

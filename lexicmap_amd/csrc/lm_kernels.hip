@@ -65,6 +65,25 @@ __global__ void k_extract_kmers(const uint8_t *__restrict__ qseq, const int64_t 
     }
 }
 
+// bucket table over the leading LM_TAB_BITS bits of each query's sorted (filtered) k-mer array:
+// tab[q][b] = first index (relative to the query's segment) whose key >> (2K-bits) >= b; tab[q][nb] = nvalid[q]
+__global__ void k_build_cmp_tab(const uint64_t *__restrict__ keys_cmp, const int64_t *__restrict__ posoff,
+                                const int32_t *__restrict__ nvalid, int nq, int K, int bits, uint32_t *__restrict__ tab) {
+    const int nb = 1 << bits;
+    int64_t total = (int64_t)nq * (nb + 1);
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        int q = (int)(t / (nb + 1)), b = (int)(t % (nb + 1));
+        const uint64_t *keys = keys_cmp + 2 * posoff[q];
+        int n = nvalid[q];
+        int lo = n;
+        if (b < nb) {
+            uint64_t target = (uint64_t)b << ((K << 1) - bits);
+            lo = lm_lower_bound_u64(keys, 0, n, target);
+        }
+        tab[t] = (uint32_t)lo;
+    }
+}
+
 __global__ void k_fill_u32(uint32_t *p, int64_t n, uint32_t v) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -367,13 +386,13 @@ __device__ __forceinline__ int pa_min_prefix(int base, int wlen) {
 }
 
 template <bool EMIT>
-__device__ __forceinline__ uint32_t pa_position(const uint64_t *keys, const uint32_t *vals, int n, uint64_t kmer, int K,
-                                                int m, uint32_t begin, uint32_t end, int idx, uint64_t A,
-                                                uint64_t *outA, uint64_t *outB, int64_t o) {
+__device__ __forceinline__ uint32_t pa_position(const uint64_t *keys, const uint32_t *vals, int n, const uint32_t *tab,
+                                                uint64_t kmer, int K, int m, uint32_t begin, uint32_t end, int idx,
+                                                uint64_t A, uint64_t *outA, uint64_t *outB, int64_t o) {
     uint32_t cnt = 0;
     if (kmer == 0 || kmer == lm_ns(1, K) || kmer == lm_ns(2, K) || kmer == lm_kmer_mask(K)) return 0;
     int lo, hi;
-    if (lm_tree_search_range(keys, n, kmer, m, K, &lo, &hi)) {
+    if (lm_tree_search_range_tab(keys, n, kmer, m, K, tab, LM_TAB_BITS, &lo, &hi)) {
         for (int j = lo; j < hi; j++) {
             uint32_t v = vals[j];
             uint32_t lp = (uint32_t)lm_lcp(keys[j], kmer, K);
@@ -387,7 +406,7 @@ __device__ __forceinline__ uint32_t pa_position(const uint64_t *keys, const uint
         }
     }
     uint64_t rc = lm_revcomp(kmer, K);
-    if (lm_tree_search_range(keys, n, rc, m, K, &lo, &hi)) {
+    if (lm_tree_search_range_tab(keys, n, rc, m, K, tab, LM_TAB_BITS, &lo, &hi)) {
         for (int j = lo; j < hi; j++) {
             uint32_t v = vals[j];
             uint32_t lp = (uint32_t)lm_lcp(keys[j], rc, K);
@@ -405,8 +424,8 @@ __device__ __forceinline__ uint32_t pa_position(const uint64_t *keys, const uint
 
 __global__ void k_pa_count(const Task *__restrict__ tasks, int64_t ntasks, const uint8_t *__restrict__ wbuf,
                            const uint64_t *__restrict__ keys_cmp, const uint32_t *__restrict__ vals_cmp,
-                           const int64_t *__restrict__ posoff, const int32_t *__restrict__ nvalid, int K,
-                           int min_prefix, uint32_t *__restrict__ counts) {
+                           const int64_t *__restrict__ posoff, const int32_t *__restrict__ nvalid,
+                           const uint32_t *__restrict__ cmp_tab, int K, int min_prefix, uint32_t *__restrict__ counts) {
     for (int64_t ti = blockIdx.x; ti < ntasks; ti += gridDim.x) {
         const Task t = tasks[ti];
         const uint8_t *w = wbuf + t.woff;
@@ -418,8 +437,8 @@ __global__ void k_pa_count(const Task *__restrict__ tasks, int64_t ntasks, const
             uint32_t c = 0;
             if (i + K <= t.wlen && n > 0) {
                 uint64_t kmer = encode_kmer(w + i, K);
-                c = pa_position<false>(keys, vals, n, kmer, K, m, (uint32_t)t.qBegin, (uint32_t)t.qEnd, i, 0, nullptr,
-                                       nullptr, 0);
+                c = pa_position<false>(keys, vals, n, cmp_tab + (int64_t)t.q * ((1 << LM_TAB_BITS) + 1), kmer, K, m,
+                                       (uint32_t)t.qBegin, (uint32_t)t.qEnd, i, 0, nullptr, nullptr, 0);
             }
             counts[t.woff + i] = c;
         }
@@ -428,7 +447,8 @@ __global__ void k_pa_count(const Task *__restrict__ tasks, int64_t ntasks, const
 
 __global__ void k_pa_emit(const Task *__restrict__ tasks, int64_t ntasks, const uint8_t *__restrict__ wbuf,
                           const uint64_t *__restrict__ keys_cmp, const uint32_t *__restrict__ vals_cmp,
-                          const int64_t *__restrict__ posoff, const int32_t *__restrict__ nvalid, int K, int min_prefix,
+                          const int64_t *__restrict__ posoff, const int32_t *__restrict__ nvalid,
+                          const uint32_t *__restrict__ cmp_tab, int K, int min_prefix,
                           const uint32_t *__restrict__ counts, const int64_t *__restrict__ offs,
                           uint64_t *__restrict__ outA, uint64_t *__restrict__ outB) {
     for (int64_t ti = blockIdx.x; ti < ntasks; ti += gridDim.x) {
@@ -441,8 +461,8 @@ __global__ void k_pa_emit(const Task *__restrict__ tasks, int64_t ntasks, const 
         for (int i = threadIdx.x; i < t.wlen; i += blockDim.x) {
             if (counts[t.woff + i] == 0) continue;
             uint64_t kmer = encode_kmer(w + i, K);
-            pa_position<true>(keys, vals, n, kmer, K, m, (uint32_t)t.qBegin, (uint32_t)t.qEnd, i, (uint64_t)ti, outA,
-                              outB, offs[t.woff + i]);
+            pa_position<true>(keys, vals, n, cmp_tab + (int64_t)t.q * ((1 << LM_TAB_BITS) + 1), kmer, K, m,
+                              (uint32_t)t.qBegin, (uint32_t)t.qEnd, i, (uint64_t)ti, outA, outB, offs[t.woff + i]);
         }
     }
 }
@@ -493,6 +513,287 @@ __global__ void k_pa_chain(const uint64_t *__restrict__ B, const int64_t *__rest
             clr_n[ti] = 0;
         }
         out_n[ti] = nout;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Wave-cooperative Clear + Trim + Chainer2 (+ chainARegion) for one chain: lanes cover anchors for ClearSubstrPairs and
+// candidate predecessors j for the banded DP; emission order and every tie rule are those of lm_clear_sorted / lm_trim
+// / lm_run_chain2 (lm_algos.h), which stay the CPU-checked statement of the logic.
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long x = __shfl_xor(v, o, 64);
+        v = x > v ? x : v;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(64) void k_pa_chain_wave(const uint64_t *__restrict__ B, const int64_t *__restrict__ pa_off,
+                                                       int64_t ntasks, int K, LmChain2Opt opt, LmSub *__restrict__ subs_pool,
+                                                       uint8_t *__restrict__ marks_pool, uint64_t *__restrict__ msi_pool,
+                                                       int32_t *__restrict__ stack_pool, LmChain2 *__restrict__ out_pool,
+                                                       int32_t *__restrict__ out_n, int32_t *__restrict__ clr_n) {
+    const int lane = threadIdx.x;
+    for (int64_t ti = blockIdx.x; ti < ntasks; ti += gridDim.x) {
+        const int64_t o = pa_off[ti];
+        int n = (int)(pa_off[ti + 1] - o);
+        __syncthreads();
+        if (n <= 0) {
+            if (lane == 0) {
+                out_n[ti] = 0;
+                clr_n[ti] = 0;
+            }
+            continue;
+        }
+        LmSub *sb = subs_pool + o;
+        uint8_t *marks = marks_pool + o;
+        uint64_t *msi = msi_pool + o;
+        LmChain2 *res = out_pool + o;
+        for (int i = lane; i < n; i += 64) sb[i] = lm_unpack_anchor(B[o + i]);
+        __syncthreads();
+        // ---- ClearSubstrPairs (lib-index-search.go:927-972): anchor i+1 is dropped when nested in an earlier one ----
+        if (n > 1) {
+            for (int i = lane; i < n; i += 64) {
+                uint8_t mk = 0;
+                if (i >= 1) {
+                    const LmSub v = sb[i];
+                    int32_t vqend = v.qbegin + v.len;
+                    int32_t upbound = vqend - K;
+                    if (upbound < 0) upbound = 0;
+                    int32_t vtend = v.tbegin + v.len;
+                    int lo = 0, hi = i;
+                    while (lo < hi) {
+                        int mid = (lo + hi) >> 1;
+                        if (sb[mid].qbegin < upbound)
+                            lo = mid + 1;
+                        else
+                            hi = mid;
+                    }
+                    for (int j = lo; j < i; j++) {
+                        const LmSub p = sb[j];
+                        if (vqend <= p.qbegin + p.len && v.tbegin >= p.tbegin && vtend <= p.tbegin + p.len) {
+                            mk = 1;
+                            break;
+                        }
+                    }
+                }
+                marks[i] = mk;
+            }
+            __syncthreads();
+            int w = 0; // ordered in-place compaction, chunk by chunk
+            for (int c = 0; c < n; c += 64) {
+                int i = c + lane;
+                bool keep = i < n && !marks[i];
+                LmSub v;
+                if (keep) v = sb[i];
+                unsigned long long bal = __ballot(keep);
+                int before = __popcll(bal & ((1ull << lane) - 1ull));
+                __syncthreads();
+                if (keep) sb[w + before] = v;
+                w += __popcll(bal);
+            }
+            n = w;
+            __syncthreads();
+        }
+        // ---- TrimSubStrPairs (lane 0; it stops after a few anchors) ----
+        int start = 0;
+        if (lane == 0) n = lm_trim(sb, n, 100.0f, &start);
+        n = __shfl(n, 0, 64);
+        start = __shfl(start, 0, 64);
+        if (lane == 0) clr_n[ti] = n;
+        if (n <= 0) {
+            if (lane == 0) out_n[ti] = 0;
+            continue;
+        }
+        const LmSub *a_ = sb + start;
+        if (n == 1) {
+            if (lane == 0) out_n[ti] = lm_run_chain2(a_, 1, opt, msi, stack_pool + 2 * o + 4 * ti, res);
+            continue;
+        }
+        // ---- banded DP (lib-chaining2.go:222-307), candidates j scanned 64 at a time from i-1 downwards ----
+        if (lane == 0) msi[0] = (uint64_t)a_[0].len << 32;
+        long long M = 0;
+        int Mi = 0;
+        for (int i = 1; i < n; i++) {
+            __syncthreads();
+            const LmSub a = a_[i];
+            unsigned long long best = 0; // (score<<32 | ~j) of the best candidate so far, 0 = none
+            int bcount = 0;
+            bool stop = false;
+            for (int jt = i - 1; jt >= 0 && !stop; jt -= 64) {
+                int j = jt - lane;
+                bool inb = j >= 0;
+                LmSub b;
+                bool skip = true;
+                if (inb) {
+                    b = a_[j];
+                    skip = (b.qbegin == a.qbegin || b.tbegin > a.tbegin);
+                }
+                unsigned long long nskip = __ballot(!skip);
+                int cnt = bcount + __popcll(nskip & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull)));
+                bool brk = false;
+                if (!skip) {
+                    int32_t bbase = a.qbegin - b.qbegin - (int32_t)b.len;
+                    brk = !(bbase <= opt.band_base || cnt <= opt.band_count);
+                }
+                unsigned long long bm = __ballot(brk);
+                int first_brk = bm ? (__ffsll((long long)bm) - 1) : 64;
+                if (bm) stop = true;
+                if (!skip && lane < first_brk) {
+                    int32_t qd = a.qbegin - b.qbegin, td = a.tbegin - b.tbegin;
+                    if (qd < 0) qd = -qd;
+                    if (td < 0) td = -td;
+                    int32_t g = qd > td ? qd - td : td - qd;
+                    if (g <= opt.max_gap) {
+                        long long s = (long long)(msi[j] >> 32) + (long long)b.len - (long long)g;
+                        if (s >= 0) {
+                            unsigned long long key = ((unsigned long long)s << 32) | (unsigned long long)(0xffffffffu - (uint32_t)j);
+                            if (key > best) best = key;
+                        }
+                    }
+                }
+                bcount += __popcll(nskip);
+            }
+            best = wave_max_u64(best);
+            long long m = a.len;
+            int mj = i;
+            if (best != 0) {
+                long long s = (long long)(best >> 32);
+                if (s >= m) {
+                    m = s;
+                    mj = (int)(0xffffffffu - (uint32_t)(best & 0xffffffffu));
+                }
+            }
+            if (lane == 0) msi[i] = ((uint64_t)m << 32) | (uint64_t)(uint32_t)mj;
+            if (m > M) {
+                M = m;
+                Mi = i;
+            }
+        }
+        __syncthreads();
+        // ---- backtrack with the explicit region stack (lane 0), identical to lm_run_chain2's second half ----
+        if (lane == 0) {
+            int nout = 0;
+            if (M >= (long long)opt.min_score) {
+                int32_t *stack = stack_pool + 2 * o + 4 * ti;
+                int sp = 0;
+                stack[sp++] = 0;
+                stack[sp++] = n;
+                int pending_Mi0 = Mi;
+                while (sp > 0) {
+                    int hi = stack[--sp];
+                    int lo = stack[--sp];
+                    int mi;
+                    if (pending_Mi0 >= 0) {
+                        mi = pending_Mi0;
+                        pending_Mi0 = -1;
+                    } else {
+                        long long bestm = 0;
+                        mi = lo;
+                        for (int i = lo; i < hi; i++) {
+                            long long m = (long long)(msi[i] >> 32);
+                            if (m > bestm) {
+                                bestm = m;
+                                mi = i;
+                            }
+                        }
+                        if (bestm < (long long)opt.min_score) continue;
+                    }
+                    int n_matched = 0, n_abq = 0, n_abt = 0;
+                    int i = mi, j = 0;
+                    int32_t qb = 0, qe = 0, tb = 0, te = 0;
+                    int begin_of_next = 0;
+                    bool first_anchor = true, jneg = false;
+                    int n_anchors = 0;
+                    while (true) {
+                        j = (int)(msi[i] & 4294967295ull);
+                        if (j < lo) {
+                            jneg = true;
+                            break;
+                        }
+                        const LmSub sub = a_[i];
+                        n_anchors++;
+                        if (first_anchor) {
+                            first_anchor = false;
+                            qe = sub.qbegin + (int32_t)sub.len - 1;
+                            te = sub.tbegin + (int32_t)sub.len - 1;
+                            qb = sub.qbegin;
+                            tb = sub.tbegin;
+                            n_matched += sub.len;
+                        } else {
+                            qb = sub.qbegin;
+                            tb = sub.tbegin;
+                            if ((int)sub.qbegin + (int)sub.len - 1 >= begin_of_next)
+                                n_matched += begin_of_next - (int)sub.qbegin;
+                            else
+                                n_matched += sub.len;
+                        }
+                        begin_of_next = sub.qbegin;
+                        if (i == j) {
+                            n_abq += (int)qe - (int)qb + 1;
+                            if (n_abq < opt.min_align_len) break;
+                            n_abt += (int)te - (int)tb + 1;
+                            double pident = (double)n_matched / (double)(n_abq > n_abt ? n_abq : n_abt) * 100;
+                            if (pident < opt.heuristic_pident) break;
+                            if (pident > 100) pident = 100;
+                            LmChain2 p;
+                            p.nanchors = n_anchors;
+                            p.aligned_bases_q = n_abq;
+                            p.aligned_bases_t = n_abt;
+                            p.matched_bases = n_matched;
+                            p.pident = pident;
+                            p.qbegin = qb;
+                            p.qend = qe;
+                            p.tbegin = tb;
+                            p.tend = te;
+                            res[nout++] = p;
+                            break;
+                        }
+                        i = j;
+                    }
+                    if (jneg && n_anchors > 0) {
+                        n_abq += (int)qe - (int)qb + 1;
+                        n_abt += (int)te - (int)tb + 1;
+                        if (n_abq >= opt.min_align_len) {
+                            double pident = (double)n_matched / (double)(n_abq > n_abt ? n_abq : n_abt) * 100;
+                            if (pident >= opt.heuristic_pident) {
+                                if (pident > 100) pident = 100;
+                                LmChain2 p;
+                                p.nanchors = n_anchors;
+                                p.aligned_bases_q = n_abq;
+                                p.aligned_bases_t = n_abt;
+                                p.matched_bases = n_matched;
+                                p.pident = pident;
+                                p.qbegin = qb;
+                                p.qend = qe;
+                                p.tbegin = tb;
+                                p.tend = te;
+                                res[nout++] = p;
+                            }
+                        }
+                    }
+                    if (i > lo) {
+                        stack[sp++] = lo;
+                        stack[sp++] = i;
+                    }
+                    if (mi != hi - 1) {
+                        stack[sp++] = mi + 1;
+                        stack[sp++] = hi;
+                    }
+                }
+                for (int i = 1; i < nout; i++) { // stable sort by QBegin (lib-seq_compare.go:501-508)
+                    LmChain2 x = res[i];
+                    int j = i - 1;
+                    while (j >= 0 && res[j].qbegin > x.qbegin) {
+                        res[j + 1] = res[j];
+                        j--;
+                    }
+                    res[j + 1] = x;
+                }
+            }
+            out_n[ti] = nout;
+        }
     }
 }
 
@@ -872,6 +1173,340 @@ __global__ __launch_bounds__(64) void k_wfa_wave(const WfaIn *__restrict__ in, i
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// LDS-staged WFA: the last 9 M-wavefronts and the last 3 I/D-wavefronts (all the recurrence ever reads) live in an LDS
+// ring together with their headers; global memory only receives the offsets needed by the backtrace (coalesced
+// stores, no dependent global loads in the score loop except the sequence bytes).  Wavefronts wider than WFA_W fall
+// back to k_wfa_wave (status 3).  Semantics identical to lm_wfa_align.
+#define WFA_W 128
+#define WFA_NC (WFA_W / 64)
+
+struct WfHdr {
+    int lo, hi, alo; // valid range, allocation base diagonal
+};
+
+__device__ __forceinline__ int32_t lds_val(const int32_t *ring, const WfHdr &h, int k) {
+    return (k < h.lo || k > h.hi) ? LM_NULL_OFF : ring[k - h.alo];
+}
+
+__device__ __forceinline__ void lds_trim(WfHdr &h, const int32_t *ring, int plen, int tlen, int lane) {
+    auto valid = [&](int k) {
+        int32_t off = ring[k - h.alo];
+        return (uint32_t)off <= (uint32_t)tlen && (uint32_t)(off - k) <= (uint32_t)plen;
+    };
+    int nhi = wave_find_last(h.hi, h.lo - 1, lane, valid);
+    int nlo = wave_find_first(h.lo, nhi + 1, lane, valid);
+    if (nhi < h.lo) nlo = h.lo;
+    h.lo = nlo;
+    h.hi = nhi;
+}
+
+// One wavefront per workgroup: LDS traffic of a single wave is processed in issue order, so cross-lane LDS hand-offs
+// only need the compiler not to reorder them. A workgroup barrier would also drain the outstanding global stores
+// (s_waitcnt vmcnt(0)) of the backtrace store on every score step, which is what this avoids.
+#define LDS_WAVE_SYNC()                                        \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+
+__global__ __launch_bounds__(64) void k_wfa_lds(const WfaIn *__restrict__ in, int64_t n, const int32_t *__restrict__ todo,
+                                                 int64_t ntodo, int32_t *__restrict__ hdr_pool,
+                                                 int32_t *__restrict__ arena_pool, uint64_t *__restrict__ ops_pool,
+                                                 WfaOut *__restrict__ out) {
+    __shared__ int32_t ringM[9][WFA_W];
+    __shared__ int32_t ringI[3][WFA_W];
+    __shared__ int32_t ringD[3][WFA_W];
+    __shared__ int32_t shM[9][4], shI[3][4], shD[3][4];
+    const int lane = threadIdx.x;
+    const int X = 4, OE = 8, E = 2;
+    for (int64_t x = blockIdx.x; x < ntodo; x += gridDim.x) {
+        int64_t i = todo ? todo[x] : x;
+        if (i >= n) continue;
+        const WfaIn w = in[i];
+        const uint8_t *__restrict__ q = w.q;
+        const uint8_t *__restrict__ t = w.t;
+        const int plen = w.qlen, tlen = w.tlen;
+        int32_t *hdr = hdr_pool + w.hdr_off;
+        int32_t *arena = arena_pool + w.arena_off;
+        const int64_t arena_cap = w.arena_cap;
+        const int max_score = w.max_score;
+        const int ak = tlen - plen;
+        // headers of the ring slots live in LDS as well (wave-uniform broadcast reads; lane 0 writes)
+        auto getM = [&](int slot) -> WfHdr { return WfHdr{shM[slot][0], shM[slot][1], shM[slot][2]}; };
+        auto setM = [&](int slot, WfHdr v) {
+            if (lane == 0) {
+                shM[slot][0] = v.lo;
+                shM[slot][1] = v.hi;
+                shM[slot][2] = v.alo;
+            }
+        };
+        auto get3 = [&](int32_t(*a)[4], int slot) -> WfHdr { return WfHdr{a[slot][0], a[slot][1], a[slot][2]}; };
+        auto set3 = [&](int32_t(*a)[4], int slot, WfHdr v) {
+            if (lane == 0) {
+                a[slot][0] = v.lo;
+                a[slot][1] = v.hi;
+                a[slot][2] = v.alo;
+            }
+        };
+        int32_t(*hI)[4] = shI;
+        int32_t(*hD)[4] = shD;
+        LDS_WAVE_SYNC();
+        if (lane < 9) {
+            shM[lane][0] = 1;
+            shM[lane][1] = -1;
+            shM[lane][2] = 0;
+        }
+        if (lane < 3) {
+            shI[lane][0] = shD[lane][0] = 1;
+            shI[lane][1] = shD[lane][1] = -1;
+            shI[lane][2] = shD[lane][2] = 0;
+        }
+        LDS_WAVE_SYNC();
+        int status = 0;
+        int64_t used = 1;
+        int64_t gbM = 0, gbI = 0, gbD = 0; // global bases (arena index of diagonal `alo`) of the current score
+        bool pend = false;
+        int plo = 0, phi = -1;
+        int32_t pvi[WFA_NC], pvd[WFA_NC];
+        LDS_WAVE_SYNC();
+        if (max_score < 1 || arena_cap < 1) status = 1;
+        setM(0, {0, 0, 0});
+        if (lane == 0) ringM[0][0] = 0;
+        int s = 0;
+        while (status == 0) {
+            LDS_WAVE_SYNC();
+            const int ms = s % 9, is = s % 3;
+            WfHdr m = getM(ms);
+            bool done = false;
+            auto flush_pending = [&]() { // deferred global stores of I[s], D[s] (gbI/gbD still describe score s)
+                if (pend) {
+#pragma unroll
+                    for (int c = 0; c < WFA_NC; c++) {
+                        int k = plo + lane + 64 * c;
+                        if (k <= phi) {
+                            arena[gbI + (k - plo)] = pvi[c];
+                            arena[gbD + (k - plo)] = pvd[c];
+                        }
+                    }
+                    pend = false;
+                }
+            };
+            if (m.lo > m.hi) flush_pending();
+            if (m.lo <= m.hi) {
+                int32_t *rm = ringM[ms];
+                int32_t eo[WFA_NC];
+#pragma unroll
+                for (int c = 0; c < WFA_NC; c++) {
+                    int k = m.lo + lane + 64 * c;
+                    eo[c] = LM_NULL_OFF;
+                    if (k > m.hi) continue;
+                    int32_t off = rm[k - m.alo];
+                    if (off >= 0) {
+                        int v = off - k, h = off;
+                        bool fin = false;
+                        while (v + 8 <= plen && h + 8 <= tlen) {
+                            uint64_t a, b;
+                            __builtin_memcpy(&a, q + v, 8);
+                            __builtin_memcpy(&b, t + h, 8);
+                            uint64_t d = a ^ b;
+                            if (d) {
+                                int nb = __builtin_ctzll(d) >> 3;
+                                v += nb;
+                                h += nb;
+                                fin = true;
+                                break;
+                            }
+                            v += 8;
+                            h += 8;
+                        }
+                        if (!fin)
+                            while (v < plen && h < tlen && q[v] == t[h]) {
+                                v++;
+                                h++;
+                            }
+                        off = h;
+                        rm[k - m.alo] = off;
+                    }
+                    eo[c] = off;
+                }
+                // all sequence loads of this step are done: now issue the stores of M[s] (and of I[s], D[s] below)
+#pragma unroll
+                for (int c = 0; c < WFA_NC; c++) {
+                    int k = m.lo + lane + 64 * c;
+                    if (k <= m.hi) arena[gbM + (k - m.alo)] = eo[c];
+                }
+                flush_pending();
+                LDS_WAVE_SYNC();
+                if (m.lo <= ak && ak <= m.hi && rm[ak - m.alo] >= tlen) {
+                    done = true;
+                } else if (m.hi - m.lo + 1 >= 10) {
+                    int dmin = 2147483647;
+#pragma unroll
+                    for (int c = 0; c < WFA_NC; c++) {
+                        int k = m.lo + lane + 64 * c;
+                        if (k <= m.hi) {
+                            int d = wf_dist(rm[k - m.alo], k, plen, tlen);
+                            dmin = d < dmin ? d : dmin;
+                        }
+                    }
+                    dmin = wave_min_i32(dmin);
+                    auto keep = [&](int k) { return wf_dist(rm[k - m.alo], k, plen, tlen) - dmin <= 50; };
+                    int nlo = m.lo, nhi = m.hi;
+                    int top = ak < m.hi ? ak : m.hi;
+                    if (m.lo < top) nlo = wave_find_first(m.lo, top, lane, keep);
+                    int bottom = ak > nlo ? ak : nlo;
+                    if (m.hi > bottom) nhi = wave_find_last(m.hi, bottom, lane, keep);
+                    m.lo = nlo;
+                    m.hi = nhi;
+                    setM(ms, m);
+                    WfHdr hi_ = get3(hI, is), hd_ = get3(hD, is);
+                    if (hi_.lo <= hi_.hi) {
+                        if (nlo > hi_.lo) hi_.lo = nlo;
+                        if (nhi < hi_.hi) hi_.hi = nhi;
+                        set3(hI, is, hi_);
+                    }
+                    if (hd_.lo <= hd_.hi) {
+                        if (nlo > hd_.lo) hd_.lo = nlo;
+                        if (nhi < hd_.hi) hd_.hi = nhi;
+                        set3(hD, is, hd_);
+                    }
+                }
+            }
+            // global header of score s (final after extension / cut-off)
+            if (lane == 0) {
+                WfHdr hi_ = get3(hI, is), hd_ = get3(hD, is);
+                int32_t *ho = hdr + s * 9;
+                ho[0] = m.lo; ho[1] = m.hi; ho[2] = (int32_t)(gbM + (m.lo - m.alo));
+                ho[3] = hi_.lo; ho[4] = hi_.hi; ho[5] = (int32_t)(gbI + (hi_.lo - hi_.alo));
+                ho[6] = hd_.lo; ho[7] = hd_.hi; ho[8] = (int32_t)(gbD + (hd_.lo - hd_.alo));
+            }
+            if (done) break;
+            s++;
+            if (s >= max_score) {
+                status = 1;
+                break;
+            }
+            // ---- compute score s from the LDS ring ----
+            const int ns = s % 9, nis = s % 3;
+            WfHdr mm = s - X >= 0 ? getM((s - X) % 9) : WfHdr{1, -1, 0};
+            WfHdr mo = s - OE >= 0 ? getM((s - OE) % 9) : WfHdr{1, -1, 0};
+            WfHdr ie = s - E >= 0 ? get3(hI, (s - E) % 3) : WfHdr{1, -1, 0};
+            WfHdr de = s - E >= 0 ? get3(hD, (s - E) % 3) : WfHdr{1, -1, 0};
+            int lo = 2147483647, hi = -2147483647;
+            bool any = false;
+            if (mm.lo <= mm.hi) { any = true; lo = mm.lo < lo ? mm.lo : lo; hi = mm.hi > hi ? mm.hi : hi; }
+            if (mo.lo <= mo.hi) { any = true; lo = mo.lo - 1 < lo ? mo.lo - 1 : lo; hi = mo.hi + 1 > hi ? mo.hi + 1 : hi; }
+            if (ie.lo <= ie.hi) { any = true; lo = ie.lo + 1 < lo ? ie.lo + 1 : lo; hi = ie.hi + 1 > hi ? ie.hi + 1 : hi; }
+            if (de.lo <= de.hi) { any = true; lo = de.lo - 1 < lo ? de.lo - 1 : lo; hi = de.hi - 1 > hi ? de.hi - 1 : hi; }
+            if (!any || lo > hi) {
+                setM(ns, {1, -1, 0});
+                set3(hI, nis, {1, -1, 0});
+                set3(hD, nis, {1, -1, 0});
+                gbM = gbI = gbD = 0;
+                continue;
+            }
+            int wd = hi - lo + 1;
+            if (wd > WFA_W) {
+                status = 3;
+                break;
+            }
+            if (used + 3ll * wd > arena_cap) {
+                status = 1;
+                break;
+            }
+            gbM = used;
+            gbI = used + wd;
+            gbD = used + 2ll * wd;
+            used += 3ll * wd;
+            const int32_t *rmm = ringM[(s - X + 9) % 9], *rmo = ringM[(s - OE + 18) % 9];
+            const int32_t *rie = ringI[(s - E + 3) % 3], *rde = ringD[(s - E + 3) % 3];
+            int32_t vi[WFA_NC], vd[WFA_NC], vm[WFA_NC];
+#pragma unroll
+            for (int c = 0; c < WFA_NC; c++) {
+                int k = lo + lane + 64 * c;
+                vi[c] = vd[c] = vm[c] = LM_NULL_OFF;
+                if (k > hi) continue;
+                int32_t a = lds_val(rmo, mo, k - 1), b = lds_val(rie, ie, k - 1);
+                int32_t ins = (a > b ? a : b) + 1;
+                a = lds_val(rmo, mo, k + 1);
+                b = lds_val(rde, de, k + 1);
+                int32_t del = a > b ? a : b;
+                int32_t mis = lds_val(rmm, mm, k) + 1;
+                int32_t mx = mis > ins ? mis : ins;
+                if (del > mx) mx = del;
+                uint32_t hh = (uint32_t)mx, vv = (uint32_t)(mx - k);
+                if (hh > (uint32_t)tlen) mx = LM_NULL_OFF;
+                if (vv > (uint32_t)plen) mx = LM_NULL_OFF;
+                vi[c] = ins;
+                vd[c] = del;
+                vm[c] = mx;
+            }
+            LDS_WAVE_SYNC(); // all reads of the ring done before slot ns / nis are overwritten
+#pragma unroll
+            for (int c = 0; c < WFA_NC; c++) {
+                int k = lo + lane + 64 * c;
+                if (k > hi) continue;
+                ringI[nis][k - lo] = vi[c];
+                ringD[nis][k - lo] = vd[c];
+                ringM[ns][k - lo] = vm[c];
+                pvi[c] = vi[c];
+                pvd[c] = vd[c];
+            }
+            pend = true; // the I/D stores of this score are issued after the next extension's loads (see below)
+            plo = lo;
+            phi = hi;
+            LDS_WAVE_SYNC();
+            WfHdr nm = {lo, hi, lo}, ni = {lo, hi, lo}, nd = {lo, hi, lo};
+            lds_trim(nm, ringM[ns], plen, tlen, lane);
+            lds_trim(ni, ringI[nis], plen, tlen, lane);
+            lds_trim(nd, ringD[nis], plen, tlen, lane);
+            setM(ns, nm);
+            set3(hI, nis, ni);
+            set3(hD, nis, nd);
+            // M of a null range still needs its (never read) arena cells defined for the store in the next iteration
+        }
+        __syncthreads(); // the backtrace (lane 0) reads what every lane stored to global memory
+        if (lane == 0) {
+            WfaOut o;
+            o.blast_score = 0;
+            if (status != 0) {
+                o.r.status = status;
+                o.r.score = 0;
+                o.r.nops = 0;
+                o.r.qbegin = o.r.qend = o.r.tbegin = o.r.tend = 0;
+                o.r.align_len = o.r.matches = o.r.gaps = o.r.gap_regions = 0;
+            } else {
+                uint64_t *ops = ops_pool + w.ops_off;
+                lm_wfa_backtrace(hdr, arena, s, plen, tlen, ops, w.ops_cap, &o.r);
+                if (o.r.status == 0) {
+                    int first = -1, last = -1;
+                    for (int j = 0; j < o.r.nops; j++)
+                        if ((ops[j] >> 32) == 'M') {
+                            if (first < 0) first = j;
+                            last = j;
+                        }
+                    int score = 0;
+                    for (int j = first; j >= 0 && j <= last; j++) {
+                        int nn = (int)(ops[j] & 0xffffffffu);
+                        char op = (char)(ops[j] >> 32);
+                        if (op == 'M')
+                            score += nn * 2;
+                        else if (op == 'X')
+                            score += nn * -3;
+                        else
+                            score -= 5 + nn * 2;
+                    }
+                    o.blast_score = score;
+                }
+            }
+            out[i] = o;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // host-callable launchers
 static inline int grid_for(int64_t n, int block, int maxb = 2048 * 8) {
@@ -932,19 +1567,23 @@ void launch_extract_windows(hipStream_t st, DevIndexView ix, const Task *tasks, 
     int g = (int)(ntasks < 1 ? 1 : (ntasks > 1048576 ? 1048576 : ntasks));
     hipLaunchKernelGGL(k_extract_windows, dim3(g), dim3(256), 0, st, ix, tasks, ntasks, wbuf);
 }
+void launch_build_cmp_tab(hipStream_t st, const uint64_t *keys_cmp, const int64_t *posoff, const int32_t *nvalid, int nq,
+                          int K, uint32_t *tab) {
+    LM_LAUNCH_1D(k_build_cmp_tab, (int64_t)nq * ((1 << LM_TAB_BITS) + 1), st, keys_cmp, posoff, nvalid, nq, K, LM_TAB_BITS, tab);
+}
 void launch_pa_count(hipStream_t st, const Task *tasks, int64_t ntasks, const uint8_t *wbuf, const uint64_t *keys_cmp,
-                     const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid, int K, int min_prefix,
-                     uint32_t *counts) {
+                     const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_tab, int K,
+                     int min_prefix, uint32_t *counts) {
     int g = (int)(ntasks < 1 ? 1 : (ntasks > 1048576 ? 1048576 : ntasks));
-    hipLaunchKernelGGL(k_pa_count, dim3(g), dim3(256), 0, st, tasks, ntasks, wbuf, keys_cmp, vals_cmp, posoff, nvalid, K,
-                       min_prefix, counts);
+    hipLaunchKernelGGL(k_pa_count, dim3(g), dim3(256), 0, st, tasks, ntasks, wbuf, keys_cmp, vals_cmp, posoff, nvalid, cmp_tab,
+                       K, min_prefix, counts);
 }
 void launch_pa_emit(hipStream_t st, const Task *tasks, int64_t ntasks, const uint8_t *wbuf, const uint64_t *keys_cmp,
-                    const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid, int K, int min_prefix,
-                    const uint32_t *counts, const int64_t *offs, uint64_t *outA, uint64_t *outB) {
+                    const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_tab, int K,
+                    int min_prefix, const uint32_t *counts, const int64_t *offs, uint64_t *outA, uint64_t *outB) {
     int g = (int)(ntasks < 1 ? 1 : (ntasks > 1048576 ? 1048576 : ntasks));
-    hipLaunchKernelGGL(k_pa_emit, dim3(g), dim3(256), 0, st, tasks, ntasks, wbuf, keys_cmp, vals_cmp, posoff, nvalid, K,
-                       min_prefix, counts, offs, outA, outB);
+    hipLaunchKernelGGL(k_pa_emit, dim3(g), dim3(256), 0, st, tasks, ntasks, wbuf, keys_cmp, vals_cmp, posoff, nvalid, cmp_tab,
+                       K, min_prefix, counts, offs, outA, outB);
 }
 void launch_pa_task_off(hipStream_t st, const Task *tasks, int64_t ntasks, const int64_t *offs, int64_t total_pos,
                         int64_t total_anchors, int64_t *pa_off) {
@@ -953,8 +1592,9 @@ void launch_pa_task_off(hipStream_t st, const Task *tasks, int64_t ntasks, const
 void launch_pa_chain(hipStream_t st, const uint64_t *B, const int64_t *pa_off, int64_t ntasks, int K, LmChain2Opt opt,
                      LmSub *subs, uint8_t *marks, uint64_t *msi, int32_t *stack, LmChain2 *out, int32_t *out_n,
                      int32_t *clr_n) {
-    hipLaunchKernelGGL(k_pa_chain, dim3(grid_for(ntasks, 64)), dim3(64), 0, st, B, pa_off, ntasks, K, opt, subs, marks, msi,
-                       stack, out, out_n, clr_n);
+    int g = (int)(ntasks < 1 ? 1 : (ntasks > 262144 ? 262144 : ntasks));
+    hipLaunchKernelGGL(k_pa_chain_wave, dim3(g), dim3(64), 0, st, B, pa_off, ntasks, K, opt, subs, marks, msi, stack, out, out_n,
+                       clr_n);
 }
 void launch_gather_chain2(hipStream_t st, const LmChain2 *in, const int64_t *pa_off, const int32_t *out_n,
                           const int64_t *res_off, int64_t ntasks, LmChain2 *out) {
@@ -973,6 +1613,11 @@ void launch_extend(hipStream_t st, const HspIn *hsps, int64_t n, const uint8_t *
 void launch_wfa(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int32_t *hdr_pool,
                 int32_t *arena_pool, uint64_t *ops_pool, WfaOut *out) {
     // one wavefront per alignment; enough workgroups to fill 256 CUs x 32 waves
+    int g = (int)(ntodo < 1 ? 1 : (ntodo > 65536 ? 65536 : ntodo));
+    hipLaunchKernelGGL(k_wfa_lds, dim3(g), dim3(64), 0, st, in, n, todo, ntodo, hdr_pool, arena_pool, ops_pool, out);
+}
+void launch_wfa_wide(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int32_t *hdr_pool,
+                     int32_t *arena_pool, uint64_t *ops_pool, WfaOut *out) {
     int g = (int)(ntodo < 1 ? 1 : (ntodo > 65536 ? 65536 : ntodo));
     hipLaunchKernelGGL(k_wfa_wave, dim3(g), dim3(64), 0, st, in, n, todo, ntodo, hdr_pool, arena_pool, ops_pool, out);
 }

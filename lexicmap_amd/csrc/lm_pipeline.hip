@@ -207,7 +207,7 @@ struct Work {
     lm_qbatch *qb;
     // stage A
     DBuf<uint64_t> keys_all, keys_all2, keys_cmp, keys_cmp2;
-    DBuf<uint32_t> vals_all, vals_all2, vals_cmp, vals_cmp2, first_mask;
+    DBuf<uint32_t> vals_all, vals_all2, vals_cmp, vals_cmp2, first_mask, cmp_tab;
     DBuf<int32_t> nvalid;
     uint64_t *k_all = nullptr, *k_cmp = nullptr; // sorted
     uint32_t *v_all = nullptr, *v_cmp = nullptr;
@@ -296,6 +296,8 @@ static void stage_kmers(Work &w) {
     w.v_all = w.vals_all2.p;
     w.k_cmp = w.keys_cmp2.p;
     w.v_cmp = w.vals_cmp2.p;
+    w.cmp_tab.ensure((size_t)qb->nq * ((1 << LM_TAB_BITS) + 1));
+    launch_build_cmp_tab(ix->st, w.k_cmp, qb->d_posoff.p, w.nvalid.p, qb->nq, ix->host.k, w.cmp_tab.p);
 }
 
 static void stage_mask(Work &w) {
@@ -867,11 +869,12 @@ struct AlignCtx {
     DBuf<LmSub> ext_subs;
     DBuf<WfaIn> wfa_in;
     DBuf<WfaOut> wfa_out;
-    DBuf<int32_t> wfa_todo, hdr_pool, arena_pool;
+    DBuf<int32_t> wfa_todo, wfa_todo2, hdr_pool, arena_pool;
     DBuf<uint64_t> ops_pool;
 };
 
 struct HspMeta { // host-side view of one WFA problem
+    float est_div; // divergence implied by the pseudo-alignment identity (scratch sizing only)
     int64_t task;
     uint32_t q;
     HspIn in;
@@ -904,7 +907,7 @@ static void run_pseudo(AlignCtx &a, const std::vector<Task> &ht, std::vector<int
     {
         Prof p(ix, "k_pa_count", W);
         launch_pa_count(ix->st, a.tasks.p, nt, a.wbuf.p, a.w->k_cmp, a.w->v_cmp, qb->d_posoff.p, a.w->nvalid.p,
-                        ix->host.k, 11, a.pa_counts.p);
+                        a.w->cmp_tab.p, ix->host.k, 11, a.pa_counts.p);
     }
     int64_t TP = scan_to_i64<uint32_t, CastU32>(ix, a.pa_counts.p, W, a.pa_offs.p);
     a.stats->pa_anchors += TP;
@@ -921,7 +924,7 @@ static void run_pseudo(AlignCtx &a, const std::vector<Task> &ht, std::vector<int
         {
             Prof p(ix, "k_pa_emit", TP * 16);
             launch_pa_emit(ix->st, a.tasks.p, nt, a.wbuf.p, a.w->k_cmp, a.w->v_cmp, qb->d_posoff.p, a.w->nvalid.p,
-                           ix->host.k, 11, a.pa_counts.p, a.pa_offs.p, a.A0.p, a.B0.p);
+                           a.w->cmp_tab.p, ix->host.k, 11, a.pa_counts.p, a.pa_offs.p, a.A0.p, a.B0.p);
         }
         {
             Prof p(ix, "sort_pa_anchors");
@@ -959,9 +962,50 @@ static void run_pseudo(AlignCtx &a, const std::vector<Task> &ht, std::vector<int
     }
 }
 
+// algorithmic bytes of WFA: both sequences are read once, 2*(len_q+len_t)
+static int64_t wfa_bytes(const std::vector<WfaIn> &in, const std::vector<int32_t> &ids) {
+    int64_t b = 0;
+    for (int32_t i : ids) b += 2ll * ((int64_t)in[i].qlen + in[i].tlen);
+    return b;
+}
+
 // WFA for a list of problems already described by device pointers; retries with more memory on overflow.
+// expected number of wavefront cells (M+I+D) up to score s: the width grows by 2 every gap-open step until the
+// wf-adaptive cut-off (max distance 50) caps it at ~110 diagonals
+static int64_t wfa_cells(int64_t s) {
+    if (s <= 444) return 3 * (s + s * s / 8 + 1);
+    return 3 * (444 + 24642 + (s - 444) * 112);
+}
+// divergence implied by a pseudo-alignment identity (fraction of bases covered by exact >=11-mers):
+// f(d) = (1-d)^11 (1+11d), inverted by bisection
+static double div_from_pseudo_pident_slow(double pid) {
+    double x = pid / 100.0, lo = 0.0, hi = 0.6;
+    for (int it = 0; it < 40; it++) {
+        double mid = 0.5 * (lo + hi);
+        double f = std::pow(1.0 - mid, 11) * (1.0 + 11.0 * mid);
+        if (f > x)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return hi;
+}
+
+static double div_from_pseudo_pident(double pid) { // table over integer percent, built once
+    static float lut[102];
+    static bool init = false;
+    if (!init) {
+        for (int i = 0; i <= 101; i++) lut[i] = (float)div_from_pseudo_pident_slow((double)i);
+        init = true;
+    }
+    int i = (int)pid;
+    if (i < 0) i = 0;
+    if (i > 100) i = 100;
+    return lut[i]; // floor of the identity => slightly over-estimated divergence
+}
+
 static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &out, std::vector<uint64_t> &ops_h,
-                    std::vector<int64_t> &ops_off_h, bool want_ops) {
+                    std::vector<int64_t> &ops_off_h, bool want_ops, const std::vector<float> *est_div = nullptr) {
     lm_index *ix = a.ix;
     int64_t n = (int64_t)in.size();
     out.assign(n, WfaOut());
@@ -971,7 +1015,8 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
     std::vector<int32_t> todo(n);
     for (int64_t i = 0; i < n; i++) todo[i] = (int32_t)i;
     std::vector<int32_t> level(n, 0);
-    const int64_t budget = (int64_t)32 << 30; // bytes of scratch per launch
+    const int64_t budget = (int64_t)72 << 30; // bytes of scratch per launch (288 GB HBM: index + genomes + this)
+    std::vector<uint8_t> is_wide(n, 0);
     a.wfa_out.ensure((size_t)n);
     std::vector<std::vector<uint64_t>> ops_keep(want_ops ? n : 0);
     while (!todo.empty()) {
@@ -983,11 +1028,13 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
             int32_t i = todo[taken];
             WfaIn &w = in[i];
             int64_t L = (int64_t)w.qlen + w.tlen;
-            // first guess covers ~15% divergence; every retry quadruples the scratch
-            int64_t ms = (96 + L / 3) << (2 * level[i]);
+            // first guess from the divergence estimate (pseudo-alignment identity) with 40% head-room, every retry
+            // doubles the score bound (the cell estimate follows it)
+            double dv = est_div ? (double)(*est_div)[i] : 0.12;
+            int64_t ms = (int64_t)(96 + 1.4 * dv * 4.6 * (double)(L / 2) + 0.05 * (double)L) << level[i];
             if (ms > 8 * L + 64) ms = 8 * L + 64; // a global alignment never exceeds this penalty
-            int64_t ar = std::max<int64_t>(4096, ms * 420) << (2 * level[i]);
-            int64_t oc = std::min<int64_t>(L + 2, (128 + L / 4) << (2 * level[i]));
+            int64_t ar = std::max<int64_t>(4096, wfa_cells(ms) + wfa_cells(ms) / 4) << (level[i] > 2 ? level[i] - 2 : 0);
+            int64_t oc = std::min<int64_t>(L + 2, (int64_t)(128 + 3.0 * dv * (double)L) << level[i]);
             int64_t need = (ms * 9 + ar) * 4 + oc * 8;
             if (!cur.empty() && (hdr_tot * 9 + arena_tot) * 4 + ops_tot * 8 + need > budget) break;
             w.max_score = (int32_t)std::min<int64_t>(ms, 2000000000);
@@ -1008,11 +1055,23 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
         a.wfa_in.ensure((size_t)n);
         a.wfa_todo.ensure(cur.size());
         HIPCHK(hipMemcpyAsync(a.wfa_in.p, in.data(), sizeof(WfaIn) * n, hipMemcpyHostToDevice, ix->st));
-        HIPCHK(hipMemcpyAsync(a.wfa_todo.p, cur.data(), sizeof(int32_t) * cur.size(), hipMemcpyHostToDevice, ix->st));
         {
-            Prof p(ix, "k_wfa");
-            launch_wfa(ix->st, a.wfa_in.p, n, a.wfa_todo.p, (int64_t)cur.size(), a.hdr_pool.p, a.arena_pool.p,
-                       a.ops_pool.p, a.wfa_out.p);
+            // pass 1: LDS-ring kernel; pass 2 (rare): wavefronts wider than the ring, same scratch, global-memory ring
+            std::vector<int32_t> narrow, wide;
+            for (int32_t i : cur) (is_wide[i] ? wide : narrow).push_back(i);
+            if (!narrow.empty()) {
+                HIPCHK(hipMemcpyAsync(a.wfa_todo.p, narrow.data(), sizeof(int32_t) * narrow.size(), hipMemcpyHostToDevice, ix->st));
+                Prof p(ix, "k_wfa", wfa_bytes(in, narrow));
+                launch_wfa(ix->st, a.wfa_in.p, n, a.wfa_todo.p, (int64_t)narrow.size(), a.hdr_pool.p, a.arena_pool.p,
+                           a.ops_pool.p, a.wfa_out.p);
+            }
+            if (!wide.empty()) {
+                a.wfa_todo2.ensure(wide.size());
+                HIPCHK(hipMemcpyAsync(a.wfa_todo2.p, wide.data(), sizeof(int32_t) * wide.size(), hipMemcpyHostToDevice, ix->st));
+                Prof p(ix, "k_wfa_wide", wfa_bytes(in, wide));
+                launch_wfa_wide(ix->st, a.wfa_in.p, n, a.wfa_todo2.p, (int64_t)wide.size(), a.hdr_pool.p, a.arena_pool.p,
+                                a.ops_pool.p, a.wfa_out.p);
+            }
         }
         std::vector<WfaOut> tmp;
         d2h(ix, tmp, a.wfa_out.p, (size_t)n);
@@ -1020,7 +1079,11 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
         if (want_ops) d2h(ix, ops_tmp, a.ops_pool.p, (size_t)ops_tot);
         sync(ix);
         for (int32_t i : cur) {
-            if (tmp[i].r.status == 1) {
+            if (tmp[i].r.status == 3) { // wider than the LDS ring: rerun with the global-ring kernel, same scratch level
+                is_wide[i] = 1;
+                a.stats->wfa_retries++;
+                todo.push_back(i);
+            } else if (tmp[i].r.status == 1) {
                 level[i]++;
                 a.stats->wfa_retries++;
                 if (level[i] > 12) throw HipError("WFA scratch overflow after 12 retries");
@@ -1207,7 +1270,7 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
 
     // ---- alignment in chunks of whole segments ----
     AlignCtx &a = get_actx(ix, qb, &w, &st);
-    const int64_t max_window_bytes = (int64_t)192 << 20;
+    const int64_t max_window_bytes = (int64_t)2 << 30;
     std::vector<HGenome> genomes; // in (query, genome) order
     const int K = ix->host.k;
     const bool want_seq = ix->opt.output_seq != 0;
@@ -1292,6 +1355,7 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
                         ext2 += 10;
                     HspMeta h;
                     h.task = cl.task;
+                    h.est_div = (float)div_from_pseudo_pident(c.pident);
                     h.q = gen.q;
                     h.in.q = gen.q;
                     h.in.rc = cl.rc ? 1 : 0;
@@ -1348,7 +1412,9 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
                 win[i].qlen = hext[i].qe - hext[i].qs;
                 win[i].tlen = hext[i].te - hext[i].ts;
             }
-            run_wfa(a, win, wout, ops_h, ops_off_h, want_seq);
+            std::vector<float> est(NH);
+            for (int64_t i = 0; i < NH; i++) est[i] = hsps[i].est_div;
+            run_wfa(a, win, wout, ops_h, ops_off_h, want_seq, &est);
             if (want_seq) {
                 d2h(ix, wbuf_h, a.wbuf.p, (size_t)off);
                 sync(ix);
