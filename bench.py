@@ -205,29 +205,18 @@ def main():
     seqs = [q[1] for q in my]
     qb = gi.upload(seqs)  # bases resident in HBM before the timed region
 
-    def gather_rows(rows_count, aligned):
-        """merge per-rank hit lists: one all-gather of the per-rank row payload (here: counts + aligned bases; the
-        row payload itself is gathered as a byte tensor)"""
-        if world == 1:
-            return rows_count, aligned
-        t = torch.tensor([rows_count, aligned], dtype=torch.int64, device="cuda")
-        out = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(out, t)
-        return int(sum(o[0].item() for o in out)), int(sum(o[1].item() for o in out))
+    from lexicmap_amd import merge
 
-    def step(want_rows=False):
-        rows, st = gi.search_resident(qb, want_rows=want_rows)
+    def step():
+        """one pass of the hot path over this rank's resident batch, then (N>1) the hit-list merge: one all-gather of
+        the per-rank HSP row records over RCCL and the reference's final ordering"""
+        rows, st = gi.search_resident_np(qb)
         if world > 1:
-            # row payload all-gather (variable length): sizes then padded bytes
-            payload = torch.zeros(max(1, st["rows"]) * 96, dtype=torch.uint8, device="cuda")
-            sizes = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(world)]
-            dist.all_gather(sizes, torch.tensor([payload.numel()], dtype=torch.int64, device="cuda"))
-            mx = int(max(s.item() for s in sizes))
-            pad = torch.zeros(mx, dtype=torch.uint8, device="cuda")
-            pad[:payload.numel()] = payload
-            bufs = [torch.zeros(mx, dtype=torch.uint8, device="cuda") for _ in range(world)]
-            dist.all_gather(bufs, pad)
-        return st
+            if args.shard == "queries":
+                rows["query"] = rows["query"] * world + rank  # local -> global query number (round-robin sharding)
+            per_rank = merge.all_gather_rows(rows, device="cuda")
+            rows = merge.merge_sharded(per_rank) if args.shard == "index" else merge.merge_query_sharded(per_rank)
+        return rows, st
 
     for _ in range(args.warmup):
         step()
@@ -238,8 +227,9 @@ def main():
     torch.cuda.synchronize()
     t0 = time.time()
     stats = None
+    rows_np = None
     for _ in range(args.steps):
-        stats = step()
+        rows_np, stats = step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -250,7 +240,7 @@ def main():
         dt = float(tt.item())
     prof = gi.profile_get()
     gi.profile(False)
-    rows_total, aligned_total = gather_rows(stats["rows"], stats["aligned_bases"])
+    rows_total, aligned_total = int(len(rows_np)), int(rows_np["aligned_length"].sum())
 
     nq_total = len(queries)
     value = nq_total * args.steps / dt

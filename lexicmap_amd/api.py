@@ -232,6 +232,29 @@ class Index:
         L.lm_result_free(res)
         return out
 
+    def search_resident_np(self, qb):
+        """rows as a numpy structured array sharing the lm_hsp layout (fast path for bench / merging) + stats"""
+        import numpy as np
+        from .merge import ROW_DTYPE
+        L = lib()
+        res = C.c_void_p()
+        st = L.lm_search_resident(self.h, qb, C.byref(res))
+        if st != 0:
+            self._err(st)
+        rows_p = C.POINTER(Hsp)()
+        n = L.lm_result_rows(res, C.byref(rows_p))
+        stats = StageStats()
+        L.lm_result_stats(res, C.byref(stats))
+        if n:
+            buf = (C.c_char * (n * C.sizeof(Hsp))).from_address(C.addressof(rows_p.contents))
+            arr = np.frombuffer(buf, dtype=ROW_DTYPE).copy()
+        else:
+            arr = np.zeros(0, dtype=ROW_DTYPE)
+        for f in ("genome_id", "seq_id", "cigar", "qseq", "sseq", "align"):
+            arr[f] = 0  # pointers into the freed result / the index are not portable
+        L.lm_result_free(res)
+        return arr, {f[0]: getattr(stats, f[0]) for f in StageStats._fields_}
+
     def _collect(self, res, want_rows=True):
         L = lib()
         rows_p = C.POINTER(Hsp)()

@@ -919,7 +919,10 @@ LM_HD bool lm_tree_search_range_tab(const uint64_t *keys, int n, uint64_t key, i
 
 // ---------------------------------------------------------------------------------------------------------------
 // WFA, gap-affine (x=4,o=6,e=2), end-to-end, wf-adaptive(10,50,1), WFA2 backtrace priority — one work item.
-// Same semantics as oracle/lmo_wfa.c (see the header there for what is restated and from where).
+// Restates github.com/shenwei356/wfa v0.5.0 as used at lib-index-search.go:1910-1911,2261,2528 (not in the reference
+// tree): pattern = query (v), text = target (h), k = h - v, offset = h; 'I' consumes target, 'D' consumes query;
+// backtrace priority on equal offsets mismatch > D-ext > D-open > I-ext > I-open (WFA2 piggy-back codes); reads
+// outside a stored wavefront's [lo,hi] are NULL; cut-off applied after every extension.
 // Memory: `hdr` holds per score 3x(lo,hi,base) int32 = 9*max_score ints; `arena` holds offsets.
 struct LmWfaOut {
     int32_t status; // 0 ok, 1 arena/score overflow (retry with more memory), 2 no alignment

@@ -1,0 +1,287 @@
+"""The oracle pinned against the reference's own known-answer tests and golden files:
+  kv/kv-data_test.go:31-361   seed-file format + prefix range query (counts, exact hit)        -> test_kv_*
+  genome/genome_test.go:30-164 2-bit codec round trip + every (start,end) sub-sequence          -> test_genome_*
+  util/varint-GB_test.go:54-75 group-varint round trip                                           -> test_varint
+  tree/tree_test.go            Search == brute-force LCP filter (+ quirk documented separately)  -> test_tree
+  demo/*.tsv (committed under tests/golden/demo)                                                 -> test_demo_*
+These run on the CPU (no GPU)."""
+import ctypes as C
+import os
+import random
+
+import pytest
+
+import oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "demo")
+
+
+class KvRec(C.Structure):
+    _fields_ = [("kmer", C.c_uint64), ("vals", C.POINTER(C.c_uint64)), ("nvals", C.c_int)]
+
+
+class KvSr(C.Structure):
+    _fields_ = [("iquery", C.c_int), ("iquery2", C.c_int), ("len", C.c_uint8), ("is_suffix", C.c_uint8),
+                ("val_off", C.c_int64), ("nvals", C.c_int)]
+
+
+class KvResults(C.Structure):
+    _fields_ = [("sr", C.POINTER(KvSr)), ("n", C.c_int), ("cap", C.c_int), ("vals", C.POINTER(C.c_uint64)),
+                ("nv", C.c_int64), ("capv", C.c_int64)]
+
+
+def _kv_lib():
+    L = O.lib()
+    L.lmo_kv_write.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.POINTER(KvRec)), C.POINTER(C.c_int),
+                               C.c_int, C.c_int, C.c_int]
+    L.lmo_kv_load.restype = C.c_void_p
+    L.lmo_kv_load.argtypes = [C.c_char_p]
+    L.lmo_kv_free.argtypes = [C.c_void_p]
+    L.lmo_kv_search.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int, C.c_int, C.c_int, C.POINTER(KvResults)]
+    L.lmo_kv_results_free.argtypes = [C.POINTER(KvResults)]
+    L.lmo_kv_read_index.argtypes = [C.c_char_p] + [C.POINTER(C.c_int)] * 5 + [C.POINTER(C.POINTER(C.POINTER(C.c_uint64)))]
+    return L
+
+
+def test_kv_known_answer_of_reference_test(tmp_path):
+    """kv-data_test.go: K=5, maskPrefix=2, anchorPrefix=2, 4 masks, every k-mer CT|i (i<64) with value i, nbatches=512.
+    For p in {4,5}: the searcher returns exactly nMasks*4^(k-p) results and the exact hit has Len==k, Values[0]==i."""
+    L = _kv_lib()
+    k, lp, nmasks = 5, 2, 4
+    prefix = 0b0111 << ((k - lp) << 1)
+    n = 1 << ((k - lp) << 1)
+    keep = []
+    recs_p = (C.POINTER(KvRec) * nmasks)()
+    nrecs = (C.c_int * nmasks)()
+    for j in range(nmasks):
+        arr = (KvRec * n)()
+        for i in range(n):
+            v = (C.c_uint64 * 1)(i)
+            keep.append(v)
+            arr[i].kmer, arr[i].vals, arr[i].nvals = prefix | i, v, 1
+        keep.append(arr)
+        recs_p[j] = arr
+        nrecs[j] = n
+    f = str(tmp_path / "t.kv").encode()
+    assert L.lmo_kv_write(f, k, 0, nmasks, recs_p, nrecs, lp, 2, 512) == 0
+    # header bytes of the reference layout (kv-data.go:261-305)
+    raw = open(f, "rb").read()
+    assert raw[:8] == b".kv-data" and raw[8] == 1 and raw[10] == k and raw[11] == 1  # 7-byte values (nbatches<=512)
+    idx = open(f + b".idx", "rb").read()
+    assert idx[:8] == b".kvindex" and idx[11] == lp and idx[12] == 2
+    # dense anchor index: first record = (nRecords, firstOffset<<1)
+    kk, ci, cs, mp, ap = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    tabs = C.POINTER(C.POINTER(C.c_uint64))()
+    assert L.lmo_kv_read_index(f + b".idx", C.byref(kk), C.byref(ci), C.byref(cs), C.byref(mp), C.byref(ap),
+                               C.byref(tabs)) == 0
+    assert (kk.value, ci.value, cs.value, mp.value, ap.value) == (5, 0, 4, 2, 2)
+    # record 0 = (nRecords, firstOffset<<1); the 64 k-mers CT|i cover all 4^2 anchor partitions -> 1 + 16 records
+    assert tabs[0][0] == 17 and tabs[0][1] == (32 + 8) << 1
+    for a in range(16):
+        assert tabs[0][2 + 2 * a] == prefix | (a << 2)  # first k-mer of each anchor partition (kv-data.go:413-434)
+    m = L.lmo_kv_load(f)
+    assert m
+    kmers = (C.c_uint64 * nmasks)()
+    for p in (4, 5):
+        for i in range(1, n - 1):
+            for j in range(nmasks):
+                kmers[j] = prefix | i
+            res = KvResults()
+            assert L.lmo_kv_search(m, kmers, p, 0, 0, C.byref(res)) == 0
+            assert res.n == nmasks * (1 << ((k - p) << 1))
+            hit = [res.vals[res.sr[r].val_off] for r in range(res.n) if res.sr[r].len == k]
+            assert hit == [i] * nmasks
+            L.lmo_kv_results_free(C.byref(res))
+    L.lmo_kv_free(m)
+
+
+def test_kv_reverse_flag_filter_and_8byte_values(tmp_path):
+    """checkFlag semantics of kv-searcher2.go:302 (per value) and the 8-byte value layout used when nbatches > 512"""
+    L = _kv_lib()
+    k, mp, ap = 31, 3, 2
+    rng = random.Random(4)
+    base = rng.getrandbits(62) & ~((1 << 40) - 1)
+    kms = sorted({base | rng.getrandbits(40) for _ in range(301)})
+    keep = []
+    arr = (KvRec * len(kms))()
+    for i, x in enumerate(kms):
+        vs = [(rng.getrandbits(63) & ~1) | (j & 1) for j in range(1 + i % 3)]
+        v = (C.c_uint64 * len(vs))(*vs)
+        keep.append(v)
+        arr[i].kmer, arr[i].vals, arr[i].nvals = x, v, len(vs)
+    recs_p = (C.POINTER(KvRec) * 1)(arr)
+    nrecs = (C.c_int * 1)(len(kms))
+    f = str(tmp_path / "u.kv").encode()
+    assert L.lmo_kv_write(f, k, 0, 1, recs_p, nrecs, mp, ap, 600) == 0
+    assert open(f, "rb").read()[11] == 0  # 8-byte values
+    m = L.lmo_kv_load(f)
+    q = (C.c_uint64 * 1)(kms[150])
+    for rv in (0, 1):
+        res = KvResults()
+        L.lmo_kv_search(m, q, 12, 1, rv, C.byref(res))
+        got = sorted(res.vals[i] for i in range(res.nv))
+        lo, hi = kms[150] & ~((1 << 38) - 1), kms[150] | ((1 << 38) - 1)
+        exp = sorted(arr[i].vals[j] for i in range(len(kms)) if lo <= kms[i] <= hi for j in range(arr[i].nvals)
+                     if arr[i].vals[j] & 1 == rv)
+        assert got == exp
+        L.lmo_kv_results_free(C.byref(res))
+    L.lmo_kv_free(m)
+
+
+def test_varint_gb_round_trip():
+    L = O.lib()
+    L.lmo_put_uint64s.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint8)]
+    L.lmo_get_uint64s.argtypes = [C.c_uint8, C.c_char_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    rng = random.Random(0)
+    cases = [(0, 0), (1, 255), (256, 65535), (1 << 63, (1 << 64) - 1)] + \
+            [(rng.getrandbits(rng.randint(1, 64)), rng.getrandbits(rng.randint(1, 64))) for _ in range(2000)]
+    buf = C.create_string_buffer(16)
+    for a, b in cases:
+        ctrl = C.c_uint8()
+        n = L.lmo_put_uint64s(buf, a, b, C.byref(ctrl))
+        assert n == ((ctrl.value >> 3) & 7) + (ctrl.value & 7) + 2  # CtrlByte2ByteLengthsUint64
+        v1, v2 = C.c_uint64(), C.c_uint64()
+        assert L.lmo_get_uint64s(ctrl, buf.raw[:n], n, C.byref(v1), C.byref(v2)) == n
+        assert (v1.value, v2.value) == (a, b)
+
+
+SEQS = [b"A", b"C", b"CA", b"CAT", b"CATG", b"CATGC", b"CATGCC", b"CATGCCA", b"CATGCCAC", b"CATGCCACG",
+        b"ACCCTCGAGCGACTAG", b"ACTAGACGACGTACGCGTACGTAGTACGATGCTCGA",
+        b"ACGCAGTCGTCATCATGCGTGTCGCATGAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAACATGCTGCATGC"
+        b"AAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAATGCTGTGATGCGTCTCAGTAGATGAT"]
+
+
+def test_genome_twobit_round_trip_all_prefixes():
+    """genome_test.go:30-50"""
+    L = O.lib()
+    L.lmo_seq2twobit.argtypes = [C.c_char_p, C.c_int, C.c_char_p]
+    L.lmo_twobit2seq.argtypes = [C.c_char_p, C.c_int, C.c_char_p]
+    s = b"ACTAGACGACGTACGCGTACGTAGTACGATGCTCGA"
+    for n in range(1, len(s)):
+        b2 = C.create_string_buffer(n)
+        nb = L.lmo_seq2twobit(s[:n], n, b2)
+        assert nb == (n + 3) // 4
+        out = C.create_string_buffer(n)
+        L.lmo_twobit2seq(b2.raw[:nb], n, out)
+        assert out.raw[:n] == s[:n]
+    # first base in bits 7-6 (genome.go:1480); degenerate bases (genome.go:1427-1444)
+    b2 = C.create_string_buffer(1)
+    L.lmo_seq2twobit(b"CATG", 4, b2)
+    assert b2.raw[0] == 0b01001110
+    L.lmo_seq2twobit(b"NRYK", 4, b2)
+    assert b2.raw[0] == 0b00000110
+
+
+def test_genome_store_every_subsequence(tmp_path):
+    """genome_test.go:52-164: write 13 sequences, read every (start,end) sub-sequence (SubSeq3 decode path)"""
+    d = str(tmp_path / "g.lmi")
+    genomes = [("seq_%d" % (i + 1), [("test", s + b"A" * max(0, 31 - len(s)))]) for i, s in enumerate(SEQS)]
+    # the builder needs >= k bases per genome; pad with A's and only test the original span
+    O.build_index(d, genomes, O.default_build_opt(masks=64, chunks=1))
+    L = O.lib()
+    L.lmo_greader_open.restype = C.c_void_p
+    L.lmo_greader_open.argtypes = [C.c_char_p]
+    L.lmo_greader_close.argtypes = [C.c_void_p]
+
+    class Genome(C.Structure):
+        _fields_ = [("genome_size", C.c_int), ("len", C.c_int), ("nseqs", C.c_int), ("seq_sizes", C.POINTER(C.c_int)),
+                    ("seq_ids", C.POINTER(C.c_char_p)), ("seq_offset", C.c_int64), ("seq", C.POINTER(C.c_uint8)),
+                    ("seqlen", C.c_int), ("seqcap", C.c_int)]
+
+    L.lmo_subseq3.restype = C.POINTER(Genome)
+    L.lmo_subseq3.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(Genome)]
+    L.lmo_genome_free.argtypes = [C.POINTER(Genome)]
+    raw = open(os.path.join(d, "genomes", "batch_0000", "genomes.bin"), "rb").read()
+    assert raw[:8] == b".genomes" and raw[8:10] == b"\x00\x01"
+    r = L.lmo_greader_open(os.path.join(d, "genomes", "batch_0000", "genomes.bin").encode())
+    assert r
+    for i, s in enumerate(SEQS):
+        g = None
+        for start in range(len(s)):
+            for end in range(start, len(s)):
+                g = L.lmo_subseq3(r, i, start, end, g)
+                got = bytes(g.contents.seq[j] for j in range(g.contents.seqlen))
+                assert got == s[start:end + 1], (i, start, end)
+        assert g.contents.nseqs == 1 and g.contents.seq_ids[0] == b"test"
+        L.lmo_genome_free(g)
+    L.lmo_greader_close(r)
+
+
+def test_tree_search_equals_bruteforce_lcp_filter():
+    """tree_test.go: InsertBatch/Insert equivalence + Search results; here: every returned key has the reported LCP, and
+    every key with LCP >= p is returned (extra keys can only come from the documented :496-500 quirk)"""
+    L = O.lib()
+    rng = random.Random(1)
+    k = 21
+    for n in (1, 2, 100, 5000):
+        keys = sorted({rng.getrandbits(2 * k) for _ in range(n)})
+        t = L.lmo_tree_new(k)
+        for i, x in enumerate(keys):
+            L.lmo_tree_insert(t, x, i)
+        out = C.POINTER(O.TreeSr)()
+        cap = C.c_int(0)
+        for _ in range(300):
+            q = rng.choice(keys) ^ rng.getrandbits(rng.randint(0, 2 * k - 8)) if rng.random() < 0.7 else rng.getrandbits(2 * k)
+            for p in (3, 7, 11, 21):
+                cnt = L.lmo_tree_search(t, q, p, C.byref(out), C.byref(cap))
+                got = {out[i].kmer: out[i].len_prefix for i in range(cnt)}
+                lcp = lambda a, b: k if a == b else (2 * k - (a ^ b).bit_length()) // 2
+                for x, l in got.items():
+                    assert l == lcp(q, x)
+                must = {x for x in keys if lcp(q, x) >= p}
+                assert must <= set(got)
+                assert [out[i].kmer for i in range(cnt)] == sorted(got)  # lexicographic order of the walk
+        L.free(out)
+        L.lmo_tree_free(t)
+
+
+def test_blast_statistics_of_golden_row():
+    """1539 M + 3 X -> score 3069 -> even 3068 -> bitscore floor((0.625*3068 - ln 0.41)/ln 2) = 2767,
+    evalue 0.00e+00 with totalBases = 54,142,446 (demo/q.gene.fasta.lexicmap.tsv:2)"""
+    L = O.lib()
+    ops = (C.c_uint64 * 7)(*[(ord(o) << 32) | n for o, n in
+                              (("M", 79), ("X", 1), ("M", 8), ("X", 1), ("M", 120), ("X", 1), ("M", 1332))])
+    r = O.WfaResult()
+    r.ops, r.nops = ops, 7
+    score, bits, ev = C.c_int(), C.c_int(), C.c_double()
+    L.lmo_score_evalue(C.byref(r), 1542, 54142446, C.byref(score), C.byref(bits), C.byref(ev))
+    assert (score.value, bits.value) == (3069, 2767)
+    assert "%.2e" % ev.value == "0.00e+00"
+
+
+@pytest.fixture(scope="module")
+def demo_index(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("demo") / "demo2.lmi")
+    genomes = [(f[:-6], O.read_fasta(os.path.join(GOLD, f))) for f in ("GCF_002949675.1.fa.gz", "GCF_003697165.2.fa.gz")]
+    O.build_index(d, genomes, O.default_build_opt(chunks=4))
+    return d
+
+
+def test_demo_golden_top2_all_columns(demo_index):
+    """demo/q.gene.fasta.lexicmap_top-2-genomes_all.tsv: 14 rows incl. CIGAR, qseq, sseq, alignment text — byte for
+    byte (the two genomes of that golden are the whole index here; rows do not depend on the other 13 genomes)"""
+    idx = O.Index(demo_index, O.default_search_opt(top_n=2, output_seq=1))
+    q = O.read_fasta(os.path.join(GOLD, "q.gene.fasta"))[0]
+    rows = idx.search_tsv(q[0], q[1], more_columns=True)
+    gold = open(os.path.join(GOLD, "q.gene.fasta.lexicmap_top-2-genomes_all.tsv")).read().rstrip("\n").split("\n")[1:]
+    assert rows == gold
+    idx.close()
+
+
+def test_demo_golden_prophage_high_identity_rows(demo_index):
+    """demo/q.prophage.fasta.lexicmap.tsv: the >=96% identity HSPs (gapped WFA alignments of 5.9-9.4 kb) reproduce in
+    every HSP column; low-identity rows depend on which masks found the region (own mask set) — SURVEY §8c(v)"""
+    idx = O.Index(demo_index)
+    q = O.read_fasta(os.path.join(GOLD, "q.prophage.fasta"))[0]
+    rows = [r.split("\t") for r in idx.search_tsv(q[0], q[1])]
+    gold = [r.split("\t") for r in
+            open(os.path.join(GOLD, "q.prophage.fasta.lexicmap.tsv")).read().rstrip("\n").split("\n")[1:]]
+    # all columns but hits/qcovGnm/cls/hsp (they depend on the other genomes/rows) and evalue (it scales with the
+    # database size: this fixture index holds 2 of the golden's 15 genomes; bitscore is compared)
+    cols = [0, 1, 3, 4] + list(range(8, 18)) + [19]
+    ours = {tuple(r[c] for c in cols) for r in rows}
+    strong = [g for g in gold if float(g[10]) >= 96.0 and g[3] == "GCF_003697165.2"]
+    assert len(strong) == 4
+    for g in strong:
+        assert tuple(g[c] for c in cols) in ours
+    idx.close()
