@@ -894,6 +894,8 @@ LM_HDN bool lm_tree_search_range(const uint64_t *keys, int n, uint64_t key, int 
         *hi_out = hi;
         return true;
     }
+    // the quirk needs bases [L,p) of the key to be A for some L < p: base p-1 is A or nothing is returned
+    if ((key >> sh) & 3ull) return false;
     return lm_tree_search_miss(keys, n, key, p, K, lo, lo_out, hi_out);
 }
 
@@ -914,6 +916,8 @@ LM_HD bool lm_tree_search_range_tab(const uint64_t *keys, int n, uint64_t key, i
         *hi_out = hi;
         return true;
     }
+    // the quirk needs bases [L,p) of the key to be A for some L < p: base p-1 is A or nothing is returned
+    if ((key >> sh) & 3ull) return false;
     return lm_tree_search_miss(keys, n, key, p, K, lo, lo_out, hi_out);
 }
 

@@ -30,6 +30,7 @@ struct Task { // one lexichash chain of one (query, genome): the pseudo-alignmen
     int32_t tBegin, tEnd, qBegin, qEnd;
     int32_t nseeds, wlen;
     int64_t woff;
+    uint64_t bg; // batch:17|genome:17 key of the genome
 };
 
 struct HspIn { // extendMatch input (lib-index-search.go:2255,2522)
@@ -82,12 +83,13 @@ void launch_extract_windows(hipStream_t st, DevIndexView ix, const Task *tasks, 
 #define LM_TAB_BITS 12 /* bucket table over the first 6 bases of the query's sorted k-mers */
 void launch_build_cmp_tab(hipStream_t st, const uint64_t *keys_cmp, const int64_t *posoff, const int32_t *nvalid, int nq,
                           int K, uint32_t *tab);
-void launch_pa_count(hipStream_t st, const Task *tasks, int64_t ntasks, const uint8_t *wbuf, const uint64_t *keys_cmp,
+void launch_pa_count(hipStream_t st, DevIndexView ix, const Task *tasks, int64_t ntasks, const uint8_t *wbuf, const uint64_t *keys_cmp,
                      const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_tab, int K,
                      int min_prefix, uint32_t *counts);
-void launch_pa_emit(hipStream_t st, const Task *tasks, int64_t ntasks, const uint8_t *wbuf, const uint64_t *keys_cmp,
+void launch_pa_emit(hipStream_t st, DevIndexView ix, const Task *tasks, int64_t ntasks, const uint8_t *wbuf, const uint64_t *keys_cmp,
                     const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_tab, int K,
                     int min_prefix, const uint32_t *counts, const int64_t *offs, uint64_t *outA, uint64_t *outB);
+void launch_sum_i32(hipStream_t st, const int32_t *v, int64_t n, unsigned long long *out);
 void launch_pa_task_off(hipStream_t st, const Task *tasks, int64_t ntasks, const int64_t *offs, int64_t total_pos,
                         int64_t total_anchors, int64_t *pa_off);
 void launch_pa_chain(hipStream_t st, const uint64_t *B, const int64_t *pa_off, int64_t ntasks, int K, LmChain2Opt opt,
@@ -100,8 +102,11 @@ void launch_extend_count(hipStream_t st, const HspIn *hsps, int64_t n, const uin
 void launch_extend(hipStream_t st, const HspIn *hsps, int64_t n, const uint8_t *qseq, const int64_t *qoff,
                    const uint8_t *wbuf, const int32_t *cap, const int64_t *scratch_off, LmSub *subs, int64_t *msi,
                    HspExt *out);
-void launch_wfa(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int32_t *hdr_pool,
-                int32_t *arena_pool, uint64_t *ops_pool, WfaOut *out);
+// kind 0: k_wfa_l64 (<= 62 diagonals), kind 1: k_wfa_lds (<= 128 diagonals); both persistent with private scratch
+int wfa_resident_blocks(int device, int seq_words, int kind);
+void launch_wfa(hipStream_t st, int kind, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks,
+                int32_t *hdr_pool, int64_t hdr_stride, int32_t *arena_pool, int64_t arena_stride, uint64_t *ops_pool,
+                unsigned int *queue, int seq_words, WfaOut *out);
 
 // wavefronts wider than the LDS ring (status 3 from launch_wfa): same algorithm with the ring in global memory
 void launch_wfa_wide(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int32_t *hdr_pool,

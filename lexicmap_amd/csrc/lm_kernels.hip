@@ -334,6 +334,7 @@ __global__ void k_make_tasks(DevIndexView ix, const uint64_t *__restrict__ segA,
             if (wlen < tEnd - tBegin + 1) tEnd -= tEnd - tBegin + 1 - wlen;
             Task t;
             t.seg = (uint32_t)s;
+            t.bg = bg;
             t.q = q;
             t.g = g;
             t.rc = rc ? 1 : 0;
@@ -349,6 +350,12 @@ __global__ void k_make_tasks(DevIndexView ix, const uint64_t *__restrict__ segA,
     }
 }
 
+__global__ void k_sum_i32(const int32_t *__restrict__ v, int64_t n, unsigned long long *__restrict__ out) {
+    unsigned long long acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) acc += (unsigned long long)v[i];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
 __global__ void k_task_wlen(const Task *__restrict__ tasks, int64_t ntasks, int32_t *__restrict__ wlen) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ntasks; i += (int64_t)gridDim.x * blockDim.x)
         wlen[i] = tasks[i].wlen;
@@ -385,19 +392,58 @@ __device__ __forceinline__ int pa_min_prefix(int base, int wlen) {
     return base;
 }
 
+// k-mer starting at base `pos` of a 2-bit packed genome (4 bases per byte, first base in the top bits): two aligned
+// 64-bit loads instead of K byte loads from the ASCII window. The genome store is padded so the second word exists.
+__device__ __forceinline__ uint64_t kmer_from_bits(const uint8_t *__restrict__ gbits, int64_t goff, int pos, int K) {
+    const int64_t byte = goff + (pos >> 2);
+    const uint64_t *p = (const uint64_t *)(gbits + (byte & ~7ll));
+    const uint64_t H = __builtin_bswap64(p[0]), L = __builtin_bswap64(p[1]);
+    const int o = (int)(byte & 7) * 8 + (pos & 3) * 2; // 0..62
+    const uint64_t v = o ? ((H << o) | (L >> (64 - o))) : H;
+    return v >> (64 - 2 * K);
+}
+
+struct PaCtx {
+    const uint64_t *keys;
+    const uint32_t *vals;
+    const uint32_t *tab;
+    int n, K, m;
+    uint32_t begin, end;
+    uint64_t ccc, ggg, ttt;
+};
+
+// window k-mer at position i (and its reverse complement), from the packed genome when the task has one
+__device__ __forceinline__ void pa_kmer(const Task &t, const uint8_t *__restrict__ w, const uint8_t *__restrict__ gbits,
+                                        int64_t goff, int i, int K, uint64_t *kmer, uint64_t *rc) {
+    if (gbits) {
+        if (t.rc) {
+            uint64_t g = kmer_from_bits(gbits, goff, t.tBegin + t.wlen - K - i, K);
+            *rc = g;
+            *kmer = lm_revcomp(g, K);
+        } else {
+            uint64_t g = kmer_from_bits(gbits, goff, t.tBegin + i, K);
+            *kmer = g;
+            *rc = lm_revcomp(g, K);
+        }
+    } else {
+        *kmer = encode_kmer(w + i, K);
+        *rc = lm_revcomp(*kmer, K);
+    }
+}
+
 template <bool EMIT>
-__device__ __forceinline__ uint32_t pa_position(const uint64_t *keys, const uint32_t *vals, int n, const uint32_t *tab,
-                                                uint64_t kmer, int K, int m, uint32_t begin, uint32_t end, int idx,
-                                                uint64_t A, uint64_t *outA, uint64_t *outB, int64_t o) {
+__device__ __forceinline__ uint32_t pa_position(const PaCtx &c, uint64_t kmer, uint64_t rc, int idx, uint64_t A,
+                                                uint64_t *outA, uint64_t *outB, int64_t o) {
     uint32_t cnt = 0;
-    if (kmer == 0 || kmer == lm_ns(1, K) || kmer == lm_ns(2, K) || kmer == lm_kmer_mask(K)) return 0;
+    const int K = c.K;
+    if (kmer == 0 || kmer == c.ccc || kmer == c.ggg || kmer == c.ttt) return 0;
     int lo, hi;
-    if (lm_tree_search_range_tab(keys, n, kmer, m, K, tab, LM_TAB_BITS, &lo, &hi)) {
+    if (lm_tree_search_range_tab(c.keys, c.n, kmer, c.m, K, c.tab, LM_TAB_BITS, &lo, &hi)) {
         for (int j = lo; j < hi; j++) {
-            uint32_t v = vals[j];
-            uint32_t lp = (uint32_t)lm_lcp(keys[j], kmer, K);
+            uint32_t v = c.vals[j];
+            uint32_t lp = (uint32_t)lm_lcp(c.keys[j], kmer, K);
             uint32_t p = v >> 1;
-            if ((v & 1u) == 1u || p < begin || p + lp > end) continue;
+            if ((v & 1u) == 1u || p < c.begin || p + lp > c.end) continue;
             if (EMIT) {
                 outA[o + cnt] = A;
                 outB[o + cnt] = lm_pack_anchor((int)p, (int)lp, idx, false, false);
@@ -405,13 +451,12 @@ __device__ __forceinline__ uint32_t pa_position(const uint64_t *keys, const uint
             cnt++;
         }
     }
-    uint64_t rc = lm_revcomp(kmer, K);
-    if (lm_tree_search_range_tab(keys, n, rc, m, K, tab, LM_TAB_BITS, &lo, &hi)) {
+    if (lm_tree_search_range_tab(c.keys, c.n, rc, c.m, K, c.tab, LM_TAB_BITS, &lo, &hi)) {
         for (int j = lo; j < hi; j++) {
-            uint32_t v = vals[j];
-            uint32_t lp = (uint32_t)lm_lcp(keys[j], rc, K);
+            uint32_t v = c.vals[j];
+            uint32_t lp = (uint32_t)lm_lcp(c.keys[j], rc, K);
             uint32_t p = (v >> 1) + (uint32_t)K - lp;
-            if ((v & 1u) == 0u || p + lp < begin || p > end) continue;
+            if ((v & 1u) == 0u || p + lp < c.begin || p > c.end) continue;
             if (EMIT) {
                 outA[o + cnt] = A;
                 outB[o + cnt] = lm_pack_anchor((int)p, (int)lp, idx + K - (int)lp, true, true);
@@ -422,47 +467,64 @@ __device__ __forceinline__ uint32_t pa_position(const uint64_t *keys, const uint
     return cnt;
 }
 
-__global__ void k_pa_count(const Task *__restrict__ tasks, int64_t ntasks, const uint8_t *__restrict__ wbuf,
-                           const uint64_t *__restrict__ keys_cmp, const uint32_t *__restrict__ vals_cmp,
-                           const int64_t *__restrict__ posoff, const int32_t *__restrict__ nvalid,
-                           const uint32_t *__restrict__ cmp_tab, int K, int min_prefix, uint32_t *__restrict__ counts) {
+__device__ __forceinline__ PaCtx pa_ctx(const Task &t, const uint64_t *keys_cmp, const uint32_t *vals_cmp,
+                                        const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_tab, int K,
+                                        int min_prefix) {
+    PaCtx c;
+    c.keys = keys_cmp + 2 * posoff[t.q];
+    c.vals = vals_cmp + 2 * posoff[t.q];
+    c.tab = cmp_tab + (int64_t)t.q * ((1 << LM_TAB_BITS) + 1);
+    c.n = nvalid[t.q];
+    c.K = K;
+    c.m = pa_min_prefix(min_prefix, t.wlen);
+    c.begin = (uint32_t)t.qBegin;
+    c.end = (uint32_t)t.qEnd;
+    c.ccc = lm_ns(1, K);
+    c.ggg = lm_ns(2, K);
+    c.ttt = lm_kmer_mask(K);
+    return c;
+}
+
+__global__ void k_pa_count(DevIndexView ix, const Task *__restrict__ tasks, int64_t ntasks,
+                           const uint8_t *__restrict__ wbuf, const uint64_t *__restrict__ keys_cmp,
+                           const uint32_t *__restrict__ vals_cmp, const int64_t *__restrict__ posoff,
+                           const int32_t *__restrict__ nvalid, const uint32_t *__restrict__ cmp_tab, int K, int min_prefix,
+                           uint32_t *__restrict__ counts) {
     for (int64_t ti = blockIdx.x; ti < ntasks; ti += gridDim.x) {
         const Task t = tasks[ti];
         const uint8_t *w = wbuf + t.woff;
-        const uint64_t *keys = keys_cmp + 2 * posoff[t.q];
-        const uint32_t *vals = vals_cmp + 2 * posoff[t.q];
-        int n = nvalid[t.q];
-        int m = pa_min_prefix(min_prefix, t.wlen);
+        const PaCtx c = pa_ctx(t, keys_cmp, vals_cmp, posoff, nvalid, cmp_tab, K, min_prefix);
+        const uint8_t *gb = t.g >= 0 ? ix.gbits : nullptr;
+        const int64_t goff = t.g >= 0 ? ix.g_off[t.g] : 0;
         for (int i = threadIdx.x; i < t.wlen; i += blockDim.x) {
-            uint32_t c = 0;
-            if (i + K <= t.wlen && n > 0) {
-                uint64_t kmer = encode_kmer(w + i, K);
-                c = pa_position<false>(keys, vals, n, cmp_tab + (int64_t)t.q * ((1 << LM_TAB_BITS) + 1), kmer, K, m,
-                                       (uint32_t)t.qBegin, (uint32_t)t.qEnd, i, 0, nullptr, nullptr, 0);
+            uint32_t cnt = 0;
+            if (i + K <= t.wlen && c.n > 0) {
+                uint64_t kmer, rc;
+                pa_kmer(t, w, gb, goff, i, K, &kmer, &rc);
+                cnt = pa_position<false>(c, kmer, rc, i, 0, nullptr, nullptr, 0);
             }
-            counts[t.woff + i] = c;
+            counts[t.woff + i] = cnt;
         }
     }
 }
 
-__global__ void k_pa_emit(const Task *__restrict__ tasks, int64_t ntasks, const uint8_t *__restrict__ wbuf,
-                          const uint64_t *__restrict__ keys_cmp, const uint32_t *__restrict__ vals_cmp,
-                          const int64_t *__restrict__ posoff, const int32_t *__restrict__ nvalid,
-                          const uint32_t *__restrict__ cmp_tab, int K, int min_prefix,
+__global__ void k_pa_emit(DevIndexView ix, const Task *__restrict__ tasks, int64_t ntasks,
+                          const uint8_t *__restrict__ wbuf, const uint64_t *__restrict__ keys_cmp,
+                          const uint32_t *__restrict__ vals_cmp, const int64_t *__restrict__ posoff,
+                          const int32_t *__restrict__ nvalid, const uint32_t *__restrict__ cmp_tab, int K, int min_prefix,
                           const uint32_t *__restrict__ counts, const int64_t *__restrict__ offs,
                           uint64_t *__restrict__ outA, uint64_t *__restrict__ outB) {
     for (int64_t ti = blockIdx.x; ti < ntasks; ti += gridDim.x) {
         const Task t = tasks[ti];
         const uint8_t *w = wbuf + t.woff;
-        const uint64_t *keys = keys_cmp + 2 * posoff[t.q];
-        const uint32_t *vals = vals_cmp + 2 * posoff[t.q];
-        int n = nvalid[t.q];
-        int m = pa_min_prefix(min_prefix, t.wlen);
+        const PaCtx c = pa_ctx(t, keys_cmp, vals_cmp, posoff, nvalid, cmp_tab, K, min_prefix);
+        const uint8_t *gb = t.g >= 0 ? ix.gbits : nullptr;
+        const int64_t goff = t.g >= 0 ? ix.g_off[t.g] : 0;
         for (int i = threadIdx.x; i < t.wlen; i += blockDim.x) {
             if (counts[t.woff + i] == 0) continue;
-            uint64_t kmer = encode_kmer(w + i, K);
-            pa_position<true>(keys, vals, n, cmp_tab + (int64_t)t.q * ((1 << LM_TAB_BITS) + 1), kmer, K, m,
-                              (uint32_t)t.qBegin, (uint32_t)t.qEnd, i, (uint64_t)ti, outA, outB, offs[t.woff + i]);
+            uint64_t kmer, rc;
+            pa_kmer(t, w, gb, goff, i, K, &kmer, &rc);
+            pa_position<true>(c, kmer, rc, i, (uint64_t)ti, outA, outB, offs[t.woff + i]);
         }
     }
 }
@@ -1212,28 +1274,367 @@ __device__ __forceinline__ void lds_trim(WfHdr &h, const int32_t *ring, int plen
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
     } while (0)
 
+// BLAST-style score of the M-trimmed CIGAR (lib-index-search-util.go:260-304: 2/-3/5/2)
+__device__ __forceinline__ int blast_score_of(const uint64_t *ops, int nops) {
+    int first = -1, last = -1;
+    for (int j = 0; j < nops; j++)
+        if ((ops[j] >> 32) == 'M') {
+            if (first < 0) first = j;
+            last = j;
+        }
+    int score = 0;
+    for (int j = first; j >= 0 && j <= last; j++) {
+        int nn = (int)(ops[j] & 0xffffffffu);
+        char op = (char)(ops[j] >> 32);
+        if (op == 'M')
+            score += nn * 2;
+        else if (op == 'X')
+            score += nn * -3;
+        else
+            score -= 5 + nn * 2;
+    }
+    return score;
+}
+
+// 16 bases -> one 32-bit word, first base in the top bits. Any injective 2-bit code works for equality tests:
+// (c >> 1) & 3 maps A,C,T,G to 0,1,2,3. *bad is raised for any other byte (the caller falls back to byte compares).
+__device__ __forceinline__ uint32_t pack_base(uint32_t c, bool *bad) {
+    uint32_t code = (c >> 1) & 3u;
+    *bad |= c != ((0x47544341u >> (code << 3)) & 0xffu); // 'A','C','T','G' by code
+    return code;
+}
+__device__ __forceinline__ uint32_t pack16(const uint8_t *__restrict__ s, int nb, bool *bad) {
+    uint32_t w = 0;
+    if (nb >= 16) {
+        uint32_t b[4];
+        __builtin_memcpy(b, s, 16);
+#pragma unroll
+        for (int j = 0; j < 16; j++) w = (w << 2) | pack_base((b[j >> 2] >> ((j & 3) << 3)) & 0xffu, bad);
+    } else {
+        for (int j = 0; j < nb; j++) w = (w << 2) | pack_base(s[j], bad);
+        w <<= 2 * (16 - nb);
+    }
+    return w;
+}
+// 16 packed bases starting at base `pos` (needs one padding word after the last one)
+__device__ __forceinline__ uint32_t get16(const uint32_t *seq, int pos) {
+    const int w = pos >> 4, sh = (pos & 15) << 1;
+    return __funnelshift_l(seq[w + 1], seq[w], sh);
+}
+
+__device__ __forceinline__ unsigned long long rotr64(unsigned long long x, int r) {
+    r &= 63;
+    return r ? ((x >> r) | (x << (64 - r))) : x;
+}
+
+// ---- k_wfa_l64: the lean variant ---------------------------------------------------------------------------------
+// One lane per diagonal: cell of diagonal k of every ring row lives at LDS slot (k & 63), cells outside a row's valid
+// range hold LM_NULL_OFF, so the recurrence reads its five neighbours without range tests as long as a wavefront is
+// at most 62 diagonals wide (wider ones return status 3 and take k_wfa_lds). The valid ranges of the last 9 (M) / 3
+// (I, D) scores are wave-uniform scalars kept in registers and rotated every score; trimming and the wf-adaptive
+// cut-off are single ballots. No global loads inside the score loop: sequences are 2-bit packed in LDS.
+// Results are identical to lm_wfa_align.
+__global__ __launch_bounds__(64) void k_wfa_l64(const WfaIn *__restrict__ in, int64_t n, const int32_t *__restrict__ todo,
+                                                 int64_t ntodo, int32_t *__restrict__ hdr_pool, int64_t hdr_stride,
+                                                 int32_t *__restrict__ arena_pool, int64_t arena_stride,
+                                                 uint64_t *__restrict__ ops_pool, unsigned int *__restrict__ queue,
+                                                 int seq_words, WfaOut *__restrict__ out) {
+    __shared__ int32_t rM[9][64];
+    __shared__ int32_t rI[3][64];
+    __shared__ int32_t rD[3][64];
+    __shared__ unsigned int sh_x;
+    extern __shared__ uint32_t seq_lds[];
+    uint32_t *Qp = seq_lds, *Tp = seq_lds + seq_words + 1;
+    const int lane = threadIdx.x;
+    int32_t *hdr = hdr_pool + (int64_t)blockIdx.x * hdr_stride;
+    int32_t *arena = arena_pool + (int64_t)blockIdx.x * arena_stride;
+    const int64_t arena_cap = arena_stride;
+    const int max_score = (int)(hdr_stride / 9);
+    while (true) {
+        if (lane == 0) sh_x = atomicAdd(queue, 1u);
+        LDS_WAVE_SYNC();
+        // broadcast through LDS, then made provably wave-uniform so everything derived from it stays scalar
+        const unsigned int x = (unsigned int)__builtin_amdgcn_readfirstlane((int)sh_x);
+        LDS_WAVE_SYNC();
+        if ((int64_t)x >= ntodo) break;
+        const int64_t i = todo ? todo[x] : (int64_t)x;
+        if (i < 0 || i >= n) break; // malformed work list
+        const WfaIn w = in[i];
+        const int plen = w.qlen, tlen = w.tlen;
+        const int ak = tlen - plen;
+        int status = 0;
+        LDS_WAVE_SYNC(); // the previous alignment is done with the packed sequences and the ring
+        {
+            const int qw = (plen + 15) >> 4, tw = (tlen + 15) >> 4;
+            if (qw > seq_words || tw > seq_words) {
+                status = 3;
+            } else {
+                bool bad = false;
+                for (int j = lane; j < qw; j += 64) Qp[j] = pack16(w.q + 16 * j, plen - 16 * j, &bad);
+                for (int j = lane; j < tw; j += 64) Tp[j] = pack16(w.t + 16 * j, tlen - 16 * j, &bad);
+                if (lane == 0) {
+                    Qp[qw] = 0;
+                    Tp[tw] = 0;
+                }
+                if (__ballot(bad) != 0ull) status = 3;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 9; r++) rM[r][lane] = LM_NULL_OFF;
+#pragma unroll
+        for (int r = 0; r < 3; r++) rI[r][lane] = rD[r][lane] = LM_NULL_OFF;
+        // valid ranges by age: mlo[a]..mhi[a] is M[s-a]
+        int mlo[9], mhi[9], ilo[3], ihi[3], dlo[3], dhi[3];
+#pragma unroll
+        for (int a = 0; a < 9; a++) {
+            mlo[a] = 1;
+            mhi[a] = -1;
+        }
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            ilo[a] = dlo[a] = 1;
+            ihi[a] = dhi[a] = -1;
+        }
+        if (max_score < 1 || arena_cap < 1) status = 1;
+        mlo[0] = mhi[0] = 0;
+        LDS_WAVE_SYNC();
+        if (lane == 0) rM[0][0] = 0;
+        int s = 0, ms = 0, is = 0; // ring rows of score s
+        int alo = 0;               // first diagonal of the arena slices of score s
+        int64_t used = 1, gbM = 0, gbI = 0, gbD = 0;
+        while (status == 0) {
+            const int k = alo + ((lane - alo) & 63); // this lane's diagonal at score s
+            bool done = false;
+            if (mlo[0] <= mhi[0]) {
+                const bool inr = k >= mlo[0] && k <= mhi[0];
+                int32_t off = rM[ms][lane];
+                if (inr && off >= 0) {
+                    int v = off - k, h = off;
+                    while (true) {
+                        int rem = plen - v < tlen - h ? plen - v : tlen - h;
+                        if (rem <= 0) break;
+                        uint32_t d = get16(Qp, v) ^ get16(Tp, h);
+                        int nm = d ? (__clz(d) >> 1) : 16;
+                        if (nm > rem) nm = rem;
+                        v += nm;
+                        h += nm;
+                        if (nm < 16) break;
+                    }
+                    off = h;
+                    rM[ms][lane] = off;
+                }
+                if (inr) arena[gbM + (k - alo)] = off;
+                done = __ballot(inr && k == ak && off >= tlen) != 0ull;
+                if (!done && mhi[0] - mlo[0] + 1 >= 10) { // wf-adaptive(10, 50)
+                    const int dist = inr ? wf_dist(off, k, plen, tlen) : 2147483647;
+                    const int dmin = __builtin_amdgcn_readfirstlane(wave_min_i32(dist));
+                    const bool keep = inr && (dist - dmin <= 50);
+                    const unsigned long long kb = rotr64(__ballot(keep), mlo[0]); // bit j <-> diagonal mlo+j
+                    int nlo = mlo[0], nhi = mhi[0];
+                    const int top = ak < mhi[0] ? ak : mhi[0];
+                    if (mlo[0] < top) {
+                        unsigned long long mk = kb & ((1ull << (top - mlo[0])) - 1ull);
+                        nlo = mk ? mlo[0] + (__ffsll((long long)mk) - 1) : top;
+                    }
+                    const int bottom = ak > nlo ? ak : nlo;
+                    if (mhi[0] > bottom) {
+                        const int b0 = bottom - mlo[0] + 1;
+                        unsigned long long mk = (kb >> b0) << b0;
+                        nhi = mk ? mlo[0] + (63 - __clzll((long long)mk)) : bottom;
+                    }
+                    if (nlo != mlo[0] || nhi != mhi[0]) {
+                        if (inr && (k < nlo || k > nhi)) rM[ms][lane] = LM_NULL_OFF;
+                        mlo[0] = nlo;
+                        mhi[0] = nhi;
+                        if (ilo[0] <= ihi[0]) {
+                            const bool was = k >= ilo[0] && k <= ihi[0];
+                            if (nlo > ilo[0]) ilo[0] = nlo;
+                            if (nhi < ihi[0]) ihi[0] = nhi;
+                            if (was && (k < ilo[0] || k > ihi[0])) rI[is][lane] = LM_NULL_OFF;
+                        }
+                        if (dlo[0] <= dhi[0]) {
+                            const bool was = k >= dlo[0] && k <= dhi[0];
+                            if (nlo > dlo[0]) dlo[0] = nlo;
+                            if (nhi < dhi[0]) dhi[0] = nhi;
+                            if (was && (k < dlo[0] || k > dhi[0])) rD[is][lane] = LM_NULL_OFF;
+                        }
+                    }
+                }
+            }
+            if (lane < 9) { // header of score s for the backtrace
+                int32_t hv;
+                switch (lane) {
+                case 0: hv = mlo[0]; break;
+                case 1: hv = mhi[0]; break;
+                case 2: hv = (int32_t)(gbM + (mlo[0] - alo)); break;
+                case 3: hv = ilo[0]; break;
+                case 4: hv = ihi[0]; break;
+                case 5: hv = (int32_t)(gbI + (ilo[0] - alo)); break;
+                case 6: hv = dlo[0]; break;
+                case 7: hv = dhi[0]; break;
+                default: hv = (int32_t)(gbD + (dlo[0] - alo)); break;
+                }
+                hdr[s * 9 + lane] = hv;
+            }
+            if (done) break;
+            s++;
+            if (s >= max_score) {
+                status = 1;
+                break;
+            }
+#pragma unroll
+            for (int a = 8; a > 0; a--) {
+                mlo[a] = mlo[a - 1];
+                mhi[a] = mhi[a - 1];
+            }
+#pragma unroll
+            for (int a = 2; a > 0; a--) {
+                ilo[a] = ilo[a - 1];
+                ihi[a] = ihi[a - 1];
+                dlo[a] = dlo[a - 1];
+                dhi[a] = dhi[a - 1];
+            }
+            ms = ms == 8 ? 0 : ms + 1;
+            is = is == 2 ? 0 : is + 1;
+            // sources: M[s-4] (mismatch), M[s-8] (gap open), I[s-2] / D[s-2] (gap extension)
+            int lo = 2147483647, hi = -2147483647;
+            bool any = false;
+            if (mlo[4] <= mhi[4]) { any = true; lo = mlo[4] < lo ? mlo[4] : lo; hi = mhi[4] > hi ? mhi[4] : hi; }
+            if (mlo[8] <= mhi[8]) { any = true; lo = mlo[8] - 1 < lo ? mlo[8] - 1 : lo; hi = mhi[8] + 1 > hi ? mhi[8] + 1 : hi; }
+            if (ilo[2] <= ihi[2]) { any = true; lo = ilo[2] + 1 < lo ? ilo[2] + 1 : lo; hi = ihi[2] + 1 > hi ? ihi[2] + 1 : hi; }
+            if (dlo[2] <= dhi[2]) { any = true; lo = dlo[2] - 1 < lo ? dlo[2] - 1 : lo; hi = dhi[2] - 1 > hi ? dhi[2] - 1 : hi; }
+            if (!any || lo > hi) {
+                mlo[0] = ilo[0] = dlo[0] = 1;
+                mhi[0] = ihi[0] = dhi[0] = -1;
+                rM[ms][lane] = LM_NULL_OFF;
+                rI[is][lane] = LM_NULL_OFF;
+                rD[is][lane] = LM_NULL_OFF;
+                gbM = gbI = gbD = 0;
+                alo = 0;
+                continue;
+            }
+            const int wd = hi - lo + 1;
+            if (wd > 62) {
+                status = 3;
+                break;
+            }
+            if (used + 3ll * wd > arena_cap) {
+                status = 1;
+                break;
+            }
+            gbM = used;
+            gbI = used + wd;
+            gbD = used + 2ll * wd;
+            used += 3ll * wd;
+            alo = lo;
+            const int kk = lo + ((lane - lo) & 63);
+            const bool inr = kk <= hi;
+            const int r4 = ms >= 4 ? ms - 4 : ms + 5, r8 = ms == 8 ? 0 : ms + 1, r2 = is == 2 ? 0 : is + 1;
+            LDS_WAVE_SYNC(); // the neighbours' extension results are in the ring
+            const int lm1 = (lane + 63) & 63, lp1 = (lane + 1) & 63;
+            int32_t a = rM[r8][lm1], b = rI[r2][lm1];
+            const int32_t ins = (a > b ? a : b) + 1;
+            a = rM[r8][lp1];
+            b = rD[r2][lp1];
+            const int32_t del = a > b ? a : b;
+            const int32_t mis = rM[r4][lane] + 1;
+            int32_t mx = mis > ins ? mis : ins;
+            if (del > mx) mx = del;
+            if ((uint32_t)mx > (uint32_t)tlen) mx = LM_NULL_OFF;
+            if ((uint32_t)(mx - kk) > (uint32_t)plen) mx = LM_NULL_OFF;
+            if (inr) {
+                arena[gbI + (kk - lo)] = ins;
+                arena[gbD + (kk - lo)] = del;
+            }
+            // trim each of the three new wavefronts to its first/last cell inside the DP matrix
+            auto okc = [&](int32_t off) {
+                return inr && (uint32_t)off <= (uint32_t)tlen && (uint32_t)(off - kk) <= (uint32_t)plen;
+            };
+            const unsigned long long bm = rotr64(__ballot(okc(mx)), lo);
+            const unsigned long long bi = rotr64(__ballot(okc(ins)), lo);
+            const unsigned long long bd = rotr64(__ballot(okc(del)), lo);
+            mlo[0] = bm ? lo + (__ffsll((long long)bm) - 1) : lo;
+            mhi[0] = bm ? lo + (63 - __clzll((long long)bm)) : lo - 1;
+            ilo[0] = bi ? lo + (__ffsll((long long)bi) - 1) : lo;
+            ihi[0] = bi ? lo + (63 - __clzll((long long)bi)) : lo - 1;
+            dlo[0] = bd ? lo + (__ffsll((long long)bd) - 1) : lo;
+            dhi[0] = bd ? lo + (63 - __clzll((long long)bd)) : lo - 1;
+            LDS_WAVE_SYNC(); // every lane has read the old rows before row ms / is are overwritten
+            rM[ms][lane] = (kk >= mlo[0] && kk <= mhi[0]) ? mx : LM_NULL_OFF;
+            rI[is][lane] = (kk >= ilo[0] && kk <= ihi[0]) ? ins : LM_NULL_OFF;
+            rD[is][lane] = (kk >= dlo[0] && kk <= dhi[0]) ? del : LM_NULL_OFF;
+        }
+        __syncthreads(); // the backtrace (lane 0) reads what every lane stored to global memory
+        if (lane == 0) {
+            WfaOut o;
+            o.blast_score = 0;
+            if (status != 0) {
+                o.r.status = status;
+                o.r.score = 0;
+                o.r.nops = 0;
+                o.r.qbegin = o.r.qend = o.r.tbegin = o.r.tend = 0;
+                o.r.align_len = o.r.matches = o.r.gaps = o.r.gap_regions = 0;
+            } else {
+                uint64_t *ops = ops_pool + w.ops_off;
+                lm_wfa_backtrace(hdr, arena, s, plen, tlen, ops, w.ops_cap, &o.r);
+                if (o.r.status == 0) o.blast_score = blast_score_of(ops, o.r.nops);
+            }
+            out[i] = o;
+        }
+    }
+}
+
+// Persistent wavefronts: each workgroup (one wave) owns a private header/arena region and pops alignments from a
+// queue ordered by decreasing expected cost, so scratch is resident_waves x worst case instead of alignments x estimate
+// and the launch has one short tail. Both sequences are 2-bit packed into LDS first: the extension compares 16 bases
+// per LDS word pair instead of 8 per pair of dependent global loads.
 __global__ __launch_bounds__(64) void k_wfa_lds(const WfaIn *__restrict__ in, int64_t n, const int32_t *__restrict__ todo,
-                                                 int64_t ntodo, int32_t *__restrict__ hdr_pool,
-                                                 int32_t *__restrict__ arena_pool, uint64_t *__restrict__ ops_pool,
-                                                 WfaOut *__restrict__ out) {
+                                                 int64_t ntodo, int32_t *__restrict__ hdr_pool, int64_t hdr_stride,
+                                                 int32_t *__restrict__ arena_pool, int64_t arena_stride,
+                                                 uint64_t *__restrict__ ops_pool, unsigned int *__restrict__ queue,
+                                                 int seq_words, WfaOut *__restrict__ out) {
     __shared__ int32_t ringM[9][WFA_W];
     __shared__ int32_t ringI[3][WFA_W];
     __shared__ int32_t ringD[3][WFA_W];
     __shared__ int32_t shM[9][4], shI[3][4], shD[3][4];
+    __shared__ unsigned int sh_x;
+    extern __shared__ uint32_t seq_lds[];
+    uint32_t *Qp = seq_lds, *Tp = seq_lds + seq_words + 1;
     const int lane = threadIdx.x;
     const int X = 4, OE = 8, E = 2;
-    for (int64_t x = blockIdx.x; x < ntodo; x += gridDim.x) {
-        int64_t i = todo ? todo[x] : x;
-        if (i >= n) continue;
+    int32_t *hdr = hdr_pool + (int64_t)blockIdx.x * hdr_stride;
+    int32_t *arena = arena_pool + (int64_t)blockIdx.x * arena_stride;
+    const int64_t arena_cap = arena_stride;
+    const int max_score = (int)(hdr_stride / 9);
+    while (true) {
+        if (lane == 0) sh_x = atomicAdd(queue, 1u);
+        LDS_WAVE_SYNC();
+        // broadcast through LDS, then made provably wave-uniform so everything derived from it stays scalar
+        const unsigned int x = (unsigned int)__builtin_amdgcn_readfirstlane((int)sh_x);
+        LDS_WAVE_SYNC();
+        if ((int64_t)x >= ntodo) break;
+        const int64_t i = todo ? todo[x] : (int64_t)x;
+        if (i < 0 || i >= n) break; // malformed work list
         const WfaIn w = in[i];
-        const uint8_t *__restrict__ q = w.q;
-        const uint8_t *__restrict__ t = w.t;
         const int plen = w.qlen, tlen = w.tlen;
-        int32_t *hdr = hdr_pool + w.hdr_off;
-        int32_t *arena = arena_pool + w.arena_off;
-        const int64_t arena_cap = w.arena_cap;
-        const int max_score = w.max_score;
         const int ak = tlen - plen;
+        int status = 0;
+        LDS_WAVE_SYNC(); // the previous alignment is done with the packed sequences and the ring
+        {
+            const int qw = (plen + 15) >> 4, tw = (tlen + 15) >> 4;
+            if (qw > seq_words || tw > seq_words) {
+                status = 3;
+            } else {
+                bool bad = false;
+                for (int j = lane; j < qw; j += 64) Qp[j] = pack16(w.q + 16 * j, plen - 16 * j, &bad);
+                for (int j = lane; j < tw; j += 64) Tp[j] = pack16(w.t + 16 * j, tlen - 16 * j, &bad);
+                if (lane == 0) {
+                    Qp[qw] = 0;
+                    Tp[tw] = 0;
+                }
+                if (__ballot(bad) != 0ull) status = 3;
+            }
+        }
         // headers of the ring slots live in LDS as well (wave-uniform broadcast reads; lane 0 writes)
         auto getM = [&](int slot) -> WfHdr { return WfHdr{shM[slot][0], shM[slot][1], shM[slot][2]}; };
         auto setM = [&](int slot, WfHdr v) {
@@ -1265,7 +1666,6 @@ __global__ __launch_bounds__(64) void k_wfa_lds(const WfaIn *__restrict__ in, in
             shI[lane][2] = shD[lane][2] = 0;
         }
         LDS_WAVE_SYNC();
-        int status = 0;
         int64_t used = 1;
         int64_t gbM = 0, gbI = 0, gbD = 0; // global bases (arena index of diagonal `alo`) of the current score
         bool pend = false;
@@ -1306,27 +1706,16 @@ __global__ __launch_bounds__(64) void k_wfa_lds(const WfaIn *__restrict__ in, in
                     int32_t off = rm[k - m.alo];
                     if (off >= 0) {
                         int v = off - k, h = off;
-                        bool fin = false;
-                        while (v + 8 <= plen && h + 8 <= tlen) {
-                            uint64_t a, b;
-                            __builtin_memcpy(&a, q + v, 8);
-                            __builtin_memcpy(&b, t + h, 8);
-                            uint64_t d = a ^ b;
-                            if (d) {
-                                int nb = __builtin_ctzll(d) >> 3;
-                                v += nb;
-                                h += nb;
-                                fin = true;
-                                break;
-                            }
-                            v += 8;
-                            h += 8;
+                        while (true) {
+                            int rem = plen - v < tlen - h ? plen - v : tlen - h;
+                            if (rem <= 0) break;
+                            uint32_t d = get16(Qp, v) ^ get16(Tp, h);
+                            int nm = d ? (__clz(d) >> 1) : 16;
+                            if (nm > rem) nm = rem;
+                            v += nm;
+                            h += nm;
+                            if (nm < 16) break;
                         }
-                        if (!fin)
-                            while (v < plen && h < tlen && q[v] == t[h]) {
-                                v++;
-                                h++;
-                            }
                         off = h;
                         rm[k - m.alo] = off;
                     }
@@ -1571,19 +1960,24 @@ void launch_build_cmp_tab(hipStream_t st, const uint64_t *keys_cmp, const int64_
                           int K, uint32_t *tab) {
     LM_LAUNCH_1D(k_build_cmp_tab, (int64_t)nq * ((1 << LM_TAB_BITS) + 1), st, keys_cmp, posoff, nvalid, nq, K, LM_TAB_BITS, tab);
 }
-void launch_pa_count(hipStream_t st, const Task *tasks, int64_t ntasks, const uint8_t *wbuf, const uint64_t *keys_cmp,
+void launch_pa_count(hipStream_t st, DevIndexView ix, const Task *tasks, int64_t ntasks, const uint8_t *wbuf, const uint64_t *keys_cmp,
                      const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_tab, int K,
                      int min_prefix, uint32_t *counts) {
     int g = (int)(ntasks < 1 ? 1 : (ntasks > 1048576 ? 1048576 : ntasks));
-    hipLaunchKernelGGL(k_pa_count, dim3(g), dim3(256), 0, st, tasks, ntasks, wbuf, keys_cmp, vals_cmp, posoff, nvalid, cmp_tab,
+    hipLaunchKernelGGL(k_pa_count, dim3(g), dim3(256), 0, st, ix, tasks, ntasks, wbuf, keys_cmp, vals_cmp, posoff, nvalid, cmp_tab,
                        K, min_prefix, counts);
 }
-void launch_pa_emit(hipStream_t st, const Task *tasks, int64_t ntasks, const uint8_t *wbuf, const uint64_t *keys_cmp,
+void launch_pa_emit(hipStream_t st, DevIndexView ix, const Task *tasks, int64_t ntasks, const uint8_t *wbuf, const uint64_t *keys_cmp,
                     const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_tab, int K,
                     int min_prefix, const uint32_t *counts, const int64_t *offs, uint64_t *outA, uint64_t *outB) {
     int g = (int)(ntasks < 1 ? 1 : (ntasks > 1048576 ? 1048576 : ntasks));
-    hipLaunchKernelGGL(k_pa_emit, dim3(g), dim3(256), 0, st, tasks, ntasks, wbuf, keys_cmp, vals_cmp, posoff, nvalid, cmp_tab,
+    hipLaunchKernelGGL(k_pa_emit, dim3(g), dim3(256), 0, st, ix, tasks, ntasks, wbuf, keys_cmp, vals_cmp, posoff, nvalid, cmp_tab,
                        K, min_prefix, counts, offs, outA, outB);
+}
+void launch_sum_i32(hipStream_t st, const int32_t *v, int64_t n, unsigned long long *out) {
+    int g = (int)((n + 255) / 256);
+    g = g < 1 ? 1 : (g > 2048 ? 2048 : g);
+    hipLaunchKernelGGL(k_sum_i32, dim3(g), dim3(256), 0, st, v, n, out);
 }
 void launch_pa_task_off(hipStream_t st, const Task *tasks, int64_t ntasks, const int64_t *offs, int64_t total_pos,
                         int64_t total_anchors, int64_t *pa_off) {
@@ -1610,11 +2004,26 @@ void launch_extend(hipStream_t st, const HspIn *hsps, int64_t n, const uint8_t *
     hipLaunchKernelGGL(k_extend, dim3(grid_for(n, 64)), dim3(64), 0, st, hsps, n, qseq, qoff, wbuf, cap, scratch_off, subs,
                        msi, out);
 }
-void launch_wfa(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int32_t *hdr_pool,
-                int32_t *arena_pool, uint64_t *ops_pool, WfaOut *out) {
-    // one wavefront per alignment; enough workgroups to fill 256 CUs x 32 waves
-    int g = (int)(ntodo < 1 ? 1 : (ntodo > 65536 ? 65536 : ntodo));
-    hipLaunchKernelGGL(k_wfa_lds, dim3(g), dim3(64), 0, st, in, n, todo, ntodo, hdr_pool, arena_pool, ops_pool, out);
+static int resident_blocks_of(const void *kern, int device, int seq_words) {
+    int nb = 0, cus = 0;
+    size_t dyn = (size_t)(2 * (seq_words + 1)) * sizeof(uint32_t);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64, dyn) != hipSuccess || nb < 1) nb = 8;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
+    return nb * cus;
+}
+int wfa_resident_blocks(int device, int seq_words, int kind) {
+    return resident_blocks_of(kind == 0 ? (const void *)k_wfa_l64 : (const void *)k_wfa_lds, device, seq_words);
+}
+void launch_wfa(hipStream_t st, int kind, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks,
+                int32_t *hdr_pool, int64_t hdr_stride, int32_t *arena_pool, int64_t arena_stride, uint64_t *ops_pool,
+                unsigned int *queue, int seq_words, WfaOut *out) {
+    size_t dyn = (size_t)(2 * (seq_words + 1)) * sizeof(uint32_t);
+    if (kind == 0)
+        hipLaunchKernelGGL(k_wfa_l64, dim3(nblocks), dim3(64), dyn, st, in, n, todo, ntodo, hdr_pool, hdr_stride, arena_pool,
+                           arena_stride, ops_pool, queue, seq_words, out);
+    else
+        hipLaunchKernelGGL(k_wfa_lds, dim3(nblocks), dim3(64), dyn, st, in, n, todo, ntodo, hdr_pool, hdr_stride, arena_pool,
+                           arena_stride, ops_pool, queue, seq_words, out);
 }
 void launch_wfa_wide(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int32_t *hdr_pool,
                      int32_t *arena_pool, uint64_t *ops_pool, WfaOut *out) {

@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -25,6 +26,9 @@
 #include "lm_kernels.h"
 
 #include "lm_internal.h"
+#include <atomic>
+#include <exception>
+#include <thread>
 
 thread_local std::string g_open_error;
 
@@ -131,6 +135,37 @@ template <typename T> static void d2h(lm_index *ix, std::vector<T> &h, const T *
     if (n) HIPCHK(hipMemcpyAsync(h.data(), d, n * sizeof(T), hipMemcpyDeviceToHost, ix->st));
 }
 static void sync(lm_index *ix) { HIPCHK(hipStreamSynchronize(ix->st)); }
+
+// Host-side glue between kernels is embarrassingly parallel over (query, genome) pairs: a small fork-join helper.
+template <typename F> static void parallel_for(int64_t n, int64_t grain, F f) {
+    if (n <= 0) return;
+    int64_t nchunks = (n + grain - 1) / grain;
+    int nt = (int)std::min<int64_t>(std::min<int64_t>(nchunks, 24), std::max(1u, std::thread::hardware_concurrency()));
+    if (nt <= 1) {
+        f((int64_t)0, n);
+        return;
+    }
+    std::atomic<int64_t> next{0};
+    std::exception_ptr err;
+    std::mutex emu;
+    auto body = [&]() {
+        try {
+            while (true) {
+                int64_t b = next.fetch_add(grain);
+                if (b >= n) break;
+                f(b, std::min(n, b + grain));
+            }
+        } catch (...) {
+            std::lock_guard<std::mutex> l(emu);
+            if (!err) err = std::current_exception();
+        }
+    };
+    std::vector<std::thread> th;
+    for (int i = 1; i < nt; i++) th.emplace_back(body);
+    body();
+    for (auto &t : th) t.join();
+    if (err) std::rethrow_exception(err);
+}
 
 // exclusive scan of n+1 uint32 counts (counts[n] must be 0) into int64 offsets; returns total after sync
 struct CastU32 {
@@ -709,6 +744,7 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
         h2d(ix, ix->d_seed_kmers, h.seed_kmers);
         h2d(ix, ix->d_seed_vals, h.seed_vals);
         h2d(ix, ix->d_mask_off, h.mask_off);
+        ix->d_gbits.ensure(h.gbits.size() + 64); // k-mer extraction reads whole aligned words past the last base
         h2d(ix, ix->d_gbits, h.gbits);
         std::vector<int64_t> goff;
         std::vector<int32_t> glen;
@@ -870,6 +906,7 @@ struct AlignCtx {
     DBuf<WfaIn> wfa_in;
     DBuf<WfaOut> wfa_out;
     DBuf<int32_t> wfa_todo, wfa_todo2, hdr_pool, arena_pool;
+    DBuf<unsigned int> wfa_queue;
     DBuf<uint64_t> ops_pool;
 };
 
@@ -906,7 +943,7 @@ static void run_pseudo(AlignCtx &a, const std::vector<Task> &ht, std::vector<int
     HIPCHK(hipMemsetAsync(a.pa_counts.p + W, 0, sizeof(uint32_t), ix->st));
     {
         Prof p(ix, "k_pa_count", W);
-        launch_pa_count(ix->st, a.tasks.p, nt, a.wbuf.p, a.w->k_cmp, a.w->v_cmp, qb->d_posoff.p, a.w->nvalid.p,
+        launch_pa_count(ix->st, ix->view, a.tasks.p, nt, a.wbuf.p, a.w->k_cmp, a.w->v_cmp, qb->d_posoff.p, a.w->nvalid.p,
                         a.w->cmp_tab.p, ix->host.k, 11, a.pa_counts.p);
     }
     int64_t TP = scan_to_i64<uint32_t, CastU32>(ix, a.pa_counts.p, W, a.pa_offs.p);
@@ -923,7 +960,7 @@ static void run_pseudo(AlignCtx &a, const std::vector<Task> &ht, std::vector<int
         a.B1.ensure((size_t)TP);
         {
             Prof p(ix, "k_pa_emit", TP * 16);
-            launch_pa_emit(ix->st, a.tasks.p, nt, a.wbuf.p, a.w->k_cmp, a.w->v_cmp, qb->d_posoff.p, a.w->nvalid.p,
+            launch_pa_emit(ix->st, ix->view, a.tasks.p, nt, a.wbuf.p, a.w->k_cmp, a.w->v_cmp, qb->d_posoff.p, a.w->nvalid.p,
                            a.w->cmp_tab.p, ix->host.k, 11, a.pa_counts.p, a.pa_offs.p, a.A0.p, a.B0.p);
         }
         {
@@ -1012,13 +1049,109 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
     ops_off_h.assign(n + 1, 0);
     ops_h.clear();
     if (n == 0) return;
-    std::vector<int32_t> todo(n);
-    for (int64_t i = 0; i < n; i++) todo[i] = (int32_t)i;
+    std::vector<int32_t> todo;
     std::vector<int32_t> level(n, 0);
     const int64_t budget = (int64_t)72 << 30; // bytes of scratch per launch (288 GB HBM: index + genomes + this)
     std::vector<uint8_t> is_wide(n, 0);
     a.wfa_out.ensure((size_t)n);
+    a.wfa_in.ensure((size_t)n);
     std::vector<std::vector<uint64_t>> ops_keep(want_ops ? n : 0);
+    {
+        // ---- pass 1: every problem through the persistent LDS kernel, longest expected first ----
+        std::vector<int32_t> order(n);
+        int maxlen = 1;
+        int64_t Lmax = 1, ops_tot = 0;
+        {
+            const int NB = 1024;
+            std::vector<float> key(n);
+            float kmax = 1e-9f;
+            for (int64_t i = 0; i < n; i++) {
+                int64_t L = (int64_t)in[i].qlen + in[i].tlen;
+                float dv = est_div ? (*est_div)[i] : 0.12f;
+                key[i] = (dv + 0.01f) * (float)L;
+                kmax = std::max(kmax, key[i]);
+                maxlen = std::max(maxlen, std::max(in[i].qlen, in[i].tlen));
+                Lmax = std::max(Lmax, L);
+            }
+            std::vector<int32_t> cnt(NB + 1, 0);
+            std::vector<int16_t> bk(n);
+            for (int64_t i = 0; i < n; i++) {
+                int b = NB - 1 - (int)(key[i] / kmax * (NB - 1)); // bucket 0 = most expensive
+                bk[i] = (int16_t)b;
+                cnt[b + 1]++;
+            }
+            for (int b = 0; b < NB; b++) cnt[b + 1] += cnt[b];
+            for (int64_t i = 0; i < n; i++) order[cnt[bk[i]]++] = (int32_t)i;
+        }
+        for (int64_t i = 0; i < n; i++) {
+            WfaIn &w = in[i];
+            int64_t L = (int64_t)w.qlen + w.tlen;
+            double dv = est_div ? (double)(*est_div)[i] : 0.12;
+            int64_t oc = std::min<int64_t>(L + 2, (int64_t)(128 + 3.0 * dv * (double)L));
+            w.hdr_off = w.arena_off = w.arena_cap = 0;
+            w.max_score = 0;
+            w.ops_off = ops_tot;
+            w.ops_cap = (int32_t)oc;
+            ops_tot += oc;
+        }
+        const int seq_words = std::min((maxlen + 15) / 16, 4096); // longer sequences take the global-memory kernel
+        const int64_t smax = 8 * Lmax + 64;
+        a.ops_pool.ensure((size_t)ops_tot + 16);
+        a.wfa_todo.ensure((size_t)n);
+        a.wfa_queue.ensure(1);
+        HIPCHK(hipMemcpyAsync(a.wfa_in.p, in.data(), sizeof(WfaIn) * n, hipMemcpyHostToDevice, ix->st));
+        // kind 0: lean 64-diagonal kernel, kind 1: 128-diagonal LDS kernel for the wavefronts that outgrow it
+        auto persistent_pass = [&](int kind, const std::vector<int32_t> &items, std::vector<int32_t> &too_wide) {
+            const int64_t m = (int64_t)items.size();
+            int nblocks = (int)std::min<int64_t>(m, wfa_resident_blocks(ix->device, seq_words, kind));
+            // private scratch per resident wave: never more than the worst case of the longest problem
+            int64_t cells = ((int64_t)40 << 30) / nblocks * 10 / 46 / 4;
+            cells = std::min<int64_t>(cells, std::min<int64_t>(3 * 128 * (smax + 1), 2000000000));
+            cells = std::max<int64_t>(cells, 4096);
+            int64_t rows = std::min<int64_t>(std::max<int64_t>(cells / 64, 256), smax + 1);
+            a.hdr_pool.ensure((size_t)(rows * 9) * nblocks + 16);
+            a.arena_pool.ensure((size_t)cells * nblocks + 16);
+            HIPCHK(hipMemcpyAsync(a.wfa_todo.p, items.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice, ix->st));
+            HIPCHK(hipMemsetAsync(a.wfa_queue.p, 0, sizeof(unsigned int), ix->st));
+            {
+                Prof p(ix, kind == 0 ? "k_wfa" : "k_wfa_w128", wfa_bytes(in, items));
+                launch_wfa(ix->st, kind, a.wfa_in.p, n, a.wfa_todo.p, m, nblocks, a.hdr_pool.p, rows * 9, a.arena_pool.p,
+                           cells, a.ops_pool.p, a.wfa_queue.p, seq_words, a.wfa_out.p);
+            }
+            std::vector<WfaOut> tmp;
+            d2h(ix, tmp, a.wfa_out.p, (size_t)n);
+            std::vector<uint64_t> ops_tmp;
+            if (want_ops) d2h(ix, ops_tmp, a.ops_pool.p, (size_t)ops_tot);
+            sync(ix);
+            for (int32_t i : items) {
+                int stt = tmp[i].r.status;
+                if (stt == 3) {
+                    too_wide.push_back(i);
+                    a.stats->wfa_retries++;
+                } else if (stt == 1) { // scratch or ops overflow: per-problem scratch in the global-memory kernel
+                    is_wide[i] = 1;
+                    level[i] = 1;
+                    a.stats->wfa_retries++;
+                    todo.push_back(i);
+                } else {
+                    out[i] = tmp[i];
+                    if (want_ops && tmp[i].r.nops > 0)
+                        ops_keep[i].assign(ops_tmp.begin() + in[i].ops_off,
+                                           ops_tmp.begin() + in[i].ops_off + tmp[i].r.nops);
+                }
+            }
+        };
+        std::vector<int32_t> wide1, wide2;
+        if (getenv("LM_DEBUG_SKIP_WFA_L64")) // debugging aid: force everything through the 128-diagonal kernel
+            wide1 = order;
+        else
+            persistent_pass(0, order, wide1);
+        if (!wide1.empty()) persistent_pass(1, wide1, wide2);
+        for (int32_t i : wide2) { // wider than 128 diagonals, longer than the LDS buffers, or not plain ACGT
+            is_wide[i] = 1;
+            todo.push_back(i);
+        }
+    }
     while (!todo.empty()) {
         // take a prefix of todo that fits the scratch budget
         std::vector<int32_t> cur;
@@ -1059,12 +1192,7 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
             // pass 1: LDS-ring kernel; pass 2 (rare): wavefronts wider than the ring, same scratch, global-memory ring
             std::vector<int32_t> narrow, wide;
             for (int32_t i : cur) (is_wide[i] ? wide : narrow).push_back(i);
-            if (!narrow.empty()) {
-                HIPCHK(hipMemcpyAsync(a.wfa_todo.p, narrow.data(), sizeof(int32_t) * narrow.size(), hipMemcpyHostToDevice, ix->st));
-                Prof p(ix, "k_wfa", wfa_bytes(in, narrow));
-                launch_wfa(ix->st, a.wfa_in.p, n, a.wfa_todo.p, (int64_t)narrow.size(), a.hdr_pool.p, a.arena_pool.p,
-                           a.ops_pool.p, a.wfa_out.p);
-            }
+            if (!narrow.empty()) throw HipError("internal: narrow WFA problem in the fallback pass");
             if (!wide.empty()) {
                 a.wfa_todo2.ensure(wide.size());
                 HIPCHK(hipMemcpyAsync(a.wfa_todo2.p, wide.data(), sizeof(int32_t) * wide.size(), hipMemcpyHostToDevice, ix->st));
@@ -1218,13 +1346,18 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
     // ---- top-N genomes per query (lib-index-search.go:1781-1805), host selection on (score desc, genome asc)
     std::vector<uint64_t> segA_h;
     std::vector<float> score_h;
-    std::vector<int32_t> segn_h, nch_h;
-    d2h(ix, segA_h, w.segA.p, (size_t)nseg);
-    d2h(ix, score_h, w.seg_score.p, (size_t)nseg);
-    d2h(ix, segn_h, w.seg_n.p, (size_t)nseg);
-    d2h(ix, nch_h, w.seg_nch.p, (size_t)nseg);
-    sync(ix);
-    for (int s = 0; s < nseg; s++) st.anchors_cleared += segn_h[s];
+    {   // anchors surviving ClearSubstrPairs, summed on the device (statistics only)
+        unsigned long long hv = 0;
+        HIPCHK(hipMemsetAsync(w.stat.p + 1, 0, sizeof(unsigned long long), ix->st));
+        launch_sum_i32(ix->st, w.seg_n.p, nseg, w.stat.p + 1);
+        HIPCHK(hipMemcpyAsync(&hv, w.stat.p + 1, sizeof hv, hipMemcpyDeviceToHost, ix->st));
+        if (ix->opt.top_n_genomes > 0) { // only the top-N selection needs the per-pair scores on the host
+            d2h(ix, segA_h, w.segA.p, (size_t)nseg);
+            d2h(ix, score_h, w.seg_score.p, (size_t)nseg);
+        }
+        sync(ix);
+        st.anchors_cleared += (int64_t)hv;
+    }
     const float min_score = chain_opt(ix).min_score;
     const uint8_t *keep_d = nullptr;
     if (ix->opt.top_n_genomes > 0) {
@@ -1299,80 +1432,95 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
         run_pseudo(a, ht, res_off, resv);
         double tb = now_ms();
         st.ms_pseudo += tb - ta;
-        // glue per segment
+        // glue per segment (parallel over segments; the order of `genomes` stays the segment order)
         size_t g0 = genomes.size();
         std::vector<HspMeta> hsps;
         {
-            size_t i = 0;
-            while (i < ht.size()) {
-                size_t e = i;
-                while (e < ht.size() && ht[e].seg == ht[i].seg) e++;
-                HGenome gen;
-                gen.q = ht[i].q;
-                gen.bg = segA_h[ht[i].seg] & ((1ull << 34) - 1);
-                gen.g = ht[i].g;
-                std::map<AKey, bool> keys;
-                if (gen.g >= 0)
-                    for (size_t t = i; t < e; t++)
-                        glue_task(ix, gen, keys, ht[t], (int64_t)t, resv.data() + res_off[t],
-                                  (int)(res_off[t + 1] - res_off[t]));
-                if (!gen.sds.empty()) genomes.push_back(std::move(gen));
-                i = e;
-            }
-        }
-        // HSP list (Update2 + the start of the finalisation loops :2223-2255 / :2490-2522)
-        for (size_t gi = g0; gi < genomes.size(); gi++) {
-            HGenome &gen = genomes[gi];
-            int qlen = (int)(qb->h_qoff[gen.q + 1] - qb->h_qoff[gen.q]);
-            for (auto &cl : gen.sds) {
-                const Task &t = ht[cl.task];
-                for (auto &c : cl.chains) {
-                    c.aligned_fraction = (double)c.aligned_bases_q / (double)qlen * 100;
-                    if (c.qbegin >= c.qend + 1) {
-                        c.alive = false;
-                        continue;
+            std::vector<size_t> seg_start;
+            for (size_t i = 0; i < ht.size(); i++)
+                if (i == 0 || ht[i].seg != ht[i - 1].seg) seg_start.push_back(i);
+            seg_start.push_back(ht.size());
+            const int64_t ns = (int64_t)seg_start.size() - 1;
+            std::vector<HGenome> gens((size_t)ns);
+            std::vector<std::vector<HspMeta>> ghsps((size_t)ns);
+            (void)div_from_pseudo_pident(0); // builds its table before the threads use it
+            parallel_for(ns, 256, [&](int64_t s0, int64_t s1) {
+                for (int64_t si = s0; si < s1; si++) {
+                    size_t i = seg_start[si], e = seg_start[si + 1];
+                    HGenome &gen = gens[si];
+                    gen.q = ht[i].q;
+                    gen.bg = ht[i].bg;
+                    gen.g = ht[i].g;
+                    std::map<AKey, bool> keys;
+                    if (gen.g >= 0)
+                        for (size_t t = i; t < e; t++)
+                            glue_task(ix, gen, keys, ht[t], (int64_t)t, resv.data() + res_off[t],
+                                      (int)(res_off[t + 1] - res_off[t]));
+                    if (gen.sds.empty()) continue;
+                    // HSP list (Update2 + the start of the finalisation loops :2223-2255 / :2490-2522)
+                    int qlen = (int)(qb->h_qoff[gen.q + 1] - qb->h_qoff[gen.q]);
+                    std::vector<HspMeta> &lh = ghsps[si];
+                    for (auto &cl : gen.sds) {
+                        const Task &t = ht[cl.task];
+                        for (auto &c : cl.chains) {
+                            c.aligned_fraction = (double)c.aligned_bases_q / (double)qlen * 100;
+                            if (c.qbegin >= c.qend + 1) {
+                                c.alive = false;
+                                continue;
+                            }
+                            int start, end;
+                            if (cl.rc) {
+                                start = cl.tEnd - c.tend - c.tpos_offset_begin;
+                                end = cl.tEnd - c.tbegin - c.tpos_offset_begin + 1;
+                            } else {
+                                start = c.tpos_offset_begin + c.tbegin - cl.tBegin;
+                                end = c.tpos_offset_begin + c.tend - cl.tBegin + 1;
+                            }
+                            if (start >= end) {
+                                c.alive = false;
+                                continue;
+                            }
+                            int ext2 = ix->opt.ext_len2;
+                            if (c.aligned_bases_q > 1000000)
+                                ext2 += 80;
+                            else if (c.aligned_bases_q > 250000)
+                                ext2 += 40;
+                            else if (c.aligned_bases_q > 50000)
+                                ext2 += 20;
+                            else if (c.aligned_bases_q > 10000)
+                                ext2 += 10;
+                            HspMeta h;
+                            h.task = cl.task;
+                            h.est_div = (float)div_from_pseudo_pident(c.pident);
+                            h.q = gen.q;
+                            h.in.q = gen.q;
+                            h.in.rc = cl.rc ? 1 : 0;
+                            h.in.woff = t.woff;
+                            h.in.len1 = qlen;
+                            h.in.len2 = t.wlen;
+                            h.in.start1 = c.qbegin;
+                            h.in.end1 = c.qend + 1;
+                            h.in.start2 = start;
+                            h.in.end2 = end;
+                            h.in.ext_len = ext2;
+                            h.in.tbegin = c.tbegin;
+                            h.in.max_ext_len = c.max_ext_len;
+                            h.in.pad = 0;
+                            c.hsp = (int64_t)lh.size(); // local index, rebased below
+                            lh.push_back(h);
+                        }
                     }
-                    int start, end;
-                    if (cl.rc) {
-                        start = cl.tEnd - c.tend - c.tpos_offset_begin;
-                        end = cl.tEnd - c.tbegin - c.tpos_offset_begin + 1;
-                    } else {
-                        start = c.tpos_offset_begin + c.tbegin - cl.tBegin;
-                        end = c.tpos_offset_begin + c.tend - cl.tBegin + 1;
-                    }
-                    if (start >= end) {
-                        c.alive = false;
-                        continue;
-                    }
-                    int ext2 = ix->opt.ext_len2;
-                    if (c.aligned_bases_q > 1000000)
-                        ext2 += 80;
-                    else if (c.aligned_bases_q > 250000)
-                        ext2 += 40;
-                    else if (c.aligned_bases_q > 50000)
-                        ext2 += 20;
-                    else if (c.aligned_bases_q > 10000)
-                        ext2 += 10;
-                    HspMeta h;
-                    h.task = cl.task;
-                    h.est_div = (float)div_from_pseudo_pident(c.pident);
-                    h.q = gen.q;
-                    h.in.q = gen.q;
-                    h.in.rc = cl.rc ? 1 : 0;
-                    h.in.woff = t.woff;
-                    h.in.len1 = qlen;
-                    h.in.len2 = t.wlen;
-                    h.in.start1 = c.qbegin;
-                    h.in.end1 = c.qend + 1;
-                    h.in.start2 = start;
-                    h.in.end2 = end;
-                    h.in.ext_len = ext2;
-                    h.in.tbegin = c.tbegin;
-                    h.in.max_ext_len = c.max_ext_len;
-                    h.in.pad = 0;
-                    c.hsp = (int64_t)hsps.size();
-                    hsps.push_back(std::move(h));
                 }
+            });
+            for (int64_t si = 0; si < ns; si++) {
+                if (gens[si].sds.empty()) continue;
+                int64_t base = (int64_t)hsps.size();
+                if (base)
+                    for (auto &cl : gens[si].sds)
+                        for (auto &c : cl.chains)
+                            if (c.hsp >= 0) c.hsp += base;
+                hsps.insert(hsps.end(), ghsps[si].begin(), ghsps[si].end());
+                genomes.push_back(std::move(gens[si]));
             }
         }
         double tc = now_ms();
@@ -1423,7 +1571,9 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
         double td = now_ms();
         st.ms_extend_wfa += td - tc;
         // ---- finalisation of this chunk's genomes (:2266-2357 / :2533-2626, then :2684-2749) ----
-        for (size_t gi = g0; gi < genomes.size(); gi++) {
+        std::mutex strings_mu;
+        parallel_for((int64_t)(genomes.size() - g0), 128, [&](int64_t gb0, int64_t gb1) {
+        for (size_t gi = g0 + (size_t)gb0; gi < g0 + (size_t)gb1; gi++) {
             HGenome &gen = genomes[gi];
             int qlen = (int)(qb->h_qoff[gen.q + 1] - qb->h_qoff[gen.q]);
             for (auto &cl : gen.sds) {
@@ -1485,6 +1635,7 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
                         c.align = new std::string();
                         fmt_alignment(ops, qb->h_seq.data() + qb->h_qoff[h.q] + h.ext.qs,
                                       wbuf_h.data() + h.in.woff + h.ext.ts, c.qseq, c.align, c.tseq);
+                        std::lock_guard<std::mutex> sl(strings_mu);
                         res->strings.push_back(c.cigar);
                         res->strings.push_back(c.qseq);
                         res->strings.push_back(c.tseq);
@@ -1519,6 +1670,7 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
             }
             std::stable_sort(gen.sds.begin(), gen.sds.end(), [](const HCluster &x, const HCluster &y) { return x.sim > y.sim; });
         }
+        });
         st.ms_finalize += now_ms() - td;
         tpos = tend;
     }
@@ -1800,6 +1952,7 @@ lm_status lm_pseudoalign_batch(lm_index *ix, const lm_query *queries, size_t nq,
             t.seg = (uint32_t)i;
             t.q = qidx[i];
             t.g = -1; // windows come from the caller, k_extract_windows skips them
+            t.bg = 0;
             t.qBegin = (int32_t)qbegin[i];
             t.qEnd = (int32_t)qend[i];
             t.wlen = (int32_t)targets[i].len;
