@@ -1350,10 +1350,13 @@ __global__ __launch_bounds__(64) void k_wfa_l64(const WfaIn *__restrict__ in, in
     int32_t *arena = arena_pool + (int64_t)blockIdx.x * arena_stride;
     const int64_t arena_cap = arena_stride;
     const int max_score = (int)(hdr_stride / 9);
+    // Work queue: lane 0 pops the next problem at the END of the loop body (inside the block that writes the result)
+    // and the index travels through LDS. Keeping lane-conditional code away from the loop header matters: with the pop
+    // at the top the compiler peels lane 0 into an outer loop and lets the other 63 lanes iterate without it.
+    if (lane == 0) sh_x = atomicAdd(queue, 1u);
     while (true) {
-        if (lane == 0) sh_x = atomicAdd(queue, 1u);
         LDS_WAVE_SYNC();
-        // broadcast through LDS, then made provably wave-uniform so everything derived from it stays scalar
+        // made provably wave-uniform so everything derived from it stays scalar
         const unsigned int x = (unsigned int)__builtin_amdgcn_readfirstlane((int)sh_x);
         LDS_WAVE_SYNC();
         if ((int64_t)x >= ntodo) break;
@@ -1580,6 +1583,7 @@ __global__ __launch_bounds__(64) void k_wfa_l64(const WfaIn *__restrict__ in, in
                 if (o.r.status == 0) o.blast_score = blast_score_of(ops, o.r.nops);
             }
             out[i] = o;
+            sh_x = atomicAdd(queue, 1u);
         }
     }
 }
@@ -1606,10 +1610,13 @@ __global__ __launch_bounds__(64) void k_wfa_lds(const WfaIn *__restrict__ in, in
     int32_t *arena = arena_pool + (int64_t)blockIdx.x * arena_stride;
     const int64_t arena_cap = arena_stride;
     const int max_score = (int)(hdr_stride / 9);
+    // Work queue: lane 0 pops the next problem at the END of the loop body (inside the block that writes the result)
+    // and the index travels through LDS. Keeping lane-conditional code away from the loop header matters: with the pop
+    // at the top the compiler peels lane 0 into an outer loop and lets the other 63 lanes iterate without it.
+    if (lane == 0) sh_x = atomicAdd(queue, 1u);
     while (true) {
-        if (lane == 0) sh_x = atomicAdd(queue, 1u);
         LDS_WAVE_SYNC();
-        // broadcast through LDS, then made provably wave-uniform so everything derived from it stays scalar
+        // made provably wave-uniform so everything derived from it stays scalar
         const unsigned int x = (unsigned int)__builtin_amdgcn_readfirstlane((int)sh_x);
         LDS_WAVE_SYNC();
         if ((int64_t)x >= ntodo) break;
@@ -1892,6 +1899,7 @@ __global__ __launch_bounds__(64) void k_wfa_lds(const WfaIn *__restrict__ in, in
                 }
             }
             out[i] = o;
+            sh_x = atomicAdd(queue, 1u);
         }
     }
 }
