@@ -1237,33 +1237,6 @@ __global__ __launch_bounds__(64) void k_wfa_wave(const WfaIn *__restrict__ in, i
 
 
 // ------------------------------------------------------------------------------------------------------------
-// LDS-staged WFA: the last 9 M-wavefronts and the last 3 I/D-wavefronts (all the recurrence ever reads) live in an LDS
-// ring together with their headers; global memory only receives the offsets needed by the backtrace (coalesced
-// stores, no dependent global loads in the score loop except the sequence bytes).  Wavefronts wider than WFA_W fall
-// back to k_wfa_wave (status 3).  Semantics identical to lm_wfa_align.
-#define WFA_W 128
-#define WFA_NC (WFA_W / 64)
-
-struct WfHdr {
-    int lo, hi, alo; // valid range, allocation base diagonal
-};
-
-__device__ __forceinline__ int32_t lds_val(const int32_t *ring, const WfHdr &h, int k) {
-    return (k < h.lo || k > h.hi) ? LM_NULL_OFF : ring[k - h.alo];
-}
-
-__device__ __forceinline__ void lds_trim(WfHdr &h, const int32_t *ring, int plen, int tlen, int lane) {
-    auto valid = [&](int k) {
-        int32_t off = ring[k - h.alo];
-        return (uint32_t)off <= (uint32_t)tlen && (uint32_t)(off - k) <= (uint32_t)plen;
-    };
-    int nhi = wave_find_last(h.hi, h.lo - 1, lane, valid);
-    int nlo = wave_find_first(h.lo, nhi + 1, lane, valid);
-    if (nhi < h.lo) nlo = h.lo;
-    h.lo = nlo;
-    h.hi = nhi;
-}
-
 // One wavefront per workgroup: LDS traffic of a single wave is processed in issue order, so cross-lane LDS hand-offs
 // only need the compiler not to reorder them. A workgroup barrier would also drain the outstanding global stores
 // (s_waitcnt vmcnt(0)) of the backtrace store on every score step, which is what this avoids.
@@ -1327,21 +1300,86 @@ __device__ __forceinline__ unsigned long long rotr64(unsigned long long x, int r
     return r ? ((x >> r) | (x << (64 - r))) : x;
 }
 
-// ---- k_wfa_l64: the lean variant ---------------------------------------------------------------------------------
-// One lane per diagonal: cell of diagonal k of every ring row lives at LDS slot (k & 63), cells outside a row's valid
-// range hold LM_NULL_OFF, so the recurrence reads its five neighbours without range tests as long as a wavefront is
-// at most 62 diagonals wide (wider ones return status 3 and take k_wfa_lds). The valid ranges of the last 9 (M) / 3
-// (I, D) scores are wave-uniform scalars kept in registers and rotated every score; trimming and the wf-adaptive
-// cut-off are single ballots. No global loads inside the score loop: sequences are 2-bit packed in LDS.
-// Results are identical to lm_wfa_align.
-__global__ __launch_bounds__(64) void k_wfa_l64(const WfaIn *__restrict__ in, int64_t n, const int32_t *__restrict__ todo,
-                                                 int64_t ntodo, int32_t *__restrict__ hdr_pool, int64_t hdr_stride,
-                                                 int32_t *__restrict__ arena_pool, int64_t arena_stride,
-                                                 uint64_t *__restrict__ ops_pool, unsigned int *__restrict__ queue,
-                                                 int seq_words, WfaOut *__restrict__ out) {
-    __shared__ int32_t rM[9][64];
-    __shared__ int32_t rI[3][64];
-    __shared__ int32_t rD[3][64];
+// ---- k_wfa_lean<NC>: the LDS wavefront kernel ------------------------------------------------------------------------
+// NC cells per lane (W = 64*NC diagonals): the cell of diagonal k of every ring row lives at LDS slot (k mod W), cells
+// outside a row's valid range hold LM_NULL_OFF, so the recurrence reads its five neighbours without range tests as long
+// as a wavefront is at most W-2 diagonals wide (wider ones return status 3: NC=1 -> NC=2 -> k_wfa_wave). The valid
+// ranges of the last 9 (M) / 3 (I, D) scores are wave-uniform scalars kept in registers and rotated every score;
+// trimming and the wf-adaptive cut-off are ballots. No global loads inside the score loop: both sequences are 2-bit
+// packed in LDS. Persistent wavefronts: each workgroup (one wave) owns a private header/arena region and pops problems
+// from a queue ordered by decreasing expected cost. Results are identical to lm_wfa_align.
+template <int NC> struct SlotMask { // one bit per LDS slot / per diagonal offset, W = 64*NC bits
+    unsigned long long w[NC];
+};
+template <int NC> __device__ __forceinline__ SlotMask<NC> sm_rotr(SlotMask<NC> m, int r) {
+    // bit j of the result = bit (j + r) mod W of m
+    if (NC == 1) {
+        SlotMask<NC> o;
+        o.w[0] = rotr64(m.w[0], r);
+        return o;
+    }
+    r &= 127;
+    unsigned long long a = m.w[0], b = m.w[NC - 1];
+    if (r >= 64) {
+        unsigned long long t = a;
+        a = b;
+        b = t;
+        r -= 64;
+    }
+    SlotMask<NC> o;
+    o.w[0] = r ? ((a >> r) | (b << (64 - r))) : a;
+    o.w[NC - 1] = r ? ((b >> r) | (a << (64 - r))) : b;
+    return o;
+}
+template <int NC> __device__ __forceinline__ bool sm_any(const SlotMask<NC> &m) {
+    return NC == 1 ? m.w[0] != 0 : (m.w[0] | m.w[NC - 1]) != 0;
+}
+template <int NC> __device__ __forceinline__ int sm_first(const SlotMask<NC> &m) { // lowest set bit (m non-zero)
+    if (NC == 1 || m.w[0]) return __ffsll((long long)m.w[0]) - 1;
+    return 64 + __ffsll((long long)m.w[NC - 1]) - 1;
+}
+template <int NC> __device__ __forceinline__ int sm_last(const SlotMask<NC> &m) { // highest set bit (m non-zero)
+    if (NC == 1 || m.w[NC - 1] == 0) return 63 - __clzll((long long)m.w[0]);
+    return 127 - __clzll((long long)m.w[NC - 1]);
+}
+template <int NC> __device__ __forceinline__ SlotMask<NC> sm_below(SlotMask<NC> m, int nbits) { // keep bits [0, nbits)
+    if (NC == 1) {
+        m.w[0] &= nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull);
+        return m;
+    }
+    if (nbits <= 64) {
+        m.w[0] &= nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull);
+        m.w[NC - 1] = 0;
+    } else {
+        m.w[NC - 1] &= nbits >= 128 ? ~0ull : ((1ull << (nbits - 64)) - 1ull);
+    }
+    return m;
+}
+template <int NC> __device__ __forceinline__ SlotMask<NC> sm_from(SlotMask<NC> m, int b0) { // keep bits [b0, W)
+    if (NC == 1) {
+        m.w[0] = b0 >= 64 ? 0ull : ((m.w[0] >> b0) << b0);
+        return m;
+    }
+    if (b0 >= 64) {
+        m.w[0] = 0;
+        m.w[NC - 1] = b0 >= 128 ? 0ull : ((m.w[NC - 1] >> (b0 - 64)) << (b0 - 64));
+    } else {
+        m.w[0] = (m.w[0] >> b0) << b0;
+    }
+    return m;
+}
+
+template <int NC>
+__global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, int64_t n, const int32_t *__restrict__ todo,
+                                                  int64_t ntodo, int32_t *__restrict__ hdr_pool, int64_t hdr_stride,
+                                                  int32_t *__restrict__ arena_pool, int64_t arena_stride,
+                                                  uint64_t *__restrict__ ops_pool, unsigned int *__restrict__ queue,
+                                                  int seq_words, WfaOut *__restrict__ out) {
+    static_assert(NC == 1 || NC == 2, "one or two cells per lane");
+    constexpr int W = 64 * NC;
+    __shared__ int32_t rM[9][W];
+    __shared__ int32_t rI[3][W];
+    __shared__ int32_t rD[3][W];
     __shared__ unsigned int sh_x;
     extern __shared__ uint32_t seq_lds[];
     uint32_t *Qp = seq_lds, *Tp = seq_lds + seq_words + 1;
@@ -1383,9 +1421,12 @@ __global__ __launch_bounds__(64) void k_wfa_l64(const WfaIn *__restrict__ in, in
             }
         }
 #pragma unroll
-        for (int r = 0; r < 9; r++) rM[r][lane] = LM_NULL_OFF;
+        for (int c = 0; c < NC; c++) {
 #pragma unroll
-        for (int r = 0; r < 3; r++) rI[r][lane] = rD[r][lane] = LM_NULL_OFF;
+            for (int r = 0; r < 9; r++) rM[r][lane + 64 * c] = LM_NULL_OFF;
+#pragma unroll
+            for (int r = 0; r < 3; r++) rI[r][lane + 64 * c] = rD[r][lane + 64 * c] = LM_NULL_OFF;
+        }
         // valid ranges by age: mlo[a]..mhi[a] is M[s-a]
         int mlo[9], mhi[9], ilo[3], ihi[3], dlo[3], dhi[3];
 #pragma unroll
@@ -1406,61 +1447,83 @@ __global__ __launch_bounds__(64) void k_wfa_l64(const WfaIn *__restrict__ in, in
         int alo = 0;               // first diagonal of the arena slices of score s
         int64_t used = 1, gbM = 0, gbI = 0, gbD = 0;
         while (status == 0) {
-            const int k = alo + ((lane - alo) & 63); // this lane's diagonal at score s
             bool done = false;
             if (mlo[0] <= mhi[0]) {
-                const bool inr = k >= mlo[0] && k <= mhi[0];
-                int32_t off = rM[ms][lane];
-                if (inr && off >= 0) {
-                    int v = off - k, h = off;
-                    while (true) {
-                        int rem = plen - v < tlen - h ? plen - v : tlen - h;
-                        if (rem <= 0) break;
-                        uint32_t d = get16(Qp, v) ^ get16(Tp, h);
-                        int nm = d ? (__clz(d) >> 1) : 16;
-                        if (nm > rem) nm = rem;
-                        v += nm;
-                        h += nm;
-                        if (nm < 16) break;
+                int kc[NC];
+                bool inr[NC];
+                int32_t off[NC];
+                SlotMask<NC> fin;
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const int slot = lane + 64 * c;
+                    const int k = alo + ((slot - alo) & (W - 1)); // this cell's diagonal at score s
+                    kc[c] = k;
+                    inr[c] = k >= mlo[0] && k <= mhi[0];
+                    int32_t o = rM[ms][slot];
+                    if (inr[c] && o >= 0) {
+                        int v = o - k, h = o;
+                        while (true) {
+                            int rem = plen - v < tlen - h ? plen - v : tlen - h;
+                            if (rem <= 0) break;
+                            uint32_t d = get16(Qp, v) ^ get16(Tp, h);
+                            int nm = d ? (__clz(d) >> 1) : 16;
+                            if (nm > rem) nm = rem;
+                            v += nm;
+                            h += nm;
+                            if (nm < 16) break;
+                        }
+                        o = h;
+                        rM[ms][slot] = o;
                     }
-                    off = h;
-                    rM[ms][lane] = off;
+                    off[c] = o;
+                    if (inr[c]) arena[gbM + (k - alo)] = o;
+                    fin.w[c] = __ballot(inr[c] && k == ak && o >= tlen);
                 }
-                if (inr) arena[gbM + (k - alo)] = off;
-                done = __ballot(inr && k == ak && off >= tlen) != 0ull;
+                done = sm_any<NC>(fin);
                 if (!done && mhi[0] - mlo[0] + 1 >= 10) { // wf-adaptive(10, 50)
-                    const int dist = inr ? wf_dist(off, k, plen, tlen) : 2147483647;
-                    const int dmin = __builtin_amdgcn_readfirstlane(wave_min_i32(dist));
-                    const bool keep = inr && (dist - dmin <= 50);
-                    const unsigned long long kb = rotr64(__ballot(keep), mlo[0]); // bit j <-> diagonal mlo+j
+                    int dist[NC];
+                    int dm = 2147483647;
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+                        dist[c] = inr[c] ? wf_dist(off[c], kc[c], plen, tlen) : 2147483647;
+                        dm = dist[c] < dm ? dist[c] : dm;
+                    }
+                    const int dmin = __builtin_amdgcn_readfirstlane(wave_min_i32(dm));
+                    SlotMask<NC> kb;
+#pragma unroll
+                    for (int c = 0; c < NC; c++) kb.w[c] = __ballot(inr[c] && (dist[c] - dmin <= 50));
+                    kb = sm_rotr<NC>(kb, mlo[0]); // bit j <-> diagonal mlo+j
                     int nlo = mlo[0], nhi = mhi[0];
                     const int top = ak < mhi[0] ? ak : mhi[0];
                     if (mlo[0] < top) {
-                        unsigned long long mk = kb & ((1ull << (top - mlo[0])) - 1ull);
-                        nlo = mk ? mlo[0] + (__ffsll((long long)mk) - 1) : top;
+                        SlotMask<NC> mk = sm_below<NC>(kb, top - mlo[0]);
+                        nlo = sm_any<NC>(mk) ? mlo[0] + sm_first<NC>(mk) : top;
                     }
                     const int bottom = ak > nlo ? ak : nlo;
                     if (mhi[0] > bottom) {
-                        const int b0 = bottom - mlo[0] + 1;
-                        unsigned long long mk = (kb >> b0) << b0;
-                        nhi = mk ? mlo[0] + (63 - __clzll((long long)mk)) : bottom;
+                        SlotMask<NC> mk = sm_from<NC>(kb, bottom - mlo[0] + 1);
+                        nhi = sm_any<NC>(mk) ? mlo[0] + sm_last<NC>(mk) : bottom;
                     }
                     if (nlo != mlo[0] || nhi != mhi[0]) {
-                        if (inr && (k < nlo || k > nhi)) rM[ms][lane] = LM_NULL_OFF;
-                        mlo[0] = nlo;
-                        mhi[0] = nhi;
-                        if (ilo[0] <= ihi[0]) {
-                            const bool was = k >= ilo[0] && k <= ihi[0];
+                        const bool hasI = ilo[0] <= ihi[0], hasD = dlo[0] <= dhi[0];
+                        const int oil = ilo[0], oih = ihi[0], odl = dlo[0], odh = dhi[0];
+                        if (hasI) {
                             if (nlo > ilo[0]) ilo[0] = nlo;
                             if (nhi < ihi[0]) ihi[0] = nhi;
-                            if (was && (k < ilo[0] || k > ihi[0])) rI[is][lane] = LM_NULL_OFF;
                         }
-                        if (dlo[0] <= dhi[0]) {
-                            const bool was = k >= dlo[0] && k <= dhi[0];
+                        if (hasD) {
                             if (nlo > dlo[0]) dlo[0] = nlo;
                             if (nhi < dhi[0]) dhi[0] = nhi;
-                            if (was && (k < dlo[0] || k > dhi[0])) rD[is][lane] = LM_NULL_OFF;
                         }
+#pragma unroll
+                        for (int c = 0; c < NC; c++) {
+                            const int slot = lane + 64 * c, k = kc[c];
+                            if (inr[c] && (k < nlo || k > nhi)) rM[ms][slot] = LM_NULL_OFF;
+                            if (hasI && k >= oil && k <= oih && (k < ilo[0] || k > ihi[0])) rI[is][slot] = LM_NULL_OFF;
+                            if (hasD && k >= odl && k <= odh && (k < dlo[0] || k > dhi[0])) rD[is][slot] = LM_NULL_OFF;
+                        }
+                        mlo[0] = nlo;
+                        mhi[0] = nhi;
                     }
                 }
             }
@@ -1509,15 +1572,18 @@ __global__ __launch_bounds__(64) void k_wfa_l64(const WfaIn *__restrict__ in, in
             if (!any || lo > hi) {
                 mlo[0] = ilo[0] = dlo[0] = 1;
                 mhi[0] = ihi[0] = dhi[0] = -1;
-                rM[ms][lane] = LM_NULL_OFF;
-                rI[is][lane] = LM_NULL_OFF;
-                rD[is][lane] = LM_NULL_OFF;
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    rM[ms][lane + 64 * c] = LM_NULL_OFF;
+                    rI[is][lane + 64 * c] = LM_NULL_OFF;
+                    rD[is][lane + 64 * c] = LM_NULL_OFF;
+                }
                 gbM = gbI = gbD = 0;
                 alo = 0;
                 continue;
             }
             const int wd = hi - lo + 1;
-            if (wd > 62) {
+            if (wd > W - 2) {
                 status = 3;
                 break;
             }
@@ -1530,42 +1596,62 @@ __global__ __launch_bounds__(64) void k_wfa_l64(const WfaIn *__restrict__ in, in
             gbD = used + 2ll * wd;
             used += 3ll * wd;
             alo = lo;
-            const int kk = lo + ((lane - lo) & 63);
-            const bool inr = kk <= hi;
             const int r4 = ms >= 4 ? ms - 4 : ms + 5, r8 = ms == 8 ? 0 : ms + 1, r2 = is == 2 ? 0 : is + 1;
             LDS_WAVE_SYNC(); // the neighbours' extension results are in the ring
-            const int lm1 = (lane + 63) & 63, lp1 = (lane + 1) & 63;
-            int32_t a = rM[r8][lm1], b = rI[r2][lm1];
-            const int32_t ins = (a > b ? a : b) + 1;
-            a = rM[r8][lp1];
-            b = rD[r2][lp1];
-            const int32_t del = a > b ? a : b;
-            const int32_t mis = rM[r4][lane] + 1;
-            int32_t mx = mis > ins ? mis : ins;
-            if (del > mx) mx = del;
-            if ((uint32_t)mx > (uint32_t)tlen) mx = LM_NULL_OFF;
-            if ((uint32_t)(mx - kk) > (uint32_t)plen) mx = LM_NULL_OFF;
-            if (inr) {
-                arena[gbI + (kk - lo)] = ins;
-                arena[gbD + (kk - lo)] = del;
+            int kk[NC];
+            bool inr[NC];
+            int32_t vins[NC], vdel[NC], vmx[NC];
+            SlotMask<NC> bm, bi, bd;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const int slot = lane + 64 * c;
+                const int k = lo + ((slot - lo) & (W - 1));
+                kk[c] = k;
+                inr[c] = k <= hi;
+                const int sm1 = (slot + W - 1) & (W - 1), sp1 = (slot + 1) & (W - 1);
+                int32_t a = rM[r8][sm1], b = rI[r2][sm1];
+                const int32_t ins = (a > b ? a : b) + 1;
+                a = rM[r8][sp1];
+                b = rD[r2][sp1];
+                const int32_t del = a > b ? a : b;
+                const int32_t mis = rM[r4][slot] + 1;
+                int32_t mx = mis > ins ? mis : ins;
+                if (del > mx) mx = del;
+                if ((uint32_t)mx > (uint32_t)tlen) mx = LM_NULL_OFF;
+                if ((uint32_t)(mx - k) > (uint32_t)plen) mx = LM_NULL_OFF;
+                if (inr[c]) {
+                    arena[gbI + (k - lo)] = ins;
+                    arena[gbD + (k - lo)] = del;
+                }
+                vins[c] = ins;
+                vdel[c] = del;
+                vmx[c] = mx;
+                // trim each of the three new wavefronts to its first/last cell inside the DP matrix
+                auto okc = [&](int32_t o) {
+                    return inr[c] && (uint32_t)o <= (uint32_t)tlen && (uint32_t)(o - k) <= (uint32_t)plen;
+                };
+                bm.w[c] = __ballot(okc(mx));
+                bi.w[c] = __ballot(okc(ins));
+                bd.w[c] = __ballot(okc(del));
             }
-            // trim each of the three new wavefronts to its first/last cell inside the DP matrix
-            auto okc = [&](int32_t off) {
-                return inr && (uint32_t)off <= (uint32_t)tlen && (uint32_t)(off - kk) <= (uint32_t)plen;
-            };
-            const unsigned long long bm = rotr64(__ballot(okc(mx)), lo);
-            const unsigned long long bi = rotr64(__ballot(okc(ins)), lo);
-            const unsigned long long bd = rotr64(__ballot(okc(del)), lo);
-            mlo[0] = bm ? lo + (__ffsll((long long)bm) - 1) : lo;
-            mhi[0] = bm ? lo + (63 - __clzll((long long)bm)) : lo - 1;
-            ilo[0] = bi ? lo + (__ffsll((long long)bi) - 1) : lo;
-            ihi[0] = bi ? lo + (63 - __clzll((long long)bi)) : lo - 1;
-            dlo[0] = bd ? lo + (__ffsll((long long)bd) - 1) : lo;
-            dhi[0] = bd ? lo + (63 - __clzll((long long)bd)) : lo - 1;
+            bm = sm_rotr<NC>(bm, lo);
+            bi = sm_rotr<NC>(bi, lo);
+            bd = sm_rotr<NC>(bd, lo);
+            const bool hm = sm_any<NC>(bm), hi_ = sm_any<NC>(bi), hd = sm_any<NC>(bd);
+            mlo[0] = hm ? lo + sm_first<NC>(bm) : lo;
+            mhi[0] = hm ? lo + sm_last<NC>(bm) : lo - 1;
+            ilo[0] = hi_ ? lo + sm_first<NC>(bi) : lo;
+            ihi[0] = hi_ ? lo + sm_last<NC>(bi) : lo - 1;
+            dlo[0] = hd ? lo + sm_first<NC>(bd) : lo;
+            dhi[0] = hd ? lo + sm_last<NC>(bd) : lo - 1;
             LDS_WAVE_SYNC(); // every lane has read the old rows before row ms / is are overwritten
-            rM[ms][lane] = (kk >= mlo[0] && kk <= mhi[0]) ? mx : LM_NULL_OFF;
-            rI[is][lane] = (kk >= ilo[0] && kk <= ihi[0]) ? ins : LM_NULL_OFF;
-            rD[is][lane] = (kk >= dlo[0] && kk <= dhi[0]) ? del : LM_NULL_OFF;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const int slot = lane + 64 * c, k = kk[c];
+                rM[ms][slot] = (k >= mlo[0] && k <= mhi[0]) ? vmx[c] : LM_NULL_OFF;
+                rI[is][slot] = (k >= ilo[0] && k <= ihi[0]) ? vins[c] : LM_NULL_OFF;
+                rD[is][slot] = (k >= dlo[0] && k <= dhi[0]) ? vdel[c] : LM_NULL_OFF;
+            }
         }
         __syncthreads(); // the backtrace (lane 0) reads what every lane stored to global memory
         if (lane == 0) {
@@ -1588,321 +1674,6 @@ __global__ __launch_bounds__(64) void k_wfa_l64(const WfaIn *__restrict__ in, in
     }
 }
 
-// Persistent wavefronts: each workgroup (one wave) owns a private header/arena region and pops alignments from a
-// queue ordered by decreasing expected cost, so scratch is resident_waves x worst case instead of alignments x estimate
-// and the launch has one short tail. Both sequences are 2-bit packed into LDS first: the extension compares 16 bases
-// per LDS word pair instead of 8 per pair of dependent global loads.
-__global__ __launch_bounds__(64) void k_wfa_lds(const WfaIn *__restrict__ in, int64_t n, const int32_t *__restrict__ todo,
-                                                 int64_t ntodo, int32_t *__restrict__ hdr_pool, int64_t hdr_stride,
-                                                 int32_t *__restrict__ arena_pool, int64_t arena_stride,
-                                                 uint64_t *__restrict__ ops_pool, unsigned int *__restrict__ queue,
-                                                 int seq_words, WfaOut *__restrict__ out) {
-    __shared__ int32_t ringM[9][WFA_W];
-    __shared__ int32_t ringI[3][WFA_W];
-    __shared__ int32_t ringD[3][WFA_W];
-    __shared__ int32_t shM[9][4], shI[3][4], shD[3][4];
-    __shared__ unsigned int sh_x;
-    extern __shared__ uint32_t seq_lds[];
-    uint32_t *Qp = seq_lds, *Tp = seq_lds + seq_words + 1;
-    const int lane = threadIdx.x;
-    const int X = 4, OE = 8, E = 2;
-    int32_t *hdr = hdr_pool + (int64_t)blockIdx.x * hdr_stride;
-    int32_t *arena = arena_pool + (int64_t)blockIdx.x * arena_stride;
-    const int64_t arena_cap = arena_stride;
-    const int max_score = (int)(hdr_stride / 9);
-    // Work queue: lane 0 pops the next problem at the END of the loop body (inside the block that writes the result)
-    // and the index travels through LDS. Keeping lane-conditional code away from the loop header matters: with the pop
-    // at the top the compiler peels lane 0 into an outer loop and lets the other 63 lanes iterate without it.
-    if (lane == 0) sh_x = atomicAdd(queue, 1u);
-    while (true) {
-        LDS_WAVE_SYNC();
-        // made provably wave-uniform so everything derived from it stays scalar
-        const unsigned int x = (unsigned int)__builtin_amdgcn_readfirstlane((int)sh_x);
-        LDS_WAVE_SYNC();
-        if ((int64_t)x >= ntodo) break;
-        const int64_t i = todo ? todo[x] : (int64_t)x;
-        if (i < 0 || i >= n) break; // malformed work list
-        const WfaIn w = in[i];
-        const int plen = w.qlen, tlen = w.tlen;
-        const int ak = tlen - plen;
-        int status = 0;
-        LDS_WAVE_SYNC(); // the previous alignment is done with the packed sequences and the ring
-        {
-            const int qw = (plen + 15) >> 4, tw = (tlen + 15) >> 4;
-            if (qw > seq_words || tw > seq_words) {
-                status = 3;
-            } else {
-                bool bad = false;
-                for (int j = lane; j < qw; j += 64) Qp[j] = pack16(w.q + 16 * j, plen - 16 * j, &bad);
-                for (int j = lane; j < tw; j += 64) Tp[j] = pack16(w.t + 16 * j, tlen - 16 * j, &bad);
-                if (lane == 0) {
-                    Qp[qw] = 0;
-                    Tp[tw] = 0;
-                }
-                if (__ballot(bad) != 0ull) status = 3;
-            }
-        }
-        // headers of the ring slots live in LDS as well (wave-uniform broadcast reads; lane 0 writes)
-        auto getM = [&](int slot) -> WfHdr { return WfHdr{shM[slot][0], shM[slot][1], shM[slot][2]}; };
-        auto setM = [&](int slot, WfHdr v) {
-            if (lane == 0) {
-                shM[slot][0] = v.lo;
-                shM[slot][1] = v.hi;
-                shM[slot][2] = v.alo;
-            }
-        };
-        auto get3 = [&](int32_t(*a)[4], int slot) -> WfHdr { return WfHdr{a[slot][0], a[slot][1], a[slot][2]}; };
-        auto set3 = [&](int32_t(*a)[4], int slot, WfHdr v) {
-            if (lane == 0) {
-                a[slot][0] = v.lo;
-                a[slot][1] = v.hi;
-                a[slot][2] = v.alo;
-            }
-        };
-        int32_t(*hI)[4] = shI;
-        int32_t(*hD)[4] = shD;
-        LDS_WAVE_SYNC();
-        if (lane < 9) {
-            shM[lane][0] = 1;
-            shM[lane][1] = -1;
-            shM[lane][2] = 0;
-        }
-        if (lane < 3) {
-            shI[lane][0] = shD[lane][0] = 1;
-            shI[lane][1] = shD[lane][1] = -1;
-            shI[lane][2] = shD[lane][2] = 0;
-        }
-        LDS_WAVE_SYNC();
-        int64_t used = 1;
-        int64_t gbM = 0, gbI = 0, gbD = 0; // global bases (arena index of diagonal `alo`) of the current score
-        bool pend = false;
-        int plo = 0, phi = -1;
-        int32_t pvi[WFA_NC], pvd[WFA_NC];
-        LDS_WAVE_SYNC();
-        if (max_score < 1 || arena_cap < 1) status = 1;
-        setM(0, {0, 0, 0});
-        if (lane == 0) ringM[0][0] = 0;
-        int s = 0;
-        while (status == 0) {
-            LDS_WAVE_SYNC();
-            const int ms = s % 9, is = s % 3;
-            WfHdr m = getM(ms);
-            bool done = false;
-            auto flush_pending = [&]() { // deferred global stores of I[s], D[s] (gbI/gbD still describe score s)
-                if (pend) {
-#pragma unroll
-                    for (int c = 0; c < WFA_NC; c++) {
-                        int k = plo + lane + 64 * c;
-                        if (k <= phi) {
-                            arena[gbI + (k - plo)] = pvi[c];
-                            arena[gbD + (k - plo)] = pvd[c];
-                        }
-                    }
-                    pend = false;
-                }
-            };
-            if (m.lo > m.hi) flush_pending();
-            if (m.lo <= m.hi) {
-                int32_t *rm = ringM[ms];
-                int32_t eo[WFA_NC];
-#pragma unroll
-                for (int c = 0; c < WFA_NC; c++) {
-                    int k = m.lo + lane + 64 * c;
-                    eo[c] = LM_NULL_OFF;
-                    if (k > m.hi) continue;
-                    int32_t off = rm[k - m.alo];
-                    if (off >= 0) {
-                        int v = off - k, h = off;
-                        while (true) {
-                            int rem = plen - v < tlen - h ? plen - v : tlen - h;
-                            if (rem <= 0) break;
-                            uint32_t d = get16(Qp, v) ^ get16(Tp, h);
-                            int nm = d ? (__clz(d) >> 1) : 16;
-                            if (nm > rem) nm = rem;
-                            v += nm;
-                            h += nm;
-                            if (nm < 16) break;
-                        }
-                        off = h;
-                        rm[k - m.alo] = off;
-                    }
-                    eo[c] = off;
-                }
-                // all sequence loads of this step are done: now issue the stores of M[s] (and of I[s], D[s] below)
-#pragma unroll
-                for (int c = 0; c < WFA_NC; c++) {
-                    int k = m.lo + lane + 64 * c;
-                    if (k <= m.hi) arena[gbM + (k - m.alo)] = eo[c];
-                }
-                flush_pending();
-                LDS_WAVE_SYNC();
-                if (m.lo <= ak && ak <= m.hi && rm[ak - m.alo] >= tlen) {
-                    done = true;
-                } else if (m.hi - m.lo + 1 >= 10) {
-                    int dmin = 2147483647;
-#pragma unroll
-                    for (int c = 0; c < WFA_NC; c++) {
-                        int k = m.lo + lane + 64 * c;
-                        if (k <= m.hi) {
-                            int d = wf_dist(rm[k - m.alo], k, plen, tlen);
-                            dmin = d < dmin ? d : dmin;
-                        }
-                    }
-                    dmin = wave_min_i32(dmin);
-                    auto keep = [&](int k) { return wf_dist(rm[k - m.alo], k, plen, tlen) - dmin <= 50; };
-                    int nlo = m.lo, nhi = m.hi;
-                    int top = ak < m.hi ? ak : m.hi;
-                    if (m.lo < top) nlo = wave_find_first(m.lo, top, lane, keep);
-                    int bottom = ak > nlo ? ak : nlo;
-                    if (m.hi > bottom) nhi = wave_find_last(m.hi, bottom, lane, keep);
-                    m.lo = nlo;
-                    m.hi = nhi;
-                    setM(ms, m);
-                    WfHdr hi_ = get3(hI, is), hd_ = get3(hD, is);
-                    if (hi_.lo <= hi_.hi) {
-                        if (nlo > hi_.lo) hi_.lo = nlo;
-                        if (nhi < hi_.hi) hi_.hi = nhi;
-                        set3(hI, is, hi_);
-                    }
-                    if (hd_.lo <= hd_.hi) {
-                        if (nlo > hd_.lo) hd_.lo = nlo;
-                        if (nhi < hd_.hi) hd_.hi = nhi;
-                        set3(hD, is, hd_);
-                    }
-                }
-            }
-            // global header of score s (final after extension / cut-off)
-            if (lane == 0) {
-                WfHdr hi_ = get3(hI, is), hd_ = get3(hD, is);
-                int32_t *ho = hdr + s * 9;
-                ho[0] = m.lo; ho[1] = m.hi; ho[2] = (int32_t)(gbM + (m.lo - m.alo));
-                ho[3] = hi_.lo; ho[4] = hi_.hi; ho[5] = (int32_t)(gbI + (hi_.lo - hi_.alo));
-                ho[6] = hd_.lo; ho[7] = hd_.hi; ho[8] = (int32_t)(gbD + (hd_.lo - hd_.alo));
-            }
-            if (done) break;
-            s++;
-            if (s >= max_score) {
-                status = 1;
-                break;
-            }
-            // ---- compute score s from the LDS ring ----
-            const int ns = s % 9, nis = s % 3;
-            WfHdr mm = s - X >= 0 ? getM((s - X) % 9) : WfHdr{1, -1, 0};
-            WfHdr mo = s - OE >= 0 ? getM((s - OE) % 9) : WfHdr{1, -1, 0};
-            WfHdr ie = s - E >= 0 ? get3(hI, (s - E) % 3) : WfHdr{1, -1, 0};
-            WfHdr de = s - E >= 0 ? get3(hD, (s - E) % 3) : WfHdr{1, -1, 0};
-            int lo = 2147483647, hi = -2147483647;
-            bool any = false;
-            if (mm.lo <= mm.hi) { any = true; lo = mm.lo < lo ? mm.lo : lo; hi = mm.hi > hi ? mm.hi : hi; }
-            if (mo.lo <= mo.hi) { any = true; lo = mo.lo - 1 < lo ? mo.lo - 1 : lo; hi = mo.hi + 1 > hi ? mo.hi + 1 : hi; }
-            if (ie.lo <= ie.hi) { any = true; lo = ie.lo + 1 < lo ? ie.lo + 1 : lo; hi = ie.hi + 1 > hi ? ie.hi + 1 : hi; }
-            if (de.lo <= de.hi) { any = true; lo = de.lo - 1 < lo ? de.lo - 1 : lo; hi = de.hi - 1 > hi ? de.hi - 1 : hi; }
-            if (!any || lo > hi) {
-                setM(ns, {1, -1, 0});
-                set3(hI, nis, {1, -1, 0});
-                set3(hD, nis, {1, -1, 0});
-                gbM = gbI = gbD = 0;
-                continue;
-            }
-            int wd = hi - lo + 1;
-            if (wd > WFA_W) {
-                status = 3;
-                break;
-            }
-            if (used + 3ll * wd > arena_cap) {
-                status = 1;
-                break;
-            }
-            gbM = used;
-            gbI = used + wd;
-            gbD = used + 2ll * wd;
-            used += 3ll * wd;
-            const int32_t *rmm = ringM[(s - X + 9) % 9], *rmo = ringM[(s - OE + 18) % 9];
-            const int32_t *rie = ringI[(s - E + 3) % 3], *rde = ringD[(s - E + 3) % 3];
-            int32_t vi[WFA_NC], vd[WFA_NC], vm[WFA_NC];
-#pragma unroll
-            for (int c = 0; c < WFA_NC; c++) {
-                int k = lo + lane + 64 * c;
-                vi[c] = vd[c] = vm[c] = LM_NULL_OFF;
-                if (k > hi) continue;
-                int32_t a = lds_val(rmo, mo, k - 1), b = lds_val(rie, ie, k - 1);
-                int32_t ins = (a > b ? a : b) + 1;
-                a = lds_val(rmo, mo, k + 1);
-                b = lds_val(rde, de, k + 1);
-                int32_t del = a > b ? a : b;
-                int32_t mis = lds_val(rmm, mm, k) + 1;
-                int32_t mx = mis > ins ? mis : ins;
-                if (del > mx) mx = del;
-                uint32_t hh = (uint32_t)mx, vv = (uint32_t)(mx - k);
-                if (hh > (uint32_t)tlen) mx = LM_NULL_OFF;
-                if (vv > (uint32_t)plen) mx = LM_NULL_OFF;
-                vi[c] = ins;
-                vd[c] = del;
-                vm[c] = mx;
-            }
-            LDS_WAVE_SYNC(); // all reads of the ring done before slot ns / nis are overwritten
-#pragma unroll
-            for (int c = 0; c < WFA_NC; c++) {
-                int k = lo + lane + 64 * c;
-                if (k > hi) continue;
-                ringI[nis][k - lo] = vi[c];
-                ringD[nis][k - lo] = vd[c];
-                ringM[ns][k - lo] = vm[c];
-                pvi[c] = vi[c];
-                pvd[c] = vd[c];
-            }
-            pend = true; // the I/D stores of this score are issued after the next extension's loads (see below)
-            plo = lo;
-            phi = hi;
-            LDS_WAVE_SYNC();
-            WfHdr nm = {lo, hi, lo}, ni = {lo, hi, lo}, nd = {lo, hi, lo};
-            lds_trim(nm, ringM[ns], plen, tlen, lane);
-            lds_trim(ni, ringI[nis], plen, tlen, lane);
-            lds_trim(nd, ringD[nis], plen, tlen, lane);
-            setM(ns, nm);
-            set3(hI, nis, ni);
-            set3(hD, nis, nd);
-            // M of a null range still needs its (never read) arena cells defined for the store in the next iteration
-        }
-        __syncthreads(); // the backtrace (lane 0) reads what every lane stored to global memory
-        if (lane == 0) {
-            WfaOut o;
-            o.blast_score = 0;
-            if (status != 0) {
-                o.r.status = status;
-                o.r.score = 0;
-                o.r.nops = 0;
-                o.r.qbegin = o.r.qend = o.r.tbegin = o.r.tend = 0;
-                o.r.align_len = o.r.matches = o.r.gaps = o.r.gap_regions = 0;
-            } else {
-                uint64_t *ops = ops_pool + w.ops_off;
-                lm_wfa_backtrace(hdr, arena, s, plen, tlen, ops, w.ops_cap, &o.r);
-                if (o.r.status == 0) {
-                    int first = -1, last = -1;
-                    for (int j = 0; j < o.r.nops; j++)
-                        if ((ops[j] >> 32) == 'M') {
-                            if (first < 0) first = j;
-                            last = j;
-                        }
-                    int score = 0;
-                    for (int j = first; j >= 0 && j <= last; j++) {
-                        int nn = (int)(ops[j] & 0xffffffffu);
-                        char op = (char)(ops[j] >> 32);
-                        if (op == 'M')
-                            score += nn * 2;
-                        else if (op == 'X')
-                            score += nn * -3;
-                        else
-                            score -= 5 + nn * 2;
-                    }
-                    o.blast_score = score;
-                }
-            }
-            out[i] = o;
-            sh_x = atomicAdd(queue, 1u);
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------------------
 // host-callable launchers
@@ -2020,17 +1791,17 @@ static int resident_blocks_of(const void *kern, int device, int seq_words) {
     return nb * cus;
 }
 int wfa_resident_blocks(int device, int seq_words, int kind) {
-    return resident_blocks_of(kind == 0 ? (const void *)k_wfa_l64 : (const void *)k_wfa_lds, device, seq_words);
+    return resident_blocks_of(kind == 0 ? (const void *)k_wfa_lean<1> : (const void *)k_wfa_lean<2>, device, seq_words);
 }
 void launch_wfa(hipStream_t st, int kind, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks,
                 int32_t *hdr_pool, int64_t hdr_stride, int32_t *arena_pool, int64_t arena_stride, uint64_t *ops_pool,
                 unsigned int *queue, int seq_words, WfaOut *out) {
     size_t dyn = (size_t)(2 * (seq_words + 1)) * sizeof(uint32_t);
     if (kind == 0)
-        hipLaunchKernelGGL(k_wfa_l64, dim3(nblocks), dim3(64), dyn, st, in, n, todo, ntodo, hdr_pool, hdr_stride, arena_pool,
+        hipLaunchKernelGGL(k_wfa_lean<1>, dim3(nblocks), dim3(64), dyn, st, in, n, todo, ntodo, hdr_pool, hdr_stride, arena_pool,
                            arena_stride, ops_pool, queue, seq_words, out);
     else
-        hipLaunchKernelGGL(k_wfa_lds, dim3(nblocks), dim3(64), dyn, st, in, n, todo, ntodo, hdr_pool, hdr_stride, arena_pool,
+        hipLaunchKernelGGL(k_wfa_lean<2>, dim3(nblocks), dim3(64), dyn, st, in, n, todo, ntodo, hdr_pool, hdr_stride, arena_pool,
                            arena_stride, ops_pool, queue, seq_words, out);
 }
 void launch_wfa_wide(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int32_t *hdr_pool,

@@ -1114,7 +1114,7 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
             HIPCHK(hipMemcpyAsync(a.wfa_todo.p, items.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice, ix->st));
             HIPCHK(hipMemsetAsync(a.wfa_queue.p, 0, sizeof(unsigned int), ix->st));
             {
-                Prof p(ix, kind == 0 ? "k_wfa" : "k_wfa_w128", wfa_bytes(in, items));
+                Prof p(ix, kind == 0 ? "k_wfa_lean64" : "k_wfa_lean128", wfa_bytes(in, items));
                 launch_wfa(ix->st, kind, a.wfa_in.p, n, a.wfa_todo.p, m, nblocks, a.hdr_pool.p, rows * 9, a.arena_pool.p,
                            cells, a.ops_pool.p, a.wfa_queue.p, seq_words, a.wfa_out.p);
             }
@@ -1141,11 +1141,19 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
                 }
             }
         };
-        std::vector<int32_t> wide1, wide2;
-        if (getenv("LM_DEBUG_SKIP_WFA_L64")) // debugging aid: force everything through the 128-diagonal kernel
-            wide1 = order;
-        else
-            persistent_pass(0, order, wide1);
+        // 64-diagonal kernel for the problems expected to stay narrow (low divergence, similar lengths: wavefronts of
+        // <= 48 diagonals up to ~6% divergence), 128-diagonal kernel for the rest and for what outgrows the first
+        std::vector<int32_t> narrow, wide1, wide2;
+        const bool skip64 = getenv("LM_DEBUG_SKIP_WFA_L64") != nullptr; // debugging aid
+        for (int32_t i : order) {
+            float dv = est_div ? (*est_div)[i] : 0.12f;
+            int dl = in[i].tlen - in[i].qlen;
+            if (!skip64 && dv <= 0.06f && dl >= -16 && dl <= 16)
+                narrow.push_back(i);
+            else
+                wide1.push_back(i);
+        }
+        if (!narrow.empty()) persistent_pass(0, narrow, wide1);
         if (!wide1.empty()) persistent_pass(1, wide1, wide2);
         for (int32_t i : wide2) { // wider than 128 diagonals, longer than the LDS buffers, or not plain ACGT
             is_wide[i] = 1;
