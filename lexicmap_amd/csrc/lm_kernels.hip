@@ -1300,6 +1300,198 @@ __device__ __forceinline__ unsigned long long rotr64(unsigned long long x, int r
     return r ? ((x >> r) | (x << (64 - r))) : x;
 }
 
+// Backtrace of one alignment by the whole wavefront (same walk as lm_wfa_backtrace, lm_algos.h): per step ONE coalesced
+// load brings the three header rows (27 lanes), five lanes then fetch the five candidate offsets in parallel, and the
+// choice is a wave max - two dependent global latencies per edit operation instead of ~16 with a single lane. The
+// statistics (bounds, aligned length, matches, gaps, BLAST score over the M-trimmed CIGAR) are accumulated while walking
+// instead of re-reading the ops; ops are only written when the caller wants the CIGAR.
+struct BtStats {
+    bool seen_m;
+    uint32_t align_len, matches, gaps, gap_regions;
+    int bscore;
+    uint32_t p_len, p_gaps, p_regions; // runs generated after the most recent 'M' run (pending)
+    int p_bscore, p_q, p_t;
+    int trail_q, trail_t; // consumed after the last 'M' of the alignment (generated before the first 'M' run)
+};
+__device__ __forceinline__ void bt_flush(BtStats &st, char op, uint32_t n, uint64_t *ops, int &wp, bool want_ops,
+                                         bool &overflow, int &nruns, int lane) {
+    if (n == 0) return;
+    nruns++;
+    if (want_ops) {
+        if (wp <= 0)
+            overflow = true;
+        else {
+            --wp;
+            if (lane == 0) ops[wp] = ((uint64_t)(uint8_t)op << 32) | n;
+        }
+    }
+    if (op == 'M') {
+        if (!st.seen_m) {
+            st.seen_m = true;
+            st.trail_q = st.p_q;
+            st.trail_t = st.p_t;
+        } else {
+            st.align_len += st.p_len;
+            st.gaps += st.p_gaps;
+            st.gap_regions += st.p_regions;
+            st.bscore += st.p_bscore;
+        }
+        st.p_len = st.p_gaps = st.p_regions = 0;
+        st.p_bscore = st.p_q = st.p_t = 0;
+        st.align_len += n;
+        st.matches += n;
+        st.bscore += 2 * (int)n;
+    } else {
+        st.p_len += n;
+        if (op == 'X') {
+            st.p_bscore -= 3 * (int)n;
+            st.p_q += (int)n;
+            st.p_t += (int)n;
+        } else {
+            st.p_gaps += n;
+            st.p_regions++;
+            st.p_bscore -= 5 + 2 * (int)n;
+            if (op == 'I')
+                st.p_t += (int)n;
+            else
+                st.p_q += (int)n;
+        }
+    }
+}
+__device__ __forceinline__ void wave_backtrace(const int32_t *__restrict__ hdr, const int32_t *__restrict__ arena, int s,
+                                               int plen, int tlen, uint64_t *__restrict__ ops, int ops_cap, bool want_ops,
+                                               int lane, LmWfaOut *out, int *blast) {
+    const int X = 4, OE = 8, E = 2;
+    const int ak = tlen - plen;
+    BtStats st;
+    st.seen_m = false;
+    st.align_len = st.matches = st.gaps = st.gap_regions = 0;
+    st.bscore = 0;
+    st.p_len = st.p_gaps = st.p_regions = 0;
+    st.p_bscore = st.p_q = st.p_t = 0;
+    st.trail_q = st.trail_t = 0;
+    int wp = ops_cap, nruns = 0;
+    char cur_op = 0;
+    uint32_t cur_n = 0;
+    bool overflow = false;
+    auto push = [&](char op, int nn) {
+        if (nn <= 0) return;
+        if (cur_op == op) {
+            cur_n += (uint32_t)nn;
+        } else {
+            bt_flush(st, cur_op, cur_n, ops, wp, want_ops, overflow, nruns, lane);
+            cur_op = op;
+            cur_n = (uint32_t)nn;
+        }
+    };
+    int score = s, k = ak;
+    int32_t offset = tlen;
+    int v = offset - k, h = offset;
+    int matrix = 0;
+    // per-lane roles: lanes 0..26 load header cell (row = lane / 9 of {s-X, s-OE, s-E}, column = lane % 9);
+    // lanes 0..4 evaluate one candidate each: 0 mismatch, 1 I-open, 2 D-open, 3 I-ext, 4 D-ext
+    const int hrow = lane / 9, hcol = lane - hrow * 9;
+    const int c_src = lane == 0 ? 0 : (lane == 1 || lane == 2) ? 9 : lane == 3 ? 18 + 3 : 18 + 6; // first header lane
+    const int c_dk = (lane == 1 || lane == 3) ? -1 : (lane == 2 || lane == 4) ? 1 : 0;
+    const int c_add = (lane == 0 || lane == 1 || lane == 3) ? 1 : 0;
+    const int c_tag = lane == 0 ? 9 : lane == 1 ? 1 : lane == 2 ? 3 : lane == 3 ? 2 : 4;
+    while (v > 0 && h > 0 && score > 0) {
+        const int s_mis = score - X, s_open = score - OE, s_ext = score - E;
+        int32_t hv = (hcol % 3 == 1) ? -1 : 1; // empty range for negative scores
+        if (lane < 27) {
+            const int srow = hrow == 0 ? s_mis : hrow == 1 ? s_open : s_ext;
+            if (srow >= 0) hv = hdr[srow * 9 + hcol];
+        }
+        const int32_t lo = __shfl(hv, c_src), hi = __shfl(hv, c_src + 1), base = __shfl(hv, c_src + 2);
+        int32_t cand = -1;
+        if (lane < 5) {
+            const bool use = matrix == 0 || (matrix == 1 && (lane == 1 || lane == 3)) || (matrix == 2 && (lane == 2 || lane == 4));
+            const int kq = k + c_dk;
+            if (use && kq >= lo && kq <= hi) {
+                const int32_t o = arena[base + (kq - lo)] + c_add;
+                if (o >= 0) cand = (o << 4) | c_tag;
+            }
+        }
+        // max over lanes 0..7 (the others hold -1)
+        int32_t mx = cand;
+        {
+            int32_t y = __shfl_xor(mx, 1);
+            mx = y > mx ? y : mx;
+            y = __shfl_xor(mx, 2);
+            mx = y > mx ? y : mx;
+            y = __shfl_xor(mx, 4);
+            mx = y > mx ? y : mx;
+        }
+        mx = __builtin_amdgcn_readfirstlane(mx);
+        if (mx < 0) break;
+        if (matrix == 0) {
+            const int32_t max_off = mx >> 4;
+            push('M', offset - max_off);
+            offset = max_off;
+            v = offset - k;
+            h = offset;
+            if (v <= 0 || h <= 0) break;
+        }
+        const int bt = mx & 15;
+        if (bt == 9) {
+            score = s_mis; matrix = 0; push('X', 1); --offset;
+        } else if (bt == 1) {
+            score = s_open; matrix = 0; push('I', 1); --k; --offset;
+        } else if (bt == 2) {
+            score = s_ext; matrix = 1; push('I', 1); --k; --offset;
+        } else if (bt == 3) {
+            score = s_open; matrix = 0; push('D', 1); ++k;
+        } else {
+            score = s_ext; matrix = 2; push('D', 1); ++k;
+        }
+        v = offset - k;
+        h = offset;
+    }
+    if (v > 0 && h > 0) {
+        int nm = v < h ? v : h;
+        push('M', nm);
+        v -= nm;
+        h -= nm;
+    }
+    if (v > 0) push('D', v);
+    if (h > 0) push('I', h);
+    bt_flush(st, cur_op, cur_n, ops, wp, want_ops, overflow, nruns, lane);
+    out->status = 0;
+    out->score = s;
+    out->nops = 0;
+    out->qbegin = out->qend = out->tbegin = out->tend = 0;
+    out->align_len = out->matches = out->gaps = out->gap_regions = 0;
+    *blast = 0;
+    if (overflow) {
+        out->status = 1;
+        return;
+    }
+    out->nops = nruns;
+    if (want_ops && wp > 0) { // move the runs to the front of the buffer (ascending chunks: destination is below the source)
+        __syncthreads();
+        for (int c = 0; c < nruns; c += 64) {
+            uint64_t x = 0;
+            if (c + lane < nruns) x = ops[wp + c + lane];
+            __syncthreads();
+            if (c + lane < nruns) ops[c + lane] = x;
+            __syncthreads();
+        }
+    }
+    if (!st.seen_m) {
+        out->status = 2;
+        return;
+    }
+    out->qbegin = st.p_q + 1;
+    out->tbegin = st.p_t + 1;
+    out->qend = plen - st.trail_q;
+    out->tend = tlen - st.trail_t;
+    out->align_len = st.align_len;
+    out->matches = st.matches;
+    out->gaps = st.gaps;
+    out->gap_regions = st.gap_regions;
+    *blast = st.bscore;
+}
+
 // ---- k_wfa_lean<NC>: the LDS wavefront kernel ------------------------------------------------------------------------
 // NC cells per lane (W = 64*NC diagonals): the cell of diagonal k of every ring row lives at LDS slot (k mod W), cells
 // outside a row's valid range hold LM_NULL_OFF, so the recurrence reads its five neighbours without range tests as long
@@ -1374,7 +1566,7 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                                                   int64_t ntodo, int32_t *__restrict__ hdr_pool, int64_t hdr_stride,
                                                   int32_t *__restrict__ arena_pool, int64_t arena_stride,
                                                   uint64_t *__restrict__ ops_pool, unsigned int *__restrict__ queue,
-                                                  int seq_words, WfaOut *__restrict__ out) {
+                                                  int seq_words, int want_ops, WfaOut *__restrict__ out) {
     static_assert(NC == 1 || NC == 2, "one or two cells per lane");
     constexpr int W = 64 * NC;
     __shared__ int32_t rM[9][W];
@@ -1653,21 +1845,20 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                 rD[is][slot] = (k >= dlo[0] && k <= dhi[0]) ? vdel[c] : LM_NULL_OFF;
             }
         }
-        __syncthreads(); // the backtrace (lane 0) reads what every lane stored to global memory
+        __syncthreads(); // the backtrace reads what every lane stored to global memory
+        WfaOut o;
+        o.blast_score = 0;
+        if (status != 0) {
+            o.r.status = status;
+            o.r.score = 0;
+            o.r.nops = 0;
+            o.r.qbegin = o.r.qend = o.r.tbegin = o.r.tend = 0;
+            o.r.align_len = o.r.matches = o.r.gaps = o.r.gap_regions = 0;
+        } else {
+            wave_backtrace(hdr, arena, s, plen, tlen, ops_pool + w.ops_off, w.ops_cap, want_ops != 0, lane, &o.r,
+                           &o.blast_score);
+        }
         if (lane == 0) {
-            WfaOut o;
-            o.blast_score = 0;
-            if (status != 0) {
-                o.r.status = status;
-                o.r.score = 0;
-                o.r.nops = 0;
-                o.r.qbegin = o.r.qend = o.r.tbegin = o.r.tend = 0;
-                o.r.align_len = o.r.matches = o.r.gaps = o.r.gap_regions = 0;
-            } else {
-                uint64_t *ops = ops_pool + w.ops_off;
-                lm_wfa_backtrace(hdr, arena, s, plen, tlen, ops, w.ops_cap, &o.r);
-                if (o.r.status == 0) o.blast_score = blast_score_of(ops, o.r.nops);
-            }
             out[i] = o;
             sh_x = atomicAdd(queue, 1u);
         }
@@ -1795,14 +1986,14 @@ int wfa_resident_blocks(int device, int seq_words, int kind) {
 }
 void launch_wfa(hipStream_t st, int kind, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks,
                 int32_t *hdr_pool, int64_t hdr_stride, int32_t *arena_pool, int64_t arena_stride, uint64_t *ops_pool,
-                unsigned int *queue, int seq_words, WfaOut *out) {
+                unsigned int *queue, int seq_words, int want_ops, WfaOut *out) {
     size_t dyn = (size_t)(2 * (seq_words + 1)) * sizeof(uint32_t);
     if (kind == 0)
         hipLaunchKernelGGL(k_wfa_lean<1>, dim3(nblocks), dim3(64), dyn, st, in, n, todo, ntodo, hdr_pool, hdr_stride, arena_pool,
-                           arena_stride, ops_pool, queue, seq_words, out);
+                           arena_stride, ops_pool, queue, seq_words, want_ops, out);
     else
         hipLaunchKernelGGL(k_wfa_lean<2>, dim3(nblocks), dim3(64), dyn, st, in, n, todo, ntodo, hdr_pool, hdr_stride, arena_pool,
-                           arena_stride, ops_pool, queue, seq_words, out);
+                           arena_stride, ops_pool, queue, seq_words, want_ops, out);
 }
 void launch_wfa_wide(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int32_t *hdr_pool,
                      int32_t *arena_pool, uint64_t *ops_pool, WfaOut *out) {

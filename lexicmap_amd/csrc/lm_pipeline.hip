@@ -1116,7 +1116,7 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
             {
                 Prof p(ix, kind == 0 ? "k_wfa_lean64" : "k_wfa_lean128", wfa_bytes(in, items));
                 launch_wfa(ix->st, kind, a.wfa_in.p, n, a.wfa_todo.p, m, nblocks, a.hdr_pool.p, rows * 9, a.arena_pool.p,
-                           cells, a.ops_pool.p, a.wfa_queue.p, seq_words, a.wfa_out.p);
+                           cells, a.ops_pool.p, a.wfa_queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p);
             }
             std::vector<WfaOut> tmp;
             d2h(ix, tmp, a.wfa_out.p, (size_t)n);
