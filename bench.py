@@ -58,6 +58,23 @@ WORKLOADS = {
 }
 
 
+def usable_cores():
+    """cores this process may really use: the CPU count capped by the affinity mask and the cgroup quota"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(index_dir, queries, seconds, ncores):
     """oracle (port) on the host cores, bounded sample; returns dict"""
     import multiprocessing as mp
@@ -289,7 +306,7 @@ def main():
     # CPU baseline on rank 0, N=1 only
     if rank == 0 and world == 1 and not args.no_cpu_baseline and index_dir:
         try:
-            ncores = os.cpu_count() or 1
+            ncores = usable_cores()
             cb = cpu_baseline(index_dir, cpu_queries or queries, args.cpu_seconds, ncores)
             if cpu_queries is not None:
                 cb["sample"] += ("; SAMPLE INDEX = %d members of one family fetched from the GPU-built set and indexed by "

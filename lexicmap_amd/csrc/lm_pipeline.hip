@@ -137,10 +137,23 @@ template <typename T> static void d2h(lm_index *ix, std::vector<T> &h, const T *
 static void sync(lm_index *ix) { HIPCHK(hipStreamSynchronize(ix->st)); }
 
 // Host-side glue between kernels is embarrassingly parallel over (query, genome) pairs: a small fork-join helper.
+static int host_threads() { // cores this process may use: hardware threads capped by the cgroup CPU quota and by 24
+    static int n = [] {
+        int v = (int)std::max(1u, std::thread::hardware_concurrency());
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            long long quota = 0, period = 0;
+            if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
+                v = (int)std::min<long long>(v, std::max<long long>(1, quota / period));
+            fclose(f);
+        }
+        return std::min(v, 24);
+    }();
+    return n;
+}
 template <typename F> static void parallel_for(int64_t n, int64_t grain, F f) {
     if (n <= 0) return;
     int64_t nchunks = (n + grain - 1) / grain;
-    int nt = (int)std::min<int64_t>(std::min<int64_t>(nchunks, 24), std::max(1u, std::thread::hardware_concurrency()));
+    int nt = (int)std::min<int64_t>(nchunks, host_threads());
     if (nt <= 1) {
         f((int64_t)0, n);
         return;
@@ -916,8 +929,6 @@ struct HspMeta { // host-side view of one WFA problem
     uint32_t q;
     HspIn in;
     HspExt ext;
-    WfaOut out;
-    std::vector<uint64_t> ops;
 };
 
 // Runs pseudo-alignment for tasks[t0,t1) (host copy `ht`), returns per task the Chain2 results.
@@ -1109,6 +1120,10 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
             cells = std::min<int64_t>(cells, std::min<int64_t>(3 * 128 * (smax + 1), 2000000000));
             cells = std::max<int64_t>(cells, 4096);
             int64_t rows = std::min<int64_t>(std::max<int64_t>(cells / 64, 256), smax + 1);
+            if (getenv("LM_DEBUG"))
+                fprintf(stderr, "[lm] wfa pass kind=%d problems=%lld blocks=%d (resident %d) cells/block=%lld rows=%lld seq_words=%d\n",
+                        kind, (long long)m, nblocks, wfa_resident_blocks(ix->device, seq_words, kind), (long long)cells,
+                        (long long)rows, seq_words);
             a.hdr_pool.ensure((size_t)(rows * 9) * nblocks + 16);
             a.arena_pool.ensure((size_t)cells * nblocks + 16);
             HIPCHK(hipMemcpyAsync(a.wfa_todo.p, items.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice, ix->st));
@@ -1440,36 +1455,37 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
         run_pseudo(a, ht, res_off, resv);
         double tb = now_ms();
         st.ms_pseudo += tb - ta;
-        // glue per segment (parallel over segments; the order of `genomes` stays the segment order)
+        // glue per segment with results (parallel; the order of `genomes` stays the segment order)
         size_t g0 = genomes.size();
         std::vector<HspMeta> hsps;
         {
-            std::vector<size_t> seg_start;
-            for (size_t i = 0; i < ht.size(); i++)
-                if (i == 0 || ht[i].seg != ht[i - 1].seg) seg_start.push_back(i);
-            seg_start.push_back(ht.size());
-            const int64_t ns = (int64_t)seg_start.size() - 1;
+            std::vector<std::pair<size_t, size_t>> active; // task ranges of the segments that have Chain2 results
+            for (size_t i = 0; i < ht.size();) {
+                size_t e = i;
+                while (e < ht.size() && ht[e].seg == ht[i].seg) e++;
+                if (res_off[e] > res_off[i] && ht[i].g >= 0) active.push_back({i, e});
+                i = e;
+            }
+            const int64_t ns = (int64_t)active.size();
             std::vector<HGenome> gens((size_t)ns);
-            std::vector<std::vector<HspMeta>> ghsps((size_t)ns);
-            (void)div_from_pseudo_pident(0); // builds its table before the threads use it
-            parallel_for(ns, 256, [&](int64_t s0, int64_t s1) {
+            std::vector<int32_t> nh((size_t)ns + 1, 0); // HSPs per segment
+            (void)div_from_pseudo_pident(0);            // builds its table before the threads use it
+            parallel_for(ns, 64, [&](int64_t s0, int64_t s1) {
                 for (int64_t si = s0; si < s1; si++) {
-                    size_t i = seg_start[si], e = seg_start[si + 1];
+                    size_t i = active[si].first, e = active[si].second;
                     HGenome &gen = gens[si];
                     gen.q = ht[i].q;
                     gen.bg = ht[i].bg;
                     gen.g = ht[i].g;
                     std::map<AKey, bool> keys;
-                    if (gen.g >= 0)
-                        for (size_t t = i; t < e; t++)
-                            glue_task(ix, gen, keys, ht[t], (int64_t)t, resv.data() + res_off[t],
-                                      (int)(res_off[t + 1] - res_off[t]));
-                    if (gen.sds.empty()) continue;
-                    // HSP list (Update2 + the start of the finalisation loops :2223-2255 / :2490-2522)
+                    for (size_t t = i; t < e; t++)
+                        glue_task(ix, gen, keys, ht[t], (int64_t)t, resv.data() + res_off[t],
+                                  (int)(res_off[t + 1] - res_off[t]));
+                    // HSP list (Update2 + the start of the finalisation loops :2223-2255 / :2490-2522): which chains
+                    // go to extendMatch/WFA; c.hsp = index within the genome for now
                     int qlen = (int)(qb->h_qoff[gen.q + 1] - qb->h_qoff[gen.q]);
-                    std::vector<HspMeta> &lh = ghsps[si];
-                    for (auto &cl : gen.sds) {
-                        const Task &t = ht[cl.task];
+                    int cnt = 0;
+                    for (auto &cl : gen.sds)
                         for (auto &c : cl.chains) {
                             c.aligned_fraction = (double)c.aligned_bases_q / (double)qlen * 100;
                             if (c.qbegin >= c.qend + 1) {
@@ -1488,6 +1504,30 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
                                 c.alive = false;
                                 continue;
                             }
+                            c.hsp = cnt++;
+                        }
+                    nh[si] = cnt;
+                }
+            });
+            std::vector<int64_t> hbase((size_t)ns + 1, 0);
+            for (int64_t si = 0; si < ns; si++) hbase[si + 1] = hbase[si] + nh[si];
+            hsps.resize((size_t)hbase[ns]);
+            parallel_for(ns, 64, [&](int64_t s0, int64_t s1) {
+                for (int64_t si = s0; si < s1; si++) {
+                    HGenome &gen = gens[si];
+                    int qlen = (int)(qb->h_qoff[gen.q + 1] - qb->h_qoff[gen.q]);
+                    for (auto &cl : gen.sds) {
+                        const Task &t = ht[cl.task];
+                        for (auto &c : cl.chains) {
+                            if (!c.alive || c.hsp < 0) continue;
+                            int start, end;
+                            if (cl.rc) {
+                                start = cl.tEnd - c.tend - c.tpos_offset_begin;
+                                end = cl.tEnd - c.tbegin - c.tpos_offset_begin + 1;
+                            } else {
+                                start = c.tpos_offset_begin + c.tbegin - cl.tBegin;
+                                end = c.tpos_offset_begin + c.tend - cl.tBegin + 1;
+                            }
                             int ext2 = ix->opt.ext_len2;
                             if (c.aligned_bases_q > 1000000)
                                 ext2 += 80;
@@ -1497,7 +1537,8 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
                                 ext2 += 20;
                             else if (c.aligned_bases_q > 10000)
                                 ext2 += 10;
-                            HspMeta h;
+                            c.hsp += hbase[si];
+                            HspMeta &h = hsps[(size_t)c.hsp];
                             h.task = cl.task;
                             h.est_div = (float)div_from_pseudo_pident(c.pident);
                             h.q = gen.q;
@@ -1514,22 +1555,13 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
                             h.in.tbegin = c.tbegin;
                             h.in.max_ext_len = c.max_ext_len;
                             h.in.pad = 0;
-                            c.hsp = (int64_t)lh.size(); // local index, rebased below
-                            lh.push_back(h);
                         }
                     }
                 }
             });
-            for (int64_t si = 0; si < ns; si++) {
-                if (gens[si].sds.empty()) continue;
-                int64_t base = (int64_t)hsps.size();
-                if (base)
-                    for (auto &cl : gens[si].sds)
-                        for (auto &c : cl.chains)
-                            if (c.hsp >= 0) c.hsp += base;
-                hsps.insert(hsps.end(), ghsps[si].begin(), ghsps[si].end());
-                genomes.push_back(std::move(gens[si]));
-            }
+            genomes.reserve(genomes.size() + (size_t)ns);
+            for (int64_t si = 0; si < ns; si++)
+                if (!gens[si].sds.empty()) genomes.push_back(std::move(gens[si]));
         }
         double tc = now_ms();
         st.ms_glue += tc - tb;
@@ -1679,6 +1711,7 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
             std::stable_sort(gen.sds.begin(), gen.sds.end(), [](const HCluster &x, const HCluster &y) { return x.sim > y.sim; });
         }
         });
+        if (getenv("LM_DEBUG")) fprintf(stderr, "[lm] finalize: parallel part %.2f ms\n", now_ms() - td);
         st.ms_finalize += now_ms() - td;
         tpos = tend;
     }
@@ -1755,6 +1788,7 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
             i = e;
         }
     }
+    if (getenv("LM_DEBUG")) fprintf(stderr, "[lm] row emission %.2f ms\n", now_ms() - te0);
     st.ms_finalize += now_ms() - te0;
     st.ms_total = st.ms_mask + st.ms_lookup + st.ms_chain + st.ms_window + st.ms_pseudo + st.ms_glue + st.ms_extend_wfa +
                   st.ms_finalize;
