@@ -1595,6 +1595,10 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
         const WfaIn w = in[i];
         const int plen = w.qlen, tlen = w.tlen;
         const int ak = tlen - plen;
+        // slot of diagonal k = (k + koff) mod W: the band between diagonal 0 and the final diagonal ak is centred on the
+        // first 64 slots, so that the second cell of every lane (NC == 2) is only touched when a wavefront is wide or
+        // has drifted (chunks without a valid cell are skipped with a scalar branch)
+        const int koff = 32 - (ak >= -40 && ak <= 40 ? ak / 2 : 0);
         int status = 0;
         LDS_WAVE_SYNC(); // the previous alignment is done with the packed sequences and the ring
         {
@@ -1634,10 +1638,17 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
         if (max_score < 1 || arena_cap < 1) status = 1;
         mlo[0] = mhi[0] = 0;
         LDS_WAVE_SYNC();
-        if (lane == 0) rM[0][0] = 0;
+        if (lane == 0) rM[0][koff & (W - 1)] = 0;
+        LDS_WAVE_SYNC();
         int s = 0, ms = 0, is = 0; // ring rows of score s
         int alo = 0;               // first diagonal of the arena slices of score s
         int64_t used = 1, gbM = 0, gbI = 0, gbD = 0;
+        // does the slot range of diagonals [lo, hi] touch the 64 slots of chunk c ?
+        auto chunk_has = [&](int c, int lo_, int hi_) {
+            if (NC == 1) return true;
+            const int s0 = (lo_ + koff) & (W - 1), s1 = s0 + (hi_ - lo_); // s1 < 2W
+            return c == 0 ? (s0 < 64 || s1 >= W) : (s1 >= 64 && !(s0 < 64 && s1 < 64));
+        };
         while (status == 0) {
             bool done = false;
             if (mlo[0] <= mhi[0]) {
@@ -1648,8 +1659,12 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
                     const int slot = lane + 64 * c;
-                    const int k = alo + ((slot - alo) & (W - 1)); // this cell's diagonal at score s
+                    const int k = alo + ((slot - koff - alo) & (W - 1)); // this cell's diagonal at score s
                     kc[c] = k;
+                    inr[c] = false;
+                    off[c] = LM_NULL_OFF;
+                    fin.w[c] = 0;
+                    if (!chunk_has(c, mlo[0], mhi[0])) continue;
                     inr[c] = k >= mlo[0] && k <= mhi[0];
                     int32_t o = rM[ms][slot];
                     if (inr[c] && o >= 0) {
@@ -1684,7 +1699,7 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                     SlotMask<NC> kb;
 #pragma unroll
                     for (int c = 0; c < NC; c++) kb.w[c] = __ballot(inr[c] && (dist[c] - dmin <= 50));
-                    kb = sm_rotr<NC>(kb, mlo[0]); // bit j <-> diagonal mlo+j
+                    kb = sm_rotr<NC>(kb, mlo[0] + koff); // bit j <-> diagonal mlo+j
                     int nlo = mlo[0], nhi = mhi[0];
                     const int top = ak < mhi[0] ? ak : mhi[0];
                     if (mlo[0] < top) {
@@ -1797,8 +1812,12 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
 #pragma unroll
             for (int c = 0; c < NC; c++) {
                 const int slot = lane + 64 * c;
-                const int k = lo + ((slot - lo) & (W - 1));
+                const int k = lo + ((slot - koff - lo) & (W - 1));
                 kk[c] = k;
+                inr[c] = false;
+                vins[c] = vdel[c] = vmx[c] = LM_NULL_OFF;
+                bm.w[c] = bi.w[c] = bd.w[c] = 0;
+                if (!chunk_has(c, lo, hi)) continue;
                 inr[c] = k <= hi;
                 const int sm1 = (slot + W - 1) & (W - 1), sp1 = (slot + 1) & (W - 1);
                 int32_t a = rM[r8][sm1], b = rI[r2][sm1];
@@ -1826,9 +1845,9 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                 bi.w[c] = __ballot(okc(ins));
                 bd.w[c] = __ballot(okc(del));
             }
-            bm = sm_rotr<NC>(bm, lo);
-            bi = sm_rotr<NC>(bi, lo);
-            bd = sm_rotr<NC>(bd, lo);
+            bm = sm_rotr<NC>(bm, lo + koff);
+            bi = sm_rotr<NC>(bi, lo + koff);
+            bd = sm_rotr<NC>(bd, lo + koff);
             const bool hm = sm_any<NC>(bm), hi_ = sm_any<NC>(bi), hd = sm_any<NC>(bd);
             mlo[0] = hm ? lo + sm_first<NC>(bm) : lo;
             mhi[0] = hm ? lo + sm_last<NC>(bm) : lo - 1;

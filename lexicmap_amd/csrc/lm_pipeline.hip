@@ -1163,7 +1163,7 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
         for (int32_t i : order) {
             float dv = est_div ? (*est_div)[i] : 0.12f;
             int dl = in[i].tlen - in[i].qlen;
-            if (!skip64 && dv <= 0.06f && dl >= -16 && dl <= 16)
+            if (!skip64 && dv <= 0.03f && dl >= -8 && dl <= 8)
                 narrow.push_back(i);
             else
                 wide1.push_back(i);
@@ -1718,75 +1718,96 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
     // ---- per query: sort genomes by best cluster (:2919-2921, ties by genome key), regroup by sseqid, emit rows ----
     double te0 = now_ms();
     {
-        size_t i = 0;
-        while (i < genomes.size()) {
-            size_t e = i;
-            while (e < genomes.size() && genomes[e].q == genomes[i].q) e++;
-            std::vector<HGenome *> gs;
-            for (size_t j = i; j < e; j++)
-                if (genomes[j].alive) gs.push_back(&genomes[j]);
-            std::stable_sort(gs.begin(), gs.end(), [](const HGenome *x, const HGenome *y) {
-                if (x->sds[0].sim != y->sds[0].sim) return x->sds[0].sim > y->sds[0].sim;
-                return x->bg < y->bg;
-            });
-            for (HGenome *g : gs) {
-                const HostGenome &G = ix->host.genomes[g->g];
-                // SortBySeqID (:1042-1096): group clusters by sseqid keeping first-seen order
+        std::vector<size_t> qstart; // first genome of every query that has any
+        for (size_t i = 0; i < genomes.size(); i++)
+            if (i == 0 || genomes[i].q != genomes[i - 1].q) qstart.push_back(i);
+        qstart.push_back(genomes.size());
+        const int64_t nqg = (int64_t)qstart.size() - 1;
+        std::vector<std::vector<lm_hsp>> qrows((size_t)nqg);
+        std::vector<int64_t> qbases((size_t)nqg, 0);
+        parallel_for(nqg, 4, [&](int64_t q0, int64_t q1) {
+            for (int64_t qi = q0; qi < q1; qi++) {
+                const size_t i = qstart[qi], e = qstart[qi + 1];
+                std::vector<lm_hsp> &rows = qrows[qi];
+                std::vector<HGenome *> gs;
+                for (size_t j = i; j < e; j++)
+                    if (genomes[j].alive) gs.push_back(&genomes[j]);
+                std::stable_sort(gs.begin(), gs.end(), [](const HGenome *x, const HGenome *y) {
+                    if (x->sds[0].sim != y->sds[0].sim) return x->sds[0].sim > y->sds[0].sim;
+                    return x->bg < y->bg;
+                });
                 std::vector<HCluster *> order;
-                std::vector<bool> used(g->sds.size(), false);
-                for (size_t x = 0; x < g->sds.size(); x++) {
-                    if (used[x]) continue;
-                    for (size_t y = x; y < g->sds.size(); y++)
-                        if (!used[y] && G.seq_ids[g->sds[y].seq_idx] == G.seq_ids[g->sds[x].seq_idx]) {
-                            order.push_back(&g->sds[y]);
-                            used[y] = true;
-                        }
-                }
-                int cls = 1, hspn = 1;
-                for (HCluster *cl : order) {
-                    for (auto &c : cl->chains) {
-                        if (!c.alive) continue;
-                        lm_hsp r;
-                        memset(&r, 0, sizeof r);
-                        r.query = g->q;
-                        r.hits = (uint32_t)gs.size();
-                        r.batch_genome = g->bg;
-                        r.qcov_genome = g->aligned_fraction;
-                        r.cls = cls;
-                        r.hsp = hspn++;
-                        r.seq_idx = cl->seq_idx;
-                        r.nseqs = G.nseqs;
-                        r.seq_len = G.seq_sizes[cl->seq_idx];
-                        r.nchunks = 1;
-                        r.chunk_idx = 0;
-                        r.rc = cl->rc ? 1 : 0;
-                        r.qcov_hsp = c.aligned_fraction;
-                        r.aligned_length = c.aligned_length;
-                        r.pident = c.pident;
-                        r.gaps = c.gaps;
-                        r.qbegin = c.qbegin;
-                        r.qend = c.qend;
-                        r.tbegin = c.tbegin;
-                        r.tend = c.tend;
-                        r.evalue = c.evalue;
-                        r.bitscore = c.bitscore;
-                        r.score = c.score;
-                        r.matched_bases = c.matched_bases;
-                        r.genome_id = G.id.c_str();
-                        r.seq_id = G.seq_ids[cl->seq_idx].c_str();
-                        r.cigar = c.cigar ? c.cigar->c_str() : nullptr;
-                        r.qseq = c.qseq ? c.qseq->c_str() : nullptr;
-                        r.sseq = c.tseq ? c.tseq->c_str() : nullptr;
-                        r.align = c.align ? c.align->c_str() : nullptr;
-                        res->rows.push_back(r);
-                        st.rows++;
-                        st.aligned_bases += c.aligned_length;
+                std::vector<char> used;
+                for (HGenome *g : gs) {
+                    const HostGenome &G = ix->host.genomes[g->g];
+                    // SortBySeqID (:1042-1096): group clusters by sseqid keeping first-seen order
+                    order.clear();
+                    used.assign(g->sds.size(), 0);
+                    for (size_t x = 0; x < g->sds.size(); x++) {
+                        if (used[x]) continue;
+                        for (size_t y = x; y < g->sds.size(); y++)
+                            if (!used[y] && (g->sds[y].seq_idx == g->sds[x].seq_idx ||
+                                             G.seq_ids[g->sds[y].seq_idx] == G.seq_ids[g->sds[x].seq_idx])) {
+                                order.push_back(&g->sds[y]);
+                                used[y] = 1;
+                            }
                     }
-                    cls++;
+                    int cls = 1, hspn = 1;
+                    for (HCluster *cl : order) {
+                        for (auto &c : cl->chains) {
+                            if (!c.alive) continue;
+                            rows.emplace_back();
+                            lm_hsp &r = rows.back();
+                            memset(&r, 0, sizeof r);
+                            r.query = g->q;
+                            r.hits = (uint32_t)gs.size();
+                            r.batch_genome = g->bg;
+                            r.qcov_genome = g->aligned_fraction;
+                            r.cls = cls;
+                            r.hsp = hspn++;
+                            r.seq_idx = cl->seq_idx;
+                            r.nseqs = G.nseqs;
+                            r.seq_len = G.seq_sizes[cl->seq_idx];
+                            r.nchunks = 1;
+                            r.chunk_idx = 0;
+                            r.rc = cl->rc ? 1 : 0;
+                            r.qcov_hsp = c.aligned_fraction;
+                            r.aligned_length = c.aligned_length;
+                            r.pident = c.pident;
+                            r.gaps = c.gaps;
+                            r.qbegin = c.qbegin;
+                            r.qend = c.qend;
+                            r.tbegin = c.tbegin;
+                            r.tend = c.tend;
+                            r.evalue = c.evalue;
+                            r.bitscore = c.bitscore;
+                            r.score = c.score;
+                            r.matched_bases = c.matched_bases;
+                            r.genome_id = G.id.c_str();
+                            r.seq_id = G.seq_ids[cl->seq_idx].c_str();
+                            r.cigar = c.cigar ? c.cigar->c_str() : nullptr;
+                            r.qseq = c.qseq ? c.qseq->c_str() : nullptr;
+                            r.sseq = c.tseq ? c.tseq->c_str() : nullptr;
+                            r.align = c.align ? c.align->c_str() : nullptr;
+                            qbases[qi] += c.aligned_length;
+                        }
+                        cls++;
+                    }
                 }
             }
-            i = e;
+        });
+        std::vector<size_t> roff((size_t)nqg + 1, 0);
+        for (int64_t qi = 0; qi < nqg; qi++) {
+            roff[qi + 1] = roff[qi] + qrows[qi].size();
+            st.aligned_bases += qbases[qi];
         }
+        res->rows.resize(roff[nqg]);
+        st.rows += (int64_t)roff[nqg];
+        parallel_for(nqg, 16, [&](int64_t q0, int64_t q1) {
+            for (int64_t qi = q0; qi < q1; qi++)
+                if (!qrows[qi].empty())
+                    memcpy(res->rows.data() + roff[qi], qrows[qi].data(), qrows[qi].size() * sizeof(lm_hsp));
+        });
     }
     if (getenv("LM_DEBUG")) fprintf(stderr, "[lm] row emission %.2f ms\n", now_ms() - te0);
     st.ms_finalize += now_ms() - te0;
