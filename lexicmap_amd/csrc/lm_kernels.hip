@@ -916,16 +916,150 @@ __global__ void k_extend_count(const HspIn *__restrict__ hsps, int64_t n, const 
     }
 }
 
+// One flank of extendMatch (lib-index-search-util.go:34-96): all pairs of equal 2-mers between the two flanks in the
+// order (q asc, t asc), then Chainer3 over them. The pairs come from bit masks: B[b] has bit t set when target flank
+// base t is b, so the target positions matching the 2-mer (a,b) are B[a] & (B[b] >> 1) - no inner loop over the target
+// flank (flanks are <= 50..130 bases; longer ones take the plain double loop of lm_extend_right).
+struct Mask128 {
+    unsigned long long lo, hi;
+};
+__device__ __forceinline__ void extend_side(const uint8_t *__restrict__ s1, int n1, const uint8_t *__restrict__ s2, int n2,
+                                            bool rev, LmSub *__restrict__ subs, int64_t *__restrict__ msi, int cap,
+                                            int *o1, int *o2) {
+    *o1 = 0;
+    *o2 = 0;
+    if (n1 < 2 || n2 < 2) return;
+    if (n2 > 128) {
+        lm_extend_right(s1, n1, s2, n2, rev, subs, msi, cap, o1, o2);
+        return;
+    }
+    Mask128 B0 = {0, 0}, B1 = {0, 0}, B2 = {0, 0}, B3 = {0, 0};
+    for (int t = 0; t < n2; t++) {
+        const uint32_t c = lm_base2bit(lm_flank_base(s2, n2, t, rev));
+        const unsigned long long bl = t < 64 ? 1ull << t : 0ull, bh = t >= 64 ? 1ull << (t - 64) : 0ull;
+        if (c == 0) { B0.lo |= bl; B0.hi |= bh; }
+        else if (c == 1) { B1.lo |= bl; B1.hi |= bh; }
+        else if (c == 2) { B2.lo |= bl; B2.hi |= bh; }
+        else { B3.lo |= bl; B3.hi |= bh; }
+    }
+    // valid 2-mer starts: t <= n2-2
+    Mask128 V;
+    {
+        const int nv = n2 - 1;
+        V.lo = nv >= 64 ? ~0ull : ((1ull << nv) - 1ull);
+        V.hi = nv <= 64 ? 0ull : (nv >= 128 ? ~0ull : ((1ull << (nv - 64)) - 1ull));
+    }
+    auto sel = [&](uint32_t c) -> Mask128 { return c == 0 ? B0 : c == 1 ? B1 : c == 2 ? B2 : B3; };
+    int n = 0;
+    uint32_t ca = lm_base2bit(lm_flank_base(s1, n1, 0, rev));
+    for (int p = 0; p + 1 < n1; p++) {
+        const uint32_t cb = lm_base2bit(lm_flank_base(s1, n1, p + 1, rev));
+        const Mask128 A = sel(ca), Bn = sel(cb);
+        // Bn >> 1 over 128 bits
+        unsigned long long mlo = A.lo & ((Bn.lo >> 1) | (Bn.hi << 63)) & V.lo;
+        unsigned long long mhi = A.hi & (Bn.hi >> 1) & V.hi;
+        while (mlo) {
+            const int t = __ffsll((long long)mlo) - 1;
+            mlo &= mlo - 1;
+            if (n >= cap) return;
+            LmSub x;
+            x.qbegin = p;
+            x.tbegin = t;
+            x.len = 2;
+            x.qrc = x.trc = x.pad = 0;
+            subs[n++] = x;
+        }
+        while (mhi) {
+            const int t = 64 + __ffsll((long long)mhi) - 1;
+            mhi &= mhi - 1;
+            if (n >= cap) return;
+            LmSub x;
+            x.qbegin = p;
+            x.tbegin = t;
+            x.len = 2;
+            x.qrc = x.trc = x.pad = 0;
+            subs[n++] = x;
+        }
+        ca = cb;
+    }
+    if (n == 0) return;
+    int qe, te;
+    if (lm_run_chain3(subs, n, msi, &qe, &te)) {
+        *o1 = qe + 1;
+        *o2 = te + 1;
+    }
+}
+
+// work item = (HSP, side): the two flanks of an HSP are independent, which doubles the parallelism of this
+// latency-bound stage. side 0 = right flank -> (e1, e2), side 1 = left flank -> (s1, s2).
 __global__ void k_extend(const HspIn *__restrict__ hsps, int64_t n, const uint8_t *__restrict__ qseq,
                          const int64_t *__restrict__ qoff, const uint8_t *__restrict__ wbuf,
                          const int32_t *__restrict__ cap, const int64_t *__restrict__ scratch_off,
                          LmSub *__restrict__ subs, int64_t *__restrict__ msi, HspExt *__restrict__ out) {
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < 2 * n; w += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = w >> 1;
+        const int side = (int)(w & 1);
+        const HspIn h = hsps[i];
+        const uint8_t *seq1 = qseq + qoff[h.q];
+        const uint8_t *seq2 = wbuf + h.woff;
+        const bool rc = h.rc != 0;
+        const int m = 2;
+        LmSub *sb = subs + 2 * scratch_off[i] + (int64_t)side * cap[i];
+        int64_t *ms = msi + 2 * scratch_off[i] + (int64_t)side * cap[i];
+        int d1 = 0, d2 = 0;
+        if (side == 0) {
+            if (h.end1 + m < h.len1 && h.end2 + m < h.len2) {
+                int ext = rc ? (h.ext_len < h.tbegin ? h.ext_len : h.tbegin)
+                             : (h.ext_len < h.max_ext_len ? h.ext_len : h.max_ext_len);
+                if (ext > 2) {
+                    int e1 = h.end1 + ext < h.len1 ? h.end1 + ext : h.len1;
+                    int e2 = h.end2 + ext < h.len2 ? h.end2 + ext : h.len2;
+                    extend_side(seq1 + h.end1, e1 - h.end1, seq2 + h.end2, e2 - h.end2, false, sb, ms, cap[i], &d1, &d2);
+                }
+            }
+            out[i].e1 = d1;
+            out[i].e2 = d2;
+        } else {
+            if (h.start1 > m && h.start2 > m) {
+                int ext = rc ? (h.ext_len < h.max_ext_len ? h.ext_len : h.max_ext_len)
+                             : (h.ext_len < h.tbegin ? h.ext_len : h.tbegin);
+                if (ext > 2) {
+                    int s1 = h.start1 - ext > 0 ? h.start1 - ext : 0;
+                    int s2 = h.start2 - ext > 0 ? h.start2 - ext : 0;
+                    extend_side(seq1 + s1, h.start1 - s1, seq2 + s2, h.start2 - s2, true, sb, ms, cap[i], &d1, &d2);
+                }
+            }
+            out[i].s1 = d1;
+            out[i].s2 = d2;
+        }
+    }
+}
+// the tail of extendMatch: apply the two flank results and the bounds checks (:84-95)
+__global__ void k_extend_fin(const HspIn *__restrict__ hsps, int64_t n, HspExt *__restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const HspIn h = hsps[i];
-        HspExt e;
-        lm_extend_match(qseq + qoff[h.q], h.len1, wbuf + h.woff, h.len2, h.start1, h.end1, h.start2, h.end2, h.ext_len,
-                        h.tbegin, h.max_ext_len, h.rc != 0, subs + scratch_off[i], msi + scratch_off[i], cap[i], &e.qs,
-                        &e.qe, &e.ts, &e.te, &e.s1, &e.e1, &e.s2, &e.e2);
+        HspExt e = out[i];
+        int start1 = h.start1, end1 = h.end1, start2 = h.start2, end2 = h.end2;
+        if (e.e1 > 0 || e.e2 > 0) {
+            end1 += e.e1;
+            end2 += e.e2;
+        }
+        if (e.s1 > 0 || e.s2 > 0) {
+            start1 -= e.s1;
+            start2 -= e.s2;
+        }
+        if (start1 < 0 || start2 < 0) {
+            start1 = h.start1;
+            start2 = h.start2;
+        }
+        if (end1 > h.len1 || end2 > h.len2) {
+            end1 = h.end1;
+            end2 = h.end2;
+        }
+        e.qs = start1;
+        e.qe = end1;
+        e.ts = start2;
+        e.te = end2;
         out[i] = e;
     }
 }
@@ -1292,7 +1426,8 @@ __device__ __forceinline__ uint32_t pack16(const uint8_t *__restrict__ s, int nb
 // 16 packed bases starting at base `pos` (needs one padding word after the last one)
 __device__ __forceinline__ uint32_t get16(const uint32_t *seq, int pos) {
     const int w = pos >> 4, sh = (pos & 15) << 1;
-    return __funnelshift_l(seq[w + 1], seq[w], sh);
+    const unsigned long long two = ((unsigned long long)seq[w] << 32) | seq[w + 1]; // both words, no branch on sh
+    return (uint32_t)((two << sh) >> 32);
 }
 
 __device__ __forceinline__ unsigned long long rotr64(unsigned long long x, int r) {
@@ -1569,9 +1704,12 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                                                   int seq_words, int want_ops, WfaOut *__restrict__ out) {
     static_assert(NC == 1 || NC == 2, "one or two cells per lane");
     constexpr int W = 64 * NC;
-    __shared__ int32_t rM[9][W];
-    __shared__ int32_t rI[3][W];
-    __shared__ int32_t rD[3][W];
+    // All penalties are even (x=4, o+e=8, e=2): only even scores have wavefronts, so the ring holds the last five even
+    // M scores (s, s-2, .. s-8) and the last two I / D scores, and the score loop steps by 2. (Odd scores are empty
+    // wavefronts in the reference and the backtrace never visits them.)
+    __shared__ int32_t rM[5][W];
+    __shared__ int32_t rI[2][W];
+    __shared__ int32_t rD[2][W];
     __shared__ unsigned int sh_x;
     extern __shared__ uint32_t seq_lds[];
     uint32_t *Qp = seq_lds, *Tp = seq_lds + seq_words + 1;
@@ -1619,19 +1757,19 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
 #pragma unroll
         for (int c = 0; c < NC; c++) {
 #pragma unroll
-            for (int r = 0; r < 9; r++) rM[r][lane + 64 * c] = LM_NULL_OFF;
+            for (int r = 0; r < 5; r++) rM[r][lane + 64 * c] = LM_NULL_OFF;
 #pragma unroll
-            for (int r = 0; r < 3; r++) rI[r][lane + 64 * c] = rD[r][lane + 64 * c] = LM_NULL_OFF;
+            for (int r = 0; r < 2; r++) rI[r][lane + 64 * c] = rD[r][lane + 64 * c] = LM_NULL_OFF;
         }
-        // valid ranges by age: mlo[a]..mhi[a] is M[s-a]
-        int mlo[9], mhi[9], ilo[3], ihi[3], dlo[3], dhi[3];
+        // valid ranges by age in even scores: mlo[a]..mhi[a] is M[s-2a]
+        int mlo[5], mhi[5], ilo[2], ihi[2], dlo[2], dhi[2];
 #pragma unroll
-        for (int a = 0; a < 9; a++) {
+        for (int a = 0; a < 5; a++) {
             mlo[a] = 1;
             mhi[a] = -1;
         }
 #pragma unroll
-        for (int a = 0; a < 3; a++) {
+        for (int a = 0; a < 2; a++) {
             ilo[a] = dlo[a] = 1;
             ihi[a] = dhi[a] = -1;
         }
@@ -1750,32 +1888,29 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                 hdr[s * 9 + lane] = hv;
             }
             if (done) break;
-            s++;
+            s += 2;
             if (s >= max_score) {
                 status = 1;
                 break;
             }
 #pragma unroll
-            for (int a = 8; a > 0; a--) {
+            for (int a = 4; a > 0; a--) {
                 mlo[a] = mlo[a - 1];
                 mhi[a] = mhi[a - 1];
             }
-#pragma unroll
-            for (int a = 2; a > 0; a--) {
-                ilo[a] = ilo[a - 1];
-                ihi[a] = ihi[a - 1];
-                dlo[a] = dlo[a - 1];
-                dhi[a] = dhi[a - 1];
-            }
-            ms = ms == 8 ? 0 : ms + 1;
-            is = is == 2 ? 0 : is + 1;
+            ilo[1] = ilo[0];
+            ihi[1] = ihi[0];
+            dlo[1] = dlo[0];
+            dhi[1] = dhi[0];
+            ms = ms == 4 ? 0 : ms + 1;
+            is ^= 1;
             // sources: M[s-4] (mismatch), M[s-8] (gap open), I[s-2] / D[s-2] (gap extension)
             int lo = 2147483647, hi = -2147483647;
             bool any = false;
-            if (mlo[4] <= mhi[4]) { any = true; lo = mlo[4] < lo ? mlo[4] : lo; hi = mhi[4] > hi ? mhi[4] : hi; }
-            if (mlo[8] <= mhi[8]) { any = true; lo = mlo[8] - 1 < lo ? mlo[8] - 1 : lo; hi = mhi[8] + 1 > hi ? mhi[8] + 1 : hi; }
-            if (ilo[2] <= ihi[2]) { any = true; lo = ilo[2] + 1 < lo ? ilo[2] + 1 : lo; hi = ihi[2] + 1 > hi ? ihi[2] + 1 : hi; }
-            if (dlo[2] <= dhi[2]) { any = true; lo = dlo[2] - 1 < lo ? dlo[2] - 1 : lo; hi = dhi[2] - 1 > hi ? dhi[2] - 1 : hi; }
+            if (mlo[2] <= mhi[2]) { any = true; lo = mlo[2] < lo ? mlo[2] : lo; hi = mhi[2] > hi ? mhi[2] : hi; }
+            if (mlo[4] <= mhi[4]) { any = true; lo = mlo[4] - 1 < lo ? mlo[4] - 1 : lo; hi = mhi[4] + 1 > hi ? mhi[4] + 1 : hi; }
+            if (ilo[1] <= ihi[1]) { any = true; lo = ilo[1] + 1 < lo ? ilo[1] + 1 : lo; hi = ihi[1] + 1 > hi ? ihi[1] + 1 : hi; }
+            if (dlo[1] <= dhi[1]) { any = true; lo = dlo[1] - 1 < lo ? dlo[1] - 1 : lo; hi = dhi[1] - 1 > hi ? dhi[1] - 1 : hi; }
             if (!any || lo > hi) {
                 mlo[0] = ilo[0] = dlo[0] = 1;
                 mhi[0] = ihi[0] = dhi[0] = -1;
@@ -1803,7 +1938,7 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
             gbD = used + 2ll * wd;
             used += 3ll * wd;
             alo = lo;
-            const int r4 = ms >= 4 ? ms - 4 : ms + 5, r8 = ms == 8 ? 0 : ms + 1, r2 = is == 2 ? 0 : is + 1;
+            const int r4 = ms >= 2 ? ms - 2 : ms + 3, r8 = ms == 4 ? 0 : ms + 1, r2 = is ^ 1; // rows of s-4, s-8, s-2
             LDS_WAVE_SYNC(); // the neighbours' extension results are in the ring
             int kk[NC];
             bool inr[NC];
@@ -1990,8 +2125,10 @@ void launch_extend_count(hipStream_t st, const HspIn *hsps, int64_t n, const uin
 void launch_extend(hipStream_t st, const HspIn *hsps, int64_t n, const uint8_t *qseq, const int64_t *qoff,
                    const uint8_t *wbuf, const int32_t *cap, const int64_t *scratch_off, LmSub *subs, int64_t *msi,
                    HspExt *out) {
-    hipLaunchKernelGGL(k_extend, dim3(grid_for(n, 64)), dim3(64), 0, st, hsps, n, qseq, qoff, wbuf, cap, scratch_off, subs,
-                       msi, out);
+    // subs / msi hold 2 * scratch_off[n] entries: both flanks of an HSP are chained concurrently
+    hipLaunchKernelGGL(k_extend, dim3(grid_for(2 * n, 64)), dim3(64), 0, st, hsps, n, qseq, qoff, wbuf, cap, scratch_off,
+                       subs, msi, out);
+    hipLaunchKernelGGL(k_extend_fin, dim3(grid_for(n, 256)), dim3(256), 0, st, hsps, n, out);
 }
 static int resident_blocks_of(const void *kern, int device, int seq_words) {
     int nb = 0, cus = 0;

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <malloc.h>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -135,6 +136,21 @@ template <typename T> static void d2h(lm_index *ix, std::vector<T> &h, const T *
     if (n) HIPCHK(hipMemcpyAsync(h.data(), d, n * sizeof(T), hipMemcpyDeviceToHost, ix->st));
 }
 static void sync(lm_index *ix) { HIPCHK(hipStreamSynchronize(ix->st)); }
+
+// Every call moves ~150 MB through freshly allocated host vectors (tasks, chains, HSP records, rows). With glibc's
+// defaults blocks above 128 KB are mmap'ed and unmapped again on free, so each call pays the page faults again (tens of
+// ms per batch). Keep big blocks on the heap instead; LM_KEEP_MALLOC_DEFAULTS=1 opts out.
+static void tune_malloc_once() {
+    static bool done = [] {
+        if (!getenv("LM_KEEP_MALLOC_DEFAULTS")) {
+            mallopt(M_MMAP_THRESHOLD, 1 << 30);
+            mallopt(M_TRIM_THRESHOLD, 2047 << 20);
+            mallopt(M_TOP_PAD, 64 << 20);
+        }
+        return true;
+    }();
+    (void)done;
+}
 
 // Host-side glue between kernels is embarrassingly parallel over (query, genome) pairs: a small fork-join helper.
 static int host_threads() { // cores this process may use: hardware threads capped by the cgroup CPU quota and by 24
@@ -1343,6 +1359,7 @@ static AlignCtx &get_actx(lm_index *ix, lm_qbatch *qb, Work *w, lm_stage_stats *
 
 static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
     std::lock_guard<std::mutex> lock(ix->mu);
+    tune_malloc_once();
     lm_stage_stats &st = res->stats;
     memset(&st, 0, sizeof st);
     HIPCHK(hipSetDevice(ix->device));
@@ -1582,8 +1599,8 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
             HIPCHK(hipMemsetAsync(a.ext_cap.p + NH, 0, sizeof(int32_t), ix->st));
             launch_extend_count(ix->st, a.hsp_in.p, NH, qb->d_seq.p, qb->d_qoff.p, a.wbuf.p, a.ext_cap.p);
             int64_t ES = scan_to_i64<int32_t, CastI32>(ix, a.ext_cap.p, NH, a.ext_off.p);
-            a.ext_subs.ensure((size_t)ES + 16);
-            a.ext_msi.ensure((size_t)ES + 16);
+            a.ext_subs.ensure(2 * (size_t)ES + 16); // both flanks of an HSP are chained concurrently
+            a.ext_msi.ensure(2 * (size_t)ES + 16);
             {
                 Prof p(ix, "k_extend");
                 launch_extend(ix->st, a.hsp_in.p, NH, qb->d_seq.p, qb->d_qoff.p, a.wbuf.p, a.ext_cap.p, a.ext_off.p,
