@@ -273,6 +273,8 @@ def main():
             kernels.append(dict(name=p["name"], launches=p["launches"], avg_ms=round(avg_ms, 4),
                                 algorithmic_bytes_per_launch=int(p["bytes"] / max(p["launches"], 1)),
                                 achieved_GBs=round(gbs, 3), frac_of_hbm_peak=round(gbs / HBM_PEAK_GBS, 6)))
+        prims = [dict(name=p["name"], launches=p["launches"], avg_ms=round(p["total_ms"] / max(p["launches"], 1), 4))
+                 for p in sorted(prof, key=lambda p: -p["total_ms"]) if not p["name"].startswith("k_")]
         roofline = None
         if dom:
             avg_ms = dom["total_ms"] / max(dom["launches"], 1)
@@ -301,6 +303,7 @@ def main():
             "rows": rows_total,
             "roofline": roofline,
             "kernels": kernels,
+            "rocprim_calls": prims,
         }
     gi.free_batch(qb)
     # CPU baseline on rank 0, N=1 only

@@ -99,8 +99,9 @@ void launch_gather_chain2(hipStream_t st, const LmChain2 *in, const int64_t *pa_
                           const int64_t *res_off, int64_t ntasks, LmChain2 *out);
 void launch_extend_count(hipStream_t st, const HspIn *hsps, int64_t n, const uint8_t *qseq, const int64_t *qoff,
                          const uint8_t *wbuf, int32_t *cap);
+void launch_extend_wave_cap(hipStream_t st, const int32_t *cap, int64_t n, int32_t *wcap, int64_t nw);
 void launch_extend(hipStream_t st, const HspIn *hsps, int64_t n, const uint8_t *qseq, const int64_t *qoff,
-                   const uint8_t *wbuf, const int32_t *cap, const int64_t *scratch_off, LmSub *subs, int64_t *msi,
+                   const uint8_t *wbuf, const int32_t *cap, const int64_t *woff, uint16_t *subs, int32_t *msi,
                    HspExt *out);
 // kind 0: k_wfa_l64 (<= 62 diagonals), kind 1: k_wfa_lds (<= 128 diagonals); both persistent with private scratch
 int wfa_resident_blocks(int device, int seq_words, int kind);

@@ -917,86 +917,176 @@ __global__ void k_extend_count(const HspIn *__restrict__ hsps, int64_t n, const 
 }
 
 // One flank of extendMatch (lib-index-search-util.go:34-96): all pairs of equal 2-mers between the two flanks in the
-// order (q asc, t asc), then Chainer3 over them. The pairs come from bit masks: B[b] has bit t set when target flank
-// base t is b, so the target positions matching the 2-mer (a,b) are B[a] & (B[b] >> 1) - no inner loop over the target
-// flank (flanks are <= 50..130 bases; longer ones take the plain double loop of lm_extend_right).
+// order (q asc, t asc), then Chainer3 (lib-chaining3.go, restated in lm_run_chain3) over them.
+// * pairs come from bit masks: B[b] has bit t set when target flank base t is b, so the target positions matching the
+//   2-mer (a,b) are B[a] & (B[b] >> 1) - no inner loop over the target flank (flanks are <= 50..130 bases);
+// * the per-item scratch is compressed (anchor = q | t << 8, DP cell = score << 16 | predecessor) and TRANSPOSED across
+//   the wavefront: element j of lane L lives at (j * 64 + L), so the 64 concurrent chainers of a wave share cache lines
+//   instead of touching 64 distant ones per step (this stage is bound by the latency of those dependent loads).
+__device__ __forceinline__ bool chain3_t(const uint16_t *__restrict__ subs, int n, int32_t *__restrict__ msi, int *qend_out,
+                                         int *tend_out) {
+    const int band_base = 10, band_count = 20, max_gap = 5, max_distance = 10, min_score = 1, min_align_len = 2;
+    if (n <= 0) return false;
+    int M = 0, Mi = 0;
+    for (int i = 0; i < n; i++) {
+        const uint32_t a = subs[(int64_t)i * 64];
+        const int aq = (int)(a & 255u), at = (int)(a >> 8);
+        int m = 2 - (aq > at ? aq : at) - (aq > at ? aq - at : at - aq);
+        int mj = i;
+        int bcount = 0;
+        for (int j = i - 1; j >= 0; j--) {
+            const uint32_t b = subs[(int64_t)j * 64];
+            const int bq = (int)(b & 255u), bt = (int)(b >> 8);
+            if (bq == aq || bt > at) continue;
+            bcount++;
+            const int bbase = aq - bq - 2;
+            if (!(bbase <= band_base || bcount <= band_count)) break;
+            int dq = aq - bq, dt = at - bt;
+            if (dq < 0) dq = -dq;
+            if (dt < 0) dt = -dt;
+            const int d = dq > dt ? dq : dt;
+            if (d > max_distance) continue;
+            const int g = dq > dt ? dq - dt : dt - dq;
+            if (g > max_gap) continue;
+            const int sc = (msi[(int64_t)j * 64] >> 16) + 2 - d - g;
+            if (sc >= m) {
+                m = sc;
+                mj = j;
+            }
+        }
+        msi[(int64_t)i * 64] = (int32_t)(((uint32_t)m << 16) | (uint32_t)(mj & 0xffff));
+        if (i > 0 && m > M) {
+            M = m;
+            Mi = i;
+        }
+    }
+    if (M < min_score) return false;
+    int n_matched = 0, n_abq = 0, n_abt = 0;
+    int i = Mi;
+    int qb = 0, qe = 0, tb = 0, te = 0, begin_of_next = 0;
+    bool first_anchor = true;
+    while (true) {
+        const int j = (int)((uint32_t)msi[(int64_t)i * 64] & 0xffffu);
+        const uint32_t sb = subs[(int64_t)i * 64];
+        const int sq = (int)(sb & 255u), st = (int)(sb >> 8);
+        if (first_anchor) {
+            first_anchor = false;
+            qe = sq + 1;
+            te = st + 1;
+            qb = sq;
+            tb = st;
+            n_matched += 2;
+        } else {
+            qb = sq;
+            tb = st;
+            if (sq + 1 >= begin_of_next)
+                n_matched += begin_of_next - sq;
+            else
+                n_matched += 2;
+        }
+        begin_of_next = sq;
+        if (i == j) {
+            n_abq += qe - qb + 1;
+            if (n_abq < min_align_len) return false;
+            n_abt += te - tb + 1;
+            const double pident = (double)n_matched / (double)(n_abq > n_abt ? n_abq : n_abt) * 100;
+            if (pident < 15) return false;
+            *qend_out = qe;
+            *tend_out = te;
+            return true;
+        }
+        i = j;
+    }
+}
+
 struct Mask128 {
     unsigned long long lo, hi;
 };
 __device__ __forceinline__ void extend_side(const uint8_t *__restrict__ s1, int n1, const uint8_t *__restrict__ s2, int n2,
-                                            bool rev, LmSub *__restrict__ subs, int64_t *__restrict__ msi, int cap,
+                                            bool rev, uint16_t *__restrict__ subs, int32_t *__restrict__ msi, int cap,
                                             int *o1, int *o2) {
     *o1 = 0;
     *o2 = 0;
-    if (n1 < 2 || n2 < 2) return;
-    if (n2 > 128) {
-        lm_extend_right(s1, n1, s2, n2, rev, subs, msi, cap, o1, o2);
-        return;
-    }
-    Mask128 B0 = {0, 0}, B1 = {0, 0}, B2 = {0, 0}, B3 = {0, 0};
-    for (int t = 0; t < n2; t++) {
-        const uint32_t c = lm_base2bit(lm_flank_base(s2, n2, t, rev));
-        const unsigned long long bl = t < 64 ? 1ull << t : 0ull, bh = t >= 64 ? 1ull << (t - 64) : 0ull;
-        if (c == 0) { B0.lo |= bl; B0.hi |= bh; }
-        else if (c == 1) { B1.lo |= bl; B1.hi |= bh; }
-        else if (c == 2) { B2.lo |= bl; B2.hi |= bh; }
-        else { B3.lo |= bl; B3.hi |= bh; }
-    }
-    // valid 2-mer starts: t <= n2-2
-    Mask128 V;
-    {
-        const int nv = n2 - 1;
-        V.lo = nv >= 64 ? ~0ull : ((1ull << nv) - 1ull);
-        V.hi = nv <= 64 ? 0ull : (nv >= 128 ? ~0ull : ((1ull << (nv - 64)) - 1ull));
-    }
-    auto sel = [&](uint32_t c) -> Mask128 { return c == 0 ? B0 : c == 1 ? B1 : c == 2 ? B2 : B3; };
+    if (n1 < 2 || n2 < 2 || n1 > 255 || n2 > 255) return; // flanks are at most ext_len2 + 80 = 130 bases
     int n = 0;
-    uint32_t ca = lm_base2bit(lm_flank_base(s1, n1, 0, rev));
-    for (int p = 0; p + 1 < n1; p++) {
-        const uint32_t cb = lm_base2bit(lm_flank_base(s1, n1, p + 1, rev));
-        const Mask128 A = sel(ca), Bn = sel(cb);
-        // Bn >> 1 over 128 bits
-        unsigned long long mlo = A.lo & ((Bn.lo >> 1) | (Bn.hi << 63)) & V.lo;
-        unsigned long long mhi = A.hi & (Bn.hi >> 1) & V.hi;
-        while (mlo) {
-            const int t = __ffsll((long long)mlo) - 1;
-            mlo &= mlo - 1;
-            if (n >= cap) return;
-            LmSub x;
-            x.qbegin = p;
-            x.tbegin = t;
-            x.len = 2;
-            x.qrc = x.trc = x.pad = 0;
-            subs[n++] = x;
+    if (n2 > 128) { // plain double loop (only reachable with the +80 extension of > 1 Mb alignments)
+        for (int p = 0; p + 1 < n1; p++) {
+            const uint32_t km1 = (lm_base2bit(lm_flank_base(s1, n1, p, rev)) << 2) | lm_base2bit(lm_flank_base(s1, n1, p + 1, rev));
+            for (int t = 0; t + 1 < n2; t++) {
+                const uint32_t km2 =
+                    (lm_base2bit(lm_flank_base(s2, n2, t, rev)) << 2) | lm_base2bit(lm_flank_base(s2, n2, t + 1, rev));
+                if (km1 == km2) {
+                    if (n >= cap) return;
+                    subs[(int64_t)(n++) * 64] = (uint16_t)(p | (t << 8));
+                }
+            }
         }
-        while (mhi) {
-            const int t = 64 + __ffsll((long long)mhi) - 1;
-            mhi &= mhi - 1;
-            if (n >= cap) return;
-            LmSub x;
-            x.qbegin = p;
-            x.tbegin = t;
-            x.len = 2;
-            x.qrc = x.trc = x.pad = 0;
-            subs[n++] = x;
+    } else {
+        Mask128 B0 = {0, 0}, B1 = {0, 0}, B2 = {0, 0}, B3 = {0, 0};
+        for (int t = 0; t < n2; t++) {
+            const uint32_t c = lm_base2bit(lm_flank_base(s2, n2, t, rev));
+            const unsigned long long bl = t < 64 ? 1ull << t : 0ull, bh = t >= 64 ? 1ull << (t - 64) : 0ull;
+            if (c == 0) { B0.lo |= bl; B0.hi |= bh; }
+            else if (c == 1) { B1.lo |= bl; B1.hi |= bh; }
+            else if (c == 2) { B2.lo |= bl; B2.hi |= bh; }
+            else { B3.lo |= bl; B3.hi |= bh; }
         }
-        ca = cb;
+        Mask128 V; // valid 2-mer starts: t <= n2-2
+        {
+            const int nv = n2 - 1;
+            V.lo = nv >= 64 ? ~0ull : ((1ull << nv) - 1ull);
+            V.hi = nv <= 64 ? 0ull : (nv >= 128 ? ~0ull : ((1ull << (nv - 64)) - 1ull));
+        }
+        auto sel = [&](uint32_t c) -> Mask128 { return c == 0 ? B0 : c == 1 ? B1 : c == 2 ? B2 : B3; };
+        uint32_t ca = lm_base2bit(lm_flank_base(s1, n1, 0, rev));
+        for (int p = 0; p + 1 < n1; p++) {
+            const uint32_t cb = lm_base2bit(lm_flank_base(s1, n1, p + 1, rev));
+            const Mask128 A = sel(ca), Bn = sel(cb);
+            unsigned long long mlo = A.lo & ((Bn.lo >> 1) | (Bn.hi << 63)) & V.lo;
+            unsigned long long mhi = A.hi & (Bn.hi >> 1) & V.hi;
+            while (mlo) {
+                const int t = __ffsll((long long)mlo) - 1;
+                mlo &= mlo - 1;
+                if (n >= cap) return;
+                subs[(int64_t)(n++) * 64] = (uint16_t)(p | (t << 8));
+            }
+            while (mhi) {
+                const int t = 64 + __ffsll((long long)mhi) - 1;
+                mhi &= mhi - 1;
+                if (n >= cap) return;
+                subs[(int64_t)(n++) * 64] = (uint16_t)(p | (t << 8));
+            }
+            ca = cb;
+        }
     }
     if (n == 0) return;
     int qe, te;
-    if (lm_run_chain3(subs, n, msi, &qe, &te)) {
+    if (chain3_t(subs, n, msi, &qe, &te)) {
         *o1 = qe + 1;
         *o2 = te + 1;
     }
 }
 
+// scratch rows needed by each wavefront of k_extend: the largest pair count of its 32 HSPs
+__global__ void k_extend_wave_cap(const int32_t *__restrict__ cap, int64_t n, int32_t *__restrict__ wcap, int64_t nw) {
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nw; w += (int64_t)gridDim.x * blockDim.x) {
+        int m = 0;
+        for (int64_t i = 32 * w; i < 32 * w + 32 && i < n; i++) m = cap[i] > m ? cap[i] : m;
+        wcap[w] = m;
+    }
+}
+
 // work item = (HSP, side): the two flanks of an HSP are independent, which doubles the parallelism of this
-// latency-bound stage. side 0 = right flank -> (e1, e2), side 1 = left flank -> (s1, s2).
-__global__ void k_extend(const HspIn *__restrict__ hsps, int64_t n, const uint8_t *__restrict__ qseq,
-                         const int64_t *__restrict__ qoff, const uint8_t *__restrict__ wbuf,
-                         const int32_t *__restrict__ cap, const int64_t *__restrict__ scratch_off,
-                         LmSub *__restrict__ subs, int64_t *__restrict__ msi, HspExt *__restrict__ out) {
-    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < 2 * n; w += (int64_t)gridDim.x * blockDim.x) {
+// latency-bound stage. side 0 = right flank -> (e1, e2), side 1 = left flank -> (s1, s2). One wavefront per workgroup;
+// woff[w] = first scratch row of wavefront w.
+__global__ __launch_bounds__(64) void k_extend(const HspIn *__restrict__ hsps, int64_t n, const uint8_t *__restrict__ qseq,
+                                               const int64_t *__restrict__ qoff, const uint8_t *__restrict__ wbuf,
+                                               const int32_t *__restrict__ cap, const int64_t *__restrict__ woff,
+                                               uint16_t *__restrict__ subs, int32_t *__restrict__ msi,
+                                               HspExt *__restrict__ out) {
+    for (int64_t wv = blockIdx.x; wv * 64 < 2 * n; wv += gridDim.x) {
+        const int64_t w = wv * 64 + threadIdx.x;
+        if (w >= 2 * n) continue;
         const int64_t i = w >> 1;
         const int side = (int)(w & 1);
         const HspIn h = hsps[i];
@@ -1004,8 +1094,8 @@ __global__ void k_extend(const HspIn *__restrict__ hsps, int64_t n, const uint8_
         const uint8_t *seq2 = wbuf + h.woff;
         const bool rc = h.rc != 0;
         const int m = 2;
-        LmSub *sb = subs + 2 * scratch_off[i] + (int64_t)side * cap[i];
-        int64_t *ms = msi + 2 * scratch_off[i] + (int64_t)side * cap[i];
+        uint16_t *sb = subs + woff[wv] * 64 + threadIdx.x;
+        int32_t *ms = msi + woff[wv] * 64 + threadIdx.x;
         int d1 = 0, d2 = 0;
         if (side == 0) {
             if (h.end1 + m < h.len1 && h.end2 + m < h.len2) {
@@ -2122,12 +2212,16 @@ void launch_extend_count(hipStream_t st, const HspIn *hsps, int64_t n, const uin
                          const uint8_t *wbuf, int32_t *cap) {
     hipLaunchKernelGGL(k_extend_count, dim3(grid_for(n, 64)), dim3(64), 0, st, hsps, n, qseq, qoff, wbuf, cap);
 }
+void launch_extend_wave_cap(hipStream_t st, const int32_t *cap, int64_t n, int32_t *wcap, int64_t nw) {
+    hipLaunchKernelGGL(k_extend_wave_cap, dim3(grid_for(nw, 256)), dim3(256), 0, st, cap, n, wcap, nw);
+}
 void launch_extend(hipStream_t st, const HspIn *hsps, int64_t n, const uint8_t *qseq, const int64_t *qoff,
-                   const uint8_t *wbuf, const int32_t *cap, const int64_t *scratch_off, LmSub *subs, int64_t *msi,
+                   const uint8_t *wbuf, const int32_t *cap, const int64_t *woff, uint16_t *subs, int32_t *msi,
                    HspExt *out) {
-    // subs / msi hold 2 * scratch_off[n] entries: both flanks of an HSP are chained concurrently
-    hipLaunchKernelGGL(k_extend, dim3(grid_for(2 * n, 64)), dim3(64), 0, st, hsps, n, qseq, qoff, wbuf, cap, scratch_off,
-                       subs, msi, out);
+    // one wavefront per 32 HSPs (64 flanks); subs / msi hold 64 * woff[nw] entries (transposed per wavefront)
+    int64_t nw = (2 * n + 63) / 64;
+    int g = (int)(nw < 1 ? 1 : (nw > 1048576 ? 1048576 : nw));
+    hipLaunchKernelGGL(k_extend, dim3(g), dim3(64), 0, st, hsps, n, qseq, qoff, wbuf, cap, woff, subs, msi, out);
     hipLaunchKernelGGL(k_extend_fin, dim3(grid_for(n, 256)), dim3(256), 0, st, hsps, n, out);
 }
 static int resident_blocks_of(const void *kern, int device, int seq_words) {

@@ -929,9 +929,9 @@ struct AlignCtx {
     DBuf<Task> tasks;
     DBuf<HspIn> hsp_in;
     DBuf<HspExt> hsp_ext;
-    DBuf<int32_t> ext_cap;
-    DBuf<int64_t> ext_off, ext_msi;
-    DBuf<LmSub> ext_subs;
+    DBuf<int32_t> ext_cap, ext_wcap, ext_msi;
+    DBuf<int64_t> ext_off;
+    DBuf<uint16_t> ext_subs;
     DBuf<WfaIn> wfa_in;
     DBuf<WfaOut> wfa_out;
     DBuf<int32_t> wfa_todo, wfa_todo2, hdr_pool, arena_pool;
@@ -973,7 +973,11 @@ static void run_pseudo(AlignCtx &a, const std::vector<Task> &ht, std::vector<int
         launch_pa_count(ix->st, ix->view, a.tasks.p, nt, a.wbuf.p, a.w->k_cmp, a.w->v_cmp, qb->d_posoff.p, a.w->nvalid.p,
                         a.w->cmp_tab.p, ix->host.k, 11, a.pa_counts.p);
     }
-    int64_t TP = scan_to_i64<uint32_t, CastU32>(ix, a.pa_counts.p, W, a.pa_offs.p);
+    int64_t TP;
+    {
+        Prof p(ix, "scan_pa_counts", W * 12);
+        TP = scan_to_i64<uint32_t, CastU32>(ix, a.pa_counts.p, W, a.pa_offs.p);
+    }
     a.stats->pa_anchors += TP;
     if (TP >= (int64_t)1 << 31) throw HipError("too many pseudo-alignment anchors in one chunk");
     a.pa_off.ensure((size_t)nt + 2);
@@ -1598,9 +1602,15 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
             HIPCHK(hipMemcpyAsync(a.hsp_in.p, hin.data(), sizeof(HspIn) * NH, hipMemcpyHostToDevice, ix->st));
             HIPCHK(hipMemsetAsync(a.ext_cap.p + NH, 0, sizeof(int32_t), ix->st));
             launch_extend_count(ix->st, a.hsp_in.p, NH, qb->d_seq.p, qb->d_qoff.p, a.wbuf.p, a.ext_cap.p);
-            int64_t ES = scan_to_i64<int32_t, CastI32>(ix, a.ext_cap.p, NH, a.ext_off.p);
-            a.ext_subs.ensure(2 * (size_t)ES + 16); // both flanks of an HSP are chained concurrently
-            a.ext_msi.ensure(2 * (size_t)ES + 16);
+            // scratch rows per wavefront of k_extend (32 HSPs = 64 flanks each), transposed layout
+            const int64_t NW = (2 * NH + 63) / 64;
+            a.ext_wcap.ensure((size_t)NW + 1);
+            a.ext_off.ensure((size_t)NW + 2);
+            HIPCHK(hipMemsetAsync(a.ext_wcap.p + NW, 0, sizeof(int32_t), ix->st));
+            launch_extend_wave_cap(ix->st, a.ext_cap.p, NH, a.ext_wcap.p, NW);
+            int64_t ER = scan_to_i64<int32_t, CastI32>(ix, a.ext_wcap.p, NW, a.ext_off.p);
+            a.ext_subs.ensure(64 * (size_t)ER + 64);
+            a.ext_msi.ensure(64 * (size_t)ER + 64);
             {
                 Prof p(ix, "k_extend");
                 launch_extend(ix->st, a.hsp_in.p, NH, qb->d_seq.p, qb->d_qoff.p, a.wbuf.p, a.ext_cap.p, a.ext_off.p,
