@@ -230,6 +230,7 @@ def main():
         rows, st = gi.search_resident_np(qb)
         if world > 1:
             if args.shard == "queries":
+                rows = rows.copy()  # the array is a view of the library's result
                 rows["query"] = rows["query"] * world + rank  # local -> global query number (round-robin sharding)
             per_rank = merge.all_gather_rows(rows, device="cuda")
             rows = merge.merge_sharded(per_rank) if args.shard == "index" else merge.merge_query_sharded(per_rank)

@@ -233,7 +233,10 @@ class Index:
         return out
 
     def search_resident_np(self, qb):
-        """rows as a numpy structured array sharing the lm_hsp layout (fast path for bench / merging) + stats"""
+        """rows as a numpy structured array VIEW of the library's lm_hsp rows (no copy; the lm_result is released when
+        the array is garbage collected) + stats. The six `char *` columns are process-local addresses (valid while the
+        array / the index are alive); lexicmap_amd.merge zeroes them before rows leave the process."""
+        import weakref
         import numpy as np
         from .merge import ROW_DTYPE
         L = lib()
@@ -247,12 +250,11 @@ class Index:
         L.lm_result_stats(res, C.byref(stats))
         if n:
             buf = (C.c_char * (n * C.sizeof(Hsp))).from_address(C.addressof(rows_p.contents))
-            arr = np.frombuffer(buf, dtype=ROW_DTYPE).copy()
+            arr = np.frombuffer(buf, dtype=ROW_DTYPE)
+            weakref.finalize(buf, L.lm_result_free, res)  # arr -> buf keeps the rows alive
         else:
             arr = np.zeros(0, dtype=ROW_DTYPE)
-        for f in ("genome_id", "seq_id", "cigar", "qseq", "sseq", "align"):
-            arr[f] = 0  # pointers into the freed result / the index are not portable
-        L.lm_result_free(res)
+            L.lm_result_free(res)
         return arr, {f[0]: getattr(stats, f[0]) for f in StageStats._fields_}
 
     def _collect(self, res, want_rows=True):

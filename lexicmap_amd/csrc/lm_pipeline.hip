@@ -28,6 +28,9 @@
 
 #include "lm_internal.h"
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <exception>
 #include <thread>
 
@@ -136,6 +139,50 @@ template <typename T> static void d2h(lm_index *ix, std::vector<T> &h, const T *
     if (n) HIPCHK(hipMemcpyAsync(h.data(), d, n * sizeof(T), hipMemcpyDeviceToHost, ix->st));
 }
 static void sync(lm_index *ix) { HIPCHK(hipStreamSynchronize(ix->st)); }
+
+// Big nested host containers (per-genome cluster/chain trees, task lists) are destroyed by a background thread: their
+// destructors are hundreds of thousands of small frees that would otherwise sit between two batches with the GPU idle.
+struct Janitor {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::function<void()>> q;
+    bool stop = false;
+    std::thread th;
+    Janitor() : th([this] { run(); }) {}
+    ~Janitor() {
+        {
+            std::lock_guard<std::mutex> l(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        th.join();
+    }
+    void run() {
+        std::unique_lock<std::mutex> l(mu);
+        while (true) {
+            cv.wait(l, [this] { return stop || !q.empty(); });
+            if (q.empty() && stop) return;
+            std::vector<std::function<void()>> work;
+            work.swap(q);
+            l.unlock();
+            for (auto &f : work) f();
+            work.clear();
+            l.lock();
+        }
+    }
+    template <typename T> void dispose(T &&obj) {
+        auto p = std::make_shared<typename std::decay<T>::type>(std::move(obj));
+        {
+            std::lock_guard<std::mutex> l(mu);
+            q.emplace_back([p]() mutable { p.reset(); });
+        }
+        cv.notify_one();
+    }
+};
+static Janitor &janitor() {
+    static Janitor j;
+    return j;
+}
 
 // Every call moves ~150 MB through freshly allocated host vectors (tasks, chains, HSP records, rows). With glibc's
 // defaults blocks above 128 KB are mmap'ed and unmapped again on free, so each call pays the page faults again (tens of
@@ -1371,10 +1418,16 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
     st.query_bases = qb->total_len;
     st.query_kmers = 2 * qb->total_pos;
     Work &w = get_work(ix, qb);
+    double tm1 = now_ms();
     stage_kmers(w);
+    double tm2 = now_ms();
     stage_mask(w);
+    double tm3 = now_ms();
     sync(ix);
     t1 = now_ms();
+    if (getenv("LM_DEBUG"))
+        fprintf(stderr, "[lm] mask stage: get_work %.2f, kmers(launch) %.2f, mask(launch) %.2f, sync %.2f ms\n", tm1 - t0,
+                tm2 - tm1, tm3 - tm2, t1 - tm3);
     st.ms_mask = t1 - t0;
     t0 = t1;
     stage_lookup(w, st);
@@ -1741,6 +1794,10 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
         if (getenv("LM_DEBUG")) fprintf(stderr, "[lm] finalize: parallel part %.2f ms\n", now_ms() - td);
         st.ms_finalize += now_ms() - td;
         tpos = tend;
+        janitor().dispose(std::move(hsps));
+        janitor().dispose(std::move(resv));
+        janitor().dispose(std::move(ht));
+        janitor().dispose(std::move(wout));
     }
     // ---- per query: sort genomes by best cluster (:2919-2921, ties by genome key), regroup by sseqid, emit rows ----
     double te0 = now_ms();
@@ -1840,6 +1897,8 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
     st.ms_finalize += now_ms() - te0;
     st.ms_total = st.ms_mask + st.ms_lookup + st.ms_chain + st.ms_window + st.ms_pseudo + st.ms_glue + st.ms_extend_wfa +
                   st.ms_finalize;
+    janitor().dispose(std::move(genomes));
+    janitor().dispose(std::move(tasks_h));
 }
 
 } // namespace lm

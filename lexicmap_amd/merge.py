@@ -47,6 +47,8 @@ def all_gather_rows(arr, device="cpu"):
     import torch.distributed as dist
     world = dist.get_world_size()
     arr = _cat([arr])
+    for f in ("genome_id", "seq_id", "cigar", "qseq", "sseq", "align"):
+        arr[f] = 0  # process-local addresses mean nothing on another rank
     payload = torch.from_numpy(np.frombuffer(arr.tobytes(), dtype=np.uint8).copy()).to(device)
     size = torch.tensor([payload.numel()], dtype=torch.int64, device=device)
     sizes = [torch.zeros_like(size) for _ in range(world)]
