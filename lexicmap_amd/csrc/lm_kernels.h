@@ -83,15 +83,12 @@ void launch_extract_windows(hipStream_t st, DevIndexView ix, const Task *tasks, 
 #define LM_TAB_BITS 12 /* bucket table over the first 6 bases of the query's sorted k-mers */
 void launch_build_cmp_tab(hipStream_t st, const uint64_t *keys_cmp, const int64_t *posoff, const int32_t *nvalid, int nq,
                           int K, uint32_t *tab);
-void launch_pa_count(hipStream_t st, DevIndexView ix, const Task *tasks, int64_t ntasks, const uint8_t *wbuf, const uint64_t *keys_cmp,
-                     const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_tab, int K,
-                     int min_prefix, uint32_t *counts);
-void launch_pa_emit(hipStream_t st, DevIndexView ix, const Task *tasks, int64_t ntasks, const uint8_t *wbuf, const uint64_t *keys_cmp,
-                    const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_tab, int K,
-                    int min_prefix, const uint32_t *counts, const int64_t *offs, uint64_t *outA, uint64_t *outB);
 void launch_sum_i32(hipStream_t st, const int32_t *v, int64_t n, unsigned long long *out);
-void launch_pa_task_off(hipStream_t st, const Task *tasks, int64_t ntasks, const int64_t *offs, int64_t total_pos,
-                        int64_t total_anchors, int64_t *pa_off);
+void launch_pa_anchors(hipStream_t st, DevIndexView ix, const Task *tasks, int64_t ntasks, const uint8_t *wbuf,
+                       const uint64_t *keys_cmp, const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid,
+                       const uint32_t *cmp_tab, int K, int min_prefix, unsigned long long *count, int64_t cap,
+                       uint64_t *outA, uint64_t *outB);
+void launch_pa_task_off_sorted(hipStream_t st, const uint64_t *sortedA, int64_t total, int64_t ntasks, int64_t *pa_off);
 void launch_pa_chain(hipStream_t st, const uint64_t *B, const int64_t *pa_off, int64_t ntasks, int K, LmChain2Opt opt,
                      LmSub *subs, uint8_t *marks, uint64_t *msi, int32_t *stack, LmChain2 *out, int32_t *out_n,
                      int32_t *clr_n);

@@ -431,42 +431,6 @@ __device__ __forceinline__ void pa_kmer(const Task &t, const uint8_t *__restrict
     }
 }
 
-template <bool EMIT>
-__device__ __forceinline__ uint32_t pa_position(const PaCtx &c, uint64_t kmer, uint64_t rc, int idx, uint64_t A,
-                                                uint64_t *outA, uint64_t *outB, int64_t o) {
-    uint32_t cnt = 0;
-    const int K = c.K;
-    if (kmer == 0 || kmer == c.ccc || kmer == c.ggg || kmer == c.ttt) return 0;
-    int lo, hi;
-    if (lm_tree_search_range_tab(c.keys, c.n, kmer, c.m, K, c.tab, LM_TAB_BITS, &lo, &hi)) {
-        for (int j = lo; j < hi; j++) {
-            uint32_t v = c.vals[j];
-            uint32_t lp = (uint32_t)lm_lcp(c.keys[j], kmer, K);
-            uint32_t p = v >> 1;
-            if ((v & 1u) == 1u || p < c.begin || p + lp > c.end) continue;
-            if (EMIT) {
-                outA[o + cnt] = A;
-                outB[o + cnt] = lm_pack_anchor((int)p, (int)lp, idx, false, false);
-            }
-            cnt++;
-        }
-    }
-    if (lm_tree_search_range_tab(c.keys, c.n, rc, c.m, K, c.tab, LM_TAB_BITS, &lo, &hi)) {
-        for (int j = lo; j < hi; j++) {
-            uint32_t v = c.vals[j];
-            uint32_t lp = (uint32_t)lm_lcp(c.keys[j], rc, K);
-            uint32_t p = (v >> 1) + (uint32_t)K - lp;
-            if ((v & 1u) == 0u || p + lp < c.begin || p > c.end) continue;
-            if (EMIT) {
-                outA[o + cnt] = A;
-                outB[o + cnt] = lm_pack_anchor((int)p, (int)lp, idx + K - (int)lp, true, true);
-            }
-            cnt++;
-        }
-    }
-    return cnt;
-}
-
 __device__ __forceinline__ PaCtx pa_ctx(const Task &t, const uint64_t *keys_cmp, const uint32_t *vals_cmp,
                                         const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_tab, int K,
                                         int min_prefix) {
@@ -485,61 +449,166 @@ __device__ __forceinline__ PaCtx pa_ctx(const Task &t, const uint64_t *keys_cmp,
     return c;
 }
 
-__global__ void k_pa_count(DevIndexView ix, const Task *__restrict__ tasks, int64_t ntasks,
-                           const uint8_t *__restrict__ wbuf, const uint64_t *__restrict__ keys_cmp,
-                           const uint32_t *__restrict__ vals_cmp, const int64_t *__restrict__ posoff,
-                           const int32_t *__restrict__ nvalid, const uint32_t *__restrict__ cmp_tab, int K, int min_prefix,
-                           uint32_t *__restrict__ counts) {
+// ---- single-pass pseudo-alignment anchors ----------------------------------------------------------------------------
+// k_pa_anchors replaces the count / scan / emit triple: one workgroup per chain window, every thread runs only the cheap
+// part per position (2-bit k-mer from the packed genome, bucket table, one or two probes). Positions that need more - a
+// non-empty match range to enumerate, or a candidate for the partial-prefix rule of tree.Search - are pushed into an LDS
+// work list that the whole workgroup then processes densely, so the expensive paths are not executed by every
+// wavefront for the sake of one lane. Anchors are staged in LDS and appended to the global list with one atomic per
+// flush; their order is irrelevant because the list is sorted by (task, B) afterwards. `count` keeps counting past
+// `cap`, so the host can re-run with a larger buffer.
+#define PA_QCAP 1024
+#define PA_OCAP 2048
+struct PaItem {
+    uint32_t pos_strand; // position << 1 | strand (1 = reverse complement)
+    int32_t lo, hi;      // hi >= 0: match range [lo, hi); hi < 0: partial-prefix candidate, lo = insertion point
+};
+__global__ __launch_bounds__(256) void k_pa_anchors(DevIndexView ix, const Task *__restrict__ tasks, int64_t ntasks,
+                                                     const uint8_t *__restrict__ wbuf,
+                                                     const uint64_t *__restrict__ keys_cmp,
+                                                     const uint32_t *__restrict__ vals_cmp,
+                                                     const int64_t *__restrict__ posoff, const int32_t *__restrict__ nvalid,
+                                                     const uint32_t *__restrict__ cmp_tab, int K, int min_prefix,
+                                                     unsigned long long *__restrict__ count, int64_t cap,
+                                                     uint64_t *__restrict__ outA, uint64_t *__restrict__ outB) {
+    __shared__ PaItem q_item[PA_QCAP];
+    __shared__ uint64_t s_out[PA_OCAP];
+    __shared__ int q_n, s_on;
+    __shared__ unsigned long long s_base;
+    const int tid = threadIdx.x;
     for (int64_t ti = blockIdx.x; ti < ntasks; ti += gridDim.x) {
         const Task t = tasks[ti];
         const uint8_t *w = wbuf + t.woff;
         const PaCtx c = pa_ctx(t, keys_cmp, vals_cmp, posoff, nvalid, cmp_tab, K, min_prefix);
         const uint8_t *gb = t.g >= 0 ? ix.gbits : nullptr;
         const int64_t goff = t.g >= 0 ? ix.g_off[t.g] : 0;
-        for (int i = threadIdx.x; i < t.wlen; i += blockDim.x) {
-            uint32_t cnt = 0;
-            if (i + K <= t.wlen && c.n > 0) {
+        const int npos = c.n > 0 ? t.wlen - K + 1 : 0;
+        const int sh = (K - (c.m > K ? K : c.m)) << 1;
+        const uint64_t low = sh >= 64 ? ~0ull : ((1ull << sh) - 1);
+        if (tid == 0) {
+            q_n = 0;
+            s_on = 0;
+        }
+        __syncthreads();
+        auto emit = [&](uint64_t B) {
+            int slot = atomicAdd(&s_on, 1);
+            if (slot < PA_OCAP) {
+                s_out[slot] = B;
+            } else { // staging buffer full (rare): straight to the global list
+                unsigned long long idx = atomicAdd(count, 1ull);
+                if ((int64_t)idx < cap) {
+                    outA[idx] = (uint64_t)ti;
+                    outB[idx] = B;
+                }
+            }
+        };
+        auto flush = [&]() { // all threads
+            __syncthreads();
+            const int n = s_on < PA_OCAP ? s_on : PA_OCAP;
+            if (tid == 0 && n > 0) s_base = atomicAdd(count, (unsigned long long)n);
+            __syncthreads();
+            for (int j = tid; j < n; j += 256) {
+                const unsigned long long idx = s_base + (unsigned long long)j;
+                if ((int64_t)idx < cap) {
+                    outA[idx] = (uint64_t)ti;
+                    outB[idx] = s_out[j];
+                }
+            }
+            __syncthreads();
+            if (tid == 0) s_on = 0;
+            __syncthreads();
+        };
+        auto drain = [&]() { // all threads: process the work list densely
+            __syncthreads();
+            const int nq = q_n < PA_QCAP ? q_n : PA_QCAP;
+            for (int base = 0; base < nq; base += 256) {
+                if (base + tid < nq) {
+                    const PaItem it = q_item[base + tid];
+                    const int i = (int)(it.pos_strand >> 1);
+                    const bool rcs = (it.pos_strand & 1u) != 0;
+                    uint64_t kmer, rc;
+                    pa_kmer(t, w, gb, goff, i, K, &kmer, &rc);
+                    const uint64_t key = rcs ? rc : kmer;
+                    int lo = it.lo, hi = it.hi;
+                    bool ok = hi >= 0;
+                    if (!ok) ok = lm_tree_search_miss(c.keys, c.n, key, c.m > K ? K : c.m, K, lo, &lo, &hi);
+                    if (ok) {
+                        for (int j = lo; j < hi; j++) {
+                            const uint32_t v = c.vals[j];
+                            const uint32_t lp = (uint32_t)lm_lcp(c.keys[j], key, K);
+                            if (!rcs) {
+                                const uint32_t p = v >> 1;
+                                if ((v & 1u) == 1u || p < c.begin || p + lp > c.end) continue;
+                                emit(lm_pack_anchor((int)p, (int)lp, i, false, false));
+                            } else {
+                                const uint32_t p = (v >> 1) + (uint32_t)K - lp;
+                                if ((v & 1u) == 0u || p + lp < c.begin || p > c.end) continue;
+                                emit(lm_pack_anchor((int)p, (int)lp, i + K - (int)lp, true, true));
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+                if (s_on > PA_OCAP / 2) flush(); // uniform: s_on is read after the barrier
+            }
+            __syncthreads();
+            if (tid == 0) q_n = 0;
+            __syncthreads();
+        };
+        for (int tile = 0; tile < npos; tile += 256) {
+            const int i = tile + tid;
+            if (i < npos) {
                 uint64_t kmer, rc;
                 pa_kmer(t, w, gb, goff, i, K, &kmer, &rc);
-                cnt = pa_position<false>(c, kmer, rc, i, 0, nullptr, nullptr, 0);
+                if (!(kmer == 0 || kmer == c.ccc || kmer == c.ggg || kmer == c.ttt)) {
+#pragma unroll
+                    for (int strand = 0; strand < 2; strand++) {
+                        const uint64_t key = strand ? rc : kmer;
+                        const uint32_t b = (uint32_t)(key >> ((K << 1) - LM_TAB_BITS));
+                        const int t0 = (int)c.tab[b], t1 = (int)c.tab[b + 1];
+                        const uint64_t left = key & ~low, right = key | low;
+                        const int lo = lm_lower_bound_u64(c.keys, t0, t1, left);
+                        PaItem it;
+                        it.pos_strand = ((uint32_t)i << 1) | (uint32_t)strand;
+                        it.lo = lo;
+                        bool push = false;
+                        if (lo < t1 && c.keys[lo] <= right) {
+                            it.hi = lm_upper_bound_u64(c.keys, lo + 1, t1, right);
+                            push = true;
+                        } else if (((key >> sh) & 3ull) == 0) { // partial-prefix rule needs base p-1 == A
+                            it.hi = -1;
+                            push = true;
+                        }
+                        if (push) {
+                            const int slot = atomicAdd(&q_n, 1);
+                            if (slot < PA_QCAP) q_item[slot] = it;
+                        }
+                    }
+                }
             }
-            counts[t.woff + i] = cnt;
+            __syncthreads();
+            if (q_n > PA_QCAP - 512) drain(); // at most 512 new items per tile: the list never overflows
         }
+        drain();
+        flush();
     }
 }
-
-__global__ void k_pa_emit(DevIndexView ix, const Task *__restrict__ tasks, int64_t ntasks,
-                          const uint8_t *__restrict__ wbuf, const uint64_t *__restrict__ keys_cmp,
-                          const uint32_t *__restrict__ vals_cmp, const int64_t *__restrict__ posoff,
-                          const int32_t *__restrict__ nvalid, const uint32_t *__restrict__ cmp_tab, int K, int min_prefix,
-                          const uint32_t *__restrict__ counts, const int64_t *__restrict__ offs,
-                          uint64_t *__restrict__ outA, uint64_t *__restrict__ outB) {
-    for (int64_t ti = blockIdx.x; ti < ntasks; ti += gridDim.x) {
-        const Task t = tasks[ti];
-        const uint8_t *w = wbuf + t.woff;
-        const PaCtx c = pa_ctx(t, keys_cmp, vals_cmp, posoff, nvalid, cmp_tab, K, min_prefix);
-        const uint8_t *gb = t.g >= 0 ? ix.gbits : nullptr;
-        const int64_t goff = t.g >= 0 ? ix.g_off[t.g] : 0;
-        for (int i = threadIdx.x; i < t.wlen; i += blockDim.x) {
-            if (counts[t.woff + i] == 0) continue;
-            uint64_t kmer, rc;
-            pa_kmer(t, w, gb, goff, i, K, &kmer, &rc);
-            pa_position<true>(c, kmer, rc, i, (uint64_t)ti, outA, outB, offs[t.woff + i]);
-        }
-    }
-}
-
-__global__ void k_pa_task_off(const Task *__restrict__ tasks, int64_t ntasks, const int64_t *__restrict__ offs,
-                              int64_t total_pos, int64_t total_anchors, int64_t *__restrict__ pa_off) {
+// first anchor of every task in the (task, B)-sorted list
+__global__ void k_pa_task_off_sorted(const uint64_t *__restrict__ sortedA, int64_t total, int64_t ntasks,
+                                     int64_t *__restrict__ pa_off) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= ntasks; i += (int64_t)gridDim.x * blockDim.x) {
-        if (i == ntasks) {
-            pa_off[i] = total_anchors;
-        } else {
-            int64_t w = tasks[i].woff;
-            pa_off[i] = w < total_pos ? offs[w] : total_anchors;
+        int64_t lo = 0, hi = total;
+        while (lo < hi) {
+            int64_t mid = (lo + hi) >> 1;
+            if (sortedA[mid] < (uint64_t)i)
+                lo = mid + 1;
+            else
+                hi = mid;
         }
+        pa_off[i] = lo;
     }
 }
+
 
 // Clear + Trim + Chainer2 per chain (lib-seq_compare.go:447-508)
 __global__ void k_pa_chain(const uint64_t *__restrict__ B, const int64_t *__restrict__ pa_off, int64_t ntasks, int K,
@@ -2174,28 +2243,21 @@ void launch_build_cmp_tab(hipStream_t st, const uint64_t *keys_cmp, const int64_
                           int K, uint32_t *tab) {
     LM_LAUNCH_1D(k_build_cmp_tab, (int64_t)nq * ((1 << LM_TAB_BITS) + 1), st, keys_cmp, posoff, nvalid, nq, K, LM_TAB_BITS, tab);
 }
-void launch_pa_count(hipStream_t st, DevIndexView ix, const Task *tasks, int64_t ntasks, const uint8_t *wbuf, const uint64_t *keys_cmp,
-                     const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_tab, int K,
-                     int min_prefix, uint32_t *counts) {
-    int g = (int)(ntasks < 1 ? 1 : (ntasks > 1048576 ? 1048576 : ntasks));
-    hipLaunchKernelGGL(k_pa_count, dim3(g), dim3(256), 0, st, ix, tasks, ntasks, wbuf, keys_cmp, vals_cmp, posoff, nvalid, cmp_tab,
-                       K, min_prefix, counts);
-}
-void launch_pa_emit(hipStream_t st, DevIndexView ix, const Task *tasks, int64_t ntasks, const uint8_t *wbuf, const uint64_t *keys_cmp,
-                    const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_tab, int K,
-                    int min_prefix, const uint32_t *counts, const int64_t *offs, uint64_t *outA, uint64_t *outB) {
-    int g = (int)(ntasks < 1 ? 1 : (ntasks > 1048576 ? 1048576 : ntasks));
-    hipLaunchKernelGGL(k_pa_emit, dim3(g), dim3(256), 0, st, ix, tasks, ntasks, wbuf, keys_cmp, vals_cmp, posoff, nvalid, cmp_tab,
-                       K, min_prefix, counts, offs, outA, outB);
-}
 void launch_sum_i32(hipStream_t st, const int32_t *v, int64_t n, unsigned long long *out) {
     int g = (int)((n + 255) / 256);
     g = g < 1 ? 1 : (g > 2048 ? 2048 : g);
     hipLaunchKernelGGL(k_sum_i32, dim3(g), dim3(256), 0, st, v, n, out);
 }
-void launch_pa_task_off(hipStream_t st, const Task *tasks, int64_t ntasks, const int64_t *offs, int64_t total_pos,
-                        int64_t total_anchors, int64_t *pa_off) {
-    LM_LAUNCH_1D(k_pa_task_off, ntasks + 1, st, tasks, ntasks, offs, total_pos, total_anchors, pa_off);
+void launch_pa_anchors(hipStream_t st, DevIndexView ix, const Task *tasks, int64_t ntasks, const uint8_t *wbuf,
+                       const uint64_t *keys_cmp, const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid,
+                       const uint32_t *cmp_tab, int K, int min_prefix, unsigned long long *count, int64_t cap,
+                       uint64_t *outA, uint64_t *outB) {
+    int g = (int)(ntasks < 1 ? 1 : (ntasks > 1048576 ? 1048576 : ntasks));
+    hipLaunchKernelGGL(k_pa_anchors, dim3(g), dim3(256), 0, st, ix, tasks, ntasks, wbuf, keys_cmp, vals_cmp, posoff, nvalid,
+                       cmp_tab, K, min_prefix, count, cap, outA, outB);
+}
+void launch_pa_task_off_sorted(hipStream_t st, const uint64_t *sortedA, int64_t total, int64_t ntasks, int64_t *pa_off) {
+    LM_LAUNCH_1D(k_pa_task_off_sorted, ntasks + 1, st, sortedA, total, ntasks, pa_off);
 }
 void launch_pa_chain(hipStream_t st, const uint64_t *B, const int64_t *pa_off, int64_t ntasks, int K, LmChain2Opt opt,
                      LmSub *subs, uint8_t *marks, uint64_t *msi, int32_t *stack, LmChain2 *out, int32_t *out_n,

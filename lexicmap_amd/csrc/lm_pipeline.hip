@@ -866,11 +866,13 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
     return LM_OK;
 }
 
+void lm_free_align_ctx(lm_index *ix);
+
 void lm_index_close(lm_index *ix) {
     if (!ix) return;
     prof_resolve(ix);
     delete ix->work;
-    delete ix->actx;
+    lm_free_align_ctx(ix); // AlignCtx is defined further down
     if (ix->st) (void)hipStreamDestroy(ix->st);
     delete ix;
 }
@@ -964,8 +966,9 @@ struct AlignCtx {
     DBuf<int32_t> wlen;
     DBuf<int64_t> woff;
     DBuf<uint8_t> wbuf;
-    DBuf<uint32_t> pa_counts;
-    DBuf<int64_t> pa_offs, pa_off;
+    DBuf<unsigned long long> pa_count;
+    int64_t pa_cap = 0; // running estimate of the anchors per chunk
+    DBuf<int64_t> pa_off;
     DBuf<uint64_t> A0, B0, A1, B1;
     DBuf<LmSub> subs;
     DBuf<uint8_t> marks;
@@ -985,6 +988,13 @@ struct AlignCtx {
     DBuf<unsigned int> wfa_queue;
     DBuf<uint64_t> ops_pool;
 };
+
+} // namespace lm
+void lm_free_align_ctx(lm_index *ix) {
+    delete ix->actx;
+    ix->actx = nullptr;
+}
+namespace lm {
 
 struct HspMeta { // host-side view of one WFA problem
     float est_div; // divergence implied by the pseudo-alignment identity (scratch sizing only)
@@ -1012,18 +1022,27 @@ static void run_pseudo(AlignCtx &a, const std::vector<Task> &ht, std::vector<int
         launch_extract_windows(ix->st, ix->view, a.tasks.p, nt, a.wbuf.p);
     }
     a.stats->window_bases += W;
-    a.pa_counts.ensure((size_t)W + 1);
-    a.pa_offs.ensure((size_t)W + 1);
-    HIPCHK(hipMemsetAsync(a.pa_counts.p + W, 0, sizeof(uint32_t), ix->st));
-    {
-        Prof p(ix, "k_pa_count", W);
-        launch_pa_count(ix->st, ix->view, a.tasks.p, nt, a.wbuf.p, a.w->k_cmp, a.w->v_cmp, qb->d_posoff.p, a.w->nvalid.p,
-                        a.w->cmp_tab.p, ix->host.k, 11, a.pa_counts.p);
-    }
-    int64_t TP;
-    {
-        Prof p(ix, "scan_pa_counts", W * 12);
-        TP = scan_to_i64<uint32_t, CastU32>(ix, a.pa_counts.p, W, a.pa_offs.p);
+    // single pass: anchors appended to (A0, B0) in arbitrary order; the buffer size is a running estimate, the kernel
+    // counts past it, so an undersized buffer costs one re-run
+    a.pa_count.ensure(1);
+    if (a.pa_cap < (int64_t)1 << 20) a.pa_cap = std::max<int64_t>((int64_t)1 << 20, W / 8);
+    int64_t TP = 0;
+    for (int attempt = 0;; attempt++) {
+        a.A0.ensure((size_t)a.pa_cap);
+        a.B0.ensure((size_t)a.pa_cap);
+        HIPCHK(hipMemsetAsync(a.pa_count.p, 0, sizeof(unsigned long long), ix->st));
+        {
+            Prof p(ix, "k_pa_anchors", W);
+            launch_pa_anchors(ix->st, ix->view, a.tasks.p, nt, a.wbuf.p, a.w->k_cmp, a.w->v_cmp, qb->d_posoff.p,
+                              a.w->nvalid.p, a.w->cmp_tab.p, ix->host.k, 11, a.pa_count.p, a.pa_cap, a.A0.p, a.B0.p);
+        }
+        unsigned long long hv = 0;
+        HIPCHK(hipMemcpyAsync(&hv, a.pa_count.p, sizeof hv, hipMemcpyDeviceToHost, ix->st));
+        sync(ix);
+        TP = (int64_t)hv;
+        if (TP <= a.pa_cap) break;
+        if (attempt > 2) throw HipError("pseudo-alignment anchor buffer keeps overflowing");
+        a.pa_cap = TP + TP / 8;
     }
     a.stats->pa_anchors += TP;
     if (TP >= (int64_t)1 << 31) throw HipError("too many pseudo-alignment anchors in one chunk");
@@ -1032,22 +1051,15 @@ static void run_pseudo(AlignCtx &a, const std::vector<Task> &ht, std::vector<int
     a.clr_n.ensure((size_t)nt + 1);
     HIPCHK(hipMemsetAsync(a.out_n.p, 0, sizeof(int32_t) * (nt + 1), ix->st));
     if (TP > 0) {
-        a.A0.ensure((size_t)TP);
-        a.B0.ensure((size_t)TP);
-        a.A1.ensure((size_t)TP);
-        a.B1.ensure((size_t)TP);
-        {
-            Prof p(ix, "k_pa_emit", TP * 16);
-            launch_pa_emit(ix->st, ix->view, a.tasks.p, nt, a.wbuf.p, a.w->k_cmp, a.w->v_cmp, qb->d_posoff.p, a.w->nvalid.p,
-                           a.w->cmp_tab.p, ix->host.k, 11, a.pa_counts.p, a.pa_offs.p, a.A0.p, a.B0.p);
-        }
+        a.A1.ensure((size_t)a.pa_cap);
+        a.B1.ensure((size_t)a.pa_cap);
         {
             Prof p(ix, "sort_pa_anchors");
             int abits = 1;
             while (((int64_t)1 << abits) < nt + 1) abits++;
             sort_anchors(ix, a.A0.p, a.B0.p, a.A1.p, a.B1.p, TP, abits);
         }
-        launch_pa_task_off(ix->st, a.tasks.p, nt, a.pa_offs.p, W, TP, a.pa_off.p);
+        launch_pa_task_off_sorted(ix->st, a.A0.p, TP, nt, a.pa_off.p);
         a.subs.ensure((size_t)TP);
         a.marks.ensure((size_t)TP);
         a.msi.ensure((size_t)TP);
