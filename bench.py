@@ -58,6 +58,29 @@ WORKLOADS = {
 }
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_c2_pmc_{fetch,write}.json,
+    two separate --pmc runs of this same workload): (FETCH_SIZE + WRITE_SIZE) * 1024. On gfx950 FETCH_SIZE tallies
+    128-B read requests as 64 B for wide streaming reads (MI355X_MICROARCH.md, HBM), so the read part is a lower
+    bound (at most 2x low). Returns (bytes or None, note)."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    tot, found = 0.0, False
+    for fn, ctr in (("r01_c2_pmc_fetch.json", "FETCH_SIZE"), ("r01_c2_pmc_write.json", "WRITE_SIZE")):
+        try:
+            pm = json.load(open(os.path.join(here, "profiles", fn))).get("pmc", {})
+        except (OSError, ValueError):
+            return None, "no committed PMC pass"
+        best = None
+        for k, v in pm.items():  # rocprof reports template kernels without the bench's suffix (k_wfa_lean vs k_wfa_lean128)
+            if ctr in v and (kernel.startswith(k) or k.startswith(kernel)) and (best is None or len(k) > len(best[0])):
+                best = (k, v[ctr])
+        if best is None:
+            return None, "kernel not in the committed PMC pass"
+        tot += best[1]["mean"] * 1024.0
+        found = True
+    return (int(tot) if found else None), "(FETCH_SIZE+WRITE_SIZE)*1024 from profiles/r01_c2_pmc_*.json; read part is a lower bound on gfx950"
+
+
 def usable_cores():
     """cores this process may really use: the CPU count capped by the affinity mask and the cgroup quota"""
     n = os.cpu_count() or 1
@@ -280,8 +303,9 @@ def main():
         if dom:
             avg_ms = dom["total_ms"] / max(dom["launches"], 1)
             ach = (dom["bytes"] / max(dom["launches"], 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            traffic, tnote = pmc_traffic(dom["name"]) if args.workload == "c2" else (None, "PMC passes are taken on c2")
             roofline = dict(bound="hbm", kernel=dom["name"], achieved=round(ach, 3), peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=round(ach / HBM_PEAK_GBS, 6), traffic=None,
+                            frac=round(ach / HBM_PEAK_GBS, 6), traffic=traffic, traffic_source=tnote,
                             avg_launch_ms=round(avg_ms, 4), launches=dom["launches"])
         go = shutil.which("go")
         result = {
