@@ -41,7 +41,7 @@ def parse():
     p.add_argument("--genome-len", type=int, default=0)
     p.add_argument("--shard", default="queries", choices=["queries", "index"])
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-seconds", type=float, default=20.0)
+    p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--builder", default=None, choices=["gpu", "oracle"],
                    help="gpu: genomes+index generated in HBM (default for c2); oracle: CPU writer + on-disk format")
     p.add_argument("--cpu-sample-genomes", type=int, default=12)
@@ -112,15 +112,16 @@ def cpu_baseline(index_dir, queries, seconds, ncores):
         k += 1
     per = (time.time() - t0) / max(k, 1)
     oi.close()
-    nsample = int(max(ncores, min(n, seconds * ncores / max(per, 1e-4))))
-    sample = queries[:nsample]
+    # enough searches for ~`seconds` of wall time on all cores (the batch is repeated when it is too short for that)
+    nsample = int(max(ncores, min(40 * n, seconds * ncores / max(per, 1e-4))))
+    sample = [queries[i % n] for i in range(nsample)]
     with mp.Pool(ncores, initializer=_cpu_init, initargs=(index_dir,)) as pool:
         t0 = time.time()
         res = pool.map(_cpu_one, [q[1] for q in sample], chunksize=max(1, len(sample) // (ncores * 8)))
         dt = time.time() - t0
     rows = sum(r[0] for r in res)
     return dict(value=len(sample) / dt, unit="queries/s", cores=ncores, kind="port",
-                sample="%d of %d queries of the same batch, oracle/liblmo.so (C restatement of the Go reference, "
+                sample="%d searches over the %d sample queries of the same batch, oracle/liblmo.so (C restatement of the Go reference, "
                        "RAM-resident index = the reference's -w regime) on %d processes, %.1f s, %d HSP rows"
                        % (len(sample), n, ncores, dt, rows))
 

@@ -801,6 +801,282 @@ LM_HDN void lm_extend_match(const uint8_t *seq1, int len1, const uint8_t *seq2, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// extendMatch flank, grid form (same result as lm_extend_right): bit-parallel 2-mer pairs + Chainer3 on the (q, t) grid.
+// * pairs: B[b] has bit t set when target flank base t is b, so the target positions matching the query 2-mer (a,b) at q
+//   are rows[q] = B[a] & (B[b] >> 1): no inner loop over the target flank (<= 128 bases; longer flanks use the caller's
+//   plain path);
+// * chaining: in lm_run_chain3 every predecessor that can be accepted has 1 <= dq <= 10 (max_distance), 0 <= dt <= 10
+//   and |dq - dt| <= 5 (max_gap), and the scan limit (band_base / band_count) only ever stops at anchors more than 12
+//   query positions back. So instead of walking ~70 earlier anchors per anchor, the ten previous rows are read as bit
+//   masks and only the set bits inside the allowed window are visited (~7). Ties: the earliest anchor among equal best
+//   scores, and a predecessor beats "start a new chain" on equality - what the descending scan with `>=` produces.
+// Scratch is strided (element j at [j * stride]) so a wavefront can interleave its 64 work items.
+#define LM_EXT_ROWS 132 /* query-flank rows: ext_len2 (50) + 80 = 130 at most */
+struct LmM128 {
+    uint64_t lo, hi;
+};
+LM_HD LmM128 lm_m128_range(int a, int b) { // bits [a, b], 0 <= a <= b <= 127
+    LmM128 r;
+    const uint64_t lo_from = a >= 64 ? 0ull : (~0ull << a), hi_from = a >= 64 ? (~0ull << (a - 64)) : ~0ull;
+    const uint64_t lo_to = b >= 63 ? ~0ull : ((1ull << (b + 1)) - 1ull);
+    const uint64_t hi_to = b < 64 ? 0ull : (b >= 127 ? ~0ull : ((1ull << (b - 63)) - 1ull));
+    r.lo = lo_from & lo_to;
+    r.hi = hi_from & hi_to;
+    return r;
+}
+LM_HD int lm_m128_count_below(const LmM128 &m, int t) { // set bits at positions < t
+    if (t <= 0) return 0;
+    if (t < 64) return __builtin_popcountll(m.lo & ((1ull << t) - 1ull));
+    if (t == 64) return __builtin_popcountll(m.lo);
+    return __builtin_popcountll(m.lo) + __builtin_popcountll(m.hi & (t >= 128 ? ~0ull : ((1ull << (t - 64)) - 1ull)));
+}
+LM_HDN bool lm_chain3_grid(const LmM128 *rows, const uint32_t *rstart, int n1, const uint16_t *subs, int n, int32_t *msi,
+                           int stride, int *qend_out, int *tend_out) {
+    if (n <= 0) return false;
+    int M = 0, Mi = 0, i = 0;
+    for (int p = 0; p + 1 < n1; p++) {
+        const LmM128 cur = rows[(int64_t)p * stride];
+        LmM128 prev[10]; // the (up to) ten previous rows, loaded together: independent loads, one latency
+        uint32_t pstart[10];
+#pragma unroll
+        for (int dq = 1; dq <= 10; dq++) {
+            const int q2 = p - dq;
+            if (q2 >= 0) {
+                prev[dq - 1] = rows[(int64_t)q2 * stride];
+                pstart[dq - 1] = rstart[(int64_t)q2 * stride];
+            } else {
+                prev[dq - 1].lo = prev[dq - 1].hi = 0;
+                pstart[dq - 1] = 0;
+            }
+        }
+        for (int half = 0; half < 2; half++) {
+            uint64_t bits = half ? cur.hi : cur.lo;
+            while (bits) {
+                const int at = (half << 6) + __builtin_ctzll(bits);
+                bits &= bits - 1;
+                const int aq = p;
+                const int base = 2 - (aq > at ? aq : at) - (aq > at ? aq - at : at - aq);
+                int best = -2147483647, bj = -1;
+#pragma unroll
+                for (int dq = 10; dq >= 1; dq--) { // far rows first = ascending anchor index
+                    int tlo = at - (dq + 5 < 10 ? dq + 5 : 10), thi = at - (dq > 5 ? dq - 5 : 0);
+                    if (thi < 0) continue;
+                    if (tlo < 0) tlo = 0;
+                    const LmM128 pr = prev[dq - 1];
+                    const LmM128 rg = lm_m128_range(tlo, thi);
+                    uint64_t c0 = pr.lo & rg.lo, c1 = pr.hi & rg.hi;
+                    while (c0 | c1) {
+                        int bt;
+                        if (c0) {
+                            bt = __builtin_ctzll(c0);
+                            c0 &= c0 - 1;
+                        } else {
+                            bt = 64 + __builtin_ctzll(c1);
+                            c1 &= c1 - 1;
+                        }
+                        const int j = (int)pstart[dq - 1] + lm_m128_count_below(pr, bt);
+                        const int dt = at - bt;
+                        const int d = dq > dt ? dq : dt;
+                        const int g = dq > dt ? dq - dt : dt - dq;
+                        const int sc = (msi[(int64_t)j * stride] >> 16) + 2 - d - g;
+                        if (sc > best) {
+                            best = sc;
+                            bj = j;
+                        }
+                    }
+                }
+                int m = base, mj = i;
+                if (bj >= 0 && best >= base) {
+                    m = best;
+                    mj = bj;
+                }
+                msi[(int64_t)i * stride] = (int32_t)(((uint32_t)m << 16) | (uint32_t)(mj & 0xffff));
+                if (i > 0 && m > M) {
+                    M = m;
+                    Mi = i;
+                }
+                i++;
+            }
+        }
+    }
+    if (M < 1) return false;
+    int n_matched = 0, n_abq = 0, n_abt = 0;
+    int k = Mi;
+    int qb = 0, qe = 0, tb = 0, te = 0, begin_of_next = 0;
+    bool first_anchor = true;
+    while (true) {
+        const int j = (int)((uint32_t)msi[(int64_t)k * stride] & 0xffffu);
+        const uint32_t sb = subs[(int64_t)k * stride];
+        const int sq = (int)(sb & 255u), st = (int)(sb >> 8);
+        if (first_anchor) {
+            first_anchor = false;
+            qe = sq + 1;
+            te = st + 1;
+            qb = sq;
+            tb = st;
+            n_matched += 2;
+        } else {
+            qb = sq;
+            tb = st;
+            if (sq + 1 >= begin_of_next)
+                n_matched += begin_of_next - sq;
+            else
+                n_matched += 2;
+        }
+        begin_of_next = sq;
+        if (k == j) {
+            n_abq += qe - qb + 1;
+            if (n_abq < 2) return false;
+            n_abt += te - tb + 1;
+            const double pident = (double)n_matched / (double)(n_abq > n_abt ? n_abq : n_abt) * 100;
+            if (pident < 15) return false;
+            *qend_out = qe;
+            *tend_out = te;
+            return true;
+        }
+        k = j;
+    }
+}
+// Chainer3 over compressed anchors in list form (fallback when the flanks do not fit the grid)
+LM_HDN bool lm_chain3_list(const uint16_t *subs, int n, int32_t *msi, int stride, int *qend_out, int *tend_out) {
+    if (n <= 0) return false;
+    int M = 0, Mi = 0;
+    for (int i = 0; i < n; i++) {
+        const uint32_t a = subs[(int64_t)i * stride];
+        const int aq = (int)(a & 255u), at = (int)(a >> 8);
+        int m = 2 - (aq > at ? aq : at) - (aq > at ? aq - at : at - aq);
+        int mj = i;
+        int bcount = 0;
+        for (int j = i - 1; j >= 0; j--) {
+            const uint32_t b = subs[(int64_t)j * stride];
+            const int bq = (int)(b & 255u), bt = (int)(b >> 8);
+            if (bq == aq || bt > at) continue;
+            bcount++;
+            const int bbase = aq - bq - 2;
+            if (!(bbase <= 10 || bcount <= 20)) break;
+            int dq = aq - bq, dt = at - bt;
+            if (dq < 0) dq = -dq;
+            if (dt < 0) dt = -dt;
+            const int d = dq > dt ? dq : dt;
+            if (d > 10) continue;
+            const int g = dq > dt ? dq - dt : dt - dq;
+            if (g > 5) continue;
+            const int sc = (msi[(int64_t)j * stride] >> 16) + 2 - d - g;
+            if (sc >= m) {
+                m = sc;
+                mj = j;
+            }
+        }
+        msi[(int64_t)i * stride] = (int32_t)(((uint32_t)m << 16) | (uint32_t)(mj & 0xffff));
+        if (i > 0 && m > M) {
+            M = m;
+            Mi = i;
+        }
+    }
+    if (M < 1) return false;
+    int n_matched = 0, n_abq = 0, n_abt = 0;
+    int i = Mi;
+    int qb = 0, qe = 0, tb = 0, te = 0, begin_of_next = 0;
+    bool first_anchor = true;
+    while (true) {
+        const int j = (int)((uint32_t)msi[(int64_t)i * stride] & 0xffffu);
+        const uint32_t sb = subs[(int64_t)i * stride];
+        const int sq = (int)(sb & 255u), st = (int)(sb >> 8);
+        if (first_anchor) {
+            first_anchor = false;
+            qe = sq + 1;
+            te = st + 1;
+            qb = sq;
+            tb = st;
+            n_matched += 2;
+        } else {
+            qb = sq;
+            tb = st;
+            if (sq + 1 >= begin_of_next)
+                n_matched += begin_of_next - sq;
+            else
+                n_matched += 2;
+        }
+        begin_of_next = sq;
+        if (i == j) {
+            n_abq += qe - qb + 1;
+            if (n_abq < 2) return false;
+            n_abt += te - tb + 1;
+            const double pident = (double)n_matched / (double)(n_abq > n_abt ? n_abq : n_abt) * 100;
+            if (pident < 15) return false;
+            *qend_out = qe;
+            *tend_out = te;
+            return true;
+        }
+        i = j;
+    }
+}
+// subs: cap entries (q | t << 8), msi: cap entries, rows / rstart: LM_EXT_ROWS entries, all with `stride`
+LM_HDN void lm_extend_flank_grid(const uint8_t *s1, int n1, const uint8_t *s2, int n2, bool rev, uint16_t *subs,
+                                 int32_t *msi, int cap, LmM128 *rows, uint32_t *rstart, int stride, int *o1, int *o2) {
+    *o1 = 0;
+    *o2 = 0;
+    if (n1 < 2 || n2 < 2 || n1 > 255 || n2 > 255) return;
+    int n = 0;
+    const bool grid = n2 <= 128 && n1 <= LM_EXT_ROWS;
+    if (!grid) { // plain double loop (only reachable with the +80 extension of > 1 Mb alignments)
+        for (int p = 0; p + 1 < n1; p++) {
+            const uint32_t km1 = (lm_base2bit(lm_flank_base(s1, n1, p, rev)) << 2) | lm_base2bit(lm_flank_base(s1, n1, p + 1, rev));
+            for (int t = 0; t + 1 < n2; t++) {
+                const uint32_t km2 =
+                    (lm_base2bit(lm_flank_base(s2, n2, t, rev)) << 2) | lm_base2bit(lm_flank_base(s2, n2, t + 1, rev));
+                if (km1 == km2) {
+                    if (n >= cap) return;
+                    subs[(int64_t)(n++) * stride] = (uint16_t)(p | (t << 8));
+                }
+            }
+        }
+    } else {
+        LmM128 B0 = {0, 0}, B1 = {0, 0}, B2 = {0, 0}, B3 = {0, 0};
+        for (int t = 0; t < n2; t++) {
+            const uint32_t c = lm_base2bit(lm_flank_base(s2, n2, t, rev));
+            const uint64_t bl = t < 64 ? 1ull << t : 0ull, bh = t >= 64 ? 1ull << (t - 64) : 0ull;
+            if (c == 0) { B0.lo |= bl; B0.hi |= bh; }
+            else if (c == 1) { B1.lo |= bl; B1.hi |= bh; }
+            else if (c == 2) { B2.lo |= bl; B2.hi |= bh; }
+            else { B3.lo |= bl; B3.hi |= bh; }
+        }
+        const LmM128 V = lm_m128_range(0, n2 - 2); // valid 2-mer starts
+        uint32_t ca = lm_base2bit(lm_flank_base(s1, n1, 0, rev));
+        for (int p = 0; p + 1 < n1; p++) {
+            const uint32_t cb = lm_base2bit(lm_flank_base(s1, n1, p + 1, rev));
+            const LmM128 A = ca == 0 ? B0 : ca == 1 ? B1 : ca == 2 ? B2 : B3;
+            const LmM128 Bn = cb == 0 ? B0 : cb == 1 ? B1 : cb == 2 ? B2 : B3;
+            uint64_t mlo = A.lo & ((Bn.lo >> 1) | (Bn.hi << 63)) & V.lo;
+            uint64_t mhi = A.hi & (Bn.hi >> 1) & V.hi;
+            LmM128 row = {mlo, mhi};
+            rows[(int64_t)p * stride] = row;
+            rstart[(int64_t)p * stride] = (uint32_t)n;
+            while (mlo) {
+                const int t = __builtin_ctzll(mlo);
+                mlo &= mlo - 1;
+                if (n >= cap) return;
+                subs[(int64_t)(n++) * stride] = (uint16_t)(p | (t << 8));
+            }
+            while (mhi) {
+                const int t = 64 + __builtin_ctzll(mhi);
+                mhi &= mhi - 1;
+                if (n >= cap) return;
+                subs[(int64_t)(n++) * stride] = (uint16_t)(p | (t << 8));
+            }
+            ca = cb;
+        }
+    }
+    if (n == 0) return;
+    int qe, te;
+    if (grid ? lm_chain3_grid(rows, rstart, n1, subs, n, msi, stride, &qe, &te)
+             : lm_chain3_list(subs, n, msi, stride, &qe, &te)) {
+        *o1 = qe + 1;
+        *o2 = te + 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // tree.Search(key, p) over a sorted key array (tree/tree.go:441-527): the range of entries the radix tree would
 // return, INCLUDING the partial-prefix quirk at :496-500 (uint8 wrap of n.k-atleast turns the test into
 // "bases [d,p) of the key are all A", which returns a subtree whose leaves share fewer than p bases).

@@ -97,12 +97,13 @@ void launch_gather_chain2(hipStream_t st, const LmChain2 *in, const int64_t *pa_
 void launch_extend_count(hipStream_t st, const HspIn *hsps, int64_t n, const uint8_t *qseq, const int64_t *qoff,
                          const uint8_t *wbuf, int32_t *cap);
 void launch_extend_wave_cap(hipStream_t st, const int32_t *cap, int64_t n, int32_t *wcap, int64_t nw);
+int extend_grid_blocks(int64_t n);
 void launch_extend(hipStream_t st, const HspIn *hsps, int64_t n, const uint8_t *qseq, const int64_t *qoff,
                    const uint8_t *wbuf, const int32_t *cap, const int64_t *woff, uint16_t *subs, int32_t *msi,
-                   HspExt *out);
-// kind 0: k_wfa_l64 (<= 62 diagonals), kind 1: k_wfa_lds (<= 128 diagonals); both persistent with private scratch
-int wfa_resident_blocks(int device, int seq_words, int kind);
-void launch_wfa(hipStream_t st, int kind, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks,
+                   void *rows_pool, uint32_t *rstart_pool, HspExt *out);
+// k_wfa_lean<2>: persistent wavefronts with private scratch, <= 126 diagonals (status 3 beyond)
+int wfa_resident_blocks(int device, int seq_words);
+void launch_wfa(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks,
                 int32_t *hdr_pool, int64_t hdr_stride, int32_t *arena_pool, int64_t arena_stride, uint64_t *ops_pool,
                 unsigned int *queue, int seq_words, int want_ops, WfaOut *out);
 

@@ -985,157 +985,9 @@ __global__ void k_extend_count(const HspIn *__restrict__ hsps, int64_t n, const 
     }
 }
 
-// One flank of extendMatch (lib-index-search-util.go:34-96): all pairs of equal 2-mers between the two flanks in the
-// order (q asc, t asc), then Chainer3 (lib-chaining3.go, restated in lm_run_chain3) over them.
-// * pairs come from bit masks: B[b] has bit t set when target flank base t is b, so the target positions matching the
-//   2-mer (a,b) are B[a] & (B[b] >> 1) - no inner loop over the target flank (flanks are <= 50..130 bases);
-// * the per-item scratch is compressed (anchor = q | t << 8, DP cell = score << 16 | predecessor) and TRANSPOSED across
-//   the wavefront: element j of lane L lives at (j * 64 + L), so the 64 concurrent chainers of a wave share cache lines
-//   instead of touching 64 distant ones per step (this stage is bound by the latency of those dependent loads).
-__device__ __forceinline__ bool chain3_t(const uint16_t *__restrict__ subs, int n, int32_t *__restrict__ msi, int *qend_out,
-                                         int *tend_out) {
-    const int band_base = 10, band_count = 20, max_gap = 5, max_distance = 10, min_score = 1, min_align_len = 2;
-    if (n <= 0) return false;
-    int M = 0, Mi = 0;
-    for (int i = 0; i < n; i++) {
-        const uint32_t a = subs[(int64_t)i * 64];
-        const int aq = (int)(a & 255u), at = (int)(a >> 8);
-        int m = 2 - (aq > at ? aq : at) - (aq > at ? aq - at : at - aq);
-        int mj = i;
-        int bcount = 0;
-        for (int j = i - 1; j >= 0; j--) {
-            const uint32_t b = subs[(int64_t)j * 64];
-            const int bq = (int)(b & 255u), bt = (int)(b >> 8);
-            if (bq == aq || bt > at) continue;
-            bcount++;
-            const int bbase = aq - bq - 2;
-            if (!(bbase <= band_base || bcount <= band_count)) break;
-            int dq = aq - bq, dt = at - bt;
-            if (dq < 0) dq = -dq;
-            if (dt < 0) dt = -dt;
-            const int d = dq > dt ? dq : dt;
-            if (d > max_distance) continue;
-            const int g = dq > dt ? dq - dt : dt - dq;
-            if (g > max_gap) continue;
-            const int sc = (msi[(int64_t)j * 64] >> 16) + 2 - d - g;
-            if (sc >= m) {
-                m = sc;
-                mj = j;
-            }
-        }
-        msi[(int64_t)i * 64] = (int32_t)(((uint32_t)m << 16) | (uint32_t)(mj & 0xffff));
-        if (i > 0 && m > M) {
-            M = m;
-            Mi = i;
-        }
-    }
-    if (M < min_score) return false;
-    int n_matched = 0, n_abq = 0, n_abt = 0;
-    int i = Mi;
-    int qb = 0, qe = 0, tb = 0, te = 0, begin_of_next = 0;
-    bool first_anchor = true;
-    while (true) {
-        const int j = (int)((uint32_t)msi[(int64_t)i * 64] & 0xffffu);
-        const uint32_t sb = subs[(int64_t)i * 64];
-        const int sq = (int)(sb & 255u), st = (int)(sb >> 8);
-        if (first_anchor) {
-            first_anchor = false;
-            qe = sq + 1;
-            te = st + 1;
-            qb = sq;
-            tb = st;
-            n_matched += 2;
-        } else {
-            qb = sq;
-            tb = st;
-            if (sq + 1 >= begin_of_next)
-                n_matched += begin_of_next - sq;
-            else
-                n_matched += 2;
-        }
-        begin_of_next = sq;
-        if (i == j) {
-            n_abq += qe - qb + 1;
-            if (n_abq < min_align_len) return false;
-            n_abt += te - tb + 1;
-            const double pident = (double)n_matched / (double)(n_abq > n_abt ? n_abq : n_abt) * 100;
-            if (pident < 15) return false;
-            *qend_out = qe;
-            *tend_out = te;
-            return true;
-        }
-        i = j;
-    }
-}
-
-struct Mask128 {
-    unsigned long long lo, hi;
-};
-__device__ __forceinline__ void extend_side(const uint8_t *__restrict__ s1, int n1, const uint8_t *__restrict__ s2, int n2,
-                                            bool rev, uint16_t *__restrict__ subs, int32_t *__restrict__ msi, int cap,
-                                            int *o1, int *o2) {
-    *o1 = 0;
-    *o2 = 0;
-    if (n1 < 2 || n2 < 2 || n1 > 255 || n2 > 255) return; // flanks are at most ext_len2 + 80 = 130 bases
-    int n = 0;
-    if (n2 > 128) { // plain double loop (only reachable with the +80 extension of > 1 Mb alignments)
-        for (int p = 0; p + 1 < n1; p++) {
-            const uint32_t km1 = (lm_base2bit(lm_flank_base(s1, n1, p, rev)) << 2) | lm_base2bit(lm_flank_base(s1, n1, p + 1, rev));
-            for (int t = 0; t + 1 < n2; t++) {
-                const uint32_t km2 =
-                    (lm_base2bit(lm_flank_base(s2, n2, t, rev)) << 2) | lm_base2bit(lm_flank_base(s2, n2, t + 1, rev));
-                if (km1 == km2) {
-                    if (n >= cap) return;
-                    subs[(int64_t)(n++) * 64] = (uint16_t)(p | (t << 8));
-                }
-            }
-        }
-    } else {
-        Mask128 B0 = {0, 0}, B1 = {0, 0}, B2 = {0, 0}, B3 = {0, 0};
-        for (int t = 0; t < n2; t++) {
-            const uint32_t c = lm_base2bit(lm_flank_base(s2, n2, t, rev));
-            const unsigned long long bl = t < 64 ? 1ull << t : 0ull, bh = t >= 64 ? 1ull << (t - 64) : 0ull;
-            if (c == 0) { B0.lo |= bl; B0.hi |= bh; }
-            else if (c == 1) { B1.lo |= bl; B1.hi |= bh; }
-            else if (c == 2) { B2.lo |= bl; B2.hi |= bh; }
-            else { B3.lo |= bl; B3.hi |= bh; }
-        }
-        Mask128 V; // valid 2-mer starts: t <= n2-2
-        {
-            const int nv = n2 - 1;
-            V.lo = nv >= 64 ? ~0ull : ((1ull << nv) - 1ull);
-            V.hi = nv <= 64 ? 0ull : (nv >= 128 ? ~0ull : ((1ull << (nv - 64)) - 1ull));
-        }
-        auto sel = [&](uint32_t c) -> Mask128 { return c == 0 ? B0 : c == 1 ? B1 : c == 2 ? B2 : B3; };
-        uint32_t ca = lm_base2bit(lm_flank_base(s1, n1, 0, rev));
-        for (int p = 0; p + 1 < n1; p++) {
-            const uint32_t cb = lm_base2bit(lm_flank_base(s1, n1, p + 1, rev));
-            const Mask128 A = sel(ca), Bn = sel(cb);
-            unsigned long long mlo = A.lo & ((Bn.lo >> 1) | (Bn.hi << 63)) & V.lo;
-            unsigned long long mhi = A.hi & (Bn.hi >> 1) & V.hi;
-            while (mlo) {
-                const int t = __ffsll((long long)mlo) - 1;
-                mlo &= mlo - 1;
-                if (n >= cap) return;
-                subs[(int64_t)(n++) * 64] = (uint16_t)(p | (t << 8));
-            }
-            while (mhi) {
-                const int t = 64 + __ffsll((long long)mhi) - 1;
-                mhi &= mhi - 1;
-                if (n >= cap) return;
-                subs[(int64_t)(n++) * 64] = (uint16_t)(p | (t << 8));
-            }
-            ca = cb;
-        }
-    }
-    if (n == 0) return;
-    int qe, te;
-    if (chain3_t(subs, n, msi, &qe, &te)) {
-        *o1 = qe + 1;
-        *o2 = te + 1;
-    }
-}
-
+// One flank of extendMatch: lm_extend_flank_grid (lm_algos.h) - bit-parallel 2-mer pairs + Chainer3 on the (q, t) grid,
+// with the per-item scratch TRANSPOSED across the wavefront (element j of lane L at [j * 64 + L]) so the 64 concurrent
+// chainers of a wave share cache lines.
 // scratch rows needed by each wavefront of k_extend: the largest pair count of its 32 HSPs
 __global__ void k_extend_wave_cap(const int32_t *__restrict__ cap, int64_t n, int32_t *__restrict__ wcap, int64_t nw) {
     for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nw; w += (int64_t)gridDim.x * blockDim.x) {
@@ -1152,7 +1004,11 @@ __global__ __launch_bounds__(64) void k_extend(const HspIn *__restrict__ hsps, i
                                                const int64_t *__restrict__ qoff, const uint8_t *__restrict__ wbuf,
                                                const int32_t *__restrict__ cap, const int64_t *__restrict__ woff,
                                                uint16_t *__restrict__ subs, int32_t *__restrict__ msi,
+                                               LmM128 *__restrict__ rows_pool, uint32_t *__restrict__ rstart_pool,
                                                HspExt *__restrict__ out) {
+    // grid-chainer rows: one private [LM_EXT_ROWS][64] slab per workgroup (the grid is sized to the resident wavefronts)
+    LmM128 *rows = rows_pool + (int64_t)blockIdx.x * LM_EXT_ROWS * 64 + threadIdx.x;
+    uint32_t *rstart = rstart_pool + (int64_t)blockIdx.x * LM_EXT_ROWS * 64 + threadIdx.x;
     for (int64_t wv = blockIdx.x; wv * 64 < 2 * n; wv += gridDim.x) {
         const int64_t w = wv * 64 + threadIdx.x;
         if (w >= 2 * n) continue;
@@ -1173,7 +1029,8 @@ __global__ __launch_bounds__(64) void k_extend(const HspIn *__restrict__ hsps, i
                 if (ext > 2) {
                     int e1 = h.end1 + ext < h.len1 ? h.end1 + ext : h.len1;
                     int e2 = h.end2 + ext < h.len2 ? h.end2 + ext : h.len2;
-                    extend_side(seq1 + h.end1, e1 - h.end1, seq2 + h.end2, e2 - h.end2, false, sb, ms, cap[i], &d1, &d2);
+                    lm_extend_flank_grid(seq1 + h.end1, e1 - h.end1, seq2 + h.end2, e2 - h.end2, false, sb, ms, cap[i], rows, rstart,
+                                         64, &d1, &d2);
                 }
             }
             out[i].e1 = d1;
@@ -1185,7 +1042,8 @@ __global__ __launch_bounds__(64) void k_extend(const HspIn *__restrict__ hsps, i
                 if (ext > 2) {
                     int s1 = h.start1 - ext > 0 ? h.start1 - ext : 0;
                     int s2 = h.start2 - ext > 0 ? h.start2 - ext : 0;
-                    extend_side(seq1 + s1, h.start1 - s1, seq2 + s2, h.start2 - s2, true, sb, ms, cap[i], &d1, &d2);
+                    lm_extend_flank_grid(seq1 + s1, h.start1 - s1, seq2 + s2, h.start2 - s2, true, sb, ms, cap[i], rows, rstart, 64,
+                                         &d1, &d2);
                 }
             }
             out[i].s1 = d1;
@@ -2277,13 +2135,17 @@ void launch_extend_count(hipStream_t st, const HspIn *hsps, int64_t n, const uin
 void launch_extend_wave_cap(hipStream_t st, const int32_t *cap, int64_t n, int32_t *wcap, int64_t nw) {
     hipLaunchKernelGGL(k_extend_wave_cap, dim3(grid_for(nw, 256)), dim3(256), 0, st, cap, n, wcap, nw);
 }
+int extend_grid_blocks(int64_t n) { // workgroups of k_extend = slabs of the rows / rstart pools
+    int64_t nw = (2 * n + 63) / 64;
+    return (int)(nw < 1 ? 1 : (nw > 8192 ? 8192 : nw));
+}
 void launch_extend(hipStream_t st, const HspIn *hsps, int64_t n, const uint8_t *qseq, const int64_t *qoff,
                    const uint8_t *wbuf, const int32_t *cap, const int64_t *woff, uint16_t *subs, int32_t *msi,
-                   HspExt *out) {
-    // one wavefront per 32 HSPs (64 flanks); subs / msi hold 64 * woff[nw] entries (transposed per wavefront)
-    int64_t nw = (2 * n + 63) / 64;
-    int g = (int)(nw < 1 ? 1 : (nw > 1048576 ? 1048576 : nw));
-    hipLaunchKernelGGL(k_extend, dim3(g), dim3(64), 0, st, hsps, n, qseq, qoff, wbuf, cap, woff, subs, msi, out);
+                   void *rows_pool, uint32_t *rstart_pool, HspExt *out) {
+    // one wavefront per 32 HSPs (64 flanks); subs / msi hold 64 * woff[nw] entries (transposed per wavefront);
+    // rows_pool: extend_grid_blocks(n) * LM_EXT_ROWS * 64 * 16 bytes, rstart_pool: the same count of uint32
+    hipLaunchKernelGGL(k_extend, dim3(extend_grid_blocks(n)), dim3(64), 0, st, hsps, n, qseq, qoff, wbuf, cap, woff, subs, msi,
+                       (LmM128 *)rows_pool, rstart_pool, out);
     hipLaunchKernelGGL(k_extend_fin, dim3(grid_for(n, 256)), dim3(256), 0, st, hsps, n, out);
 }
 static int resident_blocks_of(const void *kern, int device, int seq_words) {
@@ -2293,19 +2155,15 @@ static int resident_blocks_of(const void *kern, int device, int seq_words) {
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
     return nb * cus;
 }
-int wfa_resident_blocks(int device, int seq_words, int kind) {
-    return resident_blocks_of(kind == 0 ? (const void *)k_wfa_lean<1> : (const void *)k_wfa_lean<2>, device, seq_words);
+int wfa_resident_blocks(int device, int seq_words) {
+    return resident_blocks_of((const void *)k_wfa_lean<2>, device, seq_words);
 }
-void launch_wfa(hipStream_t st, int kind, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks,
+void launch_wfa(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks,
                 int32_t *hdr_pool, int64_t hdr_stride, int32_t *arena_pool, int64_t arena_stride, uint64_t *ops_pool,
                 unsigned int *queue, int seq_words, int want_ops, WfaOut *out) {
     size_t dyn = (size_t)(2 * (seq_words + 1)) * sizeof(uint32_t);
-    if (kind == 0)
-        hipLaunchKernelGGL(k_wfa_lean<1>, dim3(nblocks), dim3(64), dyn, st, in, n, todo, ntodo, hdr_pool, hdr_stride, arena_pool,
-                           arena_stride, ops_pool, queue, seq_words, want_ops, out);
-    else
-        hipLaunchKernelGGL(k_wfa_lean<2>, dim3(nblocks), dim3(64), dyn, st, in, n, todo, ntodo, hdr_pool, hdr_stride, arena_pool,
-                           arena_stride, ops_pool, queue, seq_words, want_ops, out);
+    hipLaunchKernelGGL(k_wfa_lean<2>, dim3(nblocks), dim3(64), dyn, st, in, n, todo, ntodo, hdr_pool, hdr_stride, arena_pool,
+                       arena_stride, ops_pool, queue, seq_words, want_ops, out);
 }
 void launch_wfa_wide(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int32_t *hdr_pool,
                      int32_t *arena_pool, uint64_t *ops_pool, WfaOut *out) {

@@ -349,6 +349,8 @@ struct Work {
     DBuf<int64_t> task_off;
     DBuf<uint8_t> keep;
     DBuf<Task> tasks;
+    DBuf<int32_t> task_wlen;
+    DBuf<int64_t> task_woff;
     int64_t ntasks = 0;
     explicit Work(lm_index *i, lm_qbatch *q) : ix(i), qb(q) {}
     void rebind(lm_qbatch *q) {
@@ -982,6 +984,8 @@ struct AlignCtx {
     DBuf<int32_t> ext_cap, ext_wcap, ext_msi;
     DBuf<int64_t> ext_off;
     DBuf<uint16_t> ext_subs;
+    DBuf<uint64_t> ext_rows;   // grid chainer: per resident wavefront [LM_EXT_ROWS][64] x 128-bit row masks
+    DBuf<uint32_t> ext_rstart; // first anchor index of each row
     DBuf<WfaIn> wfa_in;
     DBuf<WfaOut> wfa_out;
     DBuf<int32_t> wfa_todo, wfa_todo2, hdr_pool, arena_pool;
@@ -1006,7 +1010,7 @@ struct HspMeta { // host-side view of one WFA problem
 
 // Runs pseudo-alignment for tasks[t0,t1) (host copy `ht`), returns per task the Chain2 results.
 static void run_pseudo(AlignCtx &a, const std::vector<Task> &ht, std::vector<int64_t> &res_off_h,
-                       std::vector<LmChain2> &res_h) {
+                       std::vector<LmChain2> &res_h, const Task *dev_tasks = nullptr) {
     lm_index *ix = a.ix;
     lm_qbatch *qb = a.qb;
     int64_t nt = (int64_t)ht.size();
@@ -1015,11 +1019,15 @@ static void run_pseudo(AlignCtx &a, const std::vector<Task> &ht, std::vector<int
     if (nt == 0) return;
     int64_t W = ht.back().woff + ht.back().wlen;
     a.wbuf.ensure((size_t)W + 64);
-    a.tasks.ensure((size_t)nt);
-    HIPCHK(hipMemcpyAsync(a.tasks.p, ht.data(), sizeof(Task) * nt, hipMemcpyHostToDevice, ix->st));
+    const Task *tasks_d = dev_tasks; // the device copy already carries these window offsets (single-chunk case)
+    if (!tasks_d) {
+        a.tasks.ensure((size_t)nt);
+        HIPCHK(hipMemcpyAsync(a.tasks.p, ht.data(), sizeof(Task) * nt, hipMemcpyHostToDevice, ix->st));
+        tasks_d = a.tasks.p;
+    }
     {
         Prof p(ix, "k_extract_windows", W + W / 4);
-        launch_extract_windows(ix->st, ix->view, a.tasks.p, nt, a.wbuf.p);
+        launch_extract_windows(ix->st, ix->view, tasks_d, nt, a.wbuf.p);
     }
     a.stats->window_bases += W;
     // single pass: anchors appended to (A0, B0) in arbitrary order; the buffer size is a running estimate, the kernel
@@ -1033,7 +1041,7 @@ static void run_pseudo(AlignCtx &a, const std::vector<Task> &ht, std::vector<int
         HIPCHK(hipMemsetAsync(a.pa_count.p, 0, sizeof(unsigned long long), ix->st));
         {
             Prof p(ix, "k_pa_anchors", W);
-            launch_pa_anchors(ix->st, ix->view, a.tasks.p, nt, a.wbuf.p, a.w->k_cmp, a.w->v_cmp, qb->d_posoff.p,
+            launch_pa_anchors(ix->st, ix->view, tasks_d, nt, a.wbuf.p, a.w->k_cmp, a.w->v_cmp, qb->d_posoff.p,
                               a.w->nvalid.p, a.w->cmp_tab.p, ix->host.k, 11, a.pa_count.p, a.pa_cap, a.A0.p, a.B0.p);
         }
         unsigned long long hv = 0;
@@ -1190,26 +1198,25 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
         a.wfa_todo.ensure((size_t)n);
         a.wfa_queue.ensure(1);
         HIPCHK(hipMemcpyAsync(a.wfa_in.p, in.data(), sizeof(WfaIn) * n, hipMemcpyHostToDevice, ix->st));
-        // kind 0: lean 64-diagonal kernel, kind 1: 128-diagonal LDS kernel for the wavefronts that outgrow it
-        auto persistent_pass = [&](int kind, const std::vector<int32_t> &items, std::vector<int32_t> &too_wide) {
+        auto persistent_pass = [&](const std::vector<int32_t> &items, std::vector<int32_t> &too_wide) {
             const int64_t m = (int64_t)items.size();
-            int nblocks = (int)std::min<int64_t>(m, wfa_resident_blocks(ix->device, seq_words, kind));
+            int nblocks = (int)std::min<int64_t>(m, wfa_resident_blocks(ix->device, seq_words));
             // private scratch per resident wave: never more than the worst case of the longest problem
             int64_t cells = ((int64_t)40 << 30) / nblocks * 10 / 46 / 4;
             cells = std::min<int64_t>(cells, std::min<int64_t>(3 * 128 * (smax + 1), 2000000000));
             cells = std::max<int64_t>(cells, 4096);
             int64_t rows = std::min<int64_t>(std::max<int64_t>(cells / 64, 256), smax + 1);
             if (getenv("LM_DEBUG"))
-                fprintf(stderr, "[lm] wfa pass kind=%d problems=%lld blocks=%d (resident %d) cells/block=%lld rows=%lld seq_words=%d\n",
-                        kind, (long long)m, nblocks, wfa_resident_blocks(ix->device, seq_words, kind), (long long)cells,
+                fprintf(stderr, "[lm] wfa pass problems=%lld blocks=%d (resident %d) cells/block=%lld rows=%lld seq_words=%d\n",
+                        (long long)m, nblocks, wfa_resident_blocks(ix->device, seq_words), (long long)cells,
                         (long long)rows, seq_words);
             a.hdr_pool.ensure((size_t)(rows * 9) * nblocks + 16);
             a.arena_pool.ensure((size_t)cells * nblocks + 16);
             HIPCHK(hipMemcpyAsync(a.wfa_todo.p, items.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice, ix->st));
             HIPCHK(hipMemsetAsync(a.wfa_queue.p, 0, sizeof(unsigned int), ix->st));
             {
-                Prof p(ix, kind == 0 ? "k_wfa_lean64" : "k_wfa_lean128", wfa_bytes(in, items));
-                launch_wfa(ix->st, kind, a.wfa_in.p, n, a.wfa_todo.p, m, nblocks, a.hdr_pool.p, rows * 9, a.arena_pool.p,
+                Prof p(ix, "k_wfa_lean", wfa_bytes(in, items));
+                launch_wfa(ix->st, a.wfa_in.p, n, a.wfa_todo.p, m, nblocks, a.hdr_pool.p, rows * 9, a.arena_pool.p,
                            cells, a.ops_pool.p, a.wfa_queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p);
             }
             std::vector<WfaOut> tmp;
@@ -1235,20 +1242,10 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
                 }
             }
         };
-        // 64-diagonal kernel for the problems expected to stay narrow (low divergence, similar lengths: wavefronts of
-        // <= 48 diagonals up to ~6% divergence), 128-diagonal kernel for the rest and for what outgrows the first
-        std::vector<int32_t> narrow, wide1, wide2;
-        const bool skip64 = getenv("LM_DEBUG_SKIP_WFA_L64") != nullptr; // debugging aid
-        for (int32_t i : order) {
-            float dv = est_div ? (*est_div)[i] : 0.12f;
-            int dl = in[i].tlen - in[i].qlen;
-            if (!skip64 && dv <= 0.03f && dl >= -8 && dl <= 8)
-                narrow.push_back(i);
-            else
-                wide1.push_back(i);
-        }
-        if (!narrow.empty()) persistent_pass(0, narrow, wide1);
-        if (!wide1.empty()) persistent_pass(1, wide1, wide2);
+        // one pass through the 128-diagonal LDS kernel (it only touches its second 64-slot chunk when a wavefront is
+        // wide or has drifted); what outgrows it goes to the global-memory kernel below
+        std::vector<int32_t> wide2;
+        persistent_pass(order, wide2);
         for (int32_t i : wide2) { // wider than 128 diagonals, longer than the LDS buffers, or not plain ACGT
             is_wide[i] = 1;
             todo.push_back(i);
@@ -1503,6 +1500,14 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
     w.tasks.ensure((size_t)NT);
     launch_make_tasks(ix->st, ix->view, w.segA.p, w.seg_off.p, nseg, w.subs.p, w.chain_off_pool.p, w.chain_idx_pool.p,
                       w.ntask.p, w.task_off.p, qb->d_qoff.p, ix->opt.ext_len, w.order_scratch.p, w.tasks.p);
+    {   // window offsets of all tasks laid end to end (what a single alignment chunk uses as is)
+        w.task_wlen.ensure((size_t)NT + 1);
+        w.task_woff.ensure((size_t)NT + 2);
+        HIPCHK(hipMemsetAsync(w.task_wlen.p + NT, 0, sizeof(int32_t), ix->st));
+        launch_task_wlen(ix->st, w.tasks.p, NT, w.task_wlen.p);
+        (void)scan_to_i64<int32_t, CastI32>(ix, w.task_wlen.p, NT, w.task_woff.p);
+        launch_task_set_woff(ix->st, w.tasks.p, NT, w.task_woff.p);
+    }
     std::vector<Task> tasks_h;
     d2h(ix, tasks_h, w.tasks.p, (size_t)NT);
     sync(ix);
@@ -1529,16 +1534,23 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
             wb += segw;
             tend = e;
         }
-        std::vector<Task> ht(tasks_h.begin() + tpos, tasks_h.begin() + tend);
+        const bool whole = tpos == 0 && tend == NT; // one chunk: host and device task lists are used in place
+        std::vector<Task> ht_chunk;
         int64_t off = 0;
-        for (auto &t : ht) {
-            t.woff = off;
-            off += t.wlen;
+        if (whole) {
+            off = tasks_h.back().woff + tasks_h.back().wlen;
+        } else {
+            ht_chunk.assign(tasks_h.begin() + tpos, tasks_h.begin() + tend);
+            for (auto &t : ht_chunk) {
+                t.woff = off;
+                off += t.wlen;
+            }
         }
+        const std::vector<Task> &ht = whole ? tasks_h : ht_chunk;
         std::vector<int64_t> res_off;
         std::vector<LmChain2> resv;
         double ta = now_ms();
-        run_pseudo(a, ht, res_off, resv);
+        run_pseudo(a, ht, res_off, resv, whole ? w.tasks.p : nullptr);
         double tb = now_ms();
         st.ms_pseudo += tb - ta;
         // glue per segment with results (parallel; the order of `genomes` stays the segment order)
@@ -1674,12 +1686,14 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
             HIPCHK(hipMemsetAsync(a.ext_wcap.p + NW, 0, sizeof(int32_t), ix->st));
             launch_extend_wave_cap(ix->st, a.ext_cap.p, NH, a.ext_wcap.p, NW);
             int64_t ER = scan_to_i64<int32_t, CastI32>(ix, a.ext_wcap.p, NW, a.ext_off.p);
+            a.ext_rows.ensure((size_t)extend_grid_blocks(NH) * LM_EXT_ROWS * 64 * 2);
+            a.ext_rstart.ensure((size_t)extend_grid_blocks(NH) * LM_EXT_ROWS * 64);
             a.ext_subs.ensure(64 * (size_t)ER + 64);
             a.ext_msi.ensure(64 * (size_t)ER + 64);
             {
                 Prof p(ix, "k_extend");
                 launch_extend(ix->st, a.hsp_in.p, NH, qb->d_seq.p, qb->d_qoff.p, a.wbuf.p, a.ext_cap.p, a.ext_off.p,
-                              a.ext_subs.p, a.ext_msi.p, a.hsp_ext.p);
+                              a.ext_subs.p, a.ext_msi.p, a.ext_rows.p, a.ext_rstart.p, a.hsp_ext.p);
             }
             std::vector<HspExt> hext;
             d2h(ix, hext, a.hsp_ext.p, (size_t)NH);
@@ -1808,7 +1822,7 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
         tpos = tend;
         janitor().dispose(std::move(hsps));
         janitor().dispose(std::move(resv));
-        janitor().dispose(std::move(ht));
+        janitor().dispose(std::move(ht_chunk));
         janitor().dispose(std::move(wout));
     }
     // ---- per query: sort genomes by best cluster (:2919-2921, ties by genome key), regroup by sseqid, emit rows ----

@@ -64,6 +64,22 @@ void ha_extend_match(const uint8_t *seq1, int len1, const uint8_t *seq2, int len
                     subs.data(), msi.data(), cap, &o[0], &o[1], &o[2], &o[3], &o[4], &o[5], &o[6], &o[7]);
 }
 
+// one flank through both forms of the 2-mer chainer: list (lm_extend_right) and grid (lm_extend_flank_grid, the form the
+// HIP kernel runs, here with a stride of 3 to exercise the interleaved scratch addressing)
+void ha_extend_flank_both(const uint8_t *s1, int n1, const uint8_t *s2, int n2, int rev, int *o) {
+    int cap = 260 * 260;
+    std::vector<LmSub> subs(cap);
+    std::vector<int64_t> msi(cap);
+    lm_extend_right(s1, n1, s2, n2, rev != 0, subs.data(), msi.data(), cap, &o[0], &o[1]);
+    const int stride = 3;
+    std::vector<uint16_t> subs16((size_t)cap * stride, 0xffff);
+    std::vector<int32_t> msi32((size_t)cap * stride, -1);
+    std::vector<LmM128> rows((size_t)LM_EXT_ROWS * stride);
+    std::vector<uint32_t> rstart((size_t)LM_EXT_ROWS * stride);
+    lm_extend_flank_grid(s1, n1, s2, n2, rev != 0, subs16.data() + 1, msi32.data() + 1, cap, rows.data() + 1, rstart.data() + 1,
+                         stride, &o[2], &o[3]);
+}
+
 int ha_tree_search_range(const uint64_t *keys, int n, uint64_t key, int p, int K, int *lo, int *hi) {
     return lm_tree_search_range(keys, n, key, p, K, lo, hi) ? 1 : 0;
 }

@@ -56,6 +56,7 @@ def lib():
         L.ha_chain2.argtypes = [C.POINTER(Sub), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                                 C.POINTER(Chain2)]
         L.ha_extend_match.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int] + [C.c_int] * 8 + [C.POINTER(C.c_int)]
+        L.ha_extend_flank_both.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
         L.ha_tree_search_range.argtypes = [C.POINTER(C.c_uint64), C.c_int, C.c_uint64, C.c_int, C.c_int,
                                            C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.ha_wfa.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_uint64),

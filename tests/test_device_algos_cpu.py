@@ -332,6 +332,35 @@ def test_extend_match_matches_oracle(seed):
         assert [x.value for x in o] == list(d)
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_extend_flank_grid_equals_list_chainer(seed):
+    """a14: the grid form of the flank chainer the HIP kernel runs (bit-parallel pairs + windowed predecessor search on
+    the (q,t) grid, strided scratch) returns what the list form (Chainer3 as written, lib-chaining3.go) returns"""
+    Hh = H.lib()
+    rng = random.Random(900 + seed)
+    for it in range(600):
+        n1 = rng.choice([2, 3, 10, 30, 50, 50, 50, 60, 90, 130, 131, 132, 140])
+        n2 = rng.choice([2, 5, 30, 50, 50, 50, 64, 65, 100, 127, 128, 129, 130])
+        kind = rng.random()
+        if kind < 0.15:      # low complexity: many pairs
+            a = bytes(rng.choice(b"AT") for _ in range(n1))
+            b = bytes(rng.choice(b"AT") for _ in range(n2))
+        elif kind < 0.25:
+            a = b"A" * n1
+            b = b"A" * (n2 - 1) + b"C"
+        elif kind < 0.75:    # homologous flanks with substitutions / indels
+            a = rand_seq(rng, n1)
+            b = mutate(rng, a, 0.12, 0.04, 0.04)
+            b = (b + rand_seq(rng, n2))[:n2] if len(b) < n2 else b[:n2]
+            if len(b) < 2:
+                b = rand_seq(rng, 2)
+        else:
+            a, b = rand_seq(rng, n1), rand_seq(rng, n2)
+        o = (C.c_int * 4)()
+        Hh.ha_extend_flank_both(a, len(a), b, len(b), int(rng.random() < 0.5), o)
+        assert (o[0], o[1]) == (o[2], o[3]), (it, len(a), len(b), a, b, list(o))
+
+
 def run_oracle_wfa(q, t):
     L = O.lib()
     r = O.WfaResult()
