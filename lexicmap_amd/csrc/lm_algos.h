@@ -41,26 +41,19 @@ LM_HD uint8_t lm_base2bit(uint8_t c) {
 
 LM_HD uint64_t lm_kmer_mask(int k) { return k >= 32 ? ~0ull : ((1ull << (k << 1)) - 1); }
 
-LM_HD uint64_t lm_revcomp(uint64_t x, int k) {
-    // complement then reverse 2-bit groups
-    x = ~x;
-    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+// reverse the order of the 32 2-bit groups of a word: byte swap (v_perm on gfx950), then the two sub-byte stages
+LM_HD uint64_t lm_reverse_groups(uint64_t x) {
+    x = __builtin_bswap64(x);
     x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
-    x = ((x >> 8) & 0x00FF00FF00FF00FFull) | ((x & 0x00FF00FF00FF00FFull) << 8);
-    x = ((x >> 16) & 0x0000FFFF0000FFFFull) | ((x & 0x0000FFFF0000FFFFull) << 16);
-    x = (x >> 32) | (x << 32);
-    return x >> (64 - (k << 1));
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    return x;
+}
+LM_HD uint64_t lm_revcomp(uint64_t x, int k) { // complement, reverse the bases
+    return lm_reverse_groups(~x) >> (64 - (k << 1));
 }
 
 // kmers.MustReverse: base-wise reversal without complement (lib-index-search.go:1327)
-LM_HD uint64_t lm_reverse(uint64_t x, int k) {
-    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
-    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
-    x = ((x >> 8) & 0x00FF00FF00FF00FFull) | ((x & 0x00FF00FF00FF00FFull) << 8);
-    x = ((x >> 16) & 0x0000FFFF0000FFFFull) | ((x & 0x0000FFFF0000FFFFull) << 16);
-    x = (x >> 32) | (x << 32);
-    return x >> (64 - (k << 1));
-}
+LM_HD uint64_t lm_reverse(uint64_t x, int k) { return lm_reverse_groups(x) >> (64 - (k << 1)); }
 
 LM_HD uint64_t lm_ns(uint64_t b, int k) {
     uint64_t c = b;

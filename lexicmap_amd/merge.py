@@ -42,50 +42,62 @@ def _cat(parts):
 
 
 def all_gather_rows(arr, device="cpu"):
-    """all-gatherv of row records: sizes first, then padded payloads. Returns the list of per-rank arrays."""
+    """all-gatherv of row records: sizes first, then one all-gather of padded payloads (RCCL on GPUs).
+    Returns the list of per-rank arrays."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size()
-    arr = _cat([arr])
+    arr = np.ascontiguousarray(arr, dtype=ROW_DTYPE).copy()
     for f in ("genome_id", "seq_id", "cigar", "qseq", "sseq", "align"):
         arr[f] = 0  # process-local addresses mean nothing on another rank
-    payload = torch.from_numpy(np.frombuffer(arr.tobytes(), dtype=np.uint8).copy()).to(device)
-    size = torch.tensor([payload.numel()], dtype=torch.int64, device=device)
-    sizes = [torch.zeros_like(size) for _ in range(world)]
-    dist.all_gather(sizes, size)
-    mx = max(1, int(max(s.item() for s in sizes)))
+    item = ROW_DTYPE.itemsize
+    payload = torch.from_numpy(arr.view(np.uint8).reshape(-1)) if len(arr) else torch.zeros(0, dtype=torch.uint8)
+    size = torch.tensor([len(arr)], dtype=torch.int64, device=device)
+    sizes = torch.zeros(world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(sizes, size)
+    sizes = [int(x) for x in sizes.cpu().tolist()]
+    mx = max(1, max(sizes)) * item
     pad = torch.zeros(mx, dtype=torch.uint8, device=device)
-    pad[:payload.numel()] = payload
-    bufs = [torch.zeros(mx, dtype=torch.uint8, device=device) for _ in range(world)]
-    dist.all_gather(bufs, pad)
-    out = []
-    for b, s in zip(bufs, sizes):
-        raw = b[:int(s.item())].cpu().numpy().tobytes()
-        out.append(np.frombuffer(raw, dtype=ROW_DTYPE).copy())
-    return out
+    pad[:payload.numel()] = payload.to(device, non_blocking=True)
+    allb = torch.empty(world * mx, dtype=torch.uint8, device=device)
+    dist.all_gather_into_tensor(allb, pad)
+    host = allb.cpu().numpy()
+    return [host[r * mx:r * mx + sizes[r] * item].view(ROW_DTYPE) for r in range(world)]
 
 
 def merge_sharded(per_rank):
-    """rows of disjoint genome shards -> one row array in the reference's output order, `hits` recomputed"""
+    """rows of disjoint genome shards -> one row array in the reference's output order, `hits` recomputed:
+    per query, genomes by their best bitscore*pident descending (ties by genome key), each genome's rows in their
+    (already final) order"""
     allr = _cat(per_rank)
-    if len(allr) == 0:
+    n = len(allr)
+    if n == 0:
         return allr
-    out = []
-    for q in np.unique(allr["query"]):
-        rq = allr[allr["query"] == q]
-        genomes = {}
-        for i, r in enumerate(rq):  # keep each genome's rows in their (already final) per-genome order
-            genomes.setdefault(int(r["batch_genome"]), []).append(i)
-        best = {g: max(float(rq["bitscore"][i]) * float(rq["pident"][i]) for i in ix) for g, ix in genomes.items()}
-        order = sorted(genomes, key=lambda g: (-best[g], g))
-        for g in order:
-            blk = rq[genomes[g]].copy()
-            blk["hits"] = len(order)
-            out.append(blk)
-    return _cat(out)
+    q = allr["query"].astype(np.int64)
+    g = allr["batch_genome"].astype(np.int64)
+    sim = allr["bitscore"].astype(np.float64) * allr["pident"]
+    idx = np.arange(n)
+    # groups of (query, genome): best similarity per group
+    o = np.lexsort((idx, g, q))
+    qs, gs = q[o], g[o]
+    new = np.ones(n, dtype=bool)
+    new[1:] = (qs[1:] != qs[:-1]) | (gs[1:] != gs[:-1])
+    starts = np.flatnonzero(new)
+    gid = np.cumsum(new) - 1                      # group id of every sorted row
+    best = np.maximum.reduceat(sim[o], starts)    # per group
+    # order: query asc, best desc, genome asc, original row order
+    o2 = np.lexsort((idx[o], gs, -best[gid], qs))
+    out = _cat([allr[o][o2]])  # fresh zeroed records: fancy indexing leaves the struct padding undefined
+    # hits = genomes per query
+    gq = qs[starts]
+    uq, cnt = np.unique(gq, return_counts=True)
+    hits = dict(zip(uq.tolist(), cnt.tolist()))
+    out["hits"] = np.array([hits[int(x)] for x in out["query"]], dtype=out["hits"].dtype) if n < 4096 else \
+        cnt[np.searchsorted(uq, out["query"].astype(np.int64))].astype(out["hits"].dtype)
+    return out
 
 
 def merge_query_sharded(per_rank):
-    """query-sharded ranks: rows are already final per query; just concatenate in query order"""
-    allr = _cat(per_rank)
-    return allr[np.argsort(allr["query"], kind="stable")]
+    """query-sharded ranks: rows are already final per query and grouped per query; the order across queries is
+    arrival order in the reference (search.go:47), here rank order"""
+    return _cat(per_rank)
