@@ -1034,6 +1034,7 @@ static void run_pseudo(AlignCtx &a, const std::vector<Task> &ht, std::vector<int
     // counts past it, so an undersized buffer costs one re-run
     a.pa_count.ensure(1);
     if (a.pa_cap < (int64_t)1 << 20) a.pa_cap = std::max<int64_t>((int64_t)1 << 20, W / 8);
+    if (const char *e = getenv("LM_DEBUG_PA_CAP")) a.pa_cap = std::max<int64_t>(1, atoll(e)); // test hook: force the re-run
     int64_t TP = 0;
     for (int attempt = 0;; attempt++) {
         a.A0.ensure((size_t)a.pa_cap);
@@ -1517,7 +1518,8 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
 
     // ---- alignment in chunks of whole segments ----
     AlignCtx &a = get_actx(ix, qb, &w, &st);
-    const int64_t max_window_bytes = (int64_t)2 << 30;
+    int64_t max_window_bytes = (int64_t)2 << 30;
+    if (const char *e = getenv("LM_DEBUG_MAX_WINDOW_BYTES")) max_window_bytes = std::max<int64_t>(1, atoll(e)); // test hook
     std::vector<HGenome> genomes; // in (query, genome) order
     const int K = ix->host.k;
     const bool want_seq = ix->opt.output_seq != 0;

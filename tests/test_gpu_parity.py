@@ -269,6 +269,24 @@ def test_full_search_parity(both, queries):
     assert stats["rows"] == nrows and stats["chains"] > 0 and stats["hsps_aligned"] >= nrows
 
 
+def test_chunked_alignment_and_anchor_buffer_rerun_give_the_same_rows(both, queries, monkeypatch):
+    """the alignment half runs in chunks of whole (query, genome) segments when the windows of a batch exceed its window
+    budget, and re-runs the anchor kernel when its output buffer estimate was too small: both paths, forced here through
+    the library's test hooks, must return exactly the rows of the single-chunk run"""
+    _oi, gi = both
+    seqs = [q[1] for q in queries]
+    base, st0 = gi.search(seqs)
+    monkeypatch.setenv("LM_DEBUG_MAX_WINDOW_BYTES", "20000")   # a few chain windows per chunk
+    monkeypatch.setenv("LM_DEBUG_PA_CAP", "64")                # anchor buffer far too small -> counted, re-run
+    got, st1 = gi.search(seqs)
+    monkeypatch.delenv("LM_DEBUG_MAX_WINDOW_BYTES")
+    monkeypatch.delenv("LM_DEBUG_PA_CAP")
+    assert len(base) == len(got) and len(base) > 50
+    for b, g in zip(base, got):
+        assert b == g
+    assert st0["rows"] == st1["rows"] and st0["pa_anchors"] == st1["pa_anchors"]
+
+
 def test_search_options_topn_and_all_columns(small_index, queries):
     """-n/--top-n-genomes, -N/--top-n-chains and -a/--all (CIGAR/qseq/sseq/align strings)"""
     la = _la()
