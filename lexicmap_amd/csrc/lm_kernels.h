@@ -84,10 +84,13 @@ void launch_extract_windows(hipStream_t st, DevIndexView ix, const Task *tasks, 
 void launch_build_cmp_tab(hipStream_t st, const uint64_t *keys_cmp, const int64_t *posoff, const int32_t *nvalid, int nq,
                           int K, uint32_t *tab);
 void launch_sum_i32(hipStream_t st, const int32_t *v, int64_t n, unsigned long long *out);
+#define LM_PFX_WORDS_PER_QUERY 2048 /* 4^8 bits: 8-base prefix bitmap of a query's filtered k-mers */
+void launch_build_cmp_bits(hipStream_t st, const uint64_t *keys_cmp, const int64_t *posoff, const int32_t *nvalid, int nq,
+                           int K, uint32_t *bits);
 void launch_pa_anchors(hipStream_t st, DevIndexView ix, const Task *tasks, int64_t ntasks, const uint8_t *wbuf,
                        const uint64_t *keys_cmp, const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid,
-                       const uint32_t *cmp_tab, int K, int min_prefix, unsigned long long *count, int64_t cap,
-                       uint64_t *outA, uint64_t *outB);
+                       const uint32_t *cmp_tab, const uint32_t *cmp_bits, int K, int min_prefix,
+                       unsigned long long *count, int64_t cap, uint64_t *outA, uint64_t *outB);
 void launch_pa_task_off_sorted(hipStream_t st, const uint64_t *sortedA, int64_t total, int64_t ntasks, int64_t *pa_off);
 void launch_pa_chain(hipStream_t st, const uint64_t *B, const int64_t *pa_off, int64_t ntasks, int K, LmChain2Opt opt,
                      LmSub *subs, uint8_t *marks, uint64_t *msi, int32_t *stack, LmChain2 *out, int32_t *out_n,

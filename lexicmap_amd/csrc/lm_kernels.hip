@@ -83,6 +83,31 @@ __global__ void k_build_cmp_tab(const uint64_t *__restrict__ keys_cmp, const int
         tab[t] = (uint32_t)lo;
     }
 }
+// exact bitmap of the 8-base prefixes present among a query's (filtered) k-mers: 4^8 bits = 8 KB per query.
+// A window k-mer whose prefix is absent shares at most 7 bases with any query k-mer, so it cannot match at the
+// pseudo-alignment prefix length (>= 11) and the partial-prefix rule of tree.Search can only fire when its bases
+// [7, p) are all A - one L1/L2-resident load decides ~95 % of the window positions (k_pa_anchors).
+#define LM_PFX_BITS 16
+#define LM_PFX_WORDS (1 << (LM_PFX_BITS - 5))
+__global__ __launch_bounds__(256) void k_build_cmp_bits(const uint64_t *__restrict__ keys_cmp,
+                                                         const int64_t *__restrict__ posoff,
+                                                         const int32_t *__restrict__ nvalid, int nq, int K,
+                                                         uint32_t *__restrict__ bits) {
+    __shared__ uint32_t sb[LM_PFX_WORDS];
+    for (int q = blockIdx.x; q < nq; q += gridDim.x) {
+        for (int j = threadIdx.x; j < LM_PFX_WORDS; j += blockDim.x) sb[j] = 0;
+        __syncthreads();
+        const uint64_t *keys = keys_cmp + 2 * posoff[q];
+        const int n = nvalid[q];
+        for (int j = threadIdx.x; j < n; j += blockDim.x) {
+            const uint32_t pfx = (uint32_t)(keys[j] >> ((K << 1) - LM_PFX_BITS));
+            atomicOr(&sb[pfx >> 5], 1u << (pfx & 31));
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < LM_PFX_WORDS; j += blockDim.x) bits[(int64_t)q * LM_PFX_WORDS + j] = sb[j];
+        __syncthreads();
+    }
+}
 
 __global__ void k_fill_u32(uint32_t *p, int64_t n, uint32_t v) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
@@ -407,6 +432,7 @@ struct PaCtx {
     const uint64_t *keys;
     const uint32_t *vals;
     const uint32_t *tab;
+    const uint32_t *bits; // 8-base prefix bitmap (k_build_cmp_bits), may be null
     int n, K, m;
     uint32_t begin, end;
     uint64_t ccc, ggg, ttt;
@@ -432,9 +458,10 @@ __device__ __forceinline__ void pa_kmer(const Task &t, const uint8_t *__restrict
 }
 
 __device__ __forceinline__ PaCtx pa_ctx(const Task &t, const uint64_t *keys_cmp, const uint32_t *vals_cmp,
-                                        const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_tab, int K,
-                                        int min_prefix) {
+                                        const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_tab,
+                                        const uint32_t *cmp_bits, int K, int min_prefix) {
     PaCtx c;
+    c.bits = cmp_bits ? cmp_bits + (int64_t)t.q * LM_PFX_WORDS : nullptr;
     c.keys = keys_cmp + 2 * posoff[t.q];
     c.vals = vals_cmp + 2 * posoff[t.q];
     c.tab = cmp_tab + (int64_t)t.q * ((1 << LM_TAB_BITS) + 1);
@@ -450,28 +477,26 @@ __device__ __forceinline__ PaCtx pa_ctx(const Task &t, const uint64_t *keys_cmp,
 }
 
 // ---- single-pass pseudo-alignment anchors ----------------------------------------------------------------------------
-// k_pa_anchors replaces the count / scan / emit triple: one workgroup per chain window, every thread runs only the cheap
-// part per position (2-bit k-mer from the packed genome, bucket table, one or two probes). Positions that need more - a
-// non-empty match range to enumerate, or a candidate for the partial-prefix rule of tree.Search - are pushed into an LDS
-// work list that the whole workgroup then processes densely, so the expensive paths are not executed by every
-// wavefront for the sake of one lane. Anchors are staged in LDS and appended to the global list with one atomic per
-// flush; their order is irrelevant because the list is sorted by (task, B) afterwards. `count` keeps counting past
-// `cap`, so the host can re-run with a larger buffer.
-#define PA_QCAP 1024
+// k_pa_anchors replaces a count / scan / emit triple: one workgroup per chain window. Per window position every thread
+// only extracts the 2-bit k-mer (and its reverse complement) from the packed genome and tests the query's 8-base prefix
+// bitmap: ~95 % of the (position, strand) pairs end there. The rest - a query k-mer shares 8 bases, or the k-mer's
+// bases [7, p) are all A so the partial-prefix rule of tree.Search could fire - go into an LDS work list that the whole
+// workgroup processes densely with the exact search (lm_tree_search_range_tab) and the enumeration of the matches, so
+// the expensive path is never executed by a wavefront for the sake of one lane. Anchors are staged in LDS and appended
+// to the global list with one atomic per flush; their order is irrelevant because the list is sorted by (task, B)
+// afterwards. `count` keeps counting past `cap`, so the host can re-run with a larger buffer.
+#define PA_QCAP 2048
 #define PA_OCAP 2048
-struct PaItem {
-    uint32_t pos_strand; // position << 1 | strand (1 = reverse complement)
-    int32_t lo, hi;      // hi >= 0: match range [lo, hi); hi < 0: partial-prefix candidate, lo = insertion point
-};
 __global__ __launch_bounds__(256) void k_pa_anchors(DevIndexView ix, const Task *__restrict__ tasks, int64_t ntasks,
                                                      const uint8_t *__restrict__ wbuf,
                                                      const uint64_t *__restrict__ keys_cmp,
                                                      const uint32_t *__restrict__ vals_cmp,
                                                      const int64_t *__restrict__ posoff, const int32_t *__restrict__ nvalid,
-                                                     const uint32_t *__restrict__ cmp_tab, int K, int min_prefix,
+                                                     const uint32_t *__restrict__ cmp_tab,
+                                                     const uint32_t *__restrict__ cmp_bits, int K, int min_prefix,
                                                      unsigned long long *__restrict__ count, int64_t cap,
                                                      uint64_t *__restrict__ outA, uint64_t *__restrict__ outB) {
-    __shared__ PaItem q_item[PA_QCAP];
+    __shared__ uint32_t q_item[PA_QCAP]; // position << 1 | strand (1 = reverse complement)
     __shared__ uint64_t s_out[PA_OCAP];
     __shared__ int q_n, s_on;
     __shared__ unsigned long long s_base;
@@ -479,12 +504,14 @@ __global__ __launch_bounds__(256) void k_pa_anchors(DevIndexView ix, const Task 
     for (int64_t ti = blockIdx.x; ti < ntasks; ti += gridDim.x) {
         const Task t = tasks[ti];
         const uint8_t *w = wbuf + t.woff;
-        const PaCtx c = pa_ctx(t, keys_cmp, vals_cmp, posoff, nvalid, cmp_tab, K, min_prefix);
+        const PaCtx c = pa_ctx(t, keys_cmp, vals_cmp, posoff, nvalid, cmp_tab, cmp_bits, K, min_prefix);
         const uint8_t *gb = t.g >= 0 ? ix.gbits : nullptr;
         const int64_t goff = t.g >= 0 ? ix.g_off[t.g] : 0;
         const int npos = c.n > 0 ? t.wlen - K + 1 : 0;
-        const int sh = (K - (c.m > K ? K : c.m)) << 1;
-        const uint64_t low = sh >= 64 ? ~0ull : ((1ull << sh) - 1);
+        const int p = c.m > K ? K : c.m;
+        const int sh = (K - p) << 1;
+        const bool use_bits = c.bits != nullptr && p > 8 && 2 * K >= LM_PFX_BITS;
+        const uint64_t tail_mask = p > 7 ? ((p - 7) >= 32 ? ~0ull : ((1ull << ((p - 7) << 1)) - 1ull)) : 0ull; // bases [7,p)
         if (tid == 0) {
             q_n = 0;
             s_on = 0;
@@ -518,32 +545,30 @@ __global__ __launch_bounds__(256) void k_pa_anchors(DevIndexView ix, const Task 
             if (tid == 0) s_on = 0;
             __syncthreads();
         };
-        auto drain = [&]() { // all threads: process the work list densely
+        auto drain = [&]() { // all threads: exact search + enumeration for the listed (position, strand) pairs
             __syncthreads();
             const int nq = q_n < PA_QCAP ? q_n : PA_QCAP;
             for (int base = 0; base < nq; base += 256) {
                 if (base + tid < nq) {
-                    const PaItem it = q_item[base + tid];
-                    const int i = (int)(it.pos_strand >> 1);
-                    const bool rcs = (it.pos_strand & 1u) != 0;
+                    const uint32_t it = q_item[base + tid];
+                    const int i = (int)(it >> 1);
+                    const bool rcs = (it & 1u) != 0;
                     uint64_t kmer, rc;
                     pa_kmer(t, w, gb, goff, i, K, &kmer, &rc);
                     const uint64_t key = rcs ? rc : kmer;
-                    int lo = it.lo, hi = it.hi;
-                    bool ok = hi >= 0;
-                    if (!ok) ok = lm_tree_search_miss(c.keys, c.n, key, c.m > K ? K : c.m, K, lo, &lo, &hi);
-                    if (ok) {
+                    int lo, hi;
+                    if (lm_tree_search_range_tab(c.keys, c.n, key, c.m, K, c.tab, LM_TAB_BITS, &lo, &hi)) {
                         for (int j = lo; j < hi; j++) {
                             const uint32_t v = c.vals[j];
                             const uint32_t lp = (uint32_t)lm_lcp(c.keys[j], key, K);
                             if (!rcs) {
-                                const uint32_t p = v >> 1;
-                                if ((v & 1u) == 1u || p < c.begin || p + lp > c.end) continue;
-                                emit(lm_pack_anchor((int)p, (int)lp, i, false, false));
+                                const uint32_t pp = v >> 1;
+                                if ((v & 1u) == 1u || pp < c.begin || pp + lp > c.end) continue;
+                                emit(lm_pack_anchor((int)pp, (int)lp, i, false, false));
                             } else {
-                                const uint32_t p = (v >> 1) + (uint32_t)K - lp;
-                                if ((v & 1u) == 0u || p + lp < c.begin || p > c.end) continue;
-                                emit(lm_pack_anchor((int)p, (int)lp, i + K - (int)lp, true, true));
+                                const uint32_t pp = (v >> 1) + (uint32_t)K - lp;
+                                if ((v & 1u) == 0u || pp + lp < c.begin || pp > c.end) continue;
+                                emit(lm_pack_anchor((int)pp, (int)lp, i + K - (int)lp, true, true));
                             }
                         }
                     }
@@ -564,24 +589,14 @@ __global__ __launch_bounds__(256) void k_pa_anchors(DevIndexView ix, const Task 
 #pragma unroll
                     for (int strand = 0; strand < 2; strand++) {
                         const uint64_t key = strand ? rc : kmer;
-                        const uint32_t b = (uint32_t)(key >> ((K << 1) - LM_TAB_BITS));
-                        const int t0 = (int)c.tab[b], t1 = (int)c.tab[b + 1];
-                        const uint64_t left = key & ~low, right = key | low;
-                        const int lo = lm_lower_bound_u64(c.keys, t0, t1, left);
-                        PaItem it;
-                        it.pos_strand = ((uint32_t)i << 1) | (uint32_t)strand;
-                        it.lo = lo;
-                        bool push = false;
-                        if (lo < t1 && c.keys[lo] <= right) {
-                            it.hi = lm_upper_bound_u64(c.keys, lo + 1, t1, right);
-                            push = true;
-                        } else if (((key >> sh) & 3ull) == 0) { // partial-prefix rule needs base p-1 == A
-                            it.hi = -1;
-                            push = true;
+                        bool cand = true;
+                        if (use_bits) {
+                            const uint32_t pfx = (uint32_t)(key >> ((K << 1) - LM_PFX_BITS));
+                            cand = ((c.bits[pfx >> 5] >> (pfx & 31)) & 1u) != 0 || ((key >> sh) & tail_mask) == 0;
                         }
-                        if (push) {
+                        if (cand) {
                             const int slot = atomicAdd(&q_n, 1);
-                            if (slot < PA_QCAP) q_item[slot] = it;
+                            if (slot < PA_QCAP) q_item[slot] = ((uint32_t)i << 1) | (uint32_t)strand;
                         }
                     }
                 }
@@ -2106,13 +2121,18 @@ void launch_sum_i32(hipStream_t st, const int32_t *v, int64_t n, unsigned long l
     g = g < 1 ? 1 : (g > 2048 ? 2048 : g);
     hipLaunchKernelGGL(k_sum_i32, dim3(g), dim3(256), 0, st, v, n, out);
 }
+void launch_build_cmp_bits(hipStream_t st, const uint64_t *keys_cmp, const int64_t *posoff, const int32_t *nvalid, int nq,
+                           int K, uint32_t *bits) {
+    int g = nq < 1 ? 1 : (nq > 65536 ? 65536 : nq);
+    hipLaunchKernelGGL(k_build_cmp_bits, dim3(g), dim3(256), 0, st, keys_cmp, posoff, nvalid, nq, K, bits);
+}
 void launch_pa_anchors(hipStream_t st, DevIndexView ix, const Task *tasks, int64_t ntasks, const uint8_t *wbuf,
                        const uint64_t *keys_cmp, const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid,
-                       const uint32_t *cmp_tab, int K, int min_prefix, unsigned long long *count, int64_t cap,
-                       uint64_t *outA, uint64_t *outB) {
+                       const uint32_t *cmp_tab, const uint32_t *cmp_bits, int K, int min_prefix,
+                       unsigned long long *count, int64_t cap, uint64_t *outA, uint64_t *outB) {
     int g = (int)(ntasks < 1 ? 1 : (ntasks > 1048576 ? 1048576 : ntasks));
     hipLaunchKernelGGL(k_pa_anchors, dim3(g), dim3(256), 0, st, ix, tasks, ntasks, wbuf, keys_cmp, vals_cmp, posoff, nvalid,
-                       cmp_tab, K, min_prefix, count, cap, outA, outB);
+                       cmp_tab, cmp_bits, K, min_prefix, count, cap, outA, outB);
 }
 void launch_pa_task_off_sorted(hipStream_t st, const uint64_t *sortedA, int64_t total, int64_t ntasks, int64_t *pa_off) {
     LM_LAUNCH_1D(k_pa_task_off_sorted, ntasks + 1, st, sortedA, total, ntasks, pa_off);

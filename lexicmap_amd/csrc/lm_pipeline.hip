@@ -318,7 +318,7 @@ struct Work {
     lm_qbatch *qb;
     // stage A
     DBuf<uint64_t> keys_all, keys_all2, keys_cmp, keys_cmp2;
-    DBuf<uint32_t> vals_all, vals_all2, vals_cmp, vals_cmp2, first_mask, cmp_tab;
+    DBuf<uint32_t> vals_all, vals_all2, vals_cmp, vals_cmp2, first_mask, cmp_tab, cmp_bits;
     DBuf<int32_t> nvalid;
     uint64_t *k_all = nullptr, *k_cmp = nullptr; // sorted
     uint32_t *v_all = nullptr, *v_cmp = nullptr;
@@ -411,6 +411,8 @@ static void stage_kmers(Work &w) {
     w.v_cmp = w.vals_cmp2.p;
     w.cmp_tab.ensure((size_t)qb->nq * ((1 << LM_TAB_BITS) + 1));
     launch_build_cmp_tab(ix->st, w.k_cmp, qb->d_posoff.p, w.nvalid.p, qb->nq, ix->host.k, w.cmp_tab.p);
+    w.cmp_bits.ensure((size_t)qb->nq * LM_PFX_WORDS_PER_QUERY);
+    launch_build_cmp_bits(ix->st, w.k_cmp, qb->d_posoff.p, w.nvalid.p, qb->nq, ix->host.k, w.cmp_bits.p);
 }
 
 static void stage_mask(Work &w) {
@@ -1043,7 +1045,7 @@ static void run_pseudo(AlignCtx &a, const std::vector<Task> &ht, std::vector<int
         {
             Prof p(ix, "k_pa_anchors", W);
             launch_pa_anchors(ix->st, ix->view, tasks_d, nt, a.wbuf.p, a.w->k_cmp, a.w->v_cmp, qb->d_posoff.p,
-                              a.w->nvalid.p, a.w->cmp_tab.p, ix->host.k, 11, a.pa_count.p, a.pa_cap, a.A0.p, a.B0.p);
+                              a.w->nvalid.p, a.w->cmp_tab.p, a.w->cmp_bits.p, ix->host.k, 11, a.pa_count.p, a.pa_cap, a.A0.p, a.B0.p);
         }
         unsigned long long hv = 0;
         HIPCHK(hipMemcpyAsync(&hv, a.pa_count.p, sizeof hv, hipMemcpyDeviceToHost, ix->st));
