@@ -77,7 +77,7 @@ struct AlignCtx;
 
 struct lm_index {
     lm::Work *work = nullptr;       // device scratch reused across calls (grow-only)
-    lm::AlignCtx *actx = nullptr;
+    lm::AlignCtx *actx[2] = {nullptr, nullptr}; // one per alignment worker
     std::mutex mu;                  // one in-flight call per handle
     HostIndex host;
     lm_options opt;
@@ -97,6 +97,7 @@ struct lm_index {
     DBuf<uint8_t> tmp; // rocPRIM temporary storage
     // profiling
     bool prof = false;
+    std::mutex prof_mu;
     std::vector<ProfEntry> prof_entries;
     std::vector<lm_kernel_time> prof_out;
     struct Pending {

@@ -39,35 +39,48 @@ thread_local std::string g_open_error;
 namespace lm {
 
 // ---- profiling: HIP events on the library's stream around each named launch ---------------------------------
+// The alignment half of a batch is split between two host threads (align_range), each with its own stream, rocPRIM
+// scratch and AlignCtx, so the host-side glue of one half overlaps the kernels of the other. Helpers take the stream
+// from here; outside those workers it is the handle's stream.
+static thread_local hipStream_t tls_stream = nullptr;
+static thread_local DBuf<uint8_t> *tls_tmp = nullptr;
+static inline hipStream_t S(lm_index *ix) { return tls_stream ? tls_stream : ix->st; }
+static inline DBuf<uint8_t> &TMP(lm_index *ix) { return tls_tmp ? *tls_tmp : ix->tmp; }
+
 struct Prof {
     lm_index *ix;
     int entry = -1;
     hipEvent_t a = nullptr, b = nullptr;
     Prof(lm_index *ix_, const char *name, int64_t bytes = 0) : ix(ix_) {
         if (!ix->prof) return;
-        for (size_t i = 0; i < ix->prof_entries.size(); i++)
-            if (ix->prof_entries[i].name == name) entry = (int)i;
-        if (entry < 0) {
-            ProfEntry e;
-            e.name = name;
-            ix->prof_entries.push_back(e);
-            entry = (int)ix->prof_entries.size() - 1;
+        {
+            std::lock_guard<std::mutex> l(ix->prof_mu);
+            for (size_t i = 0; i < ix->prof_entries.size(); i++)
+                if (ix->prof_entries[i].name == name) entry = (int)i;
+            if (entry < 0) {
+                ProfEntry e;
+                e.name = name;
+                ix->prof_entries.push_back(e);
+                entry = (int)ix->prof_entries.size() - 1;
+            }
+            ix->prof_entries[entry].bytes += bytes;
+            ix->prof_entries[entry].launches++;
         }
-        ix->prof_entries[entry].bytes += bytes;
-        ix->prof_entries[entry].launches++;
         HIPCHK(hipEventCreate(&a));
         HIPCHK(hipEventCreate(&b));
-        HIPCHK(hipEventRecord(a, ix->st));
+        HIPCHK(hipEventRecord(a, S(ix)));
     }
     ~Prof() {
         if (entry < 0) return;
-        (void)hipEventRecord(b, ix->st);
+        (void)hipEventRecord(b, S(ix));
+        std::lock_guard<std::mutex> l(ix->prof_mu);
         ix->pending.push_back({entry, a, b});
     }
 };
 
 static void prof_add_bytes(lm_index *ix, const char *name, int64_t bytes) {
     if (!ix->prof) return;
+    std::lock_guard<std::mutex> l(ix->prof_mu);
     for (auto &e : ix->prof_entries)
         if (e.name == name) e.bytes += bytes;
 }
@@ -124,21 +137,21 @@ void lm_fill_gap_lut(lm_index *ix) {
     std::vector<float> lut(ix->gap_lut_n);
     for (int g = 0; g < ix->gap_lut_n; g++) lut[g] = lm::gap_score((float)g);
     ix->d_gap_lut.ensure(lut.size());
-    HIPCHK(hipMemcpyAsync(ix->d_gap_lut.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice, ix->st));
-    HIPCHK(hipStreamSynchronize(ix->st));
+    HIPCHK(hipMemcpyAsync(ix->d_gap_lut.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice, S(ix)));
+    HIPCHK(hipStreamSynchronize(S(ix)));
 }
 
 namespace lm {
 
 template <typename T> static void h2d(lm_index *ix, DBuf<T> &d, const std::vector<T> &h) {
     d.ensure(std::max<size_t>(h.size(), 1));
-    if (!h.empty()) HIPCHK(hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, ix->st));
+    if (!h.empty()) HIPCHK(hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, S(ix)));
 }
 template <typename T> static void d2h(lm_index *ix, std::vector<T> &h, const T *d, size_t n) {
     h.resize(n);
-    if (n) HIPCHK(hipMemcpyAsync(h.data(), d, n * sizeof(T), hipMemcpyDeviceToHost, ix->st));
+    if (n) HIPCHK(hipMemcpyAsync(h.data(), d, n * sizeof(T), hipMemcpyDeviceToHost, S(ix)));
 }
-static void sync(lm_index *ix) { HIPCHK(hipStreamSynchronize(ix->st)); }
+static void sync(lm_index *ix) { HIPCHK(hipStreamSynchronize(S(ix))); }
 
 // Big nested host containers (per-genome cluster/chain trees, task lists) are destroyed by a background thread: their
 // destructors are hundreds of thousands of small frees that would otherwise sit between two batches with the GPU idle.
@@ -254,11 +267,11 @@ template <typename InT, typename Cast>
 static int64_t scan_to_i64(lm_index *ix, const InT *counts, int64_t n, int64_t *offs) {
     hipcub::TransformInputIterator<int64_t, Cast, const InT *> it(counts, Cast());
     size_t bytes = 0;
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, it, offs, (int)(n + 1), ix->st));
-    ix->tmp.ensure(bytes);
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(ix->tmp.p, bytes, it, offs, (int)(n + 1), ix->st));
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, it, offs, (int)(n + 1), S(ix)));
+    TMP(ix).ensure(bytes);
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(TMP(ix).p, bytes, it, offs, (int)(n + 1), S(ix)));
     int64_t total = 0;
-    HIPCHK(hipMemcpyAsync(&total, offs + n, sizeof(int64_t), hipMemcpyDeviceToHost, ix->st));
+    HIPCHK(hipMemcpyAsync(&total, offs + n, sizeof(int64_t), hipMemcpyDeviceToHost, S(ix)));
     sync(ix);
     return total;
 }
@@ -266,9 +279,9 @@ static int64_t scan_to_i64(lm_index *ix, const InT *counts, int64_t n, int64_t *
 static void sort_pairs_u64(lm_index *ix, uint64_t *k_in, uint64_t *k_out, uint64_t *v_in, uint64_t *v_out, int64_t n,
                            int begin_bit, int end_bit) {
     size_t bytes = 0;
-    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k_in, k_out, v_in, v_out, (int)n, begin_bit, end_bit, ix->st));
-    ix->tmp.ensure(bytes);
-    HIPCHK(hipcub::DeviceRadixSort::SortPairs(ix->tmp.p, bytes, k_in, k_out, v_in, v_out, (int)n, begin_bit, end_bit, ix->st));
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k_in, k_out, v_in, v_out, (int)n, begin_bit, end_bit, S(ix)));
+    TMP(ix).ensure(bytes);
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(TMP(ix).p, bytes, k_in, k_out, v_in, v_out, (int)n, begin_bit, end_bit, S(ix)));
 }
 
 // sort anchors by (A, B): LSD — stable sort by B, then by A. Result lands in (A0,B0).
@@ -375,7 +388,7 @@ static void stage_kmers(Work &w) {
     w.vals_cmp.ensure(n2);
     w.vals_cmp2.ensure(n2);
     w.nvalid.ensure(qb->nq + 1);
-    HIPCHK(hipMemsetAsync(w.nvalid.p, 0, sizeof(int32_t) * (qb->nq + 1), ix->st));
+    HIPCHK(hipMemsetAsync(w.nvalid.p, 0, sizeof(int32_t) * (qb->nq + 1), S(ix)));
     w.k_all = w.keys_all.p;
     w.v_all = w.vals_all.p;
     w.k_cmp = w.keys_cmp.p;
@@ -383,7 +396,7 @@ static void stage_kmers(Work &w) {
     if (P == 0) return;
     {
         Prof p(ix, "k_extract_kmers", qb->total_len + 2 * P * 24);
-        launch_extract_kmers(ix->st, qb->d_seq.p, qb->d_qoff.p, qb->d_posoff.p, qb->nq, ix->host.k, P, w.keys_all.p,
+        launch_extract_kmers(S(ix), qb->d_seq.p, qb->d_qoff.p, qb->d_posoff.p, qb->nq, ix->host.k, P, w.keys_all.p,
                              w.vals_all.p, w.keys_cmp.p, w.vals_cmp.p, w.nvalid.p);
     }
     {
@@ -392,27 +405,27 @@ static void stage_kmers(Work &w) {
         int end_bit = std::min(64, 2 * ix->host.k);
         HIPCHK(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, bytes, w.keys_all.p, w.keys_all2.p, w.vals_all.p,
                                                            w.vals_all2.p, (int)(2 * P), qb->nq, qb->d_segoff.p,
-                                                           qb->d_segoff.p + 1, 0, end_bit, ix->st));
-        ix->tmp.ensure(bytes);
-        HIPCHK(hipcub::DeviceSegmentedRadixSort::SortPairs(ix->tmp.p, bytes, w.keys_all.p, w.keys_all2.p, w.vals_all.p,
+                                                           qb->d_segoff.p + 1, 0, end_bit, S(ix)));
+        TMP(ix).ensure(bytes);
+        HIPCHK(hipcub::DeviceSegmentedRadixSort::SortPairs(TMP(ix).p, bytes, w.keys_all.p, w.keys_all2.p, w.vals_all.p,
                                                            w.vals_all2.p, (int)(2 * P), qb->nq, qb->d_segoff.p,
-                                                           qb->d_segoff.p + 1, 0, end_bit, ix->st));
+                                                           qb->d_segoff.p + 1, 0, end_bit, S(ix)));
         HIPCHK(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, bytes, w.keys_cmp.p, w.keys_cmp2.p, w.vals_cmp.p,
                                                            w.vals_cmp2.p, (int)(2 * P), qb->nq, qb->d_segoff.p,
-                                                           qb->d_segoff.p + 1, 0, 64, ix->st));
-        ix->tmp.ensure(bytes);
-        HIPCHK(hipcub::DeviceSegmentedRadixSort::SortPairs(ix->tmp.p, bytes, w.keys_cmp.p, w.keys_cmp2.p, w.vals_cmp.p,
+                                                           qb->d_segoff.p + 1, 0, 64, S(ix)));
+        TMP(ix).ensure(bytes);
+        HIPCHK(hipcub::DeviceSegmentedRadixSort::SortPairs(TMP(ix).p, bytes, w.keys_cmp.p, w.keys_cmp2.p, w.vals_cmp.p,
                                                            w.vals_cmp2.p, (int)(2 * P), qb->nq, qb->d_segoff.p,
-                                                           qb->d_segoff.p + 1, 0, 64, ix->st));
+                                                           qb->d_segoff.p + 1, 0, 64, S(ix)));
     }
     w.k_all = w.keys_all2.p;
     w.v_all = w.vals_all2.p;
     w.k_cmp = w.keys_cmp2.p;
     w.v_cmp = w.vals_cmp2.p;
     w.cmp_tab.ensure((size_t)qb->nq * ((1 << LM_TAB_BITS) + 1));
-    launch_build_cmp_tab(ix->st, w.k_cmp, qb->d_posoff.p, w.nvalid.p, qb->nq, ix->host.k, w.cmp_tab.p);
+    launch_build_cmp_tab(S(ix), w.k_cmp, qb->d_posoff.p, w.nvalid.p, qb->nq, ix->host.k, w.cmp_tab.p);
     w.cmp_bits.ensure((size_t)qb->nq * LM_PFX_WORDS_PER_QUERY);
-    launch_build_cmp_bits(ix->st, w.k_cmp, qb->d_posoff.p, w.nvalid.p, qb->nq, ix->host.k, w.cmp_bits.p);
+    launch_build_cmp_bits(S(ix), w.k_cmp, qb->d_posoff.p, w.nvalid.p, qb->nq, ix->host.k, w.cmp_bits.p);
 }
 
 static void stage_mask(Work &w) {
@@ -424,9 +437,9 @@ static void stage_mask(Work &w) {
     w.klo.ensure((size_t)nqm + 1);
     w.khi.ensure((size_t)nqm + 1);
     w.first_mask.ensure((size_t)std::max<int64_t>(2 * qb->total_pos, 1));
-    launch_fill_u32(ix->st, w.first_mask.p, 2 * qb->total_pos, 0xffffffffu);
+    launch_fill_u32(S(ix), w.first_mask.p, 2 * qb->total_pos, 0xffffffffu);
     Prof p(ix, "k_mask", nqm * 32);
-    launch_mask(ix->st, w.k_all, qb->d_posoff.p, qb->nq, M, ix->host.k, ix->view.masks, w.kmers.p, w.klo.p, w.khi.p,
+    launch_mask(S(ix), w.k_all, qb->d_posoff.p, qb->nq, M, ix->host.k, ix->view.masks, w.kmers.p, w.klo.p, w.khi.p,
                 w.first_mask.p);
 }
 
@@ -441,11 +454,11 @@ static void stage_lookup(Work &w, lm_stage_stats &stats) {
     w.lk_starts.ensure((size_t)n + 1);
     w.lk_nscan.ensure((size_t)n + 1);
     w.stat.ensure(4);
-    HIPCHK(hipMemsetAsync(w.stat.p, 0, 4 * sizeof(unsigned long long), ix->st));
-    HIPCHK(hipMemsetAsync(w.lk_counts.p + n, 0, sizeof(uint32_t), ix->st));
+    HIPCHK(hipMemsetAsync(w.stat.p, 0, 4 * sizeof(unsigned long long), S(ix)));
+    HIPCHK(hipMemsetAsync(w.lk_counts.p + n, 0, sizeof(uint32_t), S(ix)));
     {
         Prof p(ix, "k_lookup_count");
-        launch_lookup_count(ix->st, ix->view, w.kmers.p, w.klo.p, w.khi.p, w.first_mask.p, nqm, ix->opt.min_prefix,
+        launch_lookup_count(S(ix), ix->view, w.kmers.p, w.klo.p, w.khi.p, w.first_mask.p, nqm, ix->opt.min_prefix,
                             w.lk_counts.p, w.lk_starts.p, w.lk_nscan.p, w.stat.p);
     }
     int64_t T;
@@ -454,7 +467,7 @@ static void stage_lookup(Work &w, lm_stage_stats &stats) {
         T = scan_to_i64<uint32_t, CastU32>(ix, w.lk_counts.p, n, w.lk_offs.p);
     }
     unsigned long long hv = 0;
-    HIPCHK(hipMemcpyAsync(&hv, w.stat.p, sizeof hv, hipMemcpyDeviceToHost, ix->st));
+    HIPCHK(hipMemcpyAsync(&hv, w.stat.p, sizeof hv, hipMemcpyDeviceToHost, S(ix)));
     sync(ix);
     stats.seed_lookups += n;
     stats.seed_values += (int64_t)hv;
@@ -475,7 +488,7 @@ static void stage_lookup(Work &w, lm_stage_stats &stats) {
     w.B1.ensure((size_t)T);
     {
         Prof p(ix, "k_lookup_emit", T * 16);
-        launch_lookup_emit(ix->st, ix->view, w.kmers.p, w.klo.p, w.khi.p, w.v_all, nqm, w.lk_counts.p, w.lk_offs.p,
+        launch_lookup_emit(S(ix), ix->view, w.kmers.p, w.klo.p, w.khi.p, w.v_all, nqm, w.lk_counts.p, w.lk_offs.p,
                            w.lk_starts.p, w.lk_nscan.p, w.A0.p, w.B0.p);
     }
     {
@@ -489,15 +502,15 @@ static void stage_lookup(Work &w, lm_stage_stats &stats) {
     {
         Prof p(ix, "rle");
         size_t bytes = 0;
-        HIPCHK(hipcub::DeviceRunLengthEncode::Encode(nullptr, bytes, w.A0.p, w.segA.p, w.seg_len.p, w.nseg_d.p, (int)T, ix->st));
-        ix->tmp.ensure(bytes);
-        HIPCHK(hipcub::DeviceRunLengthEncode::Encode(ix->tmp.p, bytes, w.A0.p, w.segA.p, w.seg_len.p, w.nseg_d.p, (int)T, ix->st));
+        HIPCHK(hipcub::DeviceRunLengthEncode::Encode(nullptr, bytes, w.A0.p, w.segA.p, w.seg_len.p, w.nseg_d.p, (int)T, S(ix)));
+        TMP(ix).ensure(bytes);
+        HIPCHK(hipcub::DeviceRunLengthEncode::Encode(TMP(ix).p, bytes, w.A0.p, w.segA.p, w.seg_len.p, w.nseg_d.p, (int)T, S(ix)));
     }
     int32_t nseg = 0;
-    HIPCHK(hipMemcpyAsync(&nseg, w.nseg_d.p, sizeof nseg, hipMemcpyDeviceToHost, ix->st));
+    HIPCHK(hipMemcpyAsync(&nseg, w.nseg_d.p, sizeof nseg, hipMemcpyDeviceToHost, S(ix)));
     sync(ix);
     w.nseg = nseg;
-    HIPCHK(hipMemsetAsync(w.seg_len.p + nseg, 0, sizeof(int32_t), ix->st));
+    HIPCHK(hipMemsetAsync(w.seg_len.p + nseg, 0, sizeof(int32_t), S(ix)));
     w.seg_off.ensure((size_t)nseg + 2);
     scan_to_i64<int32_t, CastI32>(ix, w.seg_len.p, nseg, w.seg_off.p);
     stats.genome_pairs += nseg;
@@ -532,7 +545,7 @@ static void stage_chain1(Work &w) {
     w.seg_nch.ensure((size_t)nseg + 1);
     w.seg_score.ensure(nseg);
     Prof p(ix, "k_chain1", T * 8 * 3);
-    launch_chain1(ix->st, w.B0.p, w.seg_off.p, nseg, chain_opt(ix), ix->host.k, w.subs.p, w.marks.p, w.msi.p, w.s2i.p,
+    launch_chain1(S(ix), w.B0.p, w.seg_off.p, nseg, chain_opt(ix), ix->host.k, w.subs.p, w.marks.p, w.msi.p, w.s2i.p,
                   w.dirs.p, w.visited.p, w.chain_off_pool.p, w.chain_idx_pool.p, w.seg_n.p, w.seg_score.p, w.seg_nch.p);
 }
 
@@ -961,11 +974,26 @@ void lm_qbatch_free(lm_qbatch *qb) { delete qb; }
 namespace lm {
 
 // ---- alignment half of the pipeline: tasks -> windows -> pseudo-alignment -> glue -> extend -> WFA -> finalize ----
+struct TaskSpan { // a contiguous range of the host copy of the task list
+    const Task *p = nullptr;
+    size_t n = 0;
+    const Task &operator[](size_t i) const { return p[i]; }
+    size_t size() const { return n; }
+    const Task &back() const { return p[n - 1]; }
+};
+
 struct AlignCtx {
     lm_index *ix;
     lm_qbatch *qb;
     Work *w;
     lm_stage_stats *stats;
+    hipStream_t st = nullptr;  // this worker's stream
+    DBuf<uint8_t> tmp;         // this worker's rocPRIM temporary storage
+    const uint8_t *wb = nullptr; // window buffer biased so that wb + task.woff addresses this chunk's windows
+    int64_t wfa_budget = (int64_t)40 << 30;
+    ~AlignCtx() {
+        if (st) (void)hipStreamDestroy(st);
+    }
     // per chunk device buffers
     DBuf<int32_t> wlen;
     DBuf<int64_t> woff;
@@ -997,8 +1025,10 @@ struct AlignCtx {
 
 } // namespace lm
 void lm_free_align_ctx(lm_index *ix) {
-    delete ix->actx;
-    ix->actx = nullptr;
+    for (auto &c : ix->actx) {
+        delete c;
+        c = nullptr;
+    }
 }
 namespace lm {
 
@@ -1011,25 +1041,29 @@ struct HspMeta { // host-side view of one WFA problem
 };
 
 // Runs pseudo-alignment for tasks[t0,t1) (host copy `ht`), returns per task the Chain2 results.
-static void run_pseudo(AlignCtx &a, const std::vector<Task> &ht, std::vector<int64_t> &res_off_h,
-                       std::vector<LmChain2> &res_h, const Task *dev_tasks = nullptr) {
+// `ht`: host copy of the tasks; `dev_tasks` their device copy (null: upload `ht`); `base` = window offset of the first
+// task (the tasks carry offsets into one virtual buffer of all windows of the batch, a chunk uses a slice of it)
+static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h, std::vector<LmChain2> &res_h,
+                       const Task *dev_tasks = nullptr, int64_t base = 0) {
     lm_index *ix = a.ix;
     lm_qbatch *qb = a.qb;
     int64_t nt = (int64_t)ht.size();
     res_off_h.assign(nt + 1, 0);
     res_h.clear();
     if (nt == 0) return;
-    int64_t W = ht.back().woff + ht.back().wlen;
+    int64_t W = ht.back().woff + ht.back().wlen - base;
     a.wbuf.ensure((size_t)W + 64);
-    const Task *tasks_d = dev_tasks; // the device copy already carries these window offsets (single-chunk case)
+    a.wb = a.wbuf.p - base;
+    uint8_t *wbw = a.wbuf.p - base;
+    const Task *tasks_d = dev_tasks;
     if (!tasks_d) {
         a.tasks.ensure((size_t)nt);
-        HIPCHK(hipMemcpyAsync(a.tasks.p, ht.data(), sizeof(Task) * nt, hipMemcpyHostToDevice, ix->st));
+        HIPCHK(hipMemcpyAsync(a.tasks.p, ht.p, sizeof(Task) * nt, hipMemcpyHostToDevice, S(ix)));
         tasks_d = a.tasks.p;
     }
     {
         Prof p(ix, "k_extract_windows", W + W / 4);
-        launch_extract_windows(ix->st, ix->view, tasks_d, nt, a.wbuf.p);
+        launch_extract_windows(S(ix), ix->view, tasks_d, nt, wbw);
     }
     a.stats->window_bases += W;
     // single pass: anchors appended to (A0, B0) in arbitrary order; the buffer size is a running estimate, the kernel
@@ -1041,14 +1075,14 @@ static void run_pseudo(AlignCtx &a, const std::vector<Task> &ht, std::vector<int
     for (int attempt = 0;; attempt++) {
         a.A0.ensure((size_t)a.pa_cap);
         a.B0.ensure((size_t)a.pa_cap);
-        HIPCHK(hipMemsetAsync(a.pa_count.p, 0, sizeof(unsigned long long), ix->st));
+        HIPCHK(hipMemsetAsync(a.pa_count.p, 0, sizeof(unsigned long long), S(ix)));
         {
             Prof p(ix, "k_pa_anchors", W);
-            launch_pa_anchors(ix->st, ix->view, tasks_d, nt, a.wbuf.p, a.w->k_cmp, a.w->v_cmp, qb->d_posoff.p,
+            launch_pa_anchors(S(ix), ix->view, tasks_d, nt, a.wb, a.w->k_cmp, a.w->v_cmp, qb->d_posoff.p,
                               a.w->nvalid.p, a.w->cmp_tab.p, a.w->cmp_bits.p, ix->host.k, 11, a.pa_count.p, a.pa_cap, a.A0.p, a.B0.p);
         }
         unsigned long long hv = 0;
-        HIPCHK(hipMemcpyAsync(&hv, a.pa_count.p, sizeof hv, hipMemcpyDeviceToHost, ix->st));
+        HIPCHK(hipMemcpyAsync(&hv, a.pa_count.p, sizeof hv, hipMemcpyDeviceToHost, S(ix)));
         sync(ix);
         TP = (int64_t)hv;
         if (TP <= a.pa_cap) break;
@@ -1060,7 +1094,7 @@ static void run_pseudo(AlignCtx &a, const std::vector<Task> &ht, std::vector<int
     a.pa_off.ensure((size_t)nt + 2);
     a.out_n.ensure((size_t)nt + 1);
     a.clr_n.ensure((size_t)nt + 1);
-    HIPCHK(hipMemsetAsync(a.out_n.p, 0, sizeof(int32_t) * (nt + 1), ix->st));
+    HIPCHK(hipMemsetAsync(a.out_n.p, 0, sizeof(int32_t) * (nt + 1), S(ix)));
     if (TP > 0) {
         a.A1.ensure((size_t)a.pa_cap);
         a.B1.ensure((size_t)a.pa_cap);
@@ -1070,7 +1104,7 @@ static void run_pseudo(AlignCtx &a, const std::vector<Task> &ht, std::vector<int
             while (((int64_t)1 << abits) < nt + 1) abits++;
             sort_anchors(ix, a.A0.p, a.B0.p, a.A1.p, a.B1.p, TP, abits);
         }
-        launch_pa_task_off_sorted(ix->st, a.A0.p, TP, nt, a.pa_off.p);
+        launch_pa_task_off_sorted(S(ix), a.A0.p, TP, nt, a.pa_off.p);
         a.subs.ensure((size_t)TP);
         a.marks.ensure((size_t)TP);
         a.msi.ensure((size_t)TP);
@@ -1085,14 +1119,14 @@ static void run_pseudo(AlignCtx &a, const std::vector<Task> &ht, std::vector<int
         o2.heuristic_pident = 15;
         {
             Prof p(ix, "k_pa_chain", TP * 32);
-            launch_pa_chain(ix->st, a.B0.p, a.pa_off.p, nt, ix->host.k, o2, a.subs.p, a.marks.p, a.msi.p, a.stack.p,
+            launch_pa_chain(S(ix), a.B0.p, a.pa_off.p, nt, ix->host.k, o2, a.subs.p, a.marks.p, a.msi.p, a.stack.p,
                             a.out.p, a.out_n.p, a.clr_n.p);
         }
         a.res_off.ensure((size_t)nt + 2);
         int64_t NR = scan_to_i64<int32_t, CastI32>(ix, a.out_n.p, nt, a.res_off.p);
         if (NR > 0) {
             a.out_compact.ensure((size_t)NR);
-            launch_gather_chain2(ix->st, a.out.p, a.pa_off.p, a.out_n.p, a.res_off.p, nt, a.out_compact.p);
+            launch_gather_chain2(S(ix), a.out.p, a.pa_off.p, a.out_n.p, a.res_off.p, nt, a.out_compact.p);
             d2h(ix, res_h, a.out_compact.p, (size_t)NR);
         }
         d2h(ix, res_off_h, a.res_off.p, (size_t)nt + 1);
@@ -1200,12 +1234,12 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
         a.ops_pool.ensure((size_t)ops_tot + 16);
         a.wfa_todo.ensure((size_t)n);
         a.wfa_queue.ensure(1);
-        HIPCHK(hipMemcpyAsync(a.wfa_in.p, in.data(), sizeof(WfaIn) * n, hipMemcpyHostToDevice, ix->st));
+        HIPCHK(hipMemcpyAsync(a.wfa_in.p, in.data(), sizeof(WfaIn) * n, hipMemcpyHostToDevice, S(ix)));
         auto persistent_pass = [&](const std::vector<int32_t> &items, std::vector<int32_t> &too_wide) {
             const int64_t m = (int64_t)items.size();
             int nblocks = (int)std::min<int64_t>(m, wfa_resident_blocks(ix->device, seq_words));
             // private scratch per resident wave: never more than the worst case of the longest problem
-            int64_t cells = ((int64_t)40 << 30) / nblocks * 10 / 46 / 4;
+            int64_t cells = a.wfa_budget / nblocks * 10 / 46 / 4;
             cells = std::min<int64_t>(cells, std::min<int64_t>(3 * 128 * (smax + 1), 2000000000));
             cells = std::max<int64_t>(cells, 4096);
             int64_t rows = std::min<int64_t>(std::max<int64_t>(cells / 64, 256), smax + 1);
@@ -1215,11 +1249,11 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
                         (long long)rows, seq_words);
             a.hdr_pool.ensure((size_t)(rows * 9) * nblocks + 16);
             a.arena_pool.ensure((size_t)cells * nblocks + 16);
-            HIPCHK(hipMemcpyAsync(a.wfa_todo.p, items.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice, ix->st));
-            HIPCHK(hipMemsetAsync(a.wfa_queue.p, 0, sizeof(unsigned int), ix->st));
+            HIPCHK(hipMemcpyAsync(a.wfa_todo.p, items.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice, S(ix)));
+            HIPCHK(hipMemsetAsync(a.wfa_queue.p, 0, sizeof(unsigned int), S(ix)));
             {
                 Prof p(ix, "k_wfa_lean", wfa_bytes(in, items));
-                launch_wfa(ix->st, a.wfa_in.p, n, a.wfa_todo.p, m, nblocks, a.hdr_pool.p, rows * 9, a.arena_pool.p,
+                launch_wfa(S(ix), a.wfa_in.p, n, a.wfa_todo.p, m, nblocks, a.hdr_pool.p, rows * 9, a.arena_pool.p,
                            cells, a.ops_pool.p, a.wfa_queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p);
             }
             std::vector<WfaOut> tmp;
@@ -1289,7 +1323,7 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
         a.ops_pool.ensure((size_t)ops_tot + 16);
         a.wfa_in.ensure((size_t)n);
         a.wfa_todo.ensure(cur.size());
-        HIPCHK(hipMemcpyAsync(a.wfa_in.p, in.data(), sizeof(WfaIn) * n, hipMemcpyHostToDevice, ix->st));
+        HIPCHK(hipMemcpyAsync(a.wfa_in.p, in.data(), sizeof(WfaIn) * n, hipMemcpyHostToDevice, S(ix)));
         {
             // pass 1: LDS-ring kernel; pass 2 (rare): wavefronts wider than the ring, same scratch, global-memory ring
             std::vector<int32_t> narrow, wide;
@@ -1297,9 +1331,9 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
             if (!narrow.empty()) throw HipError("internal: narrow WFA problem in the fallback pass");
             if (!wide.empty()) {
                 a.wfa_todo2.ensure(wide.size());
-                HIPCHK(hipMemcpyAsync(a.wfa_todo2.p, wide.data(), sizeof(int32_t) * wide.size(), hipMemcpyHostToDevice, ix->st));
+                HIPCHK(hipMemcpyAsync(a.wfa_todo2.p, wide.data(), sizeof(int32_t) * wide.size(), hipMemcpyHostToDevice, S(ix)));
                 Prof p(ix, "k_wfa_wide", wfa_bytes(in, wide));
-                launch_wfa_wide(ix->st, a.wfa_in.p, n, a.wfa_todo2.p, (int64_t)wide.size(), a.hdr_pool.p, a.arena_pool.p,
+                launch_wfa_wide(S(ix), a.wfa_in.p, n, a.wfa_todo2.p, (int64_t)wide.size(), a.hdr_pool.p, a.arena_pool.p,
                                 a.ops_pool.p, a.wfa_out.p);
             }
         }
@@ -1410,9 +1444,12 @@ static Work &get_work(lm_index *ix, lm_qbatch *qb) {
     ix->work->rebind(qb);
     return *ix->work;
 }
-static AlignCtx &get_actx(lm_index *ix, lm_qbatch *qb, Work *w, lm_stage_stats *st) {
-    if (!ix->actx) ix->actx = new AlignCtx();
-    AlignCtx &a = *ix->actx;
+static AlignCtx &get_actx(lm_index *ix, lm_qbatch *qb, Work *w, lm_stage_stats *st, int slot = 0) {
+    if (!ix->actx[slot]) {
+        ix->actx[slot] = new AlignCtx();
+        HIPCHK(hipStreamCreate(&ix->actx[slot]->st));
+    }
+    AlignCtx &a = *ix->actx[slot];
     a.ix = ix;
     a.qb = qb;
     a.w = w;
@@ -1420,141 +1457,37 @@ static AlignCtx &get_actx(lm_index *ix, lm_qbatch *qb, Work *w, lm_stage_stats *
     return a;
 }
 
-static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
-    std::lock_guard<std::mutex> lock(ix->mu);
-    tune_malloc_once();
-    lm_stage_stats &st = res->stats;
-    memset(&st, 0, sizeof st);
-    HIPCHK(hipSetDevice(ix->device));
-    double t0 = now_ms(), t1;
-    st.query_bases = qb->total_len;
-    st.query_kmers = 2 * qb->total_pos;
-    Work &w = get_work(ix, qb);
-    double tm1 = now_ms();
-    stage_kmers(w);
-    double tm2 = now_ms();
-    stage_mask(w);
-    double tm3 = now_ms();
-    sync(ix);
-    t1 = now_ms();
-    if (getenv("LM_DEBUG"))
-        fprintf(stderr, "[lm] mask stage: get_work %.2f, kmers(launch) %.2f, mask(launch) %.2f, sync %.2f ms\n", tm1 - t0,
-                tm2 - tm1, tm3 - tm2, t1 - tm3);
-    st.ms_mask = t1 - t0;
-    t0 = t1;
-    stage_lookup(w, st);
-    t1 = now_ms();
-    st.ms_lookup = t1 - t0;
-    t0 = t1;
-    if (w.nseg == 0) {
-        st.ms_total = st.ms_mask + st.ms_lookup;
-        return;
-    }
-    stage_chain1(w);
-    int nseg = w.nseg;
-    // ---- top-N genomes per query (lib-index-search.go:1781-1805), host selection on (score desc, genome asc)
-    std::vector<uint64_t> segA_h;
-    std::vector<float> score_h;
-    {   // anchors surviving ClearSubstrPairs, summed on the device (statistics only)
-        unsigned long long hv = 0;
-        HIPCHK(hipMemsetAsync(w.stat.p + 1, 0, sizeof(unsigned long long), ix->st));
-        launch_sum_i32(ix->st, w.seg_n.p, nseg, w.stat.p + 1);
-        HIPCHK(hipMemcpyAsync(&hv, w.stat.p + 1, sizeof hv, hipMemcpyDeviceToHost, ix->st));
-        if (ix->opt.top_n_genomes > 0) { // only the top-N selection needs the per-pair scores on the host
-            d2h(ix, segA_h, w.segA.p, (size_t)nseg);
-            d2h(ix, score_h, w.seg_score.p, (size_t)nseg);
-        }
-        sync(ix);
-        st.anchors_cleared += (int64_t)hv;
-    }
-    const float min_score = chain_opt(ix).min_score;
-    const uint8_t *keep_d = nullptr;
-    if (ix->opt.top_n_genomes > 0) {
-        std::vector<uint8_t> keep(nseg, 0);
-        int s = 0;
-        while (s < nseg) {
-            int e = s;
-            uint64_t q = segA_h[s] >> 34;
-            while (e < nseg && (segA_h[e] >> 34) == q) e++;
-            std::vector<int> cand;
-            for (int i = s; i < e; i++)
-                if (score_h[i] >= min_score) cand.push_back(i);
-            std::stable_sort(cand.begin(), cand.end(), [&](int x, int y) { return score_h[x] > score_h[y]; });
-            for (size_t i = 0; i < cand.size() && (int)i < ix->opt.top_n_genomes; i++) keep[cand[i]] = 1;
-            s = e;
-        }
-        w.keep.ensure(nseg);
-        HIPCHK(hipMemcpyAsync(w.keep.p, keep.data(), nseg, hipMemcpyHostToDevice, ix->st));
-        keep_d = w.keep.p;
-    }
-    w.ntask.ensure((size_t)nseg + 1);
-    w.task_off.ensure((size_t)nseg + 2);
-    HIPCHK(hipMemsetAsync(w.ntask.p + nseg, 0, sizeof(int32_t), ix->st));
-    launch_task_count(ix->st, w.seg_score.p, w.seg_nch.p, keep_d, nseg, min_score, w.ntask.p);
-    int64_t NT = scan_to_i64<int32_t, CastI32>(ix, w.ntask.p, nseg, w.task_off.p);
-    st.chains += NT;
-    t1 = now_ms();
-    st.ms_chain = t1 - t0;
-    t0 = t1;
-    if (NT == 0) {
-        st.ms_total = st.ms_mask + st.ms_lookup + st.ms_chain;
-        return;
-    }
-    w.tasks.ensure((size_t)NT);
-    launch_make_tasks(ix->st, ix->view, w.segA.p, w.seg_off.p, nseg, w.subs.p, w.chain_off_pool.p, w.chain_idx_pool.p,
-                      w.ntask.p, w.task_off.p, qb->d_qoff.p, ix->opt.ext_len, w.order_scratch.p, w.tasks.p);
-    {   // window offsets of all tasks laid end to end (what a single alignment chunk uses as is)
-        w.task_wlen.ensure((size_t)NT + 1);
-        w.task_woff.ensure((size_t)NT + 2);
-        HIPCHK(hipMemsetAsync(w.task_wlen.p + NT, 0, sizeof(int32_t), ix->st));
-        launch_task_wlen(ix->st, w.tasks.p, NT, w.task_wlen.p);
-        (void)scan_to_i64<int32_t, CastI32>(ix, w.task_wlen.p, NT, w.task_woff.p);
-        launch_task_set_woff(ix->st, w.tasks.p, NT, w.task_woff.p);
-    }
-    std::vector<Task> tasks_h;
-    d2h(ix, tasks_h, w.tasks.p, (size_t)NT);
-    sync(ix);
-    t1 = now_ms();
-    st.ms_window = t1 - t0;
-    t0 = t1;
-
-    // ---- alignment in chunks of whole segments ----
-    AlignCtx &a = get_actx(ix, qb, &w, &st);
+// The alignment half for tasks [r0, r1) of the batch (whole (query, genome) segments): pseudo-alignment -> glue ->
+// extendMatch -> WFA -> per-genome finalisation, in chunks bounded by the window budget. Appends to `genomes` in task
+// order. Runs on the calling thread's stream (tls_stream) with the private scratch of `a`.
+static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskSpan tasks_h, int64_t r0, int64_t r1,
+                        lm_stage_stats &st, std::vector<HGenome> &genomes, lm_result *res, std::mutex &strings_mu) {
     int64_t max_window_bytes = (int64_t)2 << 30;
     if (const char *e = getenv("LM_DEBUG_MAX_WINDOW_BYTES")) max_window_bytes = std::max<int64_t>(1, atoll(e)); // test hook
-    std::vector<HGenome> genomes; // in (query, genome) order
-    const int K = ix->host.k;
     const bool want_seq = ix->opt.output_seq != 0;
-    int64_t tpos = 0;
-    while (tpos < NT) {
+    int64_t tpos = r0;
+    while (tpos < r1) {
         // chunk [tpos, tend): whole segments, bounded window bytes
         int64_t tend = tpos, wb = 0;
-        while (tend < NT) {
+        while (tend < r1) {
             int64_t e = tend;
             uint32_t seg = tasks_h[tend].seg;
             int64_t segw = 0;
-            while (e < NT && tasks_h[e].seg == seg) segw += tasks_h[e++].wlen;
+            while (e < r1 && tasks_h[e].seg == seg) segw += tasks_h[e++].wlen;
             if (tend > tpos && wb + segw > max_window_bytes) break;
             wb += segw;
             tend = e;
         }
-        const bool whole = tpos == 0 && tend == NT; // one chunk: host and device task lists are used in place
-        std::vector<Task> ht_chunk;
-        int64_t off = 0;
-        if (whole) {
-            off = tasks_h.back().woff + tasks_h.back().wlen;
-        } else {
-            ht_chunk.assign(tasks_h.begin() + tpos, tasks_h.begin() + tend);
-            for (auto &t : ht_chunk) {
-                t.woff = off;
-                off += t.wlen;
-            }
-        }
-        const std::vector<Task> &ht = whole ? tasks_h : ht_chunk;
+        // host and device task lists are used in place: window offsets are global, this chunk's slice starts at `base`
+        TaskSpan ht;
+        ht.p = tasks_h.p + tpos;
+        ht.n = (size_t)(tend - tpos);
+        const int64_t base = ht[0].woff;
+        const int64_t off = ht.back().woff + ht.back().wlen - base; // window bytes of the chunk
         std::vector<int64_t> res_off;
         std::vector<LmChain2> resv;
         double ta = now_ms();
-        run_pseudo(a, ht, res_off, resv, whole ? w.tasks.p : nullptr);
+        run_pseudo(a, ht, res_off, resv, w.tasks.p + tpos, base);
         double tb = now_ms();
         st.ms_pseudo += tb - ta;
         // glue per segment with results (parallel; the order of `genomes` stays the segment order)
@@ -1680,15 +1613,15 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
             a.hsp_ext.ensure((size_t)NH);
             a.ext_cap.ensure((size_t)NH + 1);
             a.ext_off.ensure((size_t)NH + 2);
-            HIPCHK(hipMemcpyAsync(a.hsp_in.p, hin.data(), sizeof(HspIn) * NH, hipMemcpyHostToDevice, ix->st));
-            HIPCHK(hipMemsetAsync(a.ext_cap.p + NH, 0, sizeof(int32_t), ix->st));
-            launch_extend_count(ix->st, a.hsp_in.p, NH, qb->d_seq.p, qb->d_qoff.p, a.wbuf.p, a.ext_cap.p);
+            HIPCHK(hipMemcpyAsync(a.hsp_in.p, hin.data(), sizeof(HspIn) * NH, hipMemcpyHostToDevice, S(ix)));
+            HIPCHK(hipMemsetAsync(a.ext_cap.p + NH, 0, sizeof(int32_t), S(ix)));
+            launch_extend_count(S(ix), a.hsp_in.p, NH, qb->d_seq.p, qb->d_qoff.p, a.wb, a.ext_cap.p);
             // scratch rows per wavefront of k_extend (32 HSPs = 64 flanks each), transposed layout
             const int64_t NW = (2 * NH + 63) / 64;
             a.ext_wcap.ensure((size_t)NW + 1);
             a.ext_off.ensure((size_t)NW + 2);
-            HIPCHK(hipMemsetAsync(a.ext_wcap.p + NW, 0, sizeof(int32_t), ix->st));
-            launch_extend_wave_cap(ix->st, a.ext_cap.p, NH, a.ext_wcap.p, NW);
+            HIPCHK(hipMemsetAsync(a.ext_wcap.p + NW, 0, sizeof(int32_t), S(ix)));
+            launch_extend_wave_cap(S(ix), a.ext_cap.p, NH, a.ext_wcap.p, NW);
             int64_t ER = scan_to_i64<int32_t, CastI32>(ix, a.ext_wcap.p, NW, a.ext_off.p);
             a.ext_rows.ensure((size_t)extend_grid_blocks(NH) * LM_EXT_ROWS * 64 * 2);
             a.ext_rstart.ensure((size_t)extend_grid_blocks(NH) * LM_EXT_ROWS * 64);
@@ -1696,7 +1629,7 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
             a.ext_msi.ensure(64 * (size_t)ER + 64);
             {
                 Prof p(ix, "k_extend");
-                launch_extend(ix->st, a.hsp_in.p, NH, qb->d_seq.p, qb->d_qoff.p, a.wbuf.p, a.ext_cap.p, a.ext_off.p,
+                launch_extend(S(ix), a.hsp_in.p, NH, qb->d_seq.p, qb->d_qoff.p, a.wb, a.ext_cap.p, a.ext_off.p,
                               a.ext_subs.p, a.ext_msi.p, a.ext_rows.p, a.ext_rstart.p, a.hsp_ext.p);
             }
             std::vector<HspExt> hext;
@@ -1706,7 +1639,7 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
             for (int64_t i = 0; i < NH; i++) {
                 hsps[i].ext = hext[i];
                 win[i].q = qb->d_seq.p + qb->h_qoff[hsps[i].q] + hext[i].qs;
-                win[i].t = a.wbuf.p + hsps[i].in.woff + hext[i].ts;
+                win[i].t = a.wb + hsps[i].in.woff + hext[i].ts;
                 win[i].qlen = hext[i].qe - hext[i].qs;
                 win[i].tlen = hext[i].te - hext[i].ts;
             }
@@ -1721,7 +1654,6 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
         double td = now_ms();
         st.ms_extend_wfa += td - tc;
         // ---- finalisation of this chunk's genomes (:2266-2357 / :2533-2626, then :2684-2749) ----
-        std::mutex strings_mu;
         parallel_for((int64_t)(genomes.size() - g0), 128, [&](int64_t gb0, int64_t gb1) {
         for (size_t gi = g0 + (size_t)gb0; gi < g0 + (size_t)gb1; gi++) {
             HGenome &gen = genomes[gi];
@@ -1784,7 +1716,7 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
                         c.tseq = new std::string();
                         c.align = new std::string();
                         fmt_alignment(ops, qb->h_seq.data() + qb->h_qoff[h.q] + h.ext.qs,
-                                      wbuf_h.data() + h.in.woff + h.ext.ts, c.qseq, c.align, c.tseq);
+                                      wbuf_h.data() + (h.in.woff - base) + h.ext.ts, c.qseq, c.align, c.tseq);
                         std::lock_guard<std::mutex> sl(strings_mu);
                         res->strings.push_back(c.cigar);
                         res->strings.push_back(c.qseq);
@@ -1826,8 +1758,184 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
         tpos = tend;
         janitor().dispose(std::move(hsps));
         janitor().dispose(std::move(resv));
-        janitor().dispose(std::move(ht_chunk));
         janitor().dispose(std::move(wout));
+    }
+}
+
+static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
+    std::lock_guard<std::mutex> lock(ix->mu);
+    tune_malloc_once();
+    lm_stage_stats &st = res->stats;
+    memset(&st, 0, sizeof st);
+    HIPCHK(hipSetDevice(ix->device));
+    double t0 = now_ms(), t1;
+    st.query_bases = qb->total_len;
+    st.query_kmers = 2 * qb->total_pos;
+    Work &w = get_work(ix, qb);
+    double tm1 = now_ms();
+    stage_kmers(w);
+    double tm2 = now_ms();
+    stage_mask(w);
+    double tm3 = now_ms();
+    sync(ix);
+    t1 = now_ms();
+    if (getenv("LM_DEBUG"))
+        fprintf(stderr, "[lm] mask stage: get_work %.2f, kmers(launch) %.2f, mask(launch) %.2f, sync %.2f ms\n", tm1 - t0,
+                tm2 - tm1, tm3 - tm2, t1 - tm3);
+    st.ms_mask = t1 - t0;
+    t0 = t1;
+    stage_lookup(w, st);
+    t1 = now_ms();
+    st.ms_lookup = t1 - t0;
+    t0 = t1;
+    if (w.nseg == 0) {
+        st.ms_total = st.ms_mask + st.ms_lookup;
+        return;
+    }
+    stage_chain1(w);
+    int nseg = w.nseg;
+    // ---- top-N genomes per query (lib-index-search.go:1781-1805), host selection on (score desc, genome asc)
+    std::vector<uint64_t> segA_h;
+    std::vector<float> score_h;
+    {   // anchors surviving ClearSubstrPairs, summed on the device (statistics only)
+        unsigned long long hv = 0;
+        HIPCHK(hipMemsetAsync(w.stat.p + 1, 0, sizeof(unsigned long long), S(ix)));
+        launch_sum_i32(S(ix), w.seg_n.p, nseg, w.stat.p + 1);
+        HIPCHK(hipMemcpyAsync(&hv, w.stat.p + 1, sizeof hv, hipMemcpyDeviceToHost, S(ix)));
+        if (ix->opt.top_n_genomes > 0) { // only the top-N selection needs the per-pair scores on the host
+            d2h(ix, segA_h, w.segA.p, (size_t)nseg);
+            d2h(ix, score_h, w.seg_score.p, (size_t)nseg);
+        }
+        sync(ix);
+        st.anchors_cleared += (int64_t)hv;
+    }
+    const float min_score = chain_opt(ix).min_score;
+    const uint8_t *keep_d = nullptr;
+    if (ix->opt.top_n_genomes > 0) {
+        std::vector<uint8_t> keep(nseg, 0);
+        int s = 0;
+        while (s < nseg) {
+            int e = s;
+            uint64_t q = segA_h[s] >> 34;
+            while (e < nseg && (segA_h[e] >> 34) == q) e++;
+            std::vector<int> cand;
+            for (int i = s; i < e; i++)
+                if (score_h[i] >= min_score) cand.push_back(i);
+            std::stable_sort(cand.begin(), cand.end(), [&](int x, int y) { return score_h[x] > score_h[y]; });
+            for (size_t i = 0; i < cand.size() && (int)i < ix->opt.top_n_genomes; i++) keep[cand[i]] = 1;
+            s = e;
+        }
+        w.keep.ensure(nseg);
+        HIPCHK(hipMemcpyAsync(w.keep.p, keep.data(), nseg, hipMemcpyHostToDevice, S(ix)));
+        keep_d = w.keep.p;
+    }
+    w.ntask.ensure((size_t)nseg + 1);
+    w.task_off.ensure((size_t)nseg + 2);
+    HIPCHK(hipMemsetAsync(w.ntask.p + nseg, 0, sizeof(int32_t), S(ix)));
+    launch_task_count(S(ix), w.seg_score.p, w.seg_nch.p, keep_d, nseg, min_score, w.ntask.p);
+    int64_t NT = scan_to_i64<int32_t, CastI32>(ix, w.ntask.p, nseg, w.task_off.p);
+    st.chains += NT;
+    t1 = now_ms();
+    st.ms_chain = t1 - t0;
+    t0 = t1;
+    if (NT == 0) {
+        st.ms_total = st.ms_mask + st.ms_lookup + st.ms_chain;
+        return;
+    }
+    w.tasks.ensure((size_t)NT);
+    launch_make_tasks(S(ix), ix->view, w.segA.p, w.seg_off.p, nseg, w.subs.p, w.chain_off_pool.p, w.chain_idx_pool.p,
+                      w.ntask.p, w.task_off.p, qb->d_qoff.p, ix->opt.ext_len, w.order_scratch.p, w.tasks.p);
+    {   // window offsets of all tasks laid end to end (what a single alignment chunk uses as is)
+        w.task_wlen.ensure((size_t)NT + 1);
+        w.task_woff.ensure((size_t)NT + 2);
+        HIPCHK(hipMemsetAsync(w.task_wlen.p + NT, 0, sizeof(int32_t), S(ix)));
+        launch_task_wlen(S(ix), w.tasks.p, NT, w.task_wlen.p);
+        (void)scan_to_i64<int32_t, CastI32>(ix, w.task_wlen.p, NT, w.task_woff.p);
+        launch_task_set_woff(S(ix), w.tasks.p, NT, w.task_woff.p);
+    }
+    std::vector<Task> tasks_h;
+    d2h(ix, tasks_h, w.tasks.p, (size_t)NT);
+    sync(ix);
+    t1 = now_ms();
+    st.ms_window = t1 - t0;
+    t0 = t1;
+
+    // ---- alignment: two workers, each on its own stream, so one worker's host-side glue / finalisation overlaps the other's
+    // kernels. The split is at a (query, genome) segment boundary near half of the window bytes.
+    std::vector<HGenome> genomes; // in (query, genome) order
+    {
+        TaskSpan th;
+        th.p = tasks_h.data();
+        th.n = (size_t)NT;
+        const int64_t Wtot = tasks_h.back().woff + tasks_h.back().wlen;
+        int64_t mid = NT;
+        const bool big = NT >= 4096 && Wtot >= ((int64_t)8 << 20);
+        if ((big || getenv("LM_DEBUG_FORCE_SPLIT")) && NT >= 2 && !getenv("LM_SINGLE_STREAM")) { // 2nd: test hook
+            int64_t lo = 0, hi = NT; // first task whose window starts past the middle ...
+            while (lo < hi) {
+                int64_t m = (lo + hi) >> 1;
+                if (tasks_h[m].woff < Wtot / 2)
+                    lo = m + 1;
+                else
+                    hi = m;
+            }
+            mid = lo;
+            while (mid < NT && mid > 0 && tasks_h[mid].seg == tasks_h[mid - 1].seg) mid++; // ... moved to a segment start
+        }
+        std::mutex strings_mu;
+        if (mid <= 0 || mid >= NT) {
+            AlignCtx &a = get_actx(ix, qb, &w, &st, 0);
+            a.wfa_budget = (int64_t)40 << 30;
+            tls_stream = a.st;
+            tls_tmp = &a.tmp;
+            HIPCHK(hipStreamSynchronize(ix->st)); // the workers' streams start after everything queued so far
+            try {
+                align_range(ix, qb, w, a, th, 0, NT, st, genomes, res, strings_mu);
+            } catch (...) {
+                tls_stream = nullptr;
+                tls_tmp = nullptr;
+                throw;
+            }
+            tls_stream = nullptr;
+            tls_tmp = nullptr;
+        } else {
+            HIPCHK(hipStreamSynchronize(ix->st));
+            lm_stage_stats st2[2];
+            memset(st2, 0, sizeof st2);
+            std::vector<HGenome> gen2[2];
+            std::exception_ptr err[2];
+            AlignCtx *ac[2] = {&get_actx(ix, qb, &w, &st2[0], 0), &get_actx(ix, qb, &w, &st2[1], 1)};
+            auto worker = [&](int k) {
+                try {
+                    HIPCHK(hipSetDevice(ix->device));
+                    ac[k]->wfa_budget = (int64_t)20 << 30;
+                    tls_stream = ac[k]->st;
+                    tls_tmp = &ac[k]->tmp;
+                    align_range(ix, qb, w, *ac[k], th, k == 0 ? 0 : mid, k == 0 ? mid : NT, st2[k], gen2[k], res, strings_mu);
+                } catch (...) {
+                    err[k] = std::current_exception();
+                }
+                tls_stream = nullptr;
+                tls_tmp = nullptr;
+            };
+            std::thread t1w(worker, 1);
+            worker(0);
+            t1w.join();
+            for (int k = 0; k < 2; k++)
+                if (err[k]) std::rethrow_exception(err[k]);
+            genomes = std::move(gen2[0]);
+            genomes.reserve(genomes.size() + gen2[1].size());
+            for (auto &g : gen2[1]) genomes.push_back(std::move(g));
+            // counters add up; the two workers ran side by side, so stage times are averaged
+            st.window_bases += st2[0].window_bases + st2[1].window_bases;
+            st.pa_anchors += st2[0].pa_anchors + st2[1].pa_anchors;
+            st.hsps_aligned += st2[0].hsps_aligned + st2[1].hsps_aligned;
+            st.wfa_retries += st2[0].wfa_retries + st2[1].wfa_retries;
+            st.ms_pseudo += 0.5 * (st2[0].ms_pseudo + st2[1].ms_pseudo);
+            st.ms_glue += 0.5 * (st2[0].ms_glue + st2[1].ms_glue);
+            st.ms_extend_wfa += 0.5 * (st2[0].ms_extend_wfa + st2[1].ms_extend_wfa);
+            st.ms_finalize += 0.5 * (st2[0].ms_finalize + st2[1].ms_finalize);
+        }
     }
     // ---- per query: sort genomes by best cluster (:2919-2921, ties by genome key), regroup by sseqid, emit rows ----
     double te0 = now_ms();
@@ -2143,10 +2251,13 @@ lm_status lm_pseudoalign_batch(lm_index *ix, const lm_query *queries, size_t nq,
         for (size_t i = 0; i < nproblems; i++)
             if (targets[i].len) memcpy(&wb[(size_t)ht[i].woff], targets[i].seq, targets[i].len);
         a.wbuf.ensure(wb.size());
-        HIPCHK(hipMemcpyAsync(a.wbuf.p, wb.data(), wb.size(), hipMemcpyHostToDevice, ix->st));
+        HIPCHK(hipMemcpyAsync(a.wbuf.p, wb.data(), wb.size(), hipMemcpyHostToDevice, S(ix)));
         std::vector<int64_t> ro;
         std::vector<LmChain2> rv;
-        run_pseudo(a, ht, ro, rv);
+        TaskSpan sp;
+        sp.p = ht.data();
+        sp.n = ht.size();
+        run_pseudo(a, sp, ro, rv);
         sg->i64a = ro;
         sg->chains2.resize(rv.size());
         for (size_t i = 0; i < rv.size(); i++)
@@ -2189,7 +2300,7 @@ lm_status lm_wfa_batch(lm_index *ix, const lm_query *q, const lm_query *t, size_
         }
         buf.resize(buf.size() + 64, 'A');
         a.wbuf.ensure(buf.size());
-        HIPCHK(hipMemcpyAsync(a.wbuf.p, buf.data(), buf.size(), hipMemcpyHostToDevice, ix->st));
+        HIPCHK(hipMemcpyAsync(a.wbuf.p, buf.data(), buf.size(), hipMemcpyHostToDevice, S(ix)));
         std::vector<WfaIn> win(n);
         for (size_t i = 0; i < n; i++) {
             win[i].q = a.wbuf.p + qo[i];
