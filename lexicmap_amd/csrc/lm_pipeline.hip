@@ -1461,9 +1461,22 @@ static AlignCtx &get_actx(lm_index *ix, lm_qbatch *qb, Work *w, lm_stage_stats *
 // extendMatch -> WFA -> per-genome finalisation, in chunks bounded by the window budget. Appends to `genomes` in task
 // order. Runs on the calling thread's stream (tls_stream) with the private scratch of `a`.
 static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskSpan tasks_h, int64_t r0, int64_t r1,
-                        lm_stage_stats &st, std::vector<HGenome> &genomes, lm_result *res, std::mutex &strings_mu) {
+                        lm_stage_stats &st, std::vector<HGenome> &genomes, lm_result *res, std::mutex &strings_mu,
+                        std::mutex *gpu_mu = nullptr, int64_t chunk_bytes = 0) {
+    // gpu_mu: with two workers the kernel phases take turns on the GPU (they would only slow each other down) while the
+    // host phases (glue, finalisation) of one worker run during the kernel phase of the other
     int64_t max_window_bytes = (int64_t)2 << 30;
+    if (chunk_bytes > 0) max_window_bytes = std::min(max_window_bytes, chunk_bytes);
     if (const char *e = getenv("LM_DEBUG_MAX_WINDOW_BYTES")) max_window_bytes = std::max<int64_t>(1, atoll(e)); // test hook
+    struct GpuTurn {
+        std::mutex *m;
+        explicit GpuTurn(std::mutex *mm) : m(mm) {
+            if (m) m->lock();
+        }
+        ~GpuTurn() {
+            if (m) m->unlock();
+        }
+    };
     const bool want_seq = ix->opt.output_seq != 0;
     int64_t tpos = r0;
     while (tpos < r1) {
@@ -1487,7 +1500,11 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
         std::vector<int64_t> res_off;
         std::vector<LmChain2> resv;
         double ta = now_ms();
-        run_pseudo(a, ht, res_off, resv, w.tasks.p + tpos, base);
+        {
+            GpuTurn turn(gpu_mu);
+            ta = now_ms();
+            run_pseudo(a, ht, res_off, resv, w.tasks.p + tpos, base);
+        }
         double tb = now_ms();
         st.ms_pseudo += tb - ta;
         // glue per segment with results (parallel; the order of `genomes` stays the segment order)
@@ -1605,6 +1622,8 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
         std::vector<WfaOut> wout;
         std::vector<uint64_t> ops_h;
         std::vector<int64_t> ops_off_h;
+        std::unique_ptr<GpuTurn> turn2(new GpuTurn(gpu_mu)); // released after the WFA results are back
+        tc = now_ms();
         std::vector<uint8_t> wbuf_h;
         if (NH > 0) {
             std::vector<HspIn> hin(NH);
@@ -1651,6 +1670,7 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
                 sync(ix);
             }
         }
+        turn2.reset();
         double td = now_ms();
         st.ms_extend_wfa += td - tc;
         // ---- finalisation of this chunk's genomes (:2266-2357 / :2533-2626, then :2684-2749) ----
@@ -1905,13 +1925,15 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
             std::vector<HGenome> gen2[2];
             std::exception_ptr err[2];
             AlignCtx *ac[2] = {&get_actx(ix, qb, &w, &st2[0], 0), &get_actx(ix, qb, &w, &st2[1], 1)};
+            std::mutex gpu_mu;
             auto worker = [&](int k) {
                 try {
                     HIPCHK(hipSetDevice(ix->device));
                     ac[k]->wfa_budget = (int64_t)20 << 30;
                     tls_stream = ac[k]->st;
                     tls_tmp = &ac[k]->tmp;
-                    align_range(ix, qb, w, *ac[k], th, k == 0 ? 0 : mid, k == 0 ? mid : NT, st2[k], gen2[k], res, strings_mu);
+                    align_range(ix, qb, w, *ac[k], th, k == 0 ? 0 : mid, k == 0 ? mid : NT, st2[k], gen2[k], res, strings_mu,
+                                &gpu_mu, Wtot / 4 + (1 << 20));
                 } catch (...) {
                     err[k] = std::current_exception();
                 }
