@@ -39,9 +39,8 @@ thread_local std::string g_open_error;
 namespace lm {
 
 // ---- profiling: HIP events on the library's stream around each named launch ---------------------------------
-// The alignment half of a batch is split between two host threads (align_range), each with its own stream, rocPRIM
-// scratch and AlignCtx, so the host-side glue of one half overlaps the kernels of the other. Helpers take the stream
-// from here; outside those workers it is the handle's stream.
+// Helpers take the stream and the rocPRIM scratch from here: a host thread may install its own (thread-local) pair to
+// run part of a batch beside the handle's stream; by default it is the handle's.
 static thread_local hipStream_t tls_stream = nullptr;
 static thread_local DBuf<uint8_t> *tls_tmp = nullptr;
 static inline hipStream_t S(lm_index *ix) { return tls_stream ? tls_stream : ix->st; }
@@ -987,13 +986,9 @@ struct AlignCtx {
     lm_qbatch *qb;
     Work *w;
     lm_stage_stats *stats;
-    hipStream_t st = nullptr;  // this worker's stream
-    DBuf<uint8_t> tmp;         // this worker's rocPRIM temporary storage
     const uint8_t *wb = nullptr; // window buffer biased so that wb + task.woff addresses this chunk's windows
     int64_t wfa_budget = (int64_t)40 << 30;
-    ~AlignCtx() {
-        if (st) (void)hipStreamDestroy(st);
-    }
+
     // per chunk device buffers
     DBuf<int32_t> wlen;
     DBuf<int64_t> woff;
@@ -1445,10 +1440,7 @@ static Work &get_work(lm_index *ix, lm_qbatch *qb) {
     return *ix->work;
 }
 static AlignCtx &get_actx(lm_index *ix, lm_qbatch *qb, Work *w, lm_stage_stats *st, int slot = 0) {
-    if (!ix->actx[slot]) {
-        ix->actx[slot] = new AlignCtx();
-        HIPCHK(hipStreamCreate(&ix->actx[slot]->st));
-    }
+    if (!ix->actx[slot]) ix->actx[slot] = new AlignCtx();
     AlignCtx &a = *ix->actx[slot];
     a.ix = ix;
     a.qb = qb;
@@ -1461,22 +1453,9 @@ static AlignCtx &get_actx(lm_index *ix, lm_qbatch *qb, Work *w, lm_stage_stats *
 // extendMatch -> WFA -> per-genome finalisation, in chunks bounded by the window budget. Appends to `genomes` in task
 // order. Runs on the calling thread's stream (tls_stream) with the private scratch of `a`.
 static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskSpan tasks_h, int64_t r0, int64_t r1,
-                        lm_stage_stats &st, std::vector<HGenome> &genomes, lm_result *res, std::mutex &strings_mu,
-                        std::mutex *gpu_mu = nullptr, int64_t chunk_bytes = 0) {
-    // gpu_mu: with two workers the kernel phases take turns on the GPU (they would only slow each other down) while the
-    // host phases (glue, finalisation) of one worker run during the kernel phase of the other
+                        lm_stage_stats &st, std::vector<HGenome> &genomes, lm_result *res, std::mutex &strings_mu) {
     int64_t max_window_bytes = (int64_t)2 << 30;
-    if (chunk_bytes > 0) max_window_bytes = std::min(max_window_bytes, chunk_bytes);
     if (const char *e = getenv("LM_DEBUG_MAX_WINDOW_BYTES")) max_window_bytes = std::max<int64_t>(1, atoll(e)); // test hook
-    struct GpuTurn {
-        std::mutex *m;
-        explicit GpuTurn(std::mutex *mm) : m(mm) {
-            if (m) m->lock();
-        }
-        ~GpuTurn() {
-            if (m) m->unlock();
-        }
-    };
     const bool want_seq = ix->opt.output_seq != 0;
     int64_t tpos = r0;
     while (tpos < r1) {
@@ -1500,11 +1479,7 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
         std::vector<int64_t> res_off;
         std::vector<LmChain2> resv;
         double ta = now_ms();
-        {
-            GpuTurn turn(gpu_mu);
-            ta = now_ms();
-            run_pseudo(a, ht, res_off, resv, w.tasks.p + tpos, base);
-        }
+        run_pseudo(a, ht, res_off, resv, w.tasks.p + tpos, base);
         double tb = now_ms();
         st.ms_pseudo += tb - ta;
         // glue per segment with results (parallel; the order of `genomes` stays the segment order)
@@ -1622,8 +1597,6 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
         std::vector<WfaOut> wout;
         std::vector<uint64_t> ops_h;
         std::vector<int64_t> ops_off_h;
-        std::unique_ptr<GpuTurn> turn2(new GpuTurn(gpu_mu)); // released after the WFA results are back
-        tc = now_ms();
         std::vector<uint8_t> wbuf_h;
         if (NH > 0) {
             std::vector<HspIn> hin(NH);
@@ -1670,7 +1643,6 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
                 sync(ix);
             }
         }
-        turn2.reset();
         double td = now_ms();
         st.ms_extend_wfa += td - tc;
         // ---- finalisation of this chunk's genomes (:2266-2357 / :2533-2626, then :2684-2749) ----
@@ -1880,84 +1852,17 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
     st.ms_window = t1 - t0;
     t0 = t1;
 
-    // ---- alignment: two workers, each on its own stream, so one worker's host-side glue / finalisation overlaps the other's
-    // kernels. The split is at a (query, genome) segment boundary near half of the window bytes.
+    // ---- alignment half, in chunks of whole (query, genome) segments (align_range). Splitting it over two host
+    // threads / streams so that one half's host glue overlaps the other half's kernels was measured at C2 and gave
+    // nothing (the halves run in lock-step, and the kernels only slow each other down), so it runs on one stream.
     std::vector<HGenome> genomes; // in (query, genome) order
     {
         TaskSpan th;
         th.p = tasks_h.data();
         th.n = (size_t)NT;
-        const int64_t Wtot = tasks_h.back().woff + tasks_h.back().wlen;
-        int64_t mid = NT;
-        const bool big = NT >= 4096 && Wtot >= ((int64_t)8 << 20);
-        if ((big || getenv("LM_DEBUG_FORCE_SPLIT")) && NT >= 2 && !getenv("LM_SINGLE_STREAM")) { // 2nd: test hook
-            int64_t lo = 0, hi = NT; // first task whose window starts past the middle ...
-            while (lo < hi) {
-                int64_t m = (lo + hi) >> 1;
-                if (tasks_h[m].woff < Wtot / 2)
-                    lo = m + 1;
-                else
-                    hi = m;
-            }
-            mid = lo;
-            while (mid < NT && mid > 0 && tasks_h[mid].seg == tasks_h[mid - 1].seg) mid++; // ... moved to a segment start
-        }
         std::mutex strings_mu;
-        if (mid <= 0 || mid >= NT) {
-            AlignCtx &a = get_actx(ix, qb, &w, &st, 0);
-            a.wfa_budget = (int64_t)40 << 30;
-            tls_stream = a.st;
-            tls_tmp = &a.tmp;
-            HIPCHK(hipStreamSynchronize(ix->st)); // the workers' streams start after everything queued so far
-            try {
-                align_range(ix, qb, w, a, th, 0, NT, st, genomes, res, strings_mu);
-            } catch (...) {
-                tls_stream = nullptr;
-                tls_tmp = nullptr;
-                throw;
-            }
-            tls_stream = nullptr;
-            tls_tmp = nullptr;
-        } else {
-            HIPCHK(hipStreamSynchronize(ix->st));
-            lm_stage_stats st2[2];
-            memset(st2, 0, sizeof st2);
-            std::vector<HGenome> gen2[2];
-            std::exception_ptr err[2];
-            AlignCtx *ac[2] = {&get_actx(ix, qb, &w, &st2[0], 0), &get_actx(ix, qb, &w, &st2[1], 1)};
-            std::mutex gpu_mu;
-            auto worker = [&](int k) {
-                try {
-                    HIPCHK(hipSetDevice(ix->device));
-                    ac[k]->wfa_budget = (int64_t)20 << 30;
-                    tls_stream = ac[k]->st;
-                    tls_tmp = &ac[k]->tmp;
-                    align_range(ix, qb, w, *ac[k], th, k == 0 ? 0 : mid, k == 0 ? mid : NT, st2[k], gen2[k], res, strings_mu,
-                                &gpu_mu, Wtot / 4 + (1 << 20));
-                } catch (...) {
-                    err[k] = std::current_exception();
-                }
-                tls_stream = nullptr;
-                tls_tmp = nullptr;
-            };
-            std::thread t1w(worker, 1);
-            worker(0);
-            t1w.join();
-            for (int k = 0; k < 2; k++)
-                if (err[k]) std::rethrow_exception(err[k]);
-            genomes = std::move(gen2[0]);
-            genomes.reserve(genomes.size() + gen2[1].size());
-            for (auto &g : gen2[1]) genomes.push_back(std::move(g));
-            // counters add up; the two workers ran side by side, so stage times are averaged
-            st.window_bases += st2[0].window_bases + st2[1].window_bases;
-            st.pa_anchors += st2[0].pa_anchors + st2[1].pa_anchors;
-            st.hsps_aligned += st2[0].hsps_aligned + st2[1].hsps_aligned;
-            st.wfa_retries += st2[0].wfa_retries + st2[1].wfa_retries;
-            st.ms_pseudo += 0.5 * (st2[0].ms_pseudo + st2[1].ms_pseudo);
-            st.ms_glue += 0.5 * (st2[0].ms_glue + st2[1].ms_glue);
-            st.ms_extend_wfa += 0.5 * (st2[0].ms_extend_wfa + st2[1].ms_extend_wfa);
-            st.ms_finalize += 0.5 * (st2[0].ms_finalize + st2[1].ms_finalize);
-        }
+        AlignCtx &a = get_actx(ix, qb, &w, &st);
+        align_range(ix, qb, w, a, th, 0, NT, st, genomes, res, strings_mu);
     }
     // ---- per query: sort genomes by best cluster (:2919-2921, ties by genome key), regroup by sseqid, emit rows ----
     double te0 = now_ms();

@@ -285,20 +285,6 @@ def test_chunked_alignment_and_anchor_buffer_rerun_give_the_same_rows(both, quer
     for b, g in zip(base, got):
         assert b == g
     assert st0["rows"] == st1["rows"] and st0["pa_anchors"] == st1["pa_anchors"]
-    # the two-worker split of the alignment half (two streams, two host threads; used for large batches), alone and
-    # combined with chunking inside each worker
-    for extra in ({}, {"LM_DEBUG_MAX_WINDOW_BYTES": "30000"}):
-        monkeypatch.setenv("LM_DEBUG_FORCE_SPLIT", "1")
-        for k, v in extra.items():
-            monkeypatch.setenv(k, v)
-        got2, st2 = gi.search(seqs)
-        monkeypatch.delenv("LM_DEBUG_FORCE_SPLIT")
-        for k in extra:
-            monkeypatch.delenv(k)
-        assert len(base) == len(got2)
-        for b, g in zip(base, got2):
-            assert b == g
-        assert st0["rows"] == st2["rows"] and st0["pa_anchors"] == st2["pa_anchors"] and st0["hsps_aligned"] == st2["hsps_aligned"]
 
 
 def test_search_options_topn_and_all_columns(small_index, queries):
