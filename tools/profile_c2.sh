@@ -24,4 +24,4 @@ timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_f -o c2f
 python $R/tools/summarize_rocprof.py /tmp/prof_f $R/gpurun_out/r01_c2_pmc_fetch.json
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_w -o c2w -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /tmp/prof_w.log 2>&1
 python $R/tools/summarize_rocprof.py /tmp/prof_w $R/gpurun_out/r01_c2_pmc_write.json
-tail -2 /tmp/prof_f.log /tmp/prof_w.log
+tail -n 2 /tmp/prof_f.log; tail -n 2 /tmp/prof_w.log
