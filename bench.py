@@ -42,6 +42,8 @@ def parse():
     p.add_argument("--shard", default="queries", choices=["queries", "index"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
+    p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                   help="nccl = RCCL (one GPU per rank); gloo only to exercise the N>1 logic with ranks sharing a GPU")
     p.add_argument("--builder", default=None, choices=["gpu", "oracle"],
                    help="gpu: genomes+index generated in HBM (default for c2); oracle: CPU writer + on-disk format")
     p.add_argument("--cpu-sample-genomes", type=int, default=12)
@@ -151,10 +153,14 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and args.dist_backend == "nccl":
+        raise SystemExit("rank %d has no GPU of its own (%d visible)" % (rank, ndev))
+    local_rank = local_rank % ndev  # only differs with --dist-backend gloo (ranks sharing a GPU: a test of the N>1 logic)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     import lexicmap_amd as la
     from lexicmap_amd import synth
@@ -256,7 +262,7 @@ def main():
             if args.shard == "queries":
                 rows = rows.copy()  # the array is a view of the library's result
                 rows["query"] = rows["query"] * world + rank  # local -> global query number (round-robin sharding)
-            per_rank = merge.all_gather_rows(rows, device="cuda")
+            per_rank = merge.all_gather_rows(rows, device="cuda" if args.dist_backend == "nccl" else "cpu")
             rows = merge.merge_sharded(per_rank) if args.shard == "index" else merge.merge_query_sharded(per_rank)
         return rows, st
 
@@ -277,7 +283,7 @@ def main():
         dist.barrier()
     dt = time.time() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     prof = gi.profile_get()
