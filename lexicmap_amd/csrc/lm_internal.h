@@ -51,6 +51,27 @@ template <typename T> struct DBuf {
     }
 };
 
+// grow-only pinned host buffer: the destination of the big per-batch device-to-host copies (pageable targets go through
+// a staging copy at a fraction of the PCIe rate)
+template <typename T> struct PBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    PBuf() = default;
+    PBuf(const PBuf &) = delete;
+    PBuf &operator=(const PBuf &) = delete;
+    ~PBuf() {
+        if (p) (void)hipHostFree(p);
+    }
+    void ensure(size_t n) {
+        if (n <= cap && p) return;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        size_t want = std::max<size_t>(n + n / 8, 64);
+        HIPCHK(hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault));
+        cap = want;
+    }
+};
+
 static double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }

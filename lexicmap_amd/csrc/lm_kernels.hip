@@ -1835,20 +1835,24 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                     off[c] = LM_NULL_OFF;
                     fin.w[c] = 0;
                     if (!chunk_has(c, mlo[0], mhi[0])) continue;
-                    inr[c] = k >= mlo[0] && k <= mhi[0];
+                    inr[c] = (uint32_t)(k - mlo[0]) <= (uint32_t)(mhi[0] - mlo[0]);
                     int32_t o = rM[ms][slot];
-                    if (inr[c] && o >= 0) {
-                        int v = o - k, h = o;
-                        while (true) {
-                            int rem = plen - v < tlen - h ? plen - v : tlen - h;
-                            if (rem <= 0) break;
-                            uint32_t d = get16(Qp, v) ^ get16(Tp, h);
-                            int nm = d ? (__clz(d) >> 1) : 16;
-                            if (nm > rem) nm = rem;
-                            v += nm;
-                            h += nm;
-                            if (nm < 16) break;
-                        }
+                    const bool act = inr[c] && o >= 0;
+                    // extension as a wave-uniform loop (ballot) with per-lane predication by arithmetic: far less
+                    // exec-mask bookkeeping on the scalar unit than a per-lane while loop
+                    int v = act ? o - k : 0, h = act ? o : 0;
+                    bool ext = act;
+                    while (__ballot(ext) != 0ull) {
+                        int rem = plen - v < tlen - h ? plen - v : tlen - h;
+                        const uint32_t d = get16(Qp, v) ^ get16(Tp, h);
+                        int nm = d ? (__clz(d) >> 1) : 16;
+                        nm = nm < rem ? nm : rem;
+                        nm = (ext && nm > 0) ? nm : 0;
+                        v += nm;
+                        h += nm;
+                        ext = nm == 16;
+                    }
+                    if (act) {
                         o = h;
                         rM[ms][slot] = o;
                     }
@@ -2026,9 +2030,9 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
 #pragma unroll
             for (int c = 0; c < NC; c++) {
                 const int slot = lane + 64 * c, k = kk[c];
-                rM[ms][slot] = (k >= mlo[0] && k <= mhi[0]) ? vmx[c] : LM_NULL_OFF;
-                rI[is][slot] = (k >= ilo[0] && k <= ihi[0]) ? vins[c] : LM_NULL_OFF;
-                rD[is][slot] = (k >= dlo[0] && k <= dhi[0]) ? vdel[c] : LM_NULL_OFF;
+                rM[ms][slot] = (uint32_t)(k - mlo[0]) <= (uint32_t)(mhi[0] - mlo[0]) && mlo[0] <= mhi[0] ? vmx[c] : LM_NULL_OFF;
+                rI[is][slot] = (uint32_t)(k - ilo[0]) <= (uint32_t)(ihi[0] - ilo[0]) && ilo[0] <= ihi[0] ? vins[c] : LM_NULL_OFF;
+                rD[is][slot] = (uint32_t)(k - dlo[0]) <= (uint32_t)(dhi[0] - dlo[0]) && dlo[0] <= dhi[0] ? vdel[c] : LM_NULL_OFF;
             }
         }
         __syncthreads(); // the backtrace reads what every lane stored to global memory
@@ -2170,7 +2174,7 @@ void launch_extend(hipStream_t st, const HspIn *hsps, int64_t n, const uint8_t *
 }
 static int resident_blocks_of(const void *kern, int device, int seq_words) {
     int nb = 0, cus = 0;
-    size_t dyn = (size_t)(2 * (seq_words + 1)) * sizeof(uint32_t);
+    size_t dyn = (size_t)(2 * (seq_words + 1) + 2) * sizeof(uint32_t);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64, dyn) != hipSuccess || nb < 1) nb = 8;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
     return nb * cus;
@@ -2181,7 +2185,8 @@ int wfa_resident_blocks(int device, int seq_words) {
 void launch_wfa(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks,
                 int32_t *hdr_pool, int64_t hdr_stride, int32_t *arena_pool, int64_t arena_stride, uint64_t *ops_pool,
                 unsigned int *queue, int seq_words, int want_ops, WfaOut *out) {
-    size_t dyn = (size_t)(2 * (seq_words + 1)) * sizeof(uint32_t);
+    // two packed sequences with one padding word each, +2 words: the predicated extension may read one word past
+    size_t dyn = (size_t)(2 * (seq_words + 1) + 2) * sizeof(uint32_t);
     hipLaunchKernelGGL(k_wfa_lean<2>, dim3(nblocks), dim3(64), dyn, st, in, n, todo, ntodo, hdr_pool, hdr_stride, arena_pool,
                        arena_stride, ops_pool, queue, seq_words, want_ops, out);
 }

@@ -361,6 +361,7 @@ struct Work {
     DBuf<int64_t> task_off;
     DBuf<uint8_t> keep;
     DBuf<Task> tasks;
+    PBuf<Task> tasks_host;
     DBuf<int32_t> task_wlen;
     DBuf<int64_t> task_woff;
     int64_t ntasks = 0;
@@ -1845,8 +1846,9 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
         (void)scan_to_i64<int32_t, CastI32>(ix, w.task_wlen.p, NT, w.task_woff.p);
         launch_task_set_woff(S(ix), w.tasks.p, NT, w.task_woff.p);
     }
-    std::vector<Task> tasks_h;
-    d2h(ix, tasks_h, w.tasks.p, (size_t)NT);
+    w.tasks_host.ensure((size_t)NT);
+    Task *tasks_h = w.tasks_host.p; // pinned, reused across batches
+    HIPCHK(hipMemcpyAsync(tasks_h, w.tasks.p, sizeof(Task) * (size_t)NT, hipMemcpyDeviceToHost, S(ix)));
     sync(ix);
     t1 = now_ms();
     st.ms_window = t1 - t0;
@@ -1858,7 +1860,7 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
     std::vector<HGenome> genomes; // in (query, genome) order
     {
         TaskSpan th;
-        th.p = tasks_h.data();
+        th.p = tasks_h;
         th.n = (size_t)NT;
         std::mutex strings_mu;
         AlignCtx &a = get_actx(ix, qb, &w, &st);
@@ -1963,7 +1965,6 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
     st.ms_total = st.ms_mask + st.ms_lookup + st.ms_chain + st.ms_window + st.ms_pseudo + st.ms_glue + st.ms_extend_wfa +
                   st.ms_finalize;
     janitor().dispose(std::move(genomes));
-    janitor().dispose(std::move(tasks_h));
 }
 
 } // namespace lm
