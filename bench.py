@@ -288,6 +288,12 @@ def main():
         dt = float(tt.item())
     prof = gi.profile_get()
     gi.profile(False)
+    try:
+        import resource
+        log("[rank %d] peak host RSS %.1f GB after %d steps" % (rank, resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1048576.0,
+                                                             args.steps + args.warmup))
+    except Exception:
+        pass
     rows_total, aligned_total = int(len(rows_np)), int(rows_np["aligned_length"].sum())
 
     nq_total = len(queries)
