@@ -2,6 +2,8 @@
 #include "lm_format.h"
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -72,9 +74,10 @@ inline int gv2(uint8_t ctrl, const uint8_t *p, uint64_t &a, uint64_t &b) {
 } // namespace
 
 // Decodes one seeds chunk (kv-data.go:66-89 layout) and appends every (k-mer,value) whose genome passes `keep`.
-static std::string load_chunk(const std::string &path, HostIndex &idx, const std::vector<int64_t> &batch_first,
+// Chunk files cover disjoint mask ranges, so several can be decoded at the same time (km / vv are per mask).
+static std::string load_chunk(const std::string &path, const HostIndex &idx, const std::vector<int64_t> &batch_first,
                               std::vector<std::vector<uint64_t>> &km, std::vector<std::vector<uint64_t>> &vv,
-                              int &status) {
+                              int &status, int &anchor_prefix_out) {
     std::vector<uint8_t> buf;
     if (!read_all(path, buf)) {
         status = 1;
@@ -103,7 +106,7 @@ static std::string load_chunk(const std::string &path, HostIndex &idx, const std
             status = 2;
             return "lengths of mask prefix mismatch between info.toml and the seed data";
         }
-        idx.anchor_prefix = h[12]; // users might have run 'utils reindex-seeds' (lib-index-search.go:611)
+        anchor_prefix_out = h[12]; // users might have run 'utils reindex-seeds' (lib-index-search.go:611)
     }
     size_t p = 32;
     const size_t n = buf.size();
@@ -311,19 +314,53 @@ std::string load_index(const std::string &dir, int shard_rank, int shard_count, 
         return "seeds file not found in: " + dir + "/seeds";
     }
     std::vector<std::vector<uint64_t>> km(out.M), vv(out.M);
-    for (auto &f : files) {
-        std::string e = load_chunk(dir + "/seeds/" + f, out, out.batch_first, km, vv, status);
-        if (!e.empty()) return e;
+    // decode the chunk files in parallel (the reference reads them with one goroutine per file, kv-reader.go:762-1021)
+    const int nthreads = (int)std::max<size_t>(1, std::min<size_t>(files.size(), std::min(16u, std::max(1u, std::thread::hardware_concurrency()))));
+    std::vector<std::string> errs(files.size());
+    std::vector<int> stats(files.size(), 0), anchors(files.size(), -1);
+    {
+        std::atomic<size_t> next{0};
+        auto body = [&]() {
+            for (;;) {
+                size_t i = next.fetch_add(1);
+                if (i >= files.size()) break;
+                errs[i] = load_chunk(dir + "/seeds/" + files[i], out, out.batch_first, km, vv, stats[i], anchors[i]);
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nthreads; t++) th.emplace_back(body);
+        body();
+        for (auto &t : th) t.join();
+    }
+    for (size_t i = 0; i < files.size(); i++) {
+        if (!errs[i].empty()) {
+            status = stats[i];
+            return errs[i];
+        }
+        if (anchors[i] >= 0) out.anchor_prefix = anchors[i];
     }
     out.mask_off.assign(out.M + 1, 0);
     for (int i = 0; i < out.M; i++) out.mask_off[i + 1] = out.mask_off[i] + (int64_t)km[i].size();
     out.seed_kmers.resize((size_t)out.mask_off[out.M]);
     out.seed_vals.resize((size_t)out.mask_off[out.M]);
-    for (int i = 0; i < out.M; i++) {
-        std::copy(km[i].begin(), km[i].end(), out.seed_kmers.begin() + out.mask_off[i]);
-        std::copy(vv[i].begin(), vv[i].end(), out.seed_vals.begin() + out.mask_off[i]);
-        std::vector<uint64_t>().swap(km[i]);
-        std::vector<uint64_t>().swap(vv[i]);
+    {
+        std::atomic<int> next{0};
+        auto body = [&]() {
+            for (;;) {
+                int i0 = next.fetch_add(256);
+                if (i0 >= out.M) break;
+                for (int i = i0; i < std::min(out.M, i0 + 256); i++) {
+                    std::copy(km[i].begin(), km[i].end(), out.seed_kmers.begin() + out.mask_off[i]);
+                    std::copy(vv[i].begin(), vv[i].end(), out.seed_vals.begin() + out.mask_off[i]);
+                    std::vector<uint64_t>().swap(km[i]);
+                    std::vector<uint64_t>().swap(vv[i]);
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nthreads; t++) th.emplace_back(body);
+        body();
+        for (auto &t : th) t.join();
     }
     return "";
 }
