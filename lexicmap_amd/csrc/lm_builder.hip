@@ -618,6 +618,7 @@ lm_status lm_index_build_synthetic(const lm_synth_spec *spec, const lm_options *
         v.shard_rank = h.shard_rank;
         v.shard_count = h.shard_count;
         ix->hbm_bytes = (int64_t)(N * 16 + (uint64_t)(nlocal * sp.gbytes) + (uint64_t)M * 16 + pfx.size() * 4 + nlocal * 12);
+        lm_build_seed_top(ix);
     } catch (const std::exception &e) {
         g_open_error = e.what();
         delete ix;

@@ -90,6 +90,7 @@ using namespace lm;
 extern thread_local std::string g_open_error; // text of the last failed open/build (lm_last_error(NULL))
 struct lm_index;
 void lm_fill_gap_lut(lm_index *ix);
+void lm_build_seed_top(lm_index *ix);
 
 namespace lm {
 struct Work;
@@ -106,9 +107,9 @@ struct lm_index {
     hipStream_t st = nullptr;
     std::string err;
     // HBM image
-    DBuf<uint64_t> d_masks, d_seed_kmers, d_seed_vals;
+    DBuf<uint64_t> d_masks, d_seed_kmers, d_seed_vals, d_seed_top;
     DBuf<int32_t> d_pfx_first, d_g_len;
-    DBuf<int64_t> d_mask_off, d_g_off, d_batch_first;
+    DBuf<int64_t> d_mask_off, d_g_off, d_batch_first, d_top_off;
     DBuf<uint8_t> d_gbits;
     DBuf<float> d_gap_lut;
     int gap_lut_n = 0;

@@ -15,6 +15,8 @@ struct DevIndexView {
     const uint64_t *seed_kmers; // [N] per mask sorted ascending
     const uint64_t *seed_vals;  // [N] batch:17|genome:17|pos:28|rc:1|reversed:1 (lib-index-build.go:412-455)
     const int64_t *mask_off;    // [M+1]
+    const uint64_t *seed_top;   // every 16th k-mer of each mask's list (sample j of list m = seed_kmers[mask_off[m] + 16 j])
+    const int64_t *top_off;     // [M+1] first sample of each list
     const uint8_t *gbits;       // 2-bit genomes, first base in bits 7-6 (genome.go:1480)
     const int64_t *g_off;       // [G] byte offset
     const int32_t *g_len;       // [G] concatenated length in bases
@@ -62,12 +64,18 @@ void launch_extract_kmers(hipStream_t st, const uint8_t *qseq, const int64_t *qo
 void launch_fill_u32(hipStream_t st, uint32_t *p, int64_t n, uint32_t v);
 void launch_mask(hipStream_t st, const uint64_t *keys_all, const int64_t *posoff, int nq, int M, int K,
                  const uint64_t *masks, uint64_t *out_kmers, int64_t *out_lo, int64_t *out_hi, uint32_t *first_mask);
+#define LM_TOP_STEP 16
+void launch_seed_top_counts(hipStream_t st, const int64_t *mask_off, int M, int32_t *cnt);
+void launch_seed_top_fill(hipStream_t st, const uint64_t *seed_kmers, const int64_t *mask_off, const int64_t *top_off, int M,
+                          uint64_t *top);
+void launch_lookup_prep(hipStream_t st, DevIndexView ix, const uint64_t *kmers, const int64_t *klo, const uint32_t *first_mask,
+                        int64_t nqm, uint32_t *list, uint32_t *iota);
 void launch_lookup_count(hipStream_t st, DevIndexView ix, const uint64_t *kmers, const int64_t *klo, const int64_t *khi,
-                         const uint32_t *first_mask, int64_t nqm, int min_prefix, uint32_t *counts, int64_t *starts,
-                         int32_t *nscan, unsigned long long *stat_values);
+                         const uint32_t *perm, const uint32_t *slist, int64_t nqm, int min_prefix, uint32_t *counts,
+                         int64_t *starts, int32_t *nscan, unsigned long long *stat_values);
 void launch_lookup_emit(hipStream_t st, DevIndexView ix, const uint64_t *kmers, const int64_t *klo, const int64_t *khi,
-                        const uint32_t *vals_all, int64_t nqm, const uint32_t *counts, const int64_t *offs,
-                        const int64_t *starts, const int32_t *nscan, uint64_t *outA, uint64_t *outB);
+                        const uint32_t *vals_all, const uint32_t *perm, int64_t nqm, const uint32_t *counts,
+                        const int64_t *offs, const int64_t *starts, const int32_t *nscan, uint64_t *outA, uint64_t *outB);
 void launch_chain1(hipStream_t st, const uint64_t *B, const int64_t *seg_off, int nseg, LmChainOpt opt, int K, LmSub *subs,
                    uint8_t *marks, uint64_t *msi, uint64_t *s2i, int8_t *dirs, uint8_t *visited, int32_t *chain_off_pool,
                    int32_t *chain_idx_pool, int32_t *seg_n, float *seg_score, int32_t *seg_nch);

@@ -152,110 +152,152 @@ __device__ __forceinline__ int argmin_mask(const uint64_t *masks, const int32_t 
     return minj;
 }
 
-__device__ __forceinline__ bool lookup_setup(const DevIndexView &ix, const uint64_t *kmers, const int64_t *klo,
-                                             const uint32_t *first_mask, int64_t t, int min_prefix, int *dir_out,
-                                             uint64_t *key_out, int64_t *b_out, int64_t *e_out, uint64_t *right_out,
-                                             int64_t *qm_out) {
-    int dir = (int)(t & 1);
-    int64_t qm = t >> 1;
-    uint64_t kmer = kmers[qm];
-    *dir_out = dir;
-    *qm_out = qm;
-    if (kmer == 0) return false;
-    int m = (int)(qm % ix.M);
-    int list = m;
-    uint64_t key = kmer;
-    if (dir == 1) {
-        if (first_mask[klo[qm]] != (uint32_t)m) return false; // de-duplicated reversed k-mer (:1288-1298)
-        key = lm_reverse(kmer, ix.K);
-        list = argmin_mask(ix.masks, ix.pfx_first, ix.K, ix.mask_prefix, key);
-        if (list < 0) return false;
-    }
-    uint64_t left, right;
-    if (min_prefix < ix.K) {
-        int s2 = (ix.K - min_prefix) << 1;
-        uint64_t low = (1ull << s2) - 1;
-        left = key & ~low;
-        right = key | low;
-    } else {
-        left = right = key;
-    }
-    int64_t b = ix.mask_off[list], e = ix.mask_off[list + 1];
-    // lower_bound(left)
-    int64_t lo = b, hi = e;
-    while (lo < hi) {
-        int64_t mid = (lo + hi) >> 1;
-        if (ix.seed_kmers[mid] < left)
-            lo = mid + 1;
-        else
-            hi = mid;
-    }
-    *key_out = key;
-    *b_out = lo;
-    *e_out = e;
-    *right_out = right;
-    return true;
+// ---- seed lookup ------------------------------------------------------------------------------------------------------
+// Layout: per mask a sorted list of k-mers (seed_kmers) with their values, plus every 16th k-mer again in seed_top.
+// A lookup is a lower bound in the list: the search runs in the sampled array first (1/16 of the bytes, shared by all
+// the lookups of that list) and then inside ONE 16-key block of the list, so a lookup touches ~2 sectors of the big
+// array instead of ~9 (a plain binary search over 1e5 keys per list made the batch read the whole 17 GB k-mer array,
+// 3.4x its algorithmic bytes). For that sharing to happen the lookups are processed in list order (k_lookup_prep +
+// one radix sort by list id) and a list's lookups stay on one XCD (workgroups are dealt round-robin to the 8 XCDs, each
+// with its own L2), see lookup_index().
+__global__ void k_seed_top_counts(const int64_t *__restrict__ mask_off, int M, int32_t *__restrict__ cnt) {
+    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x)
+        cnt[m] = (int32_t)((mask_off[m + 1] - mask_off[m] + LM_TOP_STEP - 1) / LM_TOP_STEP);
 }
-
-__global__ void k_lookup_count(DevIndexView ix, const uint64_t *__restrict__ kmers, const int64_t *__restrict__ klo,
-                               const int64_t *__restrict__ khi, const uint32_t *__restrict__ first_mask, int64_t nqm,
-                               int min_prefix, uint32_t *__restrict__ counts, int64_t *__restrict__ starts,
-                               int32_t *__restrict__ nscan, unsigned long long *__restrict__ stat_values) {
-    int64_t total = nqm * 2;
+__global__ void k_seed_top_fill(const uint64_t *__restrict__ seed_kmers, const int64_t *__restrict__ mask_off,
+                                const int64_t *__restrict__ top_off, int M, uint64_t *__restrict__ top) {
+    for (int m = blockIdx.x; m < M; m += gridDim.x) {
+        const int64_t b = mask_off[m], ns = top_off[m + 1] - top_off[m];
+        for (int64_t j = threadIdx.x; j < ns; j += blockDim.x) top[top_off[m] + j] = seed_kmers[b + j * LM_TOP_STEP];
+    }
+}
+// list (mask) searched by lookup t = (query*M + mask)*2 + dir, or M when there is nothing to look up; iota[t] = t
+__global__ void k_lookup_prep(DevIndexView ix, const uint64_t *__restrict__ kmers, const int64_t *__restrict__ klo,
+                              const uint32_t *__restrict__ first_mask, int64_t nqm, uint32_t *__restrict__ list,
+                              uint32_t *__restrict__ iota) {
+    const int64_t total = nqm * 2;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        int dir;
-        uint64_t key, right;
-        int64_t b, e, qm;
-        uint32_t cnt = 0;
-        int32_t ns = 0;
-        int64_t st = 0;
-        if (lookup_setup(ix, kmers, klo, first_mask, t, min_prefix, &dir, &key, &b, &e, &right, &qm)) {
-            uint32_t nv = 0;
-            int64_t i = b;
-            while (i < e && ix.seed_kmers[i] <= right) {
-                if ((ix.seed_vals[i] & 1ull) == (uint64_t)dir) nv++;
-                i++;
+        const int dir = (int)(t & 1);
+        const int64_t qm = t >> 1;
+        const uint64_t kmer = kmers[qm];
+        const int m = (int)(qm % ix.M);
+        int l = ix.M;
+        if (kmer != 0) {
+            if (dir == 0) {
+                l = m;
+            } else if (first_mask[klo[qm]] == (uint32_t)m) { // de-duplicated reversed k-mer (:1288-1298)
+                const int a = argmin_mask(ix.masks, ix.pfx_first, ix.K, ix.mask_prefix, lm_reverse(kmer, ix.K));
+                if (a >= 0) l = a;
             }
-            ns = (int32_t)(i - b);
-            st = b;
-            cnt = nv * (uint32_t)(khi[qm] - klo[qm]);
-            if (nv) atomicAdd(stat_values, (unsigned long long)nv);
         }
-        counts[t] = cnt;
-        starts[t] = st;
-        nscan[t] = ns;
+        list[t] = (uint32_t)l;
+        iota[t] = (uint32_t)t;
     }
 }
-
-__global__ void k_lookup_emit(DevIndexView ix, const uint64_t *__restrict__ kmers, const int64_t *__restrict__ klo,
-                              const int64_t *__restrict__ khi, const uint32_t *__restrict__ vals_all, int64_t nqm,
-                              const uint32_t *__restrict__ counts, const int64_t *__restrict__ offs,
-                              const int64_t *__restrict__ starts, const int32_t *__restrict__ nscan,
-                              uint64_t *__restrict__ outA, uint64_t *__restrict__ outB) {
-    int64_t total = nqm * 2;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        if (counts[t] == 0) continue;
-        int dir = (int)(t & 1);
-        int64_t qm = t >> 1;
-        uint64_t q = (uint64_t)(qm / ix.M);
+// position in list order handled by this thread: logical workgroup x*per + y runs as hardware workgroup y*8 + x, i.e.
+// XCD x owns one contiguous eighth of the list-ordered lookups
+__device__ __forceinline__ int64_t lookup_index(int64_t total) {
+    const int64_t per = (int64_t)(gridDim.x >> 3);
+    const int64_t lb = (int64_t)(blockIdx.x & 7) * per + (int64_t)(blockIdx.x >> 3);
+    const int64_t j = lb * blockDim.x + threadIdx.x;
+    return j < total ? j : -1;
+}
+__global__ __launch_bounds__(256) void k_lookup_count(DevIndexView ix, const uint64_t *__restrict__ kmers,
+                                                      const int64_t *__restrict__ klo, const int64_t *__restrict__ khi,
+                                                      const uint32_t *__restrict__ perm, const uint32_t *__restrict__ slist,
+                                                      int64_t nqm, int min_prefix, uint32_t *__restrict__ counts,
+                                                      int64_t *__restrict__ starts, int32_t *__restrict__ nscan,
+                                                      unsigned long long *__restrict__ stat_values) {
+    const int64_t j = lookup_index(nqm * 2);
+    if (j < 0) return;
+    const uint32_t list = slist[j];
+    uint32_t cnt = 0;
+    int32_t ns = 0;
+    int64_t st = 0;
+    if ((int)list < ix.M) {
+        const int64_t t = (int64_t)perm[j];
+        const int dir = (int)(t & 1);
+        const int64_t qm = t >> 1;
         uint64_t key = kmers[qm];
         if (dir) key = lm_reverse(key, ix.K);
-        int64_t o = offs[t];
-        int64_t b = starts[t];
-        for (int32_t s = 0; s < nscan[t]; s++) {
-            uint64_t v = ix.seed_vals[b + s];
-            if ((v & 1ull) != (uint64_t)dir) continue;
-            int kprefix = lm_lcp(key, ix.seed_kmers[b + s], ix.K);
-            uint64_t A = (q << 34) | (v >> 30);
-            for (int64_t li = klo[qm]; li < khi[qm]; li++) {
-                uint32_t loc = vals_all[li];
-                int bq, bt;
-                bool rct;
-                lm_anchor_coords(v, (int)(loc >> 1), (loc & 1u) != 0, kprefix, ix.K, &bq, &bt, &rct);
-                outA[o] = A;
-                outB[o] = lm_pack_anchor(bq, kprefix, bt, (loc & 1u) != 0, rct);
-                o++;
+        uint64_t left, right;
+        if (min_prefix < ix.K) {
+            const int s2 = (ix.K - min_prefix) << 1;
+            const uint64_t low = (1ull << s2) - 1;
+            left = key & ~low;
+            right = key | low;
+        } else {
+            left = right = key;
+        }
+        const int64_t b = ix.mask_off[list], e = ix.mask_off[list + 1];
+        // samples < left
+        const uint64_t *top = ix.seed_top + ix.top_off[list];
+        int64_t lo = 0, hi = ix.top_off[list + 1] - ix.top_off[list];
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (top[mid] < left)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        int64_t i = b;
+        if (lo > 0) { // seed_kmers[b + 16 (lo-1)] < left <= seed_kmers[b + 16 lo] (if that one exists)
+            int64_t l2 = b + (lo - 1) * LM_TOP_STEP + 1, h2 = b + lo * LM_TOP_STEP;
+            if (h2 > e) h2 = e;
+            while (l2 < h2) {
+                const int64_t mid = (l2 + h2) >> 1;
+                if (ix.seed_kmers[mid] < left)
+                    l2 = mid + 1;
+                else
+                    h2 = mid;
             }
+            i = l2;
+        }
+        st = i;
+        uint32_t nv = 0;
+        while (i < e && ix.seed_kmers[i] <= right) {
+            if ((ix.seed_vals[i] & 1ull) == (uint64_t)dir) nv++;
+            i++;
+        }
+        ns = (int32_t)(i - st);
+        cnt = nv * (uint32_t)(khi[qm] - klo[qm]);
+        if (nv) atomicAdd(stat_values, (unsigned long long)nv);
+    }
+    counts[j] = cnt;
+    starts[j] = st;
+    nscan[j] = ns;
+}
+
+__global__ __launch_bounds__(256) void k_lookup_emit(DevIndexView ix, const uint64_t *__restrict__ kmers,
+                                                     const int64_t *__restrict__ klo, const int64_t *__restrict__ khi,
+                                                     const uint32_t *__restrict__ vals_all, const uint32_t *__restrict__ perm,
+                                                     int64_t nqm, const uint32_t *__restrict__ counts,
+                                                     const int64_t *__restrict__ offs, const int64_t *__restrict__ starts,
+                                                     const int32_t *__restrict__ nscan, uint64_t *__restrict__ outA,
+                                                     uint64_t *__restrict__ outB) {
+    const int64_t j = lookup_index(nqm * 2);
+    if (j < 0 || counts[j] == 0) return;
+    const int64_t t = (int64_t)perm[j];
+    int dir = (int)(t & 1);
+    int64_t qm = t >> 1;
+    uint64_t q = (uint64_t)(qm / ix.M);
+    uint64_t key = kmers[qm];
+    if (dir) key = lm_reverse(key, ix.K);
+    int64_t o = offs[j];
+    int64_t b = starts[j];
+    for (int32_t s = 0; s < nscan[j]; s++) {
+        uint64_t v = ix.seed_vals[b + s];
+        if ((v & 1ull) != (uint64_t)dir) continue;
+        int kprefix = lm_lcp(key, ix.seed_kmers[b + s], ix.K);
+        uint64_t A = (q << 34) | (v >> 30);
+        for (int64_t li = klo[qm]; li < khi[qm]; li++) {
+            uint32_t loc = vals_all[li];
+            int bq, bt;
+            bool rct;
+            lm_anchor_coords(v, (int)(loc >> 1), (loc & 1u) != 0, kprefix, ix.K, &bq, &bt, &rct);
+            outA[o] = A;
+            outB[o] = lm_pack_anchor(bq, kprefix, bt, (loc & 1u) != 0, rct);
+            o++;
         }
     }
 }
@@ -2078,16 +2120,34 @@ void launch_mask(hipStream_t st, const uint64_t *keys_all, const int64_t *posoff
                  const uint64_t *masks, uint64_t *out_kmers, int64_t *out_lo, int64_t *out_hi, uint32_t *first_mask) {
     LM_LAUNCH_1D(k_mask, (int64_t)nq * M, st, keys_all, posoff, nq, M, K, masks, out_kmers, out_lo, out_hi, first_mask);
 }
+void launch_seed_top_counts(hipStream_t st, const int64_t *mask_off, int M, int32_t *cnt) {
+    LM_LAUNCH_1D(k_seed_top_counts, M, st, mask_off, M, cnt);
+}
+void launch_seed_top_fill(hipStream_t st, const uint64_t *seed_kmers, const int64_t *mask_off, const int64_t *top_off, int M,
+                          uint64_t *top) {
+    int g = M < 1 ? 1 : (M > 65536 ? 65536 : M);
+    hipLaunchKernelGGL(k_seed_top_fill, dim3(g), dim3(256), 0, st, seed_kmers, mask_off, top_off, M, top);
+}
+void launch_lookup_prep(hipStream_t st, DevIndexView ix, const uint64_t *kmers, const int64_t *klo, const uint32_t *first_mask,
+                        int64_t nqm, uint32_t *list, uint32_t *iota) {
+    LM_LAUNCH_1D(k_lookup_prep, nqm * 2, st, ix, kmers, klo, first_mask, nqm, list, iota);
+}
+static int lookup_grid(int64_t total) { // one thread per lookup, workgroup count a multiple of 8 (see lookup_index)
+    int64_t nb = (total + 255) / 256;
+    nb = (nb + 7) / 8 * 8;
+    return (int)(nb < 8 ? 8 : nb);
+}
 void launch_lookup_count(hipStream_t st, DevIndexView ix, const uint64_t *kmers, const int64_t *klo, const int64_t *khi,
-                         const uint32_t *first_mask, int64_t nqm, int min_prefix, uint32_t *counts, int64_t *starts,
-                         int32_t *nscan, unsigned long long *stat_values) {
-    LM_LAUNCH_1D(k_lookup_count, nqm * 2, st, ix, kmers, klo, khi, first_mask, nqm, min_prefix, counts, starts, nscan,
-                 stat_values);
+                         const uint32_t *perm, const uint32_t *slist, int64_t nqm, int min_prefix, uint32_t *counts,
+                         int64_t *starts, int32_t *nscan, unsigned long long *stat_values) {
+    hipLaunchKernelGGL(k_lookup_count, dim3(lookup_grid(nqm * 2)), dim3(256), 0, st, ix, kmers, klo, khi, perm, slist, nqm,
+                       min_prefix, counts, starts, nscan, stat_values);
 }
 void launch_lookup_emit(hipStream_t st, DevIndexView ix, const uint64_t *kmers, const int64_t *klo, const int64_t *khi,
-                        const uint32_t *vals_all, int64_t nqm, const uint32_t *counts, const int64_t *offs,
-                        const int64_t *starts, const int32_t *nscan, uint64_t *outA, uint64_t *outB) {
-    LM_LAUNCH_1D(k_lookup_emit, nqm * 2, st, ix, kmers, klo, khi, vals_all, nqm, counts, offs, starts, nscan, outA, outB);
+                        const uint32_t *vals_all, const uint32_t *perm, int64_t nqm, const uint32_t *counts,
+                        const int64_t *offs, const int64_t *starts, const int32_t *nscan, uint64_t *outA, uint64_t *outB) {
+    hipLaunchKernelGGL(k_lookup_emit, dim3(lookup_grid(nqm * 2)), dim3(256), 0, st, ix, kmers, klo, khi, vals_all, perm, nqm,
+                       counts, offs, starts, nscan, outA, outB);
 }
 void launch_chain1(hipStream_t st, const uint64_t *B, const int64_t *seg_off, int nseg, LmChainOpt opt, int K, LmSub *subs,
                    uint8_t *marks, uint64_t *msi, uint64_t *s2i, int8_t *dirs, uint8_t *visited, int32_t *chain_off_pool,

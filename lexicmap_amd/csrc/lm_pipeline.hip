@@ -283,6 +283,14 @@ static void sort_pairs_u64(lm_index *ix, uint64_t *k_in, uint64_t *k_out, uint64
     HIPCHK(hipcub::DeviceRadixSort::SortPairs(TMP(ix).p, bytes, k_in, k_out, v_in, v_out, (int)n, begin_bit, end_bit, S(ix)));
 }
 
+static void sort_pairs_u32(lm_index *ix, uint32_t *k_in, uint32_t *k_out, uint32_t *v_in, uint32_t *v_out, int64_t n,
+                           int begin_bit, int end_bit) {
+    size_t bytes = 0;
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k_in, k_out, v_in, v_out, (int)n, begin_bit, end_bit, S(ix)));
+    TMP(ix).ensure(bytes);
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(TMP(ix).p, bytes, k_in, k_out, v_in, v_out, (int)n, begin_bit, end_bit, S(ix)));
+}
+
 // sort anchors by (A, B): LSD — stable sort by B, then by A. Result lands in (A0,B0).
 static void sort_anchors(lm_index *ix, uint64_t *A0, uint64_t *B0, uint64_t *A1, uint64_t *B1, int64_t n, int a_bits) {
     if (n <= 0) return;
@@ -292,6 +300,25 @@ static void sort_anchors(lm_index *ix, uint64_t *A0, uint64_t *B0, uint64_t *A1,
 
 // ---- query batch ---------------------------------------------------------------------------------------------
 } // namespace lm
+
+// Sampled top array of the seed lists (every LM_TOP_STEP-th k-mer of each list, see the lookup kernels); called once the
+// seeds and mask offsets are on the device, by lm_index_open and by the synthetic builder.
+void lm_build_seed_top(lm_index *ix) {
+    const int M = ix->host.M;
+    DBuf<int32_t> cnt;
+    cnt.ensure((size_t)M + 1);
+    ix->d_top_off.ensure((size_t)M + 2);
+    HIPCHK(hipMemsetAsync(cnt.p + M, 0, sizeof(int32_t), ix->st));
+    launch_seed_top_counts(ix->st, ix->d_mask_off.p, M, cnt.p);
+    int64_t total = scan_to_i64<int32_t, CastI32>(ix, cnt.p, M, ix->d_top_off.p);
+    ix->d_seed_top.ensure((size_t)std::max<int64_t>(total, 1));
+    launch_seed_top_fill(ix->st, ix->d_seed_kmers.p, ix->d_mask_off.p, ix->d_top_off.p, M, ix->d_seed_top.p);
+    HIPCHK(hipStreamSynchronize(ix->st));
+    ix->view.seed_top = ix->d_seed_top.p;
+    ix->view.top_off = ix->d_top_off.p;
+    ix->hbm_bytes += total * 8 + ((int64_t)M + 1) * 8;
+}
+
 
 struct lm_qbatch {
     lm_index *ix = nullptr;
@@ -338,7 +365,7 @@ struct Work {
     DBuf<uint64_t> kmers;
     DBuf<int64_t> klo, khi;
     // stage C
-    DBuf<uint32_t> lk_counts;
+    DBuf<uint32_t> lk_counts, lk_list, lk_list2, lk_perm, lk_perm2;
     DBuf<int64_t> lk_offs, lk_starts;
     DBuf<int32_t> lk_nscan;
     DBuf<unsigned long long> stat;
@@ -456,9 +483,26 @@ static void stage_lookup(Work &w, lm_stage_stats &stats) {
     w.stat.ensure(4);
     HIPCHK(hipMemsetAsync(w.stat.p, 0, 4 * sizeof(unsigned long long), S(ix)));
     HIPCHK(hipMemsetAsync(w.lk_counts.p + n, 0, sizeof(uint32_t), S(ix)));
+    // lookups in list (mask) order: all the searches of one seed list run together (and on one XCD), so the sampled
+    // top array of the list is fetched once and every lookup adds only its one 16-key block of the big array
+    if (n >= ((int64_t)1 << 32)) throw HipError("too many seed lookups in one batch; use a smaller query batch");
+    w.lk_list.ensure((size_t)n);
+    w.lk_list2.ensure((size_t)n);
+    w.lk_perm.ensure((size_t)n);
+    w.lk_perm2.ensure((size_t)n);
+    {
+        Prof p(ix, "k_lookup_prep", n * 12);
+        launch_lookup_prep(S(ix), ix->view, w.kmers.p, w.klo.p, w.first_mask.p, nqm, w.lk_list.p, w.lk_perm.p);
+    }
+    {
+        Prof p(ix, "sort_lookups");
+        int lbits = 1;
+        while ((1 << lbits) <= M) lbits++;
+        sort_pairs_u32(ix, w.lk_list.p, w.lk_list2.p, w.lk_perm.p, w.lk_perm2.p, n, 0, lbits);
+    }
     {
         Prof p(ix, "k_lookup_count");
-        launch_lookup_count(S(ix), ix->view, w.kmers.p, w.klo.p, w.khi.p, w.first_mask.p, nqm, ix->opt.min_prefix,
+        launch_lookup_count(S(ix), ix->view, w.kmers.p, w.klo.p, w.khi.p, w.lk_perm2.p, w.lk_list2.p, nqm, ix->opt.min_prefix,
                             w.lk_counts.p, w.lk_starts.p, w.lk_nscan.p, w.stat.p);
     }
     int64_t T;
@@ -488,7 +532,7 @@ static void stage_lookup(Work &w, lm_stage_stats &stats) {
     w.B1.ensure((size_t)T);
     {
         Prof p(ix, "k_lookup_emit", T * 16);
-        launch_lookup_emit(S(ix), ix->view, w.kmers.p, w.klo.p, w.khi.p, w.v_all, nqm, w.lk_counts.p, w.lk_offs.p,
+        launch_lookup_emit(S(ix), ix->view, w.kmers.p, w.klo.p, w.khi.p, w.v_all, w.lk_perm2.p, nqm, w.lk_counts.p, w.lk_offs.p,
                            w.lk_starts.p, w.lk_nscan.p, w.A0.p, w.B0.p);
     }
     {
@@ -870,6 +914,7 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
         v.shard_count = h.shard_count;
         ix->hbm_bytes = (int64_t)(h.masks.size() * 8 + pfx.size() * 4 + h.seed_kmers.size() * 16 + h.mask_off.size() * 8 +
                                   h.gbits.size() + goff.size() * 12 + h.batch_first.size() * 8);
+        lm_build_seed_top(ix);
         // the packed host copies are no longer needed
         std::vector<uint64_t>().swap(h.seed_kmers);
         std::vector<uint64_t>().swap(h.seed_vals);
