@@ -1511,84 +1511,31 @@ __device__ __forceinline__ unsigned long long rotr64(unsigned long long x, int r
 
 // Backtrace of one alignment by the whole wavefront (same walk as lm_wfa_backtrace, lm_algos.h): per step ONE coalesced
 // load brings the three header rows (27 lanes), five lanes then fetch the five candidate offsets in parallel, and the
-// choice is a wave max - two dependent global latencies per edit operation instead of ~16 with a single lane. The
-// statistics (bounds, aligned length, matches, gaps, BLAST score over the M-trimmed CIGAR) are accumulated while walking
-// instead of re-reading the ops; ops are only written when the caller wants the CIGAR.
-struct BtStats {
-    bool seen_m;
-    uint32_t align_len, matches, gaps, gap_regions;
-    int bscore;
-    uint32_t p_len, p_gaps, p_regions; // runs generated after the most recent 'M' run (pending)
-    int p_bscore, p_q, p_t;
-    int trail_q, trail_t; // consumed after the last 'M' of the alignment (generated before the first 'M' run)
-};
-__device__ __forceinline__ void bt_flush(BtStats &st, char op, uint32_t n, uint64_t *ops, int &wp, bool want_ops,
-                                         bool &overflow, int &nruns, int lane) {
-    if (n == 0) return;
-    nruns++;
-    if (want_ops) {
-        if (wp <= 0)
-            overflow = true;
-        else {
-            --wp;
-            if (lane == 0) ops[wp] = ((uint64_t)(uint8_t)op << 32) | n;
-        }
-    }
-    if (op == 'M') {
-        if (!st.seen_m) {
-            st.seen_m = true;
-            st.trail_q = st.p_q;
-            st.trail_t = st.p_t;
-        } else {
-            st.align_len += st.p_len;
-            st.gaps += st.p_gaps;
-            st.gap_regions += st.p_regions;
-            st.bscore += st.p_bscore;
-        }
-        st.p_len = st.p_gaps = st.p_regions = 0;
-        st.p_bscore = st.p_q = st.p_t = 0;
-        st.align_len += n;
-        st.matches += n;
-        st.bscore += 2 * (int)n;
-    } else {
-        st.p_len += n;
-        if (op == 'X') {
-            st.p_bscore -= 3 * (int)n;
-            st.p_q += (int)n;
-            st.p_t += (int)n;
-        } else {
-            st.p_gaps += n;
-            st.p_regions++;
-            st.p_bscore -= 5 + 2 * (int)n;
-            if (op == 'I')
-                st.p_t += (int)n;
-            else
-                st.p_q += (int)n;
-        }
-    }
-}
+// choice is a wave max - two dependent global latencies per edit operation instead of ~16 with a single lane. The walk
+// only merges runs and stores them (scalar work per step is what bounds this kernel); the alignment statistics (bounds,
+// aligned length, matches, gaps, BLAST score over the M-trimmed CIGAR) are computed afterwards from the stored runs, by
+// all lanes in parallel.
 __device__ __forceinline__ void wave_backtrace(const int32_t *__restrict__ hdr, const int32_t *__restrict__ arena, int s,
-                                               int plen, int tlen, uint64_t *__restrict__ ops, int ops_cap, bool want_ops,
-                                               int lane, LmWfaOut *out, int *blast) {
+                                               int plen, int tlen, uint64_t *__restrict__ ops, int ops_cap, int lane,
+                                               LmWfaOut *out, int *blast) {
     const int X = 4, OE = 8, E = 2;
     const int ak = tlen - plen;
-    BtStats st;
-    st.seen_m = false;
-    st.align_len = st.matches = st.gaps = st.gap_regions = 0;
-    st.bscore = 0;
-    st.p_len = st.p_gaps = st.p_regions = 0;
-    st.p_bscore = st.p_q = st.p_t = 0;
-    st.trail_q = st.trail_t = 0;
-    int wp = ops_cap, nruns = 0;
-    char cur_op = 0;
+    int wp = ops_cap; // runs are written from the end of the buffer towards its start
+    int cur_op = 0;
     uint32_t cur_n = 0;
     bool overflow = false;
-    auto push = [&](char op, int nn) {
-        if (nn <= 0) return;
+    auto push = [&](int op, int nn) { // nn > 0
         if (cur_op == op) {
             cur_n += (uint32_t)nn;
         } else {
-            bt_flush(st, cur_op, cur_n, ops, wp, want_ops, overflow, nruns, lane);
+            if (cur_n) {
+                if (wp <= 0)
+                    overflow = true;
+                else {
+                    --wp;
+                    if (lane == 0) ops[wp] = ((uint64_t)(uint32_t)cur_op << 32) | cur_n;
+                }
+            }
             cur_op = op;
             cur_n = (uint32_t)nn;
         }
@@ -1604,6 +1551,8 @@ __device__ __forceinline__ void wave_backtrace(const int32_t *__restrict__ hdr, 
     const int c_dk = (lane == 1 || lane == 3) ? -1 : (lane == 2 || lane == 4) ? 1 : 0;
     const int c_add = (lane == 0 || lane == 1 || lane == 3) ? 1 : 0;
     const int c_tag = lane == 0 ? 9 : lane == 1 ? 1 : lane == 2 ? 3 : lane == 3 ? 2 : 4;
+    // which candidates a matrix may use: M all five, I {1,3}, D {2,4}
+    const uint32_t c_use = lane == 0 ? 1u : (lane == 1 || lane == 3) ? 3u : (lane == 2 || lane == 4) ? 5u : 0u; // bit m
     while (v > 0 && h > 0 && score > 0) {
         const int s_mis = score - X, s_open = score - OE, s_ext = score - E;
         int32_t hv = (hcol % 3 == 1) ? -1 : 1; // empty range for negative scores
@@ -1613,16 +1562,14 @@ __device__ __forceinline__ void wave_backtrace(const int32_t *__restrict__ hdr, 
         }
         const int32_t lo = __shfl(hv, c_src), hi = __shfl(hv, c_src + 1), base = __shfl(hv, c_src + 2);
         int32_t cand = -1;
-        if (lane < 5) {
-            const bool use = matrix == 0 || (matrix == 1 && (lane == 1 || lane == 3)) || (matrix == 2 && (lane == 2 || lane == 4));
+        {
             const int kq = k + c_dk;
-            if (use && kq >= lo && kq <= hi) {
+            if (((c_use >> matrix) & 1u) && kq >= lo && kq <= hi) {
                 const int32_t o = arena[base + (kq - lo)] + c_add;
                 if (o >= 0) cand = (o << 4) | c_tag;
             }
         }
-        // max over lanes 0..7 (the others hold -1)
-        int32_t mx = cand;
+        int32_t mx = cand; // max over lanes 0..7 (the others hold -1)
         {
             int32_t y = __shfl_xor(mx, 1);
             mx = y > mx ? y : mx;
@@ -1633,38 +1580,36 @@ __device__ __forceinline__ void wave_backtrace(const int32_t *__restrict__ hdr, 
         }
         mx = __builtin_amdgcn_readfirstlane(mx);
         if (mx < 0) break;
+        const int bt = mx & 15;
         if (matrix == 0) {
             const int32_t max_off = mx >> 4;
-            push('M', offset - max_off);
+            if (offset > max_off) push('M', offset - max_off);
             offset = max_off;
-            v = offset - k;
-            h = offset;
-            if (v <= 0 || h <= 0) break;
+            if (offset - k <= 0 || offset <= 0) {
+                v = offset - k;
+                h = offset;
+                break;
+            }
         }
-        const int bt = mx & 15;
-        if (bt == 9) {
-            score = s_mis; matrix = 0; push('X', 1); --offset;
-        } else if (bt == 1) {
-            score = s_open; matrix = 0; push('I', 1); --k; --offset;
-        } else if (bt == 2) {
-            score = s_ext; matrix = 1; push('I', 1); --k; --offset;
-        } else if (bt == 3) {
-            score = s_open; matrix = 0; push('D', 1); ++k;
-        } else {
-            score = s_ext; matrix = 2; push('D', 1); ++k;
-        }
+        // one edit operation: 9 = X (to M[s-4]), 1 / 2 = I from M[s-8] / I[s-2], 3 / 4 = D from M[s-8] / D[s-2]
+        const bool is_x = bt == 9, is_i = bt == 1 || bt == 2, opens = bt == 1 || bt == 3;
+        score = is_x ? s_mis : (opens ? s_open : s_ext);
+        matrix = (is_x || opens) ? 0 : (bt == 2 ? 1 : 2);
+        push(is_x ? 'X' : (is_i ? 'I' : 'D'), 1);
+        if (is_x || is_i) --offset;
+        k += is_x ? 0 : (is_i ? -1 : 1);
         v = offset - k;
         h = offset;
     }
     if (v > 0 && h > 0) {
-        int nm = v < h ? v : h;
+        const int nm = v < h ? v : h;
         push('M', nm);
         v -= nm;
         h -= nm;
     }
     if (v > 0) push('D', v);
     if (h > 0) push('I', h);
-    bt_flush(st, cur_op, cur_n, ops, wp, want_ops, overflow, nruns, lane);
+    push(0, 1); // flushes the last run
     out->status = 0;
     out->score = s;
     out->nops = 0;
@@ -1675,9 +1620,10 @@ __device__ __forceinline__ void wave_backtrace(const int32_t *__restrict__ hdr, 
         out->status = 1;
         return;
     }
+    const int nruns = ops_cap - wp;
     out->nops = nruns;
-    if (want_ops && wp > 0) { // move the runs to the front of the buffer (ascending chunks: destination is below the source)
-        __syncthreads();
+    __syncthreads(); // lane 0's stores are visible to the other lanes
+    if (wp > 0) {    // move the runs to the front of the buffer (ascending chunks: the destination is below the source)
         for (int c = 0; c < nruns; c += 64) {
             uint64_t x = 0;
             if (c + lane < nruns) x = ops[wp + c + lane];
@@ -1686,19 +1632,65 @@ __device__ __forceinline__ void wave_backtrace(const int32_t *__restrict__ hdr, 
             __syncthreads();
         }
     }
-    if (!st.seen_m) {
+    // ---- statistics over the runs, all lanes ----
+    int first = 2147483647, last = -1;
+    for (int c = 0; c < nruns; c += 64) {
+        const bool is_m = c + lane < nruns && (uint32_t)(ops[c + lane] >> 32) == (uint32_t)'M';
+        const unsigned long long bm = __ballot(is_m);
+        if (bm) {
+            if (first == 2147483647) first = c + (__ffsll((long long)bm) - 1);
+            last = c + (63 - __clzll((long long)bm));
+        }
+    }
+    if (last < 0) {
         out->status = 2;
         return;
     }
-    out->qbegin = st.p_q + 1;
-    out->tbegin = st.p_t + 1;
-    out->qend = plen - st.trail_q;
-    out->tend = tlen - st.trail_t;
-    out->align_len = st.align_len;
-    out->matches = st.matches;
-    out->gaps = st.gaps;
-    out->gap_regions = st.gap_regions;
-    *blast = st.bscore;
+    // per-lane partial sums: [0] aligned length, [1] matches, [2] gaps, [3] gap regions, [4] BLAST score,
+    // [5] / [6] query / target bases before `first`, [7] / [8] query / target bases up to and including `last`
+    int acc[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) acc[j] = 0;
+    for (int c = lane; c < nruns; c += 64) {
+        const uint64_t r = ops[c];
+        const int op = (int)(r >> 32), nn = (int)(uint32_t)r;
+        const int cq = (op == 'M' || op == 'X' || op == 'D') ? nn : 0, ct = (op == 'M' || op == 'X' || op == 'I') ? nn : 0;
+        if (c < first) {
+            acc[5] += cq;
+            acc[6] += ct;
+        }
+        if (c <= last) {
+            acc[7] += cq;
+            acc[8] += ct;
+        }
+        if (c >= first && c <= last) {
+            acc[0] += nn;
+            if (op == 'M') {
+                acc[1] += nn;
+                acc[4] += 2 * nn;
+            } else if (op == 'X') {
+                acc[4] -= 3 * nn;
+            } else {
+                acc[2] += nn;
+                acc[3] += 1;
+                acc[4] -= 5 + 2 * nn;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[j] += __shfl_xor(acc[j], o);
+    }
+    out->qbegin = acc[5] + 1;
+    out->tbegin = acc[6] + 1;
+    out->qend = acc[7];
+    out->tend = acc[8];
+    out->align_len = (uint32_t)acc[0];
+    out->matches = (uint32_t)acc[1];
+    out->gaps = (uint32_t)acc[2];
+    out->gap_regions = (uint32_t)acc[3];
+    *blast = acc[4];
 }
 
 // ---- k_wfa_lean<NC>: the LDS wavefront kernel ------------------------------------------------------------------------
@@ -2087,8 +2079,7 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
             o.r.qbegin = o.r.qend = o.r.tbegin = o.r.tend = 0;
             o.r.align_len = o.r.matches = o.r.gaps = o.r.gap_regions = 0;
         } else {
-            wave_backtrace(hdr, arena, s, plen, tlen, ops_pool + w.ops_off, w.ops_cap, want_ops != 0, lane, &o.r,
-                           &o.blast_score);
+            wave_backtrace(hdr, arena, s, plen, tlen, ops_pool + w.ops_off, w.ops_cap, lane, &o.r, &o.blast_score);
         }
         if (lane == 0) {
             out[i] = o;
