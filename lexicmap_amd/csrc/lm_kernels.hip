@@ -1846,7 +1846,7 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
         LDS_WAVE_SYNC();
         int s = 0, ms = 0, is = 0; // ring rows of score s
         int alo = 0;               // first diagonal of the arena slices of score s
-        int64_t used = 1, gbM = 0, gbI = 0, gbD = 0;
+        int32_t used = 1, gbM = 0, gbI = 0, gbD = 0; // arena cells (the slab holds < 2^31)
         // does the slot range of diagonals [lo, hi] touch the 64 slots of chunk c ?
         auto chunk_has = [&](int c, int lo_, int hi_) {
             if (NC == 1) return true;
@@ -1907,17 +1907,34 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                     SlotMask<NC> kb;
 #pragma unroll
                     for (int c = 0; c < NC; c++) kb.w[c] = __ballot(inr[c] && (dist[c] - dmin <= 50));
-                    kb = sm_rotr<NC>(kb, mlo[0] + koff); // bit j <-> diagonal mlo+j
                     int nlo = mlo[0], nhi = mhi[0];
                     const int top = ak < mhi[0] ? ak : mhi[0];
-                    if (mlo[0] < top) {
-                        SlotMask<NC> mk = sm_below<NC>(kb, top - mlo[0]);
-                        nlo = sm_any<NC>(mk) ? mlo[0] + sm_first<NC>(mk) : top;
-                    }
-                    const int bottom = ak > nlo ? ak : nlo;
-                    if (mhi[0] > bottom) {
-                        SlotMask<NC> mk = sm_from<NC>(kb, bottom - mlo[0] + 1);
-                        nhi = sm_any<NC>(mk) ? mlo[0] + sm_last<NC>(mk) : bottom;
+                    const bool a0 = chunk_has(0, mlo[0], mhi[0]), a1 = NC == 2 && chunk_has(NC - 1, mlo[0], mhi[0]);
+                    if (NC == 2 && a0 != a1) {
+                        // the whole wavefront sits in one 64-slot chunk, unwrapped: plain 64-bit masks
+                        const int sh = ((mlo[0] + koff) & (W - 1)) & 63;
+                        const unsigned long long k64 = (a1 ? kb.w[NC - 1] : kb.w[0]) >> sh; // bit j <-> diagonal mlo+j
+                        if (mlo[0] < top) {
+                            const unsigned long long mk = k64 & ((1ull << (top - mlo[0])) - 1ull);
+                            nlo = mk ? mlo[0] + (__ffsll((long long)mk) - 1) : top;
+                        }
+                        const int bottom = ak > nlo ? ak : nlo;
+                        if (mhi[0] > bottom) {
+                            const int b0 = bottom - mlo[0] + 1;
+                            const unsigned long long mk = (k64 >> b0) << b0;
+                            nhi = mk ? mlo[0] + (63 - __clzll((long long)mk)) : bottom;
+                        }
+                    } else {
+                        kb = sm_rotr<NC>(kb, mlo[0] + koff); // bit j <-> diagonal mlo+j
+                        if (mlo[0] < top) {
+                            SlotMask<NC> mk = sm_below<NC>(kb, top - mlo[0]);
+                            nlo = sm_any<NC>(mk) ? mlo[0] + sm_first<NC>(mk) : top;
+                        }
+                        const int bottom = ak > nlo ? ak : nlo;
+                        if (mhi[0] > bottom) {
+                            SlotMask<NC> mk = sm_from<NC>(kb, bottom - mlo[0] + 1);
+                            nhi = sm_any<NC>(mk) ? mlo[0] + sm_last<NC>(mk) : bottom;
+                        }
                     }
                     if (nlo != mlo[0] || nhi != mhi[0]) {
                         const bool hasI = ilo[0] <= ihi[0], hasD = dlo[0] <= dhi[0];
@@ -1942,20 +1959,17 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                     }
                 }
             }
-            if (lane < 9) { // header of score s for the backtrace
-                int32_t hv;
-                switch (lane) {
-                case 0: hv = mlo[0]; break;
-                case 1: hv = mhi[0]; break;
-                case 2: hv = (int32_t)(gbM + (mlo[0] - alo)); break;
-                case 3: hv = ilo[0]; break;
-                case 4: hv = ihi[0]; break;
-                case 5: hv = (int32_t)(gbI + (ilo[0] - alo)); break;
-                case 6: hv = dlo[0]; break;
-                case 7: hv = dhi[0]; break;
-                default: hv = (int32_t)(gbD + (dlo[0] - alo)); break;
-                }
-                hdr[s * 9 + lane] = hv;
+            { // header of score s for the backtrace: lanes 0..8 store one field each (selects, no branches)
+                int32_t hv = gbD + (dlo[0] - alo);
+                hv = lane == 7 ? dhi[0] : hv;
+                hv = lane == 6 ? dlo[0] : hv;
+                hv = lane == 5 ? gbI + (ilo[0] - alo) : hv;
+                hv = lane == 4 ? ihi[0] : hv;
+                hv = lane == 3 ? ilo[0] : hv;
+                hv = lane == 2 ? gbM + (mlo[0] - alo) : hv;
+                hv = lane == 1 ? mhi[0] : hv;
+                hv = lane == 0 ? mlo[0] : hv;
+                if (lane < 9) hdr[s * 9 + lane] = hv;
             }
             if (done) break;
             s += 2;
@@ -1999,14 +2013,14 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                 status = 3;
                 break;
             }
-            if (used + 3ll * wd > arena_cap) {
+            if ((int64_t)used + 3 * wd > arena_cap) {
                 status = 1;
                 break;
             }
             gbM = used;
             gbI = used + wd;
-            gbD = used + 2ll * wd;
-            used += 3ll * wd;
+            gbD = used + 2 * wd;
+            used += 3 * wd;
             alo = lo;
             const int r4 = ms >= 2 ? ms - 2 : ms + 3, r8 = ms == 4 ? 0 : ms + 1, r2 = is ^ 1; // rows of s-4, s-8, s-2
             LDS_WAVE_SYNC(); // the neighbours' extension results are in the ring
@@ -2050,16 +2064,30 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                 bi.w[c] = __ballot(okc(ins));
                 bd.w[c] = __ballot(okc(del));
             }
-            bm = sm_rotr<NC>(bm, lo + koff);
-            bi = sm_rotr<NC>(bi, lo + koff);
-            bd = sm_rotr<NC>(bd, lo + koff);
-            const bool hm = sm_any<NC>(bm), hi_ = sm_any<NC>(bi), hd = sm_any<NC>(bd);
-            mlo[0] = hm ? lo + sm_first<NC>(bm) : lo;
-            mhi[0] = hm ? lo + sm_last<NC>(bm) : lo - 1;
-            ilo[0] = hi_ ? lo + sm_first<NC>(bi) : lo;
-            ihi[0] = hi_ ? lo + sm_last<NC>(bi) : lo - 1;
-            dlo[0] = hd ? lo + sm_first<NC>(bd) : lo;
-            dhi[0] = hd ? lo + sm_last<NC>(bd) : lo - 1;
+            const bool t0 = chunk_has(0, lo, hi), t1 = NC == 2 && chunk_has(NC - 1, lo, hi);
+            if (NC == 2 && t0 != t1) { // the new wavefront sits in one chunk, unwrapped: 64-bit masks, plain shift
+                const int sh = ((lo + koff) & (W - 1)) & 63;
+                const unsigned long long m64 = (t1 ? bm.w[NC - 1] : bm.w[0]) >> sh;
+                const unsigned long long i64 = (t1 ? bi.w[NC - 1] : bi.w[0]) >> sh;
+                const unsigned long long d64 = (t1 ? bd.w[NC - 1] : bd.w[0]) >> sh;
+                mlo[0] = m64 ? lo + (__ffsll((long long)m64) - 1) : lo;
+                mhi[0] = m64 ? lo + (63 - __clzll((long long)m64)) : lo - 1;
+                ilo[0] = i64 ? lo + (__ffsll((long long)i64) - 1) : lo;
+                ihi[0] = i64 ? lo + (63 - __clzll((long long)i64)) : lo - 1;
+                dlo[0] = d64 ? lo + (__ffsll((long long)d64) - 1) : lo;
+                dhi[0] = d64 ? lo + (63 - __clzll((long long)d64)) : lo - 1;
+            } else {
+                bm = sm_rotr<NC>(bm, lo + koff);
+                bi = sm_rotr<NC>(bi, lo + koff);
+                bd = sm_rotr<NC>(bd, lo + koff);
+                const bool hm = sm_any<NC>(bm), hi_ = sm_any<NC>(bi), hd = sm_any<NC>(bd);
+                mlo[0] = hm ? lo + sm_first<NC>(bm) : lo;
+                mhi[0] = hm ? lo + sm_last<NC>(bm) : lo - 1;
+                ilo[0] = hi_ ? lo + sm_first<NC>(bi) : lo;
+                ihi[0] = hi_ ? lo + sm_last<NC>(bi) : lo - 1;
+                dlo[0] = hd ? lo + sm_first<NC>(bd) : lo;
+                dhi[0] = hd ? lo + sm_last<NC>(bd) : lo - 1;
+            }
             LDS_WAVE_SYNC(); // every lane has read the old rows before row ms / is are overwritten
 #pragma unroll
             for (int c = 0; c < NC; c++) {
