@@ -1827,17 +1827,19 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
 #pragma unroll
             for (int r = 0; r < 2; r++) rI[r][lane + 64 * c] = rD[r][lane + 64 * c] = LM_NULL_OFF;
         }
-        // valid ranges by age in even scores: mlo[a]..mhi[a] is M[s-2a]
+        // valid ranges by age in even scores: mlo[a]..mhi[a] is M[s-2a]. An empty range is (E_LO, E_HI): far apart, so
+        // min / max unions and the unsigned range tests below need no "is it empty" cases
+        constexpr int E_LO = 1 << 28, E_HI = -(1 << 28);
         int mlo[5], mhi[5], ilo[2], ihi[2], dlo[2], dhi[2];
 #pragma unroll
         for (int a = 0; a < 5; a++) {
-            mlo[a] = 1;
-            mhi[a] = -1;
+            mlo[a] = E_LO;
+            mhi[a] = E_HI;
         }
 #pragma unroll
         for (int a = 0; a < 2; a++) {
-            ilo[a] = dlo[a] = 1;
-            ihi[a] = dhi[a] = -1;
+            ilo[a] = dlo[a] = E_LO;
+            ihi[a] = dhi[a] = E_HI;
         }
         if (max_score < 1 || arena_cap < 1) status = 1;
         mlo[0] = mhi[0] = 0;
@@ -1947,6 +1949,14 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                             if (nlo > dlo[0]) dlo[0] = nlo;
                             if (nhi < dhi[0]) dhi[0] = nhi;
                         }
+                        if (ilo[0] > ihi[0]) { // clamped away completely: the canonical empty range
+                            ilo[0] = E_LO;
+                            ihi[0] = E_HI;
+                        }
+                        if (dlo[0] > dhi[0]) {
+                            dlo[0] = E_LO;
+                            dhi[0] = E_HI;
+                        }
 #pragma unroll
                         for (int c = 0; c < NC; c++) {
                             const int slot = lane + 64 * c, k = kc[c];
@@ -1989,15 +1999,15 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
             ms = ms == 4 ? 0 : ms + 1;
             is ^= 1;
             // sources: M[s-4] (mismatch), M[s-8] (gap open), I[s-2] / D[s-2] (gap extension)
-            int lo = 2147483647, hi = -2147483647;
-            bool any = false;
-            if (mlo[2] <= mhi[2]) { any = true; lo = mlo[2] < lo ? mlo[2] : lo; hi = mhi[2] > hi ? mhi[2] : hi; }
-            if (mlo[4] <= mhi[4]) { any = true; lo = mlo[4] - 1 < lo ? mlo[4] - 1 : lo; hi = mhi[4] + 1 > hi ? mhi[4] + 1 : hi; }
-            if (ilo[1] <= ihi[1]) { any = true; lo = ilo[1] + 1 < lo ? ilo[1] + 1 : lo; hi = ihi[1] + 1 > hi ? ihi[1] + 1 : hi; }
-            if (dlo[1] <= dhi[1]) { any = true; lo = dlo[1] - 1 < lo ? dlo[1] - 1 : lo; hi = dhi[1] - 1 > hi ? dhi[1] - 1 : hi; }
-            if (!any || lo > hi) {
-                mlo[0] = ilo[0] = dlo[0] = 1;
-                mhi[0] = ihi[0] = dhi[0] = -1;
+            int lo = mlo[2] < mlo[4] - 1 ? mlo[2] : mlo[4] - 1, hi = mhi[2] > mhi[4] + 1 ? mhi[2] : mhi[4] + 1;
+            {
+                const int l2 = ilo[1] + 1 < dlo[1] - 1 ? ilo[1] + 1 : dlo[1] - 1, h2 = ihi[1] + 1 > dhi[1] - 1 ? ihi[1] + 1 : dhi[1] - 1;
+                lo = l2 < lo ? l2 : lo;
+                hi = h2 > hi ? h2 : hi;
+            }
+            if (lo > hi) { // no source wavefront (all four empty)
+                mlo[0] = ilo[0] = dlo[0] = E_LO;
+                mhi[0] = ihi[0] = dhi[0] = E_HI;
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
                     rM[ms][lane + 64 * c] = LM_NULL_OFF;
@@ -2070,31 +2080,32 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                 const unsigned long long m64 = (t1 ? bm.w[NC - 1] : bm.w[0]) >> sh;
                 const unsigned long long i64 = (t1 ? bi.w[NC - 1] : bi.w[0]) >> sh;
                 const unsigned long long d64 = (t1 ? bd.w[NC - 1] : bd.w[0]) >> sh;
-                mlo[0] = m64 ? lo + (__ffsll((long long)m64) - 1) : lo;
-                mhi[0] = m64 ? lo + (63 - __clzll((long long)m64)) : lo - 1;
-                ilo[0] = i64 ? lo + (__ffsll((long long)i64) - 1) : lo;
-                ihi[0] = i64 ? lo + (63 - __clzll((long long)i64)) : lo - 1;
-                dlo[0] = d64 ? lo + (__ffsll((long long)d64) - 1) : lo;
-                dhi[0] = d64 ? lo + (63 - __clzll((long long)d64)) : lo - 1;
+                mlo[0] = m64 ? lo + (__ffsll((long long)m64) - 1) : E_LO;
+                mhi[0] = m64 ? lo + (63 - __clzll((long long)m64)) : E_HI;
+                ilo[0] = i64 ? lo + (__ffsll((long long)i64) - 1) : E_LO;
+                ihi[0] = i64 ? lo + (63 - __clzll((long long)i64)) : E_HI;
+                dlo[0] = d64 ? lo + (__ffsll((long long)d64) - 1) : E_LO;
+                dhi[0] = d64 ? lo + (63 - __clzll((long long)d64)) : E_HI;
             } else {
                 bm = sm_rotr<NC>(bm, lo + koff);
                 bi = sm_rotr<NC>(bi, lo + koff);
                 bd = sm_rotr<NC>(bd, lo + koff);
                 const bool hm = sm_any<NC>(bm), hi_ = sm_any<NC>(bi), hd = sm_any<NC>(bd);
-                mlo[0] = hm ? lo + sm_first<NC>(bm) : lo;
-                mhi[0] = hm ? lo + sm_last<NC>(bm) : lo - 1;
-                ilo[0] = hi_ ? lo + sm_first<NC>(bi) : lo;
-                ihi[0] = hi_ ? lo + sm_last<NC>(bi) : lo - 1;
-                dlo[0] = hd ? lo + sm_first<NC>(bd) : lo;
-                dhi[0] = hd ? lo + sm_last<NC>(bd) : lo - 1;
+                mlo[0] = hm ? lo + sm_first<NC>(bm) : E_LO;
+                mhi[0] = hm ? lo + sm_last<NC>(bm) : E_HI;
+                ilo[0] = hi_ ? lo + sm_first<NC>(bi) : E_LO;
+                ihi[0] = hi_ ? lo + sm_last<NC>(bi) : E_HI;
+                dlo[0] = hd ? lo + sm_first<NC>(bd) : E_LO;
+                dhi[0] = hd ? lo + sm_last<NC>(bd) : E_HI;
             }
             LDS_WAVE_SYNC(); // every lane has read the old rows before row ms / is are overwritten
+            const uint32_t spm = (uint32_t)(mhi[0] - mlo[0]), spi = (uint32_t)(ihi[0] - ilo[0]), spd = (uint32_t)(dhi[0] - dlo[0]);
 #pragma unroll
-            for (int c = 0; c < NC; c++) {
+            for (int c = 0; c < NC; c++) { // (k - E_LO) as unsigned is above every span, also above the span of an empty range
                 const int slot = lane + 64 * c, k = kk[c];
-                rM[ms][slot] = (uint32_t)(k - mlo[0]) <= (uint32_t)(mhi[0] - mlo[0]) && mlo[0] <= mhi[0] ? vmx[c] : LM_NULL_OFF;
-                rI[is][slot] = (uint32_t)(k - ilo[0]) <= (uint32_t)(ihi[0] - ilo[0]) && ilo[0] <= ihi[0] ? vins[c] : LM_NULL_OFF;
-                rD[is][slot] = (uint32_t)(k - dlo[0]) <= (uint32_t)(dhi[0] - dlo[0]) && dlo[0] <= dhi[0] ? vdel[c] : LM_NULL_OFF;
+                rM[ms][slot] = (uint32_t)(k - mlo[0]) <= spm ? vmx[c] : LM_NULL_OFF;
+                rI[is][slot] = (uint32_t)(k - ilo[0]) <= spi ? vins[c] : LM_NULL_OFF;
+                rD[is][slot] = (uint32_t)(k - dlo[0]) <= spd ? vdel[c] : LM_NULL_OFF;
             }
         }
         __syncthreads(); // the backtrace reads what every lane stored to global memory
