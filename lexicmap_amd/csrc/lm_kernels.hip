@@ -1939,17 +1939,15 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                         }
                     }
                     if (nlo != mlo[0] || nhi != mhi[0]) {
-                        const bool hasI = ilo[0] <= ihi[0], hasD = dlo[0] <= dhi[0];
-                        const int oil = ilo[0], oih = ihi[0], odl = dlo[0], odh = dhi[0];
-                        if (hasI) {
-                            if (nlo > ilo[0]) ilo[0] = nlo;
-                            if (nhi < ihi[0]) ihi[0] = nhi;
-                        }
-                        if (hasD) {
-                            if (nlo > dlo[0]) dlo[0] = nlo;
-                            if (nhi < dhi[0]) dhi[0] = nhi;
-                        }
-                        if (ilo[0] > ihi[0]) { // clamped away completely: the canonical empty range
+                        // clamp I[s] / D[s] to the reduced M range (empty stays empty: the sentinels survive max / min) and
+                        // put NULL back into the ring cells that left a range
+                        const int oil = ilo[0], odl = dlo[0];
+                        const uint32_t oisp = (uint32_t)(ihi[0] - ilo[0]), odsp = (uint32_t)(dhi[0] - dlo[0]);
+                        ilo[0] = ilo[0] > nlo ? ilo[0] : nlo;
+                        ihi[0] = ihi[0] < nhi ? ihi[0] : nhi;
+                        dlo[0] = dlo[0] > nlo ? dlo[0] : nlo;
+                        dhi[0] = dhi[0] < nhi ? dhi[0] : nhi;
+                        if (ilo[0] > ihi[0]) {
                             ilo[0] = E_LO;
                             ihi[0] = E_HI;
                         }
@@ -1957,12 +1955,13 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                             dlo[0] = E_LO;
                             dhi[0] = E_HI;
                         }
+                        const uint32_t nmsp = (uint32_t)(nhi - nlo), nisp = (uint32_t)(ihi[0] - ilo[0]), ndsp = (uint32_t)(dhi[0] - dlo[0]);
 #pragma unroll
                         for (int c = 0; c < NC; c++) {
                             const int slot = lane + 64 * c, k = kc[c];
-                            if (inr[c] && (k < nlo || k > nhi)) rM[ms][slot] = LM_NULL_OFF;
-                            if (hasI && k >= oil && k <= oih && (k < ilo[0] || k > ihi[0])) rI[is][slot] = LM_NULL_OFF;
-                            if (hasD && k >= odl && k <= odh && (k < dlo[0] || k > dhi[0])) rD[is][slot] = LM_NULL_OFF;
+                            if (inr[c] && (uint32_t)(k - nlo) > nmsp) rM[ms][slot] = LM_NULL_OFF;
+                            if ((uint32_t)(k - oil) <= oisp && (uint32_t)(k - ilo[0]) > nisp) rI[is][slot] = LM_NULL_OFF;
+                            if ((uint32_t)(k - odl) <= odsp && (uint32_t)(k - dlo[0]) > ndsp) rD[is][slot] = LM_NULL_OFF;
                         }
                         mlo[0] = nlo;
                         mhi[0] = nhi;
