@@ -433,9 +433,12 @@ __global__ void k_task_set_woff(Task *__restrict__ tasks, int64_t ntasks, const 
 }
 
 // genome.SubSeq3 (genome.go:931-1143) + RC (:2943) — one workgroup per chain window
+// `only` (may be null): per task, > 0 when its window is needed (tasks with pseudo-alignment results: extendMatch and WFA
+// read the ASCII window, the pseudo-alignment itself takes its k-mers from the packed genome)
 __global__ void k_extract_windows(DevIndexView ix, const Task *__restrict__ tasks, int64_t ntasks,
-                                  uint8_t *__restrict__ wbuf) {
+                                  const int32_t *__restrict__ only, uint8_t *__restrict__ wbuf) {
     for (int64_t ti = blockIdx.x; ti < ntasks; ti += gridDim.x) {
+        if (only && only[ti] <= 0) continue;
         const Task t = tasks[ti];
         if (t.wlen <= 0 || t.g < 0) continue;
         const uint8_t *gb = ix.gbits + ix.g_off[t.g];
@@ -2201,9 +2204,10 @@ void launch_task_wlen(hipStream_t st, const Task *tasks, int64_t ntasks, int32_t
 void launch_task_set_woff(hipStream_t st, Task *tasks, int64_t ntasks, const int64_t *woff) {
     LM_LAUNCH_1D(k_task_set_woff, ntasks, st, tasks, ntasks, woff);
 }
-void launch_extract_windows(hipStream_t st, DevIndexView ix, const Task *tasks, int64_t ntasks, uint8_t *wbuf) {
+void launch_extract_windows(hipStream_t st, DevIndexView ix, const Task *tasks, int64_t ntasks, const int32_t *only,
+                            uint8_t *wbuf) {
     int g = (int)(ntasks < 1 ? 1 : (ntasks > 1048576 ? 1048576 : ntasks));
-    hipLaunchKernelGGL(k_extract_windows, dim3(g), dim3(256), 0, st, ix, tasks, ntasks, wbuf);
+    hipLaunchKernelGGL(k_extract_windows, dim3(g), dim3(256), 0, st, ix, tasks, ntasks, only, wbuf);
 }
 void launch_build_cmp_tab(hipStream_t st, const uint64_t *keys_cmp, const int64_t *posoff, const int32_t *nvalid, int nq,
                           int K, uint32_t *tab) {

@@ -298,6 +298,16 @@ static void sort_anchors(lm_index *ix, uint64_t *A0, uint64_t *B0, uint64_t *A1,
     sort_pairs_u64(ix, A1, A0, B1, B0, n, 0, a_bits);
 }
 
+// Same order as sort_anchors for keys whose TBegin < 2^tbits and QBegin < 2^qbits: B = QBegin:27 | (32-Len):6 | TBegin:29 |
+// 2 flags has long runs of zero bits then, which the LSD passes skip. Three ping-pong sorts: the result lands in (A1, B1).
+static void sort_anchors_fields(lm_index *ix, uint64_t *A0, uint64_t *B0, uint64_t *A1, uint64_t *B1, int64_t n, int a_bits,
+                                int qbits, int tbits) {
+    if (n <= 0) return;
+    sort_pairs_u64(ix, B0, B1, A0, A1, n, 0, std::min(31, 2 + tbits));
+    sort_pairs_u64(ix, B1, B0, A1, A0, n, 31, std::min(64, 37 + qbits));
+    sort_pairs_u64(ix, A0, A1, B0, B1, n, 0, a_bits);
+}
+
 // ---- query batch ---------------------------------------------------------------------------------------------
 } // namespace lm
 
@@ -1102,10 +1112,6 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
         HIPCHK(hipMemcpyAsync(a.tasks.p, ht.p, sizeof(Task) * nt, hipMemcpyHostToDevice, S(ix)));
         tasks_d = a.tasks.p;
     }
-    {
-        Prof p(ix, "k_extract_windows", W + W / 4);
-        launch_extract_windows(S(ix), ix->view, tasks_d, nt, wbw);
-    }
     a.stats->window_bases += W;
     // single pass: anchors appended to (A0, B0) in arbitrary order; the buffer size is a running estimate, the kernel
     // counts past it, so an undersized buffer costs one re-run
@@ -1141,9 +1147,18 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
         a.B1.ensure((size_t)a.pa_cap);
         {
             Prof p(ix, "sort_pa_anchors");
-            int abits = 1;
+            int abits = 1, qbits = 1, tbits = 1;
             while (((int64_t)1 << abits) < nt + 1) abits++;
-            sort_anchors(ix, a.A0.p, a.B0.p, a.A1.p, a.B1.p, TP, abits);
+            int maxw = 1, maxq = 1;
+            for (int64_t i = 0; i < nt; i++) maxw = std::max(maxw, ht[i].wlen);
+            for (int q = 0; q < qb->nq; q++) maxq = std::max<int>(maxq, (int)(qb->h_qoff[q + 1] - qb->h_qoff[q]));
+            while ((1 << tbits) <= maxw + 64) tbits++; // reverse-strand anchors start up to K bases past the last k-mer
+            while ((1 << qbits) <= maxq) qbits++;
+            sort_anchors_fields(ix, a.A0.p, a.B0.p, a.A1.p, a.B1.p, TP, abits, qbits, tbits);
+            std::swap(a.A0.p, a.A1.p); // the sorted list is in (A1, B1): make it (A0, B0) for what follows
+            std::swap(a.A0.cap, a.A1.cap);
+            std::swap(a.B0.p, a.B1.p);
+            std::swap(a.B0.cap, a.B1.cap);
         }
         launch_pa_task_off_sorted(S(ix), a.A0.p, TP, nt, a.pa_off.p);
         a.subs.ensure((size_t)TP);
@@ -1162,6 +1177,10 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
             Prof p(ix, "k_pa_chain", TP * 32);
             launch_pa_chain(S(ix), a.B0.p, a.pa_off.p, nt, ix->host.k, o2, a.subs.p, a.marks.p, a.msi.p, a.stack.p,
                             a.out.p, a.out_n.p, a.clr_n.p);
+        }
+        {   // ASCII windows only for the tasks that produced chains: extendMatch / WFA are the only readers
+            Prof p(ix, "k_extract_windows", W / 4);
+            launch_extract_windows(S(ix), ix->view, tasks_d, nt, a.out_n.p, wbw);
         }
         a.res_off.ensure((size_t)nt + 2);
         int64_t NR = scan_to_i64<int32_t, CastI32>(ix, a.out_n.p, nt, a.res_off.p);
