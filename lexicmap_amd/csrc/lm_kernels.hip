@@ -530,8 +530,7 @@ __device__ __forceinline__ PaCtx pa_ctx(const Task &t, const uint64_t *keys_cmp,
 // the expensive path is never executed by a wavefront for the sake of one lane. Anchors are staged in LDS and appended
 // to the global list with one atomic per flush; their order is irrelevant because the list is sorted by (task, B)
 // afterwards. `count` keeps counting past `cap`, so the host can re-run with a larger buffer.
-#define PA_RUN 4    /* consecutive window positions per thread */
-#define PA_QCAP 4096 /* work list: >= 2 * 512 * PA_RUN */
+#define PA_QCAP 2048
 #define PA_OCAP 2048
 __global__ __launch_bounds__(256) void k_pa_anchors(DevIndexView ix, const Task *__restrict__ tasks, int64_t ntasks,
                                                      const uint8_t *__restrict__ wbuf,
@@ -626,63 +625,29 @@ __global__ __launch_bounds__(256) void k_pa_anchors(DevIndexView ix, const Task 
             if (tid == 0) q_n = 0;
             __syncthreads();
         };
-        auto consider = [&](int i, uint64_t kmer, uint64_t rc) { // the cheap per-position part
-            if (kmer == 0 || kmer == c.ccc || kmer == c.ggg || kmer == c.ttt) return;
+        for (int tile = 0; tile < npos; tile += 256) {
+            const int i = tile + tid;
+            if (i < npos) {
+                uint64_t kmer, rc;
+                pa_kmer(t, w, gb, goff, i, K, &kmer, &rc);
+                if (!(kmer == 0 || kmer == c.ccc || kmer == c.ggg || kmer == c.ttt)) {
 #pragma unroll
-            for (int strand = 0; strand < 2; strand++) {
-                const uint64_t key = strand ? rc : kmer;
-                bool cand = true;
-                if (use_bits) {
-                    const uint32_t pfx = (uint32_t)(key >> ((K << 1) - LM_PFX_BITS));
-                    cand = ((c.bits[pfx >> 5] >> (pfx & 31)) & 1u) != 0 || ((key >> sh) & tail_mask) == 0;
-                }
-                if (cand) {
-                    const int slot = atomicAdd(&q_n, 1);
-                    if (slot < PA_QCAP) q_item[slot] = ((uint32_t)i << 1) | (uint32_t)strand;
-                }
-            }
-        };
-        // every thread takes PA_RUN consecutive positions: two k-mer extractions (first and last of the run) give the
-        // others by shifting in one base, and the reverse complements roll the same way
-        for (int tile = 0; tile < npos; tile += 256 * PA_RUN) {
-            const int i0 = tile + tid * PA_RUN;
-            if (i0 < npos) {
-                if (gb) {
-                    // genome positions of the run, ascending: window i0+j <-> p0+j (forward) or p0+PA_RUN-1-j (reverse)
-                    const int p0 = t.rc ? t.tBegin + t.wlen - K - i0 - (PA_RUN - 1) : t.tBegin + i0;
-                    uint64_t G[PA_RUN], R[PA_RUN];
-                    const uint64_t kmask = lm_kmer_mask(K);
-                    // a reverse-strand run at the very start of the genome may begin before base 0: extract per k-mer then
-                    if (p0 >= 0) {
-                        G[0] = kmer_from_bits(gb, goff, p0, K);
-                        G[PA_RUN - 1] = kmer_from_bits(gb, goff, p0 + PA_RUN - 1, K);
-#pragma unroll
-                        for (int j = 1; j < PA_RUN - 1; j++)
-                            G[j] = ((G[j - 1] << 2) | ((G[PA_RUN - 1] >> ((PA_RUN - 1 - j) << 1)) & 3ull)) & kmask;
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < PA_RUN; j++) G[j] = p0 + j >= 0 ? kmer_from_bits(gb, goff, p0 + j, K) : 0ull;
-                    }
-                    R[0] = lm_revcomp(G[0], K);
-#pragma unroll
-                    for (int j = 1; j < PA_RUN; j++) R[j] = (R[j - 1] >> 2) | ((3ull - (G[j] & 3ull)) << ((K - 1) << 1));
-#pragma unroll
-                    for (int j = 0; j < PA_RUN; j++) {
-                        const int i = i0 + j;
-                        if (i >= npos) break;
-                        const int gj = t.rc ? PA_RUN - 1 - j : j;
-                        consider(i, t.rc ? R[gj] : G[gj], t.rc ? G[gj] : R[gj]);
-                    }
-                } else {
-                    for (int j = 0; j < PA_RUN && i0 + j < npos; j++) {
-                        uint64_t kmer, rc;
-                        pa_kmer(t, w, gb, goff, i0 + j, K, &kmer, &rc);
-                        consider(i0 + j, kmer, rc);
+                    for (int strand = 0; strand < 2; strand++) {
+                        const uint64_t key = strand ? rc : kmer;
+                        bool cand = true;
+                        if (use_bits) {
+                            const uint32_t pfx = (uint32_t)(key >> ((K << 1) - LM_PFX_BITS));
+                            cand = ((c.bits[pfx >> 5] >> (pfx & 31)) & 1u) != 0 || ((key >> sh) & tail_mask) == 0;
+                        }
+                        if (cand) {
+                            const int slot = atomicAdd(&q_n, 1);
+                            if (slot < PA_QCAP) q_item[slot] = ((uint32_t)i << 1) | (uint32_t)strand;
+                        }
                     }
                 }
             }
             __syncthreads();
-            if (q_n > PA_QCAP - 512 * PA_RUN) drain(); // at most 512*PA_RUN new items per tile: the list never overflows
+            if (q_n > PA_QCAP - 512) drain(); // at most 512 new items per tile: the list never overflows
         }
         drain();
         flush();
