@@ -1,16 +1,19 @@
 // lm_kernels.hip — gfx950 kernels of the `lexicmap search` hot path.
 //
-// Work decomposition (DESIGN.md §kernels):
-//   k_extract_kmers   one lane per query position       -> 2-bit k-mers of both strands (+ filtered copy)
-//   k_mask            one lane per (query, mask)         -> LexicHash capture over the sorted k-mer array
-//   k_lookup_count/emit one lane per (query, mask, dir)  -> prefix/suffix range query in the HBM seed arrays
-//   k_chain1          one lane per (query, genome)       -> ClearSubstrPairs + Chainer.Chain
-//   k_make_tasks      one lane per (query, genome)       -> chain windows
-//   k_extract_windows one workgroup per chain            -> 2-bit genome -> ASCII window (rc applied)
-//   k_pa_count/emit   one workgroup per chain            -> SeqComparator.Compare anchor generation
-//   k_pa_chain        one lane per chain                 -> Clear + Trim + Chainer2
-//   k_extend_count/k_extend one lane per HSP             -> extendMatch
-//   k_wfa             one lane per HSP                   -> WFA + backtrace + BLAST-style score
+// Work decomposition (DESIGN.md §4):
+//   k_extract_kmers     one lane per query position          -> 2-bit k-mers of both strands (+ filtered copy)
+//   k_build_cmp_tab/bits per query                           -> bucket table + 8-base prefix bitmap of the filtered k-mers
+//   k_mask              one lane per (query, mask)           -> LexicHash capture over the sorted k-mer array
+//   k_lookup_prep/count/emit one lane per (query, mask, dir) -> prefix/suffix range query in the HBM seed arrays,
+//                                                               in seed-list order, sampled top array first
+//   k_chain1            one lane per (query, genome)         -> ClearSubstrPairs + Chainer.Chain
+//   k_make_tasks        one lane per (query, genome)         -> chain windows
+//   k_pa_anchors        one workgroup per chain window       -> SeqComparator.Compare anchor generation
+//   k_pa_chain_wave     one wavefront per chain              -> Clear + Trim + Chainer2
+//   k_extract_windows   one workgroup per chain with results -> 2-bit genome -> ASCII window (rc applied)
+//   k_extend_count/k_extend/k_extend_fin one lane per HSP flank -> extendMatch (Chainer3 on the (q,t) grid)
+//   k_wfa_lean<2>       persistent wavefronts, queue of HSPs -> WFA + backtrace + statistics + BLAST-style score
+//   k_wfa_wave          one wavefront per HSP                -> the same with a global-memory ring (fallback)
 // Radix sorts / scans / run-length encodes between kernels are rocPRIM device primitives (plumbing).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -671,41 +674,6 @@ __global__ void k_pa_task_off_sorted(const uint64_t *__restrict__ sortedA, int64
 
 
 // Clear + Trim + Chainer2 per chain (lib-seq_compare.go:447-508)
-__global__ void k_pa_chain(const uint64_t *__restrict__ B, const int64_t *__restrict__ pa_off, int64_t ntasks, int K,
-                           LmChain2Opt opt, LmSub *__restrict__ subs, uint8_t *__restrict__ marks,
-                           uint64_t *__restrict__ msi, int32_t *__restrict__ stack, LmChain2 *__restrict__ out,
-                           int32_t *__restrict__ out_n, int32_t *__restrict__ clr_n) {
-    for (int64_t ti = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ti < ntasks; ti += (int64_t)gridDim.x * blockDim.x) {
-        int64_t o = pa_off[ti];
-        int n = (int)(pa_off[ti + 1] - o);
-        int nout = 0;
-        if (n > 0) {
-            LmSub *sb = subs + o;
-            for (int i = 0; i < n; i++) sb[i] = lm_unpack_anchor(B[o + i]);
-            if (n > 1) n = lm_clear_sorted(sb, n, K, marks + o);
-            int start = 0;
-            n = lm_trim(sb, n, 100.0f, &start);
-            clr_n[ti] = n;
-            if (n > 0) {
-                LmChain2 *res = out + o;
-                nout = lm_run_chain2(sb + start, n, opt, msi + o, stack + 2 * o + 4 * ti, res);
-                // "very important": sort by QBegin (:501-508), stable
-                for (int i = 1; i < nout; i++) {
-                    LmChain2 x = res[i];
-                    int j = i - 1;
-                    while (j >= 0 && res[j].qbegin > x.qbegin) {
-                        res[j + 1] = res[j];
-                        j--;
-                    }
-                    res[j + 1] = x;
-                }
-            }
-        } else {
-            clr_n[ti] = 0;
-        }
-        out_n[ti] = nout;
-    }
-}
 
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1143,43 +1111,6 @@ __global__ void k_extend_fin(const HspIn *__restrict__ hsps, int64_t n, HspExt *
 
 // ------------------------------------------------------------------------------------------------------------
 // WFA + BLAST-style score (lib-index-search-util.go:260-304: 2/-3/5/2 over the M-trimmed ops)
-__global__ void k_wfa(const WfaIn *__restrict__ in, int64_t n, const int32_t *__restrict__ todo, int64_t ntodo,
-                      int32_t *__restrict__ hdr_pool, int32_t *__restrict__ arena_pool, uint64_t *__restrict__ ops_pool,
-                      WfaOut *__restrict__ out) {
-    for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < ntodo; x += (int64_t)gridDim.x * blockDim.x) {
-        int64_t i = todo ? todo[x] : x;
-        if (i >= n) continue;
-        const WfaIn w = in[i];
-        LmWfaOut r;
-        lm_wfa_align(w.q, w.qlen, w.t, w.tlen, hdr_pool + w.hdr_off, w.max_score, arena_pool + w.arena_off, w.arena_cap,
-                     ops_pool + w.ops_off, w.ops_cap, &r);
-        WfaOut o;
-        o.r = r;
-        o.blast_score = 0;
-        if (r.status == 0) {
-            const uint64_t *ops = ops_pool + w.ops_off;
-            int first = -1, last = -1;
-            for (int j = 0; j < r.nops; j++)
-                if ((ops[j] >> 32) == 'M') {
-                    if (first < 0) first = j;
-                    last = j;
-                }
-            int score = 0;
-            for (int j = first; j >= 0 && j <= last; j++) {
-                int nn = (int)(ops[j] & 0xffffffffu);
-                char op = (char)(ops[j] >> 32);
-                if (op == 'M')
-                    score += nn * 2;
-                else if (op == 'X')
-                    score += nn * -3;
-                else
-                    score -= 5 + nn * 2;
-            }
-            o.blast_score = score;
-        }
-        out[i] = o;
-    }
-}
 
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1458,27 +1389,6 @@ __global__ __launch_bounds__(64) void k_wfa_wave(const WfaIn *__restrict__ in, i
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
     } while (0)
 
-// BLAST-style score of the M-trimmed CIGAR (lib-index-search-util.go:260-304: 2/-3/5/2)
-__device__ __forceinline__ int blast_score_of(const uint64_t *ops, int nops) {
-    int first = -1, last = -1;
-    for (int j = 0; j < nops; j++)
-        if ((ops[j] >> 32) == 'M') {
-            if (first < 0) first = j;
-            last = j;
-        }
-    int score = 0;
-    for (int j = first; j >= 0 && j <= last; j++) {
-        int nn = (int)(ops[j] & 0xffffffffu);
-        char op = (char)(ops[j] >> 32);
-        if (op == 'M')
-            score += nn * 2;
-        else if (op == 'X')
-            score += nn * -3;
-        else
-            score -= 5 + nn * 2;
-    }
-    return score;
-}
 
 // 16 bases -> one 32-bit word, first base in the top bits. Any injective 2-bit code works for equality tests:
 // (c >> 1) & 3 maps A,C,T,G to 0,1,2,3. *bad is raised for any other byte (the caller falls back to byte compares).
@@ -2287,11 +2197,6 @@ void launch_wfa_wide(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *
                      int32_t *arena_pool, uint64_t *ops_pool, WfaOut *out) {
     int g = (int)(ntodo < 1 ? 1 : (ntodo > 65536 ? 65536 : ntodo));
     hipLaunchKernelGGL(k_wfa_wave, dim3(g), dim3(64), 0, st, in, n, todo, ntodo, hdr_pool, arena_pool, ops_pool, out);
-}
-void launch_wfa_lane(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int32_t *hdr_pool,
-                     int32_t *arena_pool, uint64_t *ops_pool, WfaOut *out) {
-    hipLaunchKernelGGL(k_wfa, dim3(grid_for(ntodo, 64)), dim3(64), 0, st, in, n, todo, ntodo, hdr_pool, arena_pool, ops_pool,
-                       out);
 }
 
 } // namespace lm
