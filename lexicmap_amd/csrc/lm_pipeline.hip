@@ -1343,8 +1343,9 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
         // wide or has drifted); what outgrows it goes to the global-memory kernel below
         std::vector<int32_t> wide2;
         persistent_pass(order, wide2);
-        for (int32_t i : wide2) { // wider than 128 diagonals, longer than the LDS buffers, or not plain ACGT
+        for (int32_t i : wide2) { // wider than 126 diagonals, longer than the LDS buffers, or not plain ACGT
             is_wide[i] = 1;
+            level[i] = 2; // these are the hard ones: generous scratch at once instead of an overflow and a second launch
             todo.push_back(i);
         }
     }
@@ -1559,6 +1560,7 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
                 i = e;
             }
             const int64_t ns = (int64_t)active.size();
+            const double tg0 = now_ms();
             std::vector<HGenome> gens((size_t)ns);
             std::vector<int32_t> nh((size_t)ns + 1, 0); // HSPs per segment
             (void)div_from_pseudo_pident(0);            // builds its table before the threads use it
@@ -1601,6 +1603,7 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
                     nh[si] = cnt;
                 }
             });
+            const double tg1 = now_ms();
             std::vector<int64_t> hbase((size_t)ns + 1, 0);
             for (int64_t si = 0; si < ns; si++) hbase[si + 1] = hbase[si] + nh[si];
             hsps.resize((size_t)hbase[ns]);
@@ -1651,9 +1654,13 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
                     }
                 }
             });
+            const double tg2 = now_ms();
             genomes.reserve(genomes.size() + (size_t)ns);
             for (int64_t si = 0; si < ns; si++)
                 if (!gens[si].sds.empty()) genomes.push_back(std::move(gens[si]));
+            if (getenv("LM_DEBUG"))
+                fprintf(stderr, "[lm] glue: active scan %.2f, glue_task pass %.2f, hsp fill %.2f, move %.2f ms (%lld genomes)\n",
+                        tg0 - tb, tg1 - tg0, tg2 - tg1, now_ms() - tg2, (long long)ns);
         }
         double tc = now_ms();
         st.ms_glue += tc - tb;
