@@ -366,6 +366,24 @@ def main():
                                  "the oracle writer (~%d genome hits/query instead of ~%d in the GPU run, so this CPU "
                                  "number is an upper bound for the full index)" %
                                  (args.cpu_sample_genomes, args.cpu_sample_genomes, wl["genomes"] // wl["families"]))
+            if cpu_queries is not None:
+                # the same sample (same index directory, same queries) through the HIP path: a like-for-like pair of numbers
+                try:
+                    g2 = la.Index(index_dir, device=local_rank)
+                    qb2 = g2.upload([q[1] for q in cpu_queries])
+                    g2.search_resident_np(qb2)
+                    torch.cuda.synchronize()
+                    t1 = time.time()
+                    reps = 5
+                    for _ in range(reps):
+                        r2, _s2 = g2.search_resident_np(qb2)
+                    torch.cuda.synchronize()
+                    cb["gpu_on_same_sample"] = dict(value=round(len(cpu_queries) * reps / (time.time() - t1), 1),
+                                                    unit="queries/s", rows_per_pass=int(len(r2)))
+                    g2.free_batch(qb2)
+                    g2.close()
+                except Exception as e:
+                    cb["gpu_on_same_sample"] = "failed: %r" % (e,)
             result["cpu_baseline"] = cb
         except Exception as e:  # the baseline must not kill the bench line
             result["cpu_baseline"] = dict(value=None, unit="queries/s", cores=0, kind="port", sample="failed: %r" % (e,))
