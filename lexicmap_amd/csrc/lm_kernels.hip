@@ -505,6 +505,29 @@ __device__ __forceinline__ void pa_kmer(const Task &t, const uint8_t *__restrict
     }
 }
 
+// The first P bases (P <= 16) of the window k-mer at position i and of its reverse complement, straight from the packed
+// genome: all the per-position test of k_pa_anchors needs (8-base bitmap prefix + the bases [7, P) of the
+// partial-prefix rule). About half the arithmetic of building both full k-mers.
+__device__ __forceinline__ uint32_t revcomp_small(uint32_t x, int P) { // P bases in the low 2P bits
+    uint32_t y = __builtin_bitreverse32(~x);
+    y = ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
+    return y >> (32 - 2 * P);
+}
+__device__ __forceinline__ void pa_prefixes(const Task &t, const uint8_t *__restrict__ gbits, int64_t goff, int i, int K,
+                                            int P, uint32_t *fwd, uint32_t *rc) {
+    const int pos = t.rc ? t.tBegin + t.wlen - K - i : t.tBegin + i;
+    const int64_t byte = goff + (pos >> 2);
+    const uint64_t *p = (const uint64_t *)(gbits + (byte & ~7ll));
+    const uint64_t H = __builtin_bswap64(p[0]), L = __builtin_bswap64(p[1]);
+    const int o = (int)(byte & 7) * 8 + (pos & 3) * 2; // 0..62
+    const uint64_t v = o ? ((H << o) | (L >> (64 - o))) : H; // 32 bases from `pos`, left aligned
+    const uint32_t first = (uint32_t)(v >> (64 - 2 * P));
+    const uint32_t last = (uint32_t)(v >> (64 - 2 * K)) & ((1u << (2 * P)) - 1u);
+    const uint32_t rl = revcomp_small(last, P);
+    *fwd = t.rc ? rl : first;
+    *rc = t.rc ? first : rl;
+}
+
 __device__ __forceinline__ PaCtx pa_ctx(const Task &t, const uint64_t *keys_cmp, const uint32_t *vals_cmp,
                                         const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_tab,
                                         const uint32_t *cmp_bits, int K, int min_prefix) {
@@ -559,6 +582,7 @@ __global__ __launch_bounds__(256) void k_pa_anchors(DevIndexView ix, const Task 
         const int p = c.m > K ? K : c.m;
         const int sh = (K - p) << 1;
         const bool use_bits = c.bits != nullptr && p > 8 && 2 * K >= LM_PFX_BITS;
+        const bool fast_pfx = use_bits && gb != nullptr && p <= 15 && K >= 16;
         const uint64_t tail_mask = p > 7 ? ((p - 7) >= 32 ? ~0ull : ((1ull << ((p - 7) << 1)) - 1ull)) : 0ull; // bases [7,p)
         if (tid == 0) {
             q_n = 0;
@@ -604,8 +628,9 @@ __global__ __launch_bounds__(256) void k_pa_anchors(DevIndexView ix, const Task 
                     uint64_t kmer, rc;
                     pa_kmer(t, w, gb, goff, i, K, &kmer, &rc);
                     const uint64_t key = rcs ? rc : kmer;
+                    const bool lowc = kmer == 0 || kmer == c.ccc || kmer == c.ggg || kmer == c.ttt; // lib-seq_compare.go:374
                     int lo, hi;
-                    if (lm_tree_search_range_tab(c.keys, c.n, key, c.m, K, c.tab, LM_TAB_BITS, &lo, &hi)) {
+                    if (!lowc && lm_tree_search_range_tab(c.keys, c.n, key, c.m, K, c.tab, LM_TAB_BITS, &lo, &hi)) {
                         for (int j = lo; j < hi; j++) {
                             const uint32_t v = c.vals[j];
                             const uint32_t lp = (uint32_t)lm_lcp(c.keys[j], key, K);
@@ -630,7 +655,20 @@ __global__ __launch_bounds__(256) void k_pa_anchors(DevIndexView ix, const Task 
         };
         for (int tile = 0; tile < npos; tile += 256) {
             const int i = tile + tid;
-            if (i < npos) {
+            if (i < npos && fast_pfx) {
+                // prefixes only; the low-complexity filter (which needs the whole k-mer) is applied in drain()
+                uint32_t pf[2];
+                pa_prefixes(t, gb, goff, i, K, p, &pf[0], &pf[1]);
+#pragma unroll
+                for (int strand = 0; strand < 2; strand++) {
+                    const uint32_t pfx = pf[strand] >> (2 * (p - 8));
+                    const bool cand = ((c.bits[pfx >> 5] >> (pfx & 31)) & 1u) != 0 || (pf[strand] & ((1u << (2 * (p - 7))) - 1u)) == 0;
+                    if (cand) {
+                        const int slot = atomicAdd(&q_n, 1);
+                        if (slot < PA_QCAP) q_item[slot] = ((uint32_t)i << 1) | (uint32_t)strand;
+                    }
+                }
+            } else if (i < npos) {
                 uint64_t kmer, rc;
                 pa_kmer(t, w, gb, goff, i, K, &kmer, &rc);
                 if (!(kmer == 0 || kmer == c.ccc || kmer == c.ggg || kmer == c.ttt)) {
