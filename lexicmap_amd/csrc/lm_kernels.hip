@@ -556,7 +556,8 @@ __device__ __forceinline__ PaCtx pa_ctx(const Task &t, const uint64_t *keys_cmp,
 // the expensive path is never executed by a wavefront for the sake of one lane. Anchors are staged in LDS and appended
 // to the global list with one atomic per flush; their order is irrelevant because the list is sorted by (task, B)
 // afterwards. `count` keeps counting past `cap`, so the host can re-run with a larger buffer.
-#define PA_QCAP 2048
+#define PA_UNROLL 2 /* window positions per thread between two barriers */
+#define PA_QCAP 2048 /* >= 2 * 512 * PA_UNROLL */
 #define PA_OCAP 2048
 __global__ __launch_bounds__(256) void k_pa_anchors(DevIndexView ix, const Task *__restrict__ tasks, int64_t ntasks,
                                                      const uint8_t *__restrict__ wbuf,
@@ -653,25 +654,47 @@ __global__ __launch_bounds__(256) void k_pa_anchors(DevIndexView ix, const Task 
             if (tid == 0) q_n = 0;
             __syncthreads();
         };
-        for (int tile = 0; tile < npos; tile += 256) {
-            const int i = tile + tid;
-            if (i < npos && fast_pfx) {
+        // PA_UNROLL positions per thread and barrier: their loads are independent and in flight together (this kernel
+        // waits on memory and on the barrier most of the time)
+        for (int tile = 0; tile < npos; tile += 256 * PA_UNROLL) {
+            if (fast_pfx) {
                 // prefixes only; the low-complexity filter (which needs the whole k-mer) is applied in drain()
-                uint32_t pf[2];
-                pa_prefixes(t, gb, goff, i, K, p, &pf[0], &pf[1]);
+                uint32_t pf[PA_UNROLL][2];
 #pragma unroll
-                for (int strand = 0; strand < 2; strand++) {
-                    const uint32_t pfx = pf[strand] >> (2 * (p - 8));
-                    const bool cand = ((c.bits[pfx >> 5] >> (pfx & 31)) & 1u) != 0 || (pf[strand] & ((1u << (2 * (p - 7))) - 1u)) == 0;
-                    if (cand) {
-                        const int slot = atomicAdd(&q_n, 1);
-                        if (slot < PA_QCAP) q_item[slot] = ((uint32_t)i << 1) | (uint32_t)strand;
+                for (int u = 0; u < PA_UNROLL; u++) {
+                    const int i = tile + u * 256 + tid;
+                    pf[u][0] = pf[u][1] = 0xffffffffu;
+                    if (i < npos) pa_prefixes(t, gb, goff, i, K, p, &pf[u][0], &pf[u][1]);
+                }
+                uint32_t word[PA_UNROLL][2];
+#pragma unroll
+                for (int u = 0; u < PA_UNROLL; u++)
+#pragma unroll
+                    for (int strand = 0; strand < 2; strand++) {
+                        const uint32_t pfx = (pf[u][strand] >> (2 * (p - 8))) & ((1u << LM_PFX_BITS) - 1u);
+                        word[u][strand] = c.bits[pfx >> 5];
+                    }
+#pragma unroll
+                for (int u = 0; u < PA_UNROLL; u++) {
+                    const int i = tile + u * 256 + tid;
+                    if (i >= npos) continue;
+#pragma unroll
+                    for (int strand = 0; strand < 2; strand++) {
+                        const uint32_t pfx = pf[u][strand] >> (2 * (p - 8));
+                        const bool cand = ((word[u][strand] >> (pfx & 31)) & 1u) != 0 || (pf[u][strand] & ((1u << (2 * (p - 7))) - 1u)) == 0;
+                        if (cand) {
+                            const int slot = atomicAdd(&q_n, 1);
+                            if (slot < PA_QCAP) q_item[slot] = ((uint32_t)i << 1) | (uint32_t)strand;
+                        }
                     }
                 }
-            } else if (i < npos) {
-                uint64_t kmer, rc;
-                pa_kmer(t, w, gb, goff, i, K, &kmer, &rc);
-                if (!(kmer == 0 || kmer == c.ccc || kmer == c.ggg || kmer == c.ttt)) {
+            } else {
+                for (int u = 0; u < PA_UNROLL; u++) {
+                    const int i = tile + u * 256 + tid;
+                    if (i >= npos) continue;
+                    uint64_t kmer, rc;
+                    pa_kmer(t, w, gb, goff, i, K, &kmer, &rc);
+                    if (kmer == 0 || kmer == c.ccc || kmer == c.ggg || kmer == c.ttt) continue;
 #pragma unroll
                     for (int strand = 0; strand < 2; strand++) {
                         const uint64_t key = strand ? rc : kmer;
@@ -688,7 +711,7 @@ __global__ __launch_bounds__(256) void k_pa_anchors(DevIndexView ix, const Task 
                 }
             }
             __syncthreads();
-            if (q_n > PA_QCAP - 512) drain(); // at most 512 new items per tile: the list never overflows
+            if (q_n > PA_QCAP - 512 * PA_UNROLL) drain(); // at most 512*PA_UNROLL new items per pass: the list never overflows
         }
         drain();
         flush();
