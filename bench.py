@@ -35,7 +35,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=3)
     p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--workload", default=os.environ.get("LM_BENCH_WORKLOAD", "c2"), choices=["c2", "small", "tiny"])
+    p.add_argument("--workload", default=os.environ.get("LM_BENCH_WORKLOAD", "c2"), choices=["c2", "small", "tiny", "c3mini"])
     p.add_argument("--queries", type=int, default=0, help="override the number of queries")
     p.add_argument("--genomes", type=int, default=0, help="override the number of genomes")
     p.add_argument("--genome-len", type=int, default=0)
@@ -57,6 +57,9 @@ WORKLOADS = {
     # scaled-down shapes for development (NOT the headline config)
     "small": dict(genomes=200, genome_len=500_000, families=4, queries=1000, qlen=(1000, 2000)),
     "tiny": dict(genomes=24, genome_len=100_000, families=4, queries=64, qlen=(300, 1500)),
+    # shape of BASELINE.json configs[2] (ONT-style long reads, chaining + WFA stress) at a size that builds in seconds;
+    # a robustness run, not a headline number
+    "c3mini": dict(genomes=2000, genome_len=5_000_000, families=40, queries=500, qlen=(5000, 50000)),
 }
 
 
@@ -166,7 +169,7 @@ def main():
     from lexicmap_amd import synth
 
     if args.builder is None:
-        args.builder = "gpu" if args.workload == "c2" else "oracle"
+        args.builder = "gpu" if args.workload in ("c2", "c3mini") else "oracle"
     wl = dict(WORKLOADS[args.workload])
     if args.queries:
         wl["queries"] = args.queries
