@@ -42,6 +42,10 @@ def parse():
     p.add_argument("--shard", default="queries", choices=["queries", "index"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
+    p.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                   help="N>1 with --shard queries: weak = every GPU searches its own batch of the workload's size (the "
+                        "queries are independent units: no data-path collective, only the final row gather); strong = "
+                        "the one batch is divided over the GPUs")
     p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                    help="nccl = RCCL (one GPU per rank); gloo only to exercise the N>1 logic with ranks sharing a GPU")
     p.add_argument("--builder", default=None, choices=["gpu", "oracle"],
@@ -185,6 +189,7 @@ def main():
     if args.shard == "index" and world > 1:
         opt_kw = dict(shard_rank=rank, shard_count=world)
     gpu_built = args.builder == "gpu"
+    weak = world > 1 and args.shard == "queries" and args.scaling == "weak"
     cpu_queries = None
     if gpu_built:
         # synthetic genomes + index generated directly in HBM by the GPU builder (no disk): the only way to have the
@@ -208,14 +213,17 @@ def main():
                 out.append(("q%05d" % i, q.tobytes()))
             return out
 
-        if rank == 0:
-            queries = draw_queries(np.random.default_rng(2000), wl["queries"], np.arange(nloc))
+        if weak:
+            queries = draw_queries(np.random.default_rng(2000 + rank), wl["queries"], np.arange(nloc))  # this GPU's own batch
         else:
-            queries = None
-        if world > 1:
-            box = [queries]
-            dist.broadcast_object_list(box, src=0)
-            queries = box[0]
+            if rank == 0:
+                queries = draw_queries(np.random.default_rng(2000), wl["queries"], np.arange(nloc))
+            else:
+                queries = None
+            if world > 1:
+                box = [queries]
+                dist.broadcast_object_list(box, src=0)
+                queries = box[0]
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             # CPU-baseline sample: the first members of family 0 are fetched back from HBM and indexed by the ORACLE's
             # writer (reference on-disk format); sample queries are drawn from them with the same generator.
@@ -239,7 +247,8 @@ def main():
             O.build_index(index_dir, genomes, O.default_build_opt(chunks=8))
         if world > 1:
             dist.barrier()
-        queries = synth.make_gene_queries(genomes, wl["queries"], seed=2000, len_range=wl["qlen"], max_div=0.10)
+        queries = synth.make_gene_queries(genomes, wl["queries"], seed=2000 + (rank if weak else 0), len_range=wl["qlen"],
+                                          max_div=0.10)
         if opt_kw:
             whole_bases = sum(sum(len(c[1]) for c in g[1]) for g in genomes)
             opt_kw["total_bases_override"] = whole_bases
@@ -248,7 +257,9 @@ def main():
     log("[rank %d] index ready in %.1f s: %s" % (rank, time.time() - t_setup, info))
 
     # queries of this rank
-    if args.shard == "queries" and world > 1:
+    if weak:
+        my = queries
+    elif args.shard == "queries" and world > 1:
         my = [q for i, q in enumerate(queries) if i % world == rank]
     else:
         my = queries
@@ -264,7 +275,10 @@ def main():
         if world > 1:
             if args.shard == "queries":
                 rows = rows.copy()  # the array is a view of the library's result
-                rows["query"] = rows["query"] * world + rank  # local -> global query number (round-robin sharding)
+                if weak:
+                    rows["query"] = rows["query"] + rank * len(queries)  # every rank has its own batch
+                else:
+                    rows["query"] = rows["query"] * world + rank  # local -> global query number (round-robin sharding)
             per_rank = merge.all_gather_rows(rows, device="cuda" if args.dist_backend == "nccl" else "cpu")
             rows = merge.merge_sharded(per_rank) if args.shard == "index" else merge.merge_query_sharded(per_rank)
         return rows, st
@@ -299,7 +313,7 @@ def main():
         pass
     rows_total, aligned_total = int(len(rows_np)), int(rows_np["aligned_length"].sum())
 
-    nq_total = len(queries)
+    nq_total = len(queries) * (world if weak else 1)
     value = nq_total * args.steps / dt
     result = None
     if rank == 0:
@@ -339,7 +353,8 @@ def main():
             "metric": "queries/sec (lexicmap search hot path, seed index HBM-resident)",
             "value": round(value, 3), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "strong",  # the query batch and the index are fixed as N grows (queries or genomes are divided)
+            # weak: every GPU searches its own batch of the workload's size; strong: one batch (or the index) is divided
+            "scaling": "weak" if weak else "strong",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "gbp_aligned_per_s": round(aligned_total * args.steps / dt / 1e9 * (1 if world == 1 else 1), 6),
             "config": {"workload": "%s: %d gene queries (%d-%d bp, <=10%% divergence) vs %d synthetic genomes x %d bp "
@@ -348,7 +363,8 @@ def main():
                                     wl["families"], info["masks"], info["k"],
                                     "GPU-built in HBM" if gpu_built else "oracle-built, loaded from the reference format"),
                        "seeds_resident": info["seeds"], "index_hbm_bytes": info["hbm_bytes"], "parallelism":
-                           ("q-shard x%d (index replicated)" % world) if args.shard == "queries" else ("index-shard x%d" % world),
+                           (("q-shard x%d (index replicated), %d queries per GPU" % (world, len(my))) if args.shard == "queries"
+                            else ("index-shard x%d" % world)),
                        "go_toolchain": go or "absent (reference Go binary cannot be built; CPU baseline is the C port)"},
             "stage_ms": {k: round(v, 3) for k, v in stats.items() if k.startswith("ms_")},
             "work": {k: v for k, v in stats.items() if not k.startswith("ms_")},
