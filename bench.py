@@ -354,7 +354,7 @@ def main():
             "value": round(value, 3), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             # weak: every GPU searches its own batch of the workload's size; strong: one batch (or the index) is divided
-            "scaling": "weak" if weak else "strong",
+            "scaling": "weak" if (weak or (world == 1 and args.shard == "queries" and args.scaling == "weak")) else "strong",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "gbp_aligned_per_s": round(aligned_total * args.steps / dt / 1e9 * (1 if world == 1 else 1), 6),
             "config": {"workload": "%s: %d gene queries (%d-%d bp, <=10%% divergence) vs %d synthetic genomes x %d bp "
