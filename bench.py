@@ -279,7 +279,7 @@ def main():
                     rows["query"] = rows["query"] + rank * len(queries)  # every rank has its own batch
                 else:
                     rows["query"] = rows["query"] * world + rank  # local -> global query number (round-robin sharding)
-            per_rank = merge.all_gather_rows(rows, device="cuda" if args.dist_backend == "nccl" else "cpu")
+            per_rank = merge.all_gather_rows(rows, device="cuda" if args.dist_backend == "nccl" else "cpu", host_on=0)
             rows = merge.merge_sharded(per_rank) if args.shard == "index" else merge.merge_query_sharded(per_rank)
         return rows, st
 

@@ -41,9 +41,15 @@ def _cat(parts):
     return out
 
 
-def all_gather_rows(arr, device="cpu"):
+_PINNED = None  # grow-only pinned staging buffer for the gathered rows (GPU path)
+
+
+def all_gather_rows(arr, device="cpu", host_on=None):
     """all-gatherv of row records: sizes first, then one all-gather of padded payloads (RCCL on GPUs).
-    Returns the list of per-rank arrays."""
+    Returns the list of per-rank arrays. `host_on`: if given, only that rank copies the gathered payload to the host
+    (the others return their own rows only) - the merged table is needed in one place. On the GPU path the returned
+    arrays are views of a reused pinned buffer: valid until the next call."""
+    global _PINNED
     import torch
     import torch.distributed as dist
     world = dist.get_world_size()
@@ -61,7 +67,17 @@ def all_gather_rows(arr, device="cpu"):
     pad[:payload.numel()] = payload.to(device, non_blocking=True)
     allb = torch.empty(world * mx, dtype=torch.uint8, device=device)
     dist.all_gather_into_tensor(allb, pad)
-    host = allb.cpu().numpy()
+    if host_on is not None and dist.get_rank() != host_on:
+        return [arr]
+    if allb.is_cuda:
+        if _PINNED is None or _PINNED.numel() < allb.numel():
+            _PINNED = torch.empty(int(allb.numel() * 1.25) + 1024, dtype=torch.uint8, pin_memory=True)
+        host_t = _PINNED[:allb.numel()]
+        host_t.copy_(allb, non_blocking=True)
+        torch.cuda.synchronize()
+        host = host_t.numpy()
+    else:
+        host = allb.numpy()
     return [host[r * mx:r * mx + sizes[r] * item].view(ROW_DTYPE) for r in range(world)]
 
 
