@@ -169,6 +169,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
+    if world > 1:  # the ranks of a node share its cores: split them instead of oversubscribing the host-side stages
+        os.environ.setdefault("LM_HOST_THREADS", str(max(1, usable_cores() // world)))
     import lexicmap_amd as la
     from lexicmap_amd import synth
 

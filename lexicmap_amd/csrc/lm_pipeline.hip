@@ -221,6 +221,10 @@ static int host_threads() { // cores this process may use: hardware threads capp
                 v = (int)std::min<long long>(v, std::max<long long>(1, quota / period));
             fclose(f);
         }
+        if (const char *e = getenv("LM_HOST_THREADS")) { // several processes per host (one per GPU) share its cores
+            int w = atoi(e);
+            if (w >= 1) v = std::min(v, w);
+        }
         return std::min(v, 24);
     }();
     return n;
