@@ -99,11 +99,12 @@ void launch_build_cmp_bits(hipStream_t st, const uint64_t *keys_cmp, const int64
 void launch_pa_anchors(hipStream_t st, DevIndexView ix, const Task *tasks, int64_t ntasks, const uint8_t *wbuf,
                        const uint64_t *keys_cmp, const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid,
                        const uint32_t *cmp_tab, const uint32_t *cmp_bits, int K, int min_prefix,
-                       unsigned long long *count, int64_t cap, uint64_t *outA, uint64_t *outB);
-void launch_pa_task_off_sorted(hipStream_t st, const uint64_t *sortedA, int64_t total, int64_t ntasks, int64_t *pa_off);
+                       unsigned long long *count, int64_t cap, uint64_t *outA, uint64_t *outB, int qbits, int tbits);
+void launch_pa_task_off_sorted(hipStream_t st, const uint64_t *sortedA, int shift, int64_t total, int64_t ntasks,
+                               int64_t *pa_off);
 void launch_pa_chain(hipStream_t st, const uint64_t *B, const int64_t *pa_off, int64_t ntasks, int K, LmChain2Opt opt,
                      LmSub *subs, uint8_t *marks, uint64_t *msi, int32_t *stack, LmChain2 *out, int32_t *out_n,
-                     int32_t *clr_n);
+                     int32_t *clr_n, int qbits, int tbits);
 void launch_gather_chain2(hipStream_t st, const LmChain2 *in, const int64_t *pa_off, const int32_t *out_n,
                           const int64_t *res_off, int64_t ntasks, LmChain2 *out);
 void launch_extend_count(hipStream_t st, const HspIn *hsps, int64_t n, const uint8_t *qseq, const int64_t *qoff,

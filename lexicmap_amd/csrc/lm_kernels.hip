@@ -567,7 +567,10 @@ __global__ __launch_bounds__(256) void k_pa_anchors(DevIndexView ix, const Task 
                                                      const uint32_t *__restrict__ cmp_tab,
                                                      const uint32_t *__restrict__ cmp_bits, int K, int min_prefix,
                                                      unsigned long long *__restrict__ count, int64_t cap,
-                                                     uint64_t *__restrict__ outA, uint64_t *__restrict__ outB) {
+                                                     uint64_t *__restrict__ outA, uint64_t *__restrict__ outB, int qbits,
+                                                     int tbits) {
+    // qbits > 0: compact single-key anchors, task | QBegin:qbits | (32-Len):6 | TBegin:tbits | 2 flags in one u64 (outA is
+    // not written): same order as (task, B) and one keys-only radix sort over the bits in use instead of two pair sorts
     __shared__ uint32_t q_item[PA_QCAP]; // position << 1 | strand (1 = reverse complement)
     __shared__ uint64_t s_out[PA_OCAP];
     __shared__ int q_n, s_on;
@@ -590,14 +593,20 @@ __global__ __launch_bounds__(256) void k_pa_anchors(DevIndexView ix, const Task 
             s_on = 0;
         }
         __syncthreads();
+        const int sh_t = 2, sh_l = 2 + tbits, sh_q = 8 + tbits, sh_a = 8 + tbits + qbits;
         auto emit = [&](uint64_t B) {
+            if (qbits > 0) { // repack the fields of B under the task number
+                const LmSub u = lm_unpack_anchor(B);
+                B = ((uint64_t)ti << sh_a) | ((uint64_t)(uint32_t)u.qbegin << sh_q) | ((uint64_t)(32 - (int)u.len) << sh_l) |
+                    ((uint64_t)(uint32_t)u.tbegin << sh_t) | ((uint64_t)u.qrc << 1) | (uint64_t)u.trc;
+            }
             int slot = atomicAdd(&s_on, 1);
             if (slot < PA_OCAP) {
                 s_out[slot] = B;
             } else { // staging buffer full (rare): straight to the global list
                 unsigned long long idx = atomicAdd(count, 1ull);
                 if ((int64_t)idx < cap) {
-                    outA[idx] = (uint64_t)ti;
+                    if (qbits == 0) outA[idx] = (uint64_t)ti;
                     outB[idx] = B;
                 }
             }
@@ -610,7 +619,7 @@ __global__ __launch_bounds__(256) void k_pa_anchors(DevIndexView ix, const Task 
             for (int j = tid; j < n; j += 256) {
                 const unsigned long long idx = s_base + (unsigned long long)j;
                 if ((int64_t)idx < cap) {
-                    outA[idx] = (uint64_t)ti;
+                    if (qbits == 0) outA[idx] = (uint64_t)ti;
                     outB[idx] = s_out[j];
                 }
             }
@@ -718,13 +727,13 @@ __global__ __launch_bounds__(256) void k_pa_anchors(DevIndexView ix, const Task 
     }
 }
 // first anchor of every task in the (task, B)-sorted list
-__global__ void k_pa_task_off_sorted(const uint64_t *__restrict__ sortedA, int64_t total, int64_t ntasks,
+__global__ void k_pa_task_off_sorted(const uint64_t *__restrict__ sortedA, int shift, int64_t total, int64_t ntasks,
                                      int64_t *__restrict__ pa_off) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= ntasks; i += (int64_t)gridDim.x * blockDim.x) {
         int64_t lo = 0, hi = total;
         while (lo < hi) {
             int64_t mid = (lo + hi) >> 1;
-            if (sortedA[mid] < (uint64_t)i)
+            if ((sortedA[mid] >> shift) < (uint64_t)i)
                 lo = mid + 1;
             else
                 hi = mid;
@@ -753,7 +762,8 @@ __global__ __launch_bounds__(64) void k_pa_chain_wave(const uint64_t *__restrict
                                                        int64_t ntasks, int K, LmChain2Opt opt, LmSub *__restrict__ subs_pool,
                                                        uint8_t *__restrict__ marks_pool, uint64_t *__restrict__ msi_pool,
                                                        int32_t *__restrict__ stack_pool, LmChain2 *__restrict__ out_pool,
-                                                       int32_t *__restrict__ out_n, int32_t *__restrict__ clr_n) {
+                                                       int32_t *__restrict__ out_n, int32_t *__restrict__ clr_n, int qbits,
+                                                       int tbits) {
     const int lane = threadIdx.x;
     for (int64_t ti = blockIdx.x; ti < ntasks; ti += gridDim.x) {
         const int64_t o = pa_off[ti];
@@ -770,7 +780,21 @@ __global__ __launch_bounds__(64) void k_pa_chain_wave(const uint64_t *__restrict
         uint8_t *marks = marks_pool + o;
         uint64_t *msi = msi_pool + o;
         LmChain2 *res = out_pool + o;
-        for (int i = lane; i < n; i += 64) sb[i] = lm_unpack_anchor(B[o + i]);
+        for (int i = lane; i < n; i += 64) {
+            const uint64_t v = B[o + i];
+            if (qbits > 0) { // compact single-key form (see k_pa_anchors)
+                LmSub u;
+                u.qbegin = (int32_t)((v >> (8 + tbits)) & ((1ull << qbits) - 1ull));
+                u.len = (uint8_t)(32 - (int)((v >> (2 + tbits)) & 63));
+                u.tbegin = (int32_t)((v >> 2) & ((1ull << tbits) - 1ull));
+                u.qrc = (uint8_t)((v >> 1) & 1);
+                u.trc = (uint8_t)(v & 1);
+                u.pad = 0;
+                sb[i] = u;
+            } else {
+                sb[i] = lm_unpack_anchor(v);
+            }
+        }
         __syncthreads();
         // ---- ClearSubstrPairs (lib-index-search.go:927-972): anchor i+1 is dropped when nested in an earlier one ----
         if (n > 1) {
@@ -2197,20 +2221,21 @@ void launch_build_cmp_bits(hipStream_t st, const uint64_t *keys_cmp, const int64
 void launch_pa_anchors(hipStream_t st, DevIndexView ix, const Task *tasks, int64_t ntasks, const uint8_t *wbuf,
                        const uint64_t *keys_cmp, const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid,
                        const uint32_t *cmp_tab, const uint32_t *cmp_bits, int K, int min_prefix,
-                       unsigned long long *count, int64_t cap, uint64_t *outA, uint64_t *outB) {
+                       unsigned long long *count, int64_t cap, uint64_t *outA, uint64_t *outB, int qbits, int tbits) {
     int g = (int)(ntasks < 1 ? 1 : (ntasks > 1048576 ? 1048576 : ntasks));
     hipLaunchKernelGGL(k_pa_anchors, dim3(g), dim3(256), 0, st, ix, tasks, ntasks, wbuf, keys_cmp, vals_cmp, posoff, nvalid,
-                       cmp_tab, cmp_bits, K, min_prefix, count, cap, outA, outB);
+                       cmp_tab, cmp_bits, K, min_prefix, count, cap, outA, outB, qbits, tbits);
 }
-void launch_pa_task_off_sorted(hipStream_t st, const uint64_t *sortedA, int64_t total, int64_t ntasks, int64_t *pa_off) {
-    LM_LAUNCH_1D(k_pa_task_off_sorted, ntasks + 1, st, sortedA, total, ntasks, pa_off);
+void launch_pa_task_off_sorted(hipStream_t st, const uint64_t *sortedA, int shift, int64_t total, int64_t ntasks,
+                               int64_t *pa_off) {
+    LM_LAUNCH_1D(k_pa_task_off_sorted, ntasks + 1, st, sortedA, shift, total, ntasks, pa_off);
 }
 void launch_pa_chain(hipStream_t st, const uint64_t *B, const int64_t *pa_off, int64_t ntasks, int K, LmChain2Opt opt,
                      LmSub *subs, uint8_t *marks, uint64_t *msi, int32_t *stack, LmChain2 *out, int32_t *out_n,
-                     int32_t *clr_n) {
+                     int32_t *clr_n, int qbits, int tbits) {
     int g = (int)(ntasks < 1 ? 1 : (ntasks > 262144 ? 262144 : ntasks));
     hipLaunchKernelGGL(k_pa_chain_wave, dim3(g), dim3(64), 0, st, B, pa_off, ntasks, K, opt, subs, marks, msi, stack, out, out_n,
-                       clr_n);
+                       clr_n, qbits, tbits);
 }
 void launch_gather_chain2(hipStream_t st, const LmChain2 *in, const int64_t *pa_off, const int32_t *out_n,
                           const int64_t *res_off, int64_t ntasks, LmChain2 *out) {

@@ -1117,6 +1117,18 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
         tasks_d = a.tasks.p;
     }
     a.stats->window_bases += W;
+    // key layout: when task number + anchor fields fit 64 bits the anchors are single compact keys (keys-only sort)
+    int abits = 1, qbits = 1, tbits = 1;
+    {
+        while (((int64_t)1 << abits) < nt + 1) abits++;
+        int maxw = 1, maxq = 1;
+        for (int64_t i = 0; i < nt; i++) maxw = std::max(maxw, ht[i].wlen);
+        for (int q = 0; q < qb->nq; q++) maxq = std::max<int>(maxq, (int)(qb->h_qoff[q + 1] - qb->h_qoff[q]));
+        while ((1 << tbits) <= maxw + 64) tbits++; // reverse-strand anchors start up to K bases past the last k-mer
+        while ((1 << qbits) <= maxq) qbits++;
+    }
+    const bool compact = abits + qbits + 6 + tbits + 2 <= 64 && !getenv("LM_DEBUG_PA_WIDE_KEYS"); // 2nd: test hook
+    const int key_bits = abits + qbits + 6 + tbits + 2, sh_a = qbits + 6 + tbits + 2;
     // single pass: anchors appended to (A0, B0) in arbitrary order; the buffer size is a running estimate, the kernel
     // counts past it, so an undersized buffer costs one re-run
     a.pa_count.ensure(1);
@@ -1124,13 +1136,14 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
     if (const char *e = getenv("LM_DEBUG_PA_CAP")) a.pa_cap = std::max<int64_t>(1, atoll(e)); // test hook: force the re-run
     int64_t TP = 0;
     for (int attempt = 0;; attempt++) {
-        a.A0.ensure((size_t)a.pa_cap);
+        if (!compact) a.A0.ensure((size_t)a.pa_cap);
         a.B0.ensure((size_t)a.pa_cap);
         HIPCHK(hipMemsetAsync(a.pa_count.p, 0, sizeof(unsigned long long), S(ix)));
         {
             Prof p(ix, "k_pa_anchors", W);
             launch_pa_anchors(S(ix), ix->view, tasks_d, nt, a.wb, a.w->k_cmp, a.w->v_cmp, qb->d_posoff.p,
-                              a.w->nvalid.p, a.w->cmp_tab.p, a.w->cmp_bits.p, ix->host.k, 11, a.pa_count.p, a.pa_cap, a.A0.p, a.B0.p);
+                              a.w->nvalid.p, a.w->cmp_tab.p, a.w->cmp_bits.p, ix->host.k, 11, a.pa_count.p, a.pa_cap, a.A0.p, a.B0.p,
+                              compact ? qbits : 0, compact ? tbits : 0);
         }
         unsigned long long hv = 0;
         HIPCHK(hipMemcpyAsync(&hv, a.pa_count.p, sizeof hv, hipMemcpyDeviceToHost, S(ix)));
@@ -1147,24 +1160,26 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
     a.clr_n.ensure((size_t)nt + 1);
     HIPCHK(hipMemsetAsync(a.out_n.p, 0, sizeof(int32_t) * (nt + 1), S(ix)));
     if (TP > 0) {
-        a.A1.ensure((size_t)a.pa_cap);
+        if (!compact) a.A1.ensure((size_t)a.pa_cap);
         a.B1.ensure((size_t)a.pa_cap);
-        {
+        if (compact) {
             Prof p(ix, "sort_pa_anchors");
-            int abits = 1, qbits = 1, tbits = 1;
-            while (((int64_t)1 << abits) < nt + 1) abits++;
-            int maxw = 1, maxq = 1;
-            for (int64_t i = 0; i < nt; i++) maxw = std::max(maxw, ht[i].wlen);
-            for (int q = 0; q < qb->nq; q++) maxq = std::max<int>(maxq, (int)(qb->h_qoff[q + 1] - qb->h_qoff[q]));
-            while ((1 << tbits) <= maxw + 64) tbits++; // reverse-strand anchors start up to K bases past the last k-mer
-            while ((1 << qbits) <= maxq) qbits++;
+            size_t bytes = 0;
+            HIPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, a.B0.p, a.B1.p, (int)TP, 0, key_bits, S(ix)));
+            TMP(ix).ensure(bytes);
+            HIPCHK(hipcub::DeviceRadixSort::SortKeys(TMP(ix).p, bytes, a.B0.p, a.B1.p, (int)TP, 0, key_bits, S(ix)));
+            std::swap(a.B0.p, a.B1.p); // sorted keys are what follows calls B0
+            std::swap(a.B0.cap, a.B1.cap);
+            launch_pa_task_off_sorted(S(ix), a.B0.p, sh_a, TP, nt, a.pa_off.p);
+        } else {
+            Prof p(ix, "sort_pa_anchors");
             sort_anchors_fields(ix, a.A0.p, a.B0.p, a.A1.p, a.B1.p, TP, abits, qbits, tbits);
             std::swap(a.A0.p, a.A1.p); // the sorted list is in (A1, B1): make it (A0, B0) for what follows
             std::swap(a.A0.cap, a.A1.cap);
             std::swap(a.B0.p, a.B1.p);
             std::swap(a.B0.cap, a.B1.cap);
+            launch_pa_task_off_sorted(S(ix), a.A0.p, 0, TP, nt, a.pa_off.p);
         }
-        launch_pa_task_off_sorted(S(ix), a.A0.p, TP, nt, a.pa_off.p);
         a.subs.ensure((size_t)TP);
         a.marks.ensure((size_t)TP);
         a.msi.ensure((size_t)TP);
@@ -1180,7 +1195,7 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
         {
             Prof p(ix, "k_pa_chain", TP * 32);
             launch_pa_chain(S(ix), a.B0.p, a.pa_off.p, nt, ix->host.k, o2, a.subs.p, a.marks.p, a.msi.p, a.stack.p,
-                            a.out.p, a.out_n.p, a.clr_n.p);
+                            a.out.p, a.out_n.p, a.clr_n.p, compact ? qbits : 0, compact ? tbits : 0);
         }
         {   // ASCII windows only for the tasks that produced chains: extendMatch / WFA are the only readers
             Prof p(ix, "k_extract_windows", W / 4);
