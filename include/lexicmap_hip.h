@@ -67,7 +67,11 @@ typedef struct lm_index_info {
     int64_t genomes;       /* genomes resident on this device */
     int64_t seeds;         /* (k-mer,value) pairs resident on this device */
     int64_t genome_bases;  /* concatenated bases resident on this device */
-    int64_t hbm_bytes;     /* device memory held by the index image */
+    int64_t hbm_bytes;     /* device memory held by the index image (seeds + genomes + tables) */
+    int64_t seed_bytes;    /* device memory of the packed seed image alone (partition tables + key and value streams) */
+    int64_t outlier_seeds; /* seeds kept in the flat 16-byte form (k-mer does not start with its mask's prefix) */
+    int32_t key_bits, val_bits, partition_bases; /* packed seed layout: bits per k-mer remainder / value, bases per partition */
+    int32_t pad;
 } lm_index_info;
 
 /* search.go:631-731 flag defaults */

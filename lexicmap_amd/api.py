@@ -26,7 +26,8 @@ class Options(C.Structure):
 class IndexInfo(C.Structure):
     _fields_ = [("k", C.c_int32), ("masks", C.c_int32), ("mask_prefix", C.c_int32), ("anchor_prefix", C.c_int32),
                 ("total_bases", C.c_int64), ("genomes", C.c_int64), ("seeds", C.c_int64), ("genome_bases", C.c_int64),
-                ("hbm_bytes", C.c_int64)]
+                ("hbm_bytes", C.c_int64), ("seed_bytes", C.c_int64), ("outlier_seeds", C.c_int64),
+                ("key_bits", C.c_int32), ("val_bits", C.c_int32), ("partition_bases", C.c_int32), ("pad", C.c_int32)]
 
 
 class Query(C.Structure):

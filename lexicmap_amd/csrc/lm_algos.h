@@ -89,6 +89,74 @@ LM_HD bool lm_low_complexity(uint64_t kmer, int k) {
 LM_HD int lm_lcp(uint64_t a, uint64_t b, int k) { return (lm_clz64(a ^ b) >> 1) + k - 32; }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Packed seed image: the seeds of one (mask, direction) whose k-mers start with the mask's p-base prefix
+// are bucketed by their next a bases (the reference's anchor partitions, kv-data.go:90-125) and stored as two bit
+// streams of fixed-width elements, little-endian bit order inside 64-bit words:
+//   key  = the k-mer's last K-p-a bases                      (key_bits = 2 (K-p-a); 36 for K=31, p=7, a=6)
+//   val  = local genome number | position | strand           (gid_bits + pos_bits + 1; 40 for 100k x 3-Mb genomes)
+// versus the 2 x 64 bits of the reference's RAM form (kv-reader.go:762-1021): k-mer u64 + value u64
+// (batch:17|genome:17|pos:28|rc:1|reversed:1, lib-index-build.go:412-455).  The reversed flag is the direction of the
+// list, the p-base prefix is the mask's, the a-base partition is the table index.
+LM_HD uint64_t lm_bits_get(const uint64_t *a, int64_t i, int w) {
+    const int64_t bit = i * (int64_t)w;
+    const int64_t word = bit >> 6;
+    const int sh = (int)(bit & 63);
+    uint64_t v = a[word] >> sh;
+    if (sh + w > 64) v |= a[word + 1] << (64 - sh);
+    return w >= 64 ? v : (v & ((1ull << w) - 1));
+}
+LM_HD uint64_t lm_pack_seed_val(uint64_t local_genome, uint64_t v64, int pos_bits) {
+    const uint64_t pos = (v64 >> 2) & 0xfffffffull, rc = (v64 >> 1) & 1ull;
+    return (local_genome << (pos_bits + 1)) | (pos << 1) | rc;
+}
+// back to the reference's value layout given the genome's batch:17|genome:17 key and the list's direction
+LM_HD uint64_t lm_unpack_seed_val(uint64_t pv, uint64_t bg, int pos_bits, int dir) {
+    const uint64_t pos = (pv >> 1) & ((1ull << pos_bits) - 1);
+    return (bg << 30) | (pos << 2) | ((pv & 1ull) << 1) | (uint64_t)dir;
+}
+LM_HD uint64_t lm_packed_val_genome(uint64_t pv, int pos_bits) { return pv >> (pos_bits + 1); }
+// word `w` of a bit stream rebuilt from the elements [first, first+n) that overlap it (get(i) = element first+i);
+// *mask = the bits of the word that belong to those elements (the rest belongs to the neighbouring partitions)
+template <typename Get>
+LM_HD uint64_t lm_bits_build_word(int64_t w, int64_t first, int64_t n, int width, Get get, uint64_t *mask) {
+    const int64_t wlo = w << 6, whi = wlo + 64; // bit range of the word
+    int64_t e0 = wlo / width, e1 = (whi - 1) / width;
+    if (e0 < first) e0 = first;
+    if (e1 > first + n - 1) e1 = first + n - 1;
+    uint64_t v = 0, m = 0;
+    const uint64_t em = width >= 64 ? ~0ull : ((1ull << width) - 1);
+    for (int64_t e = e0; e <= e1; e++) {
+        const int64_t b = e * width - wlo; // negative: the element starts in the previous word
+        const uint64_t x = get(e - first);
+        if (b >= 0) {
+            v |= x << b;
+            m |= em << b;
+        } else {
+            v |= x >> (-b);
+            m |= em >> (-b);
+        }
+    }
+    *mask = m;
+    return v;
+}
+// seeds of the sorted partition [b, e) whose key lies in [lrem, rrem]: returns the count, *first = the first one
+// (kv-searcher2.go:105-323: lower bound of the range's left end, then scan)
+LM_HD int32_t lm_partition_range(const uint64_t *keys, int key_bits, int64_t b, int64_t e, uint64_t lrem, uint64_t rrem,
+                                 int64_t *first) {
+    int64_t lo = b, hi = e;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (lm_bits_get(keys, mid, key_bits) < lrem)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    *first = lo;
+    while (lo < e && lm_bits_get(keys, lo, key_bits) <= rrem) lo++;
+    return (int32_t)(lo - *first);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // LexicHash capture of one mask over a query's sorted k-mer array (lexichash.Mask semantics: argmin of mask^kmer).
 // a[0..n) sorted ascending (duplicates allowed). Returns the winning k-mer; [*lo,*hi) = its occurrences.
 LM_HD uint64_t lm_xor_argmin(const uint64_t *a, int n, uint64_t m, int *lo_out, int *hi_out) {

@@ -16,12 +16,11 @@
 //   * seed values batch:17|genome:17|pos:28|strand:1|reversed:1, per-mask arrays sorted by k-mer
 // The search kernels and the parity tests never depend on this file: parity uses indexes written in the reference's
 // on-disk format by the oracle's writer.
-#include <hipcub/hipcub.hpp>
-
 #include <cmath>
 #include <cstring>
 
 #include "lm_internal.h"
+#include "lm_prims.h"
 
 namespace lm {
 
@@ -307,25 +306,6 @@ __global__ void k_reverse_seeds(MaskTab mt, unsigned long long from, unsigned lo
     }
 }
 
-__global__ void k_mask_hist(const uint16_t *__restrict__ s_mask, unsigned long long n, unsigned long long *__restrict__ counts) {
-    for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < n;
-         t += (unsigned long long)gridDim.x * blockDim.x)
-        atomicAdd(&counts[s_mask[t]], 1ull);
-}
-
-__global__ void k_mask_scatter(const uint16_t *__restrict__ s_mask, const uint64_t *__restrict__ s_kmer,
-                               const uint64_t *__restrict__ s_val, unsigned long long n, const int64_t *__restrict__ mask_off,
-                               unsigned long long *__restrict__ cursor, uint64_t *__restrict__ out_k,
-                               uint64_t *__restrict__ out_v) {
-    for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < n;
-         t += (unsigned long long)gridDim.x * blockDim.x) {
-        int m = s_mask[t];
-        unsigned long long o = (unsigned long long)mask_off[m] + atomicAdd(&cursor[m], 1ull);
-        out_k[o] = s_kmer[t];
-        out_v[o] = s_val[t];
-    }
-}
-
 __global__ void k_fill_u64(unsigned long long *p, int64_t n, unsigned long long v) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -451,7 +431,7 @@ lm_status lm_index_build_synthetic(const lm_synth_spec *spec, const lm_options *
         copy_up(ix->d_pfx_first, pfx);
         copy_up(ix->d_batch_first, h.batch_first);
         // genomes
-        ix->d_gbits.ensure((size_t)(nlocal * sp.gbytes) + 64);
+        ix->d_gbits.alloc_exact((size_t)(nlocal * sp.gbytes) + 64);
         HIPCHK(hipMemsetAsync(ix->d_gbits.p, 0, (size_t)(nlocal * sp.gbytes) + 64, ix->st));
         DBuf<int16_t> shifts;
         shifts.ensure((size_t)(nlocal * sp.nblk) + 1);
@@ -461,122 +441,10 @@ lm_status lm_index_build_synthetic(const lm_synth_spec *spec, const lm_options *
         bsync(ix);
         shifts.release();
         MaskTab mt{ix->d_masks.p, ix->d_pfx_first.p, K, p, M};
-        // seed buffer
-        double per_genome = 2.0 * (1.45 * M + (double)spec->genome_len / 42.0) + 1024;
-        unsigned long long cap = (unsigned long long)(per_genome * (double)nlocal) + 65536;
-        DBuf<uint16_t> s_mask;
-        DBuf<uint64_t> s_kmer, s_val;
-        s_mask.ensure(cap);
-        s_kmer.ensure(cap);
-        s_val.ensure(cap);
-        DBuf<unsigned long long> counters;
-        counters.ensure(8);
-        HIPCHK(hipMemsetAsync(counters.p, 0, 8 * sizeof(unsigned long long), ix->st));
-        const int CH = (int)std::min<int64_t>(nlocal, std::max<int64_t>(1, (int64_t)(256ll << 20) / ((int64_t)M * 8)));
-        DBuf<unsigned long long> hashes;
-        hashes.ensure((size_t)CH * M);
-        unsigned long long pos_cap = (unsigned long long)((1.45 * M + 64) * CH) + CH + 64;
-        DBuf<uint64_t> pos_keys, pos_keys2;
-        pos_keys.ensure(pos_cap);
-        pos_keys2.ensure(pos_cap);
-        unsigned long long seeds_done = 0; // seeds already reversed
-        const int64_t npos = (int64_t)spec->genome_len - K + 1;
-        for (int64_t l0 = 0; l0 < nlocal; l0 += CH) {
-            int nch = (int)std::min<int64_t>(CH, nlocal - l0);
-            hipLaunchKernelGGL(k_fill_u64, dim3(gridn((int64_t)nch * M)), dim3(256), 0, ix->st, hashes.p, (int64_t)nch * M,
-                               ~0ull);
-            HIPCHK(hipMemsetAsync(counters.p + 1, 0, sizeof(unsigned long long), ix->st));
-            hipLaunchKernelGGL(k_cap_argmin, dim3(gridn((int64_t)nch * npos)), dim3(256), 0, ix->st, sp, mt, ix->d_gbits.p, l0,
-                               nch, hashes.p);
-            hipLaunchKernelGGL(k_cap_emit, dim3(gridn((int64_t)nch * npos)), dim3(256), 0, ix->st, sp, mt, ix->d_gbits.p, l0,
-                               nch, hashes.p, s_mask.p, s_kmer.p, s_val.p, counters.p, cap, pos_keys.p, counters.p + 1,
-                               pos_cap - CH - 1);
-            unsigned long long hc[2];
-            HIPCHK(hipMemcpyAsync(hc, counters.p, sizeof hc, hipMemcpyDeviceToHost, ix->st));
-            bsync(ix);
-            if (hc[0] >= cap || hc[1] >= pos_cap - CH - 1) throw HipError("synthetic builder: seed buffer too small");
-            unsigned long long npk = hc[1];
-            hipLaunchKernelGGL(k_pseudo_pos, dim3((nch + 63) / 64), dim3(64), 0, ix->st, nch, (int32_t)(spec->genome_len - K),
-                               pos_keys.p, npk);
-            npk += nch;
-            {
-                size_t bytes = 0;
-                HIPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, pos_keys.p, pos_keys2.p, (int)npk, 0, 64, ix->st));
-                ix->tmp.ensure(bytes);
-                HIPCHK(hipcub::DeviceRadixSort::SortKeys(ix->tmp.p, bytes, pos_keys.p, pos_keys2.p, (int)npk, 0, 64, ix->st));
-            }
-            hipLaunchKernelGGL(k_desert_fill, dim3(gridn((int64_t)npk, 64)), dim3(64), 0, ix->st, sp, mt, ix->d_gbits.p, l0,
-                               pos_keys2.p, (int64_t)npk, spec->max_desert, spec->seed_dist, s_mask.p, s_kmer.p, s_val.p,
-                               counters.p, cap);
-            HIPCHK(hipMemcpyAsync(hc, counters.p, sizeof hc, hipMemcpyDeviceToHost, ix->st));
-            bsync(ix);
-            if (hc[0] >= cap) throw HipError("synthetic builder: seed buffer too small (desert)");
-            unsigned long long upto = hc[0];
-            hipLaunchKernelGGL(k_reverse_seeds, dim3(gridn((int64_t)(upto - seeds_done))), dim3(256), 0, ix->st, mt, seeds_done,
-                               upto, s_mask.p, s_kmer.p, s_val.p, counters.p, cap);
-            HIPCHK(hipMemcpyAsync(hc, counters.p, sizeof hc, hipMemcpyDeviceToHost, ix->st));
-            bsync(ix);
-            if (hc[0] >= cap) throw HipError("synthetic builder: seed buffer too small (reversed)");
-            seeds_done = hc[0];
-        }
-        hashes.release();
-        pos_keys.release();
-        pos_keys2.release();
-        unsigned long long N = seeds_done;
-        // bucket by mask
-        DBuf<unsigned long long> counts, cursor;
-        counts.ensure(M + 1);
-        cursor.ensure(M + 1);
-        HIPCHK(hipMemsetAsync(counts.p, 0, (M + 1) * sizeof(unsigned long long), ix->st));
-        HIPCHK(hipMemsetAsync(cursor.p, 0, (M + 1) * sizeof(unsigned long long), ix->st));
-        hipLaunchKernelGGL(k_mask_hist, dim3(gridn((int64_t)N)), dim3(256), 0, ix->st, s_mask.p, N, counts.p);
-        std::vector<unsigned long long> hcounts(M);
-        HIPCHK(hipMemcpyAsync(hcounts.data(), counts.p, M * sizeof(unsigned long long), hipMemcpyDeviceToHost, ix->st));
-        bsync(ix);
-        h.mask_off.assign(M + 1, 0);
-        for (int i = 0; i < M; i++) h.mask_off[i + 1] = h.mask_off[i] + (int64_t)hcounts[i];
-        copy_up(ix->d_mask_off, h.mask_off);
-        DBuf<uint64_t> bk, bv;
-        bk.ensure((size_t)N + 1);
-        bv.ensure((size_t)N + 1);
-        hipLaunchKernelGGL(k_mask_scatter, dim3(gridn((int64_t)N)), dim3(256), 0, ix->st, s_mask.p, s_kmer.p, s_val.p, N,
-                           ix->d_mask_off.p, cursor.p, bk.p, bv.p);
-        bsync(ix);
-        s_mask.release();
-        s_kmer.release();
-        s_val.release();
-        ix->d_seed_kmers.ensure((size_t)N + 1);
-        ix->d_seed_vals.ensure((size_t)N + 1);
-        // per-mask sort by k-mer, in groups of masks below 2^31 items
-        {
-            int m0 = 0;
-            DBuf<int64_t> rel;
-            while (m0 < M) {
-                int m1 = m0;
-                while (m1 < M && h.mask_off[m1 + 1] - h.mask_off[m0] < ((int64_t)1 << 31) - 1) m1++;
-                if (m1 == m0) throw HipError("synthetic builder: a single mask list exceeds 2^31 seeds");
-                int64_t base = h.mask_off[m0], items = h.mask_off[m1] - base;
-                std::vector<int64_t> relh(m1 - m0 + 1);
-                for (int i = m0; i <= m1; i++) relh[i - m0] = h.mask_off[i] - base;
-                rel.ensure(relh.size());
-                HIPCHK(hipMemcpyAsync(rel.p, relh.data(), relh.size() * sizeof(int64_t), hipMemcpyHostToDevice, ix->st));
-                size_t bytes = 0;
-                HIPCHK(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, bytes, bk.p + base, ix->d_seed_kmers.p + base,
-                                                                   bv.p + base, ix->d_seed_vals.p + base, (int)items, m1 - m0,
-                                                                   rel.p, rel.p + 1, 0, 2 * K, ix->st));
-                ix->tmp.ensure(bytes);
-                HIPCHK(hipcub::DeviceSegmentedRadixSort::SortPairs(ix->tmp.p, bytes, bk.p + base, ix->d_seed_kmers.p + base,
-                                                                   bv.p + base, ix->d_seed_vals.p + base, (int)items, m1 - m0,
-                                                                   rel.p, rel.p + 1, 0, 2 * K, ix->st));
-                bsync(ix);
-                m0 = m1;
-            }
-        }
-        bk.release();
-        bv.release();
         // genome tables + host metadata
         std::vector<int64_t> goff(nlocal);
         std::vector<int32_t> glen(nlocal, spec->genome_len);
+        std::vector<uint64_t> gbg(nlocal);
         h.genomes.resize(nlocal);
         for (int64_t l = 0; l < nlocal; l++) {
             int64_t g = h.shard_count > 1 ? l * h.shard_count + h.shard_rank : l;
@@ -594,10 +462,12 @@ lm_status lm_index_build_synthetic(const lm_synth_spec *spec, const lm_options *
             G.seq_ids = {std::string(nm)};
             G.bits_off = l * sp.gbytes;
             goff[l] = G.bits_off;
+            gbg[l] = G.bg;
             ix->bg2local[G.bg] = (int)l;
         }
         copy_up(ix->d_g_off, goff);
         copy_up(ix->d_g_len, glen);
+        copy_up(ix->d_g_bg, gbg);
         lm_fill_gap_lut(ix); // same table as lm_index_open (lib-chaining.go:662-667)
         bsync(ix);
         DevIndexView &v = ix->view;
@@ -606,9 +476,7 @@ lm_status lm_index_build_synthetic(const lm_synth_spec *spec, const lm_options *
         v.mask_prefix = p;
         v.masks = ix->d_masks.p;
         v.pfx_first = ix->d_pfx_first.p;
-        v.seed_kmers = ix->d_seed_kmers.p;
-        v.seed_vals = ix->d_seed_vals.p;
-        v.mask_off = ix->d_mask_off.p;
+        v.g_bg = ix->d_g_bg.p;
         v.gbits = ix->d_gbits.p;
         v.g_off = ix->d_g_off.p;
         v.g_len = ix->d_g_len.p;
@@ -617,8 +485,90 @@ lm_status lm_index_build_synthetic(const lm_synth_spec *spec, const lm_options *
         v.ngenomes = nlocal;
         v.shard_rank = h.shard_rank;
         v.shard_count = h.shard_count;
-        ix->hbm_bytes = (int64_t)(N * 16 + (uint64_t)(nlocal * sp.gbytes) + (uint64_t)M * 16 + pfx.size() * 4 + nlocal * 12);
-        lm_build_seed_top(ix);
+
+        // ---- seeds: generated per chunk of genomes into a staging buffer and shown to the packer, twice (count, place):
+        // the unpacked seeds of the whole set never exist (they would not fit beside the packed image at BASELINE configs 3-5)
+        const bool dbg = getenv("LM_DEBUG") != nullptr;
+        const int CH = (int)std::min<int64_t>(nlocal, std::max<int64_t>(1, (int64_t)(192ll << 20) / ((int64_t)M * 8)));
+        double per_genome = 2.0 * (1.45 * M + (double)spec->genome_len / 42.0) + 1024;
+        unsigned long long cap = (unsigned long long)(per_genome * (double)CH) + 65536;
+        DBuf<uint16_t> s_mask;
+        DBuf<uint64_t> s_kmer, s_val;
+        s_mask.alloc_exact(cap);
+        s_kmer.alloc_exact(cap);
+        s_val.alloc_exact(cap);
+        DBuf<unsigned long long> counters;
+        counters.ensure(8);
+        DBuf<unsigned long long> hashes;
+        hashes.alloc_exact((size_t)CH * M);
+        unsigned long long pos_cap = (unsigned long long)((1.45 * M + 64) * CH) + CH + 64;
+        DBuf<uint64_t> pos_keys, pos_keys2;
+        pos_keys.alloc_exact(pos_cap);
+        pos_keys2.alloc_exact(pos_cap);
+        const int64_t npos = (int64_t)spec->genome_len - K + 1;
+        SeedPacker packer;
+        packer.begin(ix, nlocal, spec->genome_len);
+        double t_cap = 0, t_desert = 0, t_pack = 0;
+        for (int pass = 0; pass < 2; pass++) {
+            for (int64_t l0 = 0; l0 < nlocal; l0 += CH) {
+                int nch = (int)std::min<int64_t>(CH, nlocal - l0);
+                double ta = now_ms();
+                hipLaunchKernelGGL(k_fill_u64, dim3(gridn((int64_t)nch * M)), dim3(256), 0, ix->st, hashes.p, (int64_t)nch * M,
+                                   ~0ull);
+                HIPCHK(hipMemsetAsync(counters.p, 0, 2 * sizeof(unsigned long long), ix->st));
+                hipLaunchKernelGGL(k_cap_argmin, dim3(gridn((int64_t)nch * npos)), dim3(256), 0, ix->st, sp, mt, ix->d_gbits.p, l0,
+                                   nch, hashes.p);
+                hipLaunchKernelGGL(k_cap_emit, dim3(gridn((int64_t)nch * npos)), dim3(256), 0, ix->st, sp, mt, ix->d_gbits.p, l0,
+                                   nch, hashes.p, s_mask.p, s_kmer.p, s_val.p, counters.p, cap, pos_keys.p, counters.p + 1,
+                                   pos_cap - CH - 1);
+                unsigned long long hc[2];
+                HIPCHK(hipMemcpyAsync(hc, counters.p, sizeof hc, hipMemcpyDeviceToHost, ix->st));
+                bsync(ix);
+                if (hc[0] >= cap || hc[1] >= pos_cap - CH - 1) throw HipError("synthetic builder: seed buffer too small");
+                double tb = now_ms();
+                unsigned long long npk = hc[1];
+                hipLaunchKernelGGL(k_pseudo_pos, dim3((nch + 63) / 64), dim3(64), 0, ix->st, nch, (int32_t)(spec->genome_len - K),
+                                   pos_keys.p, npk);
+                npk += nch;
+                prim_sort_keys(ix->st, ix->tmp, pos_keys.p, pos_keys2.p, (size_t)npk, 0, 64);
+                hipLaunchKernelGGL(k_desert_fill, dim3(gridn((int64_t)npk, 64)), dim3(64), 0, ix->st, sp, mt, ix->d_gbits.p, l0,
+                                   pos_keys2.p, (int64_t)npk, spec->max_desert, spec->seed_dist, s_mask.p, s_kmer.p, s_val.p,
+                                   counters.p, cap);
+                HIPCHK(hipMemcpyAsync(hc, counters.p, sizeof hc, hipMemcpyDeviceToHost, ix->st));
+                bsync(ix);
+                if (hc[0] >= cap) throw HipError("synthetic builder: seed buffer too small (desert)");
+                unsigned long long upto = hc[0];
+                hipLaunchKernelGGL(k_reverse_seeds, dim3(gridn((int64_t)upto)), dim3(256), 0, ix->st, mt, 0ull, upto, s_mask.p,
+                                   s_kmer.p, s_val.p, counters.p, cap);
+                HIPCHK(hipMemcpyAsync(hc, counters.p, sizeof hc, hipMemcpyDeviceToHost, ix->st));
+                bsync(ix);
+                if (hc[0] >= cap) throw HipError("synthetic builder: seed buffer too small (reversed)");
+                double tc = now_ms();
+                if (pass == 0)
+                    packer.count(s_mask.p, s_kmer.p, s_val.p, (int64_t)hc[0]);
+                else
+                    packer.place(s_mask.p, s_kmer.p, s_val.p, (int64_t)hc[0]);
+                bsync(ix);
+                t_cap += tb - ta;
+                t_desert += tc - tb;
+                t_pack += now_ms() - tc;
+            }
+            if (pass == 0) packer.end_count();
+            if (dbg)
+                fprintf(stderr, "[lm] builder pass %d: capture %.0f ms, desert+reverse %.0f ms, packer %.0f ms (cumulative)\n", pass,
+                        t_cap, t_desert, t_pack);
+        }
+        hashes.release();
+        pos_keys.release();
+        pos_keys2.release();
+        s_mask.release();
+        s_kmer.release();
+        s_val.release();
+        double tf = now_ms();
+        packer.finish();
+        if (dbg) fprintf(stderr, "[lm] builder: partition sort %.0f ms; %lld seeds (%lld outliers), %.2f B/seed\n", now_ms() - tf,
+                         (long long)ix->n_seeds, (long long)ix->n_seeds_outlier, (double)ix->seed_bytes / std::max<double>(1.0, (double)ix->n_seeds));
+        ix->hbm_bytes = ix->seed_bytes + (int64_t)((uint64_t)(nlocal * sp.gbytes) + 64 + (uint64_t)M * 8 + pfx.size() * 4 + nlocal * 20);
     } catch (const std::exception &e) {
         g_open_error = e.what();
         delete ix;

@@ -44,6 +44,14 @@ template <typename T> struct DBuf {
         HIPCHK(hipMalloc((void **)&p, want * sizeof(T)));
         cap = want;
     }
+    // exactly n elements (the immutable index arrays: no head-room, optionally zero-filled)
+    void alloc_exact(size_t n, bool zero = false, hipStream_t st = nullptr) {
+        release();
+        size_t want = std::max<size_t>(n, 1);
+        HIPCHK(hipMalloc((void **)&p, want * sizeof(T)));
+        cap = want;
+        if (zero) HIPCHK(hipMemsetAsync(p, 0, want * sizeof(T), st));
+    }
     void release() {
         if (p) (void)hipFree(p);
         p = nullptr;
@@ -72,7 +80,7 @@ template <typename T> struct PBuf {
     }
 };
 
-static double now_ms() {
+static inline double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
@@ -90,11 +98,26 @@ using namespace lm;
 extern thread_local std::string g_open_error; // text of the last failed open/build (lm_last_error(NULL))
 struct lm_index;
 void lm_fill_gap_lut(lm_index *ix);
-void lm_build_seed_top(lm_index *ix);
 
 namespace lm {
 struct Work;
 struct AlignCtx;
+
+// Two-pass construction of the packed seed image in HBM (lm_seedpack.hip): every seed is shown twice, in any order and
+// in batches of any size, as (mask, k-mer, value in the reference layout): count() sizes the partitions, place() stores.
+struct SeedPacker {
+    lm_index *ix = nullptr;
+    int a = 0, P1 = 0, key_bits = 0, gid_bits = 0, pos_bits = 0;
+    int64_t n_main = 0, n_out = 0;
+    DBuf<unsigned long long> out_cnt; // [2M+1] outlier counts, then cursors
+    bool placing = false;
+    // ix->view.masks / pfx_first / batch_first / shard fields and ix->host.{k, M, mask_prefix, anchor_prefix} must be set
+    void begin(lm_index *ix, int64_t local_genomes, int64_t max_genome_len);
+    void count(const uint16_t *mask, const uint64_t *kmer, const uint64_t *val, int64_t n);
+    void end_count();
+    void place(const uint16_t *mask, const uint64_t *kmer, const uint64_t *val, int64_t n);
+    void finish(); // sorts the partitions, fills ix->view / ix->n_seeds / ix->seed_bytes
+};
 } // namespace lm
 
 struct lm_index {
@@ -107,9 +130,11 @@ struct lm_index {
     hipStream_t st = nullptr;
     std::string err;
     // HBM image
-    DBuf<uint64_t> d_masks, d_seed_kmers, d_seed_vals, d_seed_top;
+    DBuf<uint64_t> d_masks, d_pk_keys, d_pk_vals, d_out_kmers, d_out_vals, d_g_bg;
+    DBuf<uint32_t> d_part_tab;
     DBuf<int32_t> d_pfx_first, d_g_len;
-    DBuf<int64_t> d_mask_off, d_g_off, d_batch_first, d_top_off;
+    DBuf<int64_t> d_md_off, d_out_off, d_g_off, d_batch_first;
+    int64_t n_seeds = 0, n_seeds_outlier = 0, seed_bytes = 0; // resident seeds; bytes of the whole seed image
     DBuf<uint8_t> d_gbits;
     DBuf<float> d_gap_lut;
     int gap_lut_n = 0;

@@ -12,11 +12,21 @@ struct DevIndexView {
     int K, M, mask_prefix;
     const uint64_t *masks;      // [M] sorted
     const int32_t *pfx_first;   // [4^p + 1] masks sharing each p-base prefix
-    const uint64_t *seed_kmers; // [N] per mask sorted ascending
-    const uint64_t *seed_vals;  // [N] batch:17|genome:17|pos:28|rc:1|reversed:1 (lib-index-build.go:412-455)
-    const int64_t *mask_off;    // [M+1]
-    const uint64_t *seed_top;   // every 16th k-mer of each mask's list (sample j of list m = seed_kmers[mask_off[m] + 16 j])
-    const int64_t *top_off;     // [M+1] first sample of each list
+    // packed seed image: list md = 2*mask + direction (0 = prefix seeds, 1 = reversed/suffix seeds)
+    int part_bases;             // a: bases of the partition index (the index's anchor prefix, kv-data.go:90-125)
+    int P1;                     // 4^a + 1: stride of part_tab
+    int key_bits;               // 2 (K - p - a)
+    int gid_bits, pos_bits;     // value = local genome : gid_bits | position : pos_bits | strand : 1
+    const uint64_t *pk_keys;    // bit stream, key_bits per seed
+    const uint64_t *pk_vals;    // bit stream, gid_bits + pos_bits + 1 per seed
+    const uint32_t *part_tab;   // [2M][P1] first seed of each partition, relative to md_off[md]; [P1-1] = list length
+    const int64_t *md_off;      // [2M+1] first seed of each list
+    const uint64_t *g_bg;       // [G] batch:17|genome:17 key of each local genome (genomes.map.bin key)
+    // seeds whose k-mer does not start with its mask's p-base prefix (captures of genomes that lack the prefix:
+    // tiny genomes only) keep the reference's flat form, per list sorted by (k-mer, value)
+    const uint64_t *out_kmers;  // [No]
+    const uint64_t *out_vals;   // [No] batch:17|genome:17|pos:28|rc:1|reversed:1 (lib-index-build.go:412-455)
+    const int64_t *out_off;     // [2M+1]
     const uint8_t *gbits;       // 2-bit genomes, first base in bits 7-6 (genome.go:1480)
     const int64_t *g_off;       // [G] byte offset
     const int32_t *g_len;       // [G] concatenated length in bases
@@ -64,18 +74,15 @@ void launch_extract_kmers(hipStream_t st, const uint8_t *qseq, const int64_t *qo
 void launch_fill_u32(hipStream_t st, uint32_t *p, int64_t n, uint32_t v);
 void launch_mask(hipStream_t st, const uint64_t *keys_all, const int64_t *posoff, int nq, int M, int K,
                  const uint64_t *masks, uint64_t *out_kmers, int64_t *out_lo, int64_t *out_hi, uint32_t *first_mask);
-#define LM_TOP_STEP 16
-void launch_seed_top_counts(hipStream_t st, const int64_t *mask_off, int M, int32_t *cnt);
-void launch_seed_top_fill(hipStream_t st, const uint64_t *seed_kmers, const int64_t *mask_off, const int64_t *top_off, int M,
-                          uint64_t *top);
 void launch_lookup_prep(hipStream_t st, DevIndexView ix, const uint64_t *kmers, const int64_t *klo, const uint32_t *first_mask,
-                        int64_t nqm, uint32_t *list, uint32_t *iota);
+                        int64_t nqm, uint32_t *keys, uint32_t *slots, unsigned long long *counter);
 void launch_lookup_count(hipStream_t st, DevIndexView ix, const uint64_t *kmers, const int64_t *klo, const int64_t *khi,
-                         const uint32_t *perm, const uint32_t *slist, int64_t nqm, int min_prefix, uint32_t *counts,
+                         const uint32_t *skeys, const uint32_t *sslots, int64_t nlk, int min_prefix, uint32_t *counts,
                          int64_t *starts, int32_t *nscan, unsigned long long *stat_values);
 void launch_lookup_emit(hipStream_t st, DevIndexView ix, const uint64_t *kmers, const int64_t *klo, const int64_t *khi,
-                        const uint32_t *vals_all, const uint32_t *perm, int64_t nqm, const uint32_t *counts,
-                        const int64_t *offs, const int64_t *starts, const int32_t *nscan, uint64_t *outA, uint64_t *outB);
+                        const uint32_t *vals_all, const uint32_t *skeys, const uint32_t *sslots, int64_t nlk,
+                        const uint32_t *counts, const int64_t *offs, const int64_t *starts, const int32_t *nscan,
+                        uint64_t *outA, uint64_t *outB);
 void launch_chain1(hipStream_t st, const uint64_t *B, const int64_t *seg_off, int nseg, LmChainOpt opt, int K, LmSub *subs,
                    uint8_t *marks, uint64_t *msi, uint64_t *s2i, int8_t *dirs, uint8_t *visited, int32_t *chain_off_pool,
                    int32_t *chain_idx_pool, int32_t *seg_n, float *seg_score, int32_t *seg_nch);

@@ -156,145 +156,172 @@ __device__ __forceinline__ int argmin_mask(const uint64_t *masks, const int32_t 
 }
 
 // ---- seed lookup ------------------------------------------------------------------------------------------------------
-// Layout: per mask a sorted list of k-mers (seed_kmers) with their values, plus every 16th k-mer again in seed_top.
-// A lookup is a lower bound in the list: the search runs in the sampled array first (1/16 of the bytes, shared by all
-// the lookups of that list) and then inside ONE 16-key block of the list, so a lookup touches ~2 sectors of the big
-// array instead of ~9 (a plain binary search over 1e5 keys per list made the batch read the whole 17 GB k-mer array,
-// 3.4x its algorithmic bytes). For that sharing to happen the lookups are processed in list order (k_lookup_prep +
-// one radix sort by list id) and a list's lookups stay on one XCD (workgroups are dealt round-robin to the 8 XCDs, each
-// with its own L2), see lookup_index().
-__global__ void k_seed_top_counts(const int64_t *__restrict__ mask_off, int M, int32_t *__restrict__ cnt) {
-    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x)
-        cnt[m] = (int32_t)((mask_off[m + 1] - mask_off[m] + LM_TOP_STEP - 1) / LM_TOP_STEP);
-}
-__global__ void k_seed_top_fill(const uint64_t *__restrict__ seed_kmers, const int64_t *__restrict__ mask_off,
-                                const int64_t *__restrict__ top_off, int M, uint64_t *__restrict__ top) {
-    for (int m = blockIdx.x; m < M; m += gridDim.x) {
-        const int64_t b = mask_off[m], ns = top_off[m + 1] - top_off[m];
-        for (int64_t j = threadIdx.x; j < ns; j += blockDim.x) top[top_off[m] + j] = seed_kmers[b + j * LM_TOP_STEP];
+// Packed seed image (DevIndexView, lm_seedpack.hip): list md = (mask, direction) -> partition table over the a bases that
+// follow the mask's p-base prefix (the reference's anchor partitions, kv-data.go:90-125, 413-434) -> sorted key_bits-wide
+// k-mer remainders + packed values.  A lookup reads one table entry pair, binary-searches ONE partition (tens of seeds:
+// a few hundred bytes) and scans the matches: kv-searcher2.go:105-323 semantics ("all k-mers in [kmer & ~m, kmer | m]
+// whose reversed flag equals the direction"; the range never leaves a partition because MinPrefix >= p + a,
+// lib-index-search.go:483-485).  Captured k-mers that do not start with the mask's prefix (short queries: most masks)
+// can only match seeds of the flat outlier lists, which exist for tiny genomes only; when the list is empty the lookup
+// is not even issued.
+// Lookups are compacted and sorted by (list, partition) so that neighbouring threads read neighbouring table entries
+// and partitions, and logical workgroups are laid out so that a contiguous eighth of the sorted lookups runs on one
+// XCD (each XCD has its own L2), see lookup_index().
+#define LM_LK_OUTLIER_BIT 31
+__device__ __forceinline__ uint32_t lookup_sort_key(const DevIndexView &ix, uint32_t md, uint64_t x) {
+    const int p = ix.mask_prefix;
+    const uint64_t mp = ix.masks[md >> 1] >> ((ix.K - p) << 1);
+    if ((x >> ((ix.K - p) << 1)) == mp) {
+        const uint32_t part = (uint32_t)(x >> ix.key_bits) & (uint32_t)(ix.P1 - 2);
+        return (md << (ix.part_bases << 1)) | part;
     }
+    if (ix.out_off[md + 1] > ix.out_off[md]) return (1u << LM_LK_OUTLIER_BIT) | md;
+    return 0xffffffffu; // nothing stored under this list can share min_prefix >= p bases with x
 }
-// list (mask) searched by lookup t = (query*M + mask)*2 + dir, or M when there is nothing to look up; iota[t] = t
-__global__ void k_lookup_prep(DevIndexView ix, const uint64_t *__restrict__ kmers, const int64_t *__restrict__ klo,
-                              const uint32_t *__restrict__ first_mask, int64_t nqm, uint32_t *__restrict__ list,
-                              uint32_t *__restrict__ iota) {
+// one slot per (query, mask, direction): t = (query*M + mask)*2 + dir.  Issued lookups are appended (wave-aggregated)
+// to (key, slot) in arbitrary order; the radix sort that follows puts them in (list, partition) order.
+__global__ __launch_bounds__(256) void k_lookup_prep(DevIndexView ix, const uint64_t *__restrict__ kmers,
+                                                     const int64_t *__restrict__ klo,
+                                                     const uint32_t *__restrict__ first_mask, int64_t nqm,
+                                                     uint32_t *__restrict__ keys, uint32_t *__restrict__ slots,
+                                                     unsigned long long *__restrict__ counter) {
     const int64_t total = nqm * 2;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int dir = (int)(t & 1);
-        const int64_t qm = t >> 1;
-        const uint64_t kmer = kmers[qm];
-        const int m = (int)(qm % ix.M);
-        int l = ix.M;
-        if (kmer != 0) {
-            if (dir == 0) {
-                l = m;
-            } else if (first_mask[klo[qm]] == (uint32_t)m) { // de-duplicated reversed k-mer (:1288-1298)
-                const int a = argmin_mask(ix.masks, ix.pfx_first, ix.K, ix.mask_prefix, lm_reverse(kmer, ix.K));
-                if (a >= 0) l = a;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t rounds = (total + stride - 1) / stride;
+    for (int64_t r = 0; r < rounds; r++) {
+        const int64_t t = r * stride + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        uint32_t key = 0xffffffffu;
+        if (t < total) {
+            const int dir = (int)(t & 1);
+            const int64_t qm = t >> 1;
+            const uint64_t kmer = kmers[qm];
+            const int m = (int)(qm % ix.M);
+            if (kmer != 0) {
+                if (dir == 0) {
+                    key = lookup_sort_key(ix, (uint32_t)m << 1, kmer);
+                } else if (first_mask[klo[qm]] == (uint32_t)m) { // de-duplicated reversed k-mer (:1288-1298)
+                    const uint64_t rev = lm_reverse(kmer, ix.K);
+                    const int a = argmin_mask(ix.masks, ix.pfx_first, ix.K, ix.mask_prefix, rev);
+                    if (a >= 0) key = lookup_sort_key(ix, ((uint32_t)a << 1) | 1u, rev);
+                }
             }
         }
-        list[t] = (uint32_t)l;
-        iota[t] = (uint32_t)t;
+        const bool issue = key != 0xffffffffu;
+        const unsigned long long bal = __ballot(issue);
+        if (bal) {
+            const int lane = threadIdx.x & 63;
+            unsigned long long base = 0;
+            if (lane == __ffsll((long long)bal) - 1) base = atomicAdd(counter, (unsigned long long)__popcll(bal));
+            base = __shfl(base, __ffsll((long long)bal) - 1);
+            if (issue) {
+                const unsigned long long o = base + (unsigned long long)__popcll(bal & ((1ull << lane) - 1));
+                keys[o] = key;
+                slots[o] = (uint32_t)t;
+            }
+        }
     }
 }
-// position in list order handled by this thread: logical workgroup x*per + y runs as hardware workgroup y*8 + x, i.e.
-// XCD x owns one contiguous eighth of the list-ordered lookups
+// position in sorted order handled by this thread: logical workgroup x*per + y runs as hardware workgroup y*8 + x, i.e.
+// XCD x owns one contiguous eighth of the sorted lookups
 __device__ __forceinline__ int64_t lookup_index(int64_t total) {
     const int64_t per = (int64_t)(gridDim.x >> 3);
     const int64_t lb = (int64_t)(blockIdx.x & 7) * per + (int64_t)(blockIdx.x >> 3);
     const int64_t j = lb * blockDim.x + threadIdx.x;
     return j < total ? j : -1;
 }
+__device__ __forceinline__ void lookup_range(uint64_t key, int K, int min_prefix, uint64_t *left, uint64_t *right) {
+    if (min_prefix < K) {
+        const uint64_t low = (1ull << ((K - min_prefix) << 1)) - 1;
+        *left = key & ~low;
+        *right = key | low;
+    } else {
+        *left = *right = key;
+    }
+}
 __global__ __launch_bounds__(256) void k_lookup_count(DevIndexView ix, const uint64_t *__restrict__ kmers,
                                                       const int64_t *__restrict__ klo, const int64_t *__restrict__ khi,
-                                                      const uint32_t *__restrict__ perm, const uint32_t *__restrict__ slist,
-                                                      int64_t nqm, int min_prefix, uint32_t *__restrict__ counts,
+                                                      const uint32_t *__restrict__ skeys, const uint32_t *__restrict__ sslots,
+                                                      int64_t nlk, int min_prefix, uint32_t *__restrict__ counts,
                                                       int64_t *__restrict__ starts, int32_t *__restrict__ nscan,
                                                       unsigned long long *__restrict__ stat_values) {
-    const int64_t j = lookup_index(nqm * 2);
+    const int64_t j = lookup_index(nlk);
     if (j < 0) return;
-    const uint32_t list = slist[j];
-    uint32_t cnt = 0;
-    int32_t ns = 0;
-    int64_t st = 0;
-    if ((int)list < ix.M) {
-        const int64_t t = (int64_t)perm[j];
-        const int dir = (int)(t & 1);
-        const int64_t qm = t >> 1;
-        uint64_t key = kmers[qm];
-        if (dir) key = lm_reverse(key, ix.K);
-        uint64_t left, right;
-        if (min_prefix < ix.K) {
-            const int s2 = (ix.K - min_prefix) << 1;
-            const uint64_t low = (1ull << s2) - 1;
-            left = key & ~low;
-            right = key | low;
-        } else {
-            left = right = key;
-        }
-        const int64_t b = ix.mask_off[list], e = ix.mask_off[list + 1];
-        // samples < left
-        const uint64_t *top = ix.seed_top + ix.top_off[list];
-        int64_t lo = 0, hi = ix.top_off[list + 1] - ix.top_off[list];
+    const uint32_t sk = skeys[j];
+    const int64_t t = (int64_t)sslots[j];
+    const int dir = (int)(t & 1);
+    const int64_t qm = t >> 1;
+    uint64_t key = kmers[qm];
+    if (dir) key = lm_reverse(key, ix.K);
+    uint64_t left, right;
+    lookup_range(key, ix.K, min_prefix, &left, &right);
+    int64_t st;
+    int32_t nv = 0;
+    if (!(sk >> LM_LK_OUTLIER_BIT)) {
+        const int pb = ix.part_bases << 1;
+        const uint32_t md = sk >> pb, part = sk & ((1u << pb) - 1);
+        const uint32_t *row = ix.part_tab + (int64_t)md * ix.P1 + part;
+        const int64_t base = ix.md_off[md];
+        const uint64_t km = (1ull << ix.key_bits) - 1;
+        nv = lm_partition_range(ix.pk_keys, ix.key_bits, base + row[0], base + row[1], left & km, right & km, &st);
+    } else {
+        const uint32_t md = sk & 0x7fffffffu;
+        int64_t lo = ix.out_off[md], hi = ix.out_off[md + 1];
+        const int64_t e = hi;
         while (lo < hi) {
             const int64_t mid = (lo + hi) >> 1;
-            if (top[mid] < left)
+            if (ix.out_kmers[mid] < left)
                 lo = mid + 1;
             else
                 hi = mid;
         }
-        int64_t i = b;
-        if (lo > 0) { // seed_kmers[b + 16 (lo-1)] < left <= seed_kmers[b + 16 lo] (if that one exists)
-            int64_t l2 = b + (lo - 1) * LM_TOP_STEP + 1, h2 = b + lo * LM_TOP_STEP;
-            if (h2 > e) h2 = e;
-            while (l2 < h2) {
-                const int64_t mid = (l2 + h2) >> 1;
-                if (ix.seed_kmers[mid] < left)
-                    l2 = mid + 1;
-                else
-                    h2 = mid;
-            }
-            i = l2;
-        }
-        st = i;
-        uint32_t nv = 0;
-        while (i < e && ix.seed_kmers[i] <= right) {
-            if ((ix.seed_vals[i] & 1ull) == (uint64_t)dir) nv++;
-            i++;
-        }
-        ns = (int32_t)(i - st);
-        cnt = nv * (uint32_t)(khi[qm] - klo[qm]);
-        if (nv) atomicAdd(stat_values, (unsigned long long)nv);
+        st = lo;
+        while (lo < e && ix.out_kmers[lo] <= right) lo++;
+        nv = (int32_t)(lo - st);
     }
-    counts[j] = cnt;
+    counts[j] = (uint32_t)nv * (uint32_t)(khi[qm] - klo[qm]);
     starts[j] = st;
-    nscan[j] = ns;
+    nscan[j] = nv;
+    if (nv) atomicAdd(stat_values, (unsigned long long)nv);
 }
 
 __global__ __launch_bounds__(256) void k_lookup_emit(DevIndexView ix, const uint64_t *__restrict__ kmers,
                                                      const int64_t *__restrict__ klo, const int64_t *__restrict__ khi,
-                                                     const uint32_t *__restrict__ vals_all, const uint32_t *__restrict__ perm,
-                                                     int64_t nqm, const uint32_t *__restrict__ counts,
+                                                     const uint32_t *__restrict__ vals_all,
+                                                     const uint32_t *__restrict__ skeys, const uint32_t *__restrict__ sslots,
+                                                     int64_t nlk, const uint32_t *__restrict__ counts,
                                                      const int64_t *__restrict__ offs, const int64_t *__restrict__ starts,
                                                      const int32_t *__restrict__ nscan, uint64_t *__restrict__ outA,
                                                      uint64_t *__restrict__ outB) {
-    const int64_t j = lookup_index(nqm * 2);
+    const int64_t j = lookup_index(nlk);
     if (j < 0 || counts[j] == 0) return;
-    const int64_t t = (int64_t)perm[j];
-    int dir = (int)(t & 1);
-    int64_t qm = t >> 1;
-    uint64_t q = (uint64_t)(qm / ix.M);
+    const uint32_t sk = skeys[j];
+    const int64_t t = (int64_t)sslots[j];
+    const int dir = (int)(t & 1);
+    const int64_t qm = t >> 1;
+    const uint64_t q = (uint64_t)(qm / ix.M);
     uint64_t key = kmers[qm];
     if (dir) key = lm_reverse(key, ix.K);
     int64_t o = offs[j];
-    int64_t b = starts[j];
+    const int64_t b = starts[j];
+    const bool outlier = (sk >> LM_LK_OUTLIER_BIT) != 0;
+    const uint64_t km = (1ull << ix.key_bits) - 1;
+    const int fixed = ix.K - (ix.key_bits >> 1); // p + a bases shared by construction
     for (int32_t s = 0; s < nscan[j]; s++) {
-        uint64_t v = ix.seed_vals[b + s];
-        if ((v & 1ull) != (uint64_t)dir) continue;
-        int kprefix = lm_lcp(key, ix.seed_kmers[b + s], ix.K);
-        uint64_t A = (q << 34) | (v >> 30);
+        uint64_t v;
+        int kprefix;
+        if (!outlier) {
+            const uint64_t sr = lm_bits_get(ix.pk_keys, b + s, ix.key_bits);
+            const uint64_t d = sr ^ (key & km);
+            kprefix = fixed + (d ? ((lm_clz64(d) - (64 - ix.key_bits)) >> 1) : (ix.key_bits >> 1));
+            const uint64_t pv = lm_bits_get(ix.pk_vals, b + s, ix.gid_bits + ix.pos_bits + 1);
+            v = lm_unpack_seed_val(pv, ix.g_bg[lm_packed_val_genome(pv, ix.pos_bits)], ix.pos_bits, dir);
+        } else {
+            v = ix.out_vals[b + s];
+            kprefix = lm_lcp(key, ix.out_kmers[b + s], ix.K);
+        }
+        const uint64_t A = (q << 34) | (v >> 30);
         for (int64_t li = klo[qm]; li < khi[qm]; li++) {
-            uint32_t loc = vals_all[li];
+            const uint32_t loc = vals_all[li];
             int bq, bt;
             bool rct;
             lm_anchor_coords(v, (int)(loc >> 1), (loc & 1u) != 0, kprefix, ix.K, &bq, &bt, &rct);
@@ -2147,17 +2174,9 @@ void launch_mask(hipStream_t st, const uint64_t *keys_all, const int64_t *posoff
                  const uint64_t *masks, uint64_t *out_kmers, int64_t *out_lo, int64_t *out_hi, uint32_t *first_mask) {
     LM_LAUNCH_1D(k_mask, (int64_t)nq * M, st, keys_all, posoff, nq, M, K, masks, out_kmers, out_lo, out_hi, first_mask);
 }
-void launch_seed_top_counts(hipStream_t st, const int64_t *mask_off, int M, int32_t *cnt) {
-    LM_LAUNCH_1D(k_seed_top_counts, M, st, mask_off, M, cnt);
-}
-void launch_seed_top_fill(hipStream_t st, const uint64_t *seed_kmers, const int64_t *mask_off, const int64_t *top_off, int M,
-                          uint64_t *top) {
-    int g = M < 1 ? 1 : (M > 65536 ? 65536 : M);
-    hipLaunchKernelGGL(k_seed_top_fill, dim3(g), dim3(256), 0, st, seed_kmers, mask_off, top_off, M, top);
-}
 void launch_lookup_prep(hipStream_t st, DevIndexView ix, const uint64_t *kmers, const int64_t *klo, const uint32_t *first_mask,
-                        int64_t nqm, uint32_t *list, uint32_t *iota) {
-    LM_LAUNCH_1D(k_lookup_prep, nqm * 2, st, ix, kmers, klo, first_mask, nqm, list, iota);
+                        int64_t nqm, uint32_t *keys, uint32_t *slots, unsigned long long *counter) {
+    LM_LAUNCH_1D(k_lookup_prep, nqm * 2, st, ix, kmers, klo, first_mask, nqm, keys, slots, counter);
 }
 static int lookup_grid(int64_t total) { // one thread per lookup, workgroup count a multiple of 8 (see lookup_index)
     int64_t nb = (total + 255) / 256;
@@ -2165,16 +2184,17 @@ static int lookup_grid(int64_t total) { // one thread per lookup, workgroup coun
     return (int)(nb < 8 ? 8 : nb);
 }
 void launch_lookup_count(hipStream_t st, DevIndexView ix, const uint64_t *kmers, const int64_t *klo, const int64_t *khi,
-                         const uint32_t *perm, const uint32_t *slist, int64_t nqm, int min_prefix, uint32_t *counts,
+                         const uint32_t *skeys, const uint32_t *sslots, int64_t nlk, int min_prefix, uint32_t *counts,
                          int64_t *starts, int32_t *nscan, unsigned long long *stat_values) {
-    hipLaunchKernelGGL(k_lookup_count, dim3(lookup_grid(nqm * 2)), dim3(256), 0, st, ix, kmers, klo, khi, perm, slist, nqm,
+    hipLaunchKernelGGL(k_lookup_count, dim3(lookup_grid(nlk)), dim3(256), 0, st, ix, kmers, klo, khi, skeys, sslots, nlk,
                        min_prefix, counts, starts, nscan, stat_values);
 }
 void launch_lookup_emit(hipStream_t st, DevIndexView ix, const uint64_t *kmers, const int64_t *klo, const int64_t *khi,
-                        const uint32_t *vals_all, const uint32_t *perm, int64_t nqm, const uint32_t *counts,
-                        const int64_t *offs, const int64_t *starts, const int32_t *nscan, uint64_t *outA, uint64_t *outB) {
-    hipLaunchKernelGGL(k_lookup_emit, dim3(lookup_grid(nqm * 2)), dim3(256), 0, st, ix, kmers, klo, khi, vals_all, perm, nqm,
-                       counts, offs, starts, nscan, outA, outB);
+                        const uint32_t *vals_all, const uint32_t *skeys, const uint32_t *sslots, int64_t nlk,
+                        const uint32_t *counts, const int64_t *offs, const int64_t *starts, const int32_t *nscan,
+                        uint64_t *outA, uint64_t *outB) {
+    hipLaunchKernelGGL(k_lookup_emit, dim3(lookup_grid(nlk)), dim3(256), 0, st, ix, kmers, klo, khi, vals_all, skeys, sslots,
+                       nlk, counts, offs, starts, nscan, outA, outB);
 }
 void launch_chain1(hipStream_t st, const uint64_t *B, const int64_t *seg_off, int nseg, LmChainOpt opt, int K, LmSub *subs,
                    uint8_t *marks, uint64_t *msi, uint64_t *s2i, int8_t *dirs, uint8_t *visited, int32_t *chain_off_pool,

@@ -5,7 +5,6 @@
 // (:2701-2749,2919-2932).  All of §8(a) rows a1-a12,a14,a15 run in the kernels of lm_kernels.hip.  There is no CPU path:
 // without a HIP device every entry point fails with LM_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <chrono>
@@ -27,6 +26,7 @@
 #include "lm_kernels.h"
 
 #include "lm_internal.h"
+#include "lm_prims.h"
 #include <atomic>
 #include <condition_variable>
 #include <functional>
@@ -259,20 +259,12 @@ template <typename F> static void parallel_for(int64_t n, int64_t grain, F f) {
     if (err) std::rethrow_exception(err);
 }
 
-// exclusive scan of n+1 uint32 counts (counts[n] must be 0) into int64 offsets; returns total after sync
-struct CastU32 {
-    __host__ __device__ int64_t operator()(const uint32_t &x) const { return (int64_t)x; }
-};
-struct CastI32 {
-    __host__ __device__ int64_t operator()(const int32_t &x) const { return (int64_t)x; }
-};
+// exclusive scan of n+1 counts (counts[n] must be 0) into int64 offsets; returns the total after a sync
+struct CastU32 {};
+struct CastI32 {};
 template <typename InT, typename Cast>
 static int64_t scan_to_i64(lm_index *ix, const InT *counts, int64_t n, int64_t *offs) {
-    hipcub::TransformInputIterator<int64_t, Cast, const InT *> it(counts, Cast());
-    size_t bytes = 0;
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, it, offs, (int)(n + 1), S(ix)));
-    TMP(ix).ensure(bytes);
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(TMP(ix).p, bytes, it, offs, (int)(n + 1), S(ix)));
+    prim_scan_to_i64(S(ix), TMP(ix), counts, (size_t)n, offs);
     int64_t total = 0;
     HIPCHK(hipMemcpyAsync(&total, offs + n, sizeof(int64_t), hipMemcpyDeviceToHost, S(ix)));
     sync(ix);
@@ -281,18 +273,12 @@ static int64_t scan_to_i64(lm_index *ix, const InT *counts, int64_t n, int64_t *
 
 static void sort_pairs_u64(lm_index *ix, uint64_t *k_in, uint64_t *k_out, uint64_t *v_in, uint64_t *v_out, int64_t n,
                            int begin_bit, int end_bit) {
-    size_t bytes = 0;
-    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k_in, k_out, v_in, v_out, (int)n, begin_bit, end_bit, S(ix)));
-    TMP(ix).ensure(bytes);
-    HIPCHK(hipcub::DeviceRadixSort::SortPairs(TMP(ix).p, bytes, k_in, k_out, v_in, v_out, (int)n, begin_bit, end_bit, S(ix)));
+    prim_sort_pairs(S(ix), TMP(ix), k_in, k_out, v_in, v_out, (size_t)n, begin_bit, end_bit);
 }
 
 static void sort_pairs_u32(lm_index *ix, uint32_t *k_in, uint32_t *k_out, uint32_t *v_in, uint32_t *v_out, int64_t n,
                            int begin_bit, int end_bit) {
-    size_t bytes = 0;
-    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k_in, k_out, v_in, v_out, (int)n, begin_bit, end_bit, S(ix)));
-    TMP(ix).ensure(bytes);
-    HIPCHK(hipcub::DeviceRadixSort::SortPairs(TMP(ix).p, bytes, k_in, k_out, v_in, v_out, (int)n, begin_bit, end_bit, S(ix)));
+    prim_sort_pairs(S(ix), TMP(ix), k_in, k_out, v_in, v_out, (size_t)n, begin_bit, end_bit);
 }
 
 // sort anchors by (A, B): LSD — stable sort by B, then by A. Result lands in (A0,B0).
@@ -314,25 +300,6 @@ static void sort_anchors_fields(lm_index *ix, uint64_t *A0, uint64_t *B0, uint64
 
 // ---- query batch ---------------------------------------------------------------------------------------------
 } // namespace lm
-
-// Sampled top array of the seed lists (every LM_TOP_STEP-th k-mer of each list, see the lookup kernels); called once the
-// seeds and mask offsets are on the device, by lm_index_open and by the synthetic builder.
-void lm_build_seed_top(lm_index *ix) {
-    const int M = ix->host.M;
-    DBuf<int32_t> cnt;
-    cnt.ensure((size_t)M + 1);
-    ix->d_top_off.ensure((size_t)M + 2);
-    HIPCHK(hipMemsetAsync(cnt.p + M, 0, sizeof(int32_t), ix->st));
-    launch_seed_top_counts(ix->st, ix->d_mask_off.p, M, cnt.p);
-    int64_t total = scan_to_i64<int32_t, CastI32>(ix, cnt.p, M, ix->d_top_off.p);
-    ix->d_seed_top.ensure((size_t)std::max<int64_t>(total, 1));
-    launch_seed_top_fill(ix->st, ix->d_seed_kmers.p, ix->d_mask_off.p, ix->d_top_off.p, M, ix->d_seed_top.p);
-    HIPCHK(hipStreamSynchronize(ix->st));
-    ix->view.seed_top = ix->d_seed_top.p;
-    ix->view.top_off = ix->d_top_off.p;
-    ix->hbm_bytes += total * 8 + ((int64_t)M + 1) * 8;
-}
-
 
 struct lm_qbatch {
     lm_index *ix = nullptr;
@@ -442,22 +409,11 @@ static void stage_kmers(Work &w) {
     }
     {
         Prof p(ix, "segmented_sort_kmers");
-        size_t bytes = 0;
         int end_bit = std::min(64, 2 * ix->host.k);
-        HIPCHK(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, bytes, w.keys_all.p, w.keys_all2.p, w.vals_all.p,
-                                                           w.vals_all2.p, (int)(2 * P), qb->nq, qb->d_segoff.p,
-                                                           qb->d_segoff.p + 1, 0, end_bit, S(ix)));
-        TMP(ix).ensure(bytes);
-        HIPCHK(hipcub::DeviceSegmentedRadixSort::SortPairs(TMP(ix).p, bytes, w.keys_all.p, w.keys_all2.p, w.vals_all.p,
-                                                           w.vals_all2.p, (int)(2 * P), qb->nq, qb->d_segoff.p,
-                                                           qb->d_segoff.p + 1, 0, end_bit, S(ix)));
-        HIPCHK(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, bytes, w.keys_cmp.p, w.keys_cmp2.p, w.vals_cmp.p,
-                                                           w.vals_cmp2.p, (int)(2 * P), qb->nq, qb->d_segoff.p,
-                                                           qb->d_segoff.p + 1, 0, 64, S(ix)));
-        TMP(ix).ensure(bytes);
-        HIPCHK(hipcub::DeviceSegmentedRadixSort::SortPairs(TMP(ix).p, bytes, w.keys_cmp.p, w.keys_cmp2.p, w.vals_cmp.p,
-                                                           w.vals_cmp2.p, (int)(2 * P), qb->nq, qb->d_segoff.p,
-                                                           qb->d_segoff.p + 1, 0, 64, S(ix)));
+        prim_segmented_sort_pairs(S(ix), TMP(ix), w.keys_all.p, w.keys_all2.p, w.vals_all.p, w.vals_all2.p, (size_t)(2 * P),
+                                  (size_t)qb->nq, qb->d_segoff.p, 0, end_bit);
+        prim_segmented_sort_pairs(S(ix), TMP(ix), w.keys_cmp.p, w.keys_cmp2.p, w.vals_cmp.p, w.vals_cmp2.p, (size_t)(2 * P),
+                                  (size_t)qb->nq, qb->d_segoff.p, 0, 64);
     }
     w.k_all = w.keys_all2.p;
     w.v_all = w.vals_all2.p;
@@ -489,55 +445,62 @@ static void stage_lookup(Work &w, lm_stage_stats &stats) {
     lm_qbatch *qb = w.qb;
     int M = ix->host.M;
     int64_t nqm = (int64_t)qb->nq * M;
-    int64_t n = nqm * 2;
-    w.lk_counts.ensure((size_t)n + 1);
-    w.lk_offs.ensure((size_t)n + 1);
-    w.lk_starts.ensure((size_t)n + 1);
-    w.lk_nscan.ensure((size_t)n + 1);
+    int64_t n = nqm * 2; // (query, mask, direction) slots; the slot number travels as a u32
+    if (n >= ((int64_t)1 << 32)) throw HipError("too many seed lookups in one batch; use a smaller query batch");
     w.stat.ensure(4);
     HIPCHK(hipMemsetAsync(w.stat.p, 0, 4 * sizeof(unsigned long long), S(ix)));
-    HIPCHK(hipMemsetAsync(w.lk_counts.p + n, 0, sizeof(uint32_t), S(ix)));
-    // lookups in list (mask) order: all the searches of one seed list run together (and on one XCD), so the sampled
-    // top array of the list is fetched once and every lookup adds only its one 16-key block of the big array
-    if (n >= ((int64_t)1 << 32)) throw HipError("too many seed lookups in one batch; use a smaller query batch");
+    // issued lookups, compacted: (sort key = list | partition, slot)
     w.lk_list.ensure((size_t)n);
     w.lk_list2.ensure((size_t)n);
     w.lk_perm.ensure((size_t)n);
     w.lk_perm2.ensure((size_t)n);
     {
         Prof p(ix, "k_lookup_prep", n * 12);
-        launch_lookup_prep(S(ix), ix->view, w.kmers.p, w.klo.p, w.first_mask.p, nqm, w.lk_list.p, w.lk_perm.p);
+        launch_lookup_prep(S(ix), ix->view, w.kmers.p, w.klo.p, w.first_mask.p, nqm, w.lk_list.p, w.lk_perm.p, w.stat.p + 2);
     }
+    unsigned long long nlk_u = 0;
+    HIPCHK(hipMemcpyAsync(&nlk_u, w.stat.p + 2, sizeof nlk_u, hipMemcpyDeviceToHost, S(ix)));
+    sync(ix);
+    const int64_t nlk = (int64_t)nlk_u;
+    stats.seed_lookups += nlk;
+    w.n_anchors = 0;
+    w.nseg = 0;
+    if (nlk == 0) return;
     {
+        // in (list, partition) order: neighbouring threads read neighbouring table rows and partitions; outlier
+        // lookups (bit 31) sort to the end
         Prof p(ix, "sort_lookups");
-        int lbits = 1;
-        while ((1 << lbits) <= M) lbits++;
-        sort_pairs_u32(ix, w.lk_list.p, w.lk_list2.p, w.lk_perm.p, w.lk_perm2.p, n, 0, lbits);
+        sort_pairs_u32(ix, w.lk_list.p, w.lk_list2.p, w.lk_perm.p, w.lk_perm2.p, nlk, 0, 32);
     }
+    w.lk_counts.ensure((size_t)nlk + 1);
+    w.lk_offs.ensure((size_t)nlk + 1);
+    w.lk_starts.ensure((size_t)nlk + 1);
+    w.lk_nscan.ensure((size_t)nlk + 1);
+    HIPCHK(hipMemsetAsync(w.lk_counts.p + nlk, 0, sizeof(uint32_t), S(ix)));
     {
         Prof p(ix, "k_lookup_count");
-        launch_lookup_count(S(ix), ix->view, w.kmers.p, w.klo.p, w.khi.p, w.lk_perm2.p, w.lk_list2.p, nqm, ix->opt.min_prefix,
+        launch_lookup_count(S(ix), ix->view, w.kmers.p, w.klo.p, w.khi.p, w.lk_list2.p, w.lk_perm2.p, nlk, ix->opt.min_prefix,
                             w.lk_counts.p, w.lk_starts.p, w.lk_nscan.p, w.stat.p);
     }
     int64_t T;
     {
         Prof p(ix, "scan");
-        T = scan_to_i64<uint32_t, CastU32>(ix, w.lk_counts.p, n, w.lk_offs.p);
+        T = scan_to_i64<uint32_t, CastU32>(ix, w.lk_counts.p, nlk, w.lk_offs.p);
     }
     unsigned long long hv = 0;
     HIPCHK(hipMemcpyAsync(&hv, w.stat.p, sizeof hv, hipMemcpyDeviceToHost, S(ix)));
     sync(ix);
-    stats.seed_lookups += n;
     stats.seed_values += (int64_t)hv;
-    {   // algorithmic bytes of the lookup: per probe one mask-offset entry + ceil(log2 S) 8-byte k-mer
-        // probes of the binary search, plus 16 B (k-mer + value) per returned seed
-        double avg_list = (double)ix->host.mask_off.back() / std::max(1, ix->host.M);
-        int64_t probes = (int64_t)std::ceil(std::log2(avg_list + 2.0));
-        prof_add_bytes(ix, "k_lookup_count", n * (8 + 8 * probes) + 16 * (int64_t)hv);
+    {   // algorithmic bytes of the lookup, SURVEY.md §8(d) as written (reference-format sizes): per ISSUED lookup one
+        // 8-byte anchor-table entry + ceil(log2 S_b) 8-byte k-mer probes, S_b = mean seeds per anchor partition, plus
+        // 16 B (k-mer + value) per returned seed.  The packed image moves less than that: 2 x 4 B of table, key_bits / 8
+        // per probe and (key_bits + val_bits) / 8 per returned seed (reported as k_lookup_count_packed).
+        const double sb = (double)ix->n_seeds / std::max<double>(1.0, 2.0 * M * (double)(ix->view.P1 - 1));
+        const int64_t probes = (int64_t)std::ceil(std::log2(sb + 1.0));
+        prof_add_bytes(ix, "k_lookup_count", nlk * (8 + 8 * probes) + 16 * (int64_t)hv);
     }
     stats.anchors_raw += T;
     w.n_anchors = T;
-    w.nseg = 0;
     if (T == 0) return;
     if (T >= (int64_t)1 << 31) throw HipError("too many anchors in one batch; use a smaller query batch");
     w.A0.ensure((size_t)T);
@@ -546,8 +509,8 @@ static void stage_lookup(Work &w, lm_stage_stats &stats) {
     w.B1.ensure((size_t)T);
     {
         Prof p(ix, "k_lookup_emit", T * 16);
-        launch_lookup_emit(S(ix), ix->view, w.kmers.p, w.klo.p, w.khi.p, w.v_all, w.lk_perm2.p, nqm, w.lk_counts.p, w.lk_offs.p,
-                           w.lk_starts.p, w.lk_nscan.p, w.A0.p, w.B0.p);
+        launch_lookup_emit(S(ix), ix->view, w.kmers.p, w.klo.p, w.khi.p, w.v_all, w.lk_list2.p, w.lk_perm2.p, nlk, w.lk_counts.p,
+                           w.lk_offs.p, w.lk_starts.p, w.lk_nscan.p, w.A0.p, w.B0.p);
     }
     {
         Prof p(ix, "sort_anchors");
@@ -559,10 +522,7 @@ static void stage_lookup(Work &w, lm_stage_stats &stats) {
     w.nseg_d.ensure(2);
     {
         Prof p(ix, "rle");
-        size_t bytes = 0;
-        HIPCHK(hipcub::DeviceRunLengthEncode::Encode(nullptr, bytes, w.A0.p, w.segA.p, w.seg_len.p, w.nseg_d.p, (int)T, S(ix)));
-        TMP(ix).ensure(bytes);
-        HIPCHK(hipcub::DeviceRunLengthEncode::Encode(TMP(ix).p, bytes, w.A0.p, w.segA.p, w.seg_len.p, w.nseg_d.p, (int)T, S(ix)));
+        prim_rle(S(ix), TMP(ix), w.A0.p, (size_t)T, w.segA.p, w.seg_len.p, w.nseg_d.p);
     }
     int32_t nseg = 0;
     HIPCHK(hipMemcpyAsync(&nseg, w.nseg_d.p, sizeof nseg, hipMemcpyDeviceToHost, S(ix)));
@@ -892,20 +852,24 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
         for (size_t i = 1; i < pfx.size(); i++) pfx[i] += pfx[i - 1];
         h2d(ix, ix->d_masks, h.masks);
         h2d(ix, ix->d_pfx_first, pfx);
-        h2d(ix, ix->d_seed_kmers, h.seed_kmers);
-        h2d(ix, ix->d_seed_vals, h.seed_vals);
-        h2d(ix, ix->d_mask_off, h.mask_off);
-        ix->d_gbits.ensure(h.gbits.size() + 64); // k-mer extraction reads whole aligned words past the last base
-        h2d(ix, ix->d_gbits, h.gbits);
+        ix->d_gbits.alloc_exact(h.gbits.size() + 64); // k-mer extraction reads whole aligned words past the last base
+        if (!h.gbits.empty())
+            HIPCHK(hipMemcpyAsync(ix->d_gbits.p, h.gbits.data(), h.gbits.size(), hipMemcpyHostToDevice, S(ix)));
+        HIPCHK(hipMemsetAsync(ix->d_gbits.p + h.gbits.size(), 0, 64, S(ix)));
         std::vector<int64_t> goff;
         std::vector<int32_t> glen;
+        std::vector<uint64_t> gbg;
+        int64_t max_len = 1;
         for (size_t i = 0; i < h.genomes.size(); i++) {
             goff.push_back(h.genomes[i].bits_off);
             glen.push_back(h.genomes[i].len);
+            gbg.push_back(h.genomes[i].bg);
+            max_len = std::max<int64_t>(max_len, h.genomes[i].len);
             ix->bg2local[h.genomes[i].bg] = (int)i;
         }
         h2d(ix, ix->d_g_off, goff);
         h2d(ix, ix->d_g_len, glen);
+        h2d(ix, ix->d_g_bg, gbg);
         h2d(ix, ix->d_batch_first, h.batch_first);
         lm_fill_gap_lut(ix);
         sync(ix);
@@ -915,9 +879,7 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
         v.mask_prefix = h.mask_prefix;
         v.masks = ix->d_masks.p;
         v.pfx_first = ix->d_pfx_first.p;
-        v.seed_kmers = ix->d_seed_kmers.p;
-        v.seed_vals = ix->d_seed_vals.p;
-        v.mask_off = ix->d_mask_off.p;
+        v.g_bg = ix->d_g_bg.p;
         v.gbits = ix->d_gbits.p;
         v.g_off = ix->d_g_off.p;
         v.g_len = ix->d_g_len.p;
@@ -926,10 +888,44 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
         v.ngenomes = (int64_t)h.genomes.size();
         v.shard_rank = h.shard_rank;
         v.shard_count = h.shard_count;
-        ix->hbm_bytes = (int64_t)(h.masks.size() * 8 + pfx.size() * 4 + h.seed_kmers.size() * 16 + h.mask_off.size() * 8 +
-                                  h.gbits.size() + goff.size() * 12 + h.batch_first.size() * 8);
-        lm_build_seed_top(ix);
-        // the packed host copies are no longer needed
+        {   // packed seed image: the decoded seeds are shown to the packer twice (count, place) in slices of whole masks
+            SeedPacker sp;
+            sp.begin(ix, (int64_t)h.genomes.size(), max_len);
+            const int64_t slice = (int64_t)32 << 20;
+            DBuf<uint64_t> dk, dv;
+            DBuf<uint16_t> dm;
+            std::vector<uint16_t> hm;
+            for (int pass = 0; pass < 2; pass++) {
+                int m0 = 0;
+                while (m0 < h.M) {
+                    int m1 = m0 + 1;
+                    while (m1 < h.M && h.mask_off[m1 + 1] - h.mask_off[m0] <= slice) m1++;
+                    const int64_t b0 = h.mask_off[m0], cnt = h.mask_off[m1] - b0;
+                    if (cnt > 0) {
+                        hm.resize((size_t)cnt);
+                        for (int m = m0; m < m1; m++)
+                            std::fill(hm.begin() + (h.mask_off[m] - b0), hm.begin() + (h.mask_off[m + 1] - b0), (uint16_t)m);
+                        dk.ensure((size_t)cnt);
+                        dv.ensure((size_t)cnt);
+                        dm.ensure((size_t)cnt);
+                        HIPCHK(hipMemcpyAsync(dk.p, h.seed_kmers.data() + b0, (size_t)cnt * 8, hipMemcpyHostToDevice, S(ix)));
+                        HIPCHK(hipMemcpyAsync(dv.p, h.seed_vals.data() + b0, (size_t)cnt * 8, hipMemcpyHostToDevice, S(ix)));
+                        HIPCHK(hipMemcpyAsync(dm.p, hm.data(), (size_t)cnt * 2, hipMemcpyHostToDevice, S(ix)));
+                        if (pass == 0)
+                            sp.count(dm.p, dk.p, dv.p, cnt);
+                        else
+                            sp.place(dm.p, dk.p, dv.p, cnt);
+                        sync(ix); // the host slices are reused
+                    }
+                    m0 = m1;
+                }
+                if (pass == 0) sp.end_count();
+            }
+            sp.finish();
+        }
+        ix->hbm_bytes = ix->seed_bytes + (int64_t)(h.masks.size() * 8 + pfx.size() * 4 + h.gbits.size() + 64 + goff.size() * 20 +
+                                                   h.batch_first.size() * 8);
+        // the unpacked host copies are no longer needed
         std::vector<uint64_t>().swap(h.seed_kmers);
         std::vector<uint64_t>().swap(h.seed_vals);
         std::vector<uint8_t>().swap(h.gbits);
@@ -961,11 +957,16 @@ lm_status lm_index_get_info(const lm_index *ix, lm_index_info *info) {
     info->anchor_prefix = ix->host.anchor_prefix;
     info->total_bases = ix->host.total_bases;
     info->genomes = (int64_t)ix->host.genomes.size();
-    info->seeds = ix->host.mask_off.empty() ? 0 : ix->host.mask_off.back();
+    info->seeds = ix->n_seeds;
     int64_t gb = 0;
     for (auto &g : ix->host.genomes) gb += g.len;
     info->genome_bases = gb;
     info->hbm_bytes = ix->hbm_bytes;
+    info->seed_bytes = ix->seed_bytes;
+    info->outlier_seeds = ix->n_seeds_outlier;
+    info->key_bits = ix->view.key_bits;
+    info->val_bits = ix->view.gid_bits + ix->view.pos_bits + 1;
+    info->partition_bases = ix->view.part_bases;
     return LM_OK;
 }
 
@@ -1164,10 +1165,7 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
         a.B1.ensure((size_t)a.pa_cap);
         if (compact) {
             Prof p(ix, "sort_pa_anchors");
-            size_t bytes = 0;
-            HIPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, a.B0.p, a.B1.p, (int)TP, 0, key_bits, S(ix)));
-            TMP(ix).ensure(bytes);
-            HIPCHK(hipcub::DeviceRadixSort::SortKeys(TMP(ix).p, bytes, a.B0.p, a.B1.p, (int)TP, 0, key_bits, S(ix)));
+            prim_sort_keys(S(ix), TMP(ix), a.B0.p, a.B1.p, (size_t)TP, 0, key_bits);
             std::swap(a.B0.p, a.B1.p); // sorted keys are what follows calls B0
             std::swap(a.B0.cap, a.B1.cap);
             launch_pa_task_off_sorted(S(ix), a.B0.p, sh_a, TP, nt, a.pa_off.p);

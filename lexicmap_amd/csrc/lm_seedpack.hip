@@ -1,0 +1,381 @@
+// lm_seedpack.hip — construction of the packed seed image in HBM (DevIndexView).
+//
+// Replaces the 16 B/seed RAM form of the reference (kv-reader.go:762-1021: per mask a flat []uint64{kmer, value, ...} plus a
+// 4^a-entry first-offset table) by, per list md = (mask, direction):
+//     part_tab[md][4^a + 1]   u32 offsets of the anchor partitions (the a bases after the mask's p-base prefix)
+//     pk_keys                 bit stream, 2 (K-p-a) bits per seed: the rest of the k-mer, ascending inside a partition
+//     pk_vals                 bit stream, gid_bits + pos_bits + 1 bits per seed: local genome | position | strand
+// = 9.5 B/seed for K=31, p=7, a=6 and 100k x 3-Mb genomes per GPU (+ 0.66 GB of table for M=20000), so that BASELINE
+// configs 3-5 fit the 288 GB of one MI355X per shard.  Seeds that do not start with their mask's prefix (only possible
+// for genomes that lack the prefix, i.e. tiny ones) keep the flat 16-byte form in per-list outlier arrays.
+//
+// Built in two passes over the seeds, shown in any order and any batching (loader: chunk files; synthetic builder:
+// genome chunks): count() -> partition sizes, place() -> atomic slot per partition + atomicOr into the zeroed streams,
+// finish() -> every partition sorted by key in place (one wavefront per partition, LDS bitonic network; partitions
+// shared words are merged with masked atomics).  No copy of the unpacked seeds ever exists.
+#include "lm_prims.h"
+
+namespace lm {
+
+#define SP_MAXN 1024 /* largest partition the LDS sorter takes; beyond: rocPRIM fallback */
+
+struct SpParams {
+    const uint64_t *masks;
+    int K, p, a, P1, key_bits, gid_bits, pos_bits, M;
+    const int64_t *batch_first;
+    int nbatches, shard_rank, shard_count;
+};
+
+__device__ __forceinline__ int64_t sp_local_genome(const SpParams &sp, uint64_t bg) {
+    const uint64_t batch = bg >> 17, gi = bg & 0x1ffff;
+    int64_t g = (batch < (uint64_t)sp.nbatches ? sp.batch_first[batch] : 0) + (int64_t)gi;
+    if (sp.shard_count > 1) g /= sp.shard_count;
+    return g;
+}
+
+// returns the table slot (md*P1 + part) of a seed, or -1 - md for an outlier
+__device__ __forceinline__ int64_t sp_classify(const SpParams &sp, uint32_t m, uint64_t kmer, uint64_t val) {
+    const uint32_t md = (m << 1) | (uint32_t)(val & 1ull);
+    const int sh = (sp.K - sp.p) << 1;
+    if ((kmer >> sh) != (sp.masks[m] >> sh)) return -1 - (int64_t)md;
+    const uint32_t part = (uint32_t)(kmer >> sp.key_bits) & (uint32_t)(sp.P1 - 2);
+    return (int64_t)md * sp.P1 + part;
+}
+
+__global__ void k_sp_count(SpParams sp, const uint16_t *__restrict__ mask, const uint64_t *__restrict__ kmer,
+                           const uint64_t *__restrict__ val, int64_t n, uint32_t *__restrict__ tab,
+                           unsigned long long *__restrict__ out_cnt) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = sp_classify(sp, mask[i], kmer[i], val[i]);
+        if (s >= 0)
+            atomicAdd(&tab[s + 1], 1u); // count of partition `part` sits one entry up: see k_sp_scan_rows
+        else
+            atomicAdd(&out_cnt[-1 - s], 1ull);
+    }
+}
+
+// per list: counts in row[1..P] -> row[i+1] = first seed of partition i (exclusive scan), row[0] = 0; total -> md_cnt.
+// place() then uses row[i+1] as the cursor of partition i, which leaves row[i+1] = first seed of partition i+1: the
+// final table needs no second array.
+__global__ __launch_bounds__(256) void k_sp_scan_rows(uint32_t *__restrict__ tab, int P1, int64_t nmd,
+                                                      unsigned long long *__restrict__ md_cnt) {
+    __shared__ uint32_t part_sum[256];
+    const int P = P1 - 1;
+    const int ipt = (P + 255) / 256;
+    for (int64_t md = blockIdx.x; md < nmd; md += gridDim.x) {
+        uint32_t *row = tab + md * P1 + 1;
+        const int b = threadIdx.x * ipt, e = min(P, b + ipt);
+        uint32_t s = 0;
+        for (int i = b; i < e; i++) s += row[i];
+        part_sum[threadIdx.x] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t acc = 0;
+            for (int t = 0; t < 256; t++) {
+                const uint32_t v = part_sum[t];
+                part_sum[t] = acc;
+                acc += v;
+            }
+            md_cnt[md] = acc;
+        }
+        __syncthreads();
+        uint32_t acc = part_sum[threadIdx.x];
+        for (int i = b; i < e; i++) {
+            const uint32_t v = row[i];
+            row[i] = acc;
+            acc += v;
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void sp_bits_or(uint64_t *a, int64_t i, int w, uint64_t v) {
+    const int64_t bit = i * (int64_t)w;
+    const int64_t word = bit >> 6;
+    const int sh = (int)(bit & 63);
+    atomicOr((unsigned long long *)&a[word], (unsigned long long)(v << sh));
+    if (sh + w > 64) atomicOr((unsigned long long *)&a[word + 1], (unsigned long long)(v >> (64 - sh)));
+}
+
+__global__ void k_sp_place(SpParams sp, const uint16_t *__restrict__ mask, const uint64_t *__restrict__ kmer,
+                           const uint64_t *__restrict__ val, int64_t n, uint32_t *__restrict__ tab,
+                           const int64_t *__restrict__ md_off, uint64_t *__restrict__ pk_keys, uint64_t *__restrict__ pk_vals,
+                           const int64_t *__restrict__ out_off, unsigned long long *__restrict__ out_cur,
+                           uint64_t *__restrict__ out_kmers, uint64_t *__restrict__ out_vals) {
+    const uint64_t km = (1ull << sp.key_bits) - 1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t k = kmer[i], v = val[i];
+        const int64_t s = sp_classify(sp, mask[i], k, v);
+        if (s >= 0) {
+            const int64_t md = s / sp.P1;
+            const int64_t slot = md_off[md] + (int64_t)atomicAdd(&tab[s + 1], 1u);
+            sp_bits_or(pk_keys, slot, sp.key_bits, k & km);
+            sp_bits_or(pk_vals, slot, sp.gid_bits + sp.pos_bits + 1,
+                       lm_pack_seed_val((uint64_t)sp_local_genome(sp, v >> 30), v, sp.pos_bits));
+        } else {
+            const int64_t md = -1 - s;
+            const int64_t o = out_off[md] + (int64_t)atomicAdd(&out_cur[md], 1ull);
+            out_kmers[o] = k;
+            out_vals[o] = v;
+        }
+    }
+}
+
+// ---- in-place sort of the partitions -----------------------------------------------------------------------------------
+template <typename Get>
+__device__ __forceinline__ void sp_store_range(uint64_t *a, int64_t first, int64_t n, int width, Get get, int lane, int nl) {
+    const int64_t w0 = (first * width) >> 6, w1 = ((first + n) * width - 1) >> 6;
+    for (int64_t w = w0 + lane; w <= w1; w += nl) {
+        uint64_t m;
+        const uint64_t v = lm_bits_build_word(w, first, n, width, get, &m);
+        if (m == ~0ull) {
+            a[w] = v;
+        } else { // a word shared with the neighbouring partitions: only our bits
+            atomicAnd((unsigned long long *)&a[w], (unsigned long long)~m);
+            atomicOr((unsigned long long *)&a[w], (unsigned long long)v);
+        }
+    }
+}
+
+// one wavefront per partition; partitions above SP_MAXN go to `big` (list of table slots)
+__global__ __launch_bounds__(64) void k_sp_sort_parts(const uint32_t *__restrict__ tab, const int64_t *__restrict__ md_off,
+                                                      int P1, int64_t nmd, int key_bits, int val_bits,
+                                                      uint64_t *__restrict__ pk_keys, uint64_t *__restrict__ pk_vals,
+                                                      unsigned long long *__restrict__ big, unsigned long long big_cap,
+                                                      unsigned long long *__restrict__ nbig) {
+    __shared__ uint64_t sk[SP_MAXN], sv[SP_MAXN];
+    const int lane = threadIdx.x;
+    const int P = P1 - 1;
+    const int64_t nparts = nmd * P;
+    for (int64_t pi = blockIdx.x; pi < nparts; pi += gridDim.x) {
+        const int64_t md = pi / P, part = pi % P;
+        const uint32_t *row = tab + md * P1 + part;
+        const int64_t n = (int64_t)row[1] - (int64_t)row[0];
+        if (n <= 1) continue;
+        const int64_t first = md_off[md] + row[0];
+        if (n > SP_MAXN) {
+            if (lane == 0) {
+                const unsigned long long o = atomicAdd(nbig, 1ull);
+                if (o < big_cap) big[o] = (unsigned long long)(md * P1 + part);
+            }
+            continue;
+        }
+        int npad = 2;
+        while (npad < n) npad <<= 1;
+        bool sorted = true;
+        for (int i = lane; i < npad; i += 64) {
+            if (i < n) {
+                sk[i] = lm_bits_get(pk_keys, first + i, key_bits);
+                sv[i] = lm_bits_get(pk_vals, first + i, val_bits);
+            } else {
+                sk[i] = ~0ull;
+                sv[i] = ~0ull;
+            }
+        }
+        __syncthreads();
+        for (int i = lane; i + 1 < n; i += 64)
+            if (sk[i] > sk[i + 1]) sorted = false;
+        if (__ballot(!sorted) == 0) { // nothing to do (chunks arrive in key order more often than not)
+            __syncthreads();
+            continue;
+        }
+        for (int k = 2; k <= npad; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = lane; i < (npad >> 1); i += 64) {
+                    const int x = ((i & ~(j - 1)) << 1) | (i & (j - 1)), y = x | j;
+                    const bool up = (x & k) == 0;
+                    const uint64_t kx = sk[x], ky = sk[y];
+                    if ((kx > ky) == up && kx != ky) {
+                        sk[x] = ky;
+                        sk[y] = kx;
+                        const uint64_t t = sv[x];
+                        sv[x] = sv[y];
+                        sv[y] = t;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        sp_store_range(pk_keys, first, n, key_bits, [&](int64_t i) { return sk[i]; }, lane, 64);
+        sp_store_range(pk_vals, first, n, val_bits, [&](int64_t i) { return sv[i]; }, lane, 64);
+        __syncthreads();
+    }
+}
+
+__global__ void k_sp_unpack(const uint64_t *__restrict__ stream, int64_t first, int64_t n, int width, uint64_t *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = lm_bits_get(stream, first + i, width);
+}
+__global__ void k_sp_repack(uint64_t *__restrict__ stream, int64_t first, int64_t n, int width, const uint64_t *__restrict__ in) {
+    sp_store_range(stream, first, n, width, [&](int64_t i) { return in[i]; }, (int)(blockIdx.x * blockDim.x + threadIdx.x),
+                   (int)(gridDim.x * blockDim.x));
+}
+
+static int sp_grid(int64_t n, int block = 256) {
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > 262144) g = 262144;
+    return (int)g;
+}
+
+static SpParams sp_params(const SeedPacker &sp) {
+    const lm_index *ix = sp.ix;
+    SpParams p;
+    p.masks = ix->view.masks;
+    p.K = ix->host.k;
+    p.p = ix->host.mask_prefix;
+    p.a = sp.a;
+    p.P1 = sp.P1;
+    p.key_bits = sp.key_bits;
+    p.gid_bits = sp.gid_bits;
+    p.pos_bits = sp.pos_bits;
+    p.M = ix->host.M;
+    p.batch_first = ix->view.batch_first;
+    p.nbatches = ix->view.nbatches;
+    p.shard_rank = ix->view.shard_rank;
+    p.shard_count = ix->view.shard_count;
+    return p;
+}
+
+static int bits_for(int64_t n) { // bits needed for values in [0, n)
+    int b = 1;
+    while (((int64_t)1 << b) < n) b++;
+    return b;
+}
+
+void SeedPacker::begin(lm_index *ix_, int64_t local_genomes, int64_t max_genome_len) {
+    ix = ix_;
+    const HostIndex &h = ix->host;
+    if (h.M > 32767) throw HipError("seed image: more than 32767 masks are not supported");
+    a = std::min(h.anchor_prefix, 6);
+    while (a > 0 && h.mask_prefix + a >= h.k) a--;
+    P1 = (1 << (2 * a)) + 1;
+    key_bits = 2 * (h.k - h.mask_prefix - a);
+    gid_bits = bits_for(std::max<int64_t>(local_genomes, 2));
+    pos_bits = bits_for(std::max<int64_t>(max_genome_len + 1, 2));
+    if (pos_bits > 28) throw HipError("seed image: genome longer than 2^28 bases (lib-index-build.go:421-425)");
+    if (gid_bits + pos_bits + 1 > 64) throw HipError("seed image: value does not fit 64 bits");
+    const int64_t nmd = 2ll * h.M;
+    ix->d_part_tab.alloc_exact((size_t)(nmd * P1), true, ix->st);
+    out_cnt.alloc_exact((size_t)nmd + 1, true, ix->st);
+    n_main = n_out = 0;
+    placing = false;
+}
+
+void SeedPacker::count(const uint16_t *mask, const uint64_t *kmer, const uint64_t *val, int64_t n) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_sp_count, dim3(sp_grid(n)), dim3(256), 0, ix->st, sp_params(*this), mask, kmer, val, n,
+                       ix->d_part_tab.p, out_cnt.p);
+}
+
+void SeedPacker::end_count() {
+    const int64_t nmd = 2ll * ix->host.M;
+    DBuf<unsigned long long> md_cnt;
+    md_cnt.alloc_exact((size_t)nmd + 1, true, ix->st);
+    hipLaunchKernelGGL(k_sp_scan_rows, dim3((unsigned)std::min<int64_t>(nmd, 65536)), dim3(256), 0, ix->st, ix->d_part_tab.p,
+                       P1, nmd, md_cnt.p);
+    ix->d_md_off.alloc_exact((size_t)nmd + 1);
+    ix->d_out_off.alloc_exact((size_t)nmd + 1);
+    prim_scan_to_i64(ix->st, ix->tmp, md_cnt.p, (size_t)nmd, ix->d_md_off.p);
+    prim_scan_to_i64(ix->st, ix->tmp, out_cnt.p, (size_t)nmd, ix->d_out_off.p);
+    int64_t tot[2];
+    HIPCHK(hipMemcpyAsync(&tot[0], ix->d_md_off.p + nmd, sizeof(int64_t), hipMemcpyDeviceToHost, ix->st));
+    HIPCHK(hipMemcpyAsync(&tot[1], ix->d_out_off.p + nmd, sizeof(int64_t), hipMemcpyDeviceToHost, ix->st));
+    HIPCHK(hipStreamSynchronize(ix->st));
+    n_main = tot[0];
+    n_out = tot[1];
+    const int val_bits = gid_bits + pos_bits + 1;
+    // +2 words: lm_bits_get may touch the word after the last element
+    ix->d_pk_keys.alloc_exact((size_t)((n_main * key_bits + 63) / 64 + 2), true, ix->st);
+    ix->d_pk_vals.alloc_exact((size_t)((n_main * val_bits + 63) / 64 + 2), true, ix->st);
+    ix->d_out_kmers.alloc_exact((size_t)n_out + 1);
+    ix->d_out_vals.alloc_exact((size_t)n_out + 1);
+    HIPCHK(hipMemsetAsync(out_cnt.p, 0, ((size_t)nmd + 1) * sizeof(unsigned long long), ix->st)); // now the outlier cursors
+    placing = true;
+}
+
+void SeedPacker::place(const uint16_t *mask, const uint64_t *kmer, const uint64_t *val, int64_t n) {
+    if (n <= 0) return;
+    if (!placing) throw HipError("SeedPacker::place before end_count");
+    hipLaunchKernelGGL(k_sp_place, dim3(sp_grid(n)), dim3(256), 0, ix->st, sp_params(*this), mask, kmer, val, n,
+                       ix->d_part_tab.p, ix->d_md_off.p, ix->d_pk_keys.p, ix->d_pk_vals.p, ix->d_out_off.p, out_cnt.p,
+                       ix->d_out_kmers.p, ix->d_out_vals.p);
+}
+
+void SeedPacker::finish() {
+    const HostIndex &h = ix->host;
+    const int64_t nmd = 2ll * h.M;
+    const int val_bits = gid_bits + pos_bits + 1;
+    // ---- main partitions
+    const unsigned long long big_cap = 1 << 20;
+    DBuf<unsigned long long> big, nbig;
+    big.alloc_exact(big_cap);
+    nbig.alloc_exact(1, true, ix->st);
+    if (n_main > 0) {
+        const int64_t nparts = nmd * (P1 - 1);
+        hipLaunchKernelGGL(k_sp_sort_parts, dim3((unsigned)std::min<int64_t>(nparts, (int64_t)1 << 22)), dim3(64), 0, ix->st,
+                           ix->d_part_tab.p, ix->d_md_off.p, P1, nmd, key_bits, val_bits, ix->d_pk_keys.p, ix->d_pk_vals.p,
+                           big.p, big_cap, nbig.p);
+        unsigned long long nb = 0;
+        HIPCHK(hipMemcpyAsync(&nb, nbig.p, sizeof nb, hipMemcpyDeviceToHost, ix->st));
+        HIPCHK(hipStreamSynchronize(ix->st));
+        if (nb > big_cap) throw HipError("seed image: too many partitions above the LDS sorter's size");
+        if (nb > 0) { // rare: rocPRIM on an unpacked copy of the partition
+            std::vector<unsigned long long> slots(nb);
+            HIPCHK(hipMemcpy(slots.data(), big.p, nb * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            std::vector<int64_t> mdo((size_t)nmd + 1);
+            HIPCHK(hipMemcpy(mdo.data(), ix->d_md_off.p, ((size_t)nmd + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+            DBuf<uint64_t> k0, k1, v0, v1;
+            for (unsigned long long s : slots) {
+                uint32_t be[2];
+                HIPCHK(hipMemcpy(be, ix->d_part_tab.p + s, sizeof be, hipMemcpyDeviceToHost));
+                const int64_t first = mdo[s / P1] + be[0], n = (int64_t)be[1] - be[0];
+                k0.ensure((size_t)n);
+                k1.ensure((size_t)n);
+                v0.ensure((size_t)n);
+                v1.ensure((size_t)n);
+                hipLaunchKernelGGL(k_sp_unpack, dim3(sp_grid(n)), dim3(256), 0, ix->st, ix->d_pk_keys.p, first, n, key_bits, k0.p);
+                hipLaunchKernelGGL(k_sp_unpack, dim3(sp_grid(n)), dim3(256), 0, ix->st, ix->d_pk_vals.p, first, n, val_bits, v0.p);
+                prim_sort_pairs(ix->st, ix->tmp, k0.p, k1.p, v0.p, v1.p, (size_t)n, 0, key_bits);
+                const int64_t nw = (n * std::max(key_bits, val_bits)) / 64 + 2;
+                hipLaunchKernelGGL(k_sp_repack, dim3(sp_grid(nw)), dim3(256), 0, ix->st, ix->d_pk_keys.p, first, n, key_bits, k1.p);
+                hipLaunchKernelGGL(k_sp_repack, dim3(sp_grid(nw)), dim3(256), 0, ix->st, ix->d_pk_vals.p, first, n, val_bits, v1.p);
+                HIPCHK(hipStreamSynchronize(ix->st));
+            }
+        }
+    }
+    // ---- outlier lists: per list by k-mer
+    if (n_out > 0) {
+        DBuf<uint64_t> k1, v1;
+        k1.alloc_exact((size_t)n_out + 1);
+        v1.alloc_exact((size_t)n_out + 1);
+        prim_segmented_sort_pairs(ix->st, ix->tmp, ix->d_out_kmers.p, k1.p, ix->d_out_vals.p, v1.p, (size_t)n_out, (size_t)nmd,
+                                  ix->d_out_off.p, 0, 2 * h.k);
+        HIPCHK(hipStreamSynchronize(ix->st));
+        std::swap(ix->d_out_kmers.p, k1.p);
+        std::swap(ix->d_out_kmers.cap, k1.cap);
+        std::swap(ix->d_out_vals.p, v1.p);
+        std::swap(ix->d_out_vals.cap, v1.cap);
+    }
+    HIPCHK(hipStreamSynchronize(ix->st));
+    out_cnt.release();
+    DevIndexView &v = ix->view;
+    v.part_bases = a;
+    v.P1 = P1;
+    v.key_bits = key_bits;
+    v.gid_bits = gid_bits;
+    v.pos_bits = pos_bits;
+    v.pk_keys = ix->d_pk_keys.p;
+    v.pk_vals = ix->d_pk_vals.p;
+    v.part_tab = ix->d_part_tab.p;
+    v.md_off = ix->d_md_off.p;
+    v.out_kmers = ix->d_out_kmers.p;
+    v.out_vals = ix->d_out_vals.p;
+    v.out_off = ix->d_out_off.p;
+    ix->n_seeds = n_main + n_out;
+    ix->n_seeds_outlier = n_out;
+    ix->seed_bytes = (int64_t)(ix->d_pk_keys.cap * 8 + ix->d_pk_vals.cap * 8 + ix->d_part_tab.cap * 4 + ix->d_md_off.cap * 8 +
+                               ix->d_out_off.cap * 8 + ix->d_out_kmers.cap * 8 + ix->d_out_vals.cap * 8);
+}
+
+} // namespace lm

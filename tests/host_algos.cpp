@@ -14,6 +14,25 @@ int ha_dust(uint64_t x, int k) { return lm_dust(x, k); }
 int ha_low_complexity(uint64_t x, int k) { return lm_low_complexity(x, k); }
 int ha_base2bit(int c) { return lm_base2bit((uint8_t)c); }
 
+// packed seed image helpers (lm_seedpack.hip / k_lookup_count): element read, word rebuild, partition range query
+uint64_t ha_bits_get(const uint64_t *a, int64_t i, int w) { return lm_bits_get(a, i, w); }
+// writes elements [first, first+n) of width w into the stream the way k_sp_sort_parts does (full words stored, shared
+// words merged under their mask)
+void ha_bits_store_range(uint64_t *a, int64_t first, int64_t n, int w, const uint64_t *elems) {
+    const int64_t w0 = (first * w) >> 6, w1 = ((first + n) * w - 1) >> 6;
+    for (int64_t x = w0; x <= w1; x++) {
+        uint64_t m;
+        const uint64_t v = lm_bits_build_word(x, first, n, w, [&](int64_t i) { return elems[i]; }, &m);
+        a[x] = (a[x] & ~m) | v;
+    }
+}
+int32_t ha_partition_range(const uint64_t *keys, int key_bits, int64_t b, int64_t e, uint64_t lrem, uint64_t rrem,
+                           int64_t *first) {
+    return lm_partition_range(keys, key_bits, b, e, lrem, rrem, first);
+}
+uint64_t ha_pack_seed_val(uint64_t g, uint64_t v64, int pos_bits) { return lm_pack_seed_val(g, v64, pos_bits); }
+uint64_t ha_unpack_seed_val(uint64_t pv, uint64_t bg, int pos_bits, int dir) { return lm_unpack_seed_val(pv, bg, pos_bits, dir); }
+
 uint64_t ha_xor_argmin(const uint64_t *a, int n, uint64_t m, int *lo, int *hi) { return lm_xor_argmin(a, n, m, lo, hi); }
 
 uint64_t ha_pack_anchor(int qb, int len, int tb, int qrc, int trc) { return lm_pack_anchor(qb, len, tb, qrc, trc); }

@@ -61,5 +61,15 @@ def lib():
                                            C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.ha_wfa.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_uint64),
                              C.c_int, C.POINTER(WfaOut)]
+        L.ha_bits_get.restype = C.c_uint64
+        L.ha_bits_get.argtypes = [C.POINTER(C.c_uint64), C.c_int64, C.c_int]
+        L.ha_bits_store_range.argtypes = [C.POINTER(C.c_uint64), C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_uint64)]
+        L.ha_partition_range.restype = C.c_int32
+        L.ha_partition_range.argtypes = [C.POINTER(C.c_uint64), C.c_int, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64,
+                                         C.POINTER(C.c_int64)]
+        L.ha_pack_seed_val.restype = C.c_uint64
+        L.ha_pack_seed_val.argtypes = [C.c_uint64, C.c_uint64, C.c_int]
+        L.ha_unpack_seed_val.restype = C.c_uint64
+        L.ha_unpack_seed_val.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int]
         _lib = L
     return _lib

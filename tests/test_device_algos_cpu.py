@@ -400,3 +400,68 @@ def test_wfa_matches_oracle(n, div, seed):
         got = (0, out.score, [ops[i] for i in range(out.nops)], out.qbegin, out.qend, out.tbegin, out.tend,
                out.align_len, out.matches, out.gaps, out.gap_regions)
         assert got == exp
+
+
+# ---- packed seed image (lm_seedpack.hip, k_lookup_count): bit streams, in-place partition rewrite, range query -------
+@pytest.mark.parametrize("width", [1, 7, 31, 36, 40, 47, 63, 64])
+def test_bit_stream_store_and_get_roundtrip(width):
+    """elements of any width written partition by partition (full words stored, shared words merged under their mask,
+    the way the in-place partition sort writes) read back unchanged, and neighbours are never disturbed"""
+    Hh = H.lib()
+    rng = random.Random(width)
+    n = 1000
+    mask = (1 << width) - 1
+    elems = [rng.getrandbits(64) & mask for _ in range(n)]
+    words = (n * width + 63) // 64 + 2
+    stream = (C.c_uint64 * words)()
+    # partitions of random sizes (including 1-element ones that share a word with both neighbours), in random order
+    cuts = sorted(set([0, n] + [rng.randrange(1, n) for _ in range(120)]))
+    parts = list(zip(cuts[:-1], cuts[1:]))
+    rng.shuffle(parts)
+    for b, e in parts:
+        arr = (C.c_uint64 * (e - b))(*elems[b:e])
+        Hh.ha_bits_store_range(stream, b, e - b, width, arr)
+    assert [Hh.ha_bits_get(stream, i, width) for i in range(n)] == elems
+    # rewrite one partition with other values: only its elements change
+    b, e = parts[0]
+    new = [rng.getrandbits(64) & mask for _ in range(e - b)]
+    Hh.ha_bits_store_range(stream, b, e - b, width, (C.c_uint64 * (e - b))(*new))
+    exp = elems[:b] + new + elems[e:]
+    assert [Hh.ha_bits_get(stream, i, width) for i in range(n)] == exp
+
+
+def test_partition_range_matches_flat_search():
+    """k_lookup_count's search of one sorted partition = all keys in [left, right] (kv-searcher2.go:105-323)"""
+    Hh = H.lib()
+    rng = random.Random(9)
+    kb = 36
+    for trial in range(200):
+        n = rng.randrange(0, 90)
+        keys = sorted(rng.getrandbits(kb) >> rng.choice([0, 0, 20, 30]) for _ in range(n))
+        pad_before = rng.randrange(0, 5)
+        allk = [rng.getrandbits(kb) for _ in range(pad_before)] + keys + [rng.getrandbits(kb) for _ in range(3)]
+        stream = (C.c_uint64 * ((len(allk) * kb + 63) // 64 + 2))()
+        Hh.ha_bits_store_range(stream, 0, len(allk), kb, (C.c_uint64 * len(allk))(*allk))
+        x = rng.choice(keys) if keys and rng.random() < 0.7 else rng.getrandbits(kb)
+        low = (1 << (2 * rng.choice([0, 1, 4, 8, 16]))) - 1
+        left, right = x & ~low, x | low
+        first = C.c_int64()
+        cnt = Hh.ha_partition_range(stream, kb, pad_before, pad_before + n, left, right, C.byref(first))
+        exp = [i for i, k in enumerate(keys) if left <= k <= right]
+        assert cnt == len(exp)
+        if exp:
+            assert first.value == pad_before + exp[0]
+
+
+def test_packed_seed_value_roundtrip():
+    Hh = H.lib()
+    rng = random.Random(4)
+    for _ in range(500):
+        pos_bits = rng.randrange(10, 29)
+        g = rng.randrange(0, 1 << 18)
+        bg = rng.getrandbits(34)
+        pos, rc, rv = rng.getrandbits(pos_bits), rng.getrandbits(1), rng.getrandbits(1)
+        v64 = (bg << 30) | (pos << 2) | (rc << 1) | rv  # lib-index-build.go:412-455
+        pv = Hh.ha_pack_seed_val(g, v64, pos_bits)
+        assert pv >> (pos_bits + 1) == g
+        assert Hh.ha_unpack_seed_val(pv, bg, pos_bits, rv) == v64

@@ -73,7 +73,11 @@ def test_index_info_and_masks(both, small_index):
     om = L.lmo_index_masks(oi.h)
     gm = _la().lib().lm_index_masks(gi.h)
     assert [om[i] for i in range(0, 20000, 97)] == [gm[i] for i in range(0, 20000, 97)]
-    assert info["seeds"] > 0 and info["hbm_bytes"] > 16 * info["seeds"]
+    assert info["seeds"] > 0 and info["hbm_bytes"] > info["seed_bytes"] > 0
+    # packed seed image: K-p-a bases per key, local genome | position | strand per value
+    assert info["partition_bases"] == 6 and info["key_bits"] == 2 * (31 - 7 - 6)
+    assert info["val_bits"] in (5 + 17 + 1, 5 + 18 + 1)  # 24 genomes, ~2^17 bases each (contigs + spacers), strand
+    assert 0 <= info["outlier_seeds"] < info["seeds"]
 
 
 def test_mask_parity(both, queries):
