@@ -2,18 +2,27 @@
 """bench.py — queries/s of the MI355X `lexicmap search` hot path (BASELINE.json metric), one JSON line on rank 0.
 
 A "step" = one pass of the whole hot path (mask -> lookup -> chain -> pseudo-align -> extend/WFA -> HSP rows) over one
-batch of synthetic queries whose bases are already resident in HBM.  N>1: one process per GPU; the index is replicated,
-the query batch is sharded (strong scaling: total work fixed) and per-rank HSP rows are merged with one RCCL all-gather
-per step.  `--shard index` shards the genomes instead (index larger than one GPU).
+batch of synthetic queries whose bases are already resident in HBM.
+
+Default workload = BASELINE.json configs[2] ("c3"): 10 000 ONT-style long reads (5-50 kb, sub 2 % / ins 2 % / del 3 %)
+against 100 000 synthetic genomes on ONE MI355X — the largest single-GPU configuration; the genome length that fits the
+288 GB next to the packed seed image is stated in config.workload.  `--workload c2` is configs[1] (1 000 gene queries vs
+10 000 x 5-Mb genomes).
+
+N > 1 (`--gpus N`: the script launches its own N ranks, one per GPU, unless it already runs under torchrun): the north-star
+layout — the genome set and its seed index are SHARDED over the GPUs (genome g on rank g % N), every rank searches the whole
+batch against its shard, per-shard HSP rows are merged with one RCCL all-gatherv per step; total work is fixed ("strong").
+`--shard queries` (index replicated, queries divided; `--scaling weak|strong`) is an explicitly labelled extra.
 
 The CPU baseline is the oracle (oracle/liblmo.so, a C restatement of the reference; kind "port") timed on the host cores
 on a bounded sample of the same workload.  The Go reference cannot be built here (`go` absent) — probed and printed.
 """
 import argparse
+import hashlib
 import json
-import math
 import os
 import shutil
+import socket
 import subprocess
 import sys
 import tempfile
@@ -35,59 +44,79 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=3)
     p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--workload", default=os.environ.get("LM_BENCH_WORKLOAD", "c2"), choices=["c2", "small", "tiny", "c3mini"])
+    p.add_argument("--workload", default=os.environ.get("LM_BENCH_WORKLOAD", "c3"),
+                   choices=["c3", "c2", "small", "tiny", "c3mini"])
     p.add_argument("--queries", type=int, default=0, help="override the number of queries")
     p.add_argument("--genomes", type=int, default=0, help="override the number of genomes")
     p.add_argument("--genome-len", type=int, default=0)
-    p.add_argument("--shard", default="queries", choices=["queries", "index"])
+    p.add_argument("--shard", default="index", choices=["index", "queries"],
+                   help="N>1: index = genomes + seed index sharded over the GPUs, queries broadcast (north-star layout, "
+                        "default); queries = index replicated, query batch divided")
+    p.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                   help="only with --shard queries: weak = every GPU searches its own batch of the workload's size")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
-    p.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                   help="N>1 with --shard queries: weak = every GPU searches its own batch of the workload's size (the "
-                        "queries are independent units: no data-path collective, only the final row gather); strong = "
-                        "the one batch is divided over the GPUs")
     p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                    help="nccl = RCCL (one GPU per rank); gloo only to exercise the N>1 logic with ranks sharing a GPU")
     p.add_argument("--builder", default=None, choices=["gpu", "oracle"],
-                   help="gpu: genomes+index generated in HBM (default for c2); oracle: CPU writer + on-disk format")
-    p.add_argument("--cpu-sample-genomes", type=int, default=12)
-    p.add_argument("--cpu-sample-queries", type=int, default=512)
+                   help="gpu: genomes+index generated in HBM (default for c2/c3); oracle: CPU writer + on-disk format")
+    p.add_argument("--cpu-sample-genomes", type=int, default=0,
+                   help="genomes of the CPU-baseline sample index (default: one whole family + 16 genomes of other families)")
+    p.add_argument("--cpu-sample-queries", type=int, default=0)
     return p.parse_args()
 
 
 WORKLOADS = {
+    # BASELINE.json configs[2]: 10k ONT-style long reads (5-50 kb) vs 100k genomes, 1 MI355X (chaining + WFA stress).
+    # 100 000 x 2-Mb genomes: packed seed image ~105 GB + 2-bit genomes 50 GB of the 288 GB (5-Mb genomes would need
+    # 125 GB of genomes + ~230 GB of seeds even at 9.5 B/seed: SURVEY.md §8d asks to state the shape that fits).
+    # 1001 families (~100 members each; 1001 is coprime with 2/4/8 so family members spread over index shards).
+    "c3": dict(genomes=100000, genome_len=2_000_000, families=1001, queries=10000, qlen=(5000, 50000), kind="reads"),
     # BASELINE.json configs[1]: 1k gene queries (1-2 kb) vs 10k synthetic 5-Mb genomes, index HBM-resident
-    "c2": dict(genomes=10000, genome_len=5_000_000, families=100, queries=1000, qlen=(1000, 2000)),
-    # scaled-down shapes for development (NOT the headline config)
-    "small": dict(genomes=200, genome_len=500_000, families=4, queries=1000, qlen=(1000, 2000)),
-    "tiny": dict(genomes=24, genome_len=100_000, families=4, queries=64, qlen=(300, 1500)),
-    # shape of BASELINE.json configs[2] (ONT-style long reads, chaining + WFA stress) at a size that builds in seconds;
-    # a robustness run, not a headline number
-    "c3mini": dict(genomes=2000, genome_len=5_000_000, families=40, queries=500, qlen=(5000, 50000)),
+    "c2": dict(genomes=10000, genome_len=5_000_000, families=100, queries=1000, qlen=(1000, 2000), kind="genes"),
+    # scaled-down shapes for development (NOT headline configs)
+    "small": dict(genomes=200, genome_len=500_000, families=4, queries=1000, qlen=(1000, 2000), kind="genes"),
+    "tiny": dict(genomes=24, genome_len=100_000, families=4, queries=64, qlen=(300, 1500), kind="genes"),
+    "c3mini": dict(genomes=2000, genome_len=2_000_000, families=21, queries=500, qlen=(5000, 50000), kind="reads"),
 }
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_c2_pmc_{fetch,write}.json,
-    two separate --pmc runs of this same workload): (FETCH_SIZE + WRITE_SIZE) * 1024. On gfx950 FETCH_SIZE tallies
-    128-B read requests as 64 B for wide streaming reads (MI355X_MICROARCH.md, HBM), so the read part is a lower
-    bound (at most 2x low). Returns (bytes or None, note)."""
-    here = os.path.dirname(os.path.abspath(__file__))
+def source_hash():
+    """identity of the kernels a PMC pass was taken on: sha256 over the library sources"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "lexicmap_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel, workload):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of THIS workload and THESE sources
+    (profiles/r02_<workload>_pmc_{fetch,write}.json, two separate --pmc runs): (FETCH_SIZE + WRITE_SIZE) * 1024.  On
+    gfx950 FETCH_SIZE tallies 128-B read requests as 64 B for wide streaming reads (MI355X_MICROARCH.md, HBM), so the read
+    part is a lower bound (at most 2x low).  Passes recorded on other sources are refused.  Returns (bytes|None, note)."""
     tot, found = 0.0, False
-    for fn, ctr in (("r01_c2_pmc_fetch.json", "FETCH_SIZE"), ("r01_c2_pmc_write.json", "WRITE_SIZE")):
+    for fn, ctr in (("r02_%s_pmc_fetch.json" % workload, "FETCH_SIZE"), ("r02_%s_pmc_write.json" % workload, "WRITE_SIZE")):
         try:
-            pm = json.load(open(os.path.join(here, "profiles", fn))).get("pmc", {})
+            doc = json.load(open(os.path.join(ROOT, "profiles", fn)))
         except (OSError, ValueError):
-            return None, "no committed PMC pass"
+            return None, "no committed PMC pass for workload %s" % workload
+        if doc.get("source_hash") != source_hash():
+            return None, "committed PMC pass was taken on other kernel sources (%s != %s): refused" % (
+                doc.get("source_hash"), source_hash())
+        pm = doc.get("pmc", {})
         best = None
-        for k, v in pm.items():  # rocprof reports template kernels without the bench's suffix (k_wfa_lean vs k_wfa_lean128)
+        for k, v in pm.items():  # rocprof reports template kernels without the bench's suffix
             if ctr in v and (kernel.startswith(k) or k.startswith(kernel)) and (best is None or len(k) > len(best[0])):
                 best = (k, v[ctr])
         if best is None:
             return None, "kernel not in the committed PMC pass"
         tot += best[1]["mean"] * 1024.0
         found = True
-    return (int(tot) if found else None), "(FETCH_SIZE+WRITE_SIZE)*1024 from profiles/r01_c2_pmc_*.json; read part is a lower bound on gfx950"
+    return (int(tot) if found else None), ("(FETCH_SIZE+WRITE_SIZE)*1024 from profiles/r02_%s_pmc_*.json (same sources); "
+                                           "read part is a lower bound on gfx950" % workload)
 
 
 def usable_cores():
@@ -97,31 +126,28 @@ def usable_cores():
         n = min(n, len(os.sched_getaffinity(0)))
     except AttributeError:
         pass
-    for path in ("/sys/fs/cgroup/cpu.max",):
-        try:
-            quota, period = open(path).read().split()[:2]
-            if quota != "max":
-                n = min(n, max(1, int(int(quota) / int(period))))
-        except (OSError, ValueError):
-            pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
     return n
 
 
 def cpu_baseline(index_dir, queries, seconds, ncores):
     """oracle (port) on the host cores, bounded sample; returns dict"""
     import multiprocessing as mp
-    n = len(queries)
-    # calibrate on a few queries with one core
     import oracle as O
-    oi = O.Index(index_dir)
+    n = len(queries)
+    oi = O.Index(index_dir)  # calibrate on a few queries with one core
     t0 = time.time()
     k = 0
-    while k < min(n, 4):
+    while k < min(n, 3):
         oi.search(queries[k][1])
         k += 1
     per = (time.time() - t0) / max(k, 1)
     oi.close()
-    # enough searches for ~`seconds` of wall time on all cores (the batch is repeated when it is too short for that)
     nsample = int(max(ncores, min(40 * n, seconds * ncores / max(per, 1e-4))))
     sample = [queries[i % n] for i in range(nsample)]
     with mp.Pool(ncores, initializer=_cpu_init, initargs=(index_dir,)) as pool:
@@ -129,9 +155,11 @@ def cpu_baseline(index_dir, queries, seconds, ncores):
         res = pool.map(_cpu_one, [q[1] for q in sample], chunksize=max(1, len(sample) // (ncores * 8)))
         dt = time.time() - t0
     rows = sum(r[0] for r in res)
+    bases = sum(r[1] for r in res)
     return dict(value=len(sample) / dt, unit="queries/s", cores=ncores, kind="port",
-                sample="%d searches over the %d sample queries of the same batch, oracle/liblmo.so (C restatement of the Go reference, "
-                       "RAM-resident index = the reference's -w regime) on %d processes, %.1f s, %d HSP rows"
+                gbp_aligned_per_s=bases / dt / 1e9, rows_per_query=rows / max(len(sample), 1),
+                sample="%d searches over %d sample queries, oracle/liblmo.so (C restatement of the Go reference, RAM-resident "
+                       "index = the reference's -w regime) on %d processes, %.1f s, %d HSP rows"
                        % (len(sample), n, ncores, dt, rows))
 
 
@@ -149,8 +177,49 @@ def _cpu_one(seq):
     return (len(rows), sum(r["aligned_length"] for r in rows))
 
 
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def maybe_spawn(args):
+    """`bench.py --gpus N` outside torchrun: launch N ranks of this script (one per GPU) and wait"""
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is not None:
+        if int(world_env) != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s" % (args.gpus, world_env))
+        return
+    if args.gpus <= 1:
+        return
+    import torch
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev < args.gpus and args.dist_backend == "nccl":
+        raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible" % (args.gpus, ndev))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def draw_query(np, synth, rng, seq, wl):
+    """one synthetic query from genome bases `seq` (uint8 array)"""
+    if wl["kind"] == "reads":  # ONT-like: sub 2 %, ins 2 %, del 3 % (SURVEY.md §8d)
+        q = synth.mutate(rng, seq, sub=0.02, ins=0.02, dele=0.03)
+    else:
+        d = rng.random() * 0.10
+        q = synth.mutate(rng, seq, sub=d, ins=d / 10, dele=d / 10)
+    if rng.random() < 0.5:
+        q = np.frombuffer(q.tobytes().translate(bytes.maketrans(b"ACGT", b"TGCA"))[::-1], dtype=np.uint8)
+    return q.tobytes()
+
+
 def main():
     args = parse()
+    maybe_spawn(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -168,14 +237,13 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
-
-    if world > 1:  # the ranks of a node share its cores: split them instead of oversubscribing the host-side stages
+        # the ranks of a node share its cores: split them instead of oversubscribing the host-side stages
         os.environ.setdefault("LM_HOST_THREADS", str(max(1, usable_cores() // world)))
     import lexicmap_amd as la
-    from lexicmap_amd import synth
+    from lexicmap_amd import merge, synth
 
     if args.builder is None:
-        args.builder = "gpu" if args.workload in ("c2", "c3mini") else "oracle"
+        args.builder = "gpu" if args.workload in ("c2", "c3", "c3mini") else "oracle"
     wl = dict(WORKLOADS[args.workload])
     if args.queries:
         wl["queries"] = args.queries
@@ -183,62 +251,92 @@ def main():
         wl["genomes"] = args.genomes
     if args.genome_len:
         wl["genome_len"] = args.genome_len
+    wl["families"] = min(wl["families"], wl["genomes"])
 
     t_setup = time.time()
     tmpdir = None
     index_dir = None
     opt_kw = {}
-    if args.shard == "index" and world > 1:
+    index_sharded = args.shard == "index" and world > 1
+    if index_sharded:
         opt_kw = dict(shard_rank=rank, shard_count=world)
     gpu_built = args.builder == "gpu"
     weak = world > 1 and args.shard == "queries" and args.scaling == "weak"
     cpu_queries = None
+    lo_len, hi_len = wl["qlen"]
+
+    def qlen_of(rng):
+        if wl["kind"] == "reads":  # log-uniform lengths
+            return int(np.exp(rng.uniform(np.log(lo_len), np.log(hi_len))))
+        return int(rng.integers(lo_len, hi_len + 1))
+
     if gpu_built:
-        # synthetic genomes + index generated directly in HBM by the GPU builder (no disk): the only way to have the
-        # C2-size index on a fresh box within minutes
+        # synthetic genomes + index generated directly in HBM by the GPU builder (no disk): the only way to have a
+        # C2/C3-size index on a fresh box within minutes
         gi = la.Index.synthetic(wl["genomes"], wl["genome_len"], wl["families"], seed=1000, max_div=0.10,
                                 options=la.api.default_options(**opt_kw), device=local_rank)
         nloc = gi.info()["genomes"]
+        nshard = world if index_sharded else 1
 
-        def draw_queries(rng, n, locals_):
-            out = []
-            for i in range(n):
-                l = int(locals_[int(rng.integers(0, len(locals_)))])
-                L = int(rng.integers(wl["qlen"][0], wl["qlen"][1] + 1))
-                L = min(L, wl["genome_len"])
-                st = int(rng.integers(0, wl["genome_len"] - L + 1))
-                q = np.frombuffer(gi.fetch(l, st, L), dtype=np.uint8)
-                d = rng.random() * 0.10
-                q = synth.mutate(rng, q, sub=d, ins=d / 10, dele=d / 10)
-                if rng.random() < 0.5:
-                    q = np.frombuffer(q.tobytes().translate(bytes.maketrans(b"ACGT", b"TGCA"))[::-1], dtype=np.uint8)
-                out.append(("q%05d" % i, q.tobytes()))
-            return out
+        def query_i(i, seed_base):
+            """query number i of the batch: the same bases whatever the number of ranks; None on ranks that do not hold
+            its source genome (index sharding)"""
+            rng = np.random.default_rng([seed_base, i])
+            g = int(rng.integers(0, wl["genomes"]))
+            L = min(qlen_of(rng), wl["genome_len"])
+            st = int(rng.integers(0, wl["genome_len"] - L + 1))
+            if g % nshard != (rank if index_sharded else 0):
+                return None
+            src = np.frombuffer(gi.fetch(g // nshard, st, L), dtype=np.uint8)
+            return ("q%05d" % i, draw_query(np, synth, rng, src, wl))
 
         if weak:
-            queries = draw_queries(np.random.default_rng(2000 + rank), wl["queries"], np.arange(nloc))  # this GPU's own batch
+            queries = [query_i(i, 2000 + rank) for i in range(wl["queries"])]  # this GPU's own batch
+        elif index_sharded:
+            mine = [(i, query_i(i, 2000)) for i in range(wl["queries"])]
+            mine = [(i, q) for i, q in mine if q is not None]
+            box = [None] * world
+            dist.all_gather_object(box, mine)
+            queries = [None] * wl["queries"]
+            for part in box:
+                for i, q in part:
+                    queries[i] = q
         else:
-            if rank == 0:
-                queries = draw_queries(np.random.default_rng(2000), wl["queries"], np.arange(nloc))
-            else:
-                queries = None
+            queries = [query_i(i, 2000) for i in range(wl["queries"])] if rank == 0 else None
             if world > 1:
                 box = [queries]
                 dist.broadcast_object_list(box, src=0)
                 queries = box[0]
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            # CPU-baseline sample: the first members of family 0 are fetched back from HBM and indexed by the ORACLE's
-            # writer (reference on-disk format); sample queries are drawn from them with the same generator.
+            # CPU-baseline sample index: ONE WHOLE FAMILY (so that a sample query sees the same ~genomes/family hits as
+            # in the GPU run) + a slice of other families, fetched back from HBM and indexed by the ORACLE's writer
+            # (reference on-disk format); sample queries are drawn from the family with the same generator.
             import oracle as O
             fam = wl["families"]
-            members = [g for g in range(0, wl["genomes"], fam)][:args.cpu_sample_genomes]
+            members = [g for g in range(0, wl["genomes"], fam)]
+            others = [g for g in range(1, wl["genomes"]) if g % fam != 0][:16]
+            if args.cpu_sample_genomes:
+                members = members[:args.cpu_sample_genomes]
+                others = others[:max(0, args.cpu_sample_genomes - len(members))]
             tmpdir = tempfile.mkdtemp(prefix="lm_cpu_sample_")
             index_dir = os.path.join(tmpdir, "sample.lmi")
             t_s = time.time()
-            gl = [("SYN_%09d.1" % g, [("syn%09d_c1" % g, gi.fetch(g, 0, wl["genome_len"]))]) for g in members]
+            gl = [("SYN_%09d.1" % g, [("syn%09d_c1" % g, gi.fetch(g, 0, wl["genome_len"]))]) for g in members + others]
             O.build_index(index_dir, gl, O.default_build_opt(chunks=8))
-            cpu_queries = draw_queries(np.random.default_rng(2001), args.cpu_sample_queries, np.array(members))
-            log("[rank 0] CPU sample index (%d genomes of family 0) built by the oracle in %.1f s" % (len(members), time.time() - t_s))
+            nsq = args.cpu_sample_queries or (64 if wl["kind"] == "reads" else 512)
+            cpu_queries = []
+            for i in range(nsq):
+                rng = np.random.default_rng([2001, i])
+                g = members[int(rng.integers(0, len(members)))]
+                L = min(qlen_of(rng), wl["genome_len"])
+                st = int(rng.integers(0, wl["genome_len"] - L + 1))
+                src = np.frombuffer(gi.fetch(g, st, L), dtype=np.uint8)
+                cpu_queries.append(("s%05d" % i, draw_query(np, synth, rng, src, wl)))
+            cpu_sample_note = ("SAMPLE INDEX = the %d members of family 0 + %d genomes of other families, fetched from the "
+                               "GPU-built set and indexed by the oracle writer (%.0f s); sample queries drawn from the family, "
+                               "so hits/query match the GPU run; the full index adds only no-hit seed lookups" %
+                               (len(members), len(others), time.time() - t_s))
+            log("[rank 0] CPU sample index (%d genomes) built by the oracle in %.1f s" % (len(gl), time.time() - t_s))
     else:
         import oracle as O
         tmpdir = os.path.join(tempfile.gettempdir(), "lm_bench_%s_%d_%d" % (args.workload, wl["genomes"], wl["genome_len"]))
@@ -249,40 +347,42 @@ def main():
             O.build_index(index_dir, genomes, O.default_build_opt(chunks=8))
         if world > 1:
             dist.barrier()
-        queries = synth.make_gene_queries(genomes, wl["queries"], seed=2000 + (rank if weak else 0), len_range=wl["qlen"],
-                                          max_div=0.10)
+        if wl["kind"] == "reads":
+            queries = synth.make_reads(genomes, wl["queries"], seed=2000 + (rank if weak else 0), len_range=wl["qlen"])
+        else:
+            queries = synth.make_gene_queries(genomes, wl["queries"], seed=2000 + (rank if weak else 0), len_range=wl["qlen"],
+                                              max_div=0.10)
+        cpu_sample_note = "the bench index itself (oracle-built)"
         if opt_kw:
-            whole_bases = sum(sum(len(c[1]) for c in g[1]) for g in genomes)
-            opt_kw["total_bases_override"] = whole_bases
+            opt_kw["total_bases_override"] = sum(sum(len(c[1]) for c in g[1]) for g in genomes)
         gi = la.Index(index_dir, la.api.default_options(**opt_kw), device=local_rank)
     info = gi.info()
     log("[rank %d] index ready in %.1f s: %s" % (rank, time.time() - t_setup, info))
 
     # queries of this rank
-    if weak:
+    if weak or index_sharded or world == 1:
         my = queries
-    elif args.shard == "queries" and world > 1:
-        my = [q for i, q in enumerate(queries) if i % world == rank]
     else:
-        my = queries
+        my = [q for i, q in enumerate(queries) if i % world == rank]
     seqs = [q[1] for q in my]
+    t_up = time.time()
     qb = gi.upload(seqs)  # bases resident in HBM before the timed region
-
-    from lexicmap_amd import merge
+    upload_s = time.time() - t_up
+    query_bases = sum(len(s) for s in seqs)
 
     def step():
         """one pass of the hot path over this rank's resident batch, then (N>1) the hit-list merge: one all-gather of
         the per-rank HSP row records over RCCL and the reference's final ordering"""
         rows, st = gi.search_resident_np(qb)
         if world > 1:
-            if args.shard == "queries":
+            if not index_sharded:
                 rows = rows.copy()  # the array is a view of the library's result
                 if weak:
                     rows["query"] = rows["query"] + rank * len(queries)  # every rank has its own batch
                 else:
                     rows["query"] = rows["query"] * world + rank  # local -> global query number (round-robin sharding)
             per_rank = merge.all_gather_rows(rows, device="cuda" if args.dist_backend == "nccl" else "cpu", host_on=0)
-            rows = merge.merge_sharded(per_rank) if args.shard == "index" else merge.merge_query_sharded(per_rank)
+            rows = merge.merge_sharded(per_rank) if index_sharded else merge.merge_query_sharded(per_rank)
         return rows, st
 
     for _ in range(args.warmup):
@@ -319,62 +419,90 @@ def main():
     value = nq_total * args.steps / dt
     result = None
     if rank == 0:
+        step_s = dt / args.steps
         kern = [p for p in prof if p["name"].startswith("k_")]
         kern.sort(key=lambda p: -p["total_ms"])
-        dom = kern[0] if kern else None
         kernels = []
         for p in kern:
+            per_step_ms = p["total_ms"] / args.steps
             avg_ms = p["total_ms"] / max(p["launches"], 1)
             gbs = (p["bytes"] / max(p["launches"], 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            kernels.append(dict(name=p["name"], launches=p["launches"], avg_ms=round(avg_ms, 4),
+            kernels.append(dict(name=p["name"], launches=p["launches"], avg_ms=round(avg_ms, 4), ms_per_step=round(per_step_ms, 3),
                                 algorithmic_bytes_per_launch=int(p["bytes"] / max(p["launches"], 1)),
                                 achieved_GBs=round(gbs, 3), frac_of_hbm_peak=round(gbs / HBM_PEAK_GBS, 6)))
-        prims = [dict(name=p["name"], launches=p["launches"], avg_ms=round(p["total_ms"] / max(p["launches"], 1), 4))
+        prims = [dict(name=p["name"], launches=p["launches"], avg_ms=round(p["total_ms"] / max(p["launches"], 1), 4),
+                      ms_per_step=round(p["total_ms"] / args.steps, 3))
                  for p in sorted(prof, key=lambda p: -p["total_ms"]) if not p["name"].startswith("k_")]
-        roofline = None
-        if dom:
-            avg_ms = dom["total_ms"] / max(dom["launches"], 1)
-            ach = (dom["bytes"] / max(dom["launches"], 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            traffic, tnote = pmc_traffic(dom["name"]) if args.workload == "c2" else (None, "PMC passes are taken on c2")
-            roofline = dict(bound="hbm", kernel=dom["name"], achieved=round(ach, 3), peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=round(ach / HBM_PEAK_GBS, 6), traffic=traffic, traffic_source=tnote,
-                            avg_launch_ms=round(avg_ms, 4), launches=dom["launches"])
-        # the HBM-bound kernel of the path (north_star: seed lookup against the in-HBM index) reported next to the dominant one
+
+        def roof(pk):
+            avg_ms = pk["total_ms"] / max(pk["launches"], 1)
+            ach = (pk["bytes"] / max(pk["launches"], 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            tr, tn = pmc_traffic(pk["name"], args.workload)
+            alg = pk["bytes"] / max(pk["launches"], 1)
+            return dict(bound="hbm", kernel=pk["name"], achieved=round(ach, 3), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(ach / HBM_PEAK_GBS, 6), traffic=tr, traffic_source=tn,
+                        traffic_over_algorithmic=(round(tr / alg, 2) if tr and alg else None),
+                        traffic_GBs=(round(tr / (avg_ms * 1e-3) / 1e9, 1) if tr else None),
+                        algorithmic_bytes_per_launch=int(alg), avg_launch_ms=round(avg_ms, 4), launches=pk["launches"])
+
+        roofline = roof(kern[0]) if kern else None
+        # the HBM-bound stage of the path (north_star: seed lookup against the in-HBM index): the search kernel and the
+        # whole stage (prep + sort + count + scan + emit) against the same SURVEY §8(d) bytes
         roofline_lookup = None
-        for pk in kern:
-            if pk["name"] == "k_lookup_count":
-                avg_ms = pk["total_ms"] / max(pk["launches"], 1)
-                ach = (pk["bytes"] / max(pk["launches"], 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-                tr, tn = pmc_traffic(pk["name"]) if args.workload == "c2" else (None, "PMC passes are taken on c2")
-                roofline_lookup = dict(bound="hbm", kernel=pk["name"], achieved=round(ach, 3), peak=HBM_PEAK_GBS, unit="GB/s",
-                                       frac=round(ach / HBM_PEAK_GBS, 6), traffic=tr, traffic_source=tn,
-                                       avg_launch_ms=round(avg_ms, 4), launches=pk["launches"],
-                                       traffic_GBs=(round(tr / (avg_ms * 1e-3) / 1e9, 1) if tr else None))
+        byname = {p["name"]: p for p in prof}
+        if "k_lookup_count" in byname:
+            roofline_lookup = roof(byname["k_lookup_count"])
+            stage_ms = sum(byname[n]["total_ms"] for n in ("k_lookup_prep", "sort_lookups", "k_lookup_count", "scan", "k_lookup_emit")
+                           if n in byname) / max(byname["k_lookup_count"]["launches"], 1)
+            stage_bytes = (byname["k_lookup_count"]["bytes"] + byname.get("k_lookup_emit", {"bytes": 0})["bytes"]) / \
+                max(byname["k_lookup_count"]["launches"], 1)
+            roofline_lookup["stage_ms"] = round(stage_ms, 4)
+            roofline_lookup["stage_frac"] = round(stage_bytes / (stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if stage_ms > 0 else None
+        # whole pipeline: sum of the algorithmic bytes of all kernels per step over the step time
+        alg_step = sum(p["bytes"] for p in kern) / args.steps
+        kern_ms_step = sum(p["total_ms"] for p in prof) / args.steps
+        roofline_pipeline = dict(bound="hbm", achieved=round(alg_step / step_s / 1e9, 3), peak=HBM_PEAK_GBS, unit="GB/s",
+                                 frac=round(alg_step / step_s / 1e9 / HBM_PEAK_GBS, 6),
+                                 algorithmic_bytes_per_step=int(alg_step),
+                                 kernel_ms_per_step=round(kern_ms_step, 3),
+                                 kernel_time_fraction_of_step=round(kern_ms_step / (step_s * 1e3), 4))
         go = shutil.which("go")
+        qdesc = ("ONT-style reads (%d-%d bp log-uniform, sub 2%% ins 2%% del 3%%)" if wl["kind"] == "reads" else
+                 "gene queries (%d-%d bp, <=10%% divergence)") % (lo_len, hi_len)
+        seed_B = info["seed_bytes"] / max(info["seeds"], 1)
         result = {
             "metric": "queries/sec (lexicmap search hot path, seed index HBM-resident)",
             "value": round(value, 3), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            # weak: every GPU searches its own batch of the workload's size; strong: one batch (or the index) is divided
-            "scaling": "weak" if (weak or (world == 1 and args.shard == "queries" and args.scaling == "weak")) else "strong",
+            "ms_per_step": round(step_s * 1e3, 3), "higher_is_better": True,
+            # strong: the batch (and with index sharding the genome set) is fixed as N grows; weak: own batch per GPU
+            "scaling": "weak" if weak else "strong",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "gbp_aligned_per_s": round(aligned_total * args.steps / dt / 1e9 * (1 if world == 1 else 1), 6),
-            "config": {"workload": "%s: %d gene queries (%d-%d bp, <=10%% divergence) vs %d synthetic genomes x %d bp "
-                                   "(%d families), M=%d masks, k=%d, index %s" %
-                                   (args.workload, nq_total, wl["qlen"][0], wl["qlen"][1], wl["genomes"], wl["genome_len"],
+            "gbp_aligned_per_s": round(aligned_total * args.steps / dt / 1e9, 6),
+            "config": {"workload": "%s: %d %s vs %d synthetic genomes x %d bp (%d families), M=%d masks, k=%d, index %s" %
+                                   (args.workload, nq_total, qdesc, wl["genomes"], wl["genome_len"],
                                     wl["families"], info["masks"], info["k"],
                                     "GPU-built in HBM" if gpu_built else "oracle-built, loaded from the reference format"),
-                       "seeds_resident": info["seeds"], "index_hbm_bytes": info["hbm_bytes"], "parallelism":
-                           (("q-shard x%d (index replicated), %d queries per GPU" % (world, len(my))) if args.shard == "queries"
-                            else ("index-shard x%d" % world)),
+                       "seeds_resident": info["seeds"], "index_hbm_bytes": info["hbm_bytes"],
+                       "seed_image_bytes": info["seed_bytes"], "seed_image_bytes_per_seed": round(seed_B, 3),
+                       "index_hbm_bytes_per_seed": round(info["hbm_bytes"] / max(info["seeds"], 1), 3),
+                       "seed_layout": "partition table (%d bases) + %d-bit k-mer remainder + %d-bit value per seed; %d outlier seeds flat" %
+                                      (info["partition_bases"], info["key_bits"], info["val_bits"], info["outlier_seeds"]),
+                       "genomes_resident": info["genomes"], "query_bases": query_bases,
+                       "parallelism": ("1 GPU" if world == 1 else
+                                       ("index-shard x%d (genome g on rank g %% %d), queries broadcast, one all-gatherv of HSP rows per step" % (world, world))
+                                       if index_sharded else
+                                       ("q-shard x%d (index replicated), %d queries per GPU" % (world, len(my)))),
+                       "pcie_upload_s": round(upload_s, 4),
                        "go_toolchain": go or "absent (reference Go binary cannot be built; CPU baseline is the C port)"},
             "stage_ms": {k: round(v, 3) for k, v in stats.items() if k.startswith("ms_")},
             "work": {k: v for k, v in stats.items() if not k.startswith("ms_")},
             "rows": rows_total,
             "roofline": roofline,
             "roofline_seed_lookup": roofline_lookup,
+            "roofline_pipeline": roofline_pipeline,
             "kernels": kernels,
             "rocprim_calls": prims,
+            "source_hash": source_hash(),
         }
     gi.free_batch(qb)
     # CPU baseline on rank 0, N=1 only
@@ -382,11 +510,7 @@ def main():
         try:
             ncores = usable_cores()
             cb = cpu_baseline(index_dir, cpu_queries or queries, args.cpu_seconds, ncores)
-            if cpu_queries is not None:
-                cb["sample"] += ("; SAMPLE INDEX = %d members of one family fetched from the GPU-built set and indexed by "
-                                 "the oracle writer (~%d genome hits/query instead of ~%d in the GPU run, so this CPU "
-                                 "number is an upper bound for the full index)" %
-                                 (args.cpu_sample_genomes, args.cpu_sample_genomes, wl["genomes"] // wl["families"]))
+            cb["sample"] += "; " + cpu_sample_note
             if cpu_queries is not None:
                 # the same sample (same index directory, same queries) through the HIP path: a like-for-like pair of numbers
                 try:
@@ -395,12 +519,12 @@ def main():
                     g2.search_resident_np(qb2)
                     torch.cuda.synchronize()
                     t1 = time.time()
-                    reps = 5
+                    reps = 3
                     for _ in range(reps):
                         r2, _s2 = g2.search_resident_np(qb2)
                     torch.cuda.synchronize()
                     cb["gpu_on_same_sample"] = dict(value=round(len(cpu_queries) * reps / (time.time() - t1), 1),
-                                                    unit="queries/s", rows_per_pass=int(len(r2)))
+                                                    unit="queries/s", rows_per_query=round(len(r2) / len(cpu_queries), 2))
                     g2.free_batch(qb2)
                     g2.close()
                 except Exception as e:
@@ -409,6 +533,8 @@ def main():
         except Exception as e:  # the baseline must not kill the bench line
             result["cpu_baseline"] = dict(value=None, unit="queries/s", cores=0, kind="port", sample="failed: %r" % (e,))
     gi.close()
+    if tmpdir and gpu_built:
+        shutil.rmtree(tmpdir, ignore_errors=True)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -105,6 +105,10 @@ void lm_index_close(lm_index *idx);
 lm_status lm_index_get_info(const lm_index *idx, lm_index_info *info);
 /* masks of the index (lexichash.LexicHash.Masks), borrowed until close */
 const uint64_t *lm_index_masks(const lm_index *idx);
+/* (k-mer, value) pairs stored under one mask (normal seeds, then reversed seeds; each part ascending by k-mer), values
+ * in the reference layout batch:17|genome:17|pos:28|rc:1|reversed:1: kv.Reader.ReadDataOfAMaskAsList
+ * (kv/kv-reader.go:762), what `lexicmap utils kmers --mask` prints (kmers.go:101-180). Call with cap = 0 for the count. */
+lm_status lm_index_mask_seeds(lm_index *idx, int32_t mask, uint64_t *kmers, uint64_t *vals, size_t cap, size_t *n);
 /* text of the last error on this handle, or of the last failed lm_index_open when idx == NULL */
 const char *lm_last_error(const lm_index *idx);
 

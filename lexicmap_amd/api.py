@@ -137,6 +137,8 @@ def lib():
     L.lm_wfa_batch.argtypes = [vp, C.POINTER(Query), C.POINTER(Query), C.c_size_t, C.POINTER(vp),
                                C.POINTER(C.POINTER(Wfa)), C.POINTER(C.POINTER(C.c_uint64))]
     L.lm_index_build_synthetic.argtypes = [C.POINTER(SynthSpec), C.POINTER(Options), C.c_int, C.POINTER(vp)]
+    L.lm_index_mask_seeds.argtypes = [vp, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_size_t,
+                                      C.POINTER(C.c_size_t)]
     L.lm_index_fetch.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64, C.c_char_p]
     L.lm_profile_enable.argtypes = [vp, C.c_int]
     L.lm_profile_reset.argtypes = [vp]
@@ -211,6 +213,21 @@ class Index:
         i = IndexInfo()
         lib().lm_index_get_info(self.h, C.byref(i))
         return {f[0]: getattr(i, f[0]) for f in IndexInfo._fields_}
+
+    def mask_seeds(self, mask):
+        """(k-mers, values) stored under one mask as numpy uint64 arrays (reference value layout)"""
+        import numpy as np
+        n = C.c_size_t()
+        st = lib().lm_index_mask_seeds(self.h, mask, None, None, 0, C.byref(n))
+        if st != 0:
+            self._err(st)
+        k = np.zeros(max(n.value, 1), dtype=np.uint64)
+        v = np.zeros(max(n.value, 1), dtype=np.uint64)
+        st = lib().lm_index_mask_seeds(self.h, mask, k.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                       v.ctypes.data_as(C.POINTER(C.c_uint64)), n.value, C.byref(n))
+        if st != 0:
+            self._err(st)
+        return k[:n.value], v[:n.value]
 
     def upload(self, seqs):
         arr, keep = _queries(seqs)

@@ -195,6 +195,113 @@ __global__ void k_cap_emit(SynthDev sp, MaskTab mt, const uint8_t *__restrict__ 
     }
 }
 
+// LexicHash capture of one genome by one workgroup, both passes in one launch: the per-mask minima live in LDS
+// (M x 8 B = 160 KB for the default 20000 masks: the whole LDS of a CU) instead of a global table hammered with atomics.
+// Masks of a p-base prefix are found without a table in memory: in a lexicmap mask set every prefix has one mask and
+// some have two (docs/content/usage/utils/masks.md:69-110), so first(pf) = pf + #doubled prefixes below pf: a 4^p-bit
+// map + per-word counts (2.5 KB).  Phase 1: ds_min_u64 of mask^kmer; phase 2: every k-mer equal to its mask's minimum is
+// emitted (all occurrences, lib-index-build.go:1028-1046), low-complexity captures dropped.
+__global__ __launch_bounds__(1024) void k_capture_lds(SynthDev sp, MaskTab mt, const uint8_t *__restrict__ gbits, int64_t l0,
+                                                      const uint64_t *__restrict__ dbl_map, const uint32_t *__restrict__ dbl_cnt,
+                                                      uint16_t *__restrict__ s_mask, uint64_t *__restrict__ s_kmer,
+                                                      uint64_t *__restrict__ s_val, unsigned long long *__restrict__ counter,
+                                                      unsigned long long cap, uint64_t *__restrict__ pos_keys,
+                                                      unsigned long long *__restrict__ pos_counter, unsigned long long pos_cap) {
+    extern __shared__ unsigned long long lds_dyn[];
+    unsigned long long *hs = lds_dyn;                                   // [M]
+    const int nw = ((1 << (2 * mt.p)) + 63) >> 6;
+    unsigned long long *bm = hs + mt.M;                                  // [nw]
+    uint32_t *bc = (uint32_t *)(bm + nw);                                // [nw]
+    const int c = blockIdx.x;
+    const uint8_t *gb = gbits + (l0 + c) * sp.gbytes;
+    const int64_t npos = (int64_t)sp.genome_len - mt.K + 1;
+    const int shift = (mt.K - mt.p) << 1;
+    for (int i = threadIdx.x; i < mt.M; i += blockDim.x) hs[i] = ~0ull;
+    for (int i = threadIdx.x; i < nw; i += blockDim.x) {
+        bm[i] = dbl_map[i];
+        bc[i] = dbl_cnt[i];
+    }
+    __syncthreads();
+    for (int64_t pos = threadIdx.x; pos < npos; pos += blockDim.x) {
+        const uint64_t fwd = packed_kmer(gb, pos, mt.K);
+        const uint64_t rc = lm_revcomp(fwd, mt.K);
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const uint64_t x = s ? rc : fwd;
+            const uint32_t pf = (uint32_t)(x >> shift);
+            const unsigned long long w = bm[pf >> 6];
+            const int j0 = (int)(pf + bc[pf >> 6] + (uint32_t)__popcll(w & ((1ull << (pf & 63)) - 1)));
+            const int nj = 1 + (int)((w >> (pf & 63)) & 1ull);
+            for (int j = j0; j < j0 + nj; j++) {
+                const unsigned long long h = mt.masks[j] ^ x;
+                if (h < hs[j]) atomicMin(&hs[j], h);
+            }
+        }
+    }
+    __syncthreads();
+    const int64_t g = global_genome(sp, l0 + c);
+    const uint64_t bg = ((uint64_t)(g / 5000) << 17) | (uint64_t)(g % 5000);
+    // phase 2a counts this thread's captures, the workgroup reserves ONE contiguous range of the staging arrays for the
+    // genome (a per-capture atomic on the shared counter costs more than the whole sweep), phase 2b writes
+    uint32_t *wsum = bc + nw; // [16] wave totals
+    __shared__ unsigned long long base_seed, base_pos;
+    uint32_t mine = 0;
+    for (int sweep = 0; sweep < 2; sweep++) {
+        unsigned long long o = 0, po = 0;
+        if (sweep == 1) {
+            uint32_t incl = mine;
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t v = __shfl_up(incl, d);
+                if (lane >= d) incl += v;
+            }
+            if (lane == 63) wsum[wave] = incl;
+            __syncthreads();
+            uint32_t before = 0, all = 0;
+            for (int w2 = 0; w2 < (int)(blockDim.x >> 6); w2++) {
+                if (w2 < wave) before += wsum[w2];
+                all += wsum[w2];
+            }
+            if (threadIdx.x == 0) {
+                base_seed = atomicAdd(counter, (unsigned long long)all);
+                base_pos = atomicAdd(pos_counter, (unsigned long long)all);
+            }
+            __syncthreads();
+            o = base_seed + before + (incl - mine);
+            po = base_pos + before + (incl - mine);
+        }
+        for (int64_t pos = threadIdx.x; pos < npos; pos += blockDim.x) {
+            const uint64_t fwd = packed_kmer(gb, pos, mt.K);
+            const uint64_t rc = lm_revcomp(fwd, mt.K);
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const uint64_t x = s ? rc : fwd;
+                const uint32_t pf = (uint32_t)(x >> shift);
+                const unsigned long long w = bm[pf >> 6];
+                const int j0 = (int)(pf + bc[pf >> 6] + (uint32_t)__popcll(w & ((1ull << (pf & 63)) - 1)));
+                const int nj = 1 + (int)((w >> (pf & 63)) & 1ull);
+                for (int j = j0; j < j0 + nj; j++) {
+                    if ((mt.masks[j] ^ x) != hs[j]) continue;
+                    if (x == 0 || lm_low_complexity(x, mt.K)) continue;
+                    if (sweep == 0) {
+                        mine++;
+                        continue;
+                    }
+                    if (o < cap) {
+                        s_mask[o] = (uint16_t)j;
+                        s_kmer[o] = x;
+                        s_val[o] = (bg << 30) | ((uint64_t)pos << 2) | ((uint64_t)s << 1);
+                    }
+                    if (po < pos_cap) pos_keys[po] = ((uint64_t)c << 32) | ((uint64_t)pos << 1) | (uint64_t)s;
+                    o++;
+                    po++;
+                }
+            }
+        }
+    }
+}
+
 __global__ void k_pseudo_pos(int nchunk, int32_t last_pos, uint64_t *__restrict__ pos_keys, unsigned long long base) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < nchunk) pos_keys[base + c] = ((uint64_t)c << 32) | ((uint64_t)(uint32_t)last_pos << 1) | 1ull; // sorts last
@@ -489,7 +596,27 @@ lm_status lm_index_build_synthetic(const lm_synth_spec *spec, const lm_options *
         // ---- seeds: generated per chunk of genomes into a staging buffer and shown to the packer, twice (count, place):
         // the unpacked seeds of the whole set never exist (they would not fit beside the packed image at BASELINE configs 3-5)
         const bool dbg = getenv("LM_DEBUG") != nullptr;
-        const int CH = (int)std::min<int64_t>(nlocal, std::max<int64_t>(1, (int64_t)(192ll << 20) / ((int64_t)M * 8)));
+        // capture in LDS when the per-mask minima fit a CU's LDS and the mask set has the lexicmap structure (every
+        // p-base prefix once or twice); otherwise minima in a global table
+        const int npfx = 1 << (2 * p), nwords = (npfx + 63) >> 6;
+        bool lds_capture = true;
+        std::vector<uint64_t> dmap(nwords, 0);
+        std::vector<uint32_t> dcnt(nwords, 0);
+        for (int f = 0; f < npfx; f++) {
+            const int c = pfx[f + 1] - pfx[f];
+            if (c < 1 || c > 2) lds_capture = false;
+            if (c == 2) dmap[f >> 6] |= 1ull << (f & 63);
+        }
+        for (int w = 1; w < nwords; w++) dcnt[w] = dcnt[w - 1] + (uint32_t)__builtin_popcountll(dmap[w - 1]);
+        const size_t lds_bytes = (size_t)M * 8 + (size_t)nwords * 12 + 64;
+        if (lds_bytes > 160 * 1024 || getenv("LM_BUILDER_GLOBAL_CAPTURE")) lds_capture = false;
+        DBuf<uint64_t> dbl_map;
+        DBuf<uint32_t> dbl_cnt;
+        copy_up(dbl_map, dmap);
+        copy_up(dbl_cnt, dcnt);
+        if (lds_capture && lds_bytes > 64 * 1024)
+            HIPCHK(hipFuncSetAttribute((const void *)k_capture_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        const int CH = (int)std::min<int64_t>(nlocal, lds_capture ? 2048 : std::max<int64_t>(1, (int64_t)(192ll << 20) / ((int64_t)M * 8)));
         double per_genome = 2.0 * (1.45 * M + (double)spec->genome_len / 42.0) + 1024;
         unsigned long long cap = (unsigned long long)(per_genome * (double)CH) + 65536;
         DBuf<uint16_t> s_mask;
@@ -500,7 +627,7 @@ lm_status lm_index_build_synthetic(const lm_synth_spec *spec, const lm_options *
         DBuf<unsigned long long> counters;
         counters.ensure(8);
         DBuf<unsigned long long> hashes;
-        hashes.alloc_exact((size_t)CH * M);
+        hashes.alloc_exact(lds_capture ? 1 : (size_t)CH * M);
         unsigned long long pos_cap = (unsigned long long)((1.45 * M + 64) * CH) + CH + 64;
         DBuf<uint64_t> pos_keys, pos_keys2;
         pos_keys.alloc_exact(pos_cap);
@@ -513,14 +640,20 @@ lm_status lm_index_build_synthetic(const lm_synth_spec *spec, const lm_options *
             for (int64_t l0 = 0; l0 < nlocal; l0 += CH) {
                 int nch = (int)std::min<int64_t>(CH, nlocal - l0);
                 double ta = now_ms();
-                hipLaunchKernelGGL(k_fill_u64, dim3(gridn((int64_t)nch * M)), dim3(256), 0, ix->st, hashes.p, (int64_t)nch * M,
-                                   ~0ull);
                 HIPCHK(hipMemsetAsync(counters.p, 0, 2 * sizeof(unsigned long long), ix->st));
-                hipLaunchKernelGGL(k_cap_argmin, dim3(gridn((int64_t)nch * npos)), dim3(256), 0, ix->st, sp, mt, ix->d_gbits.p, l0,
-                                   nch, hashes.p);
-                hipLaunchKernelGGL(k_cap_emit, dim3(gridn((int64_t)nch * npos)), dim3(256), 0, ix->st, sp, mt, ix->d_gbits.p, l0,
-                                   nch, hashes.p, s_mask.p, s_kmer.p, s_val.p, counters.p, cap, pos_keys.p, counters.p + 1,
-                                   pos_cap - CH - 1);
+                if (lds_capture) {
+                    hipLaunchKernelGGL(k_capture_lds, dim3(nch), dim3(1024), lds_bytes, ix->st, sp, mt, ix->d_gbits.p, l0,
+                                       dbl_map.p, dbl_cnt.p, s_mask.p, s_kmer.p, s_val.p, counters.p, cap, pos_keys.p,
+                                       counters.p + 1, pos_cap - CH - 1);
+                } else {
+                    hipLaunchKernelGGL(k_fill_u64, dim3(gridn((int64_t)nch * M)), dim3(256), 0, ix->st, hashes.p,
+                                       (int64_t)nch * M, ~0ull);
+                    hipLaunchKernelGGL(k_cap_argmin, dim3(gridn((int64_t)nch * npos)), dim3(256), 0, ix->st, sp, mt,
+                                       ix->d_gbits.p, l0, nch, hashes.p);
+                    hipLaunchKernelGGL(k_cap_emit, dim3(gridn((int64_t)nch * npos)), dim3(256), 0, ix->st, sp, mt, ix->d_gbits.p,
+                                       l0, nch, hashes.p, s_mask.p, s_kmer.p, s_val.p, counters.p, cap, pos_keys.p,
+                                       counters.p + 1, pos_cap - CH - 1);
+                }
                 unsigned long long hc[2];
                 HIPCHK(hipMemcpyAsync(hc, counters.p, sizeof hc, hipMemcpyDeviceToHost, ix->st));
                 bsync(ix);
@@ -568,7 +701,9 @@ lm_status lm_index_build_synthetic(const lm_synth_spec *spec, const lm_options *
         packer.finish();
         if (dbg) fprintf(stderr, "[lm] builder: partition sort %.0f ms; %lld seeds (%lld outliers), %.2f B/seed\n", now_ms() - tf,
                          (long long)ix->n_seeds, (long long)ix->n_seeds_outlier, (double)ix->seed_bytes / std::max<double>(1.0, (double)ix->n_seeds));
+        ix->tmp.release();
         ix->hbm_bytes = ix->seed_bytes + (int64_t)((uint64_t)(nlocal * sp.gbytes) + 64 + (uint64_t)M * 8 + pfx.size() * 4 + nlocal * 20);
+        lm_set_scratch_budget(ix);
     } catch (const std::exception &e) {
         g_open_error = e.what();
         delete ix;

@@ -98,6 +98,7 @@ using namespace lm;
 extern thread_local std::string g_open_error; // text of the last failed open/build (lm_last_error(NULL))
 struct lm_index;
 void lm_fill_gap_lut(lm_index *ix);
+void lm_set_scratch_budget(lm_index *ix);
 
 namespace lm {
 struct Work;
@@ -135,6 +136,7 @@ struct lm_index {
     DBuf<int32_t> d_pfx_first, d_g_len;
     DBuf<int64_t> d_md_off, d_out_off, d_g_off, d_batch_first;
     int64_t n_seeds = 0, n_seeds_outlier = 0, seed_bytes = 0; // resident seeds; bytes of the whole seed image
+    int64_t scratch_budget = 0; // device memory left for per-batch scratch once the index image is resident
     DBuf<uint8_t> d_gbits;
     DBuf<float> d_gap_lut;
     int gap_lut_n = 0;

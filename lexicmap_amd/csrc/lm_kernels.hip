@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "lm_algos.h"
 #include "lm_kernels.h"
 
@@ -178,47 +180,72 @@ __device__ __forceinline__ uint32_t lookup_sort_key(const DevIndexView &ix, uint
     if (ix.out_off[md + 1] > ix.out_off[md]) return (1u << LM_LK_OUTLIER_BIT) | md;
     return 0xffffffffu; // nothing stored under this list can share min_prefix >= p bases with x
 }
-// one slot per (query, mask, direction): t = (query*M + mask)*2 + dir.  Issued lookups are appended (wave-aggregated)
-// to (key, slot) in arbitrary order; the radix sort that follows puts them in (list, partition) order.
+// one slot per (query, mask, direction): t = (query*M + mask)*2 + dir.  A workgroup classifies a tile of LK_TILE
+// consecutive slots, reserves room for its issued lookups with ONE atomic and appends them (key, slot); the radix sort
+// that follows puts them in (list, partition) order.
+#define LK_PER_THREAD 8
+#define LK_TILE (256 * LK_PER_THREAD)
 __global__ __launch_bounds__(256) void k_lookup_prep(DevIndexView ix, const uint64_t *__restrict__ kmers,
                                                      const int64_t *__restrict__ klo,
                                                      const uint32_t *__restrict__ first_mask, int64_t nqm,
                                                      uint32_t *__restrict__ keys, uint32_t *__restrict__ slots,
                                                      unsigned long long *__restrict__ counter) {
+    __shared__ uint32_t wave_cnt[4];
+    __shared__ unsigned long long tile_base;
     const int64_t total = nqm * 2;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t rounds = (total + stride - 1) / stride;
-    for (int64_t r = 0; r < rounds; r++) {
-        const int64_t t = r * stride + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        uint32_t key = 0xffffffffu;
-        if (t < total) {
-            const int dir = (int)(t & 1);
-            const int64_t qm = t >> 1;
-            const uint64_t kmer = kmers[qm];
-            const int m = (int)(qm % ix.M);
-            if (kmer != 0) {
-                if (dir == 0) {
-                    key = lookup_sort_key(ix, (uint32_t)m << 1, kmer);
-                } else if (first_mask[klo[qm]] == (uint32_t)m) { // de-duplicated reversed k-mer (:1288-1298)
-                    const uint64_t rev = lm_reverse(kmer, ix.K);
-                    const int a = argmin_mask(ix.masks, ix.pfx_first, ix.K, ix.mask_prefix, rev);
-                    if (a >= 0) key = lookup_sort_key(ix, ((uint32_t)a << 1) | 1u, rev);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t tile = (int64_t)blockIdx.x * LK_TILE; tile < total; tile += (int64_t)gridDim.x * LK_TILE) {
+        uint32_t key[LK_PER_THREAD];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int r = 0; r < LK_PER_THREAD; r++) {
+            const int64_t t = tile + r * 256 + threadIdx.x; // coalesced over the tile
+            uint32_t k = 0xffffffffu;
+            if (t < total) {
+                const int dir = (int)(t & 1);
+                const int64_t qm = t >> 1;
+                const uint64_t kmer = kmers[qm];
+                const int m = (int)(qm % ix.M);
+                if (kmer != 0) {
+                    if (dir == 0) {
+                        k = lookup_sort_key(ix, (uint32_t)m << 1, kmer);
+                    } else if (first_mask[klo[qm]] == (uint32_t)m) { // de-duplicated reversed k-mer (:1288-1298)
+                        const uint64_t rev = lm_reverse(kmer, ix.K);
+                        const int a = argmin_mask(ix.masks, ix.pfx_first, ix.K, ix.mask_prefix, rev);
+                        if (a >= 0) k = lookup_sort_key(ix, ((uint32_t)a << 1) | 1u, rev);
+                    }
                 }
             }
+            key[r] = k;
+            mine += k != 0xffffffffu;
         }
-        const bool issue = key != 0xffffffffu;
-        const unsigned long long bal = __ballot(issue);
-        if (bal) {
-            const int lane = threadIdx.x & 63;
-            unsigned long long base = 0;
-            if (lane == __ffsll((long long)bal) - 1) base = atomicAdd(counter, (unsigned long long)__popcll(bal));
-            base = __shfl(base, __ffsll((long long)bal) - 1);
-            if (issue) {
-                const unsigned long long o = base + (unsigned long long)__popcll(bal & ((1ull << lane) - 1));
-                keys[o] = key;
-                slots[o] = (uint32_t)t;
-            }
+        // exclusive prefix of `mine` over the workgroup: wave scan + 4 wave totals
+        uint32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
         }
+        if (lane == 63) wave_cnt[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+        for (int w2 = 0; w2 < 4; w2++) {
+            if (w2 < wave) before += wave_cnt[w2];
+            all += wave_cnt[w2];
+        }
+        if (threadIdx.x == 0 && all) tile_base = atomicAdd(counter, (unsigned long long)all);
+        __syncthreads();
+        if (mine) {
+            unsigned long long o = tile_base + before + (incl - mine);
+#pragma unroll
+            for (int r = 0; r < LK_PER_THREAD; r++)
+                if (key[r] != 0xffffffffu) {
+                    keys[o] = key[r];
+                    slots[o] = (uint32_t)(tile + r * 256 + threadIdx.x);
+                    o++;
+                }
+        }
+        __syncthreads();
     }
 }
 // position in sorted order handled by this thread: logical workgroup x*per + y runs as hardware workgroup y*8 + x, i.e.
@@ -2176,7 +2203,9 @@ void launch_mask(hipStream_t st, const uint64_t *keys_all, const int64_t *posoff
 }
 void launch_lookup_prep(hipStream_t st, DevIndexView ix, const uint64_t *kmers, const int64_t *klo, const uint32_t *first_mask,
                         int64_t nqm, uint32_t *keys, uint32_t *slots, unsigned long long *counter) {
-    LM_LAUNCH_1D(k_lookup_prep, nqm * 2, st, ix, kmers, klo, first_mask, nqm, keys, slots, counter);
+    const int64_t tiles = (nqm * 2 + 2047) / 2048;
+    hipLaunchKernelGGL(k_lookup_prep, dim3((unsigned)std::min<int64_t>(std::max<int64_t>(tiles, 1), 65536)), dim3(256), 0, st, ix,
+                       kmers, klo, first_mask, nqm, keys, slots, counter);
 }
 static int lookup_grid(int64_t total) { // one thread per lookup, workgroup count a multiple of 8 (see lookup_index)
     int64_t nb = (total + 255) / 256;

@@ -140,6 +140,17 @@ void lm_fill_gap_lut(lm_index *ix) {
     HIPCHK(hipStreamSynchronize(S(ix)));
 }
 
+// what is left of the device once the index image is resident bounds the per-batch scratch (query parts, WFA pools)
+void lm_set_scratch_budget(lm_index *ix) {
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) return;
+    ix->scratch_budget = (int64_t)((double)fr * 0.85);
+    if (const char *e = getenv("LM_SCRATCH_BUDGET_MB")) ix->scratch_budget = std::max<int64_t>(64, atoll(e)) << 20;
+    if (getenv("LM_DEBUG"))
+        fprintf(stderr, "[lm] index resident: %.2f GB, device free %.2f of %.2f GB, scratch budget %.2f GB\n",
+                (double)ix->hbm_bytes / 1e9, (double)fr / 1e9, (double)tot / 1e9, (double)ix->scratch_budget / 1e9);
+}
+
 namespace lm {
 
 template <typename T> static void h2d(lm_index *ix, DBuf<T> &d, const std::vector<T> &h) {
@@ -304,6 +315,13 @@ static void sort_anchors_fields(lm_index *ix, uint64_t *A0, uint64_t *B0, uint64
 struct lm_qbatch {
     lm_index *ix = nullptr;
     int nq = 0;
+    // a batch too large for one pass of the pipeline (device scratch, 32-bit slot numbers) is held as consecutive parts;
+    // `parts` is empty for a plain batch. q0 = number of the part's first query in the caller's batch.
+    std::vector<lm_qbatch *> parts;
+    uint32_t q0 = 0;
+    ~lm_qbatch() {
+        for (auto *p : parts) delete p;
+    }
     std::vector<uint8_t> h_seq;
     std::vector<int64_t> h_qoff, h_posoff;
     int64_t total_len = 0, total_pos = 0;
@@ -929,6 +947,8 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
         std::vector<uint64_t>().swap(h.seed_kmers);
         std::vector<uint64_t>().swap(h.seed_vals);
         std::vector<uint8_t>().swap(h.gbits);
+        ix->tmp.release();
+        lm_set_scratch_budget(ix);
     } catch (const std::exception &e) {
         g_open_error = e.what();
         delete ix;
@@ -986,14 +1006,12 @@ size_t lm_profile_get(lm_index *ix, const lm_kernel_time **out) {
 }
 
 // ---- query upload ---------------------------------------------------------------------------------------------
-lm_status lm_qbatch_upload(lm_index *ix, const lm_query *queries, size_t nq, lm_qbatch **out) {
-    *out = nullptr;
-    if (!ix) return LM_ERR_ARG;
+static lm_qbatch *upload_part(lm_index *ix, const lm_query *queries, size_t nq, uint32_t q0) {
+    lm_qbatch *qb = new lm_qbatch();
     try {
-        HIPCHK(hipSetDevice(ix->device));
-        lm_qbatch *qb = new lm_qbatch();
         qb->ix = ix;
         qb->nq = (int)nq;
+        qb->q0 = q0;
         qb->h_qoff.assign(nq + 1, 0);
         qb->h_posoff.assign(nq + 1, 0);
         int K = ix->host.k;
@@ -1004,11 +1022,6 @@ lm_status lm_qbatch_upload(lm_index *ix, const lm_query *queries, size_t nq, lm_
         }
         qb->total_len = qb->h_qoff[nq];
         qb->total_pos = qb->h_posoff[nq];
-        if (2 * qb->total_pos >= ((int64_t)1 << 31) || nq >= ((size_t)1 << 30)) {
-            ix->err = "query batch too large (more than 2^30 k-mers); split the batch";
-            delete qb;
-            return LM_ERR_ARG;
-        }
         qb->h_seq.resize((size_t)qb->total_len + 64, 'A');
         for (size_t i = 0; i < nq; i++)
             if (queries[i].len) memcpy(&qb->h_seq[(size_t)qb->h_qoff[i]], queries[i].seq, queries[i].len);
@@ -1019,7 +1032,81 @@ lm_status lm_qbatch_upload(lm_index *ix, const lm_query *queries, size_t nq, lm_
         h2d(ix, qb->d_posoff, qb->h_posoff);
         h2d(ix, qb->d_segoff, segoff);
         sync(ix);
-        *out = qb;
+    } catch (...) {
+        delete qb;
+        throw;
+    }
+    return qb;
+}
+
+// Limits of one pass: slot numbers (query, mask, direction) and k-mer numbers travel as 32-bit values, and the arrays
+// sized by them must fit the device memory left beside the index (LM_MAX_PART_KMERS / LM_MAX_PART_SLOTS override).
+static void part_limits(lm_index *ix, int64_t *max_pos, int64_t *max_qm) {
+    int64_t pos = ((int64_t)1 << 30) - 1, qm = ((int64_t)1 << 31) - 1;
+    // ~104 B per k-mer position (two sorted k-mer arrays with their double buffers, capture marks) and ~80 B per
+    // (query, mask) pair (captured k-mers, location ranges, lookup lists) may take a fifth of the scratch budget
+    if (ix->scratch_budget > 0) {
+        const int64_t b = ix->scratch_budget / 5;
+        pos = std::min<int64_t>(pos, std::max<int64_t>(b / 2 / 104, 1 << 16));
+        qm = std::min<int64_t>(qm, std::max<int64_t>(b / 2 / 80, (int64_t)ix->host.M));
+    }
+    if (const char *e = getenv("LM_MAX_PART_KMERS")) pos = std::max<int64_t>(1, std::min<int64_t>(pos, atoll(e)));
+    if (const char *e = getenv("LM_MAX_PART_SLOTS")) qm = std::max<int64_t>(ix->host.M, std::min<int64_t>(qm, atoll(e)));
+    *max_pos = pos;
+    *max_qm = qm;
+}
+
+extern "C" lm_status lm_qbatch_upload(lm_index *ix, const lm_query *queries, size_t nq, lm_qbatch **out) {
+    *out = nullptr;
+    if (!ix) return LM_ERR_ARG;
+    if (nq >= ((size_t)1 << 31)) {
+        ix->err = "query batch too large; split the batch";
+        return LM_ERR_ARG;
+    }
+    try {
+        std::lock_guard<std::mutex> lock(ix->mu);
+        HIPCHK(hipSetDevice(ix->device));
+        int64_t max_pos, max_qm;
+        part_limits(ix, &max_pos, &max_qm);
+        const int K = ix->host.k, M = ix->host.M;
+        // greedy split into consecutive parts within the limits (a single query above them is refused)
+        std::vector<size_t> cuts{0};
+        int64_t pos = 0, nqp = 0;
+        for (size_t i = 0; i < nq; i++) {
+            const int64_t np = std::max<int64_t>((int64_t)queries[i].len - K + 1, 0);
+            if (np > max_pos) {
+                ix->err = "a query of " + std::to_string(queries[i].len) + " bases exceeds what one pass can hold (" +
+                          std::to_string(max_pos) + " k-mers)";
+                return LM_ERR_ARG;
+            }
+            if (nqp > 0 && (pos + np > max_pos || (nqp + 1) * (int64_t)M > max_qm)) {
+                cuts.push_back(i);
+                pos = 0;
+                nqp = 0;
+            }
+            pos += np;
+            nqp++;
+        }
+        cuts.push_back(nq);
+        if (cuts.size() == 2) {
+            *out = upload_part(ix, queries, nq, 0);
+            return LM_OK;
+        }
+        lm_qbatch *top = new lm_qbatch();
+        top->ix = ix;
+        top->nq = (int)nq;
+        try {
+            for (size_t c = 0; c + 1 < cuts.size(); c++)
+                top->parts.push_back(upload_part(ix, queries + cuts[c], cuts[c + 1] - cuts[c], (uint32_t)cuts[c]));
+        } catch (...) {
+            delete top;
+            throw;
+        }
+        for (auto *p : top->parts) {
+            top->total_len += p->total_len;
+            top->total_pos += p->total_pos;
+        }
+        *out = top;
         return LM_OK;
     } catch (const std::exception &e) {
         ix->err = e.what();
@@ -1263,7 +1350,8 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
     if (n == 0) return;
     std::vector<int32_t> todo;
     std::vector<int32_t> level(n, 0);
-    const int64_t budget = (int64_t)72 << 30; // bytes of scratch per launch (288 GB HBM: index + genomes + this)
+    // bytes of scratch per launch of the global-memory fallback (288 GB HBM: index + genomes + this)
+    const int64_t budget = ix->scratch_budget > 0 ? std::min<int64_t>((int64_t)72 << 30, ix->scratch_budget * 2 / 5) : (int64_t)72 << 30;
     std::vector<uint8_t> is_wide(n, 0);
     a.wfa_out.ensure((size_t)n);
     a.wfa_in.ensure((size_t)n);
@@ -1316,7 +1404,8 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
             const int64_t m = (int64_t)items.size();
             int nblocks = (int)std::min<int64_t>(m, wfa_resident_blocks(ix->device, seq_words));
             // private scratch per resident wave: never more than the worst case of the longest problem
-            int64_t cells = a.wfa_budget / nblocks * 10 / 46 / 4;
+            const int64_t lean_budget = ix->scratch_budget > 0 ? std::min<int64_t>(a.wfa_budget, ix->scratch_budget * 2 / 5) : a.wfa_budget;
+            int64_t cells = lean_budget / nblocks * 10 / 46 / 4;
             cells = std::min<int64_t>(cells, std::min<int64_t>(3 * 128 * (smax + 1), 2000000000));
             cells = std::max<int64_t>(cells, 4096);
             int64_t rows = std::min<int64_t>(std::max<int64_t>(cells / 64, 256), smax + 1);
@@ -2064,7 +2153,25 @@ lm_status lm_search_resident(lm_index *ix, lm_qbatch *qb, lm_result **out) {
     if (!ix || !qb) return LM_ERR_ARG;
     lm_result *res = new lm_result();
     try {
-        search_impl(ix, qb, res);
+        if (qb->parts.empty()) {
+            search_impl(ix, qb, res);
+        } else { // consecutive parts of the caller's batch: rows are already grouped by query, in batch order
+            memset(&res->stats, 0, sizeof res->stats);
+            for (lm_qbatch *part : qb->parts) {
+                lm_result pr;
+                search_impl(ix, part, &pr);
+                for (auto &r : pr.rows) r.query += part->q0;
+                res->rows.insert(res->rows.end(), pr.rows.begin(), pr.rows.end());
+                res->strings.insert(res->strings.end(), pr.strings.begin(), pr.strings.end());
+                pr.strings.clear();
+                const int64_t *a = &pr.stats.query_bases;
+                int64_t *b = &res->stats.query_bases;
+                for (int i = 0; i < 14; i++) b[i] += a[i]; // the int64 counters of lm_stage_stats
+                const double *c = &pr.stats.ms_mask;
+                double *d = &res->stats.ms_mask;
+                for (int i = 0; i < 9; i++) d[i] += c[i];
+            }
+        }
     } catch (const std::exception &e) {
         ix->err = e.what();
         delete res;

@@ -211,6 +211,29 @@ __global__ void k_sp_repack(uint64_t *__restrict__ stream, int64_t first, int64_
                    (int)(gridDim.x * blockDim.x));
 }
 
+// all seeds of one list back in the reference's (k-mer, value) form
+__global__ void k_sp_dump_list(DevIndexView ix, uint32_t md, int64_t n_main, uint64_t *__restrict__ kmers,
+                               uint64_t *__restrict__ vals) {
+    const int64_t base = ix.md_off[md];
+    const uint32_t *row = ix.part_tab + (int64_t)md * ix.P1;
+    const uint64_t pfx = ix.masks[md >> 1] >> ((ix.K - ix.mask_prefix) << 1);
+    const int P = ix.P1 - 1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_main; i += (int64_t)gridDim.x * blockDim.x) {
+        int lo = 0, hi = P; // partition of seed i: last row entry <= i
+        while (lo + 1 < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((int64_t)row[mid] <= i)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const uint64_t rem = lm_bits_get(ix.pk_keys, base + i, ix.key_bits);
+        const uint64_t pv = lm_bits_get(ix.pk_vals, base + i, ix.gid_bits + ix.pos_bits + 1);
+        kmers[i] = (((pfx << (ix.part_bases << 1)) | (uint64_t)lo) << ix.key_bits) | rem;
+        vals[i] = lm_unpack_seed_val(pv, ix.g_bg[lm_packed_val_genome(pv, ix.pos_bits)], ix.pos_bits, (int)(md & 1));
+    }
+}
+
 static int sp_grid(int64_t n, int block = 256) {
     int64_t g = (n + block - 1) / block;
     if (g < 1) g = 1;
@@ -379,3 +402,46 @@ void SeedPacker::finish() {
 }
 
 } // namespace lm
+
+// (k-mer, value) pairs stored under one mask, both directions, in the reference's in-memory form: what `lexicmap utils
+// kmers -m <mask>` lists (cmd/kmers.go:101-180) and what kv.Reader.ReadDataOfAMaskAsList returns (kv-reader.go:762).
+// Inspection / test entry point: the search path never unpacks lists.
+extern "C" lm_status lm_index_mask_seeds(lm_index *ix, int32_t mask, uint64_t *kmers, uint64_t *vals, size_t cap, size_t *n_out) {
+    if (!ix || mask < 0 || mask >= ix->host.M || !n_out) return LM_ERR_ARG;
+    try {
+        std::lock_guard<std::mutex> lock(ix->mu);
+        HIPCHK(hipSetDevice(ix->device));
+        const int64_t nmd = 2ll * ix->host.M;
+        int64_t mdo[3], oo[3];
+        HIPCHK(hipMemcpy(mdo, ix->d_md_off.p + 2 * mask, sizeof mdo, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(oo, ix->d_out_off.p + 2 * mask, sizeof oo, hipMemcpyDeviceToHost));
+        (void)nmd;
+        const size_t total = (size_t)(mdo[2] - mdo[0]) + (size_t)(oo[2] - oo[0]);
+        *n_out = total;
+        if (!kmers || !vals || cap < total) return LM_OK; // size query
+        DBuf<uint64_t> dk, dv;
+        size_t w = 0;
+        for (int dir = 0; dir < 2; dir++) {
+            const int64_t nm = mdo[dir + 1] - mdo[dir], no = oo[dir + 1] - oo[dir];
+            if (nm > 0) {
+                dk.ensure((size_t)nm);
+                dv.ensure((size_t)nm);
+                hipLaunchKernelGGL(lm::k_sp_dump_list, dim3(lm::sp_grid(nm)), dim3(256), 0, ix->st, ix->view,
+                                   (uint32_t)(2 * mask + dir), nm, dk.p, dv.p);
+                HIPCHK(hipMemcpyAsync(kmers + w, dk.p, (size_t)nm * 8, hipMemcpyDeviceToHost, ix->st));
+                HIPCHK(hipMemcpyAsync(vals + w, dv.p, (size_t)nm * 8, hipMemcpyDeviceToHost, ix->st));
+                HIPCHK(hipStreamSynchronize(ix->st));
+                w += (size_t)nm;
+            }
+            if (no > 0) {
+                HIPCHK(hipMemcpy(kmers + w, ix->d_out_kmers.p + oo[dir], (size_t)no * 8, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(vals + w, ix->d_out_vals.p + oo[dir], (size_t)no * 8, hipMemcpyDeviceToHost));
+                w += (size_t)no;
+            }
+        }
+        return LM_OK;
+    } catch (const std::exception &e) {
+        ix->err = e.what();
+        return LM_ERR_HIP;
+    }
+}

@@ -34,8 +34,10 @@ def test_synthetic_genomes_family_structure(synth_index):
 
 
 def test_captures_match_oracle_lexichash(synth_index):
-    """normal (non-desert) seeds are the exact LexicHash capture of the genome: every (mask, k-mer) the oracle captures
-    for the fetched genome must be retrievable through the search path"""
+    """normal (non-desert) seeds are the exact LexicHash capture of the genome: for every mask, the k-mer the oracle's
+    lexichash captures on the fetched genome is stored under that mask with exactly the oracle's (position, strand) set
+    (lib-index-build.go:1028-1046), read back through lm_index_mask_seeds"""
+    import hostalgos as H
     import lexicmap_amd as la
     gi = synth_index
     L = O.lib()
@@ -49,6 +51,26 @@ def test_captures_match_oracle_lexichash(synth_index):
     kmers = (C.c_uint64 * M)()
     off, locs = C.POINTER(C.c_int)(), C.POINTER(C.c_int)()
     assert L.lmo_lh_mask(lh, seq, len(seq), None, 0, 1, kmers, C.byref(off), C.byref(locs)) == 0
+    Hh = H.lib()
+    checked = 0
+    for m in range(0, M, 3):
+        if kmers[m] == 0 or Hh.ha_low_complexity(kmers[m], 31):
+            continue
+        exp = sorted(int(locs[i]) for i in range(off[m], off[m + 1]))       # pos<<1 | strand
+        k, v = gi.mask_seeds(m)
+        sel = (k == np.uint64(kmers[m])) & ((v >> np.uint64(30)) == np.uint64(g)) & ((v & np.uint64(1)) == 0)
+        got = sorted(int(x) for x in ((v[sel] >> np.uint64(1)) & np.uint64((1 << 29) - 1)))
+        assert got == exp, (m, got[:4], exp[:4])
+        # and its reversed twin sits in some list with the reversed flag (lib-index-build.go:776-890)
+        checked += 1
+    assert checked > 0.25 * M
+    # the lists are sorted by k-mer inside each direction, values carry the direction of their half
+    k, v = gi.mask_seeds(123)
+    nrm = (v & np.uint64(1)) == 0
+    assert nrm.any() and (~nrm).any()
+    first_rev = int(np.argmax(~nrm))
+    assert nrm[:first_rev].all() and (~nrm[first_rev:]).all()
+    assert (np.diff(k[:first_rev].astype(np.int64)) >= 0).all() and (np.diff(k[first_rev:].astype(np.int64)) >= 0).all()
     # a query cut from this genome must recover anchors on genome g at the right coordinates
     rows, st = gi.search([seq[50_000:51_500]])
     assert st["rows"] >= 1
@@ -58,8 +80,6 @@ def test_captures_match_oracle_lexichash(synth_index):
     # family members are found too (3 families x 4 members)
     fam = {r["batch_genome"] for r in rows}
     assert fam == {1, 4, 7, 10}
-    ncap = sum(1 for m in range(M) if kmers[m] != 0)
-    assert ncap > 0.9 * M
     L.free(off)
     L.free(locs)
     L.lmo_lh_free(lh)

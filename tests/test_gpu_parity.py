@@ -80,6 +80,43 @@ def test_index_info_and_masks(both, small_index):
     assert 0 <= info["outlier_seeds"] < info["seeds"]
 
 
+class _KvMem(C.Structure):  # lmo_kv_mem (oracle/lmo.h): the reference's RAM form of a chunk file, kv-reader.go:762
+    _fields_ = [("k", C.c_int), ("chunk_index", C.c_int), ("chunk_size", C.c_int), ("mask_prefix", C.c_int),
+                ("anchor_prefix", C.c_int), ("use7", C.c_int), ("kv", C.POINTER(C.POINTER(C.c_uint64))),
+                ("kvlen", C.POINTER(C.c_int64)), ("index", C.POINTER(C.POINTER(C.c_int64)))]
+
+
+def test_packed_seed_image_holds_exactly_the_seeds_of_the_chunk_files(both, small_index):
+    """a20 / f1: every (k-mer, value) the reference format stores under a mask comes back out of the packed HBM image
+    (partition table + 36-bit k-mer remainders + packed values, outliers flat), nothing more, each half sorted"""
+    _, gi = both
+    d, _ = small_index
+    L = O.lib()
+    L.lmo_kv_load.restype = C.POINTER(_KvMem)
+    L.lmo_kv_load.argtypes = [C.c_char_p]
+    L.lmo_kv_free.argtypes = [C.POINTER(_KvMem)]
+    total = 0
+    for chunk in sorted(os.listdir(os.path.join(d, "seeds"))):
+        if not chunk.endswith(".bin"):
+            continue
+        m = L.lmo_kv_load(os.path.join(d, "seeds", chunk).encode())
+        km = m.contents
+        for i in list(range(0, km.chunk_size, 41)) + [km.chunk_size - 1]:
+            n = km.kvlen[i]
+            flat = np.ctypeslib.as_array(km.kv[i], shape=(n,)).copy() if n else np.zeros(0, dtype=np.uint64)
+            exp = sorted(zip(flat[0::2].tolist(), flat[1::2].tolist()))
+            k, v = gi.mask_seeds(km.chunk_index + i)
+            assert sorted(zip(k.tolist(), v.tolist())) == exp, km.chunk_index + i
+            nrm = (v & np.uint64(1)) == 0
+            first_rev = int(np.argmax(~nrm)) if (~nrm).any() else len(v)
+            assert nrm[:first_rev].all() and (~nrm[first_rev:]).all()
+            total += len(k)
+        L.lmo_kv_free(m)
+    assert total > 1000
+    info = gi.info()
+    assert info["seed_bytes"] > 0 and info["outlier_seeds"] >= 0
+
+
 def test_mask_parity(both, queries):
     """a1+a2: LexicHash capture of every mask + low-complexity zeroing + all locations"""
     oi, gi = both
