@@ -110,17 +110,15 @@ __global__ void k_synth_genomes(SynthDev sp, const int16_t *__restrict__ shifts,
     }
 }
 
-// 31-mer at base position pos of a packed genome (needs 16 readable bytes from pos>>2)
+// 31-mer at base position pos of a packed genome: two ALIGNED 64-bit loads + funnel shift (genomes start on 8-byte
+// boundaries and are padded by 16 bytes; an unaligned 8-byte memcpy compiles to byte loads)
 __device__ __forceinline__ uint64_t packed_kmer(const uint8_t *gb, int64_t pos, int K) {
-    const uint8_t *p = gb + (pos >> 2);
-    uint64_t hi, lo;
-    __builtin_memcpy(&hi, p, 8);
-    __builtin_memcpy(&lo, p + 8, 8);
-    hi = __builtin_bswap64(hi);
-    lo = __builtin_bswap64(lo);
-    int s = (int)(pos & 3) << 1;
-    uint64_t x = s ? ((hi << s) | (lo >> (64 - s))) : hi;
-    return x >> (64 - (K << 1));
+    const int64_t byte = pos >> 2;
+    const uint64_t *p = (const uint64_t *)(gb + (byte & ~7ll));
+    const uint64_t H = __builtin_bswap64(p[0]), L = __builtin_bswap64(p[1]);
+    const int o = (int)(byte & 7) * 8 + (int)(pos & 3) * 2; // 0..62
+    const uint64_t v = o ? ((H << o) | (L >> (64 - o))) : H;
+    return v >> (64 - (K << 1));
 }
 
 struct MaskTab {

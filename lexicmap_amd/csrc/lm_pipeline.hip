@@ -1427,8 +1427,11 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
             std::vector<uint64_t> ops_tmp;
             if (want_ops) d2h(ix, ops_tmp, a.ops_pool.p, (size_t)ops_tot);
             sync(ix);
+            int64_t n3 = 0, n1 = 0;
             for (int32_t i : items) {
                 int stt = tmp[i].r.status;
+                n3 += stt == 3;
+                n1 += stt == 1;
                 if (stt == 3) {
                     too_wide.push_back(i);
                     a.stats->wfa_retries++;
@@ -1444,6 +1447,9 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
                                            ops_tmp.begin() + in[i].ops_off + tmp[i].r.nops);
                 }
             }
+            if (getenv("LM_DEBUG") && (n3 || n1))
+                fprintf(stderr, "[lm] wfa pass: %lld problems left the LDS kernel as too wide / long / non-ACGT, %lld on scratch overflow\n",
+                        (long long)n3, (long long)n1);
         };
         // one pass through the 128-diagonal LDS kernel (it only touches its second 64-slot chunk when a wavefront is
         // wide or has drifted); what outgrows it goes to the global-memory kernel below
