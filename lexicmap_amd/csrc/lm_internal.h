@@ -41,7 +41,15 @@ template <typename T> struct DBuf {
         if (p) (void)hipFree(p);
         p = nullptr;
         size_t want = std::max<size_t>(n + n / 8, 64);
-        HIPCHK(hipMalloc((void **)&p, want * sizeof(T)));
+        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            cap = 0;
+            size_t fr = 0, tot = 0;
+            (void)hipMemGetInfo(&fr, &tot);
+            throw HipError("device scratch allocation of " + std::to_string(want * sizeof(T) >> 20) + " MB failed (" +
+                           hipGetErrorString(e) + "; " + std::to_string(fr >> 20) + " MB free): use a smaller query batch");
+        }
         cap = want;
     }
     // exactly n elements (the immutable index arrays: no head-room, optionally zero-filled)

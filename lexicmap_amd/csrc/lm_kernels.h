@@ -124,7 +124,7 @@ void launch_extend(hipStream_t st, const HspIn *hsps, int64_t n, const uint8_t *
 // k_wfa_lean<2>: persistent wavefronts with private scratch, <= 126 diagonals (status 3 beyond)
 int wfa_resident_blocks(int device, int seq_words);
 void launch_wfa(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks,
-                int32_t *hdr_pool, int64_t hdr_stride, int32_t *arena_pool, int64_t arena_stride, uint64_t *ops_pool,
+                int32_t *hdr_pool, int64_t hdr_stride, uint8_t *arena_pool, int64_t arena_stride, uint64_t *ops_pool,
                 unsigned int *queue, int seq_words, int want_ops, WfaOut *out);
 
 // wavefronts wider than the LDS ring (status 3 from launch_wfa): same algorithm with the ring in global memory

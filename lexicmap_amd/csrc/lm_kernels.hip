@@ -1561,188 +1561,239 @@ __device__ __forceinline__ unsigned long long rotr64(unsigned long long x, int r
     return r ? ((x >> r) | (x << (64 - r))) : x;
 }
 
-// Backtrace of one alignment by the whole wavefront (same walk as lm_wfa_backtrace, lm_algos.h): per step ONE coalesced
-// load brings the three header rows (27 lanes), five lanes then fetch the five candidate offsets in parallel, and the
-// choice is a wave max - two dependent global latencies per edit operation instead of ~16 with a single lane. The walk
-// only merges runs and stores them (scalar work per step is what bounds this kernel); the alignment statistics (bounds,
-// aligned length, matches, gaps, BLAST score over the M-trimmed CIGAR) are computed afterwards from the stored runs, by
-// all lanes in parallel.
-__device__ __forceinline__ void wave_backtrace(const int32_t *__restrict__ hdr, const int32_t *__restrict__ arena, int s,
-                                               int plen, int tlen, uint64_t *__restrict__ ops, int ops_cap, int lane,
-                                               LmWfaOut *out, int *blast) {
-    const int X = 4, OE = 8, E = 2;
-    const int ak = tlen - plen;
-    int wp = ops_cap; // runs are written from the end of the buffer towards its start
-    int cur_op = 0;
-    uint32_t cur_n = 0;
-    bool overflow = false;
-    auto push = [&](int op, int nn) { // nn > 0
-        if (cur_op == op) {
-            cur_n += (uint32_t)nn;
-        } else {
-            if (cur_n) {
-                if (wp <= 0)
-                    overflow = true;
-                else {
-                    --wp;
-                    if (lane == 0) ops[wp] = ((uint64_t)(uint32_t)cur_op << 32) | cur_n;
-                }
+// ---- backtrace of the LDS wavefront kernel ----------------------------------------------------------------------------
+// The forward pass stores ONE BYTE per wavefront cell instead of the three 32-bit offsets (M, I, D) of WFA2 / lm_wfa_align:
+//   bits 0-1  where M[s][k] came from: 0 mismatch (M[s-4][k]), 1 insertion (I[s][k]), 2 deletion (D[s][k]), with the
+//             priority of lm_wfa_backtrace on equal offsets (mismatch > D > I)
+//   bit 2     I[s][k] came from I[s-2][k-1] (extension) rather than M[s-8][k-1] (open); ties -> extension
+//   bit 3     the same for D[s][k]
+// and per even score {first diagonal, byte offset of the row}.  The walk from (final score, final diagonal) to score 0
+// follows those codes - it needs no offsets: which cell precedes which is all that is stored - and yields the edit
+// operations in reverse; the match runs between them are recovered by replaying the operations forwards with the same
+// greedy extension the forward pass used (every M cell was extended maximally, so the replay lands on the same cells).
+// 12x less wavefront traffic than the offsets, and the walk runs out of LDS: rows of ~30 scores are fetched with one
+// coalesced copy (their bytes are contiguous), so one global round trip serves ~10-15 operations instead of two round
+// trips per operation.
+#define BT_WIN 4096 /* bytes of backtrace rows held in LDS during the walk */
+struct BtLds {
+    uint8_t win[BT_WIN + 32];
+    int32_t lo[64], base[64];
+};
+
+// Returns the number of edit operations written (descending from opseq_end), or -1 on overflow / inconsistency.
+// ops bytes: bits 0-1 = 0 X, 1 I, 2 D; bit 2 = the cell the operation arrives at is an M cell (extend after it).
+__device__ __forceinline__ int bt_walk(const int32_t *__restrict__ hdr2, const uint8_t *__restrict__ bt, int s_final, int ak,
+                                       uint8_t *__restrict__ opseq_end, int64_t opseq_room, BtLds *L, int lane) {
+    int score = s_final, k = ak, matrix = 0;
+    int64_t nops = 0;
+    while (score > 0) {
+        // window: rows of scores score, score-2, ... as far down as BT_WIN bytes reach (at most 64 rows)
+        const int top = score >> 1;
+        int32_t lo_j = 0, base_j = 0;
+        if (top - lane >= 0) {
+            lo_j = hdr2[2 * (top - lane)];
+            base_j = hdr2[2 * (top - lane) + 1];
+        }
+        const int32_t top_end = __builtin_amdgcn_readfirstlane(hdr2[2 * (top + 1) + 1]);
+        const unsigned long long fits = __ballot(top - lane >= 0 && top_end - base_j <= BT_WIN);
+        // rows are contiguous and in score order: the lanes that fit form a prefix
+        const unsigned long long nfit = ~fits;
+        const int nrows = nfit ? __ffsll((long long)nfit) - 1 : 64;
+        if (nrows < 1) return -1;
+        const int32_t wbase = __builtin_amdgcn_readfirstlane(__shfl(base_j, nrows - 1));
+        LDS_WAVE_SYNC();
+        L->lo[lane] = lo_j;
+        L->base[lane] = base_j;
+        {
+            const int32_t a0 = wbase & ~15; // aligned 16-byte copies
+            const int nchunks = (top_end - a0 + 15) >> 4;
+            for (int c = lane; c < nchunks; c += 64) {
+                const uint4 v = *(const uint4 *)(bt + a0 + 16 * c);
+                *(uint4 *)(L->win + 16 * c) = v;
             }
-            cur_op = op;
-            cur_n = (uint32_t)nn;
+            LDS_WAVE_SYNC();
+            const int32_t shift = wbase - a0; // win[shift + (byte - wbase)]
+            const int low = score - 2 * (nrows - 1);
+            while (score >= low && score > 0) {
+                const int j = (2 * top - score) >> 1;
+                const int32_t rlo = L->lo[j], rbase = L->base[j];
+                const int code = L->win[shift + (rbase - wbase) + (k - rlo)];
+                int op, ext;
+                if (matrix == 0) {
+                    op = code & 3;
+                    ext = op == 1 ? (code >> 2) & 1 : (code >> 3) & 1;
+                } else {
+                    op = matrix;
+                    ext = matrix == 1 ? (code >> 2) & 1 : (code >> 3) & 1;
+                }
+                if (op == 3 || k < rlo) return -1;
+                if (nops >= opseq_room) return -1;
+                nops++;
+                if (lane == 0) opseq_end[-nops] = (uint8_t)(op | (matrix == 0 ? 4 : 0));
+                if (op == 0) {
+                    score -= 4;
+                    matrix = 0;
+                } else {
+                    score -= ext ? 2 : 8;
+                    k += op == 1 ? -1 : 1;
+                    matrix = ext ? op : 0;
+                }
+                score = __builtin_amdgcn_readfirstlane(score);
+                k = __builtin_amdgcn_readfirstlane(k);
+                matrix = __builtin_amdgcn_readfirstlane(matrix);
+            }
+        }
+    }
+    if (score != 0 || k != 0 || matrix != 0) return -1;
+    return (int)nops;
+}
+
+// Forward replay of the edit operations: match runs by greedy extension over the 2-bit packed sequences in LDS, runs merged
+// like lm_wfa_backtrace's push, alignment statistics of the M-trimmed run list (lib-index-search.go:2278-2302) and the
+// BLAST-style score (lib-index-search-util.go:260-304) accumulated on the way; runs stored only when `ops` is given.
+__device__ __forceinline__ void bt_replay(const uint8_t *__restrict__ opseq, int nops, const uint32_t *Qp, const uint32_t *Tp,
+                                          int plen, int tlen, uint64_t *__restrict__ ops, int ops_cap, int lane, int s_final,
+                                          LmWfaOut *out, int *blast) {
+    int v = 0, h = 0;
+    int cur_op = 0, cur_n = 0, run_q = 0, run_t = 0; // pending run and where it starts
+    bool seen_m = false, overflow = false;
+    int wp = 0;
+    int alen = 0, matches = 0, gaps = 0, greg = 0, bl = 0;          // since the first M run
+    int c_alen = 0, c_matches = 0, c_gaps = 0, c_greg = 0, c_bl = 0; // up to the last M run
+    int qbegin = 0, tbegin = 0, qend = 0, tend = 0;
+    auto flush = [&]() {
+        if (cur_n == 0) return;
+        if (ops) {
+            if (wp >= ops_cap)
+                overflow = true;
+            else if (lane == 0)
+                ops[wp] = ((uint64_t)(uint32_t)cur_op << 32) | (uint32_t)cur_n;
+            wp++;
+        }
+        if (cur_op == 'M') {
+            if (!seen_m) {
+                seen_m = true;
+                qbegin = run_q + 1;
+                tbegin = run_t + 1;
+            }
+            alen += cur_n;
+            matches += cur_n;
+            bl += 2 * cur_n;
+            c_alen = alen;
+            c_matches = matches;
+            c_gaps = gaps;
+            c_greg = greg;
+            c_bl = bl;
+            qend = run_q + cur_n;
+            tend = run_t + cur_n;
+        } else if (seen_m) {
+            alen += cur_n;
+            if (cur_op == 'X') {
+                bl -= 3 * cur_n;
+            } else {
+                gaps += cur_n;
+                greg++;
+                bl -= 5 + 2 * cur_n;
+            }
         }
     };
-    int score = s, k = ak;
-    int32_t offset = tlen;
-    int v = offset - k, h = offset;
-    int matrix = 0;
-    // per-lane roles: lanes 0..26 load header cell (row = lane / 9 of {s-X, s-OE, s-E}, column = lane % 9);
-    // lanes 0..4 evaluate one candidate each: 0 mismatch, 1 I-open, 2 D-open, 3 I-ext, 4 D-ext
-    const int hrow = lane / 9, hcol = lane - hrow * 9;
-    const int c_src = lane == 0 ? 0 : (lane == 1 || lane == 2) ? 9 : lane == 3 ? 18 + 3 : 18 + 6; // first header lane
-    const int c_dk = (lane == 1 || lane == 3) ? -1 : (lane == 2 || lane == 4) ? 1 : 0;
-    const int c_add = (lane == 0 || lane == 1 || lane == 3) ? 1 : 0;
-    const int c_tag = lane == 0 ? 9 : lane == 1 ? 1 : lane == 2 ? 3 : lane == 3 ? 2 : 4;
-    // which candidates a matrix may use: M all five, I {1,3}, D {2,4}
-    const uint32_t c_use = lane == 0 ? 1u : (lane == 1 || lane == 3) ? 3u : (lane == 2 || lane == 4) ? 5u : 0u; // bit m
-    while (v > 0 && h > 0 && score > 0) {
-        const int s_mis = score - X, s_open = score - OE, s_ext = score - E;
-        int32_t hv = (hcol % 3 == 1) ? -1 : 1; // empty range for negative scores
-        if (lane < 27) {
-            const int srow = hrow == 0 ? s_mis : hrow == 1 ? s_open : s_ext;
-            if (srow >= 0) hv = hdr[srow * 9 + hcol];
+    auto extend = [&]() {
+        int run = 0;
+        while (true) {
+            const int rem = plen - v < tlen - h ? plen - v : tlen - h;
+            if (rem <= 0) break;
+            const uint32_t d = get16(Qp, v) ^ get16(Tp, h);
+            int nm = d ? (__clz(d) >> 1) : 16;
+            nm = nm < rem ? nm : rem;
+            v += nm;
+            h += nm;
+            run += nm;
+            if (nm < 16) break;
         }
-        const int32_t lo = __shfl(hv, c_src), hi = __shfl(hv, c_src + 1), base = __shfl(hv, c_src + 2);
-        int32_t cand = -1;
-        {
-            const int kq = k + c_dk;
-            if (((c_use >> matrix) & 1u) && kq >= lo && kq <= hi) {
-                const int32_t o = arena[base + (kq - lo)] + c_add;
-                if (o >= 0) cand = (o << 4) | c_tag;
-            }
-        }
-        int32_t mx = cand; // max over lanes 0..7 (the others hold -1)
-        {
-            int32_t y = __shfl_xor(mx, 1);
-            mx = y > mx ? y : mx;
-            y = __shfl_xor(mx, 2);
-            mx = y > mx ? y : mx;
-            y = __shfl_xor(mx, 4);
-            mx = y > mx ? y : mx;
-        }
-        mx = __builtin_amdgcn_readfirstlane(mx);
-        if (mx < 0) break;
-        const int bt = mx & 15;
-        if (matrix == 0) {
-            const int32_t max_off = mx >> 4;
-            if (offset > max_off) push('M', offset - max_off);
-            offset = max_off;
-            if (offset - k <= 0 || offset <= 0) {
-                v = offset - k;
-                h = offset;
-                break;
-            }
-        }
-        // one edit operation: 9 = X (to M[s-4]), 1 / 2 = I from M[s-8] / I[s-2], 3 / 4 = D from M[s-8] / D[s-2]
-        const bool is_x = bt == 9, is_i = bt == 1 || bt == 2, opens = bt == 1 || bt == 3;
-        score = is_x ? s_mis : (opens ? s_open : s_ext);
-        matrix = (is_x || opens) ? 0 : (bt == 2 ? 1 : 2);
-        push(is_x ? 'X' : (is_i ? 'I' : 'D'), 1);
-        if (is_x || is_i) --offset;
-        k += is_x ? 0 : (is_i ? -1 : 1);
-        v = offset - k;
-        h = offset;
-    }
-    if (v > 0 && h > 0) {
-        const int nm = v < h ? v : h;
-        push('M', nm);
-        v -= nm;
-        h -= nm;
-    }
-    if (v > 0) push('D', v);
-    if (h > 0) push('I', h);
-    push(0, 1); // flushes the last run
-    out->status = 0;
-    out->score = s;
-    out->nops = 0;
-    out->qbegin = out->qend = out->tbegin = out->tend = 0;
-    out->align_len = out->matches = out->gaps = out->gap_regions = 0;
-    *blast = 0;
-    if (overflow) {
-        out->status = 1;
-        return;
-    }
-    const int nruns = ops_cap - wp;
-    out->nops = nruns;
-    __syncthreads(); // lane 0's stores are visible to the other lanes
-    if (wp > 0) {    // move the runs to the front of the buffer (ascending chunks: the destination is below the source)
-        for (int c = 0; c < nruns; c += 64) {
-            uint64_t x = 0;
-            if (c + lane < nruns) x = ops[wp + c + lane];
-            __syncthreads();
-            if (c + lane < nruns) ops[c + lane] = x;
-            __syncthreads();
+        return run;
+    };
+    {
+        const int q0 = v, t0 = h;
+        const int r = extend();
+        if (r > 0) {
+            cur_op = 'M';
+            cur_n = r;
+            run_q = q0;
+            run_t = t0;
         }
     }
-    // ---- statistics over the runs, all lanes ----
-    int first = 2147483647, last = -1;
-    for (int c = 0; c < nruns; c += 64) {
-        const bool is_m = c + lane < nruns && (uint32_t)(ops[c + lane] >> 32) == (uint32_t)'M';
-        const unsigned long long bm = __ballot(is_m);
-        if (bm) {
-            if (first == 2147483647) first = c + (__ffsll((long long)bm) - 1);
-            last = c + (63 - __clzll((long long)bm));
-        }
-    }
-    if (last < 0) {
-        out->status = 2;
-        return;
-    }
-    // per-lane partial sums: [0] aligned length, [1] matches, [2] gaps, [3] gap regions, [4] BLAST score,
-    // [5] / [6] query / target bases before `first`, [7] / [8] query / target bases up to and including `last`
-    int acc[9];
-#pragma unroll
-    for (int j = 0; j < 9; j++) acc[j] = 0;
-    for (int c = lane; c < nruns; c += 64) {
-        const uint64_t r = ops[c];
-        const int op = (int)(r >> 32), nn = (int)(uint32_t)r;
-        const int cq = (op == 'M' || op == 'X' || op == 'D') ? nn : 0, ct = (op == 'M' || op == 'X' || op == 'I') ? nn : 0;
-        if (c < first) {
-            acc[5] += cq;
-            acc[6] += ct;
-        }
-        if (c <= last) {
-            acc[7] += cq;
-            acc[8] += ct;
-        }
-        if (c >= first && c <= last) {
-            acc[0] += nn;
-            if (op == 'M') {
-                acc[1] += nn;
-                acc[4] += 2 * nn;
-            } else if (op == 'X') {
-                acc[4] -= 3 * nn;
+    for (int c = 0; c < nops; c += 64) {
+        const int mine = c + lane < nops ? (int)opseq[c + lane] : 0;
+        const int lim = nops - c < 64 ? nops - c : 64;
+        for (int i = 0; i < lim; i++) {
+            const int ob = __builtin_amdgcn_readfirstlane(__shfl(mine, i));
+            const int op = ob & 3;
+            const int q0 = v, t0 = h;
+            // the run starts where the operation starts
+            if (op == 0) {
+                if (cur_op != 'X') {
+                    flush();
+                    cur_op = 'X';
+                    cur_n = 0;
+                    run_q = q0;
+                    run_t = t0;
+                }
+                cur_n++;
+                v++;
+                h++;
+            } else if (op == 1) {
+                if (cur_op != 'I') {
+                    flush();
+                    cur_op = 'I';
+                    cur_n = 0;
+                    run_q = q0;
+                    run_t = t0;
+                }
+                cur_n++;
+                h++;
             } else {
-                acc[2] += nn;
-                acc[3] += 1;
-                acc[4] -= 5 + 2 * nn;
+                if (cur_op != 'D') {
+                    flush();
+                    cur_op = 'D';
+                    cur_n = 0;
+                    run_q = q0;
+                    run_t = t0;
+                }
+                cur_n++;
+                v++;
+            }
+            if (ob & 4) {
+                const int q1 = v, t1 = h;
+                const int r = extend();
+                if (r > 0) {
+                    flush();
+                    cur_op = 'M';
+                    cur_n = r;
+                    run_q = q1;
+                    run_t = t1;
+                }
             }
         }
     }
-#pragma unroll
-    for (int j = 0; j < 9; j++) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc[j] += __shfl_xor(acc[j], o);
+    flush();
+    out->status = 0;
+    out->score = s_final;
+    out->nops = ops ? wp : 0;
+    out->qbegin = qbegin;
+    out->tbegin = tbegin;
+    out->qend = qend;
+    out->tend = tend;
+    out->align_len = (uint32_t)c_alen;
+    out->matches = (uint32_t)c_matches;
+    out->gaps = (uint32_t)c_gaps;
+    out->gap_regions = (uint32_t)c_greg;
+    *blast = c_bl;
+    if (overflow || v != plen || h != tlen) {
+        out->status = 1;
+        out->nops = 0;
+    } else if (!seen_m) {
+        out->status = 2;
     }
-    out->qbegin = acc[5] + 1;
-    out->tbegin = acc[6] + 1;
-    out->qend = acc[7];
-    out->tend = acc[8];
-    out->align_len = (uint32_t)acc[0];
-    out->matches = (uint32_t)acc[1];
-    out->gaps = (uint32_t)acc[2];
-    out->gap_regions = (uint32_t)acc[3];
-    *blast = acc[4];
 }
 
 // ---- k_wfa_lean<NC>: the LDS wavefront kernel ------------------------------------------------------------------------
@@ -1817,7 +1868,7 @@ template <int NC> __device__ __forceinline__ SlotMask<NC> sm_from(SlotMask<NC> m
 template <int NC>
 __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, int64_t n, const int32_t *__restrict__ todo,
                                                   int64_t ntodo, int32_t *__restrict__ hdr_pool, int64_t hdr_stride,
-                                                  int32_t *__restrict__ arena_pool, int64_t arena_stride,
+                                                  uint8_t *__restrict__ arena_pool, int64_t arena_stride,
                                                   uint64_t *__restrict__ ops_pool, unsigned int *__restrict__ queue,
                                                   int seq_words, int want_ops, WfaOut *__restrict__ out) {
     static_assert(NC == 1 || NC == 2, "one or two cells per lane");
@@ -1829,13 +1880,15 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
     __shared__ int32_t rI[2][W];
     __shared__ int32_t rD[2][W];
     __shared__ unsigned int sh_x;
+    __shared__ BtLds btl;
     extern __shared__ uint32_t seq_lds[];
     uint32_t *Qp = seq_lds, *Tp = seq_lds + seq_words + 1;
     const int lane = threadIdx.x;
-    int32_t *hdr = hdr_pool + (int64_t)blockIdx.x * hdr_stride;
-    int32_t *arena = arena_pool + (int64_t)blockIdx.x * arena_stride;
-    const int64_t arena_cap = arena_stride;
-    const int max_score = (int)(hdr_stride / 9);
+    // per resident wavefront: {first diagonal, row offset} per even score, and the backtrace bytes (one per cell)
+    int32_t *hdr2 = hdr_pool + (int64_t)blockIdx.x * hdr_stride;
+    uint8_t *bt = arena_pool + (int64_t)blockIdx.x * arena_stride;
+    const int64_t arena_cap = arena_stride - 16; // the window copies of the walk read whole 16-byte chunks
+    const int max_score = (int)(hdr_stride / 2 - 2) * 2;
     // Work queue: lane 0 pops the next problem at the END of the loop body (inside the block that writes the result)
     // and the index travels through LDS. Keeping lane-conditional code away from the loop header matters: with the pop
     // at the top the compiler peels lane 0 into an outer loop and lets the other 63 lanes iterate without it.
@@ -1899,8 +1952,14 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
         if (lane == 0) rM[0][koff & (W - 1)] = 0;
         LDS_WAVE_SYNC();
         int s = 0, ms = 0, is = 0; // ring rows of score s
-        int alo = 0;               // first diagonal of the arena slices of score s
-        int32_t used = 1, gbM = 0, gbI = 0, gbD = 0; // arena cells (the slab holds < 2^31)
+        int alo = 0;               // first diagonal of the row of score s
+        int32_t used = 1;          // backtrace bytes (the slab holds < 2^31); score 0 = one cell that is never read
+        if (lane == 0) {
+            hdr2[0] = 0;
+            hdr2[1] = 0;
+            hdr2[2] = 0;
+            hdr2[3] = 1;
+        }
         // does the slot range of diagonals [lo, hi] touch the 64 slots of chunk c ?
         auto chunk_has = [&](int c, int lo_, int hi_) {
             if (NC == 1) return true;
@@ -1945,7 +2004,6 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                         rM[ms][slot] = o;
                     }
                     off[c] = o;
-                    if (inr[c]) arena[gbM + (k - alo)] = o;
                     fin.w[c] = __ballot(inr[c] && k == ak && o >= tlen);
                 }
                 done = sm_any<NC>(fin);
@@ -2020,18 +2078,6 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                     }
                 }
             }
-            { // header of score s for the backtrace: lanes 0..8 store one field each (selects, no branches)
-                int32_t hv = gbD + (dlo[0] - alo);
-                hv = lane == 7 ? dhi[0] : hv;
-                hv = lane == 6 ? dlo[0] : hv;
-                hv = lane == 5 ? gbI + (ilo[0] - alo) : hv;
-                hv = lane == 4 ? ihi[0] : hv;
-                hv = lane == 3 ? ilo[0] : hv;
-                hv = lane == 2 ? gbM + (mlo[0] - alo) : hv;
-                hv = lane == 1 ? mhi[0] : hv;
-                hv = lane == 0 ? mlo[0] : hv;
-                if (lane < 9) hdr[s * 9 + lane] = hv;
-            }
             if (done) break;
             s += 2;
             if (s >= max_score) {
@@ -2065,8 +2111,12 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                     rI[is][lane + 64 * c] = LM_NULL_OFF;
                     rD[is][lane + 64 * c] = LM_NULL_OFF;
                 }
-                gbM = gbI = gbD = 0;
                 alo = 0;
+                if (lane == 0) { // an empty row: same offset as the next one
+                    hdr2[s] = 0;
+                    hdr2[s + 1] = used;
+                    hdr2[s + 3] = used;
+                }
                 continue;
             }
             const int wd = hi - lo + 1;
@@ -2074,15 +2124,18 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                 status = 3;
                 break;
             }
-            if ((int64_t)used + 3 * wd > arena_cap) {
+            if ((int64_t)used + wd > arena_cap) {
                 status = 1;
                 break;
             }
-            gbM = used;
-            gbI = used + wd;
-            gbD = used + 2 * wd;
-            used += 3 * wd;
+            const int32_t rowb = used;
+            used += wd;
             alo = lo;
+            if (lane == 0) { // entry s/2 = {lo, row offset}; the offset of entry s/2+1 closes the row
+                hdr2[s] = lo;
+                hdr2[s + 1] = rowb;
+                hdr2[s + 3] = used;
+            }
             const int r4 = ms >= 2 ? ms - 2 : ms + 3, r8 = ms == 4 ? 0 : ms + 1, r2 = is ^ 1; // rows of s-4, s-8, s-2
             LDS_WAVE_SYNC(); // the neighbours' extension results are in the ring
             int kk[NC];
@@ -2101,19 +2154,20 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                 inr[c] = k <= hi;
                 const int sm1 = (slot + W - 1) & (W - 1), sp1 = (slot + 1) & (W - 1);
                 int32_t a = rM[r8][sm1], b = rI[r2][sm1];
-                const int32_t ins = (a > b ? a : b) + 1;
+                const bool iext = b >= a; // equal offsets: extension (lm_wfa_backtrace tags 2 > 1)
+                const int32_t ins = (iext ? b : a) + 1;
                 a = rM[r8][sp1];
                 b = rD[r2][sp1];
-                const int32_t del = a > b ? a : b;
+                const bool dext = b >= a; // tags 4 > 3
+                const int32_t del = dext ? b : a;
                 const int32_t mis = rM[r4][slot] + 1;
                 int32_t mx = mis > ins ? mis : ins;
                 if (del > mx) mx = del;
+                // predecessor of the M cell on equal offsets: mismatch (tag 9) > deletion (4, 3) > insertion (2, 1)
+                const uint32_t mc = (mis >= del && mis >= ins) ? 0u : (del >= ins ? 2u : 1u);
                 if ((uint32_t)mx > (uint32_t)tlen) mx = LM_NULL_OFF;
                 if ((uint32_t)(mx - k) > (uint32_t)plen) mx = LM_NULL_OFF;
-                if (inr[c]) {
-                    arena[gbI + (k - lo)] = ins;
-                    arena[gbD + (k - lo)] = del;
-                }
+                if (inr[c]) bt[rowb + (k - lo)] = (uint8_t)(mc | (iext ? 4u : 0u) | (dext ? 8u : 0u));
                 vins[c] = ins;
                 vdel[c] = del;
                 vmx[c] = mx;
@@ -2169,7 +2223,20 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
             o.r.qbegin = o.r.qend = o.r.tbegin = o.r.tend = 0;
             o.r.align_len = o.r.matches = o.r.gaps = o.r.gap_regions = 0;
         } else {
-            wave_backtrace(hdr, arena, s, plen, tlen, ops_pool + w.ops_off, w.ops_cap, lane, &o.r, &o.blast_score);
+            // operations (reversed) into the unused tail of this wavefront's slab, then the forward replay
+            const int nops = bt_walk(hdr2, bt, s, ak, bt + arena_stride - 16, arena_stride - 16 - ((used + 15) & ~15), &btl, lane);
+            __threadfence_block();
+            __syncthreads(); // lane 0's operation bytes are visible to the other lanes
+            if (nops < 0) {
+                o.r.status = 1;
+                o.r.score = 0;
+                o.r.nops = 0;
+                o.r.qbegin = o.r.qend = o.r.tbegin = o.r.tend = 0;
+                o.r.align_len = o.r.matches = o.r.gaps = o.r.gap_regions = 0;
+            } else {
+                bt_replay(bt + arena_stride - 16 - nops, nops, Qp, Tp, plen, tlen, want_ops ? ops_pool + w.ops_off : nullptr,
+                          w.ops_cap, lane, s, &o.r, &o.blast_score);
+            }
         }
         if (lane == 0) {
             out[i] = o;
@@ -2321,7 +2388,7 @@ int wfa_resident_blocks(int device, int seq_words) {
     return resident_blocks_of((const void *)k_wfa_lean<2>, device, seq_words);
 }
 void launch_wfa(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks,
-                int32_t *hdr_pool, int64_t hdr_stride, int32_t *arena_pool, int64_t arena_stride, uint64_t *ops_pool,
+                int32_t *hdr_pool, int64_t hdr_stride, uint8_t *arena_pool, int64_t arena_stride, uint64_t *ops_pool,
                 unsigned int *queue, int seq_words, int want_ops, WfaOut *out) {
     // two packed sequences with one padding word each, +2 words: the predicated extension may read one word past
     size_t dyn = (size_t)(2 * (seq_words + 1) + 2) * sizeof(uint32_t);

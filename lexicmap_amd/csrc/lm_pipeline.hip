@@ -458,6 +458,8 @@ static void stage_mask(Work &w) {
                 w.first_mask.p);
 }
 
+struct PartTooLarge : std::exception {};
+
 static void stage_lookup(Work &w, lm_stage_stats &stats) {
     lm_index *ix = w.ix;
     lm_qbatch *qb = w.qb;
@@ -517,10 +519,17 @@ static void stage_lookup(Work &w, lm_stage_stats &stats) {
         const int64_t probes = (int64_t)std::ceil(std::log2(sb + 1.0));
         prof_add_bytes(ix, "k_lookup_count", nlk * (8 + 8 * probes) + 16 * (int64_t)hv);
     }
+    // anchors + their chaining scratch (~96 B each) must fit a quarter of the scratch budget, and their number 31 bits:
+    // otherwise the caller halves this part of the batch and comes back (lm_search_resident)
+    const char *dbg_max = getenv("LM_DEBUG_MAX_ANCHORS"); // test hook: forces the halving path
+    if (T >= (int64_t)1 << 31 || (ix->scratch_budget > 0 && T * 96 > ix->scratch_budget / 4) ||
+        (dbg_max && qb->nq > 1 && T > atoll(dbg_max))) {
+        if (qb->nq <= 1) throw HipError("one query yields more seed anchors than the device can hold");
+        throw PartTooLarge();
+    }
     stats.anchors_raw += T;
     w.n_anchors = T;
     if (T == 0) return;
-    if (T >= (int64_t)1 << 31) throw HipError("too many anchors in one batch; use a smaller query batch");
     w.A0.ensure((size_t)T);
     w.B0.ensure((size_t)T);
     w.A1.ensure((size_t)T);
@@ -1394,33 +1403,40 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
             w.ops_cap = (int32_t)oc;
             ops_tot += oc;
         }
-        const int seq_words = std::min((maxlen + 15) / 16, 4096); // longer sequences take the global-memory kernel
-        const int64_t smax = 8 * Lmax + 64;
+        (void)maxlen;
+        (void)Lmax;
         a.ops_pool.ensure((size_t)ops_tot + 16);
         a.wfa_todo.ensure((size_t)n);
         a.wfa_queue.ensure(1);
         HIPCHK(hipMemcpyAsync(a.wfa_in.p, in.data(), sizeof(WfaIn) * n, hipMemcpyHostToDevice, S(ix)));
-        auto persistent_pass = [&](const std::vector<int32_t> &items, std::vector<int32_t> &too_wide) {
+        // one launch of the persistent LDS kernel per length class: the packed sequences live in LDS, so the resident
+        // wavefronts per CU are set by the longest problem of the launch (gene-sized HSPs: 24 per CU, 50-kb reads: 5)
+        auto persistent_pass = [&](const std::vector<int32_t> &items, int seq_words, int64_t lmax,
+                                   std::vector<int32_t> &too_wide) {
             const int64_t m = (int64_t)items.size();
-            int nblocks = (int)std::min<int64_t>(m, wfa_resident_blocks(ix->device, seq_words));
-            // private scratch per resident wave: never more than the worst case of the longest problem
+            if (m == 0) return;
+            const int resident = wfa_resident_blocks(ix->device, seq_words);
+            int nblocks = (int)std::min<int64_t>(m, resident);
+            // private scratch per resident wave: one backtrace byte per wavefront cell + 8 bytes per even score; never
+            // more than the worst case of the longest problem of the class
+            const int64_t smax = 8 * lmax + 64; // a global alignment never exceeds this penalty
             const int64_t lean_budget = ix->scratch_budget > 0 ? std::min<int64_t>(a.wfa_budget, ix->scratch_budget * 2 / 5) : a.wfa_budget;
-            int64_t cells = lean_budget / nblocks * 10 / 46 / 4;
-            cells = std::min<int64_t>(cells, std::min<int64_t>(3 * 128 * (smax + 1), 2000000000));
-            cells = std::max<int64_t>(cells, 4096);
-            int64_t rows = std::min<int64_t>(std::max<int64_t>(cells / 64, 256), smax + 1);
+            int64_t bytes = lean_budget / nblocks * 7 / 8;
+            bytes = std::min<int64_t>(bytes, (smax / 2 + 2) * 128 + 2 * lmax + 4096);
+            bytes = std::max<int64_t>(bytes, 65536);
+            bytes = std::min<int64_t>(bytes, 2000000000) & ~(int64_t)15;
+            int64_t entries = std::min<int64_t>(smax / 2 + 4, bytes / 24 + 1024);
             if (getenv("LM_DEBUG"))
-                fprintf(stderr, "[lm] wfa pass problems=%lld blocks=%d (resident %d) cells/block=%lld rows=%lld seq_words=%d\n",
-                        (long long)m, nblocks, wfa_resident_blocks(ix->device, seq_words), (long long)cells,
-                        (long long)rows, seq_words);
-            a.hdr_pool.ensure((size_t)(rows * 9) * nblocks + 16);
-            a.arena_pool.ensure((size_t)cells * nblocks + 16);
+                fprintf(stderr, "[lm] wfa pass problems=%lld blocks=%d (resident %d) bytes/block=%lld scores=%lld seq_words=%d\n",
+                        (long long)m, nblocks, resident, (long long)bytes, (long long)(2 * entries), seq_words);
+            a.hdr_pool.ensure((size_t)(entries * 2) * nblocks + 16);
+            a.arena_pool.ensure((size_t)(bytes / 4) * nblocks + 16);
             HIPCHK(hipMemcpyAsync(a.wfa_todo.p, items.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice, S(ix)));
             HIPCHK(hipMemsetAsync(a.wfa_queue.p, 0, sizeof(unsigned int), S(ix)));
             {
                 Prof p(ix, "k_wfa_lean", wfa_bytes(in, items));
-                launch_wfa(S(ix), a.wfa_in.p, n, a.wfa_todo.p, m, nblocks, a.hdr_pool.p, rows * 9, a.arena_pool.p,
-                           cells, a.ops_pool.p, a.wfa_queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p);
+                launch_wfa(S(ix), a.wfa_in.p, n, a.wfa_todo.p, m, nblocks, a.hdr_pool.p, entries * 2, (uint8_t *)a.arena_pool.p,
+                           bytes, a.ops_pool.p, a.wfa_queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p);
             }
             std::vector<WfaOut> tmp;
             d2h(ix, tmp, a.wfa_out.p, (size_t)n);
@@ -1451,10 +1467,28 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
                 fprintf(stderr, "[lm] wfa pass: %lld problems left the LDS kernel as too wide / long / non-ACGT, %lld on scratch overflow\n",
                         (long long)n3, (long long)n1);
         };
-        // one pass through the 128-diagonal LDS kernel (it only touches its second 64-slot chunk when a wavefront is
-        // wide or has drifted); what outgrows it goes to the global-memory kernel below
+        // length classes (sequence words of 16 bases); within a class the queue keeps the longest-expected-first order
         std::vector<int32_t> wide2;
-        persistent_pass(order, wide2);
+        {
+            const int bounds[4] = {128, 512, 2048, 4096};
+            std::vector<int32_t> cls[4];
+            int cw[4] = {1, 1, 1, 1};
+            int64_t cl[4] = {1, 1, 1, 1};
+            for (int32_t i : order) {
+                const int wds = (std::max(in[i].qlen, in[i].tlen) + 15) / 16;
+                int c = 0;
+                while (c < 4 && wds > bounds[c]) c++;
+                if (c == 4) { // longer than the LDS buffers
+                    wide2.push_back(i);
+                    a.stats->wfa_retries++;
+                    continue;
+                }
+                cls[c].push_back(i);
+                cw[c] = std::max(cw[c], wds);
+                cl[c] = std::max<int64_t>(cl[c], (int64_t)in[i].qlen + in[i].tlen);
+            }
+            for (int c = 3; c >= 0; c--) persistent_pass(cls[c], cw[c], cl[c], wide2);
+        }
         for (int32_t i : wide2) { // wider than 126 diagonals, longer than the LDS buffers, or not plain ACGT
             is_wide[i] = 1;
             level[i] = 2; // these are the hard ones: generous scratch at once instead of an overflow and a second launch
@@ -2152,6 +2186,39 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
 
 } // namespace lm
 
+// halves part `pi` of the batch (or the plain batch itself when `whole`): two new parts from the host copy of its bases
+static void split_part(lm_index *ix, lm_qbatch *top, size_t pi, bool whole) {
+    lm_qbatch *src = whole ? top : top->parts[pi];
+    const size_t nq = (size_t)src->nq, h = nq / 2;
+    if (nq < 2) throw HipError("one query yields more seed anchors than the device can hold");
+    std::vector<lm_query> qs(nq);
+    for (size_t i = 0; i < nq; i++) {
+        qs[i].seq = src->h_seq.data() + src->h_qoff[i];
+        qs[i].len = (uint32_t)(src->h_qoff[i + 1] - src->h_qoff[i]);
+    }
+    std::lock_guard<std::mutex> lock(ix->mu);
+    lm_qbatch *a = upload_part(ix, qs.data(), h, src->q0);
+    lm_qbatch *b = nullptr;
+    try {
+        b = upload_part(ix, qs.data() + h, nq - h, src->q0 + (uint32_t)h);
+    } catch (...) {
+        delete a;
+        throw;
+    }
+    if (getenv("LM_DEBUG")) fprintf(stderr, "[lm] batch part of %zu queries halved (seed anchors above the scratch budget)\n", nq);
+    if (whole) {
+        top->parts = {a, b};
+        top->d_seq.release(); // the plain batch's own device copy is no longer used
+        top->d_qoff.release();
+        top->d_posoff.release();
+        top->d_segoff.release();
+    } else {
+        delete src;
+        top->parts[pi] = a;
+        top->parts.insert(top->parts.begin() + pi + 1, b);
+    }
+}
+
 extern "C" {
 
 lm_status lm_search_resident(lm_index *ix, lm_qbatch *qb, lm_result **out) {
@@ -2159,13 +2226,26 @@ lm_status lm_search_resident(lm_index *ix, lm_qbatch *qb, lm_result **out) {
     if (!ix || !qb) return LM_ERR_ARG;
     lm_result *res = new lm_result();
     try {
+        // parts of the caller's batch, in order; a part whose seed anchors outgrow the device is halved in place (the split
+        // stays in the batch handle, so the next search of the same resident batch does not repeat it)
         if (qb->parts.empty()) {
-            search_impl(ix, qb, res);
-        } else { // consecutive parts of the caller's batch: rows are already grouped by query, in batch order
+            try {
+                search_impl(ix, qb, res);
+            } catch (const PartTooLarge &) {
+                split_part(ix, qb, 0, true);
+            }
+        }
+        if (!qb->parts.empty()) {
             memset(&res->stats, 0, sizeof res->stats);
-            for (lm_qbatch *part : qb->parts) {
+            for (size_t pi = 0; pi < qb->parts.size();) {
+                lm_qbatch *part = qb->parts[pi];
                 lm_result pr;
-                search_impl(ix, part, &pr);
+                try {
+                    search_impl(ix, part, &pr);
+                } catch (const PartTooLarge &) {
+                    split_part(ix, qb, pi, false);
+                    continue;
+                }
                 for (auto &r : pr.rows) r.query += part->q0;
                 res->rows.insert(res->rows.end(), pr.rows.begin(), pr.rows.end());
                 res->strings.insert(res->strings.end(), pr.strings.begin(), pr.strings.end());
@@ -2176,6 +2256,7 @@ lm_status lm_search_resident(lm_index *ix, lm_qbatch *qb, lm_result **out) {
                 const double *c = &pr.stats.ms_mask;
                 double *d = &res->stats.ms_mask;
                 for (int i = 0; i < 9; i++) d[i] += c[i];
+                pi++;
             }
         }
     } catch (const std::exception &e) {

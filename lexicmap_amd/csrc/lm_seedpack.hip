@@ -142,7 +142,7 @@ __global__ __launch_bounds__(64) void k_sp_sort_parts(const uint32_t *__restrict
                                                       int P1, int64_t nmd, int key_bits, int val_bits,
                                                       uint64_t *__restrict__ pk_keys, uint64_t *__restrict__ pk_vals,
                                                       unsigned long long *__restrict__ big, unsigned long long big_cap,
-                                                      unsigned long long *__restrict__ nbig) {
+                                                      unsigned long long *__restrict__ nbig, int dbg_mode) {
     __shared__ uint64_t sk[SP_MAXN], sv[SP_MAXN];
     const int lane = threadIdx.x;
     const int P = P1 - 1;
@@ -179,7 +179,11 @@ __global__ __launch_bounds__(64) void k_sp_sort_parts(const uint32_t *__restrict
             __syncthreads();
             continue;
         }
-        for (int k = 2; k <= npad; k <<= 1) {
+        if (dbg_mode & 1) {
+            __syncthreads();
+            continue;
+        }
+        for (int k = 2; k <= ((dbg_mode & 2) ? 1 : npad); k <<= 1) {
             for (int j = k >> 1; j > 0; j >>= 1) {
                 for (int i = lane; i < (npad >> 1); i += 64) {
                     const int x = ((i & ~(j - 1)) << 1) | (i & (j - 1)), y = x | j;
@@ -196,8 +200,10 @@ __global__ __launch_bounds__(64) void k_sp_sort_parts(const uint32_t *__restrict
                 __syncthreads();
             }
         }
-        sp_store_range(pk_keys, first, n, key_bits, [&](int64_t i) { return sk[i]; }, lane, 64);
-        sp_store_range(pk_vals, first, n, val_bits, [&](int64_t i) { return sv[i]; }, lane, 64);
+        if (!(dbg_mode & 4)) {
+            sp_store_range(pk_keys, first, n, key_bits, [&](int64_t i) { return sk[i]; }, lane, 64);
+            sp_store_range(pk_vals, first, n, val_bits, [&](int64_t i) { return sv[i]; }, lane, 64);
+        }
         __syncthreads();
     }
 }
@@ -336,12 +342,17 @@ void SeedPacker::finish() {
     nbig.alloc_exact(1, true, ix->st);
     if (n_main > 0) {
         const int64_t nparts = nmd * (P1 - 1);
+        const int dbg_mode = getenv("LM_SP_DEBUG_MODE") ? atoi(getenv("LM_SP_DEBUG_MODE")) : 0; // timing experiments only
+        const double t0 = now_ms();
         hipLaunchKernelGGL(k_sp_sort_parts, dim3((unsigned)std::min<int64_t>(nparts, (int64_t)1 << 22)), dim3(64), 0, ix->st,
                            ix->d_part_tab.p, ix->d_md_off.p, P1, nmd, key_bits, val_bits, ix->d_pk_keys.p, ix->d_pk_vals.p,
-                           big.p, big_cap, nbig.p);
+                           big.p, big_cap, nbig.p, dbg_mode);
         unsigned long long nb = 0;
         HIPCHK(hipMemcpyAsync(&nb, nbig.p, sizeof nb, hipMemcpyDeviceToHost, ix->st));
         HIPCHK(hipStreamSynchronize(ix->st));
+        if (getenv("LM_DEBUG"))
+            fprintf(stderr, "[lm] seed image: partition sort kernel %.0f ms (mode %d), %llu partitions above %d seeds\n", now_ms() - t0,
+                    dbg_mode, nb, SP_MAXN);
         if (nb > big_cap) throw HipError("seed image: too many partitions above the LDS sorter's size");
         if (nb > 0) { // rare: rocPRIM on an unpacked copy of the partition
             std::vector<unsigned long long> slots(nb);

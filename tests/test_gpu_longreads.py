@@ -99,8 +99,16 @@ def test_batch_split_into_parts_gives_the_same_rows(lr_index, lr_queries, monkey
     monkeypatch.setenv("LM_MAX_PART_KMERS", "60000")   # ~one long read per part
     got, st1 = gi.search(seqs)
     monkeypatch.delenv("LM_MAX_PART_KMERS")
-    gi.close()
     assert len(base) == len(got) and len(base) > 10
     for b, g in zip(base, got):
         assert b == g
     assert st0["rows"] == st1["rows"] and st0["chains"] == st1["chains"]
+    # a part whose seed anchors outgrow the scratch budget is halved on the fly (forced here): same rows again
+    monkeypatch.setenv("LM_DEBUG_MAX_ANCHORS", "1500")
+    got2, st2 = gi.search(seqs)
+    monkeypatch.delenv("LM_DEBUG_MAX_ANCHORS")
+    gi.close()
+    assert len(base) == len(got2)
+    for b, g in zip(base, got2):
+        assert b == g
+    assert st0["rows"] == st2["rows"]
