@@ -123,7 +123,8 @@ static std::string load_chunk(const std::string &path, const HostIndex &idx, con
         std::vector<uint64_t> &V = vv[(size_t)(mask0 + im)];
         uint64_t off = 0;
         for (;;) {
-            if (p + 1 > n) {
+            // a record = ctrl byte + two group-varint values (<= 16 bytes), twice: k-mer deltas, then value counts
+            if (p + 1 > n || p + 1 + (size_t)(((buf[p] >> 3) & 7) + (buf[p] & 7) + 2) > n) {
                 status = 2;
                 return "k-mer-value data: broken file: " + path;
             }
@@ -134,12 +135,16 @@ static std::string load_chunk(const std::string &path, const HostIndex &idx, con
             p += gv2(ctrl, &buf[p], d1, d2);
             uint64_t k1 = d1 + off, k2 = k1 + d2;
             off = k2;
+            if (p + 1 > n || p + 1 + (size_t)(((buf[p] >> 3) & 7) + (buf[p] & 7) + 2) > n) {
+                status = 2;
+                return "k-mer-value data: broken file: " + path;
+            }
             ctrl = buf[p++];
             p += gv2(ctrl, &buf[p], l1, l2);
             for (int w = 0; w < 2; w++) {
                 if (w == 1 && last_pair && !has2) break;
                 uint64_t kmer = w == 0 ? k1 : k2, lv = w == 0 ? l1 : l2;
-                if (p + lv * nvb > n) {
+                if (lv > n || p + lv * nvb > n) {
                     status = 2;
                     return "k-mer-value data: broken file: " + path;
                 }
@@ -184,19 +189,42 @@ std::string load_index(const std::string &dir, int shard_rank, int shard_count, 
     out.genome_batches = (int)toml_int(text, "genome-batches", 1);
     int partitions = (int)toml_int(text, "index-partitions", 4096);
 
-    // masks.bin (own layout, written by this build's index writers)
-    if (!read_all(dir + "/masks.bin", buf) || buf.size() < 24 || memcmp(buf.data(), "LMMASKS1", 8) != 0) {
+    // masks.bin.  Two layouts are accepted:
+    //  (a) this build's own (magic LMMASKS1: k u8 at 8, count u32 at 12, masks from 24), written by the oracle's index writer;
+    //  (b) a headered list of big-endian 64-bit masks as lexichash's WriteToFile is believed to produce (lexichash v0.5.x is
+    //      not in the reference tree, so this cannot be verified against a real file): 8-byte magic, 8 meta bytes with k at
+    //      byte 10, u64 count, u64 seed, then the masks.  It is only accepted when k and the count agree with info.toml
+    //      (max-K, masks), the size is exact and the masks are strictly ascending, else the open fails with LM_ERR_FORMAT.
+    if (!read_all(dir + "/masks.bin", buf) || buf.size() < 24) {
         status = buf.empty() ? 1 : 2;
         return "failed to read masks: " + dir + "/masks.bin";
     }
-    out.k = buf[8];
-    out.M = (int)be32(&buf[12]);
-    if (buf.size() < 24 + (size_t)out.M * 8 || out.k < 1 || out.k > 32) {
+    size_t mask_at = 24;
+    if (memcmp(buf.data(), "LMMASKS1", 8) == 0) {
+        out.k = buf[8];
+        out.M = (int)be32(&buf[12]);
+    } else {
+        const long long tk = toml_int(text, "max-K", -1), tm = toml_int(text, "masks", -1);
+        bool ok = false;
+        if (buf.size() >= 32 && tk >= 1 && tk <= 32 && tm >= 1 && buf.size() == 32 + (size_t)tm * 8 && (long long)buf[10] == tk &&
+            (long long)be64(&buf[16]) == tm) {
+            ok = true;
+            for (long long i = 1; i < tm && ok; i++) ok = be64(&buf[32 + (size_t)i * 8]) > be64(&buf[32 + (size_t)(i - 1) * 8]);
+        }
+        if (!ok) {
+            status = 2;
+            return "masks.bin: unknown layout (neither this build's LMMASKS1 nor a k/count-consistent lexichash mask list): " + dir;
+        }
+        out.k = (int)tk;
+        out.M = (int)tm;
+        mask_at = 32;
+    }
+    if (buf.size() < mask_at + (size_t)out.M * 8 || out.k < 1 || out.k > 32) {
         status = 2;
         return "broken masks file";
     }
     out.masks.resize(out.M);
-    for (int i = 0; i < out.M; i++) out.masks[i] = be64(&buf[24 + (size_t)i * 8]);
+    for (int i = 0; i < out.M; i++) out.masks[i] = be64(&buf[mask_at + (size_t)i * 8]);
     {   // lib-index-search.go:467-469
         int p = (int)(std::log2((double)out.M) / 2);
         out.mask_prefix = p < 1 ? 1 : p;

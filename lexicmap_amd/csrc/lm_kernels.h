@@ -100,13 +100,14 @@ void launch_extract_windows(hipStream_t st, DevIndexView ix, const Task *tasks, 
 void launch_build_cmp_tab(hipStream_t st, const uint64_t *keys_cmp, const int64_t *posoff, const int32_t *nvalid, int nq,
                           int K, uint32_t *tab);
 void launch_sum_i32(hipStream_t st, const int32_t *v, int64_t n, unsigned long long *out);
-#define LM_PFX_WORDS_PER_QUERY 2048 /* 4^8 bits: 8-base prefix bitmap of a query's filtered k-mers */
+// hashed 11-base prefix bitmap per query: 2^bits_log[q] bits at word bits_off[q] (sized by the host, ~16 bits per k-mer)
 void launch_build_cmp_bits(hipStream_t st, const uint64_t *keys_cmp, const int64_t *posoff, const int32_t *nvalid, int nq,
-                           int K, uint32_t *bits);
+                           int K, const int64_t *bits_off, const int32_t *bits_log, uint32_t *bits);
 void launch_pa_anchors(hipStream_t st, DevIndexView ix, const Task *tasks, int64_t ntasks, const uint8_t *wbuf,
                        const uint64_t *keys_cmp, const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid,
-                       const uint32_t *cmp_tab, const uint32_t *cmp_bits, int K, int min_prefix,
-                       unsigned long long *count, int64_t cap, uint64_t *outA, uint64_t *outB, int qbits, int tbits);
+                       const uint32_t *cmp_tab, const uint32_t *cmp_bits, const int64_t *bits_off, const int32_t *bits_log,
+                       int K, int min_prefix, unsigned long long *count, int64_t cap, uint64_t *outA, uint64_t *outB,
+                       int qbits, int tbits);
 void launch_pa_task_off_sorted(hipStream_t st, const uint64_t *sortedA, int shift, int64_t total, int64_t ntasks,
                                int64_t *pa_off);
 void launch_pa_chain(hipStream_t st, const uint64_t *B, const int64_t *pa_off, int64_t ntasks, int K, LmChain2Opt opt,
@@ -121,11 +122,11 @@ int extend_grid_blocks(int64_t n);
 void launch_extend(hipStream_t st, const HspIn *hsps, int64_t n, const uint8_t *qseq, const int64_t *qoff,
                    const uint8_t *wbuf, const int32_t *cap, const int64_t *woff, uint16_t *subs, int32_t *msi,
                    void *rows_pool, uint32_t *rstart_pool, HspExt *out);
-// k_wfa_lean<2>: persistent wavefronts with private scratch, <= 126 diagonals (status 3 beyond)
-int wfa_resident_blocks(int device, int seq_words);
+// k_wfa_lean<nc>: persistent wavefronts with private scratch, <= 64 nc - 2 diagonals (status 3 beyond); nc = 2 or 4
+int wfa_resident_blocks(int device, int seq_words, int nc = 2);
 void launch_wfa(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks,
                 int32_t *hdr_pool, int64_t hdr_stride, uint8_t *arena_pool, int64_t arena_stride, uint64_t *ops_pool,
-                unsigned int *queue, int seq_words, int want_ops, WfaOut *out);
+                unsigned int *queue, int seq_words, int want_ops, WfaOut *out, int nc = 2);
 
 // wavefronts wider than the LDS ring (status 3 from launch_wfa): same algorithm with the ring in global memory
 void launch_wfa_wide(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int32_t *hdr_pool,

@@ -88,29 +88,32 @@ __global__ void k_build_cmp_tab(const uint64_t *__restrict__ keys_cmp, const int
         tab[t] = (uint32_t)lo;
     }
 }
-// exact bitmap of the 8-base prefixes present among a query's (filtered) k-mers: 4^8 bits = 8 KB per query.
-// A window k-mer whose prefix is absent shares at most 7 bases with any query k-mer, so it cannot match at the
-// pseudo-alignment prefix length (>= 11) and the partial-prefix rule of tree.Search can only fire when its bases
-// [7, p) are all A - one L1/L2-resident load decides ~95 % of the window positions (k_pa_anchors).
-#define LM_PFX_BITS 16
-#define LM_PFX_WORDS (1 << (LM_PFX_BITS - 5))
+// Prefix filter of a query for the pseudo-alignment: a bitmap over the 11-base prefixes of its (filtered) k-mers, the
+// smallest prefix length SeqComparator.Compare ever asks for (lib-seq_compare.go:339-348).  Sized per query, 2^log bits
+// with ~16 bits per k-mer (a 1.5-kb gene: 64 Kbit, a 50-kb read: 2 Mbit; log = 22 is the exact 4^11-bit map), prefixes are
+// hashed into it.  A window k-mer whose 11-base prefix misses the map shares fewer than 11 bases with every query k-mer,
+// so it cannot match, and the partial-prefix rule of tree.Search (tree.go:496-500) can then only fire if its bases
+// [7, p) are all A: one load decides ~95 % of the window positions (k_pa_anchors).  The earlier exact 8-base map filled
+// up with long reads (a 20-kb read sets 45 % of its 65536 bits).
+#define LM_PFX_BASES 11
+__device__ __forceinline__ uint32_t pfx_slot(uint32_t pfx22, int log) {
+    return log >= 2 * LM_PFX_BASES ? pfx22 : (pfx22 * 0x9E3779B1u) >> (32 - log);
+}
 __global__ __launch_bounds__(256) void k_build_cmp_bits(const uint64_t *__restrict__ keys_cmp,
                                                          const int64_t *__restrict__ posoff,
                                                          const int32_t *__restrict__ nvalid, int nq, int K,
-                                                         uint32_t *__restrict__ bits) {
-    __shared__ uint32_t sb[LM_PFX_WORDS];
+                                                         const int64_t *__restrict__ bits_off,
+                                                         const int32_t *__restrict__ bits_log, uint32_t *__restrict__ bits) {
+    // the bitmaps were zeroed by the host; one workgroup per query sets its bits
     for (int q = blockIdx.x; q < nq; q += gridDim.x) {
-        for (int j = threadIdx.x; j < LM_PFX_WORDS; j += blockDim.x) sb[j] = 0;
-        __syncthreads();
         const uint64_t *keys = keys_cmp + 2 * posoff[q];
         const int n = nvalid[q];
+        const int log = bits_log[q];
+        uint32_t *b = bits + bits_off[q];
         for (int j = threadIdx.x; j < n; j += blockDim.x) {
-            const uint32_t pfx = (uint32_t)(keys[j] >> ((K << 1) - LM_PFX_BITS));
-            atomicOr(&sb[pfx >> 5], 1u << (pfx & 31));
+            const uint32_t h = pfx_slot((uint32_t)(keys[j] >> ((K - LM_PFX_BASES) << 1)), log);
+            atomicOr(&b[h >> 5], 1u << (h & 31));
         }
-        __syncthreads();
-        for (int j = threadIdx.x; j < LM_PFX_WORDS; j += blockDim.x) bits[(int64_t)q * LM_PFX_WORDS + j] = sb[j];
-        __syncthreads();
     }
 }
 
@@ -534,7 +537,8 @@ struct PaCtx {
     const uint64_t *keys;
     const uint32_t *vals;
     const uint32_t *tab;
-    const uint32_t *bits; // 8-base prefix bitmap (k_build_cmp_bits), may be null
+    const uint32_t *bits; // hashed 11-base prefix bitmap of the query (k_build_cmp_bits), may be null
+    int bits_log;
     int n, K, m;
     uint32_t begin, end;
     uint64_t ccc, ggg, ttt;
@@ -584,9 +588,11 @@ __device__ __forceinline__ void pa_prefixes(const Task &t, const uint8_t *__rest
 
 __device__ __forceinline__ PaCtx pa_ctx(const Task &t, const uint64_t *keys_cmp, const uint32_t *vals_cmp,
                                         const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_tab,
-                                        const uint32_t *cmp_bits, int K, int min_prefix) {
+                                        const uint32_t *cmp_bits, const int64_t *bits_off, const int32_t *bits_log, int K,
+                                        int min_prefix) {
     PaCtx c;
-    c.bits = cmp_bits ? cmp_bits + (int64_t)t.q * LM_PFX_WORDS : nullptr;
+    c.bits = cmp_bits ? cmp_bits + bits_off[t.q] : nullptr;
+    c.bits_log = cmp_bits ? bits_log[t.q] : 0;
     c.keys = keys_cmp + 2 * posoff[t.q];
     c.vals = vals_cmp + 2 * posoff[t.q];
     c.tab = cmp_tab + (int64_t)t.q * ((1 << LM_TAB_BITS) + 1);
@@ -619,7 +625,9 @@ __global__ __launch_bounds__(256) void k_pa_anchors(DevIndexView ix, const Task 
                                                      const uint32_t *__restrict__ vals_cmp,
                                                      const int64_t *__restrict__ posoff, const int32_t *__restrict__ nvalid,
                                                      const uint32_t *__restrict__ cmp_tab,
-                                                     const uint32_t *__restrict__ cmp_bits, int K, int min_prefix,
+                                                     const uint32_t *__restrict__ cmp_bits,
+                                                     const int64_t *__restrict__ bits_off,
+                                                     const int32_t *__restrict__ bits_log, int K, int min_prefix,
                                                      unsigned long long *__restrict__ count, int64_t cap,
                                                      uint64_t *__restrict__ outA, uint64_t *__restrict__ outB, int qbits,
                                                      int tbits) {
@@ -633,13 +641,13 @@ __global__ __launch_bounds__(256) void k_pa_anchors(DevIndexView ix, const Task 
     for (int64_t ti = blockIdx.x; ti < ntasks; ti += gridDim.x) {
         const Task t = tasks[ti];
         const uint8_t *w = wbuf + t.woff;
-        const PaCtx c = pa_ctx(t, keys_cmp, vals_cmp, posoff, nvalid, cmp_tab, cmp_bits, K, min_prefix);
+        const PaCtx c = pa_ctx(t, keys_cmp, vals_cmp, posoff, nvalid, cmp_tab, cmp_bits, bits_off, bits_log, K, min_prefix);
         const uint8_t *gb = t.g >= 0 ? ix.gbits : nullptr;
         const int64_t goff = t.g >= 0 ? ix.g_off[t.g] : 0;
         const int npos = c.n > 0 ? t.wlen - K + 1 : 0;
         const int p = c.m > K ? K : c.m;
         const int sh = (K - p) << 1;
-        const bool use_bits = c.bits != nullptr && p > 8 && 2 * K >= LM_PFX_BITS;
+        const bool use_bits = c.bits != nullptr && p >= LM_PFX_BASES && K >= LM_PFX_BASES;
         const bool fast_pfx = use_bits && gb != nullptr && p <= 15 && K >= 16;
         const uint64_t tail_mask = p > 7 ? ((p - 7) >= 32 ? ~0ull : ((1ull << ((p - 7) << 1)) - 1ull)) : 0ull; // bases [7,p)
         if (tid == 0) {
@@ -734,8 +742,8 @@ __global__ __launch_bounds__(256) void k_pa_anchors(DevIndexView ix, const Task 
                 for (int u = 0; u < PA_UNROLL; u++)
 #pragma unroll
                     for (int strand = 0; strand < 2; strand++) {
-                        const uint32_t pfx = (pf[u][strand] >> (2 * (p - 8))) & ((1u << LM_PFX_BITS) - 1u);
-                        word[u][strand] = c.bits[pfx >> 5];
+                        const uint32_t h = pfx_slot((pf[u][strand] >> (2 * (p - LM_PFX_BASES))) & ((1u << (2 * LM_PFX_BASES)) - 1u), c.bits_log);
+                        word[u][strand] = c.bits[h >> 5];
                     }
 #pragma unroll
                 for (int u = 0; u < PA_UNROLL; u++) {
@@ -743,8 +751,8 @@ __global__ __launch_bounds__(256) void k_pa_anchors(DevIndexView ix, const Task 
                     if (i >= npos) continue;
 #pragma unroll
                     for (int strand = 0; strand < 2; strand++) {
-                        const uint32_t pfx = pf[u][strand] >> (2 * (p - 8));
-                        const bool cand = ((word[u][strand] >> (pfx & 31)) & 1u) != 0 || (pf[u][strand] & ((1u << (2 * (p - 7))) - 1u)) == 0;
+                        const uint32_t h = pfx_slot((pf[u][strand] >> (2 * (p - LM_PFX_BASES))) & ((1u << (2 * LM_PFX_BASES)) - 1u), c.bits_log);
+                        const bool cand = ((word[u][strand] >> (h & 31)) & 1u) != 0 || (pf[u][strand] & ((1u << (2 * (p - 7))) - 1u)) == 0;
                         if (cand) {
                             const int slot = atomicAdd(&q_n, 1);
                             if (slot < PA_QCAP) q_item[slot] = ((uint32_t)i << 1) | (uint32_t)strand;
@@ -763,8 +771,8 @@ __global__ __launch_bounds__(256) void k_pa_anchors(DevIndexView ix, const Task 
                         const uint64_t key = strand ? rc : kmer;
                         bool cand = true;
                         if (use_bits) {
-                            const uint32_t pfx = (uint32_t)(key >> ((K << 1) - LM_PFX_BITS));
-                            cand = ((c.bits[pfx >> 5] >> (pfx & 31)) & 1u) != 0 || ((key >> sh) & tail_mask) == 0;
+                            const uint32_t h = pfx_slot((uint32_t)(key >> ((K - LM_PFX_BASES) << 1)), c.bits_log);
+                            cand = ((c.bits[h >> 5] >> (h & 31)) & 1u) != 0 || ((key >> sh) & tail_mask) == 0;
                         }
                         if (cand) {
                             const int slot = atomicAdd(&q_n, 1);
@@ -1574,7 +1582,7 @@ __device__ __forceinline__ unsigned long long rotr64(unsigned long long x, int r
 // 12x less wavefront traffic than the offsets, and the walk runs out of LDS: rows of ~30 scores are fetched with one
 // coalesced copy (their bytes are contiguous), so one global round trip serves ~10-15 operations instead of two round
 // trips per operation.
-#define BT_WIN 4096 /* bytes of backtrace rows held in LDS during the walk */
+#define BT_WIN 4032 /* bytes of backtrace rows held in LDS during the walk (BtLds fits the 128-diagonal ring it reuses) */
 struct BtLds {
     uint8_t win[BT_WIN + 32];
     int32_t lo[64], base[64];
@@ -1809,58 +1817,53 @@ template <int NC> struct SlotMask { // one bit per LDS slot / per diagonal offse
 };
 template <int NC> __device__ __forceinline__ SlotMask<NC> sm_rotr(SlotMask<NC> m, int r) {
     // bit j of the result = bit (j + r) mod W of m
+    SlotMask<NC> o;
     if (NC == 1) {
-        SlotMask<NC> o;
         o.w[0] = rotr64(m.w[0], r);
         return o;
     }
-    r &= 127;
-    unsigned long long a = m.w[0], b = m.w[NC - 1];
-    if (r >= 64) {
-        unsigned long long t = a;
-        a = b;
-        b = t;
-        r -= 64;
+    r &= 64 * NC - 1;
+    const int ws = r >> 6, bs = r & 63;
+#pragma unroll
+    for (int i = 0; i < NC; i++) {
+        const unsigned long long a = m.w[(i + ws) & (NC - 1)], b = m.w[(i + ws + 1) & (NC - 1)];
+        o.w[i] = bs ? ((a >> bs) | (b << (64 - bs))) : a;
     }
-    SlotMask<NC> o;
-    o.w[0] = r ? ((a >> r) | (b << (64 - r))) : a;
-    o.w[NC - 1] = r ? ((b >> r) | (a << (64 - r))) : b;
     return o;
 }
 template <int NC> __device__ __forceinline__ bool sm_any(const SlotMask<NC> &m) {
-    return NC == 1 ? m.w[0] != 0 : (m.w[0] | m.w[NC - 1]) != 0;
+    unsigned long long x = 0;
+#pragma unroll
+    for (int i = 0; i < NC; i++) x |= m.w[i];
+    return x != 0;
 }
 template <int NC> __device__ __forceinline__ int sm_first(const SlotMask<NC> &m) { // lowest set bit (m non-zero)
-    if (NC == 1 || m.w[0]) return __ffsll((long long)m.w[0]) - 1;
-    return 64 + __ffsll((long long)m.w[NC - 1]) - 1;
+    int r = 64 * (NC - 1) + __ffsll((long long)m.w[NC - 1]) - 1;
+#pragma unroll
+    for (int i = NC - 2; i >= 0; i--)
+        if (m.w[i]) r = 64 * i + __ffsll((long long)m.w[i]) - 1;
+    return r;
 }
 template <int NC> __device__ __forceinline__ int sm_last(const SlotMask<NC> &m) { // highest set bit (m non-zero)
-    if (NC == 1 || m.w[NC - 1] == 0) return 63 - __clzll((long long)m.w[0]);
-    return 127 - __clzll((long long)m.w[NC - 1]);
+    int r = 63 - __clzll((long long)m.w[0]);
+#pragma unroll
+    for (int i = 1; i < NC; i++)
+        if (m.w[i]) r = 64 * i + 63 - __clzll((long long)m.w[i]);
+    return r;
 }
 template <int NC> __device__ __forceinline__ SlotMask<NC> sm_below(SlotMask<NC> m, int nbits) { // keep bits [0, nbits)
-    if (NC == 1) {
-        m.w[0] &= nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull);
-        return m;
-    }
-    if (nbits <= 64) {
-        m.w[0] &= nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull);
-        m.w[NC - 1] = 0;
-    } else {
-        m.w[NC - 1] &= nbits >= 128 ? ~0ull : ((1ull << (nbits - 64)) - 1ull);
+#pragma unroll
+    for (int i = 0; i < NC; i++) {
+        const int nb = nbits - 64 * i;
+        m.w[i] &= nb >= 64 ? ~0ull : (nb <= 0 ? 0ull : ((1ull << nb) - 1ull));
     }
     return m;
 }
 template <int NC> __device__ __forceinline__ SlotMask<NC> sm_from(SlotMask<NC> m, int b0) { // keep bits [b0, W)
-    if (NC == 1) {
-        m.w[0] = b0 >= 64 ? 0ull : ((m.w[0] >> b0) << b0);
-        return m;
-    }
-    if (b0 >= 64) {
-        m.w[0] = 0;
-        m.w[NC - 1] = b0 >= 128 ? 0ull : ((m.w[NC - 1] >> (b0 - 64)) << (b0 - 64));
-    } else {
-        m.w[0] = (m.w[0] >> b0) << b0;
+#pragma unroll
+    for (int i = 0; i < NC; i++) {
+        const int b = b0 - 64 * i;
+        m.w[i] = b >= 64 ? 0ull : (b <= 0 ? m.w[i] : ((m.w[i] >> b) << b));
     }
     return m;
 }
@@ -1871,16 +1874,19 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                                                   uint8_t *__restrict__ arena_pool, int64_t arena_stride,
                                                   uint64_t *__restrict__ ops_pool, unsigned int *__restrict__ queue,
                                                   int seq_words, int want_ops, WfaOut *__restrict__ out) {
-    static_assert(NC == 1 || NC == 2, "one or two cells per lane");
+    static_assert(NC == 1 || NC == 2 || NC == 4, "one, two or four cells per lane");
     constexpr int W = 64 * NC;
     // All penalties are even (x=4, o+e=8, e=2): only even scores have wavefronts, so the ring holds the last five even
     // M scores (s, s-2, .. s-8) and the last two I / D scores, and the score loop steps by 2. (Odd scores are empty
     // wavefronts in the reference and the backtrace never visits them.)
-    __shared__ int32_t rM[5][W];
-    __shared__ int32_t rI[2][W];
-    __shared__ int32_t rD[2][W];
+    // ring of wavefront rows; the backtrace walk reuses the same LDS (the ring is dead by then) for its row window
+    constexpr int RING_BYTES = 9 * W * 4 > (int)sizeof(BtLds) ? 9 * W * 4 : (int)sizeof(BtLds);
+    __shared__ __attribute__((aligned(16))) uint8_t ring_raw[RING_BYTES];
+    int32_t(*rM)[W] = (int32_t(*)[W])ring_raw;
+    int32_t(*rI)[W] = (int32_t(*)[W])(ring_raw + 5 * W * 4);
+    int32_t(*rD)[W] = (int32_t(*)[W])(ring_raw + 7 * W * 4);
+    BtLds &btl = *(BtLds *)ring_raw;
     __shared__ unsigned int sh_x;
-    __shared__ BtLds btl;
     extern __shared__ uint32_t seq_lds[];
     uint32_t *Qp = seq_lds, *Tp = seq_lds + seq_words + 1;
     const int lane = threadIdx.x;
@@ -1963,8 +1969,9 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
         // does the slot range of diagonals [lo, hi] touch the 64 slots of chunk c ?
         auto chunk_has = [&](int c, int lo_, int hi_) {
             if (NC == 1) return true;
-            const int s0 = (lo_ + koff) & (W - 1), s1 = s0 + (hi_ - lo_); // s1 < 2W
-            return c == 0 ? (s0 < 64 || s1 >= W) : (s1 >= 64 && !(s0 < 64 && s1 < 64));
+            const int s0 = (lo_ + koff) & (W - 1), s1 = s0 + (hi_ - lo_); // s1 < 2W: slots [s0, s1], wrapping past W
+            const int c0 = 64 * c, c1 = 64 * c + 63;
+            return (s0 <= c1 && s1 >= c0) || (s1 >= W && s1 - W >= c0);
         };
         while (status == 0) {
             bool done = false;
@@ -2021,7 +2028,7 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                     for (int c = 0; c < NC; c++) kb.w[c] = __ballot(inr[c] && (dist[c] - dmin <= 50));
                     int nlo = mlo[0], nhi = mhi[0];
                     const int top = ak < mhi[0] ? ak : mhi[0];
-                    const bool a0 = chunk_has(0, mlo[0], mhi[0]), a1 = NC == 2 && chunk_has(NC - 1, mlo[0], mhi[0]);
+                    const bool a0 = NC == 2 && chunk_has(0, mlo[0], mhi[0]), a1 = NC == 2 && chunk_has(NC - 1, mlo[0], mhi[0]);
                     if (NC == 2 && a0 != a1) {
                         // the whole wavefront sits in one 64-slot chunk, unwrapped: plain 64-bit masks
                         const int sh = ((mlo[0] + koff) & (W - 1)) & 63;
@@ -2179,7 +2186,7 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                 bi.w[c] = __ballot(okc(ins));
                 bd.w[c] = __ballot(okc(del));
             }
-            const bool t0 = chunk_has(0, lo, hi), t1 = NC == 2 && chunk_has(NC - 1, lo, hi);
+            const bool t0 = NC == 2 && chunk_has(0, lo, hi), t1 = NC == 2 && chunk_has(NC - 1, lo, hi);
             if (NC == 2 && t0 != t1) { // the new wavefront sits in one chunk, unwrapped: 64-bit masks, plain shift
                 const int sh = ((lo + koff) & (W - 1)) & 63;
                 const unsigned long long m64 = (t1 ? bm.w[NC - 1] : bm.w[0]) >> sh;
@@ -2330,17 +2337,18 @@ void launch_sum_i32(hipStream_t st, const int32_t *v, int64_t n, unsigned long l
     hipLaunchKernelGGL(k_sum_i32, dim3(g), dim3(256), 0, st, v, n, out);
 }
 void launch_build_cmp_bits(hipStream_t st, const uint64_t *keys_cmp, const int64_t *posoff, const int32_t *nvalid, int nq,
-                           int K, uint32_t *bits) {
+                           int K, const int64_t *bits_off, const int32_t *bits_log, uint32_t *bits) {
     int g = nq < 1 ? 1 : (nq > 65536 ? 65536 : nq);
-    hipLaunchKernelGGL(k_build_cmp_bits, dim3(g), dim3(256), 0, st, keys_cmp, posoff, nvalid, nq, K, bits);
+    hipLaunchKernelGGL(k_build_cmp_bits, dim3(g), dim3(256), 0, st, keys_cmp, posoff, nvalid, nq, K, bits_off, bits_log, bits);
 }
 void launch_pa_anchors(hipStream_t st, DevIndexView ix, const Task *tasks, int64_t ntasks, const uint8_t *wbuf,
                        const uint64_t *keys_cmp, const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid,
-                       const uint32_t *cmp_tab, const uint32_t *cmp_bits, int K, int min_prefix,
-                       unsigned long long *count, int64_t cap, uint64_t *outA, uint64_t *outB, int qbits, int tbits) {
+                       const uint32_t *cmp_tab, const uint32_t *cmp_bits, const int64_t *bits_off, const int32_t *bits_log,
+                       int K, int min_prefix, unsigned long long *count, int64_t cap, uint64_t *outA, uint64_t *outB,
+                       int qbits, int tbits) {
     int g = (int)(ntasks < 1 ? 1 : (ntasks > 1048576 ? 1048576 : ntasks));
     hipLaunchKernelGGL(k_pa_anchors, dim3(g), dim3(256), 0, st, ix, tasks, ntasks, wbuf, keys_cmp, vals_cmp, posoff, nvalid,
-                       cmp_tab, cmp_bits, K, min_prefix, count, cap, outA, outB, qbits, tbits);
+                       cmp_tab, cmp_bits, bits_off, bits_log, K, min_prefix, count, cap, outA, outB, qbits, tbits);
 }
 void launch_pa_task_off_sorted(hipStream_t st, const uint64_t *sortedA, int shift, int64_t total, int64_t ntasks,
                                int64_t *pa_off) {
@@ -2384,16 +2392,20 @@ static int resident_blocks_of(const void *kern, int device, int seq_words) {
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
     return nb * cus;
 }
-int wfa_resident_blocks(int device, int seq_words) {
-    return resident_blocks_of((const void *)k_wfa_lean<2>, device, seq_words);
+int wfa_resident_blocks(int device, int seq_words, int nc) {
+    return resident_blocks_of(nc == 4 ? (const void *)k_wfa_lean<4> : (const void *)k_wfa_lean<2>, device, seq_words);
 }
 void launch_wfa(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks,
                 int32_t *hdr_pool, int64_t hdr_stride, uint8_t *arena_pool, int64_t arena_stride, uint64_t *ops_pool,
-                unsigned int *queue, int seq_words, int want_ops, WfaOut *out) {
+                unsigned int *queue, int seq_words, int want_ops, WfaOut *out, int nc) {
     // two packed sequences with one padding word each, +2 words: the predicated extension may read one word past
     size_t dyn = (size_t)(2 * (seq_words + 1) + 2) * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_wfa_lean<2>, dim3(nblocks), dim3(64), dyn, st, in, n, todo, ntodo, hdr_pool, hdr_stride, arena_pool,
-                       arena_stride, ops_pool, queue, seq_words, want_ops, out);
+    if (nc == 4)
+        hipLaunchKernelGGL(k_wfa_lean<4>, dim3(nblocks), dim3(64), dyn, st, in, n, todo, ntodo, hdr_pool, hdr_stride, arena_pool,
+                           arena_stride, ops_pool, queue, seq_words, want_ops, out);
+    else
+        hipLaunchKernelGGL(k_wfa_lean<2>, dim3(nblocks), dim3(64), dyn, st, in, n, todo, ntodo, hdr_pool, hdr_stride, arena_pool,
+                           arena_stride, ops_pool, queue, seq_words, want_ops, out);
 }
 void launch_wfa_wide(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int32_t *hdr_pool,
                      int32_t *arena_pool, uint64_t *ops_pool, WfaOut *out) {

@@ -327,6 +327,10 @@ struct lm_qbatch {
     int64_t total_len = 0, total_pos = 0;
     DBuf<uint8_t> d_seq;
     DBuf<int64_t> d_qoff, d_posoff, d_segoff;
+    // per-query prefix filter of the pseudo-alignment (k_build_cmp_bits): 2^bits_log[q] bits at word bits_off[q]
+    DBuf<int64_t> d_bits_off;
+    DBuf<int32_t> d_bits_log;
+    int64_t bits_words = 0;
 };
 
 struct lm_result {
@@ -439,8 +443,10 @@ static void stage_kmers(Work &w) {
     w.v_cmp = w.vals_cmp2.p;
     w.cmp_tab.ensure((size_t)qb->nq * ((1 << LM_TAB_BITS) + 1));
     launch_build_cmp_tab(S(ix), w.k_cmp, qb->d_posoff.p, w.nvalid.p, qb->nq, ix->host.k, w.cmp_tab.p);
-    w.cmp_bits.ensure((size_t)qb->nq * LM_PFX_WORDS_PER_QUERY);
-    launch_build_cmp_bits(S(ix), w.k_cmp, qb->d_posoff.p, w.nvalid.p, qb->nq, ix->host.k, w.cmp_bits.p);
+    w.cmp_bits.ensure((size_t)qb->bits_words + 1);
+    HIPCHK(hipMemsetAsync(w.cmp_bits.p, 0, (size_t)qb->bits_words * sizeof(uint32_t), S(ix)));
+    launch_build_cmp_bits(S(ix), w.k_cmp, qb->d_posoff.p, w.nvalid.p, qb->nq, ix->host.k, qb->d_bits_off.p, qb->d_bits_log.p,
+                          w.cmp_bits.p);
 }
 
 static void stage_mask(Work &w) {
@@ -1040,6 +1046,20 @@ static lm_qbatch *upload_part(lm_index *ix, const lm_query *queries, size_t nq, 
         h2d(ix, qb->d_qoff, qb->h_qoff);
         h2d(ix, qb->d_posoff, qb->h_posoff);
         h2d(ix, qb->d_segoff, segoff);
+        {   // ~16 filter bits per k-mer (both strands), 2^13 .. 2^22 (= the exact 4^11-bit map)
+            std::vector<int64_t> boff(nq + 1, 0);
+            std::vector<int32_t> blog(nq + 1, 13);
+            for (size_t i = 0; i < nq; i++) {
+                const int64_t nk = 2 * (qb->h_posoff[i + 1] - qb->h_posoff[i]);
+                int lg = 13;
+                while (lg < 22 && ((int64_t)1 << lg) < 16 * nk) lg++;
+                blog[i] = lg;
+                boff[i + 1] = boff[i] + ((int64_t)1 << (lg - 5));
+            }
+            qb->bits_words = boff[nq];
+            h2d(ix, qb->d_bits_off, boff);
+            h2d(ix, qb->d_bits_log, blog);
+        }
         sync(ix);
     } catch (...) {
         delete qb;
@@ -1239,7 +1259,7 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
         {
             Prof p(ix, "k_pa_anchors", W);
             launch_pa_anchors(S(ix), ix->view, tasks_d, nt, a.wb, a.w->k_cmp, a.w->v_cmp, qb->d_posoff.p,
-                              a.w->nvalid.p, a.w->cmp_tab.p, a.w->cmp_bits.p, ix->host.k, 11, a.pa_count.p, a.pa_cap, a.A0.p, a.B0.p,
+                              a.w->nvalid.p, a.w->cmp_tab.p, a.w->cmp_bits.p, qb->d_bits_off.p, qb->d_bits_log.p, ix->host.k, 11, a.pa_count.p, a.pa_cap, a.A0.p, a.B0.p,
                               compact ? qbits : 0, compact ? tbits : 0);
         }
         unsigned long long hv = 0;
@@ -1412,31 +1432,31 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
         // one launch of the persistent LDS kernel per length class: the packed sequences live in LDS, so the resident
         // wavefronts per CU are set by the longest problem of the launch (gene-sized HSPs: 24 per CU, 50-kb reads: 5)
         auto persistent_pass = [&](const std::vector<int32_t> &items, int seq_words, int64_t lmax,
-                                   std::vector<int32_t> &too_wide) {
+                                   std::vector<int32_t> &too_wide, int nc) {
             const int64_t m = (int64_t)items.size();
             if (m == 0) return;
-            const int resident = wfa_resident_blocks(ix->device, seq_words);
+            const int resident = wfa_resident_blocks(ix->device, seq_words, nc);
             int nblocks = (int)std::min<int64_t>(m, resident);
             // private scratch per resident wave: one backtrace byte per wavefront cell + 8 bytes per even score; never
             // more than the worst case of the longest problem of the class
             const int64_t smax = 8 * lmax + 64; // a global alignment never exceeds this penalty
             const int64_t lean_budget = ix->scratch_budget > 0 ? std::min<int64_t>(a.wfa_budget, ix->scratch_budget * 2 / 5) : a.wfa_budget;
             int64_t bytes = lean_budget / nblocks * 7 / 8;
-            bytes = std::min<int64_t>(bytes, (smax / 2 + 2) * 128 + 2 * lmax + 4096);
+            bytes = std::min<int64_t>(bytes, (smax / 2 + 2) * 64 * nc + 2 * lmax + 4096);
             bytes = std::max<int64_t>(bytes, 65536);
             bytes = std::min<int64_t>(bytes, 2000000000) & ~(int64_t)15;
             int64_t entries = std::min<int64_t>(smax / 2 + 4, bytes / 24 + 1024);
             if (getenv("LM_DEBUG"))
-                fprintf(stderr, "[lm] wfa pass problems=%lld blocks=%d (resident %d) bytes/block=%lld scores=%lld seq_words=%d\n",
-                        (long long)m, nblocks, resident, (long long)bytes, (long long)(2 * entries), seq_words);
+                fprintf(stderr, "[lm] wfa pass (%d diagonals) problems=%lld blocks=%d (resident %d) bytes/block=%lld scores=%lld seq_words=%d\n",
+                        64 * nc, (long long)m, nblocks, resident, (long long)bytes, (long long)(2 * entries), seq_words);
             a.hdr_pool.ensure((size_t)(entries * 2) * nblocks + 16);
             a.arena_pool.ensure((size_t)(bytes / 4) * nblocks + 16);
             HIPCHK(hipMemcpyAsync(a.wfa_todo.p, items.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice, S(ix)));
             HIPCHK(hipMemsetAsync(a.wfa_queue.p, 0, sizeof(unsigned int), S(ix)));
             {
-                Prof p(ix, "k_wfa_lean", wfa_bytes(in, items));
+                Prof p(ix, nc == 4 ? "k_wfa_lean256" : "k_wfa_lean", wfa_bytes(in, items));
                 launch_wfa(S(ix), a.wfa_in.p, n, a.wfa_todo.p, m, nblocks, a.hdr_pool.p, entries * 2, (uint8_t *)a.arena_pool.p,
-                           bytes, a.ops_pool.p, a.wfa_queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p);
+                           bytes, a.ops_pool.p, a.wfa_queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc);
             }
             std::vector<WfaOut> tmp;
             d2h(ix, tmp, a.wfa_out.p, (size_t)n);
@@ -1450,7 +1470,7 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
                 n1 += stt == 1;
                 if (stt == 3) {
                     too_wide.push_back(i);
-                    a.stats->wfa_retries++;
+                    if (nc == 4) a.stats->wfa_retries++; // counted when a problem leaves the LDS kernels for good
                 } else if (stt == 1) { // scratch or ops overflow: per-problem scratch in the global-memory kernel
                     is_wide[i] = 1;
                     level[i] = 1;
@@ -1487,7 +1507,12 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
                 cw[c] = std::max(cw[c], wds);
                 cl[c] = std::max<int64_t>(cl[c], (int64_t)in[i].qlen + in[i].tlen);
             }
-            for (int c = 3; c >= 0; c--) persistent_pass(cls[c], cw[c], cl[c], wide2);
+            for (int c = 3; c >= 0; c--) {
+                // 126 diagonals first (a wavefront wider than that returns status 3), then the same kernel with 254
+                std::vector<int32_t> wider;
+                persistent_pass(cls[c], cw[c], cl[c], wider, 2);
+                persistent_pass(wider, cw[c], cl[c], wide2, 4);
+            }
         }
         for (int32_t i : wide2) { // wider than 126 diagonals, longer than the LDS buffers, or not plain ACGT
             is_wide[i] = 1;

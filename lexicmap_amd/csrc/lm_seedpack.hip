@@ -208,13 +208,51 @@ __global__ __launch_bounds__(64) void k_sp_sort_parts(const uint32_t *__restrict
     }
 }
 
-__global__ void k_sp_unpack(const uint64_t *__restrict__ stream, int64_t first, int64_t n, int width, uint64_t *__restrict__ out) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = lm_bits_get(stream, first + i, width);
+// ---- partitions above SP_MAXN seeds ------------------------------------------------------------------------------------
+// Every mask has a few of them: the k-mers a mask captures are the ones closest to it, so the captures of ALL genomes under a
+// mask share ~log4(genome length) bases with the mask and pile up in the partitions around the mask's own 13-base prefix
+// (thousands to 10^5 seeds at 10^4-10^5 genomes).  They are unpacked in batches, sorted by one rocPRIM segmented radix sort
+// per batch and packed back.
+__global__ void k_sp_big_info(const unsigned long long *__restrict__ slots, int64_t nb, const uint32_t *__restrict__ tab,
+                              const int64_t *__restrict__ md_off, int P1, int64_t *__restrict__ first, int64_t *__restrict__ cnt) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long s = slots[i];
+        first[i] = md_off[s / P1] + tab[s];
+        cnt[i] = (int64_t)tab[s + 1] - (int64_t)tab[s];
+    }
 }
-__global__ void k_sp_repack(uint64_t *__restrict__ stream, int64_t first, int64_t n, int width, const uint64_t *__restrict__ in) {
-    sp_store_range(stream, first, n, width, [&](int64_t i) { return in[i]; }, (int)(blockIdx.x * blockDim.x + threadIdx.x),
-                   (int)(gridDim.x * blockDim.x));
+// element e of the batch = seed (e - off[p]) of big partition p (off relative to the batch)
+__global__ void k_sp_unpack_many(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ vals, int key_bits, int val_bits,
+                                 const int64_t *__restrict__ first, const int64_t *__restrict__ off, int64_t nseg, int64_t base,
+                                 int64_t total, uint64_t *__restrict__ ko, uint64_t *__restrict__ vo) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        int64_t lo = 0, hi = nseg; // last p with off[p] - base <= e
+        while (lo + 1 < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (off[mid] - base <= e)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const int64_t src = first[lo] + (e - (off[lo] - base));
+        ko[e] = lm_bits_get(keys, src, key_bits);
+        vo[e] = lm_bits_get(vals, src, val_bits);
+    }
+}
+__global__ void k_sp_rel_offsets(const int64_t *__restrict__ off, int64_t nseg, int64_t base, uint32_t *__restrict__ rel) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= nseg; i += (int64_t)gridDim.x * blockDim.x)
+        rel[i] = (uint32_t)(off[i] - base);
+}
+__global__ __launch_bounds__(256) void k_sp_repack_many(uint64_t *__restrict__ keys, uint64_t *__restrict__ vals, int key_bits,
+                                                         int val_bits, const int64_t *__restrict__ first,
+                                                         const uint32_t *__restrict__ rel, int64_t nseg,
+                                                         const uint64_t *__restrict__ ki, const uint64_t *__restrict__ vi) {
+    for (int64_t p = blockIdx.x; p < nseg; p += gridDim.x) {
+        const int64_t n = (int64_t)rel[p + 1] - (int64_t)rel[p];
+        const uint64_t *k = ki + rel[p], *v = vi + rel[p];
+        sp_store_range(keys, first[p], n, key_bits, [&](int64_t i) { return k[i]; }, (int)threadIdx.x, (int)blockDim.x);
+        sp_store_range(vals, first[p], n, val_bits, [&](int64_t i) { return v[i]; }, (int)threadIdx.x, (int)blockDim.x);
+    }
 }
 
 // all seeds of one list back in the reference's (k-mer, value) form
@@ -354,28 +392,48 @@ void SeedPacker::finish() {
             fprintf(stderr, "[lm] seed image: partition sort kernel %.0f ms (mode %d), %llu partitions above %d seeds\n", now_ms() - t0,
                     dbg_mode, nb, SP_MAXN);
         if (nb > big_cap) throw HipError("seed image: too many partitions above the LDS sorter's size");
-        if (nb > 0) { // rare: rocPRIM on an unpacked copy of the partition
-            std::vector<unsigned long long> slots(nb);
-            HIPCHK(hipMemcpy(slots.data(), big.p, nb * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-            std::vector<int64_t> mdo((size_t)nmd + 1);
-            HIPCHK(hipMemcpy(mdo.data(), ix->d_md_off.p, ((size_t)nmd + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+        if (nb > 0) {
+            const double t1 = now_ms();
+            DBuf<int64_t> bfirst, bcnt, boff;
+            bfirst.alloc_exact((size_t)nb + 1);
+            bcnt.alloc_exact((size_t)nb + 1, true, ix->st);
+            boff.alloc_exact((size_t)nb + 2);
+            hipLaunchKernelGGL(k_sp_big_info, dim3(sp_grid((int64_t)nb)), dim3(256), 0, ix->st, big.p, (int64_t)nb, ix->d_part_tab.p,
+                               ix->d_md_off.p, P1, bfirst.p, bcnt.p);
+            prim_scan_to_i64(ix->st, ix->tmp, bcnt.p, (size_t)nb, boff.p);
+            std::vector<int64_t> off((size_t)nb + 1);
+            HIPCHK(hipMemcpyAsync(off.data(), boff.p, ((size_t)nb + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, ix->st));
+            HIPCHK(hipStreamSynchronize(ix->st));
+            // batches of whole partitions: 4 temporary u64 arrays, at most a quarter of what is free and 2^31 elements
+            size_t fr = 0, tot = 0;
+            (void)hipMemGetInfo(&fr, &tot);
+            int64_t batch = std::min<int64_t>(((int64_t)1 << 31) - 1, std::max<int64_t>((int64_t)(fr / 4 / 40), 1 << 20));
             DBuf<uint64_t> k0, k1, v0, v1;
-            for (unsigned long long s : slots) {
-                uint32_t be[2];
-                HIPCHK(hipMemcpy(be, ix->d_part_tab.p + s, sizeof be, hipMemcpyDeviceToHost));
-                const int64_t first = mdo[s / P1] + be[0], n = (int64_t)be[1] - be[0];
-                k0.ensure((size_t)n);
-                k1.ensure((size_t)n);
-                v0.ensure((size_t)n);
-                v1.ensure((size_t)n);
-                hipLaunchKernelGGL(k_sp_unpack, dim3(sp_grid(n)), dim3(256), 0, ix->st, ix->d_pk_keys.p, first, n, key_bits, k0.p);
-                hipLaunchKernelGGL(k_sp_unpack, dim3(sp_grid(n)), dim3(256), 0, ix->st, ix->d_pk_vals.p, first, n, val_bits, v0.p);
-                prim_sort_pairs(ix->st, ix->tmp, k0.p, k1.p, v0.p, v1.p, (size_t)n, 0, key_bits);
-                const int64_t nw = (n * std::max(key_bits, val_bits)) / 64 + 2;
-                hipLaunchKernelGGL(k_sp_repack, dim3(sp_grid(nw)), dim3(256), 0, ix->st, ix->d_pk_keys.p, first, n, key_bits, k1.p);
-                hipLaunchKernelGGL(k_sp_repack, dim3(sp_grid(nw)), dim3(256), 0, ix->st, ix->d_pk_vals.p, first, n, val_bits, v1.p);
+            DBuf<uint32_t> rel;
+            int64_t done_elems = 0;
+            for (size_t b0 = 0; b0 < (size_t)nb;) {
+                size_t b1 = b0 + 1;
+                while (b1 < (size_t)nb && off[b1 + 1] - off[b0] <= batch) b1++;
+                const int64_t E = off[b1] - off[b0], nseg = (int64_t)(b1 - b0);
+                if (E >= (int64_t)1 << 32) throw HipError("seed image: one partition holds more than 2^32 seeds");
+                k0.ensure((size_t)E);
+                k1.ensure((size_t)E);
+                v0.ensure((size_t)E);
+                v1.ensure((size_t)E);
+                rel.ensure((size_t)nseg + 1);
+                hipLaunchKernelGGL(k_sp_unpack_many, dim3(sp_grid(E)), dim3(256), 0, ix->st, ix->d_pk_keys.p, ix->d_pk_vals.p, key_bits,
+                                   val_bits, bfirst.p + b0, boff.p + b0, nseg, off[b0], E, k0.p, v0.p);
+                hipLaunchKernelGGL(k_sp_rel_offsets, dim3(sp_grid(nseg + 1)), dim3(256), 0, ix->st, boff.p + b0, nseg, off[b0], rel.p);
+                prim_segmented_sort_pairs(ix->st, ix->tmp, k0.p, k1.p, v0.p, v1.p, (size_t)E, (size_t)nseg, rel.p, 0, key_bits);
+                hipLaunchKernelGGL(k_sp_repack_many, dim3((unsigned)std::min<int64_t>(nseg, 65536)), dim3(256), 0, ix->st,
+                                   ix->d_pk_keys.p, ix->d_pk_vals.p, key_bits, val_bits, bfirst.p + b0, rel.p, nseg, k1.p, v1.p);
                 HIPCHK(hipStreamSynchronize(ix->st));
+                done_elems += E;
+                b0 = b1;
             }
+            if (getenv("LM_DEBUG"))
+                fprintf(stderr, "[lm] seed image: %llu large partitions (%lld seeds) sorted by rocPRIM in %.0f ms\n", nb,
+                        (long long)done_elems, now_ms() - t1);
         }
     }
     // ---- outlier lists: per list by k-mer
