@@ -1236,6 +1236,23 @@ LM_HDN bool lm_tree_search_range(const uint64_t *keys, int n, uint64_t key, int 
     return lm_tree_search_miss(keys, n, key, p, K, lo, lo_out, hi_out);
 }
 
+// Prefix filter of the pseudo-alignment (k_build_cmp_bits / k_pa_anchors): a query's bitmap over the hashed 11-base
+// prefixes of its k-mers, 2^log bits.  lm_pa_candidate is a NECESSARY condition for lm_tree_search_range(keys, key, p) to
+// return true (p >= 11): either some query k-mer shares the key's 11-base prefix (normal match, needs >= p >= 11 common
+// bases), or - filter miss, so the longest common prefix L is <= 10 - the partial-prefix rule fires at a node of depth
+// d <= L-1 <= 9, which needs the bases [d, p) and therefore [9, p) of the key to be all A.
+#define LM_PFX_BASES 11
+LM_HD uint32_t lm_pa_filter_slot(uint32_t pfx22, int log) {
+    return log >= 2 * LM_PFX_BASES ? pfx22 : (pfx22 * 0x9E3779B1u) >> (32 - log);
+}
+LM_HD bool lm_pa_candidate(const uint32_t *bits, int log, uint64_t key, int p, int K) {
+    const uint32_t h = lm_pa_filter_slot((uint32_t)(key >> ((K - LM_PFX_BASES) << 1)), log);
+    if ((bits[h >> 5] >> (h & 31)) & 1u) return true;
+    const int qfrom = LM_PFX_BASES - 2;
+    const uint64_t tail = (key >> ((K - p) << 1)) & ((1ull << ((p - qfrom) << 1)) - 1ull); // bases [9, p)
+    return tail == 0;
+}
+
 // Same, with the two binary searches narrowed by a bucket table over the leading `tab_bits/2` bases:
 // tab[b] = first index whose leading bits are >= b, tab[nbuckets] = n.  Requires 2*p >= tab_bits.
 LM_HD bool lm_tree_search_range_tab(const uint64_t *keys, int n, uint64_t key, int p, int K, const uint32_t *tab,

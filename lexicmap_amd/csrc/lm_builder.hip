@@ -491,6 +491,9 @@ lm_status lm_index_build_synthetic(const lm_synth_spec *spec, const lm_options *
         h.M = M;
         h.main_version = 3;
         h.minor_version = 5;
+        h.synthetic = true;
+        h.synth_genome_len = spec->genome_len;
+        h.synth_genomes = spec->genomes;
         h.mask_prefix = std::max(1, (int)(std::log2((double)M) / 2));
         h.anchor_prefix = 6;
         h.contig_interval = 1000;

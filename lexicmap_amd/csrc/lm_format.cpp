@@ -266,7 +266,9 @@ std::string load_index(const std::string &dir, int shard_rank, int shard_count, 
             return std::string("genome data: invalid binary format: ") + name;
         }
         for (uint32_t r = 0; r < nrec; r++, global++) {
-            if ((int)(global % shard_count) != shard_rank) continue;
+            // a shard keeps the bases of its own genomes only, but the names and sizes of all of them: rank 0 prints the
+            // merged rows of every shard (lm_merge_sharded)
+            const bool local = (int)(global % shard_count) == shard_rank;
             if (24 + (size_t)r * 12 + 12 > ib.size()) {
                 status = 2;
                 return "genome data: broken file (index)";
@@ -311,6 +313,11 @@ std::string load_index(const std::string &dir, int shard_rank, int shard_count, 
             if (p + nbytes > gb.size()) {
                 status = 2;
                 return "genome data: broken file";
+            }
+            if (!local) {
+                out.other_of[g.bg] = (int)out.others.size();
+                out.others.push_back(std::move(g));
+                continue;
             }
             g.bits_off = (int64_t)out.gbits.size();
             out.gbits.insert(out.gbits.end(), gb.begin() + p, gb.begin() + p + nbytes);

@@ -1,11 +1,12 @@
 // lm_format.h — host-side readers of the reference on-disk index (format 3.x) used to build the HBM image.
 // Reference: info.toml (lib-index-build.go:1914-1932), seeds/chunk_NNN.bin(.idx) (kv/kv-data.go:66-125,394-562;
 // kv/kv-reader.go:762-1021), genomes/batch_NNNN/genomes.bin(.idx) (genome/genome.go:184-358,388-474),
-// genomes.map.bin (lib-index-build.go:649-655,1969-2016).  masks.bin uses this build's own layout (the upstream
-// lexichash layout is not available).
+// genomes.map.bin (lib-index-build.go:649-655,1969-2016).  masks.bin: this build's own layout or a headered big-endian mask
+// list (the upstream lexichash layout is not in the reference tree; see lm_format.cpp and DESIGN.md).
 #pragma once
 #include <stdint.h>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 namespace lm {
@@ -32,6 +33,12 @@ struct HostIndex {
     std::vector<uint64_t> seed_kmers, seed_vals;
     // genomes of this shard
     std::vector<HostGenome> genomes;
+    // names / contig tables of the genomes held by the OTHER shards (no bases), keyed by batch<<17|index
+    std::vector<HostGenome> others;
+    std::unordered_map<uint64_t, int> other_of;
+    bool synthetic = false;        // built by lm_index_build_synthetic: names are a function of the genome number
+    int64_t synth_genomes = 0;
+    int32_t synth_genome_len = 0;
     std::vector<uint8_t> gbits;    // 2-bit packed, first base in bits 7-6; each genome padded to 8 bytes
     std::vector<int64_t> batch_first; // [batches+1] global dense number of the first genome of each batch
     int shard_rank = 0, shard_count = 1;

@@ -91,14 +91,12 @@ __global__ void k_build_cmp_tab(const uint64_t *__restrict__ keys_cmp, const int
 // Prefix filter of a query for the pseudo-alignment: a bitmap over the 11-base prefixes of its (filtered) k-mers, the
 // smallest prefix length SeqComparator.Compare ever asks for (lib-seq_compare.go:339-348).  Sized per query, 2^log bits
 // with ~16 bits per k-mer (a 1.5-kb gene: 64 Kbit, a 50-kb read: 2 Mbit; log = 22 is the exact 4^11-bit map), prefixes are
-// hashed into it.  A window k-mer whose 11-base prefix misses the map shares fewer than 11 bases with every query k-mer,
-// so it cannot match, and the partial-prefix rule of tree.Search (tree.go:496-500) can then only fire if its bases
-// [7, p) are all A: one load decides ~95 % of the window positions (k_pa_anchors).  The earlier exact 8-base map filled
+// hashed into it.  A window k-mer whose 11-base prefix misses the map shares L <= 10 bases with every query k-mer, so it
+// cannot match, and the partial-prefix rule of tree.Search (tree.go:496-500) fires at a node of depth d <= L-1 <= 9 and
+// needs the bases [d, p) of the k-mer to be all A: it can only fire if the bases [9, p) are all A (1/16 of the positions
+// at p = 11, 1/256 at p = 13).  One load decides ~90 % of the window positions (k_pa_anchors).  The earlier exact 8-base map filled
 // up with long reads (a 20-kb read sets 45 % of its 65536 bits).
-#define LM_PFX_BASES 11
-__device__ __forceinline__ uint32_t pfx_slot(uint32_t pfx22, int log) {
-    return log >= 2 * LM_PFX_BASES ? pfx22 : (pfx22 * 0x9E3779B1u) >> (32 - log);
-}
+__device__ __forceinline__ uint32_t pfx_slot(uint32_t pfx22, int log) { return lm_pa_filter_slot(pfx22, log); }
 __global__ __launch_bounds__(256) void k_build_cmp_bits(const uint64_t *__restrict__ keys_cmp,
                                                          const int64_t *__restrict__ posoff,
                                                          const int32_t *__restrict__ nvalid, int nq, int K,
@@ -646,10 +644,10 @@ __global__ __launch_bounds__(256) void k_pa_anchors(DevIndexView ix, const Task 
         const int64_t goff = t.g >= 0 ? ix.g_off[t.g] : 0;
         const int npos = c.n > 0 ? t.wlen - K + 1 : 0;
         const int p = c.m > K ? K : c.m;
-        const int sh = (K - p) << 1;
         const bool use_bits = c.bits != nullptr && p >= LM_PFX_BASES && K >= LM_PFX_BASES;
         const bool fast_pfx = use_bits && gb != nullptr && p <= 15 && K >= 16;
-        const uint64_t tail_mask = p > 7 ? ((p - 7) >= 32 ? ~0ull : ((1ull << ((p - 7) << 1)) - 1ull)) : 0ull; // bases [7,p)
+        const int qfrom = LM_PFX_BASES - 2; // the partial-prefix rule needs the bases [9, p) to be all A after a filter miss
+        const uint64_t tail_mask = p > qfrom ? ((p - qfrom) >= 32 ? ~0ull : ((1ull << ((p - qfrom) << 1)) - 1ull)) : 0ull;
         if (tid == 0) {
             q_n = 0;
             s_on = 0;
@@ -752,7 +750,7 @@ __global__ __launch_bounds__(256) void k_pa_anchors(DevIndexView ix, const Task 
 #pragma unroll
                     for (int strand = 0; strand < 2; strand++) {
                         const uint32_t h = pfx_slot((pf[u][strand] >> (2 * (p - LM_PFX_BASES))) & ((1u << (2 * LM_PFX_BASES)) - 1u), c.bits_log);
-                        const bool cand = ((word[u][strand] >> (h & 31)) & 1u) != 0 || (pf[u][strand] & ((1u << (2 * (p - 7))) - 1u)) == 0;
+                        const bool cand = ((word[u][strand] >> (h & 31)) & 1u) != 0 || (pf[u][strand] & (uint32_t)tail_mask) == 0;
                         if (cand) {
                             const int slot = atomicAdd(&q_n, 1);
                             if (slot < PA_QCAP) q_item[slot] = ((uint32_t)i << 1) | (uint32_t)strand;
@@ -771,8 +769,7 @@ __global__ __launch_bounds__(256) void k_pa_anchors(DevIndexView ix, const Task 
                         const uint64_t key = strand ? rc : kmer;
                         bool cand = true;
                         if (use_bits) {
-                            const uint32_t h = pfx_slot((uint32_t)(key >> ((K - LM_PFX_BASES) << 1)), c.bits_log);
-                            cand = ((c.bits[h >> 5] >> (h & 31)) & 1u) != 0 || ((key >> sh) & tail_mask) == 0;
+                            cand = lm_pa_candidate(c.bits, c.bits_log, key, p, K);
                         }
                         if (cand) {
                             const int slot = atomicAdd(&q_n, 1);
@@ -1869,12 +1866,12 @@ template <int NC> __device__ __forceinline__ SlotMask<NC> sm_from(SlotMask<NC> m
 }
 
 template <int NC>
-__global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, int64_t n, const int32_t *__restrict__ todo,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 2 ? 7 : (NC == 4 ? 4 : 2), NC == 2 ? 7 : (NC == 4 ? 4 : 2)))) void k_wfa_lean(const WfaIn *__restrict__ in, int64_t n, const int32_t *__restrict__ todo,
                                                   int64_t ntodo, int32_t *__restrict__ hdr_pool, int64_t hdr_stride,
                                                   uint8_t *__restrict__ arena_pool, int64_t arena_stride,
                                                   uint64_t *__restrict__ ops_pool, unsigned int *__restrict__ queue,
                                                   int seq_words, int want_ops, WfaOut *__restrict__ out) {
-    static_assert(NC == 1 || NC == 2 || NC == 4, "one, two or four cells per lane");
+    static_assert(NC == 1 || NC == 2 || NC == 4 || NC == 8, "1, 2, 4 or 8 cells per lane");
     constexpr int W = 64 * NC;
     // All penalties are even (x=4, o+e=8, e=2): only even scores have wavefronts, so the ring holds the last five even
     // M scores (s, s-2, .. s-8) and the last two I / D scores, and the score loop steps by 2. (Odd scores are empty
@@ -1958,6 +1955,7 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
         if (lane == 0) rM[0][koff & (W - 1)] = 0;
         LDS_WAVE_SYNC();
         int s = 0, ms = 0, is = 0; // ring rows of score s
+        int wide_at = 0;           // width that did not fit the ring (status 3), reported in the score field
         int alo = 0;               // first diagonal of the row of score s
         int32_t used = 1;          // backtrace bytes (the slab holds < 2^31); score 0 = one cell that is never read
         if (lane == 0) {
@@ -2129,6 +2127,7 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
             const int wd = hi - lo + 1;
             if (wd > W - 2) {
                 status = 3;
+                wide_at = wd;
                 break;
             }
             if ((int64_t)used + wd > arena_cap) {
@@ -2225,7 +2224,7 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
         o.blast_score = 0;
         if (status != 0) {
             o.r.status = status;
-            o.r.score = 0;
+            o.r.score = wide_at;
             o.r.nops = 0;
             o.r.qbegin = o.r.qend = o.r.tbegin = o.r.tend = 0;
             o.r.align_len = o.r.matches = o.r.gaps = o.r.gap_regions = 0;
@@ -2393,14 +2392,18 @@ static int resident_blocks_of(const void *kern, int device, int seq_words) {
     return nb * cus;
 }
 int wfa_resident_blocks(int device, int seq_words, int nc) {
-    return resident_blocks_of(nc == 4 ? (const void *)k_wfa_lean<4> : (const void *)k_wfa_lean<2>, device, seq_words);
+    return resident_blocks_of(nc == 8 ? (const void *)k_wfa_lean<8> : nc == 4 ? (const void *)k_wfa_lean<4> : (const void *)k_wfa_lean<2>,
+                              device, seq_words);
 }
 void launch_wfa(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks,
                 int32_t *hdr_pool, int64_t hdr_stride, uint8_t *arena_pool, int64_t arena_stride, uint64_t *ops_pool,
                 unsigned int *queue, int seq_words, int want_ops, WfaOut *out, int nc) {
     // two packed sequences with one padding word each, +2 words: the predicated extension may read one word past
     size_t dyn = (size_t)(2 * (seq_words + 1) + 2) * sizeof(uint32_t);
-    if (nc == 4)
+    if (nc == 8)
+        hipLaunchKernelGGL(k_wfa_lean<8>, dim3(nblocks), dim3(64), dyn, st, in, n, todo, ntodo, hdr_pool, hdr_stride, arena_pool,
+                           arena_stride, ops_pool, queue, seq_words, want_ops, out);
+    else if (nc == 4)
         hipLaunchKernelGGL(k_wfa_lean<4>, dim3(nblocks), dim3(64), dyn, st, in, n, todo, ntodo, hdr_pool, hdr_stride, arena_pool,
                            arena_stride, ops_pool, queue, seq_words, want_ops, out);
     else

@@ -1454,7 +1454,7 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
             HIPCHK(hipMemcpyAsync(a.wfa_todo.p, items.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice, S(ix)));
             HIPCHK(hipMemsetAsync(a.wfa_queue.p, 0, sizeof(unsigned int), S(ix)));
             {
-                Prof p(ix, nc == 4 ? "k_wfa_lean256" : "k_wfa_lean", wfa_bytes(in, items));
+                Prof p(ix, nc == 8 ? "k_wfa_lean512" : nc == 4 ? "k_wfa_lean256" : "k_wfa_lean", wfa_bytes(in, items));
                 launch_wfa(S(ix), a.wfa_in.p, n, a.wfa_todo.p, m, nblocks, a.hdr_pool.p, entries * 2, (uint8_t *)a.arena_pool.p,
                            bytes, a.ops_pool.p, a.wfa_queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc);
             }
@@ -1464,13 +1464,15 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
             if (want_ops) d2h(ix, ops_tmp, a.ops_pool.p, (size_t)ops_tot);
             sync(ix);
             int64_t n3 = 0, n1 = 0;
+            int maxw = 0;
             for (int32_t i : items) {
                 int stt = tmp[i].r.status;
                 n3 += stt == 3;
                 n1 += stt == 1;
                 if (stt == 3) {
+                    maxw = std::max(maxw, tmp[i].r.score); // the width that did not fit (0: other reasons)
                     too_wide.push_back(i);
-                    if (nc == 4) a.stats->wfa_retries++; // counted when a problem leaves the LDS kernels for good
+                    if (nc == 8) a.stats->wfa_retries++; // counted when a problem leaves the LDS kernels for good
                 } else if (stt == 1) { // scratch or ops overflow: per-problem scratch in the global-memory kernel
                     is_wide[i] = 1;
                     level[i] = 1;
@@ -1484,8 +1486,8 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
                 }
             }
             if (getenv("LM_DEBUG") && (n3 || n1))
-                fprintf(stderr, "[lm] wfa pass: %lld problems left the LDS kernel as too wide / long / non-ACGT, %lld on scratch overflow\n",
-                        (long long)n3, (long long)n1);
+                fprintf(stderr, "[lm] wfa pass: %lld problems left the LDS kernel as too wide (first width that did not fit <= %d) / long / non-ACGT, %lld on scratch overflow\n",
+                        (long long)n3, maxw, (long long)n1);
         };
         // length classes (sequence words of 16 bases); within a class the queue keeps the longest-expected-first order
         std::vector<int32_t> wide2;
@@ -1508,10 +1510,11 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
                 cl[c] = std::max<int64_t>(cl[c], (int64_t)in[i].qlen + in[i].tlen);
             }
             for (int c = 3; c >= 0; c--) {
-                // 126 diagonals first (a wavefront wider than that returns status 3), then the same kernel with 254
-                std::vector<int32_t> wider;
+                // 126 diagonals first (a wavefront wider than that returns status 3), then the same kernel with 254 and 510
+                std::vector<int32_t> wider, widest;
                 persistent_pass(cls[c], cw[c], cl[c], wider, 2);
-                persistent_pass(wider, cw[c], cl[c], wide2, 4);
+                persistent_pass(wider, cw[c], cl[c], widest, 4);
+                persistent_pass(widest, cw[c], cl[c], wide2, 8);
             }
         }
         for (int32_t i : wide2) { // wider than 126 diagonals, longer than the LDS buffers, or not plain ACGT

@@ -33,6 +33,15 @@ int32_t ha_partition_range(const uint64_t *keys, int key_bits, int64_t b, int64_
 uint64_t ha_pack_seed_val(uint64_t g, uint64_t v64, int pos_bits) { return lm_pack_seed_val(g, v64, pos_bits); }
 uint64_t ha_unpack_seed_val(uint64_t pv, uint64_t bg, int pos_bits, int dir) { return lm_unpack_seed_val(pv, bg, pos_bits, dir); }
 
+// pseudo-alignment prefix filter: bitmap of a sorted key array the way k_build_cmp_bits fills it, and the candidate test
+void ha_pa_filter_build(const uint64_t *keys, int n, int K, int log, uint32_t *bits) {
+    for (int i = 0; i < n; i++) {
+        const uint32_t h = lm_pa_filter_slot((uint32_t)(keys[i] >> ((K - LM_PFX_BASES) << 1)), log);
+        bits[h >> 5] |= 1u << (h & 31);
+    }
+}
+int ha_pa_candidate(const uint32_t *bits, int log, uint64_t key, int p, int K) { return lm_pa_candidate(bits, log, key, p, K); }
+
 uint64_t ha_xor_argmin(const uint64_t *a, int n, uint64_t m, int *lo, int *hi) { return lm_xor_argmin(a, n, m, lo, hi); }
 
 uint64_t ha_pack_anchor(int qb, int len, int tb, int qrc, int trc) { return lm_pack_anchor(qb, len, tb, qrc, trc); }

@@ -61,6 +61,8 @@ def lib():
                                            C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.ha_wfa.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_uint64),
                              C.c_int, C.POINTER(WfaOut)]
+        L.ha_pa_filter_build.argtypes = [C.POINTER(C.c_uint64), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
+        L.ha_pa_candidate.argtypes = [C.POINTER(C.c_uint32), C.c_int, C.c_uint64, C.c_int, C.c_int]
         L.ha_bits_get.restype = C.c_uint64
         L.ha_bits_get.argtypes = [C.POINTER(C.c_uint64), C.c_int64, C.c_int]
         L.ha_bits_store_range.argtypes = [C.POINTER(C.c_uint64), C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_uint64)]

@@ -271,6 +271,7 @@ def test_tree_search_quirk_matches_radix_tree():
     L, Hh = O.lib(), H.lib()
     rng = random.Random(99)
     hits_quirk = 0
+    hits_quirk_filter = 0
     for trial in range(60):
         keyset = set()
         base = rng.getrandbits(62)
@@ -288,6 +289,10 @@ def test_tree_search_quirk_matches_radix_tree():
         out = C.POINTER(O.TreeSr)()
         cap = C.c_int(0)
         lo, hi = C.c_int(), C.c_int()
+        # the pseudo-alignment prefix filter of this key set (k_build_cmp_bits): small map -> hashed, 22 -> exact
+        flog = rng.choice([13, 16, 22])
+        fbits = (C.c_uint32 * (1 << (flog - 5)))()
+        Hh.ha_pa_filter_build(arr, len(keys), K, flog, fbits)
         for _ in range(400):
             share = rng.randint(1, 12)
             sh = 62 - 2 * share
@@ -303,9 +308,15 @@ def test_tree_search_quirk_matches_radix_tree():
                 assert res == exp, (trial, hex(q), p)
                 if n and out[0].len_prefix < p:
                     hits_quirk += 1
+                    if p >= 11:
+                        hits_quirk_filter += 1
+                # k_pa_anchors only runs the search on positions the filter lets through: never a false negative
+                if n and p >= 11:
+                    assert Hh.ha_pa_candidate(fbits, flog, q, p, K), (trial, hex(q), p, flog)
         L.free(out)
         L.lmo_tree_free(t)
     assert hits_quirk > 0  # the quirk path was really exercised
+    assert hits_quirk_filter > 0  # also at the prefix lengths the filter is used with
 
 
 @pytest.mark.parametrize("seed", range(6))

@@ -401,3 +401,47 @@ def test_errors_fail_loudly(tmp_path):
     la = _la()
     with pytest.raises(RuntimeError):
         la.Index(str(tmp_path / "does_not_exist"))
+
+
+def test_index_format_variants_and_broken_files(small_index, queries, tmp_path):
+    """a20: (1) masks.bin as a headered big-endian mask list (8-byte magic, meta bytes with k at byte 10, u64 count, u64 seed:
+    the layout lexichash's WriteToFile is believed to use) opens and searches like this build's own layout - accepted only
+    because k / count agree with info.toml and the masks ascend; (2) an unknown layout, a truncated seed chunk and a
+    genomes.chunks.bin that this build cannot honour yet fail with an error instead of reading out of bounds / wrong rows"""
+    import shutil
+    import struct
+    la = _la()
+    d, _ = small_index
+    base = la.Index(d)
+    seqs = [q[1] for q in queries[:6]]
+    want, _ = base.search(seqs)
+    M = base.info()["masks"]
+    mp = la.lib().lm_index_masks(base.h)
+    masks = [mp[i] for i in range(M)]
+    base.close()
+    alt = str(tmp_path / "alt.lmi")
+    shutil.copytree(d, alt)
+    with open(os.path.join(alt, "masks.bin"), "wb") as f:
+        f.write(b"kmermask" + bytes([0, 1, 31, 0, 0, 0, 0, 0]) + struct.pack(">QQ", M, 1))
+        f.write(b"".join(struct.pack(">Q", m) for m in masks))
+    gi = la.Index(alt)
+    got, _ = gi.search(seqs)
+    gi.close()
+    assert got == want and len(want) > 0
+    # unknown masks layout
+    bad = str(tmp_path / "bad1.lmi")
+    shutil.copytree(d, bad)
+    with open(os.path.join(bad, "masks.bin"), "wb") as f:
+        f.write(b"whatever" + bytes(40))
+    with pytest.raises(RuntimeError, match="masks"):
+        la.Index(bad)
+    # truncated seed chunk: cut inside the records
+    bad2 = str(tmp_path / "bad2.lmi")
+    shutil.copytree(d, bad2)
+    chunk = sorted(f for f in os.listdir(os.path.join(bad2, "seeds")) if f.endswith(".bin"))[0]
+    path = os.path.join(bad2, "seeds", chunk)
+    data = open(path, "rb").read()
+    for cut in (len(data) // 2, len(data) - 3, 41):
+        open(path, "wb").write(data[:cut])
+        with pytest.raises(RuntimeError, match="broken|invalid"):
+            la.Index(bad2)
