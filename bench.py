@@ -382,7 +382,9 @@ def main():
                 else:
                     rows["query"] = rows["query"] * world + rank  # local -> global query number (round-robin sharding)
             per_rank = merge.all_gather_rows(rows, device="cuda" if args.dist_backend == "nccl" else "cpu", host_on=0)
-            rows = merge.merge_sharded(per_rank) if index_sharded else merge.merge_query_sharded(per_rank)
+            # index shards: the library's C merge (lm_merge_sharded: final order per query + global hits) on rank 0
+            rows = (merge.merge_sharded_c(per_rank) if rank == 0 else per_rank[0]) if index_sharded else \
+                merge.merge_query_sharded(per_rank)
         return rows, st
 
     for _ in range(args.warmup):

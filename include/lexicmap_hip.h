@@ -172,6 +172,41 @@ void lm_result_free(lm_result *res); /* RecycleSearchResults, lib-index-search.g
 /* search.go:468-523: one TSV line (no newline); returns the length that was/would be written */
 int lm_format_row(const lm_hsp *row, const char *query_id, uint32_t qlen, int more_columns, char *buf, size_t buflen);
 
+typedef struct lm_stage lm_stage; /* host arrays of a stage-level call, released with lm_stage_free */
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Genome-sharded indexes: every rank opens the index with its shard_rank / shard_count, searches the SAME
+ * query batch, and the host gathers the per-rank rows (one all-gatherv of lm_hsp records).  lm_merge_sharded then
+ * produces the reference's final order per query - genomes by the similarity (bitscore * pident) of their best HSP
+ * cluster, descending (lib-index-search.go:2919-2921), each genome's rows as they were - and the global `hits`
+ * (search.go:463,494): what `lexicmap utils merge-search-results` does for several indexes (merge-search-results.go:142-194).
+ * rows[r] / nrows[r]: the rows of rank r, grouped by query in batch order (as lm_result_rows returns them).  Host-only;
+ * idx (may be NULL) re-attaches genome_id / seq_id: every shard holds the names of all genomes.  cigar/qseq/sseq/align
+ * are process-local and come back NULL.  Free with lm_result_free. */
+lm_status lm_merge_sharded(lm_index *idx, const lm_hsp *const *rows, const size_t *nrows, int nshards, lm_result **out);
+
+/* -n/--top-n-genomes with a sharded index: the cut of lib-index-search.go:1781-1805 is over the genomes of ALL shards.
+ *   1. every rank: lm_search_scores -> its candidates, per query at most top_n (query, genome, Chainer score)
+ *   2. host: gather the candidates of all ranks; lm_topn_merge -> the global top-N per query (score descending, ties by
+ *      genome key ascending: the total order this build uses where the reference's unstable sort leaves ties open)
+ *   3. every rank: lm_search_resident_keep with that list instead of its local cut.
+ * Unsharded indexes do the cut inside lm_search_resident. lm_topn_merge output arrays are released with lm_free. */
+lm_status lm_search_scores(lm_index *idx, lm_qbatch *qb, lm_stage **out, size_t *n, const uint32_t **query,
+                           const uint64_t **batch_genome, const float **score);
+lm_status lm_topn_merge(int nshards, const uint32_t *const *query, const uint64_t *const *batch_genome,
+                        const float *const *score, const size_t *n, int top_n, uint32_t **out_query,
+                        uint64_t **out_batch_genome, size_t *out_n);
+lm_status lm_search_resident_keep(lm_index *idx, lm_qbatch *qb, const uint32_t *keep_query, const uint64_t *keep_batch_genome,
+                                  size_t nkeep, lm_result **out);
+void lm_free(void *p);
+
+/* Genome whitelist: the `genomeIds` argument of (*Index).Search (lib-index-search.go:1191,1396,1425-1489) - seeds of other
+ * genomes are ignored when anchors are assembled.  The reference derives the same kind of per-genome keep flag from
+ * taxids (-t/--taxids, LCA tests against taxdump: host-side, cached per genome): the host evaluates those and passes the
+ * resulting genome keys here.  keys = batch<<17|index (genomes.map.bin); n = 0 clears the filter.  Applies to the calls
+ * that follow on this handle. */
+lm_status lm_index_set_genome_filter(lm_index *idx, const uint64_t *batch_genome_keys, size_t n);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Stage-level entry points (inner seams) used by the parity tests. All outputs are host arrays owned
  * by the returned lm_stage object. */

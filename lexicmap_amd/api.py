@@ -137,6 +137,15 @@ def lib():
     L.lm_wfa_batch.argtypes = [vp, C.POINTER(Query), C.POINTER(Query), C.c_size_t, C.POINTER(vp),
                                C.POINTER(C.POINTER(Wfa)), C.POINTER(C.POINTER(C.c_uint64))]
     L.lm_index_build_synthetic.argtypes = [C.POINTER(SynthSpec), C.POINTER(Options), C.c_int, C.POINTER(vp)]
+    L.lm_merge_sharded.argtypes = [vp, C.POINTER(C.POINTER(Hsp)), C.POINTER(C.c_size_t), C.c_int, C.POINTER(vp)]
+    L.lm_search_scores.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.POINTER(C.c_uint32)),
+                                   C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.POINTER(C.c_float))]
+    L.lm_topn_merge.argtypes = [C.c_int, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint64)),
+                                C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t), C.c_int,
+                                C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_size_t)]
+    L.lm_search_resident_keep.argtypes = [vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(vp)]
+    L.lm_free.argtypes = [vp]
+    L.lm_index_set_genome_filter.argtypes = [vp, C.POINTER(C.c_uint64), C.c_size_t]
     L.lm_index_mask_seeds.argtypes = [vp, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_size_t,
                                       C.POINTER(C.c_size_t)]
     L.lm_index_fetch.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64, C.c_char_p]
@@ -274,6 +283,44 @@ class Index:
             arr = np.zeros(0, dtype=ROW_DTYPE)
             L.lm_result_free(res)
         return arr, {f[0]: getattr(stats, f[0]) for f in StageStats._fields_}
+
+    def set_genome_filter(self, keys):
+        """genome whitelist (batch<<17|index keys) for the searches that follow; empty / None clears it"""
+        keys = list(keys or [])
+        arr = (C.c_uint64 * max(len(keys), 1))(*keys)
+        st = lib().lm_index_set_genome_filter(self.h, arr, len(keys))
+        if st != 0:
+            self._err(st)
+
+    def search_scores(self, qb):
+        """(query, batch_genome, score) numpy arrays: this shard's candidates for the -n cut"""
+        import numpy as np
+        L = lib()
+        sg, n = C.c_void_p(), C.c_size_t()
+        q, g, s = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint64)(), C.POINTER(C.c_float)()
+        st = L.lm_search_scores(self.h, qb, C.byref(sg), C.byref(n), C.byref(q), C.byref(g), C.byref(s))
+        if st != 0:
+            self._err(st)
+        k = n.value
+        out = (np.ctypeslib.as_array(q, shape=(k,)).copy() if k else np.zeros(0, np.uint32),
+               np.ctypeslib.as_array(g, shape=(k,)).copy() if k else np.zeros(0, np.uint64),
+               np.ctypeslib.as_array(s, shape=(k,)).copy() if k else np.zeros(0, np.float32))
+        L.lm_stage_free(sg)
+        return out
+
+    def search_resident_keep(self, qb, keep_query, keep_bg):
+        import numpy as np
+        L = lib()
+        kq = np.ascontiguousarray(keep_query, dtype=np.uint32)
+        kg = np.ascontiguousarray(keep_bg, dtype=np.uint64)
+        res = C.c_void_p()
+        st = L.lm_search_resident_keep(self.h, qb, kq.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                       kg.ctypes.data_as(C.POINTER(C.c_uint64)), len(kq), C.byref(res))
+        if st != 0:
+            self._err(st)
+        out = self._collect(res)
+        L.lm_result_free(res)
+        return out
 
     def _collect(self, res, want_rows=True):
         L = lib()

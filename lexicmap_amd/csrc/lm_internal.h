@@ -140,7 +140,7 @@ struct lm_index {
     std::string err;
     // HBM image
     DBuf<uint64_t> d_masks, d_pk_keys, d_pk_vals, d_out_kmers, d_out_vals, d_g_bg;
-    DBuf<uint32_t> d_part_tab;
+    DBuf<uint32_t> d_part_tab, d_g_keep;
     DBuf<int32_t> d_pfx_first, d_g_len;
     DBuf<int64_t> d_md_off, d_out_off, d_g_off, d_batch_first;
     int64_t n_seeds = 0, n_seeds_outlier = 0, seed_bytes = 0; // resident seeds; bytes of the whole seed image

@@ -22,6 +22,7 @@ struct DevIndexView {
     const uint32_t *part_tab;   // [2M][P1] first seed of each partition, relative to md_off[md]; [P1-1] = list length
     const int64_t *md_off;      // [2M+1] first seed of each list
     const uint64_t *g_bg;       // [G] batch:17|genome:17 key of each local genome (genomes.map.bin key)
+    const uint32_t *g_keep;     // genome whitelist: bit per local genome, or null (lib-index-search.go:1425-1489)
     // seeds whose k-mer does not start with its mask's p-base prefix (captures of genomes that lack the prefix:
     // tiny genomes only) keep the reference's flat form, per list sorted by (k-mer, value)
     const uint64_t *out_kmers;  // [No]

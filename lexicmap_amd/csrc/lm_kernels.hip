@@ -171,6 +171,21 @@ __device__ __forceinline__ int argmin_mask(const uint64_t *masks, const int32_t 
 // and partitions, and logical workgroups are laid out so that a contiguous eighth of the sorted lookups runs on one
 // XCD (each XCD has its own L2), see lookup_index().
 #define LM_LK_OUTLIER_BIT 31
+__device__ __forceinline__ int local_genome(const DevIndexView &ix, uint64_t bg) {
+    uint64_t batch = bg >> 17, gi = bg & 0x1ffff;
+    if (batch >= (uint64_t)ix.nbatches) return -1;
+    int64_t g = ix.batch_first[batch] + (int64_t)gi;
+    if (ix.shard_count > 1) {
+        if ((int)(g % ix.shard_count) != ix.shard_rank) return -1;
+        g /= ix.shard_count;
+    }
+    if (g >= ix.ngenomes) return -1;
+    return (int)g;
+}
+
+__device__ __forceinline__ bool genome_kept(const DevIndexView &ix, int64_t g) {
+    return g >= 0 && ((ix.g_keep[g >> 5] >> (g & 31)) & 1u) != 0;
+}
 __device__ __forceinline__ uint32_t lookup_sort_key(const DevIndexView &ix, uint32_t md, uint64_t x) {
     const int p = ix.mask_prefix;
     const uint64_t mp = ix.masks[md >> 1] >> ((ix.K - p) << 1);
@@ -283,7 +298,7 @@ __global__ __launch_bounds__(256) void k_lookup_count(DevIndexView ix, const uin
     uint64_t left, right;
     lookup_range(key, ix.K, min_prefix, &left, &right);
     int64_t st;
-    int32_t nv = 0;
+    int32_t nv = 0, nkept = 0;
     if (!(sk >> LM_LK_OUTLIER_BIT)) {
         const int pb = ix.part_bases << 1;
         const uint32_t md = sk >> pb, part = sk & ((1u << pb) - 1);
@@ -291,6 +306,14 @@ __global__ __launch_bounds__(256) void k_lookup_count(DevIndexView ix, const uin
         const int64_t base = ix.md_off[md];
         const uint64_t km = (1ull << ix.key_bits) - 1;
         nv = lm_partition_range(ix.pk_keys, ix.key_bits, base + row[0], base + row[1], left & km, right & km, &st);
+        if (ix.g_keep && nv) { // genome whitelist: count the kept seeds only (the emit pass skips the others)
+            int32_t kept = 0;
+            for (int32_t x = 0; x < nv; x++)
+                kept += genome_kept(ix, (int64_t)lm_packed_val_genome(lm_bits_get(ix.pk_vals, st + x, ix.gid_bits + ix.pos_bits + 1), ix.pos_bits));
+            nkept = kept;
+        } else {
+            nkept = nv;
+        }
     } else {
         const uint32_t md = sk & 0x7fffffffu;
         int64_t lo = ix.out_off[md], hi = ix.out_off[md + 1];
@@ -305,11 +328,16 @@ __global__ __launch_bounds__(256) void k_lookup_count(DevIndexView ix, const uin
         st = lo;
         while (lo < e && ix.out_kmers[lo] <= right) lo++;
         nv = (int32_t)(lo - st);
+        nkept = nv;
+        if (ix.g_keep && nv) {
+            nkept = 0;
+            for (int32_t x = 0; x < nv; x++) nkept += genome_kept(ix, local_genome(ix, ix.out_vals[st + x] >> 30));
+        }
     }
-    counts[j] = (uint32_t)nv * (uint32_t)(khi[qm] - klo[qm]);
+    counts[j] = (uint32_t)nkept * (uint32_t)(khi[qm] - klo[qm]);
     starts[j] = st;
     nscan[j] = nv;
-    if (nv) atomicAdd(stat_values, (unsigned long long)nv);
+    if (nkept) atomicAdd(stat_values, (unsigned long long)nkept);
 }
 
 __global__ __launch_bounds__(256) void k_lookup_emit(DevIndexView ix, const uint64_t *__restrict__ kmers,
@@ -342,9 +370,11 @@ __global__ __launch_bounds__(256) void k_lookup_emit(DevIndexView ix, const uint
             const uint64_t d = sr ^ (key & km);
             kprefix = fixed + (d ? ((lm_clz64(d) - (64 - ix.key_bits)) >> 1) : (ix.key_bits >> 1));
             const uint64_t pv = lm_bits_get(ix.pk_vals, b + s, ix.gid_bits + ix.pos_bits + 1);
+            if (ix.g_keep && !genome_kept(ix, (int64_t)lm_packed_val_genome(pv, ix.pos_bits))) continue;
             v = lm_unpack_seed_val(pv, ix.g_bg[lm_packed_val_genome(pv, ix.pos_bits)], ix.pos_bits, dir);
         } else {
             v = ix.out_vals[b + s];
+            if (ix.g_keep && !genome_kept(ix, local_genome(ix, v >> 30))) continue;
             kprefix = lm_lcp(key, ix.out_kmers[b + s], ix.K);
         }
         const uint64_t A = (q << 34) | (v >> 30);
@@ -384,18 +414,6 @@ __global__ void k_chain1(const uint64_t *__restrict__ B, const int64_t *__restri
 
 // ------------------------------------------------------------------------------------------------------------
 // chain windows (lib-index-search.go:1966-2051)
-__device__ __forceinline__ int local_genome(const DevIndexView &ix, uint64_t bg) {
-    uint64_t batch = bg >> 17, gi = bg & 0x1ffff;
-    if (batch >= (uint64_t)ix.nbatches) return -1;
-    int64_t g = ix.batch_first[batch] + (int64_t)gi;
-    if (ix.shard_count > 1) {
-        if ((int)(g % ix.shard_count) != ix.shard_rank) return -1;
-        g /= ix.shard_count;
-    }
-    if (g >= ix.ngenomes) return -1;
-    return (int)g;
-}
-
 __global__ void k_task_count(const float *__restrict__ seg_score, const int32_t *__restrict__ seg_nch,
                              const uint8_t *__restrict__ keep, int nseg, float min_score, int32_t *__restrict__ ntask) {
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += gridDim.x * blockDim.x)
@@ -1813,7 +1831,8 @@ template <int NC> struct SlotMask { // one bit per LDS slot / per diagonal offse
     unsigned long long w[NC];
 };
 template <int NC> __device__ __forceinline__ SlotMask<NC> sm_rotr(SlotMask<NC> m, int r) {
-    // bit j of the result = bit (j + r) mod W of m
+    // bit j of the result = bit (j + r) mod W of m.  Static indices only: an array indexed by a run-time value would be
+    // put in scratch memory, in the middle of the score loop.
     SlotMask<NC> o;
     if (NC == 1) {
         o.w[0] = rotr64(m.w[0], r);
@@ -1822,8 +1841,16 @@ template <int NC> __device__ __forceinline__ SlotMask<NC> sm_rotr(SlotMask<NC> m
     r &= 64 * NC - 1;
     const int ws = r >> 6, bs = r & 63;
 #pragma unroll
+    for (int step = 1; step < NC; step <<= 1) { // whole words: log2(NC) conditional rotations by 1, 2, 4 words
+        const unsigned long long pick = (ws & step) ? ~0ull : 0ull; // masks, not selects of array elements (see above)
+        SlotMask<NC> t;
+#pragma unroll
+        for (int i = 0; i < NC; i++) t.w[i] = (m.w[i] & ~pick) | (m.w[(i + step) & (NC - 1)] & pick);
+        m = t;
+    }
+#pragma unroll
     for (int i = 0; i < NC; i++) {
-        const unsigned long long a = m.w[(i + ws) & (NC - 1)], b = m.w[(i + ws + 1) & (NC - 1)];
+        const unsigned long long a = m.w[i], b = m.w[(i + 1) & (NC - 1)];
         o.w[i] = bs ? ((a >> bs) | (b << (64 - bs))) : a;
     }
     return o;
@@ -1866,7 +1893,7 @@ template <int NC> __device__ __forceinline__ SlotMask<NC> sm_from(SlotMask<NC> m
 }
 
 template <int NC>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 2 ? 7 : (NC == 4 ? 4 : 2), NC == 2 ? 7 : (NC == 4 ? 4 : 2)))) void k_wfa_lean(const WfaIn *__restrict__ in, int64_t n, const int32_t *__restrict__ todo,
+__global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, int64_t n, const int32_t *__restrict__ todo,
                                                   int64_t ntodo, int32_t *__restrict__ hdr_pool, int64_t hdr_stride,
                                                   uint8_t *__restrict__ arena_pool, int64_t arena_stride,
                                                   uint64_t *__restrict__ ops_pool, unsigned int *__restrict__ queue,
@@ -2030,7 +2057,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 2 ? 7 
                     if (NC == 2 && a0 != a1) {
                         // the whole wavefront sits in one 64-slot chunk, unwrapped: plain 64-bit masks
                         const int sh = ((mlo[0] + koff) & (W - 1)) & 63;
-                        const unsigned long long k64 = (a1 ? kb.w[NC - 1] : kb.w[0]) >> sh; // bit j <-> diagonal mlo+j
+                        // (select by mask, not `a1 ? w[1] : w[0]`: that becomes a run-time index into the array = scratch memory)
+                        const unsigned long long pick = a1 ? ~0ull : 0ull;
+                        const unsigned long long k64 = ((kb.w[0] & ~pick) | (kb.w[NC - 1] & pick)) >> sh; // bit j <-> diagonal mlo+j
                         if (mlo[0] < top) {
                             const unsigned long long mk = k64 & ((1ull << (top - mlo[0])) - 1ull);
                             nlo = mk ? mlo[0] + (__ffsll((long long)mk) - 1) : top;
@@ -2188,9 +2217,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC == 2 ? 7 
             const bool t0 = NC == 2 && chunk_has(0, lo, hi), t1 = NC == 2 && chunk_has(NC - 1, lo, hi);
             if (NC == 2 && t0 != t1) { // the new wavefront sits in one chunk, unwrapped: 64-bit masks, plain shift
                 const int sh = ((lo + koff) & (W - 1)) & 63;
-                const unsigned long long m64 = (t1 ? bm.w[NC - 1] : bm.w[0]) >> sh;
-                const unsigned long long i64 = (t1 ? bi.w[NC - 1] : bi.w[0]) >> sh;
-                const unsigned long long d64 = (t1 ? bd.w[NC - 1] : bd.w[0]) >> sh;
+                const unsigned long long pick = t1 ? ~0ull : 0ull; // see above: no run-time array index
+                const unsigned long long m64 = ((bm.w[0] & ~pick) | (bm.w[NC - 1] & pick)) >> sh;
+                const unsigned long long i64 = ((bi.w[0] & ~pick) | (bi.w[NC - 1] & pick)) >> sh;
+                const unsigned long long d64 = ((bd.w[0] & ~pick) | (bd.w[NC - 1] & pick)) >> sh;
                 mlo[0] = m64 ? lo + (__ffsll((long long)m64) - 1) : E_LO;
                 mhi[0] = m64 ? lo + (63 - __clzll((long long)m64)) : E_HI;
                 ilo[0] = i64 ? lo + (__ffsll((long long)i64) - 1) : E_LO;

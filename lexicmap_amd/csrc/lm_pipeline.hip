@@ -343,6 +343,8 @@ struct lm_result {
 };
 
 struct lm_stage {
+    std::vector<uint32_t> u32a;
+    std::vector<float> f32a;
     std::vector<uint64_t> u64a, u64b;
     std::vector<int64_t> i64a, i64b;
     std::vector<int32_t> i32a, i32b;
@@ -2000,7 +2002,16 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
     }
 }
 
-static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
+// what a search pass is asked to do besides the plain search: report the per-(query, genome) chaining scores and stop
+// (lm_search_scores), or replace the local -n cut by a list of (query, genome) pairs to keep (lm_search_resident_keep)
+struct SearchCtl {
+    std::vector<uint32_t> *sc_query = nullptr;
+    std::vector<uint64_t> *sc_bg = nullptr;
+    std::vector<float> *sc_score = nullptr;
+    const std::unordered_map<uint64_t, std::vector<uint32_t>> *keep = nullptr; // genome key -> sorted batch query numbers
+};
+
+static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res, const SearchCtl *ctl = nullptr) {
     std::lock_guard<std::mutex> lock(ix->mu);
     tune_malloc_once();
     lm_stage_stats &st = res->stats;
@@ -2040,7 +2051,7 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
         HIPCHK(hipMemsetAsync(w.stat.p + 1, 0, sizeof(unsigned long long), S(ix)));
         launch_sum_i32(S(ix), w.seg_n.p, nseg, w.stat.p + 1);
         HIPCHK(hipMemcpyAsync(&hv, w.stat.p + 1, sizeof hv, hipMemcpyDeviceToHost, S(ix)));
-        if (ix->opt.top_n_genomes > 0) { // only the top-N selection needs the per-pair scores on the host
+        if (ix->opt.top_n_genomes > 0 || ctl) { // only the top-N selection needs the per-pair scores on the host
             d2h(ix, segA_h, w.segA.p, (size_t)nseg);
             d2h(ix, score_h, w.seg_score.p, (size_t)nseg);
         }
@@ -2049,7 +2060,18 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
     }
     const float min_score = chain_opt(ix).min_score;
     const uint8_t *keep_d = nullptr;
-    if (ix->opt.top_n_genomes > 0) {
+    if (ctl && ctl->keep) { // the caller's (query, genome) list replaces the local cut
+        std::vector<uint8_t> keep(nseg, 0);
+        for (int i = 0; i < nseg; i++) {
+            auto it = ctl->keep->find(segA_h[i] & ((1ull << 34) - 1));
+            if (it == ctl->keep->end()) continue;
+            const uint32_t q = (uint32_t)(segA_h[i] >> 34) + qb->q0;
+            keep[i] = std::binary_search(it->second.begin(), it->second.end(), q) ? 1 : 0;
+        }
+        w.keep.ensure(nseg);
+        HIPCHK(hipMemcpyAsync(w.keep.p, keep.data(), nseg, hipMemcpyHostToDevice, S(ix)));
+        keep_d = w.keep.p;
+    } else if (ix->opt.top_n_genomes > 0 || (ctl && ctl->sc_query)) {
         std::vector<uint8_t> keep(nseg, 0);
         int s = 0;
         while (s < nseg) {
@@ -2060,8 +2082,20 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res) {
             for (int i = s; i < e; i++)
                 if (score_h[i] >= min_score) cand.push_back(i);
             std::stable_sort(cand.begin(), cand.end(), [&](int x, int y) { return score_h[x] > score_h[y]; });
-            for (size_t i = 0; i < cand.size() && (int)i < ix->opt.top_n_genomes; i++) keep[cand[i]] = 1;
+            const size_t lim = ix->opt.top_n_genomes > 0 ? (size_t)ix->opt.top_n_genomes : cand.size();
+            for (size_t i = 0; i < cand.size() && i < lim; i++) {
+                keep[cand[i]] = 1;
+                if (ctl && ctl->sc_query) { // report only
+                    ctl->sc_query->push_back((uint32_t)(segA_h[cand[i]] >> 34) + qb->q0);
+                    ctl->sc_bg->push_back(segA_h[cand[i]] & ((1ull << 34) - 1));
+                    ctl->sc_score->push_back(score_h[cand[i]]);
+                }
+            }
             s = e;
+        }
+        if (ctl && ctl->sc_query) {
+            st.ms_total = st.ms_mask + st.ms_lookup;
+            return;
         }
         w.keep.ensure(nseg);
         HIPCHK(hipMemcpyAsync(w.keep.p, keep.data(), nseg, hipMemcpyHostToDevice, S(ix)));
@@ -2249,44 +2283,47 @@ static void split_part(lm_index *ix, lm_qbatch *top, size_t pi, bool whole) {
 
 extern "C" {
 
+// all parts of the caller's batch, in order; a part whose seed anchors outgrow the device is halved in place (the split
+// stays in the batch handle, so the next search of the same resident batch does not repeat it)
+static void search_parts(lm_index *ix, lm_qbatch *qb, lm_result *res, const SearchCtl *ctl) {
+    if (qb->parts.empty()) {
+        try {
+            search_impl(ix, qb, res, ctl);
+            return;
+        } catch (const PartTooLarge &) {
+            split_part(ix, qb, 0, true);
+        }
+    }
+    memset(&res->stats, 0, sizeof res->stats);
+    for (size_t pi = 0; pi < qb->parts.size();) {
+        lm_qbatch *part = qb->parts[pi];
+        lm_result pr;
+        try {
+            search_impl(ix, part, &pr, ctl);
+        } catch (const PartTooLarge &) {
+            split_part(ix, qb, pi, false);
+            continue;
+        }
+        for (auto &r : pr.rows) r.query += part->q0;
+        res->rows.insert(res->rows.end(), pr.rows.begin(), pr.rows.end());
+        res->strings.insert(res->strings.end(), pr.strings.begin(), pr.strings.end());
+        pr.strings.clear();
+        const int64_t *a = &pr.stats.query_bases;
+        int64_t *b = &res->stats.query_bases;
+        for (int i = 0; i < 14; i++) b[i] += a[i]; // the int64 counters of lm_stage_stats
+        const double *c = &pr.stats.ms_mask;
+        double *d = &res->stats.ms_mask;
+        for (int i = 0; i < 9; i++) d[i] += c[i];
+        pi++;
+    }
+}
+
 lm_status lm_search_resident(lm_index *ix, lm_qbatch *qb, lm_result **out) {
     *out = nullptr;
     if (!ix || !qb) return LM_ERR_ARG;
     lm_result *res = new lm_result();
     try {
-        // parts of the caller's batch, in order; a part whose seed anchors outgrow the device is halved in place (the split
-        // stays in the batch handle, so the next search of the same resident batch does not repeat it)
-        if (qb->parts.empty()) {
-            try {
-                search_impl(ix, qb, res);
-            } catch (const PartTooLarge &) {
-                split_part(ix, qb, 0, true);
-            }
-        }
-        if (!qb->parts.empty()) {
-            memset(&res->stats, 0, sizeof res->stats);
-            for (size_t pi = 0; pi < qb->parts.size();) {
-                lm_qbatch *part = qb->parts[pi];
-                lm_result pr;
-                try {
-                    search_impl(ix, part, &pr);
-                } catch (const PartTooLarge &) {
-                    split_part(ix, qb, pi, false);
-                    continue;
-                }
-                for (auto &r : pr.rows) r.query += part->q0;
-                res->rows.insert(res->rows.end(), pr.rows.begin(), pr.rows.end());
-                res->strings.insert(res->strings.end(), pr.strings.begin(), pr.strings.end());
-                pr.strings.clear();
-                const int64_t *a = &pr.stats.query_bases;
-                int64_t *b = &res->stats.query_bases;
-                for (int i = 0; i < 14; i++) b[i] += a[i]; // the int64 counters of lm_stage_stats
-                const double *c = &pr.stats.ms_mask;
-                double *d = &res->stats.ms_mask;
-                for (int i = 0; i < 9; i++) d[i] += c[i];
-                pi++;
-            }
-        }
+        search_parts(ix, qb, res, nullptr);
     } catch (const std::exception &e) {
         ix->err = e.what();
         delete res;
@@ -2294,6 +2331,76 @@ lm_status lm_search_resident(lm_index *ix, lm_qbatch *qb, lm_result **out) {
     }
     *out = res;
     return LM_OK;
+}
+
+lm_status lm_search_scores(lm_index *ix, lm_qbatch *qb, lm_stage **out, size_t *n, const uint32_t **query,
+                           const uint64_t **batch_genome, const float **score) {
+    *out = nullptr;
+    if (!ix || !qb || !n) return LM_ERR_ARG;
+    lm_stage *sg = new lm_stage();
+    try {
+        lm_result tmp;
+        SearchCtl ctl;
+        ctl.sc_query = &sg->u32a;
+        ctl.sc_bg = &sg->u64a;
+        ctl.sc_score = &sg->f32a;
+        search_parts(ix, qb, &tmp, &ctl);
+    } catch (const std::exception &e) {
+        ix->err = e.what();
+        delete sg;
+        return LM_ERR_HIP;
+    }
+    *n = sg->u32a.size();
+    *query = sg->u32a.data();
+    *batch_genome = sg->u64a.data();
+    *score = sg->f32a.data();
+    *out = sg;
+    return LM_OK;
+}
+
+lm_status lm_search_resident_keep(lm_index *ix, lm_qbatch *qb, const uint32_t *keep_query, const uint64_t *keep_bg, size_t nkeep,
+                                  lm_result **out) {
+    *out = nullptr;
+    if (!ix || !qb || (nkeep && (!keep_query || !keep_bg))) return LM_ERR_ARG;
+    lm_result *res = new lm_result();
+    try {
+        std::unordered_map<uint64_t, std::vector<uint32_t>> keep;
+        for (size_t i = 0; i < nkeep; i++) keep[keep_bg[i]].push_back(keep_query[i]);
+        for (auto &kv : keep) std::sort(kv.second.begin(), kv.second.end());
+        SearchCtl ctl;
+        ctl.keep = &keep;
+        search_parts(ix, qb, res, &ctl);
+    } catch (const std::exception &e) {
+        ix->err = e.what();
+        delete res;
+        return LM_ERR_HIP;
+    }
+    *out = res;
+    return LM_OK;
+}
+
+lm_status lm_index_set_genome_filter(lm_index *ix, const uint64_t *keys, size_t n) {
+    if (!ix || (n && !keys)) return LM_ERR_ARG;
+    try {
+        std::lock_guard<std::mutex> lock(ix->mu);
+        HIPCHK(hipSetDevice(ix->device));
+        if (n == 0) {
+            ix->view.g_keep = nullptr;
+            return LM_OK;
+        }
+        std::vector<uint32_t> bits((ix->host.genomes.size() + 31) / 32 + 1, 0);
+        for (size_t i = 0; i < n; i++) {
+            auto it = ix->bg2local.find(keys[i]); // genomes of other shards are not ours to filter
+            if (it != ix->bg2local.end()) bits[(size_t)it->second >> 5] |= 1u << (it->second & 31);
+        }
+        h2d(ix, ix->d_g_keep, bits);
+        sync(ix);
+        ix->view.g_keep = ix->d_g_keep.p;
+        return LM_OK;
+    } catch (const std::exception &e) {
+        ix->err = e.what();
+        return LM_ERR_HIP;
+    }
 }
 
 lm_status lm_search_batch(lm_index *ix, const lm_query *queries, size_t nq, lm_result **out) {
@@ -2565,5 +2672,137 @@ lm_status lm_wfa_batch(lm_index *ix, const lm_query *q, const lm_query *t, size_
     *out = sg;
     return LM_OK;
 }
+
+
+// ---- merging the rows of genome shards ------------------------------------------------------------
+// Host-only: no device work, callable without a GPU (idx may be NULL: names are then left NULL).
+lm_status lm_merge_sharded(lm_index *ix, const lm_hsp *const *rows, const size_t *nrows, int nshards, lm_result **out) {
+    *out = nullptr;
+    if (nshards < 1 || !rows || !nrows) return LM_ERR_ARG;
+    lm_result *res = new lm_result();
+    try {
+        memset(&res->stats, 0, sizeof res->stats);
+        size_t total = 0;
+        for (int r = 0; r < nshards; r++) total += nrows[r];
+        res->rows.reserve(total);
+        std::vector<size_t> pos((size_t)nshards, 0);
+        struct Grp {
+            int rank;
+            size_t b, e;
+            uint64_t bg;
+            double best;
+        };
+        std::vector<Grp> grps;
+        while (true) {
+            // next query = the smallest one any shard still has rows for (rows of a shard are grouped by query, ascending)
+            uint32_t q = 0;
+            bool any = false;
+            for (int r = 0; r < nshards; r++)
+                if (pos[r] < nrows[r] && (!any || rows[r][pos[r]].query < q)) {
+                    q = rows[r][pos[r]].query;
+                    any = true;
+                }
+            if (!any) break;
+            grps.clear();
+            for (int r = 0; r < nshards; r++) {
+                size_t i = pos[r];
+                while (i < nrows[r] && rows[r][i].query == q) {
+                    Grp g{r, i, i, rows[r][i].batch_genome, 0.0};
+                    while (g.e < nrows[r] && rows[r][g.e].query == q && rows[r][g.e].batch_genome == g.bg) {
+                        const double sim = (double)rows[r][g.e].bitscore * rows[r][g.e].pident; // SimilarityScore (:2352,2621)
+                        if (sim > g.best) g.best = sim;
+                        g.e++;
+                    }
+                    grps.push_back(g);
+                    i = g.e;
+                }
+                pos[r] = i;
+            }
+            // genomes by the similarity of their best HSP cluster, descending (lib-index-search.go:2919-2921), ties by key
+            std::stable_sort(grps.begin(), grps.end(), [](const Grp &x, const Grp &y) {
+                if (x.best != y.best) return x.best > y.best;
+                return x.bg < y.bg;
+            });
+            for (const Grp &g : grps)
+                for (size_t i = g.b; i < g.e; i++) {
+                    lm_hsp h = rows[g.rank][i];
+                    h.hits = (uint32_t)grps.size(); // search.go:463,494: subject genomes of the query, over all shards
+                    h.genome_id = h.seq_id = nullptr;
+                    h.cigar = h.qseq = h.sseq = h.align = nullptr; // process-local addresses of another rank
+                    if (ix) {
+                        const HostIndex &H = ix->host;
+                        auto it = ix->bg2local.find(h.batch_genome);
+                        const HostGenome *G = nullptr;
+                        if (it != ix->bg2local.end()) {
+                            G = &H.genomes[it->second];
+                        } else {
+                            auto io = H.other_of.find(h.batch_genome);
+                            if (io != H.other_of.end()) G = &H.others[io->second];
+                        }
+                        if (G) {
+                            h.genome_id = G->id.c_str();
+                            if (h.seq_idx >= 0 && h.seq_idx < (int)G->seq_ids.size()) h.seq_id = G->seq_ids[h.seq_idx].c_str();
+                        } else if (H.synthetic) { // names of the synthetic set are a function of the genome number
+                            const long long g = (long long)((h.batch_genome >> 17) * 5000 + (h.batch_genome & 0x1ffff));
+                            char nm[64];
+                            snprintf(nm, sizeof nm, "SYN_%09lld.1", g);
+                            res->strings.push_back(new std::string(nm));
+                            h.genome_id = res->strings.back()->c_str();
+                            snprintf(nm, sizeof nm, "syn%09lld_c1", g);
+                            res->strings.push_back(new std::string(nm));
+                            h.seq_id = res->strings.back()->c_str();
+                        }
+                    }
+                    res->rows.push_back(h);
+                }
+        }
+        res->stats.rows = (int64_t)res->rows.size();
+    } catch (const std::exception &e) {
+        if (ix) ix->err = e.what();
+        delete res;
+        return LM_ERR_NOMEM;
+    }
+    *out = res;
+    return LM_OK;
+}
+
+// -n/--top-n-genomes over genome shards: the cut of lib-index-search.go:1781-1805 needs the chaining scores of ALL shards.
+// Every shard reports its candidates (lm_search_scores: per query its own top-N (query, genome, score)), the host gathers
+// them, lm_topn_merge picks the global top-N per query by (score desc, genome key asc), and every shard then searches
+// with that keep list (lm_search_resident_keep).
+lm_status lm_topn_merge(int nshards, const uint32_t *const *query, const uint64_t *const *bg, const float *const *score,
+                        const size_t *n, int top_n, uint32_t **out_query, uint64_t **out_bg, size_t *out_n) {
+    if (nshards < 1 || top_n < 1 || !out_query || !out_bg || !out_n) return LM_ERR_ARG;
+    struct C {
+        uint32_t q;
+        uint64_t bg;
+        float s;
+    };
+    std::vector<C> all;
+    for (int r = 0; r < nshards; r++)
+        for (size_t i = 0; i < n[r]; i++) all.push_back({query[r][i], bg[r][i], score[r][i]});
+    std::stable_sort(all.begin(), all.end(), [](const C &x, const C &y) {
+        if (x.q != y.q) return x.q < y.q;
+        if (x.s != y.s) return x.s > y.s;
+        return x.bg < y.bg;
+    });
+    std::vector<C> keep;
+    for (size_t i = 0; i < all.size();) {
+        size_t e = i;
+        while (e < all.size() && all[e].q == all[i].q) e++;
+        for (size_t j = i; j < e && j < i + (size_t)top_n; j++) keep.push_back(all[j]);
+        i = e;
+    }
+    *out_n = keep.size();
+    *out_query = (uint32_t *)malloc(sizeof(uint32_t) * std::max<size_t>(keep.size(), 1));
+    *out_bg = (uint64_t *)malloc(sizeof(uint64_t) * std::max<size_t>(keep.size(), 1));
+    if (!*out_query || !*out_bg) return LM_ERR_NOMEM;
+    for (size_t i = 0; i < keep.size(); i++) {
+        (*out_query)[i] = keep[i].q;
+        (*out_bg)[i] = keep[i].bg;
+    }
+    return LM_OK;
+}
+void lm_free(void *p) { free(p); }
 
 } // extern "C"

@@ -117,3 +117,56 @@ def merge_query_sharded(per_rank):
     """query-sharded ranks: rows are already final per query and grouped per query; the order across queries is
     arrival order in the reference (search.go:47), here rank order"""
     return _cat(per_rank)
+
+
+def merge_sharded_c(per_rank, index=None):
+    """the same merge through the library's C entry point lm_merge_sharded (what a Go host calls); `index` (an
+    lexicmap_amd.Index or None) re-attaches genome / sequence names. Returns a fresh row array."""
+    import ctypes as C
+    from .api import Hsp, lib
+    L = lib()
+    arrs = [np.ascontiguousarray(p, dtype=ROW_DTYPE) for p in per_rank]
+    n = len(arrs)
+    ptrs = (C.POINTER(Hsp) * n)(*[a.ctypes.data_as(C.POINTER(Hsp)) for a in arrs])
+    cnts = (C.c_size_t * n)(*[len(a) for a in arrs])
+    res = C.c_void_p()
+    st = L.lm_merge_sharded(index.h if index is not None else None, ptrs, cnts, n, C.byref(res))
+    if st != 0:
+        raise RuntimeError("lm_merge_sharded failed (%d)" % st)
+    rows_p = C.POINTER(Hsp)()
+    k = L.lm_result_rows(res, C.byref(rows_p))
+    out = np.zeros(k, dtype=ROW_DTYPE)
+    if k:
+        C.memmove(out.ctypes.data, rows_p, k * C.sizeof(Hsp))
+    names = None
+    if index is not None and k:
+        names = [(rows_p[i].genome_id, rows_p[i].seq_id) for i in range(k)]
+    L.lm_result_free(res)
+    for f in ("genome_id", "seq_id", "cigar", "qseq", "sseq", "align"):
+        out[f] = 0
+    return (out, names) if index is not None else out
+
+
+def topn_merge(cands, top_n):
+    """cands: per shard (query u32, batch_genome u64, score f32) arrays -> (keep_query, keep_bg) of the global top-N"""
+    import ctypes as C
+    from .api import lib
+    L = lib()
+    n = len(cands)
+    qs = [np.ascontiguousarray(c[0], dtype=np.uint32) for c in cands]
+    gs = [np.ascontiguousarray(c[1], dtype=np.uint64) for c in cands]
+    ss = [np.ascontiguousarray(c[2], dtype=np.float32) for c in cands]
+    pq = (C.POINTER(C.c_uint32) * n)(*[a.ctypes.data_as(C.POINTER(C.c_uint32)) for a in qs])
+    pg = (C.POINTER(C.c_uint64) * n)(*[a.ctypes.data_as(C.POINTER(C.c_uint64)) for a in gs])
+    ps = (C.POINTER(C.c_float) * n)(*[a.ctypes.data_as(C.POINTER(C.c_float)) for a in ss])
+    cn = (C.c_size_t * n)(*[len(a) for a in qs])
+    oq, og, on = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint64)(), C.c_size_t()
+    st = L.lm_topn_merge(n, pq, pg, ps, cn, top_n, C.byref(oq), C.byref(og), C.byref(on))
+    if st != 0:
+        raise RuntimeError("lm_topn_merge failed (%d)" % st)
+    k = on.value
+    kq = np.ctypeslib.as_array(oq, shape=(k,)).copy() if k else np.zeros(0, np.uint32)
+    kg = np.ctypeslib.as_array(og, shape=(k,)).copy() if k else np.zeros(0, np.uint64)
+    L.lm_free(oq)
+    L.lm_free(og)
+    return kq, kg

@@ -397,6 +397,97 @@ def test_sharded_index_union_equals_whole(small_index, queries):
             assert x[f] == y[f]
 
 
+def test_sharded_rows_through_the_c_merge_equal_the_unsharded_output(small_index, queries):
+    """§8e / boundary: the per-shard row lists of two genome shards go through lm_merge_sharded (what a Go host calls
+    after its all-gatherv) and come out as the unsharded index prints them: same rows, same ORDER, same `hits`, and the
+    genome / sequence names re-attached on a rank that does not hold the genome"""
+    la = _la()
+    from lexicmap_amd import merge
+    d, _ = small_index
+    whole = la.Index(d)
+    tb = whole.info()["total_bases"]
+    seqs = [q[1] for q in queries[:14]]
+    rows_w, _ = whole.search(seqs)
+    whole.close()
+    shards = [la.Index(d, la.api.default_options(shard_rank=r, shard_count=2, total_bases_override=tb)) for r in range(2)]
+    per_rank = []
+    for si in shards:
+        qb = si.upload(seqs)
+        arr, _ = si.search_resident_np(qb)
+        per_rank.append(arr.copy())
+        si.free_batch(qb)
+    merged, names = merge.merge_sharded_c(per_rank, shards[0])   # rank 0 merges: it holds only the even genomes
+    ref = merge.merge_sharded(per_rank)                          # the numpy statement of the same rule
+    for si in shards:
+        si.close()
+    assert len(merged) == len(rows_w) > 50
+    for i, w in enumerate(rows_w):
+        for f in ROW_INT + ROW_F64 + ["evalue", "hits", "query"]:
+            assert merged[f][i] == w[f], (i, f)
+        assert names[i] == (w["genome_id"], w["seq_id"]), i
+    for f in ROW_INT + ROW_F64 + ["hits", "query"]:
+        assert (merged[f] == ref[f]).all(), f
+
+
+def test_top_n_genomes_over_shards_equals_the_unsharded_cut(small_index, queries):
+    """§8e(1): -n/--top-n-genomes with a sharded index = gather of the per-shard chaining scores (lm_search_scores),
+    global cut (lm_topn_merge), search with the keep list (lm_search_resident_keep), merge: the rows of the unsharded
+    index searched with -n"""
+    la = _la()
+    from lexicmap_amd import merge
+    d, _ = small_index
+    N = 3
+    whole = la.Index(d, la.api.default_options(top_n_genomes=N))
+    tb = whole.info()["total_bases"]
+    seqs = [q[1] for q in queries[:14]]
+    rows_w, _ = whole.search(seqs)
+    whole.close()
+    shards = [la.Index(d, la.api.default_options(shard_rank=r, shard_count=2, total_bases_override=tb, top_n_genomes=N))
+              for r in range(2)]
+    qbs = [si.upload(seqs) for si in shards]
+    cands = [si.search_scores(qb) for si, qb in zip(shards, qbs)]
+    assert all(len(c[0]) > 0 for c in cands)
+    kq, kg = merge.topn_merge(cands, N)
+    per_rank = []
+    for si, qb in zip(shards, qbs):
+        rows, _ = si.search_resident_keep(qb, kq, kg)
+        per_rank.append(merge.pack_rows(rows))
+        si.free_batch(qb)
+    merged = merge.merge_sharded_c(per_rank)
+    for si in shards:
+        si.close()
+    assert len(merged) == len(rows_w) > 10
+    for i, w in enumerate(rows_w):
+        for f in ROW_INT + ROW_F64 + ["evalue", "hits", "query"]:
+            assert merged[f][i] == w[f], (i, f)
+
+
+def test_genome_whitelist_filter(small_index, queries):
+    """a5: the `genomeIds` whitelist of (*Index).Search (lib-index-search.go:1191,1425-1489) drops the seeds of other
+    genomes at anchor assembly. Every later stage works per genome, so the filtered rows must be exactly the unfiltered
+    rows of the listed genomes, with `hits` = the number of listed genomes that hit"""
+    la = _la()
+    d, genomes = small_index
+    gi = la.Index(d)
+    seqs = [q[1] for q in queries[:12]]
+    allrows, _ = gi.search(seqs)
+    keep = sorted({r["batch_genome"] for r in allrows})[::2]      # every other genome that hit
+    gi.set_genome_filter(keep)
+    got, st = gi.search(seqs)
+    gi.set_genome_filter(None)
+    again, _ = gi.search(seqs)
+    gi.close()
+    assert again == allrows
+    exp = [dict(r) for r in allrows if r["batch_genome"] in set(keep)]
+    hits = {}
+    for r in exp:
+        hits.setdefault(r["query"], set()).add(r["batch_genome"])
+    for r in exp:
+        r["hits"] = len(hits[r["query"]])
+    assert len(got) == len(exp) > 10
+    assert got == exp
+
+
 def test_errors_fail_loudly(tmp_path):
     la = _la()
     with pytest.raises(RuntimeError):
