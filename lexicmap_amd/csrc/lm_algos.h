@@ -1236,21 +1236,28 @@ LM_HDN bool lm_tree_search_range(const uint64_t *keys, int n, uint64_t key, int 
     return lm_tree_search_miss(keys, n, key, p, K, lo, lo_out, hi_out);
 }
 
-// Prefix filter of the pseudo-alignment (k_build_cmp_bits / k_pa_anchors): a query's bitmap over the hashed 11-base
-// prefixes of its k-mers, 2^log bits.  lm_pa_candidate is a NECESSARY condition for lm_tree_search_range(keys, key, p) to
-// return true (p >= 11): either some query k-mer shares the key's 11-base prefix (normal match, needs >= p >= 11 common
-// bases), or - filter miss, so the longest common prefix L is <= 10 - the partial-prefix rule fires at a node of depth
-// d <= L-1 <= 9, which needs the bases [d, p) and therefore [9, p) of the key to be all A.
+// Prefix filter of the pseudo-alignment (k_build_cmp_bits / k_pa_anchors): per query two bitmaps of 2^log bits each, over
+// the hashed 11-base and 9-base prefixes of its k-mers (the second one right after the first).  lm_pa_candidate is a
+// NECESSARY condition for lm_tree_search_range(keys, key, p) to return true (p >= 11):
+//   * some query k-mer shares the key's 11-base prefix (a normal match needs >= p >= 11 common bases), or
+//   * the 11-base map misses, so the longest common prefix L is <= 10 and only the partial-prefix rule of tree.Search
+//     (tree.go:496-500) can fire: at a node of depth d <= L-1 with the key's bases [d, p) all A.  With a = the number of
+//     A's that end the key's first p bases, d >= p - a.  d <= 9 forces the bases [9, p) to be A (a >= p - 9); then either
+//     a >= p - 7 (bases [7, p) all A: rare, always a candidate) or d >= 8, so L >= 9 and the 9-base map must hit.
 #define LM_PFX_BASES 11
-LM_HD uint32_t lm_pa_filter_slot(uint32_t pfx22, int log) {
-    return log >= 2 * LM_PFX_BASES ? pfx22 : (pfx22 * 0x9E3779B1u) >> (32 - log);
+#define LM_PFX_BASES2 9
+LM_HD uint32_t lm_pa_filter_slot(uint32_t pfx, int log) {
+    return (pfx * 0x9E3779B1u) >> (32 - log);
 }
 LM_HD bool lm_pa_candidate(const uint32_t *bits, int log, uint64_t key, int p, int K) {
     const uint32_t h = lm_pa_filter_slot((uint32_t)(key >> ((K - LM_PFX_BASES) << 1)), log);
     if ((bits[h >> 5] >> (h & 31)) & 1u) return true;
-    const int qfrom = LM_PFX_BASES - 2;
-    const uint64_t tail = (key >> ((K - p) << 1)) & ((1ull << ((p - qfrom) << 1)) - 1ull); // bases [9, p)
-    return tail == 0;
+    const uint64_t first_p = key >> ((K - p) << 1);
+    if (first_p & ((1ull << ((p - 9) << 1)) - 1ull)) return false; // bases [9, p) not all A
+    if ((first_p & ((1ull << ((p - 7) << 1)) - 1ull)) == 0) return true; // bases [7, p) all A
+    const uint32_t h2 = lm_pa_filter_slot((uint32_t)(key >> ((K - LM_PFX_BASES2) << 1)), log);
+    const uint32_t *bits2 = bits + ((uint64_t)1 << (log - 5));
+    return ((bits2[h2 >> 5] >> (h2 & 31)) & 1u) != 0;
 }
 
 // Same, with the two binary searches narrowed by a bucket table over the leading `tab_bits/2` bases:

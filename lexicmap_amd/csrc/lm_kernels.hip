@@ -88,15 +88,13 @@ __global__ void k_build_cmp_tab(const uint64_t *__restrict__ keys_cmp, const int
         tab[t] = (uint32_t)lo;
     }
 }
-// Prefix filter of a query for the pseudo-alignment: a bitmap over the 11-base prefixes of its (filtered) k-mers, the
-// smallest prefix length SeqComparator.Compare ever asks for (lib-seq_compare.go:339-348).  Sized per query, 2^log bits
-// with ~16 bits per k-mer (a 1.5-kb gene: 64 Kbit, a 50-kb read: 2 Mbit; log = 22 is the exact 4^11-bit map), prefixes are
-// hashed into it.  A window k-mer whose 11-base prefix misses the map shares L <= 10 bases with every query k-mer, so it
-// cannot match, and the partial-prefix rule of tree.Search (tree.go:496-500) fires at a node of depth d <= L-1 <= 9 and
-// needs the bases [d, p) of the k-mer to be all A: it can only fire if the bases [9, p) are all A (1/16 of the positions
-// at p = 11, 1/256 at p = 13).  One load decides ~90 % of the window positions (k_pa_anchors).  The earlier exact 8-base map filled
-// up with long reads (a 20-kb read sets 45 % of its 65536 bits).
-__device__ __forceinline__ uint32_t pfx_slot(uint32_t pfx22, int log) { return lm_pa_filter_slot(pfx22, log); }
+// Prefix filter of a query for the pseudo-alignment (lm_pa_candidate, lm_algos.h): two bitmaps of 2^log bits over the
+// hashed 11-base prefixes (the smallest prefix length SeqComparator.Compare ever asks for, lib-seq_compare.go:339-348) and
+// 9-base prefixes of its (filtered) k-mers, sized per query with ~16 bits per k-mer (a 1.5-kb gene: 64 Kbit, a 50-kb read:
+// 2 Mbit).  One load decides ~95 % of the window positions of k_pa_anchors; the 9-base map settles the positions where only
+// the partial-prefix rule of tree.Search could still fire.  The earlier exact 8-base map filled up with long reads (a
+// 20-kb read sets 45 % of its 65536 bits).
+__device__ __forceinline__ uint32_t pfx_slot(uint32_t pfx, int log) { return lm_pa_filter_slot(pfx, log); }
 __global__ __launch_bounds__(256) void k_build_cmp_bits(const uint64_t *__restrict__ keys_cmp,
                                                          const int64_t *__restrict__ posoff,
                                                          const int32_t *__restrict__ nvalid, int nq, int K,
@@ -107,10 +105,12 @@ __global__ __launch_bounds__(256) void k_build_cmp_bits(const uint64_t *__restri
         const uint64_t *keys = keys_cmp + 2 * posoff[q];
         const int n = nvalid[q];
         const int log = bits_log[q];
-        uint32_t *b = bits + bits_off[q];
+        uint32_t *b = bits + bits_off[q], *b2 = b + ((size_t)1 << (log - 5));
         for (int j = threadIdx.x; j < n; j += blockDim.x) {
             const uint32_t h = pfx_slot((uint32_t)(keys[j] >> ((K - LM_PFX_BASES) << 1)), log);
             atomicOr(&b[h >> 5], 1u << (h & 31));
+            const uint32_t h2 = pfx_slot((uint32_t)(keys[j] >> ((K - LM_PFX_BASES2) << 1)), log);
+            atomicOr(&b2[h2 >> 5], 1u << (h2 & 31));
         }
     }
 }
@@ -664,8 +664,6 @@ __global__ __launch_bounds__(256) void k_pa_anchors(DevIndexView ix, const Task 
         const int p = c.m > K ? K : c.m;
         const bool use_bits = c.bits != nullptr && p >= LM_PFX_BASES && K >= LM_PFX_BASES;
         const bool fast_pfx = use_bits && gb != nullptr && p <= 15 && K >= 16;
-        const int qfrom = LM_PFX_BASES - 2; // the partial-prefix rule needs the bases [9, p) to be all A after a filter miss
-        const uint64_t tail_mask = p > qfrom ? ((p - qfrom) >= 32 ? ~0ull : ((1ull << ((p - qfrom) << 1)) - 1ull)) : 0ull;
         if (tid == 0) {
             q_n = 0;
             s_on = 0;
@@ -758,7 +756,7 @@ __global__ __launch_bounds__(256) void k_pa_anchors(DevIndexView ix, const Task 
                 for (int u = 0; u < PA_UNROLL; u++)
 #pragma unroll
                     for (int strand = 0; strand < 2; strand++) {
-                        const uint32_t h = pfx_slot((pf[u][strand] >> (2 * (p - LM_PFX_BASES))) & ((1u << (2 * LM_PFX_BASES)) - 1u), c.bits_log);
+                        const uint32_t h = pfx_slot(pf[u][strand] >> (2 * (p - LM_PFX_BASES)), c.bits_log);
                         word[u][strand] = c.bits[h >> 5];
                     }
 #pragma unroll
@@ -767,8 +765,16 @@ __global__ __launch_bounds__(256) void k_pa_anchors(DevIndexView ix, const Task 
                     if (i >= npos) continue;
 #pragma unroll
                     for (int strand = 0; strand < 2; strand++) {
-                        const uint32_t h = pfx_slot((pf[u][strand] >> (2 * (p - LM_PFX_BASES))) & ((1u << (2 * LM_PFX_BASES)) - 1u), c.bits_log);
-                        const bool cand = ((word[u][strand] >> (h & 31)) & 1u) != 0 || (pf[u][strand] & (uint32_t)tail_mask) == 0;
+                        const uint32_t f = pf[u][strand]; // the first p bases
+                        const uint32_t h = pfx_slot(f >> (2 * (p - LM_PFX_BASES)), c.bits_log);
+                        bool cand = ((word[u][strand] >> (h & 31)) & 1u) != 0;
+                        if (!cand && (f & ((1u << (2 * (p - 9))) - 1u)) == 0) { // lm_pa_candidate: the partial-prefix rule
+                            cand = (f & ((1u << (2 * (p - 7))) - 1u)) == 0;
+                            if (!cand) {
+                                const uint32_t h2 = pfx_slot(f >> (2 * (p - LM_PFX_BASES2)), c.bits_log);
+                                cand = ((c.bits[((size_t)1 << (c.bits_log - 5)) + (h2 >> 5)] >> (h2 & 31)) & 1u) != 0;
+                            }
+                        }
                         if (cand) {
                             const int slot = atomicAdd(&q_n, 1);
                             if (slot < PA_QCAP) q_item[slot] = ((uint32_t)i << 1) | (uint32_t)strand;

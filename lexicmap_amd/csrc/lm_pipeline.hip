@@ -1048,15 +1048,15 @@ static lm_qbatch *upload_part(lm_index *ix, const lm_query *queries, size_t nq, 
         h2d(ix, qb->d_qoff, qb->h_qoff);
         h2d(ix, qb->d_posoff, qb->h_posoff);
         h2d(ix, qb->d_segoff, segoff);
-        {   // ~16 filter bits per k-mer (both strands), 2^13 .. 2^22 (= the exact 4^11-bit map)
+        {   // two maps (11-base and 9-base prefixes) of ~16 filter bits per k-mer (both strands) each, 2^13 .. 2^24 bits
             std::vector<int64_t> boff(nq + 1, 0);
             std::vector<int32_t> blog(nq + 1, 13);
             for (size_t i = 0; i < nq; i++) {
                 const int64_t nk = 2 * (qb->h_posoff[i + 1] - qb->h_posoff[i]);
                 int lg = 13;
-                while (lg < 22 && ((int64_t)1 << lg) < 16 * nk) lg++;
+                while (lg < 24 && ((int64_t)1 << lg) < 16 * nk) lg++;
                 blog[i] = lg;
-                boff[i + 1] = boff[i] + ((int64_t)1 << (lg - 5));
+                boff[i + 1] = boff[i] + 2 * ((int64_t)1 << (lg - 5));
             }
             qb->bits_words = boff[nq];
             h2d(ix, qb->d_bits_off, boff);
@@ -1195,6 +1195,18 @@ struct AlignCtx {
     DBuf<int32_t> wfa_todo, wfa_todo2, hdr_pool, arena_pool;
     DBuf<unsigned int> wfa_queue;
     DBuf<uint64_t> ops_pool;
+    // the global-memory WFA fallback runs beside the LDS passes of the shorter length classes: own stream and buffers
+    struct WideCtx {
+        hipStream_t st = nullptr;
+        DBuf<WfaIn> in;
+        DBuf<WfaOut> out;
+        DBuf<int32_t> todo, hdr, arena;
+        DBuf<uint64_t> ops;
+        DBuf<uint8_t> tmp;
+        ~WideCtx() {
+            if (st) (void)hipStreamDestroy(st);
+        }
+    } wide;
 };
 
 } // namespace lm
@@ -1379,223 +1391,251 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
     ops_off_h.assign(n + 1, 0);
     ops_h.clear();
     if (n == 0) return;
-    std::vector<int32_t> todo;
-    std::vector<int32_t> level(n, 0);
-    // bytes of scratch per launch of the global-memory fallback (288 GB HBM: index + genomes + this)
-    const int64_t budget = ix->scratch_budget > 0 ? std::min<int64_t>((int64_t)72 << 30, ix->scratch_budget * 2 / 5) : (int64_t)72 << 30;
-    std::vector<uint8_t> is_wide(n, 0);
+    // scratch: the LDS passes and the global-memory fallback run at the same time
+    const int64_t lean_budget = ix->scratch_budget > 0 ? std::min<int64_t>(a.wfa_budget, ix->scratch_budget * 3 / 10) : a.wfa_budget;
+    const int64_t wide_budget = ix->scratch_budget > 0 ? std::min<int64_t>((int64_t)72 << 30, ix->scratch_budget / 5) : (int64_t)72 << 30;
     a.wfa_out.ensure((size_t)n);
     a.wfa_in.ensure((size_t)n);
     std::vector<std::vector<uint64_t>> ops_keep(want_ops ? n : 0);
-    {
-        // ---- pass 1: every problem through the persistent LDS kernel, longest expected first ----
-        std::vector<int32_t> order(n);
-        int maxlen = 1;
-        int64_t Lmax = 1, ops_tot = 0;
-        {
-            const int NB = 1024;
-            std::vector<float> key(n);
-            float kmax = 1e-9f;
-            for (int64_t i = 0; i < n; i++) {
-                int64_t L = (int64_t)in[i].qlen + in[i].tlen;
-                float dv = est_div ? (*est_div)[i] : 0.12f;
-                key[i] = (dv + 0.01f) * (float)L;
-                kmax = std::max(kmax, key[i]);
-                maxlen = std::max(maxlen, std::max(in[i].qlen, in[i].tlen));
-                Lmax = std::max(Lmax, L);
+    std::atomic<int64_t> retries{0};
+
+    // ---- global-memory fallback (k_wfa_wave: one wavefront per problem, ring and wavefronts in global memory) for what the
+    // LDS kernels cannot hold: wavefronts wider than 510 diagonals, sequences above 65 kb or with non-ACGT bytes, scratch
+    // overflow.  Works on its own copies (problem descriptors, output, scratch) on the calling thread's stream.
+    auto wide_run = [&](std::vector<int32_t> todo, std::vector<int32_t> level0, AlignCtx::WideCtx &wc) {
+        std::vector<WfaIn> in2(in);
+        std::vector<int32_t> level(n, 0);
+        for (size_t j = 0; j < todo.size(); j++) level[todo[j]] = level0[j];
+        wc.in.ensure((size_t)n);
+        wc.out.ensure((size_t)n);
+        while (!todo.empty()) {
+            // take a prefix of todo that fits the scratch budget
+            std::vector<int32_t> cur;
+            int64_t hdr_tot = 0, arena_tot = 0, ops_tot = 0;
+            size_t taken = 0;
+            for (; taken < todo.size(); taken++) {
+                int32_t i = todo[taken];
+                WfaIn &w = in2[i];
+                int64_t L = (int64_t)w.qlen + w.tlen;
+                // first guess from the divergence estimate (pseudo-alignment identity) with 40% head-room, every retry
+                // doubles the score bound (the cell estimate follows it)
+                double dv = est_div ? (double)(*est_div)[i] : 0.12;
+                int64_t ms = (int64_t)(96 + 1.4 * dv * 4.6 * (double)(L / 2) + 0.05 * (double)L) << level[i];
+                if (ms > 8 * L + 64) ms = 8 * L + 64; // a global alignment never exceeds this penalty
+                int64_t ar = std::max<int64_t>(4096, wfa_cells(ms) + wfa_cells(ms) / 4) << (level[i] > 2 ? level[i] - 2 : 0);
+                int64_t oc = std::min<int64_t>(L + 2, (int64_t)(128 + 3.0 * dv * (double)L) << level[i]);
+                int64_t need = (ms * 9 + ar) * 4 + oc * 8;
+                if (!cur.empty() && (hdr_tot * 9 + arena_tot) * 4 + ops_tot * 8 + need > wide_budget) break;
+                w.max_score = (int32_t)std::min<int64_t>(ms, 2000000000);
+                w.hdr_off = hdr_tot * 9;
+                w.arena_off = arena_tot;
+                w.arena_cap = ar;
+                w.ops_off = ops_tot;
+                w.ops_cap = (int32_t)oc;
+                hdr_tot += ms;
+                arena_tot += ar;
+                ops_tot += oc;
+                cur.push_back(i);
             }
-            std::vector<int32_t> cnt(NB + 1, 0);
-            std::vector<int16_t> bk(n);
-            for (int64_t i = 0; i < n; i++) {
-                int b = NB - 1 - (int)(key[i] / kmax * (NB - 1)); // bucket 0 = most expensive
-                bk[i] = (int16_t)b;
-                cnt[b + 1]++;
-            }
-            for (int b = 0; b < NB; b++) cnt[b + 1] += cnt[b];
-            for (int64_t i = 0; i < n; i++) order[cnt[bk[i]]++] = (int32_t)i;
-        }
-        for (int64_t i = 0; i < n; i++) {
-            WfaIn &w = in[i];
-            int64_t L = (int64_t)w.qlen + w.tlen;
-            double dv = est_div ? (double)(*est_div)[i] : 0.12;
-            int64_t oc = std::min<int64_t>(L + 2, (int64_t)(128 + 3.0 * dv * (double)L));
-            w.hdr_off = w.arena_off = w.arena_cap = 0;
-            w.max_score = 0;
-            w.ops_off = ops_tot;
-            w.ops_cap = (int32_t)oc;
-            ops_tot += oc;
-        }
-        (void)maxlen;
-        (void)Lmax;
-        a.ops_pool.ensure((size_t)ops_tot + 16);
-        a.wfa_todo.ensure((size_t)n);
-        a.wfa_queue.ensure(1);
-        HIPCHK(hipMemcpyAsync(a.wfa_in.p, in.data(), sizeof(WfaIn) * n, hipMemcpyHostToDevice, S(ix)));
-        // one launch of the persistent LDS kernel per length class: the packed sequences live in LDS, so the resident
-        // wavefronts per CU are set by the longest problem of the launch (gene-sized HSPs: 24 per CU, 50-kb reads: 5)
-        auto persistent_pass = [&](const std::vector<int32_t> &items, int seq_words, int64_t lmax,
-                                   std::vector<int32_t> &too_wide, int nc) {
-            const int64_t m = (int64_t)items.size();
-            if (m == 0) return;
-            const int resident = wfa_resident_blocks(ix->device, seq_words, nc);
-            int nblocks = (int)std::min<int64_t>(m, resident);
-            // private scratch per resident wave: one backtrace byte per wavefront cell + 8 bytes per even score; never
-            // more than the worst case of the longest problem of the class
-            const int64_t smax = 8 * lmax + 64; // a global alignment never exceeds this penalty
-            const int64_t lean_budget = ix->scratch_budget > 0 ? std::min<int64_t>(a.wfa_budget, ix->scratch_budget * 2 / 5) : a.wfa_budget;
-            int64_t bytes = lean_budget / nblocks * 7 / 8;
-            bytes = std::min<int64_t>(bytes, (smax / 2 + 2) * 64 * nc + 2 * lmax + 4096);
-            bytes = std::max<int64_t>(bytes, 65536);
-            bytes = std::min<int64_t>(bytes, 2000000000) & ~(int64_t)15;
-            int64_t entries = std::min<int64_t>(smax / 2 + 4, bytes / 24 + 1024);
-            if (getenv("LM_DEBUG"))
-                fprintf(stderr, "[lm] wfa pass (%d diagonals) problems=%lld blocks=%d (resident %d) bytes/block=%lld scores=%lld seq_words=%d\n",
-                        64 * nc, (long long)m, nblocks, resident, (long long)bytes, (long long)(2 * entries), seq_words);
-            a.hdr_pool.ensure((size_t)(entries * 2) * nblocks + 16);
-            a.arena_pool.ensure((size_t)(bytes / 4) * nblocks + 16);
-            HIPCHK(hipMemcpyAsync(a.wfa_todo.p, items.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice, S(ix)));
-            HIPCHK(hipMemsetAsync(a.wfa_queue.p, 0, sizeof(unsigned int), S(ix)));
+            todo.erase(todo.begin(), todo.begin() + taken);
+            wc.hdr.ensure((size_t)hdr_tot * 9 + 16);
+            wc.arena.ensure((size_t)arena_tot + 16);
+            wc.ops.ensure((size_t)ops_tot + 16);
+            wc.todo.ensure(cur.size());
+            HIPCHK(hipMemcpyAsync(wc.in.p, in2.data(), sizeof(WfaIn) * n, hipMemcpyHostToDevice, S(ix)));
+            HIPCHK(hipMemcpyAsync(wc.todo.p, cur.data(), sizeof(int32_t) * cur.size(), hipMemcpyHostToDevice, S(ix)));
             {
-                Prof p(ix, nc == 8 ? "k_wfa_lean512" : nc == 4 ? "k_wfa_lean256" : "k_wfa_lean", wfa_bytes(in, items));
-                launch_wfa(S(ix), a.wfa_in.p, n, a.wfa_todo.p, m, nblocks, a.hdr_pool.p, entries * 2, (uint8_t *)a.arena_pool.p,
-                           bytes, a.ops_pool.p, a.wfa_queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc);
+                Prof p(ix, "k_wfa_wide", wfa_bytes(in2, cur));
+                launch_wfa_wide(S(ix), wc.in.p, n, wc.todo.p, (int64_t)cur.size(), wc.hdr.p, wc.arena.p, wc.ops.p, wc.out.p);
             }
             std::vector<WfaOut> tmp;
-            d2h(ix, tmp, a.wfa_out.p, (size_t)n);
+            d2h(ix, tmp, wc.out.p, (size_t)n);
             std::vector<uint64_t> ops_tmp;
-            if (want_ops) d2h(ix, ops_tmp, a.ops_pool.p, (size_t)ops_tot);
+            if (want_ops) d2h(ix, ops_tmp, wc.ops.p, (size_t)ops_tot);
             sync(ix);
-            int64_t n3 = 0, n1 = 0;
-            int maxw = 0;
-            for (int32_t i : items) {
-                int stt = tmp[i].r.status;
-                n3 += stt == 3;
-                n1 += stt == 1;
-                if (stt == 3) {
-                    maxw = std::max(maxw, tmp[i].r.score); // the width that did not fit (0: other reasons)
-                    too_wide.push_back(i);
-                    if (nc == 8) a.stats->wfa_retries++; // counted when a problem leaves the LDS kernels for good
-                } else if (stt == 1) { // scratch or ops overflow: per-problem scratch in the global-memory kernel
-                    is_wide[i] = 1;
-                    level[i] = 1;
-                    a.stats->wfa_retries++;
+            for (int32_t i : cur) {
+                if (tmp[i].r.status == 1 || tmp[i].r.status == 3) {
+                    level[i]++;
+                    retries++;
+                    if (level[i] > 12) throw HipError("WFA scratch overflow after 12 retries");
                     todo.push_back(i);
                 } else {
                     out[i] = tmp[i];
                     if (want_ops && tmp[i].r.nops > 0)
-                        ops_keep[i].assign(ops_tmp.begin() + in[i].ops_off,
-                                           ops_tmp.begin() + in[i].ops_off + tmp[i].r.nops);
+                        ops_keep[i].assign(ops_tmp.begin() + in2[i].ops_off, ops_tmp.begin() + in2[i].ops_off + tmp[i].r.nops);
                 }
             }
-            if (getenv("LM_DEBUG") && (n3 || n1))
-                fprintf(stderr, "[lm] wfa pass: %lld problems left the LDS kernel as too wide (first width that did not fit <= %d) / long / non-ACGT, %lld on scratch overflow\n",
-                        (long long)n3, maxw, (long long)n1);
-        };
-        // length classes (sequence words of 16 bases); within a class the queue keeps the longest-expected-first order
-        std::vector<int32_t> wide2;
-        {
-            const int bounds[4] = {128, 512, 2048, 4096};
-            std::vector<int32_t> cls[4];
-            int cw[4] = {1, 1, 1, 1};
-            int64_t cl[4] = {1, 1, 1, 1};
-            for (int32_t i : order) {
-                const int wds = (std::max(in[i].qlen, in[i].tlen) + 15) / 16;
-                int c = 0;
-                while (c < 4 && wds > bounds[c]) c++;
-                if (c == 4) { // longer than the LDS buffers
-                    wide2.push_back(i);
-                    a.stats->wfa_retries++;
-                    continue;
-                }
-                cls[c].push_back(i);
-                cw[c] = std::max(cw[c], wds);
-                cl[c] = std::max<int64_t>(cl[c], (int64_t)in[i].qlen + in[i].tlen);
-            }
-            for (int c = 3; c >= 0; c--) {
-                // 126 diagonals first (a wavefront wider than that returns status 3), then the same kernel with 254 and 510
-                std::vector<int32_t> wider, widest;
-                persistent_pass(cls[c], cw[c], cl[c], wider, 2);
-                persistent_pass(wider, cw[c], cl[c], widest, 4);
-                persistent_pass(widest, cw[c], cl[c], wide2, 8);
-            }
         }
-        for (int32_t i : wide2) { // wider than 126 diagonals, longer than the LDS buffers, or not plain ACGT
-            is_wide[i] = 1;
-            level[i] = 2; // these are the hard ones: generous scratch at once instead of an overflow and a second launch
-            todo.push_back(i);
+    };
+
+    // problems in decreasing order of expected cost (divergence estimate x length): bucket sort
+    std::vector<int32_t> order(n);
+    int64_t ops_tot = 0;
+    {
+        const int NB = 1024;
+        std::vector<float> key(n);
+        float kmax = 1e-9f;
+        for (int64_t i = 0; i < n; i++) {
+            int64_t L = (int64_t)in[i].qlen + in[i].tlen;
+            float dv = est_div ? (*est_div)[i] : 0.12f;
+            key[i] = (dv + 0.01f) * (float)L;
+            kmax = std::max(kmax, key[i]);
         }
+        std::vector<int32_t> cnt(NB + 1, 0);
+        std::vector<int16_t> bk(n);
+        for (int64_t i = 0; i < n; i++) {
+            int b = NB - 1 - (int)(key[i] / kmax * (NB - 1)); // bucket 0 = most expensive
+            bk[i] = (int16_t)b;
+            cnt[b + 1]++;
+        }
+        for (int b = 0; b < NB; b++) cnt[b + 1] += cnt[b];
+        for (int64_t i = 0; i < n; i++) order[cnt[bk[i]]++] = (int32_t)i;
     }
-    while (!todo.empty()) {
-        // take a prefix of todo that fits the scratch budget
-        std::vector<int32_t> cur;
-        int64_t hdr_tot = 0, arena_tot = 0, ops_tot = 0;
-        size_t taken = 0;
-        for (; taken < todo.size(); taken++) {
-            int32_t i = todo[taken];
-            WfaIn &w = in[i];
-            int64_t L = (int64_t)w.qlen + w.tlen;
-            // first guess from the divergence estimate (pseudo-alignment identity) with 40% head-room, every retry
-            // doubles the score bound (the cell estimate follows it)
-            double dv = est_div ? (double)(*est_div)[i] : 0.12;
-            int64_t ms = (int64_t)(96 + 1.4 * dv * 4.6 * (double)(L / 2) + 0.05 * (double)L) << level[i];
-            if (ms > 8 * L + 64) ms = 8 * L + 64; // a global alignment never exceeds this penalty
-            int64_t ar = std::max<int64_t>(4096, wfa_cells(ms) + wfa_cells(ms) / 4) << (level[i] > 2 ? level[i] - 2 : 0);
-            int64_t oc = std::min<int64_t>(L + 2, (int64_t)(128 + 3.0 * dv * (double)L) << level[i]);
-            int64_t need = (ms * 9 + ar) * 4 + oc * 8;
-            if (!cur.empty() && (hdr_tot * 9 + arena_tot) * 4 + ops_tot * 8 + need > budget) break;
-            w.max_score = (int32_t)std::min<int64_t>(ms, 2000000000);
-            w.hdr_off = hdr_tot * 9;
-            w.arena_off = arena_tot;
-            w.arena_cap = ar;
-            w.ops_off = ops_tot;
-            w.ops_cap = (int32_t)oc;
-            hdr_tot += ms;
-            arena_tot += ar;
-            ops_tot += oc;
-            cur.push_back(i);
-        }
-        todo.erase(todo.begin(), todo.begin() + taken);
-        a.hdr_pool.ensure((size_t)hdr_tot * 9 + 16);
-        a.arena_pool.ensure((size_t)arena_tot + 16);
-        a.ops_pool.ensure((size_t)ops_tot + 16);
-        a.wfa_in.ensure((size_t)n);
-        a.wfa_todo.ensure(cur.size());
-        HIPCHK(hipMemcpyAsync(a.wfa_in.p, in.data(), sizeof(WfaIn) * n, hipMemcpyHostToDevice, S(ix)));
+    for (int64_t i = 0; i < n; i++) {
+        WfaIn &w = in[i];
+        int64_t L = (int64_t)w.qlen + w.tlen;
+        double dv = est_div ? (double)(*est_div)[i] : 0.12;
+        int64_t oc = std::min<int64_t>(L + 2, (int64_t)(128 + 3.0 * dv * (double)L));
+        w.hdr_off = w.arena_off = w.arena_cap = 0;
+        w.max_score = 0;
+        w.ops_off = ops_tot;
+        w.ops_cap = (int32_t)oc;
+        ops_tot += oc;
+    }
+    a.ops_pool.ensure((size_t)ops_tot + 16);
+    a.wfa_todo.ensure((size_t)n);
+    a.wfa_queue.ensure(1);
+    HIPCHK(hipMemcpyAsync(a.wfa_in.p, in.data(), sizeof(WfaIn) * n, hipMemcpyHostToDevice, S(ix)));
+    std::vector<int32_t> fb_items, fb_level; // what leaves the LDS kernels, with its starting scratch level
+    // one launch of the persistent LDS kernel per length class and ring width: the packed sequences live in LDS, so the
+    // resident wavefronts per CU are set by the longest problem of the launch (gene-sized HSPs: 28 per CU, 50-kb reads: 3-5)
+    auto persistent_pass = [&](const std::vector<int32_t> &items, int seq_words, int64_t lmax, std::vector<int32_t> &too_wide,
+                               int nc) {
+        const int64_t m = (int64_t)items.size();
+        if (m == 0) return;
+        const int resident = wfa_resident_blocks(ix->device, seq_words, nc);
+        int nblocks = (int)std::min<int64_t>(m, resident);
+        // private scratch per resident wave: one backtrace byte per wavefront cell + 8 bytes per even score; never
+        // more than the worst case of the longest problem of the class
+        const int64_t smax = 8 * lmax + 64; // a global alignment never exceeds this penalty
+        int64_t bytes = lean_budget / nblocks * 7 / 8;
+        bytes = std::min<int64_t>(bytes, (smax / 2 + 2) * 64 * nc + 2 * lmax + 4096);
+        bytes = std::max<int64_t>(bytes, 65536);
+        bytes = std::min<int64_t>(bytes, 2000000000) & ~(int64_t)15;
+        int64_t entries = std::min<int64_t>(smax / 2 + 4, bytes / 24 + 1024);
+        if (getenv("LM_DEBUG"))
+            fprintf(stderr, "[lm] wfa pass (%d diagonals) problems=%lld blocks=%d (resident %d) bytes/block=%lld scores=%lld seq_words=%d\n",
+                    64 * nc, (long long)m, nblocks, resident, (long long)bytes, (long long)(2 * entries), seq_words);
+        a.hdr_pool.ensure((size_t)(entries * 2) * nblocks + 16);
+        a.arena_pool.ensure((size_t)(bytes / 4) * nblocks + 16);
+        HIPCHK(hipMemcpyAsync(a.wfa_todo.p, items.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice, S(ix)));
+        HIPCHK(hipMemsetAsync(a.wfa_queue.p, 0, sizeof(unsigned int), S(ix)));
         {
-            // pass 1: LDS-ring kernel; pass 2 (rare): wavefronts wider than the ring, same scratch, global-memory ring
-            std::vector<int32_t> narrow, wide;
-            for (int32_t i : cur) (is_wide[i] ? wide : narrow).push_back(i);
-            if (!narrow.empty()) throw HipError("internal: narrow WFA problem in the fallback pass");
-            if (!wide.empty()) {
-                a.wfa_todo2.ensure(wide.size());
-                HIPCHK(hipMemcpyAsync(a.wfa_todo2.p, wide.data(), sizeof(int32_t) * wide.size(), hipMemcpyHostToDevice, S(ix)));
-                Prof p(ix, "k_wfa_wide", wfa_bytes(in, wide));
-                launch_wfa_wide(S(ix), a.wfa_in.p, n, a.wfa_todo2.p, (int64_t)wide.size(), a.hdr_pool.p, a.arena_pool.p,
-                                a.ops_pool.p, a.wfa_out.p);
-            }
+            Prof p(ix, nc == 8 ? "k_wfa_lean512" : nc == 4 ? "k_wfa_lean256" : "k_wfa_lean", wfa_bytes(in, items));
+            launch_wfa(S(ix), a.wfa_in.p, n, a.wfa_todo.p, m, nblocks, a.hdr_pool.p, entries * 2, (uint8_t *)a.arena_pool.p, bytes,
+                       a.ops_pool.p, a.wfa_queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc);
         }
         std::vector<WfaOut> tmp;
         d2h(ix, tmp, a.wfa_out.p, (size_t)n);
         std::vector<uint64_t> ops_tmp;
         if (want_ops) d2h(ix, ops_tmp, a.ops_pool.p, (size_t)ops_tot);
         sync(ix);
-        for (int32_t i : cur) {
-            if (tmp[i].r.status == 3) { // wider than the LDS ring: rerun with the global-ring kernel, same scratch level
-                is_wide[i] = 1;
-                a.stats->wfa_retries++;
-                todo.push_back(i);
-            } else if (tmp[i].r.status == 1) {
-                level[i]++;
-                a.stats->wfa_retries++;
-                if (level[i] > 12) throw HipError("WFA scratch overflow after 12 retries");
-                todo.push_back(i);
+        int64_t n3 = 0, n1 = 0;
+        for (int32_t i : items) {
+            int stt = tmp[i].r.status;
+            n3 += stt == 3;
+            n1 += stt == 1;
+            if (stt == 3) { // wider than this ring (or not plain ACGT)
+                too_wide.push_back(i);
+            } else if (stt == 1) { // scratch or ops overflow: per-problem scratch in the global-memory kernel
+                fb_items.push_back(i);
+                fb_level.push_back(1);
+                retries++;
             } else {
                 out[i] = tmp[i];
                 if (want_ops && tmp[i].r.nops > 0)
                     ops_keep[i].assign(ops_tmp.begin() + in[i].ops_off, ops_tmp.begin() + in[i].ops_off + tmp[i].r.nops);
             }
         }
+        if (getenv("LM_DEBUG") && (n3 || n1))
+            fprintf(stderr, "[lm] wfa pass: %lld problems wider than %d diagonals (or non-ACGT), %lld on scratch overflow\n",
+                    (long long)n3, 64 * nc - 2, (long long)n1);
+    };
+    // length classes (sequence words of 16 bases); within a class the queue keeps the longest-expected-first order
+    const int bounds[4] = {128, 512, 2048, 4096};
+    std::vector<int32_t> cls[4];
+    int cw[4] = {1, 1, 1, 1};
+    int64_t cl[4] = {1, 1, 1, 1};
+    for (int32_t i : order) {
+        const int wds = (std::max(in[i].qlen, in[i].tlen) + 15) / 16;
+        int c = 0;
+        while (c < 4 && wds > bounds[c]) c++;
+        if (c == 4) { // longer than the LDS buffers
+            fb_items.push_back(i);
+            fb_level.push_back(2);
+            retries++;
+            continue;
+        }
+        cls[c].push_back(i);
+        cw[c] = std::max(cw[c], wds);
+        cl[c] = std::max<int64_t>(cl[c], (int64_t)in[i].qlen + in[i].tlen);
     }
+    std::thread wide_thread;
+    std::exception_ptr wide_err;
+    auto start_wide = [&]() { // what has left the LDS kernels so far goes to the fallback on its own stream and thread
+        if (fb_items.empty() || wide_thread.joinable()) return;
+        if (!a.wide.st) HIPCHK(hipStreamCreate(&a.wide.st));
+        std::vector<int32_t> items, level;
+        items.swap(fb_items);
+        level.swap(fb_level);
+        wide_thread = std::thread([&, items, level]() {
+            try {
+                HIPCHK(hipSetDevice(ix->device));
+                tls_stream = a.wide.st;
+                tls_tmp = &a.wide.tmp;
+                wide_run(items, level, a.wide);
+            } catch (...) {
+                wide_err = std::current_exception();
+            }
+            tls_stream = nullptr;
+            tls_tmp = nullptr;
+        });
+    };
+    try {
+        for (int c = 3; c >= 0; c--) {
+            // ring width by experience: alignments of tens of kb at ONT error rates run wavefronts of several hundred
+            // diagonals under wf-adaptive(10,50) (all of the >= 32-kb class and two thirds of the 8-32-kb class outgrow 126),
+            // gene-sized ones stay below 126.  A pass that turns out too narrow returns status 3 and the next width takes over.
+            std::vector<int32_t> w1, w2, w3;
+            const int first = c == 3 ? 8 : (c == 2 ? 4 : 2);
+            if (first == 2) {
+                persistent_pass(cls[c], cw[c], cl[c], w1, 2);
+                persistent_pass(w1, cw[c], cl[c], w2, 4);
+                persistent_pass(w2, cw[c], cl[c], w3, 8);
+            } else if (first == 4) {
+                persistent_pass(cls[c], cw[c], cl[c], w2, 4);
+                persistent_pass(w2, cw[c], cl[c], w3, 8);
+            } else {
+                persistent_pass(cls[c], cw[c], cl[c], w3, 8);
+            }
+            for (int32_t i : w3) { // the hard ones: generous scratch at once instead of an overflow and a second launch
+                fb_items.push_back(i);
+                fb_level.push_back(2);
+                retries++;
+            }
+            if (c == 2) start_wide(); // the long classes are done: their leftovers run beside the short classes
+        }
+    } catch (...) {
+        if (wide_thread.joinable()) wide_thread.join();
+        throw;
+    }
+    if (wide_thread.joinable()) wide_thread.join();
+    if (wide_err) std::rethrow_exception(wide_err);
+    if (!fb_items.empty()) { // leftovers of the short classes (rare): same fallback, on this thread's stream
+        if (!a.wide.st) HIPCHK(hipStreamCreate(&a.wide.st));
+        wide_run(fb_items, fb_level, a.wide);
+    }
+    a.stats->wfa_retries += retries.load();
     if (want_ops) {
         for (int64_t i = 0; i < n; i++) {
             ops_off_h[i] = (int64_t)ops_h.size();

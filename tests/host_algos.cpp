@@ -35,9 +35,12 @@ uint64_t ha_unpack_seed_val(uint64_t pv, uint64_t bg, int pos_bits, int dir) { r
 
 // pseudo-alignment prefix filter: bitmap of a sorted key array the way k_build_cmp_bits fills it, and the candidate test
 void ha_pa_filter_build(const uint64_t *keys, int n, int K, int log, uint32_t *bits) {
+    uint32_t *bits2 = bits + ((size_t)1 << (log - 5));
     for (int i = 0; i < n; i++) {
         const uint32_t h = lm_pa_filter_slot((uint32_t)(keys[i] >> ((K - LM_PFX_BASES) << 1)), log);
         bits[h >> 5] |= 1u << (h & 31);
+        const uint32_t h2 = lm_pa_filter_slot((uint32_t)(keys[i] >> ((K - LM_PFX_BASES2) << 1)), log);
+        bits2[h2 >> 5] |= 1u << (h2 & 31);
     }
 }
 int ha_pa_candidate(const uint32_t *bits, int log, uint64_t key, int p, int K) { return lm_pa_candidate(bits, log, key, p, K); }

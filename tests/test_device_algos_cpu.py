@@ -290,8 +290,8 @@ def test_tree_search_quirk_matches_radix_tree():
         cap = C.c_int(0)
         lo, hi = C.c_int(), C.c_int()
         # the pseudo-alignment prefix filter of this key set (k_build_cmp_bits): small map -> hashed, 22 -> exact
-        flog = rng.choice([13, 16, 22])
-        fbits = (C.c_uint32 * (1 << (flog - 5)))()
+        flog = rng.choice([13, 16, 20])
+        fbits = (C.c_uint32 * (2 << (flog - 5)))()
         Hh.ha_pa_filter_build(arr, len(keys), K, flog, fbits)
         for _ in range(400):
             share = rng.randint(1, 12)

@@ -372,6 +372,24 @@ def test_demo_golden_rows(tmp_path):
     gi.close()
 
 
+def test_demo_c1_all_84_gene_rows_through_the_hip_path(tmp_path):
+    """BASELINE configs[0]: demo/q.gene.fasta against all 15 genomes of demo/refs (committed fixtures): the 84 rows of the
+    reference's own q.gene.fasta.lexicmap.tsv, every column, in order, through the C-ABI on the GPU"""
+    la = _la()
+    d = str(tmp_path / "demo15.lmi")
+    files = [os.path.join(GOLD, f) for f in os.listdir(GOLD) if f.endswith(".fa.gz")]
+    files += [os.path.join(GOLD, "refs", f) for f in os.listdir(os.path.join(GOLD, "refs")) if f.endswith(".fa.gz")]
+    files = sorted(files, key=os.path.basename)
+    assert len(files) == 15
+    O.build_index(d, [(os.path.basename(f)[:-6], O.read_fasta(f)) for f in files], O.default_build_opt(chunks=8))
+    qs = O.read_fasta(os.path.join(GOLD, "q.gene.fasta"))
+    gi = la.Index(d)
+    lines = gi.search_tsv([q[0] for q in qs], [q[1] for q in qs])
+    gi.close()
+    gold = open(os.path.join(GOLD, "q.gene.fasta.lexicmap.tsv")).read().rstrip("\n").split("\n")[1:]
+    assert len(gold) == 84 and lines == gold
+
+
 def test_sharded_index_union_equals_whole(small_index, queries):
     """§8e: genomes sharded over 2 'ranks' (same device here); the union of per-shard rows, re-sorted by the final
     ordering rule, equals the single-shard result (hits column recomputed)"""
