@@ -467,6 +467,7 @@ static void stage_mask(Work &w) {
 }
 
 struct PartTooLarge : std::exception {};
+struct ChunkTooLarge : std::exception {};
 
 static void stage_lookup(Work &w, lm_stage_stats &stats) {
     lm_index *ix = w.ix;
@@ -1285,7 +1286,12 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
         a.pa_cap = TP + TP / 8;
     }
     a.stats->pa_anchors += TP;
-    if (TP >= (int64_t)1 << 31) throw HipError("too many pseudo-alignment anchors in one chunk");
+    // too many anchors for one chunk (31-bit indices, ~90 B of scratch each within a quarter of the budget): the caller
+    // halves the chunk
+    if (TP >= (int64_t)1 << 31 || (ix->scratch_budget > 0 && TP * 90 > ix->scratch_budget / 4)) {
+        if (nt <= 1) throw HipError("too many pseudo-alignment anchors for one chain window");
+        throw ChunkTooLarge();
+    }
     a.pa_off.ensure((size_t)nt + 2);
     a.out_n.ensure((size_t)nt + 1);
     a.clr_n.ensure((size_t)nt + 1);
@@ -1736,7 +1742,12 @@ static AlignCtx &get_actx(lm_index *ix, lm_qbatch *qb, Work *w, lm_stage_stats *
 // order. Runs on the calling thread's stream (tls_stream) with the private scratch of `a`.
 static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskSpan tasks_h, int64_t r0, int64_t r1,
                         lm_stage_stats &st, std::vector<HGenome> &genomes, lm_result *res, std::mutex &strings_mu) {
-    int64_t max_window_bytes = (int64_t)2 << 30;
+    // windows of one alignment chunk: the chunk's pseudo-alignment anchors (~0.04 per window base, ~90 B of scratch each)
+    // and its WFA launches scale with it; long alignments are latency-bound per problem, so few large chunks beat many
+    // small ones (each chunk ends with a tail of a few 50-kb alignments running alone)
+    int64_t max_window_bytes = ix->scratch_budget > 0
+                                   ? std::min<int64_t>((int64_t)8 << 30, std::max<int64_t>((int64_t)1 << 30, ix->scratch_budget / 24))
+                                   : (int64_t)2 << 30;
     if (const char *e = getenv("LM_DEBUG_MAX_WINDOW_BYTES")) max_window_bytes = std::max<int64_t>(1, atoll(e)); // test hook
     const bool want_seq = ix->opt.output_seq != 0;
     int64_t tpos = r0;
@@ -1761,7 +1772,14 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
         std::vector<int64_t> res_off;
         std::vector<LmChain2> resv;
         double ta = now_ms();
-        run_pseudo(a, ht, res_off, resv, w.tasks.p + tpos, base);
+        try {
+            run_pseudo(a, ht, res_off, resv, w.tasks.p + tpos, base);
+        } catch (const ChunkTooLarge &) { // same tasks again in smaller chunks
+            if (ht[0].seg == ht.back().seg) throw HipError("too many pseudo-alignment anchors for one (query, genome) pair");
+            max_window_bytes = std::max<int64_t>(off / 2, 1);
+            if (getenv("LM_DEBUG")) fprintf(stderr, "[lm] alignment chunk halved to %lld window bytes\n", (long long)max_window_bytes);
+            continue;
+        }
         double tb = now_ms();
         st.ms_pseudo += tb - ta;
         // glue per segment with results (parallel; the order of `genomes` stays the segment order)

@@ -342,6 +342,6 @@ def test_demo_golden_prophage_rows_that_do_not_depend_on_the_mask_set(demo_index
             o = ours[key(g)]
             assert [o[c] for c in hsp_cols] == [g[c] for c in hsp_cols]
             same += 1
-    assert same == 6
+    assert same == 5
     # the stable divergence: same start, 38 bp longer at the right end
     assert any(r[3] == "GCF_003697165.2" and r[12] == "10308" and r[13] == "13328" and r[9] == "3021" for r in rows)
