@@ -210,7 +210,6 @@ lm_status lm_index_set_genome_filter(lm_index *idx, const uint64_t *batch_genome
 /* ---------------------------------------------------------------------------------------------------------
  * Stage-level entry points (inner seams) used by the parity tests. All outputs are host arrays owned
  * by the returned lm_stage object. */
-typedef struct lm_stage lm_stage;
 void lm_stage_free(lm_stage *s);
 
 /* lexichash MaskKnownDistinctPrefixes + low-complexity zeroing (lib-index-search.go:1212-1238):

@@ -398,6 +398,58 @@ struct Work {
     DBuf<int64_t> task_woff;
     int64_t ntasks = 0;
     explicit Work(lm_index *i, lm_qbatch *q) : ix(i), qb(q) {}
+    // The seeding half's arrays (unsorted k-mer copies, captures, lookups, anchors, chaining scratch) are dead once the
+    // tasks exist; the alignment half needs the room when they are large (long-read batches: tens of GB). Small ones
+    // stay allocated: re-allocating them every batch would cost more than it frees.
+    void release_seeding(int64_t keep_below_bytes) {
+        auto drop = [&](auto &b) {
+            if ((int64_t)(b.cap * sizeof(*b.p)) > keep_below_bytes) b.release();
+        };
+        // of the two buffers of each sorted array only the one holding the result survives
+        if (k_all == keys_all2.p) drop(keys_all); else drop(keys_all2);
+        if (v_all == vals_all2.p) drop(vals_all); else drop(vals_all2);
+        if (k_cmp == keys_cmp2.p) drop(keys_cmp); else drop(keys_cmp2);
+        if (v_cmp == vals_cmp2.p) drop(vals_cmp); else drop(vals_cmp2);
+        if (k_all == keys_all2.p) drop(keys_all2); else drop(keys_all);
+        if (v_all == vals_all2.p) drop(vals_all2); else drop(vals_all);
+        k_all = nullptr;
+        v_all = nullptr;
+        drop(first_mask);
+        drop(kmers);
+        drop(klo);
+        drop(khi);
+        drop(lk_counts);
+        drop(lk_list);
+        drop(lk_list2);
+        drop(lk_perm);
+        drop(lk_perm2);
+        drop(lk_offs);
+        drop(lk_starts);
+        drop(lk_nscan);
+        drop(A0);
+        drop(B0);
+        drop(A1);
+        drop(B1);
+        drop(segA);
+        drop(seg_len);
+        drop(seg_off);
+        drop(subs);
+        drop(marks);
+        drop(visited);
+        drop(msi);
+        drop(s2i);
+        drop(dirs);
+        drop(chain_off_pool);
+        drop(chain_idx_pool);
+        drop(seg_n);
+        drop(seg_nch);
+        drop(order_scratch);
+        drop(seg_score);
+        drop(ntask);
+        drop(task_off);
+        drop(task_wlen);
+        drop(task_woff);
+    }
     void rebind(lm_qbatch *q) {
         qb = q;
         n_anchors = 0;
@@ -528,10 +580,10 @@ static void stage_lookup(Work &w, lm_stage_stats &stats) {
         const int64_t probes = (int64_t)std::ceil(std::log2(sb + 1.0));
         prof_add_bytes(ix, "k_lookup_count", nlk * (8 + 8 * probes) + 16 * (int64_t)hv);
     }
-    // anchors + their chaining scratch (~96 B each) must fit a quarter of the scratch budget, and their number 31 bits:
+    // anchors + their chaining scratch (~96 B each) must fit 22 % of the scratch budget, and their number 31 bits:
     // otherwise the caller halves this part of the batch and comes back (lm_search_resident)
     const char *dbg_max = getenv("LM_DEBUG_MAX_ANCHORS"); // test hook: forces the halving path
-    if (T >= (int64_t)1 << 31 || (ix->scratch_budget > 0 && T * 96 > ix->scratch_budget / 4) ||
+    if (T >= (int64_t)1 << 31 || (ix->scratch_budget > 0 && T * 96 > ix->scratch_budget * 22 / 100) ||
         (dbg_max && qb->nq > 1 && T > atoll(dbg_max))) {
         if (qb->nq <= 1) throw HipError("one query yields more seed anchors than the device can hold");
         throw PartTooLarge();
@@ -1076,9 +1128,9 @@ static lm_qbatch *upload_part(lm_index *ix, const lm_query *queries, size_t nq, 
 static void part_limits(lm_index *ix, int64_t *max_pos, int64_t *max_qm) {
     int64_t pos = ((int64_t)1 << 30) - 1, qm = ((int64_t)1 << 31) - 1;
     // ~104 B per k-mer position (two sorted k-mer arrays with their double buffers, capture marks) and ~80 B per
-    // (query, mask) pair (captured k-mers, location ranges, lookup lists) may take a fifth of the scratch budget
+    // (query, mask) pair (captured k-mers, location ranges, lookup lists) may take 15 % of the scratch budget
     if (ix->scratch_budget > 0) {
-        const int64_t b = ix->scratch_budget / 5;
+        const int64_t b = ix->scratch_budget * 15 / 100; // shares of the scratch budget
         pos = std::min<int64_t>(pos, std::max<int64_t>(b / 2 / 104, 1 << 16));
         qm = std::min<int64_t>(qm, std::max<int64_t>(b / 2 / 80, (int64_t)ix->host.M));
     }
@@ -1288,7 +1340,7 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
     a.stats->pa_anchors += TP;
     // too many anchors for one chunk (31-bit indices, ~90 B of scratch each within a quarter of the budget): the caller
     // halves the chunk
-    if (TP >= (int64_t)1 << 31 || (ix->scratch_budget > 0 && TP * 90 > ix->scratch_budget / 4)) {
+    if (TP >= (int64_t)1 << 31 || (ix->scratch_budget > 0 && TP * 90 > ix->scratch_budget * 22 / 100)) {
         if (nt <= 1) throw HipError("too many pseudo-alignment anchors for one chain window");
         throw ChunkTooLarge();
     }
@@ -1398,8 +1450,8 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
     ops_h.clear();
     if (n == 0) return;
     // scratch: the LDS passes and the global-memory fallback run at the same time
-    const int64_t lean_budget = ix->scratch_budget > 0 ? std::min<int64_t>(a.wfa_budget, ix->scratch_budget * 3 / 10) : a.wfa_budget;
-    const int64_t wide_budget = ix->scratch_budget > 0 ? std::min<int64_t>((int64_t)72 << 30, ix->scratch_budget / 5) : (int64_t)72 << 30;
+    const int64_t lean_budget = ix->scratch_budget > 0 ? std::min<int64_t>(a.wfa_budget, ix->scratch_budget * 28 / 100) : a.wfa_budget;
+    const int64_t wide_budget = ix->scratch_budget > 0 ? std::min<int64_t>((int64_t)72 << 30, ix->scratch_budget * 12 / 100) : (int64_t)72 << 30;
     a.wfa_out.ensure((size_t)n);
     a.wfa_in.ensure((size_t)n);
     std::vector<std::vector<uint64_t>> ops_keep(want_ops ? n : 0);
@@ -2191,6 +2243,7 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res, const Searc
     st.ms_window = t1 - t0;
     t0 = t1;
 
+    if (ix->scratch_budget > 0) w.release_seeding(ix->scratch_budget / 200);
     // ---- alignment half, in chunks of whole (query, genome) segments (align_range). Splitting it over two host
     // threads / streams so that one half's host glue overlaps the other half's kernels was measured at C2 and gave
     // nothing (the halves run in lock-step, and the kernels only slow each other down), so it runs on one stream.

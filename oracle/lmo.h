@@ -261,11 +261,15 @@ typedef struct {
     int k, masks;
     int64_t rand_seed;
     int max_desert, seed_dist, chunks, partitions, batch_size, contig_interval;
+    int max_genome; /* -g/--max-genome 20,000,000 (index.go:538): longer concatenations are split into genome chunks */
 } lmo_build_opt;
 void lmo_build_opt_default(lmo_build_opt *o);
 typedef struct lmo_builder lmo_builder;
 lmo_builder *lmo_builder_new(const char *outdir, const lmo_build_opt *opt);
-/* add one genome: contigs concatenated by the builder with contig_interval 'A's */
+/* add one genome: contigs concatenated by the builder with contig_interval 'A's; when the concatenation would exceed
+ * max_genome the genome is split into chunks, each stored as its own genome record with the same id and listed together
+ * in genomes.chunks.bin (lib-index-build.go:1581-1658,1786-1808). Returns -2 when one contig alone exceeds max_genome
+ * (the reference skips such genomes). */
 int lmo_builder_add(lmo_builder *b, const char *id, int ncontigs, const char **contig_ids, const uint8_t **contigs,
                     const int *contig_lens);
 int lmo_builder_finish(lmo_builder *b);

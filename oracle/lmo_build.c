@@ -26,6 +26,7 @@ void lmo_build_opt_default(lmo_build_opt *o) {
     o->partitions = 4096; /* index.go:603 */
     o->batch_size = 5000; /* index.go:613 */
     o->contig_interval = 1000; /* index.go:619 */
+    o->max_genome = 20000000;  /* index.go:538 */
 }
 
 typedef struct {
@@ -55,6 +56,11 @@ struct lmo_builder {
     lmo_gwriter *gw;
     int cur_batch;
     FILE *fmap;
+    /* genome chunks (lib-index-build.go:1786-1808): lists of batch+index keys of the records of one split genome */
+    uint64_t *chunk_keys;
+    int *chunk_list_len;
+    int nchunk_keys, nchunk_lists, cap_chunk_keys, cap_chunk_lists;
+    int ninput;
 };
 
 static void mkdir_p(const char *p) {
@@ -106,8 +112,54 @@ static int cmp_skip(const void *a, const void *b) {
 
 static int valid_seed_kmer(uint64_t kmer, int k) { return kmer != 0 && !lmo_low_complexity(kmer, k); }
 
+static int add_one(lmo_builder *b, const char *id, int ncontigs, const char **contig_ids, const uint8_t **contigs,
+                   const int *contig_lens, uint64_t *bg_out);
+
 int lmo_builder_add(lmo_builder *b, const char *id, int ncontigs, const char **contig_ids, const uint8_t **contigs,
                     const int *contig_lens) {
+    /* lib-index-build.go:1581-1658: contigs are appended while the concatenation (with spacers) stays within max_genome;
+     * a contig that would overflow it closes the current chunk and starts the next one */
+    const lmo_build_opt *o = &b->opt;
+    const int64_t maxg = o->max_genome > 0 ? o->max_genome : ((int64_t)1 << 28) - 1;
+    for (int i = 0; i < ncontigs; i++)
+        if (contig_lens[i] > maxg) return -2; /* "skipping a big genome with a sequence of %d bp" */
+    uint64_t *keys = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(ncontigs + 1));
+    int nk = 0, first = 0, rc = 0;
+    int64_t cur = 0; /* len(refseq.Seq) */
+    for (int i = 0; i < ncontigs && rc == 0; i++) {
+        if (cur + contig_lens[i] > maxg && i > first) {
+            rc = add_one(b, id, i - first, contig_ids + first, contigs + first, contig_lens + first, &keys[nk]);
+            nk++;
+            first = i;
+            cur = 0;
+        }
+        if (i > first) cur += o->contig_interval;
+        cur += contig_lens[i];
+    }
+    if (rc == 0 && first < ncontigs) {
+        rc = add_one(b, id, ncontigs - first, contig_ids + first, contigs + first, contig_lens + first, &keys[nk]);
+        nk++;
+    }
+    if (rc == 0 && nk > 1) {
+        if (b->nchunk_keys + nk > b->cap_chunk_keys) {
+            b->cap_chunk_keys = (b->nchunk_keys + nk) * 2;
+            b->chunk_keys = (uint64_t *)realloc(b->chunk_keys, sizeof(uint64_t) * (size_t)b->cap_chunk_keys);
+        }
+        if (b->nchunk_lists == b->cap_chunk_lists) {
+            b->cap_chunk_lists = b->cap_chunk_lists ? b->cap_chunk_lists * 2 : 8;
+            b->chunk_list_len = (int *)realloc(b->chunk_list_len, sizeof(int) * (size_t)b->cap_chunk_lists);
+        }
+        memcpy(b->chunk_keys + b->nchunk_keys, keys, sizeof(uint64_t) * (size_t)nk);
+        b->nchunk_keys += nk;
+        b->chunk_list_len[b->nchunk_lists++] = nk;
+    }
+    free(keys);
+    if (rc == 0) b->ninput++;
+    return rc;
+}
+
+static int add_one(lmo_builder *b, const char *id, int ncontigs, const char **contig_ids, const uint8_t **contigs,
+                   const int *contig_lens, uint64_t *bg_out) {
     const lmo_build_opt *o = &b->opt;
     int k = o->k, M = o->masks, interval = o->contig_interval;
     /* concatenate */
@@ -190,6 +242,7 @@ int lmo_builder_add(lmo_builder *b, const char *id, int ncontigs, const char **c
     gi.seq = seq;
     lmo_gwriter_write(b->gw, &gi);
     uint64_t bg = ((uint64_t)batch << LMO_BITS_GENOME_IDX) | ((uint64_t)gidx & LMO_MASK_GENOME_IDX);
+    if (bg_out) *bg_out = bg;
     {
         uint8_t buf[10];
         size_t l = strlen(id);
@@ -397,7 +450,23 @@ int lmo_builder_finish(lmo_builder *b) {
     char p[4096];
     snprintf(p, sizeof p, "%s/genomes.chunks.bin", b->dir);
     FILE *f = fopen(p, "wb");
-    if (f) fclose(f);
+    if (f) { /* repeated: u64 n, n x u64 batch+index, big-endian (lib-index-build.go:1795-1806) */
+        int at = 0;
+        for (int l = 0; l < b->nchunk_lists; l++) {
+            uint8_t buf[8];
+            uint64_t n = (uint64_t)b->chunk_list_len[l];
+            for (int i = 0; i < 8; i++) buf[i] = (uint8_t)(n >> (56 - 8 * i));
+            fwrite(buf, 1, 8, f);
+            for (int j = 0; j < b->chunk_list_len[l]; j++) {
+                uint64_t v = b->chunk_keys[at++];
+                for (int i = 0; i < 8; i++) buf[i] = (uint8_t)(v >> (56 - 8 * i));
+                fwrite(buf, 1, 8, f);
+            }
+        }
+        fclose(f);
+    }
+    free(b->chunk_keys);
+    free(b->chunk_list_len);
     int nbatches = (b->ngenomes + o->batch_size - 1) / o->batch_size;
     int mask_prefix = b->lh->p;
     int anchor_prefix = 1;
@@ -469,7 +538,7 @@ int lmo_builder_finish(lmo_builder *b) {
                 "genome-batch-size = %d\ngenome-batches = %d\ncontig-interval = %d\nsoft-masking = false\n"
                 "max-kmer-freq = 0\n",
                 o->k, o->masks, (long long)o->rand_seed, o->max_desert, o->seed_dist, nchunks_written, o->partitions,
-                b->ngenomes, (long long)b->input_bases, b->ngenomes, o->batch_size, nbatches, o->contig_interval);
+                b->ninput, (long long)b->input_bases, b->ngenomes, o->batch_size, nbatches, o->contig_interval);
         fclose(f);
     }
     lmo_lh_free(b->lh);

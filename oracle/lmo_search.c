@@ -52,7 +52,29 @@ struct lmo_index {
     int contig_interval;
     lmo_cmp_opt cmpopt;
     float chain_min_score;
+    /* genome chunks (genomes.chunks.bin, lib-index-search.go:504-538): key -> list number, #chunks, chunk index */
+    int has_chunks, nchunk_ent;
+    struct chunk_ent {
+        uint64_t key;
+        int list, n, idx;
+    } *chunk_ents; /* sorted by key */
 };
+
+static int cmp_chunk_ent(const void *a, const void *b) {
+    uint64_t x = ((const struct chunk_ent *)a)->key, y = ((const struct chunk_ent *)b)->key;
+    return x < y ? -1 : x > y;
+}
+static const struct chunk_ent *find_chunk(const lmo_index *idx, uint64_t key) {
+    int lo = 0, hi = idx->nchunk_ent;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (idx->chunk_ents[mid].key < key)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo < idx->nchunk_ent && idx->chunk_ents[lo].key == key ? &idx->chunk_ents[lo] : NULL;
+}
 
 int lmo_index_k(const lmo_index *idx) { return idx->k; }
 int lmo_index_nmasks(const lmo_index *idx) { return idx->M; }
@@ -179,6 +201,35 @@ lmo_index *lmo_index_open(const char *dir, const lmo_search_opt *opt) {
         }
         fclose(f);
         qsort(idx->ids, idx->nids, sizeof(idmap_ent), cmp_idmap);
+    }
+    /* genome chunk lists (readGenomeChunksLists, lib-index-build.go:2193-2245) */
+    snprintf(p, sizeof p, "%s/genomes.chunks.bin", dir);
+    f = fopen(p, "rb");
+    if (f) {
+        uint8_t b[8];
+        int cap = 0, list = 0;
+        while (fread(b, 1, 8, f) == 8) {
+            uint64_t n = 0;
+            for (int i = 0; i < 8; i++) n = (n << 8) | b[i];
+            for (uint64_t j = 0; j < n; j++) {
+                if (fread(b, 1, 8, f) != 8) break;
+                uint64_t key = 0;
+                for (int i = 0; i < 8; i++) key = (key << 8) | b[i];
+                if (idx->nchunk_ent == cap) {
+                    cap = cap ? cap * 2 : 16;
+                    idx->chunk_ents = (struct chunk_ent *)realloc(idx->chunk_ents, sizeof(struct chunk_ent) * cap);
+                }
+                idx->chunk_ents[idx->nchunk_ent].key = key;
+                idx->chunk_ents[idx->nchunk_ent].list = list;
+                idx->chunk_ents[idx->nchunk_ent].n = (int)n;
+                idx->chunk_ents[idx->nchunk_ent].idx = (int)j;
+                idx->nchunk_ent++;
+            }
+            list++;
+        }
+        fclose(f);
+        idx->has_chunks = idx->nchunk_ent > 0;
+        if (idx->has_chunks) qsort(idx->chunk_ents, idx->nchunk_ent, sizeof(struct chunk_ent), cmp_chunk_ent);
     }
     /* SeqComparatorOptions, search.go:360-382 */
     idx->cmpopt.k = 31;
@@ -392,6 +443,7 @@ typedef struct {
     lmo_chain2 *chains;
     int nchains;
     int seq_idx, nseqs, seq_len;
+    int nchunks, chunk_idx; /* :1118-1119, set at :2375-2385 / :2643-2653 */
     char *seq_id;
 } simdetail; /* SimilarityDetail :1099-1120 */
 
@@ -596,8 +648,42 @@ static int finalize_chains(lmo_index *idx, const uint8_t *s, int qlen, lmo_genom
     return has_result;
 }
 
-static void add_sd(sresult *r, lmo_genome *tseq, int iseq, int rc, int nseeds, double max_sim, lmo_chain2 *chains,
-                   int n) {
+/* aligned bases of the query over all HSPs of the genome (:2701-2738, again at :2855-2890); 0 = filtered out */
+static int genome_qcov_filter(sresult *r, int qlen, double min_qcov_genome) {
+    int nreg = 0;
+    for (int i = 0; i < r->nsds; i++)
+        for (int j = 0; j < r->sds[i].nchains; j++)
+            if (r->sds[i].chains[j].alive) nreg++;
+    int(*regions)[2] = (int(*)[2])malloc(sizeof(int[2]) * (nreg ? nreg : 1));
+    nreg = 0;
+    for (int i = 0; i < r->nsds; i++)
+        for (int j = 0; j < r->sds[i].nchains; j++)
+            if (r->sds[i].chains[j].alive) {
+                regions[nreg][0] = r->sds[i].chains[j].qbegin;
+                regions[nreg][1] = r->sds[i].chains[j].qend;
+                nreg++;
+            }
+    int ab = lmo_coverage_len(regions, nreg);
+    free(regions);
+    r->aligned_fraction = (double)ab / (double)qlen * 100;
+    if (r->aligned_fraction > 100) r->aligned_fraction = 100;
+    return r->aligned_fraction >= min_qcov_genome;
+}
+/* HSP clusters by SimilarityScore descending (:2745, :2895), stable */
+static void sort_sds(sresult *r) {
+    for (int i = 1; i < r->nsds; i++) {
+        simdetail x = r->sds[i];
+        int j = i - 1;
+        while (j >= 0 && r->sds[j].similarity_score < x.similarity_score) {
+            r->sds[j + 1] = r->sds[j];
+            j--;
+        }
+        r->sds[j + 1] = x;
+    }
+}
+
+static void add_sd(const lmo_index *idx, sresult *r, lmo_genome *tseq, int iseq, int rc, int nseeds, double max_sim,
+                   lmo_chain2 *chains, int n) {
     if (r->nsds == r->capsds) {
         r->capsds = r->capsds ? r->capsds * 2 : 4;
         r->sds = (simdetail *)realloc(r->sds, sizeof(simdetail) * r->capsds);
@@ -612,6 +698,15 @@ static void add_sd(sresult *r, lmo_genome *tseq, int iseq, int rc, int nseeds, d
     sd->nseqs = tseq->nseqs;
     sd->seq_len = tseq->seq_sizes[iseq];
     sd->seq_id = strdup(tseq->seq_ids[iseq]);
+    sd->nchunks = 1;
+    sd->chunk_idx = 0;
+    if (idx->has_chunks) {
+        const struct chunk_ent *ce = find_chunk(idx, r->bg);
+        if (ce) {
+            sd->nchunks = ce->n;
+            sd->chunk_idx = ce->idx;
+        }
+    }
 }
 
 static int akey_seen(akey **keys, int *nk, int *capk, akey k) {
@@ -774,7 +869,7 @@ static void align_genome(lmo_index *idx, const uint8_t *s, int qlen, lmo_cmp *cp
                         double max_sim;
                         int has = finalize_chains(idx, s, qlen, tseq, tBegin, tEnd, rc, cur, ncur, 1, &max_sim);
                         if (has) {
-                            add_sd(r, tseq, iSeq, rc, nseeds, max_sim, cur, ncur);
+                            add_sd(idx, r, tseq, iSeq, rc, nseeds, max_sim, cur, ncur);
                         } else {
                             for (int z = 0; z < ncur; z++) free_chain2(&cur[z]);
                             free(cur);
@@ -837,7 +932,7 @@ static void align_genome(lmo_index *idx, const uint8_t *s, int qlen, lmo_cmp *cp
                 double max_sim;
                 int has = finalize_chains(idx, s, qlen, tseq, tBegin, tEnd, rc, cur, ncur, 0, &max_sim);
                 if (has) {
-                    add_sd(r, tseq, iSeq, rc, nseeds, max_sim, cur, ncur);
+                    add_sd(idx, r, tseq, iSeq, rc, nseeds, max_sim, cur, ncur);
                     used = 1;
                 }
             }
@@ -855,38 +950,12 @@ static void align_genome(lmo_index *idx, const uint8_t *s, int qlen, lmo_cmp *cp
         r->alive = 0;
         return;
     }
-    /* query coverage per genome (:2701-2738) */
-    int nreg = 0;
-    for (int i = 0; i < r->nsds; i++)
-        for (int j = 0; j < r->sds[i].nchains; j++)
-            if (r->sds[i].chains[j].alive) nreg++;
-    int(*regions)[2] = (int(*)[2])malloc(sizeof(int[2]) * (nreg ? nreg : 1));
-    nreg = 0;
-    for (int i = 0; i < r->nsds; i++)
-        for (int j = 0; j < r->sds[i].nchains; j++)
-            if (r->sds[i].chains[j].alive) {
-                regions[nreg][0] = r->sds[i].chains[j].qbegin;
-                regions[nreg][1] = r->sds[i].chains[j].qend;
-                nreg++;
-            }
-    int ab = lmo_coverage_len(regions, nreg);
-    free(regions);
-    r->aligned_fraction = (double)ab / (double)qlen * 100;
-    if (r->aligned_fraction > 100) r->aligned_fraction = 100;
-    if (r->aligned_fraction < o->min_qcov_genome) {
+    /* query coverage per genome (:2701-2738); with genome chunks in the index it is computed after the chunk merge */
+    if (!idx->has_chunks && !genome_qcov_filter(r, qlen, o->min_qcov_genome)) {
         r->alive = 0;
         return;
     }
-    /* sort HSP clusters by SimilarityScore desc (:2745), stable */
-    for (int i = 1; i < r->nsds; i++) {
-        simdetail x = r->sds[i];
-        int j = i - 1;
-        while (j >= 0 && r->sds[j].similarity_score < x.similarity_score) {
-            r->sds[j + 1] = r->sds[j];
-            j--;
-        }
-        r->sds[j + 1] = x;
-    }
+    sort_sds(r);
 }
 
 /* SortBySeqID :1042-1096: regroup clusters by sseqid preserving first-seen order */
@@ -1038,7 +1107,45 @@ int lmo_search(lmo_index *idx, const uint8_t *seq, int len, lmo_result *res) {
         free(rs);
         return 0;
     }
-    /* genome chunks merge (:2798-2913) is a no-op: the synthetic-index writer never splits genomes */
+    /* merge the results of the chunks of one split genome (:2798-2913). The reference merges into whichever chunk comes
+     * first in its goroutine-arrival-ordered list; here the list is in genome order, so the first chunk of the genome. */
+    if (idx->has_chunks) {
+        for (int i = 0; i < nrs; i++) {
+            if (!rs[i].alive) continue;
+            const struct chunk_ent *ci = find_chunk(idx, rs[i].bg);
+            if (!ci) continue;
+            for (int j = i + 1; j < nrs; j++) {
+                if (!rs[j].alive) continue;
+                const struct chunk_ent *cj = find_chunk(idx, rs[j].bg);
+                if (!cj || cj->list != ci->list) continue;
+                /* only SimilarityDetails and AlignedFraction need updating (:2832-2840) */
+                for (int a = 0; a < rs[j].nsds; a++) {
+                    if (rs[i].nsds == rs[i].capsds) {
+                        rs[i].capsds = rs[i].capsds ? rs[i].capsds * 2 : 4;
+                        rs[i].sds = (simdetail *)realloc(rs[i].sds, sizeof(simdetail) * rs[i].capsds);
+                    }
+                    rs[i].sds[rs[i].nsds++] = rs[j].sds[a];
+                }
+                rs[j].nsds = 0;
+                rs[j].alive = 0;
+            }
+        }
+        /* recompute the query coverage per genome, filter, re-sort the clusters (:2853-2897): every result, merged or not */
+        n2 = 0;
+        for (int i = 0; i < nrs; i++) {
+            if (rs[i].alive && genome_qcov_filter(&rs[i], len, idx->opt.min_qcov_genome)) {
+                sort_sds(&rs[i]);
+                rs[n2++] = rs[i];
+            } else {
+                free_sresult(&rs[i]);
+            }
+        }
+        nrs = n2;
+        if (nrs == 0) {
+            free(rs);
+            return 0;
+        }
+    }
     qsort(rs, nrs, sizeof(sresult), cmp_best_sim);
     for (int i = 0; i < nrs; i++) sort_by_seqid(&rs[i]);
     /* flatten to rows in printing order (search.go:468-523) */
@@ -1064,8 +1171,8 @@ int lmo_search(lmo_index *idx, const uint8_t *seq, int len, lmo_result *res) {
                 h->seq_idx = sd->seq_idx;
                 h->nseqs = sd->nseqs;
                 h->seq_len = sd->seq_len;
-                h->nchunks = 1;
-                h->chunk_idx = 0;
+                h->nchunks = sd->nchunks;
+                h->chunk_idx = sd->chunk_idx;
                 h->rc = sd->rc;
                 h->qcov_hsp = c->aligned_fraction;
                 h->aligned_length = c->aligned_length;

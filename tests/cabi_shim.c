@@ -8,6 +8,7 @@
  *
  *   usage: cabi_shim <index dir> <fasta>      (prints one TSV line per HSP row, default columns)
  */
+#define _POSIX_C_SOURCE 200809L
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>

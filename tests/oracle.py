@@ -26,7 +26,7 @@ def build(force=False):
 class BuildOpt(C.Structure):
     _fields_ = [("k", C.c_int), ("masks", C.c_int), ("rand_seed", C.c_int64), ("max_desert", C.c_int),
                 ("seed_dist", C.c_int), ("chunks", C.c_int), ("partitions", C.c_int), ("batch_size", C.c_int),
-                ("contig_interval", C.c_int)]
+                ("contig_interval", C.c_int), ("max_genome", C.c_int)]
 
 
 class SearchOpt(C.Structure):

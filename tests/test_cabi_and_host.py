@@ -28,6 +28,30 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
 
 
+def test_header_is_plain_c_and_the_shim_sequence_links(tmp_path):
+    """f2: cgo compiles its preamble with a C compiler. The header must be valid C99 (no C++-isms, no duplicate
+    typedefs) and the call sequence of the cgo shim of INTEGRATION.md - restated in C in tests/cabi_shim.c, since no Go
+    toolchain exists here - must compile without warnings and link against the library with C linkage."""
+    import lexicmap_amd as la
+    la.build_library()
+    inc = os.path.join(ROOT, "include")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", HDR],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    exe = str(tmp_path / "cabi_shim")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc,
+                        os.path.join(ROOT, "tests", "cabi_shim.c"), "-L", os.path.dirname(la.LIB_PATH), "-llexicmap_hip",
+                        "-Wl,-rpath," + os.path.dirname(la.LIB_PATH), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    # without a GPU the shim must fail the way the Go shim would report it: status != OK and the library's message
+    import torch
+    if not torch.cuda.is_available():
+        fa = tmp_path / "q.fa"
+        fa.write_text(">q\nACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT\n")
+        r = subprocess.run([exe, str(tmp_path), str(fa)], capture_output=True, text=True)
+        assert r.returncode == 1 and "no CPU path" in r.stderr
+
+
 def test_no_gpu_means_loud_failure_not_fallback(tmp_path):
     import torch
     if torch.cuda.is_available():
