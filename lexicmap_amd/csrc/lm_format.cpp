@@ -110,7 +110,7 @@ static std::string load_chunk(const std::string &path, const HostIndex &idx, con
     }
     size_t p = 32;
     const size_t n = buf.size();
-    const int sc = idx.shard_count, sr = idx.shard_rank;
+    const int sc = idx.shard_count;
     for (int64_t im = 0; im < nmask; im++) {
         if (p + 8 > n) {
             status = 2;
@@ -154,8 +154,8 @@ static std::string load_chunk(const std::string &path, const HostIndex &idx, con
                     if (sc > 1) {
                         uint64_t bg = v >> 30;
                         uint64_t batch = bg >> 17, gi = bg & 0x1ffff;
-                        int64_t g = (batch < batch_first.size() ? batch_first[batch] : 0) + (int64_t)gi;
-                        if ((int)(g % sc) != sr) continue;
+                        int64_t g = (batch + 1 < batch_first.size() ? batch_first[batch] : 0) + (int64_t)gi;
+                        if (g < 0 || g >= (int64_t)idx.g2local.size() || idx.g2local[(size_t)g] < 0) continue;
                     }
                     K.push_back(kmer);
                     V.push_back(v);
@@ -250,6 +250,56 @@ std::string load_index(const std::string &dir, int shard_rank, int shard_count, 
         status = 1;
         return "failed to read " + dir + "/genomes.map.bin";
     }
+    // pass 1: genomes per batch -> dense numbers; genome chunk lists -> shard of every genome
+    {
+        int64_t g0 = 0;
+        for (int b = 0; b < out.genome_batches; b++) {
+            char name[64];
+            snprintf(name, sizeof name, "/genomes/batch_%04d/genomes.bin.idx", b);
+            std::vector<uint8_t> ib;
+            if (!read_all(dir + name, ib) || ib.size() < 24 || memcmp(ib.data(), ".genomei", 8) != 0) {
+                status = ib.empty() ? 1 : 2;
+                return std::string("genome data: invalid binary format: ") + name;
+            }
+            out.batch_first[b] = g0;
+            g0 += be32(&ib[20]);
+        }
+        out.batch_first[out.genome_batches] = g0;
+        std::vector<int64_t> canon((size_t)g0);
+        for (int64_t g = 0; g < g0; g++) canon[(size_t)g] = g;
+        std::vector<uint8_t> cb;
+        if (read_all(dir + "/genomes.chunks.bin", cb) && !cb.empty()) { // readGenomeChunksLists, lib-index-build.go:2193-2245
+            size_t p = 0;
+            int list = 0;
+            while (p + 8 <= cb.size()) {
+                const uint64_t n = be64(&cb[p]);
+                p += 8;
+                if (n > (cb.size() - p) / 8) {
+                    status = 2;
+                    return "broken genome chunk file";
+                }
+                int64_t first = -1;
+                for (uint64_t j = 0; j < n; j++, p += 8) {
+                    const uint64_t key = be64(&cb[p]);
+                    out.chunk_of[key] = HostIndex::ChunkInfo{list, (int)n, (int)j};
+                    const uint64_t batch = key >> 17, gi = key & 0x1ffff;
+                    if (batch >= (uint64_t)out.genome_batches) continue;
+                    const int64_t g = out.batch_first[batch] + (int64_t)gi;
+                    if (g >= g0) continue;
+                    if (first < 0) first = g;
+                    canon[(size_t)g] = first;
+                }
+                list++;
+            }
+            out.has_chunks = !out.chunk_of.empty();
+        }
+        if (shard_count > 1) {
+            out.g2local.assign((size_t)g0, -1);
+            int32_t nl = 0;
+            for (int64_t g = 0; g < g0; g++)
+                if ((int)(canon[(size_t)g] % shard_count) == shard_rank) out.g2local[(size_t)g] = nl++;
+        }
+    }
     int64_t global = 0;
     for (int b = 0; b < out.genome_batches; b++) {
         char name[64];
@@ -268,7 +318,7 @@ std::string load_index(const std::string &dir, int shard_rank, int shard_count, 
         for (uint32_t r = 0; r < nrec; r++, global++) {
             // a shard keeps the bases of its own genomes only, but the names and sizes of all of them: rank 0 prints the
             // merged rows of every shard (lm_merge_sharded)
-            const bool local = (int)(global % shard_count) == shard_rank;
+            const bool local = out.g2local.empty() || out.g2local[(size_t)global] >= 0;
             if (24 + (size_t)r * 12 + 12 > ib.size()) {
                 status = 2;
                 return "genome data: broken file (index)";

@@ -36,6 +36,15 @@ struct HostIndex {
     // names / contig tables of the genomes held by the OTHER shards (no bases), keyed by batch<<17|index
     std::vector<HostGenome> others;
     std::unordered_map<uint64_t, int> other_of;
+    // genome chunks (genomes.chunks.bin, lib-index-search.go:504-538): key -> {list number, #chunks, chunk index}
+    struct ChunkInfo {
+        int list, n, idx;
+    };
+    std::unordered_map<uint64_t, ChunkInfo> chunk_of;
+    bool has_chunks = false;
+    // dense genome number -> local number on this shard (-1: another shard's); empty when unsharded. The chunks of a split
+    // genome stay together: a genome goes to shard (dense number of its FIRST chunk) % shard_count.
+    std::vector<int32_t> g2local;
     bool synthetic = false;        // built by lm_index_build_synthetic: names are a function of the genome number
     int64_t synth_genomes = 0;
     int32_t synth_genome_len = 0;

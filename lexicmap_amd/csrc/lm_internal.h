@@ -136,12 +136,12 @@ struct lm_index {
     HostIndex host;
     lm_options opt;
     int device = 0;
-    hipStream_t st = nullptr;
+    hipStream_t st = nullptr, st2 = nullptr; // st2: the pseudo-alignment producer of the alignment pipeline
     std::string err;
     // HBM image
     DBuf<uint64_t> d_masks, d_pk_keys, d_pk_vals, d_out_kmers, d_out_vals, d_g_bg;
     DBuf<uint32_t> d_part_tab, d_g_keep;
-    DBuf<int32_t> d_pfx_first, d_g_len;
+    DBuf<int32_t> d_pfx_first, d_g_len, d_g2local;
     DBuf<int64_t> d_md_off, d_out_off, d_g_off, d_batch_first;
     int64_t n_seeds = 0, n_seeds_outlier = 0, seed_bytes = 0; // resident seeds; bytes of the whole seed image
     int64_t scratch_budget = 0; // device memory left for per-batch scratch once the index image is resident
@@ -151,7 +151,7 @@ struct lm_index {
     DevIndexView view;
     int64_t hbm_bytes = 0;
     // scratch
-    DBuf<uint8_t> tmp; // rocPRIM temporary storage
+    DBuf<uint8_t> tmp, tmp2; // rocPRIM temporary storage (per stream)
     // profiling
     bool prof = false;
     std::mutex prof_mu;

@@ -35,6 +35,7 @@ struct DevIndexView {
     int nbatches;
     int64_t ngenomes;           // local
     int shard_rank, shard_count;
+    const int32_t *g2local;     // dense genome number -> local number (-1: other shard), or null: g % count == rank, g / count
 };
 
 struct Task { // one lexichash chain of one (query, genome): the pseudo-alignment problem
@@ -123,7 +124,7 @@ int extend_grid_blocks(int64_t n);
 void launch_extend(hipStream_t st, const HspIn *hsps, int64_t n, const uint8_t *qseq, const int64_t *qoff,
                    const uint8_t *wbuf, const int32_t *cap, const int64_t *woff, uint16_t *subs, int32_t *msi,
                    void *rows_pool, uint32_t *rstart_pool, HspExt *out);
-// k_wfa_lean<nc>: persistent wavefronts with private scratch, <= 64 nc - 2 diagonals (status 3 beyond); nc = 2, 4 or 8
+// k_wfa_lean<nc>: persistent wavefronts with private scratch, <= 64 nc - 2 diagonals (status 3 beyond); nc = 2, 4, 8 or 16
 int wfa_resident_blocks(int device, int seq_words, int nc = 2);
 void launch_wfa(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks,
                 int32_t *hdr_pool, int64_t hdr_stride, uint8_t *arena_pool, int64_t arena_stride, uint64_t *ops_pool,

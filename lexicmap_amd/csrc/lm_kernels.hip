@@ -175,6 +175,7 @@ __device__ __forceinline__ int local_genome(const DevIndexView &ix, uint64_t bg)
     uint64_t batch = bg >> 17, gi = bg & 0x1ffff;
     if (batch >= (uint64_t)ix.nbatches) return -1;
     int64_t g = ix.batch_first[batch] + (int64_t)gi;
+    if (ix.g2local) return g < ix.batch_first[ix.nbatches] ? ix.g2local[g] : -1; // chunk-aware shard table (loader)
     if (ix.shard_count > 1) {
         if ((int)(g % ix.shard_count) != ix.shard_rank) return -1;
         g /= ix.shard_count;
@@ -182,7 +183,6 @@ __device__ __forceinline__ int local_genome(const DevIndexView &ix, uint64_t bg)
     if (g >= ix.ngenomes) return -1;
     return (int)g;
 }
-
 __device__ __forceinline__ bool genome_kept(const DevIndexView &ix, int64_t g) {
     return g >= 0 && ((ix.g_keep[g >> 5] >> (g & 31)) & 1u) != 0;
 }
@@ -1904,7 +1904,7 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                                                   uint8_t *__restrict__ arena_pool, int64_t arena_stride,
                                                   uint64_t *__restrict__ ops_pool, unsigned int *__restrict__ queue,
                                                   int seq_words, int want_ops, WfaOut *__restrict__ out) {
-    static_assert(NC == 1 || NC == 2 || NC == 4 || NC == 8, "1, 2, 4 or 8 cells per lane");
+    static_assert(NC == 1 || NC == 2 || NC == 4 || NC == 8 || NC == 16, "1, 2, 4, 8 or 16 cells per lane");
     constexpr int W = 64 * NC;
     // All penalties are even (x=4, o+e=8, e=2): only even scores have wavefronts, so the ring holds the last five even
     // M scores (s, s-2, .. s-8) and the last two I / D scores, and the score loop steps by 2. (Odd scores are empty
@@ -2428,7 +2428,10 @@ static int resident_blocks_of(const void *kern, int device, int seq_words) {
     return nb * cus;
 }
 int wfa_resident_blocks(int device, int seq_words, int nc) {
-    return resident_blocks_of(nc == 8 ? (const void *)k_wfa_lean<8> : nc == 4 ? (const void *)k_wfa_lean<4> : (const void *)k_wfa_lean<2>,
+    return resident_blocks_of(nc == 16  ? (const void *)k_wfa_lean<16>
+                              : nc == 8 ? (const void *)k_wfa_lean<8>
+                              : nc == 4 ? (const void *)k_wfa_lean<4>
+                                        : (const void *)k_wfa_lean<2>,
                               device, seq_words);
 }
 void launch_wfa(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks,
@@ -2436,7 +2439,10 @@ void launch_wfa(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo,
                 unsigned int *queue, int seq_words, int want_ops, WfaOut *out, int nc) {
     // two packed sequences with one padding word each, +2 words: the predicated extension may read one word past
     size_t dyn = (size_t)(2 * (seq_words + 1) + 2) * sizeof(uint32_t);
-    if (nc == 8)
+    if (nc == 16)
+        hipLaunchKernelGGL(k_wfa_lean<16>, dim3(nblocks), dim3(64), dyn, st, in, n, todo, ntodo, hdr_pool, hdr_stride, arena_pool,
+                           arena_stride, ops_pool, queue, seq_words, want_ops, out);
+    else if (nc == 8)
         hipLaunchKernelGGL(k_wfa_lean<8>, dim3(nblocks), dim3(64), dyn, st, in, n, todo, ntodo, hdr_pool, hdr_stride, arena_pool,
                            arena_stride, ops_pool, queue, seq_words, want_ops, out);
     else if (nc == 4)

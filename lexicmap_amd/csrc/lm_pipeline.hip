@@ -29,6 +29,7 @@
 #include "lm_prims.h"
 #include <atomic>
 #include <condition_variable>
+#include <deque>
 #include <functional>
 #include <memory>
 #include <exception>
@@ -669,6 +670,8 @@ struct HChain { // Chain2Result (lib-chaining2.go:106-135) as it moves through f
 struct HCluster { // SimilarityDetail (:1099-1120)
     bool rc = false, variant_a = false, has_result = false;
     int nseeds = 0, seq_idx = 0;
+    int g = -1;                     // local genome record of this cluster (differs from the result's after a chunk merge)
+    int nchunks = 1, chunk_idx = 0; // :1118-1119
     double sim = 0;
     int tBegin = 0, tEnd = 0; // chain window
     int64_t task = -1;
@@ -728,6 +731,14 @@ static void glue_task(const lm_index *ix, HGenome &gen, std::map<AKey, bool> &ke
         cur.tEnd = tEnd;
         cur.task = task_id;
         cur.variant_a = variant_a;
+        cur.g = t.g;
+        if (ix->host.has_chunks) { // :2375-2385 / :2643-2653
+            auto it = ix->host.chunk_of.find(t.bg);
+            if (it != ix->host.chunk_of.end()) {
+                cur.nchunks = it->second.n;
+                cur.chunk_idx = it->second.idx;
+            }
+        }
     };
     new_cluster(false);
     auto convert = [&](HChain &c, int qb, int qe, int tb, int te, int iseq) {
@@ -959,9 +970,11 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
         h2d(ix, ix->d_g_len, glen);
         h2d(ix, ix->d_g_bg, gbg);
         h2d(ix, ix->d_batch_first, h.batch_first);
+        if (!h.g2local.empty()) h2d(ix, ix->d_g2local, h.g2local);
         lm_fill_gap_lut(ix);
         sync(ix);
         DevIndexView &v = ix->view;
+        v.g2local = h.g2local.empty() ? nullptr : ix->d_g2local.p;
         v.K = h.k;
         v.M = h.M;
         v.mask_prefix = h.mask_prefix;
@@ -1036,6 +1049,7 @@ void lm_index_close(lm_index *ix) {
     delete ix->work;
     lm_free_align_ctx(ix); // AlignCtx is defined further down
     if (ix->st) (void)hipStreamDestroy(ix->st);
+    if (ix->st2) (void)hipStreamDestroy(ix->st2);
     delete ix;
 }
 
@@ -1338,9 +1352,9 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
         a.pa_cap = TP + TP / 8;
     }
     a.stats->pa_anchors += TP;
-    // too many anchors for one chunk (31-bit indices, ~90 B of scratch each within a quarter of the budget): the caller
-    // halves the chunk
-    if (TP >= (int64_t)1 << 31 || (ix->scratch_budget > 0 && TP * 90 > ix->scratch_budget * 22 / 100)) {
+    // too many anchors for one chunk (31-bit indices, ~90 B of scratch each within 13 % of the budget - two chunks are in
+    // flight): the caller halves the chunk
+    if (TP >= (int64_t)1 << 31 || (ix->scratch_budget > 0 && TP * 90 > ix->scratch_budget * 13 / 100)) {
         if (nt <= 1) throw HipError("too many pseudo-alignment anchors for one chain window");
         throw ChunkTooLarge();
     }
@@ -1450,8 +1464,8 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
     ops_h.clear();
     if (n == 0) return;
     // scratch: the LDS passes and the global-memory fallback run at the same time
-    const int64_t lean_budget = ix->scratch_budget > 0 ? std::min<int64_t>(a.wfa_budget, ix->scratch_budget * 28 / 100) : a.wfa_budget;
-    const int64_t wide_budget = ix->scratch_budget > 0 ? std::min<int64_t>((int64_t)72 << 30, ix->scratch_budget * 12 / 100) : (int64_t)72 << 30;
+    const int64_t lean_budget = ix->scratch_budget > 0 ? std::min<int64_t>(a.wfa_budget, ix->scratch_budget * 26 / 100) : a.wfa_budget;
+    const int64_t wide_budget = ix->scratch_budget > 0 ? std::min<int64_t>((int64_t)72 << 30, ix->scratch_budget * 10 / 100) : (int64_t)72 << 30;
     a.wfa_out.ensure((size_t)n);
     a.wfa_in.ensure((size_t)n);
     std::vector<std::vector<uint64_t>> ops_keep(want_ops ? n : 0);
@@ -1664,18 +1678,19 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
             // ring width by experience: alignments of tens of kb at ONT error rates run wavefronts of several hundred
             // diagonals under wf-adaptive(10,50) (all of the >= 32-kb class and two thirds of the 8-32-kb class outgrow 126),
             // gene-sized ones stay below 126.  A pass that turns out too narrow returns status 3 and the next width takes over.
-            std::vector<int32_t> w1, w2, w3;
+            std::vector<int32_t> w1, w2, w3, w4;
             const int first = c == 3 ? 8 : (c == 2 ? 4 : 2);
             if (first == 2) {
                 persistent_pass(cls[c], cw[c], cl[c], w1, 2);
                 persistent_pass(w1, cw[c], cl[c], w2, 4);
-                persistent_pass(w2, cw[c], cl[c], w3, 8);
+                persistent_pass(w2, cw[c], cl[c], w4, 8);
             } else if (first == 4) {
                 persistent_pass(cls[c], cw[c], cl[c], w2, 4);
-                persistent_pass(w2, cw[c], cl[c], w3, 8);
+                persistent_pass(w2, cw[c], cl[c], w4, 8);
             } else {
-                persistent_pass(cls[c], cw[c], cl[c], w3, 8);
+                persistent_pass(cls[c], cw[c], cl[c], w4, 8);
             }
+            persistent_pass(w4, cw[c], cl[c], w3, 16); // 1022 diagonals: the last LDS width
             for (int32_t i : w3) { // the hard ones: generous scratch at once instead of an overflow and a second launch
                 fb_items.push_back(i);
                 fb_level.push_back(2);
@@ -1798,42 +1813,147 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
     // and its WFA launches scale with it; long alignments are latency-bound per problem, so few large chunks beat many
     // small ones (each chunk ends with a tail of a few 50-kb alignments running alone)
     int64_t max_window_bytes = ix->scratch_budget > 0
-                                   ? std::min<int64_t>((int64_t)8 << 30, std::max<int64_t>((int64_t)1 << 30, ix->scratch_budget / 24))
+                                   ? std::min<int64_t>((int64_t)16 << 30, std::max<int64_t>((int64_t)1 << 30, ix->scratch_budget * 5 / 100))
                                    : (int64_t)2 << 30;
     if (const char *e = getenv("LM_DEBUG_MAX_WINDOW_BYTES")) max_window_bytes = std::max<int64_t>(1, atoll(e)); // test hook
     const bool want_seq = ix->opt.output_seq != 0;
-    int64_t tpos = r0;
-    while (tpos < r1) {
-        // chunk [tpos, tend): whole segments, bounded window bytes
-        int64_t tend = tpos, wb = 0;
-        while (tend < r1) {
-            int64_t e = tend;
-            uint32_t seg = tasks_h[tend].seg;
-            int64_t segw = 0;
-            while (e < r1 && tasks_h[e].seg == seg) segw += tasks_h[e++].wlen;
-            if (tend > tpos && wb + segw > max_window_bytes) break;
-            wb += segw;
-            tend = e;
-        }
-        // host and device task lists are used in place: window offsets are global, this chunk's slice starts at `base`
-        TaskSpan ht;
-        ht.p = tasks_h.p + tpos;
-        ht.n = (size_t)(tend - tpos);
-        const int64_t base = ht[0].woff;
-        const int64_t off = ht.back().woff + ht.back().wlen - base; // window bytes of the chunk
+    // ---- two-stage pipeline over the chunks: a producer thread runs the pseudo-alignment of chunk c+1 on its own stream and
+    // context while this thread takes chunk c through glue -> extendMatch -> WFA -> finalisation.  The WFA passes end in
+    // tails of a few long alignments that leave most CUs idle; the anchor kernel of the next chunk fills them.
+    struct PaChunk {
+        int64_t tpos = 0, tend = 0, base = 0, off = 0;
         std::vector<int64_t> res_off;
         std::vector<LmChain2> resv;
-        double ta = now_ms();
+        int slot = 0;
+    };
+    AlignCtx *ctxs[2] = {&a, &get_actx(ix, qb, &w, &st, 1)};
+    std::mutex pm;
+    std::condition_variable pcv;
+    std::deque<PaChunk> ready;
+    bool slot_free[2] = {true, true}, prod_done = false, cons_abort = false;
+    std::exception_ptr prod_err;
+    double ms_pseudo = 0;
+    const int64_t total_window = r1 > r0 ? tasks_h[r1 - 1].woff + tasks_h[r1 - 1].wlen - tasks_h[r0].woff : 0;
+    const bool pipelined = total_window > max_window_bytes && !getenv("LM_NO_PIPELINE");
+    auto producer = [&]() {
         try {
-            run_pseudo(a, ht, res_off, resv, w.tasks.p + tpos, base);
-        } catch (const ChunkTooLarge &) { // same tasks again in smaller chunks
-            if (ht[0].seg == ht.back().seg) throw HipError("too many pseudo-alignment anchors for one (query, genome) pair");
-            max_window_bytes = std::max<int64_t>(off / 2, 1);
-            if (getenv("LM_DEBUG")) fprintf(stderr, "[lm] alignment chunk halved to %lld window bytes\n", (long long)max_window_bytes);
-            continue;
+            if (pipelined) {
+                HIPCHK(hipSetDevice(ix->device));
+                if (!ix->st2) HIPCHK(hipStreamCreate(&ix->st2));
+                tls_stream = ix->st2;
+                tls_tmp = &ix->tmp2;
+            }
+            int64_t tpos = r0;
+            int slot = 0;
+            while (tpos < r1) {
+                // chunk [tpos, tend): whole segments, bounded window bytes
+                int64_t tend = tpos, wb = 0;
+                while (tend < r1) {
+                    int64_t e = tend;
+                    uint32_t seg = tasks_h[tend].seg;
+                    int64_t segw = 0;
+                    while (e < r1 && tasks_h[e].seg == seg) segw += tasks_h[e++].wlen;
+                    if (tend > tpos && wb + segw > max_window_bytes) break;
+                    wb += segw;
+                    tend = e;
+                }
+                {
+                    std::unique_lock<std::mutex> l(pm);
+                    pcv.wait(l, [&] { return slot_free[slot] || cons_abort; });
+                    if (cons_abort) break;
+                }
+                // host and device task lists are used in place: window offsets are global, this chunk's slice starts at `base`
+                PaChunk pc;
+                pc.tpos = tpos;
+                pc.tend = tend;
+                pc.slot = slot;
+                TaskSpan ht;
+                ht.p = tasks_h.p + tpos;
+                ht.n = (size_t)(tend - tpos);
+                pc.base = ht[0].woff;
+                pc.off = ht.back().woff + ht.back().wlen - pc.base; // window bytes of the chunk
+                const double ta = now_ms();
+                try {
+                    run_pseudo(*ctxs[slot], ht, pc.res_off, pc.resv, w.tasks.p + tpos, pc.base);
+                } catch (const ChunkTooLarge &) { // same tasks again in smaller chunks
+                    if (ht[0].seg == ht.back().seg) throw HipError("too many pseudo-alignment anchors for one (query, genome) pair");
+                    max_window_bytes = std::max<int64_t>(pc.off / 2, 1);
+                    if (getenv("LM_DEBUG"))
+                        fprintf(stderr, "[lm] alignment chunk halved to %lld window bytes\n", (long long)max_window_bytes);
+                    continue;
+                }
+                ms_pseudo += now_ms() - ta;
+                {
+                    std::lock_guard<std::mutex> l(pm);
+                    slot_free[slot] = false;
+                    ready.push_back(std::move(pc));
+                }
+                pcv.notify_all();
+                slot ^= 1;
+                tpos = tend;
+                if (!pipelined) return; // single chunk at a time: the caller loops
+            }
+        } catch (...) {
+            prod_err = std::current_exception();
         }
+        if (pipelined) {
+            tls_stream = nullptr;
+            tls_tmp = nullptr;
+        }
+        {
+            std::lock_guard<std::mutex> l(pm);
+            prod_done = true;
+        }
+        pcv.notify_all();
+    };
+    std::thread prod_thread;
+    if (pipelined) prod_thread = std::thread(producer);
+    struct Joiner { // the producer never outlives this frame
+        std::thread &t;
+        std::mutex &m;
+        std::condition_variable &cv;
+        bool &abort;
+        ~Joiner() {
+            {
+                std::lock_guard<std::mutex> l(m);
+                abort = true;
+            }
+            cv.notify_all();
+            if (t.joinable()) t.join();
+        }
+    } joiner{prod_thread, pm, pcv, cons_abort};
+    int64_t np_tpos = r0; // unpipelined: next chunk start
+    while (true) {
+        PaChunk pc;
+        if (pipelined) {
+            std::unique_lock<std::mutex> l(pm);
+            pcv.wait(l, [&] { return !ready.empty() || prod_done; });
+            if (ready.empty()) break;
+            pc = std::move(ready.front());
+            ready.pop_front();
+        } else {
+            if (np_tpos >= r1) break;
+            // one chunk, inline: same code path, same thread and stream
+            const int64_t save_r0 = r0;
+            r0 = np_tpos;
+            prod_done = false;
+            producer();
+            r0 = save_r0;
+            if (prod_err) std::rethrow_exception(prod_err);
+            if (ready.empty()) break;
+            pc = std::move(ready.front());
+            ready.pop_front();
+            np_tpos = pc.tend;
+        }
+        AlignCtx &pa = *ctxs[pc.slot]; // owner of this chunk's window buffer
+        const int64_t tpos = pc.tpos, tend = pc.tend, base = pc.base, off = pc.off;
+        (void)tend;
+        TaskSpan ht;
+        ht.p = tasks_h.p + tpos;
+        ht.n = (size_t)(pc.tend - tpos);
+        std::vector<int64_t> &res_off = pc.res_off;
+        std::vector<LmChain2> &resv = pc.resv;
         double tb = now_ms();
-        st.ms_pseudo += tb - ta;
         // glue per segment with results (parallel; the order of `genomes` stays the segment order)
         size_t g0 = genomes.size();
         std::vector<HspMeta> hsps;
@@ -1965,7 +2085,7 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
             a.ext_off.ensure((size_t)NH + 2);
             HIPCHK(hipMemcpyAsync(a.hsp_in.p, hin.data(), sizeof(HspIn) * NH, hipMemcpyHostToDevice, S(ix)));
             HIPCHK(hipMemsetAsync(a.ext_cap.p + NH, 0, sizeof(int32_t), S(ix)));
-            launch_extend_count(S(ix), a.hsp_in.p, NH, qb->d_seq.p, qb->d_qoff.p, a.wb, a.ext_cap.p);
+            launch_extend_count(S(ix), a.hsp_in.p, NH, qb->d_seq.p, qb->d_qoff.p, pa.wb, a.ext_cap.p);
             // scratch rows per wavefront of k_extend (32 HSPs = 64 flanks each), transposed layout
             const int64_t NW = (2 * NH + 63) / 64;
             a.ext_wcap.ensure((size_t)NW + 1);
@@ -1979,7 +2099,7 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
             a.ext_msi.ensure(64 * (size_t)ER + 64);
             {
                 Prof p(ix, "k_extend");
-                launch_extend(S(ix), a.hsp_in.p, NH, qb->d_seq.p, qb->d_qoff.p, a.wb, a.ext_cap.p, a.ext_off.p,
+                launch_extend(S(ix), a.hsp_in.p, NH, qb->d_seq.p, qb->d_qoff.p, pa.wb, a.ext_cap.p, a.ext_off.p,
                               a.ext_subs.p, a.ext_msi.p, a.ext_rows.p, a.ext_rstart.p, a.hsp_ext.p);
             }
             std::vector<HspExt> hext;
@@ -1989,7 +2109,7 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
             for (int64_t i = 0; i < NH; i++) {
                 hsps[i].ext = hext[i];
                 win[i].q = qb->d_seq.p + qb->h_qoff[hsps[i].q] + hext[i].qs;
-                win[i].t = a.wb + hsps[i].in.woff + hext[i].ts;
+                win[i].t = pa.wb + hsps[i].in.woff + hext[i].ts;
                 win[i].qlen = hext[i].qe - hext[i].qs;
                 win[i].tlen = hext[i].te - hext[i].ts;
             }
@@ -1997,7 +2117,7 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
             for (int64_t i = 0; i < NH; i++) est[i] = hsps[i].est_div;
             run_wfa(a, win, wout, ops_h, ops_off_h, want_seq, &est);
             if (want_seq) {
-                d2h(ix, wbuf_h, a.wbuf.p, (size_t)off);
+                d2h(ix, wbuf_h, pa.wbuf.p, (size_t)off);
                 sync(ix);
             }
         }
@@ -2096,7 +2216,8 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
             int ab = coverage_len(regions);
             gen.aligned_fraction = (double)ab / (double)qlen * 100;
             if (gen.aligned_fraction > 100) gen.aligned_fraction = 100;
-            if (gen.aligned_fraction < ix->opt.min_qcov_per_genome) {
+            // with split genomes in the index the filter waits for the chunk merge (:2701 "do not filter results now")
+            if (!ix->host.has_chunks && gen.aligned_fraction < ix->opt.min_qcov_per_genome) {
                 gen.alive = false;
                 continue;
             }
@@ -2105,11 +2226,20 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
         });
         if (getenv("LM_DEBUG")) fprintf(stderr, "[lm] finalize: parallel part %.2f ms\n", now_ms() - td);
         st.ms_finalize += now_ms() - td;
-        tpos = tend;
         janitor().dispose(std::move(hsps));
         janitor().dispose(std::move(resv));
         janitor().dispose(std::move(wout));
+        {   // the chunk's windows are no longer read: its context may take the next chunk
+            std::lock_guard<std::mutex> l(pm);
+            slot_free[pc.slot] = true;
+        }
+        pcv.notify_all();
     }
+    if (pipelined) {
+        if (prod_thread.joinable()) prod_thread.join();
+        if (prod_err) std::rethrow_exception(prod_err);
+    }
+    st.ms_pseudo += ms_pseudo;
 }
 
 // what a search pass is asked to do besides the plain search: report the per-(query, genome) chaining scores and stop
@@ -2271,6 +2401,40 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res, const Searc
                 const size_t i = qstart[qi], e = qstart[qi + 1];
                 std::vector<lm_hsp> &rows = qrows[qi];
                 std::vector<HGenome *> gs;
+                if (ix->host.has_chunks) {
+                    // results of the chunks of one split genome are merged into the first of them (:2798-2851; the list is
+                    // in genome order here), then EVERY result gets its query coverage, the -Q filter and the cluster
+                    // order again (:2853-2897)
+                    for (size_t j = i; j < e; j++) {
+                        if (!genomes[j].alive) continue;
+                        auto cj = ix->host.chunk_of.find(genomes[j].bg);
+                        if (cj == ix->host.chunk_of.end()) continue;
+                        for (size_t k2 = j + 1; k2 < e; k2++) {
+                            if (!genomes[k2].alive) continue;
+                            auto ck = ix->host.chunk_of.find(genomes[k2].bg);
+                            if (ck == ix->host.chunk_of.end() || ck->second.list != cj->second.list) continue;
+                            for (auto &cl : genomes[k2].sds) genomes[j].sds.push_back(std::move(cl));
+                            genomes[k2].sds.clear();
+                            genomes[k2].alive = false;
+                        }
+                    }
+                    const int qlen = (int)(qb->h_qoff[genomes[i].q + 1] - qb->h_qoff[genomes[i].q]);
+                    for (size_t j = i; j < e; j++) {
+                        HGenome &gen = genomes[j];
+                        if (!gen.alive) continue;
+                        std::vector<std::pair<int, int>> regions;
+                        for (auto &cl : gen.sds)
+                            for (auto &c : cl.chains)
+                                if (c.alive) regions.push_back({c.qbegin, c.qend});
+                        gen.aligned_fraction = (double)coverage_len(regions) / (double)qlen * 100;
+                        if (gen.aligned_fraction > 100) gen.aligned_fraction = 100;
+                        if (gen.aligned_fraction < ix->opt.min_qcov_per_genome) {
+                            gen.alive = false;
+                            continue;
+                        }
+                        std::stable_sort(gen.sds.begin(), gen.sds.end(), [](const HCluster &x, const HCluster &y) { return x.sim > y.sim; });
+                    }
+                }
                 for (size_t j = i; j < e; j++)
                     if (genomes[j].alive) gs.push_back(&genomes[j]);
                 std::stable_sort(gs.begin(), gs.end(), [](const HGenome *x, const HGenome *y) {
@@ -2280,21 +2444,23 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res, const Searc
                 std::vector<HCluster *> order;
                 std::vector<char> used;
                 for (HGenome *g : gs) {
-                    const HostGenome &G = ix->host.genomes[g->g];
+                    const HostGenome &G0 = ix->host.genomes[g->g]; // the printed genome id: the (first) chunk's = the genome's
                     // SortBySeqID (:1042-1096): group clusters by sseqid keeping first-seen order
                     order.clear();
                     used.assign(g->sds.size(), 0);
                     for (size_t x = 0; x < g->sds.size(); x++) {
                         if (used[x]) continue;
                         for (size_t y = x; y < g->sds.size(); y++)
-                            if (!used[y] && (g->sds[y].seq_idx == g->sds[x].seq_idx ||
-                                             G.seq_ids[g->sds[y].seq_idx] == G.seq_ids[g->sds[x].seq_idx])) {
+                            if (!used[y] && ((g->sds[y].g == g->sds[x].g && g->sds[y].seq_idx == g->sds[x].seq_idx) ||
+                                             ix->host.genomes[g->sds[y].g].seq_ids[g->sds[y].seq_idx] ==
+                                                 ix->host.genomes[g->sds[x].g].seq_ids[g->sds[x].seq_idx])) {
                                 order.push_back(&g->sds[y]);
                                 used[y] = 1;
                             }
                     }
                     int cls = 1, hspn = 1;
                     for (HCluster *cl : order) {
+                        const HostGenome &G = ix->host.genomes[cl->g]; // contig table of the cluster's own chunk
                         for (auto &c : cl->chains) {
                             if (!c.alive) continue;
                             rows.emplace_back();
@@ -2309,8 +2475,8 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res, const Searc
                             r.seq_idx = cl->seq_idx;
                             r.nseqs = G.nseqs;
                             r.seq_len = G.seq_sizes[cl->seq_idx];
-                            r.nchunks = 1;
-                            r.chunk_idx = 0;
+                            r.nchunks = cl->nchunks;
+                            r.chunk_idx = cl->chunk_idx;
                             r.rc = cl->rc ? 1 : 0;
                             r.qcov_hsp = c.aligned_fraction;
                             r.aligned_length = c.aligned_length;
@@ -2324,7 +2490,7 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res, const Searc
                             r.bitscore = c.bitscore;
                             r.score = c.score;
                             r.matched_bases = c.matched_bases;
-                            r.genome_id = G.id.c_str();
+                            r.genome_id = G0.id.c_str();
                             r.seq_id = G.seq_ids[cl->seq_idx].c_str();
                             r.cigar = c.cigar ? c.cigar->c_str() : nullptr;
                             r.qseq = c.qseq ? c.qseq->c_str() : nullptr;

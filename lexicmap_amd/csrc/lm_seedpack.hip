@@ -24,11 +24,13 @@ struct SpParams {
     int K, p, a, P1, key_bits, gid_bits, pos_bits, M;
     const int64_t *batch_first;
     int nbatches, shard_rank, shard_count;
+    const int32_t *g2local;
 };
 
 __device__ __forceinline__ int64_t sp_local_genome(const SpParams &sp, uint64_t bg) {
     const uint64_t batch = bg >> 17, gi = bg & 0x1ffff;
     int64_t g = (batch < (uint64_t)sp.nbatches ? sp.batch_first[batch] : 0) + (int64_t)gi;
+    if (sp.g2local) return sp.g2local[g];
     if (sp.shard_count > 1) g /= sp.shard_count;
     return g;
 }
@@ -301,6 +303,7 @@ static SpParams sp_params(const SeedPacker &sp) {
     p.nbatches = ix->view.nbatches;
     p.shard_rank = ix->view.shard_rank;
     p.shard_count = ix->view.shard_count;
+    p.g2local = ix->view.g2local;
     return p;
 }
 

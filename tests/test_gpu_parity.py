@@ -527,6 +527,108 @@ def test_genome_whitelist_filter(small_index, queries):
     assert got == exp
 
 
+def _split_genomes():
+    """8 genomes x 150 kb cut into 5 (even) / 3 (odd) equal contigs: with max_genome = 70000 the index writer splits them
+    into 3 / 3 genome chunks (lib-index-build.go:1581-1658)"""
+    from lexicmap_amd import synth
+    g0 = synth.make_genomes(8, 150000, 2, seed=51, max_div=0.08, contigs=(1, 1))
+    genomes = []
+    for gi, (gid, contigs) in enumerate(g0):
+        s = contigs[0][1]
+        n = 5 if gi % 2 == 0 else 3
+        L = len(s) // n
+        genomes.append((gid, [("g%d_c%d" % (gi, i), s[i * L:(i + 1) * L if i < n - 1 else len(s)]) for i in range(n)]))
+    return genomes
+
+
+def test_split_genomes_chunk_merge(tmp_path):
+    """a18 / a20: an index whose genomes were split into chunks (genomes.chunks.bin): rows = oracle (which restates the merge
+    of lib-index-search.go:2798-2913), chunk columns filled, and - the property the merge exists for - everything but the
+    chunk bookkeeping equals the rows of the same genomes indexed unsplit.  Sharded, the chunks of a genome stay on one
+    shard: the two shards through lm_merge_sharded give the unsharded rows."""
+    la = _la()
+    from lexicmap_amd import merge, synth
+    genomes = _split_genomes()
+    qs = synth.make_gene_queries(genomes, 24, seed=52, len_range=(500, 3000), max_div=0.08)
+    seqs = [q[1] for q in qs]
+    d_split, d_whole = str(tmp_path / "split.lmi"), str(tmp_path / "whole.lmi")
+    O.build_index(d_split, genomes, O.default_build_opt(chunks=2, max_genome=70000))
+    O.build_index(d_whole, genomes, O.default_build_opt(chunks=2))
+    assert os.path.getsize(os.path.join(d_split, "genomes.chunks.bin")) == 8 * (8 + 3 * 8)
+    oi = O.Index(d_split, O.default_search_opt(min_qcov_genome=1.0))
+    gi = la.Index(d_split, la.api.default_options(min_qcov_per_genome=1.0))
+    assert gi.info()["genomes"] == 24
+    rows, _ = gi.search(seqs)
+    by_q = {}
+    for r in rows:
+        by_q.setdefault(r["query"], []).append(r)
+    n = 0
+    for qi, s in enumerate(seqs):
+        exp, st = oi.search(s)
+        got = by_q.get(qi, [])
+        _cmp_rows(exp, got, qs[qi][0])
+        for e, g in zip(exp, got):
+            assert (e["nchunks"], e["chunk_idx"]) == (g["nchunks"], g["chunk_idx"]) and g["nchunks"] == 3
+            assert g["hits"] == st["ngenomes"]
+        n += len(exp)
+    oi.close()
+    assert n > 50
+    gw = la.Index(d_whole, la.api.default_options(min_qcov_per_genome=1.0))
+    rows_w, _ = gw.search(seqs)
+    gw.close()
+    assert len(rows_w) == len(rows)
+    for a, b in zip(rows_w, rows):
+        for f in a:
+            if f in ("seq_idx", "nseqs", "nchunks", "chunk_idx", "batch_genome"):
+                continue
+            assert a[f] == b[f], f
+    # two shards: every genome's chunks on one shard
+    tb = gi.info()["total_bases"]
+    gi.close()
+    per_rank, held = [], []
+    for r in range(2):
+        si = la.Index(d_split, la.api.default_options(shard_rank=r, shard_count=2, total_bases_override=tb, min_qcov_per_genome=1.0))
+        held.append(si.info()["genomes"])
+        rr, _ = si.search(seqs)
+        per_rank.append(merge.pack_rows(rr))
+        si.close()
+    assert sorted(held) == [12, 12]
+    merged = merge.merge_sharded_c(per_rank)
+    assert len(merged) == len(rows)
+    for i, w in enumerate(rows):
+        for f in ROW_INT + ROW_F64 + ["evalue", "hits", "query", "nchunks", "chunk_idx"]:
+            assert merged[f][i] == w[f], (i, f)
+
+
+def test_concurrent_calls_serialise(both, queries):
+    """the reference calls Search from up to --max-query-conc goroutines (search.go:549,577-602); the handle owns all device
+    scratch, so concurrent calls on one lm_index* are serialised by its mutex: two threads searching different batches at
+    the same time both get exactly their single-threaded rows"""
+    import threading
+    _oi, gi = both
+    a = [q[1] for q in queries[:12]]
+    b = [q[1] for q in queries[12:24]]
+    want_a, _ = gi.search(a)
+    want_b, _ = gi.search(b)
+    got = {}
+
+    def run(name, seqs, reps):
+        out = []
+        for _ in range(reps):
+            rows, _st = gi.search(seqs)   # ctypes releases the GIL during the call
+            out.append(rows)
+        got[name] = out
+
+    ta = threading.Thread(target=run, args=("a", a, 4))
+    tb = threading.Thread(target=run, args=("b", b, 4))
+    ta.start()
+    tb.start()
+    ta.join()
+    tb.join()
+    assert all(r == want_a for r in got["a"]) and all(r == want_b for r in got["b"])
+    assert len(want_a) > 10 and len(want_b) > 10
+
+
 def test_errors_fail_loudly(tmp_path):
     la = _la()
     with pytest.raises(RuntimeError):

@@ -345,3 +345,42 @@ def test_demo_golden_prophage_rows_that_do_not_depend_on_the_mask_set(demo_index
     assert same == 5
     # the stable divergence: same start, 38 bp longer at the right end
     assert any(r[3] == "GCF_003697165.2" and r[12] == "10308" and r[13] == "13328" and r[9] == "3021" for r in rows)
+
+
+def test_genome_chunks_split_and_merge(tmp_path):
+    """lib-index-build.go:1581-1658 (a genome whose concatenation exceeds --max-genome is stored as several genome chunks,
+    listed in genomes.chunks.bin) and lib-index-search.go:2798-2913 (their results are merged, qcovGnm recomputed): the
+    rows of a split index equal the rows of the same genomes indexed unsplit, except for the chunk bookkeeping columns"""
+    from lexicmap_amd import synth
+    g0 = synth.make_genomes(6, 120000, 2, seed=61, max_div=0.08, contigs=(1, 1))
+    genomes = []
+    for gi, (gid, contigs) in enumerate(g0):
+        s = contigs[0][1]
+        n = 4 if gi % 2 == 0 else 3
+        L = len(s) // n
+        genomes.append((gid, [("g%d_c%d" % (gi, i), s[i * L:(i + 1) * L if i < n - 1 else len(s)]) for i in range(n)]))
+    qs = synth.make_gene_queries(genomes, 12, seed=62, len_range=(500, 2500), max_div=0.08)
+    dw, ds = str(tmp_path / "whole.lmi"), str(tmp_path / "split.lmi")
+    O.build_index(dw, genomes, O.default_build_opt(chunks=2))
+    O.build_index(ds, genomes, O.default_build_opt(chunks=2, max_genome=65000))
+    # 4 x 30 kb -> chunks of 2+2 contigs; 3 x 40 kb -> 1+1+1: lists of 2 and 3 keys
+    blob = open(os.path.join(ds, "genomes.chunks.bin"), "rb").read()
+    assert len(blob) == 3 * (8 + 2 * 8) + 3 * (8 + 3 * 8)
+    a, b = O.Index(dw, O.default_search_opt(min_qcov_genome=2.0)), O.Index(ds, O.default_search_opt(min_qcov_genome=2.0))
+    total = 0
+    for qid, s in qs:
+        ra, sa = a.search(s)
+        rb, sb = b.search(s)
+        assert len(ra) == len(rb) and sa["ngenomes"] == sb["ngenomes"]
+        for x, y in zip(ra, rb):
+            for f in x:
+                if f not in ("seq_idx", "nseqs", "nchunks", "chunk_idx", "batch_genome"):
+                    assert x[f] == y[f], (qid, f)
+            assert y["nchunks"] in (2, 3) and 0 <= y["chunk_idx"] < y["nchunks"] and x["nchunks"] == 1
+        total += len(ra)
+    a.close()
+    b.close()
+    assert total > 30
+    # one contig longer than max_genome: the reference skips the genome (lib-index-build.go:1596-1613)
+    with pytest.raises(RuntimeError):
+        O.build_index(str(tmp_path / "big.lmi"), genomes[:1], O.default_build_opt(chunks=1, max_genome=20000))

@@ -2,7 +2,7 @@
 """Condense rocprofv3 CSV output into small per-kernel summaries that are committed under profiles/.
   kernel stats : <prefix>_kernel_stats.csv          -> top kernels by total time (name shortened)
   PMC passes   : <prefix>_counter_collection.csv    -> mean counter value per kernel per dispatch
-usage: summarize_rocprof.py <dir> <out.json>"""
+usage: summarize_rocprof.py <dir> <out.json> [source_hash] [command]"""
 import csv
 import glob
 import json
@@ -24,6 +24,10 @@ def short(name):
 def main():
     d, out = sys.argv[1], sys.argv[2]
     res = {}
+    if len(sys.argv) > 3:
+        res["source_hash"] = sys.argv[3]  # bench.py source_hash(): the kernels these numbers were taken on
+    if len(sys.argv) > 4:
+        res["command"] = sys.argv[4]
     for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
         rows = list(csv.DictReader(open(f)))
         agg = {}
