@@ -1241,6 +1241,7 @@ struct AlignCtx {
     DBuf<uint8_t> wbuf;
     DBuf<unsigned long long> pa_count;
     int64_t pa_cap = 0; // running estimate of the anchors per chunk
+    double pa_ratio_own = 0, *pa_ratio = &pa_ratio_own; // anchors per window byte seen so far (shared by the two contexts)
     DBuf<int64_t> pa_off;
     DBuf<uint64_t> A0, B0, A1, B1;
     DBuf<LmSub> subs;
@@ -1351,13 +1352,16 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
         if (attempt > 2) throw HipError("pseudo-alignment anchor buffer keeps overflowing");
         a.pa_cap = TP + TP / 8;
     }
-    a.stats->pa_anchors += TP;
     // too many anchors for one chunk (31-bit indices, ~90 B of scratch each within 13 % of the budget - two chunks are in
     // flight): the caller halves the chunk
     if (TP >= (int64_t)1 << 31 || (ix->scratch_budget > 0 && TP * 90 > ix->scratch_budget * 13 / 100)) {
         if (nt <= 1) throw HipError("too many pseudo-alignment anchors for one chain window");
+        a.stats->window_bases -= W; // the chunk comes back in halves
         throw ChunkTooLarge();
     }
+    a.stats->pa_anchors += TP;
+    // anchors per window byte of what has been seen (sizes the next chunks so that they need no halving)
+    if (W > 0) *a.pa_ratio = std::max(*a.pa_ratio * 0.5, (double)TP / (double)W);
     a.pa_off.ensure((size_t)nt + 2);
     a.out_n.ensure((size_t)nt + 1);
     a.clr_n.ensure((size_t)nt + 1);
@@ -1827,6 +1831,7 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
         int slot = 0;
     };
     AlignCtx *ctxs[2] = {&a, &get_actx(ix, qb, &w, &st, 1)};
+    ctxs[1]->pa_ratio = ctxs[0]->pa_ratio;
     std::mutex pm;
     std::condition_variable pcv;
     std::deque<PaChunk> ready;
@@ -1846,6 +1851,10 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
             int64_t tpos = r0;
             int slot = 0;
             while (tpos < r1) {
+                if (ix->scratch_budget > 0 && *ctxs[0]->pa_ratio > 0) { // expected anchors within 80 % of the chunk's share
+                    const int64_t lim = (int64_t)((double)(ix->scratch_budget * 13 / 100) / 90.0 * 0.8 / *ctxs[0]->pa_ratio);
+                    if (!getenv("LM_DEBUG_MAX_WINDOW_BYTES")) max_window_bytes = std::min(max_window_bytes, std::max<int64_t>(lim, 1 << 20));
+                }
                 // chunk [tpos, tend): whole segments, bounded window bytes
                 int64_t tend = tpos, wb = 0;
                 while (tend < r1) {
