@@ -73,11 +73,14 @@ inline int gv2(uint8_t ctrl, const uint8_t *p, uint64_t &a, uint64_t &b) {
 
 } // namespace
 
-// Decodes one seeds chunk (kv-data.go:66-89 layout) and appends every (k-mer,value) whose genome passes `keep`.
-// Chunk files cover disjoint mask ranges, so several can be decoded at the same time (km / vv are per mask).
-static std::string load_chunk(const std::string &path, const HostIndex &idx, const std::vector<int64_t> &batch_first,
-                              std::vector<std::vector<uint64_t>> &km, std::vector<std::vector<uint64_t>> &vv,
-                              int &status, int &anchor_prefix_out) {
+// Decodes one seeds chunk (kv-data.go:66-89 layout) into flat (k-mer, value, mask) arrays, keeping the seeds whose genome
+// is on this shard.
+std::string decode_seed_chunk(const std::string &path, const HostIndex &idx, SeedChunk &out, int &status,
+                              int &anchor_prefix_out) {
+    const std::vector<int64_t> &batch_first = idx.batch_first;
+    out.kmers.clear();
+    out.vals.clear();
+    out.masks.clear();
     std::vector<uint8_t> buf;
     if (!read_all(path, buf)) {
         status = 1;
@@ -119,8 +122,11 @@ static std::string load_chunk(const std::string &path, const HostIndex &idx, con
         uint64_t nk = be64(&buf[p]);
         p += 8;
         if (nk == 0) continue;
-        std::vector<uint64_t> &K = km[(size_t)(mask0 + im)];
-        std::vector<uint64_t> &V = vv[(size_t)(mask0 + im)];
+        if (mask0 + im >= idx.M) {
+            status = 2;
+            return "k-mer-value data: mask number out of range: " + path;
+        }
+        const uint16_t mk = (uint16_t)(mask0 + im);
         uint64_t off = 0;
         for (;;) {
             // a record = ctrl byte + two group-varint values (<= 16 bytes), twice: k-mer deltas, then value counts
@@ -157,8 +163,9 @@ static std::string load_chunk(const std::string &path, const HostIndex &idx, con
                         int64_t g = (batch + 1 < batch_first.size() ? batch_first[batch] : 0) + (int64_t)gi;
                         if (g < 0 || g >= (int64_t)idx.g2local.size() || idx.g2local[(size_t)g] < 0) continue;
                     }
-                    K.push_back(kmer);
-                    V.push_back(v);
+                    out.kmers.push_back(kmer);
+                    out.vals.push_back(v);
+                    out.masks.push_back(mk);
                 }
             }
             if (last_pair) break;
@@ -398,54 +405,20 @@ std::string load_index(const std::string &dir, int shard_rank, int shard_count, 
         status = 1;
         return "seeds file not found in: " + dir + "/seeds";
     }
-    std::vector<std::vector<uint64_t>> km(out.M), vv(out.M);
-    // decode the chunk files in parallel (the reference reads them with one goroutine per file, kv-reader.go:762-1021)
-    const int nthreads = (int)std::max<size_t>(1, std::min<size_t>(files.size(), std::min(16u, std::max(1u, std::thread::hardware_concurrency()))));
-    std::vector<std::string> errs(files.size());
-    std::vector<int> stats(files.size(), 0), anchors(files.size(), -1);
-    {
-        std::atomic<size_t> next{0};
-        auto body = [&]() {
-            for (;;) {
-                size_t i = next.fetch_add(1);
-                if (i >= files.size()) break;
-                errs[i] = load_chunk(dir + "/seeds/" + files[i], out, out.batch_first, km, vv, stats[i], anchors[i]);
-            }
-        };
-        std::vector<std::thread> th;
-        for (int t = 1; t < nthreads; t++) th.emplace_back(body);
-        body();
-        for (auto &t : th) t.join();
-    }
-    for (size_t i = 0; i < files.size(); i++) {
-        if (!errs[i].empty()) {
-            status = stats[i];
-            return errs[i];
+    out.seed_files.clear();
+    for (auto &f : files) out.seed_files.push_back(dir + "/seeds/" + f);
+    {   // the anchor prefix of the seed data (users might have run 'utils reindex-seeds', lib-index-search.go:611)
+        File fi(out.seed_files[0] + ".idx");
+        uint8_t h[32];
+        if (!fi.ok() || !fi.read(h, 32) || memcmp(h, ".kvindex", 8) != 0) {
+            status = 2;
+            return "k-mer-value index: invalid binary format: " + out.seed_files[0] + ".idx";
         }
-        if (anchors[i] >= 0) out.anchor_prefix = anchors[i];
-    }
-    out.mask_off.assign(out.M + 1, 0);
-    for (int i = 0; i < out.M; i++) out.mask_off[i + 1] = out.mask_off[i] + (int64_t)km[i].size();
-    out.seed_kmers.resize((size_t)out.mask_off[out.M]);
-    out.seed_vals.resize((size_t)out.mask_off[out.M]);
-    {
-        std::atomic<int> next{0};
-        auto body = [&]() {
-            for (;;) {
-                int i0 = next.fetch_add(256);
-                if (i0 >= out.M) break;
-                for (int i = i0; i < std::min(out.M, i0 + 256); i++) {
-                    std::copy(km[i].begin(), km[i].end(), out.seed_kmers.begin() + out.mask_off[i]);
-                    std::copy(vv[i].begin(), vv[i].end(), out.seed_vals.begin() + out.mask_off[i]);
-                    std::vector<uint64_t>().swap(km[i]);
-                    std::vector<uint64_t>().swap(vv[i]);
-                }
-            }
-        };
-        std::vector<std::thread> th;
-        for (int t = 1; t < nthreads; t++) th.emplace_back(body);
-        body();
-        for (auto &t : th) t.join();
+        if ((int)h[11] != out.mask_prefix) {
+            status = 2;
+            return "lengths of mask prefix mismatch between info.toml and the seed data";
+        }
+        out.anchor_prefix = h[12];
     }
     return "";
 }

@@ -28,9 +28,7 @@ struct HostIndex {
     int contig_interval = 1000;
     int genome_batches = 0;
     std::vector<uint64_t> masks;
-    // seeds: per mask sorted by k-mer; SoA
-    std::vector<int64_t> mask_off; // [M+1]
-    std::vector<uint64_t> seed_kmers, seed_vals;
+    std::vector<std::string> seed_files; // seeds/chunk_NNN.bin, sorted
     // genomes of this shard
     std::vector<HostGenome> genomes;
     // names / contig tables of the genomes held by the OTHER shards (no bases), keyed by batch<<17|index
@@ -53,7 +51,17 @@ struct HostIndex {
     int shard_rank = 0, shard_count = 1;
 };
 
+// Everything of the index except the seeds (info.toml, masks, genomes, id map, chunk lists) + the list of seed chunk files.
 // returns empty string on success, else the error text. status: 1 io, 2 format
 std::string load_index(const std::string &dir, int shard_rank, int shard_count, HostIndex &out, int &status);
+
+// One seeds/chunk_NNN.bin decoded into flat arrays (k-mer, value, mask) of the seeds whose genome is on this shard: what the
+// seed packer is shown.  The reference reads these files with one goroutine per file (kv-reader.go:762-1021); the loader
+// streams them - decode, hand to the packer, drop - so the host never holds more than a few files.
+struct SeedChunk {
+    std::vector<uint64_t> kmers, vals;
+    std::vector<uint16_t> masks;
+};
+std::string decode_seed_chunk(const std::string &path, const HostIndex &idx, SeedChunk &out, int &status, int &anchor_prefix);
 
 } // namespace lm

@@ -98,6 +98,8 @@ void launch_task_wlen(hipStream_t st, const Task *tasks, int64_t ntasks, int32_t
 void launch_task_set_woff(hipStream_t st, Task *tasks, int64_t ntasks, const int64_t *woff);
 void launch_extract_windows(hipStream_t st, DevIndexView ix, const Task *tasks, int64_t ntasks, const int32_t *only,
                             uint8_t *wbuf);
+void launch_extract_windows_at(hipStream_t st, DevIndexView ix, const Task *tasks, const int32_t *idx, const int64_t *dest,
+                               int64_t n, uint8_t *wbuf);
 #define LM_TAB_BITS 12 /* bucket table over the first 6 bases of the query's sorted k-mers */
 void launch_build_cmp_tab(hipStream_t st, const uint64_t *keys_cmp, const int64_t *posoff, const int32_t *nvalid, int nq,
                           int K, uint32_t *tab);

@@ -528,6 +528,24 @@ __global__ void k_extract_windows(DevIndexView ix, const Task *__restrict__ task
     }
 }
 
+// the same for a list of tasks, each window written at its own offset of a compact buffer (the windows of the tasks that
+// produced pseudo-alignment chains, gathered over several chunks for one extendMatch / WFA round)
+__global__ void k_extract_windows_at(DevIndexView ix, const Task *__restrict__ tasks, const int32_t *__restrict__ idx,
+                                     const int64_t *__restrict__ dest, int64_t n, uint8_t *__restrict__ wbuf) {
+    for (int64_t li = blockIdx.x; li < n; li += gridDim.x) {
+        const Task t = tasks[idx[li]];
+        if (t.wlen <= 0 || t.g < 0) continue;
+        const uint8_t *gb = ix.gbits + ix.g_off[t.g];
+        uint8_t *w = wbuf + dest[li];
+        for (int i = threadIdx.x; i < t.wlen; i += blockDim.x) {
+            int pos = t.rc ? (t.tBegin + t.wlen - 1 - i) : (t.tBegin + i);
+            uint32_t code = (gb[pos >> 2] >> ((3 - (pos & 3)) << 1)) & 3u;
+            if (t.rc) code = 3u - code;
+            w[i] = (uint8_t)("ACGT"[code]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // SeqComparator.Compare anchor generation (lib-seq_compare.go:335-445)
 __device__ __forceinline__ int pa_min_prefix(int base, int wlen) {
@@ -2361,6 +2379,12 @@ void launch_extract_windows(hipStream_t st, DevIndexView ix, const Task *tasks, 
                             uint8_t *wbuf) {
     int g = (int)(ntasks < 1 ? 1 : (ntasks > 1048576 ? 1048576 : ntasks));
     hipLaunchKernelGGL(k_extract_windows, dim3(g), dim3(256), 0, st, ix, tasks, ntasks, only, wbuf);
+}
+void launch_extract_windows_at(hipStream_t st, DevIndexView ix, const Task *tasks, const int32_t *idx, const int64_t *dest,
+                               int64_t n, uint8_t *wbuf) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_extract_windows_at, dim3((unsigned)std::min<int64_t>(n, 65536)), dim3(256), 0, st, ix, tasks, idx, dest, n,
+                       wbuf);
 }
 void launch_build_cmp_tab(hipStream_t st, const uint64_t *keys_cmp, const int64_t *posoff, const int32_t *nvalid, int nq,
                           int K, uint32_t *tab) {

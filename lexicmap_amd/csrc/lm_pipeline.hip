@@ -31,6 +31,7 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <future>
 #include <memory>
 #include <exception>
 #include <thread>
@@ -989,36 +990,55 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
         v.ngenomes = (int64_t)h.genomes.size();
         v.shard_rank = h.shard_rank;
         v.shard_count = h.shard_count;
-        {   // packed seed image: the decoded seeds are shown to the packer twice (count, place) in slices of whole masks
+        {   // packed seed image: every chunk file is decoded and shown to the packer twice (count, then place). Files are
+            // decoded by a few host threads ahead of the upload and dropped right after it: the host never holds more than
+            // `ahead` files (the reference's RAM form of the whole index would be 16 B/seed of host memory).
             SeedPacker sp;
             sp.begin(ix, (int64_t)h.genomes.size(), max_len);
-            const int64_t slice = (int64_t)32 << 20;
+            const size_t nf = h.seed_files.size();
+            const size_t ahead = std::min<size_t>(4, std::max<size_t>(1, nf));
             DBuf<uint64_t> dk, dv;
             DBuf<uint16_t> dm;
-            std::vector<uint16_t> hm;
             for (int pass = 0; pass < 2; pass++) {
-                int m0 = 0;
-                while (m0 < h.M) {
-                    int m1 = m0 + 1;
-                    while (m1 < h.M && h.mask_off[m1 + 1] - h.mask_off[m0] <= slice) m1++;
-                    const int64_t b0 = h.mask_off[m0], cnt = h.mask_off[m1] - b0;
-                    if (cnt > 0) {
-                        hm.resize((size_t)cnt);
-                        for (int m = m0; m < m1; m++)
-                            std::fill(hm.begin() + (h.mask_off[m] - b0), hm.begin() + (h.mask_off[m + 1] - b0), (uint16_t)m);
-                        dk.ensure((size_t)cnt);
-                        dv.ensure((size_t)cnt);
-                        dm.ensure((size_t)cnt);
-                        HIPCHK(hipMemcpyAsync(dk.p, h.seed_kmers.data() + b0, (size_t)cnt * 8, hipMemcpyHostToDevice, S(ix)));
-                        HIPCHK(hipMemcpyAsync(dv.p, h.seed_vals.data() + b0, (size_t)cnt * 8, hipMemcpyHostToDevice, S(ix)));
-                        HIPCHK(hipMemcpyAsync(dm.p, hm.data(), (size_t)cnt * 2, hipMemcpyHostToDevice, S(ix)));
-                        if (pass == 0)
-                            sp.count(dm.p, dk.p, dv.p, cnt);
-                        else
-                            sp.place(dm.p, dk.p, dv.p, cnt);
-                        sync(ix); // the host slices are reused
+                std::vector<std::future<std::string>> fut(nf);
+                std::vector<std::unique_ptr<SeedChunk>> chunk(nf);
+                std::vector<int> stat(nf, 0), anch(nf, -1);
+                auto launch = [&](size_t i) {
+                    chunk[i].reset(new SeedChunk());
+                    fut[i] = std::async(std::launch::async, [&, i]() {
+                        return decode_seed_chunk(h.seed_files[i], h, *chunk[i], stat[i], anch[i]);
+                    });
+                };
+                for (size_t i = 0; i < std::min(ahead, nf); i++) launch(i);
+                for (size_t i = 0; i < nf; i++) {
+                    const std::string e2 = fut[i].get();
+                    if (i + ahead < nf) launch(i + ahead);
+                    if (!e2.empty()) {
+                        for (size_t j = i + 1; j < nf; j++)
+                            if (fut[j].valid()) fut[j].wait();
+                        g_open_error = e2;
+                        const int stt = stat[i];
+                        delete ix;
+                        return stt == 2 ? LM_ERR_FORMAT : LM_ERR_IO;
                     }
-                    m0 = m1;
+                    SeedChunk &c = *chunk[i];
+                    const int64_t cnt = (int64_t)c.kmers.size();
+                    const int64_t slice = (int64_t)32 << 20;
+                    for (int64_t o = 0; o < cnt; o += slice) {
+                        const int64_t m = std::min(slice, cnt - o);
+                        dk.ensure((size_t)m);
+                        dv.ensure((size_t)m);
+                        dm.ensure((size_t)m);
+                        HIPCHK(hipMemcpyAsync(dk.p, c.kmers.data() + o, (size_t)m * 8, hipMemcpyHostToDevice, S(ix)));
+                        HIPCHK(hipMemcpyAsync(dv.p, c.vals.data() + o, (size_t)m * 8, hipMemcpyHostToDevice, S(ix)));
+                        HIPCHK(hipMemcpyAsync(dm.p, c.masks.data() + o, (size_t)m * 2, hipMemcpyHostToDevice, S(ix)));
+                        if (pass == 0)
+                            sp.count(dm.p, dk.p, dv.p, m);
+                        else
+                            sp.place(dm.p, dk.p, dv.p, m);
+                        sync(ix); // the staging buffers are reused
+                    }
+                    chunk[i].reset();
                 }
                 if (pass == 0) sp.end_count();
             }
@@ -1026,9 +1046,7 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
         }
         ix->hbm_bytes = ix->seed_bytes + (int64_t)(h.masks.size() * 8 + pfx.size() * 4 + h.gbits.size() + 64 + goff.size() * 20 +
                                                    h.batch_first.size() * 8);
-        // the unpacked host copies are no longer needed
-        std::vector<uint64_t>().swap(h.seed_kmers);
-        std::vector<uint64_t>().swap(h.seed_vals);
+        // the host copy of the packed genomes is no longer needed
         std::vector<uint8_t>().swap(h.gbits);
         ix->tmp.release();
         lm_set_scratch_budget(ix);
@@ -1239,6 +1257,10 @@ struct AlignCtx {
     DBuf<int32_t> wlen;
     DBuf<int64_t> woff;
     DBuf<uint8_t> wbuf;
+    // windows of the tasks with chains, compact, gathered over the chunks of one extendMatch / WFA round
+    DBuf<uint8_t> gwbuf;
+    DBuf<int32_t> gw_idx;
+    DBuf<int64_t> gw_dest;
     DBuf<unsigned long long> pa_count;
     int64_t pa_cap = 0; // running estimate of the anchors per chunk
     double pa_ratio_own = 0, *pa_ratio = &pa_ratio_own; // anchors per window byte seen so far (shared by the two contexts)
@@ -1297,8 +1319,11 @@ struct HspMeta { // host-side view of one WFA problem
 // Runs pseudo-alignment for tasks[t0,t1) (host copy `ht`), returns per task the Chain2 results.
 // `ht`: host copy of the tasks; `dev_tasks` their device copy (null: upload `ht`); `base` = window offset of the first
 // task (the tasks carry offsets into one virtual buffer of all windows of the batch, a chunk uses a slice of it)
+// `own_windows`: the targets are caller-provided ASCII windows in a.wbuf (stage-level entry point). The search path passes
+// false: the anchor kernel takes its k-mers from the 2-bit genomes, and the ASCII windows of the tasks that produce chains
+// are extracted later, compactly, by the consumer (align_range).
 static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h, std::vector<LmChain2> &res_h,
-                       const Task *dev_tasks = nullptr, int64_t base = 0) {
+                       const Task *dev_tasks = nullptr, int64_t base = 0, bool own_windows = true) {
     lm_index *ix = a.ix;
     lm_qbatch *qb = a.qb;
     int64_t nt = (int64_t)ht.size();
@@ -1306,9 +1331,12 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
     res_h.clear();
     if (nt == 0) return;
     int64_t W = ht.back().woff + ht.back().wlen - base;
-    a.wbuf.ensure((size_t)W + 64);
-    a.wb = a.wbuf.p - base;
-    uint8_t *wbw = a.wbuf.p - base;
+    if (own_windows) {
+        a.wbuf.ensure((size_t)W + 64);
+        a.wb = a.wbuf.p - base;
+    } else {
+        a.wb = nullptr;
+    }
     const Task *tasks_d = dev_tasks;
     if (!tasks_d) {
         a.tasks.ensure((size_t)nt);
@@ -1400,10 +1428,6 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
             Prof p(ix, "k_pa_chain", TP * 32);
             launch_pa_chain(S(ix), a.B0.p, a.pa_off.p, nt, ix->host.k, o2, a.subs.p, a.marks.p, a.msi.p, a.stack.p,
                             a.out.p, a.out_n.p, a.clr_n.p, compact ? qbits : 0, compact ? tbits : 0);
-        }
-        {   // ASCII windows only for the tasks that produced chains: extendMatch / WFA are the only readers
-            Prof p(ix, "k_extract_windows", W / 4);
-            launch_extract_windows(S(ix), ix->view, tasks_d, nt, a.out_n.p, wbw);
         }
         a.res_off.ensure((size_t)nt + 2);
         int64_t NR = scan_to_i64<int32_t, CastI32>(ix, a.out_n.p, nt, a.res_off.p);
@@ -1883,7 +1907,7 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
                 pc.off = ht.back().woff + ht.back().wlen - pc.base; // window bytes of the chunk
                 const double ta = now_ms();
                 try {
-                    run_pseudo(*ctxs[slot], ht, pc.res_off, pc.resv, w.tasks.p + tpos, pc.base);
+                    run_pseudo(*ctxs[slot], ht, pc.res_off, pc.resv, w.tasks.p + tpos, pc.base, false);
                 } catch (const ChunkTooLarge &) { // same tasks again in smaller chunks
                     if (ht[0].seg == ht.back().seg) throw HipError("too many pseudo-alignment anchors for one (query, genome) pair");
                     max_window_bytes = std::max<int64_t>(pc.off / 2, 1);
@@ -1931,154 +1955,19 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
             if (t.joinable()) t.join();
         }
     } joiner{prod_thread, pm, pcv, cons_abort};
-    int64_t np_tpos = r0; // unpipelined: next chunk start
-    while (true) {
-        PaChunk pc;
-        if (pipelined) {
-            std::unique_lock<std::mutex> l(pm);
-            pcv.wait(l, [&] { return !ready.empty() || prod_done; });
-            if (ready.empty()) break;
-            pc = std::move(ready.front());
-            ready.pop_front();
-        } else {
-            if (np_tpos >= r1) break;
-            // one chunk, inline: same code path, same thread and stream
-            const int64_t save_r0 = r0;
-            r0 = np_tpos;
-            prod_done = false;
-            producer();
-            r0 = save_r0;
-            if (prod_err) std::rethrow_exception(prod_err);
-            if (ready.empty()) break;
-            pc = std::move(ready.front());
-            ready.pop_front();
-            np_tpos = pc.tend;
-        }
-        AlignCtx &pa = *ctxs[pc.slot]; // owner of this chunk's window buffer
-        const int64_t tpos = pc.tpos, tend = pc.tend, base = pc.base, off = pc.off;
-        (void)tend;
-        TaskSpan ht;
-        ht.p = tasks_h.p + tpos;
-        ht.n = (size_t)(pc.tend - tpos);
-        std::vector<int64_t> &res_off = pc.res_off;
-        std::vector<LmChain2> &resv = pc.resv;
-        double tb = now_ms();
-        // glue per segment with results (parallel; the order of `genomes` stays the segment order)
-        size_t g0 = genomes.size();
-        std::vector<HspMeta> hsps;
-        {
-            std::vector<std::pair<size_t, size_t>> active; // task ranges of the segments that have Chain2 results
-            for (size_t i = 0; i < ht.size();) {
-                size_t e = i;
-                while (e < ht.size() && ht[e].seg == ht[i].seg) e++;
-                if (res_off[e] > res_off[i] && ht[i].g >= 0) active.push_back({i, e});
-                i = e;
-            }
-            const int64_t ns = (int64_t)active.size();
-            const double tg0 = now_ms();
-            std::vector<HGenome> gens((size_t)ns);
-            std::vector<int32_t> nh((size_t)ns + 1, 0); // HSPs per segment
-            (void)div_from_pseudo_pident(0);            // builds its table before the threads use it
-            parallel_for(ns, 64, [&](int64_t s0, int64_t s1) {
-                for (int64_t si = s0; si < s1; si++) {
-                    size_t i = active[si].first, e = active[si].second;
-                    HGenome &gen = gens[si];
-                    gen.q = ht[i].q;
-                    gen.bg = ht[i].bg;
-                    gen.g = ht[i].g;
-                    std::map<AKey, bool> keys;
-                    for (size_t t = i; t < e; t++)
-                        glue_task(ix, gen, keys, ht[t], (int64_t)t, resv.data() + res_off[t],
-                                  (int)(res_off[t + 1] - res_off[t]));
-                    // HSP list (Update2 + the start of the finalisation loops :2223-2255 / :2490-2522): which chains
-                    // go to extendMatch/WFA; c.hsp = index within the genome for now
-                    int qlen = (int)(qb->h_qoff[gen.q + 1] - qb->h_qoff[gen.q]);
-                    int cnt = 0;
-                    for (auto &cl : gen.sds)
-                        for (auto &c : cl.chains) {
-                            c.aligned_fraction = (double)c.aligned_bases_q / (double)qlen * 100;
-                            if (c.qbegin >= c.qend + 1) {
-                                c.alive = false;
-                                continue;
-                            }
-                            int start, end;
-                            if (cl.rc) {
-                                start = cl.tEnd - c.tend - c.tpos_offset_begin;
-                                end = cl.tEnd - c.tbegin - c.tpos_offset_begin + 1;
-                            } else {
-                                start = c.tpos_offset_begin + c.tbegin - cl.tBegin;
-                                end = c.tpos_offset_begin + c.tend - cl.tBegin + 1;
-                            }
-                            if (start >= end) {
-                                c.alive = false;
-                                continue;
-                            }
-                            c.hsp = cnt++;
-                        }
-                    nh[si] = cnt;
-                }
-            });
-            const double tg1 = now_ms();
-            std::vector<int64_t> hbase((size_t)ns + 1, 0);
-            for (int64_t si = 0; si < ns; si++) hbase[si + 1] = hbase[si] + nh[si];
-            hsps.resize((size_t)hbase[ns]);
-            parallel_for(ns, 64, [&](int64_t s0, int64_t s1) {
-                for (int64_t si = s0; si < s1; si++) {
-                    HGenome &gen = gens[si];
-                    int qlen = (int)(qb->h_qoff[gen.q + 1] - qb->h_qoff[gen.q]);
-                    for (auto &cl : gen.sds) {
-                        const Task &t = ht[cl.task];
-                        for (auto &c : cl.chains) {
-                            if (!c.alive || c.hsp < 0) continue;
-                            int start, end;
-                            if (cl.rc) {
-                                start = cl.tEnd - c.tend - c.tpos_offset_begin;
-                                end = cl.tEnd - c.tbegin - c.tpos_offset_begin + 1;
-                            } else {
-                                start = c.tpos_offset_begin + c.tbegin - cl.tBegin;
-                                end = c.tpos_offset_begin + c.tend - cl.tBegin + 1;
-                            }
-                            int ext2 = ix->opt.ext_len2;
-                            if (c.aligned_bases_q > 1000000)
-                                ext2 += 80;
-                            else if (c.aligned_bases_q > 250000)
-                                ext2 += 40;
-                            else if (c.aligned_bases_q > 50000)
-                                ext2 += 20;
-                            else if (c.aligned_bases_q > 10000)
-                                ext2 += 10;
-                            c.hsp += hbase[si];
-                            HspMeta &h = hsps[(size_t)c.hsp];
-                            h.task = cl.task;
-                            h.est_div = (float)div_from_pseudo_pident(c.pident);
-                            h.q = gen.q;
-                            h.in.q = gen.q;
-                            h.in.rc = cl.rc ? 1 : 0;
-                            h.in.woff = t.woff;
-                            h.in.len1 = qlen;
-                            h.in.len2 = t.wlen;
-                            h.in.start1 = c.qbegin;
-                            h.in.end1 = c.qend + 1;
-                            h.in.start2 = start;
-                            h.in.end2 = end;
-                            h.in.ext_len = ext2;
-                            h.in.tbegin = c.tbegin;
-                            h.in.max_ext_len = c.max_ext_len;
-                            h.in.pad = 0;
-                        }
-                    }
-                }
-            });
-            const double tg2 = now_ms();
-            genomes.reserve(genomes.size() + (size_t)ns);
-            for (int64_t si = 0; si < ns; si++)
-                if (!gens[si].sds.empty()) genomes.push_back(std::move(gens[si]));
-            if (getenv("LM_DEBUG"))
-                fprintf(stderr, "[lm] glue: active scan %.2f, glue_task pass %.2f, hsp fill %.2f, move %.2f ms (%lld genomes)\n",
-                        tg0 - tb, tg1 - tg0, tg2 - tg1, now_ms() - tg2, (long long)ns);
+    std::vector<HspMeta> hsps; // of the current round
+    size_t g0 = genomes.size(); // first genome of the current round
+    int64_t gw_used = 0;        // bytes of the round's window buffer in use
+    const int64_t gw_target = ix->scratch_budget > 0 ? std::min<int64_t>((int64_t)6 << 30, std::max<int64_t>((int64_t)64 << 20, ix->scratch_budget * 3 / 100)) : (int64_t)1 << 30;
+    const int64_t round_hsps = getenv("LM_DEBUG_ROUND_HSPS") ? atoll(getenv("LM_DEBUG_ROUND_HSPS")) : 600000;
+    // ---- one extendMatch / WFA / finalisation round over the HSPs gathered from one or more chunks: the WFA launches end in
+    // tails of a few long alignments, so few large rounds beat one round per chunk
+    auto flush_round = [&]() {
+        if (hsps.empty() && g0 == genomes.size()) {
+            gw_used = 0;
+            return;
         }
         double tc = now_ms();
-        st.ms_glue += tc - tb;
         int64_t NH = (int64_t)hsps.size();
         st.hsps_aligned += NH;
         std::vector<WfaOut> wout;
@@ -2094,7 +1983,7 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
             a.ext_off.ensure((size_t)NH + 2);
             HIPCHK(hipMemcpyAsync(a.hsp_in.p, hin.data(), sizeof(HspIn) * NH, hipMemcpyHostToDevice, S(ix)));
             HIPCHK(hipMemsetAsync(a.ext_cap.p + NH, 0, sizeof(int32_t), S(ix)));
-            launch_extend_count(S(ix), a.hsp_in.p, NH, qb->d_seq.p, qb->d_qoff.p, pa.wb, a.ext_cap.p);
+            launch_extend_count(S(ix), a.hsp_in.p, NH, qb->d_seq.p, qb->d_qoff.p, a.gwbuf.p, a.ext_cap.p);
             // scratch rows per wavefront of k_extend (32 HSPs = 64 flanks each), transposed layout
             const int64_t NW = (2 * NH + 63) / 64;
             a.ext_wcap.ensure((size_t)NW + 1);
@@ -2108,7 +1997,7 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
             a.ext_msi.ensure(64 * (size_t)ER + 64);
             {
                 Prof p(ix, "k_extend");
-                launch_extend(S(ix), a.hsp_in.p, NH, qb->d_seq.p, qb->d_qoff.p, pa.wb, a.ext_cap.p, a.ext_off.p,
+                launch_extend(S(ix), a.hsp_in.p, NH, qb->d_seq.p, qb->d_qoff.p, a.gwbuf.p, a.ext_cap.p, a.ext_off.p,
                               a.ext_subs.p, a.ext_msi.p, a.ext_rows.p, a.ext_rstart.p, a.hsp_ext.p);
             }
             std::vector<HspExt> hext;
@@ -2118,7 +2007,7 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
             for (int64_t i = 0; i < NH; i++) {
                 hsps[i].ext = hext[i];
                 win[i].q = qb->d_seq.p + qb->h_qoff[hsps[i].q] + hext[i].qs;
-                win[i].t = pa.wb + hsps[i].in.woff + hext[i].ts;
+                win[i].t = a.gwbuf.p + hsps[i].in.woff + hext[i].ts;
                 win[i].qlen = hext[i].qe - hext[i].qs;
                 win[i].tlen = hext[i].te - hext[i].ts;
             }
@@ -2126,7 +2015,7 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
             for (int64_t i = 0; i < NH; i++) est[i] = hsps[i].est_div;
             run_wfa(a, win, wout, ops_h, ops_off_h, want_seq, &est);
             if (want_seq) {
-                d2h(ix, wbuf_h, pa.wbuf.p, (size_t)off);
+                d2h(ix, wbuf_h, a.gwbuf.p, (size_t)gw_used);
                 sync(ix);
             }
         }
@@ -2195,7 +2084,7 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
                         c.tseq = new std::string();
                         c.align = new std::string();
                         fmt_alignment(ops, qb->h_seq.data() + qb->h_qoff[h.q] + h.ext.qs,
-                                      wbuf_h.data() + (h.in.woff - base) + h.ext.ts, c.qseq, c.align, c.tseq);
+                                      wbuf_h.data() + h.in.woff + h.ext.ts, c.qseq, c.align, c.tseq);
                         std::lock_guard<std::mutex> sl(strings_mu);
                         res->strings.push_back(c.cigar);
                         res->strings.push_back(c.qseq);
@@ -2236,14 +2125,193 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
         if (getenv("LM_DEBUG")) fprintf(stderr, "[lm] finalize: parallel part %.2f ms\n", now_ms() - td);
         st.ms_finalize += now_ms() - td;
         janitor().dispose(std::move(hsps));
-        janitor().dispose(std::move(resv));
         janitor().dispose(std::move(wout));
-        {   // the chunk's windows are no longer read: its context may take the next chunk
+        hsps = std::vector<HspMeta>();
+        g0 = genomes.size();
+        gw_used = 0;
+    };
+    int64_t np_tpos = r0; // unpipelined: next chunk start
+    while (true) {
+        PaChunk pc;
+        if (pipelined) {
+            std::unique_lock<std::mutex> l(pm);
+            pcv.wait(l, [&] { return !ready.empty() || prod_done; });
+            if (ready.empty()) break;
+            pc = std::move(ready.front());
+            ready.pop_front();
+        } else {
+            if (np_tpos >= r1) break;
+            // one chunk, inline: same code path, same thread and stream
+            const int64_t save_r0 = r0;
+            r0 = np_tpos;
+            prod_done = false;
+            producer();
+            r0 = save_r0;
+            if (prod_err) std::rethrow_exception(prod_err);
+            if (ready.empty()) break;
+            pc = std::move(ready.front());
+            ready.pop_front();
+            np_tpos = pc.tend;
+        }
+        const int64_t tpos = pc.tpos;
+        TaskSpan ht;
+        ht.p = tasks_h.p + tpos;
+        ht.n = (size_t)(pc.tend - tpos);
+        std::vector<int64_t> &res_off = pc.res_off;
+        std::vector<LmChain2> &resv = pc.resv;
+        // this chunk's windows of tasks with chains must fit the round's buffer: close the round first if they might not
+        {
+            int64_t need = 0;
+            for (size_t t = 0; t < ht.size(); t++)
+                if (res_off[t + 1] > res_off[t]) need += ((int64_t)ht[t].wlen + 15) & ~(int64_t)15;
+            if (gw_used > 0 && (gw_used + need > (int64_t)a.gwbuf.cap - 64 || (int64_t)hsps.size() >= round_hsps)) flush_round();
+            if (gw_used == 0) a.gwbuf.ensure((size_t)std::max<int64_t>(need, gw_target) + 64);
+        }
+        double tb = now_ms();
+        // glue per segment with results (parallel; the order of `genomes` stays the segment order)
+        const size_t hs0 = hsps.size(); // this chunk's HSPs go behind the round's
+        {
+            std::vector<std::pair<size_t, size_t>> active; // task ranges of the segments that have Chain2 results
+            for (size_t i = 0; i < ht.size();) {
+                size_t e = i;
+                while (e < ht.size() && ht[e].seg == ht[i].seg) e++;
+                if (res_off[e] > res_off[i] && ht[i].g >= 0) active.push_back({i, e});
+                i = e;
+            }
+            const int64_t ns = (int64_t)active.size();
+            const double tg0 = now_ms();
+            std::vector<HGenome> gens((size_t)ns);
+            std::vector<int32_t> nh((size_t)ns + 1, 0); // HSPs per segment
+            (void)div_from_pseudo_pident(0);            // builds its table before the threads use it
+            parallel_for(ns, 64, [&](int64_t s0, int64_t s1) {
+                for (int64_t si = s0; si < s1; si++) {
+                    size_t i = active[si].first, e = active[si].second;
+                    HGenome &gen = gens[si];
+                    gen.q = ht[i].q;
+                    gen.bg = ht[i].bg;
+                    gen.g = ht[i].g;
+                    std::map<AKey, bool> keys;
+                    for (size_t t = i; t < e; t++)
+                        glue_task(ix, gen, keys, ht[t], (int64_t)t, resv.data() + res_off[t],
+                                  (int)(res_off[t + 1] - res_off[t]));
+                    // HSP list (Update2 + the start of the finalisation loops :2223-2255 / :2490-2522): which chains
+                    // go to extendMatch/WFA; c.hsp = index within the genome for now
+                    int qlen = (int)(qb->h_qoff[gen.q + 1] - qb->h_qoff[gen.q]);
+                    int cnt = 0;
+                    for (auto &cl : gen.sds)
+                        for (auto &c : cl.chains) {
+                            c.aligned_fraction = (double)c.aligned_bases_q / (double)qlen * 100;
+                            if (c.qbegin >= c.qend + 1) {
+                                c.alive = false;
+                                continue;
+                            }
+                            int start, end;
+                            if (cl.rc) {
+                                start = cl.tEnd - c.tend - c.tpos_offset_begin;
+                                end = cl.tEnd - c.tbegin - c.tpos_offset_begin + 1;
+                            } else {
+                                start = c.tpos_offset_begin + c.tbegin - cl.tBegin;
+                                end = c.tpos_offset_begin + c.tend - cl.tBegin + 1;
+                            }
+                            if (start >= end) {
+                                c.alive = false;
+                                continue;
+                            }
+                            c.hsp = cnt++;
+                        }
+                    nh[si] = cnt;
+                }
+            });
+            const double tg1 = now_ms();
+            std::vector<int64_t> hbase((size_t)ns + 1, 0);
+            for (int64_t si = 0; si < ns; si++) hbase[si + 1] = hbase[si] + nh[si];
+            hsps.resize(hs0 + (size_t)hbase[ns]);
+            // compact window offsets (in the round's window buffer) of the tasks with chains
+            std::vector<int64_t> tdest(ht.size(), -1);
+            std::vector<int32_t> widx;
+            std::vector<int64_t> wdest;
+            for (int64_t si = 0; si < ns; si++)
+                for (size_t t = active[si].first; t < active[si].second; t++)
+                    if (res_off[t + 1] > res_off[t] && ht[t].wlen > 0) {
+                        tdest[t] = gw_used;
+                        widx.push_back((int32_t)t);
+                        wdest.push_back(gw_used);
+                        gw_used += ((int64_t)ht[t].wlen + 15) & ~(int64_t)15;
+                    }
+            parallel_for(ns, 64, [&](int64_t s0, int64_t s1) {
+                for (int64_t si = s0; si < s1; si++) {
+                    HGenome &gen = gens[si];
+                    int qlen = (int)(qb->h_qoff[gen.q + 1] - qb->h_qoff[gen.q]);
+                    for (auto &cl : gen.sds) {
+                        const Task &t = ht[cl.task];
+                        for (auto &c : cl.chains) {
+                            if (!c.alive || c.hsp < 0) continue;
+                            int start, end;
+                            if (cl.rc) {
+                                start = cl.tEnd - c.tend - c.tpos_offset_begin;
+                                end = cl.tEnd - c.tbegin - c.tpos_offset_begin + 1;
+                            } else {
+                                start = c.tpos_offset_begin + c.tbegin - cl.tBegin;
+                                end = c.tpos_offset_begin + c.tend - cl.tBegin + 1;
+                            }
+                            int ext2 = ix->opt.ext_len2;
+                            if (c.aligned_bases_q > 1000000)
+                                ext2 += 80;
+                            else if (c.aligned_bases_q > 250000)
+                                ext2 += 40;
+                            else if (c.aligned_bases_q > 50000)
+                                ext2 += 20;
+                            else if (c.aligned_bases_q > 10000)
+                                ext2 += 10;
+                            c.hsp += (int64_t)hs0 + hbase[si];
+                            HspMeta &h = hsps[(size_t)c.hsp];
+                            h.task = cl.task;
+                            h.est_div = (float)div_from_pseudo_pident(c.pident);
+                            h.q = gen.q;
+                            h.in.q = gen.q;
+                            h.in.rc = cl.rc ? 1 : 0;
+                            h.in.woff = tdest[cl.task];
+                            h.in.len1 = qlen;
+                            h.in.len2 = t.wlen;
+                            h.in.start1 = c.qbegin;
+                            h.in.end1 = c.qend + 1;
+                            h.in.start2 = start;
+                            h.in.end2 = end;
+                            h.in.ext_len = ext2;
+                            h.in.tbegin = c.tbegin;
+                            h.in.max_ext_len = c.max_ext_len;
+                            h.in.pad = 0;
+                        }
+                    }
+                }
+            });
+            const double tg2 = now_ms();
+            // the windows of those tasks, from the 2-bit genomes into the round's buffer (it was sized before this chunk)
+            if (!widx.empty()) {
+                a.gw_idx.ensure(widx.size());
+                a.gw_dest.ensure(wdest.size());
+                HIPCHK(hipMemcpyAsync(a.gw_idx.p, widx.data(), widx.size() * sizeof(int32_t), hipMemcpyHostToDevice, S(ix)));
+                HIPCHK(hipMemcpyAsync(a.gw_dest.p, wdest.data(), wdest.size() * sizeof(int64_t), hipMemcpyHostToDevice, S(ix)));
+                Prof p(ix, "k_extract_windows", (gw_used - wdest[0]) * 5 / 4);
+                launch_extract_windows_at(S(ix), ix->view, w.tasks.p + tpos, a.gw_idx.p, a.gw_dest.p, (int64_t)widx.size(), a.gwbuf.p);
+                sync(ix); // the host lists go out of scope
+            }
+            genomes.reserve(genomes.size() + (size_t)ns);
+            for (int64_t si = 0; si < ns; si++)
+                if (!gens[si].sds.empty()) genomes.push_back(std::move(gens[si]));
+            if (getenv("LM_DEBUG"))
+                fprintf(stderr, "[lm] glue: active scan %.2f, glue_task pass %.2f, hsp fill %.2f, move %.2f ms (%lld genomes)\n",
+                        tg0 - tb, tg1 - tg0, tg2 - tg1, now_ms() - tg2, (long long)ns);
+        }
+        st.ms_glue += now_ms() - tb;
+        janitor().dispose(std::move(resv));
+        {   // the chunk's pseudo-alignment results are consumed and its windows copied: its context may take the next chunk
             std::lock_guard<std::mutex> l(pm);
             slot_free[pc.slot] = true;
         }
         pcv.notify_all();
     }
+    flush_round();
     if (pipelined) {
         if (prod_thread.joinable()) prod_thread.join();
         if (prod_err) std::rethrow_exception(prod_err);

@@ -320,7 +320,9 @@ def test_chunked_alignment_and_anchor_buffer_rerun_give_the_same_rows(both, quer
     monkeypatch.setenv("LM_DEBUG_MAX_WINDOW_BYTES", "20000")   # a few chain windows per chunk
     monkeypatch.setenv("LM_DEBUG_PA_CAP", "64")                # anchor buffer far too small -> counted, re-run
     monkeypatch.setenv("LM_DEBUG_PA_WIDE_KEYS", "1")           # two-key anchors (the layout for > 64 key bits)
+    monkeypatch.setenv("LM_DEBUG_ROUND_HSPS", "7")             # several extendMatch / WFA rounds, each over a few chunks
     got, st1 = gi.search(seqs)
+    monkeypatch.delenv("LM_DEBUG_ROUND_HSPS")
     monkeypatch.delenv("LM_DEBUG_MAX_WINDOW_BYTES")
     monkeypatch.delenv("LM_DEBUG_PA_CAP")
     monkeypatch.delenv("LM_DEBUG_PA_WIDE_KEYS")
