@@ -1236,9 +1236,17 @@ LM_HDN bool lm_tree_search_range(const uint64_t *keys, int n, uint64_t key, int 
     return lm_tree_search_miss(keys, n, key, p, K, lo, lo_out, hi_out);
 }
 
-// Prefix filter of the pseudo-alignment (k_build_cmp_bits / k_pa_anchors): per query two bitmaps of 2^log bits each, over
-// the hashed 11-base and 9-base prefixes of its k-mers (the second one right after the first).  lm_pa_candidate is a
-// NECESSARY condition for lm_tree_search_range(keys, key, p) to return true (p >= 11):
+// Prefix filter of the pseudo-alignment (k_build_cmp_bits / k_pa_filter).  Per query, lm_pa_bits_words(log) words:
+//   [0, W)        hashed bitmap of the 11-base prefixes of its k-mers, 2^log bits (~16 per k-mer), W = 2^(log-5)
+//   [W, 2W)       hashed bitmap of the 9-base prefixes, 2^log bits            (generic path only: lm_pa_candidate)
+//   [2W, 2W + B)  Bloom filter of the 11-base prefixes, two hash functions, 2^blog bits, blog = min(log, 19), B = 2^(blog-5)
+//   [.., + 8192)  exact bitmap of the 9-base prefixes (4^9 = 2^18 bits)
+// The last two (<= 96 KB) are what a workgroup of k_pa_filter keeps in LDS for the query it works on: a chain window of
+// an unrelated genome (most windows of a search against 10^5 genomes: random 17-base seed matches) is then rejected
+// position by position without a single global load; the 11-base bitmap in global memory is only asked for positions the
+// Bloom filter lets through when it is the more selective one (log > blog: reads above ~16 kb).
+// lm_pa_candidate / lm_pa_candidate2 are NECESSARY conditions for lm_tree_search_range(keys, key, p) to return true
+// (p >= 11):
 //   * some query k-mer shares the key's 11-base prefix (a normal match needs >= p >= 11 common bases), or
 //   * the 11-base map misses, so the longest common prefix L is <= 10 and only the partial-prefix rule of tree.Search
 //     (tree.go:496-500) can fire: at a node of depth d <= L-1 with the key's bases [d, p) all A.  With a = the number of
@@ -1246,8 +1254,31 @@ LM_HDN bool lm_tree_search_range(const uint64_t *keys, int n, uint64_t key, int 
 //     a >= p - 7 (bases [7, p) all A: rare, always a candidate) or d >= 8, so L >= 9 and the 9-base map must hit.
 #define LM_PFX_BASES 11
 #define LM_PFX_BASES2 9
+#define LM_PA_BLOOM_LOG_MAX 19
+#define LM_PA_MAP9_LOG 18
 LM_HD uint32_t lm_pa_filter_slot(uint32_t pfx, int log) {
     return (pfx * 0x9E3779B1u) >> (32 - log);
+}
+LM_HD int lm_pa_bloom_log(int log) { return log < LM_PA_BLOOM_LOG_MAX ? log : LM_PA_BLOOM_LOG_MAX; }
+LM_HD uint32_t lm_pa_bloom_slot(uint32_t pfx, int which, int blog) {
+    return (pfx * (which ? 0xC2B2AE35u : 0x85EBCA6Bu)) >> (32 - blog);
+}
+LM_HD uint64_t lm_pa_bits_words(int log) {
+    return 2 * ((uint64_t)1 << (log - 5)) + ((uint64_t)1 << (lm_pa_bloom_log(log) - 5)) + ((uint64_t)1 << (LM_PA_MAP9_LOG - 5));
+}
+LM_HD uint64_t lm_pa_bloom_word0(int log) { return 2 * ((uint64_t)1 << (log - 5)); }
+LM_HD uint64_t lm_pa_map9_word0(int log) { return lm_pa_bloom_word0(log) + ((uint64_t)1 << (lm_pa_bloom_log(log) - 5)); }
+// every bit a k-mer of the query sets (`or_bit(word index, mask)`: atomicOr on the device)
+template <typename OrBit> LM_HD void lm_pa_filter_set(uint64_t key, int K, int log, OrBit or_bit) {
+    const uint32_t p11 = (uint32_t)(key >> ((K - LM_PFX_BASES) << 1)), p9 = (uint32_t)(key >> ((K - LM_PFX_BASES2) << 1));
+    const int blog = lm_pa_bloom_log(log);
+    const uint32_t h = lm_pa_filter_slot(p11, log), h2 = lm_pa_filter_slot(p9, log);
+    or_bit((uint64_t)(h >> 5), 1u << (h & 31));
+    or_bit(((uint64_t)1 << (log - 5)) + (h2 >> 5), 1u << (h2 & 31));
+    const uint32_t a = lm_pa_bloom_slot(p11, 0, blog), b = lm_pa_bloom_slot(p11, 1, blog);
+    or_bit(lm_pa_bloom_word0(log) + (a >> 5), 1u << (a & 31));
+    or_bit(lm_pa_bloom_word0(log) + (b >> 5), 1u << (b & 31));
+    or_bit(lm_pa_map9_word0(log) + (p9 >> 5), 1u << (p9 & 31));
 }
 LM_HD bool lm_pa_candidate(const uint32_t *bits, int log, uint64_t key, int p, int K) {
     const uint32_t h = lm_pa_filter_slot((uint32_t)(key >> ((K - LM_PFX_BASES) << 1)), log);
@@ -1258,6 +1289,24 @@ LM_HD bool lm_pa_candidate(const uint32_t *bits, int log, uint64_t key, int p, i
     const uint32_t h2 = lm_pa_filter_slot((uint32_t)(key >> ((K - LM_PFX_BASES2) << 1)), log);
     const uint32_t *bits2 = bits + ((uint64_t)1 << (log - 5));
     return ((bits2[h2 >> 5] >> (h2 & 31)) & 1u) != 0;
+}
+// the test k_pa_filter runs per (window position, strand): `f` = the first p bases of the k-mer (11 <= p <= 15),
+// `bloom` / `map9` = the query's Bloom filter and exact 9-base map (LDS copies on the device), `bits11` = its hashed
+// 11-base bitmap in global memory
+LM_HD bool lm_pa_candidate2(const uint32_t *bloom, int blog, const uint32_t *map9, const uint32_t *bits11, int log,
+                            uint32_t f, int p) {
+    const uint32_t p11 = f >> ((p - LM_PFX_BASES) << 1);
+    const uint32_t a = lm_pa_bloom_slot(p11, 0, blog), b = lm_pa_bloom_slot(p11, 1, blog);
+    bool hit = (((bloom[a >> 5] >> (a & 31)) & (bloom[b >> 5] >> (b & 31))) & 1u) != 0;
+    if (hit && log > blog) {
+        const uint32_t h = lm_pa_filter_slot(p11, log);
+        hit = ((bits11[h >> 5] >> (h & 31)) & 1u) != 0;
+    }
+    if (hit) return true;
+    if (f & ((1u << ((p - 9) << 1)) - 1u)) return false; // bases [9, p) not all A
+    if ((f & ((1u << ((p - 7) << 1)) - 1u)) == 0) return true; // bases [7, p) all A
+    const uint32_t p9 = f >> ((p - LM_PFX_BASES2) << 1);
+    return ((map9[p9 >> 5] >> (p9 & 31)) & 1u) != 0;
 }
 
 // Same, with the two binary searches narrowed by a bucket table over the leading `tab_bits/2` bases:
@@ -1280,6 +1329,31 @@ LM_HD bool lm_tree_search_range_tab(const uint64_t *keys, int n, uint64_t key, i
     // the quirk needs bases [L,p) of the key to be A for some L < p: base p-1 is A or nothing is returned
     if ((key >> sh) & 3ull) return false;
     return lm_tree_search_miss(keys, n, key, p, K, lo, lo_out, hi_out);
+}
+
+// The form k_pa_search uses: only the lower bound is searched.  Returns 1 when keys share >= p bases with `key`: the
+// matches are keys[*lo_out], keys[*lo_out + 1], ... while they stay <= *right_out (the caller enumerates them anyway, so the
+// upper-bound search would be wasted loads); 2 when the partial-prefix quirk returns the subtree [*lo_out, *hi_out); 0 for
+// no result.  Same results as lm_tree_search_range (checked on the CPU against the reference radix tree).
+LM_HD int lm_tree_search_first_tab(const uint64_t *keys, int n, uint64_t key, int p, int K, const uint32_t *tab, int tab_bits,
+                                   int *lo_out, int *hi_out, uint64_t *right_out) {
+    if (n <= 0) return 0;
+    if (p > K) p = K;
+    const int sh = (K - p) << 1;
+    const uint64_t low = sh >= 64 ? ~0ull : ((1ull << sh) - 1);
+    const uint64_t left = key & ~low, right = key | low;
+    const uint32_t b = (uint32_t)(key >> ((K << 1) - tab_bits));
+    const int bend = (int)tab[b + 1];
+    const int lo = lm_lower_bound_u64(keys, (int)tab[b], bend, left);
+    if (lo < bend && keys[lo] <= right) { // keys sharing p bases lie in one bucket (2p >= tab_bits)
+        *lo_out = lo;
+        *hi_out = bend;
+        *right_out = right;
+        return 1;
+    }
+    if ((key >> sh) & 3ull) return 0; // the quirk needs base p-1 of the key to be A
+    *right_out = ~0ull;
+    return lm_tree_search_miss(keys, n, key, p, K, lo, lo_out, hi_out) ? 2 : 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -3,7 +3,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <cstdlib>
+#include <map>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -27,30 +30,168 @@ struct HipError : std::runtime_error {
                            std::to_string(__LINE__));                                                        \
     } while (0)
 
+// a scratch allocation failed: the search path answers by dropping its scratch and halving the query batch part
+struct DeviceOOM : HipError {
+    explicit DeviceOOM(const std::string &m) : HipError(m) {}
+};
+inline std::atomic<int64_t> g_dbuf_bytes{0}; // device bytes held by all DBufs of the process (index image + scratch)
+
+// Scratch of one index handle that comes and goes with the halves of a search (seeding / alignment): carved
+// out of a few large device allocations ("slabs") that stay with the handle, because hipMalloc / hipFree of tens of GB per
+// batch part cost seconds (the driver clears the pages).  First fit by address inside a slab, free neighbours coalesce; at
+// the end of a half every block is back, so the next half finds whole slabs.  A request no slab can take gets a slab of
+// its own; when the device refuses one, the empty slabs are handed back first.
+struct ScratchArena {
+    struct Slab {
+        char *base = nullptr;
+        size_t size = 0;
+        std::map<size_t, size_t> free; // offset -> length
+    };
+    std::mutex mu;
+    std::vector<Slab> slabs;
+    std::unordered_map<void *, std::pair<int, size_t>> live; // block -> (slab, length)
+    int64_t slab_bytes = 0, live_bytes = 0, slab_allocs = 0;
+    static constexpr size_t ALIGN = 4096;
+    ~ScratchArena() { trim(); }
+    void *alloc(size_t bytes) { // throws DeviceOOM
+        bytes = (bytes + ALIGN - 1) / ALIGN * ALIGN;
+        std::lock_guard<std::mutex> l(mu);
+        for (int pass = 0; pass < 2; pass++) {
+            int bs = -1;
+            size_t boff = 0, blen = ~(size_t)0;
+            for (size_t si = 0; si < slabs.size(); si++)
+                for (auto &f : slabs[si].free)
+                    if (f.second >= bytes && f.second < blen) { // best fit over all slabs
+                        bs = (int)si;
+                        boff = f.first;
+                        blen = f.second;
+                    }
+            if (bs >= 0) {
+                Slab &sl = slabs[bs];
+                sl.free.erase(boff);
+                if (blen > bytes) sl.free[boff + bytes] = blen - bytes;
+                void *p = sl.base + boff;
+                live[p] = {bs, bytes};
+                live_bytes += (int64_t)bytes;
+                return p;
+            }
+            if (pass == 1) break;
+            char *base = nullptr;
+            hipError_t e = hipMalloc((void **)&base, bytes);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                trim_locked();
+                e = hipMalloc((void **)&base, bytes);
+            }
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                size_t fr = 0, tot = 0;
+                (void)hipMemGetInfo(&fr, &tot);
+                throw DeviceOOM("device scratch allocation of " + std::to_string(bytes >> 20) + " MB failed (" +
+                                hipGetErrorString(e) + "; " + std::to_string(fr >> 20) + " MB free, " +
+                                std::to_string(slab_bytes >> 20) + " MB in scratch slabs, " +
+                                std::to_string(g_dbuf_bytes.load() >> 20) + " MB held by this library): use a smaller query batch");
+            }
+            Slab sl;
+            sl.base = base;
+            sl.size = bytes;
+            sl.free[0] = bytes;
+            int slot = -1;
+            for (size_t si = 0; si < slabs.size(); si++)
+                if (!slabs[si].base) slot = (int)si;
+            if (slot < 0) {
+                slabs.push_back(std::move(sl));
+            } else {
+                slabs[slot] = std::move(sl);
+            }
+            slab_bytes += (int64_t)bytes;
+            slab_allocs++;
+        }
+        throw DeviceOOM("scratch arena: internal error");
+    }
+    bool release(void *p) {
+        std::lock_guard<std::mutex> l(mu);
+        auto it = live.find(p);
+        if (it == live.end()) return false;
+        Slab &sl = slabs[it->second.first];
+        size_t off = (size_t)((char *)p - sl.base), len = it->second.second;
+        live_bytes -= (int64_t)len;
+        live.erase(it);
+        auto nx = sl.free.lower_bound(off);
+        if (nx != sl.free.end() && off + len == nx->first) { // merge with the free block behind
+            len += nx->second;
+            nx = sl.free.erase(nx);
+        }
+        if (nx != sl.free.begin()) {
+            auto pv = std::prev(nx);
+            if (pv->first + pv->second == off) { // and with the one in front
+                pv->second += len;
+                return true;
+            }
+        }
+        sl.free[off] = len;
+        return true;
+    }
+    void trim_locked() { // hand the slabs without a live block back to the device
+        for (auto &sl : slabs)
+            if (sl.base && sl.free.size() == 1 && sl.free.begin()->second == sl.size) {
+                (void)hipFree(sl.base);
+                slab_bytes -= (int64_t)sl.size;
+                sl = Slab();
+            }
+    }
+    void trim() {
+        std::lock_guard<std::mutex> l(mu);
+        trim_locked();
+    }
+};
+// the arena (and the stream) of the search running on this thread; null outside lm_search_*: plain device allocations
+inline thread_local ScratchArena *tls_arena = nullptr;
+inline thread_local hipStream_t tls_stream = nullptr;
+
 template <typename T> struct DBuf {
     T *p = nullptr;
     size_t cap = 0;
+    ScratchArena *arena = nullptr; // the block lives in this arena (phase == true buffers of a running search)
+    bool phase = false;            // released at the end of each half of a search: may live in the handle's arena
     DBuf() = default;
     DBuf(const DBuf &) = delete;
     DBuf &operator=(const DBuf &) = delete;
-    ~DBuf() {
-        if (p) (void)hipFree(p);
-    }
+    ~DBuf() { release(); }
+    size_t bytes() const { return cap * sizeof(T); }
+    static constexpr size_t ARENA_MIN = (size_t)32 << 20; // smaller buffers stay plain grow-only allocations
     void ensure(size_t n) {
         if (n <= cap && p) return;
-        if (p) (void)hipFree(p);
-        p = nullptr;
+        if (p && arena) { // the block goes back while earlier launches of this thread may still read it
+            if (tls_stream) (void)hipStreamSynchronize(tls_stream); else (void)hipDeviceSynchronize();
+        }
+        release();
         size_t want = std::max<size_t>(n + n / 8, 64);
-        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
-        if (e != hipSuccess) {
-            p = nullptr;
-            cap = 0;
-            size_t fr = 0, tot = 0;
-            (void)hipMemGetInfo(&fr, &tot);
-            throw HipError("device scratch allocation of " + std::to_string(want * sizeof(T) >> 20) + " MB failed (" +
-                           hipGetErrorString(e) + "; " + std::to_string(fr >> 20) + " MB free): use a smaller query batch");
+        if (phase && tls_arena && want * sizeof(T) >= ARENA_MIN) {
+            p = (T *)tls_arena->alloc(want * sizeof(T));
+            arena = tls_arena;
+        } else {
+            hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+            if (e != hipSuccess) {
+                p = nullptr;
+                (void)hipGetLastError();
+                if (tls_arena) { // memory parked in empty slabs
+                    tls_arena->trim();
+                    e = hipMalloc((void **)&p, want * sizeof(T));
+                }
+            }
+            if (e != hipSuccess) {
+                p = nullptr;
+                (void)hipGetLastError();
+                size_t fr = 0, tot = 0;
+                (void)hipMemGetInfo(&fr, &tot);
+                throw DeviceOOM("device scratch allocation of " + std::to_string(want * sizeof(T) >> 20) + " MB failed (" +
+                                hipGetErrorString(e) + "; " + std::to_string(fr >> 20) + " MB free, " +
+                                std::to_string(g_dbuf_bytes.load() >> 20) + " MB held by this library): use a smaller query batch");
+            }
         }
         cap = want;
+        g_dbuf_bytes += (int64_t)bytes();
     }
     // exactly n elements (the immutable index arrays: no head-room, optionally zero-filled)
     void alloc_exact(size_t n, bool zero = false, hipStream_t st = nullptr) {
@@ -58,10 +199,19 @@ template <typename T> struct DBuf {
         size_t want = std::max<size_t>(n, 1);
         HIPCHK(hipMalloc((void **)&p, want * sizeof(T)));
         cap = want;
+        g_dbuf_bytes += (int64_t)bytes();
         if (zero) HIPCHK(hipMemsetAsync(p, 0, want * sizeof(T), st));
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) {
+            if (arena) {
+                arena->release(p);
+            } else {
+                (void)hipFree(p);
+            }
+            g_dbuf_bytes -= (int64_t)bytes();
+        }
+        arena = nullptr;
         p = nullptr;
         cap = 0;
     }
@@ -151,6 +301,7 @@ struct lm_index {
     DevIndexView view;
     int64_t hbm_bytes = 0;
     // scratch
+    ScratchArena arena;      // phase buffers of the searches on this handle (destroyed after work / actx)
     DBuf<uint8_t> tmp, tmp2; // rocPRIM temporary storage (per stream)
     // profiling
     bool prof = false;

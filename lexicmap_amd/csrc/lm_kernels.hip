@@ -8,7 +8,8 @@
 //                                                               in seed-list order, sampled top array first
 //   k_chain1            one lane per (query, genome)         -> ClearSubstrPairs + Chainer.Chain
 //   k_make_tasks        one lane per (query, genome)         -> chain windows
-//   k_pa_anchors        one workgroup per chain window       -> SeqComparator.Compare anchor generation
+//   k_pa_filter         one workgroup per 64 chain windows   -> SeqComparator.Compare: positions that can match (LDS maps)
+//   k_pa_search         one lane per candidate position      -> tree.Search emulation + anchors
 //   k_pa_chain_wave     one wavefront per chain              -> Clear + Trim + Chainer2
 //   k_extract_windows   one workgroup per chain with results -> 2-bit genome -> ASCII window (rc applied)
 //   k_extend_count/k_extend/k_extend_fin one lane per HSP flank -> extendMatch (Chainer3 on the (q,t) grid)
@@ -88,13 +89,11 @@ __global__ void k_build_cmp_tab(const uint64_t *__restrict__ keys_cmp, const int
         tab[t] = (uint32_t)lo;
     }
 }
-// Prefix filter of a query for the pseudo-alignment (lm_pa_candidate, lm_algos.h): two bitmaps of 2^log bits over the
-// hashed 11-base prefixes (the smallest prefix length SeqComparator.Compare ever asks for, lib-seq_compare.go:339-348) and
-// 9-base prefixes of its (filtered) k-mers, sized per query with ~16 bits per k-mer (a 1.5-kb gene: 64 Kbit, a 50-kb read:
-// 2 Mbit).  One load decides ~95 % of the window positions of k_pa_anchors; the 9-base map settles the positions where only
-// the partial-prefix rule of tree.Search could still fire.  The earlier exact 8-base map filled up with long reads (a
-// 20-kb read sets 45 % of its 65536 bits).
-__device__ __forceinline__ uint32_t pfx_slot(uint32_t pfx, int log) { return lm_pa_filter_slot(pfx, log); }
+// Prefix filters of a query for the pseudo-alignment (layout and logic: lm_pa_filter_set / lm_pa_candidate2, lm_algos.h):
+// hashed bitmaps of 2^log bits over the 11-base prefixes (the smallest prefix length SeqComparator.Compare ever asks for,
+// lib-seq_compare.go:339-348) and the 9-base prefixes of its (filtered) k-mers, sized per query with ~16 bits per k-mer
+// (a 1.5-kb gene: 64 Kbit, a 50-kb read: 2 Mbit), plus the two maps k_pa_filter keeps in LDS: a two-hash Bloom filter
+// of the 11-base prefixes (<= 2^19 bits) and the exact 2^18-bit map of the 9-base prefixes.
 __global__ __launch_bounds__(256) void k_build_cmp_bits(const uint64_t *__restrict__ keys_cmp,
                                                          const int64_t *__restrict__ posoff,
                                                          const int32_t *__restrict__ nvalid, int nq, int K,
@@ -105,13 +104,9 @@ __global__ __launch_bounds__(256) void k_build_cmp_bits(const uint64_t *__restri
         const uint64_t *keys = keys_cmp + 2 * posoff[q];
         const int n = nvalid[q];
         const int log = bits_log[q];
-        uint32_t *b = bits + bits_off[q], *b2 = b + ((size_t)1 << (log - 5));
-        for (int j = threadIdx.x; j < n; j += blockDim.x) {
-            const uint32_t h = pfx_slot((uint32_t)(keys[j] >> ((K - LM_PFX_BASES) << 1)), log);
-            atomicOr(&b[h >> 5], 1u << (h & 31));
-            const uint32_t h2 = pfx_slot((uint32_t)(keys[j] >> ((K - LM_PFX_BASES2) << 1)), log);
-            atomicOr(&b2[h2 >> 5], 1u << (h2 & 31));
-        }
+        uint32_t *b = bits + bits_off[q];
+        for (int j = threadIdx.x; j < n; j += blockDim.x)
+            lm_pa_filter_set(keys[j], K, log, [&](uint64_t w, uint32_t m) { atomicOr(&b[w], m); });
     }
 }
 
@@ -598,7 +593,7 @@ __device__ __forceinline__ void pa_kmer(const Task &t, const uint8_t *__restrict
 }
 
 // The first P bases (P <= 16) of the window k-mer at position i and of its reverse complement, straight from the packed
-// genome: all the per-position test of k_pa_anchors needs (8-base bitmap prefix + the bases [7, P) of the
+// genome: all the per-position test of k_pa_filter needs (11-base filter prefix + the bases [7, P) of the
 // partial-prefix rule). About half the arithmetic of building both full k-mers.
 __device__ __forceinline__ uint32_t revcomp_small(uint32_t x, int P) { // P bases in the low 2P bits
     uint32_t y = __builtin_bitreverse32(~x);
@@ -641,191 +636,247 @@ __device__ __forceinline__ PaCtx pa_ctx(const Task &t, const uint64_t *keys_cmp,
     return c;
 }
 
-// ---- single-pass pseudo-alignment anchors ----------------------------------------------------------------------------
-// k_pa_anchors replaces a count / scan / emit triple: one workgroup per chain window. Per window position every thread
-// only extracts the 2-bit k-mer (and its reverse complement) from the packed genome and tests the query's 8-base prefix
-// bitmap: ~95 % of the (position, strand) pairs end there. The rest - a query k-mer shares 8 bases, or the k-mer's
-// bases [7, p) are all A so the partial-prefix rule of tree.Search could fire - go into an LDS work list that the whole
-// workgroup processes densely with the exact search (lm_tree_search_range_tab) and the enumeration of the matches, so
-// the expensive path is never executed by a wavefront for the sake of one lane. Anchors are staged in LDS and appended
-// to the global list with one atomic per flush; their order is irrelevant because the list is sorted by (task, B)
-// afterwards. `count` keeps counting past `cap`, so the host can re-run with a larger buffer.
-#define PA_UNROLL 2 /* window positions per thread between two barriers */
-#define PA_QCAP 2048 /* >= 2 * 512 * PA_UNROLL */
-#define PA_OCAP 2048
-__global__ __launch_bounds__(256) void k_pa_anchors(DevIndexView ix, const Task *__restrict__ tasks, int64_t ntasks,
-                                                     const uint8_t *__restrict__ wbuf,
-                                                     const uint64_t *__restrict__ keys_cmp,
-                                                     const uint32_t *__restrict__ vals_cmp,
-                                                     const int64_t *__restrict__ posoff, const int32_t *__restrict__ nvalid,
-                                                     const uint32_t *__restrict__ cmp_tab,
-                                                     const uint32_t *__restrict__ cmp_bits,
-                                                     const int64_t *__restrict__ bits_off,
-                                                     const int32_t *__restrict__ bits_log, int K, int min_prefix,
-                                                     unsigned long long *__restrict__ count, int64_t cap,
-                                                     uint64_t *__restrict__ outA, uint64_t *__restrict__ outB, int qbits,
-                                                     int tbits) {
-    // qbits > 0: compact single-key anchors, task | QBegin:qbits | (32-Len):6 | TBegin:tbits | 2 flags in one u64 (outA is
-    // not written): same order as (task, B) and one keys-only radix sort over the bits in use instead of two pair sorts
-    __shared__ uint32_t q_item[PA_QCAP]; // position << 1 | strand (1 = reverse complement)
-    __shared__ uint64_t s_out[PA_OCAP];
-    __shared__ int q_n, s_on;
-    __shared__ unsigned long long s_base;
-    const int tid = threadIdx.x;
-    for (int64_t ti = blockIdx.x; ti < ntasks; ti += gridDim.x) {
-        const Task t = tasks[ti];
-        const uint8_t *w = wbuf + t.woff;
-        const PaCtx c = pa_ctx(t, keys_cmp, vals_cmp, posoff, nvalid, cmp_tab, cmp_bits, bits_off, bits_log, K, min_prefix);
-        const uint8_t *gb = t.g >= 0 ? ix.gbits : nullptr;
-        const int64_t goff = t.g >= 0 ? ix.g_off[t.g] : 0;
-        const int npos = c.n > 0 ? t.wlen - K + 1 : 0;
-        const int p = c.m > K ? K : c.m;
-        const bool use_bits = c.bits != nullptr && p >= LM_PFX_BASES && K >= LM_PFX_BASES;
-        const bool fast_pfx = use_bits && gb != nullptr && p <= 15 && K >= 16;
-        if (tid == 0) {
-            q_n = 0;
-            s_on = 0;
-        }
-        __syncthreads();
-        const int sh_t = 2, sh_l = 2 + tbits, sh_q = 8 + tbits, sh_a = 8 + tbits + qbits;
-        auto emit = [&](uint64_t B) {
-            if (qbits > 0) { // repack the fields of B under the task number
-                const LmSub u = lm_unpack_anchor(B);
-                B = ((uint64_t)ti << sh_a) | ((uint64_t)(uint32_t)u.qbegin << sh_q) | ((uint64_t)(32 - (int)u.len) << sh_l) |
-                    ((uint64_t)(uint32_t)u.tbegin << sh_t) | ((uint64_t)u.qrc << 1) | (uint64_t)u.trc;
-            }
-            int slot = atomicAdd(&s_on, 1);
-            if (slot < PA_OCAP) {
-                s_out[slot] = B;
-            } else { // staging buffer full (rare): straight to the global list
-                unsigned long long idx = atomicAdd(count, 1ull);
-                if ((int64_t)idx < cap) {
-                    if (qbits == 0) outA[idx] = (uint64_t)ti;
-                    outB[idx] = B;
-                }
-            }
-        };
-        auto flush = [&]() { // all threads
-            __syncthreads();
-            const int n = s_on < PA_OCAP ? s_on : PA_OCAP;
-            if (tid == 0 && n > 0) s_base = atomicAdd(count, (unsigned long long)n);
-            __syncthreads();
-            for (int j = tid; j < n; j += 256) {
-                const unsigned long long idx = s_base + (unsigned long long)j;
-                if ((int64_t)idx < cap) {
-                    if (qbits == 0) outA[idx] = (uint64_t)ti;
-                    outB[idx] = s_out[j];
-                }
-            }
-            __syncthreads();
-            if (tid == 0) s_on = 0;
-            __syncthreads();
-        };
-        auto drain = [&]() { // all threads: exact search + enumeration for the listed (position, strand) pairs
-            __syncthreads();
-            const int nq = q_n < PA_QCAP ? q_n : PA_QCAP;
-            for (int base = 0; base < nq; base += 256) {
-                if (base + tid < nq) {
-                    const uint32_t it = q_item[base + tid];
-                    const int i = (int)(it >> 1);
-                    const bool rcs = (it & 1u) != 0;
-                    uint64_t kmer, rc;
-                    pa_kmer(t, w, gb, goff, i, K, &kmer, &rc);
-                    const uint64_t key = rcs ? rc : kmer;
-                    const bool lowc = kmer == 0 || kmer == c.ccc || kmer == c.ggg || kmer == c.ttt; // lib-seq_compare.go:374
-                    int lo, hi;
-                    if (!lowc && lm_tree_search_range_tab(c.keys, c.n, key, c.m, K, c.tab, LM_TAB_BITS, &lo, &hi)) {
-                        for (int j = lo; j < hi; j++) {
-                            const uint32_t v = c.vals[j];
-                            const uint32_t lp = (uint32_t)lm_lcp(c.keys[j], key, K);
-                            if (!rcs) {
-                                const uint32_t pp = v >> 1;
-                                if ((v & 1u) == 1u || pp < c.begin || pp + lp > c.end) continue;
-                                emit(lm_pack_anchor((int)pp, (int)lp, i, false, false));
-                            } else {
-                                const uint32_t pp = (v >> 1) + (uint32_t)K - lp;
-                                if ((v & 1u) == 0u || pp + lp < c.begin || pp > c.end) continue;
-                                emit(lm_pack_anchor((int)pp, (int)lp, i + K - (int)lp, true, true));
-                            }
-                        }
-                    }
-                }
+// ---- pseudo-alignment anchors: filter + search ---------------------------------------------------------------------------
+// Two kernels replace a count / scan / emit triple over the window positions.
+//
+// k_pa_filter: a workgroup of 1024 threads takes PA_GROUP consecutive chain windows (tasks are in (query, genome) order, so
+// nearly always windows of ONE query) and keeps that query's Bloom filter of 11-base k-mer prefixes and its exact 9-base
+// prefix map in LDS (96 KB, lm_pa_candidate2).  Per window position a lane extracts the first p bases of the k-mer and of
+// its reverse complement from the 2-bit genome and asks the LDS maps: at 10^5 genomes nine windows in ten belong to
+// unrelated genomes (random 17-base seed matches) and ~97 % of their positions end there, without a global load beyond the
+// (coalesced) genome words.  What the Bloom filter lets through asks the query's 11-base bitmap in global memory when that
+// is the more selective one (reads above ~16 kb).  The survivors - some query k-mer shares 11 bases, or the partial-prefix
+// rule of tree.Search could fire - are appended to a candidate list (task, position, strand).  Wavefronts work
+// independently (no workgroup barrier except when the query changes): each stages its candidates in its own LDS strip and
+// appends them to the global list with one atomic per ~200.
+//
+// k_pa_search: one lane per candidate, no LDS, full occupancy (the exact search is a chain of ~10 dependent loads):
+// lm_tree_search_range_tab + the enumeration of the matches; a wavefront reserves room for all its anchors with one atomic.
+// Anchor order is irrelevant because the list is sorted by (task, B) afterwards.  Both counters keep counting past their
+// capacity, so the host can re-run with larger buffers.
+#define PA_THREADS 1024
+#define PA_WAVES (PA_THREADS / 64)
+#define PA_GROUP 64  /* chain windows per workgroup pass */
+#define PA_STAGE 256 /* candidates a wavefront stages in LDS */
+#define PA_LDS_BYTES ((1 << (LM_PA_BLOOM_LOG_MAX - 3)) + (1 << (LM_PA_MAP9_LOG - 3)) + PA_WAVES * PA_STAGE * 8)
+__global__ __launch_bounds__(PA_THREADS) void k_pa_filter(DevIndexView ix, const Task *__restrict__ tasks, int64_t ntasks,
+                                                           const uint8_t *__restrict__ wbuf,
+                                                           const int64_t *__restrict__ posoff,
+                                                           const int32_t *__restrict__ nvalid,
+                                                           const uint32_t *__restrict__ cmp_bits,
+                                                           const int64_t *__restrict__ bits_off,
+                                                           const int32_t *__restrict__ bits_log, int K, int min_prefix,
+                                                           unsigned long long *__restrict__ cand_count, int64_t cand_cap,
+                                                           uint64_t *__restrict__ cand) {
+    extern __shared__ uint64_t pa_lds[];                               // PA_LDS_BYTES, dynamic (above 64 KB)
+    uint64_t *s_stage = pa_lds;                                        // [PA_WAVES][PA_STAGE]
+    uint32_t *s_bloom = (uint32_t *)(pa_lds + PA_WAVES * PA_STAGE);    // 64 KB
+    uint32_t *s_map9 = s_bloom + (1 << (LM_PA_BLOOM_LOG_MAX - 5));     // 32 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint64_t *stg = s_stage + wave * PA_STAGE;
+    int n_stg = 0; // wave-uniform
+    const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    auto flush = [&]() { // this wavefront's staged candidates -> the global list
+        if (n_stg == 0) return;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(cand_count, (unsigned long long)n_stg);
+        base = __shfl(base, 0, 64);
+        for (int j = lane; j < n_stg; j += 64)
+            if ((int64_t)(base + (unsigned long long)j) < cand_cap) cand[base + (unsigned long long)j] = stg[j];
+        n_stg = 0;
+    };
+    auto push = [&](bool c, uint64_t rec) { // all lanes of the wavefront
+        const uint64_t m = __ballot(c);
+        if (m == 0) return;
+        if (c) stg[n_stg + __popcll(m & lt_mask)] = rec;
+        n_stg += __popcll(m);
+        if (n_stg > PA_STAGE - 64) flush(); // LDS accesses of one wavefront complete in program order
+    };
+    const int64_t ngroups = (ntasks + PA_GROUP - 1) / PA_GROUP;
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        int64_t lds_q = -1; // the query whose maps are in LDS
+        const int64_t tend = ntasks < (grp + 1) * PA_GROUP ? ntasks : (grp + 1) * PA_GROUP;
+        for (int64_t ti = grp * PA_GROUP; ti < tend; ti++) {
+            const Task t = tasks[ti];
+            const int n = nvalid[t.q];
+            const int npos = n > 0 ? t.wlen - K + 1 : 0;
+            if (npos <= 0) continue;
+            const uint8_t *w = wbuf + t.woff;
+            const uint8_t *gb = t.g >= 0 ? ix.gbits : nullptr;
+            const int64_t goff = t.g >= 0 ? ix.g_off[t.g] : 0;
+            const int m = pa_min_prefix(min_prefix, t.wlen);
+            const int p = m > K ? K : m;
+            const uint32_t *qbits = cmp_bits ? cmp_bits + bits_off[t.q] : nullptr;
+            const int log = cmp_bits ? bits_log[t.q] : 0;
+            const bool use_bits = qbits != nullptr && p >= LM_PFX_BASES && K >= LM_PFX_BASES;
+            const bool fast_pfx = use_bits && gb != nullptr && p <= 15 && K >= 16;
+            const int blog = lm_pa_bloom_log(log);
+            if (fast_pfx && (int64_t)t.q != lds_q) { // uniform over the workgroup: every wavefront walks the same tasks
+                __syncthreads();                      // nobody reads the previous query's maps any more
+                const uint32_t *gbl = qbits + lm_pa_bloom_word0(log), *g9 = qbits + lm_pa_map9_word0(log);
+                const int nb = 1 << (blog - 5);
+                for (int j = tid; j < nb; j += PA_THREADS) s_bloom[j] = gbl[j];
+                for (int j = tid; j < (1 << (LM_PA_MAP9_LOG - 5)); j += PA_THREADS) s_map9[j] = g9[j];
+                lds_q = (int64_t)t.q;
                 __syncthreads();
-                if (s_on > PA_OCAP / 2) flush(); // uniform: s_on is read after the barrier
             }
-            __syncthreads();
-            if (tid == 0) q_n = 0;
-            __syncthreads();
-        };
-        // PA_UNROLL positions per thread and barrier: their loads are independent and in flight together (this kernel
-        // waits on memory and on the barrier most of the time)
-        for (int tile = 0; tile < npos; tile += 256 * PA_UNROLL) {
+            const uint64_t rec_t = (uint64_t)ti << 32;
             if (fast_pfx) {
-                // prefixes only; the low-complexity filter (which needs the whole k-mer) is applied in drain()
-                uint32_t pf[PA_UNROLL][2];
+                // prefixes only; the low-complexity filter (which needs the whole k-mer) is applied by k_pa_search.
+                // Two strips of 64 positions per pass: their genome loads are independent and in flight together.
+                for (int tile = wave * 128; tile < npos; tile += PA_WAVES * 128) {
+                    const int i0 = tile + lane, i1 = tile + 64 + lane;
+                    uint32_t pf[2][2] = {{0, 0}, {0, 0}};
+                    if (i0 < npos) pa_prefixes(t, gb, goff, i0, K, p, &pf[0][0], &pf[0][1]);
+                    if (i1 < npos) pa_prefixes(t, gb, goff, i1, K, p, &pf[1][0], &pf[1][1]);
 #pragma unroll
-                for (int u = 0; u < PA_UNROLL; u++) {
-                    const int i = tile + u * 256 + tid;
-                    pf[u][0] = pf[u][1] = 0xffffffffu;
-                    if (i < npos) pa_prefixes(t, gb, goff, i, K, p, &pf[u][0], &pf[u][1]);
-                }
-                uint32_t word[PA_UNROLL][2];
+                    for (int u = 0; u < 2; u++) {
+                        const int i = u ? i1 : i0;
 #pragma unroll
-                for (int u = 0; u < PA_UNROLL; u++)
-#pragma unroll
-                    for (int strand = 0; strand < 2; strand++) {
-                        const uint32_t h = pfx_slot(pf[u][strand] >> (2 * (p - LM_PFX_BASES)), c.bits_log);
-                        word[u][strand] = c.bits[h >> 5];
-                    }
-#pragma unroll
-                for (int u = 0; u < PA_UNROLL; u++) {
-                    const int i = tile + u * 256 + tid;
-                    if (i >= npos) continue;
-#pragma unroll
-                    for (int strand = 0; strand < 2; strand++) {
-                        const uint32_t f = pf[u][strand]; // the first p bases
-                        const uint32_t h = pfx_slot(f >> (2 * (p - LM_PFX_BASES)), c.bits_log);
-                        bool cand = ((word[u][strand] >> (h & 31)) & 1u) != 0;
-                        if (!cand && (f & ((1u << (2 * (p - 9))) - 1u)) == 0) { // lm_pa_candidate: the partial-prefix rule
-                            cand = (f & ((1u << (2 * (p - 7))) - 1u)) == 0;
-                            if (!cand) {
-                                const uint32_t h2 = pfx_slot(f >> (2 * (p - LM_PFX_BASES2)), c.bits_log);
-                                cand = ((c.bits[((size_t)1 << (c.bits_log - 5)) + (h2 >> 5)] >> (h2 & 31)) & 1u) != 0;
-                            }
-                        }
-                        if (cand) {
-                            const int slot = atomicAdd(&q_n, 1);
-                            if (slot < PA_QCAP) q_item[slot] = ((uint32_t)i << 1) | (uint32_t)strand;
+                        for (int strand = 0; strand < 2; strand++) {
+                            const bool c = i < npos && lm_pa_candidate2(s_bloom, blog, s_map9, qbits, log, pf[u][strand], p);
+                            push(c, rec_t | ((uint64_t)(uint32_t)i << 1) | (uint64_t)strand);
                         }
                     }
                 }
             } else {
-                for (int u = 0; u < PA_UNROLL; u++) {
-                    const int i = tile + u * 256 + tid;
-                    if (i >= npos) continue;
-                    uint64_t kmer, rc;
-                    pa_kmer(t, w, gb, goff, i, K, &kmer, &rc);
-                    if (kmer == 0 || kmer == c.ccc || kmer == c.ggg || kmer == c.ttt) continue;
+                for (int tile = wave * 64; tile < npos; tile += PA_WAVES * 64) {
+                    const int i = tile + lane;
+                    uint64_t kmer = 0, rc = 0;
+                    if (i < npos) pa_kmer(t, w, gb, goff, i, K, &kmer, &rc);
 #pragma unroll
                     for (int strand = 0; strand < 2; strand++) {
-                        const uint64_t key = strand ? rc : kmer;
-                        bool cand = true;
-                        if (use_bits) {
-                            cand = lm_pa_candidate(c.bits, c.bits_log, key, p, K);
-                        }
-                        if (cand) {
-                            const int slot = atomicAdd(&q_n, 1);
-                            if (slot < PA_QCAP) q_item[slot] = ((uint32_t)i << 1) | (uint32_t)strand;
-                        }
+                        const bool c = i < npos && (!use_bits || lm_pa_candidate(qbits, log, strand ? rc : kmer, p, K));
+                        push(c, rec_t | ((uint64_t)(uint32_t)i << 1) | (uint64_t)strand);
                     }
                 }
             }
-            __syncthreads();
-            if (q_n > PA_QCAP - 512 * PA_UNROLL) drain(); // at most 512*PA_UNROLL new items per pass: the list never overflows
         }
-        drain();
-        flush();
+        __syncthreads(); // the next group may start with another query's maps
     }
+    flush();
+}
+
+#define PAS_STAGE 512 /* anchors a wavefront of k_pa_search stages in LDS between two appends to the global list */
+__global__ __launch_bounds__(256) void k_pa_search(DevIndexView ix, const Task *__restrict__ tasks,
+                                                    const uint8_t *__restrict__ wbuf,
+                                                    const uint64_t *__restrict__ keys_cmp,
+                                                    const uint32_t *__restrict__ vals_cmp,
+                                                    const int64_t *__restrict__ posoff, const int32_t *__restrict__ nvalid,
+                                                    const uint32_t *__restrict__ cmp_tab, int K, int min_prefix,
+                                                    const unsigned long long *__restrict__ cand_count, int64_t cand_cap,
+                                                    const uint64_t *__restrict__ cand,
+                                                    unsigned long long *__restrict__ count, int64_t cap,
+                                                    uint64_t *__restrict__ outA, uint64_t *__restrict__ outB, int qbits,
+                                                    int tbits) {
+    // qbits > 0: compact single-key anchors, task | QBegin:qbits | (32-Len):6 | TBegin:tbits | 2 flags in one u64 (outA is
+    // not written): same order as (task, B) and one keys-only radix sort over the bits in use instead of two pair sorts.
+    // qbits == 0 (batches whose fields need more than 64 bits): (task, B) pairs, the task staged beside B.
+    __shared__ uint64_t s_stage[4][PAS_STAGE];
+    __shared__ uint32_t s_task[4][PAS_STAGE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t *stg = s_stage[wave];
+    uint32_t *stt = s_task[wave];
+    int n_stg = 0; // wave-uniform
+    const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    auto flush = [&]() { // this wavefront's staged anchors -> the global list, one atomic
+        if (n_stg == 0) return;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(count, (unsigned long long)n_stg);
+        base = __shfl(base, 0, 64);
+        for (int j = lane; j < n_stg; j += 64) {
+            const unsigned long long idx = base + (unsigned long long)j;
+            if ((int64_t)idx < cap) {
+                if (qbits == 0) outA[idx] = (uint64_t)stt[j];
+                outB[idx] = stg[j];
+            }
+        }
+        n_stg = 0;
+    };
+    int64_t nc = (int64_t)*cand_count;
+    if (nc > cand_cap) nc = cand_cap; // the host re-runs both kernels with a larger list
+    const int sh_t = 2, sh_l = 2 + tbits, sh_q = 8 + tbits, sh_a = 8 + tbits + qbits;
+    const uint64_t ccc = lm_ns(1, K), ggg = lm_ns(2, K), ttt = lm_kmer_mask(K);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < nc; base += stride) { // whole wavefronts stay together
+        const int64_t ci = base + threadIdx.x;
+        int j = 0, hi = 0, i = 0;
+        bool rcs = false;
+        uint64_t key = 0, right = 0;
+        int64_t ti = 0;
+        uint32_t qb = 0, qe = 0;
+        const uint64_t *keys = nullptr;
+        const uint32_t *vals = nullptr;
+        if (ci < nc) {
+            const uint64_t rec = cand[ci];
+            ti = (int64_t)(rec >> 32);
+            i = (int)((uint32_t)rec >> 1);
+            rcs = (rec & 1ull) != 0;
+            const Task t = tasks[ti];
+            const uint8_t *gb = t.g >= 0 ? ix.gbits : nullptr;
+            const int64_t goff = t.g >= 0 ? ix.g_off[t.g] : 0;
+            uint64_t kmer, rc;
+            pa_kmer(t, wbuf + t.woff, gb, goff, i, K, &kmer, &rc);
+            key = rcs ? rc : kmer;
+            keys = keys_cmp + 2 * posoff[t.q];
+            vals = vals_cmp + 2 * posoff[t.q];
+            qb = (uint32_t)t.qBegin;
+            qe = (uint32_t)t.qEnd;
+            const bool lowc = kmer == 0 || kmer == ccc || kmer == ggg || kmer == ttt; // lib-seq_compare.go:374
+            if (lowc || !lm_tree_search_first_tab(keys, nvalid[t.q], key, pa_min_prefix(min_prefix, t.wlen), K,
+                                                  cmp_tab + (int64_t)t.q * ((1 << LM_TAB_BITS) + 1), LM_TAB_BITS, &j, &hi,
+                                                  &right))
+                j = hi = 0;
+        }
+        // the matches of all lanes, one per lane and round, appended to the wavefront's LDS strip
+        while (true) {
+            bool live = j < hi;
+            uint64_t kj = 0;
+            if (live) {
+                kj = keys[j];
+                live = kj <= right;
+                if (!live) hi = j; // past the keys sharing p bases
+            }
+            if (__ballot(live) == 0) break;
+            bool ok = false;
+            uint64_t B = 0;
+            if (live) {
+                const uint32_t v = vals[j];
+                const uint32_t lp = (uint32_t)lm_lcp(kj, key, K);
+                if (!rcs) {
+                    const uint32_t pp = v >> 1;
+                    if (!((v & 1u) == 1u || pp < qb || pp + lp > qe)) {
+                        ok = true;
+                        B = lm_pack_anchor((int)pp, (int)lp, i, false, false);
+                    }
+                } else {
+                    const uint32_t pp = (v >> 1) + (uint32_t)K - lp;
+                    if (!((v & 1u) == 0u || pp + lp < qb || pp > qe)) {
+                        ok = true;
+                        B = lm_pack_anchor((int)pp, (int)lp, i + K - (int)lp, true, true);
+                    }
+                }
+                j++;
+            }
+            const uint64_t m = __ballot(ok);
+            if (m) {
+                if (ok) {
+                    if (qbits > 0) { // repack the fields of B under the task number
+                        const LmSub u = lm_unpack_anchor(B);
+                        B = ((uint64_t)ti << sh_a) | ((uint64_t)(uint32_t)u.qbegin << sh_q) |
+                            ((uint64_t)(32 - (int)u.len) << sh_l) | ((uint64_t)(uint32_t)u.tbegin << sh_t) |
+                            ((uint64_t)u.qrc << 1) | (uint64_t)u.trc;
+                    }
+                    const int slot = n_stg + __popcll(m & lt_mask);
+                    stg[slot] = B;
+                    stt[slot] = (uint32_t)ti;
+                }
+                n_stg += __popcll(m);
+                if (n_stg > PAS_STAGE - 64) flush(); // LDS accesses of one wavefront complete in program order
+            }
+        }
+    }
+    flush();
 }
 // first anchor of every task in the (task, B)-sorted list
 __global__ void k_pa_task_off_sorted(const uint64_t *__restrict__ sortedA, int shift, int64_t total, int64_t ntasks,
@@ -883,7 +934,7 @@ __global__ __launch_bounds__(64) void k_pa_chain_wave(const uint64_t *__restrict
         LmChain2 *res = out_pool + o;
         for (int i = lane; i < n; i += 64) {
             const uint64_t v = B[o + i];
-            if (qbits > 0) { // compact single-key form (see k_pa_anchors)
+            if (qbits > 0) { // compact single-key form (see k_pa_search)
                 LmSub u;
                 u.qbegin = (int32_t)((v >> (8 + tbits)) & ((1ull << qbits) - 1ull));
                 u.len = (uint8_t)(32 - (int)((v >> (2 + tbits)) & 63));
@@ -2400,14 +2451,30 @@ void launch_build_cmp_bits(hipStream_t st, const uint64_t *keys_cmp, const int64
     int g = nq < 1 ? 1 : (nq > 65536 ? 65536 : nq);
     hipLaunchKernelGGL(k_build_cmp_bits, dim3(g), dim3(256), 0, st, keys_cmp, posoff, nvalid, nq, K, bits_off, bits_log, bits);
 }
-void launch_pa_anchors(hipStream_t st, DevIndexView ix, const Task *tasks, int64_t ntasks, const uint8_t *wbuf,
-                       const uint64_t *keys_cmp, const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid,
-                       const uint32_t *cmp_tab, const uint32_t *cmp_bits, const int64_t *bits_off, const int32_t *bits_log,
-                       int K, int min_prefix, unsigned long long *count, int64_t cap, uint64_t *outA, uint64_t *outB,
-                       int qbits, int tbits) {
-    int g = (int)(ntasks < 1 ? 1 : (ntasks > 1048576 ? 1048576 : ntasks));
-    hipLaunchKernelGGL(k_pa_anchors, dim3(g), dim3(256), 0, st, ix, tasks, ntasks, wbuf, keys_cmp, vals_cmp, posoff, nvalid,
-                       cmp_tab, cmp_bits, bits_off, bits_log, K, min_prefix, count, cap, outA, outB, qbits, tbits);
+void launch_pa_filter(hipStream_t st, DevIndexView ix, const Task *tasks, int64_t ntasks, const uint8_t *wbuf,
+                      const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_bits, const int64_t *bits_off,
+                      const int32_t *bits_log, int K, int min_prefix, unsigned long long *cand_count, int64_t cand_cap,
+                      uint64_t *cand) {
+    const int64_t ngroups = (ntasks + PA_GROUP - 1) / PA_GROUP;
+    int g = (int)(ngroups < 1 ? 1 : (ngroups > 1048576 ? 1048576 : ngroups));
+    static bool lds_set = false;
+    if (!lds_set) {
+        (void)hipFuncSetAttribute((const void *)k_pa_filter, hipFuncAttributeMaxDynamicSharedMemorySize, PA_LDS_BYTES);
+        lds_set = true;
+    }
+    hipLaunchKernelGGL(k_pa_filter, dim3(g), dim3(PA_THREADS), PA_LDS_BYTES, st, ix, tasks, ntasks, wbuf, posoff, nvalid,
+                       cmp_bits, bits_off, bits_log, K, min_prefix, cand_count, cand_cap, cand);
+}
+void launch_pa_search(hipStream_t st, DevIndexView ix, const Task *tasks, const uint8_t *wbuf, const uint64_t *keys_cmp,
+                      const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_tab, int K,
+                      int min_prefix, const unsigned long long *cand_count, int64_t cand_cap, const uint64_t *cand,
+                      unsigned long long *count, int64_t cap, uint64_t *outA, uint64_t *outB, int qbits, int tbits) {
+    // the candidate count is only known on the device: a grid that fills the chip, striding over the list
+    int64_t gs = (cand_cap + 255) / 256;
+    if (gs > 256 * 32) gs = 256 * 32;
+    if (gs < 1) gs = 1;
+    hipLaunchKernelGGL(k_pa_search, dim3((int)gs), dim3(256), 0, st, ix, tasks, wbuf, keys_cmp, vals_cmp, posoff, nvalid, cmp_tab,
+                       K, min_prefix, cand_count, cand_cap, cand, count, cap, outA, outB, qbits, tbits);
 }
 void launch_pa_task_off_sorted(hipStream_t st, const uint64_t *sortedA, int shift, int64_t total, int64_t ntasks,
                                int64_t *pa_off) {

@@ -43,7 +43,6 @@ namespace lm {
 // ---- profiling: HIP events on the library's stream around each named launch ---------------------------------
 // Helpers take the stream and the rocPRIM scratch from here: a host thread may install its own (thread-local) pair to
 // run part of a batch beside the handle's stream; by default it is the handle's.
-static thread_local hipStream_t tls_stream = nullptr;
 static thread_local DBuf<uint8_t> *tls_tmp = nullptr;
 static inline hipStream_t S(lm_index *ix) { return tls_stream ? tls_stream : ix->st; }
 static inline DBuf<uint8_t> &TMP(lm_index *ix) { return tls_tmp ? *tls_tmp : ix->tmp; }
@@ -399,58 +398,30 @@ struct Work {
     DBuf<int32_t> task_wlen;
     DBuf<int64_t> task_woff;
     int64_t ntasks = 0;
-    explicit Work(lm_index *i, lm_qbatch *q) : ix(i), qb(q) {}
+    explicit Work(lm_index *i, lm_qbatch *q) : ix(i), qb(q) {
+        for_each_seeding([](auto &b) { b.phase = true; });
+    }
     // The seeding half's arrays (unsorted k-mer copies, captures, lookups, anchors, chaining scratch) are dead once the
-    // tasks exist; the alignment half needs the room when they are large (long-read batches: tens of GB). Small ones
-    // stay allocated: re-allocating them every batch would cost more than it frees.
+    // tasks exist; the alignment half needs the room when they are large (long-read batches: tens of GB).  They are
+    // "phase" buffers: the large ones live in the handle's scratch arena (lm_internal.h) and go back to it here, so the
+    // alignment half is carved from the same slabs; small ones stay plain grow-only allocations.
+    template <class F> void for_each_seeding(F f) {
+        f(keys_all); f(keys_all2); f(vals_all); f(vals_all2); f(first_mask); f(kmers); f(klo); f(khi); f(lk_counts);
+        f(lk_list); f(lk_list2); f(lk_perm); f(lk_perm2); f(lk_offs); f(lk_starts); f(lk_nscan); f(A0); f(B0); f(A1);
+        f(B1); f(segA); f(seg_len); f(seg_off); f(subs); f(marks); f(visited); f(msi); f(s2i); f(dirs);
+        f(chain_off_pool); f(chain_idx_pool); f(seg_n); f(seg_nch); f(order_scratch); f(seg_score); f(ntask);
+        f(task_off); f(task_wlen); f(task_woff);
+    }
     void release_seeding(int64_t keep_below_bytes) {
         auto drop = [&](auto &b) {
-            if ((int64_t)(b.cap * sizeof(*b.p)) > keep_below_bytes) b.release();
+            if (b.arena || (int64_t)b.bytes() > keep_below_bytes) b.release();
         };
-        // of the two buffers of each sorted array only the one holding the result survives
-        if (k_all == keys_all2.p) drop(keys_all); else drop(keys_all2);
-        if (v_all == vals_all2.p) drop(vals_all); else drop(vals_all2);
+        // of the two buffers of the sorted comparison arrays the one holding the result survives (pseudo-alignment)
         if (k_cmp == keys_cmp2.p) drop(keys_cmp); else drop(keys_cmp2);
         if (v_cmp == vals_cmp2.p) drop(vals_cmp); else drop(vals_cmp2);
-        if (k_all == keys_all2.p) drop(keys_all2); else drop(keys_all);
-        if (v_all == vals_all2.p) drop(vals_all2); else drop(vals_all);
         k_all = nullptr;
         v_all = nullptr;
-        drop(first_mask);
-        drop(kmers);
-        drop(klo);
-        drop(khi);
-        drop(lk_counts);
-        drop(lk_list);
-        drop(lk_list2);
-        drop(lk_perm);
-        drop(lk_perm2);
-        drop(lk_offs);
-        drop(lk_starts);
-        drop(lk_nscan);
-        drop(A0);
-        drop(B0);
-        drop(A1);
-        drop(B1);
-        drop(segA);
-        drop(seg_len);
-        drop(seg_off);
-        drop(subs);
-        drop(marks);
-        drop(visited);
-        drop(msi);
-        drop(s2i);
-        drop(dirs);
-        drop(chain_off_pool);
-        drop(chain_idx_pool);
-        drop(seg_n);
-        drop(seg_nch);
-        drop(order_scratch);
-        drop(seg_score);
-        drop(ntask);
-        drop(task_off);
-        drop(task_wlen);
-        drop(task_woff);
+        for_each_seeding(drop);
     }
     void rebind(lm_qbatch *q) {
         qb = q;
@@ -1133,7 +1104,8 @@ static lm_qbatch *upload_part(lm_index *ix, const lm_query *queries, size_t nq, 
         h2d(ix, qb->d_qoff, qb->h_qoff);
         h2d(ix, qb->d_posoff, qb->h_posoff);
         h2d(ix, qb->d_segoff, segoff);
-        {   // two maps (11-base and 9-base prefixes) of ~16 filter bits per k-mer (both strands) each, 2^13 .. 2^24 bits
+        {   // prefix filters of the pseudo-alignment (lm_pa_bits_words, lm_algos.h): ~16 bits per k-mer (both strands) in
+            // each hashed map, 2^13 .. 2^24 bits, + the Bloom filter and the exact 9-base map k_pa_filter keeps in LDS
             std::vector<int64_t> boff(nq + 1, 0);
             std::vector<int32_t> blog(nq + 1, 13);
             for (size_t i = 0; i < nq; i++) {
@@ -1141,7 +1113,7 @@ static lm_qbatch *upload_part(lm_index *ix, const lm_query *queries, size_t nq, 
                 int lg = 13;
                 while (lg < 24 && ((int64_t)1 << lg) < 16 * nk) lg++;
                 blog[i] = lg;
-                boff[i + 1] = boff[i] + 2 * ((int64_t)1 << (lg - 5));
+                boff[i + 1] = boff[i] + (int64_t)lm_pa_bits_words(lg);
             }
             qb->bits_words = boff[nq];
             h2d(ix, qb->d_bits_off, boff);
@@ -1297,6 +1269,28 @@ struct AlignCtx {
             if (st) (void)hipStreamDestroy(st);
         }
     } wide;
+    AlignCtx() {
+        for_each_phase([](auto &b) { b.phase = true; });
+    }
+    template <class F> void for_each_phase(F f) {
+        f(wlen); f(woff); f(wbuf); f(gwbuf); f(gw_idx); f(gw_dest); f(pa_off); f(A0); f(B0); f(A1); f(B1); f(subs);
+        f(marks); f(msi); f(stack); f(out_n); f(clr_n); f(out); f(out_compact); f(res_off); f(tasks); f(hsp_in);
+        f(hsp_ext); f(ext_cap); f(ext_wcap); f(ext_msi); f(ext_off); f(ext_subs); f(ext_rows); f(ext_rstart);
+        f(wfa_in); f(wfa_out); f(wfa_todo); f(wfa_todo2); f(hdr_pool); f(arena_pool); f(wfa_queue); f(ops_pool);
+        f(wide.in); f(wide.out); f(wide.todo); f(wide.hdr); f(wide.arena); f(wide.ops); f(wide.tmp);
+    }
+    // the alignment half is over: its buffers go back to the handle's scratch arena (the seeding half of the next batch
+    // part is carved from the same slabs; both halves sized to their shares of the scratch budget do not fit side by side)
+    int64_t release_big(int64_t keep_below_bytes) {
+        int64_t freed = 0;
+        for_each_phase([&](auto &b) {
+            if (b.arena || (int64_t)b.bytes() > keep_below_bytes) {
+                freed += (int64_t)b.bytes();
+                b.release();
+            }
+        });
+        return freed;
+    }
 };
 
 } // namespace lm
@@ -1358,27 +1352,34 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
     const int key_bits = abits + qbits + 6 + tbits + 2, sh_a = qbits + 6 + tbits + 2;
     // single pass: anchors appended to (A0, B0) in arbitrary order; the buffer size is a running estimate, the kernel
     // counts past it, so an undersized buffer costs one re-run
-    a.pa_count.ensure(1);
+    a.pa_count.ensure(2);
     if (a.pa_cap < (int64_t)1 << 20) a.pa_cap = std::max<int64_t>((int64_t)1 << 20, W / 8);
     if (const char *e = getenv("LM_DEBUG_PA_CAP")) a.pa_cap = std::max<int64_t>(1, atoll(e)); // test hook: force the re-run
     int64_t TP = 0;
     for (int attempt = 0;; attempt++) {
         if (!compact) a.A0.ensure((size_t)a.pa_cap);
         a.B0.ensure((size_t)a.pa_cap);
-        HIPCHK(hipMemsetAsync(a.pa_count.p, 0, sizeof(unsigned long long), S(ix)));
+        a.B1.ensure((size_t)a.pa_cap); // the sort's second buffer holds the candidate list of k_pa_filter until then
+        HIPCHK(hipMemsetAsync(a.pa_count.p, 0, 2 * sizeof(unsigned long long), S(ix)));
         {
-            Prof p(ix, "k_pa_anchors", W);
-            launch_pa_anchors(S(ix), ix->view, tasks_d, nt, a.wb, a.w->k_cmp, a.w->v_cmp, qb->d_posoff.p,
-                              a.w->nvalid.p, a.w->cmp_tab.p, a.w->cmp_bits.p, qb->d_bits_off.p, qb->d_bits_log.p, ix->host.k, 11, a.pa_count.p, a.pa_cap, a.A0.p, a.B0.p,
-                              compact ? qbits : 0, compact ? tbits : 0);
+            Prof p(ix, "k_pa_filter", W);
+            launch_pa_filter(S(ix), ix->view, tasks_d, nt, a.wb, qb->d_posoff.p, a.w->nvalid.p, a.w->cmp_bits.p,
+                             qb->d_bits_off.p, qb->d_bits_log.p, ix->host.k, 11, a.pa_count.p, a.pa_cap, a.B1.p);
         }
-        unsigned long long hv = 0;
-        HIPCHK(hipMemcpyAsync(&hv, a.pa_count.p, sizeof hv, hipMemcpyDeviceToHost, S(ix)));
+        {
+            Prof p(ix, "k_pa_search");
+            launch_pa_search(S(ix), ix->view, tasks_d, a.wb, a.w->k_cmp, a.w->v_cmp, qb->d_posoff.p, a.w->nvalid.p,
+                             a.w->cmp_tab.p, ix->host.k, 11, a.pa_count.p, a.pa_cap, a.B1.p, a.pa_count.p + 1, a.pa_cap,
+                             a.A0.p, a.B0.p, compact ? qbits : 0, compact ? tbits : 0);
+        }
+        unsigned long long hv[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(hv, a.pa_count.p, sizeof hv, hipMemcpyDeviceToHost, S(ix)));
         sync(ix);
-        TP = (int64_t)hv;
-        if (TP <= a.pa_cap) break;
-        if (attempt > 2) throw HipError("pseudo-alignment anchor buffer keeps overflowing");
-        a.pa_cap = TP + TP / 8;
+        TP = (int64_t)hv[1];
+        const int64_t need = std::max<int64_t>((int64_t)hv[0], TP); // candidates and anchors share the estimate
+        if (need <= a.pa_cap) break;
+        if (attempt > 3) throw HipError("pseudo-alignment anchor buffer keeps overflowing");
+        a.pa_cap = need + need / 8;
     }
     // too many anchors for one chunk (31-bit indices, ~90 B of scratch each within 13 % of the budget - two chunks are in
     // flight): the caller halves the chunk
@@ -1693,6 +1694,7 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
                 HIPCHK(hipSetDevice(ix->device));
                 tls_stream = a.wide.st;
                 tls_tmp = &a.wide.tmp;
+                tls_arena = &ix->arena;
                 wide_run(items, level, a.wide);
             } catch (...) {
                 wide_err = std::current_exception();
@@ -1871,6 +1873,7 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
                 if (!ix->st2) HIPCHK(hipStreamCreate(&ix->st2));
                 tls_stream = ix->st2;
                 tls_tmp = &ix->tmp2;
+                tls_arena = &ix->arena;
             }
             int64_t tpos = r0;
             int slot = 0;
@@ -1970,6 +1973,9 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
         double tc = now_ms();
         int64_t NH = (int64_t)hsps.size();
         st.hsps_aligned += NH;
+        if (getenv("LM_DEBUG"))
+            fprintf(stderr, "[lm] mem: round of %lld HSPs starts with %.2f GB of scratch held (budget %.2f)\n", (long long)NH,
+                    (double)(g_dbuf_bytes.load() - ix->hbm_bytes) / 1e9, (double)ix->scratch_budget / 1e9);
         std::vector<WfaOut> wout;
         std::vector<uint64_t> ops_h;
         std::vector<int64_t> ops_off_h;
@@ -2337,6 +2343,27 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res, const Searc
     double t0 = now_ms(), t1;
     st.query_bases = qb->total_len;
     st.query_kmers = 2 * qb->total_pos;
+    struct TlsScope { // allocations and launches of this thread belong to this handle's arena and stream
+        ScratchArena *pa = tls_arena;
+        hipStream_t ps = tls_stream;
+        explicit TlsScope(lm_index *ix) {
+            tls_arena = &ix->arena;
+            if (!tls_stream) tls_stream = ix->st;
+        }
+        ~TlsScope() {
+            tls_arena = pa;
+            tls_stream = ps;
+        }
+    } tls_scope(ix);
+    if (ix->scratch_budget > 0) { // scratch of the previous part's alignment half (the halves alternate)
+        HIPCHK(hipDeviceSynchronize());
+        int64_t freed = 0;
+        for (auto *c : ix->actx)
+            if (c) freed += c->release_big(ix->scratch_budget / 200);
+        if (freed > 0 && getenv("LM_DEBUG"))
+            fprintf(stderr, "[lm] alignment scratch of the previous part released: %.2f GB (arena: %.2f GB in slabs, %lld slab allocations so far)\n",
+                    (double)freed / 1e9, (double)ix->arena.slab_bytes / 1e9, (long long)ix->arena.slab_allocs);
+    }
     Work &w = get_work(ix, qb);
     double tm1 = now_ms();
     stage_kmers(w);
@@ -2450,10 +2477,20 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res, const Searc
     st.ms_window = t1 - t0;
     t0 = t1;
 
-    if (ix->scratch_budget > 0) w.release_seeding(ix->scratch_budget / 200);
+    if (ix->scratch_budget > 0) {
+        const int64_t before = g_dbuf_bytes.load();
+        HIPCHK(hipDeviceSynchronize());
+        w.release_seeding(ix->scratch_budget / 200);
+        if (getenv("LM_DEBUG"))
+            fprintf(stderr, "[lm] mem: seeding half held %.2f GB of scratch (budget %.2f), %.2f GB kept for the alignment half\n",
+                    (double)(before - ix->hbm_bytes) / 1e9, (double)ix->scratch_budget / 1e9,
+                    (double)(g_dbuf_bytes.load() - ix->hbm_bytes) / 1e9);
+    }
     // ---- alignment half, in chunks of whole (query, genome) segments (align_range). Splitting it over two host
     // threads / streams so that one half's host glue overlaps the other half's kernels was measured at C2 and gave
     // nothing (the halves run in lock-step, and the kernels only slow each other down), so it runs on one stream.
+    if (const char *e = getenv("LM_DEBUG_OOM_ABOVE_QUERIES")) // test hook: the out-of-memory answer of search_parts
+        if ((int64_t)qb->nq > atoll(e)) throw DeviceOOM("test hook: allocation failure between the seeding and alignment halves");
     std::vector<HGenome> genomes; // in (query, genome) order
     {
         TaskSpan th;
@@ -2639,12 +2676,27 @@ extern "C" {
 
 // all parts of the caller's batch, in order; a part whose seed anchors outgrow the device is halved in place (the split
 // stays in the batch handle, so the next search of the same resident batch does not repeat it)
+static void drop_scratch(lm_index *ix, const char *why) {
+    std::lock_guard<std::mutex> lock(ix->mu);
+    (void)hipDeviceSynchronize();
+    delete ix->work;
+    ix->work = nullptr;
+    lm_free_align_ctx(ix);
+    ix->tmp.release();
+    ix->tmp2.release();
+    ix->arena.trim();
+    if (getenv("LM_DEBUG")) fprintf(stderr, "[lm] device scratch dropped after: %s\n", why);
+}
 static void search_parts(lm_index *ix, lm_qbatch *qb, lm_result *res, const SearchCtl *ctl) {
     if (qb->parts.empty()) {
         try {
             search_impl(ix, qb, res, ctl);
             return;
         } catch (const PartTooLarge &) {
+            split_part(ix, qb, 0, true);
+        } catch (const DeviceOOM &e) { // the shares of the scratch budget are estimates: retry on half the queries
+            if (qb->nq < 2) throw;
+            drop_scratch(ix, e.what());
             split_part(ix, qb, 0, true);
         }
     }
@@ -2655,6 +2707,11 @@ static void search_parts(lm_index *ix, lm_qbatch *qb, lm_result *res, const Sear
         try {
             search_impl(ix, part, &pr, ctl);
         } catch (const PartTooLarge &) {
+            split_part(ix, qb, pi, false);
+            continue;
+        } catch (const DeviceOOM &e) {
+            if (part->nq < 2) throw;
+            drop_scratch(ix, e.what());
             split_part(ix, qb, pi, false);
             continue;
         }

@@ -34,14 +34,13 @@ uint64_t ha_pack_seed_val(uint64_t g, uint64_t v64, int pos_bits) { return lm_pa
 uint64_t ha_unpack_seed_val(uint64_t pv, uint64_t bg, int pos_bits, int dir) { return lm_unpack_seed_val(pv, bg, pos_bits, dir); }
 
 // pseudo-alignment prefix filter: bitmap of a sorted key array the way k_build_cmp_bits fills it, and the candidate test
-void ha_pa_filter_build(const uint64_t *keys, int n, int K, int log, uint32_t *bits) {
-    uint32_t *bits2 = bits + ((size_t)1 << (log - 5));
-    for (int i = 0; i < n; i++) {
-        const uint32_t h = lm_pa_filter_slot((uint32_t)(keys[i] >> ((K - LM_PFX_BASES) << 1)), log);
-        bits[h >> 5] |= 1u << (h & 31);
-        const uint32_t h2 = lm_pa_filter_slot((uint32_t)(keys[i] >> ((K - LM_PFX_BASES2) << 1)), log);
-        bits2[h2 >> 5] |= 1u << (h2 & 31);
-    }
+void ha_pa_filter_build(const uint64_t *keys, int n, int K, int log, uint32_t *bits) { // lm_pa_bits_words(log) words
+    for (int i = 0; i < n; i++) lm_pa_filter_set(keys[i], K, log, [&](uint64_t w, uint32_t m) { bits[w] |= m; });
+}
+uint64_t ha_pa_bits_words(int log) { return lm_pa_bits_words(log); }
+int ha_pa_candidate2(const uint32_t *bits, int log, uint64_t key, int p, int K) {
+    return lm_pa_candidate2(bits + lm_pa_bloom_word0(log), lm_pa_bloom_log(log), bits + lm_pa_map9_word0(log), bits, log,
+                            (uint32_t)(key >> ((K - p) << 1)), p);
 }
 int ha_pa_candidate(const uint32_t *bits, int log, uint64_t key, int p, int K) { return lm_pa_candidate(bits, log, key, p, K); }
 
@@ -113,6 +112,25 @@ void ha_extend_flank_both(const uint8_t *s1, int n1, const uint8_t *s2, int n2, 
 
 int ha_tree_search_range(const uint64_t *keys, int n, uint64_t key, int p, int K, int *lo, int *hi) {
     return lm_tree_search_range(keys, n, key, p, K, lo, hi) ? 1 : 0;
+}
+
+// the lower-bound-only form of k_pa_search over a bucket table built the way k_build_cmp_tab builds it; the enumeration
+// "while keys[j] <= right" is done here so that the result compares directly with ha_tree_search_range
+void ha_build_tab(const uint64_t *keys, int n, int K, int tab_bits, uint32_t *tab) { // (1 << tab_bits) + 1 entries
+    for (uint32_t b = 0; b <= (1u << tab_bits); b++)
+        tab[b] = b == (1u << tab_bits) ? (uint32_t)n
+                                        : (uint32_t)lm_lower_bound_u64(keys, 0, n, (uint64_t)b << ((K << 1) - tab_bits));
+}
+int ha_tree_search_first_tab(const uint64_t *keys, int n, uint64_t key, int p, int K, const uint32_t *tab, int tab_bits,
+                             int *lo, int *hi) {
+    uint64_t right = 0;
+    int r = lm_tree_search_first_tab(keys, n, key, p, K, tab, tab_bits, lo, hi, &right);
+    if (r == 1) {
+        int j = *lo;
+        while (j < *hi && keys[j] <= right) j++;
+        *hi = j;
+    }
+    return r != 0 ? 1 : 0;
 }
 
 // returns status; ops copied out

@@ -57,12 +57,18 @@ def lib():
                                 C.POINTER(Chain2)]
         L.ha_extend_match.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int] + [C.c_int] * 8 + [C.POINTER(C.c_int)]
         L.ha_extend_flank_both.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        L.ha_build_tab.argtypes = [C.POINTER(C.c_uint64), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
+        L.ha_tree_search_first_tab.argtypes = [C.POINTER(C.c_uint64), C.c_int, C.c_uint64, C.c_int, C.c_int,
+                                               C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.ha_tree_search_range.argtypes = [C.POINTER(C.c_uint64), C.c_int, C.c_uint64, C.c_int, C.c_int,
                                            C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.ha_wfa.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_uint64),
                              C.c_int, C.POINTER(WfaOut)]
         L.ha_pa_filter_build.argtypes = [C.POINTER(C.c_uint64), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
         L.ha_pa_candidate.argtypes = [C.POINTER(C.c_uint32), C.c_int, C.c_uint64, C.c_int, C.c_int]
+        L.ha_pa_candidate2.argtypes = [C.POINTER(C.c_uint32), C.c_int, C.c_uint64, C.c_int, C.c_int]
+        L.ha_pa_bits_words.argtypes = [C.c_int]
+        L.ha_pa_bits_words.restype = C.c_uint64
         L.ha_bits_get.restype = C.c_uint64
         L.ha_bits_get.argtypes = [C.POINTER(C.c_uint64), C.c_int64, C.c_int]
         L.ha_bits_store_range.argtypes = [C.POINTER(C.c_uint64), C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_uint64)]

@@ -290,9 +290,13 @@ def test_tree_search_quirk_matches_radix_tree():
         cap = C.c_int(0)
         lo, hi = C.c_int(), C.c_int()
         # the pseudo-alignment prefix filter of this key set (k_build_cmp_bits): small map -> hashed, 22 -> exact
-        flog = rng.choice([13, 16, 20])
-        fbits = (C.c_uint32 * (2 << (flog - 5)))()
+        flog = rng.choice([13, 16, 20, 21])  # 20, 21: above the Bloom filter's size, the 11-base bitmap is asked too
+        fbits = (C.c_uint32 * int(Hh.ha_pa_bits_words(flog)))()
         Hh.ha_pa_filter_build(arr, len(keys), K, flog, fbits)
+        tabs = {}
+        for tb in (12, 16):
+            tabs[tb] = (C.c_uint32 * ((1 << tb) + 1))()
+            Hh.ha_build_tab(arr, len(keys), K, tb, tabs[tb])
         for _ in range(400):
             share = rng.randint(1, 12)
             sh = 62 - 2 * share
@@ -306,13 +310,19 @@ def test_tree_search_quirk_matches_radix_tree():
                 exp = [out[i].kmer for i in range(n)]
                 res = keys[lo.value:hi.value] if got else []
                 assert res == exp, (trial, hex(q), p)
+                if p >= 11:  # the form k_pa_search runs: bucket table + lower bound only, matches enumerated
+                    for tb, tab in tabs.items():
+                        got2 = Hh.ha_tree_search_first_tab(arr, len(keys), q, p, K, tab, tb, C.byref(lo), C.byref(hi))
+                        assert (keys[lo.value:hi.value] if got2 else []) == exp, (trial, hex(q), p, tb)
                 if n and out[0].len_prefix < p:
                     hits_quirk += 1
                     if p >= 11:
                         hits_quirk_filter += 1
-                # k_pa_anchors only runs the search on positions the filter lets through: never a false negative
+                # k_pa_search only runs on positions k_pa_filter lets through on positions the filter lets through: never a false negative
                 if n and p >= 11:
                     assert Hh.ha_pa_candidate(fbits, flog, q, p, K), (trial, hex(q), p, flog)
+                    if p <= 15:  # the two-level form with the LDS-resident Bloom filter and exact 9-base map
+                        assert Hh.ha_pa_candidate2(fbits, flog, q, p, K), (trial, hex(q), p, flog)
         L.free(out)
         L.lmo_tree_free(t)
     assert hits_quirk > 0  # the quirk path was really exercised

@@ -332,6 +332,24 @@ def test_chunked_alignment_and_anchor_buffer_rerun_give_the_same_rows(both, quer
     assert st0["rows"] == st1["rows"] and st0["pa_anchors"] == st1["pa_anchors"]
 
 
+def test_out_of_memory_during_a_search_halves_the_batch_and_gives_the_same_rows(both, queries, monkeypatch):
+    """a scratch allocation that fails (forced through the library's test hook, between the seeding and the alignment
+    halves of every part above the given number of queries) makes the search drop its scratch and retry on half the
+    queries; the rows are those of the undisturbed run, in the caller's query order"""
+    _oi, gi = both
+    seqs = [q[1] for q in queries]
+    base, st0 = gi.search(seqs)
+    monkeypatch.setenv("LM_DEBUG_OOM_ABOVE_QUERIES", str(max(1, len(seqs) // 3)))  # the batch ends up in quarters
+    got, st1 = gi.search(seqs)
+    monkeypatch.delenv("LM_DEBUG_OOM_ABOVE_QUERIES")
+    assert len(base) == len(got) and len(base) > 50
+    for b, g in zip(base, got):
+        assert b == g
+    assert st0["rows"] == st1["rows"]
+    again, _ = gi.search(seqs)  # and the handle is as good as new afterwards
+    assert again == base
+
+
 def test_search_options_topn_and_all_columns(small_index, queries):
     """-n/--top-n-genomes, -N/--top-n-chains and -a/--all (CIGAR/qseq/sseq/align strings)"""
     la = _la()
