@@ -1217,6 +1217,63 @@ LM_HDN bool lm_tree_search_miss(const uint64_t *keys, int n, uint64_t key, int p
 }
 
 
+// lm_tree_search_miss with the descent through the levels the bucket table covers read from the table (two loads per level
+// instead of two binary searches over the whole array): tab over the leading tab_bits bits, tab[2^tab_bits] = n.
+LM_HDN bool lm_tree_search_miss_tab(const uint64_t *keys, int n, uint64_t key, int p, int K, int lo, const uint32_t *tab,
+                                    int tab_bits, int *lo_out, int *hi_out) {
+    const int sh = (K - p) << 1;
+    int L = 0;
+    if (lo > 0) L = lm_lcp(key, keys[lo - 1], K);
+    if (lo < n) {
+        int l2 = lm_lcp(key, keys[lo], K);
+        if (l2 > L) L = l2;
+    }
+    if (L < 1) return false;
+    {
+        uint64_t seg = (key >> sh) & ((p - L) >= 32 ? ~0ull : ((1ull << ((p - L) << 1)) - 1));
+        if (seg != 0) return false;
+    }
+    int rlo = 0, rhi = n, d = 0;
+    while (true) {
+        if (d >= K) return false;
+        const int s1 = (K - d - 1) << 1;
+        const uint64_t l1 = (1ull << s1) - 1;
+        int clo, chi;
+        if (2 * (d + 1) <= tab_bits) { // the keys sharing d+1 bases with `key` are a run of whole buckets
+            const int up = tab_bits - 2 * (d + 1);
+            const uint32_t pre = (uint32_t)(key >> ((K << 1) - 2 * (d + 1)));
+            clo = (int)tab[pre << up];
+            chi = (int)tab[(pre + 1u) << up];
+        } else {
+            clo = lm_lower_bound_u64(keys, rlo, rhi, key & ~l1);
+            chi = lm_upper_bound_u64(keys, clo, rhi, key | l1);
+        }
+        if (clo >= chi) return false;
+        int e = keys[clo] == keys[chi - 1] ? K : lm_lcp(keys[clo], keys[chi - 1], K);
+        int l = lm_lcp(key, keys[clo], K);
+        if (l >= e) {
+            if (e >= p) {
+                *lo_out = clo;
+                *hi_out = chi;
+                return true;
+            }
+            d = e;
+            rlo = clo;
+            rhi = chi;
+            continue;
+        }
+        int atleast = p - d, nk = e - d;
+        if (nk >= atleast) return false;
+        uint64_t seg = (key >> sh) & (atleast >= 32 ? ~0ull : ((1ull << (atleast << 1)) - 1));
+        if (seg == 0) {
+            *lo_out = clo;
+            *hi_out = chi;
+            return true;
+        }
+        return false;
+    }
+}
+
 LM_HDN bool lm_tree_search_range(const uint64_t *keys, int n, uint64_t key, int p, int K, int *lo_out, int *hi_out) {
     if (n <= 0) return false;
     if (p < 1) p = 1;
@@ -1252,6 +1309,8 @@ LM_HDN bool lm_tree_search_range(const uint64_t *keys, int n, uint64_t key, int 
 //     (tree.go:496-500) can fire: at a node of depth d <= L-1 with the key's bases [d, p) all A.  With a = the number of
 //     A's that end the key's first p bases, d >= p - a.  d <= 9 forces the bases [9, p) to be A (a >= p - 9); then either
 //     a >= p - 7 (bases [7, p) all A: rare, always a candidate) or d >= 8, so L >= 9 and the 9-base map must hit.
+//     lm_pa_candidate2 is sharper for the commonest case a = p - 9 (base 8 is not A, 3 in 4): then d = 9 and L = 10
+//     exactly, so one of the three 11-base prefixes that differ from the key's in base 10 (an A) must be present.
 #define LM_PFX_BASES 11
 #define LM_PFX_BASES2 9
 #define LM_PA_BLOOM_LOG_MAX 19
@@ -1305,6 +1364,20 @@ LM_HD bool lm_pa_candidate2(const uint32_t *bloom, int blog, const uint32_t *map
     if (hit) return true;
     if (f & ((1u << ((p - 9) << 1)) - 1u)) return false; // bases [9, p) not all A
     if ((f & ((1u << ((p - 7) << 1)) - 1u)) == 0) return true; // bases [7, p) all A
+    if ((f >> ((p - 9) << 1)) & 3u) {
+        // base 8 is not A: a = p - 9, so d = 9 and L = 10 exactly: some k-mer shares the key's 10 bases and differs at
+        // base 10 (an A in the key): one of the three sibling 11-base prefixes is in the set
+        for (uint32_t sib = 1; sib < 4; sib++) {
+            const uint32_t x = p11 | sib, sa = lm_pa_bloom_slot(x, 0, blog), sb = lm_pa_bloom_slot(x, 1, blog);
+            bool h = (((bloom[sa >> 5] >> (sa & 31)) & (bloom[sb >> 5] >> (sb & 31))) & 1u) != 0;
+            if (h && log > blog) {
+                const uint32_t hh = lm_pa_filter_slot(x, log);
+                h = ((bits11[hh >> 5] >> (hh & 31)) & 1u) != 0;
+            }
+            if (h) return true;
+        }
+        return false;
+    }
     const uint32_t p9 = f >> ((p - LM_PFX_BASES2) << 1);
     return ((map9[p9 >> 5] >> (p9 & 31)) & 1u) != 0;
 }
@@ -1353,7 +1426,7 @@ LM_HD int lm_tree_search_first_tab(const uint64_t *keys, int n, uint64_t key, in
     }
     if ((key >> sh) & 3ull) return 0; // the quirk needs base p-1 of the key to be A
     *right_out = ~0ull;
-    return lm_tree_search_miss(keys, n, key, p, K, lo, lo_out, hi_out) ? 2 : 0;
+    return lm_tree_search_miss_tab(keys, n, key, p, K, lo, tab, tab_bits, lo_out, hi_out) ? 2 : 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

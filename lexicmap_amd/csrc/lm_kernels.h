@@ -100,9 +100,10 @@ void launch_extract_windows(hipStream_t st, DevIndexView ix, const Task *tasks, 
                             uint8_t *wbuf);
 void launch_extract_windows_at(hipStream_t st, DevIndexView ix, const Task *tasks, const int32_t *idx, const int64_t *dest,
                                int64_t n, uint8_t *wbuf);
-#define LM_TAB_BITS 12 /* bucket table over the first 6 bases of the query's sorted k-mers */
+#define LM_TAB_BITS_MIN 12 /* bucket table over the leading bits of a query's sorted k-mers: 2^12 .. 2^20 buckets */
+#define LM_TAB_BITS_MAX 20
 void launch_build_cmp_tab(hipStream_t st, const uint64_t *keys_cmp, const int64_t *posoff, const int32_t *nvalid, int nq,
-                          int K, uint32_t *tab);
+                          int K, const int64_t *tab_off, const int32_t *tab_bits, int64_t tab_words, uint32_t *tab);
 void launch_sum_i32(hipStream_t st, const int32_t *v, int64_t n, unsigned long long *out);
 // hashed 11-base prefix bitmap per query: 2^bits_log[q] bits at word bits_off[q] (sized by the host, ~16 bits per k-mer)
 void launch_build_cmp_bits(hipStream_t st, const uint64_t *keys_cmp, const int64_t *posoff, const int32_t *nvalid, int nq,
@@ -112,8 +113,9 @@ void launch_pa_filter(hipStream_t st, DevIndexView ix, const Task *tasks, int64_
                       const int32_t *bits_log, int K, int min_prefix, unsigned long long *cand_count, int64_t cand_cap,
                       uint64_t *cand);
 void launch_pa_search(hipStream_t st, DevIndexView ix, const Task *tasks, const uint8_t *wbuf, const uint64_t *keys_cmp,
-                      const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_tab, int K,
-                      int min_prefix, const unsigned long long *cand_count, int64_t cand_cap, const uint64_t *cand,
+                      const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_tab,
+                      const int64_t *tab_off, const int32_t *tab_bits, int K, int min_prefix,
+                      const unsigned long long *cand_count, int64_t cand_cap, const uint64_t *cand,
                       unsigned long long *count, int64_t cap, uint64_t *outA, uint64_t *outB, int qbits, int tbits);
 void launch_pa_task_off_sorted(hipStream_t st, const uint64_t *sortedA, int shift, int64_t total, int64_t ntasks,
                                int64_t *pa_off);

@@ -71,14 +71,17 @@ __global__ void k_extract_kmers(const uint8_t *__restrict__ qseq, const int64_t 
     }
 }
 
-// bucket table over the leading LM_TAB_BITS bits of each query's sorted (filtered) k-mer array:
-// tab[q][b] = first index (relative to the query's segment) whose key >> (2K-bits) >= b; tab[q][nb] = nvalid[q]
+// bucket table over the leading tab_bits[q] bits of each query's sorted (filtered) k-mer array (sized per query so that a
+// bucket holds about half a k-mer: 2^13 buckets for a gene, 2^17 for a 27-kb read), at tab + tab_off[q]:
+// tab[b] = first index (relative to the query's segment) whose key >> (2K-bits) >= b; tab[2^bits] = nvalid[q]
 __global__ void k_build_cmp_tab(const uint64_t *__restrict__ keys_cmp, const int64_t *__restrict__ posoff,
-                                const int32_t *__restrict__ nvalid, int nq, int K, int bits, uint32_t *__restrict__ tab) {
-    const int nb = 1 << bits;
-    int64_t total = (int64_t)nq * (nb + 1);
+                                const int32_t *__restrict__ nvalid, int nq, int K, const int64_t *__restrict__ tab_off,
+                                const int32_t *__restrict__ tab_bits, uint32_t *__restrict__ tab) {
+    const int64_t total = tab_off[nq];
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        int q = (int)(t / (nb + 1)), b = (int)(t % (nb + 1));
+        const int q = find_segment(tab_off, nq, t);
+        const int bits = tab_bits[q], nb = 1 << bits;
+        const int b = (int)(t - tab_off[q]);
         const uint64_t *keys = keys_cmp + 2 * posoff[q];
         int n = nvalid[q];
         int lo = n;
@@ -562,17 +565,6 @@ __device__ __forceinline__ uint64_t kmer_from_bits(const uint8_t *__restrict__ g
     return v >> (64 - 2 * K);
 }
 
-struct PaCtx {
-    const uint64_t *keys;
-    const uint32_t *vals;
-    const uint32_t *tab;
-    const uint32_t *bits; // hashed 11-base prefix bitmap of the query (k_build_cmp_bits), may be null
-    int bits_log;
-    int n, K, m;
-    uint32_t begin, end;
-    uint64_t ccc, ggg, ttt;
-};
-
 // window k-mer at position i (and its reverse complement), from the packed genome when the task has one
 __device__ __forceinline__ void pa_kmer(const Task &t, const uint8_t *__restrict__ w, const uint8_t *__restrict__ gbits,
                                         int64_t goff, int i, int K, uint64_t *kmer, uint64_t *rc) {
@@ -615,27 +607,6 @@ __device__ __forceinline__ void pa_prefixes(const Task &t, const uint8_t *__rest
     *rc = t.rc ? first : rl;
 }
 
-__device__ __forceinline__ PaCtx pa_ctx(const Task &t, const uint64_t *keys_cmp, const uint32_t *vals_cmp,
-                                        const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_tab,
-                                        const uint32_t *cmp_bits, const int64_t *bits_off, const int32_t *bits_log, int K,
-                                        int min_prefix) {
-    PaCtx c;
-    c.bits = cmp_bits ? cmp_bits + bits_off[t.q] : nullptr;
-    c.bits_log = cmp_bits ? bits_log[t.q] : 0;
-    c.keys = keys_cmp + 2 * posoff[t.q];
-    c.vals = vals_cmp + 2 * posoff[t.q];
-    c.tab = cmp_tab + (int64_t)t.q * ((1 << LM_TAB_BITS) + 1);
-    c.n = nvalid[t.q];
-    c.K = K;
-    c.m = pa_min_prefix(min_prefix, t.wlen);
-    c.begin = (uint32_t)t.qBegin;
-    c.end = (uint32_t)t.qEnd;
-    c.ccc = lm_ns(1, K);
-    c.ggg = lm_ns(2, K);
-    c.ttt = lm_kmer_mask(K);
-    return c;
-}
-
 // ---- pseudo-alignment anchors: filter + search ---------------------------------------------------------------------------
 // Two kernels replace a count / scan / emit triple over the window positions.
 //
@@ -658,6 +629,7 @@ __device__ __forceinline__ PaCtx pa_ctx(const Task &t, const uint64_t *keys_cmp,
 #define PA_WAVES (PA_THREADS / 64)
 #define PA_GROUP 64  /* chain windows per workgroup pass */
 #define PA_STAGE 256 /* candidates a wavefront stages in LDS */
+#define PA_SLICE 2048 /* window positions a wavefront takes at a time */
 #define PA_LDS_BYTES ((1 << (LM_PA_BLOOM_LOG_MAX - 3)) + (1 << (LM_PA_MAP9_LOG - 3)) + PA_WAVES * PA_STAGE * 8)
 __global__ __launch_bounds__(PA_THREADS) void k_pa_filter(DevIndexView ix, const Task *__restrict__ tasks, int64_t ntasks,
                                                            const uint8_t *__restrict__ wbuf,
@@ -692,67 +664,115 @@ __global__ __launch_bounds__(PA_THREADS) void k_pa_filter(DevIndexView ix, const
         n_stg += __popcll(m);
         if (n_stg > PA_STAGE - 64) flush(); // LDS accesses of one wavefront complete in program order
     };
+    // per group: the tasks' fields every wavefront needs (one round of dependent global loads for the whole group instead
+    // of one per task and wavefront), then slices of PA_SLICE window positions handed out through an LDS counter, so the 16
+    // wavefronts are in different windows at different stages and hide each other's genome-load latency
+    __shared__ int32_t s_q[PA_GROUP], s_rc[PA_GROUP], s_tb[PA_GROUP], s_wlen[PA_GROUP], s_npos[PA_GROUP], s_log[PA_GROUP];
+    __shared__ int32_t s_first[PA_GROUP + 1]; // first slice of every task of the current run of one query
+    __shared__ int64_t s_goff[PA_GROUP], s_bits[PA_GROUP], s_woff[PA_GROUP];
+    __shared__ int s_next;
     const int64_t ngroups = (ntasks + PA_GROUP - 1) / PA_GROUP;
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-        int64_t lds_q = -1; // the query whose maps are in LDS
-        const int64_t tend = ntasks < (grp + 1) * PA_GROUP ? ntasks : (grp + 1) * PA_GROUP;
-        for (int64_t ti = grp * PA_GROUP; ti < tend; ti++) {
-            const Task t = tasks[ti];
+        const int64_t t0g = grp * PA_GROUP;
+        const int ng = (int)((ntasks < t0g + PA_GROUP ? ntasks : t0g + PA_GROUP) - t0g);
+        __syncthreads(); // the previous group is finished with the tables
+        if (tid < ng) {
+            const Task t = tasks[t0g + tid];
             const int n = nvalid[t.q];
-            const int npos = n > 0 ? t.wlen - K + 1 : 0;
-            if (npos <= 0) continue;
-            const uint8_t *w = wbuf + t.woff;
-            const uint8_t *gb = t.g >= 0 ? ix.gbits : nullptr;
-            const int64_t goff = t.g >= 0 ? ix.g_off[t.g] : 0;
-            const int m = pa_min_prefix(min_prefix, t.wlen);
-            const int p = m > K ? K : m;
-            const uint32_t *qbits = cmp_bits ? cmp_bits + bits_off[t.q] : nullptr;
-            const int log = cmp_bits ? bits_log[t.q] : 0;
-            const bool use_bits = qbits != nullptr && p >= LM_PFX_BASES && K >= LM_PFX_BASES;
-            const bool fast_pfx = use_bits && gb != nullptr && p <= 15 && K >= 16;
-            const int blog = lm_pa_bloom_log(log);
-            if (fast_pfx && (int64_t)t.q != lds_q) { // uniform over the workgroup: every wavefront walks the same tasks
-                __syncthreads();                      // nobody reads the previous query's maps any more
+            s_q[tid] = (int32_t)t.q;
+            s_rc[tid] = t.rc;
+            s_tb[tid] = t.tBegin;
+            s_wlen[tid] = t.wlen;
+            s_npos[tid] = n > 0 && t.wlen - K + 1 > 0 ? t.wlen - K + 1 : 0;
+            s_goff[tid] = t.g >= 0 ? ix.g_off[t.g] : -1;
+            s_woff[tid] = t.woff;
+            s_bits[tid] = cmp_bits ? bits_off[t.q] : -1;
+            s_log[tid] = cmp_bits ? bits_log[t.q] : 0;
+        }
+        __syncthreads();
+        int r0 = 0;
+        while (r0 < ng) { // runs of tasks of one query (nearly always the whole group)
+            int r1 = r0 + 1;
+            while (r1 < ng && s_q[r1] == s_q[r0]) r1++;
+            const int log = s_log[r0], blog = lm_pa_bloom_log(log);
+            const uint32_t *qbits = s_bits[r0] >= 0 ? cmp_bits + s_bits[r0] : nullptr;
+            // this query's LDS maps (K >= 16 and a query with maps: the fast path exists for some window of it)
+            if (qbits != nullptr && K >= 16) {
                 const uint32_t *gbl = qbits + lm_pa_bloom_word0(log), *g9 = qbits + lm_pa_map9_word0(log);
                 const int nb = 1 << (blog - 5);
                 for (int j = tid; j < nb; j += PA_THREADS) s_bloom[j] = gbl[j];
                 for (int j = tid; j < (1 << (LM_PA_MAP9_LOG - 5)); j += PA_THREADS) s_map9[j] = g9[j];
-                lds_q = (int64_t)t.q;
-                __syncthreads();
             }
-            const uint64_t rec_t = (uint64_t)ti << 32;
-            if (fast_pfx) {
-                // prefixes only; the low-complexity filter (which needs the whole k-mer) is applied by k_pa_search.
-                // Two strips of 64 positions per pass: their genome loads are independent and in flight together.
-                for (int tile = wave * 128; tile < npos; tile += PA_WAVES * 128) {
-                    const int i0 = tile + lane, i1 = tile + 64 + lane;
-                    uint32_t pf[2][2] = {{0, 0}, {0, 0}};
-                    if (i0 < npos) pa_prefixes(t, gb, goff, i0, K, p, &pf[0][0], &pf[0][1]);
-                    if (i1 < npos) pa_prefixes(t, gb, goff, i1, K, p, &pf[1][0], &pf[1][1]);
+            if (tid == 0) {
+                int acc = 0;
+                for (int j = r0; j < r1; j++) {
+                    s_first[j] = acc;
+                    acc += (s_npos[j] + PA_SLICE - 1) / PA_SLICE;
+                }
+                s_first[r1] = acc;
+                s_next = 0;
+            }
+            __syncthreads();
+            const int nslices = s_first[r1];
+            while (true) {
+                int sl = 0;
+                if (lane == 0) sl = atomicAdd(&s_next, 1);
+                sl = __builtin_amdgcn_readfirstlane(sl);
+                if (sl >= nslices) break;
+                int lo = r0, hi = r1; // the task of slice sl: last j with s_first[j] <= sl
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_first[mid] <= sl) lo = mid; else hi = mid;
+                }
+                const int j = lo;
+                Task t; // the fields pa_prefixes / pa_kmer read
+                t.rc = s_rc[j];
+                t.tBegin = s_tb[j];
+                t.wlen = s_wlen[j];
+                const int npos = s_npos[j];
+                const int p0 = (sl - s_first[j]) * PA_SLICE, p1 = p0 + PA_SLICE < npos ? p0 + PA_SLICE : npos;
+                const int64_t goff = s_goff[j];
+                const uint8_t *gb = goff >= 0 ? ix.gbits : nullptr;
+                const uint8_t *w = wbuf + s_woff[j];
+                const int m = pa_min_prefix(min_prefix, t.wlen);
+                const int p = m > K ? K : m;
+                const bool use_bits = qbits != nullptr && p >= LM_PFX_BASES && K >= LM_PFX_BASES;
+                const bool fast_pfx = use_bits && gb != nullptr && p <= 15 && K >= 16;
+                const uint64_t rec_t = (uint64_t)(t0g + j) << 32;
+                if (fast_pfx) {
+                    // prefixes only; the low-complexity filter (which needs the whole k-mer) is applied by k_pa_search.
+                    // Two strips of 64 positions per pass: their genome loads are independent and in flight together.
+                    for (int tile = p0; tile < p1; tile += 128) {
+                        const int i0 = tile + lane, i1 = tile + 64 + lane;
+                        uint32_t pf[2][2] = {{0, 0}, {0, 0}};
+                        if (i0 < p1) pa_prefixes(t, gb, goff, i0, K, p, &pf[0][0], &pf[0][1]);
+                        if (i1 < p1) pa_prefixes(t, gb, goff, i1, K, p, &pf[1][0], &pf[1][1]);
 #pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        const int i = u ? i1 : i0;
+                        for (int u = 0; u < 2; u++) {
+                            const int i = u ? i1 : i0;
+#pragma unroll
+                            for (int strand = 0; strand < 2; strand++) {
+                                const bool c = i < p1 && lm_pa_candidate2(s_bloom, blog, s_map9, qbits, log, pf[u][strand], p);
+                                push(c, rec_t | ((uint64_t)(uint32_t)i << 1) | (uint64_t)strand);
+                            }
+                        }
+                    }
+                } else {
+                    for (int tile = p0; tile < p1; tile += 64) {
+                        const int i = tile + lane;
+                        uint64_t kmer = 0, rc = 0;
+                        if (i < p1) pa_kmer(t, w, gb, goff, i, K, &kmer, &rc);
 #pragma unroll
                         for (int strand = 0; strand < 2; strand++) {
-                            const bool c = i < npos && lm_pa_candidate2(s_bloom, blog, s_map9, qbits, log, pf[u][strand], p);
+                            const bool c = i < p1 && (!use_bits || lm_pa_candidate(qbits, log, strand ? rc : kmer, p, K));
                             push(c, rec_t | ((uint64_t)(uint32_t)i << 1) | (uint64_t)strand);
                         }
                     }
                 }
-            } else {
-                for (int tile = wave * 64; tile < npos; tile += PA_WAVES * 64) {
-                    const int i = tile + lane;
-                    uint64_t kmer = 0, rc = 0;
-                    if (i < npos) pa_kmer(t, w, gb, goff, i, K, &kmer, &rc);
-#pragma unroll
-                    for (int strand = 0; strand < 2; strand++) {
-                        const bool c = i < npos && (!use_bits || lm_pa_candidate(qbits, log, strand ? rc : kmer, p, K));
-                        push(c, rec_t | ((uint64_t)(uint32_t)i << 1) | (uint64_t)strand);
-                    }
-                }
             }
+            __syncthreads(); // everybody is done with this query's maps and the slice table
+            r0 = r1;
         }
-        __syncthreads(); // the next group may start with another query's maps
     }
     flush();
 }
@@ -763,7 +783,9 @@ __global__ __launch_bounds__(256) void k_pa_search(DevIndexView ix, const Task *
                                                     const uint64_t *__restrict__ keys_cmp,
                                                     const uint32_t *__restrict__ vals_cmp,
                                                     const int64_t *__restrict__ posoff, const int32_t *__restrict__ nvalid,
-                                                    const uint32_t *__restrict__ cmp_tab, int K, int min_prefix,
+                                                    const uint32_t *__restrict__ cmp_tab,
+                                                    const int64_t *__restrict__ tab_off,
+                                                    const int32_t *__restrict__ tab_bits, int K, int min_prefix,
                                                     const unsigned long long *__restrict__ cand_count, int64_t cand_cap,
                                                     const uint64_t *__restrict__ cand,
                                                     unsigned long long *__restrict__ count, int64_t cap,
@@ -824,7 +846,7 @@ __global__ __launch_bounds__(256) void k_pa_search(DevIndexView ix, const Task *
             qe = (uint32_t)t.qEnd;
             const bool lowc = kmer == 0 || kmer == ccc || kmer == ggg || kmer == ttt; // lib-seq_compare.go:374
             if (lowc || !lm_tree_search_first_tab(keys, nvalid[t.q], key, pa_min_prefix(min_prefix, t.wlen), K,
-                                                  cmp_tab + (int64_t)t.q * ((1 << LM_TAB_BITS) + 1), LM_TAB_BITS, &j, &hi,
+                                                  cmp_tab + tab_off[t.q], tab_bits[t.q], &j, &hi,
                                                   &right))
                 j = hi = 0;
         }
@@ -1997,6 +2019,14 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
     // Work queue: lane 0 pops the next problem at the END of the loop body (inside the block that writes the result)
     // and the index travels through LDS. Keeping lane-conditional code away from the loop header matters: with the pop
     // at the top the compiler peels lane 0 into an outer loop and lets the other 63 lanes iterate without it.
+    // The passes of the length classes run side by side (run_wfa): the wide rings belong to the few long alignments every
+    // round waits for, so their wavefronts are issued ahead of the many short ones sharing the SIMDs
+    if (NC >= 16)
+        __builtin_amdgcn_s_setprio(3);
+    else if (NC >= 8)
+        __builtin_amdgcn_s_setprio(2);
+    else if (NC >= 4)
+        __builtin_amdgcn_s_setprio(1);
     if (lane == 0) sh_x = atomicAdd(queue, 1u);
     while (true) {
         LDS_WAVE_SYNC();
@@ -2438,8 +2468,8 @@ void launch_extract_windows_at(hipStream_t st, DevIndexView ix, const Task *task
                        wbuf);
 }
 void launch_build_cmp_tab(hipStream_t st, const uint64_t *keys_cmp, const int64_t *posoff, const int32_t *nvalid, int nq,
-                          int K, uint32_t *tab) {
-    LM_LAUNCH_1D(k_build_cmp_tab, (int64_t)nq * ((1 << LM_TAB_BITS) + 1), st, keys_cmp, posoff, nvalid, nq, K, LM_TAB_BITS, tab);
+                          int K, const int64_t *tab_off, const int32_t *tab_bits, int64_t tab_words, uint32_t *tab) {
+    LM_LAUNCH_1D(k_build_cmp_tab, tab_words, st, keys_cmp, posoff, nvalid, nq, K, tab_off, tab_bits, tab);
 }
 void launch_sum_i32(hipStream_t st, const int32_t *v, int64_t n, unsigned long long *out) {
     int g = (int)((n + 255) / 256);
@@ -2466,15 +2496,16 @@ void launch_pa_filter(hipStream_t st, DevIndexView ix, const Task *tasks, int64_
                        cmp_bits, bits_off, bits_log, K, min_prefix, cand_count, cand_cap, cand);
 }
 void launch_pa_search(hipStream_t st, DevIndexView ix, const Task *tasks, const uint8_t *wbuf, const uint64_t *keys_cmp,
-                      const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_tab, int K,
-                      int min_prefix, const unsigned long long *cand_count, int64_t cand_cap, const uint64_t *cand,
+                      const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_tab,
+                      const int64_t *tab_off, const int32_t *tab_bits, int K, int min_prefix,
+                      const unsigned long long *cand_count, int64_t cand_cap, const uint64_t *cand,
                       unsigned long long *count, int64_t cap, uint64_t *outA, uint64_t *outB, int qbits, int tbits) {
     // the candidate count is only known on the device: a grid that fills the chip, striding over the list
     int64_t gs = (cand_cap + 255) / 256;
     if (gs > 256 * 32) gs = 256 * 32;
     if (gs < 1) gs = 1;
     hipLaunchKernelGGL(k_pa_search, dim3((int)gs), dim3(256), 0, st, ix, tasks, wbuf, keys_cmp, vals_cmp, posoff, nvalid, cmp_tab,
-                       K, min_prefix, cand_count, cand_cap, cand, count, cap, outA, outB, qbits, tbits);
+                       tab_off, tab_bits, K, min_prefix, cand_count, cand_cap, cand, count, cap, outA, outB, qbits, tbits);
 }
 void launch_pa_task_off_sorted(hipStream_t st, const uint64_t *sortedA, int shift, int64_t total, int64_t ntasks,
                                int64_t *pa_off) {

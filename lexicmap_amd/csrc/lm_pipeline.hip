@@ -44,6 +44,10 @@ namespace lm {
 // Helpers take the stream and the rocPRIM scratch from here: a host thread may install its own (thread-local) pair to
 // run part of a batch beside the handle's stream; by default it is the handle's.
 static thread_local DBuf<uint8_t> *tls_tmp = nullptr;
+static double g_dbg_t0 = 0; // LM_DEBUG: start of the running search (time stamps of the debug lines)
+static inline void dbg_stamp(const char *what) {
+    if (getenv("LM_DEBUG")) fprintf(stderr, "[lm +%.1f ms] %s\n", now_ms() - g_dbg_t0, what);
+}
 static inline hipStream_t S(lm_index *ix) { return tls_stream ? tls_stream : ix->st; }
 static inline DBuf<uint8_t> &TMP(lm_index *ix) { return tls_tmp ? *tls_tmp : ix->tmp; }
 
@@ -332,6 +336,10 @@ struct lm_qbatch {
     DBuf<int64_t> d_bits_off;
     DBuf<int32_t> d_bits_log;
     int64_t bits_words = 0;
+    // per-query bucket table over its sorted comparison k-mers (k_build_cmp_tab): 2^tab_bits[q] + 1 entries at tab_off[q]
+    DBuf<int64_t> d_tab_off;
+    DBuf<int32_t> d_tab_bits;
+    int64_t tab_words = 0;
 };
 
 struct lm_result {
@@ -468,8 +476,9 @@ static void stage_kmers(Work &w) {
     w.v_all = w.vals_all2.p;
     w.k_cmp = w.keys_cmp2.p;
     w.v_cmp = w.vals_cmp2.p;
-    w.cmp_tab.ensure((size_t)qb->nq * ((1 << LM_TAB_BITS) + 1));
-    launch_build_cmp_tab(S(ix), w.k_cmp, qb->d_posoff.p, w.nvalid.p, qb->nq, ix->host.k, w.cmp_tab.p);
+    w.cmp_tab.ensure((size_t)qb->tab_words + 1);
+    launch_build_cmp_tab(S(ix), w.k_cmp, qb->d_posoff.p, w.nvalid.p, qb->nq, ix->host.k, qb->d_tab_off.p, qb->d_tab_bits.p,
+                         qb->tab_words, w.cmp_tab.p);
     w.cmp_bits.ensure((size_t)qb->bits_words + 1);
     HIPCHK(hipMemsetAsync(w.cmp_bits.p, 0, (size_t)qb->bits_words * sizeof(uint32_t), S(ix)));
     launch_build_cmp_bits(S(ix), w.k_cmp, qb->d_posoff.p, w.nvalid.p, qb->nq, ix->host.k, qb->d_bits_off.p, qb->d_bits_log.p,
@@ -1116,6 +1125,18 @@ static lm_qbatch *upload_part(lm_index *ix, const lm_query *queries, size_t nq, 
                 boff[i + 1] = boff[i] + (int64_t)lm_pa_bits_words(lg);
             }
             qb->bits_words = boff[nq];
+            std::vector<int64_t> toff(nq + 1, 0);
+            std::vector<int32_t> tbits(nq + 1, LM_TAB_BITS_MIN);
+            for (size_t i = 0; i < nq; i++) { // about two buckets per k-mer
+                const int64_t nk = 2 * (qb->h_posoff[i + 1] - qb->h_posoff[i]);
+                int tb = LM_TAB_BITS_MIN;
+                while (tb < LM_TAB_BITS_MAX && ((int64_t)1 << tb) < 2 * nk) tb++;
+                tbits[i] = tb;
+                toff[i + 1] = toff[i] + ((int64_t)1 << tb) + 1;
+            }
+            qb->tab_words = toff[nq];
+            h2d(ix, qb->d_tab_off, toff);
+            h2d(ix, qb->d_tab_bits, tbits);
             h2d(ix, qb->d_bits_off, boff);
             h2d(ix, qb->d_bits_log, blog);
         }
@@ -1254,9 +1275,18 @@ struct AlignCtx {
     DBuf<uint32_t> ext_rstart; // first anchor index of each row
     DBuf<WfaIn> wfa_in;
     DBuf<WfaOut> wfa_out;
-    DBuf<int32_t> wfa_todo, wfa_todo2, hdr_pool, arena_pool;
-    DBuf<unsigned int> wfa_queue;
     DBuf<uint64_t> ops_pool;
+    // the LDS WFA passes of the four length classes run side by side (a pass ends in a tail of a few long alignments that
+    // leaves most CUs idle): each class has its own stream, queue and scratch
+    struct LeanCtx {
+        hipStream_t st = nullptr;
+        DBuf<int32_t> todo, hdr_pool, arena_pool;
+        DBuf<unsigned int> queue;
+        DBuf<uint8_t> tmp;
+        ~LeanCtx() {
+            if (st) (void)hipStreamDestroy(st);
+        }
+    } lean[4];
     // the global-memory WFA fallback runs beside the LDS passes of the shorter length classes: own stream and buffers
     struct WideCtx {
         hipStream_t st = nullptr;
@@ -1276,8 +1306,9 @@ struct AlignCtx {
         f(wlen); f(woff); f(wbuf); f(gwbuf); f(gw_idx); f(gw_dest); f(pa_off); f(A0); f(B0); f(A1); f(B1); f(subs);
         f(marks); f(msi); f(stack); f(out_n); f(clr_n); f(out); f(out_compact); f(res_off); f(tasks); f(hsp_in);
         f(hsp_ext); f(ext_cap); f(ext_wcap); f(ext_msi); f(ext_off); f(ext_subs); f(ext_rows); f(ext_rstart);
-        f(wfa_in); f(wfa_out); f(wfa_todo); f(wfa_todo2); f(hdr_pool); f(arena_pool); f(wfa_queue); f(ops_pool);
+        f(wfa_in); f(wfa_out);  f(ops_pool);
         f(wide.in); f(wide.out); f(wide.todo); f(wide.hdr); f(wide.arena); f(wide.ops); f(wide.tmp);
+        for (auto &l : lean) { f(l.todo); f(l.hdr_pool); f(l.arena_pool); f(l.tmp); }
     }
     // the alignment half is over: its buffers go back to the handle's scratch arena (the seeding half of the next batch
     // part is carved from the same slabs; both halves sized to their shares of the scratch budget do not fit side by side)
@@ -1369,13 +1400,18 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
         {
             Prof p(ix, "k_pa_search");
             launch_pa_search(S(ix), ix->view, tasks_d, a.wb, a.w->k_cmp, a.w->v_cmp, qb->d_posoff.p, a.w->nvalid.p,
-                             a.w->cmp_tab.p, ix->host.k, 11, a.pa_count.p, a.pa_cap, a.B1.p, a.pa_count.p + 1, a.pa_cap,
+                             a.w->cmp_tab.p, qb->d_tab_off.p, qb->d_tab_bits.p, ix->host.k, 11, a.pa_count.p, a.pa_cap, a.B1.p,
+                             a.pa_count.p + 1, a.pa_cap,
                              a.A0.p, a.B0.p, compact ? qbits : 0, compact ? tbits : 0);
         }
         unsigned long long hv[2] = {0, 0};
         HIPCHK(hipMemcpyAsync(hv, a.pa_count.p, sizeof hv, hipMemcpyDeviceToHost, S(ix)));
         sync(ix);
         TP = (int64_t)hv[1];
+        dbg_stamp("pseudo-alignment anchors of a chunk done");
+        if (getenv("LM_DEBUG"))
+            fprintf(stderr, "[lm] pseudo-alignment: %lld window bases, %lld candidates, %lld anchors\n", (long long)W,
+                    (long long)hv[0], (long long)TP);
         const int64_t need = std::max<int64_t>((int64_t)hv[0], TP); // candidates and anchors share the estimate
         if (need <= a.pa_cap) break;
         if (attempt > 3) throw HipError("pseudo-alignment anchor buffer keeps overflowing");
@@ -1383,14 +1419,16 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
     }
     // too many anchors for one chunk (31-bit indices, ~90 B of scratch each within 13 % of the budget - two chunks are in
     // flight): the caller halves the chunk
+    // anchors per window byte of what has been seen (sizes the next chunks so that they need no halving); small chunks
+    // (the odd tasks left behind a halving) say little
+    if (W > ((int64_t)64 << 20)) *a.pa_ratio = std::max(*a.pa_ratio * 0.9, (double)TP / (double)W);
+    else if (W > 0 && *a.pa_ratio == 0) *a.pa_ratio = (double)TP / (double)W;
     if (TP >= (int64_t)1 << 31 || (ix->scratch_budget > 0 && TP * 90 > ix->scratch_budget * 13 / 100)) {
         if (nt <= 1) throw HipError("too many pseudo-alignment anchors for one chain window");
         a.stats->window_bases -= W; // the chunk comes back in halves
         throw ChunkTooLarge();
     }
     a.stats->pa_anchors += TP;
-    // anchors per window byte of what has been seen (sizes the next chunks so that they need no halving)
-    if (W > 0) *a.pa_ratio = std::max(*a.pa_ratio * 0.5, (double)TP / (double)W);
     a.pa_off.ensure((size_t)nt + 2);
     a.out_n.ensure((size_t)nt + 1);
     a.clr_n.ensure((size_t)nt + 1);
@@ -1604,38 +1642,82 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
         ops_tot += oc;
     }
     a.ops_pool.ensure((size_t)ops_tot + 16);
-    a.wfa_todo.ensure((size_t)n);
-    a.wfa_queue.ensure(1);
     HIPCHK(hipMemcpyAsync(a.wfa_in.p, in.data(), sizeof(WfaIn) * n, hipMemcpyHostToDevice, S(ix)));
+    sync(ix); // the class streams read the descriptors
     std::vector<int32_t> fb_items, fb_level; // what leaves the LDS kernels, with its starting scratch level
+    std::mutex fb_mu;
+    // length classes (sequence words of 16 bases); within a class the queue keeps the longest-expected-first order
+    const int bounds[4] = {128, 512, 2048, 4096};
+    std::vector<int32_t> cls[4];
+    int cw[4] = {1, 1, 1, 1};
+    int64_t cl[4] = {1, 1, 1, 1}, cs[4] = {0, 0, 0, 0};
+    for (int32_t i : order) {
+        const int wds = (std::max(in[i].qlen, in[i].tlen) + 15) / 16;
+        int c = 0;
+        while (c < 4 && wds > bounds[c]) c++;
+        if (c == 4) { // longer than the LDS buffers
+            fb_items.push_back(i);
+            fb_level.push_back(2);
+            retries++;
+            continue;
+        }
+        cls[c].push_back(i);
+        cw[c] = std::max(cw[c], wds);
+        const int64_t L = (int64_t)in[i].qlen + in[i].tlen;
+        cl[c] = std::max<int64_t>(cl[c], L);
+        // the score this problem is expected to reach: ~2.5 x divergence x (len_q + len_t) at the 4/6/2 penalties, with a
+        // factor two on top (what goes beyond reports a scratch overflow and is aligned by the fallback)
+        const double dv = est_div ? (double)(*est_div)[i] : 0.12;
+        cs[c] = std::max<int64_t>(cs[c], (int64_t)(5.0 * (dv + 0.01) * (double)L) + 2048);
+    }
+    const int first_nc[4] = {2, 2, 4, 8};
+    // scratch of the four classes side by side: what each would like (resident wavefronts x expected backtrace bytes of its
+    // longest problem), scaled down together when that exceeds the lean share of the budget
+    int64_t want[4], share[4];
+    int64_t want_tot = 0;
+    for (int c = 0; c < 4; c++) {
+        const int64_t m = (int64_t)cls[c].size();
+        const int64_t smax = std::min<int64_t>(8 * cl[c] + 64, cs[c]);
+        const int64_t per = (smax / 2 + 2) * 64 * first_nc[c] + 2 * cl[c] + 4096 + (smax / 2 + 4) * 16;
+        want[c] = m == 0 ? 0 : std::min<int64_t>(m, wfa_resident_blocks(ix->device, cw[c], first_nc[c])) * per * 9 / 8;
+        want_tot += want[c];
+    }
+    for (int c = 0; c < 4; c++)
+        share[c] = want_tot <= lean_budget ? std::max<int64_t>(want[c], (int64_t)64 << 20)
+                                           : std::max<int64_t>((int64_t)((double)want[c] / (double)want_tot * (double)lean_budget), (int64_t)64 << 20);
     // one launch of the persistent LDS kernel per length class and ring width: the packed sequences live in LDS, so the
     // resident wavefronts per CU are set by the longest problem of the launch (gene-sized HSPs: 28 per CU, 50-kb reads: 3-5)
-    auto persistent_pass = [&](const std::vector<int32_t> &items, int seq_words, int64_t lmax, std::vector<int32_t> &too_wide,
-                               int nc) {
+    auto persistent_pass = [&](AlignCtx::LeanCtx &lc, int64_t budget, const std::vector<int32_t> &items, int seq_words,
+                               int64_t lmax, int64_t s_expect, std::vector<int32_t> &too_wide, int nc) {
         const int64_t m = (int64_t)items.size();
         if (m == 0) return;
         const int resident = wfa_resident_blocks(ix->device, seq_words, nc);
         int nblocks = (int)std::min<int64_t>(m, resident);
         // private scratch per resident wave: one backtrace byte per wavefront cell + 8 bytes per even score; never
-        // more than the worst case of the longest problem of the class
-        const int64_t smax = 8 * lmax + 64; // a global alignment never exceeds this penalty
-        int64_t bytes = lean_budget / nblocks * 7 / 8;
+        // more than the longest problem of the class is expected to need
+        const int64_t smax = std::min<int64_t>(8 * lmax + 64, s_expect); // a global alignment never exceeds 8 per base
+        int64_t bytes = budget / nblocks * 7 / 8;
         bytes = std::min<int64_t>(bytes, (smax / 2 + 2) * 64 * nc + 2 * lmax + 4096);
         bytes = std::max<int64_t>(bytes, 65536);
         bytes = std::min<int64_t>(bytes, 2000000000) & ~(int64_t)15;
         int64_t entries = std::min<int64_t>(smax / 2 + 4, bytes / 24 + 1024);
         if (getenv("LM_DEBUG"))
-            fprintf(stderr, "[lm] wfa pass (%d diagonals) problems=%lld blocks=%d (resident %d) bytes/block=%lld scores=%lld seq_words=%d\n",
-                    64 * nc, (long long)m, nblocks, resident, (long long)bytes, (long long)(2 * entries), seq_words);
-        a.hdr_pool.ensure((size_t)(entries * 2) * nblocks + 16);
-        a.arena_pool.ensure((size_t)(bytes / 4) * nblocks + 16);
-        HIPCHK(hipMemcpyAsync(a.wfa_todo.p, items.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice, S(ix)));
-        HIPCHK(hipMemsetAsync(a.wfa_queue.p, 0, sizeof(unsigned int), S(ix)));
+            fprintf(stderr, "[lm +%.1f ms] wfa pass (%d diagonals) problems=%lld blocks=%d (resident %d) bytes/block=%lld scores=%lld seq_words=%d\n",
+                    now_ms() - g_dbg_t0, 64 * nc, (long long)m, nblocks, resident, (long long)bytes, (long long)(2 * entries), seq_words);
+        lc.hdr_pool.ensure((size_t)(entries * 2) * nblocks + 16);
+        lc.arena_pool.ensure((size_t)(bytes / 4) * nblocks + 16);
+        lc.todo.ensure((size_t)m);
+        lc.queue.ensure(1);
+        HIPCHK(hipMemcpyAsync(lc.todo.p, items.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice, S(ix)));
+        HIPCHK(hipMemsetAsync(lc.queue.p, 0, sizeof(unsigned int), S(ix)));
         {
-            Prof p(ix, nc == 8 ? "k_wfa_lean512" : nc == 4 ? "k_wfa_lean256" : "k_wfa_lean", wfa_bytes(in, items));
-            launch_wfa(S(ix), a.wfa_in.p, n, a.wfa_todo.p, m, nblocks, a.hdr_pool.p, entries * 2, (uint8_t *)a.arena_pool.p, bytes,
-                       a.ops_pool.p, a.wfa_queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc);
+            Prof p(ix, nc == 16 ? "k_wfa_lean1024" : nc == 8 ? "k_wfa_lean512" : nc == 4 ? "k_wfa_lean256" : "k_wfa_lean",
+                   wfa_bytes(in, items));
+            launch_wfa(S(ix), a.wfa_in.p, n, lc.todo.p, m, nblocks, lc.hdr_pool.p, entries * 2, (uint8_t *)lc.arena_pool.p, bytes,
+                       a.ops_pool.p, lc.queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc);
         }
+        sync(ix);
+        // this pass's results: the records of its items (other classes write theirs into the same array meanwhile)
         std::vector<WfaOut> tmp;
         d2h(ix, tmp, a.wfa_out.p, (size_t)n);
         std::vector<uint64_t> ops_tmp;
@@ -1649,6 +1731,7 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
             if (stt == 3) { // wider than this ring (or not plain ACGT)
                 too_wide.push_back(i);
             } else if (stt == 1) { // scratch or ops overflow: per-problem scratch in the global-memory kernel
+                std::lock_guard<std::mutex> l(fb_mu);
                 fb_items.push_back(i);
                 fb_level.push_back(1);
                 retries++;
@@ -1658,37 +1741,39 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
                     ops_keep[i].assign(ops_tmp.begin() + in[i].ops_off, ops_tmp.begin() + in[i].ops_off + tmp[i].r.nops);
             }
         }
-        if (getenv("LM_DEBUG") && (n3 || n1))
-            fprintf(stderr, "[lm] wfa pass: %lld problems wider than %d diagonals (or non-ACGT), %lld on scratch overflow\n",
-                    (long long)n3, 64 * nc - 2, (long long)n1);
+        if (getenv("LM_DEBUG"))
+            fprintf(stderr, "[lm +%.1f ms] wfa pass (%d diagonals, %lld problems) done: %lld wider than %d diagonals (or non-ACGT), %lld on scratch overflow\n",
+                    now_ms() - g_dbg_t0, 64 * nc, (long long)m, (long long)n3, 64 * nc - 2, (long long)n1);
     };
-    // length classes (sequence words of 16 bases); within a class the queue keeps the longest-expected-first order
-    const int bounds[4] = {128, 512, 2048, 4096};
-    std::vector<int32_t> cls[4];
-    int cw[4] = {1, 1, 1, 1};
-    int64_t cl[4] = {1, 1, 1, 1};
-    for (int32_t i : order) {
-        const int wds = (std::max(in[i].qlen, in[i].tlen) + 15) / 16;
-        int c = 0;
-        while (c < 4 && wds > bounds[c]) c++;
-        if (c == 4) { // longer than the LDS buffers
+    // ring width by experience: alignments of tens of kb at ONT error rates run wavefronts of several hundred diagonals
+    // under wf-adaptive(10,50) (all of the >= 32-kb class and two thirds of the 8-32-kb class outgrow 126), gene-sized ones
+    // stay below 126.  A pass that turns out too narrow returns status 3 and the next width takes over.
+    auto class_chain = [&](int c) {
+        AlignCtx::LeanCtx &lc = a.lean[c];
+        std::vector<int32_t> cur = cls[c], next;
+        for (int nc = first_nc[c]; nc <= 16 && !cur.empty(); nc *= 2) {
+            next.clear();
+            persistent_pass(lc, share[c], cur, cw[c], cl[c], cs[c], next, nc);
+            cur.swap(next);
+        }
+        std::lock_guard<std::mutex> l(fb_mu);
+        for (int32_t i : cur) { // the hard ones: generous scratch at once instead of an overflow and a second launch
             fb_items.push_back(i);
             fb_level.push_back(2);
             retries++;
-            continue;
         }
-        cls[c].push_back(i);
-        cw[c] = std::max(cw[c], wds);
-        cl[c] = std::max<int64_t>(cl[c], (int64_t)in[i].qlen + in[i].tlen);
-    }
+    };
     std::thread wide_thread;
     std::exception_ptr wide_err;
     auto start_wide = [&]() { // what has left the LDS kernels so far goes to the fallback on its own stream and thread
-        if (fb_items.empty() || wide_thread.joinable()) return;
-        if (!a.wide.st) HIPCHK(hipStreamCreate(&a.wide.st));
         std::vector<int32_t> items, level;
-        items.swap(fb_items);
-        level.swap(fb_level);
+        {
+            std::lock_guard<std::mutex> l(fb_mu);
+            if (fb_items.empty() || wide_thread.joinable()) return;
+            items.swap(fb_items);
+            level.swap(fb_level);
+        }
+        if (!a.wide.st) HIPCHK(hipStreamCreate(&a.wide.st));
         wide_thread = std::thread([&, items, level]() {
             try {
                 HIPCHK(hipSetDevice(ix->device));
@@ -1703,36 +1788,44 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
             tls_tmp = nullptr;
         });
     };
-    try {
-        for (int c = 3; c >= 0; c--) {
-            // ring width by experience: alignments of tens of kb at ONT error rates run wavefronts of several hundred
-            // diagonals under wf-adaptive(10,50) (all of the >= 32-kb class and two thirds of the 8-32-kb class outgrow 126),
-            // gene-sized ones stay below 126.  A pass that turns out too narrow returns status 3 and the next width takes over.
-            std::vector<int32_t> w1, w2, w3, w4;
-            const int first = c == 3 ? 8 : (c == 2 ? 4 : 2);
-            if (first == 2) {
-                persistent_pass(cls[c], cw[c], cl[c], w1, 2);
-                persistent_pass(w1, cw[c], cl[c], w2, 4);
-                persistent_pass(w2, cw[c], cl[c], w4, 8);
-            } else if (first == 4) {
-                persistent_pass(cls[c], cw[c], cl[c], w2, 4);
-                persistent_pass(w2, cw[c], cl[c], w4, 8);
-            } else {
-                persistent_pass(cls[c], cw[c], cl[c], w4, 8);
+    // the classes side by side, the long ones first (their wavefronts should all be resident from the start); the caller's
+    // thread takes the shortest class on its own stream
+    std::thread cth[4];
+    std::exception_ptr cerr[4];
+    const bool serial = getenv("LM_WFA_SERIAL") != nullptr; // debugging aid: one class after the other
+    for (int c = 3; c >= 1; c--) {
+        if (cls[c].empty()) continue;
+        if (!a.lean[c].st) HIPCHK(hipStreamCreate(&a.lean[c].st));
+        cth[c] = std::thread([&, c]() {
+            try {
+                HIPCHK(hipSetDevice(ix->device));
+                tls_stream = a.lean[c].st;
+                tls_tmp = &a.lean[c].tmp;
+                tls_arena = &ix->arena;
+                class_chain(c);
+            } catch (...) {
+                cerr[c] = std::current_exception();
             }
-            persistent_pass(w4, cw[c], cl[c], w3, 16); // 1022 diagonals: the last LDS width
-            for (int32_t i : w3) { // the hard ones: generous scratch at once instead of an overflow and a second launch
-                fb_items.push_back(i);
-                fb_level.push_back(2);
-                retries++;
-            }
-            if (c == 2) start_wide(); // the long classes are done: their leftovers run beside the short classes
-        }
-    } catch (...) {
-        if (wide_thread.joinable()) wide_thread.join();
-        throw;
+            tls_stream = nullptr;
+            tls_tmp = nullptr;
+        });
+        if (serial) cth[c].join();
     }
+    std::exception_ptr err0;
+    try {
+        class_chain(0);
+        for (int c = 3; c >= 2; c--)
+            if (cth[c].joinable()) cth[c].join();
+        start_wide(); // the long classes are done: their leftovers run beside what is left of the short classes
+    } catch (...) {
+        err0 = std::current_exception();
+    }
+    for (int c = 3; c >= 1; c--)
+        if (cth[c].joinable()) cth[c].join();
     if (wide_thread.joinable()) wide_thread.join();
+    if (err0) std::rethrow_exception(err0);
+    for (int c = 1; c < 4; c++)
+        if (cerr[c]) std::rethrow_exception(cerr[c]);
     if (wide_err) std::rethrow_exception(wide_err);
     if (!fb_items.empty()) { // leftovers of the short classes (rare): same fallback, on this thread's stream
         if (!a.wide.st) HIPCHK(hipStreamCreate(&a.wide.st));
@@ -1893,6 +1986,10 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
                     wb += segw;
                     tend = e;
                 }
+                if (getenv("LM_DEBUG"))
+                    fprintf(stderr, "[lm] alignment chunk: tasks [%lld, %lld) of [%lld, %lld), %.2f GB of windows (limit %.2f GB, %.4f anchors per window byte so far)\n",
+                            (long long)tpos, (long long)tend, (long long)r0, (long long)r1, (double)wb / 1e9,
+                            (double)max_window_bytes / 1e9, *ctxs[0]->pa_ratio);
                 {
                     std::unique_lock<std::mutex> l(pm);
                     pcv.wait(l, [&] { return slot_free[slot] || cons_abort; });
@@ -1962,7 +2059,8 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
     size_t g0 = genomes.size(); // first genome of the current round
     int64_t gw_used = 0;        // bytes of the round's window buffer in use
     const int64_t gw_target = ix->scratch_budget > 0 ? std::min<int64_t>((int64_t)6 << 30, std::max<int64_t>((int64_t)64 << 20, ix->scratch_budget * 3 / 100)) : (int64_t)1 << 30;
-    const int64_t round_hsps = getenv("LM_DEBUG_ROUND_HSPS") ? atoll(getenv("LM_DEBUG_ROUND_HSPS")) : 600000;
+    const int64_t round_hsps = getenv("LM_DEBUG_ROUND_HSPS") ? atoll(getenv("LM_DEBUG_ROUND_HSPS")) : 330000;
+    const int64_t min_round_hsps = getenv("LM_DEBUG_MIN_ROUND_HSPS") ? atoll(getenv("LM_DEBUG_MIN_ROUND_HSPS")) : 150000;
     // ---- one extendMatch / WFA / finalisation round over the HSPs gathered from one or more chunks: the WFA launches end in
     // tails of a few long alignments, so few large rounds beat one round per chunk
     auto flush_round = [&]() {
@@ -1973,6 +2071,7 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
         double tc = now_ms();
         int64_t NH = (int64_t)hsps.size();
         st.hsps_aligned += NH;
+        dbg_stamp("extendMatch / WFA round starts");
         if (getenv("LM_DEBUG"))
             fprintf(stderr, "[lm] mem: round of %lld HSPs starts with %.2f GB of scratch held (budget %.2f)\n", (long long)NH,
                     (double)(g_dbuf_bytes.load() - ix->hbm_bytes) / 1e9, (double)ix->scratch_budget / 1e9);
@@ -2026,6 +2125,7 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
             }
         }
         double td = now_ms();
+        dbg_stamp("WFA of the round done");
         st.ms_extend_wfa += td - tc;
         // ---- finalisation of this chunk's genomes (:2266-2357 / :2533-2626, then :2684-2749) ----
         parallel_for((int64_t)(genomes.size() - g0), 128, [&](int64_t gb0, int64_t gb1) {
@@ -2311,11 +2411,16 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
         }
         st.ms_glue += now_ms() - tb;
         janitor().dispose(std::move(resv));
+        bool idle = false;
         {   // the chunk's pseudo-alignment results are consumed and its windows copied: its context may take the next chunk
             std::lock_guard<std::mutex> l(pm);
             slot_free[pc.slot] = true;
+            idle = pipelined && ready.empty() && !prod_done;
         }
         pcv.notify_all();
+        // nothing to consume yet: align what has been gathered instead of waiting for the producer (the anchor kernels of the
+        // next chunks then run beside the WFA launches, whose scalar-unit-bound wavefronts leave the vector ALUs and LDS idle)
+        if (idle && (int64_t)hsps.size() >= min_round_hsps) flush_round();
     }
     flush_round();
     if (pipelined) {
@@ -2355,6 +2460,8 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res, const Searc
             tls_stream = ps;
         }
     } tls_scope(ix);
+    g_dbg_t0 = now_ms();
+    dbg_stamp("search of a batch part starts");
     if (ix->scratch_budget > 0) { // scratch of the previous part's alignment half (the halves alternate)
         HIPCHK(hipDeviceSynchronize());
         int64_t freed = 0;
@@ -2364,6 +2471,7 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res, const Searc
             fprintf(stderr, "[lm] alignment scratch of the previous part released: %.2f GB (arena: %.2f GB in slabs, %lld slab allocations so far)\n",
                     (double)freed / 1e9, (double)ix->arena.slab_bytes / 1e9, (long long)ix->arena.slab_allocs);
     }
+    dbg_stamp("previous alignment scratch released");
     Work &w = get_work(ix, qb);
     double tm1 = now_ms();
     stage_kmers(w);
@@ -2489,6 +2597,7 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res, const Searc
     // ---- alignment half, in chunks of whole (query, genome) segments (align_range). Splitting it over two host
     // threads / streams so that one half's host glue overlaps the other half's kernels was measured at C2 and gave
     // nothing (the halves run in lock-step, and the kernels only slow each other down), so it runs on one stream.
+    dbg_stamp("seeding half done, tasks on the host");
     if (const char *e = getenv("LM_DEBUG_OOM_ABOVE_QUERIES")) // test hook: the out-of-memory answer of search_parts
         if ((int64_t)qb->nq > atoll(e)) throw DeviceOOM("test hook: allocation failure between the seeding and alignment halves");
     std::vector<HGenome> genomes; // in (query, genome) order
@@ -2500,6 +2609,7 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res, const Searc
         AlignCtx &a = get_actx(ix, qb, &w, &st);
         align_range(ix, qb, w, a, th, 0, NT, st, genomes, res, strings_mu);
     }
+    dbg_stamp("alignment half done");
     // ---- per query: sort genomes by best cluster (:2919-2921, ties by genome key), regroup by sseqid, emit rows ----
     double te0 = now_ms();
     {
@@ -2635,6 +2745,7 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res, const Searc
     st.ms_total = st.ms_mask + st.ms_lookup + st.ms_chain + st.ms_window + st.ms_pseudo + st.ms_glue + st.ms_extend_wfa +
                   st.ms_finalize;
     janitor().dispose(std::move(genomes));
+    dbg_stamp("rows emitted");
 }
 
 } // namespace lm
