@@ -282,6 +282,12 @@ struct SeedPacker {
 struct lm_index {
     lm::Work *work = nullptr;       // device scratch reused across calls (grow-only)
     lm::AlignCtx *actx[2] = {nullptr, nullptr}; // one per alignment worker
+    // second lane: two parts of a large batch are searched side by side (the seeding / anchor kernels of one beside the
+    // WFA launches of the other), each with half of the scratch budget, its own scratch, streams and rocPRIM storage
+    lm::Work *work1 = nullptr;
+    lm::AlignCtx *actx1[2] = {nullptr, nullptr};
+    hipStream_t st_b = nullptr, st2_b = nullptr;
+    int active_lanes = 1;
     std::mutex mu;                  // one in-flight call per handle
     HostIndex host;
     lm_options opt;
@@ -302,7 +308,7 @@ struct lm_index {
     int64_t hbm_bytes = 0;
     // scratch
     ScratchArena arena;      // phase buffers of the searches on this handle (destroyed after work / actx)
-    DBuf<uint8_t> tmp, tmp2; // rocPRIM temporary storage (per stream)
+    DBuf<uint8_t> tmp, tmp2, tmp_b, tmp2_b; // rocPRIM temporary storage (per stream)
     // profiling
     bool prof = false;
     std::mutex prof_mu;

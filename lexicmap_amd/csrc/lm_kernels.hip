@@ -629,7 +629,7 @@ __device__ __forceinline__ void pa_prefixes(const Task &t, const uint8_t *__rest
 #define PA_WAVES (PA_THREADS / 64)
 #define PA_GROUP 64  /* chain windows per workgroup pass */
 #define PA_STAGE 256 /* candidates a wavefront stages in LDS */
-#define PA_SLICE 2048 /* window positions a wavefront takes at a time */
+#define PA_SLICE 1920 /* window positions a wavefront takes at a time: their 2-bit genome words are one 8-byte load per lane */
 #define PA_LDS_BYTES ((1 << (LM_PA_BLOOM_LOG_MAX - 3)) + (1 << (LM_PA_MAP9_LOG - 3)) + PA_WAVES * PA_STAGE * 8)
 __global__ __launch_bounds__(PA_THREADS) void k_pa_filter(DevIndexView ix, const Task *__restrict__ tasks, int64_t ntasks,
                                                            const uint8_t *__restrict__ wbuf,
@@ -741,21 +741,32 @@ __global__ __launch_bounds__(PA_THREADS) void k_pa_filter(DevIndexView ix, const
                 const uint64_t rec_t = (uint64_t)(t0g + j) << 32;
                 if (fast_pfx) {
                     // prefixes only; the low-complexity filter (which needs the whole k-mer) is applied by k_pa_search.
-                    // Two strips of 64 positions per pass: their genome loads are independent and in flight together.
-                    for (int tile = p0; tile < p1; tile += 128) {
-                        const int i0 = tile + lane, i1 = tile + 64 + lane;
-                        uint32_t pf[2][2] = {{0, 0}, {0, 0}};
-                        if (i0 < p1) pa_prefixes(t, gb, goff, i0, K, p, &pf[0][0], &pf[0][1]);
-                        if (i1 < p1) pa_prefixes(t, gb, goff, i1, K, p, &pf[1][0], &pf[1][1]);
-#pragma unroll
-                        for (int u = 0; u < 2; u++) {
-                            const int i = u ? i1 : i0;
-#pragma unroll
-                            for (int strand = 0; strand < 2; strand++) {
-                                const bool c = i < p1 && lm_pa_candidate2(s_bloom, blog, s_map9, qbits, log, pf[u][strand], p);
-                                push(c, rec_t | ((uint64_t)(uint32_t)i << 1) | (uint64_t)strand);
-                            }
-                        }
+                    // The 2-bit genome words of the whole slice in ONE load (lane l holds 32 bases: 64 lanes cover the
+                    // slice's 1920 positions + K - 1 + the word misalignment); a position takes its two words from the
+                    // lanes that hold them.  Positions are walked in genome order (a reverse-strand window runs backwards).
+                    const int np = p1 - p0;
+                    const int g0 = t.rc ? t.tBegin + t.wlen - K - (p1 - 1) : t.tBegin + p0; // first genome position
+                    const int64_t abs0 = goff * 4 + g0;                                      // in bases from gbits
+                    const int64_t w0 = abs0 >> 5;
+                    const int nwords = (int)(((abs0 + np + K - 2) >> 5) - w0) + 2; // + the word the funnel shift reads
+                    const int lw = lane < nwords ? lane : nwords - 1;
+                    const uint64_t Wl = __builtin_bswap64(((const uint64_t *)gb)[w0 + lw]);
+                    for (int tile = 0; tile < np; tile += 64) {
+                        const int r = tile + lane; // position of the slice in genome order
+                        const int64_t ab = abs0 + r;
+                        const int wi = (int)((ab >> 5) - w0), o = (int)(ab & 31) * 2;
+                        const uint64_t H = __shfl(Wl, wi, 64), L = __shfl(Wl, wi + 1, 64);
+                        const uint64_t v = o ? ((H << o) | (L >> (64 - o))) : H; // 32 bases from the position, left aligned
+                        const uint32_t first = (uint32_t)(v >> (64 - 2 * p));
+                        const uint32_t last = (uint32_t)(v >> (64 - 2 * K)) & ((1u << (2 * p)) - 1u);
+                        const uint32_t rl = revcomp_small(last, p);
+                        const uint32_t pf0 = t.rc ? rl : first, pf1 = t.rc ? first : rl;
+                        const int i = t.rc ? p1 - 1 - r : p0 + r; // window position
+                        const bool in = r < np;
+                        push(in && lm_pa_candidate2(s_bloom, blog, s_map9, qbits, log, pf0, p),
+                             rec_t | ((uint64_t)(uint32_t)i << 1));
+                        push(in && lm_pa_candidate2(s_bloom, blog, s_map9, qbits, log, pf1, p),
+                             rec_t | ((uint64_t)(uint32_t)i << 1) | 1ull);
                     }
                 } else {
                     for (int tile = p0; tile < p1; tile += 64) {
@@ -1377,11 +1388,46 @@ __global__ void k_extend_fin(const HspIn *__restrict__ hsps, int64_t n, HspExt *
 // Same recurrence, trimming, wf-adaptive cut-off and storage layout as lm_wfa_align (lm_algos.h), which is the
 // CPU-checked statement of the device logic; the backtrace is the shared lm_wfa_backtrace run by lane 0.
 __device__ __forceinline__ int wave_min_i32(int v) {
-    for (int o = 32; o > 0; o >>= 1) {
-        int x = __shfl_xor(v, o, 64);
-        v = x < v ? x : v;
-    }
-    return v;
+    // DPP reduction (no LDS round trips: this sits in the score loop of the WFA kernels): pairs, quads, 8 and 16 lanes by
+    // rotation inside the rows of 16, then the row totals by the two row broadcasts; the total is in lane 63.
+    // All 64 lanes must be active.
+    int x;
+    x = __builtin_amdgcn_mov_dpp(v, 0xb1, 0xf, 0xf, false); // quad_perm:[1,0,3,2]
+    v = x < v ? x : v;
+    x = __builtin_amdgcn_mov_dpp(v, 0x4e, 0xf, 0xf, false); // quad_perm:[2,3,0,1]
+    v = x < v ? x : v;
+    x = __builtin_amdgcn_mov_dpp(v, 0x124, 0xf, 0xf, false); // row_ror:4
+    v = x < v ? x : v;
+    x = __builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, false); // row_ror:8
+    v = x < v ? x : v;
+    x = __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
+    v = x < v ? x : v;
+    x = __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
+    v = x < v ? x : v;
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// two unsigned 16-bit minima at once (v_pk_min_u16) and their reduction over the wavefront, same DPP steps: the WFA kernels
+// keep "first / last diagonal with a property" as (j, W-1-j) pairs, j = diagonal relative to the row's first one
+typedef unsigned short lm_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+    lm_u16x2 x = __builtin_bit_cast(lm_u16x2, a), y = __builtin_bit_cast(lm_u16x2, b);
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(x, y));
+}
+__device__ __forceinline__ uint32_t wave_pkmin_u16(uint32_t v) { // all 64 lanes active; result uniform
+    uint32_t x;
+    x = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xb1, 0xf, 0xf, false);
+    v = pk_min_u16(x, v);
+    x = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4e, 0xf, 0xf, false);
+    v = pk_min_u16(x, v);
+    x = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x124, 0xf, 0xf, false);
+    v = pk_min_u16(x, v);
+    x = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xf, 0xf, false);
+    v = pk_min_u16(x, v);
+    x = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xa, 0xf, false);
+    v = pk_min_u16(x, v);
+    x = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xc, 0xf, false);
+    v = pk_min_u16(x, v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 __device__ __forceinline__ int32_t wf_val(const int32_t *arena, int lo, int hi, int base, int k) {
@@ -1921,74 +1967,10 @@ __device__ __forceinline__ void bt_replay(const uint8_t *__restrict__ opseq, int
 // outside a row's valid range hold LM_NULL_OFF, so the recurrence reads its five neighbours without range tests as long
 // as a wavefront is at most W-2 diagonals wide (wider ones return status 3: NC=1 -> NC=2 -> k_wfa_wave). The valid
 // ranges of the last 9 (M) / 3 (I, D) scores are wave-uniform scalars kept in registers and rotated every score;
-// trimming and the wf-adaptive cut-off are ballots. No global loads inside the score loop: both sequences are 2-bit
+// trimming and the wf-adaptive cut-off are DPP reductions of packed (first, last) positions (the scalar unit, which all
+// resident wavefronts of a CU share, has little else to do than the loop control). No global loads inside the score loop: both sequences are 2-bit
 // packed in LDS. Persistent wavefronts: each workgroup (one wave) owns a private header/arena region and pops problems
 // from a queue ordered by decreasing expected cost. Results are identical to lm_wfa_align.
-template <int NC> struct SlotMask { // one bit per LDS slot / per diagonal offset, W = 64*NC bits
-    unsigned long long w[NC];
-};
-template <int NC> __device__ __forceinline__ SlotMask<NC> sm_rotr(SlotMask<NC> m, int r) {
-    // bit j of the result = bit (j + r) mod W of m.  Static indices only: an array indexed by a run-time value would be
-    // put in scratch memory, in the middle of the score loop.
-    SlotMask<NC> o;
-    if (NC == 1) {
-        o.w[0] = rotr64(m.w[0], r);
-        return o;
-    }
-    r &= 64 * NC - 1;
-    const int ws = r >> 6, bs = r & 63;
-#pragma unroll
-    for (int step = 1; step < NC; step <<= 1) { // whole words: log2(NC) conditional rotations by 1, 2, 4 words
-        const unsigned long long pick = (ws & step) ? ~0ull : 0ull; // masks, not selects of array elements (see above)
-        SlotMask<NC> t;
-#pragma unroll
-        for (int i = 0; i < NC; i++) t.w[i] = (m.w[i] & ~pick) | (m.w[(i + step) & (NC - 1)] & pick);
-        m = t;
-    }
-#pragma unroll
-    for (int i = 0; i < NC; i++) {
-        const unsigned long long a = m.w[i], b = m.w[(i + 1) & (NC - 1)];
-        o.w[i] = bs ? ((a >> bs) | (b << (64 - bs))) : a;
-    }
-    return o;
-}
-template <int NC> __device__ __forceinline__ bool sm_any(const SlotMask<NC> &m) {
-    unsigned long long x = 0;
-#pragma unroll
-    for (int i = 0; i < NC; i++) x |= m.w[i];
-    return x != 0;
-}
-template <int NC> __device__ __forceinline__ int sm_first(const SlotMask<NC> &m) { // lowest set bit (m non-zero)
-    int r = 64 * (NC - 1) + __ffsll((long long)m.w[NC - 1]) - 1;
-#pragma unroll
-    for (int i = NC - 2; i >= 0; i--)
-        if (m.w[i]) r = 64 * i + __ffsll((long long)m.w[i]) - 1;
-    return r;
-}
-template <int NC> __device__ __forceinline__ int sm_last(const SlotMask<NC> &m) { // highest set bit (m non-zero)
-    int r = 63 - __clzll((long long)m.w[0]);
-#pragma unroll
-    for (int i = 1; i < NC; i++)
-        if (m.w[i]) r = 64 * i + 63 - __clzll((long long)m.w[i]);
-    return r;
-}
-template <int NC> __device__ __forceinline__ SlotMask<NC> sm_below(SlotMask<NC> m, int nbits) { // keep bits [0, nbits)
-#pragma unroll
-    for (int i = 0; i < NC; i++) {
-        const int nb = nbits - 64 * i;
-        m.w[i] &= nb >= 64 ? ~0ull : (nb <= 0 ? 0ull : ((1ull << nb) - 1ull));
-    }
-    return m;
-}
-template <int NC> __device__ __forceinline__ SlotMask<NC> sm_from(SlotMask<NC> m, int b0) { // keep bits [b0, W)
-#pragma unroll
-    for (int i = 0; i < NC; i++) {
-        const int b = b0 - 64 * i;
-        m.w[i] = b >= 64 ? 0ull : (b <= 0 ? m.w[i] : ((m.w[i] >> b) << b));
-    }
-    return m;
-}
-
 template <int NC>
 __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, int64_t n, const int32_t *__restrict__ todo,
                                                   int64_t ntodo, int32_t *__restrict__ hdr_pool, int64_t hdr_stride,
@@ -2106,18 +2088,19 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
         while (status == 0) {
             bool done = false;
             if (mlo[0] <= mhi[0]) {
-                int kc[NC];
+                int kc[NC], jc[NC];
                 bool inr[NC];
                 int32_t off[NC];
-                SlotMask<NC> fin;
+                bool fin = false;
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
                     const int slot = lane + 64 * c;
-                    const int k = alo + ((slot - koff - alo) & (W - 1)); // this cell's diagonal at score s
+                    const int j = (slot - koff - alo) & (W - 1);
+                    const int k = alo + j; // this cell's diagonal at score s
                     kc[c] = k;
+                    jc[c] = j;
                     inr[c] = false;
                     off[c] = LM_NULL_OFF;
-                    fin.w[c] = 0;
                     if (!chunk_has(c, mlo[0], mhi[0])) continue;
                     inr[c] = (uint32_t)(k - mlo[0]) <= (uint32_t)(mhi[0] - mlo[0]);
                     int32_t o = rM[ms][slot];
@@ -2141,9 +2124,9 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                         rM[ms][slot] = o;
                     }
                     off[c] = o;
-                    fin.w[c] = __ballot(inr[c] && k == ak && o >= tlen);
+                    fin = fin || (inr[c] && k == ak && o >= tlen);
                 }
-                done = sm_any<NC>(fin);
+                done = __ballot(fin) != 0ull;
                 if (!done && mhi[0] - mlo[0] + 1 >= 10) { // wf-adaptive(10, 50)
                     int dist[NC];
                     int dm = 2147483647;
@@ -2152,41 +2135,25 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                         dist[c] = inr[c] ? wf_dist(off[c], kc[c], plen, tlen) : 2147483647;
                         dm = dist[c] < dm ? dist[c] : dm;
                     }
-                    const int dmin = __builtin_amdgcn_readfirstlane(wave_min_i32(dm));
-                    SlotMask<NC> kb;
-#pragma unroll
-                    for (int c = 0; c < NC; c++) kb.w[c] = __ballot(inr[c] && (dist[c] - dmin <= 50));
-                    int nlo = mlo[0], nhi = mhi[0];
+                    const int dmin = wave_min_i32(dm);
+                    // The diagonals that stay: lm_wfa_align walks up from mlo to the first kept one below `top` and down
+                    // from mhi to the last kept one above `bottom` = max(ak, new lo) - which is max(ak, mlo): the new lo
+                    // never passes ak (it stops at top <= ak) unless nothing below top is tested at all (mlo >= top).
+                    // Both ends in one packed reduction: (j, W-1-j) of the kept cells on either side, j relative to alo.
                     const int top = ak < mhi[0] ? ak : mhi[0];
-                    const bool a0 = NC == 2 && chunk_has(0, mlo[0], mhi[0]), a1 = NC == 2 && chunk_has(NC - 1, mlo[0], mhi[0]);
-                    if (NC == 2 && a0 != a1) {
-                        // the whole wavefront sits in one 64-slot chunk, unwrapped: plain 64-bit masks
-                        const int sh = ((mlo[0] + koff) & (W - 1)) & 63;
-                        // (select by mask, not `a1 ? w[1] : w[0]`: that becomes a run-time index into the array = scratch memory)
-                        const unsigned long long pick = a1 ? ~0ull : 0ull;
-                        const unsigned long long k64 = ((kb.w[0] & ~pick) | (kb.w[NC - 1] & pick)) >> sh; // bit j <-> diagonal mlo+j
-                        if (mlo[0] < top) {
-                            const unsigned long long mk = k64 & ((1ull << (top - mlo[0])) - 1ull);
-                            nlo = mk ? mlo[0] + (__ffsll((long long)mk) - 1) : top;
-                        }
-                        const int bottom = ak > nlo ? ak : nlo;
-                        if (mhi[0] > bottom) {
-                            const int b0 = bottom - mlo[0] + 1;
-                            const unsigned long long mk = (k64 >> b0) << b0;
-                            nhi = mk ? mlo[0] + (63 - __clzll((long long)mk)) : bottom;
-                        }
-                    } else {
-                        kb = sm_rotr<NC>(kb, mlo[0] + koff); // bit j <-> diagonal mlo+j
-                        if (mlo[0] < top) {
-                            SlotMask<NC> mk = sm_below<NC>(kb, top - mlo[0]);
-                            nlo = sm_any<NC>(mk) ? mlo[0] + sm_first<NC>(mk) : top;
-                        }
-                        const int bottom = ak > nlo ? ak : nlo;
-                        if (mhi[0] > bottom) {
-                            SlotMask<NC> mk = sm_from<NC>(kb, bottom - mlo[0] + 1);
-                            nhi = sm_any<NC>(mk) ? mlo[0] + sm_last<NC>(mk) : bottom;
-                        }
+                    const int bottom = ak > mlo[0] ? ak : mlo[0];
+                    uint32_t enc = 0xffffffffu;
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+                        const bool keep = inr[c] && (dist[c] - dmin <= 50);
+                        const uint32_t l16 = (keep && kc[c] < top) ? (uint32_t)jc[c] : 0xffffu;
+                        const uint32_t h16 = (keep && kc[c] > bottom) ? (uint32_t)(W - 1 - jc[c]) : 0xffffu;
+                        enc = pk_min_u16(enc, l16 | (h16 << 16));
                     }
+                    const uint32_t red = wave_pkmin_u16(enc);
+                    int nlo = mlo[0], nhi = mhi[0];
+                    if (mlo[0] < top) nlo = (red & 0xffffu) != 0xffffu ? alo + (int)(red & 0xffffu) : top;
+                    if (mhi[0] > bottom) nhi = (red >> 16) != 0xffffu ? alo + (W - 1 - (int)(red >> 16)) : bottom;
                     if (nlo != mlo[0] || nhi != mhi[0]) {
                         // clamp I[s] / D[s] to the reduced M range (empty stays empty: the sentinels survive max / min) and
                         // put NULL back into the ring cells that left a range
@@ -2281,15 +2248,15 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
             int kk[NC];
             bool inr[NC];
             int32_t vins[NC], vdel[NC], vmx[NC];
-            SlotMask<NC> bm, bi, bd;
+            uint32_t em = 0xffffffffu, ei = 0xffffffffu, ed = 0xffffffffu; // (first, W-1-last) cell inside the DP matrix
 #pragma unroll
             for (int c = 0; c < NC; c++) {
                 const int slot = lane + 64 * c;
-                const int k = lo + ((slot - koff - lo) & (W - 1));
+                const int j = (slot - koff - lo) & (W - 1);
+                const int k = lo + j;
                 kk[c] = k;
                 inr[c] = false;
                 vins[c] = vdel[c] = vmx[c] = LM_NULL_OFF;
-                bm.w[c] = bi.w[c] = bd.w[c] = 0;
                 if (!chunk_has(c, lo, hi)) continue;
                 inr[c] = k <= hi;
                 const int sm1 = (slot + W - 1) & (W - 1), sp1 = (slot + 1) & (W - 1);
@@ -2315,34 +2282,20 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                 auto okc = [&](int32_t o) {
                     return inr[c] && (uint32_t)o <= (uint32_t)tlen && (uint32_t)(o - k) <= (uint32_t)plen;
                 };
-                bm.w[c] = __ballot(okc(mx));
-                bi.w[c] = __ballot(okc(ins));
-                bd.w[c] = __ballot(okc(del));
+                const uint32_t pos = (uint32_t)j | ((uint32_t)(W - 1 - j) << 16);
+                em = pk_min_u16(em, okc(mx) ? pos : 0xffffffffu);
+                ei = pk_min_u16(ei, okc(ins) ? pos : 0xffffffffu);
+                ed = pk_min_u16(ed, okc(del) ? pos : 0xffffffffu);
             }
-            const bool t0 = NC == 2 && chunk_has(0, lo, hi), t1 = NC == 2 && chunk_has(NC - 1, lo, hi);
-            if (NC == 2 && t0 != t1) { // the new wavefront sits in one chunk, unwrapped: 64-bit masks, plain shift
-                const int sh = ((lo + koff) & (W - 1)) & 63;
-                const unsigned long long pick = t1 ? ~0ull : 0ull; // see above: no run-time array index
-                const unsigned long long m64 = ((bm.w[0] & ~pick) | (bm.w[NC - 1] & pick)) >> sh;
-                const unsigned long long i64 = ((bi.w[0] & ~pick) | (bi.w[NC - 1] & pick)) >> sh;
-                const unsigned long long d64 = ((bd.w[0] & ~pick) | (bd.w[NC - 1] & pick)) >> sh;
-                mlo[0] = m64 ? lo + (__ffsll((long long)m64) - 1) : E_LO;
-                mhi[0] = m64 ? lo + (63 - __clzll((long long)m64)) : E_HI;
-                ilo[0] = i64 ? lo + (__ffsll((long long)i64) - 1) : E_LO;
-                ihi[0] = i64 ? lo + (63 - __clzll((long long)i64)) : E_HI;
-                dlo[0] = d64 ? lo + (__ffsll((long long)d64) - 1) : E_LO;
-                dhi[0] = d64 ? lo + (63 - __clzll((long long)d64)) : E_HI;
-            } else {
-                bm = sm_rotr<NC>(bm, lo + koff);
-                bi = sm_rotr<NC>(bi, lo + koff);
-                bd = sm_rotr<NC>(bd, lo + koff);
-                const bool hm = sm_any<NC>(bm), hi_ = sm_any<NC>(bi), hd = sm_any<NC>(bd);
-                mlo[0] = hm ? lo + sm_first<NC>(bm) : E_LO;
-                mhi[0] = hm ? lo + sm_last<NC>(bm) : E_HI;
-                ilo[0] = hi_ ? lo + sm_first<NC>(bi) : E_LO;
-                ihi[0] = hi_ ? lo + sm_last<NC>(bi) : E_HI;
-                dlo[0] = hd ? lo + sm_first<NC>(bd) : E_LO;
-                dhi[0] = hd ? lo + sm_last<NC>(bd) : E_HI;
+            {
+                const uint32_t rm = wave_pkmin_u16(em), ri = wave_pkmin_u16(ei), rd = wave_pkmin_u16(ed);
+                const bool hm = (rm & 0xffffu) != 0xffffu, hi_ = (ri & 0xffffu) != 0xffffu, hd = (rd & 0xffffu) != 0xffffu;
+                mlo[0] = hm ? lo + (int)(rm & 0xffffu) : E_LO;
+                mhi[0] = hm ? lo + (W - 1 - (int)(rm >> 16)) : E_HI;
+                ilo[0] = hi_ ? lo + (int)(ri & 0xffffu) : E_LO;
+                ihi[0] = hi_ ? lo + (W - 1 - (int)(ri >> 16)) : E_HI;
+                dlo[0] = hd ? lo + (int)(rd & 0xffffu) : E_LO;
+                dhi[0] = hd ? lo + (W - 1 - (int)(rd >> 16)) : E_HI;
             }
             LDS_WAVE_SYNC(); // every lane has read the old rows before row ms / is are overwritten
             const uint32_t spm = (uint32_t)(mhi[0] - mlo[0]), spi = (uint32_t)(ihi[0] - ilo[0]), spd = (uint32_t)(dhi[0] - dlo[0]);

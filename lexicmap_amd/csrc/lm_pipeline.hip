@@ -34,6 +34,7 @@
 #include <future>
 #include <memory>
 #include <exception>
+#include <list>
 #include <thread>
 
 thread_local std::string g_open_error;
@@ -44,12 +45,21 @@ namespace lm {
 // Helpers take the stream and the rocPRIM scratch from here: a host thread may install its own (thread-local) pair to
 // run part of a batch beside the handle's stream; by default it is the handle's.
 static thread_local DBuf<uint8_t> *tls_tmp = nullptr;
+static thread_local int tls_lane = 0; // which of the handle's two lanes this thread works for
+static inline Work *&lane_work(lm_index *ix) { return tls_lane ? ix->work1 : ix->work; }
+static inline AlignCtx **lane_actx(lm_index *ix) { return tls_lane ? ix->actx1 : ix->actx; }
+static inline hipStream_t &lane_st(lm_index *ix) { return tls_lane ? ix->st_b : ix->st; }
+static inline hipStream_t &lane_st2(lm_index *ix) { return tls_lane ? ix->st2_b : ix->st2; }
+static inline DBuf<uint8_t> &lane_tmp(lm_index *ix) { return tls_lane ? ix->tmp_b : ix->tmp; }
+static inline DBuf<uint8_t> &lane_tmp2(lm_index *ix) { return tls_lane ? ix->tmp2_b : ix->tmp2; }
+// the scratch budget of the lane this thread works for
+static inline int64_t BUDGET(lm_index *ix) { return ix->scratch_budget > 0 ? ix->scratch_budget / ix->active_lanes : ix->scratch_budget; }
 static double g_dbg_t0 = 0; // LM_DEBUG: start of the running search (time stamps of the debug lines)
 static inline void dbg_stamp(const char *what) {
     if (getenv("LM_DEBUG")) fprintf(stderr, "[lm +%.1f ms] %s\n", now_ms() - g_dbg_t0, what);
 }
-static inline hipStream_t S(lm_index *ix) { return tls_stream ? tls_stream : ix->st; }
-static inline DBuf<uint8_t> &TMP(lm_index *ix) { return tls_tmp ? *tls_tmp : ix->tmp; }
+static inline hipStream_t S(lm_index *ix) { return tls_stream ? tls_stream : lane_st(ix); }
+static inline DBuf<uint8_t> &TMP(lm_index *ix) { return tls_tmp ? *tls_tmp : lane_tmp(ix); }
 
 struct Prof {
     lm_index *ix;
@@ -565,7 +575,7 @@ static void stage_lookup(Work &w, lm_stage_stats &stats) {
     // anchors + their chaining scratch (~96 B each) must fit 22 % of the scratch budget, and their number 31 bits:
     // otherwise the caller halves this part of the batch and comes back (lm_search_resident)
     const char *dbg_max = getenv("LM_DEBUG_MAX_ANCHORS"); // test hook: forces the halving path
-    if (T >= (int64_t)1 << 31 || (ix->scratch_budget > 0 && T * 96 > ix->scratch_budget * 22 / 100) ||
+    if (T >= (int64_t)1 << 31 || (BUDGET(ix) > 0 && T * 96 > BUDGET(ix) * 22 / 100) ||
         (dbg_max && qb->nq > 1 && T > atoll(dbg_max))) {
         if (qb->nq <= 1) throw HipError("one query yields more seed anchors than the device can hold");
         throw PartTooLarge();
@@ -1039,15 +1049,18 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
     return LM_OK;
 }
 
-void lm_free_align_ctx(lm_index *ix);
+void lm_free_align_ctx(lm_index *ix, int lane = -1);
 
 void lm_index_close(lm_index *ix) {
     if (!ix) return;
     prof_resolve(ix);
     delete ix->work;
+    delete ix->work1;
     lm_free_align_ctx(ix); // AlignCtx is defined further down
     if (ix->st) (void)hipStreamDestroy(ix->st);
     if (ix->st2) (void)hipStreamDestroy(ix->st2);
+    if (ix->st_b) (void)hipStreamDestroy(ix->st_b);
+    if (ix->st2_b) (void)hipStreamDestroy(ix->st2_b);
     delete ix;
 }
 
@@ -1325,11 +1338,17 @@ struct AlignCtx {
 };
 
 } // namespace lm
-void lm_free_align_ctx(lm_index *ix) {
-    for (auto &c : ix->actx) {
-        delete c;
-        c = nullptr;
-    }
+void lm_free_align_ctx(lm_index *ix, int lane) { // lane < 0: both
+    if (lane != 1)
+        for (auto &c : ix->actx) {
+            delete c;
+            c = nullptr;
+        }
+    if (lane != 0)
+        for (auto &c : ix->actx1) {
+            delete c;
+            c = nullptr;
+        }
 }
 namespace lm {
 
@@ -1423,7 +1442,7 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
     // (the odd tasks left behind a halving) say little
     if (W > ((int64_t)64 << 20)) *a.pa_ratio = std::max(*a.pa_ratio * 0.9, (double)TP / (double)W);
     else if (W > 0 && *a.pa_ratio == 0) *a.pa_ratio = (double)TP / (double)W;
-    if (TP >= (int64_t)1 << 31 || (ix->scratch_budget > 0 && TP * 90 > ix->scratch_budget * 13 / 100)) {
+    if (TP >= (int64_t)1 << 31 || (BUDGET(ix) > 0 && TP * 90 > BUDGET(ix) * 13 / 100)) {
         if (nt <= 1) throw HipError("too many pseudo-alignment anchors for one chain window");
         a.stats->window_bases -= W; // the chunk comes back in halves
         throw ChunkTooLarge();
@@ -1525,14 +1544,15 @@ static double div_from_pseudo_pident(double pid) { // table over integer percent
 static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &out, std::vector<uint64_t> &ops_h,
                     std::vector<int64_t> &ops_off_h, bool want_ops, const std::vector<float> *est_div = nullptr) {
     lm_index *ix = a.ix;
+    const int lane = tls_lane;
     int64_t n = (int64_t)in.size();
     out.assign(n, WfaOut());
     ops_off_h.assign(n + 1, 0);
     ops_h.clear();
     if (n == 0) return;
     // scratch: the LDS passes and the global-memory fallback run at the same time
-    const int64_t lean_budget = ix->scratch_budget > 0 ? std::min<int64_t>(a.wfa_budget, ix->scratch_budget * 26 / 100) : a.wfa_budget;
-    const int64_t wide_budget = ix->scratch_budget > 0 ? std::min<int64_t>((int64_t)72 << 30, ix->scratch_budget * 10 / 100) : (int64_t)72 << 30;
+    const int64_t lean_budget = BUDGET(ix) > 0 ? std::min<int64_t>(a.wfa_budget, BUDGET(ix) * 26 / 100) : a.wfa_budget;
+    const int64_t wide_budget = BUDGET(ix) > 0 ? std::min<int64_t>((int64_t)72 << 30, BUDGET(ix) * 10 / 100) : (int64_t)72 << 30;
     a.wfa_out.ensure((size_t)n);
     a.wfa_in.ensure((size_t)n);
     std::vector<std::vector<uint64_t>> ops_keep(want_ops ? n : 0);
@@ -1777,6 +1797,7 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
         wide_thread = std::thread([&, items, level]() {
             try {
                 HIPCHK(hipSetDevice(ix->device));
+                tls_lane = lane;
                 tls_stream = a.wide.st;
                 tls_tmp = &a.wide.tmp;
                 tls_arena = &ix->arena;
@@ -1799,6 +1820,7 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
         cth[c] = std::thread([&, c]() {
             try {
                 HIPCHK(hipSetDevice(ix->device));
+                tls_lane = lane;
                 tls_stream = a.lean[c].st;
                 tls_tmp = &a.lean[c].tmp;
                 tls_arena = &ix->arena;
@@ -1913,13 +1935,15 @@ static void fmt_alignment(const std::vector<uint64_t> &ops, const uint8_t *q, co
 }
 
 static Work &get_work(lm_index *ix, lm_qbatch *qb) {
-    if (!ix->work) ix->work = new Work(ix, qb);
-    ix->work->rebind(qb);
-    return *ix->work;
+    Work *&wk = lane_work(ix);
+    if (!wk) wk = new Work(ix, qb);
+    wk->rebind(qb);
+    return *wk;
 }
 static AlignCtx &get_actx(lm_index *ix, lm_qbatch *qb, Work *w, lm_stage_stats *st, int slot = 0) {
-    if (!ix->actx[slot]) ix->actx[slot] = new AlignCtx();
-    AlignCtx &a = *ix->actx[slot];
+    AlignCtx **ac = lane_actx(ix);
+    if (!ac[slot]) ac[slot] = new AlignCtx();
+    AlignCtx &a = *ac[slot];
     a.ix = ix;
     a.qb = qb;
     a.w = w;
@@ -1935,8 +1959,8 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
     // windows of one alignment chunk: the chunk's pseudo-alignment anchors (~0.04 per window base, ~90 B of scratch each)
     // and its WFA launches scale with it; long alignments are latency-bound per problem, so few large chunks beat many
     // small ones (each chunk ends with a tail of a few 50-kb alignments running alone)
-    int64_t max_window_bytes = ix->scratch_budget > 0
-                                   ? std::min<int64_t>((int64_t)16 << 30, std::max<int64_t>((int64_t)1 << 30, ix->scratch_budget * 5 / 100))
+    int64_t max_window_bytes = BUDGET(ix) > 0
+                                   ? std::min<int64_t>((int64_t)16 << 30, std::max<int64_t>((int64_t)1 << 30, BUDGET(ix) * 5 / 100))
                                    : (int64_t)2 << 30;
     if (const char *e = getenv("LM_DEBUG_MAX_WINDOW_BYTES")) max_window_bytes = std::max<int64_t>(1, atoll(e)); // test hook
     const bool want_seq = ix->opt.output_seq != 0;
@@ -1959,20 +1983,22 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
     double ms_pseudo = 0;
     const int64_t total_window = r1 > r0 ? tasks_h[r1 - 1].woff + tasks_h[r1 - 1].wlen - tasks_h[r0].woff : 0;
     const bool pipelined = total_window > max_window_bytes && !getenv("LM_NO_PIPELINE");
+    const int lane = tls_lane;
     auto producer = [&]() {
         try {
             if (pipelined) {
                 HIPCHK(hipSetDevice(ix->device));
-                if (!ix->st2) HIPCHK(hipStreamCreate(&ix->st2));
-                tls_stream = ix->st2;
-                tls_tmp = &ix->tmp2;
+                tls_lane = lane;
+                if (!lane_st2(ix)) HIPCHK(hipStreamCreate(&lane_st2(ix)));
+                tls_stream = lane_st2(ix);
+                tls_tmp = &lane_tmp2(ix);
                 tls_arena = &ix->arena;
             }
             int64_t tpos = r0;
             int slot = 0;
             while (tpos < r1) {
-                if (ix->scratch_budget > 0 && *ctxs[0]->pa_ratio > 0) { // expected anchors within 80 % of the chunk's share
-                    const int64_t lim = (int64_t)((double)(ix->scratch_budget * 13 / 100) / 90.0 * 0.8 / *ctxs[0]->pa_ratio);
+                if (BUDGET(ix) > 0 && *ctxs[0]->pa_ratio > 0) { // expected anchors within 80 % of the chunk's share
+                    const int64_t lim = (int64_t)((double)(BUDGET(ix) * 13 / 100) / 90.0 * 0.8 / *ctxs[0]->pa_ratio);
                     if (!getenv("LM_DEBUG_MAX_WINDOW_BYTES")) max_window_bytes = std::min(max_window_bytes, std::max<int64_t>(lim, 1 << 20));
                 }
                 // chunk [tpos, tend): whole segments, bounded window bytes
@@ -2058,7 +2084,7 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
     std::vector<HspMeta> hsps; // of the current round
     size_t g0 = genomes.size(); // first genome of the current round
     int64_t gw_used = 0;        // bytes of the round's window buffer in use
-    const int64_t gw_target = ix->scratch_budget > 0 ? std::min<int64_t>((int64_t)6 << 30, std::max<int64_t>((int64_t)64 << 20, ix->scratch_budget * 3 / 100)) : (int64_t)1 << 30;
+    const int64_t gw_target = BUDGET(ix) > 0 ? std::min<int64_t>((int64_t)6 << 30, std::max<int64_t>((int64_t)64 << 20, BUDGET(ix) * 3 / 100)) : (int64_t)1 << 30;
     const int64_t round_hsps = getenv("LM_DEBUG_ROUND_HSPS") ? atoll(getenv("LM_DEBUG_ROUND_HSPS")) : 330000;
     const int64_t min_round_hsps = getenv("LM_DEBUG_MIN_ROUND_HSPS") ? atoll(getenv("LM_DEBUG_MIN_ROUND_HSPS")) : 150000;
     // ---- one extendMatch / WFA / finalisation round over the HSPs gathered from one or more chunks: the WFA launches end in
@@ -2074,7 +2100,7 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
         dbg_stamp("extendMatch / WFA round starts");
         if (getenv("LM_DEBUG"))
             fprintf(stderr, "[lm] mem: round of %lld HSPs starts with %.2f GB of scratch held (budget %.2f)\n", (long long)NH,
-                    (double)(g_dbuf_bytes.load() - ix->hbm_bytes) / 1e9, (double)ix->scratch_budget / 1e9);
+                    (double)(g_dbuf_bytes.load() - ix->hbm_bytes) / 1e9, (double)BUDGET(ix) / 1e9);
         std::vector<WfaOut> wout;
         std::vector<uint64_t> ops_h;
         std::vector<int64_t> ops_off_h;
@@ -2440,7 +2466,7 @@ struct SearchCtl {
 };
 
 static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res, const SearchCtl *ctl = nullptr) {
-    std::lock_guard<std::mutex> lock(ix->mu);
+    // the caller (search_parts) holds the handle's mutex and has set this thread's lane
     tune_malloc_once();
     lm_stage_stats &st = res->stats;
     memset(&st, 0, sizeof st);
@@ -2453,7 +2479,7 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res, const Searc
         hipStream_t ps = tls_stream;
         explicit TlsScope(lm_index *ix) {
             tls_arena = &ix->arena;
-            if (!tls_stream) tls_stream = ix->st;
+            if (!tls_stream) tls_stream = lane_st(ix);
         }
         ~TlsScope() {
             tls_arena = pa;
@@ -2462,11 +2488,11 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res, const Searc
     } tls_scope(ix);
     g_dbg_t0 = now_ms();
     dbg_stamp("search of a batch part starts");
-    if (ix->scratch_budget > 0) { // scratch of the previous part's alignment half (the halves alternate)
-        HIPCHK(hipDeviceSynchronize());
+    if (BUDGET(ix) > 0) { // scratch of the previous part's alignment half (the halves alternate)
+        HIPCHK(hipStreamSynchronize(S(ix))); // (every worker thread of the previous part synchronised its stream and was joined)
         int64_t freed = 0;
-        for (auto *c : ix->actx)
-            if (c) freed += c->release_big(ix->scratch_budget / 200);
+        for (int j = 0; j < 2; j++)
+            if (AlignCtx *c = lane_actx(ix)[j]) freed += c->release_big(BUDGET(ix) / 200);
         if (freed > 0 && getenv("LM_DEBUG"))
             fprintf(stderr, "[lm] alignment scratch of the previous part released: %.2f GB (arena: %.2f GB in slabs, %lld slab allocations so far)\n",
                     (double)freed / 1e9, (double)ix->arena.slab_bytes / 1e9, (long long)ix->arena.slab_allocs);
@@ -2585,13 +2611,13 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res, const Searc
     st.ms_window = t1 - t0;
     t0 = t1;
 
-    if (ix->scratch_budget > 0) {
+    if (BUDGET(ix) > 0) {
         const int64_t before = g_dbuf_bytes.load();
-        HIPCHK(hipDeviceSynchronize());
-        w.release_seeding(ix->scratch_budget / 200);
+        HIPCHK(hipStreamSynchronize(S(ix)));
+        w.release_seeding(BUDGET(ix) / 200);
         if (getenv("LM_DEBUG"))
             fprintf(stderr, "[lm] mem: seeding half held %.2f GB of scratch (budget %.2f), %.2f GB kept for the alignment half\n",
-                    (double)(before - ix->hbm_bytes) / 1e9, (double)ix->scratch_budget / 1e9,
+                    (double)(before - ix->hbm_bytes) / 1e9, (double)BUDGET(ix) / 1e9,
                     (double)(g_dbuf_bytes.load() - ix->hbm_bytes) / 1e9);
     }
     // ---- alignment half, in chunks of whole (query, genome) segments (align_range). Splitting it over two host
@@ -2750,9 +2776,8 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res, const Searc
 
 } // namespace lm
 
-// halves part `pi` of the batch (or the plain batch itself when `whole`): two new parts from the host copy of its bases
-static void split_part(lm_index *ix, lm_qbatch *top, size_t pi, bool whole) {
-    lm_qbatch *src = whole ? top : top->parts[pi];
+// two new batch parts from the host copy of the bases of `src` (a part, or the plain batch itself)
+static std::pair<lm_qbatch *, lm_qbatch *> halve_qbatch(lm_index *ix, lm_qbatch *src) {
     const size_t nq = (size_t)src->nq, h = nq / 2;
     if (nq < 2) throw HipError("one query yields more seed anchors than the device can hold");
     std::vector<lm_query> qs(nq);
@@ -2760,7 +2785,6 @@ static void split_part(lm_index *ix, lm_qbatch *top, size_t pi, bool whole) {
         qs[i].seq = src->h_seq.data() + src->h_qoff[i];
         qs[i].len = (uint32_t)(src->h_qoff[i + 1] - src->h_qoff[i]);
     }
-    std::lock_guard<std::mutex> lock(ix->mu);
     lm_qbatch *a = upload_part(ix, qs.data(), h, src->q0);
     lm_qbatch *b = nullptr;
     try {
@@ -2770,63 +2794,133 @@ static void split_part(lm_index *ix, lm_qbatch *top, size_t pi, bool whole) {
         throw;
     }
     if (getenv("LM_DEBUG")) fprintf(stderr, "[lm] batch part of %zu queries halved (seed anchors above the scratch budget)\n", nq);
-    if (whole) {
-        top->parts = {a, b};
-        top->d_seq.release(); // the plain batch's own device copy is no longer used
-        top->d_qoff.release();
-        top->d_posoff.release();
-        top->d_segoff.release();
-    } else {
-        delete src;
-        top->parts[pi] = a;
-        top->parts.insert(top->parts.begin() + pi + 1, b);
-    }
+    return {a, b};
 }
 
 extern "C" {
 
-// all parts of the caller's batch, in order; a part whose seed anchors outgrow the device is halved in place (the split
-// stays in the batch handle, so the next search of the same resident batch does not repeat it)
+// the scratch of the lane this thread works for goes back to the device (after an allocation failure)
 static void drop_scratch(lm_index *ix, const char *why) {
-    std::lock_guard<std::mutex> lock(ix->mu);
     (void)hipDeviceSynchronize();
-    delete ix->work;
-    ix->work = nullptr;
-    lm_free_align_ctx(ix);
-    ix->tmp.release();
-    ix->tmp2.release();
+    delete lane_work(ix);
+    lane_work(ix) = nullptr;
+    lm_free_align_ctx(ix, tls_lane);
+    lane_tmp(ix).release();
+    lane_tmp2(ix).release();
     ix->arena.trim();
-    if (getenv("LM_DEBUG")) fprintf(stderr, "[lm] device scratch dropped after: %s\n", why);
+    if (getenv("LM_DEBUG")) fprintf(stderr, "[lm] device scratch of lane %d dropped after: %s\n", tls_lane, why);
 }
+// All parts of the caller's batch, results in order.  A part whose seed anchors outgrow the device (or whose scratch
+// allocation fails) is halved in place; the split stays in the batch handle, so the next search of the same resident batch
+// does not repeat it.  A batch of several parts is searched on two lanes (two host threads, each with its own scratch,
+// streams and half of the scratch budget): the seeding and anchor kernels of one part (vector ALU, LDS, memory) run beside
+// the WFA launches of another (bound by the scalar unit), and the host work of one beside the kernels of the other.
 static void search_parts(lm_index *ix, lm_qbatch *qb, lm_result *res, const SearchCtl *ctl) {
+    std::lock_guard<std::mutex> lock(ix->mu); // one in-flight call per handle
+    HIPCHK(hipSetDevice(ix->device));
+    tls_lane = 0;
+    ix->active_lanes = 1;
     if (qb->parts.empty()) {
         try {
             search_impl(ix, qb, res, ctl);
             return;
         } catch (const PartTooLarge &) {
-            split_part(ix, qb, 0, true);
         } catch (const DeviceOOM &e) { // the shares of the scratch budget are estimates: retry on half the queries
             if (qb->nq < 2) throw;
             drop_scratch(ix, e.what());
-            split_part(ix, qb, 0, true);
         }
+        auto ab = halve_qbatch(ix, qb);
+        qb->parts = {ab.first, ab.second};
+        qb->d_seq.release(); // the plain batch's own device copy is no longer used
+        qb->d_qoff.release();
+        qb->d_posoff.release();
+        qb->d_segoff.release();
     }
-    memset(&res->stats, 0, sizeof res->stats);
-    for (size_t pi = 0; pi < qb->parts.size();) {
-        lm_qbatch *part = qb->parts[pi];
-        lm_result pr;
+    struct PartState {
+        lm_qbatch *part;
+        int state; // 0 pending, 1 running, 2 done
+        lm_result res;
+    };
+    std::list<PartState> todo;
+    for (lm_qbatch *p : qb->parts) {
+        todo.emplace_back();
+        todo.back().part = p;
+        todo.back().state = 0;
+    }
+    std::mutex lm_;
+    std::exception_ptr err;
+    // (opt-in: at the benchmark shapes the two lanes compete for the same LDS - the anchor filter keeps 112 KB per workgroup,
+    // the persistent WFA wavefronts fill the rest - and the step time is the same with one lane or two)
+    const int lanes = (ctl == nullptr && qb->parts.size() >= 2 && getenv("LM_TWO_LANES")) ? 2 : 1;
+    ix->active_lanes = lanes;
+    auto lane_fn = [&](int lane) {
+        tls_lane = lane;
+        hipStream_t saved_stream = tls_stream;
+        DBuf<uint8_t> *saved_tmp = tls_tmp;
         try {
-            search_impl(ix, part, &pr, ctl);
-        } catch (const PartTooLarge &) {
-            split_part(ix, qb, pi, false);
-            continue;
-        } catch (const DeviceOOM &e) {
-            if (part->nq < 2) throw;
-            drop_scratch(ix, e.what());
-            split_part(ix, qb, pi, false);
-            continue;
+            HIPCHK(hipSetDevice(ix->device));
+            if (!lane_st(ix)) HIPCHK(hipStreamCreate(&lane_st(ix)));
+            tls_stream = lane_st(ix);
+            tls_tmp = &lane_tmp(ix);
+            while (true) {
+                std::list<PartState>::iterator it;
+                {
+                    std::lock_guard<std::mutex> l(lm_);
+                    if (err) break;
+                    it = todo.begin();
+                    while (it != todo.end() && it->state != 0) ++it;
+                    if (it == todo.end()) break;
+                    it->state = 1;
+                }
+                bool split = false;
+                try {
+                    search_impl(ix, it->part, &it->res, ctl);
+                } catch (const PartTooLarge &) {
+                    split = true;
+                } catch (const DeviceOOM &e) {
+                    if (it->part->nq < 2) throw;
+                    drop_scratch(ix, e.what());
+                    split = true;
+                }
+                if (split) {
+                    auto ab = halve_qbatch(ix, it->part);
+                    std::lock_guard<std::mutex> l(lm_);
+                    delete it->part;
+                    it->part = ab.first; // this entry becomes the first half, the second half follows it
+                    it->state = 0;
+                    for (auto *str : it->res.strings) delete str;
+                    it->res.strings.clear();
+                    it->res.rows.clear();
+                    auto nx = std::next(it);
+                    auto ins = todo.emplace(nx);
+                    ins->part = ab.second;
+                    ins->state = 0;
+                } else {
+                    std::lock_guard<std::mutex> l(lm_);
+                    it->state = 2;
+                }
+            }
+        } catch (...) {
+            std::lock_guard<std::mutex> l(lm_);
+            if (!err) err = std::current_exception();
         }
-        for (auto &r : pr.rows) r.query += part->q0;
+        tls_stream = saved_stream;
+        tls_tmp = saved_tmp;
+        tls_lane = 0;
+    };
+    std::thread second;
+    if (lanes == 2) second = std::thread(lane_fn, 1);
+    lane_fn(0);
+    if (second.joinable()) second.join();
+    ix->active_lanes = 1;
+    // the (possibly finer) split stays with the batch handle
+    qb->parts.clear();
+    for (auto &ps : todo) qb->parts.push_back(ps.part);
+    if (err) std::rethrow_exception(err);
+    memset(&res->stats, 0, sizeof res->stats);
+    for (auto &ps : todo) {
+        lm_result &pr = ps.res;
+        for (auto &r : pr.rows) r.query += ps.part->q0;
         res->rows.insert(res->rows.end(), pr.rows.begin(), pr.rows.end());
         res->strings.insert(res->strings.end(), pr.strings.begin(), pr.strings.end());
         pr.strings.clear();
@@ -2836,7 +2930,6 @@ static void search_parts(lm_index *ix, lm_qbatch *qb, lm_result *res, const Sear
         const double *c = &pr.stats.ms_mask;
         double *d = &res->stats.ms_mask;
         for (int i = 0; i < 9; i++) d[i] += c[i];
-        pi++;
     }
 }
 
