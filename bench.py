@@ -119,6 +119,29 @@ def pmc_traffic(kernel, workload):
                                            "read part is a lower bound on gfx950" % workload)
 
 
+def pmc_issue(kernel, workload):
+    """instruction issue of `kernel` from the committed SQ pass of this workload and these sources
+    (profiles/r02_<workload>_pmc_sq.json): the WFA and anchor-filter kernels are bound by instruction issue (scalar + vector
+    ALU), not by HBM; a CU issues at most one vector and one scalar instruction per cycle (four SIMDs, a wavefront's vector
+    instruction occupies its SIMD for four cycles)"""
+    try:
+        doc = json.load(open(os.path.join(ROOT, "profiles", "r02_%s_pmc_sq.json" % workload)))
+    except (OSError, ValueError):
+        return None
+    if doc.get("source_hash") != source_hash():
+        return None
+    best = None
+    for k, v in doc.get("pmc", {}).items():
+        if "SQ_INSTS_VALU" in v and (kernel.startswith(k) or k.startswith(kernel)) and (best is None or len(k) > len(best[0])):
+            best = (k, v)
+    if best is None:
+        return None
+    v = best[1]
+    out = {c.lower() + "_per_launch": int(v[c]["mean"]) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS") if c in v}
+    out["note"] = "profiles/r02_%s_pmc_sq.json (kernels serialised by the counter pass)" % workload
+    return out
+
+
 def usable_cores():
     """cores this process may really use: the CPU count capped by the affinity mask and the cgroup quota"""
     n = os.cpu_count() or 1
@@ -445,7 +468,8 @@ def main():
                         frac=round(ach / HBM_PEAK_GBS, 6), traffic=tr, traffic_source=tn,
                         traffic_over_algorithmic=(round(tr / alg, 2) if tr and alg else None),
                         traffic_GBs=(round(tr / (avg_ms * 1e-3) / 1e9, 1) if tr else None),
-                        algorithmic_bytes_per_launch=int(alg), avg_launch_ms=round(avg_ms, 4), launches=pk["launches"])
+                        algorithmic_bytes_per_launch=int(alg), avg_launch_ms=round(avg_ms, 4), launches=pk["launches"],
+                        instruction_issue=pmc_issue(pk["name"], args.workload))
 
         roofline = roof(kern[0]) if kern else None
         # the HBM-bound stage of the path (north_star: seed lookup against the in-HBM index): the search kernel and the

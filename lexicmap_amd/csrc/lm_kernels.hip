@@ -628,7 +628,7 @@ __device__ __forceinline__ void pa_prefixes(const Task &t, const uint8_t *__rest
 #define PA_THREADS 1024
 #define PA_WAVES (PA_THREADS / 64)
 #define PA_GROUP 64  /* chain windows per workgroup pass */
-#define PA_STAGE 256 /* candidates a wavefront stages in LDS */
+#define PA_STAGE 320 /* candidates a wavefront stages in LDS */
 #define PA_SLICE 1920 /* window positions a wavefront takes at a time: their 2-bit genome words are one 8-byte load per lane */
 #define PA_LDS_BYTES ((1 << (LM_PA_BLOOM_LOG_MAX - 3)) + (1 << (LM_PA_MAP9_LOG - 3)) + PA_WAVES * PA_STAGE * 8)
 __global__ __launch_bounds__(PA_THREADS) void k_pa_filter(DevIndexView ix, const Task *__restrict__ tasks, int64_t ntasks,
@@ -638,8 +638,11 @@ __global__ __launch_bounds__(PA_THREADS) void k_pa_filter(DevIndexView ix, const
                                                            const uint32_t *__restrict__ cmp_bits,
                                                            const int64_t *__restrict__ bits_off,
                                                            const int32_t *__restrict__ bits_log, int K, int min_prefix,
-                                                           unsigned long long *__restrict__ cand_count, int64_t cand_cap,
-                                                           uint64_t *__restrict__ cand) {
+                                                           unsigned long long *__restrict__ seg_count, int nseg,
+                                                           int64_t seg_cap, uint64_t *__restrict__ cand) {
+    // the candidate list is kept as `nseg` segments of `seg_cap` entries with a counter each: a single counter is a single
+    // address in one L2 channel, and the ~10^6 appends of a launch (one per ~200 candidates) then queue up behind each other
+    // for longer than all the rest of the kernel takes
     extern __shared__ uint64_t pa_lds[];                               // PA_LDS_BYTES, dynamic (above 64 KB)
     uint64_t *s_stage = pa_lds;                                        // [PA_WAVES][PA_STAGE]
     uint32_t *s_bloom = (uint32_t *)(pa_lds + PA_WAVES * PA_STAGE);    // 64 KB
@@ -648,13 +651,15 @@ __global__ __launch_bounds__(PA_THREADS) void k_pa_filter(DevIndexView ix, const
     uint64_t *stg = s_stage + wave * PA_STAGE;
     int n_stg = 0; // wave-uniform
     const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
-    auto flush = [&]() { // this wavefront's staged candidates -> the global list
+    const int seg = (int)(((int64_t)blockIdx.x * PA_WAVES + wave) % nseg);
+    uint64_t *seg_list = cand + (int64_t)seg * seg_cap;
+    auto flush = [&]() { // this wavefront's staged candidates -> its segment of the global list
         if (n_stg == 0) return;
         unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(cand_count, (unsigned long long)n_stg);
+        if (lane == 0) base = atomicAdd(&seg_count[seg], (unsigned long long)n_stg);
         base = __shfl(base, 0, 64);
         for (int j = lane; j < n_stg; j += 64)
-            if ((int64_t)(base + (unsigned long long)j) < cand_cap) cand[base + (unsigned long long)j] = stg[j];
+            if ((int64_t)(base + (unsigned long long)j) < seg_cap) seg_list[base + (unsigned long long)j] = stg[j];
         n_stg = 0;
     };
     auto push = [&](bool c, uint64_t rec) { // all lanes of the wavefront
@@ -662,7 +667,7 @@ __global__ __launch_bounds__(PA_THREADS) void k_pa_filter(DevIndexView ix, const
         if (m == 0) return;
         if (c) stg[n_stg + __popcll(m & lt_mask)] = rec;
         n_stg += __popcll(m);
-        if (n_stg > PA_STAGE - 64) flush(); // LDS accesses of one wavefront complete in program order
+        if (n_stg > PA_STAGE - 128) flush(); // (room for the 128 of the two-strand append) LDS accesses of one wavefront complete in program order
     };
     // per group: the tasks' fields every wavefront needs (one round of dependent global loads for the whole group instead
     // of one per task and wavefront), then slices of PA_SLICE window positions handed out through an LDS counter, so the 16
@@ -763,10 +768,38 @@ __global__ __launch_bounds__(PA_THREADS) void k_pa_filter(DevIndexView ix, const
                         const uint32_t pf0 = t.rc ? rl : first, pf1 = t.rc ? first : rl;
                         const int i = t.rc ? p1 - 1 - r : p0 + r; // window position
                         const bool in = r < np;
-                        push(in && lm_pa_candidate2(s_bloom, blog, s_map9, qbits, log, pf0, p),
-                             rec_t | ((uint64_t)(uint32_t)i << 1));
-                        push(in && lm_pa_candidate2(s_bloom, blog, s_map9, qbits, log, pf1, p),
-                             rec_t | ((uint64_t)(uint32_t)i << 1) | 1ull);
+                        // lm_pa_candidate2 for both strands with the common case free of branches: two Bloom bits per
+                        // strand from LDS; the global 11-base bitmap (long reads) and the partial-prefix rule (bases [9, p)
+                        // all A: one k-mer in 16) are left to the few lanes that need them
+                        bool c0, c1;
+                        {
+                            const uint32_t a0 = pf0 >> ((p - LM_PFX_BASES) << 1), a1 = pf1 >> ((p - LM_PFX_BASES) << 1);
+                            const uint32_t s00 = lm_pa_bloom_slot(a0, 0, blog), s01 = lm_pa_bloom_slot(a0, 1, blog);
+                            const uint32_t s10 = lm_pa_bloom_slot(a1, 0, blog), s11 = lm_pa_bloom_slot(a1, 1, blog);
+                            const uint32_t b00 = s_bloom[s00 >> 5], b01 = s_bloom[s01 >> 5];
+                            const uint32_t b10 = s_bloom[s10 >> 5], b11 = s_bloom[s11 >> 5];
+                            const bool h0 = in && (((b00 >> (s00 & 31)) & (b01 >> (s01 & 31))) & 1u) != 0;
+                            const bool h1 = in && (((b10 >> (s10 & 31)) & (b11 >> (s11 & 31))) & 1u) != 0;
+                            const uint32_t m9p = (1u << ((p - 9) << 1)) - 1u;
+                            const bool q0 = in && !h0 && (pf0 & m9p) == 0, q1 = in && !h1 && (pf1 & m9p) == 0;
+                            c0 = h0;
+                            c1 = h1;
+                            if (log > blog ? __ballot(h0 || h1 || q0 || q1) != 0ull : __ballot(q0 || q1) != 0ull) {
+                                // the exact statement of the test for the lanes concerned (rare)
+                                if ((h0 && log > blog) || q0) c0 = lm_pa_candidate2(s_bloom, blog, s_map9, qbits, log, pf0, p);
+                                if ((h1 && log > blog) || q1) c1 = lm_pa_candidate2(s_bloom, blog, s_map9, qbits, log, pf1, p);
+                            }
+                        }
+                        // both strands appended with one reservation in the wavefront's strip
+                        const uint64_t m0 = __ballot(c0), m1 = __ballot(c1);
+                        if ((m0 | m1) != 0ull) {
+                            const int n0 = __popcll(m0);
+                            const uint64_t rec = rec_t | ((uint64_t)(uint32_t)i << 1);
+                            if (c0) stg[n_stg + __popcll(m0 & lt_mask)] = rec;
+                            if (c1) stg[n_stg + n0 + __popcll(m1 & lt_mask)] = rec | 1ull;
+                            n_stg += n0 + __popcll(m1);
+                            if (n_stg > PA_STAGE - 128) flush(); // LDS accesses of one wavefront complete in program order
+                        }
                     }
                 } else {
                     for (int tile = p0; tile < p1; tile += 64) {
@@ -797,8 +830,8 @@ __global__ __launch_bounds__(256) void k_pa_search(DevIndexView ix, const Task *
                                                     const uint32_t *__restrict__ cmp_tab,
                                                     const int64_t *__restrict__ tab_off,
                                                     const int32_t *__restrict__ tab_bits, int K, int min_prefix,
-                                                    const unsigned long long *__restrict__ cand_count, int64_t cand_cap,
-                                                    const uint64_t *__restrict__ cand,
+                                                    const unsigned long long *__restrict__ seg_count, int64_t seg_cap,
+                                                    int blocks_per_seg, const uint64_t *__restrict__ cand_all,
                                                     unsigned long long *__restrict__ count, int64_t cap,
                                                     uint64_t *__restrict__ outA, uint64_t *__restrict__ outB, int qbits,
                                                     int tbits) {
@@ -826,12 +859,14 @@ __global__ __launch_bounds__(256) void k_pa_search(DevIndexView ix, const Task *
         }
         n_stg = 0;
     };
-    int64_t nc = (int64_t)*cand_count;
-    if (nc > cand_cap) nc = cand_cap; // the host re-runs both kernels with a larger list
+    const int seg = blockIdx.x / blocks_per_seg, sub = blockIdx.x % blocks_per_seg; // blocks_per_seg blocks share a segment
+    const uint64_t *cand = cand_all + (int64_t)seg * seg_cap;
+    int64_t nc = (int64_t)seg_count[seg];
+    if (nc > seg_cap) nc = seg_cap; // the host re-runs both kernels with a larger list
     const int sh_t = 2, sh_l = 2 + tbits, sh_q = 8 + tbits, sh_a = 8 + tbits + qbits;
     const uint64_t ccc = lm_ns(1, K), ggg = lm_ns(2, K), ttt = lm_kmer_mask(K);
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < nc; base += stride) { // whole wavefronts stay together
+    const int64_t stride = (int64_t)blocks_per_seg * blockDim.x;
+    for (int64_t base = (int64_t)sub * blockDim.x; base < nc; base += stride) { // whole wavefronts stay together
         const int64_t ci = base + threadIdx.x;
         int j = 0, hi = 0, i = 0;
         bool rcs = false;
@@ -2436,7 +2471,7 @@ void launch_build_cmp_bits(hipStream_t st, const uint64_t *keys_cmp, const int64
 }
 void launch_pa_filter(hipStream_t st, DevIndexView ix, const Task *tasks, int64_t ntasks, const uint8_t *wbuf,
                       const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_bits, const int64_t *bits_off,
-                      const int32_t *bits_log, int K, int min_prefix, unsigned long long *cand_count, int64_t cand_cap,
+                      const int32_t *bits_log, int K, int min_prefix, unsigned long long *seg_count, int nseg, int64_t seg_cap,
                       uint64_t *cand) {
     const int64_t ngroups = (ntasks + PA_GROUP - 1) / PA_GROUP;
     int g = (int)(ngroups < 1 ? 1 : (ngroups > 1048576 ? 1048576 : ngroups));
@@ -2446,19 +2481,19 @@ void launch_pa_filter(hipStream_t st, DevIndexView ix, const Task *tasks, int64_
         lds_set = true;
     }
     hipLaunchKernelGGL(k_pa_filter, dim3(g), dim3(PA_THREADS), PA_LDS_BYTES, st, ix, tasks, ntasks, wbuf, posoff, nvalid,
-                       cmp_bits, bits_off, bits_log, K, min_prefix, cand_count, cand_cap, cand);
+                       cmp_bits, bits_off, bits_log, K, min_prefix, seg_count, nseg, seg_cap, cand);
 }
 void launch_pa_search(hipStream_t st, DevIndexView ix, const Task *tasks, const uint8_t *wbuf, const uint64_t *keys_cmp,
                       const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_tab,
                       const int64_t *tab_off, const int32_t *tab_bits, int K, int min_prefix,
-                      const unsigned long long *cand_count, int64_t cand_cap, const uint64_t *cand,
+                      const unsigned long long *seg_count, int nseg, int64_t seg_cap, const uint64_t *cand,
                       unsigned long long *count, int64_t cap, uint64_t *outA, uint64_t *outB, int qbits, int tbits) {
-    // the candidate count is only known on the device: a grid that fills the chip, striding over the list
-    int64_t gs = (cand_cap + 255) / 256;
-    if (gs > 256 * 32) gs = 256 * 32;
-    if (gs < 1) gs = 1;
-    hipLaunchKernelGGL(k_pa_search, dim3((int)gs), dim3(256), 0, st, ix, tasks, wbuf, keys_cmp, vals_cmp, posoff, nvalid, cmp_tab,
-                       tab_off, tab_bits, K, min_prefix, cand_count, cand_cap, cand, count, cap, outA, outB, qbits, tbits);
+    // the candidate counts are only known on the device: a grid that fills the chip, a fixed number of blocks per segment
+    int bps = (256 * 32 + nseg - 1) / nseg;
+    const int64_t need = (seg_cap + 255) / 256;
+    if (bps > need) bps = (int)(need < 1 ? 1 : need);
+    hipLaunchKernelGGL(k_pa_search, dim3(nseg * bps), dim3(256), 0, st, ix, tasks, wbuf, keys_cmp, vals_cmp, posoff, nvalid, cmp_tab,
+                       tab_off, tab_bits, K, min_prefix, seg_count, seg_cap, bps, cand, count, cap, outA, outB, qbits, tbits);
 }
 void launch_pa_task_off_sorted(hipStream_t st, const uint64_t *sortedA, int shift, int64_t total, int64_t ntasks,
                                int64_t *pa_off) {
@@ -2506,6 +2541,7 @@ int wfa_resident_blocks(int device, int seq_words, int nc) {
     return resident_blocks_of(nc == 16  ? (const void *)k_wfa_lean<16>
                               : nc == 8 ? (const void *)k_wfa_lean<8>
                               : nc == 4 ? (const void *)k_wfa_lean<4>
+                              : nc == 1 ? (const void *)k_wfa_lean<1>
                                         : (const void *)k_wfa_lean<2>,
                               device, seq_words);
 }
@@ -2522,6 +2558,9 @@ void launch_wfa(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo,
                            arena_stride, ops_pool, queue, seq_words, want_ops, out);
     else if (nc == 4)
         hipLaunchKernelGGL(k_wfa_lean<4>, dim3(nblocks), dim3(64), dyn, st, in, n, todo, ntodo, hdr_pool, hdr_stride, arena_pool,
+                           arena_stride, ops_pool, queue, seq_words, want_ops, out);
+    else if (nc == 1)
+        hipLaunchKernelGGL(k_wfa_lean<1>, dim3(nblocks), dim3(64), dyn, st, in, n, todo, ntodo, hdr_pool, hdr_stride, arena_pool,
                            arena_stride, ops_pool, queue, seq_words, want_ops, out);
     else
         hipLaunchKernelGGL(k_wfa_lean<2>, dim3(nblocks), dim3(64), dyn, st, in, n, todo, ntodo, hdr_pool, hdr_stride, arena_pool,

@@ -1402,7 +1402,7 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
     const int key_bits = abits + qbits + 6 + tbits + 2, sh_a = qbits + 6 + tbits + 2;
     // single pass: anchors appended to (A0, B0) in arbitrary order; the buffer size is a running estimate, the kernel
     // counts past it, so an undersized buffer costs one re-run
-    a.pa_count.ensure(2);
+    a.pa_count.ensure(1 + LM_PA_MAX_SEGS);
     if (a.pa_cap < (int64_t)1 << 20) a.pa_cap = std::max<int64_t>((int64_t)1 << 20, W / 8);
     if (const char *e = getenv("LM_DEBUG_PA_CAP")) a.pa_cap = std::max<int64_t>(1, atoll(e)); // test hook: force the re-run
     int64_t TP = 0;
@@ -1410,34 +1410,40 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
         if (!compact) a.A0.ensure((size_t)a.pa_cap);
         a.B0.ensure((size_t)a.pa_cap);
         a.B1.ensure((size_t)a.pa_cap); // the sort's second buffer holds the candidate list of k_pa_filter until then
-        HIPCHK(hipMemsetAsync(a.pa_count.p, 0, 2 * sizeof(unsigned long long), S(ix)));
+        // the candidate list in segments with a counter each (k_pa_filter), at least 4096 entries per segment
+        const int nseg = (int)std::max<int64_t>(1, std::min<int64_t>(LM_PA_MAX_SEGS, a.pa_cap / 4096));
+        const int64_t seg_cap = a.pa_cap / nseg;
+        HIPCHK(hipMemsetAsync(a.pa_count.p, 0, (size_t)(1 + nseg) * sizeof(unsigned long long), S(ix)));
         {
             Prof p(ix, "k_pa_filter", W);
             launch_pa_filter(S(ix), ix->view, tasks_d, nt, a.wb, qb->d_posoff.p, a.w->nvalid.p, a.w->cmp_bits.p,
-                             qb->d_bits_off.p, qb->d_bits_log.p, ix->host.k, 11, a.pa_count.p, a.pa_cap, a.B1.p);
+                             qb->d_bits_off.p, qb->d_bits_log.p, ix->host.k, 11, a.pa_count.p + 1, nseg, seg_cap, a.B1.p);
         }
         {
             Prof p(ix, "k_pa_search");
             launch_pa_search(S(ix), ix->view, tasks_d, a.wb, a.w->k_cmp, a.w->v_cmp, qb->d_posoff.p, a.w->nvalid.p,
-                             a.w->cmp_tab.p, qb->d_tab_off.p, qb->d_tab_bits.p, ix->host.k, 11, a.pa_count.p, a.pa_cap, a.B1.p,
-                             a.pa_count.p + 1, a.pa_cap,
-                             a.A0.p, a.B0.p, compact ? qbits : 0, compact ? tbits : 0);
+                             a.w->cmp_tab.p, qb->d_tab_off.p, qb->d_tab_bits.p, ix->host.k, 11, a.pa_count.p + 1, nseg, seg_cap,
+                             a.B1.p, a.pa_count.p, a.pa_cap, a.A0.p, a.B0.p, compact ? qbits : 0, compact ? tbits : 0);
         }
-        unsigned long long hv[2] = {0, 0};
-        HIPCHK(hipMemcpyAsync(hv, a.pa_count.p, sizeof hv, hipMemcpyDeviceToHost, S(ix)));
+        std::vector<unsigned long long> hv((size_t)1 + nseg);
+        HIPCHK(hipMemcpyAsync(hv.data(), a.pa_count.p, hv.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, S(ix)));
         sync(ix);
-        TP = (int64_t)hv[1];
+        TP = (int64_t)hv[0];
+        int64_t ncand = 0, seg_max = 0;
+        for (int j = 0; j < nseg; j++) {
+            ncand += (int64_t)hv[1 + j];
+            seg_max = std::max<int64_t>(seg_max, (int64_t)hv[1 + j]);
+        }
         dbg_stamp("pseudo-alignment anchors of a chunk done");
         if (getenv("LM_DEBUG"))
-            fprintf(stderr, "[lm] pseudo-alignment: %lld window bases, %lld candidates, %lld anchors\n", (long long)W,
-                    (long long)hv[0], (long long)TP);
-        const int64_t need = std::max<int64_t>((int64_t)hv[0], TP); // candidates and anchors share the estimate
-        if (need <= a.pa_cap) break;
-        if (attempt > 3) throw HipError("pseudo-alignment anchor buffer keeps overflowing");
-        a.pa_cap = need + need / 8;
+            fprintf(stderr, "[lm] pseudo-alignment: %lld window bases, %lld candidates (fullest of %d segments: %lld of %lld), %lld anchors\n",
+                    (long long)W, (long long)ncand, nseg, (long long)seg_max, (long long)seg_cap, (long long)TP);
+        // candidates and anchors share the estimate; a segment that overflowed dropped candidates: size for the fullest
+        const int64_t need = std::max<int64_t>(seg_max > seg_cap ? seg_max * nseg + seg_max * nseg / 8 : ncand, TP);
+        if (need <= a.pa_cap && seg_max <= seg_cap) break;
+        if (attempt > 4) throw HipError("pseudo-alignment anchor buffer keeps overflowing");
+        a.pa_cap = std::max<int64_t>(need + need / 8, a.pa_cap + a.pa_cap / 4);
     }
-    // too many anchors for one chunk (31-bit indices, ~90 B of scratch each within 13 % of the budget - two chunks are in
-    // flight): the caller halves the chunk
     // anchors per window byte of what has been seen (sizes the next chunks so that they need no halving); small chunks
     // (the odd tasks left behind a halving) say little
     if (W > ((int64_t)64 << 20)) *a.pa_ratio = std::max(*a.pa_ratio * 0.9, (double)TP / (double)W);
@@ -1690,7 +1696,13 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
         const double dv = est_div ? (double)(*est_div)[i] : 0.12;
         cs[c] = std::max<int64_t>(cs[c], (int64_t)(5.0 * (dv + 0.01) * (double)L) + 2048);
     }
-    const int first_nc[4] = {2, 2, 4, 8};
+    int first_nc[4] = {2, 2, 4, 8};
+    if (const char *e = getenv("LM_WFA_FIRST_NC")) { // experiment hook: starting widths of the four classes, e.g. "1,1,4,8"
+        int v[4];
+        if (sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4)
+            for (int c = 0; c < 4; c++)
+                if (v[c] == 1 || v[c] == 2 || v[c] == 4 || v[c] == 8 || v[c] == 16) first_nc[c] = v[c];
+    }
     // scratch of the four classes side by side: what each would like (resident wavefronts x expected backtrace bytes of its
     // longest problem), scaled down together when that exceeds the lean share of the budget
     int64_t want[4], share[4];
@@ -1731,7 +1743,7 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
         HIPCHK(hipMemcpyAsync(lc.todo.p, items.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice, S(ix)));
         HIPCHK(hipMemsetAsync(lc.queue.p, 0, sizeof(unsigned int), S(ix)));
         {
-            Prof p(ix, nc == 16 ? "k_wfa_lean1024" : nc == 8 ? "k_wfa_lean512" : nc == 4 ? "k_wfa_lean256" : "k_wfa_lean",
+            Prof p(ix, nc == 16 ? "k_wfa_lean1024" : nc == 8 ? "k_wfa_lean512" : nc == 4 ? "k_wfa_lean256" : nc == 1 ? "k_wfa_lean64" : "k_wfa_lean",
                    wfa_bytes(in, items));
             launch_wfa(S(ix), a.wfa_in.p, n, lc.todo.p, m, nblocks, lc.hdr_pool.p, entries * 2, (uint8_t *)lc.arena_pool.p, bytes,
                        a.ops_pool.p, lc.queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc);
