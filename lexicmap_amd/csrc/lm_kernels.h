@@ -112,7 +112,7 @@ void launch_build_cmp_bits(hipStream_t st, const uint64_t *keys_cmp, const int64
 void launch_pa_filter(hipStream_t st, DevIndexView ix, const Task *tasks, int64_t ntasks, const uint8_t *wbuf,
                       const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_bits, const int64_t *bits_off,
                       const int32_t *bits_log, int K, int min_prefix, unsigned long long *seg_count, int nseg, int64_t seg_cap,
-                      uint64_t *cand);
+                      uint64_t *cand, unsigned long long *group_counter, int ncu);
 void launch_pa_search(hipStream_t st, DevIndexView ix, const Task *tasks, const uint8_t *wbuf, const uint64_t *keys_cmp,
                       const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_tab,
                       const int64_t *tab_off, const int32_t *tab_bits, int K, int min_prefix,

@@ -628,9 +628,10 @@ __device__ __forceinline__ void pa_prefixes(const Task &t, const uint8_t *__rest
 #define PA_THREADS 1024
 #define PA_WAVES (PA_THREADS / 64)
 #define PA_GROUP 64  /* chain windows per workgroup pass */
-#define PA_STAGE 320 /* candidates a wavefront stages in LDS */
+#define PA_STAGE 192 /* candidates a wavefront stages in LDS */
 #define PA_SLICE 1920 /* window positions a wavefront takes at a time: their 2-bit genome words are one 8-byte load per lane */
-#define PA_LDS_BYTES ((1 << (LM_PA_BLOOM_LOG_MAX - 3)) + (1 << (LM_PA_MAP9_LOG - 3)) + PA_WAVES * PA_STAGE * 8)
+#define PA_PEND 128 /* positions a wavefront sets aside for the global bitmap: examined whenever 64 have gathered */
+#define PA_LDS_BYTES ((1 << (LM_PA_BLOOM_LOG_MAX - 3)) + (1 << (LM_PA_MAP9_LOG - 3)) + PA_WAVES * PA_STAGE * 8 + PA_WAVES * PA_PEND * 12)
 __global__ __launch_bounds__(PA_THREADS) void k_pa_filter(DevIndexView ix, const Task *__restrict__ tasks, int64_t ntasks,
                                                            const uint8_t *__restrict__ wbuf,
                                                            const int64_t *__restrict__ posoff,
@@ -639,7 +640,8 @@ __global__ __launch_bounds__(PA_THREADS) void k_pa_filter(DevIndexView ix, const
                                                            const int64_t *__restrict__ bits_off,
                                                            const int32_t *__restrict__ bits_log, int K, int min_prefix,
                                                            unsigned long long *__restrict__ seg_count, int nseg,
-                                                           int64_t seg_cap, uint64_t *__restrict__ cand) {
+                                                           int64_t seg_cap, uint64_t *__restrict__ cand,
+                                                           unsigned long long *__restrict__ group_counter) {
     // the candidate list is kept as `nseg` segments of `seg_cap` entries with a counter each: a single counter is a single
     // address in one L2 channel, and the ~10^6 appends of a launch (one per ~200 candidates) then queue up behind each other
     // for longer than all the rest of the kernel takes
@@ -647,6 +649,8 @@ __global__ __launch_bounds__(PA_THREADS) void k_pa_filter(DevIndexView ix, const
     uint64_t *s_stage = pa_lds;                                        // [PA_WAVES][PA_STAGE]
     uint32_t *s_bloom = (uint32_t *)(pa_lds + PA_WAVES * PA_STAGE);    // 64 KB
     uint32_t *s_map9 = s_bloom + (1 << (LM_PA_BLOOM_LOG_MAX - 5));     // 32 KB
+    uint64_t *s_pend_rec = (uint64_t *)(s_map9 + (1 << (LM_PA_MAP9_LOG - 5))); // [PA_WAVES][PA_PEND]
+    uint32_t *s_pend_pf = (uint32_t *)(s_pend_rec + PA_WAVES * PA_PEND);        // [PA_WAVES][PA_PEND]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint64_t *stg = s_stage + wave * PA_STAGE;
     int n_stg = 0; // wave-uniform
@@ -669,6 +673,37 @@ __global__ __launch_bounds__(PA_THREADS) void k_pa_filter(DevIndexView ix, const
         n_stg += __popcll(m);
         if (n_stg > PA_STAGE - 128) flush(); // (room for the 128 of the two-strand append) LDS accesses of one wavefront complete in program order
     };
+    // pending list of the wavefront (long reads): first p bases (+ p) and the candidate record of the positions whose test
+    // needs the global 11-base bitmap; a full 64 are examined at once.  log / blog / qbits belong to the run of one query:
+    // the list is emptied before the run ends.
+    uint32_t *pend_pf = s_pend_pf + wave * PA_PEND;
+    uint64_t *pend_rec = s_pend_rec + wave * PA_PEND;
+    int n_pend = 0; // wave-uniform
+    const uint32_t *cur_qbits = nullptr;
+    int cur_log = 0, cur_blog = 0;
+    auto pend_round = [&](int cnt) { // the last `cnt` (<= 64) pending entries
+        const int idx = n_pend - cnt + lane;
+        bool c = false;
+        uint64_t rec = 0;
+        if (lane < cnt) {
+            const uint32_t e = pend_pf[idx];
+            rec = pend_rec[idx];
+            c = lm_pa_candidate2(s_bloom, cur_blog, s_map9, cur_qbits, cur_log, e & 0x3fffffffu, LM_PFX_BASES + 2 * (int)(e >> 30));
+        }
+        n_pend -= cnt;
+        push(c, rec);
+    };
+    auto pend = [&](bool c, uint32_t e, uint64_t rec) { // all lanes of the wavefront
+        const uint64_t m = __ballot(c);
+        if (m == 0) return;
+        if (c) {
+            const int slot = n_pend + __popcll(m & lt_mask);
+            pend_pf[slot] = e;
+            pend_rec[slot] = rec;
+        }
+        n_pend += __popcll(m);
+        while (n_pend >= 64) pend_round(64);
+    };
     // per group: the tasks' fields every wavefront needs (one round of dependent global loads for the whole group instead
     // of one per task and wavefront), then slices of PA_SLICE window positions handed out through an LDS counter, so the 16
     // wavefronts are in different windows at different stages and hide each other's genome-load latency
@@ -676,8 +711,17 @@ __global__ __launch_bounds__(PA_THREADS) void k_pa_filter(DevIndexView ix, const
     __shared__ int32_t s_first[PA_GROUP + 1]; // first slice of every task of the current run of one query
     __shared__ int64_t s_goff[PA_GROUP], s_bits[PA_GROUP], s_woff[PA_GROUP];
     __shared__ int s_next;
+    // persistent workgroups (one per CU: the 140 KB of LDS allow no second one) that take the groups from a global counter:
+    // a workgroup per group left the CUs empty most of the time, between the end of one 16-wavefront workgroup and the
+    // start of the next
+    __shared__ unsigned long long s_grp;
     const int64_t ngroups = (ntasks + PA_GROUP - 1) / PA_GROUP;
-    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    while (true) {
+        __syncthreads(); // the previous group is finished (tables, s_grp)
+        if (tid == 0) s_grp = atomicAdd(group_counter, 1ull);
+        __syncthreads();
+        const int64_t grp = (int64_t)s_grp;
+        if (grp >= ngroups) break;
         const int64_t t0g = grp * PA_GROUP;
         const int ng = (int)((ntasks < t0g + PA_GROUP ? ntasks : t0g + PA_GROUP) - t0g);
         __syncthreads(); // the previous group is finished with the tables
@@ -701,6 +745,9 @@ __global__ __launch_bounds__(PA_THREADS) void k_pa_filter(DevIndexView ix, const
             while (r1 < ng && s_q[r1] == s_q[r0]) r1++;
             const int log = s_log[r0], blog = lm_pa_bloom_log(log);
             const uint32_t *qbits = s_bits[r0] >= 0 ? cmp_bits + s_bits[r0] : nullptr;
+            cur_qbits = qbits;
+            cur_log = log;
+            cur_blog = blog;
             // this query's LDS maps (K >= 16 and a query with maps: the fast path exists for some window of it)
             if (qbits != nullptr && K >= 16) {
                 const uint32_t *gbl = qbits + lm_pa_bloom_word0(log), *g9 = qbits + lm_pa_map9_word0(log);
@@ -784,10 +831,20 @@ __global__ __launch_bounds__(PA_THREADS) void k_pa_filter(DevIndexView ix, const
                             const bool q0 = in && !h0 && (pf0 & m9p) == 0, q1 = in && !h1 && (pf1 & m9p) == 0;
                             c0 = h0;
                             c1 = h1;
-                            if (log > blog ? __ballot(h0 || h1 || q0 || q1) != 0ull : __ballot(q0 || q1) != 0ull) {
-                                // the exact statement of the test for the lanes concerned (rare)
-                                if ((h0 && log > blog) || q0) c0 = lm_pa_candidate2(s_bloom, blog, s_map9, qbits, log, pf0, p);
-                                if ((h1 && log > blog) || q1) c1 = lm_pa_candidate2(s_bloom, blog, s_map9, qbits, log, pf1, p);
+                            if (log > blog) {
+                                // long reads: what the Bloom filter lets through must ask the 11-base bitmap in global
+                                // memory.  Asked where it arises, nearly every pass of the loop would stall on that load
+                                // for the sake of a handful of lanes; the lanes concerned are set aside in the wavefront's
+                                // pending list instead and examined 64 at a time (one load for 64 useful lanes)
+                                c0 = c1 = false;
+                                const uint64_t rec = rec_t | ((uint64_t)(uint32_t)i << 1);
+                                const uint32_t pcode = (uint32_t)((p - LM_PFX_BASES) >> 1) << 30; // p = 11, 13 or 15
+                                pend(h0 || q0, pf0 | pcode, rec);
+                                pend(h1 || q1, pf1 | pcode, rec | 1ull);
+                            } else if (__ballot(q0 || q1) != 0ull) {
+                                // the partial-prefix rule, all in LDS here (rare lanes)
+                                if (q0) c0 = lm_pa_candidate2(s_bloom, blog, s_map9, qbits, log, pf0, p);
+                                if (q1) c1 = lm_pa_candidate2(s_bloom, blog, s_map9, qbits, log, pf1, p);
                             }
                         }
                         // both strands appended with one reservation in the wavefront's strip
@@ -814,6 +871,7 @@ __global__ __launch_bounds__(PA_THREADS) void k_pa_filter(DevIndexView ix, const
                     }
                 }
             }
+            if (n_pend > 0) pend_round(n_pend); // (n_pend < 64 here)
             __syncthreads(); // everybody is done with this query's maps and the slice table
             r0 = r1;
         }
@@ -2472,16 +2530,16 @@ void launch_build_cmp_bits(hipStream_t st, const uint64_t *keys_cmp, const int64
 void launch_pa_filter(hipStream_t st, DevIndexView ix, const Task *tasks, int64_t ntasks, const uint8_t *wbuf,
                       const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_bits, const int64_t *bits_off,
                       const int32_t *bits_log, int K, int min_prefix, unsigned long long *seg_count, int nseg, int64_t seg_cap,
-                      uint64_t *cand) {
+                      uint64_t *cand, unsigned long long *group_counter, int ncu) {
     const int64_t ngroups = (ntasks + PA_GROUP - 1) / PA_GROUP;
-    int g = (int)(ngroups < 1 ? 1 : (ngroups > 1048576 ? 1048576 : ngroups));
+    int g = (int)(ngroups < 1 ? 1 : (ngroups > ncu ? ncu : ngroups));
     static bool lds_set = false;
     if (!lds_set) {
         (void)hipFuncSetAttribute((const void *)k_pa_filter, hipFuncAttributeMaxDynamicSharedMemorySize, PA_LDS_BYTES);
         lds_set = true;
     }
     hipLaunchKernelGGL(k_pa_filter, dim3(g), dim3(PA_THREADS), PA_LDS_BYTES, st, ix, tasks, ntasks, wbuf, posoff, nvalid,
-                       cmp_bits, bits_off, bits_log, K, min_prefix, seg_count, nseg, seg_cap, cand);
+                       cmp_bits, bits_off, bits_log, K, min_prefix, seg_count, nseg, seg_cap, cand, group_counter);
 }
 void launch_pa_search(hipStream_t st, DevIndexView ix, const Task *tasks, const uint8_t *wbuf, const uint64_t *keys_cmp,
                       const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_tab,

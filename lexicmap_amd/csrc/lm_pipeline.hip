@@ -54,6 +54,15 @@ static inline DBuf<uint8_t> &lane_tmp(lm_index *ix) { return tls_lane ? ix->tmp_
 static inline DBuf<uint8_t> &lane_tmp2(lm_index *ix) { return tls_lane ? ix->tmp2_b : ix->tmp2; }
 // the scratch budget of the lane this thread works for
 static inline int64_t BUDGET(lm_index *ix) { return ix->scratch_budget > 0 ? ix->scratch_budget / ix->active_lanes : ix->scratch_budget; }
+static int device_cus(int device) {
+    static int cus[64] = {0};
+    if (device < 0 || device >= 64) return 256;
+    if (!cus[device]) {
+        hipDeviceProp_t p;
+        cus[device] = hipGetDeviceProperties(&p, device) == hipSuccess && p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+    }
+    return cus[device];
+}
 static double g_dbg_t0 = 0; // LM_DEBUG: start of the running search (time stamps of the debug lines)
 static inline void dbg_stamp(const char *what) {
     if (getenv("LM_DEBUG")) fprintf(stderr, "[lm +%.1f ms] %s\n", now_ms() - g_dbg_t0, what);
@@ -1402,7 +1411,7 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
     const int key_bits = abits + qbits + 6 + tbits + 2, sh_a = qbits + 6 + tbits + 2;
     // single pass: anchors appended to (A0, B0) in arbitrary order; the buffer size is a running estimate, the kernel
     // counts past it, so an undersized buffer costs one re-run
-    a.pa_count.ensure(1 + LM_PA_MAX_SEGS);
+    a.pa_count.ensure(2 + LM_PA_MAX_SEGS); // anchors, the filter's group counter, candidates per segment
     if (a.pa_cap < (int64_t)1 << 20) a.pa_cap = std::max<int64_t>((int64_t)1 << 20, W / 8);
     if (const char *e = getenv("LM_DEBUG_PA_CAP")) a.pa_cap = std::max<int64_t>(1, atoll(e)); // test hook: force the re-run
     int64_t TP = 0;
@@ -1413,26 +1422,27 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
         // the candidate list in segments with a counter each (k_pa_filter), at least 4096 entries per segment
         const int nseg = (int)std::max<int64_t>(1, std::min<int64_t>(LM_PA_MAX_SEGS, a.pa_cap / 4096));
         const int64_t seg_cap = a.pa_cap / nseg;
-        HIPCHK(hipMemsetAsync(a.pa_count.p, 0, (size_t)(1 + nseg) * sizeof(unsigned long long), S(ix)));
+        HIPCHK(hipMemsetAsync(a.pa_count.p, 0, (size_t)(2 + nseg) * sizeof(unsigned long long), S(ix)));
         {
             Prof p(ix, "k_pa_filter", W);
             launch_pa_filter(S(ix), ix->view, tasks_d, nt, a.wb, qb->d_posoff.p, a.w->nvalid.p, a.w->cmp_bits.p,
-                             qb->d_bits_off.p, qb->d_bits_log.p, ix->host.k, 11, a.pa_count.p + 1, nseg, seg_cap, a.B1.p);
+                             qb->d_bits_off.p, qb->d_bits_log.p, ix->host.k, 11, a.pa_count.p + 2, nseg, seg_cap, a.B1.p,
+                             a.pa_count.p + 1, device_cus(ix->device));
         }
         {
             Prof p(ix, "k_pa_search");
             launch_pa_search(S(ix), ix->view, tasks_d, a.wb, a.w->k_cmp, a.w->v_cmp, qb->d_posoff.p, a.w->nvalid.p,
-                             a.w->cmp_tab.p, qb->d_tab_off.p, qb->d_tab_bits.p, ix->host.k, 11, a.pa_count.p + 1, nseg, seg_cap,
+                             a.w->cmp_tab.p, qb->d_tab_off.p, qb->d_tab_bits.p, ix->host.k, 11, a.pa_count.p + 2, nseg, seg_cap,
                              a.B1.p, a.pa_count.p, a.pa_cap, a.A0.p, a.B0.p, compact ? qbits : 0, compact ? tbits : 0);
         }
-        std::vector<unsigned long long> hv((size_t)1 + nseg);
+        std::vector<unsigned long long> hv((size_t)2 + nseg);
         HIPCHK(hipMemcpyAsync(hv.data(), a.pa_count.p, hv.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, S(ix)));
         sync(ix);
         TP = (int64_t)hv[0];
         int64_t ncand = 0, seg_max = 0;
         for (int j = 0; j < nseg; j++) {
-            ncand += (int64_t)hv[1 + j];
-            seg_max = std::max<int64_t>(seg_max, (int64_t)hv[1 + j]);
+            ncand += (int64_t)hv[2 + j];
+            seg_max = std::max<int64_t>(seg_max, (int64_t)hv[2 + j]);
         }
         dbg_stamp("pseudo-alignment anchors of a chunk done");
         if (getenv("LM_DEBUG"))
