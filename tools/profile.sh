@@ -34,5 +34,5 @@ python $R/tools/summarize_rocprof.py /tmp/prof_f $R/gpurun_out/r02_${W}_pmc_fetc
 timeout 1500 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_w -o w -- python $R/bench.py --workload $W --steps 1 --warmup 0 --no-cpu-baseline $EXTRA > /tmp/prof_w.log 2>&1
 python $R/tools/summarize_rocprof.py /tmp/prof_w $R/gpurun_out/r02_${W}_pmc_write.json $H "rocprofv3 --pmc WRITE_SIZE -- python bench.py --workload $W --steps 1 --warmup 0 --no-cpu-baseline $EXTRA" | tail -12
 timeout 1500 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d /tmp/prof_sq -o sq -- python $R/bench.py --workload $W --steps 1 --warmup 0 --no-cpu-baseline $EXTRA > /tmp/prof_sq.log 2>&1
-python $R/tools/summarize_rocprof.py /tmp/prof_sq $R/gpurun_out/r02_${W}_pmc_sq.json $H "rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -- python bench.py --workload $W --steps 1 --warmup 0 --no-cpu-baseline $EXTRA" | grep -E "^k_(wfa|pa_|extend|lookup)"
+python $R/tools/summarize_rocprof.py /tmp/prof_sq $R/gpurun_out/r02_${W}_pmc_sq.json $H "rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -- python bench.py --workload $W --steps 1 --warmup 0 --no-cpu-baseline $EXTRA" | grep -E "^k_(wfa|pa_|extend|lookup|chain)"
 tail -n 2 /tmp/prof_f.log /tmp/prof_w.log /tmp/prof_sq.log

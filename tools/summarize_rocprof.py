@@ -12,8 +12,10 @@ import sys
 
 
 def short(name):
-    m = re.search(r"lm::(k_[a-z0-9_]+)", name)
+    m = re.search(r"lm::(k_[a-z0-9_]+)(?:<(\d+)>)?", name)
     if m:
+        if m.group(1) == "k_wfa_lean" and m.group(2):  # the names bench.py reports: diagonals of the ring, 128 = plain
+            return "k_wfa_lean" + {"1": "64", "2": "", "4": "256", "8": "512", "16": "1024"}.get(m.group(2), m.group(2))
         return m.group(1)
     m = re.search(r"(radix_sort_\w+|segmented_radix_sort\w*|scan_impl|reduce_by_key\w*|merge_sort\w*|init_lookback\w*)", name)
     if m:
