@@ -329,6 +329,24 @@ def test_tree_search_quirk_matches_radix_tree():
     assert hits_quirk_filter > 0  # also at the prefix lengths the filter is used with
 
 
+def test_pa_filter_is_selective_not_only_necessary():
+    """the necessity of lm_pa_candidate2 is checked against the radix tree above; this checks that it also REJECTS: for a
+    gene-sized and a read-sized key set nearly all random window k-mers are turned away (what makes k_pa_filter worth
+    running), while every k-mer of the set itself passes"""
+    Hh = H.lib()
+    rng = random.Random(4)
+    for nkeys, flog in ((3000, 16), (54000, 20)):
+        keys = sorted({rng.getrandbits(62) for _ in range(nkeys)})
+        arr = (C.c_uint64 * len(keys))(*keys)
+        fbits = (C.c_uint32 * int(Hh.ha_pa_bits_words(flog)))()
+        Hh.ha_pa_filter_build(arr, len(keys), K, flog, fbits)
+        for p in (11, 13, 15):
+            assert all(Hh.ha_pa_candidate2(fbits, flog, x, p, K) for x in keys[::37])
+            passed = sum(1 for _ in range(20000) if Hh.ha_pa_candidate2(fbits, flog, rng.getrandbits(62), p, K))
+            # true 11-base prefix matches of random probes: nkeys / 4^11 (0.07 % / 1.3 %), plus the filters' false positives
+            assert passed < (0.02 if nkeys < 10000 else 0.06) * 20000, (nkeys, p, passed)
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_extend_match_matches_oracle(seed):
     L, Hh = O.lib(), H.lib()
