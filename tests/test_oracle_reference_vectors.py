@@ -321,10 +321,11 @@ def test_demo_golden_all_84_gene_rows(demo_index_full):
 def test_demo_golden_prophage_rows_that_do_not_depend_on_the_mask_set(demo_index_full):
     """demo/q.prophage.fasta.lexicmap.tsv, 9 rows.  Triage of what reproduces: the four HSPs of >= 96 %
     identity and the 331-bp hit on GCF_002949675.1 are identical in every column except hits / qcovGnm (which count the
-    HSPs below); the 820-bp (84 %) and 64-bp (86 %) rows come and go with the mask seed (seen with 8 seeds of this build's
-    generator): seed-dependent, as SURVEY 8c(v) expects for low-identity rows; the 91.7 %-identity row 10308-13290 comes
-    out as 10308-13328 (38 bp longer, 91.526 %) with every mask seed: NOT mask dependence but the unpinned third-party WFA
-    (shenwei356/wfa v0.5.0, whose v0.10.0 changelog entry says its low-similarity alignments 'tend to be slightly shorter')"""
+    HSPs below).  The other rows are cut by the edge of the target/query WINDOW their seed chain opened
+    (lib-index-search.go:2015-2047: chain span +- 1000) - which seeds closed the chain depends on the mask set: the
+    820-bp (84 %) and 64-bp (86 %) rows come and go with the mask seed, row 2 (10308-10408) ends at the edge of cluster
+    1's window, and the 91.7 % row 10308-13290 is reproduced to the digit by
+    test_demo_golden_prophage_window_clipped_row below once the window ends where the reference's did."""
     idx = O.Index(demo_index_full)
     q = O.read_fasta(os.path.join(GOLD, "q.prophage.fasta"))[0]
     rows = [r.split("\t") for r in idx.search_tsv(q[0], q[1])]
@@ -343,8 +344,62 @@ def test_demo_golden_prophage_rows_that_do_not_depend_on_the_mask_set(demo_index
             assert [o[c] for c in hsp_cols] == [g[c] for c in hsp_cols]
             same += 1
     assert same == 5
-    # the stable divergence: same start, 38 bp longer at the right end
-    assert any(r[3] == "GCF_003697165.2" and r[12] == "10308" and r[13] == "13328" and r[9] == "3021" for r in rows)
+
+
+def test_demo_golden_prophage_window_clipped_row():
+    """Golden row 5 of demo/q.prophage.fasta.lexicmap.tsv (q 10308-13290, s 1873846-1876828, 2983 bp, 91.720 %, gaps 0,
+    bitscore 4266).  Both its ends on the right are WINDOW EDGES of the reference's seed chain: with a chain whose last
+    seed ends at (q 12289, t 1875827) the window of lib-index-search.go:2015-2047 is q <= 13289 and t <= 1876827
+    (0-based) = 13290 / 1876828 (1-based), the golden's qend / send.  Pseudo-alignment (Compare) ends its chain at
+    q 13277 / t 1876815; extendMatch clips the 50-base flank at the window (`e2 = min(end2+_extLen, len(seq2))`,
+    lib-index-search-util.go:34-60); WFA on that region gives the golden to the digit.  With a window >= 38 bases
+    longer the same chain extends to 13328 (3021 bp, 91.526 %): what this build's own seed chains produce.  The row is
+    therefore mask-set dependent through the window edge, not a WFA difference."""
+    L = O.lib()
+    q = O.read_fasta(os.path.join(GOLD, "q.prophage.fasta"))[0][1]
+    g = O.read_fasta(os.path.join(GOLD, "GCF_003697165.2.fa.gz"))[0][1]  # NZ_CP033092.2, the first contig
+    assert len(g) == 4903501
+    K = 31
+    opt = O.CmpOpt()
+    opt.k, opt.min_prefix = K, 11
+    opt.c2.max_gap, opt.c2.min_score, opt.c2.min_align_len = 20, 35, 50
+    opt.c2.min_identity, opt.c2.band_count, opt.c2.band_base, opt.c2.heuristic_pident = 70.0, 50, 100, 15.0
+    opt.min_aligned_fraction, opt.min_identity = 0.0, 70.0
+    so = O.default_search_opt()
+    cmp_ = L.lmo_cmp_new(C.byref(opt))
+    assert L.lmo_cmp_index(cmp_, q, len(q)) == 0
+
+    def row_for_window_end(wend):
+        # a seed chain on the diagonal of the HSP whose last seed ends 1000 bases before the window edge
+        qb, tb = 11000, 1873845 + (11000 - 10307)
+        qe, te = 12289 + (wend - 1876827), wend - so.ext_len
+        t_begin, t_end = tb - so.ext_len, te + so.ext_len                      # :2028-2040 (+ strand)
+        q_begin, q_end = qb - so.ext_len, min(len(q) - 1, qe + so.ext_len)      # :2042-2047
+        w = g[t_begin:t_end + 1]
+        chains = C.POINTER(O.Chain2)()
+        nc = L.lmo_cmp_compare(cmp_, q_begin, q_end, w, len(w), len(q), C.byref(chains), None, None)
+        assert nc == 1
+        c = chains[0]
+        assert (c.qbegin, c.qend, t_begin + c.tbegin, t_begin + c.tend) == (10307, 13277, 1873845, 1876815)
+        ctb, cte = t_begin + c.tbegin, t_begin + c.tend                           # single contig, + strand (:2167-2200)
+        o = [C.c_int() for _ in range(8)]
+        L.lmo_extend_match(q, len(q), w, len(w), c.qbegin, c.qend + 1, c.tbegin, c.tend + 1, so.ext_len2, ctb,
+                           len(g) - 1 - cte, 0, *[C.byref(x) for x in o])
+        qs, qe2, ts, te2, s1, e1, s2, e2 = [x.value for x in o]
+        r = O.WfaResult()
+        assert L.lmo_wfa_align(q[qs:qe2], qe2 - qs, w[ts:te2], te2 - ts, 1, C.byref(r)) == 0
+        lq, lt = qe2 - qs, te2 - ts
+        score, bits, ev = C.c_int(), C.c_int(), C.c_double()
+        L.lmo_score_evalue(C.byref(r), lq, 54142446, C.byref(score), C.byref(bits), C.byref(ev))
+        row = (c.qbegin - s1 + r.qbegin, c.qend + e1 - (lq - r.qend) + 1,       # 1-based, lib-index-search.go:2541-2556
+               ctb - s2 + r.tbegin, cte + e2 - (lt - r.tend) + 1,
+               r.align_len, "%.3f" % (100.0 * r.matches / r.align_len), r.gaps, bits.value)
+        L.lmo_wfa_result_free(C.byref(r))
+        return row
+
+    assert row_for_window_end(1876827) == (10308, 13290, 1873846, 1876828, 2983, "91.720", 0, 4266)  # the golden row
+    assert row_for_window_end(1876827 + 38)[:6] == (10308, 13328, 1873846, 1876866, 3021, "91.526")
+    L.lmo_cmp_free(cmp_)
 
 
 def test_genome_chunks_split_and_merge(tmp_path):
