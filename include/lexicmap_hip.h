@@ -79,7 +79,8 @@ void lm_options_default(lm_options *opt);
 
 /* Replaces NewIndexSearcher(dir, opt) + SetSeqCompareOptions (lib-index-search.go:237-757, :217): reads info.toml,
  * masks.bin, seeds/chunk_*.bin(.idx), genomes/batch_NNNN/genomes.bin(.idx), genomes.map.bin and builds the HBM image on
- * HIP device `device`. */
+ * HIP device `device`.  Limits of this build: at most 65535 masks (the reference's default is 20 000, 40 000 before
+ * v0.6.0), genomes of at most 2^28 bases (the reference's own limit, lib-index-build.go:421-425). */
 lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_index **out);
 /* Synthetic genome set + seed index generated directly in HBM (benchmark input; nothing in the reference corresponds to
  * it — index building is out of the hot-path scope).  Genome g belongs to family g % families; genomes >= families are
@@ -107,7 +108,8 @@ lm_status lm_index_get_info(const lm_index *idx, lm_index_info *info);
 const uint64_t *lm_index_masks(const lm_index *idx);
 /* (k-mer, value) pairs stored under one mask (normal seeds, then reversed seeds; each part ascending by k-mer), values
  * in the reference layout batch:17|genome:17|pos:28|rc:1|reversed:1: kv.Reader.ReadDataOfAMaskAsList
- * (kv/kv-reader.go:762), what `lexicmap utils kmers --mask` prints (kmers.go:101-180). Call with cap = 0 for the count. */
+ * (kv/kv-reader.go:762), what `lexicmap utils kmers --mask` prints (kmers.go:101-180). Call with cap = 0 (or both arrays
+ * NULL) for the count; 0 < cap < count returns LM_ERR_ARG with *n = count and writes nothing. */
 lm_status lm_index_mask_seeds(lm_index *idx, int32_t mask, uint64_t *kmers, uint64_t *vals, size_t cap, size_t *n);
 /* text of the last error on this handle, or of the last failed lm_index_open when idx == NULL */
 const char *lm_last_error(const lm_index *idx);

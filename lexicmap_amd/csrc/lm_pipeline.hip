@@ -915,6 +915,7 @@ static lm_status check_options(const lm_options &o, int k, int mask_prefix, int 
     return LM_OK;
 }
 
+void lm_index_close(lm_index *ix);
 lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_index **out) {
     *out = nullptr;
     g_open_error.clear();
@@ -932,13 +933,13 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
                                    opt->shard_count > 1 ? opt->shard_count : 1, ix->host, status);
         if (!e.empty()) {
             g_open_error = e;
-            delete ix;
+            lm_index_close(ix);
             return status == 2 ? LM_ERR_FORMAT : LM_ERR_IO;
         }
         if (opt->total_bases_override > 0) ix->host.total_bases = opt->total_bases_override;
         lm_status st = check_options(*opt, ix->host.k, ix->host.mask_prefix, ix->host.anchor_prefix, g_open_error);
         if (st != LM_OK) {
-            delete ix;
+            lm_index_close(ix);
             return st;
         }
         HIPCHK(hipSetDevice(device));
@@ -999,9 +1000,12 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
             DBuf<uint64_t> dk, dv;
             DBuf<uint16_t> dm;
             for (int pass = 0; pass < 2; pass++) {
-                std::vector<std::future<std::string>> fut(nf);
+                // declaration order matters: `fut` is destroyed FIRST when an exception unwinds this scope (a failed upload,
+                // DeviceOOM) and a std::async future joins its task in its destructor - so the decode tasks still running
+                // have finished before the chunks and status slots they write into are freed
                 std::vector<std::unique_ptr<SeedChunk>> chunk(nf);
                 std::vector<int> stat(nf, 0), anch(nf, -1);
+                std::vector<std::future<std::string>> fut(nf);
                 auto launch = [&](size_t i) {
                     chunk[i].reset(new SeedChunk());
                     fut[i] = std::async(std::launch::async, [&, i]() {
@@ -1017,7 +1021,7 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
                             if (fut[j].valid()) fut[j].wait();
                         g_open_error = e2;
                         const int stt = stat[i];
-                        delete ix;
+                        lm_index_close(ix);
                         return stt == 2 ? LM_ERR_FORMAT : LM_ERR_IO;
                     }
                     SeedChunk &c = *chunk[i];
@@ -1051,7 +1055,7 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
         lm_set_scratch_budget(ix);
     } catch (const std::exception &e) {
         g_open_error = e.what();
-        delete ix;
+        lm_index_close(ix);
         return LM_ERR_HIP;
     }
     *out = ix;
@@ -1091,6 +1095,7 @@ lm_status lm_index_get_info(const lm_index *ix, lm_index_info *info) {
     info->key_bits = ix->view.key_bits;
     info->val_bits = ix->view.gid_bits + ix->view.pos_bits + 1;
     info->partition_bases = ix->view.part_bases;
+    info->pad = 0;
     return LM_OK;
 }
 

@@ -316,7 +316,7 @@ static int bits_for(int64_t n) { // bits needed for values in [0, n)
 void SeedPacker::begin(lm_index *ix_, int64_t local_genomes, int64_t max_genome_len) {
     ix = ix_;
     const HostIndex &h = ix->host;
-    if (h.M > 32767) throw HipError("seed image: more than 32767 masks are not supported");
+    if (h.M > 65535) throw HipError("seed image: more than 65535 masks are not supported (16-bit mask ids in the loader's staging records; include/lexicmap_hip.h)");
     a = std::min(h.anchor_prefix, 6);
     while (a > 0 && h.mask_prefix + a >= h.k) a--;
     P1 = (1 << (2 * a)) + 1;
@@ -490,7 +490,11 @@ extern "C" lm_status lm_index_mask_seeds(lm_index *ix, int32_t mask, uint64_t *k
         (void)nmd;
         const size_t total = (size_t)(mdo[2] - mdo[0]) + (size_t)(oo[2] - oo[0]);
         *n_out = total;
-        if (!kmers || !vals || cap < total) return LM_OK; // size query
+        if (cap == 0 || (!kmers && !vals)) return LM_OK; // size query
+        if (!kmers || !vals || cap < total) {
+            ix->err = "lm_index_mask_seeds: buffer too small (cap < *n) or a NULL array";
+            return LM_ERR_ARG; // nothing was written; *n holds the count to allocate
+        }
         DBuf<uint64_t> dk, dv;
         size_t w = 0;
         for (int dir = 0; dir < 2; dir++) {
