@@ -49,6 +49,8 @@ def parse():
     p.add_argument("--queries", type=int, default=0, help="override the number of queries")
     p.add_argument("--genomes", type=int, default=0, help="override the number of genomes")
     p.add_argument("--genome-len", type=int, default=0)
+    p.add_argument("--families", type=int, default=0, help="override the number of genome families")
+    p.add_argument("--tag", default="", help="free text copied into config.tag (labels A/B runs)")
     p.add_argument("--shard", default="index", choices=["index", "queries"],
                    help="N>1: index = genomes + seed index sharded over the GPUs, queries broadcast (north-star layout, "
                         "default); queries = index replicated, query batch divided")
@@ -182,7 +184,9 @@ def cpu_baseline(index_dir, queries, seconds, ncores):
         dt = time.time() - t0
     rows = sum(r[0] for r in res)
     bases = sum(r[1] for r in res)
-    return dict(value=len(sample) / dt, unit="queries/s", cores=ncores, kind="port",
+    # the oracle's rows of every sample query that was searched (query i of the sample list = queries[i % n])
+    oracle_rows = {i: res[i][2] for i in range(min(n, nsample))}
+    return dict(value=len(sample) / dt, unit="queries/s", cores=ncores, kind="port", _oracle_rows=oracle_rows,
                 gbp_aligned_per_s=bases / dt / 1e9, rows_per_query=rows / max(len(sample), 1),
                 sample="%d searches over %d sample queries, oracle/liblmo.so (C restatement of the Go reference, RAM-resident "
                        "index = the reference's -w regime) on %d processes, %.1f s, %d HSP rows"
@@ -198,9 +202,39 @@ def _cpu_init(index_dir):
     _CPU_IDX = O.Index(index_dir)
 
 
+ROW_CHECK_FIELDS = ("batch_genome", "cls", "hsp", "seq_idx", "nseqs", "seq_len", "rc", "aligned_length", "gaps", "qbegin",
+                    "qend", "tbegin", "tend", "bitscore", "score", "matched_bases", "qcov_genome", "qcov_hsp", "pident")
+
+
 def _cpu_one(seq):
     rows, st = _CPU_IDX.search(seq)
-    return (len(rows), sum(r["aligned_length"] for r in rows))
+    compact = [tuple(r[f] for f in ROW_CHECK_FIELDS) + (r["evalue"], st["ngenomes"]) for r in rows]
+    return (len(rows), sum(r["aligned_length"] for r in rows), compact)
+
+
+def rows_equal_oracle(gpu_rows, oracle_rows):
+    """HIP rows (numpy lm_hsp array of one search over the sample queries) vs the oracle's rows of the same queries, row
+    for row in output order: every integer / float64 column exact, e-value within 1e-9 relative, `hits` = the oracle's
+    genome count.  Returns (equal, rows compared, first difference or None)."""
+    import numpy as np
+    q = gpu_rows["query"].astype(np.int64)
+    ncmp = 0
+    for qi, exp in sorted(oracle_rows.items()):
+        got = gpu_rows[q == qi]  # rows of a query are contiguous and in final order
+        if len(got) != len(exp):
+            return False, ncmp, "query %d: %d HIP rows vs %d oracle rows" % (qi, len(got), len(exp))
+        for j, e in enumerate(exp):
+            g = got[j]
+            for k, f in enumerate(ROW_CHECK_FIELDS):
+                if g[f] != e[k]:
+                    return False, ncmp, "query %d row %d: %s = %r (HIP) vs %r (oracle)" % (qi, j, f, g[f].item(), e[k])
+            ev = e[len(ROW_CHECK_FIELDS)]
+            if abs(float(g["evalue"]) - ev) > 1e-9 * max(abs(ev), 1e-300):
+                return False, ncmp, "query %d row %d: evalue %r vs %r" % (qi, j, float(g["evalue"]), ev)
+            if int(g["hits"]) != e[len(ROW_CHECK_FIELDS) + 1]:
+                return False, ncmp, "query %d row %d: hits %d vs %d" % (qi, j, int(g["hits"]), e[len(ROW_CHECK_FIELDS) + 1])
+            ncmp += 1
+    return True, ncmp, None
 
 
 def free_port():
@@ -277,6 +311,8 @@ def main():
         wl["genomes"] = args.genomes
     if args.genome_len:
         wl["genome_len"] = args.genome_len
+    if args.families:
+        wl["families"] = args.families
     wl["families"] = min(wl["families"], wl["genomes"])
 
     t_setup = time.time()
@@ -558,7 +594,7 @@ def main():
                                        ("index-shard x%d (genome g on rank g %% %d), queries broadcast, one all-gatherv of HSP rows per step" % (world, world))
                                        if index_sharded else
                                        ("q-shard x%d (index replicated), %d queries per GPU" % (world, len(my)))),
-                       "pcie_upload_s": round(upload_s, 4),
+                       "pcie_upload_s": round(upload_s, 4), "tag": args.tag,
                        "go_toolchain": go or "absent (reference Go binary cannot be built; CPU baseline is the C port)"},
             "stage_ms": {k: round(v, 3) for k, v in stats.items() if k.startswith("ms_")},
             "work": {k: v for k, v in stats.items() if not k.startswith("ms_")},
@@ -571,17 +607,20 @@ def main():
             "source_hash": source_hash(),
         }
     gi.free_batch(qb)
+    sample_mismatch = None
     # CPU baseline on rank 0, N=1 only
     if rank == 0 and world == 1 and not args.no_cpu_baseline and index_dir:
         try:
             ncores = usable_cores()
             cb = cpu_baseline(index_dir, cpu_queries or queries, args.cpu_seconds, ncores)
             cb["sample"] += "; " + cpu_sample_note
-            if cpu_queries is not None:
+            oracle_rows = cb.pop("_oracle_rows")
+            if True:
                 # the same sample (same index directory, same queries) through the HIP path: a like-for-like pair of numbers
                 try:
+                    sq = cpu_queries or queries
                     g2 = la.Index(index_dir, device=local_rank)
-                    qb2 = g2.upload([q[1] for q in cpu_queries])
+                    qb2 = g2.upload([q[1] for q in sq])
                     g2.search_resident_np(qb2)
                     torch.cuda.synchronize()
                     t1 = time.time()
@@ -589,12 +628,21 @@ def main():
                     for _ in range(reps):
                         r2, _s2 = g2.search_resident_np(qb2)
                     torch.cuda.synchronize()
-                    cb["gpu_on_same_sample"] = dict(value=round(len(cpu_queries) * reps / (time.time() - t1), 1),
-                                                    unit="queries/s", rows_per_query=round(len(r2) / len(cpu_queries), 2))
+                    cb["gpu_on_same_sample"] = dict(value=round(len(sq) * reps / (time.time() - t1), 1),
+                                                    unit="queries/s", rows_per_query=round(len(r2) / len(sq), 2))
+                    # parity at the bench's own shape: the HIP rows of the sample queries against the oracle's, row for row
+                    eq, ncmp, diff = rows_equal_oracle(r2, oracle_rows)
+                    cb["sample_rows_equal"] = bool(eq)
+                    cb["sample_rows"] = int(ncmp)
+                    cb["sample_queries_compared"] = len(oracle_rows)
+                    if not eq:
+                        cb["sample_rows_first_difference"] = diff
+                        sample_mismatch = diff
                     g2.free_batch(qb2)
                     g2.close()
                 except Exception as e:
                     cb["gpu_on_same_sample"] = "failed: %r" % (e,)
+                    cb["sample_rows_equal"] = None
             result["cpu_baseline"] = cb
         except Exception as e:  # the baseline must not kill the bench line
             result["cpu_baseline"] = dict(value=None, unit="queries/s", cores=0, kind="port", sample="failed: %r" % (e,))
@@ -606,6 +654,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if sample_mismatch:  # a fast path that differs from the reference is not done: fail loudly (the line is printed first)
+        raise SystemExit("bench.py: HIP rows differ from the oracle on the CPU sample: %s" % sample_mismatch)
 
 
 if __name__ == "__main__":

@@ -279,7 +279,17 @@ struct SeedPacker {
 };
 } // namespace lm
 
+// Experiment / A-B switches of the kernels, read from the environment ONCE when the handle is created (a search never calls
+// getenv for them). Defaults are the measured winners; the alternatives stay for the profiles that justify them.
+struct lm_tune {
+    int pa_seg_by_group = 1; // candidate segments by task group + XCD-local k_pa_search (LM_PA_SEG_BY_WAVE=1: by wavefront)
+    lm_tune() {
+        if (const char *e = getenv("LM_PA_SEG_BY_WAVE")) pa_seg_by_group = atoi(e) ? 0 : 1;
+    }
+};
+
 struct lm_index {
+    lm_tune tune;
     lm::Work *work = nullptr;       // device scratch reused across calls (grow-only)
     lm::AlignCtx *actx[2] = {nullptr, nullptr}; // one per alignment worker
     // second lane: two parts of a large batch are searched side by side (the seeding / anchor kernels of one beside the

@@ -108,16 +108,19 @@ void launch_sum_i32(hipStream_t st, const int32_t *v, int64_t n, unsigned long l
 // hashed 11-base prefix bitmap per query: 2^bits_log[q] bits at word bits_off[q] (sized by the host, ~16 bits per k-mer)
 void launch_build_cmp_bits(hipStream_t st, const uint64_t *keys_cmp, const int64_t *posoff, const int32_t *nvalid, int nq,
                            int K, const int64_t *bits_off, const int32_t *bits_log, uint32_t *bits);
-#define LM_PA_MAX_SEGS 1024 /* segments (each with its own counter) of the candidate list of k_pa_filter */
+#define LM_PA_MAX_SEGS 8192 /* segments (each with its own counter) of the candidate list of k_pa_filter */
+#define LM_PA_RANGE_SEGS 16 /* segments per range of task groups (= wavefronts of a k_pa_filter workgroup) */
+#define LM_PA_GROUP 64 /* chain windows per k_pa_filter workgroup pass */
 void launch_pa_filter(hipStream_t st, DevIndexView ix, const Task *tasks, int64_t ntasks, const uint8_t *wbuf,
                       const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_bits, const int64_t *bits_off,
                       const int32_t *bits_log, int K, int min_prefix, unsigned long long *seg_count, int nseg, int64_t seg_cap,
-                      uint64_t *cand, unsigned long long *group_counter, int ncu);
+                      uint64_t *cand, unsigned long long *group_counter, int ncu, int seg_by_group);
 void launch_pa_search(hipStream_t st, DevIndexView ix, const Task *tasks, const uint8_t *wbuf, const uint64_t *keys_cmp,
                       const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_tab,
                       const int64_t *tab_off, const int32_t *tab_bits, int K, int min_prefix,
                       const unsigned long long *seg_count, int nseg, int64_t seg_cap, const uint64_t *cand,
-                      unsigned long long *count, int64_t cap, uint64_t *outA, uint64_t *outB, int qbits, int tbits);
+                      unsigned long long *count, int64_t cap, uint64_t *outA, uint64_t *outB, int qbits, int tbits,
+                      int xcd_map);
 void launch_pa_task_off_sorted(hipStream_t st, const uint64_t *sortedA, int shift, int64_t total, int64_t ntasks,
                                int64_t *pa_off);
 void launch_pa_chain(hipStream_t st, const uint64_t *B, const int64_t *pa_off, int64_t ntasks, int K, LmChain2Opt opt,

@@ -26,6 +26,16 @@
 
 namespace lm {
 
+// Wavefront-private LDS: LDS traffic of a single wave is processed in issue order, so cross-lane LDS hand-offs
+// only need the compiler not to reorder them. A workgroup barrier would also drain the outstanding global stores
+// (s_waitcnt vmcnt(0)) of the backtrace store on every score step, which is what this avoids.
+#define LDS_WAVE_SYNC()                                        \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int find_segment(const int64_t *off, int n, int64_t x) {
     // largest s with off[s] <= x  (off[0]=0, off[n]=total)
@@ -627,7 +637,8 @@ __device__ __forceinline__ void pa_prefixes(const Task &t, const uint8_t *__rest
 // capacity, so the host can re-run with larger buffers.
 #define PA_THREADS 1024
 #define PA_WAVES (PA_THREADS / 64)
-#define PA_GROUP 64  /* chain windows per workgroup pass */
+static_assert(PA_WAVES == LM_PA_RANGE_SEGS, "one candidate segment per wavefront of a filter workgroup");
+#define PA_GROUP LM_PA_GROUP /* chain windows per workgroup pass */
 #define PA_STAGE 192 /* candidates a wavefront stages in LDS */
 #define PA_SLICE 1920 /* window positions a wavefront takes at a time: their 2-bit genome words are one 8-byte load per lane */
 #define PA_PEND 128 /* positions a wavefront sets aside for the global bitmap: examined whenever 64 have gathered */
@@ -641,10 +652,14 @@ __global__ __launch_bounds__(PA_THREADS) void k_pa_filter(DevIndexView ix, const
                                                            const int32_t *__restrict__ bits_log, int K, int min_prefix,
                                                            unsigned long long *__restrict__ seg_count, int nseg,
                                                            int64_t seg_cap, uint64_t *__restrict__ cand,
-                                                           unsigned long long *__restrict__ group_counter) {
+                                                           unsigned long long *__restrict__ group_counter, int seg_by_group) {
     // the candidate list is kept as `nseg` segments of `seg_cap` entries with a counter each: a single counter is a single
     // address in one L2 channel, and the ~10^6 appends of a launch (one per ~200 candidates) then queue up behind each other
-    // for longer than all the rest of the kernel takes
+    // for longer than all the rest of the kernel takes.  seg_by_group: nseg = R x PA_WAVES, the segment is chosen by the RANGE
+    // of the task group (groups are in (query, genome) order and are handed out in order, so the PA_WAVES segments of a range
+    // hold the candidates of one or two queries and k_pa_search can keep that query's tables in one XCD's L2) and by the
+    // wavefront's number inside its workgroup (one counter per range was 160 wavefronts deep in atomics: the filter took
+    // twice as long); otherwise by the wavefront alone (any query anywhere).
     extern __shared__ uint64_t pa_lds[];                               // PA_LDS_BYTES, dynamic (above 64 KB)
     uint64_t *s_stage = pa_lds;                                        // [PA_WAVES][PA_STAGE]
     uint32_t *s_bloom = (uint32_t *)(pa_lds + PA_WAVES * PA_STAGE);    // 64 KB
@@ -655,7 +670,7 @@ __global__ __launch_bounds__(PA_THREADS) void k_pa_filter(DevIndexView ix, const
     uint64_t *stg = s_stage + wave * PA_STAGE;
     int n_stg = 0; // wave-uniform
     const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
-    const int seg = (int)(((int64_t)blockIdx.x * PA_WAVES + wave) % nseg);
+    int seg = (int)(((int64_t)blockIdx.x * PA_WAVES + wave) % nseg);
     uint64_t *seg_list = cand + (int64_t)seg * seg_cap;
     auto flush = [&]() { // this wavefront's staged candidates -> its segment of the global list
         if (n_stg == 0) return;
@@ -724,6 +739,14 @@ __global__ __launch_bounds__(PA_THREADS) void k_pa_filter(DevIndexView ix, const
         if (grp >= ngroups) break;
         const int64_t t0g = grp * PA_GROUP;
         const int ng = (int)((ntasks < t0g + PA_GROUP ? ntasks : t0g + PA_GROUP) - t0g);
+        if (seg_by_group) { // nseg = ranges x PA_WAVES: the range of the group, this wavefront's own counter inside it
+            const int gseg = (int)(grp * (int64_t)(nseg / PA_WAVES) / ngroups) * PA_WAVES + wave;
+            if (gseg != seg) {
+                flush(); // what is staged belongs to the previous group's segment
+                seg = gseg;
+                seg_list = cand + (int64_t)seg * seg_cap;
+            }
+        }
         __syncthreads(); // the previous group is finished with the tables
         if (tid < ng) {
             const Task t = tasks[t0g + tid];
@@ -892,7 +915,7 @@ __global__ __launch_bounds__(256) void k_pa_search(DevIndexView ix, const Task *
                                                     int blocks_per_seg, const uint64_t *__restrict__ cand_all,
                                                     unsigned long long *__restrict__ count, int64_t cap,
                                                     uint64_t *__restrict__ outA, uint64_t *__restrict__ outB, int qbits,
-                                                    int tbits) {
+                                                    int tbits, int nseg, int xcd_map) {
     // qbits > 0: compact single-key anchors, task | QBegin:qbits | (32-Len):6 | TBegin:tbits | 2 flags in one u64 (outA is
     // not written): same order as (task, B) and one keys-only radix sort over the bits in use instead of two pair sorts.
     // qbits == 0 (batches whose fields need more than 64 bits): (task, B) pairs, the task staged beside B.
@@ -917,7 +940,19 @@ __global__ __launch_bounds__(256) void k_pa_search(DevIndexView ix, const Task *
         }
         n_stg = 0;
     };
-    const int seg = blockIdx.x / blocks_per_seg, sub = blockIdx.x % blocks_per_seg; // blocks_per_seg blocks share a segment
+    // blocks_per_seg blocks share a segment.  xcd_map: hardware workgroup b runs on XCD b % 8 (round-robin dispatch), so the
+    // blocks of a segment are given ids of ONE residue class: the per-query tables its candidates probe (bucket table, sorted
+    // k-mers, positions: 1-2 MB) then stay in that XCD's 4-MB L2 instead of being fetched by all eight
+    int seg, sub;
+    if (xcd_map) { // segments come in ranges of LM_PA_RANGE_SEGS (one range = one or two queries): range R on XCD R % 8
+        const int r = blockIdx.x >> 3, sr = r / blocks_per_seg;
+        seg = ((sr / LM_PA_RANGE_SEGS) * 8 + (blockIdx.x & 7)) * LM_PA_RANGE_SEGS + sr % LM_PA_RANGE_SEGS;
+        sub = r % blocks_per_seg;
+        if (seg >= nseg) return;
+    } else {
+        seg = blockIdx.x / blocks_per_seg;
+        sub = blockIdx.x % blocks_per_seg;
+    }
     const uint64_t *cand = cand_all + (int64_t)seg * seg_cap;
     int64_t nc = (int64_t)seg_count[seg];
     if (nc > seg_cap) nc = seg_cap; // the host re-runs both kernels with a larger list
@@ -1777,15 +1812,6 @@ __global__ __launch_bounds__(64) void k_wfa_wave(const WfaIn *__restrict__ in, i
 
 
 // ------------------------------------------------------------------------------------------------------------
-// One wavefront per workgroup: LDS traffic of a single wave is processed in issue order, so cross-lane LDS hand-offs
-// only need the compiler not to reorder them. A workgroup barrier would also drain the outstanding global stores
-// (s_waitcnt vmcnt(0)) of the backtrace store on every score step, which is what this avoids.
-#define LDS_WAVE_SYNC()                                        \
-    do {                                                       \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
-        __builtin_amdgcn_wave_barrier();                       \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
-    } while (0)
 
 
 // 16 bases -> one 32-bit word, first base in the top bits. Any injective 2-bit code works for equality tests:
@@ -2530,7 +2556,7 @@ void launch_build_cmp_bits(hipStream_t st, const uint64_t *keys_cmp, const int64
 void launch_pa_filter(hipStream_t st, DevIndexView ix, const Task *tasks, int64_t ntasks, const uint8_t *wbuf,
                       const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_bits, const int64_t *bits_off,
                       const int32_t *bits_log, int K, int min_prefix, unsigned long long *seg_count, int nseg, int64_t seg_cap,
-                      uint64_t *cand, unsigned long long *group_counter, int ncu) {
+                      uint64_t *cand, unsigned long long *group_counter, int ncu, int seg_by_group) {
     const int64_t ngroups = (ntasks + PA_GROUP - 1) / PA_GROUP;
     int g = (int)(ngroups < 1 ? 1 : (ngroups > ncu ? ncu : ngroups));
     static bool lds_set = false;
@@ -2539,19 +2565,24 @@ void launch_pa_filter(hipStream_t st, DevIndexView ix, const Task *tasks, int64_
         lds_set = true;
     }
     hipLaunchKernelGGL(k_pa_filter, dim3(g), dim3(PA_THREADS), PA_LDS_BYTES, st, ix, tasks, ntasks, wbuf, posoff, nvalid,
-                       cmp_bits, bits_off, bits_log, K, min_prefix, seg_count, nseg, seg_cap, cand, group_counter);
+                       cmp_bits, bits_off, bits_log, K, min_prefix, seg_count, nseg, seg_cap, cand, group_counter, seg_by_group);
 }
 void launch_pa_search(hipStream_t st, DevIndexView ix, const Task *tasks, const uint8_t *wbuf, const uint64_t *keys_cmp,
                       const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_tab,
                       const int64_t *tab_off, const int32_t *tab_bits, int K, int min_prefix,
                       const unsigned long long *seg_count, int nseg, int64_t seg_cap, const uint64_t *cand,
-                      unsigned long long *count, int64_t cap, uint64_t *outA, uint64_t *outB, int qbits, int tbits) {
-    // the candidate counts are only known on the device: a grid that fills the chip, a fixed number of blocks per segment
-    int bps = (256 * 32 + nseg - 1) / nseg;
+                      unsigned long long *count, int64_t cap, uint64_t *outA, uint64_t *outB, int qbits, int tbits,
+                      int xcd_map) {
+    // the candidate counts are only known on the device: a fixed number of blocks per segment.  xcd_map (segments in query
+    // order, k_pa_filter's seg_by_group): as many blocks per range of segments as one XCD holds (32 CUs x 8), so that an XCD
+    // works on one or two ranges - a few queries - at a time; otherwise a grid that just fills the chip.
+    int bps = xcd_map ? 256 / LM_PA_RANGE_SEGS : (256 * 32 + nseg - 1) / nseg;
     const int64_t need = (seg_cap + 255) / 256;
     if (bps > need) bps = (int)(need < 1 ? 1 : need);
-    hipLaunchKernelGGL(k_pa_search, dim3(nseg * bps), dim3(256), 0, st, ix, tasks, wbuf, keys_cmp, vals_cmp, posoff, nvalid, cmp_tab,
-                       tab_off, tab_bits, K, min_prefix, seg_count, seg_cap, bps, cand, count, cap, outA, outB, qbits, tbits);
+    const int nseg8 = xcd_map ? (nseg / LM_PA_RANGE_SEGS + 7) / 8 * 8 * LM_PA_RANGE_SEGS : nseg;
+    hipLaunchKernelGGL(k_pa_search, dim3(nseg8 * bps), dim3(256), 0, st, ix, tasks, wbuf, keys_cmp, vals_cmp, posoff, nvalid, cmp_tab,
+                       tab_off, tab_bits, K, min_prefix, seg_count, seg_cap, bps, cand, count, cap, outA, outB, qbits, tbits, nseg,
+                       xcd_map);
 }
 void launch_pa_task_off_sorted(hipStream_t st, const uint64_t *sortedA, int shift, int64_t total, int64_t ntasks,
                                int64_t *pa_off) {

@@ -1420,25 +1420,36 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
     if (a.pa_cap < (int64_t)1 << 20) a.pa_cap = std::max<int64_t>((int64_t)1 << 20, W / 8);
     if (const char *e = getenv("LM_DEBUG_PA_CAP")) a.pa_cap = std::max<int64_t>(1, atoll(e)); // test hook: force the re-run
     int64_t TP = 0;
+    int nseg = 1;
     for (int attempt = 0;; attempt++) {
         if (!compact) a.A0.ensure((size_t)a.pa_cap);
         a.B0.ensure((size_t)a.pa_cap);
         a.B1.ensure((size_t)a.pa_cap); // the sort's second buffer holds the candidate list of k_pa_filter until then
-        // the candidate list in segments with a counter each (k_pa_filter), at least 4096 entries per segment
-        const int nseg = (int)std::max<int64_t>(1, std::min<int64_t>(LM_PA_MAX_SEGS, a.pa_cap / 4096));
+        // the candidate list in segments with a counter each (k_pa_filter), at least 4096 entries per segment; segments by
+        // task group: never more segments than groups, and a re-run after an overflow keeps the number of segments (the
+        // measured fullest segment then sizes the next attempt exactly)
+        if (!ix->tune.pa_seg_by_group) {
+            nseg = (int)std::max<int64_t>(1, std::min<int64_t>(1024, a.pa_cap / 4096));
+        } else if (attempt == 0) { // ranges of task groups x LM_PA_RANGE_SEGS segments each
+            const int64_t ngroups = (nt + LM_PA_GROUP - 1) / LM_PA_GROUP;
+            const int64_t ranges = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(LM_PA_MAX_SEGS / LM_PA_RANGE_SEGS, ngroups),
+                                                                          a.pa_cap / 4096 / LM_PA_RANGE_SEGS));
+            nseg = (int)ranges * LM_PA_RANGE_SEGS;
+        }
         const int64_t seg_cap = a.pa_cap / nseg;
         HIPCHK(hipMemsetAsync(a.pa_count.p, 0, (size_t)(2 + nseg) * sizeof(unsigned long long), S(ix)));
         {
             Prof p(ix, "k_pa_filter", W);
             launch_pa_filter(S(ix), ix->view, tasks_d, nt, a.wb, qb->d_posoff.p, a.w->nvalid.p, a.w->cmp_bits.p,
                              qb->d_bits_off.p, qb->d_bits_log.p, ix->host.k, 11, a.pa_count.p + 2, nseg, seg_cap, a.B1.p,
-                             a.pa_count.p + 1, device_cus(ix->device));
+                             a.pa_count.p + 1, device_cus(ix->device), ix->tune.pa_seg_by_group);
         }
         {
             Prof p(ix, "k_pa_search");
             launch_pa_search(S(ix), ix->view, tasks_d, a.wb, a.w->k_cmp, a.w->v_cmp, qb->d_posoff.p, a.w->nvalid.p,
                              a.w->cmp_tab.p, qb->d_tab_off.p, qb->d_tab_bits.p, ix->host.k, 11, a.pa_count.p + 2, nseg, seg_cap,
-                             a.B1.p, a.pa_count.p, a.pa_cap, a.A0.p, a.B0.p, compact ? qbits : 0, compact ? tbits : 0);
+                             a.B1.p, a.pa_count.p, a.pa_cap, a.A0.p, a.B0.p, compact ? qbits : 0, compact ? tbits : 0,
+                             ix->tune.pa_seg_by_group);
         }
         std::vector<unsigned long long> hv((size_t)2 + nseg);
         HIPCHK(hipMemcpyAsync(hv.data(), a.pa_count.p, hv.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, S(ix)));
