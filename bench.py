@@ -514,7 +514,7 @@ def main():
         # 128/256/512/1024 diagonals for the length classes of a round, side by side on four streams); its figures are the
         # launch-weighted means over the instantiations, which stay listed one by one in kernels[].
         def family(name):
-            return "k_wfa_lean" if name.startswith("k_wfa_lean") else name
+            return "k_wfa_lean" if name.startswith(("k_wfa_lean", "k_wfa_win")) else name
 
         fam = {}
         for pk in kern:

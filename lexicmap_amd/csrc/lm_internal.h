@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -281,9 +282,27 @@ struct SeedPacker {
 
 // Experiment / A-B switches of the kernels, read from the environment ONCE when the handle is created (a search never calls
 // getenv for them). Defaults are the measured winners; the alternatives stay for the profiles that justify them.
+#define LM_WFA_CLASSES 5 /* length classes of the WFA problems of a round (run_wfa) */
 struct lm_tune {
+    // WFA per length class (<= 2 kb, <= 8 kb, <= 32 kb, <= 65 kb, longer): the ring width (cells per lane x 64 diagonals) a
+    // problem starts with, and whether the kernel reads the sequences through sliding LDS windows (1) or keeps them whole in
+    // LDS (0; impossible beyond 65 kb).  LM_WFA_FIRST_NC="2,2,4,8,8", LM_WFA_WIN="00101" override.
+    int wfa_first_nc[LM_WFA_CLASSES] = {2, 2, 4, 8, 8};
+    int wfa_win[LM_WFA_CLASSES] = {0, 0, 1, 0, 1};
     int pa_seg_by_group = 1; // candidate segments by task group + XCD-local k_pa_search (LM_PA_SEG_BY_WAVE=1: by wavefront)
+    int wfa_serial = 0;      // LM_WFA_SERIAL=1: the WFA length classes one after the other (exclusive kernel timings)
+    int no_pipeline = 0;     // LM_NO_PIPELINE=1: no pseudo-alignment producer beside extend / WFA (exclusive kernel timings)
     lm_tune() {
+        wfa_serial = getenv("LM_WFA_SERIAL") != nullptr;
+        if (const char *e = getenv("LM_WFA_FIRST_NC")) {
+            int v[LM_WFA_CLASSES];
+            if (sscanf(e, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]) == LM_WFA_CLASSES)
+                for (int c = 0; c < LM_WFA_CLASSES; c++)
+                    if (v[c] == 1 || v[c] == 2 || v[c] == 4 || v[c] == 8 || v[c] == 16) wfa_first_nc[c] = v[c];
+        }
+        if (const char *e = getenv("LM_WFA_WIN"))
+            for (int c = 0; c < LM_WFA_CLASSES && e[c]; c++) wfa_win[c] = e[c] == '1';
+        no_pipeline = getenv("LM_NO_PIPELINE") != nullptr;
         if (const char *e = getenv("LM_PA_SEG_BY_WAVE")) pa_seg_by_group = atoi(e) ? 0 : 1;
     }
 };

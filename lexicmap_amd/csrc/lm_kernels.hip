@@ -1834,11 +1834,91 @@ __device__ __forceinline__ uint32_t pack16(const uint8_t *__restrict__ s, int nb
     }
     return w;
 }
-// 16 packed bases starting at base `pos` (needs one padding word after the last one)
+// ---- sliding 2-bit windows of the two sequences of an alignment (k_wfa_lean) --------------------------------------------
+// The wavefront kernel used to keep BOTH WHOLE sequences 2-bit packed in LDS: 25 KB for a 50-kb read, which left three to
+// six wavefronts per CU (one per SIMD) and nothing to hide the LDS / DPP latencies of the score loop behind.  A wavefront
+// only ever reads near its front: under wf-adaptive(10, 50) every kept cell is within 50 + W bases of the leading one.  So
+// each sequence is held as a circular window of WFA_WINW words of 16 bases (4096 bases, 1 KB); the LDS of a resident
+// wavefront no longer depends on the length of its alignment (and sequences beyond 65 kb need no global-memory fallback).
+// Word w of the sequence lives at slot w & (WINW-1); slots 0 and 1 are mirrored behind the last slot so that three
+// consecutive words never wrap.  When an extending cell is outside a window, both windows are moved to the SMALLEST
+// positions among the extending cells: the cell with the smallest query position is then inside both (two cells of one
+// wavefront are less than W < 4000 diagonals apart), so every pass of the extension loop serves somebody; cells further
+// ahead wait for the next move.  In the steady state that is one move per ~2900 bases of progress; a cell left far behind
+// (possible while a wavefront is narrower than 10 diagonals, before the cut-off applies) costs two moves per score step
+// until the cut-off drops it.
+#define WFA_WINW 256
+struct WfaWin {
+    uint32_t *buf;      // WFA_WINW + 2 words of LDS
+    const uint8_t *src; // ASCII sequence
+    int len;
+    int w0;             // words [w0, w0 + WFA_WINW) are resident (wave-uniform)
+};
+// Makes words [qw0, qw0 + WINW) of Q and [tw0, tw0 + WINW) of T resident (wave-uniform, >= 0); words that stay are not
+// reloaded.  ONE loop serves both windows (the byte packing is 60 instructions: the kernel has three copies of this - start
+// of an alignment, the extension loop, the replay - instead of two per ring chunk).  *bad: a non-ACGT byte was packed.
+__device__ __forceinline__ void wfa_win_move2(WfaWin &Q, int qw0, WfaWin &T, int tw0, int lane, bool *bad, bool fresh) {
+    LDS_WAVE_SYNC(); // every lane is done reading the slots that are about to change
+    const bool qkeep = !fresh && qw0 >= Q.w0 && qw0 < Q.w0 + WFA_WINW, tkeep = !fresh && tw0 >= T.w0 && tw0 < T.w0 + WFA_WINW;
+    const int qfrom = qkeep ? Q.w0 + WFA_WINW : qw0, tfrom = tkeep ? T.w0 + WFA_WINW : tw0;
+    const int nq = qw0 + WFA_WINW - qfrom, nt = tw0 + WFA_WINW - tfrom; // words to load (0 when a window does not move)
+    for (int i = lane; i < nq + nt; i += 64) {
+        const bool isq = i < nq;
+        const int w = isq ? qfrom + i : tfrom + (i - nq);
+        const uint8_t *src = isq ? Q.src : T.src;
+        uint32_t *buf = isq ? Q.buf : T.buf;
+        const int nb = (isq ? Q.len : T.len) - 16 * w;
+        const uint32_t word = nb > 0 ? pack16(src + 16 * (int64_t)w, nb, bad) : 0u;
+        const int slot = w & (WFA_WINW - 1);
+        buf[slot] = word;
+        if (slot < 2) buf[WFA_WINW + slot] = word;
+    }
+    Q.w0 = __builtin_amdgcn_readfirstlane(qw0); // provably wave-uniform: the window tests stay cheap
+    T.w0 = __builtin_amdgcn_readfirstlane(tw0);
+    LDS_WAVE_SYNC();
+}
+// can 32 bases from `pos` be read from the window ? (three words: pos >> 4 .. +2)
+__device__ __forceinline__ bool wfa_win_has(const WfaWin &W, int pos) {
+    return (uint32_t)((pos >> 4) - W.w0) < (uint32_t)(WFA_WINW - 2);
+}
+// 32 packed bases starting at base `pos`, first base in the top bits
+__device__ __forceinline__ uint64_t wfa_win_get32(const WfaWin &W, int pos) {
+    const uint32_t *p = W.buf + ((pos >> 4) & (WFA_WINW - 1));
+    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+    const int rs = 32 - ((pos & 15) << 1); // 2..32: 64-bit shifts, so that no case needs a branch or a select
+    const uint32_t hi = (uint32_t)((((uint64_t)d0 << 32) | d1) >> rs);
+    const uint32_t lo = (uint32_t)((((uint64_t)d1 << 32) | d2) >> rs);
+    return ((uint64_t)hi << 32) | lo;
+}
+// 16 packed bases starting at base `pos` of a WHOLE packed sequence (one padding word after the last one)
 __device__ __forceinline__ uint32_t get16(const uint32_t *seq, int pos) {
     const int w = pos >> 4, sh = (pos & 15) << 1;
     const unsigned long long two = ((unsigned long long)seq[w] << 32) | seq[w + 1]; // both words, no branch on sh
     return (uint32_t)((two << sh) >> 32);
+}
+// Matching bases at (v, h): one step of the greedy extension.  WIN: at most 32, through the sliding windows (both
+// positions inside); otherwise at most 16, the whole packed sequences being in LDS (buf = the sequence, w0 = 0).  The
+// windows cost 2 KB of LDS whatever the length; whole sequences cost len / 4 bytes but a cheaper step: alignments up to
+// 8 kb keep the latter (measured: 128 vs 138 ms per c3-shaped launch), longer ones gain more from the residency.
+template <bool WIN> __device__ __forceinline__ int wfa_match_run(const WfaWin &Q, const WfaWin &T, int v, int h) {
+    int nm;
+    if (WIN) {
+        const uint64_t d = wfa_win_get32(Q, v) ^ wfa_win_get32(T, h);
+        nm = __clzll((long long)d) >> 1; // 32 when all 32 bases match (__clzll(0) == 64)
+    } else {
+        const uint32_t d = get16(Q.buf, v) ^ get16(T.buf, h);
+        nm = d ? (__clz(d) >> 1) : 16;
+    }
+    const int rem = Q.len - v < T.len - h ? Q.len - v : T.len - h;
+    nm = nm < rem ? nm : rem;
+    return nm > 0 ? nm : 0;
+}
+__device__ __forceinline__ int wave_min_i32_slow(int v) { // rare paths only
+    for (int o = 32; o > 0; o >>= 1) {
+        const int x = __shfl_xor(v, o, 64);
+        v = x < v ? x : v;
+    }
+    return v;
 }
 
 __device__ __forceinline__ unsigned long long rotr64(unsigned long long x, int r) {
@@ -1936,9 +2016,11 @@ __device__ __forceinline__ int bt_walk(const int32_t *__restrict__ hdr2, const u
 // Forward replay of the edit operations: match runs by greedy extension over the 2-bit packed sequences in LDS, runs merged
 // like lm_wfa_backtrace's push, alignment statistics of the M-trimmed run list (lib-index-search.go:2278-2302) and the
 // BLAST-style score (lib-index-search-util.go:260-304) accumulated on the way; runs stored only when `ops` is given.
-__device__ __forceinline__ void bt_replay(const uint8_t *__restrict__ opseq, int nops, const uint32_t *Qp, const uint32_t *Tp,
+template <bool WIN>
+__device__ __forceinline__ void bt_replay(const uint8_t *__restrict__ opseq, int nops, WfaWin &Q, WfaWin &T,
                                           int plen, int tlen, uint64_t *__restrict__ ops, int ops_cap, int lane, int s_final,
                                           LmWfaOut *out, int *blast) {
+    bool bad = false;
     int v = 0, h = 0;
     int cur_op = 0, cur_n = 0, run_q = 0, run_t = 0; // pending run and where it starts
     bool seen_m = false, overflow = false;
@@ -1982,18 +2064,16 @@ __device__ __forceinline__ void bt_replay(const uint8_t *__restrict__ opseq, int
             }
         }
     };
-    auto extend = [&]() {
-        int run = 0;
+    auto extend = [&]() { // v and h are the same in every lane: the windows simply follow them (forwards; the first call
+        int run = 0;      // brings them back from where the forward pass left them)
         while (true) {
-            const int rem = plen - v < tlen - h ? plen - v : tlen - h;
-            if (rem <= 0) break;
-            const uint32_t d = get16(Qp, v) ^ get16(Tp, h);
-            int nm = d ? (__clz(d) >> 1) : 16;
-            nm = nm < rem ? nm : rem;
+            if (plen - v <= 0 || tlen - h <= 0) break;
+            if (WIN && !(wfa_win_has(Q, v) && wfa_win_has(T, h))) wfa_win_move2(Q, v >> 4, T, h >> 4, lane, &bad, false);
+            const int nm = wfa_match_run<WIN>(Q, T, v, h);
             v += nm;
             h += nm;
             run += nm;
-            if (nm < 16) break;
+            if (nm < (WIN ? 32 : 16)) break;
         }
         return run;
     };
@@ -2079,6 +2159,10 @@ __device__ __forceinline__ void bt_replay(const uint8_t *__restrict__ opseq, int
     } else if (!seen_m) {
         out->status = 2;
     }
+    if (__ballot(bad) != 0ull) { // a byte that is not A/C/G/T was packed on the way: the byte-comparing kernel takes it
+        out->status = 3;
+        out->nops = 0;
+    }
 }
 
 // ---- k_wfa_lean<NC>: the LDS wavefront kernel ------------------------------------------------------------------------
@@ -2090,7 +2174,7 @@ __device__ __forceinline__ void bt_replay(const uint8_t *__restrict__ opseq, int
 // resident wavefronts of a CU share, has little else to do than the loop control). No global loads inside the score loop: both sequences are 2-bit
 // packed in LDS. Persistent wavefronts: each workgroup (one wave) owns a private header/arena region and pops problems
 // from a queue ordered by decreasing expected cost. Results are identical to lm_wfa_align.
-template <int NC>
+template <int NC, bool WIN>
 __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, int64_t n, const int32_t *__restrict__ todo,
                                                   int64_t ntodo, int32_t *__restrict__ hdr_pool, int64_t hdr_stride,
                                                   uint8_t *__restrict__ arena_pool, int64_t arena_stride,
@@ -2109,8 +2193,9 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
     int32_t(*rD)[W] = (int32_t(*)[W])(ring_raw + 7 * W * 4);
     BtLds &btl = *(BtLds *)ring_raw;
     __shared__ unsigned int sh_x;
+    // WIN: the two sequence windows; otherwise both whole packed sequences in dynamic LDS (seq_words + 1 words each)
+    __shared__ uint32_t qwin_buf[WIN ? WFA_WINW + 2 : 1], twin_buf[WIN ? WFA_WINW + 2 : 1];
     extern __shared__ uint32_t seq_lds[];
-    uint32_t *Qp = seq_lds, *Tp = seq_lds + seq_words + 1;
     const int lane = threadIdx.x;
     // per resident wavefront: {first diagonal, row offset} per even score, and the backtrace bytes (one per cell)
     int32_t *hdr2 = hdr_pool + (int64_t)blockIdx.x * hdr_stride;
@@ -2145,18 +2230,29 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
         // has drifted (chunks without a valid cell are skipped with a scalar branch)
         const int koff = 32 - (ak >= -40 && ak <= 40 ? ak / 2 : 0);
         int status = 0;
-        LDS_WAVE_SYNC(); // the previous alignment is done with the packed sequences and the ring
-        {
+        LDS_WAVE_SYNC(); // the previous alignment is done with the sequence windows and the ring
+        bool bad = false;  // a non-ACGT byte was packed (checked when the alignment ends: the result is discarded)
+        WfaWin Q, T;
+        Q.buf = WIN ? qwin_buf : seq_lds;
+        Q.src = w.q;
+        Q.len = plen;
+        Q.w0 = 0;
+        T.buf = WIN ? twin_buf : seq_lds + seq_words + 1;
+        T.src = w.t;
+        T.len = tlen;
+        T.w0 = 0;
+        if (WIN) {
+            wfa_win_move2(Q, 0, T, 0, lane, &bad, true);
+        } else {
             const int qw = (plen + 15) >> 4, tw = (tlen + 15) >> 4;
             if (qw > seq_words || tw > seq_words) {
                 status = 3;
             } else {
-                bool bad = false;
-                for (int j = lane; j < qw; j += 64) Qp[j] = pack16(w.q + 16 * j, plen - 16 * j, &bad);
-                for (int j = lane; j < tw; j += 64) Tp[j] = pack16(w.t + 16 * j, tlen - 16 * j, &bad);
+                for (int j = lane; j < qw; j += 64) Q.buf[j] = pack16(w.q + 16 * j, plen - 16 * j, &bad);
+                for (int j = lane; j < tw; j += 64) T.buf[j] = pack16(w.t + 16 * j, tlen - 16 * j, &bad);
                 if (lane == 0) {
-                    Qp[qw] = 0;
-                    Tp[tw] = 0;
+                    Q.buf[qw] = 0;
+                    T.buf[tw] = 0;
                 }
                 if (__ballot(bad) != 0ull) status = 3;
             }
@@ -2211,39 +2307,96 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                 bool inr[NC];
                 int32_t off[NC];
                 bool fin = false;
+                // Extension as wave-uniform loops (ballot) with per-lane predication by arithmetic: far less exec-mask
+                // bookkeeping on the scalar unit than per-lane while loops.
+                if (!WIN) {
 #pragma unroll
-                for (int c = 0; c < NC; c++) {
-                    const int slot = lane + 64 * c;
-                    const int j = (slot - koff - alo) & (W - 1);
-                    const int k = alo + j; // this cell's diagonal at score s
-                    kc[c] = k;
-                    jc[c] = j;
-                    inr[c] = false;
-                    off[c] = LM_NULL_OFF;
-                    if (!chunk_has(c, mlo[0], mhi[0])) continue;
-                    inr[c] = (uint32_t)(k - mlo[0]) <= (uint32_t)(mhi[0] - mlo[0]);
-                    int32_t o = rM[ms][slot];
-                    const bool act = inr[c] && o >= 0;
-                    // extension as a wave-uniform loop (ballot) with per-lane predication by arithmetic: far less
-                    // exec-mask bookkeeping on the scalar unit than a per-lane while loop
-                    int v = act ? o - k : 0, h = act ? o : 0;
-                    bool ext = act;
-                    while (__ballot(ext) != 0ull) {
-                        int rem = plen - v < tlen - h ? plen - v : tlen - h;
-                        const uint32_t d = get16(Qp, v) ^ get16(Tp, h);
-                        int nm = d ? (__clz(d) >> 1) : 16;
-                        nm = nm < rem ? nm : rem;
-                        nm = (ext && nm > 0) ? nm : 0;
-                        v += nm;
-                        h += nm;
-                        ext = nm == 16;
+                    for (int c = 0; c < NC; c++) {
+                        const int slot = lane + 64 * c;
+                        const int j = (slot - koff - alo) & (W - 1);
+                        const int k = alo + j; // this cell's diagonal at score s
+                        kc[c] = k;
+                        jc[c] = j;
+                        inr[c] = false;
+                        off[c] = LM_NULL_OFF;
+                        if (!chunk_has(c, mlo[0], mhi[0])) continue;
+                        inr[c] = (uint32_t)(k - mlo[0]) <= (uint32_t)(mhi[0] - mlo[0]);
+                        int32_t o = rM[ms][slot];
+                        const bool act = inr[c] && o >= 0;
+                        int v = act ? o - k : 0, h = act ? o : 0;
+                        bool ext = act;
+                        while (__ballot(ext) != 0ull) { // 16 bases per pass from the whole packed sequences
+                            const int run = wfa_match_run<false>(Q, T, v, h);
+                            const int nm = ext ? run : 0;
+                            v += nm;
+                            h += nm;
+                            ext = nm == 16;
+                        }
+                        if (act) {
+                            o = h;
+                            rM[ms][slot] = o;
+                        }
+                        off[c] = o;
+                        fin = fin || (inr[c] && k == ak && o >= tlen);
                     }
-                    if (act) {
-                        o = h;
-                        rM[ms][slot] = o;
+                } else {
+                    uint32_t extm = 0; // bit c: this lane's cell of chunk c is still being extended
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+                        const int slot = lane + 64 * c;
+                        const int j = (slot - koff - alo) & (W - 1);
+                        const int k = alo + j; // this cell's diagonal at score s
+                        kc[c] = k;
+                        jc[c] = j;
+                        inr[c] = false;
+                        off[c] = LM_NULL_OFF;
+                        if (!chunk_has(c, mlo[0], mhi[0])) continue;
+                        inr[c] = (uint32_t)(k - mlo[0]) <= (uint32_t)(mhi[0] - mlo[0]);
+                        const int32_t o = rM[ms][slot];
+                        off[c] = o;
+                        if (inr[c] && o >= 0) extm |= 1u << c;
                     }
-                    off[c] = o;
-                    fin = fin || (inr[c] && k == ak && o >= tlen);
+                    // 32 bases per pass from the sequence windows; a cell outside a window waits, and once nobody inside
+                    // extends any more both windows move to the smallest waiting positions (rare: one move per ~2900 bases
+                    // of progress; ONE inlined copy of the move)
+                    while (true) {
+#pragma unroll
+                        for (int c = 0; c < NC; c++) {
+                            if (!chunk_has(c, mlo[0], mhi[0])) continue;
+                            bool ext = ((extm >> c) & 1u) != 0;
+                            int h = ext ? off[c] : 0, v = ext ? h - kc[c] : 0;
+                            while (true) {
+                                const bool in = wfa_win_has(Q, v) && wfa_win_has(T, h);
+                                if (__ballot(ext && in) == 0ull) break;
+                                // (read by every lane - the slots are masked, any position is a valid LDS address - so that
+                                // the compiler has no branch to build around the LDS loads)
+                                const int run = wfa_match_run<true>(Q, T, v, h);
+                                const int nm = (ext && in) ? run : 0;
+                                v += nm;
+                                h += nm;
+                                ext = ext && (!in || nm == 32);
+                            }
+                            if ((extm >> c) & 1u) off[c] = h;
+                            if (!ext) extm &= ~(1u << c);
+                        }
+                        if (__ballot(extm != 0u) == 0ull) break;
+                        int mv = 2147483647, mh = 2147483647;
+#pragma unroll
+                        for (int c = 0; c < NC; c++) {
+                            const bool wt = ((extm >> c) & 1u) != 0;
+                            const int h = off[c], v = off[c] - kc[c];
+                            mh = wt && h < mh ? h : mh;
+                            mv = wt && v < mv ? v : mv;
+                        }
+                        mv = wave_min_i32_slow(mv);
+                        mh = wave_min_i32_slow(mh);
+                        wfa_win_move2(Q, mv >> 4, T, mh >> 4, lane, &bad, false);
+                    }
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+                        if (inr[c] && off[c] >= 0) rM[ms][lane + 64 * c] = off[c];
+                        fin = fin || (inr[c] && kc[c] == ak && off[c] >= tlen);
+                    }
                 }
                 done = __ballot(fin) != 0ull;
                 if (!done && mhi[0] - mlo[0] + 1 >= 10) { // wf-adaptive(10, 50)
@@ -2426,6 +2579,7 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                 rD[is][slot] = (uint32_t)(k - dlo[0]) <= spd ? vdel[c] : LM_NULL_OFF;
             }
         }
+        if (status == 0 && __ballot(bad) != 0ull) status = 3; // not plain ACGT: the byte-comparing kernel takes it
         __syncthreads(); // the backtrace reads what every lane stored to global memory
         WfaOut o;
         o.blast_score = 0;
@@ -2447,7 +2601,7 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                 o.r.qbegin = o.r.qend = o.r.tbegin = o.r.tend = 0;
                 o.r.align_len = o.r.matches = o.r.gaps = o.r.gap_regions = 0;
             } else {
-                bt_replay(bt + arena_stride - 16 - nops, nops, Qp, Tp, plen, tlen, want_ops ? ops_pool + w.ops_off : nullptr,
+                bt_replay<WIN>(bt + arena_stride - 16 - nops, nops, Q, T, plen, tlen, want_ops ? ops_pool + w.ops_off : nullptr,
                           w.ops_cap, lane, s, &o.r, &o.blast_score);
             }
         }
@@ -2619,41 +2773,33 @@ void launch_extend(hipStream_t st, const HspIn *hsps, int64_t n, const uint8_t *
                        (LmM128 *)rows_pool, rstart_pool, out);
     hipLaunchKernelGGL(k_extend_fin, dim3(grid_for(n, 256)), dim3(256), 0, st, hsps, n, out);
 }
-static int resident_blocks_of(const void *kern, int device, int seq_words) {
+// the kernel instantiations: ring width x (whole sequences in LDS | sliding windows)
+typedef void (*WfaLeanFn)(const WfaIn *, int64_t, const int32_t *, int64_t, int32_t *, int64_t, uint8_t *, int64_t, uint64_t *,
+                          unsigned int *, int, int, WfaOut *);
+static WfaLeanFn wfa_lean_fn(int nc, bool win) {
+    switch (nc) {
+    case 16: return win ? k_wfa_lean<16, true> : k_wfa_lean<16, false>;
+    case 8: return win ? k_wfa_lean<8, true> : k_wfa_lean<8, false>;
+    case 4: return win ? k_wfa_lean<4, true> : k_wfa_lean<4, false>;
+    case 1: return win ? k_wfa_lean<1, true> : k_wfa_lean<1, false>;
+    default: return win ? k_wfa_lean<2, true> : k_wfa_lean<2, false>;
+    }
+}
+static size_t wfa_dyn_lds(int seq_words, bool win) { // two packed sequences with one padding word each (+2: the predicated
+    return win ? 0 : (size_t)(2 * (seq_words + 1) + 2) * sizeof(uint32_t); // extension may read one word past)
+}
+int wfa_resident_blocks(int device, int seq_words, int nc, bool win) {
     int nb = 0, cus = 0;
-    size_t dyn = (size_t)(2 * (seq_words + 1) + 2) * sizeof(uint32_t);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64, dyn) != hipSuccess || nb < 1) nb = 8;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)wfa_lean_fn(nc, win), 64, wfa_dyn_lds(seq_words, win)) != hipSuccess || nb < 1)
+        nb = 8;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
     return nb * cus;
 }
-int wfa_resident_blocks(int device, int seq_words, int nc) {
-    return resident_blocks_of(nc == 16  ? (const void *)k_wfa_lean<16>
-                              : nc == 8 ? (const void *)k_wfa_lean<8>
-                              : nc == 4 ? (const void *)k_wfa_lean<4>
-                              : nc == 1 ? (const void *)k_wfa_lean<1>
-                                        : (const void *)k_wfa_lean<2>,
-                              device, seq_words);
-}
 void launch_wfa(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks,
                 int32_t *hdr_pool, int64_t hdr_stride, uint8_t *arena_pool, int64_t arena_stride, uint64_t *ops_pool,
-                unsigned int *queue, int seq_words, int want_ops, WfaOut *out, int nc) {
-    // two packed sequences with one padding word each, +2 words: the predicated extension may read one word past
-    size_t dyn = (size_t)(2 * (seq_words + 1) + 2) * sizeof(uint32_t);
-    if (nc == 16)
-        hipLaunchKernelGGL(k_wfa_lean<16>, dim3(nblocks), dim3(64), dyn, st, in, n, todo, ntodo, hdr_pool, hdr_stride, arena_pool,
-                           arena_stride, ops_pool, queue, seq_words, want_ops, out);
-    else if (nc == 8)
-        hipLaunchKernelGGL(k_wfa_lean<8>, dim3(nblocks), dim3(64), dyn, st, in, n, todo, ntodo, hdr_pool, hdr_stride, arena_pool,
-                           arena_stride, ops_pool, queue, seq_words, want_ops, out);
-    else if (nc == 4)
-        hipLaunchKernelGGL(k_wfa_lean<4>, dim3(nblocks), dim3(64), dyn, st, in, n, todo, ntodo, hdr_pool, hdr_stride, arena_pool,
-                           arena_stride, ops_pool, queue, seq_words, want_ops, out);
-    else if (nc == 1)
-        hipLaunchKernelGGL(k_wfa_lean<1>, dim3(nblocks), dim3(64), dyn, st, in, n, todo, ntodo, hdr_pool, hdr_stride, arena_pool,
-                           arena_stride, ops_pool, queue, seq_words, want_ops, out);
-    else
-        hipLaunchKernelGGL(k_wfa_lean<2>, dim3(nblocks), dim3(64), dyn, st, in, n, todo, ntodo, hdr_pool, hdr_stride, arena_pool,
-                           arena_stride, ops_pool, queue, seq_words, want_ops, out);
+                unsigned int *queue, int seq_words, int want_ops, WfaOut *out, int nc, bool win) {
+    hipLaunchKernelGGL(wfa_lean_fn(nc, win), dim3(nblocks), dim3(64), wfa_dyn_lds(seq_words, win), st, in, n, todo, ntodo, hdr_pool,
+                       hdr_stride, arena_pool, arena_stride, ops_pool, queue, seq_words, want_ops, out);
 }
 void launch_wfa_wide(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int32_t *hdr_pool,
                      int32_t *arena_pool, uint64_t *ops_pool, WfaOut *out) {

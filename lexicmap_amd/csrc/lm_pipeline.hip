@@ -1313,7 +1313,7 @@ struct AlignCtx {
         ~LeanCtx() {
             if (st) (void)hipStreamDestroy(st);
         }
-    } lean[4];
+    } lean[LM_WFA_CLASSES];
     // the global-memory WFA fallback runs beside the LDS passes of the shorter length classes: own stream and buffers
     struct WideCtx {
         hipStream_t st = nullptr;
@@ -1698,21 +1698,24 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
     sync(ix); // the class streams read the descriptors
     std::vector<int32_t> fb_items, fb_level; // what leaves the LDS kernels, with its starting scratch level
     std::mutex fb_mu;
-    // length classes (sequence words of 16 bases); within a class the queue keeps the longest-expected-first order
-    const int bounds[4] = {128, 512, 2048, 4096};
-    std::vector<int32_t> cls[4];
-    int cw[4] = {1, 1, 1, 1};
-    int64_t cl[4] = {1, 1, 1, 1}, cs[4] = {0, 0, 0, 0};
+    // length classes (sequence words of 16 bases): they pick the ring width a problem starts with, whether the kernel keeps
+    // the whole packed sequences in LDS or reads them through sliding windows (lm_tune::wfa_win), and keep the few long
+    // alignments of a round off the queue of the many short ones.  The last class (beyond 65 kb: what the whole-sequence
+    // kernel cannot hold) is open-ended and always windowed.  Within a class the queue keeps the longest-expected-first order
+    constexpr int NCLS = LM_WFA_CLASSES;
+    const int bounds[NCLS - 1] = {128, 512, 2048, 4096};
+    std::vector<int32_t> cls[NCLS];
+    int cw[NCLS];
+    int64_t cl[NCLS], cs[NCLS];
+    for (int c = 0; c < NCLS; c++) {
+        cw[c] = 1;
+        cl[c] = 1;
+        cs[c] = 0;
+    }
     for (int32_t i : order) {
         const int wds = (std::max(in[i].qlen, in[i].tlen) + 15) / 16;
         int c = 0;
-        while (c < 4 && wds > bounds[c]) c++;
-        if (c == 4) { // longer than the LDS buffers
-            fb_items.push_back(i);
-            fb_level.push_back(2);
-            retries++;
-            continue;
-        }
+        while (c < NCLS - 1 && wds > bounds[c]) c++;
         cls[c].push_back(i);
         cw[c] = std::max(cw[c], wds);
         const int64_t L = (int64_t)in[i].qlen + in[i].tlen;
@@ -1722,34 +1725,34 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
         const double dv = est_div ? (double)(*est_div)[i] : 0.12;
         cs[c] = std::max<int64_t>(cs[c], (int64_t)(5.0 * (dv + 0.01) * (double)L) + 2048);
     }
-    int first_nc[4] = {2, 2, 4, 8};
-    if (const char *e = getenv("LM_WFA_FIRST_NC")) { // experiment hook: starting widths of the four classes, e.g. "1,1,4,8"
-        int v[4];
-        if (sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4)
-            for (int c = 0; c < 4; c++)
-                if (v[c] == 1 || v[c] == 2 || v[c] == 4 || v[c] == 8 || v[c] == 16) first_nc[c] = v[c];
+    int first_nc[NCLS];
+    bool win[NCLS];
+    for (int c = 0; c < NCLS; c++) {
+        first_nc[c] = ix->tune.wfa_first_nc[c];
+        win[c] = ix->tune.wfa_win[c] != 0 || c == NCLS - 1;
     }
-    // scratch of the four classes side by side: what each would like (resident wavefronts x expected backtrace bytes of its
+    // scratch of the classes side by side: what each would like (resident wavefronts x expected backtrace bytes of its
     // longest problem), scaled down together when that exceeds the lean share of the budget
-    int64_t want[4], share[4];
+    int64_t want[NCLS], share[NCLS];
     int64_t want_tot = 0;
-    for (int c = 0; c < 4; c++) {
+    for (int c = 0; c < NCLS; c++) {
         const int64_t m = (int64_t)cls[c].size();
         const int64_t smax = std::min<int64_t>(8 * cl[c] + 64, cs[c]);
         const int64_t per = (smax / 2 + 2) * 64 * first_nc[c] + 2 * cl[c] + 4096 + (smax / 2 + 4) * 16;
-        want[c] = m == 0 ? 0 : std::min<int64_t>(m, wfa_resident_blocks(ix->device, cw[c], first_nc[c])) * per * 9 / 8;
+        want[c] = m == 0 ? 0 : std::min<int64_t>(m, wfa_resident_blocks(ix->device, cw[c], first_nc[c], win[c])) * per * 9 / 8;
         want_tot += want[c];
     }
-    for (int c = 0; c < 4; c++)
+    for (int c = 0; c < NCLS; c++)
         share[c] = want_tot <= lean_budget ? std::max<int64_t>(want[c], (int64_t)64 << 20)
                                            : std::max<int64_t>((int64_t)((double)want[c] / (double)want_tot * (double)lean_budget), (int64_t)64 << 20);
-    // one launch of the persistent LDS kernel per length class and ring width: the packed sequences live in LDS, so the
-    // resident wavefronts per CU are set by the longest problem of the launch (gene-sized HSPs: 28 per CU, 50-kb reads: 3-5)
-    auto persistent_pass = [&](AlignCtx::LeanCtx &lc, int64_t budget, const std::vector<int32_t> &items, int seq_words,
+    // one launch of the persistent LDS kernel per length class and ring width.  Resident wavefronts per CU: windowed, set by
+    // the ring width alone (128 diagonals: 23, 256: 14, 512: 7, 1024: 4); whole sequences in LDS, by the longest problem of
+    // the launch too (gene-sized HSPs at 128 diagonals: 28, 8-32 kb at 256: 6)
+    auto persistent_pass = [&](AlignCtx::LeanCtx &lc, int64_t budget, const std::vector<int32_t> &items, int seq_words, bool use_win,
                                int64_t lmax, int64_t s_expect, std::vector<int32_t> &too_wide, int nc) {
         const int64_t m = (int64_t)items.size();
         if (m == 0) return;
-        const int resident = wfa_resident_blocks(ix->device, seq_words, nc);
+        const int resident = wfa_resident_blocks(ix->device, seq_words, nc, use_win);
         int nblocks = (int)std::min<int64_t>(m, resident);
         // private scratch per resident wave: one backtrace byte per wavefront cell + 8 bytes per even score; never
         // more than the longest problem of the class is expected to need
@@ -1760,8 +1763,9 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
         bytes = std::min<int64_t>(bytes, 2000000000) & ~(int64_t)15;
         int64_t entries = std::min<int64_t>(smax / 2 + 4, bytes / 24 + 1024);
         if (getenv("LM_DEBUG"))
-            fprintf(stderr, "[lm +%.1f ms] wfa pass (%d diagonals) problems=%lld blocks=%d (resident %d) bytes/block=%lld scores=%lld seq_words=%d\n",
-                    now_ms() - g_dbg_t0, 64 * nc, (long long)m, nblocks, resident, (long long)bytes, (long long)(2 * entries), seq_words);
+            fprintf(stderr, "[lm +%.1f ms] wfa pass (%d diagonals, %s) problems=%lld blocks=%d (resident %d) bytes/block=%lld scores=%lld longest=%lld\n",
+                    now_ms() - g_dbg_t0, 64 * nc, use_win ? "windows" : "whole sequences", (long long)m, nblocks, resident, (long long)bytes,
+                    (long long)(2 * entries), (long long)lmax);
         lc.hdr_pool.ensure((size_t)(entries * 2) * nblocks + 16);
         lc.arena_pool.ensure((size_t)(bytes / 4) * nblocks + 16);
         lc.todo.ensure((size_t)m);
@@ -1769,10 +1773,11 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
         HIPCHK(hipMemcpyAsync(lc.todo.p, items.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice, S(ix)));
         HIPCHK(hipMemsetAsync(lc.queue.p, 0, sizeof(unsigned int), S(ix)));
         {
-            Prof p(ix, nc == 16 ? "k_wfa_lean1024" : nc == 8 ? "k_wfa_lean512" : nc == 4 ? "k_wfa_lean256" : nc == 1 ? "k_wfa_lean64" : "k_wfa_lean",
-                   wfa_bytes(in, items));
+            static const char *const names[2][5] = {{"k_wfa_lean64", "k_wfa_lean", "k_wfa_lean256", "k_wfa_lean512", "k_wfa_lean1024"},
+                                                    {"k_wfa_win64", "k_wfa_win128", "k_wfa_win256", "k_wfa_win512", "k_wfa_win1024"}};
+            Prof p(ix, names[use_win ? 1 : 0][nc == 16 ? 4 : nc == 8 ? 3 : nc == 4 ? 2 : nc == 1 ? 0 : 1], wfa_bytes(in, items));
             launch_wfa(S(ix), a.wfa_in.p, n, lc.todo.p, m, nblocks, lc.hdr_pool.p, entries * 2, (uint8_t *)lc.arena_pool.p, bytes,
-                       a.ops_pool.p, lc.queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc);
+                       a.ops_pool.p, lc.queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc, use_win);
         }
         sync(ix);
         // this pass's results: the records of its items (other classes write theirs into the same array meanwhile)
@@ -1811,7 +1816,7 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
         std::vector<int32_t> cur = cls[c], next;
         for (int nc = first_nc[c]; nc <= 16 && !cur.empty(); nc *= 2) {
             next.clear();
-            persistent_pass(lc, share[c], cur, cw[c], cl[c], cs[c], next, nc);
+            persistent_pass(lc, share[c], cur, cw[c], win[c], cl[c], cs[c], next, nc);
             cur.swap(next);
         }
         std::lock_guard<std::mutex> l(fb_mu);
@@ -1831,7 +1836,6 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
             items.swap(fb_items);
             level.swap(fb_level);
         }
-        if (!a.wide.st) HIPCHK(hipStreamCreate(&a.wide.st));
         wide_thread = std::thread([&, items, level]() {
             try {
                 HIPCHK(hipSetDevice(ix->device));
@@ -1849,12 +1853,15 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
     };
     // the classes side by side, the long ones first (their wavefronts should all be resident from the start); the caller's
     // thread takes the shortest class on its own stream
-    std::thread cth[4];
-    std::exception_ptr cerr[4];
-    const bool serial = getenv("LM_WFA_SERIAL") != nullptr; // debugging aid: one class after the other
-    for (int c = 3; c >= 1; c--) {
+    // every stream exists before the first thread starts: a failing hipStreamCreate must not unwind past joinable threads
+    for (int c = NCLS - 1; c >= 1; c--)
+        if (!cls[c].empty() && !a.lean[c].st) HIPCHK(hipStreamCreate(&a.lean[c].st));
+    if (!a.wide.st) HIPCHK(hipStreamCreate(&a.wide.st));
+    std::thread cth[NCLS];
+    std::exception_ptr cerr[NCLS];
+    const bool serial = ix->tune.wfa_serial; // exclusive kernel timings: one class after the other
+    for (int c = NCLS - 1; c >= 1; c--) {
         if (cls[c].empty()) continue;
-        if (!a.lean[c].st) HIPCHK(hipStreamCreate(&a.lean[c].st));
         cth[c] = std::thread([&, c]() {
             try {
                 HIPCHK(hipSetDevice(ix->device));
@@ -1874,21 +1881,20 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
     std::exception_ptr err0;
     try {
         class_chain(0);
-        for (int c = 3; c >= 2; c--)
+        for (int c = NCLS - 1; c >= 2; c--)
             if (cth[c].joinable()) cth[c].join();
         start_wide(); // the long classes are done: their leftovers run beside what is left of the short classes
     } catch (...) {
         err0 = std::current_exception();
     }
-    for (int c = 3; c >= 1; c--)
+    for (int c = NCLS - 1; c >= 1; c--)
         if (cth[c].joinable()) cth[c].join();
     if (wide_thread.joinable()) wide_thread.join();
     if (err0) std::rethrow_exception(err0);
-    for (int c = 1; c < 4; c++)
+    for (int c = 1; c < NCLS; c++)
         if (cerr[c]) std::rethrow_exception(cerr[c]);
     if (wide_err) std::rethrow_exception(wide_err);
     if (!fb_items.empty()) { // leftovers of the short classes (rare): same fallback, on this thread's stream
-        if (!a.wide.st) HIPCHK(hipStreamCreate(&a.wide.st));
         wide_run(fb_items, fb_level, a.wide);
     }
     a.stats->wfa_retries += retries.load();
@@ -2020,7 +2026,7 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
     std::exception_ptr prod_err;
     double ms_pseudo = 0;
     const int64_t total_window = r1 > r0 ? tasks_h[r1 - 1].woff + tasks_h[r1 - 1].wlen - tasks_h[r0].woff : 0;
-    const bool pipelined = total_window > max_window_bytes && !getenv("LM_NO_PIPELINE");
+    const bool pipelined = total_window > max_window_bytes && !ix->tune.no_pipeline;
     const int lane = tls_lane;
     auto producer = [&]() {
         try {

@@ -12,9 +12,12 @@ import sys
 
 
 def short(name):
-    m = re.search(r"lm::(k_[a-z0-9_]+)(?:<(\d+)>)?", name)
+    m = re.search(r"lm::(k_[a-z0-9_]+)(?:<(\d+)(?:, *(true|false|\(bool\)[01]|[01]))?>)?", name)
     if m:
-        if m.group(1) == "k_wfa_lean" and m.group(2):  # the names bench.py reports: diagonals of the ring, 128 = plain
+        if m.group(1) == "k_wfa_lean" and m.group(2):  # the names bench.py reports: k_wfa_lean<NC, WIN> -> diagonals of the ring
+            win = (m.group(3) or "").replace("(bool)", "") in ("true", "1")  # (128 = plain); WIN = sliding sequence windows
+            if win:
+                return "k_wfa_win" + {"1": "64", "2": "128", "4": "256", "8": "512", "16": "1024"}.get(m.group(2), m.group(2))
             return "k_wfa_lean" + {"1": "64", "2": "", "4": "256", "8": "512", "16": "1024"}.get(m.group(2), m.group(2))
         return m.group(1)
     m = re.search(r"(radix_sort_\w+|segmented_radix_sort\w*|scan_impl|reduce_by_key\w*|merge_sort\w*|init_lookback\w*)", name)
