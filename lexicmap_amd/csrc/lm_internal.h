@@ -290,10 +290,12 @@ struct lm_tune {
     int wfa_first_nc[LM_WFA_CLASSES] = {2, 2, 4, 8, 8};
     int wfa_win[LM_WFA_CLASSES] = {0, 0, 1, 0, 1};
     int pa_seg_by_group = 1; // candidate segments by task group + XCD-local k_pa_search (LM_PA_SEG_BY_WAVE=1: by wavefront)
+    FILE *wfa_dump = nullptr; // LM_DEBUG_WFA_DUMP=<file>: one line per WFA problem and pass (width, status, lengths, estimate, score)
     int wfa_serial = 0;      // LM_WFA_SERIAL=1: the WFA length classes one after the other (exclusive kernel timings)
     int no_pipeline = 0;     // LM_NO_PIPELINE=1: no pseudo-alignment producer beside extend / WFA (exclusive kernel timings)
     lm_tune() {
         wfa_serial = getenv("LM_WFA_SERIAL") != nullptr;
+        if (const char *e = getenv("LM_DEBUG_WFA_DUMP")) wfa_dump = fopen(e, "a");
         if (const char *e = getenv("LM_WFA_FIRST_NC")) {
             int v[LM_WFA_CLASSES];
             if (sscanf(e, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]) == LM_WFA_CLASSES)

@@ -2300,9 +2300,22 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
             const int c0 = 64 * c, c1 = 64 * c + 63;
             return (s0 <= c1 && s1 >= c0) || (s1 >= W && s1 - W >= c0);
         };
+        // the same for all chunks at once (bit c), a dozen scalar instructions per range instead of a dozen per chunk and
+        // loop: the wide rings (8 / 16 chunks, of which a wavefront touches two to eight) spent more scalar time deciding
+        // which chunks to skip than on anything else
+        auto chunk_mask = [&](int lo_, int hi_) -> uint32_t {
+            if (NC <= 2) return 0xffffffffu; // (chunk_has is used there)
+            const int s0 = (lo_ + koff) & (W - 1), s1 = s0 + (hi_ - lo_);
+            const int cf = s0 >> 6, cl = (s1 >> 6) < NC - 1 ? (s1 >> 6) : NC - 1;
+            uint32_t m = ((2u << (cl - cf)) - 1u) << cf;
+            if (s1 >= W) m |= (2u << ((s1 - W) >> 6)) - 1u;
+            return (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
+        };
+        auto chunk_on = [&](uint32_t cm, int c, int lo_, int hi_) { return NC <= 2 ? chunk_has(c, lo_, hi_) : ((cm >> c) & 1u) != 0; };
         while (status == 0) {
             bool done = false;
             if (mlo[0] <= mhi[0]) {
+                const uint32_t cmx = chunk_mask(mlo[0], mhi[0]);
                 int kc[NC], jc[NC];
                 bool inr[NC];
                 int32_t off[NC];
@@ -2319,7 +2332,7 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                         jc[c] = j;
                         inr[c] = false;
                         off[c] = LM_NULL_OFF;
-                        if (!chunk_has(c, mlo[0], mhi[0])) continue;
+                        if (!chunk_on(cmx, c, mlo[0], mhi[0])) continue;
                         inr[c] = (uint32_t)(k - mlo[0]) <= (uint32_t)(mhi[0] - mlo[0]);
                         int32_t o = rM[ms][slot];
                         const bool act = inr[c] && o >= 0;
@@ -2350,7 +2363,7 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                         jc[c] = j;
                         inr[c] = false;
                         off[c] = LM_NULL_OFF;
-                        if (!chunk_has(c, mlo[0], mhi[0])) continue;
+                        if (!chunk_on(cmx, c, mlo[0], mhi[0])) continue;
                         inr[c] = (uint32_t)(k - mlo[0]) <= (uint32_t)(mhi[0] - mlo[0]);
                         const int32_t o = rM[ms][slot];
                         off[c] = o;
@@ -2362,7 +2375,7 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                     while (true) {
 #pragma unroll
                         for (int c = 0; c < NC; c++) {
-                            if (!chunk_has(c, mlo[0], mhi[0])) continue;
+                            if (!chunk_on(cmx, c, mlo[0], mhi[0])) continue;
                             bool ext = ((extm >> c) & 1u) != 0;
                             int h = ext ? off[c] : 0, v = ext ? h - kc[c] : 0;
                             while (true) {
@@ -2517,6 +2530,7 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
             }
             const int r4 = ms >= 2 ? ms - 2 : ms + 3, r8 = ms == 4 ? 0 : ms + 1, r2 = is ^ 1; // rows of s-4, s-8, s-2
             LDS_WAVE_SYNC(); // the neighbours' extension results are in the ring
+            const uint32_t cmr = chunk_mask(lo, hi);
             int kk[NC];
             bool inr[NC];
             int32_t vins[NC], vdel[NC], vmx[NC];
@@ -2529,7 +2543,7 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                 kk[c] = k;
                 inr[c] = false;
                 vins[c] = vdel[c] = vmx[c] = LM_NULL_OFF;
-                if (!chunk_has(c, lo, hi)) continue;
+                if (!chunk_on(cmr, c, lo, hi)) continue;
                 inr[c] = k <= hi;
                 const int sm1 = (slot + W - 1) & (W - 1), sp1 = (slot + 1) & (W - 1);
                 int32_t a = rM[r8][sm1], b = rI[r2][sm1];

@@ -1712,6 +1712,12 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
         cl[c] = 1;
         cs[c] = 0;
     }
+    int first_nc[NCLS];
+    bool win[NCLS];
+    for (int c = 0; c < NCLS; c++) {
+        first_nc[c] = ix->tune.wfa_first_nc[c];
+        win[c] = ix->tune.wfa_win[c] != 0 || c == NCLS - 1;
+    }
     for (int32_t i : order) {
         const int wds = (std::max(in[i].qlen, in[i].tlen) + 15) / 16;
         int c = 0;
@@ -1724,12 +1730,6 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
         // factor two on top (what goes beyond reports a scratch overflow and is aligned by the fallback)
         const double dv = est_div ? (double)(*est_div)[i] : 0.12;
         cs[c] = std::max<int64_t>(cs[c], (int64_t)(5.0 * (dv + 0.01) * (double)L) + 2048);
-    }
-    int first_nc[NCLS];
-    bool win[NCLS];
-    for (int c = 0; c < NCLS; c++) {
-        first_nc[c] = ix->tune.wfa_first_nc[c];
-        win[c] = ix->tune.wfa_win[c] != 0 || c == NCLS - 1;
     }
     // scratch of the classes side by side: what each would like (resident wavefronts x expected backtrace bytes of its
     // longest problem), scaled down together when that exceeds the lean share of the budget
@@ -1787,6 +1787,13 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
         if (want_ops) d2h(ix, ops_tmp, a.ops_pool.p, (size_t)ops_tot);
         sync(ix);
         int64_t n3 = 0, n1 = 0;
+        if (ix->tune.wfa_dump) { // experiment log: what predicts the ring width a problem needs
+            std::lock_guard<std::mutex> l(fb_mu);
+            for (int32_t i : items)
+                fprintf(ix->tune.wfa_dump, "%d %d %d %d %.4f %d %d\n", 64 * nc, tmp[i].r.status, in[i].qlen, in[i].tlen,
+                        est_div ? (double)(*est_div)[i] : -1.0, tmp[i].r.score, (int)tmp[i].r.gaps);
+            fflush(ix->tune.wfa_dump);
+        }
         for (int32_t i : items) {
             int stt = tmp[i].r.status;
             n3 += stt == 3;
@@ -1810,7 +1817,11 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
     };
     // ring width by experience: alignments of tens of kb at ONT error rates run wavefronts of several hundred diagonals
     // under wf-adaptive(10,50) (all of the >= 32-kb class and two thirds of the 8-32-kb class outgrow 126), gene-sized ones
-    // stay below 126.  A pass that turns out too narrow returns status 3 and the next width takes over.
+    // stay below 126.  A pass that turns out too narrow returns status 3 and the next width takes over.  (The width a
+    // problem ends up needing is |tlen - qlen| + a few dozen diagonals - the wavefront must reach the final diagonal; of
+    // 78 000 c3-shaped problems exactly the ones with |tlen - qlen| >= 210..260 outgrew 254 diagonals, >= 505 outgrew 510 -
+    // but STARTING there was measured slower, 2.48 s vs 1.99 s per step: a failed narrow attempt costs little, the wide
+    // rings are slower per score and their LDS keeps the anchor filter's workgroups off the CUs.)
     auto class_chain = [&](int c) {
         AlignCtx::LeanCtx &lc = a.lean[c];
         std::vector<int32_t> cur = cls[c], next;
