@@ -33,6 +33,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PROFILE_ROUND = "r03"  # profiles/<round>_<workload>_pmc_*.json: the committed counter passes roofline.traffic is read from
+# instruction-issue peaks of the chip (MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, a wave64 VALU instruction issues over 2
+# cycles; ONE scalar unit per CU), wave-instructions per second at 2.4 GHz
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2
+SALU_ISSUE_PEAK = 256 * 2.4e9
 
 
 def log(*a):
@@ -45,7 +50,12 @@ def parse():
     p.add_argument("--steps", type=int, default=3)
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--workload", default=os.environ.get("LM_BENCH_WORKLOAD", "c3"),
-                   choices=["c3", "c2", "small", "tiny", "c3mini"])
+                   choices=["c3", "c2", "c4", "c5", "small", "tiny", "c3mini"])
+    p.add_argument("--shard-of", type=int, default=0,
+                   help="ONE process searches shard --shard-rank of an index sharded over this many GPUs (genome g on shard "
+                        "g %% N, global total_bases): what one rank of the N-GPU run does, measurable on one GPU; adds the "
+                        "host-timed lm_merge_sharded over N shards' worth of rows and a predicted N-GPU step (DESIGN.md 8)")
+    p.add_argument("--shard-rank", type=int, default=0)
     p.add_argument("--queries", type=int, default=0, help="override the number of queries")
     p.add_argument("--genomes", type=int, default=0, help="override the number of genomes")
     p.add_argument("--genome-len", type=int, default=0)
@@ -57,6 +67,8 @@ def parse():
     p.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                    help="only with --shard queries: weak = every GPU searches its own batch of the workload's size")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-exclusive-step", action="store_true",
+                   help="skip the extra serialised step (outside the timed region) that gives the exclusive kernel durations")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                    help="nccl = RCCL (one GPU per rank); gloo only to exercise the N>1 logic with ranks sharing a GPU")
@@ -76,6 +88,14 @@ WORKLOADS = {
     "c3": dict(genomes=100000, genome_len=2_000_000, families=1001, queries=10000, qlen=(5000, 50000), kind="reads"),
     # BASELINE.json configs[1]: 1k gene queries (1-2 kb) vs 10k synthetic 5-Mb genomes, index HBM-resident
     "c2": dict(genomes=10000, genome_len=5_000_000, families=100, queries=1000, qlen=(1000, 2000), kind="genes"),
+    # BASELINE.json configs[3]: plasmid/prophage queries (50-200 kb, circular) vs 1M genomes, index sharded over 4 MI355X.
+    # 800-kb genomes: a shard (250 000 genomes) is ~1.5e10 seeds = ~144 GB packed + 50 GB of 2-bit genomes of the 288 GB.
+    # One GPU runs ONE shard of it (--shard-of 4 --shard-rank r); the driver's 4-GPU run shards it over the ranks.
+    "c4": dict(genomes=1_000_000, genome_len=800_000, families=10007, queries=100, qlen=(50000, 200000), kind="circular",
+               shards=4),
+    # BASELINE.json configs[4]: AllTheBacteria-scale 1.9M genomes over 8 x 288 GB, mixed gene + read batch (90 % / 10 %)
+    "c5": dict(genomes=1_900_000, genome_len=800_000, families=19001, queries=10000, qlen=(1000, 2000), kind="mixed",
+               read_qlen=(5000, 50000), shards=8),
     # scaled-down shapes for development (NOT headline configs)
     "small": dict(genomes=200, genome_len=500_000, families=4, queries=1000, qlen=(1000, 2000), kind="genes"),
     "tiny": dict(genomes=24, genome_len=100_000, families=4, queries=64, qlen=(300, 1500), kind="genes"),
@@ -100,7 +120,7 @@ def pmc_traffic(kernel, workload):
     gfx950 FETCH_SIZE tallies 128-B read requests as 64 B for wide streaming reads (MI355X_MICROARCH.md, HBM), so the read
     part is a lower bound (at most 2x low).  Passes recorded on other sources are refused.  Returns (bytes|None, note)."""
     tot, found = 0.0, False
-    for fn, ctr in (("r02_%s_pmc_fetch.json" % workload, "FETCH_SIZE"), ("r02_%s_pmc_write.json" % workload, "WRITE_SIZE")):
+    for fn, ctr in (("%s_%s_pmc_fetch.json" % (PROFILE_ROUND, workload), "FETCH_SIZE"), ("%s_%s_pmc_write.json" % (PROFILE_ROUND, workload), "WRITE_SIZE")):
         try:
             doc = json.load(open(os.path.join(ROOT, "profiles", fn)))
         except (OSError, ValueError):
@@ -118,8 +138,8 @@ def pmc_traffic(kernel, workload):
             return None, "kernel not in the committed PMC pass"
         tot += best[1]["mean"] * 1024.0
         found = True
-    return (int(tot) if found else None), ("(FETCH_SIZE+WRITE_SIZE)*1024 from profiles/r02_%s_pmc_*.json (same sources); "
-                                           "read part is a lower bound on gfx950" % workload)
+    return (int(tot) if found else None), ("(FETCH_SIZE+WRITE_SIZE)*1024 from profiles/%s_%s_pmc_*.json (same sources); "
+                                           "read part is a lower bound on gfx950" % (PROFILE_ROUND, workload))
 
 
 def pmc_issue(kernel, workload):
@@ -128,7 +148,7 @@ def pmc_issue(kernel, workload):
     ALU), not by HBM; a CU issues at most one vector and one scalar instruction per cycle (four SIMDs, a wavefront's vector
     instruction occupies its SIMD for four cycles)"""
     try:
-        doc = json.load(open(os.path.join(ROOT, "profiles", "r02_%s_pmc_sq.json" % workload)))
+        doc = json.load(open(os.path.join(ROOT, "profiles", "%s_%s_pmc_sq.json" % (PROFILE_ROUND, workload))))
     except (OSError, ValueError):
         return None
     if doc.get("source_hash") != source_hash():
@@ -143,7 +163,7 @@ def pmc_issue(kernel, workload):
         return None
     v = best[1]
     out = {c.lower() + "_per_launch": int(v[c]["mean"]) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS") if c in v}
-    out["note"] = "profiles/r02_%s_pmc_sq.json (kernels serialised by the counter pass)" % workload
+    out["note"] = "profiles/%s_%s_pmc_sq.json (kernels serialised by the counter pass)" % (PROFILE_ROUND, workload)
     return out
 
 
@@ -265,10 +285,13 @@ def maybe_spawn(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
-def draw_query(np, synth, rng, seq, wl):
+def draw_query(np, synth, rng, seq, wl, as_read=False):
     """one synthetic query from genome bases `seq` (uint8 array)"""
-    if wl["kind"] == "reads":  # ONT-like: sub 2 %, ins 2 %, del 3 % (SURVEY.md §8d)
+    if wl["kind"] == "reads" or as_read:  # ONT-like: sub 2 %, ins 2 %, del 3 % (SURVEY.md §8d)
         q = synth.mutate(rng, seq, sub=0.02, ins=0.02, dele=0.03)
+    elif wl["kind"] == "circular":  # a plasmid / prophage: the region read from a random rotation point, lightly diverged
+        rot = int(rng.integers(0, len(seq)))
+        q = synth.mutate(rng, np.concatenate([seq[rot:], seq[:rot]]), sub=0.01, ins=0.002, dele=0.002)
     else:
         d = rng.random() * 0.10
         q = synth.mutate(rng, seq, sub=d, ins=d / 10, dele=d / 10)
@@ -303,7 +326,7 @@ def main():
     from lexicmap_amd import merge, synth
 
     if args.builder is None:
-        args.builder = "gpu" if args.workload in ("c2", "c3", "c3mini") else "oracle"
+        args.builder = "gpu" if args.workload in ("c2", "c3", "c4", "c5", "c3mini") else "oracle"
     wl = dict(WORKLOADS[args.workload])
     if args.queries:
         wl["queries"] = args.queries
@@ -322,14 +345,29 @@ def main():
     index_sharded = args.shard == "index" and world > 1
     if index_sharded:
         opt_kw = dict(shard_rank=rank, shard_count=world)
+    # one shard of an N-GPU run on this one GPU: c4 / c5 only exist sharded (a shard is what fits 288 GB)
+    if world == 1 and not args.shard_of and wl.get("shards"):
+        args.shard_of = wl["shards"]
+    shard_of = args.shard_of if (world == 1 and args.shard_of > 1) else 0
+    if shard_of:
+        if not (0 <= args.shard_rank < shard_of):
+            raise SystemExit("bench.py: --shard-rank must be in [0, --shard-of)")
+        if args.builder != "gpu":
+            raise SystemExit("bench.py: --shard-of needs the GPU builder")
+        opt_kw = dict(shard_rank=args.shard_rank, shard_count=shard_of)
+        args.no_cpu_baseline = True  # the CPU leg belongs to the N=1 line of the unsharded workloads
     gpu_built = args.builder == "gpu"
     weak = world > 1 and args.shard == "queries" and args.scaling == "weak"
     cpu_queries = None
     lo_len, hi_len = wl["qlen"]
 
-    def qlen_of(rng):
-        if wl["kind"] == "reads":  # log-uniform lengths
-            return int(np.exp(rng.uniform(np.log(lo_len), np.log(hi_len))))
+    def is_read(i):  # mixed batch (c5): every tenth query is an ONT-style read, the rest are genes
+        return wl["kind"] == "mixed" and i % 10 == 9
+
+    def qlen_of(rng, i=0):
+        if wl["kind"] == "reads" or is_read(i):  # log-uniform lengths
+            lo, hi = wl["read_qlen"] if is_read(i) else (lo_len, hi_len)
+            return int(np.exp(rng.uniform(np.log(lo), np.log(hi))))
         return int(rng.integers(lo_len, hi_len + 1))
 
     if gpu_built:
@@ -338,19 +376,23 @@ def main():
         gi = la.Index.synthetic(wl["genomes"], wl["genome_len"], wl["families"], seed=1000, max_div=0.10,
                                 options=la.api.default_options(**opt_kw), device=local_rank)
         nloc = gi.info()["genomes"]
-        nshard = world if index_sharded else 1
+        nshard = world if index_sharded else (shard_of or 1)
+        my_shard = rank if index_sharded else (args.shard_rank if shard_of else 0)
 
         def query_i(i, seed_base):
             """query number i of the batch: the same bases whatever the number of ranks; None on ranks that do not hold
-            its source genome (index sharding)"""
+            its source genome (index sharding).  --shard-of: the source is moved to the member of its residue class that
+            this shard holds (the family members on the other shards are what the other ranks would find)."""
             rng = np.random.default_rng([seed_base, i])
             g = int(rng.integers(0, wl["genomes"]))
-            L = min(qlen_of(rng), wl["genome_len"])
+            L = min(qlen_of(rng, i), wl["genome_len"])
             st = int(rng.integers(0, wl["genome_len"] - L + 1))
-            if g % nshard != (rank if index_sharded else 0):
+            if shard_of:
+                g = min(g - g % nshard + my_shard, (wl["genomes"] - 1 - my_shard) // nshard * nshard + my_shard)
+            if g % nshard != my_shard:
                 return None
             src = np.frombuffer(gi.fetch(g // nshard, st, L), dtype=np.uint8)
-            return ("q%05d" % i, draw_query(np, synth, rng, src, wl))
+            return ("q%05d" % i, draw_query(np, synth, rng, src, wl, as_read=is_read(i)))
 
         if weak:
             queries = [query_i(i, 2000 + rank) for i in range(wl["queries"])]  # this GPU's own batch
@@ -421,6 +463,8 @@ def main():
     info = gi.info()
     log("[rank %d] index ready in %.1f s: %s" % (rank, time.time() - t_setup, info))
 
+    if gpu_built and rank == 0:
+        log("[rank 0] %d queries drawn in %.1f s" % (len(queries), time.time() - t_setup))
     # queries of this rank
     if weak or index_sharded or world == 1:
         my = queries
@@ -471,12 +515,54 @@ def main():
         dt = float(tt.item())
     prof = gi.profile_get()
     gi.profile(False)
+    # One more step OUTSIDE the timed region with the kernels serialised (no overlapped streams): in the timed steps the WFA
+    # length classes, the anchor kernels of the next chunk and the fallback share the chip, so a kernel's HIP-event time there
+    # includes the time it spent waiting for issue slots; the roofline figures use the exclusive durations of this step.
+    prof_x = None
+    if rank == 0 and world == 1 and not args.no_exclusive_step:
+        gi.profile_exclusive(True)
+        gi.profile(True)
+        gi.profile_reset()
+        step()
+        torch.cuda.synchronize()
+        prof_x = {p["name"]: p for p in gi.profile_get()}
+        gi.profile(False)
+        gi.profile_exclusive(False)
     try:
         import resource
         log("[rank %d] peak host RSS %.1f GB after %d steps" % (rank, resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1048576.0,
                                                              args.steps + args.warmup))
     except Exception:
         pass
+    shard_model = None
+    if shard_of and rank == 0:
+        # What the N-GPU step adds on top of this shard's search: the row gather and lm_merge_sharded on rank 0.  The other
+        # shards' rows are emulated by re-keyed copies of this shard's rows (same number, other genomes), so the merge runs
+        # on a full N-shard row set; timed on the host.
+        base = rows_np.copy()
+        per_rank = []
+        for r in range(shard_of):
+            c = base.copy()
+            c["batch_genome"] = c["batch_genome"] + (np.uint64(r) << np.uint64(40))  # distinct genomes per emulated shard
+            per_rank.append(c)
+        t_m = time.time()
+        merged = merge.merge_sharded_c(per_rank)
+        merge_s = time.time() - t_m
+        row_bytes = int(base.dtype.itemsize) * len(base)
+        # gather to rank 0 over xGMI: (N-1) shards' rows into one GPU, ~153 GB/s per link (MI355X_MICROARCH.md), + D2H
+        gather_s = (shard_of - 1) * row_bytes / 153e9 + shard_of * row_bytes / 50e9
+        step_s0 = dt / args.steps
+        fe_ms = sum(v for k, v in stats.items() if k in ("ms_mask", "ms_lookup"))
+        shard_model = dict(shards=shard_of, shard_rank=args.shard_rank, shard_step_ms=round(step_s0 * 1e3, 3),
+                           replicated_front_end_ms=round(fe_ms, 3),
+                           rows_this_shard=int(len(base)), rows_merged=int(len(merged)), row_bytes_per_shard=row_bytes,
+                           merge_ms_host=round(merge_s * 1e3, 3), gather_ms_estimated=round(gather_s * 1e3, 3),
+                           predicted_step_ms=round((step_s0 + merge_s + gather_s) * 1e3, 3),
+                           predicted_queries_per_s=round(len(queries) / (step_s0 + merge_s + gather_s), 3),
+                           note="one shard measured on one GPU; predicted N-GPU step = this shard's step + gather (estimated "
+                                "from the row bytes) + host-timed lm_merge_sharded over N shards' worth of rows; the efficiency "
+                                "against the 1-GPU line is computed in DESIGN.md section 8, not here")
+        del merged, per_rank, base
     rows_total, aligned_total = int(len(rows_np)), int(rows_np["aligned_length"].sum())
 
     nq_total = len(queries) * (world if weak else 1)
@@ -486,91 +572,102 @@ def main():
         step_s = dt / args.steps
         kern = [p for p in prof if p["name"].startswith("k_")]
         kern.sort(key=lambda p: -p["total_ms"])
-        kernels = []
-        for p in kern:
+
+        def excl(name):
+            """(exclusive avg ms per launch, launches, bytes per launch) of the serialised extra step, or None"""
+            if not prof_x or name not in prof_x or not prof_x[name]["launches"]:
+                return None
+            q = prof_x[name]
+            return q["total_ms"] / q["launches"], q["launches"], q["bytes"] / q["launches"]
+
+        def entry(p):
             per_step_ms = p["total_ms"] / args.steps
             avg_ms = p["total_ms"] / max(p["launches"], 1)
-            gbs = (p["bytes"] / max(p["launches"], 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            kernels.append(dict(name=p["name"], launches=p["launches"], avg_ms=round(avg_ms, 4), ms_per_step=round(per_step_ms, 3),
-                                algorithmic_bytes_per_launch=int(p["bytes"] / max(p["launches"], 1)),
-                                achieved_GBs=round(gbs, 3), frac_of_hbm_peak=round(gbs / HBM_PEAK_GBS, 6)))
-        prims = [dict(name=p["name"], launches=p["launches"], avg_ms=round(p["total_ms"] / max(p["launches"], 1), 4),
-                      ms_per_step=round(p["total_ms"] / args.steps, 3))
-                 for p in sorted(prof, key=lambda p: -p["total_ms"]) if not p["name"].startswith("k_")]
+            alg = p["bytes"] / max(p["launches"], 1)
+            e = excl(p["name"])
+            ex_ms, ex_alg = (e[0], e[2]) if e else (None, None)
+            gbs = (ex_alg / (ex_ms * 1e-3) / 1e9) if e and ex_ms > 0 else (alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0)
+            return dict(name=p["name"], launches=p["launches"], avg_ms=round(avg_ms, 4), ms_per_step=round(per_step_ms, 3),
+                        exclusive_avg_ms=(round(ex_ms, 4) if e else None),
+                        exclusive_ms_per_step=(round(e[0] * e[1], 3) if e else None),
+                        algorithmic_bytes_per_launch=int(ex_alg if e else alg),
+                        achieved_GBs=round(gbs, 3), frac_of_hbm_peak=round(gbs / HBM_PEAK_GBS, 6))
+
+        kernels = [entry(p) for p in kern]
+        prims = [entry(p) for p in sorted(prof, key=lambda p: -p["total_ms"]) if not p["name"].startswith("k_")]
 
         def roof(pk):
+            """roofline entry of ONE kernel (instantiation): achieved = algorithmic bytes per launch / EXCLUSIVE launch
+            duration (serialised extra step; the co-scheduled duration of the timed steps is given beside it)"""
             avg_ms = pk["total_ms"] / max(pk["launches"], 1)
-            ach = (pk["bytes"] / max(pk["launches"], 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            e = excl(pk["name"])
+            dur_ms = e[0] if e else avg_ms
+            alg = e[2] if e else pk["bytes"] / max(pk["launches"], 1)
+            ach = alg / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
             tr, tn = pmc_traffic(pk["name"], args.workload)
-            alg = pk["bytes"] / max(pk["launches"], 1)
+            issue = pmc_issue(pk["name"], args.workload)
+            if issue and dur_ms > 0:
+                # the kernel's wave-instructions per second against what the chip can issue (MI355X_MICROARCH.md)
+                issue["issue_frac_valu"] = round(issue.get("sq_insts_valu_per_launch", 0) / (dur_ms * 1e-3) / VALU_ISSUE_PEAK, 4)
+                issue["issue_frac_salu"] = round(issue.get("sq_insts_salu_per_launch", 0) / (dur_ms * 1e-3) / SALU_ISSUE_PEAK, 4)
             return dict(bound="hbm", kernel=pk["name"], achieved=round(ach, 3), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(ach / HBM_PEAK_GBS, 6), traffic=tr, traffic_source=tn,
                         traffic_over_algorithmic=(round(tr / alg, 2) if tr and alg else None),
-                        traffic_GBs=(round(tr / (avg_ms * 1e-3) / 1e9, 1) if tr else None),
-                        algorithmic_bytes_per_launch=int(alg), avg_launch_ms=round(avg_ms, 4), launches=pk["launches"],
-                        instruction_issue=pmc_issue(pk["name"], args.workload))
+                        traffic_GBs=(round(tr / (dur_ms * 1e-3) / 1e9, 1) if tr else None),
+                        algorithmic_bytes_per_launch=int(alg), avg_launch_ms=round(dur_ms, 4),
+                        duration_kind=("exclusive (serialised extra step)" if e else "co-scheduled (timed steps)"),
+                        avg_launch_ms_coscheduled=round(avg_ms, 4), launches=pk["launches"], instruction_issue=issue)
 
-        # The dominant kernel: the instantiations of one kernel template count as one kernel (k_wfa_lean<NC> is launched at
-        # 128/256/512/1024 diagonals for the length classes of a round, side by side on four streams); its figures are the
-        # launch-weighted means over the instantiations, which stay listed one by one in kernels[].
+        # The dominant kernel = the single kernel (one instantiation of a template counts by itself) with the largest
+        # exclusive time per step; the other instantiations of its template are listed beside it, each with its own figures.
         def family(name):
-            return "k_wfa_lean" if name.startswith(("k_wfa_lean", "k_wfa_win")) else name
+            return "k_wfa" if name.startswith(("k_wfa_lean", "k_wfa_win")) else name
 
-        fam = {}
-        for pk in kern:
-            f = fam.setdefault(family(pk["name"]), dict(total_ms=0.0, members=[]))
-            f["total_ms"] += pk["total_ms"]
-            f["members"].append(pk)
+        def xtime(pk):
+            e = excl(pk["name"])
+            return e[0] * e[1] if e else pk["total_ms"] / args.steps
+
         roofline = None
-        if fam:
-            top = max(fam.items(), key=lambda kv: kv[1]["total_ms"])
-            mem = top[1]["members"]
-            if len(mem) == 1:
-                roofline = roof(mem[0])
-            else:
-                parts = [roof(m) for m in mem]
-                nl = sum(m["launches"] for m in mem)
-                tms = sum(m["total_ms"] for m in mem)
-                byt = sum(m["bytes"] for m in mem)
-                ach = byt / (tms * 1e-3) / 1e9 if tms > 0 else 0.0
-                have_tr = all(r["traffic"] for r in parts)
-                tr = int(sum(r["traffic"] * m["launches"] for r, m in zip(parts, mem)) / nl) if have_tr else None
-                issue = None
-                if all(r["instruction_issue"] for r in parts):
-                    issue = {k: int(sum(r["instruction_issue"][k] * m["launches"] for r, m in zip(parts, mem)) / nl)
-                             for k in parts[0]["instruction_issue"] if k != "note"}
-                    issue["note"] = parts[0]["instruction_issue"]["note"]
-                roofline = dict(bound="hbm", kernel=top[0] + "<NC> (%s)" % ", ".join(m["name"] for m in mem),
-                                achieved=round(ach, 3), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 6),
-                                traffic=tr, traffic_source=parts[0]["traffic_source"],
-                                traffic_over_algorithmic=(round(tr / (byt / nl), 2) if tr and byt else None),
-                                traffic_GBs=(round(tr / (tms / nl * 1e-3) / 1e9, 1) if tr else None),
-                                algorithmic_bytes_per_launch=int(byt / nl), avg_launch_ms=round(tms / nl, 4), launches=nl,
-                                instruction_issue=issue, instantiations=parts,
-                                note="bound by instruction issue (vector + scalar ALU), not by HBM: DESIGN.md section 4")
+        if kern:
+            top = max(kern, key=xtime)
+            roofline = roof(top)
+            sibs = [roof(m) for m in kern if m is not top and family(m["name"]) == family(top["name"])]
+            if sibs:
+                roofline["other_instantiations"] = sibs
+            if family(top["name"]) == "k_wfa":
+                roofline["note"] = ("integer wavefront recurrences out of LDS: bound by instruction issue (see instruction_issue: "
+                                    "the scalar unit first), not by HBM - DESIGN.md section 4")
         # the HBM-bound stage of the path (north_star: seed lookup against the in-HBM index): the search kernel and the
-        # whole stage (prep + sort + count + scan + emit) against the same SURVEY §8(d) bytes
+        # whole stage (prep + sort + count + scan + emit) against the same SURVEY 8(d) bytes
         roofline_lookup = None
         byname = {p["name"]: p for p in prof}
         if "k_lookup_count" in byname:
             roofline_lookup = roof(byname["k_lookup_count"])
-            stage_ms = sum(byname[n]["total_ms"] for n in ("k_lookup_prep", "sort_lookups", "k_lookup_count", "scan", "k_lookup_emit")
-                           if n in byname) / max(byname["k_lookup_count"]["launches"], 1)
-            stage_bytes = (byname["k_lookup_count"]["bytes"] + byname.get("k_lookup_emit", {"bytes": 0})["bytes"]) / \
-                max(byname["k_lookup_count"]["launches"], 1)
+            names = ("k_lookup_prep", "sort_lookups", "k_lookup_count", "scan", "k_lookup_emit")
+            nl = max(byname["k_lookup_count"]["launches"], 1)
+            if prof_x and all(n in prof_x for n in names if n in byname):
+                stage_ms = sum(prof_x[n]["total_ms"] for n in names if n in prof_x) / max(prof_x["k_lookup_count"]["launches"], 1)
+            else:
+                stage_ms = sum(byname[n]["total_ms"] for n in names if n in byname) / nl
+            stage_bytes = (byname["k_lookup_count"]["bytes"] + byname.get("k_lookup_emit", {"bytes": 0})["bytes"]) / nl
             roofline_lookup["stage_ms"] = round(stage_ms, 4)
             roofline_lookup["stage_frac"] = round(stage_bytes / (stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if stage_ms > 0 else None
-        # whole pipeline: sum of the algorithmic bytes of all kernels per step over the step time
-        alg_step = sum(p["bytes"] for p in kern) / args.steps
+        # whole pipeline: sum of the algorithmic bytes of all kernels AND rocPRIM calls per step over the step time
+        alg_step = sum(p["bytes"] for p in prof) / args.steps
         kern_ms_step = sum(p["total_ms"] for p in prof) / args.steps
         roofline_pipeline = dict(bound="hbm", achieved=round(alg_step / step_s / 1e9, 3), peak=HBM_PEAK_GBS, unit="GB/s",
                                  frac=round(alg_step / step_s / 1e9 / HBM_PEAK_GBS, 6),
                                  algorithmic_bytes_per_step=int(alg_step),
                                  kernel_ms_per_step=round(kern_ms_step, 3),
-                                 kernel_time_fraction_of_step=round(kern_ms_step / (step_s * 1e3), 4))
+                                 kernel_time_fraction_of_step=round(kern_ms_step / (step_s * 1e3), 4),
+                                 exclusive_kernel_ms_per_step=(round(sum(q["total_ms"] for q in prof_x.values()), 3) if prof_x else None),
+                                 note="kernel_ms_per_step sums co-scheduled durations (streams overlap: it may exceed the step); "
+                                      "exclusive_kernel_ms_per_step is the same sum with the kernels serialised")
         go = shutil.which("go")
-        qdesc = ("ONT-style reads (%d-%d bp log-uniform, sub 2%% ins 2%% del 3%%)" if wl["kind"] == "reads" else
-                 "gene queries (%d-%d bp, <=10%% divergence)") % (lo_len, hi_len)
+        qdesc = {"reads": "ONT-style reads (%d-%d bp log-uniform, sub 2%% ins 2%% del 3%%)",
+                 "circular": "circular plasmid/prophage queries (%d-%d bp, random rotation, sub 1%% indel 0.4%%)",
+                 "mixed": "mixed batch: 90%% gene queries (%d-%d bp, <=10%% divergence) + 10%% ONT-style reads (5-50 kb)",
+                 }.get(wl["kind"], "gene queries (%d-%d bp, <=10%% divergence)") % (lo_len, hi_len)
         seed_B = info["seed_bytes"] / max(info["seeds"], 1)
         result = {
             "metric": "queries/sec (lexicmap search hot path, seed index HBM-resident)",
@@ -590,7 +687,9 @@ def main():
                        "seed_layout": "partition table (%d bases) + %d-bit k-mer remainder + %d-bit value per seed; %d outlier seeds flat" %
                                       (info["partition_bases"], info["key_bits"], info["val_bits"], info["outlier_seeds"]),
                        "genomes_resident": info["genomes"], "query_bases": query_bases,
-                       "parallelism": ("1 GPU" if world == 1 else
+                       "parallelism": (("1 GPU holding shard %d of %d (genome g on shard g %% %d, global total_bases): one rank of "
+                                        "the %d-GPU index-sharded run" % (args.shard_rank, shard_of, shard_of, shard_of)) if shard_of
+                                       else "1 GPU" if world == 1 else
                                        ("index-shard x%d (genome g on rank g %% %d), queries broadcast, one all-gatherv of HSP rows per step" % (world, world))
                                        if index_sharded else
                                        ("q-shard x%d (index replicated), %d queries per GPU" % (world, len(my)))),
@@ -604,6 +703,7 @@ def main():
             "roofline_pipeline": roofline_pipeline,
             "kernels": kernels,
             "rocprim_calls": prims,
+            "sharding_model": shard_model,
             "source_hash": source_hash(),
         }
     gi.free_batch(qb)

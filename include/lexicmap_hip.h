@@ -272,6 +272,9 @@ typedef struct lm_kernel_time {
 } lm_kernel_time;
 void lm_profile_enable(lm_index *idx, int on);
 void lm_profile_reset(lm_index *idx);
+/* exclusive != 0: the searches that follow run their kernels one after the other (no overlapped streams), so that the
+ * per-kernel HIP-event times are exclusive times; results are unchanged. Measurement only. */
+void lm_profile_exclusive(lm_index *idx, int exclusive);
 size_t lm_profile_get(lm_index *idx, const lm_kernel_time **out);
 
 #ifdef __cplusplus

@@ -151,6 +151,7 @@ def lib():
     L.lm_index_fetch.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64, C.c_char_p]
     L.lm_profile_enable.argtypes = [vp, C.c_int]
     L.lm_profile_reset.argtypes = [vp]
+    L.lm_profile_exclusive.argtypes = [vp, C.c_int]
     L.lm_profile_get.argtypes = [vp, C.POINTER(C.POINTER(KernelTime))]
     L.lm_profile_get.restype = C.c_size_t
     _lib = L
@@ -448,6 +449,10 @@ class Index:
 
     def profile_reset(self):
         lib().lm_profile_reset(self.h)
+
+    def profile_exclusive(self, on=True):
+        """kernels of the following searches one after the other: exclusive per-kernel times (measurement only)"""
+        lib().lm_profile_exclusive(self.h, int(on))
 
     def profile_get(self):
         p = C.POINTER(KernelTime)()

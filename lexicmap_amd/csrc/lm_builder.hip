@@ -7,11 +7,11 @@
 //     indel-shifted copies; single contig; stored 2-bit MSB-first like genome/genome.go:1471-1508
 //   * normal seeds: EXACT LexicHash capture per genome — for every mask the argmin of mask^kmer over both strands, all
 //     occurrences, low-complexity captures dropped (lib-index-build.go:1028-1046)
-//   * seed-desert filling: every gap >= max_desert between neighbouring seeds is filled every seed_dist bases with the
-//     nearest non-low-complexity k-mer (scan 25 up-, then 24 downstream, + strand before - strand), stored under the
-//     closest mask sharing its p-base prefix.  SIMPLIFICATION vs lib-index-build.go:1094-1407: the reference also
-//     requires the k-mer to be the capture of that mask within the +-1000 bp window.  Seed density and the
-//     prefix-structure of every mask's list are the same; which k-mer near a step is picked may differ.
+//   * seed-desert filling as the reference does it (lib-index-build.go:1094-1407): every gap >= max_desert between
+//     neighbouring seeds is filled every seed_dist bases with the nearest non-low-complexity k-mer (scan 25 up-, then 24
+//     downstream, + strand before - strand) that is the capture of a mask when the window [pre - 1000, pos + 1000 + k)
+//     alone is masked, stored under the last mask capturing it (tests/test_gpu_builder.py: every mask's list equals what
+//     the oracle's writer stores for the same genomes)
 //   * reversed (suffix) seeds for every normal and desert seed (lib-index-build.go:776-890)
 //   * seed values batch:17|genome:17|pos:28|strand:1|reversed:1, per-mask arrays sorted by k-mer
 // The search kernels and the parity tests never depend on this file: parity uses indexes written in the reference's
@@ -319,77 +319,120 @@ __device__ __forceinline__ int closest_mask(const MaskTab &mt, uint64_t x) {
     return minj;
 }
 
-// desert filling: one lane per neighbouring seed pair of a genome (sorted position keys)
-__global__ void k_desert_fill(SynthDev sp, MaskTab mt, const uint8_t *__restrict__ gbits, int64_t l0,
-                              const uint64_t *__restrict__ pos_keys, int64_t npk, int max_desert, int seed_dist,
-                              uint16_t *__restrict__ s_mask, uint64_t *__restrict__ s_kmer, uint64_t *__restrict__ s_val,
-                              unsigned long long *__restrict__ counter, unsigned long long cap) {
+// Desert filling, lib-index-build.go:1094-1407, as the reference does it: for every pair of neighbouring seeds at least
+// max_desert apart, walk from pre + seed_dist in steps of seed_dist; at each step scan seed_pos_r positions upstream, then
+// downstream, for a non-low-complexity k-mer (+ strand before - strand) that IS THE CAPTURE OF SOME MASK WHEN THE WINDOW
+// [pre - 1000, pos + 1000 + k) ALONE IS MASKED (MaskKnownDistinctPrefixes(window, nil, false), :1191-1240), and store it
+// under that mask - the LAST (largest-index) mask that captures it.  A wavefront takes 64 seed pairs, finds the deserts
+// among them and walks them one after the other; the capture test of a candidate is a sweep of the window by the 64 lanes
+// (is any window k-mer of either strand with the same p-base prefix closer to the mask?).
+__device__ __forceinline__ int desert_capturing_mask(const MaskTab &mt, const uint8_t *gb, int64_t wstart, int nk, uint64_t x,
+                                                     int lane) {
+    const int shift = (mt.K - mt.p) << 1;
+    const uint64_t pf = x >> shift;
+    int im = -1;
+    for (int j = mt.pfx_first[pf]; j < mt.pfx_first[pf + 1]; j++) {
+        const uint64_t mk = mt.masks[j], hx = mk ^ x;
+        bool beaten = false;
+        for (int w = lane; w < nk; w += 64) {
+            const uint64_t f = packed_kmer(gb, wstart + w, mt.K), r = lm_revcomp(f, mt.K);
+            beaten |= ((f >> shift) == pf && (mk ^ f) < hx) || ((r >> shift) == pf && (mk ^ r) < hx);
+        }
+        if (__ballot(beaten) == 0ull) im = j; // x attains the window's minimum for mask j; the last such mask is recorded
+    }
+    return im;
+}
+__global__ __launch_bounds__(256) void k_desert_fill(SynthDev sp, MaskTab mt, const uint8_t *__restrict__ gbits, int64_t l0,
+                                                      const uint64_t *__restrict__ pos_keys, int64_t npk, int max_desert,
+                                                      int seed_dist, uint16_t *__restrict__ s_mask,
+                                                      uint64_t *__restrict__ s_kmer, uint64_t *__restrict__ s_val,
+                                                      unsigned long long *__restrict__ counter, unsigned long long cap) {
     const int seed_pos_r = seed_dist / 2;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < npk; t += (int64_t)gridDim.x * blockDim.x) {
-        uint64_t key = pos_keys[t];
-        int c = (int)(key >> 32);
-        int64_t pos = (int64_t)((key & 0xffffffffu) >> 1);
-        int64_t pre = 0;
-        if (t > 0 && (int)(pos_keys[t - 1] >> 32) == c) pre = (int64_t)((pos_keys[t - 1] & 0xffffffffu) >> 1);
-        if (pos - pre < max_desert) continue;
-        const uint8_t *gb = gbits + (l0 + c) * sp.gbytes;
-        int64_t g = global_genome(sp, l0 + c);
-        uint64_t bg = ((uint64_t)(g / 5000) << 17) | (uint64_t)(g % 5000);
-        int64_t j = pre + seed_dist;
-        while (j < pos) {
-            int64_t start_dn = j + 1, end_up = j - seed_pos_r;
-            bool ok = false;
-            uint64_t kmer = 0;
-            int strand = 0;
-            int64_t at = j;
-            for (; at > end_up; at--) {
-                if (at < 0) continue;
-                uint64_t f = packed_kmer(gb, at, mt.K);
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t base = wave * 64; base < npk; base += nwaves * 64) {
+        const int64_t t = base + lane;
+        int c = 0, pos = 0, pre = 0;
+        bool isd = false;
+        if (t < npk) {
+            const uint64_t key = pos_keys[t];
+            c = (int)(key >> 32);
+            pos = (int)((key & 0xffffffffu) >> 1);
+            if (t > 0 && (int)(pos_keys[t - 1] >> 32) == c) pre = (int)((pos_keys[t - 1] & 0xffffffffu) >> 1);
+            isd = pos - pre >= max_desert;
+        }
+        uint64_t todo = __ballot(isd);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int gc = __builtin_amdgcn_readfirstlane(__shfl(c, src, 64));
+            const int gpos = __builtin_amdgcn_readfirstlane(__shfl(pos, src, 64));
+            const int gpre = __builtin_amdgcn_readfirstlane(__shfl(pre, src, 64));
+            const uint8_t *gb = gbits + (l0 + gc) * sp.gbytes;
+            const int64_t g = global_genome(sp, l0 + gc);
+            const uint64_t bg = ((uint64_t)(g / 5000) << 17) | (uint64_t)(g % 5000);
+            // the window that is masked on its own (:1150-1190)
+            int wstart = gpre - 1000;
+            if (wstart < 0) wstart = 0;
+            int wend = gpos + 1000 + mt.K;
+            if (wend > sp.genome_len) wend = sp.genome_len;
+            const int nk = wend - wstart - mt.K + 1; // k-mers of the window
+            auto try_at = [&](int at, uint64_t *kmer, int *strand, int *im) { // the candidate at genome position `at`
+                const int rel = at - wstart;
+                if (rel < 0 || rel >= nk) return false;
+                const uint64_t f = packed_kmer(gb, at, mt.K);
                 if (f != 0 && !lm_low_complexity(f, mt.K)) {
-                    kmer = f;
-                    strand = 0;
-                    ok = true;
-                    break;
+                    const int m = desert_capturing_mask(mt, gb, wstart, nk, f, lane);
+                    if (m >= 0) {
+                        *kmer = f;
+                        *strand = 0;
+                        *im = m;
+                        return true;
+                    }
                 }
-                uint64_t r = lm_revcomp(f, mt.K);
+                const uint64_t r = lm_revcomp(f, mt.K);
                 if (r != 0 && !lm_low_complexity(r, mt.K)) {
-                    kmer = r;
-                    strand = 1;
-                    ok = true;
-                    break;
+                    const int m = desert_capturing_mask(mt, gb, wstart, nk, r, lane);
+                    if (m >= 0) {
+                        *kmer = r;
+                        *strand = 1;
+                        *im = m;
+                        return true;
+                    }
                 }
-            }
-            if (!ok) {
-                if (start_dn >= pos) break;
-                int64_t end_dn = start_dn + seed_pos_r;
-                if (end_dn >= pos) end_dn = pos - 1;
-                for (at = start_dn; at < end_dn; at++) {
-                    uint64_t f = packed_kmer(gb, at, mt.K);
-                    if (f != 0 && !lm_low_complexity(f, mt.K)) {
-                        kmer = f;
-                        strand = 0;
+                return false;
+            };
+            int j = gpre + seed_dist;
+            while (j < gpos) {
+                const int start_dn = j + 1, end_up = j - seed_pos_r;
+                bool ok = false;
+                uint64_t kmer = 0;
+                int strand = 0, im = -1, at = j;
+                for (; at > end_up; at--)
+                    if (try_at(at, &kmer, &strand, &im)) {
                         ok = true;
                         break;
                     }
-                    uint64_t r = lm_revcomp(f, mt.K);
-                    if (r != 0 && !lm_low_complexity(r, mt.K)) {
-                        kmer = r;
-                        strand = 1;
-                        ok = true;
-                        break;
+                if (!ok) {
+                    if (start_dn >= gpos) break;
+                    int end_dn = start_dn + seed_pos_r;
+                    if (end_dn >= gpos) end_dn = gpos - 1;
+                    for (at = start_dn; at < end_dn; at++)
+                        if (try_at(at, &kmer, &strand, &im)) {
+                            ok = true;
+                            break;
+                        }
+                }
+                if (ok && lane == 0) {
+                    const unsigned long long o = atomicAdd(counter, 1ull);
+                    if (o < cap) {
+                        s_mask[o] = (uint16_t)im;
+                        s_kmer[o] = kmer;
+                        s_val[o] = (bg << 30) | ((uint64_t)at << 2) | ((uint64_t)strand << 1);
                     }
                 }
+                j = at + seed_dist;
             }
-            if (ok) {
-                int m = closest_mask(mt, kmer);
-                unsigned long long o = atomicAdd(counter, 1ull);
-                if (o < cap && m >= 0) {
-                    s_mask[o] = (uint16_t)m;
-                    s_kmer[o] = kmer;
-                    s_val[o] = (bg << 30) | ((uint64_t)at << 2) | ((uint64_t)strand << 1);
-                }
-            }
-            j = at + seed_dist;
         }
     }
 }
@@ -665,7 +708,7 @@ lm_status lm_index_build_synthetic(const lm_synth_spec *spec, const lm_options *
                                    pos_keys.p, npk);
                 npk += nch;
                 prim_sort_keys(ix->st, ix->tmp, pos_keys.p, pos_keys2.p, (size_t)npk, 0, 64);
-                hipLaunchKernelGGL(k_desert_fill, dim3(gridn((int64_t)npk, 64)), dim3(64), 0, ix->st, sp, mt, ix->d_gbits.p, l0,
+                hipLaunchKernelGGL(k_desert_fill, dim3(gridn(((int64_t)npk + 63) / 64, 4)), dim3(256), 0, ix->st, sp, mt, ix->d_gbits.p, l0,
                                    pos_keys2.p, (int64_t)npk, spec->max_desert, spec->seed_dist, s_mask.p, s_kmer.p, s_val.p,
                                    counters.p, cap);
                 HIPCHK(hipMemcpyAsync(hc, counters.p, sizeof hc, hipMemcpyDeviceToHost, ix->st));

@@ -484,7 +484,7 @@ static void stage_kmers(Work &w) {
                              w.vals_all.p, w.keys_cmp.p, w.vals_cmp.p, w.nvalid.p);
     }
     {
-        Prof p(ix, "segmented_sort_kmers");
+        Prof p(ix, "segmented_sort_kmers", 2 * (2 * P) * 24); // two sorts of 2P (u64 key, u32 value) pairs, in and out
         int end_bit = std::min(64, 2 * ix->host.k);
         prim_segmented_sort_pairs(S(ix), TMP(ix), w.keys_all.p, w.keys_all2.p, w.vals_all.p, w.vals_all2.p, (size_t)(2 * P),
                                   (size_t)qb->nq, qb->d_segoff.p, 0, end_bit);
@@ -551,7 +551,7 @@ static void stage_lookup(Work &w, lm_stage_stats &stats) {
     {
         // in (list, partition) order: neighbouring threads read neighbouring table rows and partitions; outlier
         // lookups (bit 31) sort to the end
-        Prof p(ix, "sort_lookups");
+        Prof p(ix, "sort_lookups", nlk * 16); // (u32 key + u32 slot) in and out
         sort_pairs_u32(ix, w.lk_list.p, w.lk_list2.p, w.lk_perm.p, w.lk_perm2.p, nlk, 0, 32);
     }
     w.lk_counts.ensure((size_t)nlk + 1);
@@ -602,7 +602,7 @@ static void stage_lookup(Work &w, lm_stage_stats &stats) {
                            w.lk_offs.p, w.lk_starts.p, w.lk_nscan.p, w.A0.p, w.B0.p);
     }
     {
-        Prof p(ix, "sort_anchors");
+        Prof p(ix, "sort_anchors", T * 32); // two u64 per anchor in and out
         sort_anchors(ix, w.A0.p, w.B0.p, w.A1.p, w.B1.p, T, 64);
     }
     // segments = runs of equal A
@@ -610,7 +610,7 @@ static void stage_lookup(Work &w, lm_stage_stats &stats) {
     w.seg_len.ensure((size_t)T + 2);
     w.nseg_d.ensure(2);
     {
-        Prof p(ix, "rle");
+        Prof p(ix, "rle", T * 8);
         prim_rle(S(ix), TMP(ix), w.A0.p, (size_t)T, w.segA.p, w.seg_len.p, w.nseg_d.p);
     }
     int32_t nseg = 0;
@@ -1102,6 +1102,15 @@ lm_status lm_index_get_info(const lm_index *ix, lm_index_info *info) {
 const uint64_t *lm_index_masks(const lm_index *ix) { return ix ? ix->host.masks.data() : nullptr; }
 
 void lm_profile_enable(lm_index *ix, int on) { ix->prof = on != 0; }
+// measurement switch (bench.py): exclusive != 0 serialises the searches that follow on this handle - no pseudo-alignment
+// producer beside extend / WFA, the WFA length classes one after the other - so that the HIP-event time of a kernel is its
+// own time and not that of whatever shared the chip with it.  Same results either way.
+void lm_profile_exclusive(lm_index *ix, int exclusive) {
+    if (!ix) return;
+    std::lock_guard<std::mutex> lock(ix->mu);
+    ix->tune.wfa_serial = exclusive != 0 || getenv("LM_WFA_SERIAL") != nullptr;
+    ix->tune.no_pipeline = exclusive != 0 || getenv("LM_NO_PIPELINE") != nullptr;
+}
 void lm_profile_reset(lm_index *ix) {
     prof_resolve(ix);
     ix->prof_entries.clear();
@@ -1460,6 +1469,17 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
             ncand += (int64_t)hv[2 + j];
             seg_max = std::max<int64_t>(seg_max, (int64_t)hv[2 + j]);
         }
+        {   // algorithmic bytes of the search (align stage): 8 B per candidate read, 8 B per anchor written, and
+            // the comparison index of every query of the chunk once (12 B per indexed k-mer, both strands)
+            int64_t idx = 0;
+            uint32_t prevq = 0xffffffffu;
+            for (int64_t i = 0; i < nt; i++)
+                if (ht[i].q != prevq) { // tasks are in (query, genome) order
+                    prevq = ht[i].q;
+                    idx += 24 * std::max<int64_t>(0, qb->h_qoff[prevq + 1] - qb->h_qoff[prevq] - (ix->host.k - 1));
+                }
+            prof_add_bytes(ix, "k_pa_search", 8 * std::min<int64_t>(ncand, a.pa_cap) + 8 * std::min<int64_t>(TP, a.pa_cap) + idx);
+        }
         dbg_stamp("pseudo-alignment anchors of a chunk done");
         if (getenv("LM_DEBUG"))
             fprintf(stderr, "[lm] pseudo-alignment: %lld window bases, %lld candidates (fullest of %d segments: %lld of %lld), %lld anchors\n",
@@ -1488,13 +1508,13 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
         if (!compact) a.A1.ensure((size_t)a.pa_cap);
         a.B1.ensure((size_t)a.pa_cap);
         if (compact) {
-            Prof p(ix, "sort_pa_anchors");
+            Prof p(ix, "sort_pa_anchors", TP * 16); // one u64 key in and out
             prim_sort_keys(S(ix), TMP(ix), a.B0.p, a.B1.p, (size_t)TP, 0, key_bits);
             std::swap(a.B0.p, a.B1.p); // sorted keys are what follows calls B0
             std::swap(a.B0.cap, a.B1.cap);
             launch_pa_task_off_sorted(S(ix), a.B0.p, sh_a, TP, nt, a.pa_off.p);
         } else {
-            Prof p(ix, "sort_pa_anchors");
+            Prof p(ix, "sort_pa_anchors", TP * 32);
             sort_anchors_fields(ix, a.A0.p, a.B0.p, a.A1.p, a.B1.p, TP, abits, qbits, tbits);
             std::swap(a.A0.p, a.A1.p); // the sorted list is in (A1, B1): make it (A0, B0) for what follows
             std::swap(a.A0.cap, a.A1.cap);
@@ -2182,7 +2202,9 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
             a.ext_subs.ensure(64 * (size_t)ER + 64);
             a.ext_msi.ensure(64 * (size_t)ER + 64);
             {
-                Prof p(ix, "k_extend");
+                // algorithmic bytes: per HSP the two flank pairs extendMatch reads (<= ext_len + 2 bases of query and of window on
+                // either side, lib-index-search-util.go:34-201), its descriptor and its result
+                Prof p(ix, "k_extend", NH * (int64_t)(4 * (ix->opt.ext_len2 + 2) + sizeof(HspIn) + sizeof(HspExt)));
                 launch_extend(S(ix), a.hsp_in.p, NH, qb->d_seq.p, qb->d_qoff.p, a.gwbuf.p, a.ext_cap.p, a.ext_off.p,
                               a.ext_subs.p, a.ext_msi.p, a.ext_rows.p, a.ext_rstart.p, a.hsp_ext.p);
             }

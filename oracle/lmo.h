@@ -266,6 +266,7 @@ typedef struct {
 void lmo_build_opt_default(lmo_build_opt *o);
 typedef struct lmo_builder lmo_builder;
 lmo_builder *lmo_builder_new(const char *outdir, const lmo_build_opt *opt);
+int lmo_builder_set_masks(lmo_builder *b, const uint64_t *masks, int n); /* test hook: caller-provided mask set */
 /* add one genome: contigs concatenated by the builder with contig_interval 'A's; when the concatenation would exceed
  * max_genome the genome is split into chunks, each stored as its own genome record with the same id and listed together
  * in genomes.chunks.bin (lib-index-build.go:1581-1658,1786-1808). Returns -2 when one contig alone exceeds max_genome

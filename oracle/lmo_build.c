@@ -91,6 +91,19 @@ lmo_builder *lmo_builder_new(const char *outdir, const lmo_build_opt *opt) {
     return b;
 }
 
+/* Test hook: replace the generated mask set by a caller-provided one (sorted ascending, every p-base prefix present) before
+ * the first genome is added - lets the tests index genomes with the mask set of the GPU synthetic builder and compare
+ * what both writers store. masks.bin is rewritten. */
+int lmo_builder_set_masks(lmo_builder *b, const uint64_t *masks, int n) {
+    if (!b || n != b->opt.masks || b->ngenomes != 0) return -1;
+    lmo_lh_free(b->lh);
+    b->lh = lmo_lh_new(b->opt.k, masks, n);
+    char p[4096];
+    snprintf(p, sizeof p, "%s/masks.bin", b->dir);
+    lmo_lh_write(b->lh, p, b->opt.rand_seed);
+    return 0;
+}
+
 typedef struct {
     int s, e;
 } ivl;

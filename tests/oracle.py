@@ -106,6 +106,7 @@ def lib():
         L.lmo_builder_add.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_char_p),
                                       C.POINTER(C.c_char_p), C.POINTER(C.c_int)]
         L.lmo_builder_finish.argtypes = [C.c_void_p]
+        L.lmo_builder_set_masks.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
         L.lmo_index_open.restype = C.c_void_p
         L.lmo_index_open.argtypes = [C.c_char_p, C.POINTER(SearchOpt)]
         L.lmo_index_close.argtypes = [C.c_void_p]
@@ -208,11 +209,15 @@ def default_search_opt(**kw):
     return o
 
 
-def build_index(outdir, genomes, opt=None):
-    """genomes: list of (genome_id, [(contig_id, seq bytes), ...])"""
+def build_index(outdir, genomes, opt=None, masks=None):
+    """genomes: list of (genome_id, [(contig_id, seq bytes), ...]); masks: mask set to use instead of the generated one"""
     L = lib()
     opt = opt or default_build_opt()
     b = L.lmo_builder_new(outdir.encode(), C.byref(opt))
+    if masks is not None:
+        arr = (C.c_uint64 * len(masks))(*masks)
+        if L.lmo_builder_set_masks(b, arr, len(masks)) != 0:
+            raise RuntimeError("lmo_builder_set_masks failed")
     for gid, contigs in genomes:
         n = len(contigs)
         ids = (C.c_char_p * n)(*[c[0].encode() for c in contigs])

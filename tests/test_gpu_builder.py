@@ -85,6 +85,35 @@ def test_captures_match_oracle_lexichash(synth_index):
     L.lmo_lh_free(lh)
 
 
+def test_every_mask_list_equals_the_oracle_writer(synth_index, tmp_path):
+    """f4: the GPU builder stores, under EVERY mask, exactly the (k-mer, value) pairs the oracle's writer
+    (lib-index-build.go restated: captures, desert filling with the window-capture condition :1094-1407, reversed twins
+    :776-890) stores for the same genomes and the same mask set - compared list by list through lm_index_mask_seeds, the
+    oracle-written index being loaded through the reference-format loader."""
+    import lexicmap_amd as la
+    gi = synth_index
+    M = gi.info()["masks"]
+    masks_p = la.lib().lm_index_masks(gi.h)
+    masks = [masks_p[i] for i in range(M)]
+    ng = gi.info()["genomes"]
+    genomes = [("SYN_%09d.1" % g, [("syn%09d_c1" % g, gi.fetch(g, 0, 200_000))]) for g in range(ng)]
+    d = str(tmp_path / "same.lmi")
+    O.build_index(d, genomes, O.default_build_opt(chunks=4), masks=masks)
+    oi = la.Index(d)
+    assert oi.info()["seeds"] == gi.info()["seeds"]
+    nrev = ndesert = 0
+    for m in list(range(0, M, 7)) + [M - 1]:
+        k1, v1 = gi.mask_seeds(m)
+        k2, v2 = oi.mask_seeds(m)
+        a = sorted(zip(k1.tolist(), v1.tolist()))
+        b = sorted(zip(k2.tolist(), v2.tolist()))
+        assert a == b, (m, len(a), len(b), [x for x in a if x not in b][:3], [x for x in b if x not in a][:3])
+        nrev += int((v1 & np.uint64(1)).sum())
+        ndesert += len(set(k1[(v1 & np.uint64(1)) == 0].tolist())) - 1
+    oi.close()
+    assert nrev > 1000 and ndesert > 1000   # reversed twins and desert seeds were among what was compared
+
+
 def test_seed_density_like_reference_builder(synth_index):
     """~2*(M + 0.9*L/50) seeds per genome: the desert filling and the reversed copies are in place"""
     info = synth_index.info()
