@@ -289,6 +289,7 @@ struct lm_tune {
     // LDS (0; impossible beyond 65 kb).  LM_WFA_FIRST_NC="2,2,4,8,8", LM_WFA_WIN="00101" override.
     int wfa_first_nc[LM_WFA_CLASSES] = {2, 2, 4, 8, 8};
     int wfa_win[LM_WFA_CLASSES] = {0, 0, 1, 0, 1};
+    int chain1_wave = 1;     // seed chaining of pairs with many anchors by a wavefront each (LM_CHAIN1_LANES=1: one lane per pair)
     int pa_seg_by_group = 1; // candidate segments by task group + XCD-local k_pa_search (LM_PA_SEG_BY_WAVE=1: by wavefront)
     FILE *wfa_dump = nullptr; // LM_DEBUG_WFA_DUMP=<file>: one line per WFA problem and pass (width, status, lengths, estimate, score)
     int wfa_serial = 0;      // LM_WFA_SERIAL=1: the WFA length classes one after the other (exclusive kernel timings)
@@ -305,6 +306,7 @@ struct lm_tune {
         if (const char *e = getenv("LM_WFA_WIN"))
             for (int c = 0; c < LM_WFA_CLASSES && e[c]; c++) wfa_win[c] = e[c] == '1';
         no_pipeline = getenv("LM_NO_PIPELINE") != nullptr;
+        if (getenv("LM_CHAIN1_LANES")) chain1_wave = 0;
         if (const char *e = getenv("LM_PA_SEG_BY_WAVE")) pa_seg_by_group = atoi(e) ? 0 : 1;
     }
 };

@@ -87,7 +87,8 @@ void launch_lookup_emit(hipStream_t st, DevIndexView ix, const uint64_t *kmers, 
                         uint64_t *outA, uint64_t *outB);
 void launch_chain1(hipStream_t st, const uint64_t *B, const int64_t *seg_off, int nseg, LmChainOpt opt, int K, LmSub *subs,
                    uint8_t *marks, uint64_t *msi, uint64_t *s2i, int8_t *dirs, uint8_t *visited, int32_t *chain_off_pool,
-                   int32_t *chain_idx_pool, int32_t *seg_n, float *seg_score, int32_t *seg_nch);
+                   int32_t *chain_idx_pool, int32_t *seg_n, float *seg_score, int32_t *seg_nch, int32_t *big_list,
+                   unsigned int *big_count);
 void launch_task_count(hipStream_t st, const float *seg_score, const int32_t *seg_nch, const uint8_t *keep, int nseg,
                        float min_score, int32_t *ntask);
 void launch_make_tasks(hipStream_t st, DevIndexView ix, const uint64_t *segA, const int64_t *seg_off, int nseg,

@@ -400,14 +400,24 @@ __global__ __launch_bounds__(256) void k_lookup_emit(DevIndexView ix, const uint
 
 // ------------------------------------------------------------------------------------------------------------
 // per (query,genome): ClearSubstrPairs + Chainer.Chain (lib-index-search.go:1702-1775)
+// Small pairs (nearly all: the random 17-base matches of unrelated genomes give one to three anchors): one lane per pair.
+// Pairs above LM_CHAIN1_WAVE_MIN anchors (a read against the members of its own family: hundreds of anchors; a 200-kb
+// plasmid query: thousands) are left to k_chain1_wave - one lane walking n x window candidates alone kept a whole launch
+// waiting (27 ms per C3 launch, 55 ms of a 360-ms C4-shaped step).
+#define LM_CHAIN1_WAVE_MIN 48
 __global__ void k_chain1(const uint64_t *__restrict__ B, const int64_t *__restrict__ seg_off, int nseg, LmChainOpt opt,
                          int K, LmSub *__restrict__ subs, uint8_t *__restrict__ marks, uint64_t *__restrict__ msi,
                          uint64_t *__restrict__ s2i, int8_t *__restrict__ dirs, uint8_t *__restrict__ visited,
                          int32_t *__restrict__ chain_off_pool, int32_t *__restrict__ chain_idx_pool,
-                         int32_t *__restrict__ seg_n, float *__restrict__ seg_score, int32_t *__restrict__ seg_nch) {
+                         int32_t *__restrict__ seg_n, float *__restrict__ seg_score, int32_t *__restrict__ seg_nch,
+                         int32_t *__restrict__ big_list, unsigned int *__restrict__ big_count) {
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += gridDim.x * blockDim.x) {
         int64_t o = seg_off[s];
         int n = (int)(seg_off[s + 1] - o);
+        if (big_list && n > LM_CHAIN1_WAVE_MIN) {
+            big_list[atomicAdd(big_count, 1u)] = s;
+            continue;
+        }
         LmSub *sb = subs + o;
         for (int i = 0; i < n; i++) sb[i] = lm_unpack_anchor(B[o + i]);
         if (n > 1) n = lm_clear_sorted(sb, n, K, marks + o);
@@ -417,6 +427,271 @@ __global__ void k_chain1(const uint64_t *__restrict__ B, const int64_t *__restri
         seg_n[s] = n;
         seg_score[s] = sc;
         seg_nch[s] = nch;
+    }
+}
+
+// One wavefront per large pair: ClearSubstrPairs with a lane per anchor (an anchor's mark depends on the ORIGINAL list
+// only) and an ordered ballot compaction; Chainer.Chain's DP with the lanes over the candidate predecessors j (the scan
+// from high j to low j with a strict `>` keeps the largest j among equal best scores = the maximum of (score bits, j)); the
+// score list sorted by an all-ascending bitonic network in global memory (end-padded with +inf, so any n); the backtrack is
+// the serial walk of lm_run_chain1.  Same results as lm_clear_sorted + lm_run_chain1 (the CPU-checked statement).
+__device__ __forceinline__ unsigned long long chain1_wave_max_u64(unsigned long long v) {
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long x = __shfl_xor(v, o, 64);
+        v = x > v ? x : v;
+    }
+    return v;
+}
+#define CHAIN1_WAVE_SYNC()           \
+    do {                             \
+        __threadfence_block();       \
+        __builtin_amdgcn_wave_barrier(); \
+    } while (0)
+__global__ __launch_bounds__(256) void k_chain1_wave(const uint64_t *__restrict__ B, const int64_t *__restrict__ seg_off,
+                                                      LmChainOpt opt, int K, LmSub *__restrict__ subs,
+                                                      uint8_t *__restrict__ marks, uint64_t *__restrict__ msi,
+                                                      uint64_t *__restrict__ s2i, int8_t *__restrict__ dirs,
+                                                      uint8_t *__restrict__ visited, int32_t *__restrict__ chain_off_pool,
+                                                      int32_t *__restrict__ chain_idx_pool, int32_t *__restrict__ seg_n,
+                                                      float *__restrict__ seg_score, int32_t *__restrict__ seg_nch,
+                                                      const int32_t *__restrict__ big_list,
+                                                      const unsigned int *__restrict__ big_count) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const int nbig = (int)*big_count;
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    for (int bi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); bi < nbig; bi += nwaves) {
+        const int s = big_list[bi];
+        const int64_t o = seg_off[s];
+        const int n0 = (int)(seg_off[s + 1] - o);
+        LmSub *sb = subs + o;
+        uint8_t *mk = marks + o;
+        uint64_t *ms = msi + o, *s2 = s2i + o;
+        int8_t *dr = dirs + o;
+        uint8_t *vis = visited + o;
+        for (int i = lane; i < n0; i += 64) sb[i] = lm_unpack_anchor(B[o + i]);
+        CHAIN1_WAVE_SYNC();
+        // ---- ClearSubstrPairs (lm_clear_sorted): marks from the original list, then ordered compaction
+        for (int i = lane; i < n0; i += 64) {
+            uint8_t m = 0;
+            if (i >= 1) {
+                const LmSub v = sb[i];
+                const int32_t vqend = v.qbegin + v.len;
+                int32_t upbound = vqend - K;
+                if (upbound < 0) upbound = 0;
+                const int32_t vtbegin = v.tbegin, vtend = v.tbegin + v.len;
+                int lo = 0, hi = i;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (sb[mid].qbegin < upbound)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                for (int j = lo; j < i; j++) {
+                    const LmSub p = sb[j];
+                    if (vqend <= p.qbegin + p.len && vtbegin >= p.tbegin && vtend <= p.tbegin + p.len) {
+                        m = 1;
+                        break;
+                    }
+                }
+            }
+            mk[i] = m;
+        }
+        CHAIN1_WAVE_SYNC();
+        int n = 0;
+        for (int c0 = 0; c0 < n0; c0 += 64) {
+            const int i = c0 + lane;
+            const bool keep = i < n0 && mk[i] == 0;
+            LmSub v;
+            if (i < n0) v = sb[i];
+            CHAIN1_WAVE_SYNC(); // every lane holds its anchor before slots <= i are overwritten
+            const uint64_t km = __ballot(keep);
+            if (keep) sb[n + __popcll(km & lt_mask)] = v;
+            n += __popcll(km);
+        }
+        CHAIN1_WAVE_SYNC();
+        // ---- Chainer.Chain (lm_run_chain1)
+        int32_t *chain_off = chain_off_pool + o + 4ll * s, *chain_idx = chain_idx_pool + 2 * o + 8ll * s;
+        int nchains = 0, nidx = 0;
+        float result = 0;
+        if (lane == 0) chain_off[0] = 0;
+        if (n == 1) {
+            const float w = lm_seed_weight((float)sb[0].len);
+            if (w >= opt.min_score && lane == 0) {
+                chain_idx[0] = 0;
+                chain_off[1] = 1;
+            }
+            nchains = w >= opt.min_score ? 1 : 0;
+            result = w;
+        } else {
+            if (lane == 0) {
+                const float s0 = lm_seed_weight((float)sb[0].len);
+                ms[0] = (uint64_t)lm_f32bits(s0) << 32;
+                dr[0] = 0;
+                s2[0] = (uint64_t)lm_f32bits(s0) << 32;
+            }
+            const int32_t max_dist_i = (int32_t)opt.max_distance;
+            for (int i = 1; i < n; i++) {
+                CHAIN1_WAVE_SYNC(); // msi / dirs of i - 1 are visible
+                const LmSub a = sb[i];
+                const int32_t aq = a.qbegin, alen = a.len;
+                const float m0 = lm_seed_weight((float)alen);
+                int64_t tlo = (int64_t)a.tbegin - max_dist_i;
+                if (a.tbegin < max_dist_i) tlo = 0;
+                const int64_t thi = (int64_t)a.tbegin + max_dist_i;
+                unsigned long long best = 0;
+                for (int j0 = i - 1; j0 >= 0; j0 -= 64) {
+                    const int j = j0 - lane;
+                    bool within = false;
+                    LmSub b;
+                    b.qbegin = b.tbegin = 0;
+                    b.len = 0;
+                    if (j >= 0) {
+                        b = sb[j];
+                        within = aq - b.qbegin <= max_dist_i;
+                    }
+                    if (__ballot(within) == 0ull) break; // sorted by QBegin: everything further down is out as well
+                    if (!within) continue;
+                    if ((int64_t)b.tbegin < tlo || (int64_t)b.tbegin > thi) continue;
+                    if (a.qbegin == b.qbegin || a.tbegin == b.tbegin) continue;
+                    int32_t dq = a.qbegin - b.qbegin;
+                    if (dq < 0) dq = -dq;
+                    int32_t dt;
+                    if (a.tbegin >= b.tbegin)
+                        dt = a.tbegin - b.tbegin;
+                    else
+                        dt = a.tbegin + (int32_t)a.len - b.tbegin - (int32_t)b.len;
+                    if (dt < 0) dt = -dt;
+                    int32_t gi = dq - dt;
+                    if (gi < 0) gi = -gi;
+                    if ((float)gi > opt.max_gap) continue;
+                    int32_t length;
+                    float w;
+                    if (aq > b.qbegin + (int32_t)b.len) {
+                        length = alen;
+                        w = lm_seed_weight((float)length);
+                    } else if (gi == 0) {
+                        length = aq + alen - b.qbegin;
+                        w = -lm_seed_weight((float)b.len) + lm_seed_weight((float)length);
+                    } else {
+                        length = aq + alen - (b.qbegin + (int32_t)b.len);
+                        w = lm_seed_weight((float)length);
+                    }
+                    const int dir = a.tbegin >= b.tbegin ? 1 : -1;
+                    const float gs = gi < opt.gap_lut_n ? opt.gap_lut[gi] : 0.0f;
+                    const int8_t dj = dr[j];
+                    float sc;
+                    if (dj == 0 || dj == dir) {
+                        const float t = lm_f32frombits((uint32_t)(ms[j] >> 32)) + w;
+                        sc = t - gs;
+                    } else {
+                        const float t = lm_seed_weight((float)b.len) + w;
+                        sc = t - gs;
+                    }
+                    if (sc >= opt.min_score && sc > m0) { // positive floats: the bit pattern orders like the value
+                        const unsigned long long key = ((unsigned long long)lm_f32bits(sc) << 32) | ((unsigned long long)(uint32_t)j << 1) |
+                                                       (dir > 0 ? 1ull : 0ull);
+                        best = key > best ? key : best;
+                    }
+                }
+                best = chain1_wave_max_u64(best);
+                if (lane == 0) {
+                    float m = m0;
+                    int mj = i;
+                    int8_t mdir = 0;
+                    if (best != 0ull) {
+                        m = lm_f32frombits((uint32_t)(best >> 32));
+                        mj = (int)((uint32_t)best >> 1);
+                        mdir = (best & 1ull) ? 1 : -1;
+                    }
+                    ms[i] = ((uint64_t)lm_f32bits(m) << 32) | (uint32_t)mj;
+                    dr[i] = mdir;
+                    s2[i] = ((uint64_t)lm_f32bits(m) << 32) | (uint32_t)i;
+                }
+            }
+            CHAIN1_WAVE_SYNC();
+            // ---- the score list ascending: all-ascending bitonic network, elements beyond n count as +inf and never move
+            for (int i = lane; i < n; i += 64) vis[i] = 0;
+            int N = 1;
+            while (N < n) N <<= 1;
+            for (int k = 2; k <= N; k <<= 1) {
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int x = lane; x < (N >> 1); x += 64) {
+                        const int i = ((x & ~(j - 1)) << 1) | (x & (j - 1)); // bit j clear
+                        const int l = (j == (k >> 1)) ? (i ^ (k - 1)) : (i | j); // first step of a merge: mirrored partner
+                        const int lo_i = i < l ? i : l, hi_i = i < l ? l : i;
+                        if (hi_i < n) {
+                            const uint64_t u = s2[lo_i], v = s2[hi_i];
+                            if (u > v) {
+                                s2[lo_i] = v;
+                                s2[hi_i] = u;
+                            }
+                        }
+                    }
+                    CHAIN1_WAVE_SYNC();
+                }
+            }
+            // ---- backtrack (serial walk, lm_run_chain1 :400-451); lane 0 walks, the others wait
+            if (lane == 0) {
+                int imax = n - 1;
+                float max_score = 0;
+                bool first = true;
+                int nchecked = 0;
+                while (true) {
+                    nchecked++;
+                    if (opt.top_chains > 0 && nchecked > opt.top_chains) break;
+                    float M = 0;
+                    uint32_t Mi = 0;
+                    while (imax >= 0) {
+                        M = lm_f32frombits((uint32_t)(s2[imax] >> 32));
+                        Mi = (uint32_t)s2[imax];
+                        if (!vis[Mi]) {
+                            imax--;
+                            break;
+                        }
+                        imax--;
+                    }
+                    if (M < opt.min_score) break;
+                    const int pstart = nidx;
+                    int i = (int)Mi;
+                    if (first) {
+                        max_score = M;
+                        first = false;
+                    }
+                    while (true) {
+                        const int j = (int)(ms[i] & 4294967295ull);
+                        const bool change = (i != j && dr[j] != 0 && dr[i] != dr[j]);
+                        if (vis[j] && !change) {
+                            nidx = pstart;
+                            vis[i] = 1;
+                            break;
+                        }
+                        chain_idx[nidx++] = i;
+                        vis[i] = 1;
+                        if (i == j || change) {
+                            if (change) chain_idx[nidx++] = j;
+                            for (int x = pstart, y = nidx - 1; x < y; x++, y--) {
+                                const int32_t t = chain_idx[x];
+                                chain_idx[x] = chain_idx[y];
+                                chain_idx[y] = t;
+                            }
+                            chain_off[++nchains] = nidx;
+                            break;
+                        } else {
+                            i = j;
+                        }
+                    }
+                }
+                result = max_score;
+            }
+        }
+        if (lane == 0) {
+            seg_n[s] = n;
+            seg_score[s] = result;
+            seg_nch[s] = nchains;
+        }
+        CHAIN1_WAVE_SYNC();
     }
 }
 
@@ -2675,9 +2950,14 @@ void launch_lookup_emit(hipStream_t st, DevIndexView ix, const uint64_t *kmers, 
 }
 void launch_chain1(hipStream_t st, const uint64_t *B, const int64_t *seg_off, int nseg, LmChainOpt opt, int K, LmSub *subs,
                    uint8_t *marks, uint64_t *msi, uint64_t *s2i, int8_t *dirs, uint8_t *visited, int32_t *chain_off_pool,
-                   int32_t *chain_idx_pool, int32_t *seg_n, float *seg_score, int32_t *seg_nch) {
+                   int32_t *chain_idx_pool, int32_t *seg_n, float *seg_score, int32_t *seg_nch, int32_t *big_list,
+                   unsigned int *big_count) {
+    // big_list (nseg entries) / big_count (zeroed by the caller): the pairs left to the wave kernel; null = all by lanes
     hipLaunchKernelGGL(k_chain1, dim3(grid_for(nseg, 64)), dim3(64), 0, st, B, seg_off, nseg, opt, K, subs, marks, msi, s2i,
-                       dirs, visited, chain_off_pool, chain_idx_pool, seg_n, seg_score, seg_nch);
+                       dirs, visited, chain_off_pool, chain_idx_pool, seg_n, seg_score, seg_nch, big_list, big_count);
+    if (big_list)
+        hipLaunchKernelGGL(k_chain1_wave, dim3(2048), dim3(256), 0, st, B, seg_off, opt, K, subs, marks, msi, s2i, dirs, visited,
+                           chain_off_pool, chain_idx_pool, seg_n, seg_score, seg_nch, big_list, big_count);
 }
 void launch_task_count(hipStream_t st, const float *seg_score, const int32_t *seg_nch, const uint8_t *keep, int nseg,
                        float min_score, int32_t *ntask) {

@@ -414,7 +414,7 @@ struct Work {
     DBuf<uint8_t> marks, visited;
     DBuf<uint64_t> msi, s2i;
     DBuf<int8_t> dirs;
-    DBuf<int32_t> chain_off_pool, chain_idx_pool, seg_n, seg_nch, order_scratch;
+    DBuf<int32_t> chain_off_pool, chain_idx_pool, seg_n, seg_nch, order_scratch, chain_big;
     DBuf<float> seg_score;
     // stage E
     DBuf<int32_t> ntask;
@@ -436,7 +436,7 @@ struct Work {
         f(keys_all); f(keys_all2); f(vals_all); f(vals_all2); f(first_mask); f(kmers); f(klo); f(khi); f(lk_counts);
         f(lk_list); f(lk_list2); f(lk_perm); f(lk_perm2); f(lk_offs); f(lk_starts); f(lk_nscan); f(A0); f(B0); f(A1);
         f(B1); f(segA); f(seg_len); f(seg_off); f(subs); f(marks); f(visited); f(msi); f(s2i); f(dirs);
-        f(chain_off_pool); f(chain_idx_pool); f(seg_n); f(seg_nch); f(order_scratch); f(seg_score); f(ntask);
+        f(chain_off_pool); f(chain_idx_pool); f(seg_n); f(seg_nch); f(order_scratch); f(chain_big); f(seg_score); f(ntask);
         f(task_off); f(task_wlen); f(task_woff);
     }
     void release_seeding(int64_t keep_below_bytes) {
@@ -651,9 +651,13 @@ static void stage_chain1(Work &w) {
     w.seg_n.ensure(nseg);
     w.seg_nch.ensure((size_t)nseg + 1);
     w.seg_score.ensure(nseg);
+    // pairs with many anchors go to the wave-cooperative kernel (list built by the lane kernel)
+    w.chain_big.ensure((size_t)nseg + 2);
+    HIPCHK(hipMemsetAsync(w.chain_big.p, 0, sizeof(int32_t) * 2, S(ix))); // [0] = count, list from [2]
     Prof p(ix, "k_chain1", T * 8 * 3);
     launch_chain1(S(ix), w.B0.p, w.seg_off.p, nseg, chain_opt(ix), ix->host.k, w.subs.p, w.marks.p, w.msi.p, w.s2i.p,
-                  w.dirs.p, w.visited.p, w.chain_off_pool.p, w.chain_idx_pool.p, w.seg_n.p, w.seg_score.p, w.seg_nch.p);
+                  w.dirs.p, w.visited.p, w.chain_off_pool.p, w.chain_idx_pool.p, w.seg_n.p, w.seg_score.p, w.seg_nch.p,
+                  ix->tune.chain1_wave ? w.chain_big.p + 2 : nullptr, (unsigned int *)w.chain_big.p);
 }
 
 // ---- host-side result assembly types ---------------------------------------------------------------------------
