@@ -66,6 +66,9 @@ def parse():
                         "default); queries = index replicated, query batch divided")
     p.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                    help="only with --shard queries: weak = every GPU searches its own batch of the workload's size")
+    p.add_argument("--loader-check", action="store_true",
+                   help="GPU-built workloads, N=1: write the index in the reference's on-disk format (lm_index_save), time "
+                        "lm_index_open on it and compare the packed image it builds with the one made in HBM (loader GB/s)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-exclusive-step", action="store_true",
                    help="skip the extra serialised step (outside the timed region) that gives the exclusive kernel durations")
@@ -462,6 +465,28 @@ def main():
         gi = la.Index(index_dir, la.api.default_options(**opt_kw), device=local_rank)
     info = gi.info()
     log("[rank %d] index ready in %.1f s: %s" % (rank, time.time() - t_setup, info))
+    loader = None
+    if args.loader_check and gpu_built and world == 1 and not shard_of:
+        sdir = os.path.join(tempfile.mkdtemp(prefix="lm_saved_"), "saved.lmi")
+        t0 = time.time()
+        gi.save(sdir, chunks=32)
+        t_save = time.time() - t0
+        disk = sum(os.path.getsize(os.path.join(r, f)) for r, _d, fs in os.walk(sdir) for f in fs)
+        gi.close()  # one image at a time in HBM
+        t0 = time.time()
+        gi = la.Index(sdir, device=local_rank)
+        t_load = time.time() - t0
+        info2 = gi.info()
+        same = all(info[f] == info2[f] for f in ("seeds", "genomes", "genome_bases", "seed_bytes", "outlier_seeds", "key_bits", "val_bits"))
+        loader = dict(index_files_bytes=int(disk), save_s=round(t_save, 2), open_s=round(t_load, 2),
+                      open_GBps_of_files=round(disk / t_load / 1e9, 3), seeds_per_s=round(info2["seeds"] / t_load),
+                      image_equal_to_hbm_built=bool(same),
+                      note="lm_index_save -> lm_index_open on the box's local disk; the searches below run on the LOADED index")
+        log("[rank 0] loader check: %s" % loader)
+        shutil.rmtree(os.path.dirname(sdir), ignore_errors=True)
+        if not same:
+            raise SystemExit("bench.py: the index loaded from disk differs from the one built in HBM: %s vs %s" % (info, info2))
+        info = info2
 
     if gpu_built and rank == 0:
         log("[rank 0] %d queries drawn in %.1f s" % (len(queries), time.time() - t_setup))
@@ -641,15 +666,18 @@ def main():
         # whole stage (prep + sort + count + scan + emit) against the same SURVEY 8(d) bytes
         roofline_lookup = None
         byname = {p["name"]: p for p in prof}
-        if "k_lookup_count" in byname:
-            roofline_lookup = roof(byname["k_lookup_count"])
-            names = ("k_lookup_prep", "sort_lookups", "k_lookup_count", "scan", "k_lookup_emit")
-            nl = max(byname["k_lookup_count"]["launches"], 1)
-            if prof_x and all(n in prof_x for n in names if n in byname):
-                stage_ms = sum(prof_x[n]["total_ms"] for n in names if n in prof_x) / max(prof_x["k_lookup_count"]["launches"], 1)
+        lk = "k_lookup_fused" if "k_lookup_fused" in byname else ("k_lookup_count" if "k_lookup_count" in byname else None)
+        if lk:
+            roofline_lookup = roof(byname[lk])
+            names = ("k_lookup_prep", "sort_lookups", "k_lookup_fused", "k_lookup_count", "scan", "k_lookup_emit")
+            nl = max(byname[lk]["launches"], 1)
+            if prof_x and lk in prof_x:
+                stage_ms = sum(prof_x[n]["total_ms"] for n in names if n in prof_x) / max(prof_x[lk]["launches"], 1)
+                stage_bytes = sum(prof_x[n]["bytes"] for n in (lk, "k_lookup_emit") if n in prof_x) / max(prof_x[lk]["launches"], 1)
             else:
                 stage_ms = sum(byname[n]["total_ms"] for n in names if n in byname) / nl
-            stage_bytes = (byname["k_lookup_count"]["bytes"] + byname.get("k_lookup_emit", {"bytes": 0})["bytes"]) / nl
+                stage_bytes = sum(byname[n]["bytes"] for n in (lk, "k_lookup_emit") if n in byname) / nl
+            roofline_lookup["stage"] = "k_lookup_prep + sort_lookups + %s%s" % (lk, "" if lk == "k_lookup_fused" else " + scan + k_lookup_emit")
             roofline_lookup["stage_ms"] = round(stage_ms, 4)
             roofline_lookup["stage_frac"] = round(stage_bytes / (stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if stage_ms > 0 else None
         # whole pipeline: sum of the algorithmic bytes of all kernels AND rocPRIM calls per step over the step time
@@ -704,6 +732,7 @@ def main():
             "kernels": kernels,
             "rocprim_calls": prims,
             "sharding_model": shard_model,
+            "loader": loader,
             "source_hash": source_hash(),
         }
     gi.free_batch(qb)

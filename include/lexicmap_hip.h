@@ -101,6 +101,10 @@ typedef struct lm_synth_spec {
 lm_status lm_index_build_synthetic(const lm_synth_spec *spec, const lm_options *opt, int device, lm_index **out);
 /* bases [start, start+len) of local genome `local_genome` as ASCII (used to derive synthetic queries) */
 lm_status lm_index_fetch(lm_index *idx, int64_t local_genome, int64_t start, int64_t len, uint8_t *out);
+/* Writes the resident (unsharded) index to `dir` in the reference's on-disk format: info.toml, masks.bin, seeds/chunk_NNN.bin
+ * (+ .idx, kv/kv-data.go:126-602) in `chunks` files, genomes/batch_NNNN/genomes.bin (+ .idx, genome/genome.go:217-357),
+ * genomes.map.bin.  lm_index_open / the oracle read it back; used to time the loader at benchmark scale on GPU-built sets. */
+lm_status lm_index_save(lm_index *idx, const char *dir, int chunks);
 /* Replaces (*Index).Close (lib-index-search.go:760) */
 void lm_index_close(lm_index *idx);
 lm_status lm_index_get_info(const lm_index *idx, lm_index_info *info);

@@ -149,6 +149,7 @@ def lib():
     L.lm_index_mask_seeds.argtypes = [vp, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_size_t,
                                       C.POINTER(C.c_size_t)]
     L.lm_index_fetch.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64, C.c_char_p]
+    L.lm_index_save.argtypes = [vp, C.c_char_p, C.c_int]
     L.lm_profile_enable.argtypes = [vp, C.c_int]
     L.lm_profile_reset.argtypes = [vp]
     L.lm_profile_exclusive.argtypes = [vp, C.c_int]
@@ -203,6 +204,12 @@ class Index:
         if st != 0:
             raise RuntimeError("lm_index_build_synthetic failed (%d): %s" % (st, L.lm_last_error(None).decode()))
         return cls(None, opt, device, _handle=h)
+
+    def save(self, path, chunks=16):
+        """the resident index written in the reference's on-disk format (lm_index_save)"""
+        st = lib().lm_index_save(self.h, path.encode(), chunks)
+        if st != 0:
+            self._err(st)
 
     def fetch(self, local_genome, start, length):
         buf = C.create_string_buffer(length)

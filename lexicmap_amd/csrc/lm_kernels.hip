@@ -57,27 +57,52 @@ __device__ __forceinline__ uint64_t encode_kmer(const uint8_t *s, int k) {
 }
 
 // posoff[q] = number of k-mer positions before query q; keys of query q live at [2*posoff[q], 2*posoff[q+1])
+// K (<= 32) bases from 32 readable bytes: two 16-byte loads instead of K byte loads
+__device__ __forceinline__ uint64_t encode_kmer32(const uint8_t *s, int k) {
+    uint32_t w[8];
+    __builtin_memcpy(w, s, 32);
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        const uint64_t b = lm_base2bit((uint8_t)(w[i >> 2] >> ((i & 3) << 3)));
+        if (i < k) c = (c << 2) | b;
+    }
+    return c;
+}
 __global__ void k_extract_kmers(const uint8_t *__restrict__ qseq, const int64_t *__restrict__ qoff,
                                 const int64_t *__restrict__ posoff, int nq, int K, uint64_t *__restrict__ keys_all,
                                 uint32_t *__restrict__ vals_all, uint64_t *__restrict__ keys_cmp,
                                 uint32_t *__restrict__ vals_cmp, int32_t *__restrict__ nvalid) {
-    int64_t total = posoff[nq];
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int q = find_segment(posoff, nq, i);
-        int pos = (int)(i - posoff[q]);
-        uint64_t fwd = encode_kmer(qseq + qoff[q] + pos, K);
-        uint64_t rc = lm_revcomp(fwd, K);
-        keys_all[2 * i] = fwd;
-        keys_all[2 * i + 1] = rc;
-        vals_all[2 * i] = (uint32_t)pos << 1;
-        vals_all[2 * i + 1] = ((uint32_t)pos << 1) | 1u;
-        // SeqComparator.Index filter (lib-seq_compare.go:143): both strands of a position are dropped together
-        bool filtered = fwd == 0 || lm_low_complexity(fwd, K);
-        keys_cmp[2 * i] = filtered ? (1ull << 63) : fwd;
-        keys_cmp[2 * i + 1] = filtered ? (1ull << 63) : rc;
-        vals_cmp[2 * i] = (uint32_t)pos << 1;
-        vals_cmp[2 * i + 1] = ((uint32_t)pos << 1) | 1u;
-        if (!filtered) atomicAdd(&nvalid[q], 2);
+    const int64_t total = posoff[nq], nbases = qoff[nq];
+    const int64_t nround = (total + blockDim.x - 1) / blockDim.x * blockDim.x; // whole wavefronts stay together (ballot below)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += (int64_t)gridDim.x * blockDim.x) {
+        const bool live = i < total;
+        int q = 0;
+        bool filtered = true;
+        if (live) {
+            q = find_segment(posoff, nq, i);
+            const int pos = (int)(i - posoff[q]);
+            const int64_t at = qoff[q] + pos;
+            const uint64_t fwd = at + 32 <= nbases ? encode_kmer32(qseq + at, K) : encode_kmer(qseq + at, K);
+            const uint64_t rc = lm_revcomp(fwd, K);
+            keys_all[2 * i] = fwd;
+            keys_all[2 * i + 1] = rc;
+            vals_all[2 * i] = (uint32_t)pos << 1;
+            vals_all[2 * i + 1] = ((uint32_t)pos << 1) | 1u;
+            // SeqComparator.Index filter (lib-seq_compare.go:143): both strands of a position are dropped together
+            filtered = fwd == 0 || lm_low_complexity(fwd, K);
+            keys_cmp[2 * i] = filtered ? (1ull << 63) : fwd;
+            keys_cmp[2 * i + 1] = filtered ? (1ull << 63) : rc;
+            vals_cmp[2 * i] = (uint32_t)pos << 1;
+            vals_cmp[2 * i + 1] = ((uint32_t)pos << 1) | 1u;
+        }
+        // the 64 positions of a wavefront nearly always belong to one query: one atomic for all of them (one per position
+        // was ~20 M atomics on ~1000 addresses per C3 part - most of the kernel's 23 ms)
+        const int q0 = __builtin_amdgcn_readfirstlane(q);
+        const bool mine = live && !filtered;
+        const uint64_t same = __ballot(mine && q == q0);
+        if ((threadIdx.x & 63) == 0 && same) atomicAdd(&nvalid[q0], 2 * (int)__popcll(same));
+        if (mine && q != q0) atomicAdd(&nvalid[q], 2);
     }
 }
 

@@ -15,6 +15,12 @@
 // shared words are merged with masked atomics).  No copy of the unpacked seeds ever exists.
 #include "lm_prims.h"
 
+#include <errno.h>
+#include <sys/stat.h>
+
+#include <atomic>
+#include <thread>
+
 namespace lm {
 
 #define SP_MAXN 1024 /* largest partition the LDS sorter takes; beyond: rocPRIM fallback */
@@ -514,6 +520,289 @@ extern "C" lm_status lm_index_mask_seeds(lm_index *ix, int32_t mask, uint64_t *k
                 HIPCHK(hipMemcpy(vals + w, ix->d_out_vals.p + oo[dir], (size_t)no * 8, hipMemcpyDeviceToHost));
                 w += (size_t)no;
             }
+        }
+        return LM_OK;
+    } catch (const std::exception &e) {
+        ix->err = e.what();
+        return LM_ERR_HIP;
+    }
+}
+
+// ---- the HBM image written back in the reference's on-disk format ---------------------------------------------------------
+// `lexicmap index` output as the reference reads it: info.toml (lib-index-build.go:1914-1932),
+// masks.bin, seeds/chunk_NNN.bin + .idx (kv/kv-data.go:126-602: per mask the distinct k-mers ascending, two per record,
+// k-mer deltas and value counts group-varint coded, 7-byte values while there are <= 512 genome batches; the .idx holds the
+// first k-mer and offset of every anchor partition present), genomes/batch_NNNN/genomes.bin + .idx (genome/genome.go:217-357),
+// genomes.map.bin (lib-index-build.go:649-655).  What it is for here: the GPU-built benchmark sets become reference-format
+// indexes, so the loader (lm_index_open) is exercised and timed at their size and its packed image can be compared with the
+// one the builder made in HBM; and any HBM-resident index can be handed to the Go `lexicmap search`.
+namespace lm {
+namespace {
+struct OutFile {
+    FILE *f = nullptr;
+    int64_t n = 0;
+    bool bad = false;
+    explicit OutFile(const std::string &p) {
+        f = fopen(p.c_str(), "wb");
+        bad = f == nullptr;
+    }
+    ~OutFile() {
+        if (f) fclose(f);
+    }
+    void put(const void *p, size_t len) {
+        if (!bad && len && fwrite(p, 1, len, f) != len) bad = true;
+        n += (int64_t)len;
+    }
+    void be(uint64_t v, int bytes) {
+        uint8_t b[8];
+        for (int i = 0; i < bytes; i++) b[i] = (uint8_t)(v >> (8 * (bytes - 1 - i)));
+        put(b, (size_t)bytes);
+    }
+};
+inline void push_be(std::vector<uint8_t> &o, uint64_t v, int bytes) {
+    for (int i = bytes - 1; i >= 0; i--) o.push_back((uint8_t)(v >> (8 * i)));
+}
+inline int byte_len(uint64_t v) {
+    int n = 1;
+    while (n < 8 && (v >> (8 * n)) != 0) n++;
+    return n;
+}
+// control byte + the two numbers in their minimal big-endian widths (util/varint-GB.go:28-46)
+inline void push_pair(std::vector<uint8_t> &o, uint64_t a, uint64_t b, uint8_t flags) {
+    const int la = byte_len(a), lb = byte_len(b);
+    o.push_back((uint8_t)(flags | ((la - 1) << 3) | (lb - 1)));
+    push_be(o, a, la);
+    push_be(o, b, lb);
+}
+bool make_dir(const std::string &p) { return mkdir(p.c_str(), 0777) == 0 || errno == EEXIST; }
+
+// one mask's seeds (any order) -> its block of the chunk file (relative offsets) + its .idx records (kmer, rel offset<<1|second)
+void encode_mask(std::vector<std::pair<uint64_t, uint64_t>> &kv, int K, int mask_prefix, int anchor_prefix, bool use7,
+                 std::vector<uint8_t> &data, std::vector<std::pair<uint64_t, uint64_t>> &idx) {
+    data.clear();
+    idx.clear();
+    std::sort(kv.begin(), kv.end());
+    // distinct k-mers: [start, end) runs
+    std::vector<size_t> runs;
+    for (size_t i = 0; i < kv.size(); i++)
+        if (i == 0 || kv[i].first != kv[i - 1].first) runs.push_back(i);
+    const size_t nk = runs.size();
+    push_be(data, (uint64_t)nk, 8);
+    if (nk == 0) return;
+    runs.push_back(kv.size());
+    const int vb = use7 ? 7 : 8;
+    const int shift = (K - mask_prefix - anchor_prefix) << 1;
+    const uint64_t amask = ((uint64_t)1 << (anchor_prefix << 1)) - 1;
+    uint64_t seen_part = ~(uint64_t)0, prev_second = 0; // previous record's second k-mer (the delta base)
+    auto note = [&](uint64_t kmer, bool second, size_t at) { // first k-mer of every anchor partition, in file order
+        const uint64_t part = (kmer >> shift) & amask;
+        if (part != seen_part) {
+            seen_part = part;
+            idx.emplace_back(kmer, ((uint64_t)at << 1) | (second ? 1u : 0u));
+        }
+    };
+    for (size_t r = 0; r < nk; r += 2) {
+        const bool pair = r + 1 < nk, last = r + 2 >= nk;
+        const uint64_t k1 = kv[runs[r]].first, k2 = pair ? kv[runs[r + 1]].first : 0;
+        const uint64_t n1 = runs[r + 1] - runs[r], n2 = pair ? runs[r + 2] - runs[r + 1] : 0;
+        const size_t at = data.size();
+        note(k1, false, at);
+        if (pair) note(k2, true, at);
+        push_pair(data, k1 - prev_second, pair ? k2 - k1 : 0, (uint8_t)((last ? 128 : 0) | (pair ? 0 : 64)));
+        push_pair(data, n1, n2, 0);
+        for (size_t i = runs[r]; i < runs[r] + n1 + n2; i++) push_be(data, kv[i].second, vb);
+        prev_second = pair ? k2 : k1;
+    }
+}
+} // namespace
+} // namespace lm
+
+extern "C" lm_status lm_index_save(lm_index *ix, const char *dir_c, int chunks) {
+    using namespace lm;
+    if (!ix || !dir_c) return LM_ERR_ARG;
+    std::lock_guard<std::mutex> lock(ix->mu);
+    const HostIndex &h = ix->host;
+    if (h.shard_count > 1) {
+        ix->err = "lm_index_save: a shard of an index cannot be saved (open or build it unsharded)";
+        return LM_ERR_ARG;
+    }
+    try {
+        HIPCHK(hipSetDevice(ix->device));
+        const std::string dir(dir_c);
+        const int M = h.M, K = h.k;
+        if (chunks < 1) chunks = 1;
+        if (chunks > M) chunks = M;
+        const int nbatches = std::max(1, h.genome_batches > 0 ? h.genome_batches : (int)((h.genomes.size() + 4999) / 5000));
+        const bool use7 = nbatches <= 512; // kv-data.go:137
+        if (!make_dir(dir) || !make_dir(dir + "/seeds") || !make_dir(dir + "/genomes")) throw HipError("lm_index_save: cannot create " + dir);
+        // ---- masks.bin (this build's layout, lm_format.cpp) and info.toml
+        {
+            OutFile f(dir + "/masks.bin");
+            f.put("LMMASKS1", 8);
+            f.be((uint64_t)K, 1);
+            f.be(0, 3);
+            f.be((uint64_t)M, 4);
+            f.be(0, 8);
+            for (int i = 0; i < M; i++) f.be(h.masks[i], 8);
+            if (f.bad) throw HipError("lm_index_save: write failed (masks.bin)");
+        }
+        int64_t gbases = 0;
+        for (auto &g : h.genomes) gbases += g.genome_size;
+        {
+            OutFile f(dir + "/info.toml");
+            char t[1024];
+            const int n = snprintf(t, sizeof t,
+                                   "# Index format\nmain-version = 3\nminor-version = 5\n# LexicHash\nmax-K = %d\nmasks = %d\nrand-seed = 1\n"
+                                   "# Seed distance\nmax-seed-dist = 100\nseed-dist-in-desert = 50\n# Seeds (k-mer-value data) files\nchunks = %d\n"
+                                   "index-partitions = %d\n# Input genomes\ninput-genomes = %lld\ninput-bases = %lld\n# Genome data\ngenomes = %lld\n"
+                                   "genome-batch-size = 5000\ngenome-batches = %d\ncontig-interval = %d\n",
+                                   K, M, chunks, 1 << (2 * h.anchor_prefix), (long long)h.genomes.size(),
+                                   (long long)(h.total_bases > 0 ? h.total_bases : gbases), (long long)h.genomes.size(), nbatches,
+                                   h.contig_interval);
+            f.put(t, (size_t)n);
+            if (f.bad) throw HipError("lm_index_save: write failed (info.toml)");
+        }
+        // ---- genomes: batches of 5000 in dense order, bases straight from the 2-bit store in HBM
+        {
+            OutFile fmap(dir + "/genomes.map.bin");
+            std::vector<uint8_t> bits;
+            for (int b = 0; b < nbatches; b++) {
+                char nm[64];
+                snprintf(nm, sizeof nm, "/genomes/batch_%04d", b);
+                if (!make_dir(dir + nm)) throw HipError("lm_index_save: cannot create the genome batch directory");
+                OutFile fg(dir + nm + "/genomes.bin"), fi(dir + nm + "/genomes.bin.idx");
+                fg.put(".genomes", 8);
+                fg.be(0, 1);
+                fg.be(1, 1);
+                fg.be(0, 6);
+                std::vector<const HostGenome *> members;
+                for (auto &g : h.genomes)
+                    if ((int)(g.bg >> 17) == b) members.push_back(&g);
+                std::sort(members.begin(), members.end(), [](const HostGenome *x, const HostGenome *y) { return x->bg < y->bg; });
+                fi.put(".genomei", 8);
+                fi.be(0, 1);
+                fi.be(1, 1);
+                fi.be(0, 6);
+                fi.be((uint64_t)b, 4);
+                fi.be((uint64_t)members.size(), 4);
+                for (const HostGenome *g : members) {
+                    fi.be((uint64_t)fg.n, 8);
+                    fi.be((uint64_t)g->len, 4);
+                    fg.be(g->id.size(), 2);
+                    fg.put(g->id.data(), g->id.size());
+                    fg.be((uint64_t)g->genome_size, 4);
+                    fg.be((uint64_t)g->len, 4);
+                    fg.be((uint64_t)g->nseqs, 4);
+                    for (int s = 0; s < g->nseqs; s++) {
+                        fg.be((uint64_t)g->seq_sizes[s], 4);
+                        fg.be(g->seq_ids[s].size(), 2);
+                        fg.put(g->seq_ids[s].data(), g->seq_ids[s].size());
+                    }
+                    const size_t nb = ((size_t)g->len + 3) >> 2;
+                    bits.resize(nb);
+                    HIPCHK(hipMemcpy(bits.data(), ix->d_gbits.p + g->bits_off, nb, hipMemcpyDeviceToHost));
+                    fg.be(nb, 4);
+                    fg.be((uint64_t)g->len, 4);
+                    fg.put(bits.data(), nb);
+                    fmap.be(g->id.size(), 2);
+                    fmap.put(g->id.data(), g->id.size());
+                    fmap.be(g->bg, 8);
+                }
+                if (fg.bad || fi.bad) throw HipError("lm_index_save: write failed (genomes)");
+            }
+            if (fmap.bad) throw HipError("lm_index_save: write failed (genomes.map.bin)");
+        }
+        // ---- seeds: masks split evenly over the chunk files (lib-index-build.go:1861-1889)
+        std::vector<int64_t> md_off((size_t)2 * M + 1), out_off((size_t)2 * M + 1);
+        HIPCHK(hipMemcpy(md_off.data(), ix->d_md_off.p, md_off.size() * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(out_off.data(), ix->d_out_off.p, out_off.size() * 8, hipMemcpyDeviceToHost));
+        DBuf<uint64_t> dk, dv;
+        const int per = (M + chunks - 1) / chunks;
+        for (int c = 0, m0 = 0; m0 < M; c++, m0 += per) {
+            const int m1 = std::min(M, m0 + per);
+            // every list of the chunk's masks unpacked into one buffer, one copy to the host
+            const int64_t s0 = md_off[(size_t)2 * m0], s1 = md_off[(size_t)2 * m1], ns = s1 - s0;
+            std::vector<uint64_t> hk((size_t)ns), hv((size_t)ns);
+            if (ns > 0) {
+                dk.ensure((size_t)ns);
+                dv.ensure((size_t)ns);
+                for (int md = 2 * m0; md < 2 * m1; md++) {
+                    const int64_t nm = md_off[(size_t)md + 1] - md_off[(size_t)md];
+                    if (nm > 0)
+                        hipLaunchKernelGGL(lm::k_sp_dump_list, dim3(lm::sp_grid(nm)), dim3(256), 0, ix->st, ix->view, (uint32_t)md, nm,
+                                           dk.p + (md_off[(size_t)md] - s0), dv.p + (md_off[(size_t)md] - s0));
+                }
+                HIPCHK(hipMemcpyAsync(hk.data(), dk.p, (size_t)ns * 8, hipMemcpyDeviceToHost, ix->st));
+                HIPCHK(hipMemcpyAsync(hv.data(), dv.p, (size_t)ns * 8, hipMemcpyDeviceToHost, ix->st));
+                HIPCHK(hipStreamSynchronize(ix->st));
+            }
+            const int64_t o0 = out_off[(size_t)2 * m0], o1 = out_off[(size_t)2 * m1], no = o1 - o0;
+            std::vector<uint64_t> ok((size_t)no), ov((size_t)no);
+            if (no > 0) {
+                HIPCHK(hipMemcpy(ok.data(), ix->d_out_kmers.p + o0, (size_t)no * 8, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(ov.data(), ix->d_out_vals.p + o0, (size_t)no * 8, hipMemcpyDeviceToHost));
+            }
+            // encode the masks on the host threads, then lay the blocks out and fix the offsets up
+            const int nm = m1 - m0;
+            std::vector<std::vector<uint8_t>> blocks((size_t)nm);
+            std::vector<std::vector<std::pair<uint64_t, uint64_t>>> recs((size_t)nm);
+            std::atomic<int> next{0};
+            auto work = [&]() {
+                std::vector<std::pair<uint64_t, uint64_t>> kv;
+                for (int j; (j = next.fetch_add(1)) < nm;) {
+                    const int m = m0 + j;
+                    kv.clear();
+                    for (int64_t i = md_off[(size_t)2 * m] - s0; i < md_off[(size_t)2 * m + 2] - s0; i++) kv.emplace_back(hk[(size_t)i], hv[(size_t)i]);
+                    for (int64_t i = out_off[(size_t)2 * m] - o0; i < out_off[(size_t)2 * m + 2] - o0; i++) kv.emplace_back(ok[(size_t)i], ov[(size_t)i]);
+                    encode_mask(kv, K, h.mask_prefix, h.anchor_prefix, use7, blocks[(size_t)j], recs[(size_t)j]);
+                }
+            };
+            {
+                const int nth = std::max(1, std::min<int>(16, (int)std::thread::hardware_concurrency()));
+                std::vector<std::thread> th;
+                for (int t = 1; t < nth; t++) th.emplace_back(work);
+                work();
+                for (auto &t : th) t.join();
+            }
+            char nmf[64];
+            snprintf(nmf, sizeof nmf, "/seeds/chunk_%03d.bin", c);
+            OutFile fd(dir + nmf), fx(dir + nmf + ".idx");
+            fd.put(".kv-data", 8);
+            fd.be(1, 1);
+            fd.be(1, 1);
+            fd.be((uint64_t)K, 1);
+            fd.be(use7 ? 1 : 0, 1);
+            fd.be(0, 4);
+            fd.be((uint64_t)m0, 8);
+            fd.be((uint64_t)nm, 8);
+            fx.put(".kvindex", 8);
+            fx.be(1, 1);
+            fx.be(1, 1);
+            fx.be((uint64_t)K, 1);
+            fx.be((uint64_t)h.mask_prefix, 1);
+            fx.be((uint64_t)h.anchor_prefix, 1);
+            fx.be(use7 ? 1 : 0, 1);
+            fx.be(0, 2);
+            fx.be((uint64_t)m0, 8);
+            fx.be((uint64_t)nm, 8);
+            for (int j = 0; j < nm; j++) {
+                const int64_t at = fd.n; // the mask's block starts with its k-mer count
+                fd.put(blocks[(size_t)j].data(), blocks[(size_t)j].size());
+                const auto &r = recs[(size_t)j];
+                if (r.empty()) {
+                    fx.be(0, 8);
+                    continue;
+                }
+                // record 0: (number of records, offset of the mask's first record << 1), then one per anchor partition present
+                fx.be((uint64_t)r.size() + 1, 8);
+                fx.be((uint64_t)r.size() + 1, 8);
+                fx.be((uint64_t)(at + 8) << 1, 8);
+                for (auto &e : r) {
+                    fx.be(e.first, 8);
+                    fx.be((((e.second >> 1) + (uint64_t)at) << 1) | (e.second & 1), 8);
+                }
+            }
+            if (fd.bad || fx.bad) throw HipError("lm_index_save: write failed (seeds)");
         }
         return LM_OK;
     } catch (const std::exception &e) {

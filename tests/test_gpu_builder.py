@@ -114,6 +114,47 @@ def test_every_mask_list_equals_the_oracle_writer(synth_index, tmp_path):
     assert nrev > 1000 and ndesert > 1000   # reversed twins and desert seeds were among what was compared
 
 
+def test_saved_index_round_trip_and_oracle_reads_it(synth_index, tmp_path):
+    """f1 / a20: lm_index_save writes the HBM image in the reference's on-disk format; the loader rebuilds the SAME packed
+    image from it (same seeds under every sampled mask, same rows), and the oracle - an independent reader of that format -
+    opens it and returns the same rows"""
+    import lexicmap_amd as la
+    gi = synth_index
+    d = str(tmp_path / "saved.lmi")
+    gi.save(d, chunks=5)
+    li = la.Index(d)
+    a, b = gi.info(), li.info()
+    for f in ("k", "masks", "genomes", "seeds", "genome_bases", "total_bases", "outlier_seeds", "key_bits", "partition_bases"):
+        assert a[f] == b[f], f
+    for m in (0, 1, 77, 4099, 12345, 19999):
+        k1, v1 = gi.mask_seeds(m)
+        k2, v2 = li.mask_seeds(m)
+        assert sorted(zip(k1.tolist(), v1.tolist())) == sorted(zip(k2.tolist(), v2.tolist())), m
+    seqs = [gi.fetch(4, 50_000, 1500), gi.fetch(7, 120_000, 3000)[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA")),
+            gi.fetch(2, 10, 800)]
+    r1, _ = gi.search(seqs)
+    r2, _ = li.search(seqs)
+    assert len(r1) == len(r2) > 6
+    for x, y in zip(r1, r2):
+        for f in x:
+            if f not in ("genome_id", "seq_id"):
+                assert x[f] == y[f], f
+        assert x["genome_id"] == y["genome_id"] and x["seq_id"] == y["seq_id"]
+    li.close()
+    oi = O.Index(d)
+    n = 0
+    for qi, s in enumerate(seqs):
+        exp, st = oi.search(s)
+        got = [r for r in r1 if r["query"] == qi]
+        assert len(exp) == len(got)
+        for e, g in zip(exp, got):
+            for f in ("batch_genome", "aligned_length", "qbegin", "qend", "tbegin", "tend", "bitscore", "gaps", "pident"):
+                assert e[f] == g[f], (qi, f)
+        n += len(exp)
+    oi.close()
+    assert n == len(r1)
+
+
 def test_seed_density_like_reference_builder(synth_index):
     """~2*(M + 0.9*L/50) seeds per genome: the desert filling and the reversed copies are in place"""
     info = synth_index.info()
