@@ -326,20 +326,44 @@ __device__ __forceinline__ int closest_mask(const MaskTab &mt, uint64_t x) {
 // under that mask - the LAST (largest-index) mask that captures it.  A wavefront takes 64 seed pairs, finds the deserts
 // among them and walks them one after the other; the capture test of a candidate is a sweep of the window by the 64 lanes
 // (is any window k-mer of either strand with the same p-base prefix closer to the mask?).
+// the p-base prefixes (p <= 16) of the k-mer at `pos` and of its reverse complement, from one 32-base window of the 2-bit
+// genome: all the sweep below needs for the ~16 000 : 1 window k-mers that do not share the candidate's prefix
+__device__ __forceinline__ void kmer_prefixes(const uint8_t *gb, int64_t pos, int K, int p, uint32_t *fwd, uint32_t *rc) {
+    const int64_t byte = pos >> 2;
+    const uint64_t *q = (const uint64_t *)(gb + (byte & ~7ll));
+    const uint64_t H = __builtin_bswap64(q[0]), L = __builtin_bswap64(q[1]);
+    const int o = (int)(byte & 7) * 8 + (int)(pos & 3) * 2; // 0..62
+    const uint64_t v = o ? ((H << o) | (L >> (64 - o))) : H; // 32 bases from pos, left aligned
+    *fwd = (uint32_t)(v >> (64 - 2 * p));
+    const uint32_t last = (uint32_t)(v >> (64 - 2 * K)) & ((1u << (2 * p)) - 1u); // the last p bases of the k-mer
+    uint32_t y = __builtin_bitreverse32(~last);                                    // complement, reverse the bits ...
+    y = ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);                       // ... and put the base pairs back in order
+    *rc = y >> (32 - 2 * p);
+}
 __device__ __forceinline__ int desert_capturing_mask(const MaskTab &mt, const uint8_t *gb, int64_t wstart, int nk, uint64_t x,
                                                      int lane) {
     const int shift = (mt.K - mt.p) << 1;
-    const uint64_t pf = x >> shift;
-    int im = -1;
-    for (int j = mt.pfx_first[pf]; j < mt.pfx_first[pf + 1]; j++) {
-        const uint64_t mk = mt.masks[j], hx = mk ^ x;
-        bool beaten = false;
-        for (int w = lane; w < nk; w += 64) {
+    const uint32_t pf = (uint32_t)(x >> shift);
+    const int j0 = mt.pfx_first[pf], j1 = mt.pfx_first[pf + 1];
+    if (j0 >= j1) return -1;
+    // one sweep of the window for all (one or two) masks of the prefix: bit j - j0 = x is beaten for mask j
+    uint32_t beaten = 0;
+    for (int w = lane; w < nk; w += 64) {
+        uint32_t pfw, prc;
+        kmer_prefixes(gb, wstart + w, mt.K, mt.p, &pfw, &prc);
+        if (pfw == pf || prc == pf) {
             const uint64_t f = packed_kmer(gb, wstart + w, mt.K), r = lm_revcomp(f, mt.K);
-            beaten |= ((f >> shift) == pf && (mk ^ f) < hx) || ((r >> shift) == pf && (mk ^ r) < hx);
+            for (int j = j0; j < j1 && j - j0 < 32; j++) {
+                const uint64_t mk = mt.masks[j], hx = mk ^ x;
+                if ((pfw == pf && (mk ^ f) < hx) || (prc == pf && (mk ^ r) < hx)) beaten |= 1u << (j - j0);
+            }
         }
-        if (__ballot(beaten) == 0ull) im = j; // x attains the window's minimum for mask j; the last such mask is recorded
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) beaten |= (uint32_t)__shfl_xor((int)beaten, o, 64);
+    int im = -1;
+    for (int j = j0; j < j1 && j - j0 < 32; j++)
+        if (!((beaten >> (j - j0)) & 1u)) im = j; // x attains the window's minimum for mask j; the last such mask is recorded
     return im;
 }
 __global__ __launch_bounds__(256) void k_desert_fill(SynthDev sp, MaskTab mt, const uint8_t *__restrict__ gbits, int64_t l0,

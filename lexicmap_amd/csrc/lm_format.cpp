@@ -225,6 +225,10 @@ std::string load_index(const std::string &dir, int shard_rank, int shard_count, 
         out.k = (int)tk;
         out.M = (int)tm;
         mask_at = 32;
+        // not silently: this layout was inferred, no index written by the reference's own `lexicmap index` has been seen
+        fprintf(stderr, "[lexicmap_hip] warning: %s/masks.bin is not in this build's LMMASKS1 layout; read as a headered big-endian "
+                        "mask list (k = %d, %d masks, ascending) - the lexichash file layout is not verified against an upstream "
+                        "file (DESIGN.md section 5)\n", dir.c_str(), out.k, out.M);
     }
     if (buf.size() < mask_at + (size_t)out.M * 8 || out.k < 1 || out.k > 32) {
         status = 2;

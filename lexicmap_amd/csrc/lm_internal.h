@@ -291,12 +291,14 @@ struct lm_tune {
     int wfa_win[LM_WFA_CLASSES] = {0, 0, 1, 0, 1};
     int chain1_wave = 1;     // seed chaining of pairs with many anchors by a wavefront each (LM_CHAIN1_LANES=1: one lane per pair)
     int pa_seg_by_group = 1; // candidate segments by task group + XCD-local k_pa_search (LM_PA_SEG_BY_WAVE=1: by wavefront)
+    int wfa_resident_pct = 100; // LM_WFA_RESIDENT_PCT: share of the CUs' wavefront slots / LDS the persistent WFA kernels take
     FILE *wfa_dump = nullptr; // LM_DEBUG_WFA_DUMP=<file>: one line per WFA problem and pass (width, status, lengths, estimate, score)
     int wfa_serial = 0;      // LM_WFA_SERIAL=1: the WFA length classes one after the other (exclusive kernel timings)
     int no_pipeline = 0;     // LM_NO_PIPELINE=1: no pseudo-alignment producer beside extend / WFA (exclusive kernel timings)
     lm_tune() {
         wfa_serial = getenv("LM_WFA_SERIAL") != nullptr;
         if (const char *e = getenv("LM_DEBUG_WFA_DUMP")) wfa_dump = fopen(e, "a");
+        if (const char *e = getenv("LM_WFA_RESIDENT_PCT")) wfa_resident_pct = std::max(5, std::min(100, atoi(e)));
         if (const char *e = getenv("LM_WFA_FIRST_NC")) {
             int v[LM_WFA_CLASSES];
             if (sscanf(e, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]) == LM_WFA_CLASSES)

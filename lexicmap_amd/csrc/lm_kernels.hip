@@ -2593,25 +2593,19 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
             hdr2[2] = 0;
             hdr2[3] = 1;
         }
-        // does the slot range of diagonals [lo, hi] touch the 64 slots of chunk c ?
-        auto chunk_has = [&](int c, int lo_, int hi_) {
-            if (NC == 1) return true;
-            const int s0 = (lo_ + koff) & (W - 1), s1 = s0 + (hi_ - lo_); // s1 < 2W: slots [s0, s1], wrapping past W
-            const int c0 = 64 * c, c1 = 64 * c + 63;
-            return (s0 <= c1 && s1 >= c0) || (s1 >= W && s1 - W >= c0);
-        };
-        // the same for all chunks at once (bit c), a dozen scalar instructions per range instead of a dozen per chunk and
-        // loop: the wide rings (8 / 16 chunks, of which a wavefront touches two to eight) spent more scalar time deciding
-        // which chunks to skip than on anything else
+        // Which of the NC chunks of 64 slots does the slot range of diagonals [lo, hi] touch (bit c) ?  Computed once per range,
+        // a dozen scalar instructions, instead of per chunk and loop: the scalar unit is what bounds this kernel (one per
+        // CU, shared by all its wavefronts), and the wide rings (8 / 16 chunks, of which a wavefront touches two to eight)
+        // spent more scalar time deciding which chunks to skip than on anything else
         auto chunk_mask = [&](int lo_, int hi_) -> uint32_t {
-            if (NC <= 2) return 0xffffffffu; // (chunk_has is used there)
+            if (NC == 1) return 1u;
             const int s0 = (lo_ + koff) & (W - 1), s1 = s0 + (hi_ - lo_);
             const int cf = s0 >> 6, cl = (s1 >> 6) < NC - 1 ? (s1 >> 6) : NC - 1;
             uint32_t m = ((2u << (cl - cf)) - 1u) << cf;
             if (s1 >= W) m |= (2u << ((s1 - W) >> 6)) - 1u;
             return (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
         };
-        auto chunk_on = [&](uint32_t cm, int c, int lo_, int hi_) { return NC <= 2 ? chunk_has(c, lo_, hi_) : ((cm >> c) & 1u) != 0; };
+        auto chunk_on = [&](uint32_t cm, int c, int lo_, int hi_) { return NC == 1 ? true : ((cm >> c) & 1u) != 0; };
         while (status == 0) {
             bool done = false;
             if (mlo[0] <= mhi[0]) {

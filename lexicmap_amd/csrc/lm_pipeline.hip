@@ -1434,6 +1434,16 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
     if (const char *e = getenv("LM_DEBUG_PA_CAP")) a.pa_cap = std::max<int64_t>(1, atoll(e)); // test hook: force the re-run
     int64_t TP = 0;
     int nseg = 1;
+    // candidate segments by task-group range + XCD-local search pay when a query's comparison tables (12 B per k-mer and
+    // strand + the bucket table) are a sizeable part of an XCD's 4-MB L2: long reads.  For gene-sized queries (tables of tens of
+    // KB: they stay in L2 anyway) the many small blocks per range only cost (C2: k_pa_search 4.2 -> 6.4 ms), so those keep
+    // the plain layout
+    bool by_group = ix->tune.pa_seg_by_group != 0;
+    {
+        int64_t maxq = 0;
+        for (int q = 0; q < qb->nq; q++) maxq = std::max<int64_t>(maxq, qb->h_qoff[q + 1] - qb->h_qoff[q]);
+        if (maxq < 8192) by_group = false;
+    }
     for (int attempt = 0;; attempt++) {
         if (!compact) a.A0.ensure((size_t)a.pa_cap);
         a.B0.ensure((size_t)a.pa_cap);
@@ -1441,7 +1451,7 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
         // the candidate list in segments with a counter each (k_pa_filter), at least 4096 entries per segment; segments by
         // task group: never more segments than groups, and a re-run after an overflow keeps the number of segments (the
         // measured fullest segment then sizes the next attempt exactly)
-        if (!ix->tune.pa_seg_by_group) {
+        if (!by_group) {
             nseg = (int)std::max<int64_t>(1, std::min<int64_t>(1024, a.pa_cap / 4096));
         } else if (attempt == 0) { // ranges of task groups x LM_PA_RANGE_SEGS segments each
             const int64_t ngroups = (nt + LM_PA_GROUP - 1) / LM_PA_GROUP;
@@ -1455,14 +1465,14 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
             Prof p(ix, "k_pa_filter", W);
             launch_pa_filter(S(ix), ix->view, tasks_d, nt, a.wb, qb->d_posoff.p, a.w->nvalid.p, a.w->cmp_bits.p,
                              qb->d_bits_off.p, qb->d_bits_log.p, ix->host.k, 11, a.pa_count.p + 2, nseg, seg_cap, a.B1.p,
-                             a.pa_count.p + 1, device_cus(ix->device), ix->tune.pa_seg_by_group);
+                             a.pa_count.p + 1, device_cus(ix->device), by_group ? 1 : 0);
         }
         {
             Prof p(ix, "k_pa_search");
             launch_pa_search(S(ix), ix->view, tasks_d, a.wb, a.w->k_cmp, a.w->v_cmp, qb->d_posoff.p, a.w->nvalid.p,
                              a.w->cmp_tab.p, qb->d_tab_off.p, qb->d_tab_bits.p, ix->host.k, 11, a.pa_count.p + 2, nseg, seg_cap,
                              a.B1.p, a.pa_count.p, a.pa_cap, a.A0.p, a.B0.p, compact ? qbits : 0, compact ? tbits : 0,
-                             ix->tune.pa_seg_by_group);
+                             by_group ? 1 : 0);
         }
         std::vector<unsigned long long> hv((size_t)2 + nseg);
         HIPCHK(hipMemcpyAsync(hv.data(), a.pa_count.p, hv.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, S(ix)));
@@ -1777,7 +1787,7 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
         const int64_t m = (int64_t)items.size();
         if (m == 0) return;
         const int resident = wfa_resident_blocks(ix->device, seq_words, nc, use_win);
-        int nblocks = (int)std::min<int64_t>(m, resident);
+        int nblocks = (int)std::min<int64_t>(m, std::max<int64_t>(256, (int64_t)resident * ix->tune.wfa_resident_pct / 100));
         // private scratch per resident wave: one backtrace byte per wavefront cell + 8 bytes per even score; never
         // more than the longest problem of the class is expected to need
         const int64_t smax = std::min<int64_t>(8 * lmax + 64, s_expect); // a global alignment never exceeds 8 per base
@@ -2910,6 +2920,11 @@ static void search_parts(lm_index *ix, lm_qbatch *qb, lm_result *res, const Sear
             if (qb->nq < 2) throw;
             drop_scratch(ix, e.what());
         }
+        // what the aborted attempt left in the caller's result (rows, CIGAR / alignment strings) must not outlive it
+        for (auto *str : res->strings) delete str;
+        res->strings.clear();
+        res->rows.clear();
+        res->stats = lm_stage_stats();
         auto ab = halve_qbatch(ix, qb);
         qb->parts = {ab.first, ab.second};
         qb->d_seq.release(); // the plain batch's own device copy is no longer used
@@ -3380,78 +3395,124 @@ lm_status lm_merge_sharded(lm_index *ix, const lm_hsp *const *rows, const size_t
         memset(&res->stats, 0, sizeof res->stats);
         size_t total = 0;
         for (int r = 0; r < nshards; r++) total += nrows[r];
-        res->rows.reserve(total);
-        std::vector<size_t> pos((size_t)nshards, 0);
-        struct Grp {
-            int rank;
+        // Per shard the rows are grouped by query, ascending.  First the (query -> row range) table of every shard and the
+        // output position of every query; then the queries are merged independently on the host threads (at 8 shards x
+        // 6e5 rows the single-threaded merge was 0.33 s of a 2.1-s step: the serial part of the N-GPU run).
+        struct QRange {
+            uint32_t q;
             size_t b, e;
-            uint64_t bg;
-            double best;
         };
-        std::vector<Grp> grps;
-        while (true) {
-            // next query = the smallest one any shard still has rows for (rows of a shard are grouped by query, ascending)
-            uint32_t q = 0;
-            bool any = false;
-            for (int r = 0; r < nshards; r++)
-                if (pos[r] < nrows[r] && (!any || rows[r][pos[r]].query < q)) {
-                    q = rows[r][pos[r]].query;
-                    any = true;
-                }
-            if (!any) break;
-            grps.clear();
-            for (int r = 0; r < nshards; r++) {
-                size_t i = pos[r];
-                while (i < nrows[r] && rows[r][i].query == q) {
-                    Grp g{r, i, i, rows[r][i].batch_genome, 0.0};
-                    while (g.e < nrows[r] && rows[r][g.e].query == q && rows[r][g.e].batch_genome == g.bg) {
-                        const double sim = (double)rows[r][g.e].bitscore * rows[r][g.e].pident; // SimilarityScore (:2352,2621)
-                        if (sim > g.best) g.best = sim;
-                        g.e++;
-                    }
-                    grps.push_back(g);
-                    i = g.e;
-                }
-                pos[r] = i;
+        std::vector<std::vector<QRange>> qr((size_t)nshards);
+        for (int r = 0; r < nshards; r++)
+            for (size_t i = 0; i < nrows[r];) {
+                size_t e = i + 1;
+                while (e < nrows[r] && rows[r][e].query == rows[r][i].query) e++;
+                if (!qr[r].empty() && rows[r][i].query <= qr[r].back().q) throw std::runtime_error("lm_merge_sharded: rows of a shard are not grouped by ascending query");
+                qr[r].push_back(QRange{rows[r][i].query, i, e});
+                i = e;
             }
-            // genomes by the similarity of their best HSP cluster, descending (lib-index-search.go:2919-2921), ties by key
-            std::stable_sort(grps.begin(), grps.end(), [](const Grp &x, const Grp &y) {
-                if (x.best != y.best) return x.best > y.best;
-                return x.bg < y.bg;
-            });
-            for (const Grp &g : grps)
-                for (size_t i = g.b; i < g.e; i++) {
-                    lm_hsp h = rows[g.rank][i];
-                    h.hits = (uint32_t)grps.size(); // search.go:463,494: subject genomes of the query, over all shards
-                    h.genome_id = h.seq_id = nullptr;
-                    h.cigar = h.qseq = h.sseq = h.align = nullptr; // process-local addresses of another rank
-                    if (ix) {
-                        const HostIndex &H = ix->host;
-                        auto it = ix->bg2local.find(h.batch_genome);
-                        const HostGenome *G = nullptr;
-                        if (it != ix->bg2local.end()) {
-                            G = &H.genomes[it->second];
-                        } else {
-                            auto io = H.other_of.find(h.batch_genome);
-                            if (io != H.other_of.end()) G = &H.others[io->second];
-                        }
-                        if (G) {
-                            h.genome_id = G->id.c_str();
-                            if (h.seq_idx >= 0 && h.seq_idx < (int)G->seq_ids.size()) h.seq_id = G->seq_ids[h.seq_idx].c_str();
-                        } else if (H.synthetic) { // names of the synthetic set are a function of the genome number
-                            const long long g = (long long)((h.batch_genome >> 17) * 5000 + (h.batch_genome & 0x1ffff));
-                            char nm[64];
-                            snprintf(nm, sizeof nm, "SYN_%09lld.1", g);
-                            res->strings.push_back(new std::string(nm));
-                            h.genome_id = res->strings.back()->c_str();
-                            snprintf(nm, sizeof nm, "syn%09lld_c1", g);
-                            res->strings.push_back(new std::string(nm));
-                            h.seq_id = res->strings.back()->c_str();
-                        }
+        struct QJob {
+            uint32_t q;
+            size_t out;
+            std::vector<std::pair<int, int>> parts; // (shard, index into qr[shard])
+        };
+        std::vector<QJob> jobs;
+        {
+            std::vector<size_t> at((size_t)nshards, 0);
+            size_t out = 0;
+            while (true) {
+                uint32_t q = 0;
+                bool any = false;
+                for (int r = 0; r < nshards; r++)
+                    if (at[r] < qr[r].size() && (!any || qr[r][at[r]].q < q)) {
+                        q = qr[r][at[r]].q;
+                        any = true;
                     }
-                    res->rows.push_back(h);
-                }
+                if (!any) break;
+                QJob j;
+                j.q = q;
+                j.out = out;
+                for (int r = 0; r < nshards; r++)
+                    if (at[r] < qr[r].size() && qr[r][at[r]].q == q) {
+                        j.parts.emplace_back(r, (int)at[r]);
+                        out += qr[r][at[r]].e - qr[r][at[r]].b;
+                        at[r]++;
+                    }
+                jobs.push_back(std::move(j));
+            }
         }
+        res->rows.resize(total);
+        std::mutex smu;
+        parallel_for((int64_t)jobs.size(), 16, [&](int64_t j0, int64_t j1) {
+            struct Grp {
+                int rank;
+                size_t b, e;
+                uint64_t bg;
+                double best;
+            };
+            std::vector<Grp> grps;
+            std::vector<std::string *> mine;
+            for (int64_t ji = j0; ji < j1; ji++) {
+                const QJob &job = jobs[(size_t)ji];
+                grps.clear();
+                for (auto &pr : job.parts) {
+                    const int r = pr.first;
+                    const QRange &R = qr[r][(size_t)pr.second];
+                    for (size_t i = R.b; i < R.e;) {
+                        Grp g{r, i, i, rows[r][i].batch_genome, 0.0};
+                        while (g.e < R.e && rows[r][g.e].batch_genome == g.bg) {
+                            const double sim = (double)rows[r][g.e].bitscore * rows[r][g.e].pident; // SimilarityScore (:2352,2621)
+                            if (sim > g.best) g.best = sim;
+                            g.e++;
+                        }
+                        grps.push_back(g);
+                        i = g.e;
+                    }
+                }
+                // genomes by the similarity of their best HSP cluster, descending (lib-index-search.go:2919-2921), ties by key
+                std::stable_sort(grps.begin(), grps.end(), [](const Grp &x, const Grp &y) {
+                    if (x.best != y.best) return x.best > y.best;
+                    return x.bg < y.bg;
+                });
+                size_t w = job.out;
+                for (const Grp &g : grps)
+                    for (size_t i = g.b; i < g.e; i++) {
+                        lm_hsp h = rows[g.rank][i];
+                        h.hits = (uint32_t)grps.size(); // search.go:463,494: subject genomes of the query, over all shards
+                        h.genome_id = h.seq_id = nullptr;
+                        h.cigar = h.qseq = h.sseq = h.align = nullptr; // process-local addresses of another rank
+                        if (ix) {
+                            const HostIndex &H = ix->host;
+                            auto it = ix->bg2local.find(h.batch_genome);
+                            const HostGenome *G = nullptr;
+                            if (it != ix->bg2local.end()) {
+                                G = &H.genomes[it->second];
+                            } else {
+                                auto io = H.other_of.find(h.batch_genome);
+                                if (io != H.other_of.end()) G = &H.others[io->second];
+                            }
+                            if (G) {
+                                h.genome_id = G->id.c_str();
+                                if (h.seq_idx >= 0 && h.seq_idx < (int)G->seq_ids.size()) h.seq_id = G->seq_ids[h.seq_idx].c_str();
+                            } else if (H.synthetic) { // names of the synthetic set are a function of the genome number
+                                const long long g = (long long)((h.batch_genome >> 17) * 5000 + (h.batch_genome & 0x1ffff));
+                                char nm[64];
+                                snprintf(nm, sizeof nm, "SYN_%09lld.1", g);
+                                mine.push_back(new std::string(nm));
+                                h.genome_id = mine.back()->c_str();
+                                snprintf(nm, sizeof nm, "syn%09lld_c1", g);
+                                mine.push_back(new std::string(nm));
+                                h.seq_id = mine.back()->c_str();
+                            }
+                        }
+                        res->rows[w++] = h;
+                    }
+            }
+            if (!mine.empty()) {
+                std::lock_guard<std::mutex> l(smu);
+                res->strings.insert(res->strings.end(), mine.begin(), mine.end());
+            }
+        });
         res->stats.rows = (int64_t)res->rows.size();
     } catch (const std::exception &e) {
         if (ix) ix->err = e.what();

@@ -383,7 +383,9 @@ void SeedPacker::finish() {
     const int64_t nmd = 2ll * h.M;
     const int val_bits = gid_bits + pos_bits + 1;
     // ---- main partitions
-    const unsigned long long big_cap = 1 << 20;
+    // (a partition counts as big above SP_MAXN seeds, so there are fewer than n_main / SP_MAXN of them: 6e5 at C3, 1.5e6 in a
+    // 250 000-genome shard of C4)
+    const unsigned long long big_cap = (unsigned long long)(n_main / SP_MAXN) + 1024;
     DBuf<unsigned long long> big, nbig;
     big.alloc_exact(big_cap);
     nbig.alloc_exact(1, true, ix->st);
