@@ -45,14 +45,17 @@ _PINNED = None  # grow-only pinned staging buffer for the gathered rows (GPU pat
 
 
 def all_gather_rows(arr, device="cpu", host_on=None):
-    """all-gatherv of row records: sizes first, then one all-gather of padded payloads (RCCL on GPUs).
-    Returns the list of per-rank arrays. `host_on`: if given, only that rank copies the gathered payload to the host
-    (the others return their own rows only) - the merged table is needed in one place. On the GPU path the returned
-    arrays are views of a reused pinned buffer: valid until the next call."""
+    """gatherv of row records over torch.distributed (RCCL on GPUs, gloo in the CPU tests): the row counts first, then the
+    payloads.  `host_on` = r: a TRUE gatherv to rank r - every other rank sends exactly its rows to r (point-to-point
+    sends grouped in one batch: (N-1) payloads over r's xGMI links, nothing to the ranks that do not merge, no padding)
+    and returns its own rows only.  `host_on` = None: all-gather of padded payloads, every rank gets every rank's rows.
+    Returns the list of per-rank arrays.  On the GPU path the returned arrays are views of a reused pinned buffer: valid
+    until the next call."""
     global _PINNED
     import torch
     import torch.distributed as dist
     world = dist.get_world_size()
+    rank = dist.get_rank()
     arr = np.ascontiguousarray(arr, dtype=ROW_DTYPE).copy()
     for f in ("genome_id", "seq_id", "cigar", "qseq", "sseq", "align"):
         arr[f] = 0  # process-local addresses mean nothing on another rank
@@ -62,22 +65,41 @@ def all_gather_rows(arr, device="cpu", host_on=None):
     sizes = torch.zeros(world, dtype=torch.int64, device=device)
     dist.all_gather_into_tensor(sizes, size)
     sizes = [int(x) for x in sizes.cpu().tolist()]
+
+    def to_host(t):
+        global _PINNED
+        if t.is_cuda:
+            if _PINNED is None or _PINNED.numel() < t.numel():
+                _PINNED = torch.empty(int(t.numel() * 1.25) + 1024, dtype=torch.uint8, pin_memory=True)
+            host_t = _PINNED[:t.numel()]
+            host_t.copy_(t, non_blocking=True)
+            torch.cuda.synchronize()
+            return host_t.numpy()
+        return t.numpy()
+
+    if host_on is not None:
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + n * item)
+        if rank != host_on:
+            if sizes[rank]:
+                for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, payload.to(device), host_on)]):
+                    w.wait()
+            return [arr]
+        allb = torch.empty(max(1, offs[-1]), dtype=torch.uint8, device=device)
+        allb[offs[rank]:offs[rank + 1]] = payload.to(device, non_blocking=True)
+        ops = [dist.P2POp(dist.irecv, allb[offs[r]:offs[r + 1]], r) for r in range(world) if r != rank and sizes[r]]
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        host = to_host(allb)
+        return [host[offs[r]:offs[r + 1]].view(ROW_DTYPE) for r in range(world)]
     mx = max(1, max(sizes)) * item
     pad = torch.zeros(mx, dtype=torch.uint8, device=device)
     pad[:payload.numel()] = payload.to(device, non_blocking=True)
     allb = torch.empty(world * mx, dtype=torch.uint8, device=device)
     dist.all_gather_into_tensor(allb, pad)
-    if host_on is not None and dist.get_rank() != host_on:
-        return [arr]
-    if allb.is_cuda:
-        if _PINNED is None or _PINNED.numel() < allb.numel():
-            _PINNED = torch.empty(int(allb.numel() * 1.25) + 1024, dtype=torch.uint8, pin_memory=True)
-        host_t = _PINNED[:allb.numel()]
-        host_t.copy_(allb, non_blocking=True)
-        torch.cuda.synchronize()
-        host = host_t.numpy()
-    else:
-        host = allb.numpy()
+    host = to_host(allb)
     return [host[r * mx:r * mx + sizes[r] * item].view(ROW_DTYPE) for r in range(world)]
 
 
