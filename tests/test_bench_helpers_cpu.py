@@ -1,0 +1,86 @@
+"""CPU tests of bench.py's own checking / bookkeeping helpers (no GPU, no library): the row-for-row comparison that guards the
+bench's parity claim, and the kernel-name mapping of the rocprofv3 summaries the roofline block reads."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def _rows(n):
+    import bench
+    dt = np.dtype([(f, "<f8" if f in ("qcov_genome", "qcov_hsp", "pident") else "<i8") for f in bench.ROW_CHECK_FIELDS] +
+                  [("evalue", "<f8"), ("hits", "<i8"), ("query", "<i8")])
+    a = np.zeros(n, dtype=dt)
+    for i in range(n):
+        for j, f in enumerate(bench.ROW_CHECK_FIELDS):
+            a[f][i] = (i * 7 + j) % 50
+        a["evalue"][i] = 1e-30 * (i + 1)
+        a["hits"][i] = 3
+        a["query"][i] = i // 4
+    return a
+
+
+def _oracle_of(a):
+    import bench
+    out = {}
+    for r in a:
+        out.setdefault(int(r["query"]), []).append(tuple(r[f].item() for f in bench.ROW_CHECK_FIELDS) + (float(r["evalue"]), int(r["hits"])))
+    return out
+
+
+def test_rows_equal_oracle_accepts_equal_rows_and_names_the_first_difference():
+    import bench
+    a = _rows(12)
+    exp = _oracle_of(a)
+    ok, n, diff = bench.rows_equal_oracle(a, exp)
+    assert ok and n == 12 and diff is None
+    # e-value within 1e-9 relative passes, beyond fails
+    b = a.copy()
+    b["evalue"][5] *= 1 + 1e-12
+    assert bench.rows_equal_oracle(b, exp)[0]
+    b["evalue"][5] *= 1 + 1e-6
+    ok, n, diff = bench.rows_equal_oracle(b, exp)
+    assert not ok and "evalue" in diff and "query 1 row 1" in diff
+    # an integer column, the hits column, a missing row, a query without rows on one side
+    b = a.copy()
+    b["tend"][9] += 1
+    ok, n, diff = bench.rows_equal_oracle(b, exp)
+    assert not ok and "tend" in diff and n == 9
+    b = a.copy()
+    b["hits"][0] = 4
+    assert "hits" in bench.rows_equal_oracle(b, exp)[2]
+    assert "11 HIP rows" not in str(bench.rows_equal_oracle(a[:11], exp)[2]) and not bench.rows_equal_oracle(a[:11], exp)[0]
+    exp2 = dict(exp)
+    exp2[7] = []                      # the oracle found nothing for query 7, neither did the HIP path
+    assert bench.rows_equal_oracle(a, exp2)[0]
+    exp2[7] = [exp[0][0]]             # ... but now it did
+    assert not bench.rows_equal_oracle(a, exp2)[0]
+
+
+def test_rocprof_kernel_names_match_the_names_bench_reports():
+    import summarize_rocprof as S
+    assert S.short("void lm::k_wfa_lean<2, false>(lm::WfaIn const*, long)") == "k_wfa_lean"
+    assert S.short("void lm::k_wfa_lean<4, true>(lm::WfaIn const*, long)") == "k_wfa_win256"
+    assert S.short("void lm::k_wfa_lean<8, (bool)0>(x)") == "k_wfa_lean512"
+    assert S.short("void lm::k_wfa_lean<16, (bool)1>(x)") == "k_wfa_win1024"
+    assert S.short("lm::k_pa_search(lm::DevIndexView, ...)") == "k_pa_search"
+    assert S.short("void rocprim::detail::radix_sort_onesweep_kernel<...>").startswith("rocprim:")
+
+
+def test_workloads_name_every_baseline_config_and_the_shards_fit():
+    """BASELINE.json configs[1..4] = c2, c3, c4, c5; a C4 / C5 shard must fit 288 GB at the measured 9.45 B per seed"""
+    import bench
+    wl = bench.WORKLOADS
+    assert wl["c2"]["genomes"] == 10_000 and wl["c3"]["genomes"] == 100_000 and wl["c3"]["queries"] == 10_000
+    assert wl["c4"]["genomes"] == 1_000_000 and wl["c4"]["shards"] == 4 and wl["c4"]["qlen"] == (50_000, 200_000)
+    assert wl["c5"]["genomes"] == 1_900_000 and wl["c5"]["shards"] == 8 and wl["c5"]["kind"] == "mixed"
+    for w in ("c4", "c5"):
+        per_shard = wl[w]["genomes"] / wl[w]["shards"]
+        seeds = per_shard * 2 * (20_000 + wl[w]["genome_len"] / 77)      # captures + desert seeds, x2 reversed twins
+        resident = seeds * 9.45 + per_shard * wl[w]["genome_len"] / 4
+        assert resident < 0.7 * 288e9, (w, resident)                      # leaves >= 30 % of the HBM for scratch
+        assert wl[w]["families"] % 2 == 1                                 # family members spread over 2 / 4 / 8 shards

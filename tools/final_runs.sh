@@ -1,4 +1,5 @@
 #!/bin/bash
+# the round-end batch on the GPU box (one gpurun call): parity tests, the C3 profile set, the C4 / C5 shards, the shard-of-8 run, the C2 profile set
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
