@@ -183,24 +183,21 @@ def compare_setup(rng, qlen, div, tflank=300):
     return core, t
 
 
-@pytest.mark.parametrize("qlen,div,seed", [(120, 0.0, 1), (400, 0.03, 2), (1500, 0.08, 3), (1500, 0.2, 4), (5000, 0.1, 5)])
-def test_tree_range_trim_chain2_match_oracle(qlen, div, seed):
-    """pseudo-alignment: sorted-array tree.Search emulation (incl. the partial-prefix quirk) -> anchors -> clear ->
-    trim -> chain2, against the oracle's radix tree pipeline (lmo_cmp_compare)."""
+def compare_device_vs_oracle(q, t, begin, end, query_len=None):
+    """SeqComparator.Index(q) + Compare(begin, end, t): the oracle's radix-tree pipeline (lmo_cmp_compare) against the
+    device formulation (sorted-array tree.Search emulation -> anchors -> clear -> trim -> chain2); asserts equality and
+    returns the chains (qbegin, qend, tbegin, tend, nanchors, matched_bases, aligned_bases_q, pident)"""
     L, Hh = O.lib(), H.lib()
-    rng = random.Random(seed)
-    q, t = compare_setup(rng, qlen, div)
     opt = O.CmpOpt()
     opt.k, opt.min_prefix = K, 11
     opt.c2.max_gap, opt.c2.min_score, opt.c2.min_align_len = 20, 35, 50
     opt.c2.min_identity, opt.c2.band_count, opt.c2.band_base, opt.c2.heuristic_pident = 70.0, 50, 100, 15.0
     cmp_ = L.lmo_cmp_new(C.byref(opt))
     assert L.lmo_cmp_index(cmp_, q, len(q)) == 0
-    begin, end = 0, len(q) - 1
     chains = C.POINTER(O.Chain2)()
     osubs = C.POINTER(O.Sub)()
     nosubs = C.c_int()
-    nc = L.lmo_cmp_compare(cmp_, begin, end, t, len(t), len(q), C.byref(chains), C.byref(osubs), C.byref(nosubs))
+    nc = L.lmo_cmp_compare(cmp_, begin, end, t, len(t), query_len if query_len is not None else len(q), C.byref(chains), C.byref(osubs), C.byref(nosubs))
     # ---- device formulation ----
     keys, vals = [], []
     for i in range(len(q) - K + 1):
@@ -260,9 +257,23 @@ def test_tree_range_trim_chain2_match_oracle(qlen, div, seed):
         assert (d.qbegin, d.qend, d.tbegin, d.tend, d.nanchors, d.matched_bases, d.aligned_bases_q) == \
                (o.qbegin, o.qend, o.tbegin, o.tend, o.nanchors, o.matched_bases, o.aligned_bases_q)
         assert d.pident == o.pident
-    if qlen >= 400:
-        assert nc >= 1
+    res = [(chains[i].qbegin, chains[i].qend, chains[i].tbegin, chains[i].tend, chains[i].nanchors, chains[i].matched_bases,
+            chains[i].aligned_bases_q, chains[i].pident) for i in range(nc)]
     L.lmo_cmp_free(cmp_)
+    return res
+
+
+
+
+@pytest.mark.parametrize("qlen,div,seed", [(120, 0.0, 1), (400, 0.03, 2), (1500, 0.08, 3), (1500, 0.2, 4), (5000, 0.1, 5)])
+def test_tree_range_trim_chain2_match_oracle(qlen, div, seed):
+    """pseudo-alignment: sorted-array tree.Search emulation (incl. the partial-prefix quirk) -> anchors -> clear ->
+    trim -> chain2, against the oracle's radix tree pipeline (lmo_cmp_compare)."""
+    rng = random.Random(seed)
+    q, t = compare_setup(rng, qlen, div)
+    chains = compare_device_vs_oracle(q, t, 0, len(q) - 1)
+    if qlen >= 400:
+        assert len(chains) >= 1
 
 
 def test_tree_search_quirk_matches_radix_tree():
