@@ -46,9 +46,9 @@ _PINNED = None  # grow-only pinned staging buffer for the gathered rows (GPU pat
 
 def all_gather_rows(arr, device="cpu", host_on=None):
     """gatherv of row records over torch.distributed (RCCL on GPUs, gloo in the CPU tests): the row counts first, then the
-    payloads.  `host_on` = r: a TRUE gatherv to rank r - every other rank sends exactly its rows to r (point-to-point
-    sends grouped in one batch: (N-1) payloads over r's xGMI links, nothing to the ranks that do not merge, no padding)
-    and returns its own rows only.  `host_on` = None: all-gather of padded payloads, every rank gets every rank's rows.
+    payloads.  `host_on` = r: a gather to rank r only (`dist.gather` of the payloads padded to the largest: (N-1) payloads
+    over r's xGMI links, nothing to the ranks that do not merge); the other ranks return their own rows only.
+    `host_on` = None: all-gather of padded payloads, every rank gets every rank's rows.
     Returns the list of per-rank arrays.  On the GPU path the returned arrays are views of a reused pinned buffer: valid
     until the next call."""
     global _PINNED
@@ -77,26 +77,19 @@ def all_gather_rows(arr, device="cpu", host_on=None):
             return host_t.numpy()
         return t.numpy()
 
-    if host_on is not None:
-        offs = [0]
-        for n in sizes:
-            offs.append(offs[-1] + n * item)
-        if rank != host_on:
-            if sizes[rank]:
-                for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, payload.to(device), host_on)]):
-                    w.wait()
-            return [arr]
-        allb = torch.empty(max(1, offs[-1]), dtype=torch.uint8, device=device)
-        allb[offs[rank]:offs[rank + 1]] = payload.to(device, non_blocking=True)
-        ops = [dist.P2POp(dist.irecv, allb[offs[r]:offs[r + 1]], r) for r in range(world) if r != rank and sizes[r]]
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        host = to_host(allb)
-        return [host[offs[r]:offs[r + 1]].view(ROW_DTYPE) for r in range(world)]
     mx = max(1, max(sizes)) * item
     pad = torch.zeros(mx, dtype=torch.uint8, device=device)
     pad[:payload.numel()] = payload.to(device, non_blocking=True)
+    if host_on is not None:
+        # gather to the merging rank only: (N-1) payloads over ITS links, nothing to the ranks that do not merge (the shards
+        # are balanced - genome g on rank g % N - so padding to the largest payload costs a few per cent)
+        if rank != host_on:
+            dist.gather(pad, gather_list=None, dst=host_on)
+            return [arr]
+        allb = torch.empty(world * mx, dtype=torch.uint8, device=device)
+        dist.gather(pad, gather_list=[allb[r * mx:(r + 1) * mx] for r in range(world)], dst=host_on)
+        host = to_host(allb)
+        return [host[r * mx:r * mx + sizes[r] * item].view(ROW_DTYPE) for r in range(world)]
     allb = torch.empty(world * mx, dtype=torch.uint8, device=device)
     dist.all_gather_into_tensor(allb, pad)
     host = to_host(allb)
