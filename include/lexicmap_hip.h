@@ -103,7 +103,9 @@ lm_status lm_index_build_synthetic(const lm_synth_spec *spec, const lm_options *
 lm_status lm_index_fetch(lm_index *idx, int64_t local_genome, int64_t start, int64_t len, uint8_t *out);
 /* Writes the resident (unsharded) index to `dir` in the reference's on-disk format: info.toml, masks.bin, seeds/chunk_NNN.bin
  * (+ .idx, kv/kv-data.go:126-602) in `chunks` files, genomes/batch_NNNN/genomes.bin (+ .idx, genome/genome.go:217-357),
- * genomes.map.bin.  lm_index_open / the oracle read it back; used to time the loader at benchmark scale on GPU-built sets. */
+ * genomes.map.bin.  lm_index_open / the oracle read it back; used to time the loader at benchmark scale on GPU-built sets.
+ * Not written: genomes.chunks.bin (the chunk lists of genomes split at --max-genome) - an index with split genomes saved this
+ * way reports its chunks as separate genomes; a shard (shard_count > 1) is refused. */
 lm_status lm_index_save(lm_index *idx, const char *dir, int chunks);
 /* Replaces (*Index).Close (lib-index-search.go:760) */
 void lm_index_close(lm_index *idx);
