@@ -38,6 +38,10 @@ PROFILE_ROUND = "r03"  # profiles/<round>_<workload>_pmc_*.json: the committed c
 # cycles; ONE scalar unit per CU), wave-instructions per second at 2.4 GHz
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2
 SALU_ISSUE_PEAK = 256 * 2.4e9
+# ... and what a SIMD was MEASURED to sustain on the kinds of instruction the WFA kernels are made of (experiments/valu_rate,
+# profiles/r03_valu_rate.jsonl, 8 waves per SIMD): v_add_u32 2.5 cycles, but v_cmp + v_cndmask, DPP move + min, v_pk_min_u16,
+# 64-bit shifts and VOP3 f32 FMA 3.8 - 4.2 cycles per wave64 instruction; s_add_u32 1.04 cycles per CU (= SALU_ISSUE_PEAK)
+VALU_ISSUE_PEAK_MIX = 256 * 4 * 2.4e9 / 4
 
 
 def log(*a):
@@ -635,6 +639,7 @@ def main():
                 # the kernel's wave-instructions per second against what the chip can issue (MI355X_MICROARCH.md)
                 issue["issue_frac_valu"] = round(issue.get("sq_insts_valu_per_launch", 0) / (dur_ms * 1e-3) / VALU_ISSUE_PEAK, 4)
                 issue["issue_frac_salu"] = round(issue.get("sq_insts_salu_per_launch", 0) / (dur_ms * 1e-3) / SALU_ISSUE_PEAK, 4)
+                issue["issue_frac_valu_measured_mix"] = round(issue.get("sq_insts_valu_per_launch", 0) / (dur_ms * 1e-3) / VALU_ISSUE_PEAK_MIX, 4)
             return dict(bound="hbm", kernel=pk["name"], achieved=round(ach, 3), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(ach / HBM_PEAK_GBS, 6), traffic=tr, traffic_source=tn,
                         traffic_over_algorithmic=(round(tr / alg, 2) if tr and alg else None),
