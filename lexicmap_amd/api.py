@@ -7,6 +7,12 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "liblexicmap_hip.so")
+# LEXICMAP_HIP_LIB=<path>: another build of the same C-ABI (an experiment from experiments/, an A-B build) instead of the in-tree
+# library; said on stderr so that no measurement is attributed to the wrong sources
+if os.environ.get("LEXICMAP_HIP_LIB"):
+    LIB_PATH = os.path.abspath(os.environ["LEXICMAP_HIP_LIB"])
+    import sys as _sys
+    print("[lexicmap_amd] library override: %s" % LIB_PATH, file=_sys.stderr)
 
 
 class HipLibraryMissing(RuntimeError):

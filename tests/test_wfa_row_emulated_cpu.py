@@ -130,6 +130,6 @@ def test_the_emulator_itself(tmp_path):
     exe = str(tmp_path / "simt_emu_selftest")
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-o", exe, os.path.join(EXP, "simt_emu_selftest.cpp")])
     assert subprocess.run([exe], capture_output=True, text=True).stdout.startswith("ok")
-    for how in ("diverge", "early"):
+    for how in ("diverge", "early", "stuck"):
         r = subprocess.run([exe, how], capture_output=True, text=True)
         assert r.returncode == -6 and "simt_emu:" in r.stderr
