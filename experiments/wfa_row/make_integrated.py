@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """experiments/wfa_row/make_integrated.py - the product sources with k_wfa_mw wired into the 512 / 1024-diagonal WFA passes, in a
 scratch copy (experiments/csrc_mw, library experiments/lib_mw/liblexicmap_hip.so) so that lexicmap_amd/csrc - whose
-hash the committed counter passes are tied to - stays as measured.  Writes integrate_mw.patch (the diff to apply next round).
+hash the committed counter passes are tied to - stays as measured.  Writes integrate_mw.patch (the diff to apply next round: `git apply experiments/wfa_row/integrate_mw.patch`; then add lm_wfa_mw.h lm_wfa_mw_fwd.h to the Makefile's lm_kernels.o rule).
 Run the GPU tests against the scratch library with LEXICMAP_HIP_LIB=experiments/lib_mw/liblexicmap_hip.so."""
 import os
 import shutil
@@ -71,8 +71,17 @@ def main():
     m = os.path.join(DST, "Makefile")
     sub(m, "OUT = ../liblexicmap_hip.so", "OUT = ../lib_mw/liblexicmap_hip.so")  # same file name: tests that link with -llexicmap_hip work on it
     sub(m, "lm_kernels.o: lm_kernels.hip lm_kernels.h lm_algos.h", "lm_kernels.o: lm_kernels.hip lm_kernels.h lm_algos.h lm_wfa_mw.h lm_wfa_mw_fwd.h")
-    patch = subprocess.run(["diff", "-ruN", "-x", "*.o", "-x", "Makefile", "-x", ".pytest_cache", os.path.relpath(SRC, ROOT), os.path.relpath(DST, ROOT)], cwd=ROOT,
-                           capture_output=True, text=True).stdout
+    # one unified diff with a/ b/ labels on the product paths: `git apply experiments/wfa_row/integrate_mw.patch` from the root
+    patch = ""
+    for f in sorted(os.listdir(DST)):
+        if not f.endswith((".hip", ".h", ".cpp")):
+            continue
+        old = os.path.join(SRC, f)
+        rel = "lexicmap_amd/csrc/" + f
+        r = subprocess.run(["diff", "-u", "--label", "a/" + rel if os.path.exists(old) else "/dev/null", "--label", "b/" + rel,
+                            old if os.path.exists(old) else "/dev/null", os.path.join(DST, f)], capture_output=True, text=True)
+        if r.stdout:
+            patch += "diff --git a/%s b/%s\n" % (rel, rel) + ("new file mode 100644\n" if not os.path.exists(old) else "") + r.stdout
     open(os.path.join(HERE, "integrate_mw.patch"), "w").write(patch)
     print("patch: %d lines" % patch.count("\n"))
     if "--no-build" not in sys.argv:
