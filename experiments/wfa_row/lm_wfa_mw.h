@@ -1,5 +1,5 @@
 // lm_wfa_mw.h - k_wfa_mw<NCW>: the LDS wavefront kernel with a WORKGROUP of four wavefronts per alignment (512 / 1024
-// diagonals), for the 512- and 1024-diagonal passes of the long length classes: a handful of 20-50-kb alignments per round
+// diagonals; WIN: sequences through sliding windows), for the 512- and 1024-diagonal passes of the long length classes: a handful of 20-50-kb alignments per round
 // that k_wfa_lean<8 / 16> runs at single-wavefront latency (8 / 16 cells per lane) while the round waits.  Four wavefronts
 // with 2 / 4 cells per lane run the same score step ~2 x faster (three workgroup barriers per score); the backtrace is
 // bt_walk / bt_replay by the first wavefront.  Results identical to k_wfa_lean (same rows, same bytes).
@@ -12,6 +12,7 @@
 #define WR_BARRIER() __syncthreads()
 #define WR_UNIFORM(x) __builtin_amdgcn_readfirstlane((int)(x))
 #define WR_CLZ(x) __clz((int)(x))
+#define WR_CLZLL(x) __clzll((long long)(x))
 #define wr_pk_min_u16 pk_min_u16
 #define WR_WAVE_MIN_I32(v) wave_min_i32(v)
 #define WR_WAVE_PKMIN_U16(v) wave_pkmin_u16(v)
@@ -19,7 +20,7 @@
 
 #include "lm_wfa_mw_fwd.h"
 
-template <int NCW>
+template <int NCW, bool WIN>
 __global__ __launch_bounds__(MW_THREADS) void k_wfa_mw(const WfaIn *__restrict__ in, int64_t n, const int32_t *__restrict__ todo, int64_t ntodo,
                                                         int32_t *__restrict__ hdr_pool, int64_t hdr_stride, uint8_t *__restrict__ arena_pool,
                                                         int64_t arena_stride, uint64_t *__restrict__ ops_pool, unsigned int *__restrict__ queue,
@@ -27,9 +28,11 @@ __global__ __launch_bounds__(MW_THREADS) void k_wfa_mw(const WfaIn *__restrict__
     constexpr int W = MW_THREADS * NCW;
     constexpr int RING_BYTES = 9 * W * 4 > (int)sizeof(BtLds) ? 9 * W * 4 : (int)sizeof(BtLds);
     __shared__ __attribute__((aligned(16))) uint8_t ring_raw[RING_BYTES]; // the backtrace walk reuses the ring (dead by then)
-    __shared__ int32_t red[32];
+    __shared__ int32_t red[40];
     __shared__ unsigned int sh_x;
-    extern __shared__ uint32_t seq_lds[]; // Q and T: seq_words + 2 words each
+    // WIN: the two sequence windows; otherwise both whole packed sequences in dynamic LDS (seq_words + 2 words each)
+    __shared__ uint32_t qwin_buf[WIN ? MW_WINW + 2 : 1], twin_buf[WIN ? MW_WINW + 2 : 1];
+    extern __shared__ uint32_t seq_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     int32_t *hdr2 = hdr_pool + (int64_t)blockIdx.x * hdr_stride;
     uint8_t *bt = arena_pool + (int64_t)blockIdx.x * arena_stride;
@@ -54,11 +57,11 @@ __global__ __launch_bounds__(MW_THREADS) void k_wfa_mw(const WfaIn *__restrict__
         p.max_score = max_score;
         MwLds L;
         L.ring = (int32_t *)ring_raw;
-        L.qbuf = seq_lds;
-        L.tbuf = seq_lds + seq_words + 2;
+        L.qbuf = WIN ? qwin_buf : seq_lds;
+        L.tbuf = WIN ? twin_buf : seq_lds + seq_words + 2;
         L.red = red;
         MwRes res;
-        wfa_mw_forward<NCW>(p, L, seq_words, &res);
+        wfa_mw_forward<NCW, WIN>(p, L, seq_words, &res);
         __threadfence_block();
         __syncthreads(); // the backtrace reads what every thread stored to global memory; the ring is dead
         if (tid < 64) {
@@ -78,15 +81,15 @@ __global__ __launch_bounds__(MW_THREADS) void k_wfa_mw(const WfaIn *__restrict__
                     o.r.status = 1;
                 } else {
                     WfaWin Q, T;
-                    Q.buf = seq_lds;
+                    Q.buf = L.qbuf;
                     Q.src = w.q;
                     Q.len = w.qlen;
-                    Q.w0 = 0;
-                    T.buf = seq_lds + seq_words + 2;
+                    Q.w0 = WIN ? -(1 << 24) : 0; // (WIN: nothing counts as resident, the replay's first step loads its windows)
+                    T.buf = L.tbuf;
                     T.src = w.t;
                     T.len = w.tlen;
-                    T.w0 = 0;
-                    bt_replay<false>(bt + arena_stride - 16 - nops, nops, Q, T, w.qlen, w.tlen, want_ops ? ops_pool + w.ops_off : nullptr, w.ops_cap, lane,
+                    T.w0 = WIN ? -(1 << 24) : 0;
+                    bt_replay<WIN>(bt + arena_stride - 16 - nops, nops, Q, T, w.qlen, w.tlen, want_ops ? ops_pool + w.ops_off : nullptr, w.ops_cap, lane,
                                      res.score, &o.r, &o.blast_score);
                 }
             }
@@ -100,19 +103,22 @@ __global__ __launch_bounds__(MW_THREADS) void k_wfa_mw(const WfaIn *__restrict__
 
 typedef void (*WfaMwFn)(const WfaIn *, int64_t, const int32_t *, int64_t, int32_t *, int64_t, uint8_t *, int64_t, uint64_t *, unsigned int *, int,
                         int, WfaOut *);
-static WfaMwFn wfa_mw_fn(int ncw) { return ncw == 4 ? k_wfa_mw<4> : k_wfa_mw<2>; }
-static size_t wfa_mw_dyn_lds(int seq_words) { return (size_t)(2 * (seq_words + 2)) * sizeof(uint32_t); }
+static WfaMwFn wfa_mw_fn(int ncw, bool win) {
+    if (win) return ncw == 4 ? k_wfa_mw<4, true> : k_wfa_mw<2, true>;
+    return ncw == 4 ? k_wfa_mw<4, false> : k_wfa_mw<2, false>;
+}
+static size_t wfa_mw_dyn_lds(int seq_words, bool win) { return win ? 0 : (size_t)(2 * (seq_words + 2)) * sizeof(uint32_t); }
 // workgroups of k_wfa_mw<nc / 4> the device holds at once (nc = 8: 512 diagonals, 16: 1024)
-int wfa_mw_resident_blocks(int device, int seq_words, int nc) {
+int wfa_mw_resident_blocks(int device, int seq_words, int nc, bool win) {
     int nb = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)wfa_mw_fn(nc / 4), MW_THREADS, wfa_mw_dyn_lds(seq_words)) != hipSuccess || nb < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)wfa_mw_fn(nc / 4, win), MW_THREADS, wfa_mw_dyn_lds(seq_words, win)) != hipSuccess || nb < 1)
         nb = 1;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
     return nb * cus;
 }
 void launch_wfa_mw(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks, int32_t *hdr_pool,
                    int64_t hdr_stride, uint8_t *arena_pool, int64_t arena_stride, uint64_t *ops_pool, unsigned int *queue, int seq_words,
-                   int want_ops, WfaOut *out, int nc) {
-    hipLaunchKernelGGL(wfa_mw_fn(nc / 4), dim3(nblocks), dim3(MW_THREADS), wfa_mw_dyn_lds(seq_words), st, in, n, todo, ntodo, hdr_pool, hdr_stride,
+                   int want_ops, WfaOut *out, int nc, bool win) {
+    hipLaunchKernelGGL(wfa_mw_fn(nc / 4, win), dim3(nblocks), dim3(MW_THREADS), wfa_mw_dyn_lds(seq_words, win), st, in, n, todo, ntodo, hdr_pool, hdr_stride,
                        arena_pool, arena_stride, ops_pool, queue, seq_words, want_ops, out);
 }

@@ -33,15 +33,15 @@ def main():
         '#include "lm_wfa_mw.h"\n\n// ------------------------------------------------------------------------------------------------------------\n// host-callable launchers\n')
     h = os.path.join(DST, "lm_kernels.h")
     sub(h, "// wavefronts wider than the LDS ring (status 3 from launch_wfa)",
-        "// k_wfa_mw<nc / 4>: the same passes for nc = 8 / 16 (whole sequences in LDS) by a workgroup of four wavefronts per alignment\n"
-        "int wfa_mw_resident_blocks(int device, int seq_words, int nc);\n"
+        "// k_wfa_mw<nc / 4, win>: the same passes for nc = 8 / 16 by a workgroup of four wavefronts per alignment\n"
+        "int wfa_mw_resident_blocks(int device, int seq_words, int nc, bool win);\n"
         "void launch_wfa_mw(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks, int32_t *hdr_pool,\n"
         "                   int64_t hdr_stride, uint8_t *arena_pool, int64_t arena_stride, uint64_t *ops_pool, unsigned int *queue, int seq_words,\n"
-        "                   int want_ops, WfaOut *out, int nc);\n\n"
+        "                   int want_ops, WfaOut *out, int nc, bool win);\n\n"
         "// wavefronts wider than the LDS ring (status 3 from launch_wfa)")
     t = os.path.join(DST, "lm_internal.h")
     sub(t, "    int wfa_serial = 0;      // LM_WFA_SERIAL=1",
-        "    int wfa_mw = 1;          // 512 / 1024-diagonal passes over whole sequences by four wavefronts per alignment (LM_WFA_MW=0: one)\n"
+        "    int wfa_mw = 1;          // 512 / 1024-diagonal passes by a workgroup of four wavefronts per alignment (LM_WFA_MW=0: one wavefront)\n"
         "    int wfa_serial = 0;      // LM_WFA_SERIAL=1")
     sub(t, "        no_pipeline = getenv(\"LM_NO_PIPELINE\") != nullptr;\n",
         "        no_pipeline = getenv(\"LM_NO_PIPELINE\") != nullptr;\n        if (const char *e = getenv(\"LM_WFA_MW\")) wfa_mw = atoi(e) != 0;\n")
@@ -49,22 +49,23 @@ def main():
     sub(p, "        const int resident = wfa_resident_blocks(ix->device, seq_words, nc, use_win);\n"
            "        int nblocks = (int)std::min<int64_t>(m, std::max<int64_t>(256, (int64_t)resident * ix->tune.wfa_resident_pct / 100));\n",
            "        // the 512 / 1024-diagonal passes are a handful of long alignments the round waits for: a workgroup of four wavefronts each\n"
-           "        const bool mw = ix->tune.wfa_mw && !use_win && nc >= 8;\n"
-           "        const int resident = mw ? wfa_mw_resident_blocks(ix->device, seq_words, nc) : wfa_resident_blocks(ix->device, seq_words, nc, use_win);\n"
+           "        const bool mw = ix->tune.wfa_mw && nc >= 8;\n"
+           "        const int resident = mw ? wfa_mw_resident_blocks(ix->device, seq_words, nc, use_win) : wfa_resident_blocks(ix->device, seq_words, nc, use_win);\n"
            "        int nblocks = (int)std::min<int64_t>(m, std::max<int64_t>(mw ? 1 : 256, (int64_t)resident * ix->tune.wfa_resident_pct / 100));\n")
     sub(p, "            static const char *const names[2][5] = {{\"k_wfa_lean64\", \"k_wfa_lean\", \"k_wfa_lean256\", \"k_wfa_lean512\", \"k_wfa_lean1024\"},\n",
-           "            static const char *const names[3][5] = {{\"k_wfa_lean64\", \"k_wfa_lean\", \"k_wfa_lean256\", \"k_wfa_lean512\", \"k_wfa_lean1024\"},\n"
+           "            static const char *const names[4][5] = {{\"k_wfa_lean64\", \"k_wfa_lean\", \"k_wfa_lean256\", \"k_wfa_lean512\", \"k_wfa_lean1024\"},\n"
            "                                                    {\"k_wfa_win64\", \"k_wfa_win128\", \"k_wfa_win256\", \"k_wfa_win512\", \"k_wfa_win1024\"},\n"
-           "                                                    {\"\", \"\", \"\", \"k_wfa_mw512\", \"k_wfa_mw1024\"}};\n"
+           "                                                    {\"\", \"\", \"\", \"k_wfa_mw512\", \"k_wfa_mw1024\"},\n"
+           "                                                    {\"\", \"\", \"\", \"k_wfa_mww512\", \"k_wfa_mww1024\"}};\n"
            "            static const char *const unused_names[1][5] = {\n")
     sub(p, "            Prof p(ix, names[use_win ? 1 : 0][nc == 16 ? 4 : nc == 8 ? 3 : nc == 4 ? 2 : nc == 1 ? 0 : 1], wfa_bytes(in, items));\n"
            "            launch_wfa(S(ix), a.wfa_in.p, n, lc.todo.p, m, nblocks, lc.hdr_pool.p, entries * 2, (uint8_t *)lc.arena_pool.p, bytes,\n"
            "                       a.ops_pool.p, lc.queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc, use_win);\n",
            "            (void)unused_names;\n"
-           "            Prof p(ix, names[mw ? 2 : use_win ? 1 : 0][nc == 16 ? 4 : nc == 8 ? 3 : nc == 4 ? 2 : nc == 1 ? 0 : 1], wfa_bytes(in, items));\n"
+           "            Prof p(ix, names[mw ? (use_win ? 3 : 2) : use_win ? 1 : 0][nc == 16 ? 4 : nc == 8 ? 3 : nc == 4 ? 2 : nc == 1 ? 0 : 1], wfa_bytes(in, items));\n"
            "            if (mw)\n"
            "                launch_wfa_mw(S(ix), a.wfa_in.p, n, lc.todo.p, m, nblocks, lc.hdr_pool.p, entries * 2, (uint8_t *)lc.arena_pool.p, bytes,\n"
-           "                              a.ops_pool.p, lc.queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc);\n"
+           "                              a.ops_pool.p, lc.queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc, use_win);\n"
            "            else\n"
            "                launch_wfa(S(ix), a.wfa_in.p, n, lc.todo.p, m, nblocks, lc.hdr_pool.p, entries * 2, (uint8_t *)lc.arena_pool.p, bytes,\n"
            "                           a.ops_pool.p, lc.queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc, use_win);\n")

@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--n", type=int, default=48)
     ap.add_argument("--len", type=int, nargs=2, default=[20000, 45000])
     ap.add_argument("--ncw", type=int, nargs="+", default=[2, 4])
+    ap.add_argument("--win", type=int, nargs="+", default=[0], help="1: the windowed form (against k_wfa_lean<nc, true>)")
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--seed", type=int, default=11)
     ap.add_argument("--out", default="")
@@ -56,12 +57,12 @@ def main():
     L = C.CDLL(os.path.join(HERE, "libwfa_mw_exp.so"))
     seqs, qoff, qlen, toff, tlen = ont_pairs(a.n, a.len[0], a.len[1], a.seed)
     out = []
-    for ncw in a.ncw:
+    for ncw, win in [(x, y) for x in a.ncw for y in a.win]:
         r = Cmp()
         st = L.mw_compare(seqs.ctypes.data_as(C.c_void_p), C.c_int64(len(seqs)), qoff.ctypes.data_as(C.c_void_p), qlen.ctypes.data_as(C.c_void_p),
-                          toff.ctypes.data_as(C.c_void_p), tlen.ctypes.data_as(C.c_void_p), C.c_int64(a.n), ncw, a.reps, C.byref(r))
+                          toff.ctypes.data_as(C.c_void_p), tlen.ctypes.data_as(C.c_void_p), C.c_int64(a.n), ncw, win, a.reps, C.byref(r))
         d = {f[0]: getattr(r, f[0]) for f in Cmp._fields_ if f[0] != "pad"}
-        d.update(rc=st, ncw=ncw, diagonals=256 * ncw, against="k_wfa_lean<%d>" % (4 * ncw), pairs=a.n, length=a.len,
+        d.update(rc=st, ncw=ncw, diagonals=256 * ncw, windowed=bool(win), against="k_wfa_lean<%d, %s>" % (4 * ncw, "true" if win else "false"), pairs=a.n, length=a.len,
                  drift=[int(x) for x in np.sort(tlen - qlen)[[0, len(tlen) // 2, -1]]],
                  speedup=(r.ms_lean / r.ms_mw if r.ms_mw > 0 else None))
         out.append(d)

@@ -17,6 +17,7 @@ namespace lm {
 #define WR_BARRIER() __syncthreads()
 #define WR_UNIFORM(x) __builtin_amdgcn_readfirstlane((int)(x))
 #define WR_CLZ(x) __clz((int)(x))
+#define WR_CLZLL(x) __clzll((long long)(x))
 #define wr_pk_min_u16 pk_min_u16
 #define WR_WAVE_MIN_I32(v) wave_min_i32(v)
 #define WR_WAVE_PKMIN_U16(v) wave_pkmin_u16(v)
@@ -26,7 +27,7 @@ namespace lm {
 
 // Persistent workgroups of four wavefronts; each pops ONE problem at a time: forward pass by all four, then the backtrace by
 // the first wavefront (bt_walk / bt_replay of k_wfa_lean, unchanged) while the others wait at the barrier.
-template <int NCW>
+template <int NCW, bool WIN>
 __global__ __launch_bounds__(MW_THREADS) void k_wfa_mw(const WfaIn *__restrict__ in, int64_t n, const int32_t *__restrict__ todo, int64_t ntodo,
                                                         int32_t *__restrict__ hdr_pool, int64_t hdr_stride, uint8_t *__restrict__ arena_pool,
                                                         int64_t arena_stride, uint64_t *__restrict__ ops_pool, unsigned int *__restrict__ queue,
@@ -34,9 +35,11 @@ __global__ __launch_bounds__(MW_THREADS) void k_wfa_mw(const WfaIn *__restrict__
     constexpr int W = MW_THREADS * NCW;
     constexpr int RING_BYTES = 9 * W * 4 > (int)sizeof(BtLds) ? 9 * W * 4 : (int)sizeof(BtLds);
     __shared__ __attribute__((aligned(16))) uint8_t ring_raw[RING_BYTES]; // the backtrace walk reuses the ring (dead by then)
-    __shared__ int32_t red[32];
+    __shared__ int32_t red[40];
     __shared__ unsigned int sh_x;
-    extern __shared__ uint32_t seq_lds[]; // Q and T: seq_words + 2 words each
+    // WIN: the two sequence windows; otherwise both whole packed sequences in dynamic LDS (seq_words + 2 words each)
+    __shared__ uint32_t qwin_buf[WIN ? MW_WINW + 2 : 1], twin_buf[WIN ? MW_WINW + 2 : 1];
+    extern __shared__ uint32_t seq_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     int32_t *hdr2 = hdr_pool + (int64_t)blockIdx.x * hdr_stride;
     uint8_t *bt = arena_pool + (int64_t)blockIdx.x * arena_stride;
@@ -61,11 +64,11 @@ __global__ __launch_bounds__(MW_THREADS) void k_wfa_mw(const WfaIn *__restrict__
         p.max_score = max_score;
         MwLds L;
         L.ring = (int32_t *)ring_raw;
-        L.qbuf = seq_lds;
-        L.tbuf = seq_lds + seq_words + 2;
+        L.qbuf = WIN ? qwin_buf : seq_lds;
+        L.tbuf = WIN ? twin_buf : seq_lds + seq_words + 2;
         L.red = red;
         MwRes res;
-        wfa_mw_forward<NCW>(p, L, seq_words, &res);
+        wfa_mw_forward<NCW, WIN>(p, L, seq_words, &res);
         __threadfence_block();
         __syncthreads(); // the backtrace reads what every thread stored to global memory; the ring is dead
         if (tid < 64) {
@@ -85,15 +88,15 @@ __global__ __launch_bounds__(MW_THREADS) void k_wfa_mw(const WfaIn *__restrict__
                     o.r.status = 1;
                 } else {
                     WfaWin Q, T;
-                    Q.buf = seq_lds;
+                    Q.buf = L.qbuf;
                     Q.src = w.q;
                     Q.len = w.qlen;
-                    Q.w0 = 0;
-                    T.buf = seq_lds + seq_words + 2;
+                    Q.w0 = WIN ? -(1 << 24) : 0; // (WIN: nothing counts as resident, the replay's first step loads its windows)
+                    T.buf = L.tbuf;
                     T.src = w.t;
                     T.len = w.tlen;
-                    T.w0 = 0;
-                    bt_replay<false>(bt + arena_stride - 16 - nops, nops, Q, T, w.qlen, w.tlen, want_ops ? ops_pool + w.ops_off : nullptr, w.ops_cap, lane,
+                    T.w0 = WIN ? -(1 << 24) : 0;
+                    bt_replay<WIN>(bt + arena_stride - 16 - nops, nops, Q, T, w.qlen, w.tlen, want_ops ? ops_pool + w.ops_off : nullptr, w.ops_cap, lane,
                                      res.score, &o.r, &o.blast_score);
                 }
             }
@@ -107,7 +110,10 @@ __global__ __launch_bounds__(MW_THREADS) void k_wfa_mw(const WfaIn *__restrict__
 
 typedef void (*WfaMwFn)(const WfaIn *, int64_t, const int32_t *, int64_t, int32_t *, int64_t, uint8_t *, int64_t, uint64_t *, unsigned int *, int,
                         int, WfaOut *);
-static WfaMwFn wfa_mw_fn(int ncw) { return ncw == 4 ? k_wfa_mw<4> : ncw == 1 ? k_wfa_mw<1> : k_wfa_mw<2>; }
+static WfaMwFn wfa_mw_fn(int ncw, bool win) {
+    if (win) return ncw == 4 ? k_wfa_mw<4, true> : ncw == 1 ? k_wfa_mw<1, true> : k_wfa_mw<2, true>;
+    return ncw == 4 ? k_wfa_mw<4, false> : ncw == 1 ? k_wfa_mw<1, false> : k_wfa_mw<2, false>;
+}
 
 } // namespace lm
 
@@ -129,7 +135,7 @@ struct MwCompare {
 // seqs: all sequences back to back; problem i aligns [qoff, qoff+qlen) with [toff, toff+tlen).  ncw 2: 512 diagonals against
 // k_wfa_lean<8>, ncw 4: 1024 diagonals against k_wfa_lean<16>
 extern "C" int mw_compare(const uint8_t *seqs, int64_t nbytes, const int64_t *qoff, const int32_t *qlen, const int64_t *toff, const int32_t *tlen,
-                          int64_t n, int ncw, int reps, MwCompare *res) {
+                          int64_t n, int ncw, int win, int reps, MwCompare *res) {
     using namespace lm;
     memset(res, 0, sizeof *res);
     res->n = n;
@@ -189,12 +195,12 @@ extern "C" int mw_compare(const uint8_t *seqs, int64_t nbytes, const int64_t *qo
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     for (int which = 0; which < 2; which++) { // 0: the product's single-wavefront kernel, 1: four wavefronts per alignment
-        const size_t lds = (size_t)(2 * (wmax + 2)) * sizeof(uint32_t);
+        const size_t lds = win ? 0 : (size_t)(2 * (wmax + 2)) * sizeof(uint32_t);
         int nb = 0, nblocks = 0;
         if (which == 0) {
-            nblocks = (int)std::min<int64_t>(n, std::max(256, wfa_resident_blocks(device, wmax, nc, false)));
+            nblocks = (int)std::min<int64_t>(n, std::max(256, wfa_resident_blocks(device, wmax, nc, win != 0)));
         } else {
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)wfa_mw_fn(ncw), MW_THREADS, lds) != hipSuccess || nb < 1) nb = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)wfa_mw_fn(ncw, win != 0), MW_THREADS, lds) != hipSuccess || nb < 1) nb = 1;
             nblocks = (int)std::min<int64_t>(n, (int64_t)nb * cus);
         }
         int32_t *hdr = nullptr;
@@ -206,9 +212,9 @@ extern "C" int mw_compare(const uint8_t *seqs, int64_t nbytes, const int64_t *qo
             CK(hipMemsetAsync(d_queue, 0, sizeof(unsigned int), st));
             CK(hipEventRecord(e0, st));
             if (which == 0)
-                launch_wfa(st, d_in, n, d_todo, n, nblocks, hdr, entries * 2, arena, bytes, d_ops[0], d_queue, wmax, 1, d_out[0], nc, false);
+                launch_wfa(st, d_in, n, d_todo, n, nblocks, hdr, entries * 2, arena, bytes, d_ops[0], d_queue, wmax, 1, d_out[0], nc, win != 0);
             else
-                hipLaunchKernelGGL(wfa_mw_fn(ncw), dim3(nblocks), dim3(MW_THREADS), lds, st, d_in, n, d_todo, n, hdr, entries * 2, arena, bytes, d_ops[1],
+                hipLaunchKernelGGL(wfa_mw_fn(ncw, win != 0), dim3(nblocks), dim3(MW_THREADS), lds, st, d_in, n, d_todo, n, hdr, entries * 2, arena, bytes, d_ops[1],
                                    d_queue, wmax, 1, d_out[1]);
             CK(hipEventRecord(e1, st));
             CK(hipStreamSynchronize(st));

@@ -14,6 +14,7 @@
 #define WR_BARRIER() simt::barrier(__LINE__)
 #define WR_UNIFORM(x) (x)
 #define WR_CLZ(x) __builtin_clz(x)
+#define WR_CLZLL(x) __builtin_clzll(x)
 static inline uint32_t wr_pk_min_u16(uint32_t a, uint32_t b) {
     const uint32_t lo = (a & 0xffffu) < (b & 0xffffu) ? (a & 0xffffu) : (b & 0xffffu);
     const uint32_t hi = (a >> 16) < (b >> 16) ? (a >> 16) : (b >> 16);
@@ -26,13 +27,14 @@ static inline uint32_t wr_pk_min_u16(uint32_t a, uint32_t b) {
 #include "wfa_mw_fwd.h"
 #include "wfa_host_walk.h"
 
-template <int NCW>
+template <int NCW, bool WIN>
 static long run1(const uint8_t *q, int qlen, const uint8_t *t, int tlen, int seq_words, int max_score, int arena_cap, uint64_t *ops, int ops_cap,
                  WrEmuOut *out) {
     constexpr int W = MW_THREADS * NCW;
-    std::vector<int32_t> hdr((size_t)max_score + 8, 0), ring((size_t)9 * W, 0x5a5a5a5a), red(32, 0x5a5a5a5a);
+    std::vector<int32_t> hdr((size_t)max_score + 8, 0), ring((size_t)9 * W, 0x5a5a5a5a), red(40, 0x5a5a5a5a);
     std::vector<uint8_t> bt((size_t)arena_cap + 16, 0xff);
-    std::vector<uint32_t> qb((size_t)seq_words + 2, 0xdeadbeefu), tb((size_t)seq_words + 2, 0xdeadbeefu);
+    const size_t sw = WIN ? MW_WINW + 2 : (size_t)seq_words + 2;
+    std::vector<uint32_t> qb(sw, 0xdeadbeefu), tb(sw, 0xdeadbeefu);
     MwProb p;
     p.q = q;
     p.t = t;
@@ -48,7 +50,7 @@ static long run1(const uint8_t *q, int qlen, const uint8_t *t, int tlen, int seq
     L.tbuf = tb.data();
     L.red = red.data();
     std::vector<MwRes> res(MW_THREADS);
-    const long ncoll = simt::run_block(MW_WAVES, [&](int tid) { wfa_mw_forward<NCW>(p, L, seq_words, &res[tid]); });
+    const long ncoll = simt::run_block(MW_WAVES, [&](int tid) { wfa_mw_forward<NCW, WIN>(p, L, seq_words, &res[tid]); });
     for (int i = 1; i < MW_THREADS; i++)
         if (memcmp(&res[0], &res[i], sizeof(MwRes)) != 0) {
             fprintf(stderr, "wfa_mw_emu: threads disagree on the result\n");
@@ -62,12 +64,15 @@ static long run1(const uint8_t *q, int qlen, const uint8_t *t, int tlen, int seq
     return ncoll;
 }
 
-extern "C" long mw_emu_run(int ncw, const uint8_t *q, int qlen, const uint8_t *t, int tlen, int seq_words, int max_score, int arena_cap,
+extern "C" long mw_emu_run(int ncw, int win, const uint8_t *q, int qlen, const uint8_t *t, int tlen, int seq_words, int max_score, int arena_cap,
                            uint64_t *ops, int ops_cap, WrEmuOut *out) {
-    switch (ncw) {
-    case 1: return run1<1>(q, qlen, t, tlen, seq_words, max_score, arena_cap, ops, ops_cap, out);
-    case 2: return run1<2>(q, qlen, t, tlen, seq_words, max_score, arena_cap, ops, ops_cap, out);
-    case 4: return run1<4>(q, qlen, t, tlen, seq_words, max_score, arena_cap, ops, ops_cap, out);
+    switch (ncw * 2 + (win ? 1 : 0)) {
+    case 2: return run1<1, false>(q, qlen, t, tlen, seq_words, max_score, arena_cap, ops, ops_cap, out);
+    case 3: return run1<1, true>(q, qlen, t, tlen, seq_words, max_score, arena_cap, ops, ops_cap, out);
+    case 4: return run1<2, false>(q, qlen, t, tlen, seq_words, max_score, arena_cap, ops, ops_cap, out);
+    case 5: return run1<2, true>(q, qlen, t, tlen, seq_words, max_score, arena_cap, ops, ops_cap, out);
+    case 8: return run1<4, false>(q, qlen, t, tlen, seq_words, max_score, arena_cap, ops, ops_cap, out);
+    case 9: return run1<4, true>(q, qlen, t, tlen, seq_words, max_score, arena_cap, ops, ops_cap, out);
     }
     return -1;
 }

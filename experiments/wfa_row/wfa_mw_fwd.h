@@ -30,8 +30,8 @@ struct MwProb { // one alignment; identical in every thread of the workgroup
 };
 struct MwLds {
     int32_t *ring;         // 9 * W words: M rows 0-4, I rows 5-6, D rows 7-8
-    uint32_t *qbuf, *tbuf; // the 2-bit packed sequences, seq_words + 2 words each
-    int32_t *red;          // 32 words of reduction scratch
+    uint32_t *qbuf, *tbuf; // the 2-bit packed sequences, seq_words + 2 words each (WIN: the windows, MW_WINW + 2 words each)
+    int32_t *red;          // 40 words of reduction scratch
 };
 struct MwRes {
     int32_t status; // 0 aligned, 1 scratch / score overflow, 3 wider than W-2 diagonals or not plain ACGT
@@ -69,13 +69,57 @@ WR_DEV int mw_match_run(const uint32_t *qb, const uint32_t *tb, int v, int h, in
     nm = nm < rem ? nm : rem;
     return nm > 0 ? nm : 0;
 }
+// ---- sliding 2-bit windows (the WIN form): each sequence as a circular window of MW_WINW words of 16 bases (4096 bases); word w
+// lives at slot w & (MW_WINW - 1), slots 0 and 1 are mirrored behind the last one so that three consecutive words never wrap
+// (the layout of k_wfa_lean's WfaWin: bt_replay<true> continues on the same buffers)
+#define MW_WINW 256
+WR_DEV bool mw_win_has(int w0, int pos) { return (uint32_t)((pos >> 4) - w0) < (uint32_t)(MW_WINW - 2); }
+WR_DEV uint64_t mw_win_get32(const uint32_t *buf, int pos) {
+    const uint32_t *p = buf + ((pos >> 4) & (MW_WINW - 1));
+    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+    const int rs = 32 - ((pos & 15) << 1); // 2..32
+    const uint32_t hi = (uint32_t)((((uint64_t)d0 << 32) | d1) >> rs);
+    const uint32_t lo = (uint32_t)((((uint64_t)d1 << 32) | d2) >> rs);
+    return ((uint64_t)hi << 32) | lo;
+}
+WR_DEV int mw_match_run_win(const uint32_t *qb, const uint32_t *tb, int v, int h, int plen, int tlen) { // at most 32 bases
+    const uint64_t d = mw_win_get32(qb, v) ^ mw_win_get32(tb, h);
+    int nm = d ? (WR_CLZLL(d) >> 1) : 32;
+    const int rem = plen - v < tlen - h ? plen - v : tlen - h;
+    nm = nm < rem ? nm : rem;
+    return nm > 0 ? nm : 0;
+}
+// the whole workgroup makes words [qw0, qw0 + WINW) of Q and [tw0, tw0 + WINW) of T resident; words that stay are not reloaded
+WR_DEV void mw_win_move2(uint32_t *qbuf, const uint8_t *q, int plen, int *qw0_cur, int qw0, uint32_t *tbuf, const uint8_t *t, int tlen, int *tw0_cur,
+                         int tw0, int tid, bool *bad, bool fresh) {
+    WR_BARRIER(); // every thread is done reading the slots that are about to change
+    const bool qkeep = !fresh && qw0 >= *qw0_cur && qw0 < *qw0_cur + MW_WINW, tkeep = !fresh && tw0 >= *tw0_cur && tw0 < *tw0_cur + MW_WINW;
+    const int qfrom = qkeep ? *qw0_cur + MW_WINW : qw0, tfrom = tkeep ? *tw0_cur + MW_WINW : tw0;
+    const int nq = qw0 + MW_WINW - qfrom, nt = tw0 + MW_WINW - tfrom; // words to load (0 when a window does not move)
+    for (int i = tid; i < nq + nt; i += MW_THREADS) {
+        const bool isq = i < nq;
+        const int w = isq ? qfrom + i : tfrom + (i - nq);
+        const uint8_t *src = isq ? q : t;
+        uint32_t *buf = isq ? qbuf : tbuf;
+        const int nb = (isq ? plen : tlen) - 16 * w;
+        const uint32_t word = nb > 0 ? mw_pack16(src + 16 * (int64_t)w, nb, bad) : 0u;
+        const int slot = w & (MW_WINW - 1);
+        buf[slot] = word;
+        if (slot < 2) buf[MW_WINW + slot] = word;
+    }
+    *qw0_cur = WR_UNIFORM(qw0);
+    *tw0_cur = WR_UNIFORM(tw0);
+    WR_BARRIER();
+}
+
 WR_DEV int mw_dist(int32_t off, int k, int plen, int tlen) {
     if (off < 0) return 1073741824;
     const int lv = plen - (off - k), lh = tlen - off;
     return lv > lh ? lv : lh;
 }
 
-template <int NCW> WR_DEV void wfa_mw_forward(const MwProb &p, const MwLds &L, int seq_words, MwRes *res) {
+// WIN: the sequences through sliding windows (L.qbuf / L.tbuf: MW_WINW + 2 words each, any length) instead of whole in LDS
+template <int NCW, bool WIN> WR_DEV void wfa_mw_forward(const MwProb &p, const MwLds &L, int seq_words, MwRes *res) {
     static_assert(NCW == 1 || NCW == 2 || NCW == 4, "1, 2 or 4 diagonals per thread");
     constexpr int T = MW_THREADS, W = T * NCW;
     constexpr int E_LO = 1 << 28, E_HI = -(1 << 28);
@@ -86,7 +130,10 @@ template <int NCW> WR_DEV void wfa_mw_forward(const MwProb &p, const MwLds &L, i
     const int koff = W / 2 - (ak >= -(W / 2) && ak <= W / 2 ? ak / 2 : 0);
     int status = 0;
     bool bad = false;
-    {
+    int qw0 = 0, tw0 = 0; // WIN: first resident word of either window (uniform)
+    if (WIN) {
+        mw_win_move2(L.qbuf, p.q, plen, &qw0, 0, L.tbuf, p.t, tlen, &tw0, 0, tid, &bad, true);
+    } else {
         const int qw = (plen + 15) >> 4, tw = (tlen + 15) >> 4;
         if (qw > seq_words || tw > seq_words) {
             status = 3;
@@ -98,6 +145,8 @@ template <int NCW> WR_DEV void wfa_mw_forward(const MwProb &p, const MwLds &L, i
                 L.tbuf[tw] = L.tbuf[tw + 1] = 0;
             }
         }
+    }
+    {
         const bool wbad = WR_BALLOT(bad) != 0ull;
         if (lane == 0) L.red[wave] = wbad ? 1 : 0;
     }
@@ -107,7 +156,7 @@ template <int NCW> WR_DEV void wfa_mw_forward(const MwProb &p, const MwLds &L, i
         for (int r = 0; r < 9; r++) L.ring[r * W + tid + T * c] = WR_NULL_OFF;
     }
     WR_BARRIER(); // sequences, ring and the flags are in LDS
-    if (status == 0 && (L.red[0] | L.red[1] | L.red[2] | L.red[3]) != 0) status = 3;
+    if (!WIN && status == 0 && (L.red[0] | L.red[1] | L.red[2] | L.red[3]) != 0) status = 3; // (WIN: checked when the alignment ends)
     status = WR_UNIFORM(status);
     if (status == 0 && (p.max_score < 1 || p.arena_cap < 1)) status = 1;
     int mlo[5], mhi[5], ilo[2], ihi[2], dlo[2], dhi[2];
@@ -145,7 +194,7 @@ template <int NCW> WR_DEV void wfa_mw_forward(const MwProb &p, const MwLds &L, i
             int kc[NCW], jc[NCW];
             bool inr[NCW];
             int32_t off[NCW];
-            bool fin = false;
+            uint32_t extm = 0; // WIN: bit c = this thread's cell of chunk c is still being extended
 #pragma unroll
             for (int c = 0; c < NCW; c++) {
                 const int slot = tid + T * c;
@@ -157,41 +206,84 @@ template <int NCW> WR_DEV void wfa_mw_forward(const MwProb &p, const MwLds &L, i
                 off[c] = WR_NULL_OFF;
                 if (((cmx >> c) & 1u) == 0) continue; // (uniform for the workgroup)
                 inr[c] = (uint32_t)(k - mlo[0]) <= (uint32_t)(mhi[0] - mlo[0]);
-                int32_t o = rM[ms * W + slot];
-                const bool act = inr[c] && o >= 0;
-                int v = act ? o - k : 0, h = act ? o : 0;
-                bool ext = act;
-                while (WR_BALLOT(ext) != 0ull) { // per wavefront: 16 bases per pass
-                    const int run = mw_match_run(L.qbuf, L.tbuf, v, h, plen, tlen);
-                    const int nm = ext ? run : 0;
-                    v += nm;
-                    h += nm;
-                    ext = nm == 16;
-                }
-                if (act) {
-                    o = h;
-                    rM[ms * W + slot] = o;
-                }
-                off[c] = o;
-                fin = fin || (inr[c] && k == ak && o >= tlen);
+                off[c] = rM[ms * W + slot];
+                if (inr[c] && off[c] >= 0) extm |= 1u << c;
             }
-            // across the four wavefronts: has the final cell been reached, and the smallest distance to the end
             int dist[NCW];
-            int dm = 2147483647;
+            while (true) { // (one pass unless a cell has to wait for the windows)
 #pragma unroll
-            for (int c = 0; c < NCW; c++) {
-                dist[c] = inr[c] ? mw_dist(off[c], kc[c], plen, tlen) : 2147483647;
-                dm = dist[c] < dm ? dist[c] : dm;
-            }
-            {
-                const bool wfin = WR_BALLOT(fin) != 0ull;
-                const int wdm = (int)WR_WAVE_MIN_I32(dm);
-                if (lane == 0) {
-                    L.red[wave] = wfin ? 1 : 0;
-                    L.red[4 + wave] = wdm;
+                for (int c = 0; c < NCW; c++) {
+                    if (((cmx >> c) & 1u) == 0) continue;
+                    bool ext = ((extm >> c) & 1u) != 0;
+                    int h = ext ? off[c] : 0, v = ext ? h - kc[c] : 0;
+                    if (!WIN) {
+                        while (WR_BALLOT(ext) != 0ull) { // per wavefront: 16 bases per pass from the whole packed sequences
+                            const int run = mw_match_run(L.qbuf, L.tbuf, v, h, plen, tlen);
+                            const int nm = ext ? run : 0;
+                            v += nm;
+                            h += nm;
+                            ext = nm == 16;
+                        }
+                    } else {
+                        while (true) { // 32 bases per pass from the windows; a cell outside a window waits
+                            const bool in = mw_win_has(qw0, v) && mw_win_has(tw0, h);
+                            if (WR_BALLOT(ext && in) == 0ull) break;
+                            const int run = mw_match_run_win(L.qbuf, L.tbuf, v, h, plen, tlen);
+                            const int nm = (ext && in) ? run : 0;
+                            v += nm;
+                            h += nm;
+                            ext = ext && (!in || nm == 32);
+                        }
+                    }
+                    if ((extm >> c) & 1u) off[c] = h;
+                    if (!ext) extm &= ~(1u << c);
                 }
+                // across the four wavefronts: has the final cell been reached, the smallest distance to the end, and (WIN) is
+                // anybody waiting for the windows - then both move to the smallest waiting positions and the extension goes on
+                bool fin = false;
+                int dm = 2147483647, mv = 2147483647, mh = 2147483647;
+#pragma unroll
+                for (int c = 0; c < NCW; c++) {
+                    dist[c] = inr[c] ? mw_dist(off[c], kc[c], plen, tlen) : 2147483647;
+                    dm = dist[c] < dm ? dist[c] : dm;
+                    fin = fin || (inr[c] && kc[c] == ak && off[c] >= tlen);
+                    const bool wt = ((extm >> c) & 1u) != 0;
+                    mh = wt && off[c] < mh ? off[c] : mh;
+                    mv = wt && off[c] - kc[c] < mv ? off[c] - kc[c] : mv;
+                }
+                {
+                    const bool wfin = WR_BALLOT(fin) != 0ull;
+                    const int wdm = (int)WR_WAVE_MIN_I32(dm);
+                    int wmv = 0, wmh = 0;
+                    bool wwait = false;
+                    if (WIN) {
+                        wwait = WR_BALLOT(extm != 0u) != 0ull;
+                        wmv = (int)WR_WAVE_MIN_I32(mv);
+                        wmh = (int)WR_WAVE_MIN_I32(mh);
+                    }
+                    if (lane == 0) {
+                        L.red[wave] = wfin ? 1 : 0;
+                        L.red[4 + wave] = wdm;
+                        if (WIN) {
+                            L.red[24 + wave] = wwait ? 1 : 0;
+                            L.red[28 + wave] = wmv;
+                            L.red[32 + wave] = wmh;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < NCW; c++)
+                    if (inr[c] && off[c] >= 0) rM[ms * W + tid + T * c] = off[c];
+                WR_BARRIER(); // B1: the partial results, and every extended cell, are in LDS
+                if (!WIN) break;
+                if (WR_UNIFORM(L.red[24] | L.red[25] | L.red[26] | L.red[27]) == 0) break;
+                int gv = L.red[28] < L.red[29] ? L.red[28] : L.red[29], gh = L.red[32] < L.red[33] ? L.red[32] : L.red[33];
+                gv = L.red[30] < gv ? L.red[30] : gv;
+                gv = L.red[31] < gv ? L.red[31] : gv;
+                gh = L.red[34] < gh ? L.red[34] : gh;
+                gh = L.red[35] < gh ? L.red[35] : gh;
+                mw_win_move2(L.qbuf, p.q, plen, &qw0, WR_UNIFORM(gv) >> 4, L.tbuf, p.t, tlen, &tw0, WR_UNIFORM(gh) >> 4, tid, &bad, false);
             }
-            WR_BARRIER(); // B1: the partial results, and every extended cell, are in LDS
             done = WR_UNIFORM(L.red[0] | L.red[1] | L.red[2] | L.red[3]) != 0;
             if (!done && mhi[0] - mlo[0] + 1 >= 10) { // wf-adaptive(10, 50)
                 int dmin = L.red[4] < L.red[5] ? L.red[4] : L.red[5];
@@ -379,6 +471,14 @@ template <int NCW> WR_DEV void wfa_mw_forward(const MwProb &p, const MwLds &L, i
             rI[is * W + slot] = (uint32_t)(k - ilo[0]) <= spi ? vins[c] : WR_NULL_OFF;
             rD[is * W + slot] = (uint32_t)(k - dlo[0]) <= spd ? vdel[c] : WR_NULL_OFF;
         }
+    }
+    if (WIN) { // a byte that is not A/C/G/T was packed on the way: the byte-comparing kernel takes the problem
+        const bool wbad = WR_BALLOT(bad) != 0ull;
+        WR_BARRIER();
+        if (lane == 0) L.red[wave] = wbad ? 1 : 0;
+        WR_BARRIER();
+        if (status == 0 && (L.red[0] | L.red[1] | L.red[2] | L.red[3]) != 0) status = 3;
+        status = WR_UNIFORM(status);
     }
     res->status = status;
     res->score = status == 0 ? s : (status == 3 ? wide_at : 0);

@@ -27,14 +27,14 @@ def lib():
     return _lib
 
 
-def run1(q, t, ncw, seq_words=None, max_score=20000, arena_cap=1 << 22):
+def run1(q, t, ncw, seq_words=None, max_score=20000, arena_cap=1 << 22, win=False):
     L = lib()
     if seq_words is None:
         seq_words = (max(len(q), len(t)) + 15) // 16 + 1
     cap = len(q) + len(t) + 8
     ops = (C.c_uint64 * cap)()
     o = EmuOut()
-    n = L.mw_emu_run(ncw, q, len(q), t, len(t), seq_words, max_score, arena_cap, ops, cap, C.byref(o))
+    n = L.mw_emu_run(ncw, int(win), q, len(q), t, len(t), seq_words, max_score, arena_cap, ops, cap, C.byref(o))
     assert n > 0
     return o.status, (0, o.score, [ops[j] for j in range(o.nops)], o.qbegin, o.qend, o.tbegin, o.tend, o.align_len, o.matches, o.gaps,
                       o.gap_regions)
@@ -68,6 +68,31 @@ def test_workgroup_alignment_equals_the_oracle(ncw, n, div, ins, at_end, seed):
         if at_end and div >= 0.08:  # these really are wide (enough score steps before the end gap): half the ring does not hold them
             st2, got2 = run1(q, t, ncw // 2)
             assert st2 == 3 and got2[1] > 256 * (ncw // 2) - 2
+
+
+@pytest.mark.parametrize("ncw,n,div,ins,seed", [(1, 700, 0.10, 0, 31), (2, 5200, 0.05, 0, 32), (2, 9000, 0.06, 300, 33), (4, 6000, 0.10, 600, 34)])
+def test_windowed_form_equals_the_oracle(ncw, n, div, ins, seed):
+    """WIN: sequences through sliding 4096-base windows (any length; beyond 4096 bases the windows have to move, and with a
+    long end gap the cells of one wavefront wait for each other's window positions)"""
+    rng = random.Random(seed)
+    q = rand_seq(rng, n)
+    t = with_insertion(rng, q, -1, ins, div)
+    exp = run_oracle_wfa(q, t)
+    st, got = run1(q, t, ncw, win=True, seq_words=1)  # seq_words is not used by the windowed form
+    assert st == 0 and got == exp
+    if n <= 5200:  # and the whole-sequence form of the same kernel agrees
+        assert run1(q, t, ncw) == (st, got)
+
+
+def test_windowed_form_statuses():
+    rng = random.Random(41)
+    assert run1(b"ACGTNACGT" * 5, b"ACGTACGT" * 5, 1, win=True)[0] == 3          # not plain ACGT
+    q = rand_seq(rng, 5000)
+    assert run1(q[:2500] + b"N" + q[2500:], q, 1, win=True)[0] == 3               # ... met only after a window move
+    far = (rand_seq(rng, 120), rand_seq(rng, 120))
+    assert run1(far[0], far[1], 1, max_score=40, win=True)[0] == 1
+    st, got = run1(b"ACGT", b"ACGGT", 1, win=True)
+    assert (st, got) == (0, run_oracle_wfa(b"ACGT", b"ACGGT"))
 
 
 def test_too_wide_for_the_ring_says_so_and_small_cases():
