@@ -293,6 +293,8 @@ struct lm_tune {
     int pa_seg_by_group = 1; // candidate segments by task group + XCD-local k_pa_search (LM_PA_SEG_BY_WAVE=1: by wavefront)
     int wfa_resident_pct = 100; // LM_WFA_RESIDENT_PCT: share of the CUs' wavefront slots / LDS the persistent WFA kernels take
     FILE *wfa_dump = nullptr; // LM_DEBUG_WFA_DUMP=<file>: one line per WFA problem and pass (width, status, lengths, estimate, score)
+    int wfa_mw = 1;          // 512 / 1024-diagonal passes by a workgroup of four wavefronts per alignment (LM_WFA_MW=0: one wavefront)
+    int pa_chain_ring = 1;   // Chainer2 DP with the recent anchors in an LDS ring (LM_PA_CHAIN_RING=0: through global memory)
     int wfa_serial = 0;      // LM_WFA_SERIAL=1: the WFA length classes one after the other (exclusive kernel timings)
     int no_pipeline = 0;     // LM_NO_PIPELINE=1: no pseudo-alignment producer beside extend / WFA (exclusive kernel timings)
     lm_tune() {
@@ -308,6 +310,8 @@ struct lm_tune {
         if (const char *e = getenv("LM_WFA_WIN"))
             for (int c = 0; c < LM_WFA_CLASSES && e[c]; c++) wfa_win[c] = e[c] == '1';
         no_pipeline = getenv("LM_NO_PIPELINE") != nullptr;
+        if (const char *e = getenv("LM_WFA_MW")) wfa_mw = atoi(e) != 0;
+        if (const char *e = getenv("LM_PA_CHAIN_RING")) pa_chain_ring = atoi(e) != 0;
         if (getenv("LM_CHAIN1_LANES")) chain1_wave = 0;
         if (const char *e = getenv("LM_PA_SEG_BY_WAVE")) pa_seg_by_group = atoi(e) ? 0 : 1;
     }

@@ -1363,6 +1363,8 @@ __global__ void k_pa_task_off_sorted(const uint64_t *__restrict__ sortedA, int s
 // Wave-cooperative Clear + Trim + Chainer2 (+ chainARegion) for one chain: lanes cover anchors for ClearSubstrPairs and
 // candidate predecessors j for the banded DP; emission order and every tie rule are those of lm_clear_sorted / lm_trim
 // / lm_run_chain2 (lm_algos.h), which stay the CPU-checked statement of the logic.
+#include "lm_pa_chain_dp.h"
+
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
     for (int o = 32; o > 0; o >>= 1) {
         unsigned long long x = __shfl_xor(v, o, 64);
@@ -1371,6 +1373,9 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
     return v;
 }
 
+// RING: the DP keeps the recent anchors and scores in an LDS ring (lm_pa_chain_dp_core.h); otherwise every step goes
+// through global memory (kept for comparison: LM_PA_CHAIN_RING=0)
+template <bool RING>
 __global__ __launch_bounds__(64) void k_pa_chain_wave(const uint64_t *__restrict__ B, const int64_t *__restrict__ pa_off,
                                                        int64_t ntasks, int K, LmChain2Opt opt, LmSub *__restrict__ subs_pool,
                                                        uint8_t *__restrict__ marks_pool, uint64_t *__restrict__ msi_pool,
@@ -1378,6 +1383,7 @@ __global__ __launch_bounds__(64) void k_pa_chain_wave(const uint64_t *__restrict
                                                        int32_t *__restrict__ out_n, int32_t *__restrict__ clr_n, int qbits,
                                                        int tbits) {
     const int lane = threadIdx.x;
+    __shared__ PcdLds pcd_lds;
     for (int64_t ti = blockIdx.x; ti < ntasks; ti += gridDim.x) {
         const int64_t o = pa_off[ti];
         int n = (int)(pa_off[ti + 1] - o);
@@ -1469,63 +1475,68 @@ __global__ __launch_bounds__(64) void k_pa_chain_wave(const uint64_t *__restrict
             continue;
         }
         // ---- banded DP (lib-chaining2.go:222-307), candidates j scanned 64 at a time from i-1 downwards ----
-        if (lane == 0) msi[0] = (uint64_t)a_[0].len << 32;
         long long M = 0;
         int Mi = 0;
-        for (int i = 1; i < n; i++) {
-            __syncthreads();
-            const LmSub a = a_[i];
-            unsigned long long best = 0; // (score<<32 | ~j) of the best candidate so far, 0 = none
-            int bcount = 0;
-            bool stop = false;
-            for (int jt = i - 1; jt >= 0 && !stop; jt -= 64) {
-                int j = jt - lane;
-                bool inb = j >= 0;
-                LmSub b;
-                bool skip = true;
-                if (inb) {
-                    b = a_[j];
-                    skip = (b.qbegin == a.qbegin || b.tbegin > a.tbegin);
-                }
-                unsigned long long nskip = __ballot(!skip);
-                int cnt = bcount + __popcll(nskip & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull)));
-                bool brk = false;
-                if (!skip) {
-                    int32_t bbase = a.qbegin - b.qbegin - (int32_t)b.len;
-                    brk = !(bbase <= opt.band_base || cnt <= opt.band_count);
-                }
-                unsigned long long bm = __ballot(brk);
-                int first_brk = bm ? (__ffsll((long long)bm) - 1) : 64;
-                if (bm) stop = true;
-                if (!skip && lane < first_brk) {
-                    int32_t qd = a.qbegin - b.qbegin, td = a.tbegin - b.tbegin;
-                    if (qd < 0) qd = -qd;
-                    if (td < 0) td = -td;
-                    int32_t g = qd > td ? qd - td : td - qd;
-                    if (g <= opt.max_gap) {
-                        long long s = (long long)(msi[j] >> 32) + (long long)b.len - (long long)g;
-                        if (s >= 0) {
-                            unsigned long long key = ((unsigned long long)s << 32) | (unsigned long long)(0xffffffffu - (uint32_t)j);
-                            if (key > best) best = key;
+        if (RING) {
+            pa_chain_dp_ring(a_, n, opt, msi, &pcd_lds, &M, &Mi);
+            __threadfence_block();
+        } else {
+            if (lane == 0) msi[0] = (uint64_t)a_[0].len << 32;
+            for (int i = 1; i < n; i++) {
+                __syncthreads();
+                const LmSub a = a_[i];
+                unsigned long long best = 0; // (score<<32 | ~j) of the best candidate so far, 0 = none
+                int bcount = 0;
+                bool stop = false;
+                for (int jt = i - 1; jt >= 0 && !stop; jt -= 64) {
+                    int j = jt - lane;
+                    bool inb = j >= 0;
+                    LmSub b;
+                    bool skip = true;
+                    if (inb) {
+                        b = a_[j];
+                        skip = (b.qbegin == a.qbegin || b.tbegin > a.tbegin);
+                    }
+                    unsigned long long nskip = __ballot(!skip);
+                    int cnt = bcount + __popcll(nskip & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull)));
+                    bool brk = false;
+                    if (!skip) {
+                        int32_t bbase = a.qbegin - b.qbegin - (int32_t)b.len;
+                        brk = !(bbase <= opt.band_base || cnt <= opt.band_count);
+                    }
+                    unsigned long long bm = __ballot(brk);
+                    int first_brk = bm ? (__ffsll((long long)bm) - 1) : 64;
+                    if (bm) stop = true;
+                    if (!skip && lane < first_brk) {
+                        int32_t qd = a.qbegin - b.qbegin, td = a.tbegin - b.tbegin;
+                        if (qd < 0) qd = -qd;
+                        if (td < 0) td = -td;
+                        int32_t g = qd > td ? qd - td : td - qd;
+                        if (g <= opt.max_gap) {
+                            long long s = (long long)(msi[j] >> 32) + (long long)b.len - (long long)g;
+                            if (s >= 0) {
+                                unsigned long long key = ((unsigned long long)s << 32) | (unsigned long long)(0xffffffffu - (uint32_t)j);
+                                if (key > best) best = key;
+                            }
                         }
                     }
+                    bcount += __popcll(nskip);
                 }
-                bcount += __popcll(nskip);
-            }
-            best = wave_max_u64(best);
-            long long m = a.len;
-            int mj = i;
-            if (best != 0) {
-                long long s = (long long)(best >> 32);
-                if (s >= m) {
-                    m = s;
-                    mj = (int)(0xffffffffu - (uint32_t)(best & 0xffffffffu));
+                best = wave_max_u64(best);
+                long long m = a.len;
+                int mj = i;
+                if (best != 0) {
+                    long long s = (long long)(best >> 32);
+                    if (s >= m) {
+                        m = s;
+                        mj = (int)(0xffffffffu - (uint32_t)(best & 0xffffffffu));
+                    }
                 }
-            }
-            if (lane == 0) msi[i] = ((uint64_t)m << 32) | (uint64_t)(uint32_t)mj;
-            if (m > M) {
-                M = m;
-                Mi = i;
+                if (lane == 0) msi[i] = ((uint64_t)m << 32) | (uint64_t)(uint32_t)mj;
+                if (m > M) {
+                    M = m;
+                    Mi = i;
+                }
             }
         }
         __syncthreads();
@@ -2921,6 +2932,8 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
 }
 
 
+#include "lm_wfa_mw.h"
+
 // ------------------------------------------------------------------------------------------------------------
 // host-callable launchers
 static inline int grid_for(int64_t n, int block, int maxb = 2048 * 8) {
@@ -3057,9 +3070,9 @@ void launch_pa_task_off_sorted(hipStream_t st, const uint64_t *sortedA, int shif
 }
 void launch_pa_chain(hipStream_t st, const uint64_t *B, const int64_t *pa_off, int64_t ntasks, int K, LmChain2Opt opt,
                      LmSub *subs, uint8_t *marks, uint64_t *msi, int32_t *stack, LmChain2 *out, int32_t *out_n,
-                     int32_t *clr_n, int qbits, int tbits) {
+                     int32_t *clr_n, int qbits, int tbits, bool ring) {
     int g = (int)(ntasks < 1 ? 1 : (ntasks > 262144 ? 262144 : ntasks));
-    hipLaunchKernelGGL(k_pa_chain_wave, dim3(g), dim3(64), 0, st, B, pa_off, ntasks, K, opt, subs, marks, msi, stack, out, out_n,
+    hipLaunchKernelGGL(ring ? k_pa_chain_wave<true> : k_pa_chain_wave<false>, dim3(g), dim3(64), 0, st, B, pa_off, ntasks, K, opt, subs, marks, msi, stack, out, out_n,
                        clr_n, qbits, tbits);
 }
 void launch_gather_chain2(hipStream_t st, const LmChain2 *in, const int64_t *pa_off, const int32_t *out_n,

@@ -5,7 +5,7 @@
 
 #include <vector>
 
-#include "../wfa_row/simt_emu.h"
+#include "simt_emu.h"
 #include "../../lexicmap_amd/csrc/lm_algos.h"
 
 #define PCD_DEV static inline
@@ -26,7 +26,7 @@ static inline unsigned long long emu_wave_max_u64(unsigned long long v, int site
 }
 #define PCD_WAVE_MAX_U64(v) emu_wave_max_u64((v), __LINE__)
 
-#include "pa_chain_dp.h"
+#include "../../lexicmap_amd/csrc/lm_pa_chain_dp_core.h"
 
 // subs: n anchors {qbegin, tbegin, len} (sorted the way the kernel gets them); returns 0 when the emulated DP equals lm_run_chain2's
 extern "C" int pcd_emu_check(const int32_t *qb, const int32_t *tb, const uint8_t *len, int n, int max_gap, int band_base, int band_count,

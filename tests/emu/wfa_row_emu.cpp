@@ -23,7 +23,7 @@ static inline uint32_t wr_pk_min_u16(uint32_t a, uint32_t b) {
     simt::row_reduce((uint32_t)(v), __LINE__, [](uint32_t a, uint32_t b) { return (uint32_t)((int32_t)a < (int32_t)b ? (int32_t)a : (int32_t)b); })
 #define WR_ROW_PKMIN_U16(v) simt::row_reduce((v), __LINE__, [](uint32_t a, uint32_t b) { return wr_pk_min_u16(a, b); })
 
-#include "wfa_row_fwd.h"
+#include "../../experiments/wfa_row/wfa_row_fwd.h"
 
 #include "wfa_host_walk.h"
 

@@ -1,5 +1,5 @@
-"""experiments/pa_chain/pa_chain_dp.h: the banded chaining DP of the pseudo-alignment with the recent anchors in an LDS ring
-(staged for the next round, not in the product) on the host SIMT emulator against lm_run_chain2 (the CPU-checked statement of the
+"""lexicmap_amd/csrc/lm_pa_chain_dp_core.h - the banded chaining DP of k_pa_chain_wave<true> with the recent anchors in an LDS
+ring (one source for the device and for the host) - on the host SIMT emulator (tests/emu) against lm_run_chain2 (the CPU-checked statement of the
 device logic, itself equal to the oracle's Chainer2): every score and predecessor, the best score and its anchor."""
 import ctypes as C
 import os
@@ -9,17 +9,17 @@ import subprocess
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-EXP = os.path.join(os.path.dirname(HERE), "experiments", "pa_chain")
+EMU = os.path.join(HERE, "emu")
 _lib = None
 
 
 def lib():
     global _lib
     if _lib is None:
-        path = os.path.join(EXP, "libpa_chain_emu.so")
-        srcs = [os.path.join(EXP, "pa_chain_emu.cpp"), os.path.join(EXP, "pa_chain_dp.h"),
-                os.path.join(os.path.dirname(EXP), "wfa_row", "simt_emu.h"),
-                os.path.join(os.path.dirname(HERE), "lexicmap_amd", "csrc", "lm_algos.h")]
+        csrc = os.path.join(os.path.dirname(HERE), "lexicmap_amd", "csrc")
+        path = os.path.join(EMU, "libpa_chain_emu.so")
+        srcs = [os.path.join(EMU, "pa_chain_emu.cpp"), os.path.join(csrc, "lm_pa_chain_dp_core.h"), os.path.join(EMU, "simt_emu.h"),
+                os.path.join(csrc, "lm_algos.h")]
         if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(s) for s in srcs):
             subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-o", path, srcs[0]])
         _lib = C.CDLL(path)

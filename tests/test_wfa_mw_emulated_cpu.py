@@ -1,5 +1,5 @@
-"""experiments/wfa_row/wfa_mw_fwd.h: the WFA forward pass by a workgroup of four wavefronts per alignment (staged for the next
-round, not in the product) on the host SIMT emulator against the oracle: score, run list, coordinates and statistics;
+"""lexicmap_amd/csrc/lm_wfa_mw_fwd.h - the forward pass of the product's k_wfa_mw (a workgroup of four wavefronts per long
+alignment; one source for the device and for the host) - on the host SIMT emulator (tests/emu) against the oracle: score, run list, coordinates and statistics;
 wavefronts wider than one wavefront's 64 lanes, than 256 and than 512 diagonals (long insertions), and what does not fit
 256 * NCW - 2 diagonals must say so (status 3)."""
 import ctypes as C
@@ -10,7 +10,7 @@ import subprocess
 import pytest
 
 from test_device_algos_cpu import mutate, rand_seq, run_oracle_wfa
-from test_wfa_row_emulated_cpu import EXP, EmuOut
+from test_wfa_row_emulated_cpu import EMU, EmuOut
 
 _lib = None
 
@@ -18,8 +18,9 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        path = os.path.join(EXP, "libwfa_mw_emu.so")
-        srcs = [os.path.join(EXP, f) for f in ("wfa_mw_emu.cpp", "wfa_mw_fwd.h", "wfa_host_walk.h", "simt_emu.h")]
+        path = os.path.join(EMU, "libwfa_mw_emu.so")
+        srcs = [os.path.join(EMU, f) for f in ("wfa_mw_emu.cpp", "wfa_host_walk.h", "simt_emu.h")]
+        srcs.append(os.path.join(os.path.dirname(os.path.dirname(EMU)), "lexicmap_amd", "csrc", "lm_wfa_mw_fwd.h"))
         if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(s) for s in srcs):
             subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-o", path, srcs[0]])
         _lib = C.CDLL(path)

@@ -1,5 +1,5 @@
-"""experiments/wfa_row: the four-alignments-per-wavefront WFA forward pass (staged for the next round, not yet in the product)
-run on the host SIMT emulator and checked against the oracle: score, run list, coordinates and statistics of every alignment
+"""experiments/wfa_row: the four-alignments-per-wavefront WFA forward pass (measured at 1.12-1.15 x and NOT adopted; kept
+as the emulator's first user) run on the host SIMT emulator (tests/emu/simt_emu.h) and checked against the oracle: score, run list, coordinates and statistics of every alignment
 that fits its 16*NCR diagonals; what does not fit must say so (status 3), never give a different alignment."""
 import ctypes as C
 import os
@@ -13,6 +13,7 @@ from test_device_algos_cpu import mutate, rand_seq, run_oracle_wfa
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 EXP = os.path.join(os.path.dirname(HERE), "experiments", "wfa_row")
+EMU = os.path.join(HERE, "emu")   # the host SIMT emulator and the harnesses built on it
 MODES = (0, 1, 2)  # WR_EXT_MODE: how the greedy extension loops over the cells of a lane
 
 
@@ -27,8 +28,9 @@ _libs = {}
 
 def lib(mode=2):
     if mode not in _libs:
-        path = os.path.join(EXP, "libwfa_row_emu_m%d.so" % mode)
-        srcs = [os.path.join(EXP, f) for f in ("wfa_row_emu.cpp", "wfa_row_fwd.h", "simt_emu.h")]
+        path = os.path.join(EMU, "libwfa_row_emu_m%d.so" % mode)
+        srcs = [os.path.join(EMU, "wfa_row_emu.cpp"), os.path.join(EXP, "wfa_row_fwd.h"), os.path.join(EMU, "simt_emu.h"),
+                os.path.join(EMU, "wfa_host_walk.h")]
         if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(s) for s in srcs):
             subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-DWR_EXT_MODE=%d" % mode, "-o", path, srcs[0]])
         _libs[mode] = C.CDLL(path)
@@ -128,7 +130,7 @@ def test_the_emulator_itself(tmp_path):
     """cross-lane results are right, and lanes that do not meet at the same operation stop the run (SIGABRT) instead of
     returning a value - the property the CPU check of a kernel rests on"""
     exe = str(tmp_path / "simt_emu_selftest")
-    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-o", exe, os.path.join(EXP, "simt_emu_selftest.cpp")])
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-o", exe, os.path.join(EMU, "simt_emu_selftest.cpp")])
     assert subprocess.run([exe], capture_output=True, text=True).stdout.startswith("ok")
     for how in ("diverge", "early", "stuck"):
         r = subprocess.run([exe, how], capture_output=True, text=True)
