@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PROFILE_ROUND = "r03"  # profiles/<round>_<workload>_pmc_*.json: the committed counter passes roofline.traffic is read from
+PROFILE_ROUND = "r04"  # profiles/<round>_<workload>_pmc_*.json: the committed counter passes roofline.traffic is read from
 # instruction-issue peaks of the chip (MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, a wave64 VALU instruction issues over 2
 # cycles; ONE scalar unit per CU), wave-instructions per second at 2.4 GHz
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2
@@ -239,10 +239,11 @@ def _cpu_one(seq):
     return (len(rows), sum(r["aligned_length"] for r in rows), compact)
 
 
-def rows_equal_oracle(gpu_rows, oracle_rows):
+def rows_equal_oracle(gpu_rows, oracle_rows, bg_map=None):
     """HIP rows (numpy lm_hsp array of one search over the sample queries) vs the oracle's rows of the same queries, row
     for row in output order: every integer / float64 column exact, e-value within 1e-9 relative, `hits` = the oracle's
-    genome count.  Returns (equal, rows compared, first difference or None)."""
+    genome count.  bg_map: genome key in the oracle's (sample) index -> key of the same genome in the index the HIP rows
+    come from (the full bench index).  Returns (equal, rows compared, first difference or None)."""
     import numpy as np
     q = gpu_rows["query"].astype(np.int64)
     ncmp = 0
@@ -252,6 +253,8 @@ def rows_equal_oracle(gpu_rows, oracle_rows):
             return False, ncmp, "query %d: %d HIP rows vs %d oracle rows" % (qi, len(got), len(exp))
         for j, e in enumerate(exp):
             g = got[j]
+            if bg_map is not None:
+                e = (bg_map[e[0]],) + tuple(e[1:])
             for k, f in enumerate(ROW_CHECK_FIELDS):
                 if g[f] != e[k]:
                     return False, ncmp, "query %d row %d: %s = %r (HIP) vs %r (oracle)" % (qi, j, f, g[f].item(), e[k])
@@ -262,6 +265,22 @@ def rows_equal_oracle(gpu_rows, oracle_rows):
                 return False, ncmp, "query %d row %d: hits %d vs %d" % (qi, j, int(g["hits"]), e[len(ROW_CHECK_FIELDS) + 1])
             ncmp += 1
     return True, ncmp, None
+
+
+def set_input_bases(info_toml, total_bases):
+    """the e-value database size of an index (info.toml input-bases, lib-index-search.go:1918) set to that of the index it is
+    a part of"""
+    import re
+    t = open(info_toml).read()
+    t2, n = re.subn(r"(?m)^(\s*input-bases\s*=\s*)\d+", lambda m: m.group(1) + str(int(total_bases)), t)
+    if n != 1:
+        raise SystemExit("bench.py: no input-bases line in %s" % info_toml)
+    open(info_toml, "w").write(t2)
+
+
+def genome_key(g):
+    """batch << 17 | index of synthetic genome g (lm_builder.hip: 5000 genomes per batch, the reference's default)"""
+    return ((g // 5000) << 17) | (g % 5000)
 
 
 def free_port():
@@ -432,8 +451,17 @@ def main():
             tmpdir = tempfile.mkdtemp(prefix="lm_cpu_sample_")
             index_dir = os.path.join(tmpdir, "sample.lmi")
             t_s = time.time()
-            gl = [("SYN_%09d.1" % g, [("syn%09d_c1" % g, gi.fetch(g, 0, wl["genome_len"]))]) for g in members + others]
-            O.build_index(index_dir, gl, O.default_build_opt(chunks=8))
+            # ascending genome numbers (ties between genomes break on the genome key: the same relative order in both
+            # indexes), the bench index's own mask set, and its database size for the e-values: the sample index is then
+            # exactly the part of the bench index that belongs to these genomes (per-genome independence of the search,
+            # lib-index-search.go:1537-1556), which is what `full_index_rows_equal` below rests on
+            sample_genomes = sorted(members + others)
+            assert len(sample_genomes) < 5000  # one genome batch: key of the j-th sample genome = j
+            gl = [("SYN_%09d.1" % g, [("syn%09d_c1" % g, gi.fetch(g, 0, wl["genome_len"]))]) for g in sample_genomes]
+            M_ = gi.info()["masks"]
+            mp_ = la.lib().lm_index_masks(gi.h)
+            O.build_index(index_dir, gl, O.default_build_opt(chunks=8), masks=[mp_[i] for i in range(M_)])
+            set_input_bases(os.path.join(index_dir, "info.toml"), gi.info()["total_bases"])
             nsq = args.cpu_sample_queries or (64 if wl["kind"] == "reads" else 512)
             cpu_queries = []
             for i in range(nsq):
@@ -444,8 +472,8 @@ def main():
                 src = np.frombuffer(gi.fetch(g, st, L), dtype=np.uint8)
                 cpu_queries.append(("s%05d" % i, draw_query(np, synth, rng, src, wl)))
             cpu_sample_note = ("SAMPLE INDEX = the %d members of family 0 + %d genomes of other families, fetched from the "
-                               "GPU-built set and indexed by the oracle writer (%.0f s); sample queries drawn from the family, "
-                               "so hits/query match the GPU run; the full index adds only no-hit seed lookups" %
+                               "GPU-built set and indexed by the oracle writer with the bench index's masks and database size "
+                               "(%.0f s); sample queries drawn from the family, so hits/query match the GPU run" %
                                (len(members), len(others), time.time() - t_s))
             log("[rank 0] CPU sample index (%d genomes) built by the oracle in %.1f s" % (len(gl), time.time() - t_s))
     else:
@@ -651,7 +679,7 @@ def main():
         # The dominant kernel = the single kernel (one instantiation of a template counts by itself) with the largest
         # exclusive time per step; the other instantiations of its template are listed beside it, each with its own figures.
         def family(name):
-            return "k_wfa" if name.startswith(("k_wfa_lean", "k_wfa_win")) else name
+            return "k_wfa" if name.startswith(("k_wfa_lean", "k_wfa_win", "k_wfa_mw")) else name
 
         def xtime(pk):
             e = excl(pk["name"])
@@ -740,6 +768,32 @@ def main():
             "loader": loader,
             "source_hash": source_hash(),
         }
+    # The FULL-SIZE index against the oracle (the sample leg below only meets a second, small index): the search is independent
+    # per genome (lib-index-search.go:1537-1556,1743-1747), so (1) the sample queries searched on the full index with the genome
+    # whitelist = the sample genomes must give the oracle's rows on the sample index (compared after the CPU leg), and (2) the
+    # rows of those genomes inside the timed batch must be the rows of the batch searched under the same whitelist (all
+    # columns but `hits`, which counts the genomes of the whole index).
+    full_sample_rows = None
+    full_check = None
+    if rank == 0 and world == 1 and gpu_built and cpu_queries and not shard_of:
+        t_f = time.time()
+        keys = [genome_key(g) for g in sample_genomes]
+        gi.set_genome_filter(keys)
+        qb_s = gi.upload([q[1] for q in cpu_queries])
+        r_s, _ = gi.search_resident_np(qb_s)
+        full_sample_rows = r_s.copy()
+        gi.free_batch(qb_s)
+        r_b, _ = gi.search_resident_np(qb)
+        gi.set_genome_filter(None)
+        sel = rows_np[np.isin(rows_np["batch_genome"], np.array(keys, dtype=np.uint64))]
+        names = [n for n in rows_np.dtype.names if n not in ("hits", "genome_id", "seq_id", "cigar", "qseq", "sseq", "align")
+                 and not n.startswith("pad")]
+        same_n = len(sel) == len(r_b)
+        same = same_n and all(np.array_equal(sel[n], r_b[n]) for n in names)
+        full_check = dict(batch_rows_of_sample_genomes=int(len(sel)), batch_rows_under_whitelist=int(len(r_b)),
+                          batch_rows_equal=bool(same), seconds=round(time.time() - t_f, 2))
+        log("[rank 0] full-index check: %s" % full_check)
+        del r_b, sel
     gi.free_batch(qb)
     # the bench index and its scratch slabs leave HBM before the sample leg: a second handle beside a resident 137-GB index
     # gets a sliver of scratch and searches in tiny chunks (it made the like-for-like number 5x too low)
@@ -776,6 +830,22 @@ def main():
                     if not eq:
                         cb["sample_rows_first_difference"] = diff
                         sample_mismatch = diff
+                    if full_sample_rows is not None:
+                        # the bench's own full-size index, restricted to the sample genomes, against the oracle's sample rows
+                        bg_map = {j: genome_key(g) for j, g in enumerate(sample_genomes)}
+                        eq_f, ncmp_f, diff_f = rows_equal_oracle(full_sample_rows, oracle_rows, bg_map)
+                        cb["full_index_rows_equal"] = bool(eq_f and full_check["batch_rows_equal"])
+                        cb["full_index_rows"] = int(ncmp_f)
+                        cb["full_index_check"] = dict(full_check, sample_queries_on_full_index_equal_oracle=bool(eq_f),
+                                                      how="sample queries searched on the FULL bench index under the genome whitelist "
+                                                          "of the sample genomes vs the oracle on the sample index (same masks, same "
+                                                          "database size), row for row; and the timed batch's rows of those genomes "
+                                                          "vs the batch searched under the whitelist")
+                        if not eq_f:
+                            cb["full_index_rows_first_difference"] = diff_f
+                            sample_mismatch = sample_mismatch or ("full index: " + diff_f)
+                        elif not full_check["batch_rows_equal"]:
+                            sample_mismatch = sample_mismatch or "full index: the timed batch's rows of the sample genomes differ from the whitelisted search"
                     g2.free_batch(qb2)
                     g2.close()
                 except Exception as e:

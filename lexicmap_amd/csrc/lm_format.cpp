@@ -191,6 +191,15 @@ std::string load_index(const std::string &dir, int shard_rank, int shard_count, 
         status = 2;
         return "index main versions do not match";
     }
+    if (out.minor_version < 5) {
+        // lib-index-search.go:1212-1215: an index older than format 3.5 is searched with lexichash's
+        // MaskKnownDistinctPrefixesWithStrandBias, which lives in the un-vendored lexichash module and is not restated here:
+        // searching it with the 3.5 masking would silently return other seeds than the reference.  Refused, not guessed.
+        status = 2;
+        return "index format 3." + std::to_string(out.minor_version) + " (minor-version < 5) needs the strand-biased masking of "
+               "lib-index-search.go:1212-1215 (MaskKnownDistinctPrefixesWithStrandBias), which this build does not implement: "
+               "re-create the index with lexicmap >= v0.5.0 (" + dir + ")";
+    }
     out.total_bases = toml_int(text, "input-bases", 0);
     out.contig_interval = (int)toml_int(text, "contig-interval", 1000);
     out.genome_batches = (int)toml_int(text, "genome-batches", 1);

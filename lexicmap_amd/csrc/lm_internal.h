@@ -293,6 +293,7 @@ struct lm_tune {
     int pa_seg_by_group = 1; // candidate segments by task group + XCD-local k_pa_search (LM_PA_SEG_BY_WAVE=1: by wavefront)
     int wfa_resident_pct = 100; // LM_WFA_RESIDENT_PCT: share of the CUs' wavefront slots / LDS the persistent WFA kernels take
     FILE *wfa_dump = nullptr; // LM_DEBUG_WFA_DUMP=<file>: one line per WFA problem and pass (width, status, lengths, estimate, score)
+    FILE *wfa_waves = nullptr; // LM_DEBUG_WFA_WAVES=<file>: one JSON line per k_wfa_lean launch: when its wavefronts started / ended, busy share
     int wfa_mw = 1;          // 512 / 1024-diagonal passes by a workgroup of four wavefronts per alignment (LM_WFA_MW=0: one wavefront)
     int pa_chain_ring = 1;   // Chainer2 DP with the recent anchors in an LDS ring (LM_PA_CHAIN_RING=0: through global memory)
     int wfa_serial = 0;      // LM_WFA_SERIAL=1: the WFA length classes one after the other (exclusive kernel timings)
@@ -300,6 +301,7 @@ struct lm_tune {
     lm_tune() {
         wfa_serial = getenv("LM_WFA_SERIAL") != nullptr;
         if (const char *e = getenv("LM_DEBUG_WFA_DUMP")) wfa_dump = fopen(e, "a");
+        if (const char *e = getenv("LM_DEBUG_WFA_WAVES")) wfa_waves = fopen(e, "a");
         if (const char *e = getenv("LM_WFA_RESIDENT_PCT")) wfa_resident_pct = std::max(5, std::min(100, atoi(e)));
         if (const char *e = getenv("LM_WFA_FIRST_NC")) {
             int v[LM_WFA_CLASSES];

@@ -2490,7 +2490,8 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                                                   int64_t ntodo, int32_t *__restrict__ hdr_pool, int64_t hdr_stride,
                                                   uint8_t *__restrict__ arena_pool, int64_t arena_stride,
                                                   uint64_t *__restrict__ ops_pool, unsigned int *__restrict__ queue,
-                                                  int seq_words, int want_ops, WfaOut *__restrict__ out) {
+                                                  int seq_words, int want_ops, WfaOut *__restrict__ out,
+                                                  unsigned long long *__restrict__ dbg) {
     static_assert(NC == 1 || NC == 2 || NC == 4 || NC == 8 || NC == 16, "1, 2, 4, 8 or 16 cells per lane");
     constexpr int W = 64 * NC;
     // All penalties are even (x=4, o+e=8, e=2): only even scores have wavefronts, so the ring holds the last five even
@@ -2524,6 +2525,11 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
         __builtin_amdgcn_s_setprio(2);
     else if (NC >= 4)
         __builtin_amdgcn_s_setprio(1);
+    // LM_DEBUG_WFA_WAVES (dbg != nullptr): per resident wavefront {first pop, exit, problems, time in the score loops, longest
+    // problem, its queue position} on the 100-MHz wall clock - where a launch's tail comes from
+    unsigned long long d_t0 = 0, d_fwd = 0, d_max = 0, d_ts = 0;
+    unsigned int d_n = 0, d_maxx = 0;
+    if (dbg) d_t0 = wall_clock64();
     if (lane == 0) sh_x = atomicAdd(queue, 1u);
     while (true) {
         LDS_WAVE_SYNC();
@@ -2533,6 +2539,7 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
         if ((int64_t)x >= ntodo) break;
         const int64_t i = todo ? todo[x] : (int64_t)x;
         if (i < 0 || i >= n) break; // malformed work list
+        if (dbg) d_ts = wall_clock64();
         const WfaIn w = in[i];
         const int plen = w.qlen, tlen = w.tlen;
         const int ak = tlen - plen;
@@ -2900,6 +2907,7 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
         }
         if (status == 0 && __ballot(bad) != 0ull) status = 3; // not plain ACGT: the byte-comparing kernel takes it
         __syncthreads(); // the backtrace reads what every lane stored to global memory
+        if (dbg) d_fwd += wall_clock64() - d_ts;
         WfaOut o;
         o.blast_score = 0;
         if (status != 0) {
@@ -2928,6 +2936,23 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
             out[i] = o;
             sh_x = atomicAdd(queue, 1u);
         }
+        if (dbg) {
+            const unsigned long long dt = wall_clock64() - d_ts;
+            d_n++;
+            if (dt > d_max) {
+                d_max = dt;
+                d_maxx = x;
+            }
+        }
+    }
+    if (dbg && lane == 0) {
+        unsigned long long *d = dbg + 6 * (size_t)blockIdx.x;
+        d[0] = d_t0;
+        d[1] = wall_clock64();
+        d[2] = d_n;
+        d[3] = d_fwd;
+        d[4] = d_max;
+        d[5] = d_maxx;
     }
 }
 
@@ -3101,7 +3126,7 @@ void launch_extend(hipStream_t st, const HspIn *hsps, int64_t n, const uint8_t *
 }
 // the kernel instantiations: ring width x (whole sequences in LDS | sliding windows)
 typedef void (*WfaLeanFn)(const WfaIn *, int64_t, const int32_t *, int64_t, int32_t *, int64_t, uint8_t *, int64_t, uint64_t *,
-                          unsigned int *, int, int, WfaOut *);
+                          unsigned int *, int, int, WfaOut *, unsigned long long *);
 static WfaLeanFn wfa_lean_fn(int nc, bool win) {
     switch (nc) {
     case 16: return win ? k_wfa_lean<16, true> : k_wfa_lean<16, false>;
@@ -3123,9 +3148,9 @@ int wfa_resident_blocks(int device, int seq_words, int nc, bool win) {
 }
 void launch_wfa(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks,
                 int32_t *hdr_pool, int64_t hdr_stride, uint8_t *arena_pool, int64_t arena_stride, uint64_t *ops_pool,
-                unsigned int *queue, int seq_words, int want_ops, WfaOut *out, int nc, bool win) {
+                unsigned int *queue, int seq_words, int want_ops, WfaOut *out, int nc, bool win, unsigned long long *dbg) {
     hipLaunchKernelGGL(wfa_lean_fn(nc, win), dim3(nblocks), dim3(64), wfa_dyn_lds(seq_words, win), st, in, n, todo, ntodo, hdr_pool,
-                       hdr_stride, arena_pool, arena_stride, ops_pool, queue, seq_words, want_ops, out);
+                       hdr_stride, arena_pool, arena_stride, ops_pool, queue, seq_words, want_ops, out, dbg);
 }
 void launch_wfa_wide(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int32_t *hdr_pool,
                      int32_t *arena_pool, uint64_t *ops_pool, WfaOut *out) {

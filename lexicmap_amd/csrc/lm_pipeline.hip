@@ -1322,6 +1322,7 @@ struct AlignCtx {
         hipStream_t st = nullptr;
         DBuf<int32_t> todo, hdr_pool, arena_pool;
         DBuf<unsigned int> queue;
+        DBuf<unsigned long long> dbg; // LM_DEBUG_WFA_WAVES
         DBuf<uint8_t> tmp;
         ~LeanCtx() {
             if (st) (void)hipStreamDestroy(st);
@@ -1806,6 +1807,12 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
         lc.arena_pool.ensure((size_t)(bytes / 4) * nblocks + 16);
         lc.todo.ensure((size_t)m);
         lc.queue.ensure(1);
+        const bool wave_dbg = ix->tune.wfa_waves != nullptr && !mw;
+        auto items_at = [&](long long x) { return items[(size_t)x]; };
+        if (wave_dbg) {
+            lc.dbg.ensure((size_t)nblocks * 6);
+            HIPCHK(hipMemsetAsync(lc.dbg.p, 0, sizeof(unsigned long long) * 6 * nblocks, S(ix)));
+        }
         HIPCHK(hipMemcpyAsync(lc.todo.p, items.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice, S(ix)));
         HIPCHK(hipMemsetAsync(lc.queue.p, 0, sizeof(unsigned int), S(ix)));
         {
@@ -1819,9 +1826,51 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
                               a.ops_pool.p, lc.queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc, use_win);
             else
                 launch_wfa(S(ix), a.wfa_in.p, n, lc.todo.p, m, nblocks, lc.hdr_pool.p, entries * 2, (uint8_t *)lc.arena_pool.p, bytes,
-                           a.ops_pool.p, lc.queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc, use_win);
+                           a.ops_pool.p, lc.queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc, use_win, wave_dbg ? lc.dbg.p : nullptr);
         }
         sync(ix);
+        if (wave_dbg) { // where the launch's time went, wavefront by wavefront (100-MHz wall clock)
+            std::vector<unsigned long long> d;
+            d2h(ix, d, lc.dbg.p, (size_t)nblocks * 6);
+            sync(ix);
+            unsigned long long t_first = ~0ull, t_last = 0;
+            for (int b = 0; b < nblocks; b++)
+                if (d[6 * b + 1]) {
+                    t_first = std::min(t_first, d[6 * b]);
+                    t_last = std::max(t_last, d[6 * b + 1]);
+                }
+            std::vector<double> ends, starts;
+            double busy = 0, fwd = 0, worst = 0;
+            long long items = 0, worst_x = -1;
+            for (int b = 0; b < nblocks; b++) {
+                if (!d[6 * b + 1]) continue;
+                starts.push_back((double)(d[6 * b] - t_first) * 1e-5);
+                ends.push_back((double)(d[6 * b + 1] - t_first) * 1e-5);
+                busy += (double)(d[6 * b + 1] - d[6 * b]) * 1e-5;
+                fwd += (double)d[6 * b + 3] * 1e-5;
+                items += (long long)d[6 * b + 2];
+                if ((double)d[6 * b + 4] * 1e-5 > worst) {
+                    worst = (double)d[6 * b + 4] * 1e-5;
+                    worst_x = (long long)d[6 * b + 5];
+                }
+            }
+            std::sort(ends.begin(), ends.end());
+            std::sort(starts.begin(), starts.end());
+            const size_t nw = ends.size();
+            auto pct = [&](const std::vector<double> &v, double q) { return v.empty() ? 0.0 : v[std::min(v.size() - 1, (size_t)(q * (double)v.size()))]; };
+            const double span = nw ? (double)(t_last - t_first) * 1e-5 : 0;
+            std::lock_guard<std::mutex> l(fb_mu);
+            fprintf(ix->tune.wfa_waves, "{\"diagonals\": %d, \"win\": %d, \"serial\": %d, \"problems\": %lld, \"waves_launched\": %d, \"waves_ran\": %zu, \"span_ms\": %.3f, "
+                    "\"mean_busy_ms\": %.3f, \"busy_over_span\": %.3f, \"fwd_share\": %.3f, \"start_p50\": %.3f, \"start_p99\": %.3f, \"start_max\": %.3f, "
+                    "\"end_p10\": %.3f, \"end_p50\": %.3f, \"end_p90\": %.3f, \"end_p99\": %.3f, \"longest_problem_ms\": %.3f, \"its_queue_pos\": %lld, "
+                    "\"its_qlen\": %d, \"its_tlen\": %d, \"its_div\": %.3f, \"problems_done\": %lld}\n",
+                    64 * nc, use_win ? 1 : 0, ix->tune.wfa_serial ? 1 : 0, (long long)m, nblocks, nw, span, nw ? busy / (double)nw : 0.0, span > 0 ? busy / ((double)nw * span) : 0.0,
+                    busy > 0 ? fwd / busy : 0.0, pct(starts, 0.5), pct(starts, 0.99), starts.empty() ? 0.0 : starts.back(), pct(ends, 0.1), pct(ends, 0.5),
+                    pct(ends, 0.9), pct(ends, 0.99), worst, worst_x, worst_x >= 0 && worst_x < m ? in[items_at(worst_x)].qlen : 0,
+                    worst_x >= 0 && worst_x < m ? in[items_at(worst_x)].tlen : 0,
+                    worst_x >= 0 && worst_x < m && est_div ? (double)(*est_div)[items_at(worst_x)] : -1.0, items);
+            fflush(ix->tune.wfa_waves);
+        }
         // this pass's results: the records of its items (other classes write theirs into the same array meanwhile)
         std::vector<WfaOut> tmp;
         d2h(ix, tmp, a.wfa_out.p, (size_t)n);

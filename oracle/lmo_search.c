@@ -117,6 +117,9 @@ lmo_index *lmo_index_open(const char *dir, const lmo_search_opt *opt) {
     text[nr] = 0;
     fclose(f);
     if (toml_int(text, "main-version", -1) != 3) return NULL; /* :290-292 */
+    /* :1212-1215: format < 3.5 is masked with MaskKnownDistinctPrefixesWithStrandBias (un-vendored lexichash module, not
+     * restated): such an index is refused rather than searched with the wrong masking */
+    if (toml_int(text, "minor-version", 0) < 5) return NULL;
     lmo_index *idx = (lmo_index *)calloc(1, sizeof *idx);
     idx->dir = strdup(dir);
     idx->opt = *opt;

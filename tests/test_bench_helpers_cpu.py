@@ -61,12 +61,34 @@ def test_rows_equal_oracle_accepts_equal_rows_and_names_the_first_difference():
     assert not bench.rows_equal_oracle(a, exp2)[0]
 
 
+def test_rows_equal_oracle_translates_genome_keys_between_a_sample_index_and_the_full_index(tmp_path):
+    """the full-index check: the oracle's rows carry the genome keys of the SAMPLE index (j-th genome = j), the HIP rows those
+    of the full bench index; info.toml's database size is set to the full index's"""
+    import bench
+    a = _rows(12)
+    exp = _oracle_of(a)                      # keys as the sample index numbers them
+    keymap = {k: bench.genome_key(1001 * k) for k in range(50)}
+    b = a.copy()
+    b["batch_genome"] = [keymap[int(k)] for k in a["batch_genome"]]
+    assert not bench.rows_equal_oracle(b, exp)[0]
+    ok, n, diff = bench.rows_equal_oracle(b, exp, keymap)
+    assert ok and n == 12 and diff is None
+    assert bench.genome_key(4999) == 4999 and bench.genome_key(5000) == 1 << 17 and bench.genome_key(99_999) == (19 << 17) | 4999
+    t = tmp_path / "info.toml"
+    t.write_text("k = 31\ninput-bases = 1234\nmasks = 20000\n")
+    bench.set_input_bases(str(t), 200_000_000_000)
+    assert t.read_text() == "k = 31\ninput-bases = 200000000000\nmasks = 20000\n"
+
+
 def test_rocprof_kernel_names_match_the_names_bench_reports():
     import summarize_rocprof as S
     assert S.short("void lm::k_wfa_lean<2, false>(lm::WfaIn const*, long)") == "k_wfa_lean"
     assert S.short("void lm::k_wfa_lean<4, true>(lm::WfaIn const*, long)") == "k_wfa_win256"
     assert S.short("void lm::k_wfa_lean<8, (bool)0>(x)") == "k_wfa_lean512"
     assert S.short("void lm::k_wfa_lean<16, (bool)1>(x)") == "k_wfa_win1024"
+    assert S.short("void lm::k_wfa_mw<2, false>(lm::WfaIn const*, long)") == "k_wfa_mw512"
+    assert S.short("void lm::k_wfa_mw<4, (bool)1>(x)") == "k_wfa_mww1024"
+    assert S.short("void lm::k_pa_chain_wave<true>(unsigned long const*, ...)") == "k_pa_chain"
     assert S.short("lm::k_pa_search(lm::DevIndexView, ...)") == "k_pa_search"
     assert S.short("void rocprim::detail::radix_sort_onesweep_kernel<...>").startswith("rocprim:")
 

@@ -124,3 +124,30 @@ def test_batch_split_into_parts_gives_the_same_rows(lr_index, lr_queries, monkey
     gi.close()
     assert got3 == base and got4 == base
     assert st0["rows"] == st3["rows"] and st0["chains"] == st3["chains"]
+
+
+def test_rows_do_not_depend_on_which_device_implementation_of_a_stage_runs(lr_index, lr_queries, monkeypatch):
+    """LM_WFA_MW (512 / 1024-diagonal WFA passes: a workgroup of four wavefronts or one wavefront per alignment) and
+    LM_PA_CHAIN_RING (Chainer2 DP with the recent anchors in LDS or through global memory) choose between two kernels that
+    must agree to the byte: the rows of the long-read fixture (equal to the oracle's by the first test) with each switch off"""
+    la = _la()
+    d, _ = lr_index
+    seqs = [q[1] for q in lr_queries]
+    gi = la.Index(d)
+    gi.profile(True)
+    base, st0 = gi.search(seqs)
+    ran = {p["name"] for p in gi.profile_get() if p["launches"] > 0}
+    gi.close()
+    assert any(n.startswith("k_wfa_mw") for n in ran), ran   # the fixture does reach the wide passes
+    for var in ("LM_WFA_MW", "LM_PA_CHAIN_RING"):
+        monkeypatch.setenv(var, "0")
+        gi = la.Index(d)      # the switches are read once per handle
+        gi.profile(True)
+        got, st1 = gi.search(seqs)
+        ran1 = {p["name"] for p in gi.profile_get() if p["launches"] > 0}
+        gi.close()
+        monkeypatch.delenv(var)
+        assert got == base, var
+        assert st0["rows"] == st1["rows"] and st0["chains"] == st1["chains"] and st0["pa_anchors"] == st1["pa_anchors"]
+        if var == "LM_WFA_MW":
+            assert not any(n.startswith("k_wfa_mw") for n in ran1), ran1

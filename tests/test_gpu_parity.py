@@ -697,3 +697,17 @@ def test_index_format_variants_and_broken_files(small_index, queries, tmp_path):
         open(path, "wb").write(data[:cut])
         with pytest.raises(RuntimeError, match="broken|invalid"):
             la.Index(bad2)
+    # an index of format 3.4 or older: the reference masks its queries with MaskKnownDistinctPrefixesWithStrandBias
+    # (lib-index-search.go:1212-1215), which is not restated here: refused by the library AND by the oracle, never searched
+    # with the 3.5 masking
+    import re
+    for repl in ("minor-version = 4", ""):
+        old = str(tmp_path / ("old%d.lmi" % len(repl)))
+        shutil.copytree(d, old)
+        t = open(os.path.join(old, "info.toml")).read()
+        assert "minor-version = 5" in t
+        open(os.path.join(old, "info.toml"), "w").write(re.sub(r"minor-version = 5\n", repl + "\n" if repl else "", t))
+        with pytest.raises(RuntimeError, match="1212-1215"):
+            la.Index(old)
+        with pytest.raises(Exception):
+            O.Index(old)

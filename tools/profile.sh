@@ -3,7 +3,7 @@
 # PMC passes (FETCH_SIZE, WRITE_SIZE, SQ instruction mix / waits) - counters are never collected together with tracing.
 # Every summary is stamped with the hash of the library sources (bench.py source_hash): bench.py refuses PMC passes taken
 # on other sources.   usage: tools/profile.sh <workload> [steps] [extra bench args...]
-P=r03
+P=r04
 W=${1:-c3}
 STEPS=${2:-2}
 shift; shift

@@ -19,6 +19,11 @@ def short(name):
             if win:
                 return "k_wfa_win" + {"1": "64", "2": "128", "4": "256", "8": "512", "16": "1024"}.get(m.group(2), m.group(2))
             return "k_wfa_lean" + {"1": "64", "2": "", "4": "256", "8": "512", "16": "1024"}.get(m.group(2), m.group(2))
+        if m.group(1) == "k_wfa_mw" and m.group(2):  # k_wfa_mw<NCW, WIN>: four wavefronts per alignment, 256 * NCW diagonals
+            win = (m.group(3) or "").replace("(bool)", "") in ("true", "1")
+            return ("k_wfa_mww" if win else "k_wfa_mw") + {"2": "512", "4": "1024"}.get(m.group(2), m.group(2))
+        if m.group(1) == "k_pa_chain_wave":
+            return "k_pa_chain"
         return m.group(1)
     m = re.search(r"(radix_sort_\w+|segmented_radix_sort\w*|scan_impl|reduce_by_key\w*|merge_sort\w*|init_lookback\w*)", name)
     if m:
