@@ -84,6 +84,10 @@ def parse():
     p.add_argument("--cpu-sample-genomes", type=int, default=0,
                    help="genomes of the CPU-baseline sample index (default: one whole family + 16 genomes of other families)")
     p.add_argument("--cpu-sample-queries", type=int, default=0)
+    p.add_argument("--ab", default="", help="development: after the timed steps, time the same resident batch under other "
+                   "experiment switches, e.g. 'LM_WFA_R16=0|LM_WFA_MW=0 LM_WFA_R16=0' (variants separated by |, one warm-up + "
+                   "--ab-steps steps each; reported under 'ab', not part of the metric)")
+    p.add_argument("--ab-steps", type=int, default=2)
     return p.parse_args()
 
 
@@ -560,8 +564,11 @@ def main():
     t0 = time.time()
     stats = None
     rows_np = None
+    step_ms = []
     for _ in range(args.steps):
+        t_s0 = time.time()
         rows_np, stats = step()
+        step_ms.append(round((time.time() - t_s0) * 1e3, 1))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -585,6 +592,28 @@ def main():
         prof_x = {p["name"]: p for p in gi.profile_get()}
         gi.profile(False)
         gi.profile_exclusive(False)
+    ab = None
+    if args.ab and world == 1:
+        ab = []
+        for variant in args.ab.split("|"):
+            kv = dict(x.split("=", 1) for x in variant.split())
+            saved = {k: os.environ.get(k) for k in kv}
+            os.environ.update(kv)
+            gi.tuning_reload()
+            step()
+            ts = []
+            for _ in range(args.ab_steps):
+                t_s0 = time.time()
+                r_ab, _st = step()
+                ts.append(round((time.time() - t_s0) * 1e3, 1))
+            ab.append(dict(env=kv, step_ms=ts, rows=int(len(r_ab))))
+            log("[rank 0] A/B %s: %s ms per step, %d rows" % (variant, ts, len(r_ab)))
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        gi.tuning_reload()
     try:
         import resource
         log("[rank %d] peak host RSS %.1f GB after %d steps" % (rank, resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1048576.0,
@@ -733,7 +762,7 @@ def main():
         result = {
             "metric": "queries/sec (lexicmap search hot path, seed index HBM-resident)",
             "value": round(value, 3), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(step_s * 1e3, 3), "higher_is_better": True,
+            "ms_per_step": round(step_s * 1e3, 3), "step_ms": step_ms, "higher_is_better": True,
             # strong: the batch (and with index sharding the genome set) is fixed as N grows; weak: own batch per GPU
             "scaling": "weak" if weak else "strong",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
@@ -766,6 +795,7 @@ def main():
             "rocprim_calls": prims,
             "sharding_model": shard_model,
             "loader": loader,
+            "ab": ab,
             "source_hash": source_hash(),
         }
     # The FULL-SIZE index against the oracle (the sample leg below only meets a second, small index): the search is independent

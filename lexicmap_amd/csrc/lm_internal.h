@@ -54,8 +54,18 @@ struct ScratchArena {
     int64_t slab_bytes = 0, live_bytes = 0, slab_allocs = 0;
     static constexpr size_t ALIGN = 4096;
     ~ScratchArena() { trim(); }
+    // Requests are rounded up to a coarse geometric grid (2^k x {1, 1.25, 1.5, 1.75}): the pools of a search are re-cut at every
+    // batch part with sizes that follow the data (a pool per resident wavefront x the longest problem's expected score), and a
+    // request a few per cent above every block freed so far would otherwise get a NEW slab from the device - hipMalloc of
+    // several GB clears pages for seconds (measured: 1-3 s steps when the ten WFA chains of a round each re-sized their pools)
+    static size_t grid(size_t b) {
+        size_t p = ALIGN;
+        while (p * 2 <= b) p *= 2;
+        const size_t q = p / 4;
+        return (b + q - 1) / q * q;
+    }
     void *alloc(size_t bytes) { // throws DeviceOOM
-        bytes = (bytes + ALIGN - 1) / ALIGN * ALIGN;
+        bytes = grid((bytes + ALIGN - 1) / ALIGN * ALIGN);
         std::lock_guard<std::mutex> l(mu);
         for (int pass = 0; pass < 2; pass++) {
             int bs = -1;
@@ -294,6 +304,8 @@ struct lm_tune {
     int wfa_resident_pct = 100; // LM_WFA_RESIDENT_PCT: share of the CUs' wavefront slots / LDS the persistent WFA kernels take
     FILE *wfa_dump = nullptr; // LM_DEBUG_WFA_DUMP=<file>: one line per WFA problem and pass (width, status, lengths, estimate, score)
     FILE *wfa_waves = nullptr; // LM_DEBUG_WFA_WAVES=<file>: one JSON line per k_wfa_lean launch: when its wavefronts started / ended, busy share
+    int wfa_ak_margin = 40;  // LM_WFA_AK_MARGIN: a problem starts at the ring that holds |tlen - qlen| + margin diagonals (-1: at the class's width)
+    int wfa_r16 = 1;         // 16-bit ring cells in the whole-sequence WFA kernels of 128 / 256 diagonals (LM_WFA_R16=0: 32-bit)
     int wfa_mw = 1;          // 512 / 1024-diagonal passes by a workgroup of four wavefronts per alignment (LM_WFA_MW=0: one wavefront)
     int pa_chain_ring = 1;   // Chainer2 DP with the recent anchors in an LDS ring (LM_PA_CHAIN_RING=0: through global memory)
     int wfa_serial = 0;      // LM_WFA_SERIAL=1: the WFA length classes one after the other (exclusive kernel timings)
@@ -313,6 +325,8 @@ struct lm_tune {
             for (int c = 0; c < LM_WFA_CLASSES && e[c]; c++) wfa_win[c] = e[c] == '1';
         no_pipeline = getenv("LM_NO_PIPELINE") != nullptr;
         if (const char *e = getenv("LM_WFA_MW")) wfa_mw = atoi(e) != 0;
+        if (const char *e = getenv("LM_WFA_R16")) wfa_r16 = atoi(e) != 0;
+        if (const char *e = getenv("LM_WFA_AK_MARGIN")) wfa_ak_margin = atoi(e);
         if (const char *e = getenv("LM_PA_CHAIN_RING")) pa_chain_ring = atoi(e) != 0;
         if (getenv("LM_CHAIN1_LANES")) chain1_wave = 0;
         if (const char *e = getenv("LM_PA_SEG_BY_WAVE")) pa_seg_by_group = atoi(e) ? 0 : 1;

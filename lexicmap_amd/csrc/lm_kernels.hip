@@ -2251,19 +2251,21 @@ __device__ __forceinline__ unsigned long long rotr64(unsigned long long x, int r
 // coalesced copy (their bytes are contiguous), so one global round trip serves ~10-15 operations instead of two round
 // trips per operation.
 #define BT_WIN 4032 /* bytes of backtrace rows held in LDS during the walk (BtLds fits the 128-diagonal ring it reuses) */
-struct BtLds {
-    uint8_t win[BT_WIN + 32];
+template <int BW> struct BtLdsT { // BW: multiple of 16
+    uint8_t win[BW + 32];
     int32_t lo[64], base[64];
 };
+typedef BtLdsT<BT_WIN> BtLds;
 
 // Returns the number of edit operations written (descending from opseq_end), or -1 on overflow / inconsistency.
 // ops bytes: bits 0-1 = 0 X, 1 I, 2 D; bit 2 = the cell the operation arrives at is an M cell (extend after it).
+template <int BW>
 __device__ __forceinline__ int bt_walk(const int32_t *__restrict__ hdr2, const uint8_t *__restrict__ bt, int s_final, int ak,
-                                       uint8_t *__restrict__ opseq_end, int64_t opseq_room, BtLds *L, int lane) {
+                                       uint8_t *__restrict__ opseq_end, int64_t opseq_room, BtLdsT<BW> *L, int lane) {
     int score = s_final, k = ak, matrix = 0;
     int64_t nops = 0;
     while (score > 0) {
-        // window: rows of scores score, score-2, ... as far down as BT_WIN bytes reach (at most 64 rows)
+        // window: rows of scores score, score-2, ... as far down as BW bytes reach (at most 64 rows)
         const int top = score >> 1;
         int32_t lo_j = 0, base_j = 0;
         if (top - lane >= 0) {
@@ -2271,7 +2273,7 @@ __device__ __forceinline__ int bt_walk(const int32_t *__restrict__ hdr2, const u
             base_j = hdr2[2 * (top - lane) + 1];
         }
         const int32_t top_end = __builtin_amdgcn_readfirstlane(hdr2[2 * (top + 1) + 1]);
-        const unsigned long long fits = __ballot(top - lane >= 0 && top_end - base_j <= BT_WIN);
+        const unsigned long long fits = __ballot(top - lane >= 0 && top_end - base_j <= BW);
         // rows are contiguous and in score order: the lanes that fit form a prefix
         const unsigned long long nfit = ~fits;
         const int nrows = nfit ? __ffsll((long long)nfit) - 1 : 64;
@@ -2485,7 +2487,7 @@ __device__ __forceinline__ void bt_replay(const uint8_t *__restrict__ opseq, int
 // resident wavefronts of a CU share, has little else to do than the loop control). No global loads inside the score loop: both sequences are 2-bit
 // packed in LDS. Persistent wavefronts: each workgroup (one wave) owns a private header/arena region and pops problems
 // from a queue ordered by decreasing expected cost. Results are identical to lm_wfa_align.
-template <int NC, bool WIN>
+template <int NC, bool WIN, typename RT>
 __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, int64_t n, const int32_t *__restrict__ todo,
                                                   int64_t ntodo, int32_t *__restrict__ hdr_pool, int64_t hdr_stride,
                                                   uint8_t *__restrict__ arena_pool, int64_t arena_stride,
@@ -2498,12 +2500,24 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
     // M scores (s, s-2, .. s-8) and the last two I / D scores, and the score loop steps by 2. (Odd scores are empty
     // wavefronts in the reference and the backtrace never visits them.)
     // ring of wavefront rows; the backtrace walk reuses the same LDS (the ring is dead by then) for its row window
-    constexpr int RING_BYTES = 9 * W * 4 > (int)sizeof(BtLds) ? 9 * W * 4 : (int)sizeof(BtLds);
+    // RT = int16_t: the ring holds 16-bit offsets - half the LDS per wavefront, and LDS is what bounds the number of resident
+    // wavefronts of the short classes (<= 8 kb: 18 -> 24 per CU) whose dependent LDS / DPP chains need them to fill the
+    // issue slots.  Valid offsets are <= tlen; the invalid ones inside a range are RNULL + j or tlen + 1 + j with j <= s / 2
+    // (an I cell grows by one per score step: I[s][k] = max(M[s-8][k-1], I[s-2][k-1]) + 1; M cells are sanitised, D cells do
+    // not grow), so with tlen <= 12000 and s < 24000 (checked below: beyond, status 3 hands the problem to the 32-bit pass)
+    // nothing wraps, every comparison has the outcome it has with 32-bit cells, and the backtrace bytes are the same.
+    constexpr bool R16 = sizeof(RT) == 2;
+    static_assert(!R16 || (NC <= 4 && !WIN), "16-bit ring: whole-sequence kernels up to 256 diagonals");
+    constexpr int RNULL = R16 ? -16384 : LM_NULL_OFF;
+    constexpr int RING_CELLS = 9 * W * (int)sizeof(RT);
+    constexpr int BW = RING_CELLS >= (int)sizeof(BtLds) ? BT_WIN : ((RING_CELLS - 512 - 32) & ~15);
+    static_assert(BW >= 2 * W, "the walk's window holds at least two rows");
+    constexpr int RING_BYTES = RING_CELLS > (int)sizeof(BtLdsT<BW>) ? RING_CELLS : (int)sizeof(BtLdsT<BW>);
     __shared__ __attribute__((aligned(16))) uint8_t ring_raw[RING_BYTES];
-    int32_t(*rM)[W] = (int32_t(*)[W])ring_raw;
-    int32_t(*rI)[W] = (int32_t(*)[W])(ring_raw + 5 * W * 4);
-    int32_t(*rD)[W] = (int32_t(*)[W])(ring_raw + 7 * W * 4);
-    BtLds &btl = *(BtLds *)ring_raw;
+    RT(*rM)[W] = (RT(*)[W])ring_raw;
+    RT(*rI)[W] = (RT(*)[W])(ring_raw + 5 * W * sizeof(RT));
+    RT(*rD)[W] = (RT(*)[W])(ring_raw + 7 * W * sizeof(RT));
+    BtLdsT<BW> &btl = *(BtLdsT<BW> *)ring_raw;
     __shared__ unsigned int sh_x;
     // WIN: the two sequence windows; otherwise both whole packed sequences in dynamic LDS (seq_words + 1 words each)
     __shared__ uint32_t qwin_buf[WIN ? WFA_WINW + 2 : 1], twin_buf[WIN ? WFA_WINW + 2 : 1];
@@ -2578,9 +2592,9 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
 #pragma unroll
         for (int c = 0; c < NC; c++) {
 #pragma unroll
-            for (int r = 0; r < 5; r++) rM[r][lane + 64 * c] = LM_NULL_OFF;
+            for (int r = 0; r < 5; r++) rM[r][lane + 64 * c] = RNULL;
 #pragma unroll
-            for (int r = 0; r < 2; r++) rI[r][lane + 64 * c] = rD[r][lane + 64 * c] = LM_NULL_OFF;
+            for (int r = 0; r < 2; r++) rI[r][lane + 64 * c] = rD[r][lane + 64 * c] = RNULL;
         }
         // valid ranges by age in even scores: mlo[a]..mhi[a] is M[s-2a]. An empty range is (E_LO, E_HI): far apart, so
         // min / max unions and the unsigned range tests below need no "is it empty" cases
@@ -2597,6 +2611,7 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
             ihi[a] = dhi[a] = E_HI;
         }
         if (max_score < 1 || arena_cap < 1) status = 1;
+        if (R16 && (plen > 12000 || tlen > 12000)) status = 3; // (see RT above)
         mlo[0] = mhi[0] = 0;
         LDS_WAVE_SYNC();
         if (lane == 0) rM[0][koff & (W - 1)] = 0;
@@ -2643,7 +2658,7 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                         kc[c] = k;
                         jc[c] = j;
                         inr[c] = false;
-                        off[c] = LM_NULL_OFF;
+                        off[c] = RNULL;
                         if (!chunk_on(cmx, c, mlo[0], mhi[0])) continue;
                         inr[c] = (uint32_t)(k - mlo[0]) <= (uint32_t)(mhi[0] - mlo[0]);
                         int32_t o = rM[ms][slot];
@@ -2674,7 +2689,7 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                         kc[c] = k;
                         jc[c] = j;
                         inr[c] = false;
-                        off[c] = LM_NULL_OFF;
+                        off[c] = RNULL;
                         if (!chunk_on(cmx, c, mlo[0], mhi[0])) continue;
                         inr[c] = (uint32_t)(k - mlo[0]) <= (uint32_t)(mhi[0] - mlo[0]);
                         const int32_t o = rM[ms][slot];
@@ -2772,9 +2787,9 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
 #pragma unroll
                         for (int c = 0; c < NC; c++) {
                             const int slot = lane + 64 * c, k = kc[c];
-                            if (inr[c] && (uint32_t)(k - nlo) > nmsp) rM[ms][slot] = LM_NULL_OFF;
-                            if ((uint32_t)(k - oil) <= oisp && (uint32_t)(k - ilo[0]) > nisp) rI[is][slot] = LM_NULL_OFF;
-                            if ((uint32_t)(k - odl) <= odsp && (uint32_t)(k - dlo[0]) > ndsp) rD[is][slot] = LM_NULL_OFF;
+                            if (inr[c] && (uint32_t)(k - nlo) > nmsp) rM[ms][slot] = RNULL;
+                            if ((uint32_t)(k - oil) <= oisp && (uint32_t)(k - ilo[0]) > nisp) rI[is][slot] = RNULL;
+                            if ((uint32_t)(k - odl) <= odsp && (uint32_t)(k - dlo[0]) > ndsp) rD[is][slot] = RNULL;
                         }
                         mlo[0] = nlo;
                         mhi[0] = nhi;
@@ -2785,6 +2800,11 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
             s += 2;
             if (s >= max_score) {
                 status = 1;
+                break;
+            }
+            if (R16 && s >= 24000) { // the 16-bit cells could wrap from here on: the 32-bit pass takes the problem
+                status = 3;
+                wide_at = W;
                 break;
             }
 #pragma unroll
@@ -2810,9 +2830,9 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                 mhi[0] = ihi[0] = dhi[0] = E_HI;
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
-                    rM[ms][lane + 64 * c] = LM_NULL_OFF;
-                    rI[is][lane + 64 * c] = LM_NULL_OFF;
-                    rD[is][lane + 64 * c] = LM_NULL_OFF;
+                    rM[ms][lane + 64 * c] = RNULL;
+                    rI[is][lane + 64 * c] = RNULL;
+                    rD[is][lane + 64 * c] = RNULL;
                 }
                 alo = 0;
                 if (lane == 0) { // an empty row: same offset as the next one
@@ -2854,7 +2874,7 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                 const int k = lo + j;
                 kk[c] = k;
                 inr[c] = false;
-                vins[c] = vdel[c] = vmx[c] = LM_NULL_OFF;
+                vins[c] = vdel[c] = vmx[c] = RNULL;
                 if (!chunk_on(cmr, c, lo, hi)) continue;
                 inr[c] = k <= hi;
                 const int sm1 = (slot + W - 1) & (W - 1), sp1 = (slot + 1) & (W - 1);
@@ -2870,8 +2890,8 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
                 if (del > mx) mx = del;
                 // predecessor of the M cell on equal offsets: mismatch (tag 9) > deletion (4, 3) > insertion (2, 1)
                 const uint32_t mc = (mis >= del && mis >= ins) ? 0u : (del >= ins ? 2u : 1u);
-                if ((uint32_t)mx > (uint32_t)tlen) mx = LM_NULL_OFF;
-                if ((uint32_t)(mx - k) > (uint32_t)plen) mx = LM_NULL_OFF;
+                if ((uint32_t)mx > (uint32_t)tlen) mx = RNULL;
+                if ((uint32_t)(mx - k) > (uint32_t)plen) mx = RNULL;
                 if (inr[c]) bt[rowb + (k - lo)] = (uint8_t)(mc | (iext ? 4u : 0u) | (dext ? 8u : 0u));
                 vins[c] = ins;
                 vdel[c] = del;
@@ -2900,9 +2920,9 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
 #pragma unroll
             for (int c = 0; c < NC; c++) { // (k - E_LO) as unsigned is above every span, also above the span of an empty range
                 const int slot = lane + 64 * c, k = kk[c];
-                rM[ms][slot] = (uint32_t)(k - mlo[0]) <= spm ? vmx[c] : LM_NULL_OFF;
-                rI[is][slot] = (uint32_t)(k - ilo[0]) <= spi ? vins[c] : LM_NULL_OFF;
-                rD[is][slot] = (uint32_t)(k - dlo[0]) <= spd ? vdel[c] : LM_NULL_OFF;
+                rM[ms][slot] = (uint32_t)(k - mlo[0]) <= spm ? vmx[c] : RNULL;
+                rI[is][slot] = (uint32_t)(k - ilo[0]) <= spi ? vins[c] : RNULL;
+                rD[is][slot] = (uint32_t)(k - dlo[0]) <= spd ? vdel[c] : RNULL;
             }
         }
         if (status == 0 && __ballot(bad) != 0ull) status = 3; // not plain ACGT: the byte-comparing kernel takes it
@@ -3127,29 +3147,33 @@ void launch_extend(hipStream_t st, const HspIn *hsps, int64_t n, const uint8_t *
 // the kernel instantiations: ring width x (whole sequences in LDS | sliding windows)
 typedef void (*WfaLeanFn)(const WfaIn *, int64_t, const int32_t *, int64_t, int32_t *, int64_t, uint8_t *, int64_t, uint64_t *,
                           unsigned int *, int, int, WfaOut *, unsigned long long *);
-static WfaLeanFn wfa_lean_fn(int nc, bool win) {
+// r16: 16-bit ring cells (whole-sequence kernels of 128 / 256 diagonals, sequences up to 12 000 bases: lm_kernels.h)
+static WfaLeanFn wfa_lean_fn(int nc, bool win, bool r16) {
+    if (r16 && !win && nc == 2) return k_wfa_lean<2, false, int16_t>;
+    if (r16 && !win && nc == 4) return k_wfa_lean<4, false, int16_t>;
     switch (nc) {
-    case 16: return win ? k_wfa_lean<16, true> : k_wfa_lean<16, false>;
-    case 8: return win ? k_wfa_lean<8, true> : k_wfa_lean<8, false>;
-    case 4: return win ? k_wfa_lean<4, true> : k_wfa_lean<4, false>;
-    case 1: return win ? k_wfa_lean<1, true> : k_wfa_lean<1, false>;
-    default: return win ? k_wfa_lean<2, true> : k_wfa_lean<2, false>;
+    case 16: return win ? k_wfa_lean<16, true, int32_t> : k_wfa_lean<16, false, int32_t>;
+    case 8: return win ? k_wfa_lean<8, true, int32_t> : k_wfa_lean<8, false, int32_t>;
+    case 4: return win ? k_wfa_lean<4, true, int32_t> : k_wfa_lean<4, false, int32_t>;
+    case 1: return win ? k_wfa_lean<1, true, int32_t> : k_wfa_lean<1, false, int32_t>;
+    default: return win ? k_wfa_lean<2, true, int32_t> : k_wfa_lean<2, false, int32_t>;
     }
 }
+bool wfa_r16_ok(int seq_words, int nc, bool win) { return !win && (nc == 2 || nc == 4) && seq_words <= 750; }
 static size_t wfa_dyn_lds(int seq_words, bool win) { // two packed sequences with one padding word each (+2: the predicated
     return win ? 0 : (size_t)(2 * (seq_words + 1) + 2) * sizeof(uint32_t); // extension may read one word past)
 }
-int wfa_resident_blocks(int device, int seq_words, int nc, bool win) {
+int wfa_resident_blocks(int device, int seq_words, int nc, bool win, bool r16) {
     int nb = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)wfa_lean_fn(nc, win), 64, wfa_dyn_lds(seq_words, win)) != hipSuccess || nb < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)wfa_lean_fn(nc, win, r16), 64, wfa_dyn_lds(seq_words, win)) != hipSuccess || nb < 1)
         nb = 8;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
     return nb * cus;
 }
 void launch_wfa(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks,
                 int32_t *hdr_pool, int64_t hdr_stride, uint8_t *arena_pool, int64_t arena_stride, uint64_t *ops_pool,
-                unsigned int *queue, int seq_words, int want_ops, WfaOut *out, int nc, bool win, unsigned long long *dbg) {
-    hipLaunchKernelGGL(wfa_lean_fn(nc, win), dim3(nblocks), dim3(64), wfa_dyn_lds(seq_words, win), st, in, n, todo, ntodo, hdr_pool,
+                unsigned int *queue, int seq_words, int want_ops, WfaOut *out, int nc, bool win, bool r16, unsigned long long *dbg) {
+    hipLaunchKernelGGL(wfa_lean_fn(nc, win, r16), dim3(nblocks), dim3(64), wfa_dyn_lds(seq_words, win), st, in, n, todo, ntodo, hdr_pool,
                        hdr_stride, arena_pool, arena_stride, ops_pool, queue, seq_words, want_ops, out, dbg);
 }
 void launch_wfa_wide(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int32_t *hdr_pool,

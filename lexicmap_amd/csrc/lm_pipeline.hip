@@ -1115,6 +1115,15 @@ void lm_profile_exclusive(lm_index *ix, int exclusive) {
     ix->tune.wfa_serial = exclusive != 0 || getenv("LM_WFA_SERIAL") != nullptr;
     ix->tune.no_pipeline = exclusive != 0 || getenv("LM_NO_PIPELINE") != nullptr;
 }
+void lm_tuning_reload(lm_index *ix) {
+    if (!ix) return;
+    std::lock_guard<std::mutex> lock(ix->mu);
+    lm_tune fresh;
+    if (ix->tune.wfa_dump) fclose(ix->tune.wfa_dump);
+    if (ix->tune.wfa_waves) fclose(ix->tune.wfa_waves);
+    ix->tune = fresh;
+    lm_free_align_ctx(ix);
+}
 void lm_profile_reset(lm_index *ix) {
     prof_resolve(ix);
     ix->prof_entries.clear();
@@ -1327,7 +1336,7 @@ struct AlignCtx {
         ~LeanCtx() {
             if (st) (void)hipStreamDestroy(st);
         }
-    } lean[LM_WFA_CLASSES];
+    } lean[2 * LM_WFA_CLASSES]; // per length class: the chain that starts at the class's ring width, and the one of the problems predicted wider
     // the global-memory WFA fallback runs beside the LDS passes of the shorter length classes: own stream and buffers
     struct WideCtx {
         hipStream_t st = nullptr;
@@ -1737,26 +1746,46 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
     // the whole packed sequences in LDS or reads them through sliding windows (lm_tune::wfa_win), and keep the few long
     // alignments of a round off the queue of the many short ones.  The last class (beyond 65 kb: what the whole-sequence
     // kernel cannot hold) is open-ended and always windowed.  Within a class the queue keeps the longest-expected-first order
-    constexpr int NCLS = LM_WFA_CLASSES;
+    // Every class has up to TWO chains of passes running side by side: chain c starts all its problems at the class's ring width;
+    // chain NCLS + c holds the problems PREDICTED to outgrow that width and starts each at the width predicted for it.  The
+    // wavefront of a global alignment must span from where the alignment is to its final diagonal tlen - qlen (lm_wfa_align
+    // keeps the range open towards it), so a problem with |tlen - qlen| + ~40 diagonals above a ring's W - 2 fails there with
+    // status 3 after a few hundred scores whatever its divergence (measured: of 78 000 c3-shaped problems exactly those with
+    // |tlen - qlen| >= 210..260 outgrew 254 diagonals).  Left to the retry pass they are a tail the round waits for (1 % of
+    // the 2-8-kb class: a 46-ms second pass behind a 250-ms first one); started at their width at once they run beside it.
+    constexpr int NCLS = LM_WFA_CLASSES, NCH = 2 * LM_WFA_CLASSES;
     const int bounds[NCLS - 1] = {128, 512, 2048, 4096};
-    std::vector<int32_t> cls[NCLS];
-    int cw[NCLS];
-    int64_t cl[NCLS], cs[NCLS];
-    for (int c = 0; c < NCLS; c++) {
+    std::vector<int32_t> cls[NCH];
+    std::vector<int8_t> start_nc(n, 0);
+    int cw[NCH];
+    int64_t cl[NCH], cs[NCH];
+    for (int c = 0; c < NCH; c++) {
         cw[c] = 1;
         cl[c] = 1;
         cs[c] = 0;
     }
-    int first_nc[NCLS];
-    bool win[NCLS];
+    int first_nc[NCH];
+    bool win[NCH];
     for (int c = 0; c < NCLS; c++) {
         first_nc[c] = ix->tune.wfa_first_nc[c];
-        win[c] = ix->tune.wfa_win[c] != 0 || c == NCLS - 1;
+        first_nc[NCLS + c] = 16; // lowered to the narrowest predicted width of its members below
+        win[c] = win[NCLS + c] = ix->tune.wfa_win[c] != 0 || c == NCLS - 1;
     }
+    const int ak_margin = ix->tune.wfa_ak_margin; // < 0: no prediction
     for (int32_t i : order) {
         const int wds = (std::max(in[i].qlen, in[i].tlen) + 15) / 16;
         int c = 0;
         while (c < NCLS - 1 && wds > bounds[c]) c++;
+        int snc = first_nc[c];
+        if (ak_margin >= 0) {
+            const int need = std::abs(in[i].tlen - in[i].qlen) + ak_margin;
+            while (snc < 16 && need > 64 * snc - 2) snc *= 2;
+        }
+        start_nc[i] = (int8_t)snc;
+        if (snc > first_nc[c]) {
+            c += NCLS;
+            first_nc[c] = std::min(first_nc[c], snc);
+        }
         cls[c].push_back(i);
         cw[c] = std::max(cw[c], wds);
         const int64_t L = (int64_t)in[i].qlen + in[i].tlen;
@@ -1768,16 +1797,16 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
     }
     // scratch of the classes side by side: what each would like (resident wavefronts x expected backtrace bytes of its
     // longest problem), scaled down together when that exceeds the lean share of the budget
-    int64_t want[NCLS], share[NCLS];
+    int64_t want[NCH], share[NCH];
     int64_t want_tot = 0;
-    for (int c = 0; c < NCLS; c++) {
+    for (int c = 0; c < NCH; c++) {
         const int64_t m = (int64_t)cls[c].size();
         const int64_t smax = std::min<int64_t>(8 * cl[c] + 64, cs[c]);
         const int64_t per = (smax / 2 + 2) * 64 * first_nc[c] + 2 * cl[c] + 4096 + (smax / 2 + 4) * 16;
-        want[c] = m == 0 ? 0 : std::min<int64_t>(m, wfa_resident_blocks(ix->device, cw[c], first_nc[c], win[c])) * per * 9 / 8;
+        want[c] = m == 0 ? 0 : std::min<int64_t>(m, wfa_resident_blocks(ix->device, cw[c], first_nc[c], win[c], ix->tune.wfa_r16 && wfa_r16_ok(cw[c], first_nc[c], win[c]))) * per * 9 / 8;
         want_tot += want[c];
     }
-    for (int c = 0; c < NCLS; c++)
+    for (int c = 0; c < NCH; c++)
         share[c] = want_tot <= lean_budget ? std::max<int64_t>(want[c], (int64_t)64 << 20)
                                            : std::max<int64_t>((int64_t)((double)want[c] / (double)want_tot * (double)lean_budget), (int64_t)64 << 20);
     // one launch of the persistent LDS kernel per length class and ring width.  Resident wavefronts per CU: windowed, set by
@@ -1789,7 +1818,8 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
         if (m == 0) return;
         // the 512 / 1024-diagonal passes are a handful of long alignments the round waits for: a workgroup of four wavefronts each
         const bool mw = ix->tune.wfa_mw && nc >= 8;
-        const int resident = mw ? wfa_mw_resident_blocks(ix->device, seq_words, nc, use_win) : wfa_resident_blocks(ix->device, seq_words, nc, use_win);
+        const bool r16 = !mw && ix->tune.wfa_r16 && wfa_r16_ok(seq_words, nc, use_win); // 16-bit ring cells: more wavefronts per CU
+        const int resident = mw ? wfa_mw_resident_blocks(ix->device, seq_words, nc, use_win) : wfa_resident_blocks(ix->device, seq_words, nc, use_win, r16);
         int nblocks = (int)std::min<int64_t>(m, std::max<int64_t>(mw ? 1 : 256, (int64_t)resident * ix->tune.wfa_resident_pct / 100));
         // private scratch per resident wave: one backtrace byte per wavefront cell + 8 bytes per even score; never
         // more than the longest problem of the class is expected to need
@@ -1826,7 +1856,7 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
                               a.ops_pool.p, lc.queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc, use_win);
             else
                 launch_wfa(S(ix), a.wfa_in.p, n, lc.todo.p, m, nblocks, lc.hdr_pool.p, entries * 2, (uint8_t *)lc.arena_pool.p, bytes,
-                           a.ops_pool.p, lc.queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc, use_win, wave_dbg ? lc.dbg.p : nullptr);
+                           a.ops_pool.p, lc.queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc, use_win, r16, wave_dbg ? lc.dbg.p : nullptr);
         }
         sync(ix);
         if (wave_dbg) { // where the launch's time went, wavefront by wavefront (100-MHz wall clock)
@@ -1915,8 +1945,14 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
     // rings are slower per score and their LDS keeps the anchor filter's workgroups off the CUs.)
     auto class_chain = [&](int c) {
         AlignCtx::LeanCtx &lc = a.lean[c];
-        std::vector<int32_t> cur = cls[c], next;
-        for (int nc = first_nc[c]; nc <= 16 && !cur.empty(); nc *= 2) {
+        std::vector<int32_t> cur, next, later = cls[c];
+        for (int nc = first_nc[c]; nc <= 16 && (!cur.empty() || !later.empty()); nc *= 2) {
+            // what the narrower pass left (status 3) + the members that start at this width, in the queue's cost order
+            if (!later.empty()) {
+                std::vector<int32_t> keep;
+                for (int32_t i : later) (start_nc[i] <= nc ? cur : keep).push_back(i);
+                later.swap(keep);
+            }
             next.clear();
             persistent_pass(lc, share[c], cur, cw[c], win[c], cl[c], cs[c], next, nc);
             cur.swap(next);
@@ -1956,14 +1992,21 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
     // the classes side by side, the long ones first (their wavefronts should all be resident from the start); the caller's
     // thread takes the shortest class on its own stream
     // every stream exists before the first thread starts: a failing hipStreamCreate must not unwind past joinable threads
-    for (int c = NCLS - 1; c >= 1; c--)
+    for (int c = NCH - 1; c >= 1; c--)
         if (!cls[c].empty() && !a.lean[c].st) HIPCHK(hipStreamCreate(&a.lean[c].st));
     if (!a.wide.st) HIPCHK(hipStreamCreate(&a.wide.st));
-    std::thread cth[NCLS];
-    std::exception_ptr cerr[NCLS];
+    std::thread cth[NCH];
+    std::exception_ptr cerr[NCH];
     const bool serial = ix->tune.wfa_serial; // exclusive kernel timings: one class after the other
-    for (int c = NCLS - 1; c >= 1; c--) {
-        if (cls[c].empty()) continue;
+    // start order: the predicted-wide chains and the long classes first (latency-bound: resident from the start)
+    int start_order[NCH];
+    for (int c = 0; c < NCLS; c++) {
+        start_order[c] = 2 * NCLS - 1 - c;      // chains NCLS + 4 .. NCLS + 0
+        start_order[NCLS + c] = NCLS - 1 - c;   // chains 4 .. 0
+    }
+    for (int oi = 0; oi < NCH; oi++) {
+        const int c = start_order[oi];
+        if (c == 0 || cls[c].empty()) continue;
         cth[c] = std::thread([&, c]() {
             try {
                 HIPCHK(hipSetDevice(ix->device));
@@ -1983,17 +2026,17 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
     std::exception_ptr err0;
     try {
         class_chain(0);
-        for (int c = NCLS - 1; c >= 2; c--)
-            if (cth[c].joinable()) cth[c].join();
+        for (int c = NCH - 1; c >= 2; c--)
+            if (c != 1 && c != NCLS && c != NCLS + 1 && cth[c].joinable()) cth[c].join();
         start_wide(); // the long classes are done: their leftovers run beside what is left of the short classes
     } catch (...) {
         err0 = std::current_exception();
     }
-    for (int c = NCLS - 1; c >= 1; c--)
+    for (int c = NCH - 1; c >= 1; c--)
         if (cth[c].joinable()) cth[c].join();
     if (wide_thread.joinable()) wide_thread.join();
     if (err0) std::rethrow_exception(err0);
-    for (int c = 1; c < NCLS; c++)
+    for (int c = 1; c < NCH; c++)
         if (cerr[c]) std::rethrow_exception(cerr[c]);
     if (wide_err) std::rethrow_exception(wide_err);
     if (!fb_items.empty()) { // leftovers of the short classes (rare): same fallback, on this thread's stream
@@ -2178,6 +2221,7 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
                 pc.base = ht[0].woff;
                 pc.off = ht.back().woff + ht.back().wlen - pc.base; // window bytes of the chunk
                 const double ta = now_ms();
+                dbg_stamp("pseudo-alignment of a chunk starts");
                 try {
                     run_pseudo(*ctxs[slot], ht, pc.res_off, pc.resv, w.tasks.p + tpos, pc.base, false);
                 } catch (const ChunkTooLarge &) { // same tasks again in smaller chunks
@@ -2188,6 +2232,7 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
                     continue;
                 }
                 ms_pseudo += now_ms() - ta;
+                dbg_stamp("pseudo-alignment of a chunk done (chains on the host)");
                 {
                     std::lock_guard<std::mutex> l(pm);
                     slot_free[slot] = false;
@@ -2448,6 +2493,7 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
             if (gw_used == 0) a.gwbuf.ensure((size_t)std::max<int64_t>(need, gw_target) + 64);
         }
         double tb = now_ms();
+        dbg_stamp("glue of a chunk starts");
         // glue per segment with results (parallel; the order of `genomes` stays the segment order)
         const size_t hs0 = hsps.size(); // this chunk's HSPs go behind the round's
         {
@@ -2584,6 +2630,7 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
                         tg0 - tb, tg1 - tg0, tg2 - tg1, now_ms() - tg2, (long long)ns);
         }
         st.ms_glue += now_ms() - tb;
+        dbg_stamp("glue of a chunk done");
         janitor().dispose(std::move(resv));
         bool idle = false;
         {   // the chunk's pseudo-alignment results are consumed and its windows copied: its context may take the next chunk

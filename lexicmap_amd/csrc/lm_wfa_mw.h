@@ -37,6 +37,9 @@ __global__ __launch_bounds__(MW_THREADS) void k_wfa_mw(const WfaIn *__restrict__
     int32_t *hdr2 = hdr_pool + (int64_t)blockIdx.x * hdr_stride;
     uint8_t *bt = arena_pool + (int64_t)blockIdx.x * arena_stride;
     const int max_score = (int)(hdr_stride / 2 - 2) * 2;
+    // the handful of long alignments every round waits for: issued ahead of the many short ones sharing the SIMDs (as the
+    // single-wavefront 512 / 1024-diagonal passes were)
+    __builtin_amdgcn_s_setprio(NCW >= 4 ? 3 : 2);
     if (tid == 0) sh_x = atomicAdd(queue, 1u);
     while (true) {
         __syncthreads();

@@ -109,3 +109,33 @@ def test_workgroup_passes_on_small_and_degenerate_problems(tiny_index, monkeypat
     monkeypatch.delenv("LM_WFA_FIRST_NC")
     _check(pairs, got)
     assert names.get("k_wfa_mw512", 0) >= 1 and names.get("k_wfa_lean", 0) == 0, names
+
+
+def test_16_bit_ring_cells_equal_the_oracle_and_hand_over_before_they_could_wrap(tiny_index, monkeypatch):
+    """k_wfa_lean<2 / 4, false, int16_t> (half the LDS per wavefront for the classes up to 8 kb): same results as the oracle with
+    the switch on and off; a pair whose score passes 24 000 (where a 16-bit cell could wrap) must leave the 16-bit pass with
+    status 3 and come back from the 32-bit one with the oracle's alignment"""
+    la = _la()
+    from lexicmap_amd import synth
+    rng = np.random.default_rng(123)
+    pairs = []
+    for n, div in [(500, 0.1), (1900, 0.2), (2048, 0.05), (3000, 0.15), (6000, 0.1), (8000, 0.2), (8190, 0.02)]:
+        q = synth.random_seq(rng, n)
+        t = synth.mutate(rng, q, sub=div, ins=div / 4, dele=div / 4)
+        pairs.append((q.tobytes(), t.tobytes()))
+    pairs.append((synth.random_seq(rng, 7800).tobytes(), synth.random_seq(rng, 8000).tobytes()))   # unrelated sequences
+    q = synth.random_seq(rng, 7000)
+    pairs.append((q.tobytes(), synth.mutate(rng, q, sub=0.5, ins=0.1, dele=0.1).tobytes()))
+    # 8 000 mismatches in a row between matching ends: score 32 000, nothing a shift or a gap could save
+    pairs.append((b"ACGTTGCAGT" + b"A" * 8000 + b"TGCATTGACC", b"ACGTTGCAGT" + b"C" * 8000 + b"TGCATTGACC"))
+    pairs.append((b"A" * 8100, b"C" * 8100))
+    res = {}
+    for r16 in ("1", "0"):
+        monkeypatch.setenv("LM_WFA_R16", r16)
+        gi = la.Index(tiny_index)
+        res[r16] = gi.wfa(pairs)
+        gi.close()
+        _check(pairs, res[r16])
+    monkeypatch.delenv("LM_WFA_R16")
+    assert res["1"] == res["0"]
+    assert max(g["score"] for g in res["1"]) >= 24000

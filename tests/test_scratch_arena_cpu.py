@@ -16,6 +16,16 @@ LIB = os.path.join(HERE, "libarena_host.so")
 MB = 1 << 20
 
 
+def grid(n):
+    """ScratchArena::grid: requests are rounded up to 2^k x {1, 1.25, 1.5, 1.75} (multiples of 4096)"""
+    b = (n + 4095) // 4096 * 4096
+    p = 4096
+    while p * 2 <= b:
+        p *= 2
+    q = p // 4
+    return (b + q - 1) // q * q
+
+
 @pytest.fixture(scope="module")
 def L():
     if not os.path.isdir("/opt/rocm/include"):
@@ -60,7 +70,7 @@ def test_blocks_never_overlap_and_everything_coalesces_back(L):
             if p is None:      # the fake device is full: legal, nothing must have changed
                 continue
             assert p % 4096 == 0 and p not in live
-            live[p] = (n + 4095) // 4096 * 4096
+            live[p] = grid(n)
             iv = sorted(live.items())
             for (p0, n0), (p1, _n1) in zip(iv, iv[1:]):
                 assert p0 + n0 <= p1, "live blocks overlap"
@@ -102,17 +112,42 @@ def test_the_halves_of_a_search_alternate_without_device_allocations(L):
     assert L.ah_device_used() == 0
 
 
-def test_empty_slabs_are_handed_back_before_giving_up_and_oom_is_reported(L):
-    L.ah_reset(1000 * MB)
+def test_pools_whose_sizes_follow_the_data_do_not_reach_the_device_again(L):
+    """the WFA chains of a round size their pools by (wavefronts x expected score of the longest problem): a few per cent up
+    or down from round to round and from part to part.  Without the size grid every request slightly above all freed blocks
+    got a new slab (hipMalloc of GBs = seconds); with it the blocks of the first rounds serve the later ones."""
+    L.ah_reset(256 * 1024 * MB)
     a = L.ah_arena_new()
-    ps = [L.ah_arena_alloc(a, 100 * MB) for _ in range(8)]       # eight slabs of 100 MB
-    assert all(ps) and L.ah_arena_slabs(a) == 8
+    rng = random.Random(11)
+    base = [7300, 660, 1700, 5200, 5900, 14000, 2500, 900, 350, 12000]   # MB: the ten chains of a c3-shaped round
+
+    def round_(jit):
+        ps = [L.ah_arena_alloc(a, int(b * MB * rng.uniform(1 - jit, 1 + jit))) for b in base]
+        assert all(p is not None for p in ps)
+        for p in ps:
+            assert L.ah_arena_release(a, p) == 1
+
+    for _ in range(4):
+        round_(0.08)
+    m0 = L.ah_device_mallocs()
+    for _ in range(40):
+        round_(0.08)
+    assert L.ah_device_mallocs() - m0 <= 4      # (a size that crosses a grid step may still want one more slab)
+    L.ah_arena_delete(a)
+    assert L.ah_device_used() == 0
+
+
+def test_empty_slabs_are_handed_back_before_giving_up_and_oom_is_reported(L):
+    L.ah_reset(1100 * MB)
+    a = L.ah_arena_new()
+    ps = [L.ah_arena_alloc(a, 100 * MB) for _ in range(8)]       # eight slabs of 100 MB (112 MB on the grid)
+    assert all(ps) and L.ah_arena_slabs(a) == 8 and L.ah_device_used() == 8 * grid(100 * MB)
     for p in ps:
         L.ah_arena_release(a, p)
     big = L.ah_arena_alloc(a, 900 * MB)                          # fits only if the empty slabs go back first
-    assert big is not None and L.ah_arena_slabs(a) == 1 and L.ah_device_used() == 900 * MB
+    assert big is not None and L.ah_arena_slabs(a) == 1 and L.ah_device_used() == grid(900 * MB) == 1024 * MB
     assert L.ah_arena_alloc(a, 200 * MB) is None                 # DeviceOOM, arena unchanged
-    assert L.ah_arena_live_bytes(a) == 900 * MB
+    assert L.ah_arena_live_bytes(a) == 1024 * MB
     L.ah_arena_release(a, big)
     L.ah_arena_delete(a)
     assert L.ah_device_used() == 0
