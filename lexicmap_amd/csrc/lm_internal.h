@@ -304,7 +304,8 @@ struct lm_tune {
     int wfa_resident_pct = 100; // LM_WFA_RESIDENT_PCT: share of the CUs' wavefront slots / LDS the persistent WFA kernels take
     FILE *wfa_dump = nullptr; // LM_DEBUG_WFA_DUMP=<file>: one line per WFA problem and pass (width, status, lengths, estimate, score)
     FILE *wfa_waves = nullptr; // LM_DEBUG_WFA_WAVES=<file>: one JSON line per k_wfa_lean launch: when its wavefronts started / ended, busy share
-    int wfa_ak_margin = 40;  // LM_WFA_AK_MARGIN: a problem starts at the ring that holds |tlen - qlen| + margin diagonals (-1: at the class's width)
+    int wfa_ak_margin = -1;  // LM_WFA_AK_MARGIN: a problem starts at the ring that holds |tlen - qlen| + margin diagonals (-1: at the class's width)
+    int wfa_defer = 0;       // LM_WFA_DEFER=1: a round's latency-bound alignments finish beside the next round's first passes (default: every round waits for them)
     int wfa_r16 = 1;         // 16-bit ring cells in the whole-sequence WFA kernels of 128 / 256 diagonals (LM_WFA_R16=0: 32-bit)
     int wfa_mw = 1;          // 512 / 1024-diagonal passes by a workgroup of four wavefronts per alignment (LM_WFA_MW=0: one wavefront)
     int pa_chain_ring = 1;   // Chainer2 DP with the recent anchors in an LDS ring (LM_PA_CHAIN_RING=0: through global memory)
@@ -326,6 +327,7 @@ struct lm_tune {
         no_pipeline = getenv("LM_NO_PIPELINE") != nullptr;
         if (const char *e = getenv("LM_WFA_MW")) wfa_mw = atoi(e) != 0;
         if (const char *e = getenv("LM_WFA_R16")) wfa_r16 = atoi(e) != 0;
+        if (const char *e = getenv("LM_WFA_DEFER")) wfa_defer = atoi(e) != 0;
         if (const char *e = getenv("LM_WFA_AK_MARGIN")) wfa_ak_margin = atoi(e);
         if (const char *e = getenv("LM_PA_CHAIN_RING")) pa_chain_ring = atoi(e) != 0;
         if (getenv("LM_CHAIN1_LANES")) chain1_wave = 0;
@@ -336,11 +338,11 @@ struct lm_tune {
 struct lm_index {
     lm_tune tune;
     lm::Work *work = nullptr;       // device scratch reused across calls (grow-only)
-    lm::AlignCtx *actx[2] = {nullptr, nullptr}; // one per alignment worker
+    lm::AlignCtx *actx[3] = {nullptr, nullptr, nullptr}; // consumer (glue, extend, first WFA passes), pseudo-alignment producer, WFA tail
     // second lane: two parts of a large batch are searched side by side (the seeding / anchor kernels of one beside the
     // WFA launches of the other), each with half of the scratch budget, its own scratch, streams and rocPRIM storage
     lm::Work *work1 = nullptr;
-    lm::AlignCtx *actx1[2] = {nullptr, nullptr};
+    lm::AlignCtx *actx1[3] = {nullptr, nullptr, nullptr};
     hipStream_t st_b = nullptr, st2_b = nullptr;
     int active_lanes = 1;
     std::mutex mu;                  // one in-flight call per handle

@@ -1300,7 +1300,9 @@ struct AlignCtx {
     DBuf<int64_t> woff;
     DBuf<uint8_t> wbuf;
     // windows of the tasks with chains, compact, gathered over the chunks of one extendMatch / WFA round
-    DBuf<uint8_t> gwbuf;
+    DBuf<uint8_t> gwbuf, gwbuf2; // the round's compact window buffer; two alternate while a round's tail is still aligning
+    hipStream_t tail_st = nullptr; // (on the context the tail thread aligns with)
+    DBuf<uint8_t> tail_tmp;
     DBuf<int32_t> gw_idx;
     DBuf<int64_t> gw_dest;
     DBuf<unsigned long long> pa_count;
@@ -1352,8 +1354,11 @@ struct AlignCtx {
     AlignCtx() {
         for_each_phase([](auto &b) { b.phase = true; });
     }
+    ~AlignCtx() {
+        if (tail_st) (void)hipStreamDestroy(tail_st);
+    }
     template <class F> void for_each_phase(F f) {
-        f(wlen); f(woff); f(wbuf); f(gwbuf); f(gw_idx); f(gw_dest); f(pa_off); f(A0); f(B0); f(A1); f(B1); f(subs);
+        f(wlen); f(woff); f(wbuf); f(gwbuf); f(gwbuf2); f(tail_tmp); f(gw_idx); f(gw_dest); f(pa_off); f(A0); f(B0); f(A1); f(B1); f(subs);
         f(marks); f(msi); f(stack); f(out_n); f(clr_n); f(out); f(out_compact); f(res_off); f(tasks); f(hsp_in);
         f(hsp_ext); f(ext_cap); f(ext_wcap); f(ext_msi); f(ext_off); f(ext_subs); f(ext_rows); f(ext_rstart);
         f(wfa_in); f(wfa_out);  f(ops_pool);
@@ -1617,8 +1622,18 @@ static double div_from_pseudo_pident(double pid) { // table over integer percent
     return lut[i]; // floor of the identity => slightly over-estimated divergence
 }
 
+// `defer` (the search's rounds): only the FIRST pass of the classes up to 32 kb runs here - the throughput-bound launches that
+// fill the chip; what they leave (status 3 / 1), what is predicted wider than its class's ring and everything of the long
+// classes (a handful of alignments per round at single-problem latency: k_wfa_mw) is listed in `defer` with the ring width
+// it should start at, its record left at status -1: the caller aligns those in a second call (`min_nc` = those widths) on
+// another context BESIDE the next round's first passes instead of making every round wait for them.
+struct WfaDefer {
+    std::vector<int32_t> idx;
+    std::vector<int8_t> min_nc;
+};
 static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &out, std::vector<uint64_t> &ops_h,
-                    std::vector<int64_t> &ops_off_h, bool want_ops, const std::vector<float> *est_div = nullptr) {
+                    std::vector<int64_t> &ops_off_h, bool want_ops, const std::vector<float> *est_div = nullptr,
+                    WfaDefer *defer = nullptr, const std::vector<int8_t> *min_nc = nullptr, double budget_frac = 1.0) {
     lm_index *ix = a.ix;
     const int lane = tls_lane;
     int64_t n = (int64_t)in.size();
@@ -1627,8 +1642,8 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
     ops_h.clear();
     if (n == 0) return;
     // scratch: the LDS passes and the global-memory fallback run at the same time
-    const int64_t lean_budget = BUDGET(ix) > 0 ? std::min<int64_t>(a.wfa_budget, BUDGET(ix) * 26 / 100) : a.wfa_budget;
-    const int64_t wide_budget = BUDGET(ix) > 0 ? std::min<int64_t>((int64_t)72 << 30, BUDGET(ix) * 10 / 100) : (int64_t)72 << 30;
+    const int64_t lean_budget = (int64_t)(budget_frac * (double)(BUDGET(ix) > 0 ? std::min<int64_t>(a.wfa_budget, BUDGET(ix) * 26 / 100) : a.wfa_budget));
+    const int64_t wide_budget = (int64_t)(budget_frac * (double)(BUDGET(ix) > 0 ? std::min<int64_t>((int64_t)72 << 30, BUDGET(ix) * 10 / 100) : (int64_t)72 << 30));
     a.wfa_out.ensure((size_t)n);
     a.wfa_in.ensure((size_t)n);
     std::vector<std::vector<uint64_t>> ops_keep(want_ops ? n : 0);
@@ -1781,7 +1796,14 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
             const int need = std::abs(in[i].tlen - in[i].qlen) + ak_margin;
             while (snc < 16 && need > 64 * snc - 2) snc *= 2;
         }
+        if (min_nc) snc = std::max(snc, std::min(16, (int)(*min_nc)[i]));
         start_nc[i] = (int8_t)snc;
+        if (defer && (c >= 3 || snc > first_nc[c])) { // the latency-bound ones: the caller's second call
+            defer->idx.push_back(i);
+            defer->min_nc.push_back((int8_t)snc);
+            out[i].r.status = -1;
+            continue;
+        }
         if (snc > first_nc[c]) {
             c += NCLS;
             first_nc[c] = std::min(first_nc[c], snc);
@@ -1956,6 +1978,23 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
             next.clear();
             persistent_pass(lc, share[c], cur, cw[c], win[c], cl[c], cs[c], next, nc);
             cur.swap(next);
+            if (defer) { // first pass only: what outgrew this ring starts at the next width in the caller's second call
+                std::lock_guard<std::mutex> l(fb_mu);
+                for (int32_t i : cur) {
+                    defer->idx.push_back(i);
+                    defer->min_nc.push_back((int8_t)std::min(16, 2 * nc));
+                    out[i].r.status = -1;
+                }
+                for (size_t j = 0; j < fb_items.size(); j++) { // scratch overflows of this pass: same width again, own scratch there
+                    defer->idx.push_back(fb_items[j]);
+                    defer->min_nc.push_back((int8_t)nc);
+                    out[fb_items[j]].r.status = -1;
+                }
+                fb_items.clear();
+                fb_level.clear();
+                cur.clear();
+                break;
+            }
         }
         std::lock_guard<std::mutex> l(fb_mu);
         for (int32_t i : cur) { // the hard ones: generous scratch at once instead of an overflow and a second launch
@@ -2272,84 +2311,67 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
             if (t.joinable()) t.join();
         }
     } joiner{prod_thread, pm, pcv, cons_abort};
-    std::vector<HspMeta> hsps; // of the current round
-    size_t g0 = genomes.size(); // first genome of the current round
-    int64_t gw_used = 0;        // bytes of the round's window buffer in use
-    const int64_t gw_target = BUDGET(ix) > 0 ? std::min<int64_t>((int64_t)6 << 30, std::max<int64_t>((int64_t)64 << 20, BUDGET(ix) * 3 / 100)) : (int64_t)1 << 30;
-    const int64_t round_hsps = getenv("LM_DEBUG_ROUND_HSPS") ? atoll(getenv("LM_DEBUG_ROUND_HSPS")) : 330000;
-    const int64_t min_round_hsps = getenv("LM_DEBUG_MIN_ROUND_HSPS") ? atoll(getenv("LM_DEBUG_MIN_ROUND_HSPS")) : 150000;
-    // ---- one extendMatch / WFA / finalisation round over the HSPs gathered from one or more chunks: the WFA launches end in
-    // tails of a few long alignments, so few large rounds beat one round per chunk
-    auto flush_round = [&]() {
-        if (hsps.empty() && g0 == genomes.size()) {
-            gw_used = 0;
-            return;
-        }
-        double tc = now_ms();
-        int64_t NH = (int64_t)hsps.size();
-        st.hsps_aligned += NH;
-        dbg_stamp("extendMatch / WFA round starts");
-        if (getenv("LM_DEBUG"))
-            fprintf(stderr, "[lm] mem: round of %lld HSPs starts with %.2f GB of scratch held (budget %.2f)\n", (long long)NH,
-                    (double)(g_dbuf_bytes.load() - ix->hbm_bytes) / 1e9, (double)BUDGET(ix) / 1e9);
+    // ---- rounds.  The HSPs gathered from one or more chunks go through extendMatch / WFA / finalisation together.  A round's
+    // state lives in a Round object because its latency-bound alignments (the long classes and whatever outgrew the first
+    // pass's ring: a few hundred problems that keep a handful of CUs busy for ~100 ms) finish on a second context BESIDE
+    // the next round's first passes (run_wfa's `defer`): the tail thread aligns them and then finalises the round's genomes.
+    struct Round {
+        std::vector<HspMeta> hsps;
+        std::vector<HGenome> genomes; // of this round, in task order
         std::vector<WfaOut> wout;
         std::vector<uint64_t> ops_h;
         std::vector<int64_t> ops_off_h;
         std::vector<uint8_t> wbuf_h;
-        if (NH > 0) {
-            std::vector<HspIn> hin(NH);
-            for (int64_t i = 0; i < NH; i++) hin[i] = hsps[i].in;
-            a.hsp_in.ensure((size_t)NH);
-            a.hsp_ext.ensure((size_t)NH);
-            a.ext_cap.ensure((size_t)NH + 1);
-            a.ext_off.ensure((size_t)NH + 2);
-            HIPCHK(hipMemcpyAsync(a.hsp_in.p, hin.data(), sizeof(HspIn) * NH, hipMemcpyHostToDevice, S(ix)));
-            HIPCHK(hipMemsetAsync(a.ext_cap.p + NH, 0, sizeof(int32_t), S(ix)));
-            launch_extend_count(S(ix), a.hsp_in.p, NH, qb->d_seq.p, qb->d_qoff.p, a.gwbuf.p, a.ext_cap.p);
-            // scratch rows per wavefront of k_extend (32 HSPs = 64 flanks each), transposed layout
-            const int64_t NW = (2 * NH + 63) / 64;
-            a.ext_wcap.ensure((size_t)NW + 1);
-            a.ext_off.ensure((size_t)NW + 2);
-            HIPCHK(hipMemsetAsync(a.ext_wcap.p + NW, 0, sizeof(int32_t), S(ix)));
-            launch_extend_wave_cap(S(ix), a.ext_cap.p, NH, a.ext_wcap.p, NW);
-            int64_t ER = scan_to_i64<int32_t, CastI32>(ix, a.ext_wcap.p, NW, a.ext_off.p);
-            a.ext_rows.ensure((size_t)extend_grid_blocks(NH) * LM_EXT_ROWS * 64 * 2);
-            a.ext_rstart.ensure((size_t)extend_grid_blocks(NH) * LM_EXT_ROWS * 64);
-            a.ext_subs.ensure(64 * (size_t)ER + 64);
-            a.ext_msi.ensure(64 * (size_t)ER + 64);
-            {
-                // algorithmic bytes: per HSP the two flank pairs extendMatch reads (<= ext_len + 2 bases of query and of window on
-                // either side, lib-index-search-util.go:34-201), its descriptor and its result
-                Prof p(ix, "k_extend", NH * (int64_t)(4 * (ix->opt.ext_len2 + 2) + sizeof(HspIn) + sizeof(HspExt)));
-                launch_extend(S(ix), a.hsp_in.p, NH, qb->d_seq.p, qb->d_qoff.p, a.gwbuf.p, a.ext_cap.p, a.ext_off.p,
-                              a.ext_subs.p, a.ext_msi.p, a.ext_rows.p, a.ext_rstart.p, a.hsp_ext.p);
-            }
-            std::vector<HspExt> hext;
-            d2h(ix, hext, a.hsp_ext.p, (size_t)NH);
-            sync(ix);
-            std::vector<WfaIn> win(NH);
-            for (int64_t i = 0; i < NH; i++) {
-                hsps[i].ext = hext[i];
-                win[i].q = qb->d_seq.p + qb->h_qoff[hsps[i].q] + hext[i].qs;
-                win[i].t = a.gwbuf.p + hsps[i].in.woff + hext[i].ts;
-                win[i].qlen = hext[i].qe - hext[i].qs;
-                win[i].tlen = hext[i].te - hext[i].ts;
-            }
-            std::vector<float> est(NH);
-            for (int64_t i = 0; i < NH; i++) est[i] = hsps[i].est_div;
-            run_wfa(a, win, wout, ops_h, ops_off_h, want_seq, &est);
-            if (want_seq) {
-                d2h(ix, wbuf_h, a.gwbuf.p, (size_t)gw_used);
-                sync(ix);
-            }
+        // the deferred part
+        WfaDefer defer;
+        std::vector<int32_t> tail_of; // HSP -> index among the deferred ones, or -1
+        std::vector<WfaIn> in_t;
+        std::vector<float> est_t;
+        std::vector<WfaOut> wout_t;
+        std::vector<uint64_t> ops_h_t;
+        std::vector<int64_t> ops_off_t;
+        lm_stage_stats st_t;
+        int buf = 0; // which of the two window buffers holds this round's windows
+    };
+    std::vector<std::unique_ptr<Round>> rounds_done; // in round order: their genomes are appended to `genomes` at the end
+    std::unique_ptr<Round> cur(new Round());
+    std::thread tail_thread;
+    std::exception_ptr tail_err;
+    std::mutex st_mu; // the stage statistics both threads add to
+    int round_no = 0;
+    auto gwb = [&](int b) -> DBuf<uint8_t> & { return b ? a.gwbuf2 : a.gwbuf; };
+    const bool defer_tails = pipelined && ix->tune.wfa_defer && !ix->tune.wfa_serial;
+    AlignCtx *a_tail = defer_tails ? &get_actx(ix, qb, &w, &st, 2) : nullptr;
+    int64_t gw_used = 0;        // bytes of the round's window buffer in use
+    const int64_t gw_target = BUDGET(ix) > 0 ? std::min<int64_t>((int64_t)6 << 30, std::max<int64_t>((int64_t)64 << 20, BUDGET(ix) * 3 / 100)) : (int64_t)1 << 30;
+    const int64_t round_hsps = getenv("LM_DEBUG_ROUND_HSPS") ? atoll(getenv("LM_DEBUG_ROUND_HSPS")) : 330000;
+    const int64_t min_round_hsps = getenv("LM_DEBUG_MIN_ROUND_HSPS") ? atoll(getenv("LM_DEBUG_MIN_ROUND_HSPS")) : 150000;
+    struct TailJoiner { // the tail thread never outlives this frame
+        std::thread &t;
+        ~TailJoiner() {
+            if (t.joinable()) t.join();
         }
-        double td = now_ms();
-        dbg_stamp("WFA of the round done");
-        st.ms_extend_wfa += td - tc;
-        // ---- finalisation of this chunk's genomes (:2266-2357 / :2533-2626, then :2684-2749) ----
-        parallel_for((int64_t)(genomes.size() - g0), 128, [&](int64_t gb0, int64_t gb1) {
-        for (size_t gi = g0 + (size_t)gb0; gi < g0 + (size_t)gb1; gi++) {
-            HGenome &gen = genomes[gi];
+    } tail_joiner{tail_thread};
+    Round *tail_round = nullptr; // the round whose tail is (or was last) running
+    auto join_tail = [&]() {
+        if (tail_thread.joinable()) tail_thread.join();
+        if (tail_round) {
+            st.wfa_retries += tail_round->st_t.wfa_retries;
+            tail_round = nullptr;
+        }
+        if (tail_err) {
+            std::exception_ptr e = tail_err;
+            tail_err = nullptr;
+            std::rethrow_exception(e);
+        }
+    };
+    // ---- finalisation of a round's genomes (:2266-2357 / :2533-2626, then :2684-2749); on the consumer's thread, or on the
+    // tail thread once the round's deferred alignments are in
+    auto finalize_round = [&](Round &R) {
+        const double td = now_ms();
+        parallel_for((int64_t)R.genomes.size(), 128, [&](int64_t gb0, int64_t gb1) {
+        for (size_t gi = (size_t)gb0; gi < (size_t)gb1; gi++) {
+            HGenome &gen = R.genomes[gi];
             int qlen = (int)(qb->h_qoff[gen.q + 1] - qb->h_qoff[gen.q]);
             for (auto &cl : gen.sds) {
                 double max_sim = 0;
@@ -2359,8 +2381,9 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
                         c.alive = false;
                         continue;
                     }
-                    const HspMeta &h = hsps[c.hsp];
-                    const WfaOut &wo = wout[c.hsp];
+                    const HspMeta &h = R.hsps[c.hsp];
+                    const int32_t tj = R.tail_of.empty() ? -1 : R.tail_of[c.hsp]; // aligned by the tail call ?
+                    const WfaOut &wo = tj >= 0 ? R.wout_t[tj] : R.wout[c.hsp];
                     const LmWfaOut &cg = wo.r;
                     int lq = h.ext.qe - h.ext.qs, lt = h.ext.te - h.ext.ts;
                     c.score = wo.blast_score;
@@ -2403,13 +2426,14 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
                         continue;
                     }
                     if (want_seq) {
-                        std::vector<uint64_t> ops(ops_h.begin() + ops_off_h[c.hsp], ops_h.begin() + ops_off_h[c.hsp + 1]);
+                        std::vector<uint64_t> ops = tj >= 0 ? std::vector<uint64_t>(R.ops_h_t.begin() + R.ops_off_t[tj], R.ops_h_t.begin() + R.ops_off_t[tj + 1])
+                                                            : std::vector<uint64_t>(R.ops_h.begin() + R.ops_off_h[c.hsp], R.ops_h.begin() + R.ops_off_h[c.hsp + 1]);
                         c.cigar = fmt_cigar(ops);
                         c.qseq = new std::string();
                         c.tseq = new std::string();
                         c.align = new std::string();
                         fmt_alignment(ops, qb->h_seq.data() + qb->h_qoff[h.q] + h.ext.qs,
-                                      wbuf_h.data() + h.in.woff + h.ext.ts, c.qseq, c.align, c.tseq);
+                                      R.wbuf_h.data() + h.in.woff + h.ext.ts, c.qseq, c.align, c.tseq);
                         std::lock_guard<std::mutex> sl(strings_mu);
                         res->strings.push_back(c.cigar);
                         res->strings.push_back(c.qseq);
@@ -2448,12 +2472,133 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
         }
         });
         if (getenv("LM_DEBUG")) fprintf(stderr, "[lm] finalize: parallel part %.2f ms\n", now_ms() - td);
-        st.ms_finalize += now_ms() - td;
-        janitor().dispose(std::move(hsps));
-        janitor().dispose(std::move(wout));
-        hsps = std::vector<HspMeta>();
-        g0 = genomes.size();
+        {
+            std::lock_guard<std::mutex> l(st_mu);
+            st.ms_finalize += now_ms() - td;
+        }
+        janitor().dispose(std::move(R.hsps));
+        janitor().dispose(std::move(R.wout));
+        janitor().dispose(std::move(R.wout_t));
+        R.hsps = std::vector<HspMeta>();
+        R.ops_h = std::vector<uint64_t>();
+        R.ops_h_t = std::vector<uint64_t>();
+        R.wbuf_h = std::vector<uint8_t>();
+    };
+    auto flush_round = [&]() {
+        if (cur->hsps.empty() && cur->genomes.empty()) {
+            gw_used = 0;
+            return;
+        }
+        Round &R = *cur;
+        std::vector<HspMeta> &hsps = R.hsps;
+        DBuf<uint8_t> &gwbuf = gwb(R.buf);
+        double tc = now_ms();
+        int64_t NH = (int64_t)hsps.size();
+        st.hsps_aligned += NH;
+        dbg_stamp("extendMatch / WFA round starts");
+        if (getenv("LM_DEBUG"))
+            fprintf(stderr, "[lm] mem: round of %lld HSPs starts with %.2f GB of scratch held (budget %.2f)\n", (long long)NH,
+                    (double)(g_dbuf_bytes.load() - ix->hbm_bytes) / 1e9, (double)BUDGET(ix) / 1e9);
+        if (NH > 0) {
+            std::vector<HspIn> hin(NH);
+            for (int64_t i = 0; i < NH; i++) hin[i] = hsps[i].in;
+            a.hsp_in.ensure((size_t)NH);
+            a.hsp_ext.ensure((size_t)NH);
+            a.ext_cap.ensure((size_t)NH + 1);
+            a.ext_off.ensure((size_t)NH + 2);
+            HIPCHK(hipMemcpyAsync(a.hsp_in.p, hin.data(), sizeof(HspIn) * NH, hipMemcpyHostToDevice, S(ix)));
+            HIPCHK(hipMemsetAsync(a.ext_cap.p + NH, 0, sizeof(int32_t), S(ix)));
+            launch_extend_count(S(ix), a.hsp_in.p, NH, qb->d_seq.p, qb->d_qoff.p, gwbuf.p, a.ext_cap.p);
+            // scratch rows per wavefront of k_extend (32 HSPs = 64 flanks each), transposed layout
+            const int64_t NW = (2 * NH + 63) / 64;
+            a.ext_wcap.ensure((size_t)NW + 1);
+            a.ext_off.ensure((size_t)NW + 2);
+            HIPCHK(hipMemsetAsync(a.ext_wcap.p + NW, 0, sizeof(int32_t), S(ix)));
+            launch_extend_wave_cap(S(ix), a.ext_cap.p, NH, a.ext_wcap.p, NW);
+            int64_t ER = scan_to_i64<int32_t, CastI32>(ix, a.ext_wcap.p, NW, a.ext_off.p);
+            a.ext_rows.ensure((size_t)extend_grid_blocks(NH) * LM_EXT_ROWS * 64 * 2);
+            a.ext_rstart.ensure((size_t)extend_grid_blocks(NH) * LM_EXT_ROWS * 64);
+            a.ext_subs.ensure(64 * (size_t)ER + 64);
+            a.ext_msi.ensure(64 * (size_t)ER + 64);
+            {
+                // algorithmic bytes: per HSP the two flank pairs extendMatch reads (<= ext_len + 2 bases of query and of window on
+                // either side, lib-index-search-util.go:34-201), its descriptor and its result
+                Prof p(ix, "k_extend", NH * (int64_t)(4 * (ix->opt.ext_len2 + 2) + sizeof(HspIn) + sizeof(HspExt)));
+                launch_extend(S(ix), a.hsp_in.p, NH, qb->d_seq.p, qb->d_qoff.p, gwbuf.p, a.ext_cap.p, a.ext_off.p,
+                              a.ext_subs.p, a.ext_msi.p, a.ext_rows.p, a.ext_rstart.p, a.hsp_ext.p);
+            }
+            std::vector<HspExt> hext;
+            d2h(ix, hext, a.hsp_ext.p, (size_t)NH);
+            sync(ix);
+            std::vector<WfaIn> win(NH);
+            for (int64_t i = 0; i < NH; i++) {
+                hsps[i].ext = hext[i];
+                win[i].q = qb->d_seq.p + qb->h_qoff[hsps[i].q] + hext[i].qs;
+                win[i].t = gwbuf.p + hsps[i].in.woff + hext[i].ts;
+                win[i].qlen = hext[i].qe - hext[i].qs;
+                win[i].tlen = hext[i].te - hext[i].ts;
+            }
+            std::vector<float> est(NH);
+            for (int64_t i = 0; i < NH; i++) est[i] = hsps[i].est_div;
+            run_wfa(a, win, R.wout, R.ops_h, R.ops_off_h, want_seq, &est, defer_tails ? &R.defer : nullptr, nullptr, defer_tails ? 0.6 : 1.0);
+            if (want_seq) {
+                d2h(ix, R.wbuf_h, gwbuf.p, (size_t)gw_used);
+                sync(ix);
+            }
+            if (!R.defer.idx.empty()) { // the deferred problems as a batch of their own
+                const size_t nt = R.defer.idx.size();
+                R.tail_of.assign((size_t)NH, -1);
+                R.in_t.resize(nt);
+                R.est_t.resize(nt);
+                for (size_t j = 0; j < nt; j++) {
+                    const int32_t i = R.defer.idx[j];
+                    R.tail_of[i] = (int32_t)j;
+                    R.in_t[j] = win[i];
+                    R.est_t[j] = est[i];
+                }
+            }
+        }
+        {
+            std::lock_guard<std::mutex> l(st_mu);
+            st.ms_extend_wfa += now_ms() - tc;
+        }
+        dbg_stamp("first WFA passes of the round done");
+        // one tail at a time: the previous round's has had this round's first passes to finish (and its window buffer is the
+        // one the NEXT round's glue will fill)
+        join_tail();
+        std::unique_ptr<Round> done = std::move(cur);
+        cur.reset(new Round());
+        round_no++;
+        cur->buf = defer_tails ? (round_no & 1) : 0;
         gw_used = 0;
+        Round *Rp = done.get();
+        rounds_done.push_back(std::move(done));
+        if (Rp->defer.idx.empty()) {
+            finalize_round(*Rp);
+            return;
+        }
+        if (getenv("LM_DEBUG"))
+            fprintf(stderr, "[lm +%.1f ms] %zu of the round's %lld alignments deferred to the tail (long classes / wider rings)\n", now_ms() - g_dbg_t0,
+                    Rp->defer.idx.size(), (long long)NH);
+        if (!a_tail->tail_st) HIPCHK(hipStreamCreate(&a_tail->tail_st));
+        memset(&Rp->st_t, 0, sizeof Rp->st_t);
+        a_tail->stats = &Rp->st_t;
+        tail_round = Rp;
+        tail_thread = std::thread([&, Rp]() {
+            try {
+                HIPCHK(hipSetDevice(ix->device));
+                tls_lane = lane;
+                tls_stream = a_tail->tail_st;
+                tls_tmp = &a_tail->tail_tmp;
+                tls_arena = &ix->arena;
+                run_wfa(*a_tail, Rp->in_t, Rp->wout_t, Rp->ops_h_t, Rp->ops_off_t, want_seq, &Rp->est_t, nullptr, &Rp->defer.min_nc, 0.4);
+                finalize_round(*Rp);
+            } catch (...) {
+                tail_err = std::current_exception();
+            }
+            tls_stream = nullptr;
+            tls_tmp = nullptr;
+        });
     };
     int64_t np_tpos = r0; // unpipelined: next chunk start
     while (true) {
@@ -2489,12 +2634,13 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
             int64_t need = 0;
             for (size_t t = 0; t < ht.size(); t++)
                 if (res_off[t + 1] > res_off[t]) need += ((int64_t)ht[t].wlen + 15) & ~(int64_t)15;
-            if (gw_used > 0 && (gw_used + need > (int64_t)a.gwbuf.cap - 64 || (int64_t)hsps.size() >= round_hsps)) flush_round();
-            if (gw_used == 0) a.gwbuf.ensure((size_t)std::max<int64_t>(need, gw_target) + 64);
+            if (gw_used > 0 && (gw_used + need > (int64_t)gwb(cur->buf).cap - 64 || (int64_t)cur->hsps.size() >= round_hsps)) flush_round();
+            if (gw_used == 0) gwb(cur->buf).ensure((size_t)std::max<int64_t>(need, gw_target) + 64);
         }
         double tb = now_ms();
         dbg_stamp("glue of a chunk starts");
         // glue per segment with results (parallel; the order of `genomes` stays the segment order)
+        std::vector<HspMeta> &hsps = cur->hsps;
         const size_t hs0 = hsps.size(); // this chunk's HSPs go behind the round's
         {
             std::vector<std::pair<size_t, size_t>> active; // task ranges of the segments that have Chain2 results
@@ -2619,17 +2765,20 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
                 HIPCHK(hipMemcpyAsync(a.gw_idx.p, widx.data(), widx.size() * sizeof(int32_t), hipMemcpyHostToDevice, S(ix)));
                 HIPCHK(hipMemcpyAsync(a.gw_dest.p, wdest.data(), wdest.size() * sizeof(int64_t), hipMemcpyHostToDevice, S(ix)));
                 Prof p(ix, "k_extract_windows", (gw_used - wdest[0]) * 5 / 4);
-                launch_extract_windows_at(S(ix), ix->view, w.tasks.p + tpos, a.gw_idx.p, a.gw_dest.p, (int64_t)widx.size(), a.gwbuf.p);
+                launch_extract_windows_at(S(ix), ix->view, w.tasks.p + tpos, a.gw_idx.p, a.gw_dest.p, (int64_t)widx.size(), gwb(cur->buf).p);
                 sync(ix); // the host lists go out of scope
             }
-            genomes.reserve(genomes.size() + (size_t)ns);
+            cur->genomes.reserve(cur->genomes.size() + (size_t)ns);
             for (int64_t si = 0; si < ns; si++)
-                if (!gens[si].sds.empty()) genomes.push_back(std::move(gens[si]));
+                if (!gens[si].sds.empty()) cur->genomes.push_back(std::move(gens[si]));
             if (getenv("LM_DEBUG"))
                 fprintf(stderr, "[lm] glue: active scan %.2f, glue_task pass %.2f, hsp fill %.2f, move %.2f ms (%lld genomes)\n",
                         tg0 - tb, tg1 - tg0, tg2 - tg1, now_ms() - tg2, (long long)ns);
         }
-        st.ms_glue += now_ms() - tb;
+        {
+            std::lock_guard<std::mutex> l(st_mu);
+            st.ms_glue += now_ms() - tb;
+        }
         dbg_stamp("glue of a chunk done");
         janitor().dispose(std::move(resv));
         bool idle = false;
@@ -2641,9 +2790,18 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
         pcv.notify_all();
         // nothing to consume yet: align what has been gathered instead of waiting for the producer (the anchor kernels of the
         // next chunks then run beside the WFA launches, whose scalar-unit-bound wavefronts leave the vector ALUs and LDS idle)
-        if (idle && (int64_t)hsps.size() >= min_round_hsps) flush_round();
+        if (idle && (int64_t)cur->hsps.size() >= min_round_hsps) flush_round();
     }
     flush_round();
+    join_tail();
+    {
+        size_t total = genomes.size();
+        for (auto &r : rounds_done) total += r->genomes.size();
+        genomes.reserve(total);
+        for (auto &r : rounds_done)
+            for (auto &g : r->genomes) genomes.push_back(std::move(g));
+        rounds_done.clear();
+    }
     if (pipelined) {
         if (prod_thread.joinable()) prod_thread.join();
         if (prod_err) std::rethrow_exception(prod_err);
@@ -2686,7 +2844,7 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res, const Searc
     if (BUDGET(ix) > 0) { // scratch of the previous part's alignment half (the halves alternate)
         HIPCHK(hipStreamSynchronize(S(ix))); // (every worker thread of the previous part synchronised its stream and was joined)
         int64_t freed = 0;
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < 3; j++)
             if (AlignCtx *c = lane_actx(ix)[j]) freed += c->release_big(BUDGET(ix) / 200);
         if (freed > 0 && getenv("LM_DEBUG"))
             fprintf(stderr, "[lm] alignment scratch of the previous part released: %.2f GB (arena: %.2f GB in slabs, %lld slab allocations so far)\n",

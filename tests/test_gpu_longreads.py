@@ -140,7 +140,7 @@ def test_rows_do_not_depend_on_which_device_implementation_of_a_stage_runs(lr_in
     ran = {p["name"] for p in gi.profile_get() if p["launches"] > 0}
     gi.close()
     assert any(n.startswith("k_wfa_mw") for n in ran), ran   # the fixture does reach the wide passes
-    for var, off in (("LM_WFA_MW", "0"), ("LM_PA_CHAIN_RING", "0"), ("LM_WFA_R16", "0"), ("LM_WFA_AK_MARGIN", "-1")):
+    for var, off in (("LM_WFA_MW", "0"), ("LM_PA_CHAIN_RING", "0"), ("LM_WFA_R16", "0"), ("LM_WFA_AK_MARGIN", "40")):
         monkeypatch.setenv(var, off)
         gi = la.Index(d)      # the switches are read once per handle
         gi.profile(True)
@@ -152,3 +152,30 @@ def test_rows_do_not_depend_on_which_device_implementation_of_a_stage_runs(lr_in
         assert st0["rows"] == st1["rows"] and st0["chains"] == st1["chains"] and st0["pa_anchors"] == st1["pa_anchors"]
         if var == "LM_WFA_MW":
             assert not any(n.startswith("k_wfa_mw") for n in ran1), ran1
+
+
+def test_rounds_whose_long_alignments_finish_beside_the_next_round_give_the_same_rows(lr_index, lr_queries, monkeypatch):
+    """With the alignment half in chunks (forced here: several chunks, a round every few HSPs) a round's latency-bound
+    alignments - the classes above 32 kb and whatever outgrew the first pass's ring - are aligned by a second context while
+    the next round's first passes run, and the round is finalised by that thread (run_wfa `defer`, LM_WFA_DEFER).  Rows,
+    CIGAR / alignment strings included, must be those of the single-round run, with the switch on and off."""
+    la = _la()
+    d, _ = lr_index
+    seqs = [q[1] for q in lr_queries]
+    opt = dict(output_seq=1)
+    gi = la.Index(d, la.api.default_options(**opt))
+    base, st0 = gi.search(seqs)
+    gi.close()
+    assert len(base) >= 20 and max(r["aligned_length"] for r in base) > 40000
+    monkeypatch.setenv("LM_DEBUG_MAX_WINDOW_BYTES", "150000")   # a few chain windows per chunk
+    monkeypatch.setenv("LM_DEBUG_ROUND_HSPS", "4")              # a round every few HSPs
+    monkeypatch.setenv("LM_DEBUG_MIN_ROUND_HSPS", "1")
+    for defer in ("1", "0"):
+        monkeypatch.setenv("LM_WFA_DEFER", defer)
+        gi = la.Index(d, la.api.default_options(**opt))
+        got, st1 = gi.search(seqs)
+        gi.close()
+        assert got == base, defer
+        assert st0["rows"] == st1["rows"] and st0["hsps_aligned"] == st1["hsps_aligned"]
+    for v in ("LM_WFA_DEFER", "LM_DEBUG_MAX_WINDOW_BYTES", "LM_DEBUG_ROUND_HSPS", "LM_DEBUG_MIN_ROUND_HSPS"):
+        monkeypatch.delenv(v)
