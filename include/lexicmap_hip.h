@@ -179,6 +179,13 @@ void lm_result_stats(const lm_result *res, lm_stage_stats *stats);
 void lm_result_free(lm_result *res); /* RecycleSearchResults, lib-index-search.go:1170 */
 /* search.go:468-523: one TSV line (no newline); returns the length that was/would be written */
 int lm_format_row(const lm_hsp *row, const char *query_id, uint32_t qlen, int more_columns, char *buf, size_t buflen);
+/* the same line with the printer's two switches (search.go:483-520): LM_ROW_ALL = -a/--all (CIGAR, qseq, sseq, align
+ * columns), LM_ROW_SSEQ_IDX = --show-sseq-idx (sseqid as c<chunk>/<chunks>:s<seq>/<seqs>:<id>, :483-494) */
+#define LM_ROW_ALL 1
+#define LM_ROW_SSEQ_IDX 2
+int lm_format_row_ex(const lm_hsp *row, const char *query_id, uint32_t qlen, int flags, char *buf, size_t buflen);
+/* the header line of the TSV (search.go:426-430), no newline; more_columns as in lm_format_row */
+const char *lm_tsv_header(int more_columns);
 
 typedef struct lm_stage lm_stage; /* host arrays of a stage-level call, released with lm_stage_free */
 

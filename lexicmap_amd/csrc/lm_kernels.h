@@ -80,7 +80,11 @@ void launch_lookup_prep(hipStream_t st, DevIndexView ix, const uint64_t *kmers, 
                         int64_t nqm, uint32_t *keys, uint32_t *slots, unsigned long long *counter);
 void launch_lookup_count(hipStream_t st, DevIndexView ix, const uint64_t *kmers, const int64_t *klo, const int64_t *khi,
                          const uint32_t *skeys, const uint32_t *sslots, int64_t nlk, int min_prefix, uint32_t *counts,
-                         int64_t *starts, int32_t *nscan, unsigned long long *stat_values);
+                         int64_t *starts, int32_t *nscan, unsigned long long *stat_values, uint64_t *lkey, uint64_t *lrec);
+// anchors with the lanes over the output (full-line stores, seeds read front to back); not under a genome whitelist
+void launch_lookup_emit_flat(hipStream_t st, DevIndexView ix, const uint32_t *vals_all, const uint32_t *skeys, const uint32_t *sslots,
+                             int64_t nlk, const uint32_t *counts, const int64_t *offs, const int64_t *starts, const uint64_t *lkey,
+                             const uint64_t *lrec, uint64_t *outA, uint64_t *outB);
 void launch_lookup_emit(hipStream_t st, DevIndexView ix, const uint64_t *kmers, const int64_t *klo, const int64_t *khi,
                         const uint32_t *vals_all, const uint32_t *skeys, const uint32_t *sslots, int64_t nlk,
                         const uint32_t *counts, const int64_t *offs, const int64_t *starts, const int32_t *nscan,

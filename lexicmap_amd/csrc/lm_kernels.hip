@@ -319,7 +319,8 @@ __global__ __launch_bounds__(256) void k_lookup_count(DevIndexView ix, const uin
                                                       const uint32_t *__restrict__ skeys, const uint32_t *__restrict__ sslots,
                                                       int64_t nlk, int min_prefix, uint32_t *__restrict__ counts,
                                                       int64_t *__restrict__ starts, int32_t *__restrict__ nscan,
-                                                      unsigned long long *__restrict__ stat_values) {
+                                                      unsigned long long *__restrict__ stat_values,
+                                                      uint64_t *__restrict__ lkey, uint64_t *__restrict__ lrec) {
     const int64_t j = lookup_index(nlk);
     if (j < 0) return;
     const uint32_t sk = skeys[j];
@@ -367,9 +368,14 @@ __global__ __launch_bounds__(256) void k_lookup_count(DevIndexView ix, const uin
             for (int32_t x = 0; x < nv; x++) nkept += genome_kept(ix, local_genome(ix, ix.out_vals[st + x] >> 30));
         }
     }
-    counts[j] = (uint32_t)nkept * (uint32_t)(khi[qm] - klo[qm]);
+    const int64_t l0 = klo[qm], l1 = khi[qm];
+    counts[j] = (uint32_t)nkept * (uint32_t)(l1 - l0);
     starts[j] = st;
     nscan[j] = nv;
+    // what k_lookup_emit_flat needs of this lookup, in sorted order (coalesced there): the looked-up k-mer and the range of
+    // the query's locations of it - gathered by (query, mask) once, here, instead of once more per kernel
+    lkey[j] = key;
+    lrec[j] = ((uint64_t)(uint32_t)l0 << 32) | (uint64_t)(uint32_t)(l1 - l0);
     if (nkept) atomicAdd(stat_values, (unsigned long long)nkept);
 }
 
@@ -419,6 +425,91 @@ __global__ __launch_bounds__(256) void k_lookup_emit(DevIndexView ix, const uint
             outA[o] = A;
             outB[o] = lm_pack_anchor(bq, kprefix, bt, (loc & 1u) != 0, rct);
             o++;
+        }
+    }
+}
+
+// k_lookup_emit_flat: the same anchors with the lanes over the OUTPUT instead of the lookups.  The anchors of the 64 lookups of
+// a wavefront are one contiguous range of the output (offs = exclusive scan in lookup order), so lane l takes anchors l, l + 64,
+// ...: it finds the lookup an anchor belongs to by a binary search over the wavefront's 64 offsets (shuffles), takes that
+// lookup's record from the lane that holds it, reads ONE seed and writes ONE anchor.  Stores are full lines, the packed key /
+// value streams of a partition are read front to back by neighbouring lanes, a lookup that returns thousands of seeds is
+// spread over the wavefront (k_lookup_emit: one lane walking them, 8-byte stores 16 bytes apart per lane: 16 GB written for
+// 3.5 GB of anchors, 50 GB read - it re-gathered k-mer and location range by (query, mask) and touched every seed line once per
+// lane).  Not for searches under a genome whitelist (the kept seeds of a lookup are then not a prefix of its range).
+__global__ __launch_bounds__(256) void k_lookup_emit_flat(DevIndexView ix, const uint32_t *__restrict__ vals_all,
+                                                          const uint32_t *__restrict__ skeys, const uint32_t *__restrict__ sslots,
+                                                          int64_t nlk, const uint32_t *__restrict__ counts,
+                                                          const int64_t *__restrict__ offs, const int64_t *__restrict__ starts,
+                                                          const uint64_t *__restrict__ lkey, const uint64_t *__restrict__ lrec,
+                                                          uint64_t *__restrict__ outA, uint64_t *__restrict__ outB) {
+    const int64_t j = lookup_index(nlk);
+    uint32_t cnt = 0, sk = 0, slot = 0;
+    int64_t off = offs[nlk], st = 0; // (lanes behind the last lookup: the end of the output, no anchors)
+    uint64_t key = 0, rec = 0;
+    if (j >= 0) {
+        cnt = counts[j];
+        off = offs[j];
+        if (cnt) {
+            sk = skeys[j];
+            slot = sslots[j];
+            st = starts[j];
+            key = lkey[j];
+            rec = lrec[j];
+        }
+    }
+    const int64_t wave_base = __shfl(off, 0, 64);
+    const int64_t total = __shfl(off + (int64_t)cnt, 63, 64) - wave_base;
+    const uint64_t km = (1ull << ix.key_bits) - 1;
+    const int fixed = ix.K - (ix.key_bits >> 1); // p + a bases shared by construction
+    auto one = [&](uint32_t sk_, uint32_t slot_, int64_t st_, uint64_t key_, uint64_t rec_, int64_t r, uint64_t *A, uint64_t *B) {
+        const uint32_t nloc = (uint32_t)rec_;
+        const int64_t s_i = nloc == 1 ? r : r / (int64_t)nloc;
+        const uint32_t li = (uint32_t)(rec_ >> 32) + (uint32_t)(nloc == 1 ? 0 : r - s_i * (int64_t)nloc);
+        const int dir = (int)(slot_ & 1u);
+        const uint64_t q = (uint64_t)((slot_ >> 1) / (uint32_t)ix.M);
+        uint64_t v;
+        int kprefix;
+        if (!(sk_ >> LM_LK_OUTLIER_BIT)) {
+            const uint64_t sr = lm_bits_get(ix.pk_keys, st_ + s_i, ix.key_bits);
+            const uint64_t d = sr ^ (key_ & km);
+            kprefix = fixed + (d ? ((lm_clz64(d) - (64 - ix.key_bits)) >> 1) : (ix.key_bits >> 1));
+            const uint64_t pv = lm_bits_get(ix.pk_vals, st_ + s_i, ix.gid_bits + ix.pos_bits + 1);
+            v = lm_unpack_seed_val(pv, ix.g_bg[lm_packed_val_genome(pv, ix.pos_bits)], ix.pos_bits, dir);
+        } else {
+            v = ix.out_vals[st_ + s_i];
+            kprefix = lm_lcp(key_, ix.out_kmers[st_ + s_i], ix.K);
+        }
+        const uint32_t loc = vals_all[li];
+        int bq, bt;
+        bool rct;
+        lm_anchor_coords(v, (int)(loc >> 1), (loc & 1u) != 0, kprefix, ix.K, &bq, &bt, &rct);
+        *A = (q << 34) | (v >> 30);
+        *B = lm_pack_anchor(bq, kprefix, bt, (loc & 1u) != 0, rct);
+    };
+    if (total >= ((int64_t)1 << 31)) { // (never at the batch sizes the parts are cut to: the offsets below are 32-bit)
+        for (int64_t r = 0; r < (int64_t)cnt; r++) one(sk, slot, st, key, rec, r, &outA[off + r], &outB[off + r]);
+        return;
+    }
+    const uint32_t rel = (uint32_t)(off - wave_base);
+    for (uint32_t base = 0; base < (uint32_t)total; base += 64) { // wave-uniform trip count: every lane takes part in the shuffles
+        const uint32_t o = base + (uint32_t)(threadIdx.x & 63);
+        const bool act = o < (uint32_t)total;
+        int L = 0; // the last lane whose first anchor is <= o (lanes without anchors share their successor's offset)
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1) {
+            const uint32_t rc = __shfl(rel, L + step, 64); // (L + step <= 63)
+            if (rc <= o) L += step;
+        }
+        const uint32_t r = o - __shfl(rel, L, 64);
+        const uint32_t sk_ = __shfl(sk, L, 64), slot_ = __shfl(slot, L, 64);
+        const int64_t st_ = __shfl(st, L, 64);
+        const uint64_t key_ = __shfl(key, L, 64), rec_ = __shfl(rec, L, 64);
+        if (act) {
+            uint64_t A, B;
+            one(sk_, slot_, st_, key_, rec_, (int64_t)r, &A, &B);
+            outA[wave_base + o] = A;
+            outB[wave_base + o] = B;
         }
     }
 }
@@ -3014,9 +3105,15 @@ static int lookup_grid(int64_t total) { // one thread per lookup, workgroup coun
 }
 void launch_lookup_count(hipStream_t st, DevIndexView ix, const uint64_t *kmers, const int64_t *klo, const int64_t *khi,
                          const uint32_t *skeys, const uint32_t *sslots, int64_t nlk, int min_prefix, uint32_t *counts,
-                         int64_t *starts, int32_t *nscan, unsigned long long *stat_values) {
+                         int64_t *starts, int32_t *nscan, unsigned long long *stat_values, uint64_t *lkey, uint64_t *lrec) {
     hipLaunchKernelGGL(k_lookup_count, dim3(lookup_grid(nlk)), dim3(256), 0, st, ix, kmers, klo, khi, skeys, sslots, nlk,
-                       min_prefix, counts, starts, nscan, stat_values);
+                       min_prefix, counts, starts, nscan, stat_values, lkey, lrec);
+}
+void launch_lookup_emit_flat(hipStream_t st, DevIndexView ix, const uint32_t *vals_all, const uint32_t *skeys, const uint32_t *sslots,
+                             int64_t nlk, const uint32_t *counts, const int64_t *offs, const int64_t *starts, const uint64_t *lkey,
+                             const uint64_t *lrec, uint64_t *outA, uint64_t *outB) {
+    hipLaunchKernelGGL(k_lookup_emit_flat, dim3(lookup_grid(nlk)), dim3(256), 0, st, ix, vals_all, skeys, sslots, nlk, counts, offs,
+                       starts, lkey, lrec, outA, outB);
 }
 void launch_lookup_emit(hipStream_t st, DevIndexView ix, const uint64_t *kmers, const int64_t *klo, const int64_t *khi,
                         const uint32_t *vals_all, const uint32_t *skeys, const uint32_t *sslots, int64_t nlk,

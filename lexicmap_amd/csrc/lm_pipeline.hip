@@ -401,6 +401,7 @@ struct Work {
     DBuf<uint32_t> lk_counts, lk_list, lk_list2, lk_perm, lk_perm2;
     DBuf<int64_t> lk_offs, lk_starts;
     DBuf<int32_t> lk_nscan;
+    DBuf<uint64_t> lk_key, lk_rec; // per issued lookup, sorted order: the looked-up k-mer, (first location index << 32 | locations)
     DBuf<unsigned long long> stat;
     DBuf<uint64_t> A0, B0, A1, B1;
     int64_t n_anchors = 0;
@@ -434,7 +435,7 @@ struct Work {
     // alignment half is carved from the same slabs; small ones stay plain grow-only allocations.
     template <class F> void for_each_seeding(F f) {
         f(keys_all); f(keys_all2); f(vals_all); f(vals_all2); f(first_mask); f(kmers); f(klo); f(khi); f(lk_counts);
-        f(lk_list); f(lk_list2); f(lk_perm); f(lk_perm2); f(lk_offs); f(lk_starts); f(lk_nscan); f(A0); f(B0); f(A1);
+        f(lk_list); f(lk_list2); f(lk_perm); f(lk_perm2); f(lk_offs); f(lk_starts); f(lk_nscan); f(lk_key); f(lk_rec); f(A0); f(B0); f(A1);
         f(B1); f(segA); f(seg_len); f(seg_off); f(subs); f(marks); f(visited); f(msi); f(s2i); f(dirs);
         f(chain_off_pool); f(chain_idx_pool); f(seg_n); f(seg_nch); f(order_scratch); f(chain_big); f(seg_score); f(ntask);
         f(task_off); f(task_wlen); f(task_woff);
@@ -558,11 +559,13 @@ static void stage_lookup(Work &w, lm_stage_stats &stats) {
     w.lk_offs.ensure((size_t)nlk + 1);
     w.lk_starts.ensure((size_t)nlk + 1);
     w.lk_nscan.ensure((size_t)nlk + 1);
+    w.lk_key.ensure((size_t)nlk + 1);
+    w.lk_rec.ensure((size_t)nlk + 1);
     HIPCHK(hipMemsetAsync(w.lk_counts.p + nlk, 0, sizeof(uint32_t), S(ix)));
     {
         Prof p(ix, "k_lookup_count");
         launch_lookup_count(S(ix), ix->view, w.kmers.p, w.klo.p, w.khi.p, w.lk_list2.p, w.lk_perm2.p, nlk, ix->opt.min_prefix,
-                            w.lk_counts.p, w.lk_starts.p, w.lk_nscan.p, w.stat.p);
+                            w.lk_counts.p, w.lk_starts.p, w.lk_nscan.p, w.stat.p, w.lk_key.p, w.lk_rec.p);
     }
     int64_t T;
     {
@@ -598,8 +601,12 @@ static void stage_lookup(Work &w, lm_stage_stats &stats) {
     w.B1.ensure((size_t)T);
     {
         Prof p(ix, "k_lookup_emit", T * 16);
-        launch_lookup_emit(S(ix), ix->view, w.kmers.p, w.klo.p, w.khi.p, w.v_all, w.lk_list2.p, w.lk_perm2.p, nlk, w.lk_counts.p,
-                           w.lk_offs.p, w.lk_starts.p, w.lk_nscan.p, w.A0.p, w.B0.p);
+        if (ix->view.g_keep || !ix->tune.lookup_flat) // a genome whitelist: the kept seeds of a lookup are not a prefix of its range
+            launch_lookup_emit(S(ix), ix->view, w.kmers.p, w.klo.p, w.khi.p, w.v_all, w.lk_list2.p, w.lk_perm2.p, nlk, w.lk_counts.p,
+                               w.lk_offs.p, w.lk_starts.p, w.lk_nscan.p, w.A0.p, w.B0.p);
+        else
+            launch_lookup_emit_flat(S(ix), ix->view, w.v_all, w.lk_list2.p, w.lk_perm2.p, nlk, w.lk_counts.p, w.lk_offs.p, w.lk_starts.p,
+                                    w.lk_key.p, w.lk_rec.p, w.A0.p, w.B0.p);
     }
     {
         Prof p(ix, "sort_anchors", T * 32); // two u64 per anchor in and out
@@ -3393,18 +3400,35 @@ size_t lm_result_rows(const lm_result *res, const lm_hsp **rows) {
 void lm_result_stats(const lm_result *res, lm_stage_stats *stats) { *stats = res->stats; }
 void lm_result_free(lm_result *res) { delete res; }
 
-int lm_format_row(const lm_hsp *h, const char *query_id, uint32_t qlen, int more_columns, char *buf, size_t buflen) {
+int lm_format_row_ex(const lm_hsp *h, const char *query_id, uint32_t qlen, int flags, char *buf, size_t buflen) {
+    // search.go:483-520: the two Fprintf forms differ in the sseqid column only
+    char sseq[64];
+    std::string sseq_long;
+    const char *sseqid = h->seq_id ? h->seq_id : "";
+    if (flags & LM_ROW_SSEQ_IDX) {
+        int m = snprintf(sseq, sizeof sseq, "c%d/%d:s%d/%d:", h->chunk_idx + 1, h->nchunks, h->seq_idx + 1, h->nseqs);
+        (void)m;
+        sseq_long = std::string(sseq) + sseqid;
+        sseqid = sseq_long.c_str();
+    }
     int n = snprintf(buf, buflen, "%s\t%u\t%u\t%s\t%s\t%.3f\t%d\t%d\t%.3f\t%d\t%.3f\t%d\t%d\t%d\t%d\t%d\t%c\t%d\t%.2e\t%d",
-                     query_id, qlen, h->hits, h->genome_id, h->seq_id, h->qcov_genome, h->cls, h->hsp, h->qcov_hsp,
+                     query_id, qlen, h->hits, h->genome_id, sseqid, h->qcov_genome, h->cls, h->hsp, h->qcov_hsp,
                      h->aligned_length, h->pident, h->gaps, h->qbegin + 1, h->qend + 1, h->tbegin + 1, h->tend + 1,
                      h->rc ? '-' : '+', h->seq_len, h->evalue, h->bitscore);
-    if (more_columns && n > 0) {
+    if ((flags & LM_ROW_ALL) && n > 0) {
         int m = snprintf((size_t)n < buflen ? buf + n : nullptr, (size_t)n < buflen ? buflen - n : 0, "\t%s\t%s\t%s\t%s",
                          h->cigar ? h->cigar : "", h->qseq ? h->qseq : "", h->sseq ? h->sseq : "",
                          h->align ? h->align : "");
         n += m;
     }
     return n;
+}
+int lm_format_row(const lm_hsp *h, const char *query_id, uint32_t qlen, int more_columns, char *buf, size_t buflen) {
+    return lm_format_row_ex(h, query_id, qlen, more_columns ? LM_ROW_ALL : 0, buf, buflen);
+}
+const char *lm_tsv_header(int more_columns) {
+    return more_columns ? "query\tqlen\thits\tsgenome\tsseqid\tqcovGnm\tcls\thsp\tqcovHSP\talenHSP\tpident\tgaps\tqstart\tqend\tsstart\tsend\tsstr\tslen\tevalue\tbitscore\tcigar\tqseq\tsseq\talign"
+                        : "query\tqlen\thits\tsgenome\tsseqid\tqcovGnm\tcls\thsp\tqcovHSP\talenHSP\tpident\tgaps\tqstart\tqend\tsstart\tsend\tsstr\tslen\tevalue\tbitscore";
 }
 
 void lm_stage_free(lm_stage *s) { delete s; }

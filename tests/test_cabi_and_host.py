@@ -49,7 +49,16 @@ def test_header_is_plain_c_and_the_shim_sequence_links(tmp_path):
         fa = tmp_path / "q.fa"
         fa.write_text(">q\nACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT\n")
         r = subprocess.run([exe, str(tmp_path), str(fa)], capture_output=True, text=True)
-        assert r.returncode == 1 and "no CPU path" in r.stderr
+        assert r.returncode == 255 and "no CPU path" in r.stderr      # checkError: message + exit status -1
+        # the flag checks of search.go:159-229 run before the index is opened: the reference's messages
+        for args, msg in ((["q.fa"], "flag -d/--index needed"),
+                          (["-d", "x", "-p", "4", "q.fa"], "-p/--seed-min-prefix (4) should be in the range of [5, 32]"),
+                          (["-d", "x", "-p", "20", "-P", "18", "q.fa"], "should be >= that of -p/--seed-min-prefix (20)"),
+                          (["-d", "x", "-l", "10", "q.fa"], "-l/--align-min-match-len (10) should be >="),
+                          (["-d", "x", "-Q", "101", "q.fa"], "-Q/--min-qcov-per-genome"),
+                          (["-d", "x", "--frobnicate", "q.fa"], "unknown flag")):
+            r = subprocess.run([exe] + args, capture_output=True, text=True)
+            assert r.returncode == 255 and msg in r.stderr, (args, r.stderr)
 
 
 def test_no_gpu_means_loud_failure_not_fallback(tmp_path):
@@ -94,6 +103,21 @@ def test_row_formatting_matches_reference_printf():
     r.evalue = 1.72e-43
     L.lm_format_row(C.byref(r), b"q", 10, 0, buf, 4096)
     assert buf.value.decode().split("\t")[18] == "1.72e-43"
+    # --show-sseq-idx (search.go:483-494) and -a/--all (:519-521); the header line (:426-430) is the golden's first line
+    r.chunk_idx, r.nchunks, r.seq_idx, r.nseqs = 1, 3, 0, 10
+    r.cigar, r.qseq, r.sseq, r.align = b"10M", b"ACGTACGTAC", b"ACGTACGTAC", b"||||||||||"
+    L.lm_format_row_ex.argtypes = L.lm_format_row.argtypes
+    L.lm_format_row_ex(C.byref(r), b"q", 10, 2, buf, 4096)
+    cols = buf.value.decode().split("\t")
+    assert cols[4] == "c2/3:s1/10:NZ_CP033092.2" and len(cols) == 20
+    L.lm_format_row_ex(C.byref(r), b"q", 10, 3, buf, 4096)
+    cols = buf.value.decode().split("\t")
+    assert cols[4] == "c2/3:s1/10:NZ_CP033092.2" and cols[20:] == ["10M", "ACGTACGTAC", "ACGTACGTAC", "||||||||||"]
+    L.lm_tsv_header.restype = C.c_char_p
+    L.lm_tsv_header.argtypes = [C.c_int]
+    gold_dir = os.path.join(ROOT, "tests", "golden", "demo")
+    assert L.lm_tsv_header(0).decode() == open(os.path.join(gold_dir, "q.gene.fasta.lexicmap.tsv")).readline().rstrip("\n")
+    assert L.lm_tsv_header(1).decode() == open(os.path.join(gold_dir, "q.gene.fasta.lexicmap_top-2-genomes_all.tsv")).readline().rstrip("\n")
 
 
 def test_oracle_is_not_referenced_by_the_product():

@@ -130,7 +130,8 @@ def test_rows_do_not_depend_on_which_device_implementation_of_a_stage_runs(lr_in
     """LM_WFA_MW (512 / 1024-diagonal WFA passes: a workgroup of four wavefronts or one wavefront per alignment),
     LM_PA_CHAIN_RING (Chainer2 DP with the recent anchors in LDS or through global memory), LM_WFA_R16 (16- or 32-bit ring
     cells in the short WFA classes) and LM_WFA_AK_MARGIN (problems started at the ring width |tlen - qlen| predicts, or all at
-    their class's width) choose between device paths that must agree to the byte: the rows of the long-read fixture (equal to the oracle's by the first test) with each switch off"""
+    their class's width) and LM_LOOKUP_FLAT (seed anchors emitted with the lanes over the output or over the lookups) choose
+    between device paths that must agree to the byte: the rows of the long-read fixture (equal to the oracle's by the first test) with each switch off"""
     la = _la()
     d, _ = lr_index
     seqs = [q[1] for q in lr_queries]
@@ -140,7 +141,8 @@ def test_rows_do_not_depend_on_which_device_implementation_of_a_stage_runs(lr_in
     ran = {p["name"] for p in gi.profile_get() if p["launches"] > 0}
     gi.close()
     assert any(n.startswith("k_wfa_mw") for n in ran), ran   # the fixture does reach the wide passes
-    for var, off in (("LM_WFA_MW", "0"), ("LM_PA_CHAIN_RING", "0"), ("LM_WFA_R16", "0"), ("LM_WFA_AK_MARGIN", "40")):
+    for var, off in (("LM_WFA_MW", "0"), ("LM_PA_CHAIN_RING", "0"), ("LM_WFA_R16", "0"), ("LM_WFA_AK_MARGIN", "40"),
+                     ("LM_LOOKUP_FLAT", "0")):
         monkeypatch.setenv(var, off)
         gi = la.Index(d)      # the switches are read once per handle
         gi.profile(True)

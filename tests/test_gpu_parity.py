@@ -410,27 +410,6 @@ def test_demo_c1_all_84_gene_rows_through_the_hip_path(tmp_path):
     assert len(gold) == 84 and lines == gold
 
 
-def test_c_shim_prints_the_same_tsv_as_the_ctypes_path(small_index, queries, tmp_path):
-    """f2: the call sequence of the cgo shim, restated in C99 (tests/cabi_shim.c: open, search_batch,
-    result_rows, format_row, free, close) and run as its own process, prints the TSV lines the ctypes path returns"""
-    import subprocess
-    la = _la()
-    d, _ = small_index
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = str(tmp_path / "cabi_shim")
-    subprocess.check_call(["gcc", "-std=c99", "-O1", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "cabi_shim.c"),
-                           "-L", os.path.dirname(la.LIB_PATH), "-llexicmap_hip", "-Wl,-rpath," + os.path.dirname(la.LIB_PATH),
-                           "-o", exe])
-    qs = [q for q in queries[:10] if len(q[1]) >= 31]
-    fa = tmp_path / "q.fa"
-    fa.write_text("".join(">%s\n%s\n" % (q[0], q[1].decode().lower()) for q in qs))  # the reader loop upper-cases
-    out = subprocess.run([exe, d, str(fa)], capture_output=True, text=True, check=True).stdout.rstrip("\n").split("\n")
-    gi = la.Index(d)
-    want = gi.search_tsv([q[0] for q in qs], [q[1] for q in qs])
-    gi.close()
-    assert out == want and len(want) > 20
-
-
 def test_sharded_index_union_equals_whole(small_index, queries):
     """§8e: genomes sharded over 2 'ranks' (same device here); the union of per-shard rows, re-sorted by the final
     ordering rule, equals the single-shard result (hits column recomputed)"""
