@@ -504,6 +504,22 @@ def main():
     loader = None
     if args.loader_check and gpu_built and world == 1 and not shard_of:
         sdir = os.path.join(tempfile.mkdtemp(prefix="lm_saved_"), "saved.lmi")
+
+        def content_digest(ix_):
+            """sha256 over the (k-mer, value) lists of 64 evenly spaced masks and four slices of genome bases: the CONTENTS of
+            the packed image, not only its sizes"""
+            hh = hashlib.sha256()
+            M_ = ix_.info()["masks"]
+            for m_ in range(0, M_, max(1, M_ // 64)):
+                k_, v_ = ix_.mask_seeds(m_)
+                hh.update(k_.tobytes())
+                hh.update(v_.tobytes())
+            ng_ = ix_.info()["genomes"]
+            for g_ in sorted({0, ng_ // 3, (2 * ng_) // 3, ng_ - 1}):
+                hh.update(ix_.fetch(g_, 0, min(100000, wl["genome_len"])))
+            return hh.hexdigest()
+
+        digest0 = content_digest(gi)
         t0 = time.time()
         gi.save(sdir, chunks=32)
         t_save = time.time() - t0
@@ -513,10 +529,13 @@ def main():
         gi = la.Index(sdir, device=local_rank)
         t_load = time.time() - t0
         info2 = gi.info()
-        same = all(info[f] == info2[f] for f in ("seeds", "genomes", "genome_bases", "seed_bytes", "outlier_seeds", "key_bits", "val_bits"))
+        sizes_same = all(info[f] == info2[f] for f in ("seeds", "genomes", "genome_bases", "seed_bytes", "outlier_seeds", "key_bits", "val_bits"))
+        same = sizes_same and content_digest(gi) == digest0
         loader = dict(index_files_bytes=int(disk), save_s=round(t_save, 2), open_s=round(t_load, 2),
                       open_GBps_of_files=round(disk / t_load / 1e9, 3), seeds_per_s=round(info2["seeds"] / t_load),
-                      image_equal_to_hbm_built=bool(same),
+                      image_sizes_equal_to_hbm_built=bool(sizes_same), sampled_contents_equal_to_hbm_built=bool(same),
+                      contents_compared="sha256 over the (k-mer, value) lists of 64 evenly spaced masks (lm_index_mask_seeds) and "
+                                        "100-kb slices of four genomes, before the save and after the load",
                       note="lm_index_save -> lm_index_open on the box's local disk; the searches below run on the LOADED index")
         log("[rank 0] loader check: %s" % loader)
         shutil.rmtree(os.path.dirname(sdir), ignore_errors=True)

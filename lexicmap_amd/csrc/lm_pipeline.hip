@@ -1521,9 +1521,19 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
             fprintf(stderr, "[lm] pseudo-alignment: %lld window bases, %lld candidates (fullest of %d segments: %lld of %lld), %lld anchors\n",
                     (long long)W, (long long)ncand, nseg, (long long)seg_max, (long long)seg_cap, (long long)TP);
         // candidates and anchors share the estimate; a segment that overflowed dropped candidates: size for the fullest
-        const int64_t need = std::max<int64_t>(seg_max > seg_cap ? seg_max * nseg + seg_max * nseg / 8 : ncand, TP);
+        int64_t need = std::max<int64_t>(seg_max > seg_cap ? seg_max * nseg + seg_max * nseg / 8 : ncand, TP);
         if (need <= a.pa_cap && seg_max <= seg_cap) break;
         if (attempt > 4) throw HipError("pseudo-alignment anchor buffer keeps overflowing");
+        if (by_group && seg_max > seg_cap && seg_max * nseg > 3 * std::max<int64_t>(std::max(ncand, TP), 1)) {
+            // Segments by task-group range are as uneven as the batch: one 200-kb plasmid query among genes (or the reads of a
+            // mixed batch) fills its range with 10-50 x the mean, and a uniform segment capacity sized for the fullest range
+            // would blow the whole list - and the anchor buffers that share its size - up by that factor (an out-of-memory
+            // or a halved chunk exactly on the mixed workloads).  Such a chunk takes the balanced per-wavefront layout.
+            by_group = false;
+            need = std::max<int64_t>(ncand + ncand / 8, TP);
+            if (getenv("LM_DEBUG")) fprintf(stderr, "[lm] pseudo-alignment: uneven ranges (fullest %lld x %d segments vs %lld candidates): per-wavefront segments for this chunk\n",
+                                            (long long)seg_max, nseg, (long long)ncand);
+        }
         a.pa_cap = std::max<int64_t>(need + need / 8, a.pa_cap + a.pa_cap / 4);
     }
     // anchors per window byte of what has been seen (sizes the next chunks so that they need no halving); small chunks
@@ -1948,7 +1958,11 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
             int stt = tmp[i].r.status;
             n3 += stt == 3;
             n1 += stt == 1;
-            if (stt == 3) { // wider than this ring (or not plain ACGT)
+            if (stt == 3 && tmp[i].r.score == 0) { // not plain ACGT (a width overflow reports the width): no ring width helps,
+                std::lock_guard<std::mutex> l(fb_mu); // the byte-comparing kernel takes it at once
+                fb_items.push_back(i);
+                fb_level.push_back(1);
+            } else if (stt == 3) { // wider than this ring
                 too_wide.push_back(i);
             } else if (stt == 1) { // scratch or ops overflow: per-problem scratch in the global-memory kernel
                 std::lock_guard<std::mutex> l(fb_mu);

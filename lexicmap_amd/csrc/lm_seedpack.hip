@@ -530,14 +530,15 @@ extern "C" lm_status lm_index_mask_seeds(lm_index *ix, int32_t mask, uint64_t *k
     }
 }
 
-// ---- the HBM image written back in the reference's on-disk format ---------------------------------------------------------
-// `lexicmap index` output as the reference reads it: info.toml (lib-index-build.go:1914-1932),
-// masks.bin, seeds/chunk_NNN.bin + .idx (kv/kv-data.go:126-602: per mask the distinct k-mers ascending, two per record,
+// ---- the HBM image written back to disk -----------------------------------------------------------------------------------
+// `lexicmap index` output as the reference lays it out, EXCEPT masks.bin, which is written in this
+// build's own LMMASKS1 layout (lexichash's file layout is not in the reference tree): info.toml (lib-index-build.go:1914-1932),
+// seeds/chunk_NNN.bin + .idx (kv/kv-data.go:126-602: per mask the distinct k-mers ascending, two per record,
 // k-mer deltas and value counts group-varint coded, 7-byte values while there are <= 512 genome batches; the .idx holds the
 // first k-mer and offset of every anchor partition present), genomes/batch_NNNN/genomes.bin + .idx (genome/genome.go:217-357),
 // genomes.map.bin (lib-index-build.go:649-655).  What it is for here: the GPU-built benchmark sets become reference-format
 // indexes, so the loader (lm_index_open) is exercised and timed at their size and its packed image can be compared with the
-// one the builder made in HBM; and any HBM-resident index can be handed to the Go `lexicmap search`.
+// one the builder made in HBM.  (The Go `lexicmap search` could read everything but that masks.bin.)
 namespace lm {
 namespace {
 struct OutFile {
@@ -634,6 +635,9 @@ extern "C" lm_status lm_index_save(lm_index *ix, const char *dir_c, int chunks) 
         const int M = h.M, K = h.k;
         if (chunks < 1) chunks = 1;
         if (chunks > M) chunks = M;
+        // info.toml names the number of chunk FILES: ceil(M / ceil(M / chunks)) of them are written (M = 100 masks asked into 16
+        // chunks are 15 files of 7 masks), as the reference's writer and the oracle's do
+        chunks = (M + (M + chunks - 1) / chunks - 1) / ((M + chunks - 1) / chunks);
         const int nbatches = std::max(1, h.genome_batches > 0 ? h.genome_batches : (int)((h.genomes.size() + 4999) / 5000));
         const bool use7 = nbatches <= 512; // kv-data.go:137
         if (!make_dir(dir) || !make_dir(dir + "/seeds") || !make_dir(dir + "/genomes")) throw HipError("lm_index_save: cannot create " + dir);

@@ -19,6 +19,7 @@ def _row_dtype():
 
 
 ROW_DTYPE = _row_dtype()
+PTR_FIELDS = ("genome_id", "seq_id", "cigar", "qseq", "sseq", "align")  # process-local addresses
 
 
 def pack_rows(rows):
@@ -56,9 +57,9 @@ def all_gather_rows(arr, device="cpu", host_on=None):
     import torch.distributed as dist
     world = dist.get_world_size()
     rank = dist.get_rank()
-    arr = np.ascontiguousarray(arr, dtype=ROW_DTYPE).copy()
-    for f in ("genome_id", "seq_id", "cigar", "qseq", "sseq", "align"):
-        arr[f] = 0  # process-local addresses mean nothing on another rank
+    # (no private copy: the pointer columns hold process-local addresses that mean nothing on another rank, and every
+    # consumer of the gathered rows - lm_merge_sharded, merge_sharded, merge_query_sharded - clears them itself)
+    arr = np.ascontiguousarray(arr, dtype=ROW_DTYPE)
     item = ROW_DTYPE.itemsize
     payload = torch.from_numpy(arr.view(np.uint8).reshape(-1)) if len(arr) else torch.zeros(0, dtype=torch.uint8)
     size = torch.tensor([len(arr)], dtype=torch.int64, device=device)
@@ -119,6 +120,8 @@ def merge_sharded(per_rank):
     # order: query asc, best desc, genome asc, original row order
     o2 = np.lexsort((idx[o], gs, -best[gid], qs))
     out = _cat([allr[o][o2]])  # fresh zeroed records: fancy indexing leaves the struct padding undefined
+    for f in PTR_FIELDS:
+        out[f] = 0
     # hits = genomes per query
     gq = qs[starts]
     uq, cnt = np.unique(gq, return_counts=True)
@@ -131,7 +134,10 @@ def merge_sharded(per_rank):
 def merge_query_sharded(per_rank):
     """query-sharded ranks: rows are already final per query and grouped per query; the order across queries is
     arrival order in the reference (search.go:47), here rank order"""
-    return _cat(per_rank)
+    out = _cat(per_rank)
+    for f in PTR_FIELDS:
+        out[f] = 0
+    return out
 
 
 def merge_sharded_c(per_rank, index=None):
@@ -150,16 +156,25 @@ def merge_sharded_c(per_rank, index=None):
         raise RuntimeError("lm_merge_sharded failed (%d)" % st)
     rows_p = C.POINTER(Hsp)()
     k = L.lm_result_rows(res, C.byref(rows_p))
+    if index is None:
+        # a view of the library's result (its pointer columns are NULL without an index): no copy of the merged rows - at
+        # 8 shards x 6e5 rows the copy out and the six strided column writes were a third of the host-side merge
+        if not k:
+            L.lm_result_free(res)
+            return np.zeros(0, dtype=ROW_DTYPE)
+        import weakref
+        buf = (C.c_char * (k * C.sizeof(Hsp))).from_address(C.addressof(rows_p.contents))
+        out = np.frombuffer(buf, dtype=ROW_DTYPE)
+        weakref.finalize(buf, L.lm_result_free, res)  # out -> buf keeps the rows alive
+        return out
     out = np.zeros(k, dtype=ROW_DTYPE)
     if k:
         C.memmove(out.ctypes.data, rows_p, k * C.sizeof(Hsp))
-    names = None
-    if index is not None and k:
-        names = [(rows_p[i].genome_id, rows_p[i].seq_id) for i in range(k)]
+    names = [(rows_p[i].genome_id, rows_p[i].seq_id) for i in range(k)] if k else None
     L.lm_result_free(res)
-    for f in ("genome_id", "seq_id", "cigar", "qseq", "sseq", "align"):
+    for f in PTR_FIELDS:
         out[f] = 0
-    return (out, names) if index is not None else out
+    return out, names
 
 
 def topn_merge(cands, top_n):

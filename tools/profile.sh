@@ -1,6 +1,8 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): the bench line of one workload, rocprofv3 kernel stats of the same command, and separate
-# PMC passes (FETCH_SIZE, WRITE_SIZE, SQ instruction mix / waits) - counters are never collected together with tracing.
+# Runs on the GPU box (via gpurun): rocprofv3 kernel stats of the bench command, separate PMC passes (FETCH_SIZE, WRITE_SIZE,
+# SQ instruction mix / waits) - counters are never collected together with tracing - and LAST the bench line of the workload,
+# which reads the summaries of those passes (copied into profiles/ of the box's copy of the tree first), so that
+# roofline.traffic / instruction_issue of the line are filled by the run itself and nothing is refilled afterwards.
 # Every summary is stamped with the hash of the library sources (bench.py source_hash): bench.py refuses PMC passes taken
 # on other sources.   usage: tools/profile.sh <workload> [steps] [extra bench args...]
 P=r04
@@ -15,8 +17,6 @@ export TMPDIR=/tmp
 cd $R
 H=$(python -c "import bench; print(bench.source_hash())")
 echo "workload $W, sources $H"
-timeout 1500 python bench.py --workload $W --steps $STEPS --warmup 1 $EXTRA > gpurun_out/${P}_${W}_bench.json 2> gpurun_out/${P}_${W}_bench.err
-tail -2 gpurun_out/${P}_${W}_bench.err
 cd /tmp
 rm -rf /tmp/prof_ks /tmp/prof_f /tmp/prof_w /tmp/prof_sq
 timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -o ks -- python $R/bench.py --workload $W --steps $STEPS --warmup 1 --no-cpu-baseline --no-exclusive-step $EXTRA > /tmp/prof_ks.log 2>&1
@@ -37,3 +37,8 @@ python $R/tools/summarize_rocprof.py /tmp/prof_w $R/gpurun_out/${P}_${W}_pmc_wri
 timeout 1500 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d /tmp/prof_sq -o sq -- python $R/bench.py --workload $W --steps 1 --warmup 0 --no-cpu-baseline --no-exclusive-step $EXTRA > /tmp/prof_sq.log 2>&1
 python $R/tools/summarize_rocprof.py /tmp/prof_sq $R/gpurun_out/${P}_${W}_pmc_sq.json $H "rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -- python bench.py --workload $W --steps 1 --warmup 0 --no-cpu-baseline --no-exclusive-step $EXTRA" | grep -E "^k_(wfa|pa_|extend|lookup|chain)"
 tail -n 2 /tmp/prof_f.log /tmp/prof_w.log /tmp/prof_sq.log
+# the passes of THESE sources where bench.py looks for them, then the bench line
+cp $R/gpurun_out/${P}_${W}_pmc_fetch.json $R/gpurun_out/${P}_${W}_pmc_write.json $R/gpurun_out/${P}_${W}_pmc_sq.json $R/profiles/
+cd $R
+timeout 1500 python bench.py --workload $W --steps $STEPS --warmup 1 $EXTRA > gpurun_out/${P}_${W}_bench.json 2> gpurun_out/${P}_${W}_bench.err
+tail -2 gpurun_out/${P}_${W}_bench.err

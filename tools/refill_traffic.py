@@ -39,11 +39,13 @@ def fill(obj, workload):
             issue["issue_frac_valu"] = round(issue.get("sq_insts_valu_per_launch", 0) / (dur_ms * 1e-3) / bench.VALU_ISSUE_PEAK, 4)
             issue["issue_frac_salu"] = round(issue.get("sq_insts_salu_per_launch", 0) / (dur_ms * 1e-3) / bench.SALU_ISSUE_PEAK, 4)
             issue["issue_frac_valu_measured_mix"] = round(issue.get("sq_insts_valu_per_launch", 0) / (dur_ms * 1e-3) / bench.VALU_ISSUE_PEAK_MIX, 4)
+            issue["issue_filled"] = NOTE
             obj["instruction_issue"] = issue
             n += 1
     iss = obj.get("instruction_issue")
     if isinstance(iss, dict) and "issue_frac_valu_measured_mix" not in iss and dur_ms:
         iss["issue_frac_valu_measured_mix"] = round(iss.get("sq_insts_valu_per_launch", 0) / (dur_ms * 1e-3) / bench.VALU_ISSUE_PEAK_MIX, 4)
+        iss["issue_filled"] = NOTE
         n += 1
     for sib in obj.get("other_instantiations", []):
         n += fill(sib, workload)
