@@ -29,11 +29,6 @@ inline uint64_t be64(const uint8_t *b) {
     for (int i = 0; i < 8; i++) v = (v << 8) | b[i];
     return v;
 }
-inline uint64_t be56(const uint8_t *b) {
-    uint64_t v = 0;
-    for (int i = 0; i < 7; i++) v = (v << 8) | b[i];
-    return v;
-}
 inline uint32_t be32(const uint8_t *b) { return ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | b[3]; }
 inline uint32_t be16(const uint8_t *b) { return ((uint32_t)b[0] << 8) | b[1]; }
 
@@ -62,12 +57,17 @@ long long toml_int(const std::string &text, const char *key, long long dflt) {
     return dflt;
 }
 
-// group varint of two uint64 (util/varint-GB.go:88-113)
-inline int gv2(uint8_t ctrl, const uint8_t *p, uint64_t &a, uint64_t &b) {
-    int l1 = ((ctrl >> 3) & 7) + 1, l2 = (ctrl & 7) + 1;
-    a = b = 0;
-    for (int i = 0; i < l1; i++) a = (a << 8) | *p++;
-    for (int i = 0; i < l2; i++) b = (b << 8) | *p++;
+// group varint of two uint64 (util/varint-GB.go:88-113: control byte = the two byte lengths - 1), read from a buffer with >= 16
+// readable bytes behind every record (decode_seed_chunk pads its copy of the file): two unaligned 8-byte big-endian loads
+inline uint64_t load_be64(const uint8_t *p) {
+    uint64_t v;
+    memcpy(&v, p, 8);
+    return __builtin_bswap64(v);
+}
+inline int gv2_fast(uint8_t ctrl, const uint8_t *p, uint64_t &a, uint64_t &b) {
+    const int l1 = ((ctrl >> 3) & 7) + 1, l2 = (ctrl & 7) + 1;
+    a = load_be64(p) >> (64 - 8 * l1);
+    b = load_be64(p + l1) >> (64 - 8 * l2);
     return l1 + l2;
 }
 
@@ -78,15 +78,31 @@ inline int gv2(uint8_t ctrl, const uint8_t *p, uint64_t &a, uint64_t &b) {
 std::string decode_seed_chunk(const std::string &path, const HostIndex &idx, SeedChunk &out, int &status,
                               int &anchor_prefix_out) {
     const std::vector<int64_t> &batch_first = idx.batch_first;
-    out.kmers.clear();
-    out.vals.clear();
-    out.masks.clear();
-    std::vector<uint8_t> buf;
-    if (!read_all(path, buf)) {
-        status = 1;
-        return "cannot read " + path;
+    out.n = 0;
+    std::vector<uint8_t> &buf = out.file;
+    size_t file_bytes = 0;
+    {   // the file's bytes + 16 of padding (the 8-byte loads of gv2_fast / the value reads may look past the last record)
+        File f(path);
+        if (!f.ok()) {
+            status = 1;
+            return "cannot read " + path;
+        }
+        fseek(f.f, 0, SEEK_END);
+        const long nb = ftell(f.f);
+        fseek(f.f, 0, SEEK_SET);
+        if (nb < 0) {
+            status = 1;
+            return "cannot read " + path;
+        }
+        file_bytes = (size_t)nb;
+        if (buf.size() < file_bytes + 16) buf.resize(file_bytes + 16);
+        if (file_bytes && !f.read(buf.data(), file_bytes)) {
+            status = 1;
+            return "cannot read " + path;
+        }
+        memset(buf.data() + file_bytes, 0, 16);
     }
-    if (buf.size() < 32 || memcmp(buf.data(), ".kv-data", 8) != 0) {
+    if (file_bytes < 32 || memcmp(buf.data(), ".kv-data", 8) != 0) {
         status = 2;
         return "k-mer-value data: invalid binary format: " + path;
     }
@@ -112,8 +128,18 @@ std::string decode_seed_chunk(const std::string &path, const HostIndex &idx, See
         anchor_prefix_out = h[12]; // users might have run 'utils reindex-seeds' (lib-index-search.go:611)
     }
     size_t p = 32;
-    const size_t n = buf.size();
+    const size_t n = file_bytes;
     const int sc = idx.shard_count;
+    // every seed is at least nvb bytes of the file: the arrays are cut once (and kept: SeedChunk)
+    const size_t ub = (n - 32) / (size_t)nvb + 1;
+    if (out.kmers.size() < ub) {
+        out.kmers.resize(ub);
+        out.vals.resize(ub);
+        out.masks.resize(ub);
+    }
+    uint64_t *ok = out.kmers.data(), *ov = out.vals.data();
+    uint16_t *om = out.masks.data();
+    size_t ns = 0;
     for (int64_t im = 0; im < nmask; im++) {
         if (p + 8 > n) {
             status = 2;
@@ -138,7 +164,7 @@ std::string decode_seed_chunk(const std::string &path, const HostIndex &idx, See
             bool last_pair = (ctrl & 128) != 0, has2 = (ctrl & 64) == 0;
             ctrl &= 63;
             uint64_t d1, d2, l1, l2;
-            p += gv2(ctrl, &buf[p], d1, d2);
+            p += gv2_fast(ctrl, &buf[p], d1, d2);
             uint64_t k1 = d1 + off, k2 = k1 + d2;
             off = k2;
             if (p + 1 > n || p + 1 + (size_t)(((buf[p] >> 3) & 7) + (buf[p] & 7) + 2) > n) {
@@ -146,7 +172,7 @@ std::string decode_seed_chunk(const std::string &path, const HostIndex &idx, See
                 return "k-mer-value data: broken file: " + path;
             }
             ctrl = buf[p++];
-            p += gv2(ctrl, &buf[p], l1, l2);
+            p += gv2_fast(ctrl, &buf[p], l1, l2);
             for (int w = 0; w < 2; w++) {
                 if (w == 1 && last_pair && !has2) break;
                 uint64_t kmer = w == 0 ? k1 : k2, lv = w == 0 ? l1 : l2;
@@ -155,7 +181,7 @@ std::string decode_seed_chunk(const std::string &path, const HostIndex &idx, See
                     return "k-mer-value data: broken file: " + path;
                 }
                 for (uint64_t j = 0; j < lv; j++) {
-                    uint64_t v = use7 ? be56(&buf[p]) : be64(&buf[p]);
+                    uint64_t v = use7 ? load_be64(&buf[p]) >> 8 : load_be64(&buf[p]);
                     p += nvb;
                     if (sc > 1) {
                         uint64_t bg = v >> 30;
@@ -163,14 +189,16 @@ std::string decode_seed_chunk(const std::string &path, const HostIndex &idx, See
                         int64_t g = (batch + 1 < batch_first.size() ? batch_first[batch] : 0) + (int64_t)gi;
                         if (g < 0 || g >= (int64_t)idx.g2local.size() || idx.g2local[(size_t)g] < 0) continue;
                     }
-                    out.kmers.push_back(kmer);
-                    out.vals.push_back(v);
-                    out.masks.push_back(mk);
+                    ok[ns] = kmer;
+                    ov[ns] = v;
+                    om[ns] = mk;
+                    ns++;
                 }
             }
             if (last_pair) break;
         }
     }
+    out.n = ns;
     return "";
 }
 

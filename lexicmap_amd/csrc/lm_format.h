@@ -58,9 +58,13 @@ std::string load_index(const std::string &dir, int shard_rank, int shard_count, 
 // One seeds/chunk_NNN.bin decoded into flat arrays (k-mer, value, mask) of the seeds whose genome is on this shard: what the
 // seed packer is shown.  The reference reads these files with one goroutine per file (kv-reader.go:762-1021); the loader
 // streams them - decode, hand to the packer, drop - so the host never holds more than a few files.
+// A SeedChunk is REUSED for file after file: its arrays only grow (`n` seeds are valid), so that after the first files no
+// decode touches fresh pages - zero-filling and faulting in 18 B per seed of new memory per file cost more than the decoding.
 struct SeedChunk {
     std::vector<uint64_t> kmers, vals;
     std::vector<uint16_t> masks;
+    std::vector<uint8_t> file; // the file's bytes (+ 16 of padding)
+    size_t n = 0;
 };
 std::string decode_seed_chunk(const std::string &path, const HostIndex &idx, SeedChunk &out, int &status, int &anchor_prefix);
 

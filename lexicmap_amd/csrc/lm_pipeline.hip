@@ -15,6 +15,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <sys/stat.h>
 #include <stdexcept>
 #include <tuple>
 #include <string>
@@ -1001,42 +1002,85 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
         v.ngenomes = (int64_t)h.genomes.size();
         v.shard_rank = h.shard_rank;
         v.shard_count = h.shard_count;
-        {   // packed seed image: every chunk file is decoded and shown to the packer twice (count, then place). Files are
-            // decoded by a few host threads ahead of the upload and dropped right after it: the host never holds more than
-            // `ahead` files (the reference's RAM form of the whole index would be 16 B/seed of host memory).
+        {   // packed seed image: every chunk file is decoded and shown to the packer twice (count, then place).  Files are
+            // decoded by the host threads ahead of the upload into a small pool of REUSED chunk slots (after the first files
+            // no decode touches fresh pages: faulting in and zero-filling 18 B per seed of new memory per file cost more than
+            // the decoding itself), whose arrays are registered with the driver once they stop growing, so that the uploads
+            // are DMA from pinned memory.  The host never holds more than the pool (the reference's RAM form of the whole
+            // index would be 16 B/seed of host memory).
             SeedPacker sp;
             sp.begin(ix, (int64_t)h.genomes.size(), max_len);
             const size_t nf = h.seed_files.size();
-            const size_t ahead = std::min<size_t>(4, std::max<size_t>(1, nf));
+            size_t nslots = std::min<size_t>(std::max<size_t>(2, (size_t)host_threads()), std::max<size_t>(1, nf));
+            {   // a slot holds a file and its decoded seeds (~3.6 x the file): the pool may take a third of the free host memory
+                int64_t biggest = 1;
+                for (auto &f : h.seed_files) {
+                    struct stat sb;
+                    if (stat(f.c_str(), &sb) == 0) biggest = std::max<int64_t>(biggest, (int64_t)sb.st_size);
+                }
+                int64_t avail = (int64_t)64 << 30;
+                if (FILE *mf = fopen("/proc/meminfo", "r")) {
+                    char line[256];
+                    while (fgets(line, sizeof line, mf)) {
+                        long long kb = 0;
+                        if (sscanf(line, "MemAvailable: %lld kB", &kb) == 1) avail = kb * 1024;
+                    }
+                    fclose(mf);
+                }
+                const int64_t per_slot = biggest * 36 / 10 + (1 << 20);
+                nslots = (size_t)std::max<int64_t>(std::min<int64_t>(2, (int64_t)nf), std::min<int64_t>((int64_t)nslots, avail / 3 / per_slot));
+                if (const char *e = getenv("LM_LOADER_SLOTS")) nslots = (size_t)std::max(1, std::min((int)nf, atoi(e)));
+                if (nslots < 1) nslots = 1;
+            }
+            struct Slot {
+                SeedChunk c;
+                void *reg[3] = {nullptr, nullptr, nullptr}; // what is registered with the driver (the arrays' current storage)
+                ~Slot() {
+                    for (void *r : reg)
+                        if (r) (void)hipHostUnregister(r);
+                }
+                void pin() { // (re-)register the arrays when their storage moved: they only grow, a few times in all
+                    void *cur[3] = {c.kmers.data(), c.vals.data(), c.masks.data()};
+                    const size_t bytes[3] = {c.kmers.size() * 8, c.vals.size() * 8, c.masks.size() * 2};
+                    for (int j = 0; j < 3; j++) {
+                        if (cur[j] == reg[j] || bytes[j] == 0) continue;
+                        if (reg[j]) (void)hipHostUnregister(reg[j]);
+                        reg[j] = hipHostRegister(cur[j], bytes[j], hipHostRegisterDefault) == hipSuccess ? cur[j] : nullptr;
+                        if (!reg[j]) (void)hipGetLastError(); // pageable upload then: slower, not wrong
+                    }
+                }
+            };
             DBuf<uint64_t> dk, dv;
             DBuf<uint16_t> dm;
+            std::vector<std::unique_ptr<Slot>> slot(nslots); // (both passes use the same slots: warm pages, registered once)
+            for (auto &sl : slot) sl.reset(new Slot());
             for (int pass = 0; pass < 2; pass++) {
                 // declaration order matters: `fut` is destroyed FIRST when an exception unwinds this scope (a failed upload,
                 // DeviceOOM) and a std::async future joins its task in its destructor - so the decode tasks still running
-                // have finished before the chunks and status slots they write into are freed
-                std::vector<std::unique_ptr<SeedChunk>> chunk(nf);
+                // have finished before the slots and status entries they write into are freed
                 std::vector<int> stat(nf, 0), anch(nf, -1);
                 std::vector<std::future<std::string>> fut(nf);
                 auto launch = [&](size_t i) {
-                    chunk[i].reset(new SeedChunk());
                     fut[i] = std::async(std::launch::async, [&, i]() {
-                        return decode_seed_chunk(h.seed_files[i], h, *chunk[i], stat[i], anch[i]);
+                        return decode_seed_chunk(h.seed_files[i], h, slot[i % nslots]->c, stat[i], anch[i]);
                     });
                 };
-                for (size_t i = 0; i < std::min(ahead, nf); i++) launch(i);
+                for (size_t i = 0; i < std::min(nslots, nf); i++) launch(i);
                 for (size_t i = 0; i < nf; i++) {
                     const std::string e2 = fut[i].get();
-                    if (i + ahead < nf) launch(i + ahead);
                     if (!e2.empty()) {
                         for (size_t j = i + 1; j < nf; j++)
                             if (fut[j].valid()) fut[j].wait();
                         g_open_error = e2;
                         const int stt = stat[i];
+                        slot.clear(); // (before the handle and its device context go)
                         lm_index_close(ix);
                         return stt == 2 ? LM_ERR_FORMAT : LM_ERR_IO;
                     }
-                    SeedChunk &c = *chunk[i];
-                    const int64_t cnt = (int64_t)c.kmers.size();
+                    Slot &sl = *slot[i % nslots];
+                    sl.pin();
+                    SeedChunk &c = sl.c;
+                    const int64_t cnt = (int64_t)c.n;
                     const int64_t slice = (int64_t)32 << 20;
                     for (int64_t o = 0; o < cnt; o += slice) {
                         const int64_t m = std::min(slice, cnt - o);
@@ -1052,7 +1096,7 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
                             sp.place(dm.p, dk.p, dv.p, m);
                         sync(ix); // the staging buffers are reused
                     }
-                    chunk[i].reset();
+                    if (i + nslots < nf) launch(i + nslots); // this slot's next file
                 }
                 if (pass == 0) sp.end_count();
             }

@@ -28,15 +28,17 @@ def test_single_rank_rccl_all_gather_rows_roundtrip():
         rows["batch_genome"] = rng.integers(0, 1000, 5000)
         rows["bitscore"] = rng.integers(50, 3000, 5000)
         rows["pident"] = rng.integers(70, 101, 5000).astype(np.float64)
-        rows["genome_id"] = 12345  # a process-local address: must not travel
+        rows["genome_id"] = 12345  # a process-local address: means nothing on another rank - every consumer clears it
         for rep in range(2):       # the second call reuses the pinned staging buffer
             got = merge.all_gather_rows(rows, device="cuda", host_on=0)
             assert len(got) == 1 and len(got[0]) == 5000
-            exp = rows.copy()
-            exp["genome_id"] = 0
-            assert merge._cat([got[0]]).tobytes() == merge._cat([exp]).tobytes()
+            assert merge._cat([got[0]]).tobytes() == merge._cat([rows]).tobytes()
         merged = merge.merge_sharded(got)
         assert len(merged) == 5000 and (np.diff(merged["query"].astype(np.int64)) >= 0).all()
+        order = np.lexsort((np.arange(5000), rows["query"]))
+        merged_c = merge.merge_sharded_c([rows[order]])       # (the C merge wants each shard's rows grouped by query)
+        for out in (merged, merged_c, merge.merge_query_sharded(got)):
+            assert len(out) == 5000 and all((out[f] == 0).all() for f in merge.PTR_FIELDS)
         empty = merge.all_gather_rows(rows[:0], device="cuda", host_on=0)
         assert len(empty) == 1 and len(empty[0]) == 0
     finally:
