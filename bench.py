@@ -512,8 +512,9 @@ def main():
             M_ = ix_.info()["masks"]
             for m_ in range(0, M_, max(1, M_ // 64)):
                 k_, v_ = ix_.mask_seeds(m_)
-                hh.update(k_.tobytes())
-                hh.update(v_.tobytes())
+                o_ = np.lexsort((v_, k_))      # seeds with one k-mer come out in the order they were placed: not part of the image
+                hh.update(k_[o_].tobytes())
+                hh.update(v_[o_].tobytes())
             ng_ = ix_.info()["genomes"]
             for g_ in sorted({0, ng_ // 3, (2 * ng_) // 3, ng_ - 1}):
                 hh.update(ix_.fetch(g_, 0, min(100000, wl["genome_len"])))

@@ -8,7 +8,10 @@
 #include <cstdio>
 #include <cstring>
 #include <dirent.h>
+#include <fcntl.h>
 #include <map>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace lm {
 
@@ -40,6 +43,47 @@ bool read_all(const std::string &path, std::vector<uint8_t> &buf) {
     fseek(f.f, 0, SEEK_SET);
     buf.resize((size_t)n);
     return n == 0 || f.read(buf.data(), (size_t)n);
+}
+// a big file (the genome batches: GBs each) read by several threads with pread: one thread copies out of the page cache at
+// 2-3 GB/s, which made the genomes a third of the time the loader took
+bool read_all_mt(const std::string &path, std::vector<uint8_t> &buf) {
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) {
+        close(fd);
+        return false;
+    }
+    const size_t n = (size_t)sb.st_size;
+    buf.resize(n);
+    const size_t piece = (size_t)64 << 20;
+    const size_t npieces = (n + piece - 1) / piece;
+    unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    if (npieces < nt) nt = (unsigned)std::max<size_t>(1, npieces);
+    std::atomic<size_t> next{0};
+    std::atomic<bool> ok{true};
+    auto body = [&]() {
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= npieces) break;
+            size_t off = i * piece, left = std::min(piece, n - off);
+            while (left) {
+                const ssize_t r = pread(fd, buf.data() + off, left, (off_t)off);
+                if (r <= 0) {
+                    ok = false;
+                    return;
+                }
+                off += (size_t)r;
+                left -= (size_t)r;
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(body);
+    body();
+    for (auto &t : th) t.join();
+    close(fd);
+    return ok;
 }
 
 long long toml_int(const std::string &text, const char *key, long long dflt) {
@@ -202,7 +246,7 @@ std::string decode_seed_chunk(const std::string &path, const HostIndex &idx, See
     return "";
 }
 
-std::string load_index(const std::string &dir, int shard_rank, int shard_count, HostIndex &out, int &status) {
+std::string load_index(const std::string &dir, int shard_rank, int shard_count, HostIndex &out, int &status, bool genomes_now) {
     status = 0;
     if (shard_count < 1) shard_count = 1;
     out.shard_rank = shard_rank;
@@ -282,23 +326,9 @@ std::string load_index(const std::string &dir, int shard_rank, int shard_count, 
 
     // genomes: batch_NNNN/genomes.bin + .idx
     out.batch_first.assign(out.genome_batches + 1, 0);
-    std::map<uint64_t, std::string> id_of;
-    if (read_all(dir + "/genomes.map.bin", buf)) {
-        size_t p = 0;
-        while (p + 2 <= buf.size()) {
-            uint32_t l = be16(&buf[p]);
-            p += 2;
-            if (p + l + 8 > buf.size()) break;
-            std::string id((const char *)&buf[p], l);
-            p += l;
-            id_of[be64(&buf[p])] = id;
-            p += 8;
-        }
-    } else {
-        status = 1;
-        return "failed to read " + dir + "/genomes.map.bin";
-    }
     // pass 1: genomes per batch -> dense numbers; genome chunk lists -> shard of every genome
+    size_t gbits_bound = 0; // packed bytes of all genomes (+ padding): the store is cut once, not grown batch by batch
+    std::vector<int32_t> rec_len; // bases of every genome record, dense order (from the .idx files)
     {
         int64_t g0 = 0;
         for (int b = 0; b < out.genome_batches; b++) {
@@ -310,7 +340,13 @@ std::string load_index(const std::string &dir, int shard_rank, int shard_count, 
                 return std::string("genome data: invalid binary format: ") + name;
             }
             out.batch_first[b] = g0;
-            g0 += be32(&ib[20]);
+            const uint32_t nrec = be32(&ib[20]);
+            g0 += nrec;
+            for (uint32_t r = 0; r < nrec && 24 + (size_t)r * 12 + 12 <= ib.size(); r++) { // bases per record -> packed bytes, padded
+                const uint32_t bases = be32(&ib[24 + (size_t)r * 12 + 8]);
+                gbits_bound += ((size_t)bases + 3) / 4 + 16;
+                rec_len.push_back((int32_t)bases);
+            }
         }
         out.batch_first[out.genome_batches] = g0;
         std::vector<int64_t> canon((size_t)g0);
@@ -347,19 +383,92 @@ std::string load_index(const std::string &dir, int shard_rank, int shard_count, 
             for (int64_t g = 0; g < g0; g++)
                 if ((int)(canon[(size_t)g] % shard_count) == shard_rank) out.g2local[(size_t)g] = nl++;
         }
+        // what the seed packer needs of the genomes, known before their batch files are read (load_index_genomes)
+        out.n_local_genomes = 0;
+        out.max_genome_len = 1;
+        for (int64_t g = 0; g < g0 && (size_t)g < rec_len.size(); g++)
+            if (out.g2local.empty() || out.g2local[(size_t)g] >= 0) {
+                out.n_local_genomes++;
+                out.max_genome_len = std::max<int64_t>(out.max_genome_len, rec_len[(size_t)g]);
+            }
+    }
+    if (shard_count > 1) gbits_bound = gbits_bound / (size_t)shard_count + gbits_bound / (size_t)shard_count / 8 + (1 << 20);
+    out.gbits_bound = gbits_bound;
+    // seeds
+    std::vector<std::string> files;
+    {
+        DIR *d = opendir((dir + "/seeds").c_str());
+        if (!d) {
+            status = 1;
+            return "seeds file not found in: " + dir + "/seeds";
+        }
+        while (dirent *de = readdir(d)) {
+            std::string nm = de->d_name;
+            if (nm.size() > 4 && nm.compare(nm.size() - 4, 4, ".bin") == 0) files.push_back(nm);
+        }
+        closedir(d);
+        std::sort(files.begin(), files.end());
+    }
+    if (files.empty()) {
+        status = 1;
+        return "seeds file not found in: " + dir + "/seeds";
+    }
+    out.seed_files.clear();
+    for (auto &f : files) out.seed_files.push_back(dir + "/seeds/" + f);
+    {   // the anchor prefix of the seed data (users might have run 'utils reindex-seeds', lib-index-search.go:611)
+        File fi(out.seed_files[0] + ".idx");
+        uint8_t h[32];
+        if (!fi.ok() || !fi.read(h, 32) || memcmp(h, ".kvindex", 8) != 0) {
+            status = 2;
+            return "k-mer-value index: invalid binary format: " + out.seed_files[0] + ".idx";
+        }
+        if ((int)h[11] != out.mask_prefix) {
+            status = 2;
+            return "lengths of mask prefix mismatch between info.toml and the seed data";
+        }
+        out.anchor_prefix = h[12];
+    }
+    if (genomes_now) return load_index_genomes(dir, out, status);
+    return "";
+}
+
+// The genome batches (genomes/batch_NNNN/genomes.bin: names, contig tables, 2-bit bases) and the id map: everything of the
+// index that the seed packer does not need - the loader reads them on a host thread while the seed chunks are decoded and
+// packed (they were a third of the time an open took).
+std::string load_index_genomes(const std::string &dir, HostIndex &out, int &status) {
+    std::vector<uint8_t> buf;
+    std::map<uint64_t, std::string> id_of;
+    if (read_all(dir + "/genomes.map.bin", buf)) {
+        size_t p = 0;
+        while (p + 2 <= buf.size()) {
+            uint32_t l = be16(&buf[p]);
+            p += 2;
+            if (p + l + 8 > buf.size()) break;
+            std::string id((const char *)&buf[p], l);
+            p += l;
+            id_of[be64(&buf[p])] = id;
+            p += 8;
+        }
+    } else {
+        status = 1;
+        return "failed to read " + dir + "/genomes.map.bin";
     }
     int64_t global = 0;
+    out.gbits.reserve(out.gbits_bound);
+    std::vector<uint8_t> ib, gb; // (reused: the batches are GBs each)
     for (int b = 0; b < out.genome_batches; b++) {
         char name[64];
         snprintf(name, sizeof name, "/genomes/batch_%04d/genomes.bin", b);
-        std::vector<uint8_t> ib, gb;
         if (!read_all(dir + name + ".idx", ib) || ib.size() < 24 || memcmp(ib.data(), ".genomei", 8) != 0) {
             status = ib.empty() ? 1 : 2;
             return std::string("genome data: invalid binary format: ") + name + ".idx";
         }
         uint32_t nrec = be32(&ib[20]);
-        out.batch_first[b] = global;
-        if (!read_all(dir + name, gb) || gb.size() < 16 || memcmp(gb.data(), ".genomes", 8) != 0 || gb[8] != 0) {
+        if (out.batch_first[b] != global) { // (set by load_index; the seed decoders read the table meanwhile)
+            status = 2;
+            return "genome data: the batch index changed while the index was being opened";
+        }
+        if (!read_all_mt(dir + name, gb) || gb.size() < 16 || memcmp(gb.data(), ".genomes", 8) != 0 || gb[8] != 0) {
             status = gb.empty() ? 1 : 2;
             return std::string("genome data: invalid binary format: ") + name;
         }
@@ -425,42 +534,7 @@ std::string load_index(const std::string &dir, int shard_rank, int shard_count, 
             out.genomes.push_back(std::move(g));
         }
     }
-    out.batch_first[out.genome_batches] = global;
 
-    // seeds
-    std::vector<std::string> files;
-    {
-        DIR *d = opendir((dir + "/seeds").c_str());
-        if (!d) {
-            status = 1;
-            return "seeds file not found in: " + dir + "/seeds";
-        }
-        while (dirent *de = readdir(d)) {
-            std::string nm = de->d_name;
-            if (nm.size() > 4 && nm.compare(nm.size() - 4, 4, ".bin") == 0) files.push_back(nm);
-        }
-        closedir(d);
-        std::sort(files.begin(), files.end());
-    }
-    if (files.empty()) {
-        status = 1;
-        return "seeds file not found in: " + dir + "/seeds";
-    }
-    out.seed_files.clear();
-    for (auto &f : files) out.seed_files.push_back(dir + "/seeds/" + f);
-    {   // the anchor prefix of the seed data (users might have run 'utils reindex-seeds', lib-index-search.go:611)
-        File fi(out.seed_files[0] + ".idx");
-        uint8_t h[32];
-        if (!fi.ok() || !fi.read(h, 32) || memcmp(h, ".kvindex", 8) != 0) {
-            status = 2;
-            return "k-mer-value index: invalid binary format: " + out.seed_files[0] + ".idx";
-        }
-        if ((int)h[11] != out.mask_prefix) {
-            status = 2;
-            return "lengths of mask prefix mismatch between info.toml and the seed data";
-        }
-        out.anchor_prefix = h[12];
-    }
     return "";
 }
 

@@ -49,11 +49,16 @@ struct HostIndex {
     std::vector<uint8_t> gbits;    // 2-bit packed, first base in bits 7-6; each genome padded to 8 bytes
     std::vector<int64_t> batch_first; // [batches+1] global dense number of the first genome of each batch
     int shard_rank = 0, shard_count = 1;
+    int64_t n_local_genomes = 0, max_genome_len = 1; // from the batch .idx files (before the batches themselves are read)
+    size_t gbits_bound = 0;
 };
 
 // Everything of the index except the seeds (info.toml, masks, genomes, id map, chunk lists) + the list of seed chunk files.
 // returns empty string on success, else the error text. status: 1 io, 2 format
-std::string load_index(const std::string &dir, int shard_rank, int shard_count, HostIndex &out, int &status);
+std::string load_index(const std::string &dir, int shard_rank, int shard_count, HostIndex &out, int &status, bool genomes_now = true);
+// genomes_now = false leaves the genome batches (names, contig tables, bases) to this second call, which may run on another
+// thread beside the seed passes: n_local_genomes / max_genome_len / batch_first / g2local are already set by load_index
+std::string load_index_genomes(const std::string &dir, HostIndex &out, int &status);
 
 // One seeds/chunk_NNN.bin decoded into flat arrays (k-mer, value, mask) of the seeds whose genome is on this shard: what the
 // seed packer is shown.  The reference reads these files with one goroutine per file (kv-reader.go:762-1021); the loader

@@ -941,8 +941,12 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
         ix->opt = *opt;
         ix->device = device;
         int status = 0;
+        const double t_li0 = now_ms();
+        // everything but the genome batches; those (names, contig tables, 2-bit bases: GBs) are read by a host thread BESIDE the
+        // seed passes, which only need the genome count, the longest genome and the batch / shard tables
         std::string e = load_index(dir, opt->shard_count > 1 ? opt->shard_rank : 0,
-                                   opt->shard_count > 1 ? opt->shard_count : 1, ix->host, status);
+                                   opt->shard_count > 1 ? opt->shard_count : 1, ix->host, status, false);
+        if (getenv("LM_DEBUG")) fprintf(stderr, "[lm] loader: info, masks, batch and chunk tables read in %.0f ms\n", now_ms() - t_li0);
         if (!e.empty()) {
             g_open_error = e;
             lm_index_close(ix);
@@ -964,24 +968,10 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
         for (size_t i = 1; i < pfx.size(); i++) pfx[i] += pfx[i - 1];
         h2d(ix, ix->d_masks, h.masks);
         h2d(ix, ix->d_pfx_first, pfx);
-        ix->d_gbits.alloc_exact(h.gbits.size() + 64); // k-mer extraction reads whole aligned words past the last base
-        if (!h.gbits.empty())
-            HIPCHK(hipMemcpyAsync(ix->d_gbits.p, h.gbits.data(), h.gbits.size(), hipMemcpyHostToDevice, S(ix)));
-        HIPCHK(hipMemsetAsync(ix->d_gbits.p + h.gbits.size(), 0, 64, S(ix)));
-        std::vector<int64_t> goff;
-        std::vector<int32_t> glen;
-        std::vector<uint64_t> gbg;
-        int64_t max_len = 1;
-        for (size_t i = 0; i < h.genomes.size(); i++) {
-            goff.push_back(h.genomes[i].bits_off);
-            glen.push_back(h.genomes[i].len);
-            gbg.push_back(h.genomes[i].bg);
-            max_len = std::max<int64_t>(max_len, h.genomes[i].len);
-            ix->bg2local[h.genomes[i].bg] = (int)i;
-        }
-        h2d(ix, ix->d_g_off, goff);
-        h2d(ix, ix->d_g_len, glen);
-        h2d(ix, ix->d_g_bg, gbg);
+        int gstatus = 0;
+        const double t_g0 = now_ms();
+        std::future<std::string> gfut = std::async(std::launch::async, [&]() { return load_index_genomes(dir, h, gstatus); });
+        const int64_t max_len = h.max_genome_len;
         h2d(ix, ix->d_batch_first, h.batch_first);
         if (!h.g2local.empty()) h2d(ix, ix->d_g2local, h.g2local);
         lm_fill_gap_lut(ix);
@@ -993,13 +983,9 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
         v.mask_prefix = h.mask_prefix;
         v.masks = ix->d_masks.p;
         v.pfx_first = ix->d_pfx_first.p;
-        v.g_bg = ix->d_g_bg.p;
-        v.gbits = ix->d_gbits.p;
-        v.g_off = ix->d_g_off.p;
-        v.g_len = ix->d_g_len.p;
         v.batch_first = ix->d_batch_first.p;
         v.nbatches = h.genome_batches;
-        v.ngenomes = (int64_t)h.genomes.size();
+        v.ngenomes = h.n_local_genomes;
         v.shard_rank = h.shard_rank;
         v.shard_count = h.shard_count;
         {   // packed seed image: every chunk file is decoded and shown to the packer twice (count, then place).  Files are
@@ -1009,7 +995,7 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
             // are DMA from pinned memory.  The host never holds more than the pool (the reference's RAM form of the whole
             // index would be 16 B/seed of host memory).
             SeedPacker sp;
-            sp.begin(ix, (int64_t)h.genomes.size(), max_len);
+            sp.begin(ix, h.n_local_genomes, max_len);
             const size_t nf = h.seed_files.size();
             size_t nslots = std::min<size_t>(std::max<size_t>(2, (size_t)host_threads()), std::max<size_t>(1, nf));
             {   // a slot holds a file and its decoded seeds (~3.6 x the file): the pool may take a third of the free host memory
@@ -1052,6 +1038,10 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
             };
             DBuf<uint64_t> dk, dv;
             DBuf<uint16_t> dm;
+            const bool pin = !getenv("LM_LOADER_NO_PIN");
+            const bool ldbg = getenv("LM_DEBUG") != nullptr;
+            double t_wait = 0, t_pin = 0, t_pack = 0;
+            const double t_seeds0 = now_ms();
             std::vector<std::unique_ptr<Slot>> slot(nslots); // (both passes use the same slots: warm pages, registered once)
             for (auto &sl : slot) sl.reset(new Slot());
             for (int pass = 0; pass < 2; pass++) {
@@ -1067,18 +1057,24 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
                 };
                 for (size_t i = 0; i < std::min(nslots, nf); i++) launch(i);
                 for (size_t i = 0; i < nf; i++) {
+                    const double tw0 = now_ms();
                     const std::string e2 = fut[i].get();
+                    t_wait += now_ms() - tw0;
                     if (!e2.empty()) {
                         for (size_t j = i + 1; j < nf; j++)
                             if (fut[j].valid()) fut[j].wait();
                         g_open_error = e2;
                         const int stt = stat[i];
                         slot.clear(); // (before the handle and its device context go)
+                        gfut.wait();  // (the genome reader writes into the handle)
                         lm_index_close(ix);
                         return stt == 2 ? LM_ERR_FORMAT : LM_ERR_IO;
                     }
                     Slot &sl = *slot[i % nslots];
-                    sl.pin();
+                    const double tp0 = now_ms();
+                    if (pin) sl.pin();
+                    t_pin += now_ms() - tp0;
+                    const double tk0 = now_ms();
                     SeedChunk &c = sl.c;
                     const int64_t cnt = (int64_t)c.n;
                     const int64_t slice = (int64_t)32 << 20;
@@ -1096,12 +1092,54 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
                             sp.place(dm.p, dk.p, dv.p, m);
                         sync(ix); // the staging buffers are reused
                     }
+                    t_pack += now_ms() - tk0;
                     if (i + nslots < nf) launch(i + nslots); // this slot's next file
                 }
                 if (pass == 0) sp.end_count();
             }
+            const double tf0 = now_ms();
             sp.finish();
+            if (ldbg)
+                fprintf(stderr, "[lm] loader: %zu chunk files through %zu slots, two passes in %.0f ms: %.0f ms waiting for the decoders, %.0f ms "
+                                "registering the slots, %.0f ms uploading + packing, %.0f ms sorting the partitions\n",
+                        nf, nslots, now_ms() - t_seeds0, t_wait, t_pin, t_pack, now_ms() - tf0);
         }
+        // ---- the genomes (read meanwhile): bases and tables to the device
+        {
+            const std::string eg = gfut.get();
+            if (getenv("LM_DEBUG")) fprintf(stderr, "[lm] loader: genome batches read %.0f ms after their reader started\n", now_ms() - t_g0);
+            if (!eg.empty()) {
+                g_open_error = eg;
+                lm_index_close(ix);
+                return gstatus == 2 ? LM_ERR_FORMAT : LM_ERR_IO;
+            }
+            if ((int64_t)h.genomes.size() != h.n_local_genomes) {
+                g_open_error = "genome data: the batch files hold another number of genomes than their indexes";
+                lm_index_close(ix);
+                return LM_ERR_FORMAT;
+            }
+        }
+        ix->d_gbits.alloc_exact(h.gbits.size() + 64); // k-mer extraction reads whole aligned words past the last base
+        if (!h.gbits.empty())
+            HIPCHK(hipMemcpyAsync(ix->d_gbits.p, h.gbits.data(), h.gbits.size(), hipMemcpyHostToDevice, S(ix)));
+        HIPCHK(hipMemsetAsync(ix->d_gbits.p + h.gbits.size(), 0, 64, S(ix)));
+        std::vector<int64_t> goff;
+        std::vector<int32_t> glen;
+        std::vector<uint64_t> gbg;
+        for (size_t i = 0; i < h.genomes.size(); i++) {
+            goff.push_back(h.genomes[i].bits_off);
+            glen.push_back(h.genomes[i].len);
+            gbg.push_back(h.genomes[i].bg);
+            ix->bg2local[h.genomes[i].bg] = (int)i;
+        }
+        h2d(ix, ix->d_g_off, goff);
+        h2d(ix, ix->d_g_len, glen);
+        h2d(ix, ix->d_g_bg, gbg);
+        sync(ix);
+        v.g_bg = ix->d_g_bg.p;
+        v.gbits = ix->d_gbits.p;
+        v.g_off = ix->d_g_off.p;
+        v.g_len = ix->d_g_len.p;
         ix->hbm_bytes = ix->seed_bytes + (int64_t)(h.masks.size() * 8 + pfx.size() * 4 + h.gbits.size() + 64 + goff.size() * 20 +
                                                    h.batch_first.size() * 8);
         // the host copy of the packed genomes is no longer needed
