@@ -139,7 +139,7 @@ std::string decode_seed_chunk(const std::string &path, const HostIndex &idx, See
             return "cannot read " + path;
         }
         file_bytes = (size_t)nb;
-        if (buf.size() < file_bytes + 16) buf.resize(file_bytes + 16);
+        if (buf.size() < file_bytes + 16) buf.resize(std::max(file_bytes, out.min_file_bytes) + 16);
         if (file_bytes && !f.read(buf.data(), file_bytes)) {
             status = 1;
             return "cannot read " + path;
@@ -177,9 +177,10 @@ std::string decode_seed_chunk(const std::string &path, const HostIndex &idx, See
     // every seed is at least nvb bytes of the file: the arrays are cut once (and kept: SeedChunk)
     const size_t ub = (n - 32) / (size_t)nvb + 1;
     if (out.kmers.size() < ub) {
-        out.kmers.resize(ub);
-        out.vals.resize(ub);
-        out.masks.resize(ub);
+        const size_t cut = std::max(ub, out.min_seeds);
+        out.kmers.resize(cut);
+        out.vals.resize(cut);
+        out.masks.resize(cut);
     }
     uint64_t *ok = out.kmers.data(), *ov = out.vals.data();
     uint16_t *om = out.masks.data();

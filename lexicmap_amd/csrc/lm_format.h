@@ -70,6 +70,9 @@ struct SeedChunk {
     std::vector<uint16_t> masks;
     std::vector<uint8_t> file; // the file's bytes (+ 16 of padding)
     size_t n = 0;
+    // set by the owner before the first decode: the arrays are cut for at least this many seeds / file bytes at once (the
+    // loader: what its LARGEST file needs), so that they never move afterwards - they are registered with the driver
+    size_t min_seeds = 0, min_file_bytes = 0;
 };
 std::string decode_seed_chunk(const std::string &path, const HostIndex &idx, SeedChunk &out, int &status, int &anchor_prefix);
 

@@ -998,8 +998,8 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
             sp.begin(ix, h.n_local_genomes, max_len);
             const size_t nf = h.seed_files.size();
             size_t nslots = std::min<size_t>(std::max<size_t>(2, (size_t)host_threads()), std::max<size_t>(1, nf));
+            int64_t biggest = 1;
             {   // a slot holds a file and its decoded seeds (~3.6 x the file): the pool may take a third of the free host memory
-                int64_t biggest = 1;
                 for (auto &f : h.seed_files) {
                     struct stat sb;
                     if (stat(f.c_str(), &sb) == 0) biggest = std::max<int64_t>(biggest, (int64_t)sb.st_size);
@@ -1043,7 +1043,13 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
             double t_wait = 0, t_pin = 0, t_pack = 0;
             const double t_seeds0 = now_ms();
             std::vector<std::unique_ptr<Slot>> slot(nslots); // (both passes use the same slots: warm pages, registered once)
-            for (auto &sl : slot) sl.reset(new Slot());
+            for (auto &sl : slot) {
+                sl.reset(new Slot());
+                // cut for the largest file by the slot's first decode (on its thread): the arrays never move afterwards, so a
+                // registered range is never freed behind the driver's back
+                sl->c.min_file_bytes = (size_t)biggest;
+                sl->c.min_seeds = (size_t)biggest / 7 + 1;
+            }
             for (int pass = 0; pass < 2; pass++) {
                 // declaration order matters: `fut` is destroyed FIRST when an exception unwinds this scope (a failed upload,
                 // DeviceOOM) and a std::async future joins its task in its destructor - so the decode tasks still running
