@@ -305,6 +305,7 @@ struct lm_tune {
     FILE *wfa_dump = nullptr; // LM_DEBUG_WFA_DUMP=<file>: one line per WFA problem and pass (width, status, lengths, estimate, score)
     FILE *wfa_waves = nullptr; // LM_DEBUG_WFA_WAVES=<file>: one JSON line per k_wfa_lean launch: when its wavefronts started / ended, busy share
     int wfa_ak_margin = -1;  // LM_WFA_AK_MARGIN: a problem starts at the ring that holds |tlen - qlen| + margin diagonals (-1: at the class's width)
+    int two_lanes = 1;       // two parts of a batch searched side by side, each with half of the scratch budget (LM_TWO_LANES=0: one after the other)
     int lookup_flat = 1;     // anchors emitted with the lanes over the output (k_lookup_emit_flat); LM_LOOKUP_FLAT=0: one lane per lookup
     int wfa_defer = 0;       // LM_WFA_DEFER=1: a round's latency-bound alignments finish beside the next round's first passes (default: every round waits for them)
     int wfa_r16 = 1;         // 16-bit ring cells in the whole-sequence WFA kernels of 128 / 256 diagonals (LM_WFA_R16=0: 32-bit)
@@ -330,6 +331,7 @@ struct lm_tune {
         if (const char *e = getenv("LM_WFA_R16")) wfa_r16 = atoi(e) != 0;
         if (const char *e = getenv("LM_WFA_DEFER")) wfa_defer = atoi(e) != 0;
         if (const char *e = getenv("LM_LOOKUP_FLAT")) lookup_flat = atoi(e) != 0;
+        if (const char *e = getenv("LM_TWO_LANES")) two_lanes = atoi(e) != 0;
         if (const char *e = getenv("LM_WFA_AK_MARGIN")) wfa_ak_margin = atoi(e);
         if (const char *e = getenv("LM_PA_CHAIN_RING")) pa_chain_ring = atoi(e) != 0;
         if (getenv("LM_CHAIN1_LANES")) chain1_wave = 0;

@@ -2449,7 +2449,7 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
     std::mutex st_mu; // the stage statistics both threads add to
     int round_no = 0;
     auto gwb = [&](int b) -> DBuf<uint8_t> & { return b ? a.gwbuf2 : a.gwbuf; };
-    const bool defer_tails = pipelined && ix->tune.wfa_defer && !ix->tune.wfa_serial;
+    const bool defer_tails = pipelined && ix->tune.wfa_defer && !ix->tune.wfa_serial && ix->active_lanes == 1; // (two lanes + tails: too many queues)
     AlignCtx *a_tail = defer_tails ? &get_actx(ix, qb, &w, &st, 2) : nullptr;
     int64_t gw_used = 0;        // bytes of the round's window buffer in use
     const int64_t gw_target = BUDGET(ix) > 0 ? std::min<int64_t>((int64_t)6 << 30, std::max<int64_t>((int64_t)64 << 20, BUDGET(ix) * 3 / 100)) : (int64_t)1 << 30;
@@ -3316,9 +3316,10 @@ static void search_parts(lm_index *ix, lm_qbatch *qb, lm_result *res, const Sear
     }
     std::mutex lm_;
     std::exception_ptr err;
-    // (opt-in: at the benchmark shapes the two lanes compete for the same LDS - the anchor filter keeps 112 KB per workgroup,
-    // the persistent WFA wavefronts fill the rest - and the step time is the same with one lane or two)
-    const int lanes = (ctl == nullptr && qb->parts.size() >= 2 && getenv("LM_TWO_LANES")) ? 2 : 1;
+    // (round 3 measured +3..6 % at C3 and left it opt-in; with this round's WFA kernels the second lane is worth 10 %:
+    // 12.97 -> 11.75 s per C3 step - the latency-bound passes of one part's rounds run beside the throughput-bound kernels of
+    // the other part instead of beside their own round's; LM_TWO_LANES=0 turns it off)
+    const int lanes = (ctl == nullptr && qb->parts.size() >= 2 && ix->tune.two_lanes && !ix->tune.wfa_serial) ? 2 : 1; // (exclusive kernel timings: one lane)
     ix->active_lanes = lanes;
     auto lane_fn = [&](int lane) {
         tls_lane = lane;

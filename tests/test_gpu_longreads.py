@@ -111,16 +111,19 @@ def test_batch_split_into_parts_gives_the_same_rows(lr_index, lr_queries, monkey
     for b, g in zip(base, got2):
         assert b == g
     assert st0["rows"] == st2["rows"]
-    # two lanes: the parts of the batch searched side by side by two host threads (own scratch and streams, half of the
-    # scratch budget each), parts halved on the fly inside the lanes: the same rows in the same order
-    monkeypatch.setenv("LM_TWO_LANES", "1")
+    gi.close()
+    # two lanes (the default for a batch of several parts: the parts searched side by side by two host threads, own scratch
+    # and streams, half of the scratch budget each, parts halved on the fly inside the lanes) were what ran above; a handle
+    # opened with LM_TWO_LANES=0 searches the parts one after the other: the same rows in the same order
+    monkeypatch.setenv("LM_TWO_LANES", "0")
+    gi = la.Index(d)
+    monkeypatch.delenv("LM_TWO_LANES")
     monkeypatch.setenv("LM_MAX_PART_KMERS", "60000")
     got3, st3 = gi.search(seqs)
     monkeypatch.setenv("LM_DEBUG_MAX_ANCHORS", "1500")
     got4, _ = gi.search(seqs)
     monkeypatch.delenv("LM_DEBUG_MAX_ANCHORS")
     monkeypatch.delenv("LM_MAX_PART_KMERS")
-    monkeypatch.delenv("LM_TWO_LANES")
     gi.close()
     assert got3 == base and got4 == base
     assert st0["rows"] == st3["rows"] and st0["chains"] == st3["chains"]
