@@ -52,7 +52,9 @@ def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=3)
-    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--warmup", type=int, default=3,
+                   help="untimed steps (default 3: with two lanes the scratch arena of a fresh handle keeps growing for the first "
+                        "two or three steps of a C3-sized batch - 17.5, 14.5, then 12.2 s - before the steady state)")
     p.add_argument("--workload", default=os.environ.get("LM_BENCH_WORKLOAD", "c3"),
                    choices=["c3", "c2", "c4", "c5", "small", "tiny", "c3mini"])
     p.add_argument("--shard-of", type=int, default=0,
