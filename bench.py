@@ -127,7 +127,7 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel, workload):
+def pmc_traffic(kernel, workload, per_step=False):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of THIS workload and THESE sources
     (profiles/r02_<workload>_pmc_{fetch,write}.json, two separate --pmc runs): (FETCH_SIZE + WRITE_SIZE) * 1024.  On
     gfx950 FETCH_SIZE tallies 128-B read requests as 64 B for wide streaming reads (MI355X_MICROARCH.md, HBM), so the read
@@ -149,13 +149,17 @@ def pmc_traffic(kernel, workload):
                     best = (k, v[ctr])
         if best is None:
             return None, "kernel not in the committed PMC pass"
-        tot += best[1]["mean"] * 1024.0
+        # per STEP when the caller asks for it: the passes time one step (--steps 1 --warmup 0), and the number of launches a
+        # step is cut into differs between runs (batch parts halved under memory pressure stay halved), so a per-launch mean of
+        # one run over the per-launch bytes of another would mix granularities
+        tot += (best[1]["total"] if per_step else best[1]["mean"]) * 1024.0
         found = True
-    return (int(tot) if found else None), ("(FETCH_SIZE+WRITE_SIZE)*1024 from profiles/%s_%s_pmc_*.json (same sources); "
-                                           "read part is a lower bound on gfx950" % (PROFILE_ROUND, workload))
+    return (int(tot) if found else None), ("(FETCH_SIZE+WRITE_SIZE)*1024 from profiles/%s_%s_pmc_*.json (same sources%s); "
+                                           "read part is a lower bound on gfx950" %
+                                           (PROFILE_ROUND, workload, "; the pass's whole step / this run's launches per step" if per_step else ""))
 
 
-def pmc_issue(kernel, workload):
+def pmc_issue(kernel, workload, per_step_launches=0):
     """instruction issue of `kernel` from the committed SQ pass of this workload and these sources
     (profiles/r02_<workload>_pmc_sq.json): the WFA and anchor-filter kernels are bound by instruction issue (scalar + vector
     ALU), not by HBM; a CU issues at most one vector and one scalar instruction per cycle (four SIMDs, a wavefront's vector
@@ -175,7 +179,8 @@ def pmc_issue(kernel, workload):
     if best is None:
         return None
     v = best[1]
-    out = {c.lower() + "_per_launch": int(v[c]["mean"]) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS") if c in v}
+    out = {c.lower() + "_per_launch": int(v[c]["total"] / per_step_launches if per_step_launches else v[c]["mean"])
+           for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS") if c in v}
     out["note"] = "profiles/%s_%s_pmc_sq.json (kernels serialised by the counter pass)" % (PROFILE_ROUND, workload)
     return out
 
@@ -712,8 +717,13 @@ def main():
             dur_ms = e[0] if e else avg_ms
             alg = e[2] if e else pk["bytes"] / max(pk["launches"], 1)
             ach = alg / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
-            tr, tn = pmc_traffic(pk["name"], args.workload)
-            issue = pmc_issue(pk["name"], args.workload)
+            # counters of the pass's one step spread over THIS run's launches of a (serialised) step: same granularity as
+            # algorithmic_bytes_per_launch and avg_launch_ms
+            nl = e[1] if e else 0
+            tr, tn = pmc_traffic(pk["name"], args.workload, per_step=bool(nl))
+            if tr and nl:
+                tr = int(tr / nl)
+            issue = pmc_issue(pk["name"], args.workload, per_step_launches=nl)
             if issue and dur_ms > 0:
                 # the kernel's wave-instructions per second against what the chip can issue (MI355X_MICROARCH.md)
                 issue["issue_frac_valu"] = round(issue.get("sq_insts_valu_per_launch", 0) / (dur_ms * 1e-3) / VALU_ISSUE_PEAK, 4)

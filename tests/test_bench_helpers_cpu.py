@@ -106,3 +106,29 @@ def test_workloads_name_every_baseline_config_and_the_shards_fit():
         resident = seeds * 9.45 + per_shard * wl[w]["genome_len"] / 4
         assert resident < 0.7 * 288e9, (w, resident)                      # leaves >= 30 % of the HBM for scratch
         assert wl[w]["families"] % 2 == 1                                 # family members spread over 2 / 4 / 8 shards
+
+
+def test_counter_passes_are_spread_over_this_runs_launches_per_step(tmp_path, monkeypatch):
+    """roofline.traffic / instruction_issue: the committed passes time ONE step; a run whose step is cut into another number of
+    launches (batch parts halved under memory pressure stay halved) must use the pass's per-step TOTAL over its own launches
+    per step, not the pass's per-launch mean"""
+    import json
+    import bench
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    h = bench.source_hash()
+    mk = lambda ctr, n, mean: {"source_hash": h, "pmc": {"k_wfa_lean": {ctr: {"dispatches": n, "mean": mean, "total": n * mean}}}}
+    (prof / ("%s_c3_pmc_fetch.json" % bench.PROFILE_ROUND)).write_text(json.dumps(mk("FETCH_SIZE", 100, 2000.0)))
+    (prof / ("%s_c3_pmc_write.json" % bench.PROFILE_ROUND)).write_text(json.dumps(mk("WRITE_SIZE", 100, 1000.0)))
+    sq = {"source_hash": h, "pmc": {"k_wfa_lean": {c: {"dispatches": 100, "mean": 5e6, "total": 5e8} for c in
+                                                     ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS")}}}
+    (prof / ("%s_c3_pmc_sq.json" % bench.PROFILE_ROUND)).write_text(json.dumps(sq))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "source_hash", lambda: h)
+    per_launch, _ = bench.pmc_traffic("k_wfa_lean", "c3")
+    per_step, note = bench.pmc_traffic("k_wfa_lean", "c3", per_step=True)
+    assert per_launch == 3000 * 1024 and per_step == 100 * 3000 * 1024 and "launches per step" in note
+    assert bench.pmc_issue("k_wfa_lean", "c3")["sq_insts_valu_per_launch"] == 5000000
+    assert bench.pmc_issue("k_wfa_lean", "c3", per_step_launches=400)["sq_insts_valu_per_launch"] == 1250000
+    monkeypatch.setattr(bench, "source_hash", lambda: "other")   # passes of other sources are refused
+    assert bench.pmc_traffic("k_wfa_lean", "c3", per_step=True)[0] is None and bench.pmc_issue("k_wfa_lean", "c3") is None
