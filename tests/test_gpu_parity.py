@@ -690,3 +690,70 @@ def test_index_format_variants_and_broken_files(small_index, queries, tmp_path):
             la.Index(old)
         with pytest.raises(Exception):
             O.Index(old)
+
+
+def test_prophage_golden_rows_through_the_hip_stages(small_index):
+    """All 9 rows of the reference's demo/q.prophage.fasta.lexicmap.tsv through the HIP stage exports: the windows the
+    reference's seed chains opened (tests/test_oracle_reference_vectors.py pins them with the oracle) go through
+    lm_pseudoalign_batch (SeqComparator.Compare + Chainer2 on the device) and lm_wfa_batch (the LDS wavefront kernels, 64 bp to
+    9.4 kb), extendMatch between them by the oracle (no stage export), and the rows assembled from the device results -
+    coordinates, alignment length, identity, gaps, e-value, bitscore - are the golden's to the digit."""
+    la = _la()
+    L = O.lib()
+    d, _ = small_index
+    gi = la.Index(d)                      # (any handle: the stage exports need k and the device only)
+    q = O.read_fasta(os.path.join(GOLD, "q.prophage.fasta"))[0][1]
+    gold = [r.split("\t") for r in open(os.path.join(GOLD, "q.prophage.fasta.lexicmap.tsv")).read().rstrip("\n").split("\n")[1:]]
+    as_row = lambda g: (int(g[12]), int(g[13]), int(g[14]), int(g[15]), int(g[9]), g[10], int(g[11]), g[18], int(g[19]))
+    g1 = O.read_fasta(os.path.join(GOLD, "GCF_003697165.2.fa.gz"))[0][1]
+    g2 = O.read_fasta(os.path.join(GOLD, "GCF_002949675.1.fa.gz"))[0][1]
+    g3 = [O.read_fasta(os.path.join(GOLD, "refs", f)) for f in os.listdir(os.path.join(GOLD, "refs")) if f.startswith("GCF_002950215.1")][0][0][1]
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    # (genome, rc, query window, target window (0-based, inclusive), the golden rows expected from it in order)
+    wins = [(g1, False, (0, 10407), (1864410 - 1000, 1873945), [0, 1]),
+            (g1, False, (17440 - 1000, 24381 + 1000), (1882010 - 1000, 1888947 + 1000), [2]),
+            (g1, False, (24354 - 1000, 30294 + 1000), (1853097 - 1000, 1859037 + 1000), [3]),
+            (g1, False, (11000 - 1000, 12289 + 1000), (1873845 + (11000 - 10307) - 1000, 1876827), [4]),   # the window-clipped row
+            (g1, False, (14539 - 1000, 15357 + 1000), (1878797 - 1000, 1879616 + 1000), [5]),
+            (g2, True, (13918 - 1000, 14245 + 1000), (3704318 - 1000, 3704648 + 1000), [6]),
+            (g3, False, (14836 - 1000, 14897 + 1000), (71091 - 1000, 71152 + 1000), [7]),
+            (g3, False, (14836 - 1000, 14897 + 1000), (4261070 - 1000, 4261131 + 1000), [8])]
+    so = O.default_search_opt()
+    total_bases = 54142446
+    problems, targets = [], []
+    for g, rc, (qb, qe), (tb, te), _rows in wins:
+        w = g[tb:te + 1]
+        if rc:
+            w = w.translate(comp)[::-1]
+        targets.append(w)
+        problems.append((0, qb, min(qe, len(q) - 1), w))
+    chains = gi.pseudoalign([q], problems)
+    pairs, meta = [], []
+    for (g, rc, (qb, qe), (tb, te), rows), w, ch in zip(wins, targets, chains):
+        assert len(ch) == len(rows), (rows, ch)
+        for c in ch:
+            ctb, cte = (te - c["tend"], te - c["tbegin"]) if rc else (tb + c["tbegin"], tb + c["tend"])
+            o = [C.c_int() for _ in range(8)]
+            L.lmo_extend_match(q, len(q), w, len(w), c["qbegin"], c["qend"] + 1, c["tbegin"], c["tend"] + 1, so.ext_len2, ctb,
+                               len(g) - 1 - cte, 1 if rc else 0, *[C.byref(x) for x in o])
+            qs, qe2, ts, te2, s1, e1, s2, e2 = [x.value for x in o]
+            pairs.append((q[qs:qe2], w[ts:te2]))
+            meta.append((c, rc, ctb, cte, s1, e1, s2, e2, qe2 - qs, te2 - ts))
+    res = gi.wfa(pairs)
+    gi.close()
+    got = []
+    for r, (c, rc, ctb, cte, s1, e1, s2, e2, lq, lt) in zip(res, meta):
+        wr = O.WfaResult()     # lmo_score_evalue reads the run list: hand it the device's
+        wr.score, wr.nops = r["score"], len(r["ops"])
+        arr = (C.c_uint64 * max(1, len(r["ops"])))(*r["ops"])
+        wr.ops = C.cast(arr, C.POINTER(C.c_uint64))
+        score, bits, ev = C.c_int(), C.c_int(), C.c_double()
+        L.lmo_score_evalue(C.byref(wr), lq, total_bases, C.byref(score), C.byref(bits), C.byref(ev))
+        if rc:      # lib-index-search.go:2541-2556, the - strand form
+            t1, t2 = ctb - e2 + (lt - r["tend"]) + 1, cte + s2 - (r["tbegin"] - 1) + 1
+        else:
+            t1, t2 = ctb - s2 + r["tbegin"], cte + e2 - (lt - r["tend"]) + 1
+        got.append((c["qbegin"] - s1 + r["qbegin"], c["qend"] + e1 - (lq - r["qend"]) + 1, t1, t2, r["align_len"],
+                    "%.3f" % (100.0 * r["matches"] / r["align_len"]), r["gaps"], "%.2e" % ev.value, bits.value))
+    want = [as_row(gold[i]) for _g, _rc, _q, _t, rows in wins for i in rows]
+    assert got == want

@@ -402,6 +402,63 @@ def test_demo_golden_prophage_window_clipped_row():
     L.lmo_cmp_free(cmp_)
 
 
+def test_demo_golden_prophage_remaining_rows_given_the_reference_windows():
+    """The rows of demo/q.prophage.fasta.lexicmap.tsv that this build's own mask set does not open a window for - row 2
+    (101 bp, the second chain inside cluster 1's window, which ends at q 10408 / s 1873946), row 6 (820 bp at 84.390 %) and
+    rows 8-9 (64 bp at 85.938 %, two places on GCF_002950215.1) - reproduce TO THE DIGIT (coordinates, alignment length,
+    identity, gaps, bitscore, e-value) once the stages behind the seeding - Compare (lib-seq_compare.go), extendMatch
+    (lib-index-search-util.go:34-201), WFA and scoreAndEvalue (:260-304) - are run on windows containing them.  Together
+    with the tests above all 9 golden rows are pinned; what depends on the mask set is only WHICH seed chains open windows."""
+    L = O.lib()
+    q = O.read_fasta(os.path.join(GOLD, "q.prophage.fasta"))[0][1]
+    opt = O.CmpOpt()
+    opt.k, opt.min_prefix = 31, 11
+    opt.c2.max_gap, opt.c2.min_score, opt.c2.min_align_len = 20, 35, 50
+    opt.c2.min_identity, opt.c2.band_count, opt.c2.band_base, opt.c2.heuristic_pident = 70.0, 50, 100, 15.0
+    opt.min_aligned_fraction, opt.min_identity = 0.0, 70.0
+    so = O.default_search_opt()
+    cmp_ = L.lmo_cmp_new(C.byref(opt))
+    assert L.lmo_cmp_index(cmp_, q, len(q)) == 0
+    total_bases = 54142446   # input-bases of the 15 demo genomes (the golden's e-values)
+
+    def rows_for(g, q_begin, q_end, t_begin, t_end):   # + strand windows, single contig (:2028-2047, :2167-2200)
+        w = g[t_begin:t_end + 1]
+        chains = C.POINTER(O.Chain2)()
+        nc = L.lmo_cmp_compare(cmp_, q_begin, q_end, w, len(w), len(q), C.byref(chains), None, None)
+        out = []
+        for i in range(nc):
+            c = chains[i]
+            ctb, cte = t_begin + c.tbegin, t_begin + c.tend
+            o = [C.c_int() for _ in range(8)]
+            L.lmo_extend_match(q, len(q), w, len(w), c.qbegin, c.qend + 1, c.tbegin, c.tend + 1, so.ext_len2, ctb,
+                               len(g) - 1 - cte, 0, *[C.byref(x) for x in o])
+            qs, qe2, ts, te2, s1, e1, s2, e2 = [x.value for x in o]
+            r = O.WfaResult()
+            assert L.lmo_wfa_align(q[qs:qe2], qe2 - qs, w[ts:te2], te2 - ts, 1, C.byref(r)) == 0
+            lq, lt = qe2 - qs, te2 - ts
+            score, bits, ev = C.c_int(), C.c_int(), C.c_double()
+            L.lmo_score_evalue(C.byref(r), lq, total_bases, C.byref(score), C.byref(bits), C.byref(ev))
+            out.append((c.qbegin - s1 + r.qbegin, c.qend + e1 - (lq - r.qend) + 1, ctb - s2 + r.tbegin, cte + e2 - (lt - r.tend) + 1,
+                        r.align_len, "%.3f" % (100.0 * r.matches / r.align_len), r.gaps, "%.2e" % ev.value, bits.value))
+            L.lmo_wfa_result_free(C.byref(r))
+        return out
+
+    gold = [r.split("\t") for r in open(os.path.join(GOLD, "q.prophage.fasta.lexicmap.tsv")).read().rstrip("\n").split("\n")[1:]]
+    as_row = lambda g: (int(g[12]), int(g[13]), int(g[14]), int(g[15]), int(g[9]), g[10], int(g[11]), g[18], int(g[19]))
+    g1 = O.read_fasta(os.path.join(GOLD, "GCF_003697165.2.fa.gz"))[0][1]
+    # cluster 1: the window of the chain behind row 1 ends at q 10408 / s 1873946 (1-based): rows 1 AND 2, in this order
+    assert rows_for(g1, 0, 10407, 1864410 - 1000, 1873945) == [as_row(gold[0]), as_row(gold[1])]
+    # row 6: any window around it (it is not clipped by one)
+    for pad in (1000, 200):
+        assert rows_for(g1, 14539 - pad, 15357 + pad, 1878797 - pad, 1879616 + pad) == [as_row(gold[5])]
+    # rows 8 and 9: the same 64-bp alignment at two places of NZ_CP026788.1
+    g3 = [O.read_fasta(os.path.join(GOLD, "refs", f)) for f in os.listdir(os.path.join(GOLD, "refs")) if f.startswith("GCF_002950215.1")][0]
+    assert g3[0][0] == "NZ_CP026788.1"
+    for row, (a, b) in ((gold[7], (71091, 71152)), (gold[8], (4261070, 4261131))):
+        assert rows_for(g3[0][1], 14836 - 1000, 14897 + 1000, a - 1000, b + 1000) == [as_row(row)]
+    L.lmo_cmp_free(cmp_)
+
+
 def test_genome_chunks_split_and_merge(tmp_path):
     """lib-index-build.go:1581-1658 (a genome whose concatenation exceeds --max-genome is stored as several genome chunks,
     listed in genomes.chunks.bin) and lib-index-search.go:2798-2913 (their results are merged, qcovGnm recomputed): the
