@@ -1,0 +1,431 @@
+// experiments/wfa_lean2/wfa_lean2_fwd.h - the forward pass of the gap-affine WFA (x=4, o=6, e=2, wf-adaptive(10,50)) by ONE
+// wavefront, restructured for fewer instructions per score step than k_wfa_lean (lexicmap_amd/csrc/lm_kernels.hip).
+// STAGED for round 5: equal to the oracle on the host SIMT emulator (tests/test_wfa_lean2_emulated_cpu.py), compiled for
+// gfx950 beside the product kernels (compile_check.hip), instruction counts of the score loop in README.md; never run on a GPU.
+//
+// Why: k_wfa_lean is 60 % of the vector and 63 % of the scalar instructions of a C3 step (profiles/r04_c3_pmc_sq.json) and it
+// runs at its instruction roofline (experiments/README.md, valu_rate): only fewer instructions per score step make it faster.
+// Its ISA spends more than half of a step on bookkeeping: the slot -> diagonal mapping of a ring that wraps (k, j, in-range
+// masks per chunk and phase, twice per score), three packed DPP reductions for the trimmed ranges and two for the cut-off
+// (6 dependent DPP stages each), the extension as a second phase that reads M back from LDS and writes it again, separate
+// conditional stores that put NULL back after the cut-off, and scalar registers spilled to vector lanes.
+//
+// What changes (same recurrence, tie rules, trimming, cut-off, backtrace bytes and header as k_wfa_lean: its bt_walk /
+// bt_replay read the rows written here):
+//  * NO WRAP: the cell of diagonal k lives at slot k - kbase of every ring row (kbase wave-uniform), a row has a NULL pad cell
+//    on either side.  The diagonal of a lane's cell is a loop-invariant register, the neighbours k-1 / k+1 are the same
+//    address +- one cell (an instruction offset), and lane order = diagonal order.  When the live rows drift out of the frame
+//    (every few thousand scores: two indels of the same kind per hundred bases) or fit in fewer 64-slot chunks than they
+//    touch, all nine rows are shifted in LDS (recentre).
+//  * lane order = diagonal order, so the first / last valid cell of a wavefront is a BALLOT (the compare that decides
+//    validity already is one) + s_ff1 / s_flbit on the scalar unit: no DPP reduction for M, I, D or for the kept range of
+//    the cut-off (its minimum distance still is one).
+//  * the extension of M[s] is FUSED behind its computation: the new offsets are extended in registers and stored once, with
+//    the cut-off already applied - no read-back, no second store, no NULL-back stores, one LDS hand-off per score instead of
+//    three.  (M cells outside the trimmed range are NULL by sanitisation, so "valid" is all the extension has to know.)
+//  * extension step: one running offset per cell, the end-of-sequence clamp hoisted out of the loop (hmax per cell).
+// One source for the device (hipcc) and for the host emulator (tests/emu/simt_emu.h): every cross-lane operation sits in
+// wave-uniform control flow.
+#pragma once
+#include <stdint.h>
+
+#ifndef WR_NULL_OFF
+#define WR_NULL_OFF (-1073741824) /* = LM_NULL_OFF */
+#endif
+#ifndef L2_SHRINK_MARGIN
+#define L2_SHRINK_MARGIN 12 /* recentre into fewer chunks only when the live rows fit with this many free slots on either side */
+#endif
+
+struct L2Prob {        // one alignment (wave-uniform)
+    int32_t plen, tlen;
+    int32_t *hdr2;     // {first diagonal, row offset} per even score (max_score + 4 entries)
+    uint8_t *bt;       // backtrace bytes
+    int32_t arena_cap; // bytes usable at bt
+    int32_t max_score;
+};
+struct L2Res {
+    int32_t status; // 0 aligned, 1 scratch / score overflow, 3 live rows wider than the ring
+    int32_t score;  // final score (status 0) or the width that did not fit (status 3)
+    int32_t used;   // backtrace bytes written
+    int32_t recentres;
+};
+
+// cells of the ring: nine rows (M 0-4, I 5-6, D 7-8) of 64 * NC cells + a pad cell on either side
+template <int NC> constexpr int l2_ring_cells() { return 9 * (64 * NC + 2); }
+
+// 16 packed bases from base `pos` (first base in the top bits of a word; seq[-1] must be readable): the two words that hold
+// the LAST of the 32 bits, funnel-shifted - one v_alignbit_b32 whatever the position, no 64-bit shift, no half swaps
+WR_DEV uint32_t l2_get16(const uint32_t *seq, int pos) {
+    const uint32_t *w = seq + ((pos + 15) >> 4); // = (2 pos + 31) >> 5: the word of the last bit
+    return WR_ALIGNBIT(w[-1], w[0], ~(2u * (uint32_t)pos + 31u)); // ({w[-1], w[0]} >> (-2 pos & 31)) & 0xffffffff
+}
+
+#ifndef L2_FWD_ATTR
+#define L2_FWD_ATTR WR_DEV
+#endif
+// qb / tb: word 0 of the 2-bit packed sequences in LDS (one readable word in front, (len + 15) / 16 + 2 words, zero behind the
+// last base)
+template <int NC, typename RT> L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, const uint32_t *qb, const uint32_t *tb, L2Res *res) {
+    static_assert(NC == 1 || NC == 2 || NC == 4 || NC == 8 || NC == 16, "1, 2, 4, 8 or 16 cells per lane");
+    constexpr int W = 64 * NC, RS = W + 2;
+    constexpr bool R16 = sizeof(RT) == 2;
+    constexpr int RNULL = R16 ? -16384 : WR_NULL_OFF; // (16-bit cells: k_wfa_lean's argument - sequences <= 12000, s < 24000)
+    constexpr int E_LO = 1 << 28, E_HI = -(1 << 28);
+    const int lane = WR_TID & 63;
+    const int plen = p.plen, tlen = p.tlen, ak = tlen - plen;
+    int status = 0, wide_at = 0, nrec = 0;
+    for (int i = lane; i < 9 * RS; i += 64) ring[i] = (RT)RNULL;
+    // cell (row r, slot i) = ring[r * RS + 1 + i]; this lane's cell of chunk c is slot lane + 64 c
+    RT *const cell0 = ring + 1 + lane;
+    // the band between diagonal 0 and the final diagonal starts centred on the first chunk
+    int kbase = WR_UNIFORM(-(32 - (ak >= -40 && ak <= 40 ? ak / 2 : 0)));
+    int kcol[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) kcol[c] = kbase + lane + 64 * c;
+    // valid ranges by age in even scores: mlo[a]..mhi[a] is M[s-2a]; an empty range is (E_LO, E_HI)
+    int mlo[5], mhi[5], ilo[2], ihi[2], dlo[2], dhi[2];
+#pragma unroll
+    for (int a = 0; a < 5; a++) {
+        mlo[a] = E_LO;
+        mhi[a] = E_HI;
+    }
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+        ilo[a] = dlo[a] = E_LO;
+        ihi[a] = dhi[a] = E_HI;
+    }
+    // a chunk whose cells were all NULL for the last five scores is NULL in every ring row: nothing to store while it is idle
+    int last_act[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) last_act[c] = -1000;
+    last_act[0] = 0;
+    if (p.max_score < 1 || p.arena_cap < 1) status = 1;
+    if (R16 && (plen > 12000 || tlen > 12000)) status = 3;
+    int s = 0, ms = 0, is = 0;
+    int32_t used = 1; // score 0 = one cell that is never read
+    if (lane == 0) {
+        p.hdr2[0] = 0;
+        p.hdr2[1] = 0;
+        p.hdr2[2] = 0;
+        p.hdr2[3] = 1;
+    }
+    WR_WAVE_SYNC();
+    // greedy extension of one cell per lane: h = offset of a valid cell on diagonal k (idle lanes: h = k = 0), 16 bases per pass
+    auto extend = [&](bool valid, int h, int k) {
+        const int hmax = tlen < plen + k ? tlen : plen + k;
+        // a lane extends while h < lim; it stops by pulling lim down to h.  (The predicate is recomputed from registers every
+        // pass: the wave mask of one compare is free, that of a loop-carried flag costs two vector instructions.)
+        int lim = valid ? hmax : 0;
+        while (true) { // (the positions of idle lanes stay inside the sequences)
+            const bool ext = h < lim;
+            if (WR_BALLOT(ext) == 0ull) break;
+            const uint32_t d = l2_get16(qb, h - k) ^ l2_get16(tb, h);
+            const int nm = WR_CLZ(d) >> 1; // 16 when all 16 bases match
+            h += ext ? nm : 0;
+            lim = nm == 16 ? lim : h;
+        }
+        return h < hmax ? h : hmax;
+    };
+    bool done = false;
+    int done_m = 0; // -1 once done (the hot loop tests signs)
+    if (status == 0) { // score 0: the cell of diagonal 0 (chunk 0: its slot is 32 - ak / 2)
+        const bool mine = kcol[0] == 0;
+        const int h = extend(mine, 0, 0);
+        cell0[0] = (RT)(mine ? h : RNULL);
+        mlo[0] = mhi[0] = 0;
+        done = ak == 0 && WR_READLANE(h, (0 - kbase) & 63) >= tlen;
+        done_m = done ? -1 : 0;
+        WR_WAVE_SYNC();
+    }
+    // Two loops.  The INNER one is the score step and nothing else: before a step it looks at the row the step would make
+    // (from the ranges it already has) and leaves when anything but a plain step is due - the end, a limit, an empty row, a
+    // row outside the frame or in more chunks than it needs, scratch running out.  The OUTER one does that rare thing and
+    // comes back.  (With the rare paths inside the step, every variable they touch is merged on every path of every step:
+    // a fifth of the step's instructions were register copies.)
+    const int s_limit = R16 && p.max_score > 24000 ? 24000 : p.max_score; // (16-bit cells could wrap from s = 24000 on)
+    int shrink_from = 0; // no "fewer chunks ?" test before this score (a live row may be wider than the new one for a while)
+    while (status == 0 && !done) {
+        int lo, hi;
+        while (true) {
+            // the row of score s + 2; sources: M[s-2] (mismatch), M[s-6] (gap open), I[s] / D[s] (gap extension)
+            // (two-way minima pinned to the scalar unit: a three-way one is selected as v_min3_i32 + v_readfirstlane_b32)
+            lo = WR_UNIFORM(mlo[1] < mlo[3] - 1 ? mlo[1] : mlo[3] - 1);
+            hi = WR_UNIFORM(mhi[1] > mhi[3] + 1 ? mhi[1] : mhi[3] + 1);
+            {
+                const int l2 = WR_UNIFORM(ilo[0] + 1 < dlo[0] - 1 ? ilo[0] + 1 : dlo[0] - 1), h2 = WR_UNIFORM(ihi[0] + 1 > dhi[0] - 1 ? ihi[0] + 1 : dhi[0] - 1);
+                lo = l2 < lo ? l2 : lo;
+                hi = h2 > hi ? h2 : hi;
+            }
+            const uint32_t span = (uint32_t)(hi - lo); // (an empty row: far above W)
+            const int cf = (lo - kbase) >> 6, cl = (hi - kbase) >> 6; // chunks holding cells of [lo, hi]
+            // every "not a plain step" condition as the sign of one word (scalar adds and ORs, one compare): the end reached; the
+            // score limit; an empty row (hi < lo); the row outside the frame; scratch; more chunks than the row needs
+            uint32_t rare = (uint32_t)done_m | (uint32_t)(s_limit - 3 - s) | span | (uint32_t)(lo - kbase) | (uint32_t)(kbase + W - 1 - hi) |
+                            ((uint32_t)p.arena_cap - (uint32_t)used - span - 1u);
+            if (NC > 1) rare |= (uint32_t)((int)((span + 1 + 2 * L2_SHRINK_MARGIN + 63) >> 6) - (cl - cf + 1)) & ~(uint32_t)(s + 2 - shrink_from);
+            if ((int32_t)rare < 0) break;
+            // ---- a plain step ----
+            s += 2;
+#pragma unroll
+            for (int a = 4; a > 0; a--) {
+                mlo[a] = mlo[a - 1];
+                mhi[a] = mhi[a - 1];
+            }
+            ilo[1] = ilo[0];
+            ihi[1] = ihi[0];
+            dlo[1] = dlo[0];
+            dhi[1] = dhi[0];
+            ms = ms == 4 ? 0 : ms + 1;
+            is ^= 1;
+            RT *const newM = cell0 + ms * RS, *const newI = cell0 + (5 + is) * RS, *const newD = cell0 + (7 + is) * RS;
+            const int32_t rowb = used;
+            used += (int32_t)span + 1;
+            if (lane == 0) { // entry s/2 = {lo, row offset}; the offset of entry s/2+1 closes the row
+                p.hdr2[s] = lo;
+                p.hdr2[s + 1] = rowb;
+                p.hdr2[s + 3] = used;
+            }
+            const int r4 = ms >= 2 ? ms - 2 : ms + 3, r8 = ms == 4 ? 0 : ms + 1, r2 = is ^ 1; // rows of s-4, s-8, s-2
+            const RT *const M8 = cell0 + r8 * RS, *const M4 = cell0 + r4 * RS, *const I2 = cell0 + (5 + r2) * RS, *const D2 = cell0 + (7 + r2) * RS;
+            const int32_t rowk = rowb - lo; // byte of diagonal k: bt[rowk + k] (never negative for a cell of the row)
+            int32_t off[NC], vins[NC], vdel[NC];
+            // first / last cell inside the DP matrix of each of the three new wavefronts, as slots: lane order is diagonal order, so
+            // these are ballots + ff1 / flbit on the scalar unit (none: first = 0xffffffff, last < 0)
+            uint32_t fm = 0xffffffffu, fi = 0xffffffffu, fd = 0xffffffffu;
+            int lm = -1, li = -1, ld = -1;
+            uint32_t cmv = 0; // bit c: chunk c holds a valid M cell
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                off[c] = RNULL;
+                vins[c] = vdel[c] = RNULL;
+                if (NC > 1 && (c < cf || c > cl)) continue;
+                last_act[c] = s;
+                const int k = kcol[c];
+                int32_t a = M8[64 * c - 1], b = I2[64 * c - 1];
+                const bool iext = b >= a; // equal offsets: extension (lm_wfa_backtrace tags 2 > 1)
+                const int32_t ins = (iext ? b : a) + 1;
+                a = M8[64 * c + 1];
+                b = D2[64 * c + 1];
+                const bool dext = b >= a; // tags 4 > 3
+                const int32_t del = dext ? b : a;
+                const int32_t mis = (int32_t)M4[64 * c] + 1;
+                int32_t mx = mis > ins ? mis : ins;
+                if (del > mx) mx = del;
+                // predecessor of the M cell on equal offsets: mismatch (tag 9) > deletion (4, 3) > insertion (2, 1)
+                const uint32_t mc = (mis >= del && mis >= ins) ? 0u : (del >= ins ? 2u : 1u);
+                if ((uint32_t)(k - lo) <= span) p.bt[(uint32_t)(rowk + k)] = (uint8_t)(mc | (iext ? 4u : 0u) | (dext ? 8u : 0u));
+                if ((uint32_t)mx > (uint32_t)tlen) mx = RNULL;
+                if ((uint32_t)(mx - k) > (uint32_t)plen) mx = RNULL;
+                off[c] = mx;
+                vins[c] = ins;
+                vdel[c] = del;
+                // (cells outside [lo, hi] have NULL sources only, hence fail these tests by themselves; one ballot per compare: a
+                // ballot of a conjunction costs two more vector instructions than the AND of two ballots)
+                const uint64_t bm = WR_BALLOT(mx >= 0);
+                const uint64_t bi = WR_BALLOT((uint32_t)ins <= (uint32_t)tlen) & WR_BALLOT((uint32_t)(ins - k) <= (uint32_t)plen);
+                const uint64_t bd = WR_BALLOT((uint32_t)del <= (uint32_t)tlen) & WR_BALLOT((uint32_t)(del - k) <= (uint32_t)plen);
+                // WR_FF1 / WR_FLB: s_ff1_i32_b64 / s_flbit_i32_b64, -1 for an empty mask: "| 64 c" keeps that above every slot,
+                // "^ (64 c + 63)" turns the leading-zero count into the slot and an empty mask into a negative number
+                const uint32_t f_m = (uint32_t)WR_FF1(bm) | (uint32_t)(64 * c), f_i = (uint32_t)WR_FF1(bi) | (uint32_t)(64 * c), f_d = (uint32_t)WR_FF1(bd) | (uint32_t)(64 * c);
+                const int l_m = WR_FLB(bm) ^ (64 * c + 63), l_i = WR_FLB(bi) ^ (64 * c + 63), l_d = WR_FLB(bd) ^ (64 * c + 63);
+                fm = f_m < fm ? f_m : fm;
+                fi = f_i < fi ? f_i : fi;
+                fd = f_d < fd ? f_d : fd;
+                lm = l_m > lm ? l_m : lm;
+                li = l_i > li ? l_i : li;
+                ld = l_d > ld ? l_d : ld;
+                if (NC > 1) cmv |= ((uint32_t)~l_m >> 31) << c; // (l_m >= 0: the chunk has a valid M cell)
+            }
+            // (WR_UNIFORM: provably scalar - the ranges stay in scalar registers and so does everything derived from them)
+            // (an empty range = anything beyond +-2^27: "none" is clamped to the sentinels and shifted by kbase like a slot - a
+            // minimum and an add per end instead of compare, select, add)
+            mlo[0] = WR_UNIFORM(kbase + (int)(fm < (uint32_t)E_LO ? fm : (uint32_t)E_LO));
+            mhi[0] = WR_UNIFORM(kbase + (lm > E_HI ? lm : E_HI));
+            ilo[0] = WR_UNIFORM(kbase + (int)(fi < (uint32_t)E_LO ? fi : (uint32_t)E_LO));
+            ihi[0] = WR_UNIFORM(kbase + (li > E_HI ? li : E_HI));
+            dlo[0] = WR_UNIFORM(kbase + (int)(fd < (uint32_t)E_LO ? fd : (uint32_t)E_LO));
+            dhi[0] = WR_UNIFORM(kbase + (ld > E_HI ? ld : E_HI));
+            // ---- the new M cells, still in registers: greedy extension, end test, cut-off ----
+            bool cut = false;
+            if (lm >= 0) {
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    if (NC > 1 && !((cmv >> c) & 1u)) continue; // (wave-uniform)
+                    const bool valid = off[c] >= 0;
+                    const int h = extend(valid, valid ? off[c] : 0, valid ? kcol[c] : 0);
+                    off[c] = valid ? h : RNULL;
+                }
+                // the end: the cell of the final diagonal has reached the end of the target (the cut-off and the stores below
+                // still run once: nothing reads them, and the step has no way out but its end)
+                if (ak >= mlo[0] && ak <= mhi[0]) {
+                    const int sa = ak - kbase;
+                    int32_t hak = RNULL;
+#pragma unroll
+                    for (int c = 0; c < NC; c++)
+                        if ((sa >> 6) == c) hak = WR_READLANE(off[c], sa & 63);
+                    done = hak >= tlen;
+                    done_m = WR_UNIFORM((tlen - 1 - hak) >> 31); // -1 when hak >= tlen
+                }
+                if (mhi[0] - mlo[0] + 1 >= 10) { // wf-adaptive(10, 50)
+                    int32_t dist[NC];
+                    int32_t dm = 2147483647;
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+                        dist[c] = 2147483647;
+                        if (NC > 1 && !((cmv >> c) & 1u)) continue;
+                        // (an invalid cell is NULL: its distance comes out beyond every valid one + 50 by itself)
+                        const int32_t lv = plen - off[c] + kcol[c], lh = tlen - off[c];
+                        dist[c] = lv > lh ? lv : lh;
+                        dm = dist[c] < dm ? dist[c] : dm;
+                    }
+                    const int32_t dmin = WR_WAVE_MIN_I32(dm);
+                    // The diagonals that stay: lm_wfa_align walks up from mlo to the first kept one below `top` and down from
+                    // mhi to the last kept one above `bottom` = max(ak, new lo) - which is max(ak, mlo) (see k_wfa_lean)
+                    const int top = ak < mhi[0] ? ak : mhi[0];
+                    const int bottom = ak > mlo[0] ? ak : mlo[0];
+                    uint32_t fl = 0xffffffffu;
+                    int lh_ = -1;
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+                        if (NC > 1 && !((cmv >> c) & 1u)) continue;
+                        const uint64_t keep = WR_BALLOT(dist[c] - dmin <= 50);
+                        const uint64_t kl = keep & WR_BALLOT(kcol[c] < top), kh = keep & WR_BALLOT(kcol[c] > bottom);
+                        const uint32_t f = (uint32_t)WR_FF1(kl) | (uint32_t)(64 * c);
+                        const int l = WR_FLB(kh) ^ (64 * c + 63);
+                        fl = f < fl ? f : fl;
+                        lh_ = l > lh_ ? l : lh_;
+                    }
+                    int nlo = mlo[0], nhi = mhi[0];
+                    if (mlo[0] < top) nlo = (int)fl >= 0 ? kbase + (int)fl : top;
+                    if (mhi[0] > bottom) nhi = lh_ >= 0 ? kbase + lh_ : bottom;
+                    if (nlo != mlo[0] || nhi != mhi[0]) {
+                        // I[s] / D[s] are clamped to the reduced M range (empty stays empty: the sentinels survive max / min)
+                        cut = true;
+                        ilo[0] = ilo[0] > nlo ? ilo[0] : nlo;
+                        ihi[0] = ihi[0] < nhi ? ihi[0] : nhi;
+                        dlo[0] = dlo[0] > nlo ? dlo[0] : nlo;
+                        dhi[0] = dhi[0] < nhi ? dhi[0] : nhi;
+                        if (ilo[0] > ihi[0]) {
+                            ilo[0] = E_LO;
+                            ihi[0] = E_HI;
+                        }
+                        if (dlo[0] > dhi[0]) {
+                            dlo[0] = E_LO;
+                            dhi[0] = E_HI;
+                        }
+                        mlo[0] = WR_UNIFORM(nlo);
+                        mhi[0] = WR_UNIFORM(nhi);
+                        ilo[0] = WR_UNIFORM(ilo[0]);
+                        ihi[0] = WR_UNIFORM(ihi[0]);
+                        dlo[0] = WR_UNIFORM(dlo[0]);
+                        dhi[0] = WR_UNIFORM(dhi[0]);
+                    }
+                }
+            }
+            // ---- the three rows of score s: cells outside a range are NULL ----
+            {
+                const uint32_t spm = (uint32_t)(mhi[0] - mlo[0]), spi = (uint32_t)(ihi[0] - ilo[0]), spd = (uint32_t)(dhi[0] - dlo[0]);
+#pragma unroll
+                for (int c = 0; c < NC; c++) { // (k - E_LO) as unsigned is above every span, also above the span of an empty range
+                    if (NC > 1 && (c < cf || c > cl)) {
+                        if (s - last_act[c] <= 10) newM[64 * c] = newI[64 * c] = newD[64 * c] = (RT)RNULL; // what this chunk held 5 / 2 scores ago
+                        continue;
+                    }
+                    const int k = kcol[c];
+                    int32_t m = off[c];
+                    if (cut) m = (uint32_t)(k - mlo[0]) <= spm ? m : RNULL; // (without a cut the cells outside the range are NULL already)
+                    newM[64 * c] = (RT)m;
+                    newI[64 * c] = (RT)((uint32_t)(k - ilo[0]) <= spi ? vins[c] : RNULL);
+                    newD[64 * c] = (RT)((uint32_t)(k - dlo[0]) <= spd ? vdel[c] : RNULL);
+                }
+            }
+            WR_WAVE_SYNC(); // the rows of score s are in the ring
+        }
+        // ---- what is due instead of a plain step (lo, hi: the row of score s + 2) ----
+        if (done) break;
+        if (s + 2 >= s_limit) {
+            status = s + 2 >= p.max_score ? 1 : 3;
+            wide_at = W;
+            break;
+        }
+        if (lo > hi) { // no source wavefront (all four empty): an empty row
+            s += 2;
+#pragma unroll
+            for (int a = 4; a > 0; a--) {
+                mlo[a] = mlo[a - 1];
+                mhi[a] = mhi[a - 1];
+            }
+            ilo[1] = ilo[0];
+            ihi[1] = ihi[0];
+            dlo[1] = dlo[0];
+            dhi[1] = dhi[0];
+            ms = ms == 4 ? 0 : ms + 1;
+            is ^= 1;
+            mlo[0] = ilo[0] = dlo[0] = E_LO;
+            mhi[0] = ihi[0] = dhi[0] = E_HI;
+#pragma unroll
+            for (int c = 0; c < NC; c++) cell0[ms * RS + 64 * c] = cell0[(5 + is) * RS + 64 * c] = cell0[(7 + is) * RS + 64 * c] = (RT)RNULL;
+            if (lane == 0) { // same offset as the next row
+                p.hdr2[s] = 0;
+                p.hdr2[s + 1] = used;
+                p.hdr2[s + 3] = used;
+            }
+            WR_WAVE_SYNC();
+            continue;
+        }
+        if ((int64_t)used + (hi - lo + 1) > (int64_t)p.arena_cap) {
+            status = 1;
+            break;
+        }
+        // The frame.  Every live row - M[s] .. M[s-6], I / D[s] (I may start at lo - 1, D may end at hi + 1) - and the new one
+        // must be inside slots [0, W); with fewer chunks than they touch now if they fit with a margin.
+        {
+            int ulo = lo < mlo[0] ? lo : mlo[0], uhi = hi > mhi[0] ? hi : mhi[0];
+            ulo = mlo[2] < ulo ? mlo[2] : ulo;
+            uhi = mhi[2] > uhi ? mhi[2] : uhi;
+            ulo = ilo[0] < ulo ? ilo[0] : ulo;
+            uhi = dhi[0] > uhi ? dhi[0] : uhi;
+            const int uw = uhi - ulo + 1;
+            if (uw > W) {
+                status = 3;
+                wide_at = uw;
+                break;
+            }
+            int nch = (uw + 2 * L2_SHRINK_MARGIN + 63) >> 6; // chunks the live rows get
+            nch = nch < NC ? nch : NC;
+            const bool out = lo < kbase || hi > kbase + W - 1;
+            const int touched = ((uhi - kbase) >> 6) - ((ulo - kbase) >> 6) + 1;
+            if (!out && nch >= touched) { // the new row asks for fewer chunks, the live rows do not allow it yet
+                shrink_from = WR_UNIFORM(s + 2 + 8);
+                continue;
+            }
+            // shift the nine rows: the live rows centred on the first nch chunks
+            const int nk = WR_UNIFORM(ulo - (64 * nch - uw) / 2);
+            const int delta = nk - kbase; // new slot i <- old slot i + delta
+#pragma unroll 1
+            for (int r = 0; r < 9; r++) {
+                RT v[NC];
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const int src = lane + 64 * c + delta;
+                    v[c] = (uint32_t)src < (uint32_t)W ? ring[r * RS + 1 + src] : (RT)RNULL;
+                }
+                WR_WAVE_SYNC(); // every lane has read the row
+#pragma unroll
+                for (int c = 0; c < NC; c++) cell0[r * RS + 64 * c] = v[c];
+            }
+            WR_WAVE_SYNC();
+            kbase = nk;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                kcol[c] = nk + lane + 64 * c;
+                last_act[c] = s; // (anything may have moved anywhere)
+            }
+            nrec++;
+        }
+    }
+    res->status = status;
+    res->score = status == 0 ? s : wide_at;
+    res->used = used;
+    res->recentres = nrec;
+}
