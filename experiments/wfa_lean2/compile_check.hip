@@ -5,10 +5,14 @@
 
 namespace lm {
 #include "lm_wfa_lean2.h"
-template __global__ void k_wfa_lean2<2, int16_t>(const WfaIn *, int64_t, const int32_t *, int64_t, int32_t *, int64_t, uint8_t *, int64_t, uint64_t *,
+template __global__ void k_wfa_lean2<2, int16_t, false>(const WfaIn *, int64_t, const int32_t *, int64_t, int32_t *, int64_t, uint8_t *, int64_t, uint64_t *,
                                                  unsigned int *, int, int, WfaOut *, unsigned long long *);
-template __global__ void k_wfa_lean2<4, int16_t>(const WfaIn *, int64_t, const int32_t *, int64_t, int32_t *, int64_t, uint8_t *, int64_t, uint64_t *,
+template __global__ void k_wfa_lean2<4, int16_t, false>(const WfaIn *, int64_t, const int32_t *, int64_t, int32_t *, int64_t, uint8_t *, int64_t, uint64_t *,
                                                  unsigned int *, int, int, WfaOut *, unsigned long long *);
-template __global__ void k_wfa_lean2<2, int32_t>(const WfaIn *, int64_t, const int32_t *, int64_t, int32_t *, int64_t, uint8_t *, int64_t, uint64_t *,
+template __global__ void k_wfa_lean2<2, int32_t, false>(const WfaIn *, int64_t, const int32_t *, int64_t, int32_t *, int64_t, uint8_t *, int64_t, uint64_t *,
                                                  unsigned int *, int, int, WfaOut *, unsigned long long *);
+template __global__ void k_wfa_lean2<4, int32_t, true>(const WfaIn *, int64_t, const int32_t *, int64_t, int32_t *, int64_t, uint8_t *, int64_t, uint64_t *,
+                                                      unsigned int *, int, int, WfaOut *, unsigned long long *);
+template __global__ void k_wfa_lean2<8, int32_t, true>(const WfaIn *, int64_t, const int32_t *, int64_t, int32_t *, int64_t, uint8_t *, int64_t, uint64_t *,
+                                                      unsigned int *, int, int, WfaOut *, unsigned long long *);
 } // namespace lm

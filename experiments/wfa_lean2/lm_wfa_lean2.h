@@ -1,8 +1,9 @@
-// experiments/wfa_lean2/lm_wfa_lean2.h - device side of wfa_lean2_fwd.h (STAGED for round 5): k_wfa_lean2<NC, RT>, the
-// whole-sequence form of k_wfa_lean (persistent wavefronts over a queue, sequences 2-bit packed in LDS, bt_walk / bt_replay
-// of lm_kernels.hip) with the restructured forward pass.  Same signature, scratch pools and results as k_wfa_lean<NC, false,
-// RT>: the integration is one line in wfa_lean_fn().  Included inside namespace lm after lm_wfa_mw.h (whose WR_* macros it
-// shares).  NOT run on a GPU yet: compiled for gfx950 (compile_check.hip), the forward pass checked on the host SIMT emulator.
+// experiments/wfa_lean2/lm_wfa_lean2.h - device side of wfa_lean2_fwd.h (STAGED for round 5): k_wfa_lean2<NC, RT, WIN>,
+// k_wfa_lean (persistent wavefronts over a queue; the sequences 2-bit packed in LDS, whole or through sliding windows;
+// bt_walk / bt_replay of lm_kernels.hip) with the restructured forward pass.  Same signature, scratch pools and results as
+// k_wfa_lean<NC, WIN, RT>: the integration is wfa_lean_fn() returning these + 8 * seq_words + 20 bytes of dynamic LDS for the
+// whole-sequence form.  Included inside namespace lm after lm_wfa_mw.h (whose WR_* macros it shares).  NOT run on a GPU yet:
+// compiled for gfx950 (compile_check.hip), the forward pass checked on the host SIMT emulator.
 #pragma once
 
 #define WR_WAVE_SYNC() LDS_WAVE_SYNC()
@@ -42,7 +43,7 @@ __device__ __forceinline__ int l2_sflb(unsigned long long m) {
 
 #include "wfa_lean2_fwd.h"
 
-template <int NC, typename RT>
+template <int NC, typename RT, bool WIN>
 __global__ __launch_bounds__(64) void k_wfa_lean2(const WfaIn *__restrict__ in, int64_t n, const int32_t *__restrict__ todo, int64_t ntodo,
                                                    int32_t *__restrict__ hdr_pool, int64_t hdr_stride, uint8_t *__restrict__ arena_pool,
                                                    int64_t arena_stride, uint64_t *__restrict__ ops_pool, unsigned int *__restrict__ queue,
@@ -54,7 +55,10 @@ __global__ __launch_bounds__(64) void k_wfa_lean2(const WfaIn *__restrict__ in, 
     __shared__ __attribute__((aligned(16))) uint8_t ring_raw[RING_BYTES]; // the backtrace walk reuses the ring (dead by then)
     BtLdsT<BW> &btl = *(BtLdsT<BW> *)ring_raw;
     __shared__ unsigned int sh_x;
-    extern __shared__ uint32_t seq_lds[]; // one word, then both packed sequences, seq_words + 2 words each (launcher: 8 * seq_words + 20 bytes)
+    // WIN: the two sequence windows (one readable word in front of each); otherwise one word, then both whole packed sequences,
+    // seq_words + 2 words each, in dynamic LDS (launcher: 8 * seq_words + 20 bytes)
+    __shared__ uint32_t qwin_buf[WIN ? L2_WINW + 3 : 1], twin_buf[WIN ? L2_WINW + 3 : 1];
+    extern __shared__ uint32_t seq_lds[];
     const int lane = threadIdx.x;
     int32_t *hdr2 = hdr_pool + (int64_t)blockIdx.x * hdr_stride;
     uint8_t *bt = arena_pool + (int64_t)blockIdx.x * arena_stride;
@@ -77,11 +81,11 @@ __global__ __launch_bounds__(64) void k_wfa_lean2(const WfaIn *__restrict__ in, 
         const WfaIn w = in[i];
         const int plen = w.qlen, tlen = w.tlen;
         WfaWin Q, T; // (bt_replay's view of the packed sequences)
-        Q.buf = seq_lds + 1; // (l2_get16 reads one word in front of a sequence)
+        Q.buf = WIN ? qwin_buf + 1 : seq_lds + 1; // (l2_get16 / l2_win_get32 read one word in front)
         Q.src = w.q;
         Q.len = plen;
         Q.w0 = 0;
-        T.buf = seq_lds + 1 + seq_words + 2;
+        T.buf = WIN ? twin_buf + 1 : seq_lds + 1 + seq_words + 2;
         T.src = w.t;
         T.len = tlen;
         T.w0 = 0;
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(64) void k_wfa_lean2(const WfaIn *__restrict__ in, 
         r.score = 0;
         r.used = 0;
         LDS_WAVE_SYNC(); // the previous alignment is done with the sequences and the ring
-        {
+        if (!WIN) {
             bool bad = false;
             const int qw = (plen + 15) >> 4, tw = (tlen + 15) >> 4;
             if (qw > seq_words || tw > seq_words) {
@@ -107,6 +111,8 @@ __global__ __launch_bounds__(64) void k_wfa_lean2(const WfaIn *__restrict__ in, 
         }
         if (r.status == 0) {
             L2Prob p;
+            p.q = w.q;
+            p.t = w.t;
             p.plen = plen;
             p.tlen = tlen;
             p.hdr2 = hdr2;
@@ -114,7 +120,9 @@ __global__ __launch_bounds__(64) void k_wfa_lean2(const WfaIn *__restrict__ in, 
             p.arena_cap = (int32_t)(arena_stride - 16); // the window copies of the walk read whole 16-byte chunks
             p.max_score = max_score;
             LDS_WAVE_SYNC();
-            wfa_lean2_forward<NC, RT>(p, (RT *)ring_raw, Q.buf, T.buf, &r);
+            wfa_lean2_forward<NC, RT, WIN>(p, (RT *)ring_raw, Q.buf, T.buf, &r);
+            Q.w0 = r.qw0; // (WIN: bt_replay moves the windows on from where the pass left them)
+            T.w0 = r.tw0;
         }
         __syncthreads(); // the backtrace reads what every lane stored to global memory
         WfaOut o;
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(64) void k_wfa_lean2(const WfaIn *__restrict__ in, 
                 o.r.qbegin = o.r.qend = o.r.tbegin = o.r.tend = 0;
                 o.r.align_len = o.r.matches = o.r.gaps = o.r.gap_regions = 0;
             } else {
-                bt_replay<false>(bt + arena_stride - 16 - nops, nops, Q, T, plen, tlen, want_ops ? ops_pool + w.ops_off : nullptr, w.ops_cap, lane,
+                bt_replay<WIN>(bt + arena_stride - 16 - nops, nops, Q, T, plen, tlen, want_ops ? ops_pool + w.ops_off : nullptr, w.ops_cap, lane,
                                  r.score, &o.r, &o.blast_score);
             }
         }

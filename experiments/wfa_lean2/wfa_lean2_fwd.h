@@ -37,6 +37,7 @@
 #endif
 
 struct L2Prob {        // one alignment (wave-uniform)
+    const uint8_t *q, *t; // the ASCII sequences (read by the sliding-window form only)
     int32_t plen, tlen;
     int32_t *hdr2;     // {first diagonal, row offset} per even score (max_score + 4 entries)
     uint8_t *bt;       // backtrace bytes
@@ -48,6 +49,7 @@ struct L2Res {
     int32_t score;  // final score (status 0) or the width that did not fit (status 3)
     int32_t used;   // backtrace bytes written
     int32_t recentres;
+    int32_t qw0, tw0; // WIN: first resident word of either window when the pass ended (bt_replay continues from there)
 };
 
 // cells of the ring: nine rows (M 0-4, I 5-6, D 7-8) of 64 * NC cells + a pad cell on either side
@@ -60,13 +62,70 @@ WR_DEV uint32_t l2_get16(const uint32_t *seq, int pos) {
     return WR_ALIGNBIT(w[-1], w[0], ~(2u * (uint32_t)pos + 31u)); // ({w[-1], w[0]} >> (-2 pos & 31)) & 0xffffffff
 }
 
+// ---- sliding 2-bit windows (the WIN form): the layout of k_wfa_lean's WfaWin - each sequence a circular window of L2_WINW
+// words of 16 bases, word w at slot w & (L2_WINW - 1), slots 0 and 1 mirrored behind the last one so that three consecutive
+// words never wrap; bt_replay<true> continues on the same buffers.  buf[-1] must be readable.
+#define L2_WINW 256
+WR_DEV uint32_t l2_pack_base(uint32_t c, bool *bad) {
+    const uint32_t code = (c >> 1) & 3u;
+    *bad |= c != ((0x47544341u >> (code << 3)) & 0xffu); // 'A','C','T','G' by code
+    return code;
+}
+WR_DEV uint32_t l2_pack16(const uint8_t *s, int nb, bool *bad) {
+    uint32_t w = 0;
+    if (nb >= 16) {
+        uint32_t b[4];
+        __builtin_memcpy(b, s, 16);
+#pragma unroll
+        for (int j = 0; j < 16; j++) w = (w << 2) | l2_pack_base((b[j >> 2] >> ((j & 3) << 3)) & 0xffu, bad);
+    } else {
+        for (int j = 0; j < nb; j++) w = (w << 2) | l2_pack_base(s[j], bad);
+        w <<= 2 * (16 - nb);
+    }
+    return w;
+}
+// can 32 bases from `pos` be read from the window ? (words pos >> 4 .. +2)
+WR_DEV bool l2_win_has(int w0, int pos) { return (uint32_t)((pos >> 4) - w0) < (uint32_t)(L2_WINW - 2); }
+// 32 packed bases from base `pos`, as (first 16, next 16): three consecutive slots, two funnel shifts (see l2_get16; the slot
+// in front of the window's first word is read and ignored when pos is a multiple of 16)
+WR_DEV void l2_win_get32(const uint32_t *buf, int pos, uint32_t *hi, uint32_t *lo) {
+    const uint32_t *w = buf + ((((pos + 15) >> 4) - 1) & (L2_WINW - 1));
+    const uint32_t sh = ~(2u * (uint32_t)pos + 31u);
+    *hi = WR_ALIGNBIT(w[0], w[1], sh);
+    *lo = WR_ALIGNBIT(w[1], w[2], sh);
+}
+// the wavefront makes words [qw0, qw0 + WINW) of Q and [tw0, tw0 + WINW) of T resident; words that stay are not reloaded
+WR_DEV void l2_win_move2(uint32_t *qbuf, const uint8_t *q, int plen, int *qw0_cur, int qw0, uint32_t *tbuf, const uint8_t *t, int tlen, int *tw0_cur,
+                         int tw0, int lane, bool *bad, bool fresh) {
+    WR_WAVE_SYNC(); // every lane is done reading the slots that are about to change
+    const bool qkeep = !fresh && qw0 >= *qw0_cur && qw0 < *qw0_cur + L2_WINW, tkeep = !fresh && tw0 >= *tw0_cur && tw0 < *tw0_cur + L2_WINW;
+    const int qfrom = qkeep ? *qw0_cur + L2_WINW : qw0, tfrom = tkeep ? *tw0_cur + L2_WINW : tw0;
+    const int nq = qw0 + L2_WINW - qfrom, nt = tw0 + L2_WINW - tfrom; // words to load (0 when a window does not move)
+    for (int i = lane; i < nq + nt; i += 64) {
+        const bool isq = i < nq;
+        const int w = isq ? qfrom + i : tfrom + (i - nq);
+        const uint8_t *src = isq ? q : t;
+        uint32_t *buf = isq ? qbuf : tbuf;
+        const int nb = (isq ? plen : tlen) - 16 * w;
+        const uint32_t word = nb > 0 ? l2_pack16(src + 16 * (int64_t)w, nb, bad) : 0u;
+        const int slot = w & (L2_WINW - 1);
+        buf[slot] = word;
+        if (slot < 2) buf[L2_WINW + slot] = word;
+    }
+    *qw0_cur = WR_UNIFORM(qw0);
+    *tw0_cur = WR_UNIFORM(tw0);
+    WR_WAVE_SYNC();
+}
+
 #ifndef L2_FWD_ATTR
 #define L2_FWD_ATTR WR_DEV
 #endif
 // qb / tb: word 0 of the 2-bit packed sequences in LDS (one readable word in front, (len + 15) / 16 + 2 words, zero behind the
-// last base)
-template <int NC, typename RT> L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, const uint32_t *qb, const uint32_t *tb, L2Res *res) {
+// last base); WIN: the two windows instead (L2_WINW + 2 words each, one readable word in front), filled here from p.q / p.t
+template <int NC, typename RT, bool WIN = false>
+L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint32_t *tb, L2Res *res) {
     static_assert(NC == 1 || NC == 2 || NC == 4 || NC == 8 || NC == 16, "1, 2, 4, 8 or 16 cells per lane");
+    static_assert(!(WIN && sizeof(RT) == 2), "16-bit cells: whole sequences of at most 12 000 bases");
     constexpr int W = 64 * NC, RS = W + 2;
     constexpr bool R16 = sizeof(RT) == 2;
     constexpr int RNULL = R16 ? -16384 : WR_NULL_OFF; // (16-bit cells: k_wfa_lean's argument - sequences <= 12000, s < 24000)
@@ -110,6 +169,9 @@ template <int NC, typename RT> L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &
         p.hdr2[3] = 1;
     }
     WR_WAVE_SYNC();
+    bool bad = false;     // WIN: a byte that is not A / C / G / T was packed (the byte-comparing kernel takes the alignment)
+    int qw0 = 0, tw0 = 0; // WIN: first resident word of either window (wave-uniform)
+    if (WIN) l2_win_move2(qb, p.q, plen, &qw0, 0, tb, p.t, tlen, &tw0, 0, lane, &bad, true);
     // greedy extension of one cell per lane: h = offset of a valid cell on diagonal k (idle lanes: h = k = 0), 16 bases per pass
     auto extend = [&](bool valid, int h, int k) {
         const int hmax = tlen < plen + k ? tlen : plen + k;
@@ -126,11 +188,72 @@ template <int NC, typename RT> L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &
         }
         return h < hmax ? h : hmax;
     };
+    // WIN: the cells of all chunks of a lane, 32 bases per pass through the windows.  A cell outside a window waits; once
+    // nobody inside extends any more, both windows move to the smallest waiting positions (the cell with the smallest query
+    // position is then inside both: two cells of a wavefront are less than W < 4000 diagonals apart) - k_wfa_lean's scheme.
+    // h[c] / k[c]: offset and diagonal of a valid cell, 0 / 0 for an idle one; on[c]: the chunk has valid cells (wave-uniform).
+    auto extend_win = [&](int *h, const int *k, const bool *valid, const bool *on) {
+        int lim[NC], hmax[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            hmax[c] = tlen < plen + k[c] ? tlen : plen + k[c];
+            lim[c] = valid[c] ? hmax[c] : 0;
+        }
+        while (true) {
+            uint64_t pend = 0;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                if (!on[c]) continue;
+                while (true) {
+                    const uint64_t go_m = WR_BALLOT(h[c] < lim[c]) & WR_BALLOT(l2_win_has(qw0, h[c] - k[c])) & WR_BALLOT(l2_win_has(tw0, h[c]));
+                    if (go_m == 0ull) break;
+                    // (read by every lane: the slots are masked, any position is a valid LDS address)
+                    uint32_t qh, ql, th, tl;
+                    l2_win_get32(qb, h[c] - k[c], &qh, &ql);
+                    l2_win_get32(tb, h[c], &th, &tl);
+                    const uint32_t dh = qh ^ th, dl = ql ^ tl;
+                    const int nm = dh ? WR_CLZ(dh) >> 1 : 16 + (WR_CLZ(dl) >> 1); // 32 when all 32 bases match
+                    const bool go = h[c] < lim[c] && l2_win_has(qw0, h[c] - k[c]) && l2_win_has(tw0, h[c]);
+                    h[c] += go ? nm : 0;
+                    lim[c] = (!go || nm == 32) ? lim[c] : h[c];
+                }
+                pend |= WR_BALLOT(h[c] < lim[c]);
+            }
+            if (pend == 0ull) break;
+            int mv = 2147483647, mh = 2147483647;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const bool wt = on[c] && h[c] < lim[c];
+                mh = wt && h[c] < mh ? h[c] : mh;
+                mv = wt && h[c] - k[c] < mv ? h[c] - k[c] : mv;
+            }
+            mv = WR_WAVE_MIN_I32(mv);
+            mh = WR_WAVE_MIN_I32(mh);
+            l2_win_move2(qb, p.q, plen, &qw0, mv >> 4, tb, p.t, tlen, &tw0, mh >> 4, lane, &bad, false);
+        }
+#pragma unroll
+        for (int c = 0; c < NC; c++) h[c] = h[c] < hmax[c] ? h[c] : hmax[c];
+    };
     bool done = false;
     int done_m = 0; // -1 once done (the hot loop tests signs)
     if (status == 0) { // score 0: the cell of diagonal 0 (chunk 0: its slot is 32 - ak / 2)
         const bool mine = kcol[0] == 0;
-        const int h = extend(mine, 0, 0);
+        int h;
+        if (WIN) {
+            int h_[NC], k_[NC];
+            bool v_[NC], on_[NC];
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                h_[c] = k_[c] = 0;
+                v_[c] = on_[c] = false;
+            }
+            v_[0] = mine;
+            on_[0] = true;
+            extend_win(h_, k_, v_, on_);
+            h = h_[0];
+        } else {
+            h = extend(mine, 0, 0);
+        }
         cell0[0] = (RT)(mine ? h : RNULL);
         mlo[0] = mhi[0] = 0;
         done = ak == 0 && WR_READLANE(h, (0 - kbase) & 63) >= tlen;
@@ -248,12 +371,27 @@ template <int NC, typename RT> L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &
             // ---- the new M cells, still in registers: greedy extension, end test, cut-off ----
             bool cut = false;
             if (lm >= 0) {
+                if (WIN) {
+                    int h_[NC], k_[NC];
+                    bool v_[NC], on_[NC];
 #pragma unroll
-                for (int c = 0; c < NC; c++) {
-                    if (NC > 1 && !((cmv >> c) & 1u)) continue; // (wave-uniform)
-                    const bool valid = off[c] >= 0;
-                    const int h = extend(valid, valid ? off[c] : 0, valid ? kcol[c] : 0);
-                    off[c] = valid ? h : RNULL;
+                    for (int c = 0; c < NC; c++) {
+                        v_[c] = off[c] >= 0;
+                        on_[c] = NC == 1 || ((cmv >> c) & 1u) != 0;
+                        h_[c] = v_[c] ? off[c] : 0;
+                        k_[c] = v_[c] ? kcol[c] : 0;
+                    }
+                    extend_win(h_, k_, v_, on_);
+#pragma unroll
+                    for (int c = 0; c < NC; c++) off[c] = v_[c] ? h_[c] : RNULL;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+                        if (NC > 1 && !((cmv >> c) & 1u)) continue; // (wave-uniform)
+                        const bool valid = off[c] >= 0;
+                        const int h = extend(valid, valid ? off[c] : 0, valid ? kcol[c] : 0);
+                        off[c] = valid ? h : RNULL;
+                    }
                 }
                 // the end: the cell of the final diagonal has reached the end of the target (the cut-off and the stores below
                 // still run once: nothing reads them, and the step has no way out but its end)
@@ -424,6 +562,9 @@ template <int NC, typename RT> L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &
             nrec++;
         }
     }
+    if (WIN && status == 0 && WR_BALLOT(bad) != 0ull) status = 3; // not plain ACGT: the result is discarded
+    res->qw0 = qw0;
+    res->tw0 = tw0;
     res->status = status;
     res->score = status == 0 ? s : wide_at;
     res->used = used;

@@ -38,7 +38,7 @@ static bool pack_seq(const uint8_t *s, int n, std::vector<uint32_t> &w) {
     return ok;
 }
 
-template <int NC, typename RT>
+template <int NC, typename RT, bool WIN = false>
 static long run1(const uint8_t *q, int qlen, const uint8_t *t, int tlen, int max_score, int arena_cap, uint64_t *ops, int ops_cap, WrEmuOut *out,
                  int *recentres) {
     std::vector<int32_t> hdr((size_t)max_score + 8, 0);
@@ -47,11 +47,16 @@ static long run1(const uint8_t *q, int qlen, const uint8_t *t, int tlen, int max
     std::vector<uint32_t> qb, tb;
     memset(out, 0, sizeof *out);
     *recentres = 0;
-    if (!pack_seq(q, qlen, qb) || !pack_seq(t, tlen, tb)) { // (the kernel's packer says so: status 3)
+    if (WIN) { // the windows: filled by the forward pass itself
+        qb.assign((size_t)L2_WINW + 3, 0xdeadbeefu);
+        tb.assign((size_t)L2_WINW + 3, 0xdeadbeefu);
+    } else if (!pack_seq(q, qlen, qb) || !pack_seq(t, tlen, tb)) { // (the kernel's packer says so: status 3)
         out->status = 3;
         return 1;
     }
     L2Prob p;
+    p.q = q;
+    p.t = t;
     p.plen = qlen;
     p.tlen = tlen;
     p.hdr2 = hdr.data();
@@ -59,7 +64,7 @@ static long run1(const uint8_t *q, int qlen, const uint8_t *t, int tlen, int max
     p.arena_cap = arena_cap;
     p.max_score = max_score;
     std::vector<L2Res> res(64);
-    const long ncoll = simt::run_wave([&](int lane) { wfa_lean2_forward<NC, RT>(p, ring.data(), qb.data() + 1, tb.data() + 1, &res[lane]); });
+    const long ncoll = simt::run_wave([&](int lane) { wfa_lean2_forward<NC, RT, WIN>(p, ring.data(), qb.data() + 1, tb.data() + 1, &res[lane]); });
     for (int i = 1; i < 64; i++)
         if (memcmp(&res[0], &res[i], sizeof(L2Res)) != 0) {
             fprintf(stderr, "wfa_lean2_emu: lanes disagree on the result\n");
@@ -73,8 +78,15 @@ static long run1(const uint8_t *q, int qlen, const uint8_t *t, int tlen, int max
     return ncoll;
 }
 
-extern "C" long l2_emu_run(int nc, int r16, const uint8_t *q, int qlen, const uint8_t *t, int tlen, int max_score, int arena_cap, uint64_t *ops,
-                           int ops_cap, WrEmuOut *out, int *recentres) {
+extern "C" long l2_emu_run(int nc, int r16, int win, const uint8_t *q, int qlen, const uint8_t *t, int tlen, int max_score, int arena_cap,
+                           uint64_t *ops, int ops_cap, WrEmuOut *out, int *recentres) {
+    if (win) switch (nc) {
+        case 1: return run1<1, int32_t, true>(q, qlen, t, tlen, max_score, arena_cap, ops, ops_cap, out, recentres);
+        case 2: return run1<2, int32_t, true>(q, qlen, t, tlen, max_score, arena_cap, ops, ops_cap, out, recentres);
+        case 4: return run1<4, int32_t, true>(q, qlen, t, tlen, max_score, arena_cap, ops, ops_cap, out, recentres);
+        case 8: return run1<8, int32_t, true>(q, qlen, t, tlen, max_score, arena_cap, ops, ops_cap, out, recentres);
+        default: return -1;
+        }
     switch (nc * 2 + (r16 ? 1 : 0)) {
     case 2: return run1<1, int32_t>(q, qlen, t, tlen, max_score, arena_cap, ops, ops_cap, out, recentres);
     case 3: return run1<1, int16_t>(q, qlen, t, tlen, max_score, arena_cap, ops, ops_cap, out, recentres);

@@ -29,13 +29,13 @@ def lib():
     return _lib
 
 
-def run1(q, t, nc, r16=False, max_score=20000, arena_cap=1 << 22):
+def run1(q, t, nc, r16=False, max_score=20000, arena_cap=1 << 22, win=False):
     """-> status, tuple comparable with run_oracle_wfa, number of times the ring was recentred"""
     cap = len(q) + len(t) + 8
     ops = (C.c_uint64 * cap)()
     o = EmuOut()
     nrec = C.c_int(0)
-    n = lib().l2_emu_run(nc, int(r16), q, len(q), t, len(t), max_score, arena_cap, ops, cap, C.byref(o), C.byref(nrec))
+    n = lib().l2_emu_run(nc, int(r16), int(win), q, len(q), t, len(t), max_score, arena_cap, ops, cap, C.byref(o), C.byref(nrec))
     assert n > 0
     return o.status, (0, o.score, [ops[j] for j in range(o.nops)], o.qbegin, o.qend, o.tbegin, o.tend, o.align_len, o.matches, o.gaps,
                       o.gap_regions), nrec.value
@@ -146,3 +146,39 @@ def test_many_random_pairs():
         else:
             assert st != 0 or got == exp
     assert n > 200
+
+
+@pytest.mark.parametrize("nc,n,div,ins,seed", [(1, 700, 0.10, 0, 51), (2, 5200, 0.05, 0, 52), (2, 9000, 0.06, 100, 53), (4, 6000, 0.10, 200, 54),
+                                               (8, 5000, 0.08, 400, 55)])
+def test_windowed_form_equals_the_oracle(nc, n, div, ins, seed):
+    """WIN: the sequences through sliding 4096-base windows filled by the pass itself (any length; beyond 4096 bases the windows
+    move, and with a long end gap the cells of one wavefront wait for each other's window positions)"""
+    rng = random.Random(seed)
+    q = rand_seq(rng, n)
+    t = with_insertion(rng, q, -1, ins, div)
+    exp = run_oracle_wfa(q, t)
+    st, got, _ = run1(q, t, nc, win=True)
+    if st == 3:  # (64 diagonals do not hold a 10 % pair: the next width takes it)
+        assert nc == 1 and got[1] > 64
+        nc = 2
+        st, got, _ = run1(q, t, nc, win=True)
+    assert st == 0 and got == exp
+    if n <= 5200:  # and the whole-sequence form agrees
+        assert run1(q, t, nc)[:2] == (st, got)
+
+
+def test_windowed_form_statuses_and_drift():
+    rng = random.Random(61)
+    assert run1(b"ACGTNACGT" * 5, b"ACGTACGT" * 5, 1, win=True)[0] == 3          # not plain ACGT
+    q = rand_seq(rng, 5000)
+    assert run1(q[:2500] + b"N" + q[2500:], q, 1, win=True)[0] == 3               # ... met only after a window move
+    far = (rand_seq(rng, 120), rand_seq(rng, 120))
+    assert run1(far[0], far[1], 1, max_score=40, win=True)[0] == 1
+    assert run1(b"ACGT", b"ACGGT", 1, win=True)[:2] == (0, run_oracle_wfa(b"ACGT", b"ACGGT"))
+    q, t = drifting(rng, 7000, 0.03, 0.0, 0.05)  # windows move AND the ring is recentred
+    nc = 2
+    st, got, nrec = run1(q, t, nc, win=True)
+    while st == 3 and nc < 8:  # (the final diagonal is ~350 below diagonal 0 and the cut-off keeps the range open towards it)
+        nc *= 2
+        st, got, nrec = run1(q, t, nc, win=True)
+    assert st == 0 and got == run_oracle_wfa(q, t) and nrec >= 2
