@@ -7,6 +7,7 @@
 #pragma once
 
 #define WR_WAVE_SYNC() LDS_WAVE_SYNC()
+#define WR_LDS __attribute__((address_space(3)))
 // the wave mask of a predicate as the compare wrote it (__ballot goes through v_cndmask + v_cmp_ne whenever the predicate is
 // not a single compare)
 #undef WR_BALLOT

@@ -160,7 +160,22 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
     last_act[0] = 0;
     if (p.max_score < 1 || p.arena_cap < 1) status = 1;
     if (R16 && (plen > 12000 || tlen > 12000)) status = 3;
-    int s = 0, ms = 0, is = 0;
+    int s = 0;
+    // this lane's cell (chunk 0) in the ring rows, by age: pM[a] = M[s-2a] (pM[0] is also where score 0 goes), pI / pD[0] = I / D[s],
+    // [1] = I / D[s-2].  Rotated with the scores: five + four cheap register moves per score instead of the index arithmetic,
+    // multiplications and address adds of "row = f(s mod 5)" on the scalar unit (which is what bounds the step).
+    // (WR_LDS: the LDS address space on the device - 32-bit addresses and ds_* instructions however the pointers travel
+    // through the loop; without it the rotated pointers are generic 64-bit ones and every access a flat_* instruction)
+    typedef WR_LDS RT *LP;
+    LP pM[5], pI[2], pD[2];
+#pragma unroll
+    // (based one cell below the lane's own: p[64 c] is diagonal k-1, p[64 c + 1] the cell itself, p[64 c + 2] diagonal k+1 -
+    // all of them non-negative instruction offsets)
+    for (int a = 0; a < 5; a++) pM[a] = (LP)ring + lane + ((5 - a) % 5) * RS;
+    pI[0] = (LP)ring + lane + 5 * RS;
+    pI[1] = (LP)ring + lane + 6 * RS;
+    pD[0] = (LP)ring + lane + 7 * RS;
+    pD[1] = (LP)ring + lane + 8 * RS;
     int32_t used = 1; // score 0 = one cell that is never read
     if (lane == 0) {
         p.hdr2[0] = 0;
@@ -235,7 +250,6 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
         for (int c = 0; c < NC; c++) h[c] = h[c] < hmax[c] ? h[c] : hmax[c];
     };
     bool done = false;
-    int done_m = 0; // -1 once done (the hot loop tests signs)
     if (status == 0) { // score 0: the cell of diagonal 0 (chunk 0: its slot is 32 - ak / 2)
         const bool mine = kcol[0] == 0;
         int h;
@@ -254,10 +268,9 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
         } else {
             h = extend(mine, 0, 0);
         }
-        cell0[0] = (RT)(mine ? h : RNULL);
+        pM[0][1] = (RT)(mine ? h : RNULL);
         mlo[0] = mhi[0] = 0;
         done = ak == 0 && WR_READLANE(h, (0 - kbase) & 63) >= tlen;
-        done_m = done ? -1 : 0;
         WR_WAVE_SYNC();
     }
     // Two loops.  The INNER one is the score step and nothing else: before a step it looks at the row the step would make
@@ -266,6 +279,7 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
     // comes back.  (With the rare paths inside the step, every variable they touch is merged on every path of every step:
     // a fifth of the step's instructions were register copies.)
     const int s_limit = R16 && p.max_score > 24000 ? 24000 : p.max_score; // (16-bit cells could wrap from s = 24000 on)
+    int s_lim = s_limit; // the hot loop's copy: pulled below every score once the end is reached (one sign test covers both)
     int shrink_from = 0; // no "fewer chunks ?" test before this score (a live row may be wider than the new one for a while)
     while (status == 0 && !done) {
         int lo, hi;
@@ -283,9 +297,9 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
             const int cf = (lo - kbase) >> 6, cl = (hi - kbase) >> 6; // chunks holding cells of [lo, hi]
             // every "not a plain step" condition as the sign of one word (scalar adds and ORs, one compare): the end reached; the
             // score limit; an empty row (hi < lo); the row outside the frame; scratch; more chunks than the row needs
-            uint32_t rare = (uint32_t)done_m | (uint32_t)(s_limit - 3 - s) | span | (uint32_t)(lo - kbase) | (uint32_t)(kbase + W - 1 - hi) |
+            uint32_t rare = (uint32_t)(s_lim - 3 - s) | span | (uint32_t)(lo - kbase) | (uint32_t)(kbase + W - 1 - hi) |
                             ((uint32_t)p.arena_cap - (uint32_t)used - span - 1u);
-            if (NC > 1) rare |= (uint32_t)((int)((span + 1 + 2 * L2_SHRINK_MARGIN + 63) >> 6) - (cl - cf + 1)) & ~(uint32_t)(s + 2 - shrink_from);
+            if (NC > 1) rare |= (uint32_t)((int)((span + 1 + 2 * L2_SHRINK_MARGIN + 63) >> 6) - (cl - cf + 1)) & ~(uint32_t)(s + 2 - WR_UNIFORM(shrink_from));
             if ((int32_t)rare < 0) break;
             // ---- a plain step ----
             s += 2;
@@ -298,9 +312,18 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
             ihi[1] = ihi[0];
             dlo[1] = dlo[0];
             dhi[1] = dhi[0];
-            ms = ms == 4 ? 0 : ms + 1;
-            is ^= 1;
-            RT *const newM = cell0 + ms * RS, *const newI = cell0 + (5 + is) * RS, *const newD = cell0 + (7 + is) * RS;
+            {
+                const LP t = pM[4]; // (the row of s-10: dead)
+#pragma unroll
+                for (int a = 4; a > 0; a--) pM[a] = pM[a - 1];
+                pM[0] = t;
+                const LP ti = pI[0], td = pD[0];
+                pI[0] = pI[1];
+                pI[1] = ti;
+                pD[0] = pD[1];
+                pD[1] = td;
+            }
+            const LP newM = pM[0], newI = pI[0], newD = pD[0];
             const int32_t rowb = used;
             used += (int32_t)span + 1;
             if (lane == 0) { // entry s/2 = {lo, row offset}; the offset of entry s/2+1 closes the row
@@ -308,8 +331,7 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
                 p.hdr2[s + 1] = rowb;
                 p.hdr2[s + 3] = used;
             }
-            const int r4 = ms >= 2 ? ms - 2 : ms + 3, r8 = ms == 4 ? 0 : ms + 1, r2 = is ^ 1; // rows of s-4, s-8, s-2
-            const RT *const M8 = cell0 + r8 * RS, *const M4 = cell0 + r4 * RS, *const I2 = cell0 + (5 + r2) * RS, *const D2 = cell0 + (7 + r2) * RS;
+            const LP M8 = pM[4], M4 = pM[2], I2 = pI[1], D2 = pD[1]; // rows of s-8, s-4, s-2
             const int32_t rowk = rowb - lo; // byte of diagonal k: bt[rowk + k] (never negative for a cell of the row)
             int32_t off[NC], vins[NC], vdel[NC];
             // first / last cell inside the DP matrix of each of the three new wavefronts, as slots: lane order is diagonal order, so
@@ -324,14 +346,14 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
                 if (NC > 1 && (c < cf || c > cl)) continue;
                 last_act[c] = s;
                 const int k = kcol[c];
-                int32_t a = M8[64 * c - 1], b = I2[64 * c - 1];
+                int32_t a = M8[64 * c], b = I2[64 * c];
                 const bool iext = b >= a; // equal offsets: extension (lm_wfa_backtrace tags 2 > 1)
                 const int32_t ins = (iext ? b : a) + 1;
-                a = M8[64 * c + 1];
-                b = D2[64 * c + 1];
+                a = M8[64 * c + 2];
+                b = D2[64 * c + 2];
                 const bool dext = b >= a; // tags 4 > 3
                 const int32_t del = dext ? b : a;
-                const int32_t mis = (int32_t)M4[64 * c] + 1;
+                const int32_t mis = (int32_t)M4[64 * c + 1] + 1;
                 int32_t mx = mis > ins ? mis : ins;
                 if (del > mx) mx = del;
                 // predecessor of the M cell on equal offsets: mismatch (tag 9) > deletion (4, 3) > insertion (2, 1)
@@ -402,7 +424,7 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
                     for (int c = 0; c < NC; c++)
                         if ((sa >> 6) == c) hak = WR_READLANE(off[c], sa & 63);
                     done = hak >= tlen;
-                    done_m = WR_UNIFORM((tlen - 1 - hak) >> 31); // -1 when hak >= tlen
+                    s_lim = WR_UNIFORM(done ? -(1 << 30) : s_lim);
                 }
                 if (mhi[0] - mlo[0] + 1 >= 10) { // wf-adaptive(10, 50)
                     int32_t dist[NC];
@@ -466,15 +488,15 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
 #pragma unroll
                 for (int c = 0; c < NC; c++) { // (k - E_LO) as unsigned is above every span, also above the span of an empty range
                     if (NC > 1 && (c < cf || c > cl)) {
-                        if (s - last_act[c] <= 10) newM[64 * c] = newI[64 * c] = newD[64 * c] = (RT)RNULL; // what this chunk held 5 / 2 scores ago
+                        if (s - last_act[c] <= 10) newM[64 * c + 1] = newI[64 * c + 1] = newD[64 * c + 1] = (RT)RNULL; // what this chunk held 5 / 2 scores ago
                         continue;
                     }
                     const int k = kcol[c];
                     int32_t m = off[c];
                     if (cut) m = (uint32_t)(k - mlo[0]) <= spm ? m : RNULL; // (without a cut the cells outside the range are NULL already)
-                    newM[64 * c] = (RT)m;
-                    newI[64 * c] = (RT)((uint32_t)(k - ilo[0]) <= spi ? vins[c] : RNULL);
-                    newD[64 * c] = (RT)((uint32_t)(k - dlo[0]) <= spd ? vdel[c] : RNULL);
+                    newM[64 * c + 1] = (RT)m;
+                    newI[64 * c + 1] = (RT)((uint32_t)(k - ilo[0]) <= spi ? vins[c] : RNULL);
+                    newD[64 * c + 1] = (RT)((uint32_t)(k - dlo[0]) <= spd ? vdel[c] : RNULL);
                 }
             }
             WR_WAVE_SYNC(); // the rows of score s are in the ring
@@ -497,12 +519,21 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
             ihi[1] = ihi[0];
             dlo[1] = dlo[0];
             dhi[1] = dhi[0];
-            ms = ms == 4 ? 0 : ms + 1;
-            is ^= 1;
+            {
+                const LP t = pM[4];
+#pragma unroll
+                for (int a = 4; a > 0; a--) pM[a] = pM[a - 1];
+                pM[0] = t;
+                const LP ti = pI[0], td = pD[0];
+                pI[0] = pI[1];
+                pI[1] = ti;
+                pD[0] = pD[1];
+                pD[1] = td;
+            }
             mlo[0] = ilo[0] = dlo[0] = E_LO;
             mhi[0] = ihi[0] = dhi[0] = E_HI;
 #pragma unroll
-            for (int c = 0; c < NC; c++) cell0[ms * RS + 64 * c] = cell0[(5 + is) * RS + 64 * c] = cell0[(7 + is) * RS + 64 * c] = (RT)RNULL;
+            for (int c = 0; c < NC; c++) pM[0][64 * c + 1] = pI[0][64 * c + 1] = pD[0][64 * c + 1] = (RT)RNULL;
             if (lane == 0) { // same offset as the next row
                 p.hdr2[s] = 0;
                 p.hdr2[s + 1] = used;

@@ -14,6 +14,7 @@
 #define WR_BALLOT(p) simt::ballot((p), __LINE__)
 #define WR_WAVE_SYNC() simt::wave_sync(__LINE__)
 #define WR_UNIFORM(x) (x)
+#define WR_LDS
 #define WR_CLZ(x) ((x) ? __builtin_clz(x) : 32)
 #define WR_ALIGNBIT(hi, lo, sh) ((uint32_t)(((((uint64_t)(hi)) << 32) | (uint64_t)(lo)) >> ((sh) & 31)))
 #define WR_FF1(x) ((x) ? __builtin_ctzll(x) : -1) /* s_ff1_i32_b64 */
