@@ -5,6 +5,7 @@
 
 namespace lm {
 #include "lm_wfa_lean2.h"
+#include "lm_wfa_mw2.h"
 template __global__ void k_wfa_lean2<2, int16_t, false>(const WfaIn *, int64_t, const int32_t *, int64_t, int32_t *, int64_t, uint8_t *, int64_t, uint64_t *,
                                                  unsigned int *, int, int, WfaOut *, unsigned long long *);
 template __global__ void k_wfa_lean2<4, int16_t, false>(const WfaIn *, int64_t, const int32_t *, int64_t, int32_t *, int64_t, uint8_t *, int64_t, uint64_t *,
@@ -15,4 +16,12 @@ template __global__ void k_wfa_lean2<4, int32_t, true>(const WfaIn *, int64_t, c
                                                       unsigned int *, int, int, WfaOut *, unsigned long long *);
 template __global__ void k_wfa_lean2<8, int32_t, true>(const WfaIn *, int64_t, const int32_t *, int64_t, int32_t *, int64_t, uint8_t *, int64_t, uint64_t *,
                                                       unsigned int *, int, int, WfaOut *, unsigned long long *);
+template __global__ void k_wfa_mw2<2, false>(const WfaIn *, int64_t, const int32_t *, int64_t, int32_t *, int64_t, uint8_t *, int64_t, uint64_t *,
+                                             unsigned int *, int, int, WfaOut *);
+template __global__ void k_wfa_mw2<4, false>(const WfaIn *, int64_t, const int32_t *, int64_t, int32_t *, int64_t, uint8_t *, int64_t, uint64_t *,
+                                             unsigned int *, int, int, WfaOut *);
+template __global__ void k_wfa_mw2<2, true>(const WfaIn *, int64_t, const int32_t *, int64_t, int32_t *, int64_t, uint8_t *, int64_t, uint64_t *,
+                                            unsigned int *, int, int, WfaOut *);
+template __global__ void k_wfa_mw2<4, true>(const WfaIn *, int64_t, const int32_t *, int64_t, int32_t *, int64_t, uint8_t *, int64_t, uint64_t *,
+                                            unsigned int *, int, int, WfaOut *);
 } // namespace lm

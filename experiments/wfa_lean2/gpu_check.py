@@ -65,6 +65,9 @@ def main():
     pairs += [pair(rng, 3000, 0.05, 0.02, 0.02, extra=150), pair(rng, 3000, 0.05, 0.02, 0.02, extra=-300)]            # outgrow 128 / 256
     pairs += [pair(rng, 12000, 0.02, 0.02, 0.03), pair(rng, 25000, 0.02, 0.02, 0.03), pair(rng, 30000, 0.03, 0.01, 0.05)]  # windowed
     pairs += [pair(rng, 40000, 0.02, 0.02, 0.03), pair(rng, 70000, 0.02, 0.02, 0.03)]
+    # the workgroup passes (k_wfa_mw2): final diagonals 300-700 away - 512 / 1024 diagonals, windowed (8-32 kb) and whole (32-65 kb)
+    pairs += [pair(rng, 20000, 0.02, 0.02, 0.02, extra=400), pair(rng, 26000, 0.02, 0.02, 0.02, extra=-450), pair(rng, 30000, 0.02, 0.02, 0.02, extra=650),
+              pair(rng, 36000, 0.02, 0.02, 0.02, extra=380), pair(rng, 44000, 0.02, 0.02, 0.02, extra=-640)]
     total_bad = 0
     report = {}
     for env in ({"LM_WFA_LEAN2": "1"}, {"LM_WFA_LEAN2": "0"}, {"LM_WFA_LEAN2": "1", "LM_WFA_FIRST_NC": "1,1,1,1,1"},

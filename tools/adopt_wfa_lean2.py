@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """adopt_wfa_lean2.py [--root DIR]: puts the staged k_wfa_lean2 (experiments/wfa_lean2: the restructured forward pass of the
-single-wavefront WFA kernel) into the product sources under DIR (default: this repository): the two headers into
+single-wavefront WFA kernel, and k_wfa_mw2: the same for the workgroup kernel) into the product sources under DIR (default: this repository): the two headers into
 lexicmap_amd/csrc, the kernel family selectable per handle (LM_WFA_LEAN2, default on; 0 = k_wfa_lean), the dynamic LDS of the
 whole-sequence form, the Makefile dependencies.  Every edit is asserted against the text it replaces.  Round 5: run it, build,
 run experiments/wfa_lean2/gpu_check.py on the GPU, then the GPU test suite and the bench lines.  (Checked in round 4 on a copy of
@@ -24,14 +24,31 @@ def edit(path, pairs):
     open(path, "w").write(s)
 
 
-for f in ("wfa_lean2_fwd.h", "lm_wfa_lean2.h"):
+for f in ("wfa_lean2_fwd.h", "lm_wfa_lean2.h", "wfa_mw2_fwd.h", "lm_wfa_mw2.h"):
     t = open(os.path.join(src, f)).read().replace("experiments/wfa_lean2/" + f, f).replace("(STAGED for round 5)", "").replace(
         "STAGED for round 5: ", "")
     open(os.path.join(csrc, "lm_" + f if not f.startswith("lm_") else f), "w").write(t)
 edit(os.path.join(csrc, "lm_wfa_lean2.h"), [('#include "wfa_lean2_fwd.h"', '#include "lm_wfa_lean2_fwd.h"')])
+edit(os.path.join(csrc, "lm_wfa_mw2.h"), [('#include "wfa_mw2_fwd.h"', '#include "lm_wfa_mw2_fwd.h"')])
+edit(os.path.join(csrc, "lm_wfa_mw2_fwd.h"), [('#include "wfa_lean2_fwd.h"', '#include "lm_wfa_lean2_fwd.h"')])
+# the workgroup kernels: both families are included by lm_wfa_mw.h (its WR_* macros are theirs), selected by the same switch
+edit(os.path.join(csrc, "lm_wfa_mw.h"), [
+    ('#include "lm_wfa_mw_fwd.h"\n', '#include "lm_wfa_mw_fwd.h"\n#include "lm_wfa_lean2.h"\n#include "lm_wfa_mw2.h"\n'),
+    ("static WfaMwFn wfa_mw_fn(int ncw, bool win) {\n",
+     "static WfaMwFn wfa_mw_fn(int ncw, bool win, bool lean2 = false) {\n"
+     "    if (lean2) { // the restructured forward pass (lm_wfa_mw2.h)\n"
+     "        if (win) return ncw == 4 ? k_wfa_mw2<4, true> : k_wfa_mw2<2, true>;\n"
+     "        return ncw == 4 ? k_wfa_mw2<4, false> : k_wfa_mw2<2, false>;\n"
+     "    }\n"),
+    ("static size_t wfa_mw_dyn_lds(int seq_words, bool win) { return win ? 0 : (size_t)(2 * (seq_words + 2)) * sizeof(uint32_t); }",
+     "static size_t wfa_mw_dyn_lds(int seq_words, bool win) { return win ? 0 : (size_t)(2 * (seq_words + 2) + 1) * sizeof(uint32_t); } // (k_wfa_mw2: one word in front)"),
+    ("int wfa_mw_resident_blocks(int device, int seq_words, int nc, bool win) {", "int wfa_mw_resident_blocks(int device, int seq_words, int nc, bool win, bool lean2) {"),
+    ("(const void *)wfa_mw_fn(nc / 4, win), MW_THREADS,", "(const void *)wfa_mw_fn(nc / 4, win, lean2), MW_THREADS,"),
+    ("                   int want_ops, WfaOut *out, int nc, bool win) {\n    hipLaunchKernelGGL(wfa_mw_fn(nc / 4, win),",
+     "                   int want_ops, WfaOut *out, int nc, bool win, bool lean2) {\n    hipLaunchKernelGGL(wfa_mw_fn(nc / 4, win, lean2),"),
+])
 
 edit(os.path.join(csrc, "lm_kernels.hip"), [
-    ('#include "lm_wfa_mw.h"\n', '#include "lm_wfa_mw.h"\n#include "lm_wfa_lean2.h"\n'),
     ("static WfaLeanFn wfa_lean_fn(int nc, bool win, bool r16) {\n",
      "static WfaLeanFn wfa_lean2_fn(int nc, bool win, bool r16) { // the restructured forward pass (lm_wfa_lean2.h)\n"
      "    if (r16 && !win && nc == 2) return k_wfa_lean2<2, int16_t, false>;\n"
@@ -55,6 +72,8 @@ edit(os.path.join(csrc, "lm_kernels.hip"), [
      "WfaOut *out, int nc, bool win, bool r16, unsigned long long *dbg, bool lean2) {\n    hipLaunchKernelGGL(wfa_lean_fn(nc, win, r16, lean2),"),
 ])
 edit(os.path.join(csrc, "lm_kernels.h"), [
+    ("int wfa_mw_resident_blocks(int device, int seq_words, int nc, bool win);", "int wfa_mw_resident_blocks(int device, int seq_words, int nc, bool win, bool lean2 = false);"),
+    ("                   int want_ops, WfaOut *out, int nc, bool win);", "                   int want_ops, WfaOut *out, int nc, bool win, bool lean2 = false);"),
     ("int wfa_resident_blocks(int device, int seq_words, int nc, bool win, bool r16 = false);",
      "int wfa_resident_blocks(int device, int seq_words, int nc, bool win, bool r16 = false, bool lean2 = false);"),
     ("                unsigned long long *dbg = nullptr); // dbg: 6 words per workgroup (LM_DEBUG_WFA_WAVES)",
@@ -71,10 +90,12 @@ edit(os.path.join(csrc, "lm_pipeline.hip"), [
     ("ix->tune.wfa_r16 && wfa_r16_ok(cw[c], first_nc[c], win[c]))) * per * 9 / 8;",
      "ix->tune.wfa_r16 && wfa_r16_ok(cw[c], first_nc[c], win[c]), ix->tune.wfa_lean2 != 0)) * per * 9 / 8;"),
     (": wfa_resident_blocks(ix->device, seq_words, nc, use_win, r16);", ": wfa_resident_blocks(ix->device, seq_words, nc, use_win, r16, ix->tune.wfa_lean2 != 0);"),
+    ("mw ? wfa_mw_resident_blocks(ix->device, seq_words, nc, use_win) :", "mw ? wfa_mw_resident_blocks(ix->device, seq_words, nc, use_win, ix->tune.wfa_lean2 != 0) :"),
+    ("a.ops_pool.p, lc.queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc, use_win);", "a.ops_pool.p, lc.queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc, use_win, ix->tune.wfa_lean2 != 0);"),
     ("nc, use_win, r16, wave_dbg ? lc.dbg.p : nullptr);", "nc, use_win, r16, wave_dbg ? lc.dbg.p : nullptr, ix->tune.wfa_lean2 != 0);"),
 ])
 edit(os.path.join(csrc, "Makefile"), [
     ("lm_kernels.o: lm_kernels.hip lm_kernels.h lm_algos.h lm_wfa_mw.h lm_wfa_mw_fwd.h",
-     "lm_kernels.o: lm_kernels.hip lm_kernels.h lm_algos.h lm_wfa_mw.h lm_wfa_mw_fwd.h lm_wfa_lean2.h lm_wfa_lean2_fwd.h"),
+     "lm_kernels.o: lm_kernels.hip lm_kernels.h lm_algos.h lm_wfa_mw.h lm_wfa_mw_fwd.h lm_wfa_lean2.h lm_wfa_lean2_fwd.h lm_wfa_mw2.h lm_wfa_mw2_fwd.h"),
 ])
 print("k_wfa_lean2 adopted under", root)
