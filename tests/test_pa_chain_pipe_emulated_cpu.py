@@ -65,8 +65,8 @@ def test_other_interleavings_of_the_wavefronts_give_the_same_scores():
     wavefronts overtake each other differently in every run (how far ahead a wavefront evaluates its band, how many candidates
     are still pending when it gets to them): the scores must not depend on it"""
     rng = random.Random(5)
-    anchors = colinear(rng, 900)
-    dense = colinear(rng, 500, step=(1, 8))
-    for seed in range(1, 9):
+    anchors = colinear(rng, 600)
+    dense = colinear(rng, 350, step=(1, 8))
+    for seed in range(1, 5):
         assert check(anchors, sched=seed * 7919)[0] == 0
         assert check(dense, band_base=2000, band_count=200, sched=seed * 104729)[0] == 0

@@ -119,7 +119,7 @@ def test_many_random_pairs():
     """a sweep over short pairs of every shape: lengths 1-400, divergence 0-40 %, unrelated pairs, length differences"""
     rng = random.Random(41)
     n = 0
-    for rep in range(300):
+    for rep in range(120):
         la = rng.randint(1, 400)
         a = rand_seq(rng, la)
         kind = rng.randint(0, 3)
@@ -145,7 +145,7 @@ def test_many_random_pairs():
             n += 1
         else:
             assert st != 0 or got == exp
-    assert n > 200
+    assert n > 80
 
 
 @pytest.mark.parametrize("nc,n,div,ins,seed", [(1, 700, 0.10, 0, 51), (2, 5200, 0.05, 0, 52), (2, 9000, 0.06, 100, 53), (4, 6000, 0.10, 200, 54),

@@ -83,7 +83,7 @@ def test_drift_recentres_and_statuses():
     assert run1(wide, tw, 4)[:2] == (0, run_oracle_wfa(wide, tw))
 
 
-@pytest.mark.parametrize("ncw,n,div,ins,seed", [(1, 700, 0.10, 0, 31), (2, 5200, 0.05, 0, 32), (2, 9000, 0.06, 300, 33), (4, 6000, 0.10, 600, 34)])
+@pytest.mark.parametrize("ncw,n,div,ins,seed", [(1, 700, 0.10, 0, 31), (2, 5200, 0.05, 0, 32), (2, 7000, 0.06, 300, 33), (4, 4500, 0.08, 600, 34)])
 def test_windowed_form_equals_the_oracle(ncw, n, div, ins, seed):
     rng = random.Random(seed)
     q = rand_seq(rng, n)
