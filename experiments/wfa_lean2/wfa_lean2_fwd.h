@@ -29,6 +29,8 @@
 #pragma once
 #include <stdint.h>
 
+#include <type_traits>
+
 #ifndef WR_NULL_OFF
 #define WR_NULL_OFF (-1073741824) /* = LM_NULL_OFF */
 #endif
@@ -188,7 +190,13 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
     int qw0 = 0, tw0 = 0; // WIN: first resident word of either window (wave-uniform)
     if (WIN) l2_win_move2(qb, p.q, plen, &qw0, 0, tb, p.t, tlen, &tw0, 0, lane, &bad, true);
     // greedy extension of one cell per lane: h = offset of a valid cell on diagonal k (idle lanes: h = k = 0), 16 bases per pass
-    auto extend = [&](bool valid, int h, int k) {
+    // INTERIOR / EDGE.  Until some M cell has reached the end of either sequence (h = tlen or v = plen), every cell computed
+    // from a valid source lies inside the DP matrix: an I / D / mismatch step adds at most one base on either axis, and an I or
+    // D cell never leads the M cell of its own score and diagonal.  The trimmed ranges of the new wavefronts are then the
+    // first / last cells that HAVE a valid source - scalar minima and maxima of the older ranges, no ballots, no bit scans, no
+    // in-matrix compares.  That is all of an alignment but its last ~100 bases; `edge` is sticky from the first touch on.
+    int edge_m = 0; // -1 from the first touch on (the hot loop tests signs)
+    auto extend = [&](auto in_edge, bool valid, int h, int k) {
         const int hmax = tlen < plen + k ? tlen : plen + k;
         // a lane extends while h < lim; it stops by pulling lim down to h.  (The predicate is recomputed from registers every
         // pass: the wave mask of one compare is free, that of a loop-carried flag costs two vector instructions.)
@@ -201,13 +209,14 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
             h += ext ? nm : 0;
             lim = nm == 16 ? lim : h;
         }
+        if (!decltype(in_edge)::value) edge_m = WR_UNIFORM(edge_m | (WR_BALLOT(valid && h >= hmax) != 0ull ? -1 : 0));
         return h < hmax ? h : hmax;
     };
     // WIN: the cells of all chunks of a lane, 32 bases per pass through the windows.  A cell outside a window waits; once
     // nobody inside extends any more, both windows move to the smallest waiting positions (the cell with the smallest query
     // position is then inside both: two cells of a wavefront are less than W < 4000 diagonals apart) - k_wfa_lean's scheme.
     // h[c] / k[c]: offset and diagonal of a valid cell, 0 / 0 for an idle one; on[c]: the chunk has valid cells (wave-uniform).
-    auto extend_win = [&](int *h, const int *k, const bool *valid, const bool *on) {
+    auto extend_win = [&](auto in_edge, int *h, const int *k, const bool *valid, const bool *on) {
         int lim[NC], hmax[NC];
 #pragma unroll
         for (int c = 0; c < NC; c++) {
@@ -247,7 +256,10 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
             l2_win_move2(qb, p.q, plen, &qw0, mv >> 4, tb, p.t, tlen, &tw0, mh >> 4, lane, &bad, false);
         }
 #pragma unroll
-        for (int c = 0; c < NC; c++) h[c] = h[c] < hmax[c] ? h[c] : hmax[c];
+        for (int c = 0; c < NC; c++) {
+            if (!decltype(in_edge)::value && on[c]) edge_m = WR_UNIFORM(edge_m | (WR_BALLOT(valid[c] && h[c] >= hmax[c]) != 0ull ? -1 : 0));
+            h[c] = h[c] < hmax[c] ? h[c] : hmax[c];
+        }
     };
     bool done = false;
     if (status == 0) { // score 0: the cell of diagonal 0 (chunk 0: its slot is 32 - ak / 2)
@@ -263,10 +275,10 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
             }
             v_[0] = mine;
             on_[0] = true;
-            extend_win(h_, k_, v_, on_);
+            extend_win(std::false_type{}, h_, k_, v_, on_);
             h = h_[0];
         } else {
-            h = extend(mine, 0, 0);
+            h = extend(std::false_type{}, mine, 0, 0);
         }
         pM[0][1] = (RT)(mine ? h : RNULL);
         mlo[0] = mhi[0] = 0;
@@ -281,8 +293,10 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
     const int s_limit = R16 && p.max_score > 24000 ? 24000 : p.max_score; // (16-bit cells could wrap from s = 24000 on)
     int s_lim = s_limit; // the hot loop's copy: pulled below every score once the end is reached (one sign test covers both)
     int shrink_from = 0; // no "fewer chunks ?" test before this score (a live row may be wider than the new one for a while)
-    while (status == 0 && !done) {
-        int lo, hi;
+    int lo = 0, hi = 0; // the row of score s + 2 as the hot loop saw it when it left
+    // the hot loop, in two copies: INTERIOR (leaves also at the first touch) and EDGE
+    auto hot = [&](auto in_edge) {
+        constexpr bool EDGE = decltype(in_edge)::value;
         while (true) {
             // the row of score s + 2; sources: M[s-2] (mismatch), M[s-6] (gap open), I[s] / D[s] (gap extension)
             // (two-way minima pinned to the scalar unit: a three-way one is selected as v_min3_i32 + v_readfirstlane_b32)
@@ -297,7 +311,7 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
             const int cf = (lo - kbase) >> 6, cl = (hi - kbase) >> 6; // chunks holding cells of [lo, hi]
             // every "not a plain step" condition as the sign of one word (scalar adds and ORs, one compare): the end reached; the
             // score limit; an empty row (hi < lo); the row outside the frame; scratch; more chunks than the row needs
-            uint32_t rare = (uint32_t)(s_lim - 3 - s) | span | (uint32_t)(lo - kbase) | (uint32_t)(kbase + W - 1 - hi) |
+            uint32_t rare = (EDGE ? 0u : (uint32_t)edge_m) | (uint32_t)(s_lim - 3 - s) | span | (uint32_t)(lo - kbase) | (uint32_t)(kbase + W - 1 - hi) |
                             ((uint32_t)p.arena_cap - (uint32_t)used - span - 1u);
             if (NC > 1) rare |= (uint32_t)((int)((span + 1 + 2 * L2_SHRINK_MARGIN + 63) >> 6) - (cl - cf + 1)) & ~(uint32_t)(s + 2 - WR_UNIFORM(shrink_from));
             if ((int32_t)rare < 0) break;
@@ -359,11 +373,15 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
                 // predecessor of the M cell on equal offsets: mismatch (tag 9) > deletion (4, 3) > insertion (2, 1)
                 const uint32_t mc = (mis >= del && mis >= ins) ? 0u : (del >= ins ? 2u : 1u);
                 if ((uint32_t)(k - lo) <= span) p.bt[(uint32_t)(rowk + k)] = (uint8_t)(mc | (iext ? 4u : 0u) | (dext ? 8u : 0u));
+                vins[c] = ins;
+                vdel[c] = del;
+                if (!EDGE) { // interior: a cell is valid when a source is (NULL + a few otherwise)
+                    off[c] = mx < 0 ? RNULL : mx;
+                    continue;
+                }
                 if ((uint32_t)mx > (uint32_t)tlen) mx = RNULL;
                 if ((uint32_t)(mx - k) > (uint32_t)plen) mx = RNULL;
                 off[c] = mx;
-                vins[c] = ins;
-                vdel[c] = del;
                 // (cells outside [lo, hi] have NULL sources only, hence fail these tests by themselves; one ballot per compare: a
                 // ballot of a conjunction costs two more vector instructions than the AND of two ballots)
                 const uint64_t bm = WR_BALLOT(mx >= 0);
@@ -382,14 +400,35 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
                 if (NC > 1) cmv |= ((uint32_t)~l_m >> 31) << c; // (l_m >= 0: the chunk has a valid M cell)
             }
             // (WR_UNIFORM: provably scalar - the ranges stay in scalar registers and so does everything derived from them)
-            // (an empty range = anything beyond +-2^27: "none" is clamped to the sentinels and shifted by kbase like a slot - a
-            // minimum and an add per end instead of compare, select, add)
-            mlo[0] = WR_UNIFORM(kbase + (int)(fm < (uint32_t)E_LO ? fm : (uint32_t)E_LO));
-            mhi[0] = WR_UNIFORM(kbase + (lm > E_HI ? lm : E_HI));
-            ilo[0] = WR_UNIFORM(kbase + (int)(fi < (uint32_t)E_LO ? fi : (uint32_t)E_LO));
-            ihi[0] = WR_UNIFORM(kbase + (li > E_HI ? li : E_HI));
-            dlo[0] = WR_UNIFORM(kbase + (int)(fd < (uint32_t)E_LO ? fd : (uint32_t)E_LO));
-            dhi[0] = WR_UNIFORM(kbase + (ld > E_HI ? ld : E_HI));
+            if (EDGE) {
+                // (an empty range = anything beyond +-2^27: "none" is clamped to the sentinels and shifted by kbase like a slot - a
+                // minimum and an add per end instead of compare, select, add)
+                mlo[0] = WR_UNIFORM(kbase + (int)(fm < (uint32_t)E_LO ? fm : (uint32_t)E_LO));
+                mhi[0] = WR_UNIFORM(kbase + (lm > E_HI ? lm : E_HI));
+                ilo[0] = WR_UNIFORM(kbase + (int)(fi < (uint32_t)E_LO ? fi : (uint32_t)E_LO));
+                ihi[0] = WR_UNIFORM(kbase + (li > E_HI ? li : E_HI));
+                dlo[0] = WR_UNIFORM(kbase + (int)(fd < (uint32_t)E_LO ? fd : (uint32_t)E_LO));
+                dhi[0] = WR_UNIFORM(kbase + (ld > E_HI ? ld : E_HI));
+            } else {
+                // interior: I[s] has a cell where M[s-8] or I[s-2] has one, one diagonal up; D[s] one diagonal down; M[s] where
+                // M[s-4], I[s] or D[s] has one.  (Empty ranges are sentinels +- a few: they lose every minimum / maximum.)
+                const int i_lo = WR_UNIFORM((mlo[4] < ilo[1] ? mlo[4] : ilo[1]) + 1), i_hi = WR_UNIFORM((mhi[4] > ihi[1] ? mhi[4] : ihi[1]) + 1);
+                const int d_lo = WR_UNIFORM((mlo[4] < dlo[1] ? mlo[4] : dlo[1]) - 1), d_hi = WR_UNIFORM((mhi[4] > dhi[1] ? mhi[4] : dhi[1]) - 1);
+                int m_lo = WR_UNIFORM(i_lo < d_lo ? i_lo : d_lo), m_hi = WR_UNIFORM(i_hi > d_hi ? i_hi : d_hi);
+                m_lo = mlo[2] < m_lo ? mlo[2] : m_lo;
+                m_hi = mhi[2] > m_hi ? mhi[2] : m_hi;
+                ilo[0] = i_lo <= i_hi ? i_lo : E_LO;
+                ihi[0] = i_lo <= i_hi ? i_hi : E_HI;
+                dlo[0] = d_lo <= d_hi ? d_lo : E_LO;
+                dhi[0] = d_lo <= d_hi ? d_hi : E_HI;
+                mlo[0] = m_lo; // (= lo, hi of the row: never empty here)
+                mhi[0] = m_hi;
+                lm = 0; // "there is a valid M cell"
+                if (NC > 1) {
+                    const int cf2 = (m_lo - kbase) >> 6, cl2 = (m_hi - kbase) >> 6;
+                    cmv = ((2u << cl2) - 1u) & ~((1u << cf2) - 1u);
+                }
+            }
             // ---- the new M cells, still in registers: greedy extension, end test, cut-off ----
             bool cut = false;
             if (lm >= 0) {
@@ -403,7 +442,7 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
                         h_[c] = v_[c] ? off[c] : 0;
                         k_[c] = v_[c] ? kcol[c] : 0;
                     }
-                    extend_win(h_, k_, v_, on_);
+                    extend_win(in_edge, h_, k_, v_, on_);
 #pragma unroll
                     for (int c = 0; c < NC; c++) off[c] = v_[c] ? h_[c] : RNULL;
                 } else {
@@ -411,7 +450,7 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
                     for (int c = 0; c < NC; c++) {
                         if (NC > 1 && !((cmv >> c) & 1u)) continue; // (wave-uniform)
                         const bool valid = off[c] >= 0;
-                        const int h = extend(valid, valid ? off[c] : 0, valid ? kcol[c] : 0);
+                        const int h = extend(in_edge, valid, valid ? off[c] : 0, valid ? kcol[c] : 0);
                         off[c] = valid ? h : RNULL;
                     }
                 }
@@ -501,7 +540,13 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
             }
             WR_WAVE_SYNC(); // the rows of score s are in the ring
         }
-        // ---- what is due instead of a plain step (lo, hi: the row of score s + 2) ----
+    };
+    while (status == 0 && !done) {
+        if (edge_m)
+            hot(std::true_type{});
+        else
+            hot(std::false_type{});
+        // ---- what is due instead of a plain step (lo, hi: the row of score s + 2; possibly nothing but the first touch) ----
         if (done) break;
         if (s + 2 >= s_limit) {
             status = s + 2 >= p.max_score ? 1 : 3;
