@@ -105,7 +105,9 @@ template <int NCW, bool WIN> WR_DEV void wfa_mw2_forward(const L2Prob &p, int32_
         return (int32_t)WR_QUAD_MIN_I32(v);
     };
     // greedy extension of whole-sequence cells (per wavefront; see wfa_lean2_forward)
-    auto extend = [&](bool valid, int h, int k) {
+    // INTERIOR / EDGE as in wfa_lean2_forward; a wavefront notes its own touches (touch_w), strip A carries them to all four
+    int edge_m = 0, touch_w = 0;
+    auto extend = [&](auto in_edge, bool valid, int h, int k) {
         const int hmax = tlen < plen + k ? tlen : plen + k;
         int lim = valid ? hmax : 0;
         while (true) {
@@ -116,11 +118,12 @@ template <int NCW, bool WIN> WR_DEV void wfa_mw2_forward(const L2Prob &p, int32_
             h += ext ? nm : 0;
             lim = nm == 16 ? lim : h;
         }
+        if (!decltype(in_edge)::value) touch_w = WR_UNIFORM(touch_w | (WR_BALLOT(valid && h >= hmax) != 0ull ? -1 : 0));
         return h < hmax ? h : hmax;
     };
     // WIN: all cells of the workgroup through the windows; cells outside a window wait, the workgroup moves both windows to
     // the smallest waiting positions (strip red[48 .. 59]: waiting flag, smallest v, smallest h per wavefront)
-    auto extend_win = [&](int *h, const int *k, const bool *valid, const bool *on) {
+    auto extend_win = [&](auto in_edge, int *h, const int *k, const bool *valid, const bool *on) {
         int lim[NCW], hmax[NCW];
 #pragma unroll
         for (int c = 0; c < NCW; c++) {
@@ -170,7 +173,10 @@ template <int NCW, bool WIN> WR_DEV void wfa_mw2_forward(const L2Prob &p, int32_
             mw2_win_move2(qb, p.q, plen, &qw0, gv >> 4, tb, p.t, tlen, &tw0, gh >> 4, tid, &bad, false);
         }
 #pragma unroll
-        for (int c = 0; c < NCW; c++) h[c] = h[c] < hmax[c] ? h[c] : hmax[c];
+        for (int c = 0; c < NCW; c++) {
+            if (!decltype(in_edge)::value && on[c]) touch_w = WR_UNIFORM(touch_w | (WR_BALLOT(valid[c] && h[c] >= hmax[c]) != 0ull ? -1 : 0));
+            h[c] = h[c] < hmax[c] ? h[c] : hmax[c];
+        }
     };
     bool done = false;
     if (status == 0) { // score 0: the cell of diagonal 0 (its slot is W / 2 - ak / 2)
@@ -187,11 +193,11 @@ template <int NCW, bool WIN> WR_DEV void wfa_mw2_forward(const L2Prob &p, int32_
         }
         (void)mine;
         if (WIN) {
-            extend_win(h0, k0, v0, on0);
+            extend_win(std::false_type{}, h0, k0, v0, on0);
         } else {
 #pragma unroll
             for (int c = 0; c < NCW; c++)
-                if (on0[c]) h0[c] = extend(v0[c], 0, 0);
+                if (on0[c]) h0[c] = extend(std::false_type{}, v0[c], 0, 0);
         }
         int hh = 0;
 #pragma unroll
@@ -201,18 +207,24 @@ template <int NCW, bool WIN> WR_DEV void wfa_mw2_forward(const L2Prob &p, int32_
         }
         mlo[0] = mhi[0] = 0;
         // the end already ?  (the thread of diagonal 0 says so through the strip)
-        if (any_mine) red[0] = (ak == 0 && hh >= tlen) ? -1 : 0;
+        if (any_mine) {
+            red[0] = (ak == 0 && hh >= tlen) ? -1 : 0;
+            red[1] = hh >= (tlen < plen ? tlen : plen) ? -1 : 0; // the first touch already ?
+        }
         WR_BARRIER();
         done = WR_UNIFORM(red[0]) != 0;
+        edge_m = WR_UNIFORM(red[1]);
+        touch_w = 0;
         WR_BARRIER();
-        if (tid == 0) red[0] = BIG;
+        if (tid == 0) red[0] = red[1] = BIG;
         WR_BARRIER();
     }
     const int s_limit = p.max_score;
     int s_lim = s_limit;
     int shrink_from = 0;
-    while (status == 0 && !done) {
-        int lo, hi;
+    int lo = 0, hi = 0; // the row of score s + 2 as the hot loop saw it when it left
+    auto hot = [&](auto in_edge) {
+        constexpr bool EDGE = decltype(in_edge)::value;
         while (true) {
             lo = WR_UNIFORM(mlo[1] < mlo[3] - 1 ? mlo[1] : mlo[3] - 1);
             hi = WR_UNIFORM(mhi[1] > mhi[3] + 1 ? mhi[1] : mhi[3] + 1);
@@ -223,7 +235,7 @@ template <int NCW, bool WIN> WR_DEV void wfa_mw2_forward(const L2Prob &p, int32_
             }
             const uint32_t span = (uint32_t)(hi - lo);
             const int gf = (lo - kbase) >> 6, gl = (hi - kbase) >> 6; // groups of 64 slots holding cells of [lo, hi]
-            uint32_t rare = (uint32_t)(s_lim - 3 - s) | span | (uint32_t)(lo - kbase) | (uint32_t)(kbase + W - 1 - hi) |
+            uint32_t rare = (EDGE ? 0u : (uint32_t)edge_m) | (uint32_t)(s_lim - 3 - s) | span | (uint32_t)(lo - kbase) | (uint32_t)(kbase + W - 1 - hi) |
                             ((uint32_t)p.arena_cap - (uint32_t)used - span - 1u);
             // (fewer chunks: a chunk here is 256 slots = one cell of every thread)
             if (NCW > 1)
@@ -285,11 +297,16 @@ template <int NCW, bool WIN> WR_DEV void wfa_mw2_forward(const L2Prob &p, int32_
                 if (del > mx) mx = del;
                 const uint32_t mc = (mis >= del && mis >= ins) ? 0u : (del >= ins ? 2u : 1u);
                 if ((uint32_t)(k - lo) <= span) p.bt[(uint32_t)(rowk + k)] = (uint8_t)(mc | (iext ? 4u : 0u) | (dext ? 8u : 0u));
+                vins[c] = ins;
+                vdel[c] = del;
+                if (!EDGE) { // interior: a cell is valid when a source is; the row is [lo, hi] and every active group holds cells of it
+                    off[c] = mx < 0 ? RNULL : mx;
+                    cmv |= 1u << c;
+                    continue;
+                }
                 if ((uint32_t)mx > (uint32_t)tlen) mx = RNULL;
                 if ((uint32_t)(mx - k) > (uint32_t)plen) mx = RNULL;
                 off[c] = mx;
-                vins[c] = ins;
-                vdel[c] = del;
                 const uint64_t bm = WR_BALLOT(mx >= 0);
                 const uint64_t bi = WR_BALLOT((uint32_t)ins <= (uint32_t)tlen) & WR_BALLOT((uint32_t)(ins - k) <= (uint32_t)plen);
                 const uint64_t bd = WR_BALLOT((uint32_t)del <= (uint32_t)tlen) & WR_BALLOT((uint32_t)(del - k) <= (uint32_t)plen);
@@ -321,7 +338,7 @@ template <int NCW, bool WIN> WR_DEV void wfa_mw2_forward(const L2Prob &p, int32_
                     h_[c] = v_[c] ? off[c] : 0;
                     k_[c] = v_[c] ? kcol[c] : 0;
                 }
-                extend_win(h_, k_, v_, on_);
+                extend_win(in_edge, h_, k_, v_, on_);
 #pragma unroll
                 for (int c = 0; c < NCW; c++) off[c] = v_[c] ? h_[c] : RNULL;
             } else {
@@ -329,7 +346,7 @@ template <int NCW, bool WIN> WR_DEV void wfa_mw2_forward(const L2Prob &p, int32_
                 for (int c = 0; c < NCW; c++) {
                     if (!((cmv >> c) & 1u)) continue;
                     const bool valid = off[c] >= 0;
-                    const int h = extend(valid, valid ? off[c] : 0, valid ? kcol[c] : 0);
+                    const int h = extend(in_edge, valid, valid ? off[c] : 0, valid ? kcol[c] : 0);
                     off[c] = valid ? h : RNULL;
                 }
             }
@@ -351,13 +368,18 @@ template <int NCW, bool WIN> WR_DEV void wfa_mw2_forward(const L2Prob &p, int32_
                 const int32_t wdm = cmv ? (int32_t)WR_WAVE_MIN_I32(dm) : BIG;
                 const bool wfin = WR_BALLOT(fin) != 0ull;
                 if (lane == 0) { // strip A: eight quantities x four wavefronts, all combined by a minimum
-                    red[0 + wave] = fm;
-                    red[4 + wave] = -lm;
-                    red[8 + wave] = fi;
-                    red[12 + wave] = -li;
-                    red[16 + wave] = fd;
-                    red[20 + wave] = -ld;
-                    red[24 + wave] = wfin ? -1 : 0;
+                    if (EDGE) {
+                        red[0 + wave] = fm;
+                        red[4 + wave] = -lm;
+                        red[8 + wave] = fi;
+                        red[12 + wave] = -li;
+                        red[16 + wave] = fd;
+                        red[20 + wave] = -ld;
+                        red[24 + wave] = wfin ? -1 : 0;
+                    } else {
+                        red[20 + wave] = touch_w; // (interior: the first touch of an end, in a slot the ranges do not need)
+                        red[24 + wave] = wfin ? -1 : 0; // (the first touch may be the end itself)
+                    }
                     red[28 + wave] = wdm;
                 }
             }
@@ -365,17 +387,33 @@ template <int NCW, bool WIN> WR_DEV void wfa_mw2_forward(const L2Prob &p, int32_
             bool cut = false;
             {
                 const int32_t r = strip_min(red);
-                const int gfm = WR_READLANE(r, 0), glm = -WR_READLANE(r, 4), gfi = WR_READLANE(r, 8), gli = -WR_READLANE(r, 12);
-                const int gfd = WR_READLANE(r, 16), gld = -WR_READLANE(r, 20), gfin = WR_READLANE(r, 24), dmin = WR_READLANE(r, 28);
-                mlo[0] = WR_UNIFORM(glm >= 0 ? kbase + gfm : E_LO);
-                mhi[0] = WR_UNIFORM(glm >= 0 ? kbase + glm : E_HI);
-                ilo[0] = WR_UNIFORM(gli >= 0 ? kbase + gfi : E_LO);
-                ihi[0] = WR_UNIFORM(gli >= 0 ? kbase + gli : E_HI);
-                dlo[0] = WR_UNIFORM(gld >= 0 ? kbase + gfd : E_LO);
-                dhi[0] = WR_UNIFORM(gld >= 0 ? kbase + gld : E_HI);
-                // the end test of k_wfa_lean: the cell of diagonal ak inside the M range
-                done = gfin != 0 && ak >= mlo[0] && ak <= mhi[0];
-                s_lim = WR_UNIFORM(done ? -(1 << 30) : s_lim);
+                const int gfin = WR_READLANE(r, 24), dmin = WR_READLANE(r, 28);
+                if (EDGE) {
+                    const int gfm = WR_READLANE(r, 0), glm = -WR_READLANE(r, 4), gfi = WR_READLANE(r, 8), gli = -WR_READLANE(r, 12);
+                    const int gfd = WR_READLANE(r, 16), gld = -WR_READLANE(r, 20);
+                    mlo[0] = WR_UNIFORM(glm >= 0 ? kbase + gfm : E_LO);
+                    mhi[0] = WR_UNIFORM(glm >= 0 ? kbase + glm : E_HI);
+                    ilo[0] = WR_UNIFORM(gli >= 0 ? kbase + gfi : E_LO);
+                    ihi[0] = WR_UNIFORM(gli >= 0 ? kbase + gli : E_HI);
+                    dlo[0] = WR_UNIFORM(gld >= 0 ? kbase + gfd : E_LO);
+                    dhi[0] = WR_UNIFORM(gld >= 0 ? kbase + gld : E_HI);
+                    // the end test of k_wfa_lean: the cell of diagonal ak inside the M range
+                    done = gfin != 0 && ak >= mlo[0] && ak <= mhi[0];
+                    s_lim = WR_UNIFORM(done ? -(1 << 30) : s_lim);
+                } else {
+                    // interior (see wfa_lean2_forward): the ranges of the new wavefronts from those of their sources
+                    const int i_lo = WR_UNIFORM((mlo[4] < ilo[1] ? mlo[4] : ilo[1]) + 1), i_hi = WR_UNIFORM((mhi[4] > ihi[1] ? mhi[4] : ihi[1]) + 1);
+                    const int d_lo = WR_UNIFORM((mlo[4] < dlo[1] ? mlo[4] : dlo[1]) - 1), d_hi = WR_UNIFORM((mhi[4] > dhi[1] ? mhi[4] : dhi[1]) - 1);
+                    ilo[0] = i_lo <= i_hi ? i_lo : E_LO;
+                    ihi[0] = i_lo <= i_hi ? i_hi : E_HI;
+                    dlo[0] = d_lo <= d_hi ? d_lo : E_LO;
+                    dhi[0] = d_lo <= d_hi ? d_hi : E_HI;
+                    mlo[0] = lo; // (= min / max over M[s-4], I[s], D[s]: the row itself)
+                    mhi[0] = hi;
+                    edge_m = WR_UNIFORM(WR_READLANE(r, 20)); // -1 once any wavefront's cell has touched an end
+                    done = gfin != 0 && ak >= lo && ak <= hi;
+                    s_lim = WR_UNIFORM(done ? -(1 << 30) : s_lim);
+                }
                 if (mhi[0] - mlo[0] + 1 >= 10) { // wf-adaptive(10, 50)  (workgroup-uniform)
                     const int top = ak < mhi[0] ? ak : mhi[0];
                     const int bottom = ak > mlo[0] ? ak : mlo[0];
@@ -443,7 +481,13 @@ template <int NCW, bool WIN> WR_DEV void wfa_mw2_forward(const L2Prob &p, int32_
             }
             WR_BARRIER(); // C: the rows of score s are in the ring (and both strips may be written again)
         }
-        // ---- what is due instead of a plain step (lo, hi: the row of score s + 2) ----
+    };
+    while (status == 0 && !done) {
+        if (edge_m)
+            hot(std::true_type{});
+        else
+            hot(std::false_type{});
+        // ---- what is due instead of a plain step (lo, hi: the row of score s + 2; possibly nothing but the first touch) ----
         if (done) break;
         if (s + 2 >= s_limit) {
             status = 1;
