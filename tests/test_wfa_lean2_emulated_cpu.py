@@ -182,3 +182,14 @@ def test_windowed_form_statuses_and_drift():
         nc *= 2
         st, got, nrec = run1(q, t, nc, win=True)
     assert st == 0 and got == run_oracle_wfa(q, t) and nrec >= 2
+
+
+def test_the_first_touch_of_a_sequence_end_is_the_end():
+    """one edit in the middle of otherwise identical sequences: the extension that follows it runs to the end - the score step
+    that leaves the interior mode is also the last one"""
+    rng = random.Random(71)
+    q = rand_seq(rng, 900)
+    for t in (q[:450] + (b"A" if q[450:451] != b"A" else b"C") + q[451:], q[:450] + b"ACGTT" + q[450:], q[:450] + q[457:], q):
+        exp = run_oracle_wfa(q, t)
+        for nc, r16, win in ((1, False, False), (2, True, False), (2, False, True), (4, True, False)):
+            assert run1(q, t, nc, r16, win=win)[:2] == (0, exp)

@@ -108,3 +108,13 @@ def test_wandering_wavefront_recentres_the_ring():
     assert st == 0 and got == exp and nrec >= 1
     st, got, nrec = run1(q, t, 1, win=True)
     assert st == 0 and got == exp and nrec >= 1
+
+
+def test_the_first_touch_of_a_sequence_end_is_the_end():
+    """one edit in the middle of otherwise identical sequences: the score step that leaves the interior mode is also the last"""
+    rng = random.Random(71)
+    q = rand_seq(rng, 900)
+    for t in (q[:450] + (b"A" if q[450:451] != b"A" else b"C") + q[451:], q[:450] + b"ACGTT" + q[450:], q[:450] + q[457:], q):
+        exp = run_oracle_wfa(q, t)
+        for ncw, win in ((1, False), (2, True)):
+            assert run1(q, t, ncw, win=win)[:2] == (0, exp)
