@@ -15,6 +15,9 @@
 // minimum over the wavefront, result uniform; all 64 lanes active.  The DPP source selection on the minimum itself (six
 // v_min_i32_dpp) instead of six v_mov_b32_dpp + six v_min_i32; two wait states between a write and the DPP read of it.
 __device__ __forceinline__ int l2_wave_min_i32(int v) {
+#ifdef L2_NO_ASM /* -DL2_NO_ASM: the builtin forms of everything written in assembly here (first thing to try if the GPU disagrees) */
+    return wave_min_i32(v);
+#else
     asm("s_nop 1\n\tv_min_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
@@ -23,19 +26,28 @@ __device__ __forceinline__ int l2_wave_min_i32(int v) {
         "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
         : "+v"(v));
     return __builtin_amdgcn_readlane(v, 63);
+#endif
 }
 #undef WR_WAVE_MIN_I32
 #define WR_WAVE_MIN_I32(v) l2_wave_min_i32(v)
 // first set bit / leading zeros of a wave mask on the scalar unit, -1 for an empty mask (the C builtins leave that case undefined)
 __device__ __forceinline__ int l2_sff1(unsigned long long m) {
+#ifdef L2_NO_ASM
+    return m ? __builtin_ctzll(m) : -1;
+#else
     int r;
     asm("s_ff1_i32_b64 %0, %1" : "=s"(r) : "s"(m));
     return r;
+#endif
 }
 __device__ __forceinline__ int l2_sflb(unsigned long long m) {
+#ifdef L2_NO_ASM
+    return m ? __builtin_clzll(m) : -1;
+#else
     int r;
     asm("s_flbit_i32_b64 %0, %1" : "=s"(r) : "s"(m));
     return r;
+#endif
 }
 #define WR_FF1(x) l2_sff1(x)
 #define WR_FLB(x) l2_sflb(x)
