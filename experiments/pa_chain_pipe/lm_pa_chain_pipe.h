@@ -1,9 +1,11 @@
 // experiments/pa_chain_pipe/lm_pa_chain_pipe.h - device side of pa_chain_pipe.h (STAGED for round 5): k_pa_chain_pipe, a
-// workgroup of PCP_NW wavefronts per LONG chaining window (n >= a few hundred anchors; the short ones - nearly all windows -
-// stay with k_pa_chain_wave, one wavefront each).  Included inside namespace lm after k_pa_chain_wave (lm_kernels.hip): it
-// reuses lm_unpack_anchor / lm_trim / the backtrack of lm_run_chain2's second half through the same scratch pools.
-// NOT run on a GPU yet: compiled for gfx950 (experiments/pa_chain_pipe/compile_check.hip), the DP itself checked on the
-// host SIMT emulator.  What the first GPU run has to confirm is listed at the end of this file.
+// workgroup of PCP_NW wavefronts for the Chainer2 DP of a LONG chaining window.  k_pa_chain_wave (one wavefront per window)
+// keeps unpacking, ClearSubstrPairs and TrimSubStrPairs of every window and the whole of the short ones - nearly all of them;
+// a window with more than `pipe_min` anchors left after the trim is handed over (clr_n[ti] = anchors, out_n[ti] = first anchor,
+// the task appended to a list) and gets its DP here and the backtrack of lm_run_chain2's second half (lm_chain2_backtrack:
+// the block k_pa_chain_wave ran on lane 0, factored out by tools/adopt_pa_chain_pipe.py).  Included inside namespace lm after
+// k_pa_chain_wave.  NOT run on a GPU yet: compiled for gfx950, the DP checked on the host SIMT emulator
+// (tests/test_pa_chain_pipe_emulated_cpu.py).
 #pragma once
 
 #define PCP_DEV __device__ __forceinline__
@@ -24,123 +26,26 @@
 
 #include "pa_chain_pipe.h"
 
-// One workgroup (PCP_NW * 64 threads) per window of `long_tasks` (the tasks with more than LM_PA_PIPE_MIN anchors, listed by
-// the host or by a compaction kernel).  Same inputs, scratch pools and outputs as k_pa_chain_wave.
-__global__ __launch_bounds__(PCP_NW * 64) void k_pa_chain_pipe(const uint64_t *__restrict__ B, const int64_t *__restrict__ pa_off,
-                                                                const int32_t *__restrict__ long_tasks, int nlong, int K, LmChain2Opt opt,
-                                                                LmSub *__restrict__ subs_pool, uint8_t *__restrict__ marks_pool,
-                                                                uint64_t *__restrict__ msi_pool, int32_t *__restrict__ stack_pool,
-                                                                LmChain2 *__restrict__ out_pool, int32_t *__restrict__ out_n,
-                                                                int32_t *__restrict__ clr_n, int qbits, int tbits) {
-    constexpr int T = PCP_NW * 64;
+__global__ __launch_bounds__(PCP_NW * 64) void k_pa_chain_pipe(const int64_t *__restrict__ pa_off, const int32_t *__restrict__ long_tasks,
+                                                                const unsigned int *__restrict__ nlong_p, LmChain2Opt opt,
+                                                                const LmSub *__restrict__ subs_pool, uint64_t *__restrict__ msi_pool,
+                                                                int32_t *__restrict__ stack_pool, LmChain2 *__restrict__ out_pool,
+                                                                int32_t *__restrict__ out_n, const int32_t *__restrict__ clr_n) {
     __shared__ PcpLds pl;
-    __shared__ int sh_n, sh_start, sh_w;
-    __shared__ int sh_cnt[PCP_NW];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int li = blockIdx.x; li < nlong; li += gridDim.x) {
+    const int tid = threadIdx.x;
+    const unsigned int nlong = *nlong_p;
+    for (unsigned int li = blockIdx.x; li < nlong; li += gridDim.x) {
         const int64_t ti = long_tasks[li];
         const int64_t o = pa_off[ti];
-        int n = (int)(pa_off[ti + 1] - o);
-        LmSub *sb = subs_pool + o;
-        uint8_t *marks = marks_pool + o;
+        const int n = clr_n[ti], start = out_n[ti]; // (left by k_pa_chain_wave)
+        const LmSub *a_ = subs_pool + o + start;
         uint64_t *msi = msi_pool + o;
-        LmChain2 *res = out_pool + o;
-        __syncthreads();
-        for (int i = tid; i < n; i += T) { // unpack (as k_pa_chain_wave)
-            const uint64_t v = B[o + i];
-            if (qbits > 0) {
-                LmSub u;
-                u.qbegin = (int32_t)((v >> (8 + tbits)) & ((1ull << qbits) - 1ull));
-                u.len = (uint8_t)(32 - (int)((v >> (2 + tbits)) & 63));
-                u.tbegin = (int32_t)((v >> 2) & ((1ull << tbits) - 1ull));
-                u.qrc = (uint8_t)((v >> 1) & 1);
-                u.trc = (uint8_t)(v & 1);
-                u.pad = 0;
-                sb[i] = u;
-            } else {
-                sb[i] = lm_unpack_anchor(v);
-            }
-        }
-        __threadfence_block();
-        __syncthreads();
-        // ---- ClearSubstrPairs: a thread per anchor (an anchor's mark depends on the original list only) ----
-        for (int i = tid; i < n; i += T) {
-            uint8_t mk = 0;
-            if (i >= 1) {
-                const LmSub v = sb[i];
-                const int32_t vqend = v.qbegin + v.len;
-                int32_t upbound = vqend - K;
-                if (upbound < 0) upbound = 0;
-                const int32_t vtend = v.tbegin + v.len;
-                int lo = 0, hi = i;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (sb[mid].qbegin < upbound)
-                        lo = mid + 1;
-                    else
-                        hi = mid;
-                }
-                for (int j = lo; j < i; j++) {
-                    const LmSub p = sb[j];
-                    if (vqend <= p.qbegin + p.len && v.tbegin >= p.tbegin && vtend <= p.tbegin + p.len) {
-                        mk = 1;
-                        break;
-                    }
-                }
-            }
-            marks[i] = mk;
-        }
-        __threadfence_block();
-        __syncthreads();
-        // ordered in-place compaction, T anchors per pass (wave counts through LDS)
-        if (tid == 0) sh_w = 0;
-        __syncthreads();
-        for (int c = 0; c < n; c += T) {
-            const int i = c + tid;
-            const bool keep = i < n && !marks[i];
-            LmSub v;
-            if (keep) v = sb[i];
-            const unsigned long long bal = __ballot(keep);
-            if (lane == 0) sh_cnt[wave] = __popcll(bal);
-            __syncthreads(); // (also: every thread has read its anchor before anybody writes)
-            int before = sh_w + __popcll(bal & ((1ull << lane) - 1ull));
-            int total = 0;
-            for (int w2 = 0; w2 < PCP_NW; w2++) {
-                if (w2 < wave) before += sh_cnt[w2];
-                total += sh_cnt[w2];
-            }
-            if (keep) sb[before] = v;
-            __threadfence_block();
-            __syncthreads();
-            if (tid == 0) sh_w += total;
-            __syncthreads();
-        }
-        // ---- TrimSubStrPairs (thread 0; it stops after a few anchors) ----
-        if (tid == 0) {
-            int start = 0;
-            sh_n = lm_trim(sb, sh_w, 100.0f, &start);
-            sh_start = start;
-            clr_n[ti] = sh_n;
-        }
-        __syncthreads();
-        n = sh_n;
-        const LmSub *a_ = sb + sh_start;
-        if (n <= 1) { // (a long window that clears down to nothing: the wavefront kernel's small cases)
-            if (tid == 0) out_n[ti] = n <= 0 ? 0 : lm_run_chain2(a_, 1, opt, msi, stack_pool + 2 * o + 4 * ti, res);
-            continue;
-        }
+        __syncthreads(); // the previous window is done with the LDS strip (and has read out_n / clr_n)
         long long M = 0;
         int Mi = 0;
         pa_chain_dp_pipe(a_, n, opt, msi, &pl, &M, &Mi);
         __threadfence_block();
-        __syncthreads();
-        // ---- backtrack with the explicit region stack: identical to k_pa_chain_wave's (thread 0) ----
-        if (tid == 0) out_n[ti] = lm_chain2_backtrack(a_, n, opt, msi, M, Mi, stack_pool + 2 * o + 4 * ti, res);
+        __syncthreads(); // every wavefront's msi[] entries are visible to thread 0
+        if (tid == 0) out_n[ti] = lm_chain2_backtrack(a_, n, opt, msi, M, Mi, stack_pool + 2 * o + 4 * ti, out_pool + o);
     }
 }
-
-// To do at integration (round 5):
-//  * lm_chain2_backtrack: k_pa_chain_wave's lane-0 block after its DP, factored out as a function both kernels call;
-//  * the list of long tasks (n > ~512 anchors): one pass over pa_off after k_pa_task_off_sorted; k_pa_chain_wave skips them;
-//  * first GPU run: test_pseudoalign_parity, tests/test_gpu_c4c5.py, tests/test_gpu_longreads.py; then a C4 shard line
-//    (target: k_pa_chain 130 -> < 40 ms per launch) - the spin-waits on `done` are the one thing the emulator cannot time.

@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""adopt_pa_chain_pipe.py [--root DIR]: puts the staged k_pa_chain_pipe (experiments/pa_chain_pipe: the Chainer2 DP of a long
+chaining window by a workgroup of eight pipelined wavefronts) into the product sources under DIR (default: this repository).
+k_pa_chain_wave keeps unpack / ClearSubstrPairs / Trim of every window and the short windows whole; windows with more than
+LM_PA_PIPE_MIN (512) anchors after the trim are handed to k_pa_chain_pipe; switch LM_PA_CHAIN_PIPE (default on).  The backtrack
+block of k_pa_chain_wave becomes the function lm_chain2_backtrack both kernels call.  Every edit is asserted against the text
+it replaces.  (Checked in round 4 on a copy of the tree: the library builds.)  Round 5: run it, build, then
+tests/test_gpu_parity.py (pseudo-alignment chains), tests/test_gpu_c4c5.py, tests/test_gpu_longreads.py with the switch on
+and off, then a C4 shard line."""
+import os
+import sys
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if len(sys.argv) >= 3 and sys.argv[1] == "--root":
+    root = os.path.abspath(sys.argv[2])
+src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "experiments", "pa_chain_pipe")
+csrc = os.path.join(root, "lexicmap_amd", "csrc")
+
+
+def edit(path, pairs):
+    s = open(path).read()
+    for old, new in pairs:
+        assert s.count(old) == 1, (path, old[:70], s.count(old))
+        s = s.replace(old, new)
+    open(path, "w").write(s)
+
+
+for f, g in (("pa_chain_pipe.h", "lm_pa_chain_pipe_dp.h"), ("lm_pa_chain_pipe.h", "lm_pa_chain_pipe.h")):
+    t = open(os.path.join(src, f)).read().replace("experiments/pa_chain_pipe/" + f, g).replace("(STAGED for round 5)", "")
+    open(os.path.join(csrc, g), "w").write(t)
+edit(os.path.join(csrc, "lm_pa_chain_pipe.h"), [('#include "pa_chain_pipe.h"', '#include "lm_pa_chain_pipe_dp.h"')])
+
+# 1. the backtrack block of k_pa_chain_wave as a function
+k = os.path.join(csrc, "lm_kernels.hip")
+s = open(k).read()
+a = "        // ---- backtrack with the explicit region stack (lane 0), identical to lm_run_chain2's second half ----\n        if (lane == 0) {\n            int nout = 0;\n"
+b = "            out_n[ti] = nout;\n        }\n    }\n}\n"
+assert s.count(a) == 1 and s.count(b) == 1
+i, j = s.index(a), s.index(b)
+body = s[i + len(a):j]
+decl = "                int32_t *stack = stack_pool + 2 * o + 4 * ti;\n"
+assert body.count(decl) == 1
+body = body.replace(decl, "")
+body = "\n".join(ln[8:] if ln.startswith("        ") else ln for ln in body.split("\n"))  # one level out
+fn = ("// Backtrack with the explicit region stack: lm_run_chain2's second half, by one thread (k_pa_chain_wave's lane 0,\n"
+      "// k_pa_chain_pipe's thread 0).  msi[]: (score << 32 | predecessor) per anchor, M / Mi the best score and its anchor.\n"
+      "__device__ int lm_chain2_backtrack(const LmSub *a_, int n, const LmChain2Opt &opt, const uint64_t *msi, long long M, int Mi, int32_t *stack,\n"
+      "                                   LmChain2 *res) {\n    int nout = 0;\n" + body + "    return nout;\n}\n\n")
+s = s[:i] + ("        // ---- backtrack (lm_chain2_backtrack), or the hand-over of a long window to k_pa_chain_pipe ----\n"
+             "        if (lane == 0) out_n[ti] = lm_chain2_backtrack(a_, n, opt, msi, M, Mi, stack_pool + 2 * o + 4 * ti, res);\n"
+             "    }\n}\n") + s[j + len(b):]
+h = "// RING: the DP keeps the recent anchors and scores in an LDS ring (lm_pa_chain_dp_core.h); otherwise every step goes\n"
+assert s.count(h) == 1
+s = s.replace(h, fn + h)
+open(k, "w").write(s)
+
+edit(k, [
+    # 2. k_pa_chain_wave hands long windows over
+    ("                                                       int32_t *__restrict__ out_n, int32_t *__restrict__ clr_n, int qbits,\n"
+     "                                                       int tbits) {\n    const int lane = threadIdx.x;\n    __shared__ PcdLds pcd_lds;\n",
+     "                                                       int32_t *__restrict__ out_n, int32_t *__restrict__ clr_n, int qbits,\n"
+     "                                                       int tbits, int pipe_min, int32_t *__restrict__ long_tasks,\n"
+     "                                                       unsigned int *__restrict__ nlong) {\n    const int lane = threadIdx.x;\n    __shared__ PcdLds pcd_lds;\n"),
+    ("        const LmSub *a_ = sb + start;\n        if (n == 1) {\n",
+     "        const LmSub *a_ = sb + start;\n"
+     "        if (pipe_min > 0 && n > pipe_min) { // a long window: its DP and backtrack by a workgroup (k_pa_chain_pipe)\n"
+     "            if (lane == 0) {\n                out_n[ti] = start;\n                long_tasks[atomicAdd(nlong, 1u)] = (int32_t)ti;\n            }\n"
+     "            continue;\n        }\n        if (n == 1) {\n"),
+    # 3. the workgroup kernel and the launcher
+    ("__global__ void k_gather_chain2(", '#include "lm_pa_chain_pipe.h"\n\n__global__ void k_gather_chain2('),
+    ("                     int32_t *clr_n, int qbits, int tbits, bool ring) {\n"
+     "    int g = (int)(ntasks < 1 ? 1 : (ntasks > 262144 ? 262144 : ntasks));\n"
+     "    hipLaunchKernelGGL(ring ? k_pa_chain_wave<true> : k_pa_chain_wave<false>, dim3(g), dim3(64), 0, st, B, pa_off, ntasks, K, opt, subs, marks, msi, stack, out, out_n,\n"
+     "                       clr_n, qbits, tbits);\n",
+     "                     int32_t *clr_n, int qbits, int tbits, bool ring, int pipe_min, int64_t total) {\n"
+     "    int g = (int)(ntasks < 1 ? 1 : (ntasks > 262144 ? 262144 : ntasks));\n"
+     "    // pipe_min > 0: the list of long windows and its counter live behind the stacks (stack holds 2 * total + 5 * ntasks + 16 ints)\n"
+     "    int32_t *long_tasks = stack + 2 * total + 4 * ntasks + 8;\n"
+     "    unsigned int *nlong = (unsigned int *)(long_tasks + ntasks);\n"
+     "    if (pipe_min > 0) (void)hipMemsetAsync(nlong, 0, sizeof(unsigned int), st);\n"
+     "    hipLaunchKernelGGL(ring ? k_pa_chain_wave<true> : k_pa_chain_wave<false>, dim3(g), dim3(64), 0, st, B, pa_off, ntasks, K, opt, subs, marks, msi, stack, out, out_n,\n"
+     "                       clr_n, qbits, tbits, pipe_min, long_tasks, nlong);\n"
+     "    if (pipe_min > 0) // (the number of long windows is known on the device only: a grid that fills the chip, workgroups loop)\n"
+     "        hipLaunchKernelGGL(k_pa_chain_pipe, dim3((unsigned)(ntasks < 1024 ? (ntasks < 1 ? 1 : ntasks) : 1024)), dim3(PCP_NW * 64), 0, st, pa_off, long_tasks,\n"
+     "                           nlong, opt, subs, msi, stack, out, out_n, clr_n);\n"),
+])
+edit(os.path.join(csrc, "lm_kernels.h"), [
+    ("                     int32_t *clr_n, int qbits, int tbits, bool ring);", "                     int32_t *clr_n, int qbits, int tbits, bool ring, int pipe_min = 0, int64_t total = 0);"),
+])
+edit(os.path.join(csrc, "lm_internal.h"), [
+    ("    int pa_chain_ring = 1;   // Chainer2 DP with the recent anchors in an LDS ring",
+     "    int pa_chain_pipe = 1;   // the Chainer2 DP of windows with more than pa_pipe_min anchors by a workgroup of pipelined wavefronts (LM_PA_CHAIN_PIPE=0: off)\n"
+     "    int pa_pipe_min = 512;   // LM_PA_PIPE_MIN\n"
+     "    int pa_chain_ring = 1;   // Chainer2 DP with the recent anchors in an LDS ring"),
+    ('        if (const char *e = getenv("LM_PA_CHAIN_RING")) pa_chain_ring = atoi(e) != 0;\n',
+     '        if (const char *e = getenv("LM_PA_CHAIN_RING")) pa_chain_ring = atoi(e) != 0;\n'
+     '        if (const char *e = getenv("LM_PA_CHAIN_PIPE")) pa_chain_pipe = atoi(e) != 0;\n'
+     '        if (const char *e = getenv("LM_PA_PIPE_MIN")) pa_pipe_min = std::max(64, atoi(e));\n'),
+])
+edit(os.path.join(csrc, "lm_pipeline.hip"), [
+    ("        a.stack.ensure(2 * (size_t)TP + 4 * (size_t)nt + 8);\n", "        a.stack.ensure(2 * (size_t)TP + 5 * (size_t)nt + 16); // (+ the list of long windows and its counter)\n"),
+    ("a.out.p, a.out_n.p, a.clr_n.p, compact ? qbits : 0, compact ? tbits : 0, ix->tune.pa_chain_ring != 0);",
+     "a.out.p, a.out_n.p, a.clr_n.p, compact ? qbits : 0, compact ? tbits : 0, ix->tune.pa_chain_ring != 0,\n"
+     "                            ix->tune.pa_chain_pipe ? ix->tune.pa_pipe_min : 0, TP);"),
+])
+edit(os.path.join(csrc, "Makefile"), [
+    ("lm_pa_chain_dp.h lm_pa_chain_dp_core.h\n", "lm_pa_chain_dp.h lm_pa_chain_dp_core.h lm_pa_chain_pipe.h lm_pa_chain_pipe_dp.h\n"),
+])
+print("k_pa_chain_pipe adopted under", root)
