@@ -23,7 +23,12 @@
 //  * the extension of M[s] is FUSED behind its computation: the new offsets are extended in registers and stored once, with
 //    the cut-off already applied - no read-back, no second store, no NULL-back stores, one LDS hand-off per score instead of
 //    three.  (M cells outside the trimmed range are NULL by sanitisation, so "valid" is all the extension has to know.)
-//  * extension step: one running offset per cell, the end-of-sequence clamp hoisted out of the loop (hmax per cell).
+//  * extension step: v_alignbit_b32 on the two words that hold the last of the 32 bits, one running offset per cell, the
+//    end-of-sequence clamp hoisted out of the loop (hmax per cell), the predicate recomputed from registers every pass.
+//  * INTERIOR / EDGE: until some M cell has reached the end of a sequence every cell with a valid source is inside the DP
+//    matrix and the trimmed ranges are scalar minima / maxima of the older ranges; two copies of the hot loop.
+//  * the hot loop is the plain score step only (one sign test decides); rare events live in an outer loop; the lane's row
+//    addresses rotate in vector registers instead of "row = f(s mod 5)" on the scalar unit.
 // One source for the device (hipcc) and for the host emulator (tests/emu/simt_emu.h): every cross-lane operation sits in
 // wave-uniform control flow.
 #pragma once
