@@ -3,7 +3,7 @@
 // STAGED for round 5: equal to the oracle on the host SIMT emulator (tests/test_wfa_lean2_emulated_cpu.py), compiled for
 // gfx950 beside the product kernels (compile_check.hip), instruction counts of the score loop in README.md; never run on a GPU.
 //
-// Why: k_wfa_lean is 60 % of the vector and 63 % of the scalar instructions of a C3 step (profiles/r04_c3_pmc_sq.json) and it
+// Why: k_wfa_lean is 58 % of the vector and 71 % of the scalar instructions of a C3 step (profiles/r04_c3_pmc_sq.json) and it
 // runs at its instruction roofline (experiments/README.md, valu_rate): only fewer instructions per score step make it faster.
 // Its ISA spends more than half of a step on bookkeeping: the slot -> diagonal mapping of a ring that wraps (k, j, in-range
 // masks per chunk and phase, twice per score), three packed DPP reductions for the trimmed ranges and two for the cut-off
