@@ -5,5 +5,6 @@
 
 namespace lm {
 __device__ int lm_chain2_backtrack(const LmSub *, int, const LmChain2Opt &, uint64_t *, long long, int, int32_t *, LmChain2 *) { return 0; }
+#include "../pa_chain_bt/lm_pa_chain_bt.h"
 #include "lm_pa_chain_pipe.h"
 } // namespace lm

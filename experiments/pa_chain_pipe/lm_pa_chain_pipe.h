@@ -30,8 +30,9 @@ __global__ __launch_bounds__(PCP_NW * 64) void k_pa_chain_pipe(const int64_t *__
                                                                 const unsigned int *__restrict__ nlong_p, LmChain2Opt opt,
                                                                 const LmSub *__restrict__ subs_pool, uint64_t *__restrict__ msi_pool,
                                                                 int32_t *__restrict__ stack_pool, LmChain2 *__restrict__ out_pool,
-                                                                int32_t *__restrict__ out_n, const int32_t *__restrict__ clr_n) {
+                                                                int32_t *__restrict__ out_n, const int32_t *__restrict__ clr_n, int bt_wave) {
     __shared__ PcpLds pl;
+    __shared__ PcbLds pcb;
     const int tid = threadIdx.x;
     const unsigned int nlong = *nlong_p;
     for (unsigned int li = blockIdx.x; li < nlong; li += gridDim.x) {
@@ -46,6 +47,13 @@ __global__ __launch_bounds__(PCP_NW * 64) void k_pa_chain_pipe(const int64_t *__
         pa_chain_dp_pipe(a_, n, opt, msi, &pl, &M, &Mi);
         __threadfence_block();
         __syncthreads(); // every wavefront's msi[] entries are visible to thread 0
-        if (tid == 0) out_n[ti] = lm_chain2_backtrack(a_, n, opt, msi, M, Mi, stack_pool + 2 * o + 4 * ti, out_pool + o);
+        if (bt_wave) { // the first wavefront (experiments/pa_chain_bt)
+            if (tid < 64) {
+                const int no = pa_chain_backtrack_wave(a_, n, opt, msi, M, Mi, stack_pool + 2 * o + 4 * ti, out_pool + o, &pcb);
+                if (tid == 0) out_n[ti] = no;
+            }
+        } else if (tid == 0) {
+            out_n[ti] = lm_chain2_backtrack(a_, n, opt, msi, M, Mi, stack_pool + 2 * o + 4 * ti, out_pool + o);
+        }
     }
 }

@@ -2,7 +2,8 @@
 """adopt_pa_chain_pipe.py [--root DIR]: puts the staged k_pa_chain_pipe (experiments/pa_chain_pipe: the Chainer2 DP of a long
 chaining window by a workgroup of eight pipelined wavefronts) into the product sources under DIR (default: this repository).
 k_pa_chain_wave keeps unpack / ClearSubstrPairs / Trim of every window and the short windows whole; windows with more than
-LM_PA_PIPE_MIN (512) anchors after the trim are handed to k_pa_chain_pipe; switch LM_PA_CHAIN_PIPE (default on).  The backtrack
+LM_PA_PIPE_MIN (512) anchors after the trim are handed to k_pa_chain_pipe; switch LM_PA_CHAIN_PIPE (default on).  Also the backtrack by the wavefront
+(experiments/pa_chain_bt: region scans by 64 lanes, the walk out of LDS tiles) in both kernels, switch LM_PA_CHAIN_BT_WAVE.  The backtrack
 block of k_pa_chain_wave becomes the function lm_chain2_backtrack both kernels call.  Every edit is asserted against the text
 it replaces.  (Checked in round 4 on a copy of the tree: the library builds.)  Round 5: run it, build, then
 tests/test_gpu_parity.py (pseudo-alignment chains), tests/test_gpu_c4c5.py, tests/test_gpu_longreads.py with the switch on
@@ -29,6 +30,12 @@ for f, g in (("pa_chain_pipe.h", "lm_pa_chain_pipe_dp.h"), ("lm_pa_chain_pipe.h"
     t = open(os.path.join(src, f)).read().replace("experiments/pa_chain_pipe/" + f, g).replace("(STAGED for round 5)", "")
     open(os.path.join(csrc, g), "w").write(t)
 edit(os.path.join(csrc, "lm_pa_chain_pipe.h"), [('#include "pa_chain_pipe.h"', '#include "lm_pa_chain_pipe_dp.h"')])
+# the wavefront backtrack (experiments/pa_chain_bt), switch LM_PA_CHAIN_BT_WAVE
+src_bt = os.path.join(os.path.dirname(src), "pa_chain_bt")
+for f, g in (("pa_chain_bt.h", "lm_pa_chain_bt_core.h"), ("lm_pa_chain_bt.h", "lm_pa_chain_bt.h")):
+    t = open(os.path.join(src_bt, f)).read().replace("experiments/pa_chain_bt/" + f, g).replace("(STAGED for round 5)", "")
+    open(os.path.join(csrc, g), "w").write(t)
+edit(os.path.join(csrc, "lm_pa_chain_bt.h"), [('#include "pa_chain_bt.h"', '#include "lm_pa_chain_bt_core.h"')])
 
 # 1. the backtrack block of k_pa_chain_wave as a function
 k = os.path.join(csrc, "lm_kernels.hip")
@@ -47,7 +54,12 @@ fn = ("// Backtrack with the explicit region stack: lm_run_chain2's second half,
       "__device__ int lm_chain2_backtrack(const LmSub *a_, int n, const LmChain2Opt &opt, const uint64_t *msi, long long M, int Mi, int32_t *stack,\n"
       "                                   LmChain2 *res) {\n    int nout = 0;\n" + body + "    return nout;\n}\n\n")
 s = s[:i] + ("        // ---- backtrack (lm_chain2_backtrack), or the hand-over of a long window to k_pa_chain_pipe ----\n"
-             "        if (lane == 0) out_n[ti] = lm_chain2_backtrack(a_, n, opt, msi, M, Mi, stack_pool + 2 * o + 4 * ti, res);\n"
+             "        if (bt_wave) { // by the wavefront: region scans by 64 lanes, the walk out of LDS tiles (lm_pa_chain_bt.h)\n"
+             "            const int no = pa_chain_backtrack_wave(a_, n, opt, msi, M, Mi, stack_pool + 2 * o + 4 * ti, res, &pcb_lds);\n"
+             "            if (lane == 0) out_n[ti] = no;\n"
+             "        } else if (lane == 0) {\n"
+             "            out_n[ti] = lm_chain2_backtrack(a_, n, opt, msi, M, Mi, stack_pool + 2 * o + 4 * ti, res);\n"
+             "        }\n"
              "    }\n}\n") + s[j + len(b):]
 h = "// RING: the DP keeps the recent anchors and scores in an LDS ring (lm_pa_chain_dp_core.h); otherwise every step goes\n"
 assert s.count(h) == 1
@@ -60,7 +72,8 @@ edit(k, [
      "                                                       int tbits) {\n    const int lane = threadIdx.x;\n    __shared__ PcdLds pcd_lds;\n",
      "                                                       int32_t *__restrict__ out_n, int32_t *__restrict__ clr_n, int qbits,\n"
      "                                                       int tbits, int pipe_min, int32_t *__restrict__ long_tasks,\n"
-     "                                                       unsigned int *__restrict__ nlong) {\n    const int lane = threadIdx.x;\n    __shared__ PcdLds pcd_lds;\n"),
+     "                                                       unsigned int *__restrict__ nlong, int bt_wave) {\n    const int lane = threadIdx.x;\n    __shared__ PcdLds pcd_lds;\n    __shared__ PcbLds pcb_lds;\n"),
+    ('#include "lm_pa_chain_dp.h"\n', '#include "lm_pa_chain_dp.h"\n#include "lm_pa_chain_bt.h"\n'),
     ("        const LmSub *a_ = sb + start;\n        if (n == 1) {\n",
      "        const LmSub *a_ = sb + start;\n"
      "        if (pipe_min > 0 && n > pipe_min) { // a long window: its DP and backtrack by a workgroup (k_pa_chain_pipe)\n"
@@ -72,38 +85,40 @@ edit(k, [
      "    int g = (int)(ntasks < 1 ? 1 : (ntasks > 262144 ? 262144 : ntasks));\n"
      "    hipLaunchKernelGGL(ring ? k_pa_chain_wave<true> : k_pa_chain_wave<false>, dim3(g), dim3(64), 0, st, B, pa_off, ntasks, K, opt, subs, marks, msi, stack, out, out_n,\n"
      "                       clr_n, qbits, tbits);\n",
-     "                     int32_t *clr_n, int qbits, int tbits, bool ring, int pipe_min, int64_t total) {\n"
+     "                     int32_t *clr_n, int qbits, int tbits, bool ring, int pipe_min, int64_t total, bool bt_wave) {\n"
      "    int g = (int)(ntasks < 1 ? 1 : (ntasks > 262144 ? 262144 : ntasks));\n"
      "    // pipe_min > 0: the list of long windows and its counter live behind the stacks (stack holds 2 * total + 5 * ntasks + 16 ints)\n"
      "    int32_t *long_tasks = stack + 2 * total + 4 * ntasks + 8;\n"
      "    unsigned int *nlong = (unsigned int *)(long_tasks + ntasks);\n"
      "    if (pipe_min > 0) (void)hipMemsetAsync(nlong, 0, sizeof(unsigned int), st);\n"
      "    hipLaunchKernelGGL(ring ? k_pa_chain_wave<true> : k_pa_chain_wave<false>, dim3(g), dim3(64), 0, st, B, pa_off, ntasks, K, opt, subs, marks, msi, stack, out, out_n,\n"
-     "                       clr_n, qbits, tbits, pipe_min, long_tasks, nlong);\n"
+     "                       clr_n, qbits, tbits, pipe_min, long_tasks, nlong, bt_wave ? 1 : 0);\n"
      "    if (pipe_min > 0) // (the number of long windows is known on the device only: a grid that fills the chip, workgroups loop)\n"
      "        hipLaunchKernelGGL(k_pa_chain_pipe, dim3((unsigned)(ntasks < 1024 ? (ntasks < 1 ? 1 : ntasks) : 1024)), dim3(PCP_NW * 64), 0, st, pa_off, long_tasks,\n"
-     "                           nlong, opt, subs, msi, stack, out, out_n, clr_n);\n"),
+     "                           nlong, opt, subs, msi, stack, out, out_n, clr_n, bt_wave ? 1 : 0);\n"),
 ])
 edit(os.path.join(csrc, "lm_kernels.h"), [
-    ("                     int32_t *clr_n, int qbits, int tbits, bool ring);", "                     int32_t *clr_n, int qbits, int tbits, bool ring, int pipe_min = 0, int64_t total = 0);"),
+    ("                     int32_t *clr_n, int qbits, int tbits, bool ring);", "                     int32_t *clr_n, int qbits, int tbits, bool ring, int pipe_min = 0, int64_t total = 0, bool bt_wave = false);"),
 ])
 edit(os.path.join(csrc, "lm_internal.h"), [
     ("    int pa_chain_ring = 1;   // Chainer2 DP with the recent anchors in an LDS ring",
      "    int pa_chain_pipe = 1;   // the Chainer2 DP of windows with more than pa_pipe_min anchors by a workgroup of pipelined wavefronts (LM_PA_CHAIN_PIPE=0: off)\n"
      "    int pa_pipe_min = 512;   // LM_PA_PIPE_MIN\n"
+     "    int pa_chain_bt_wave = 1; // the backtrack of Chainer2 by the wavefront (LDS tiles, 64-lane region scans); LM_PA_CHAIN_BT_WAVE=0: lane 0\n"
      "    int pa_chain_ring = 1;   // Chainer2 DP with the recent anchors in an LDS ring"),
     ('        if (const char *e = getenv("LM_PA_CHAIN_RING")) pa_chain_ring = atoi(e) != 0;\n',
      '        if (const char *e = getenv("LM_PA_CHAIN_RING")) pa_chain_ring = atoi(e) != 0;\n'
      '        if (const char *e = getenv("LM_PA_CHAIN_PIPE")) pa_chain_pipe = atoi(e) != 0;\n'
-     '        if (const char *e = getenv("LM_PA_PIPE_MIN")) pa_pipe_min = std::max(64, atoi(e));\n'),
+     '        if (const char *e = getenv("LM_PA_PIPE_MIN")) pa_pipe_min = std::max(64, atoi(e));\n'
+     '        if (const char *e = getenv("LM_PA_CHAIN_BT_WAVE")) pa_chain_bt_wave = atoi(e) != 0;\n'),
 ])
 edit(os.path.join(csrc, "lm_pipeline.hip"), [
     ("        a.stack.ensure(2 * (size_t)TP + 4 * (size_t)nt + 8);\n", "        a.stack.ensure(2 * (size_t)TP + 5 * (size_t)nt + 16); // (+ the list of long windows and its counter)\n"),
     ("a.out.p, a.out_n.p, a.clr_n.p, compact ? qbits : 0, compact ? tbits : 0, ix->tune.pa_chain_ring != 0);",
      "a.out.p, a.out_n.p, a.clr_n.p, compact ? qbits : 0, compact ? tbits : 0, ix->tune.pa_chain_ring != 0,\n"
-     "                            ix->tune.pa_chain_pipe ? ix->tune.pa_pipe_min : 0, TP);"),
+     "                            ix->tune.pa_chain_pipe ? ix->tune.pa_pipe_min : 0, TP, ix->tune.pa_chain_bt_wave != 0);"),
 ])
 edit(os.path.join(csrc, "Makefile"), [
-    ("lm_pa_chain_dp.h lm_pa_chain_dp_core.h\n", "lm_pa_chain_dp.h lm_pa_chain_dp_core.h lm_pa_chain_pipe.h lm_pa_chain_pipe_dp.h\n"),
+    ("lm_pa_chain_dp.h lm_pa_chain_dp_core.h\n", "lm_pa_chain_dp.h lm_pa_chain_dp_core.h lm_pa_chain_pipe.h lm_pa_chain_pipe_dp.h lm_pa_chain_bt.h lm_pa_chain_bt_core.h\n"),
 ])
 print("k_pa_chain_pipe adopted under", root)
