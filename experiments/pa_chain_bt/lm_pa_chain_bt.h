@@ -10,3 +10,9 @@
 #define PCB_WAVE_MAX_U64(v) pcd_wave_max_u64(v)
 
 #include "pa_chain_bt.h"
+
+#define PCC_DEV __device__ __forceinline__
+#define PCC_LANE ((int)(threadIdx.x & 63))
+#define PCC_LDS_SYNC() LDS_WAVE_SYNC()
+#include "pa_clear_tile.h"
+static_assert(sizeof(PccLds) <= sizeof(PcdLds), "the clear tile aliases the DP's ring");

@@ -84,3 +84,29 @@ extern "C" int pcb_emu_check(const int32_t *qb, const int32_t *tb, const uint8_t
     }
     return bad;
 }
+
+// ---- ClearSubstrPairs marks from LDS tiles (experiments/pa_chain_bt/pa_clear_tile.h) against lm_clear_sorted ----
+#define PCC_DEV static inline
+#define PCC_LANE (simt::lane())
+#define PCC_LDS_SYNC() simt::wave_sync(__LINE__)
+#include "../../experiments/pa_chain_bt/pa_clear_tile.h"
+
+// returns the number of marks that differ from lm_clear_sorted's; *kept: anchors the reference keeps
+extern "C" int pcc_emu_check(const int32_t *qb, const int32_t *tb, const uint8_t *len, int n, int K, int *kept) {
+    std::vector<LmSub> a((size_t)n), b;
+    for (int i = 0; i < n; i++) {
+        memset(&a[i], 0, sizeof(LmSub));
+        a[i].qbegin = qb[i];
+        a[i].tbegin = tb[i];
+        a[i].len = len[i];
+    }
+    b = a;
+    std::vector<uint8_t> mref((size_t)n + 1, 0), m((size_t)n + 1, 0x5a);
+    *kept = lm_clear_sorted(b.data(), n, K, mref.data());
+    PccLds lds;
+    memset(&lds, 0x5a, sizeof lds);
+    simt::run_wave([&](int) { pa_clear_marks_wave(a.data(), n, K, m.data(), &lds); });
+    int bad = 0;
+    for (int i = 0; i < n; i++) bad += (n > 1 ? mref[i] : 0) != m[i];
+    return bad;
+}

@@ -84,3 +84,42 @@ def test_degenerate_inputs():
     assert check(sorted((rng.randrange(0, 50), rng.randrange(0, 50), 11) for _ in range(200)))[0] == 0
     assert check(colinear(rng, 500), min_score=1 << 30) == (0, 0)            # nothing reaches the score: no chain
     assert check(colinear(rng, 500), min_score=1)[0] == 0                    # every region is walked down to single anchors
+
+
+def check_clear(anchors, K=31):
+    n = len(anchors)
+    qb = (C.c_int32 * n)(*[a[0] for a in anchors])
+    tb = (C.c_int32 * n)(*[a[1] for a in anchors])
+    ln = (C.c_uint8 * n)(*[a[2] for a in anchors])
+    kept = C.c_int()
+    return lib().pcc_emu_check(qb, tb, ln, n, K, C.byref(kept)), kept.value
+
+
+def dense(rng, n, per_pos=(1, 3), step=(1, 4)):
+    """pseudo-alignment-like anchors: along a diagonal, a few per query position, lengths 11-31 - most are nested in an earlier one"""
+    out, q = [], 0
+    while len(out) < n:
+        for _ in range(rng.randint(*per_pos)):
+            out.append((q, q + rng.choice((0, 0, 0, 1, -1, 500)), rng.randint(11, 31)))
+        q += rng.randint(*step)
+    return sorted(out[:n])
+
+
+@pytest.mark.parametrize("n,seed", [(1, 1), (2, 2), (63, 3), (64, 4), (65, 5), (129, 6), (1000, 7), (4000, 8)])
+def test_clear_marks_from_lds_tiles_equal_lm_clear_sorted(n, seed):
+    rng = random.Random(seed)
+    bad, kept = check_clear(dense(rng, n))
+    assert bad == 0
+    if n >= 64:
+        assert kept < n  # (something is nested)
+    assert check_clear(colinear(rng, n))[0] == 0
+
+
+def test_clear_marks_when_the_candidates_reach_beyond_the_halo():
+    """more than 64 anchors within the K - len bases before an anchor: the scan goes on in global memory"""
+    rng = random.Random(31)
+    crowded = sorted([(100 + rng.randint(0, 3), 100 + rng.randint(0, 900), 11) for _ in range(300)] + [(104, 104, 31), (104, 600, 12)])
+    assert check_clear(crowded)[0] == 0
+    assert check_clear(dense(rng, 2000, per_pos=(20, 40), step=(1, 2)))[0] == 0
+    assert check_clear(dense(rng, 500), K=15)[0] == 0
+    assert check_clear([(5, 5, 31)] * 200)[0] == 0  # identical anchors: every one but the first is nested

@@ -32,10 +32,10 @@ for f, g in (("pa_chain_pipe.h", "lm_pa_chain_pipe_dp.h"), ("lm_pa_chain_pipe.h"
 edit(os.path.join(csrc, "lm_pa_chain_pipe.h"), [('#include "pa_chain_pipe.h"', '#include "lm_pa_chain_pipe_dp.h"')])
 # the wavefront backtrack (experiments/pa_chain_bt), switch LM_PA_CHAIN_BT_WAVE
 src_bt = os.path.join(os.path.dirname(src), "pa_chain_bt")
-for f, g in (("pa_chain_bt.h", "lm_pa_chain_bt_core.h"), ("lm_pa_chain_bt.h", "lm_pa_chain_bt.h")):
+for f, g in (("pa_chain_bt.h", "lm_pa_chain_bt_core.h"), ("pa_clear_tile.h", "lm_pa_clear_tile.h"), ("lm_pa_chain_bt.h", "lm_pa_chain_bt.h")):
     t = open(os.path.join(src_bt, f)).read().replace("experiments/pa_chain_bt/" + f, g).replace("(STAGED for round 5)", "")
     open(os.path.join(csrc, g), "w").write(t)
-edit(os.path.join(csrc, "lm_pa_chain_bt.h"), [('#include "pa_chain_bt.h"', '#include "lm_pa_chain_bt_core.h"')])
+edit(os.path.join(csrc, "lm_pa_chain_bt.h"), [('#include "pa_chain_bt.h"', '#include "lm_pa_chain_bt_core.h"'), ('#include "pa_clear_tile.h"', '#include "lm_pa_clear_tile.h"')])
 
 # 1. the backtrack block of k_pa_chain_wave as a function
 k = os.path.join(csrc, "lm_kernels.hip")
@@ -54,7 +54,7 @@ fn = ("// Backtrack with the explicit region stack: lm_run_chain2's second half,
       "__device__ int lm_chain2_backtrack(const LmSub *a_, int n, const LmChain2Opt &opt, const uint64_t *msi, long long M, int Mi, int32_t *stack,\n"
       "                                   LmChain2 *res) {\n    int nout = 0;\n" + body + "    return nout;\n}\n\n")
 s = s[:i] + ("        // ---- backtrack (lm_chain2_backtrack), or the hand-over of a long window to k_pa_chain_pipe ----\n"
-             "        if (bt_wave) { // by the wavefront: region scans by 64 lanes, the walk out of LDS tiles (lm_pa_chain_bt.h)\n"
+             "        if (bt_wave & 1) { // by the wavefront: region scans by 64 lanes, the walk out of LDS tiles (lm_pa_chain_bt.h)\n"
              "            const int no = pa_chain_backtrack_wave(a_, n, opt, msi, M, Mi, stack_pool + 2 * o + 4 * ti, res, &pcb_lds);\n"
              "            if (lane == 0) out_n[ti] = no;\n"
              "        } else if (lane == 0) {\n"
@@ -79,46 +79,50 @@ edit(k, [
      "        if (pipe_min > 0 && n > pipe_min) { // a long window: its DP and backtrack by a workgroup (k_pa_chain_pipe)\n"
      "            if (lane == 0) {\n                out_n[ti] = start;\n                long_tasks[atomicAdd(nlong, 1u)] = (int32_t)ti;\n            }\n"
      "            continue;\n        }\n        if (n == 1) {\n"),
+    # 2b. the marks of ClearSubstrPairs from LDS tiles (the tile aliases the DP's ring: the DP comes later)
+    ("            for (int i = lane; i < n; i += 64) {\n                uint8_t mk = 0;\n                if (i >= 1) {\n                    const LmSub v = sb[i];\n",
+     "            if (bt_wave & 2) pa_clear_marks_wave(sb, n, K, marks, (PccLds *)&pcd_lds);\n"
+     "            for (int i = lane; i < n && !(bt_wave & 2); i += 64) {\n                uint8_t mk = 0;\n                if (i >= 1) {\n                    const LmSub v = sb[i];\n"),
     # 3. the workgroup kernel and the launcher
     ("__global__ void k_gather_chain2(", '#include "lm_pa_chain_pipe.h"\n\n__global__ void k_gather_chain2('),
     ("                     int32_t *clr_n, int qbits, int tbits, bool ring) {\n"
      "    int g = (int)(ntasks < 1 ? 1 : (ntasks > 262144 ? 262144 : ntasks));\n"
      "    hipLaunchKernelGGL(ring ? k_pa_chain_wave<true> : k_pa_chain_wave<false>, dim3(g), dim3(64), 0, st, B, pa_off, ntasks, K, opt, subs, marks, msi, stack, out, out_n,\n"
      "                       clr_n, qbits, tbits);\n",
-     "                     int32_t *clr_n, int qbits, int tbits, bool ring, int pipe_min, int64_t total, bool bt_wave) {\n"
+     "                     int32_t *clr_n, int qbits, int tbits, bool ring, int pipe_min, int64_t total, int bt_wave) {\n"
      "    int g = (int)(ntasks < 1 ? 1 : (ntasks > 262144 ? 262144 : ntasks));\n"
      "    // pipe_min > 0: the list of long windows and its counter live behind the stacks (stack holds 2 * total + 5 * ntasks + 16 ints)\n"
      "    int32_t *long_tasks = stack + 2 * total + 4 * ntasks + 8;\n"
      "    unsigned int *nlong = (unsigned int *)(long_tasks + ntasks);\n"
      "    if (pipe_min > 0) (void)hipMemsetAsync(nlong, 0, sizeof(unsigned int), st);\n"
      "    hipLaunchKernelGGL(ring ? k_pa_chain_wave<true> : k_pa_chain_wave<false>, dim3(g), dim3(64), 0, st, B, pa_off, ntasks, K, opt, subs, marks, msi, stack, out, out_n,\n"
-     "                       clr_n, qbits, tbits, pipe_min, long_tasks, nlong, bt_wave ? 1 : 0);\n"
+     "                       clr_n, qbits, tbits, pipe_min, long_tasks, nlong, bt_wave);\n"
      "    if (pipe_min > 0) // (the number of long windows is known on the device only: a grid that fills the chip, workgroups loop)\n"
      "        hipLaunchKernelGGL(k_pa_chain_pipe, dim3((unsigned)(ntasks < 1024 ? (ntasks < 1 ? 1 : ntasks) : 1024)), dim3(PCP_NW * 64), 0, st, pa_off, long_tasks,\n"
-     "                           nlong, opt, subs, msi, stack, out, out_n, clr_n, bt_wave ? 1 : 0);\n"),
+     "                           nlong, opt, subs, msi, stack, out, out_n, clr_n, bt_wave & 1);\n"),
 ])
 edit(os.path.join(csrc, "lm_kernels.h"), [
-    ("                     int32_t *clr_n, int qbits, int tbits, bool ring);", "                     int32_t *clr_n, int qbits, int tbits, bool ring, int pipe_min = 0, int64_t total = 0, bool bt_wave = false);"),
+    ("                     int32_t *clr_n, int qbits, int tbits, bool ring);", "                     int32_t *clr_n, int qbits, int tbits, bool ring, int pipe_min = 0, int64_t total = 0, int bt_wave = 0);"),
 ])
 edit(os.path.join(csrc, "lm_internal.h"), [
     ("    int pa_chain_ring = 1;   // Chainer2 DP with the recent anchors in an LDS ring",
      "    int pa_chain_pipe = 1;   // the Chainer2 DP of windows with more than pa_pipe_min anchors by a workgroup of pipelined wavefronts (LM_PA_CHAIN_PIPE=0: off)\n"
      "    int pa_pipe_min = 512;   // LM_PA_PIPE_MIN\n"
-     "    int pa_chain_bt_wave = 1; // the backtrack of Chainer2 by the wavefront (LDS tiles, 64-lane region scans); LM_PA_CHAIN_BT_WAVE=0: lane 0\n"
+     "    int pa_chain_bt_wave = 3; // LM_PA_CHAIN_BT_WAVE: bit 0 = the backtrack of Chainer2 by the wavefront (LDS tiles, 64-lane region scans; 0: lane 0), bit 1 = the marks of ClearSubstrPairs from LDS tiles (0: binary search + scan in global memory)\n"
      "    int pa_chain_ring = 1;   // Chainer2 DP with the recent anchors in an LDS ring"),
     ('        if (const char *e = getenv("LM_PA_CHAIN_RING")) pa_chain_ring = atoi(e) != 0;\n',
      '        if (const char *e = getenv("LM_PA_CHAIN_RING")) pa_chain_ring = atoi(e) != 0;\n'
      '        if (const char *e = getenv("LM_PA_CHAIN_PIPE")) pa_chain_pipe = atoi(e) != 0;\n'
      '        if (const char *e = getenv("LM_PA_PIPE_MIN")) pa_pipe_min = std::max(64, atoi(e));\n'
-     '        if (const char *e = getenv("LM_PA_CHAIN_BT_WAVE")) pa_chain_bt_wave = atoi(e) != 0;\n'),
+     '        if (const char *e = getenv("LM_PA_CHAIN_BT_WAVE")) pa_chain_bt_wave = atoi(e) & 3;\n'),
 ])
 edit(os.path.join(csrc, "lm_pipeline.hip"), [
     ("        a.stack.ensure(2 * (size_t)TP + 4 * (size_t)nt + 8);\n", "        a.stack.ensure(2 * (size_t)TP + 5 * (size_t)nt + 16); // (+ the list of long windows and its counter)\n"),
     ("a.out.p, a.out_n.p, a.clr_n.p, compact ? qbits : 0, compact ? tbits : 0, ix->tune.pa_chain_ring != 0);",
      "a.out.p, a.out_n.p, a.clr_n.p, compact ? qbits : 0, compact ? tbits : 0, ix->tune.pa_chain_ring != 0,\n"
-     "                            ix->tune.pa_chain_pipe ? ix->tune.pa_pipe_min : 0, TP, ix->tune.pa_chain_bt_wave != 0);"),
+     "                            ix->tune.pa_chain_pipe ? ix->tune.pa_pipe_min : 0, TP, ix->tune.pa_chain_bt_wave);"),
 ])
 edit(os.path.join(csrc, "Makefile"), [
-    ("lm_pa_chain_dp.h lm_pa_chain_dp_core.h\n", "lm_pa_chain_dp.h lm_pa_chain_dp_core.h lm_pa_chain_pipe.h lm_pa_chain_pipe_dp.h lm_pa_chain_bt.h lm_pa_chain_bt_core.h\n"),
+    ("lm_pa_chain_dp.h lm_pa_chain_dp_core.h\n", "lm_pa_chain_dp.h lm_pa_chain_dp_core.h lm_pa_chain_pipe.h lm_pa_chain_pipe_dp.h lm_pa_chain_bt.h lm_pa_chain_bt_core.h lm_pa_clear_tile.h\n"),
 ])
 print("k_pa_chain_pipe adopted under", root)
