@@ -125,4 +125,8 @@ edit(os.path.join(csrc, "lm_pipeline.hip"), [
 edit(os.path.join(csrc, "Makefile"), [
     ("lm_pa_chain_dp.h lm_pa_chain_dp_core.h\n", "lm_pa_chain_dp.h lm_pa_chain_dp_core.h lm_pa_chain_pipe.h lm_pa_chain_pipe_dp.h lm_pa_chain_bt.h lm_pa_chain_bt_core.h lm_pa_clear_tile.h\n"),
 ])
+# the rows of the long-read fixture with the new switches off (tests/test_gpu_longreads.py: every pair of device paths agrees)
+t = os.path.join(root, "tests", "test_gpu_longreads.py")
+if os.path.exists(t):
+    edit(t, [('for var, off in (("LM_WFA_MW", "0"), ', 'for var, off in (("LM_WFA_MW", "0"), (\"LM_PA_CHAIN_PIPE\", \"0\"), (\"LM_PA_CHAIN_BT_WAVE\", \"0\"), (\"LM_PA_PIPE_MIN\", \"64\"), ')])
 print("k_pa_chain_pipe adopted under", root)

@@ -121,4 +121,8 @@ def test_every_instantiation_equals_the_oracle_with_the_switch_on_and_off():
     on = [v["kernels"] for k, v in report.items() if '"LM_WFA_LEAN2": "1"' in k]
     assert on and all(v for v in on)
 ''')
+# the rows of the long-read fixture with the new switches off (tests/test_gpu_longreads.py: every pair of device paths agrees)
+t = os.path.join(root, "tests", "test_gpu_longreads.py")
+if os.path.exists(t):
+    edit(t, [('for var, off in (("LM_WFA_MW", "0"), ', 'for var, off in (("LM_WFA_MW", "0"), (\"LM_WFA_LEAN2\", \"0\"), ')])
 print("k_wfa_lean2 adopted under", root)
