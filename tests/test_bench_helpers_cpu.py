@@ -86,6 +86,12 @@ def test_rocprof_kernel_names_match_the_names_bench_reports():
     assert S.short("void lm::k_wfa_lean<4, true>(lm::WfaIn const*, long)") == "k_wfa_win256"
     assert S.short("void lm::k_wfa_lean<8, (bool)0>(x)") == "k_wfa_lean512"
     assert S.short("void lm::k_wfa_lean<16, (bool)1>(x)") == "k_wfa_win1024"
+    assert S.short("void lm::k_wfa_lean<4, false, short>(x)") == "k_wfa_lean256"   # the 16-bit ring instantiations
+    assert S.short("void lm::k_wfa_lean<2, false, int>(x)") == "k_wfa_lean"
+    # the staged restructured kernels (experiments/wfa_lean2) take the names of the kernels they replace
+    assert S.short("void lm::k_wfa_lean2<2, short, false>(x)") == "k_wfa_lean"
+    assert S.short("void lm::k_wfa_lean2<4, int, (bool)1>(x)") == "k_wfa_win256"
+    assert S.short("void lm::k_wfa_mw2<4, true>(x)") == "k_wfa_mww1024"
     assert S.short("void lm::k_wfa_mw<2, false>(lm::WfaIn const*, long)") == "k_wfa_mw512"
     assert S.short("void lm::k_wfa_mw<4, (bool)1>(x)") == "k_wfa_mww1024"
     assert S.short("void lm::k_pa_chain_wave<true>(unsigned long const*, ...)") == "k_pa_chain"

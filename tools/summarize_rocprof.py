@@ -12,7 +12,18 @@ import sys
 
 
 def short(name):
-    m = re.search(r"lm::(k_[a-z0-9_]+)(?:<(\d+)(?:, *(true|false|\(bool\)[01]|[01]))?>)?", name)
+    # k_wfa_lean2<NC, cell type, WIN> / k_wfa_mw2<NCW, WIN> (the restructured forward passes): the names of the kernels they replace
+    m = re.search(r"lm::k_wfa_lean2<(\d+), *[a-z_ ]+, *(true|false|\(bool\)[01]|[01])>", name)
+    if m:
+        win = m.group(2).replace("(bool)", "") in ("true", "1")
+        if win:
+            return "k_wfa_win" + {"1": "64", "2": "128", "4": "256", "8": "512", "16": "1024"}.get(m.group(1), m.group(1))
+        return "k_wfa_lean" + {"1": "64", "2": "", "4": "256", "8": "512", "16": "1024"}.get(m.group(1), m.group(1))
+    m = re.search(r"lm::k_wfa_mw2<(\d+), *(true|false|\(bool\)[01]|[01])>", name)
+    if m:
+        win = m.group(2).replace("(bool)", "") in ("true", "1")
+        return ("k_wfa_mww" if win else "k_wfa_mw") + {"2": "512", "4": "1024"}.get(m.group(1), m.group(1))
+    m = re.search(r"lm::(k_[a-z0-9_]+)(?:<(\d+)(?:, *(true|false|\(bool\)[01]|[01]))?(?:, *[a-z_ ]+)?>)?", name)  # (<NC, WIN, cell type>)
     if m:
         if m.group(1) == "k_wfa_lean" and m.group(2):  # the names bench.py reports: k_wfa_lean<NC, WIN> -> diagonals of the ring
             win = (m.group(3) or "").replace("(bool)", "") in ("true", "1")  # (128 = plain); WIN = sliding sequence windows
