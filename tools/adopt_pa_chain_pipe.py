@@ -129,4 +129,7 @@ edit(os.path.join(csrc, "Makefile"), [
 t = os.path.join(root, "tests", "test_gpu_longreads.py")
 if os.path.exists(t):
     edit(t, [('for var, off in (("LM_WFA_MW", "0"), ', 'for var, off in (("LM_WFA_MW", "0"), (\"LM_PA_CHAIN_PIPE\", \"0\"), (\"LM_PA_CHAIN_BT_WAVE\", \"0\"), (\"LM_PA_PIPE_MIN\", \"64\"), ')])
+t = os.path.join(root, "tests", "test_adopt_scripts_cpu.py")  # (checks that the scripts apply to the UNadopted tree: done with)
+if os.path.exists(t):
+    os.remove(t)
 print("k_pa_chain_pipe adopted under", root)

@@ -125,4 +125,7 @@ def test_every_instantiation_equals_the_oracle_with_the_switch_on_and_off():
 t = os.path.join(root, "tests", "test_gpu_longreads.py")
 if os.path.exists(t):
     edit(t, [('for var, off in (("LM_WFA_MW", "0"), ', 'for var, off in (("LM_WFA_MW", "0"), (\"LM_WFA_LEAN2\", \"0\"), ')])
+t = os.path.join(root, "tests", "test_adopt_scripts_cpu.py")  # (checks that the scripts apply to the UNadopted tree: done with)
+if os.path.exists(t):
+    os.remove(t)
 print("k_wfa_lean2 adopted under", root)
