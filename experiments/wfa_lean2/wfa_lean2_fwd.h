@@ -299,6 +299,7 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
     int s_lim = s_limit; // the hot loop's copy: pulled below every score once the end is reached (one sign test covers both)
     int shrink_from = 0; // no "fewer chunks ?" test before this score (a live row may be wider than the new one for a while)
     int lo = 0, hi = 0; // the row of score s + 2 as the hot loop saw it when it left
+    int32_t *hp = p.hdr2; // = p.hdr2 + s: carried along instead of recomputed from s (a 64-bit shift and add per score)
     // the hot loop, in two copies: INTERIOR (leaves also at the first touch) and EDGE
     auto hot = [&](auto in_edge) {
         constexpr bool EDGE = decltype(in_edge)::value;
@@ -322,6 +323,7 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
             if ((int32_t)rare < 0) break;
             // ---- a plain step ----
             s += 2;
+            hp += 2;
 #pragma unroll
             for (int a = 4; a > 0; a--) {
                 mlo[a] = mlo[a - 1];
@@ -346,9 +348,9 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
             const int32_t rowb = used;
             used += (int32_t)span + 1;
             if (lane == 0) { // entry s/2 = {lo, row offset}; the offset of entry s/2+1 closes the row
-                p.hdr2[s] = lo;
-                p.hdr2[s + 1] = rowb;
-                p.hdr2[s + 3] = used;
+                hp[0] = lo;
+                hp[1] = rowb;
+                hp[3] = used;
             }
             const LP M8 = pM[4], M4 = pM[2], I2 = pI[1], D2 = pD[1]; // rows of s-8, s-4, s-2
             const int32_t rowk = rowb - lo; // byte of diagonal k: bt[rowk + k] (never negative for a cell of the row)
@@ -560,6 +562,7 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
         }
         if (lo > hi) { // no source wavefront (all four empty): an empty row
             s += 2;
+            hp += 2;
 #pragma unroll
             for (int a = 4; a > 0; a--) {
                 mlo[a] = mlo[a - 1];
@@ -585,9 +588,9 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
 #pragma unroll
             for (int c = 0; c < NC; c++) pM[0][64 * c + 1] = pI[0][64 * c + 1] = pD[0][64 * c + 1] = (RT)RNULL;
             if (lane == 0) { // same offset as the next row
-                p.hdr2[s] = 0;
-                p.hdr2[s + 1] = used;
-                p.hdr2[s + 3] = used;
+                hp[0] = 0;
+                hp[1] = used;
+                hp[3] = used;
             }
             WR_WAVE_SYNC();
             continue;
