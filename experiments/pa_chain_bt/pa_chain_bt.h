@@ -19,6 +19,9 @@
 #include <stdint.h>
 
 #define PCB_TILE 64
+#ifndef PCB_COUNT
+#define PCB_COUNT(what) /* the emulator harness counts walk steps and tile loads */
+#endif
 struct PcbLds {
     uint64_t msi[PCB_TILE];
     int32_t q[PCB_TILE], t[PCB_TILE], len[PCB_TILE];
@@ -73,6 +76,7 @@ PCB_DEV int pa_chain_backtrack_wave(const LmSub *a_, int n, const LmChain2Opt &o
         while (true) {
             if ((uint32_t)(i - tb) >= (uint32_t)PCB_TILE) { // the walk left the tile: the 64 anchors ending at i
                 PCB_LDS_SYNC(); // every lane is done with the old tile
+                PCB_COUNT(1);
                 tb = i - (PCB_TILE - 1) > 0 ? i - (PCB_TILE - 1) : 0;
                 const int g = tb + lane;
                 if (g < n) {
@@ -85,6 +89,7 @@ PCB_DEV int pa_chain_backtrack_wave(const LmSub *a_, int n, const LmChain2Opt &o
                 PCB_LDS_SYNC();
             }
             const int o = i - tb;
+            PCB_COUNT(0);
             j = (int)(L->msi[o] & 4294967295ull);
             if (j < lo) {
                 jneg = true;

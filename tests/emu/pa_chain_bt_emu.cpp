@@ -22,6 +22,8 @@ static inline unsigned long long emu_wave_max_u64(unsigned long long v, int site
     return m;
 }
 #define PCB_WAVE_MAX_U64(v) emu_wave_max_u64((v), __LINE__)
+static long g_pcb_count[2]; // walk steps, tile loads (lane 0's)
+#define PCB_COUNT(what) do { if (simt::lane() == 0) g_pcb_count[what]++; } while (0)
 
 #include "../../experiments/pa_chain_bt/pa_chain_bt.h"
 
@@ -72,6 +74,7 @@ extern "C" int pcb_emu_check(const int32_t *qb, const int32_t *tb, const uint8_t
     PcbLds lds;
     memset(&lds, 0x5a, sizeof lds);
     int nout[64];
+    g_pcb_count[0] = g_pcb_count[1] = 0;
     simt::run_wave([&](int lane) { nout[lane] = pa_chain_backtrack_wave(a.data(), n, opt, msi.data(), M, Mi, stack2.data(), got.data(), &lds); });
     int bad = 0;
     for (int l = 1; l < 64; l++) bad += nout[l] != nout[0];
@@ -83,6 +86,10 @@ extern "C" int pcb_emu_check(const int32_t *qb, const int32_t *tb, const uint8_t
                x.tbegin != y.tbegin || x.tend != y.tend;
     }
     return bad;
+}
+extern "C" void pcb_emu_counts(long *steps, long *tiles) {
+    *steps = g_pcb_count[0];
+    *tiles = g_pcb_count[1];
 }
 
 // ---- ClearSubstrPairs marks from LDS tiles (experiments/pa_chain_bt/pa_clear_tile.h) against lm_clear_sorted ----

@@ -123,3 +123,14 @@ def test_clear_marks_when_the_candidates_reach_beyond_the_halo():
     assert check_clear(dense(rng, 2000, per_pos=(20, 40), step=(1, 2)))[0] == 0
     assert check_clear(dense(rng, 500), K=15)[0] == 0
     assert check_clear([(5, 5, 31)] * 200)[0] == 0  # identical anchors: every one but the first is nested
+
+
+def test_a_tile_serves_tens_of_walk_steps():
+    """the point of the LDS tile: the walk along a chain of 3000 anchors reloads it once per ~40 steps (the lane-0 backtrack
+    it replaces makes two dependent global loads per step)"""
+    rng = random.Random(41)
+    bad, nch = check(colinear(rng, 3000))
+    assert bad == 0 and nch >= 1
+    steps, tiles = C.c_long(), C.c_long()
+    lib().pcb_emu_counts(C.byref(steps), C.byref(tiles))
+    assert steps.value >= 1000 and tiles.value * 20 <= steps.value, (steps.value, tiles.value)
