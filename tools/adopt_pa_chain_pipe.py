@@ -54,11 +54,16 @@ fn = ("// Backtrack with the explicit region stack: lm_run_chain2's second half,
       "__device__ int lm_chain2_backtrack(const LmSub *a_, int n, const LmChain2Opt &opt, const uint64_t *msi, long long M, int Mi, int32_t *stack,\n"
       "                                   LmChain2 *res) {\n    int nout = 0;\n" + body + "    return nout;\n}\n\n")
 s = s[:i] + ("        // ---- backtrack (lm_chain2_backtrack), or the hand-over of a long window to k_pa_chain_pipe ----\n"
+             "        if (dbg) d_2 = wall_clock64();\n"
              "        if (bt_wave & 1) { // by the wavefront: region scans by 64 lanes, the walk out of LDS tiles (lm_pa_chain_bt.h)\n"
              "            const int no = pa_chain_backtrack_wave(a_, n, opt, msi, M, Mi, stack_pool + 2 * o + 4 * ti, res, &pcb_lds);\n"
              "            if (lane == 0) out_n[ti] = no;\n"
              "        } else if (lane == 0) {\n"
              "            out_n[ti] = lm_chain2_backtrack(a_, n, opt, msi, M, Mi, stack_pool + 2 * o + 4 * ti, res);\n"
+             "        }\n"
+             "        if (dbg && lane == 0) {\n"
+             "            const unsigned long long d_3 = wall_clock64();\n"
+             "            atomicAdd(dbg + 0, d_1 - d_0);\n            atomicAdd(dbg + 1, d_2 - d_1);\n            atomicAdd(dbg + 2, d_3 - d_2);\n            atomicAdd(dbg + 3, 1ull);\n"
              "        }\n"
              "    }\n}\n") + s[j + len(b):]
 h = "// RING: the DP keeps the recent anchors and scores in an LDS ring (lm_pa_chain_dp_core.h); otherwise every step goes\n"
@@ -72,7 +77,14 @@ edit(k, [
      "                                                       int tbits) {\n    const int lane = threadIdx.x;\n    __shared__ PcdLds pcd_lds;\n",
      "                                                       int32_t *__restrict__ out_n, int32_t *__restrict__ clr_n, int qbits,\n"
      "                                                       int tbits, int pipe_min, int32_t *__restrict__ long_tasks,\n"
-     "                                                       unsigned int *__restrict__ nlong, int bt_wave) {\n    const int lane = threadIdx.x;\n    __shared__ PcdLds pcd_lds;\n    __shared__ PcbLds pcb_lds;\n"),
+     "                                                       unsigned int *__restrict__ nlong, int bt_wave,\n"
+     "                                                       unsigned long long *__restrict__ dbg) {\n    const int lane = threadIdx.x;\n    __shared__ PcdLds pcd_lds;\n    __shared__ PcbLds pcb_lds;\n"),
+    # LM_DEBUG_PA_CHAIN (dbg != nullptr): where a window's time goes - unpack + clear + trim / DP / backtrack, summed over the
+    # windows this kernel finishes itself, on the 100-MHz wall clock
+    ("        LmChain2 *res = out_pool + o;\n        for (int i = lane; i < n; i += 64) {\n            const uint64_t v = B[o + i];\n",
+     "        LmChain2 *res = out_pool + o;\n        unsigned long long d_0 = 0, d_1 = 0, d_2 = 0;\n        if (dbg) d_0 = wall_clock64();\n"
+     "        for (int i = lane; i < n; i += 64) {\n            const uint64_t v = B[o + i];\n"),
+    ("        long long M = 0;\n        int Mi = 0;\n        if (RING) {\n            pa_chain_dp_ring(", "        if (dbg) d_1 = wall_clock64();\n        long long M = 0;\n        int Mi = 0;\n        if (RING) {\n            pa_chain_dp_ring("),
     ('#include "lm_pa_chain_dp.h"\n', '#include "lm_pa_chain_dp.h"\n#include "lm_pa_chain_bt.h"\n'),
     ("        const LmSub *a_ = sb + start;\n        if (n == 1) {\n",
      "        const LmSub *a_ = sb + start;\n"
@@ -91,15 +103,24 @@ edit(k, [
      "                       clr_n, qbits, tbits);\n",
      "                     int32_t *clr_n, int qbits, int tbits, bool ring, int pipe_min, int64_t total, int bt_wave) {\n"
      "    int g = (int)(ntasks < 1 ? 1 : (ntasks > 262144 ? 262144 : ntasks));\n"
-     "    // pipe_min > 0: the list of long windows and its counter live behind the stacks (stack holds 2 * total + 5 * ntasks + 16 ints)\n"
+     "    // pipe_min > 0: the list of long windows and its counter live behind the stacks (stack holds 2 * total + 5 * ntasks + 48 ints)\n"
      "    int32_t *long_tasks = stack + 2 * total + 4 * ntasks + 8;\n"
      "    unsigned int *nlong = (unsigned int *)(long_tasks + ntasks);\n"
+     "    static const bool pa_dbg = getenv(\"LM_DEBUG_PA_CHAIN\") != nullptr; // phase times of k_pa_chain_wave (stack holds 16 more ints)\n"
+     "    unsigned long long *dbg = pa_dbg ? (unsigned long long *)(((uintptr_t)(nlong + 2) + 7) & ~(uintptr_t)7) : nullptr;\n"
+     "    if (dbg) (void)hipMemsetAsync(dbg, 0, 4 * sizeof(unsigned long long), st);\n"
      "    if (pipe_min > 0) (void)hipMemsetAsync(nlong, 0, sizeof(unsigned int), st);\n"
      "    hipLaunchKernelGGL(ring ? k_pa_chain_wave<true> : k_pa_chain_wave<false>, dim3(g), dim3(64), 0, st, B, pa_off, ntasks, K, opt, subs, marks, msi, stack, out, out_n,\n"
-     "                       clr_n, qbits, tbits, pipe_min, long_tasks, nlong, bt_wave);\n"
+     "                       clr_n, qbits, tbits, pipe_min, long_tasks, nlong, bt_wave, dbg);\n"
      "    if (pipe_min > 0) // (the number of long windows is known on the device only: a grid that fills the chip, workgroups loop)\n"
      "        hipLaunchKernelGGL(k_pa_chain_pipe, dim3((unsigned)(ntasks < 1024 ? (ntasks < 1 ? 1 : ntasks) : 1024)), dim3(PCP_NW * 64), 0, st, pa_off, long_tasks,\n"
-     "                           nlong, opt, subs, msi, stack, out, out_n, clr_n, bt_wave & 1);\n"),
+     "                           nlong, opt, subs, msi, stack, out, out_n, clr_n, bt_wave & 1);\n"
+     "    if (dbg) {\n"
+     "        unsigned long long h[4] = {0, 0, 0, 0};\n        unsigned int nl = 0;\n"
+     "        (void)hipStreamSynchronize(st);\n        (void)hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost);\n        (void)hipMemcpy(&nl, nlong, sizeof nl, hipMemcpyDeviceToHost);\n"
+     "        fprintf(stderr, \"[lm] k_pa_chain: %lld windows (%llu finished by the wavefront kernel, %u handed to the workgroup kernel), wavefront-ms: clear+trim %.1f, DP %.1f, backtrack %.1f\\n\",\n"
+     "                (long long)ntasks, h[3], pipe_min > 0 ? nl : 0u, (double)h[0] / 1e5, (double)h[1] / 1e5, (double)h[2] / 1e5);\n"
+     "    }\n"),
 ])
 edit(os.path.join(csrc, "lm_kernels.h"), [
     ("                     int32_t *clr_n, int qbits, int tbits, bool ring);", "                     int32_t *clr_n, int qbits, int tbits, bool ring, int pipe_min = 0, int64_t total = 0, int bt_wave = 0);"),
@@ -117,7 +138,7 @@ edit(os.path.join(csrc, "lm_internal.h"), [
      '        if (const char *e = getenv("LM_PA_CHAIN_BT_WAVE")) pa_chain_bt_wave = atoi(e) & 3;\n'),
 ])
 edit(os.path.join(csrc, "lm_pipeline.hip"), [
-    ("        a.stack.ensure(2 * (size_t)TP + 4 * (size_t)nt + 8);\n", "        a.stack.ensure(2 * (size_t)TP + 5 * (size_t)nt + 16); // (+ the list of long windows and its counter)\n"),
+    ("        a.stack.ensure(2 * (size_t)TP + 4 * (size_t)nt + 8);\n", "        a.stack.ensure(2 * (size_t)TP + 5 * (size_t)nt + 48); // (+ the list of long windows, its counter, the debug counters)\n"),
     ("a.out.p, a.out_n.p, a.clr_n.p, compact ? qbits : 0, compact ? tbits : 0, ix->tune.pa_chain_ring != 0);",
      "a.out.p, a.out_n.p, a.clr_n.p, compact ? qbits : 0, compact ? tbits : 0, ix->tune.pa_chain_ring != 0,\n"
      "                            ix->tune.pa_chain_pipe ? ix->tune.pa_pipe_min : 0, TP, ix->tune.pa_chain_bt_wave);"),
