@@ -79,6 +79,9 @@ void *ah_arena_alloc(void *a, size_t bytes) {
 }
 int ah_arena_release(void *a, void *p) { return ((lm::ScratchArena *)a)->release(p) ? 1 : 0; }
 void ah_arena_trim(void *a) { ((lm::ScratchArena *)a)->trim(); }
+#ifdef AH_HAVE_RESERVE /* tools/adopt_arena_reserve.py applied (tests/test_adopt_scripts_cpu.py builds this file against the adopted copy) */
+int ah_arena_reserve(void *a, size_t bytes) { return ((lm::ScratchArena *)a)->reserve(bytes) ? 1 : 0; }
+#endif
 long long ah_arena_slab_bytes(void *a) { return ((lm::ScratchArena *)a)->slab_bytes; }
 long long ah_arena_live_bytes(void *a) { return ((lm::ScratchArena *)a)->live_bytes; }
 long long ah_arena_slab_allocs(void *a) { return ((lm::ScratchArena *)a)->slab_allocs; }
