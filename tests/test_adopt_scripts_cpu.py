@@ -1,5 +1,5 @@
 """tools/adopt_wfa_lean2.py, tools/adopt_pa_chain_pipe.py (the staged kernels of experiments/ wired into the product sources
-behind switches) and tools/adopt_arena_reserve.py apply to a COPY of the current tree: every edit is asserted against the text it replaces, so a change
+behind switches), tools/adopt_arena_reserve.py and tools/adopt_pa_search_debug.py apply to a COPY of the current tree: every edit is asserted against the text it replaces, so a change
 of lexicmap_amd/csrc that the scripts do not follow fails here and not in the first minutes of a GPU session.  (That the
 adopted tree BUILDS is checked by hand - a minute of hipcc - and recorded in experiments/README.md.)"""
 import os
@@ -18,11 +18,11 @@ def test_both_adoptions_apply_to_a_copy_of_the_tree(tmp_path):
     shutil.copy(os.path.join(ROOT, "tests", "test_gpu_longreads.py"), dst / "tests")
     shutil.copy(os.path.join(ROOT, "tests", "arena_host.cpp"), dst / "tests")
     shutil.copytree(os.path.join(ROOT, "include"), dst / "include")
-    for script in ("adopt_wfa_lean2.py", "adopt_pa_chain_pipe.py", "adopt_arena_reserve.py"):
+    for script in ("adopt_wfa_lean2.py", "adopt_pa_chain_pipe.py", "adopt_arena_reserve.py", "adopt_pa_search_debug.py"):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script), "--root", str(dst)], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
     k = (dst / "lexicmap_amd" / "csrc" / "lm_kernels.hip").read_text()
-    assert "k_wfa_lean2<2, int16_t, false>" in k and "lm_chain2_backtrack(" in k and "pa_clear_marks_wave(" in k and "k_pa_chain_pipe" in k
+    assert "k_wfa_lean2<2, int16_t, false>" in k and "lm_chain2_backtrack(" in k and "pa_clear_marks_wave(" in k and "k_pa_chain_pipe" in k and "LM_DEBUG_PA_SEARCH" in k
     mw = (dst / "lexicmap_amd" / "csrc" / "lm_wfa_mw.h").read_text()
     assert "k_wfa_mw2<4, true>" in mw
     tune = (dst / "lexicmap_amd" / "csrc" / "lm_internal.h").read_text()
