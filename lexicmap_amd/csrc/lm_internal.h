@@ -46,15 +46,43 @@ struct ScratchArena {
     struct Slab {
         char *base = nullptr;
         size_t size = 0;
+        bool fixed = false;            // one of the handle's lane slabs (LaneSlabs): lent to this arena, never freed by trim()
         std::map<size_t, size_t> free; // offset -> length
     };
     std::mutex mu;
     std::vector<Slab> slabs;
     std::unordered_map<void *, std::pair<int, size_t>> live; // block -> (slab, length)
-    int64_t slab_bytes = 0, live_bytes = 0, slab_allocs = 0;
+    int64_t slab_bytes = 0, live_bytes = 0, slab_allocs = 0; // slab_*: what this arena took from the device itself (overflow slabs)
     static constexpr size_t ALIGN = 4096;
     ~ScratchArena() { trim(); }
-    // Requests are rounded up to a coarse geometric grid (2^k x {1, 1.25, 1.5, 1.75}): the pools of a search are re-cut at every
+    // a fixed slab of the handle, whole and free (LaneSlabs::assign)
+    void adopt(char *base, size_t size) {
+        std::lock_guard<std::mutex> l(mu);
+        Slab sl;
+        sl.base = base;
+        sl.size = size;
+        sl.fixed = true;
+        sl.free[0] = size;
+        put(std::move(sl));
+    }
+    // the fixed slabs go back to the handle; false (nothing changes) while a block of one of them is live
+    bool drop_fixed() {
+        std::lock_guard<std::mutex> l(mu);
+        for (auto &sl : slabs)
+            if (sl.base && sl.fixed && !(sl.free.size() == 1 && sl.free.begin()->second == sl.size)) return false;
+        for (auto &sl : slabs)
+            if (sl.base && sl.fixed) sl = Slab();
+        return true;
+    }
+    void put(Slab &&sl) {
+        for (auto &x : slabs)
+            if (!x.base) {
+                x = std::move(sl);
+                return;
+            }
+        slabs.push_back(std::move(sl));
+    }
+    // A slab taken from the device is sized on a coarse geometric grid (2^k x {1, 1.25, 1.5, 1.75}): the pools of a search are re-cut at every
     // batch part with sizes that follow the data (a pool per resident wavefront x the longest problem's expected score), and a
     // request a few per cent above every block freed so far would otherwise get a NEW slab from the device - hipMalloc of
     // several GB clears pages for seconds (measured: 1-3 s steps when the ten WFA chains of a round each re-sized their pools)
@@ -65,7 +93,8 @@ struct ScratchArena {
         return (b + q - 1) / q * q;
     }
     void *alloc(size_t bytes) { // throws DeviceOOM
-        bytes = grid((bytes + ALIGN - 1) / ALIGN * ALIGN);
+        bytes = (bytes + ALIGN - 1) / ALIGN * ALIGN; // (blocks are carved exactly; only a slab of its own is sized on the grid)
+        const size_t own = grid(bytes);
         std::lock_guard<std::mutex> l(mu);
         for (int pass = 0; pass < 2; pass++) {
             int bs = -1;
@@ -88,11 +117,17 @@ struct ScratchArena {
             }
             if (pass == 1) break;
             char *base = nullptr;
-            hipError_t e = hipMalloc((void **)&base, bytes);
+            size_t got = own;
+            hipError_t e = hipMalloc((void **)&base, got);
             if (e != hipSuccess) {
                 (void)hipGetLastError();
                 trim_locked();
-                e = hipMalloc((void **)&base, bytes);
+                e = hipMalloc((void **)&base, got);
+                if (e != hipSuccess && got > bytes) { // (the head-room of the grid is a convenience, not a need)
+                    (void)hipGetLastError();
+                    got = bytes;
+                    e = hipMalloc((void **)&base, got);
+                }
             }
             if (e != hipSuccess) {
                 (void)hipGetLastError();
@@ -105,17 +140,10 @@ struct ScratchArena {
             }
             Slab sl;
             sl.base = base;
-            sl.size = bytes;
-            sl.free[0] = bytes;
-            int slot = -1;
-            for (size_t si = 0; si < slabs.size(); si++)
-                if (!slabs[si].base) slot = (int)si;
-            if (slot < 0) {
-                slabs.push_back(std::move(sl));
-            } else {
-                slabs[slot] = std::move(sl);
-            }
-            slab_bytes += (int64_t)bytes;
+            sl.size = got;
+            sl.free[0] = got;
+            put(std::move(sl));
+            slab_bytes += (int64_t)got;
             slab_allocs++;
         }
         throw DeviceOOM("scratch arena: internal error");
@@ -143,9 +171,9 @@ struct ScratchArena {
         sl.free[off] = len;
         return true;
     }
-    void trim_locked() { // hand the slabs without a live block back to the device
+    void trim_locked() { // hand the slabs without a live block back to the device (the handle's fixed slabs stay)
         for (auto &sl : slabs)
-            if (sl.base && sl.free.size() == 1 && sl.free.begin()->second == sl.size) {
+            if (sl.base && !sl.fixed && sl.free.size() == 1 && sl.free.begin()->second == sl.size) {
                 (void)hipFree(sl.base);
                 slab_bytes -= (int64_t)sl.size;
                 sl = Slab();
@@ -155,6 +183,71 @@ struct ScratchArena {
         std::lock_guard<std::mutex> l(mu);
         trim_locked();
     }
+};
+// The handle's two lane slabs: cut ONCE from the scratch budget at the first search and lent to the lane arenas according
+// to the number of lanes a search's budget is divided by.  Why: both lanes used to carve their phase buffers out of one arena
+// that grew by hipMalloc on demand - a fresh handle needed three C3 steps to settle (17.5, 14.5, then 12.2 s: hipMalloc /
+// hipFree synchronise the device, so one lane's allocation waits for the other lane's persistent WFA kernels), parts were
+// halved under the transient pressure and stayed halved, and the serialised measurement step re-cut everything.  With two
+// lanes every lane's arena works inside its own slab; with one lane the arena of lane 0 works inside both.  A request no
+// slab can take gets an overflow slab from the device (counted: ScratchArena::slab_allocs) that trim() hands back.
+struct LaneSlabs {
+    char *base[2] = {nullptr, nullptr};
+    size_t size[2] = {0, 0};
+    int assigned_lanes = 0; // 0: with nobody
+    bool asked = false;     // the device was asked once (again after drop())
+    // two slabs of bytes / 2 each; false (and holds nothing) when the device refuses: the arenas then work from slabs of
+    // their own, i.e. as before
+    bool reserve(size_t bytes) {
+        drop();
+        asked = true;
+        const size_t half = bytes / 2 / ScratchArena::ALIGN * ScratchArena::ALIGN;
+        if (half == 0) return false;
+        for (int i = 0; i < 2; i++) {
+            if (hipMalloc((void **)&base[i], half) != hipSuccess) {
+                (void)hipGetLastError();
+                base[i] = nullptr;
+                drop();
+                asked = true;
+                return false;
+            }
+            size[i] = half;
+        }
+        return true;
+    }
+    // between searches (no live block): lanes == 2 -> one slab each; lanes == 1 -> both to a0.  false: a block is live
+    // somewhere (the assignment stays as it is)
+    bool assign(ScratchArena &a0, ScratchArena &a1, int lanes) {
+        if (!base[0] || lanes == assigned_lanes) return true;
+        if (assigned_lanes && !unassign(a0, a1)) return false;
+        a0.adopt(base[0], size[0]);
+        (lanes == 2 ? a1 : a0).adopt(base[1], size[1]);
+        assigned_lanes = lanes;
+        return true;
+    }
+    bool unassign(ScratchArena &a0, ScratchArena &a1) {
+        if (assigned_lanes) {
+            if (!a0.drop_fixed()) return false;
+            if (!a1.drop_fixed()) { // (a0's are back with the handle already: lend them again, nothing changed hands)
+                a0.adopt(base[0], size[0]);
+                if (assigned_lanes == 1) a0.adopt(base[1], size[1]);
+                return false;
+            }
+        }
+        assigned_lanes = 0;
+        return true;
+    }
+    void drop() { // (after unassign)
+        for (int i = 0; i < 2; i++) {
+            if (base[i]) (void)hipFree(base[i]);
+            base[i] = nullptr;
+            size[i] = 0;
+        }
+        assigned_lanes = 0;
+        asked = false;
+    }
+    int64_t bytes() const { return (int64_t)(size[0] + size[1]); }
+    ~LaneSlabs() { drop(); }
 };
 // the arena (and the stream) of the search running on this thread; null outside lm_search_*: plain device allocations
 inline thread_local ScratchArena *tls_arena = nullptr;
@@ -305,11 +398,16 @@ struct lm_tune {
     FILE *wfa_dump = nullptr; // LM_DEBUG_WFA_DUMP=<file>: one line per WFA problem and pass (width, status, lengths, estimate, score)
     FILE *wfa_waves = nullptr; // LM_DEBUG_WFA_WAVES=<file>: one JSON line per k_wfa_lean launch: when its wavefronts started / ended, busy share
     int wfa_ak_margin = -1;  // LM_WFA_AK_MARGIN: a problem starts at the ring that holds |tlen - qlen| + margin diagonals (-1: at the class's width)
+    int arena_reserve_pct = 80; // LM_ARENA_RESERVE_PCT: share of the scratch budget cut into the two lane slabs at the first search (LaneSlabs; 0: slabs on demand as in round 4)
     int two_lanes = 1;       // two parts of a batch searched side by side, each with half of the scratch budget (LM_TWO_LANES=0: one after the other)
     int lookup_flat = 1;     // anchors emitted with the lanes over the output (k_lookup_emit_flat); LM_LOOKUP_FLAT=0: one lane per lookup
     int wfa_defer = 0;       // LM_WFA_DEFER=1: a round's latency-bound alignments finish beside the next round's first passes (default: every round waits for them)
     int wfa_r16 = 1;         // 16-bit ring cells in the whole-sequence WFA kernels of 128 / 256 diagonals (LM_WFA_R16=0: 32-bit)
+    int wfa_lean2 = 1;       // the single-wavefront WFA passes by k_wfa_lean2 (restructured forward pass); LM_WFA_LEAN2=0: k_wfa_lean
     int wfa_mw = 1;          // 512 / 1024-diagonal passes by a workgroup of four wavefronts per alignment (LM_WFA_MW=0: one wavefront)
+    int pa_chain_pipe = 1;   // the Chainer2 DP of windows with more than pa_pipe_min anchors by a workgroup of pipelined wavefronts (LM_PA_CHAIN_PIPE=0: off)
+    int pa_pipe_min = 512;   // LM_PA_PIPE_MIN
+    int pa_chain_bt_wave = 3; // LM_PA_CHAIN_BT_WAVE: bit 0 = the backtrack of Chainer2 by the wavefront (LDS tiles, 64-lane region scans; 0: lane 0), bit 1 = the marks of ClearSubstrPairs from LDS tiles (0: binary search + scan in global memory)
     int pa_chain_ring = 1;   // Chainer2 DP with the recent anchors in an LDS ring (LM_PA_CHAIN_RING=0: through global memory)
     int wfa_serial = 0;      // LM_WFA_SERIAL=1: the WFA length classes one after the other (exclusive kernel timings)
     int no_pipeline = 0;     // LM_NO_PIPELINE=1: no pseudo-alignment producer beside extend / WFA (exclusive kernel timings)
@@ -329,11 +427,16 @@ struct lm_tune {
         no_pipeline = getenv("LM_NO_PIPELINE") != nullptr;
         if (const char *e = getenv("LM_WFA_MW")) wfa_mw = atoi(e) != 0;
         if (const char *e = getenv("LM_WFA_R16")) wfa_r16 = atoi(e) != 0;
+        if (const char *e = getenv("LM_WFA_LEAN2")) wfa_lean2 = atoi(e) != 0;
         if (const char *e = getenv("LM_WFA_DEFER")) wfa_defer = atoi(e) != 0;
         if (const char *e = getenv("LM_LOOKUP_FLAT")) lookup_flat = atoi(e) != 0;
         if (const char *e = getenv("LM_TWO_LANES")) two_lanes = atoi(e) != 0;
+        if (const char *e = getenv("LM_ARENA_RESERVE_PCT")) arena_reserve_pct = std::max(0, std::min(90, atoi(e)));
         if (const char *e = getenv("LM_WFA_AK_MARGIN")) wfa_ak_margin = atoi(e);
         if (const char *e = getenv("LM_PA_CHAIN_RING")) pa_chain_ring = atoi(e) != 0;
+        if (const char *e = getenv("LM_PA_CHAIN_PIPE")) pa_chain_pipe = atoi(e) != 0;
+        if (const char *e = getenv("LM_PA_PIPE_MIN")) pa_pipe_min = std::max(64, atoi(e));
+        if (const char *e = getenv("LM_PA_CHAIN_BT_WAVE")) pa_chain_bt_wave = atoi(e) & 3;
         if (getenv("LM_CHAIN1_LANES")) chain1_wave = 0;
         if (const char *e = getenv("LM_PA_SEG_BY_WAVE")) pa_seg_by_group = atoi(e) ? 0 : 1;
     }
@@ -349,6 +452,7 @@ struct lm_index {
     lm::AlignCtx *actx1[3] = {nullptr, nullptr, nullptr};
     hipStream_t st_b = nullptr, st2_b = nullptr;
     int active_lanes = 1;
+    int budget_lanes = 1; // what BUDGET() divides the scratch budget by (= active_lanes, but 2 in the serialised measurement step of a two-lane search)
     std::mutex mu;                  // one in-flight call per handle
     HostIndex host;
     lm_options opt;
@@ -368,7 +472,8 @@ struct lm_index {
     DevIndexView view;
     int64_t hbm_bytes = 0;
     // scratch
-    ScratchArena arena;      // phase buffers of the searches on this handle (destroyed after work / actx)
+    LaneSlabs lane_slabs;    // the two fixed slabs the lane arenas work in (LM_ARENA_RESERVE_PCT of the scratch budget)
+    ScratchArena arena[2];   // phase buffers of the searches on this handle, one arena per lane (destroyed after work / actx)
     DBuf<uint8_t> tmp, tmp2, tmp_b, tmp2_b; // rocPRIM temporary storage (per stream)
     // profiling
     bool prof = false;

@@ -130,7 +130,7 @@ void launch_pa_task_off_sorted(hipStream_t st, const uint64_t *sortedA, int shif
                                int64_t *pa_off);
 void launch_pa_chain(hipStream_t st, const uint64_t *B, const int64_t *pa_off, int64_t ntasks, int K, LmChain2Opt opt,
                      LmSub *subs, uint8_t *marks, uint64_t *msi, int32_t *stack, LmChain2 *out, int32_t *out_n,
-                     int32_t *clr_n, int qbits, int tbits, bool ring);
+                     int32_t *clr_n, int qbits, int tbits, bool ring, int pipe_min = 0, int64_t total = 0, int bt_wave = 0);
 void launch_gather_chain2(hipStream_t st, const LmChain2 *in, const int64_t *pa_off, const int32_t *out_n,
                           const int64_t *res_off, int64_t ntasks, LmChain2 *out);
 void launch_extend_count(hipStream_t st, const HspIn *hsps, int64_t n, const uint8_t *qseq, const int64_t *qoff,
@@ -141,19 +141,19 @@ void launch_extend(hipStream_t st, const HspIn *hsps, int64_t n, const uint8_t *
                    const uint8_t *wbuf, const int32_t *cap, const int64_t *woff, uint16_t *subs, int32_t *msi,
                    void *rows_pool, uint32_t *rstart_pool, HspExt *out);
 // k_wfa_lean<nc>: persistent wavefronts with private scratch, <= 64 nc - 2 diagonals (status 3 beyond); nc = 2, 4, 8 or 16
-int wfa_resident_blocks(int device, int seq_words, int nc, bool win, bool r16 = false);
+int wfa_resident_blocks(int device, int seq_words, int nc, bool win, bool r16 = false, bool lean2 = false);
 // 16-bit ring cells (half the LDS per wavefront): whole-sequence kernels of 128 / 256 diagonals, sequences <= 12 000 bases
 bool wfa_r16_ok(int seq_words, int nc, bool win);
 void launch_wfa(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks,
                 int32_t *hdr_pool, int64_t hdr_stride, uint8_t *arena_pool, int64_t arena_stride, uint64_t *ops_pool,
                 unsigned int *queue, int seq_words, int want_ops, WfaOut *out, int nc, bool win, bool r16 = false,
-                unsigned long long *dbg = nullptr); // dbg: 6 words per workgroup (LM_DEBUG_WFA_WAVES)
+                unsigned long long *dbg = nullptr, bool lean2 = false); // dbg: 6 words per workgroup (LM_DEBUG_WFA_WAVES); lean2: k_wfa_lean2
 
 // k_wfa_mw<nc / 4, win>: the same passes for nc = 8 / 16 by a workgroup of four wavefronts per alignment
-int wfa_mw_resident_blocks(int device, int seq_words, int nc, bool win);
+int wfa_mw_resident_blocks(int device, int seq_words, int nc, bool win, bool lean2 = false);
 void launch_wfa_mw(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks, int32_t *hdr_pool,
                    int64_t hdr_stride, uint8_t *arena_pool, int64_t arena_stride, uint64_t *ops_pool, unsigned int *queue, int seq_words,
-                   int want_ops, WfaOut *out, int nc, bool win);
+                   int want_ops, WfaOut *out, int nc, bool win, bool lean2 = false);
 
 // wavefronts wider than the LDS ring (status 3 from launch_wfa): same algorithm with the ring in global memory
 void launch_wfa_wide(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int32_t *hdr_pool,

@@ -1306,7 +1306,7 @@ __global__ __launch_bounds__(256) void k_pa_search(DevIndexView ix, const Task *
                                                     int blocks_per_seg, const uint64_t *__restrict__ cand_all,
                                                     unsigned long long *__restrict__ count, int64_t cap,
                                                     uint64_t *__restrict__ outA, uint64_t *__restrict__ outB, int qbits,
-                                                    int tbits, int nseg, int xcd_map) {
+                                                    int tbits, int nseg, int xcd_map, unsigned long long *__restrict__ dbg) {
     // qbits > 0: compact single-key anchors, task | QBegin:qbits | (32-Len):6 | TBegin:tbits | 2 flags in one u64 (outA is
     // not written): same order as (task, B) and one keys-only radix sort over the bits in use instead of two pair sorts.
     // qbits == 0 (batches whose fields need more than 64 bits): (task, B) pairs, the task staged beside B.
@@ -1352,6 +1352,8 @@ __global__ __launch_bounds__(256) void k_pa_search(DevIndexView ix, const Task *
     const int64_t stride = (int64_t)blocks_per_seg * blockDim.x;
     for (int64_t base = (int64_t)sub * blockDim.x; base < nc; base += stride) { // whole wavefronts stay together
         const int64_t ci = base + threadIdx.x;
+        unsigned long long d_0 = 0, d_1 = 0, d_it = 0, d_an = 0;
+        if (dbg) d_0 = wall_clock64();
         int j = 0, hi = 0, i = 0;
         bool rcs = false;
         uint64_t key = 0, right = 0;
@@ -1381,7 +1383,9 @@ __global__ __launch_bounds__(256) void k_pa_search(DevIndexView ix, const Task *
                 j = hi = 0;
         }
         // the matches of all lanes, one per lane and round, appended to the wavefront's LDS strip
+        if (dbg) d_1 = wall_clock64();
         while (true) {
+            d_it++;
             bool live = j < hi;
             uint64_t kj = 0;
             if (live) {
@@ -1424,7 +1428,19 @@ __global__ __launch_bounds__(256) void k_pa_search(DevIndexView ix, const Task *
                     stt[slot] = (uint32_t)ti;
                 }
                 n_stg += __popcll(m);
+                d_an += (unsigned long long)__popcll(m);
                 if (n_stg > PAS_STAGE - 64) flush(); // LDS accesses of one wavefront complete in program order
+            }
+        }
+        if (dbg) { // LM_DEBUG_PA_SEARCH: {candidates, wavefront passes, enumeration passes, anchors, clocks of the search, of the enumeration}
+            const unsigned long long nc_w = (unsigned long long)__popcll(__ballot(ci < nc)), d_2 = wall_clock64();
+            if (lane == 0) {
+                atomicAdd(dbg + 0, nc_w);
+                atomicAdd(dbg + 1, 1ull);
+                atomicAdd(dbg + 2, d_it);
+                atomicAdd(dbg + 3, d_an);
+                atomicAdd(dbg + 4, d_1 - d_0);
+                atomicAdd(dbg + 5, d_2 - d_1);
             }
         }
     }
@@ -1455,6 +1471,7 @@ __global__ void k_pa_task_off_sorted(const uint64_t *__restrict__ sortedA, int s
 // candidate predecessors j for the banded DP; emission order and every tie rule are those of lm_clear_sorted / lm_trim
 // / lm_run_chain2 (lm_algos.h), which stay the CPU-checked statement of the logic.
 #include "lm_pa_chain_dp.h"
+#include "lm_pa_chain_bt.h"
 
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
     for (int o = 32; o > 0; o >>= 1) {
@@ -1462,6 +1479,130 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
         v = x > v ? x : v;
     }
     return v;
+}
+
+// Backtrack with the explicit region stack: lm_run_chain2's second half, by one thread (k_pa_chain_wave's lane 0,
+// k_pa_chain_pipe's thread 0).  msi[]: (score << 32 | predecessor) per anchor, M / Mi the best score and its anchor.
+__device__ int lm_chain2_backtrack(const LmSub *a_, int n, const LmChain2Opt &opt, const uint64_t *msi, long long M, int Mi, int32_t *stack,
+                                   LmChain2 *res) {
+    int nout = 0;
+    if (M >= (long long)opt.min_score) {
+        int sp = 0;
+        stack[sp++] = 0;
+        stack[sp++] = n;
+        int pending_Mi0 = Mi;
+        while (sp > 0) {
+            int hi = stack[--sp];
+            int lo = stack[--sp];
+            int mi;
+            if (pending_Mi0 >= 0) {
+                mi = pending_Mi0;
+                pending_Mi0 = -1;
+            } else {
+                long long bestm = 0;
+                mi = lo;
+                for (int i = lo; i < hi; i++) {
+                    long long m = (long long)(msi[i] >> 32);
+                    if (m > bestm) {
+                        bestm = m;
+                        mi = i;
+                    }
+                }
+                if (bestm < (long long)opt.min_score) continue;
+            }
+            int n_matched = 0, n_abq = 0, n_abt = 0;
+            int i = mi, j = 0;
+            int32_t qb = 0, qe = 0, tb = 0, te = 0;
+            int begin_of_next = 0;
+            bool first_anchor = true, jneg = false;
+            int n_anchors = 0;
+            while (true) {
+                j = (int)(msi[i] & 4294967295ull);
+                if (j < lo) {
+                    jneg = true;
+                    break;
+                }
+                const LmSub sub = a_[i];
+                n_anchors++;
+                if (first_anchor) {
+                    first_anchor = false;
+                    qe = sub.qbegin + (int32_t)sub.len - 1;
+                    te = sub.tbegin + (int32_t)sub.len - 1;
+                    qb = sub.qbegin;
+                    tb = sub.tbegin;
+                    n_matched += sub.len;
+                } else {
+                    qb = sub.qbegin;
+                    tb = sub.tbegin;
+                    if ((int)sub.qbegin + (int)sub.len - 1 >= begin_of_next)
+                        n_matched += begin_of_next - (int)sub.qbegin;
+                    else
+                        n_matched += sub.len;
+                }
+                begin_of_next = sub.qbegin;
+                if (i == j) {
+                    n_abq += (int)qe - (int)qb + 1;
+                    if (n_abq < opt.min_align_len) break;
+                    n_abt += (int)te - (int)tb + 1;
+                    double pident = (double)n_matched / (double)(n_abq > n_abt ? n_abq : n_abt) * 100;
+                    if (pident < opt.heuristic_pident) break;
+                    if (pident > 100) pident = 100;
+                    LmChain2 p;
+                    p.nanchors = n_anchors;
+                    p.aligned_bases_q = n_abq;
+                    p.aligned_bases_t = n_abt;
+                    p.matched_bases = n_matched;
+                    p.pident = pident;
+                    p.qbegin = qb;
+                    p.qend = qe;
+                    p.tbegin = tb;
+                    p.tend = te;
+                    res[nout++] = p;
+                    break;
+                }
+                i = j;
+            }
+            if (jneg && n_anchors > 0) {
+                n_abq += (int)qe - (int)qb + 1;
+                n_abt += (int)te - (int)tb + 1;
+                if (n_abq >= opt.min_align_len) {
+                    double pident = (double)n_matched / (double)(n_abq > n_abt ? n_abq : n_abt) * 100;
+                    if (pident >= opt.heuristic_pident) {
+                        if (pident > 100) pident = 100;
+                        LmChain2 p;
+                        p.nanchors = n_anchors;
+                        p.aligned_bases_q = n_abq;
+                        p.aligned_bases_t = n_abt;
+                        p.matched_bases = n_matched;
+                        p.pident = pident;
+                        p.qbegin = qb;
+                        p.qend = qe;
+                        p.tbegin = tb;
+                        p.tend = te;
+                        res[nout++] = p;
+                    }
+                }
+            }
+            if (i > lo) {
+                stack[sp++] = lo;
+                stack[sp++] = i;
+            }
+            if (mi != hi - 1) {
+                stack[sp++] = mi + 1;
+                stack[sp++] = hi;
+            }
+        }
+        for (int i = 1; i < nout; i++) { // stable sort by QBegin (lib-seq_compare.go:501-508)
+            LmChain2 x = res[i];
+            int j = i - 1;
+            while (j >= 0 && res[j].qbegin > x.qbegin) {
+                res[j + 1] = res[j];
+                j--;
+            }
+            res[j + 1] = x;
+        }
+    }
+    return nout;
 }
 
 // RING: the DP keeps the recent anchors and scores in an LDS ring (lm_pa_chain_dp_core.h); otherwise every step goes
@@ -1472,9 +1613,12 @@ __global__ __launch_bounds__(64) void k_pa_chain_wave(const uint64_t *__restrict
                                                        uint8_t *__restrict__ marks_pool, uint64_t *__restrict__ msi_pool,
                                                        int32_t *__restrict__ stack_pool, LmChain2 *__restrict__ out_pool,
                                                        int32_t *__restrict__ out_n, int32_t *__restrict__ clr_n, int qbits,
-                                                       int tbits) {
+                                                       int tbits, int pipe_min, int32_t *__restrict__ long_tasks,
+                                                       unsigned int *__restrict__ nlong, int bt_wave,
+                                                       unsigned long long *__restrict__ dbg) {
     const int lane = threadIdx.x;
     __shared__ PcdLds pcd_lds;
+    __shared__ PcbLds pcb_lds;
     for (int64_t ti = blockIdx.x; ti < ntasks; ti += gridDim.x) {
         const int64_t o = pa_off[ti];
         int n = (int)(pa_off[ti + 1] - o);
@@ -1490,6 +1634,8 @@ __global__ __launch_bounds__(64) void k_pa_chain_wave(const uint64_t *__restrict
         uint8_t *marks = marks_pool + o;
         uint64_t *msi = msi_pool + o;
         LmChain2 *res = out_pool + o;
+        unsigned long long d_0 = 0, d_1 = 0, d_2 = 0;
+        if (dbg) d_0 = wall_clock64();
         for (int i = lane; i < n; i += 64) {
             const uint64_t v = B[o + i];
             if (qbits > 0) { // compact single-key form (see k_pa_search)
@@ -1508,7 +1654,8 @@ __global__ __launch_bounds__(64) void k_pa_chain_wave(const uint64_t *__restrict
         __syncthreads();
         // ---- ClearSubstrPairs (lib-index-search.go:927-972): anchor i+1 is dropped when nested in an earlier one ----
         if (n > 1) {
-            for (int i = lane; i < n; i += 64) {
+            if (bt_wave & 2) pa_clear_marks_wave(sb, n, K, marks, (PccLds *)&pcd_lds);
+            for (int i = lane; i < n && !(bt_wave & 2); i += 64) {
                 uint8_t mk = 0;
                 if (i >= 1) {
                     const LmSub v = sb[i];
@@ -1561,11 +1708,19 @@ __global__ __launch_bounds__(64) void k_pa_chain_wave(const uint64_t *__restrict
             continue;
         }
         const LmSub *a_ = sb + start;
+        if (pipe_min > 0 && n > pipe_min) { // a long window: its DP and backtrack by a workgroup (k_pa_chain_pipe)
+            if (lane == 0) {
+                out_n[ti] = start;
+                long_tasks[atomicAdd(nlong, 1u)] = (int32_t)ti;
+            }
+            continue;
+        }
         if (n == 1) {
             if (lane == 0) out_n[ti] = lm_run_chain2(a_, 1, opt, msi, stack_pool + 2 * o + 4 * ti, res);
             continue;
         }
         // ---- banded DP (lib-chaining2.go:222-307), candidates j scanned 64 at a time from i-1 downwards ----
+        if (dbg) d_1 = wall_clock64();
         long long M = 0;
         int Mi = 0;
         if (RING) {
@@ -1631,130 +1786,25 @@ __global__ __launch_bounds__(64) void k_pa_chain_wave(const uint64_t *__restrict
             }
         }
         __syncthreads();
-        // ---- backtrack with the explicit region stack (lane 0), identical to lm_run_chain2's second half ----
-        if (lane == 0) {
-            int nout = 0;
-            if (M >= (long long)opt.min_score) {
-                int32_t *stack = stack_pool + 2 * o + 4 * ti;
-                int sp = 0;
-                stack[sp++] = 0;
-                stack[sp++] = n;
-                int pending_Mi0 = Mi;
-                while (sp > 0) {
-                    int hi = stack[--sp];
-                    int lo = stack[--sp];
-                    int mi;
-                    if (pending_Mi0 >= 0) {
-                        mi = pending_Mi0;
-                        pending_Mi0 = -1;
-                    } else {
-                        long long bestm = 0;
-                        mi = lo;
-                        for (int i = lo; i < hi; i++) {
-                            long long m = (long long)(msi[i] >> 32);
-                            if (m > bestm) {
-                                bestm = m;
-                                mi = i;
-                            }
-                        }
-                        if (bestm < (long long)opt.min_score) continue;
-                    }
-                    int n_matched = 0, n_abq = 0, n_abt = 0;
-                    int i = mi, j = 0;
-                    int32_t qb = 0, qe = 0, tb = 0, te = 0;
-                    int begin_of_next = 0;
-                    bool first_anchor = true, jneg = false;
-                    int n_anchors = 0;
-                    while (true) {
-                        j = (int)(msi[i] & 4294967295ull);
-                        if (j < lo) {
-                            jneg = true;
-                            break;
-                        }
-                        const LmSub sub = a_[i];
-                        n_anchors++;
-                        if (first_anchor) {
-                            first_anchor = false;
-                            qe = sub.qbegin + (int32_t)sub.len - 1;
-                            te = sub.tbegin + (int32_t)sub.len - 1;
-                            qb = sub.qbegin;
-                            tb = sub.tbegin;
-                            n_matched += sub.len;
-                        } else {
-                            qb = sub.qbegin;
-                            tb = sub.tbegin;
-                            if ((int)sub.qbegin + (int)sub.len - 1 >= begin_of_next)
-                                n_matched += begin_of_next - (int)sub.qbegin;
-                            else
-                                n_matched += sub.len;
-                        }
-                        begin_of_next = sub.qbegin;
-                        if (i == j) {
-                            n_abq += (int)qe - (int)qb + 1;
-                            if (n_abq < opt.min_align_len) break;
-                            n_abt += (int)te - (int)tb + 1;
-                            double pident = (double)n_matched / (double)(n_abq > n_abt ? n_abq : n_abt) * 100;
-                            if (pident < opt.heuristic_pident) break;
-                            if (pident > 100) pident = 100;
-                            LmChain2 p;
-                            p.nanchors = n_anchors;
-                            p.aligned_bases_q = n_abq;
-                            p.aligned_bases_t = n_abt;
-                            p.matched_bases = n_matched;
-                            p.pident = pident;
-                            p.qbegin = qb;
-                            p.qend = qe;
-                            p.tbegin = tb;
-                            p.tend = te;
-                            res[nout++] = p;
-                            break;
-                        }
-                        i = j;
-                    }
-                    if (jneg && n_anchors > 0) {
-                        n_abq += (int)qe - (int)qb + 1;
-                        n_abt += (int)te - (int)tb + 1;
-                        if (n_abq >= opt.min_align_len) {
-                            double pident = (double)n_matched / (double)(n_abq > n_abt ? n_abq : n_abt) * 100;
-                            if (pident >= opt.heuristic_pident) {
-                                if (pident > 100) pident = 100;
-                                LmChain2 p;
-                                p.nanchors = n_anchors;
-                                p.aligned_bases_q = n_abq;
-                                p.aligned_bases_t = n_abt;
-                                p.matched_bases = n_matched;
-                                p.pident = pident;
-                                p.qbegin = qb;
-                                p.qend = qe;
-                                p.tbegin = tb;
-                                p.tend = te;
-                                res[nout++] = p;
-                            }
-                        }
-                    }
-                    if (i > lo) {
-                        stack[sp++] = lo;
-                        stack[sp++] = i;
-                    }
-                    if (mi != hi - 1) {
-                        stack[sp++] = mi + 1;
-                        stack[sp++] = hi;
-                    }
-                }
-                for (int i = 1; i < nout; i++) { // stable sort by QBegin (lib-seq_compare.go:501-508)
-                    LmChain2 x = res[i];
-                    int j = i - 1;
-                    while (j >= 0 && res[j].qbegin > x.qbegin) {
-                        res[j + 1] = res[j];
-                        j--;
-                    }
-                    res[j + 1] = x;
-                }
-            }
-            out_n[ti] = nout;
+        // ---- backtrack (lm_chain2_backtrack), or the hand-over of a long window to k_pa_chain_pipe ----
+        if (dbg) d_2 = wall_clock64();
+        if (bt_wave & 1) { // by the wavefront: region scans by 64 lanes, the walk out of LDS tiles (lm_pa_chain_bt.h)
+            const int no = pa_chain_backtrack_wave(a_, n, opt, msi, M, Mi, stack_pool + 2 * o + 4 * ti, res, &pcb_lds);
+            if (lane == 0) out_n[ti] = no;
+        } else if (lane == 0) {
+            out_n[ti] = lm_chain2_backtrack(a_, n, opt, msi, M, Mi, stack_pool + 2 * o + 4 * ti, res);
+        }
+        if (dbg && lane == 0) {
+            const unsigned long long d_3 = wall_clock64();
+            atomicAdd(dbg + 0, d_1 - d_0);
+            atomicAdd(dbg + 1, d_2 - d_1);
+            atomicAdd(dbg + 2, d_3 - d_2);
+            atomicAdd(dbg + 3, 1ull);
         }
     }
 }
+
+#include "lm_pa_chain_pipe.h"
 
 __global__ void k_gather_chain2(const LmChain2 *__restrict__ in, const int64_t *__restrict__ pa_off,
                                 const int32_t *__restrict__ out_n, const int64_t *__restrict__ res_off, int64_t ntasks,
@@ -3202,9 +3252,20 @@ void launch_pa_search(hipStream_t st, DevIndexView ix, const Task *tasks, const 
     const int64_t need = (seg_cap + 255) / 256;
     if (bps > need) bps = (int)(need < 1 ? 1 : need);
     const int nseg8 = xcd_map ? (nseg / LM_PA_RANGE_SEGS + 7) / 8 * 8 * LM_PA_RANGE_SEGS : nseg;
+    static const bool ps_dbg = getenv("LM_DEBUG_PA_SEARCH") != nullptr;
+    static unsigned long long *d_dbg = nullptr;
+    if (ps_dbg && !d_dbg && hipMalloc((void **)&d_dbg, 8 * sizeof(unsigned long long)) != hipSuccess) d_dbg = nullptr;
+    if (ps_dbg && d_dbg) (void)hipMemsetAsync(d_dbg, 0, 8 * sizeof(unsigned long long), st);
     hipLaunchKernelGGL(k_pa_search, dim3(nseg8 * bps), dim3(256), 0, st, ix, tasks, wbuf, keys_cmp, vals_cmp, posoff, nvalid, cmp_tab,
                        tab_off, tab_bits, K, min_prefix, seg_count, seg_cap, bps, cand, count, cap, outA, outB, qbits, tbits, nseg,
-                       xcd_map);
+                       xcd_map, ps_dbg ? d_dbg : nullptr);
+    if (ps_dbg && d_dbg) {
+        unsigned long long h[8] = {0};
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h, d_dbg, sizeof h, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[lm] k_pa_search: %llu candidates in %llu wavefront passes (%.1f per pass), %llu enumeration passes, %llu anchors (%.2f per enumeration pass), wavefront-ms: search %.1f, enumeration %.1f\n",
+                h[0], h[1], h[1] ? (double)h[0] / (double)h[1] : 0.0, h[2], h[3], h[2] ? (double)h[3] / (double)h[2] : 0.0, (double)h[4] / 1e5, (double)h[5] / 1e5);
+    }
 }
 void launch_pa_task_off_sorted(hipStream_t st, const uint64_t *sortedA, int shift, int64_t total, int64_t ntasks,
                                int64_t *pa_off) {
@@ -3212,10 +3273,29 @@ void launch_pa_task_off_sorted(hipStream_t st, const uint64_t *sortedA, int shif
 }
 void launch_pa_chain(hipStream_t st, const uint64_t *B, const int64_t *pa_off, int64_t ntasks, int K, LmChain2Opt opt,
                      LmSub *subs, uint8_t *marks, uint64_t *msi, int32_t *stack, LmChain2 *out, int32_t *out_n,
-                     int32_t *clr_n, int qbits, int tbits, bool ring) {
+                     int32_t *clr_n, int qbits, int tbits, bool ring, int pipe_min, int64_t total, int bt_wave) {
     int g = (int)(ntasks < 1 ? 1 : (ntasks > 262144 ? 262144 : ntasks));
+    // pipe_min > 0: the list of long windows and its counter live behind the stacks (stack holds 2 * total + 5 * ntasks + 48 ints)
+    int32_t *long_tasks = stack + 2 * total + 4 * ntasks + 8;
+    unsigned int *nlong = (unsigned int *)(long_tasks + ntasks);
+    static const bool pa_dbg = getenv("LM_DEBUG_PA_CHAIN") != nullptr; // phase times of k_pa_chain_wave (stack holds 16 more ints)
+    unsigned long long *dbg = pa_dbg ? (unsigned long long *)(((uintptr_t)(nlong + 2) + 7) & ~(uintptr_t)7) : nullptr;
+    if (dbg) (void)hipMemsetAsync(dbg, 0, 4 * sizeof(unsigned long long), st);
+    if (pipe_min > 0) (void)hipMemsetAsync(nlong, 0, sizeof(unsigned int), st);
     hipLaunchKernelGGL(ring ? k_pa_chain_wave<true> : k_pa_chain_wave<false>, dim3(g), dim3(64), 0, st, B, pa_off, ntasks, K, opt, subs, marks, msi, stack, out, out_n,
-                       clr_n, qbits, tbits);
+                       clr_n, qbits, tbits, pipe_min, long_tasks, nlong, bt_wave, dbg);
+    if (pipe_min > 0) // (the number of long windows is known on the device only: a grid that fills the chip, workgroups loop)
+        hipLaunchKernelGGL(k_pa_chain_pipe, dim3((unsigned)(ntasks < 1024 ? (ntasks < 1 ? 1 : ntasks) : 1024)), dim3(PCP_NW * 64), 0, st, pa_off, long_tasks,
+                           nlong, opt, subs, msi, stack, out, out_n, clr_n, bt_wave & 1);
+    if (dbg) {
+        unsigned long long h[4] = {0, 0, 0, 0};
+        unsigned int nl = 0;
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&nl, nlong, sizeof nl, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[lm] k_pa_chain: %lld windows (%llu finished by the wavefront kernel, %u handed to the workgroup kernel), wavefront-ms: clear+trim %.1f, DP %.1f, backtrack %.1f\n",
+                (long long)ntasks, h[3], pipe_min > 0 ? nl : 0u, (double)h[0] / 1e5, (double)h[1] / 1e5, (double)h[2] / 1e5);
+    }
 }
 void launch_gather_chain2(hipStream_t st, const LmChain2 *in, const int64_t *pa_off, const int32_t *out_n,
                           const int64_t *res_off, int64_t ntasks, LmChain2 *out) {
@@ -3245,7 +3325,19 @@ void launch_extend(hipStream_t st, const HspIn *hsps, int64_t n, const uint8_t *
 typedef void (*WfaLeanFn)(const WfaIn *, int64_t, const int32_t *, int64_t, int32_t *, int64_t, uint8_t *, int64_t, uint64_t *,
                           unsigned int *, int, int, WfaOut *, unsigned long long *);
 // r16: 16-bit ring cells (whole-sequence kernels of 128 / 256 diagonals, sequences up to 12 000 bases: lm_kernels.h)
-static WfaLeanFn wfa_lean_fn(int nc, bool win, bool r16) {
+static WfaLeanFn wfa_lean2_fn(int nc, bool win, bool r16) { // the restructured forward pass (lm_wfa_lean2.h)
+    if (r16 && !win && nc == 2) return k_wfa_lean2<2, int16_t, false>;
+    if (r16 && !win && nc == 4) return k_wfa_lean2<4, int16_t, false>;
+    switch (nc) {
+    case 16: return win ? k_wfa_lean2<16, int32_t, true> : k_wfa_lean2<16, int32_t, false>;
+    case 8: return win ? k_wfa_lean2<8, int32_t, true> : k_wfa_lean2<8, int32_t, false>;
+    case 4: return win ? k_wfa_lean2<4, int32_t, true> : k_wfa_lean2<4, int32_t, false>;
+    case 1: return win ? k_wfa_lean2<1, int32_t, true> : k_wfa_lean2<1, int32_t, false>;
+    default: return win ? k_wfa_lean2<2, int32_t, true> : k_wfa_lean2<2, int32_t, false>;
+    }
+}
+static WfaLeanFn wfa_lean_fn(int nc, bool win, bool r16, bool lean2 = false) {
+    if (lean2) return wfa_lean2_fn(nc, win, r16);
     if (r16 && !win && nc == 2) return k_wfa_lean<2, false, int16_t>;
     if (r16 && !win && nc == 4) return k_wfa_lean<4, false, int16_t>;
     switch (nc) {
@@ -3258,19 +3350,19 @@ static WfaLeanFn wfa_lean_fn(int nc, bool win, bool r16) {
 }
 bool wfa_r16_ok(int seq_words, int nc, bool win) { return !win && (nc == 2 || nc == 4) && seq_words <= 750; }
 static size_t wfa_dyn_lds(int seq_words, bool win) { // two packed sequences with one padding word each (+2: the predicated
-    return win ? 0 : (size_t)(2 * (seq_words + 1) + 2) * sizeof(uint32_t); // extension may read one word past)
+    return win ? 0 : (size_t)(2 * (seq_words + 2) + 1) * sizeof(uint32_t); // extension may read one word past; k_wfa_lean2: one word in front)
 }
-int wfa_resident_blocks(int device, int seq_words, int nc, bool win, bool r16) {
+int wfa_resident_blocks(int device, int seq_words, int nc, bool win, bool r16, bool lean2) {
     int nb = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)wfa_lean_fn(nc, win, r16), 64, wfa_dyn_lds(seq_words, win)) != hipSuccess || nb < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)wfa_lean_fn(nc, win, r16, lean2), 64, wfa_dyn_lds(seq_words, win)) != hipSuccess || nb < 1)
         nb = 8;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
     return nb * cus;
 }
 void launch_wfa(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks,
                 int32_t *hdr_pool, int64_t hdr_stride, uint8_t *arena_pool, int64_t arena_stride, uint64_t *ops_pool,
-                unsigned int *queue, int seq_words, int want_ops, WfaOut *out, int nc, bool win, bool r16, unsigned long long *dbg) {
-    hipLaunchKernelGGL(wfa_lean_fn(nc, win, r16), dim3(nblocks), dim3(64), wfa_dyn_lds(seq_words, win), st, in, n, todo, ntodo, hdr_pool,
+                unsigned int *queue, int seq_words, int want_ops, WfaOut *out, int nc, bool win, bool r16, unsigned long long *dbg, bool lean2) {
+    hipLaunchKernelGGL(wfa_lean_fn(nc, win, r16, lean2), dim3(nblocks), dim3(64), wfa_dyn_lds(seq_words, win), st, in, n, todo, ntodo, hdr_pool,
                        hdr_stride, arena_pool, arena_stride, ops_pool, queue, seq_words, want_ops, out, dbg);
 }
 void launch_wfa_wide(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int32_t *hdr_pool,

@@ -1,4 +1,4 @@
-// experiments/pa_chain_bt/lm_pa_chain_bt.h - device side of pa_chain_bt.h (STAGED for round 5): the macros under which the
+// lm_pa_chain_bt.h - device side of pa_chain_bt.h : the macros under which the
 // wavefront backtrack compiles inside lm_kernels.hip (namespace lm, after lm_pa_chain_dp.h: it uses pcd_wave_max_u64).
 // tools/adopt_pa_chain_pipe.py wires it into k_pa_chain_wave / k_pa_chain_pipe behind LM_PA_CHAIN_BT_WAVE.
 #pragma once
@@ -9,10 +9,10 @@
 #define PCB_LDS_SYNC() LDS_WAVE_SYNC()
 #define PCB_WAVE_MAX_U64(v) pcd_wave_max_u64(v)
 
-#include "pa_chain_bt.h"
+#include "lm_pa_chain_bt_core.h"
 
 #define PCC_DEV __device__ __forceinline__
 #define PCC_LANE ((int)(threadIdx.x & 63))
 #define PCC_LDS_SYNC() LDS_WAVE_SYNC()
-#include "pa_clear_tile.h"
+#include "lm_pa_clear_tile.h"
 static_assert(sizeof(PccLds) <= sizeof(PcdLds), "the clear tile aliases the DP's ring");

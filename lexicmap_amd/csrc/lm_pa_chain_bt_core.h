@@ -1,4 +1,4 @@
-// experiments/pa_chain_bt/pa_chain_bt.h - the backtrack of Chainer2 (lm_run_chain2's second half; lib-chaining2.go:309-420 as
+// lm_pa_chain_bt_core.h - the backtrack of Chainer2 (lm_run_chain2's second half; lib-chaining2.go:309-420 as
 // restated in lm_algos.h) by a WAVEFRONT instead of one lane.  STAGED for round 5: equal to lm_run_chain2 on the host SIMT
 // emulator (tests/test_pa_chain_bt_emulated_cpu.py), compiled for gfx950; never run on a GPU.
 //

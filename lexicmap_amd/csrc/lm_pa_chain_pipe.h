@@ -1,4 +1,4 @@
-// experiments/pa_chain_pipe/lm_pa_chain_pipe.h - device side of pa_chain_pipe.h (STAGED for round 5): k_pa_chain_pipe, a
+// lm_pa_chain_pipe.h - device side of pa_chain_pipe.h : k_pa_chain_pipe, a
 // workgroup of PCP_NW wavefronts for the Chainer2 DP of a LONG chaining window.  k_pa_chain_wave (one wavefront per window)
 // keeps unpacking, ClearSubstrPairs and TrimSubStrPairs of every window and the whole of the short ones - nearly all of them;
 // a window with more than `pipe_min` anchors left after the trim is handed over (clr_n[ti] = anchors, out_n[ti] = first anchor,
@@ -24,7 +24,7 @@
 #define PCP_GLOBAL_FENCE() __threadfence_block()
 #define PCP_LOAD_MSI(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 
-#include "pa_chain_pipe.h"
+#include "lm_pa_chain_pipe_dp.h"
 
 __global__ __launch_bounds__(PCP_NW * 64) void k_pa_chain_pipe(const int64_t *__restrict__ pa_off, const int32_t *__restrict__ long_tasks,
                                                                 const unsigned int *__restrict__ nlong_p, LmChain2Opt opt,

@@ -1,4 +1,4 @@
-// experiments/pa_chain_pipe/pa_chain_pipe.h - STAGED for round 5 (not in lexicmap_amd/csrc): the banded DP of Chainer2
+// lm_pa_chain_pipe_dp.h - STAGED for round 5 (not in lexicmap_amd/csrc): the banded DP of Chainer2
 // (lib-chaining2.go:222-307; k_pa_chain_wave, lm_kernels.hip) by a WORKGROUP of PCP_NW wavefronts per chain window, as a
 // pipeline over the anchors.
 //

@@ -1,4 +1,4 @@
-// experiments/pa_chain_bt/pa_clear_tile.h - the marks of ClearSubstrPairs (lib-index-search.go:927-972 as lm_clear_sorted states
+// lm_pa_clear_tile.h - the marks of ClearSubstrPairs (lib-index-search.go:927-972 as lm_clear_sorted states
 // it: an anchor is dropped when it lies inside an EARLIER anchor of the sorted list whose QBegin is at most K - len before its
 // own) from LDS tiles.  STAGED for round 5: equal to lm_clear_sorted on the host SIMT emulator; never run on a GPU.
 //

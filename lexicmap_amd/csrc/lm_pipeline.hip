@@ -54,7 +54,7 @@ static inline hipStream_t &lane_st2(lm_index *ix) { return tls_lane ? ix->st2_b 
 static inline DBuf<uint8_t> &lane_tmp(lm_index *ix) { return tls_lane ? ix->tmp_b : ix->tmp; }
 static inline DBuf<uint8_t> &lane_tmp2(lm_index *ix) { return tls_lane ? ix->tmp2_b : ix->tmp2; }
 // the scratch budget of the lane this thread works for
-static inline int64_t BUDGET(lm_index *ix) { return ix->scratch_budget > 0 ? ix->scratch_budget / ix->active_lanes : ix->scratch_budget; }
+static inline int64_t BUDGET(lm_index *ix) { return ix->scratch_budget > 0 ? ix->scratch_budget / ix->budget_lanes : ix->scratch_budget; }
 static int device_cus(int device) {
     static int cus[64] = {0};
     if (device < 0 || device >= 64) return 256;
@@ -577,14 +577,6 @@ static void stage_lookup(Work &w, lm_stage_stats &stats) {
     HIPCHK(hipMemcpyAsync(&hv, w.stat.p, sizeof hv, hipMemcpyDeviceToHost, S(ix)));
     sync(ix);
     stats.seed_values += (int64_t)hv;
-    {   // algorithmic bytes of the lookup, SURVEY.md §8(d) as written (reference-format sizes): per ISSUED lookup one
-        // 8-byte anchor-table entry + ceil(log2 S_b) 8-byte k-mer probes, S_b = mean seeds per anchor partition, plus
-        // 16 B (k-mer + value) per returned seed.  The packed image moves less than that: 2 x 4 B of table, key_bits / 8
-        // per probe and (key_bits + val_bits) / 8 per returned seed (reported as k_lookup_count_packed).
-        const double sb = (double)ix->n_seeds / std::max<double>(1.0, 2.0 * M * (double)(ix->view.P1 - 1));
-        const int64_t probes = (int64_t)std::ceil(std::log2(sb + 1.0));
-        prof_add_bytes(ix, "k_lookup_count", nlk * (8 + 8 * probes) + 16 * (int64_t)hv);
-    }
     // anchors + their chaining scratch (~96 B each) must fit 22 % of the scratch budget, and their number 31 bits:
     // otherwise the caller halves this part of the batch and comes back (lm_search_resident)
     const char *dbg_max = getenv("LM_DEBUG_MAX_ANCHORS"); // test hook: forces the halving path
@@ -592,6 +584,15 @@ static void stage_lookup(Work &w, lm_stage_stats &stats) {
         (dbg_max && qb->nq > 1 && T > atoll(dbg_max))) {
         if (qb->nq <= 1) throw HipError("one query yields more seed anchors than the device can hold");
         throw PartTooLarge();
+    }
+    {   // (only for a part that goes on: a part thrown back for halving is searched again as two)
+        // algorithmic bytes of the lookup, SURVEY.md §8(d) as written (reference-format sizes): per ISSUED lookup one
+        // 8-byte anchor-table entry + ceil(log2 S_b) 8-byte k-mer probes, S_b = mean seeds per anchor partition, plus
+        // 16 B (k-mer + value) per returned seed.  The packed image moves less than that: 2 x 4 B of table, key_bits / 8
+        // per probe and (key_bits + val_bits) / 8 per returned seed (reported as k_lookup_count_packed).
+        const double sb = (double)ix->n_seeds / std::max<double>(1.0, 2.0 * M * (double)(ix->view.P1 - 1));
+        const int64_t probes = (int64_t)std::ceil(std::log2(sb + 1.0));
+        prof_add_bytes(ix, "k_lookup_count", nlk * (8 + 8 * probes) + 16 * (int64_t)hv);
     }
     stats.anchors_raw += T;
     w.n_anchors = T;
@@ -1659,7 +1660,7 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
         a.subs.ensure((size_t)TP);
         a.marks.ensure((size_t)TP);
         a.msi.ensure((size_t)TP);
-        a.stack.ensure(2 * (size_t)TP + 4 * (size_t)nt + 8);
+        a.stack.ensure(2 * (size_t)TP + 5 * (size_t)nt + 48); // (+ the list of long windows, its counter, the debug counters)
         a.out.ensure((size_t)TP);
         LmChain2Opt o2; // search.go:364-378
         o2.max_gap = ix->opt.align_max_gap;
@@ -1671,7 +1672,8 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
         {
             Prof p(ix, "k_pa_chain", TP * 32);
             launch_pa_chain(S(ix), a.B0.p, a.pa_off.p, nt, ix->host.k, o2, a.subs.p, a.marks.p, a.msi.p, a.stack.p,
-                            a.out.p, a.out_n.p, a.clr_n.p, compact ? qbits : 0, compact ? tbits : 0, ix->tune.pa_chain_ring != 0);
+                            a.out.p, a.out_n.p, a.clr_n.p, compact ? qbits : 0, compact ? tbits : 0, ix->tune.pa_chain_ring != 0,
+                            ix->tune.pa_chain_pipe ? ix->tune.pa_pipe_min : 0, TP, ix->tune.pa_chain_bt_wave);
         }
         a.res_off.ensure((size_t)nt + 2);
         int64_t NR = scan_to_i64<int32_t, CastI32>(ix, a.out_n.p, nt, a.res_off.p);
@@ -1930,7 +1932,7 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
         const int64_t m = (int64_t)cls[c].size();
         const int64_t smax = std::min<int64_t>(8 * cl[c] + 64, cs[c]);
         const int64_t per = (smax / 2 + 2) * 64 * first_nc[c] + 2 * cl[c] + 4096 + (smax / 2 + 4) * 16;
-        want[c] = m == 0 ? 0 : std::min<int64_t>(m, wfa_resident_blocks(ix->device, cw[c], first_nc[c], win[c], ix->tune.wfa_r16 && wfa_r16_ok(cw[c], first_nc[c], win[c]))) * per * 9 / 8;
+        want[c] = m == 0 ? 0 : std::min<int64_t>(m, wfa_resident_blocks(ix->device, cw[c], first_nc[c], win[c], ix->tune.wfa_r16 && wfa_r16_ok(cw[c], first_nc[c], win[c]), ix->tune.wfa_lean2 != 0)) * per * 9 / 8;
         want_tot += want[c];
     }
     for (int c = 0; c < NCH; c++)
@@ -1946,7 +1948,7 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
         // the 512 / 1024-diagonal passes are a handful of long alignments the round waits for: a workgroup of four wavefronts each
         const bool mw = ix->tune.wfa_mw && nc >= 8;
         const bool r16 = !mw && ix->tune.wfa_r16 && wfa_r16_ok(seq_words, nc, use_win); // 16-bit ring cells: more wavefronts per CU
-        const int resident = mw ? wfa_mw_resident_blocks(ix->device, seq_words, nc, use_win) : wfa_resident_blocks(ix->device, seq_words, nc, use_win, r16);
+        const int resident = mw ? wfa_mw_resident_blocks(ix->device, seq_words, nc, use_win, ix->tune.wfa_lean2 != 0) : wfa_resident_blocks(ix->device, seq_words, nc, use_win, r16, ix->tune.wfa_lean2 != 0);
         int nblocks = (int)std::min<int64_t>(m, std::max<int64_t>(mw ? 1 : 256, (int64_t)resident * ix->tune.wfa_resident_pct / 100));
         // private scratch per resident wave: one backtrace byte per wavefront cell + 8 bytes per even score; never
         // more than the longest problem of the class is expected to need
@@ -1980,10 +1982,10 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
             Prof p(ix, names[mw ? (use_win ? 3 : 2) : use_win ? 1 : 0][nc == 16 ? 4 : nc == 8 ? 3 : nc == 4 ? 2 : nc == 1 ? 0 : 1], wfa_bytes(in, items));
             if (mw)
                 launch_wfa_mw(S(ix), a.wfa_in.p, n, lc.todo.p, m, nblocks, lc.hdr_pool.p, entries * 2, (uint8_t *)lc.arena_pool.p, bytes,
-                              a.ops_pool.p, lc.queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc, use_win);
+                              a.ops_pool.p, lc.queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc, use_win, ix->tune.wfa_lean2 != 0);
             else
                 launch_wfa(S(ix), a.wfa_in.p, n, lc.todo.p, m, nblocks, lc.hdr_pool.p, entries * 2, (uint8_t *)lc.arena_pool.p, bytes,
-                           a.ops_pool.p, lc.queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc, use_win, r16, wave_dbg ? lc.dbg.p : nullptr);
+                           a.ops_pool.p, lc.queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc, use_win, r16, wave_dbg ? lc.dbg.p : nullptr, ix->tune.wfa_lean2 != 0);
         }
         sync(ix);
         if (wave_dbg) { // where the launch's time went, wavefront by wavefront (100-MHz wall clock)
@@ -2128,7 +2130,7 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
                 tls_lane = lane;
                 tls_stream = a.wide.st;
                 tls_tmp = &a.wide.tmp;
-                tls_arena = &ix->arena;
+                tls_arena = &ix->arena[tls_lane];
                 wide_run(items, level, a.wide);
             } catch (...) {
                 wide_err = std::current_exception();
@@ -2161,7 +2163,7 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
                 tls_lane = lane;
                 tls_stream = a.lean[c].st;
                 tls_tmp = &a.lean[c].tmp;
-                tls_arena = &ix->arena;
+                tls_arena = &ix->arena[tls_lane];
                 class_chain(c);
             } catch (...) {
                 cerr[c] = std::current_exception();
@@ -2329,7 +2331,7 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
                 if (!lane_st2(ix)) HIPCHK(hipStreamCreate(&lane_st2(ix)));
                 tls_stream = lane_st2(ix);
                 tls_tmp = &lane_tmp2(ix);
-                tls_arena = &ix->arena;
+                tls_arena = &ix->arena[tls_lane];
             }
             int64_t tpos = r0;
             int slot = 0;
@@ -2699,7 +2701,7 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
                 tls_lane = lane;
                 tls_stream = a_tail->tail_st;
                 tls_tmp = &a_tail->tail_tmp;
-                tls_arena = &ix->arena;
+                tls_arena = &ix->arena[tls_lane];
                 run_wfa(*a_tail, Rp->in_t, Rp->wout_t, Rp->ops_h_t, Rp->ops_off_t, want_seq, &Rp->est_t, nullptr, &Rp->defer.min_nc, 0.4);
                 finalize_round(*Rp);
             } catch (...) {
@@ -2940,7 +2942,7 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res, const Searc
         ScratchArena *pa = tls_arena;
         hipStream_t ps = tls_stream;
         explicit TlsScope(lm_index *ix) {
-            tls_arena = &ix->arena;
+            tls_arena = &ix->arena[tls_lane];
             if (!tls_stream) tls_stream = lane_st(ix);
         }
         ~TlsScope() {
@@ -2957,7 +2959,7 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res, const Searc
             if (AlignCtx *c = lane_actx(ix)[j]) freed += c->release_big(BUDGET(ix) / 200);
         if (freed > 0 && getenv("LM_DEBUG"))
             fprintf(stderr, "[lm] alignment scratch of the previous part released: %.2f GB (arena: %.2f GB in slabs, %lld slab allocations so far)\n",
-                    (double)freed / 1e9, (double)ix->arena.slab_bytes / 1e9, (long long)ix->arena.slab_allocs);
+                    (double)freed / 1e9, (double)ix->arena[tls_lane].slab_bytes / 1e9, (long long)ix->arena[tls_lane].slab_allocs);
     }
     dbg_stamp("previous alignment scratch released");
     Work &w = get_work(ix, qb);
@@ -3269,7 +3271,7 @@ static void drop_scratch(lm_index *ix, const char *why) {
     lm_free_align_ctx(ix, tls_lane);
     lane_tmp(ix).release();
     lane_tmp2(ix).release();
-    ix->arena.trim();
+    ix->arena[tls_lane].trim(); // (its overflow slabs; the handle's lane slabs stay)
     if (getenv("LM_DEBUG")) fprintf(stderr, "[lm] device scratch of lane %d dropped after: %s\n", tls_lane, why);
 }
 // All parts of the caller's batch, results in order.  A part whose seed anchors outgrow the device (or whose scratch
@@ -3282,7 +3284,15 @@ static void search_parts(lm_index *ix, lm_qbatch *qb, lm_result *res, const Sear
     HIPCHK(hipSetDevice(ix->device));
     tls_lane = 0;
     ix->active_lanes = 1;
+    ix->budget_lanes = 1;
+    if (ix->tune.arena_reserve_pct > 0 && !ix->lane_slabs.asked && ix->scratch_budget > 0) { // once per handle (LaneSlabs, lm_internal.h)
+        const bool ok = ix->lane_slabs.reserve((size_t)(ix->scratch_budget / 100 * ix->tune.arena_reserve_pct));
+        if (getenv("LM_DEBUG"))
+            fprintf(stderr, "[lm] scratch: %d %% of the budget (%.2f GB) cut into two lane slabs: %s\n", ix->tune.arena_reserve_pct,
+                    (double)ix->lane_slabs.bytes() / 1e9, ok ? "yes" : "refused (slabs on demand)");
+    }
     if (qb->parts.empty()) {
+        ix->lane_slabs.assign(ix->arena[0], ix->arena[1], 1); // (false: a block is live - the assignment stays, overflow slabs serve)
         try {
             search_impl(ix, qb, res, ctl);
             return;
@@ -3319,8 +3329,20 @@ static void search_parts(lm_index *ix, lm_qbatch *qb, lm_result *res, const Sear
     // (round 3 measured +3..6 % at C3 and left it opt-in; with this round's WFA kernels the second lane is worth 10 %:
     // 12.97 -> 11.75 s per C3 step - the latency-bound passes of one part's rounds run beside the throughput-bound kernels of
     // the other part instead of beside their own round's; LM_TWO_LANES=0 turns it off)
-    const int lanes = (ctl == nullptr && qb->parts.size() >= 2 && ix->tune.two_lanes && !ix->tune.wfa_serial) ? 2 : 1; // (exclusive kernel timings: one lane)
+    // (exclusive kernel timings: ONE lane works, but with the budget share, the slab and therefore the parts, chunks and
+    // launches of the two-lane search it stands for)
+    const int blanes = (ctl == nullptr && qb->parts.size() >= 2 && ix->tune.two_lanes) ? 2 : 1;
+    const int lanes = (blanes == 2 && !ix->tune.wfa_serial) ? 2 : 1;
     ix->active_lanes = lanes;
+    ix->budget_lanes = blanes;
+    if (!ix->lane_slabs.assign(ix->arena[0], ix->arena[1], blanes)) { // a block outlived the previous search: give everything back first
+        for (int l = 0; l < 2; l++) {
+            tls_lane = l;
+            drop_scratch(ix, "lane slabs change hands");
+        }
+        tls_lane = 0;
+        ix->lane_slabs.assign(ix->arena[0], ix->arena[1], blanes);
+    }
     auto lane_fn = [&](int lane) {
         tls_lane = lane;
         hipStream_t saved_stream = tls_stream;
@@ -3380,7 +3402,15 @@ static void search_parts(lm_index *ix, lm_qbatch *qb, lm_result *res, const Sear
     if (lanes == 2) second = std::thread(lane_fn, 1);
     lane_fn(0);
     if (second.joinable()) second.join();
+    if (getenv("LM_DEBUG_MEM")) { // what the scratch of this search took from the device
+        size_t fr = 0, tot = 0;
+        (void)hipMemGetInfo(&fr, &tot);
+        fprintf(stderr, "[lm] scratch after a search of %zu parts on %d lane(s) (budget / %d): lane slabs %.2f GB; overflow slabs: lane 0 %.2f GB (%lld device allocations so far), lane 1 %.2f GB (%lld); device free %.2f GB; all buffers of this library %.2f GB\n",
+                todo.size(), lanes, blanes, (double)ix->lane_slabs.bytes() / 1e9, (double)ix->arena[0].slab_bytes / 1e9, (long long)ix->arena[0].slab_allocs,
+                (double)ix->arena[1].slab_bytes / 1e9, (long long)ix->arena[1].slab_allocs, (double)fr / 1e9, (double)g_dbuf_bytes.load() / 1e9);
+    }
     ix->active_lanes = 1;
+    ix->budget_lanes = 1;
     // the (possibly finer) split stays with the batch handle
     qb->parts.clear();
     for (auto &ps : todo) qb->parts.push_back(ps.part);

@@ -1,4 +1,4 @@
-// experiments/wfa_lean2/lm_wfa_lean2.h - device side of wfa_lean2_fwd.h (STAGED for round 5): k_wfa_lean2<NC, RT, WIN>,
+// lm_wfa_lean2.h - device side of wfa_lean2_fwd.h : k_wfa_lean2<NC, RT, WIN>,
 // k_wfa_lean (persistent wavefronts over a queue; the sequences 2-bit packed in LDS, whole or through sliding windows;
 // bt_walk / bt_replay of lm_kernels.hip) with the restructured forward pass.  Same signature, scratch pools and results as
 // k_wfa_lean<NC, WIN, RT>: the integration is wfa_lean_fn() returning these + 8 * seq_words + 20 bytes of dynamic LDS for the
@@ -54,7 +54,7 @@ __device__ __forceinline__ int l2_sflb(unsigned long long m) {
 #define WR_READLANE(v, l) __builtin_amdgcn_readlane((v), (l)) /* `l` is wave-uniform */
 #define WR_ALIGNBIT(hi, lo, sh) __builtin_amdgcn_alignbit((hi), (lo), (sh))
 
-#include "wfa_lean2_fwd.h"
+#include "lm_wfa_lean2_fwd.h"
 
 template <int NC, typename RT, bool WIN>
 __global__ __launch_bounds__(64) void k_wfa_lean2(const WfaIn *__restrict__ in, int64_t n, const int32_t *__restrict__ todo, int64_t ntodo,

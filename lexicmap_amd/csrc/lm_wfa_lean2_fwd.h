@@ -1,6 +1,6 @@
-// experiments/wfa_lean2/wfa_lean2_fwd.h - the forward pass of the gap-affine WFA (x=4, o=6, e=2, wf-adaptive(10,50)) by ONE
+// wfa_lean2_fwd.h - the forward pass of the gap-affine WFA (x=4, o=6, e=2, wf-adaptive(10,50)) by ONE
 // wavefront, restructured for fewer instructions per score step than k_wfa_lean (lexicmap_amd/csrc/lm_kernels.hip).
-// STAGED for round 5: equal to the oracle on the host SIMT emulator (tests/test_wfa_lean2_emulated_cpu.py), compiled for
+// equal to the oracle on the host SIMT emulator (tests/test_wfa_lean2_emulated_cpu.py), compiled for
 // gfx950 beside the product kernels (compile_check.hip), instruction counts of the score loop in README.md; never run on a GPU.
 //
 // Why: k_wfa_lean is 58 % of the vector and 71 % of the scalar instructions of a C3 step (profiles/r04_c3_pmc_sq.json) and it

@@ -19,6 +19,8 @@
 #define WR_NULL_OFF LM_NULL_OFF
 
 #include "lm_wfa_mw_fwd.h"
+#include "lm_wfa_lean2.h"
+#include "lm_wfa_mw2.h"
 
 template <int NCW, bool WIN>
 __global__ __launch_bounds__(MW_THREADS) void k_wfa_mw(const WfaIn *__restrict__ in, int64_t n, const int32_t *__restrict__ todo, int64_t ntodo,
@@ -106,22 +108,26 @@ __global__ __launch_bounds__(MW_THREADS) void k_wfa_mw(const WfaIn *__restrict__
 
 typedef void (*WfaMwFn)(const WfaIn *, int64_t, const int32_t *, int64_t, int32_t *, int64_t, uint8_t *, int64_t, uint64_t *, unsigned int *, int,
                         int, WfaOut *);
-static WfaMwFn wfa_mw_fn(int ncw, bool win) {
+static WfaMwFn wfa_mw_fn(int ncw, bool win, bool lean2 = false) {
+    if (lean2) { // the restructured forward pass (lm_wfa_mw2.h)
+        if (win) return ncw == 4 ? k_wfa_mw2<4, true> : k_wfa_mw2<2, true>;
+        return ncw == 4 ? k_wfa_mw2<4, false> : k_wfa_mw2<2, false>;
+    }
     if (win) return ncw == 4 ? k_wfa_mw<4, true> : k_wfa_mw<2, true>;
     return ncw == 4 ? k_wfa_mw<4, false> : k_wfa_mw<2, false>;
 }
-static size_t wfa_mw_dyn_lds(int seq_words, bool win) { return win ? 0 : (size_t)(2 * (seq_words + 2)) * sizeof(uint32_t); }
+static size_t wfa_mw_dyn_lds(int seq_words, bool win) { return win ? 0 : (size_t)(2 * (seq_words + 2) + 1) * sizeof(uint32_t); } // (k_wfa_mw2: one word in front)
 // workgroups of k_wfa_mw<nc / 4> the device holds at once (nc = 8: 512 diagonals, 16: 1024)
-int wfa_mw_resident_blocks(int device, int seq_words, int nc, bool win) {
+int wfa_mw_resident_blocks(int device, int seq_words, int nc, bool win, bool lean2) {
     int nb = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)wfa_mw_fn(nc / 4, win), MW_THREADS, wfa_mw_dyn_lds(seq_words, win)) != hipSuccess || nb < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)wfa_mw_fn(nc / 4, win, lean2), MW_THREADS, wfa_mw_dyn_lds(seq_words, win)) != hipSuccess || nb < 1)
         nb = 1;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
     return nb * cus;
 }
 void launch_wfa_mw(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks, int32_t *hdr_pool,
                    int64_t hdr_stride, uint8_t *arena_pool, int64_t arena_stride, uint64_t *ops_pool, unsigned int *queue, int seq_words,
-                   int want_ops, WfaOut *out, int nc, bool win) {
-    hipLaunchKernelGGL(wfa_mw_fn(nc / 4, win), dim3(nblocks), dim3(MW_THREADS), wfa_mw_dyn_lds(seq_words, win), st, in, n, todo, ntodo, hdr_pool, hdr_stride,
+                   int want_ops, WfaOut *out, int nc, bool win, bool lean2) {
+    hipLaunchKernelGGL(wfa_mw_fn(nc / 4, win, lean2), dim3(nblocks), dim3(MW_THREADS), wfa_mw_dyn_lds(seq_words, win), st, in, n, todo, ntodo, hdr_pool, hdr_stride,
                        arena_pool, arena_stride, ops_pool, queue, seq_words, want_ops, out);
 }

@@ -1,4 +1,4 @@
-// experiments/wfa_lean2/lm_wfa_mw2.h - device side of wfa_mw2_fwd.h (STAGED for round 5): k_wfa_mw2<NCW, WIN>, k_wfa_mw
+// lm_wfa_mw2.h - device side of wfa_mw2_fwd.h : k_wfa_mw2<NCW, WIN>, k_wfa_mw
 // (a workgroup of four wavefronts per long alignment; persistent over a queue; bt_walk / bt_replay by the first wavefront)
 // with the restructured forward pass.  Same signature, scratch pools and results as k_wfa_mw<NCW, WIN>; dynamic LDS of the
 // whole-sequence form 8 * seq_words + 20 bytes.  Included inside namespace lm after lm_wfa_lean2.h.  NOT run on a GPU yet:
@@ -14,7 +14,7 @@ __device__ __forceinline__ int l2_quad_min_i32(int v) {
 }
 #define WR_QUAD_MIN_I32(v) l2_quad_min_i32(v)
 
-#include "wfa_mw2_fwd.h"
+#include "lm_wfa_mw2_fwd.h"
 
 template <int NCW, bool WIN>
 __global__ __launch_bounds__(MW2_THREADS) void k_wfa_mw2(const WfaIn *__restrict__ in, int64_t n, const int32_t *__restrict__ todo, int64_t ntodo,

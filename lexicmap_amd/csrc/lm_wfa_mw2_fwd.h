@@ -1,6 +1,6 @@
-// experiments/wfa_lean2/wfa_mw2_fwd.h - the forward pass of wfa_lean2_fwd.h for a WORKGROUP of four wavefronts per alignment
+// wfa_mw2_fwd.h - the forward pass of wfa_lean2_fwd.h for a WORKGROUP of four wavefronts per alignment
 // (256 threads x NCW cells = 512 / 1024 diagonals): the restructuring of lm_wfa_mw_fwd.h (k_wfa_mw) that k_wfa_lean got.
-// STAGED for round 5: equal to the oracle on the host SIMT emulator (tests/test_wfa_mw2_emulated_cpu.py); never run on a GPU.
+// equal to the oracle on the host SIMT emulator (tests/test_wfa_mw2_emulated_cpu.py); never run on a GPU.
 //
 // k_wfa_mw is latency-bound: a handful of 20-50-kb alignments per round, each a chain of score steps, every round of the C3
 // pipeline waits for them.  Its step has FOUR workgroup barriers (extension results; kept range of the cut-off; NULL-backs and
@@ -16,7 +16,7 @@
 // Same recurrence, tie rules, trimming, cut-off, backtrace bytes and header as k_wfa_lean / k_wfa_mw.  One source for the
 // device and for the host emulator: every wave-level operation in wave-uniform, every barrier in workgroup-uniform control flow.
 #pragma once
-#include "wfa_lean2_fwd.h"
+#include "lm_wfa_lean2_fwd.h"
 
 #define MW2_THREADS 256
 #define MW2_RED_WORDS 64 /* LDS words of reduction scratch */

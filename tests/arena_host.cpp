@@ -79,9 +79,12 @@ void *ah_arena_alloc(void *a, size_t bytes) {
 }
 int ah_arena_release(void *a, void *p) { return ((lm::ScratchArena *)a)->release(p) ? 1 : 0; }
 void ah_arena_trim(void *a) { ((lm::ScratchArena *)a)->trim(); }
-#ifdef AH_HAVE_RESERVE /* tools/adopt_arena_reserve.py applied (tests/test_adopt_scripts_cpu.py builds this file against the adopted copy) */
-int ah_arena_reserve(void *a, size_t bytes) { return ((lm::ScratchArena *)a)->reserve(bytes) ? 1 : 0; }
-#endif
+// the handle's two lane slabs (lm::LaneSlabs) lent to two arenas
+void *ah_slabs_new() { return new lm::LaneSlabs(); }
+void ah_slabs_delete(void *s) { delete (lm::LaneSlabs *)s; }
+int ah_slabs_reserve(void *s, size_t bytes) { return ((lm::LaneSlabs *)s)->reserve(bytes) ? 1 : 0; }
+int ah_slabs_assign(void *s, void *a0, void *a1, int lanes) { return ((lm::LaneSlabs *)s)->assign(*(lm::ScratchArena *)a0, *(lm::ScratchArena *)a1, lanes) ? 0 : 1; }
+int ah_slabs_unassign(void *s, void *a0, void *a1) { return ((lm::LaneSlabs *)s)->unassign(*(lm::ScratchArena *)a0, *(lm::ScratchArena *)a1) ? 0 : 1; }
 long long ah_arena_slab_bytes(void *a) { return ((lm::ScratchArena *)a)->slab_bytes; }
 long long ah_arena_live_bytes(void *a) { return ((lm::ScratchArena *)a)->live_bytes; }
 long long ah_arena_slab_allocs(void *a) { return ((lm::ScratchArena *)a)->slab_allocs; }

@@ -25,7 +25,7 @@ static inline unsigned long long emu_wave_max_u64(unsigned long long v, int site
 static long g_pcb_count[2]; // walk steps, tile loads (lane 0's)
 #define PCB_COUNT(what) do { if (simt::lane() == 0) g_pcb_count[what]++; } while (0)
 
-#include "../../experiments/pa_chain_bt/pa_chain_bt.h"
+#include "../../lexicmap_amd/csrc/lm_pa_chain_bt_core.h"
 
 static void sort_by_qbegin(LmChain2 *res, int nout) { // k_pa_chain_wave's stable sort (lib-seq_compare.go:501-508)
     for (int i = 1; i < nout; i++) {
@@ -96,7 +96,7 @@ extern "C" void pcb_emu_counts(long *steps, long *tiles) {
 #define PCC_DEV static inline
 #define PCC_LANE (simt::lane())
 #define PCC_LDS_SYNC() simt::wave_sync(__LINE__)
-#include "../../experiments/pa_chain_bt/pa_clear_tile.h"
+#include "../../lexicmap_amd/csrc/lm_pa_clear_tile.h"
 
 // returns the number of marks that differ from lm_clear_sorted's; *kept: anchors the reference keeps
 extern "C" int pcc_emu_check(const int32_t *qb, const int32_t *tb, const uint8_t *len, int n, int K, int *kept) {

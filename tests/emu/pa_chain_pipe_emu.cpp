@@ -47,7 +47,7 @@ static inline void emu_sched_point() {
 }
 #define PCP_SCHED_POINT() emu_sched_point()
 
-#include "../../experiments/pa_chain_pipe/pa_chain_pipe.h"
+#include "../../lexicmap_amd/csrc/lm_pa_chain_pipe_dp.h"
 
 // returns 0 when the emulated pipeline's msi / best score / best anchor equal lm_run_chain2's
 extern "C" int pcp_emu_check(const int32_t *qb, const int32_t *tb, const uint8_t *len, int n, int max_gap, int band_base, int band_count,

@@ -23,7 +23,7 @@
 #define WR_WAVE_MIN_I32(v) \
     ((int32_t)simt::wave_reduce((uint32_t)(v), __LINE__, [](uint32_t a, uint32_t b) { return (uint32_t)((int32_t)a < (int32_t)b ? (int32_t)a : (int32_t)b); }))
 
-#include "../../experiments/wfa_lean2/wfa_lean2_fwd.h"
+#include "../../lexicmap_amd/csrc/lm_wfa_lean2_fwd.h"
 #include "wfa_host_walk.h"
 
 // 2-bit packing of k_wfa_lean's pack16 ('A' 0, 'C' 1, 'T' 2, 'G' 3; first base in the top bits); false: not plain ACGT

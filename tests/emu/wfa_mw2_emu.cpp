@@ -30,7 +30,7 @@ static inline int32_t emu_quad_min(int32_t v, int site) { // the minimum over th
 }
 #define WR_QUAD_MIN_I32(v) emu_quad_min((v), __LINE__)
 
-#include "../../experiments/wfa_lean2/wfa_mw2_fwd.h"
+#include "../../lexicmap_amd/csrc/lm_wfa_mw2_fwd.h"
 #include "wfa_host_walk.h"
 
 static bool pack_seq(const uint8_t *s, int n, std::vector<uint32_t> &w) {

@@ -1,4 +1,4 @@
-"""experiments/lane_arena/lm_lane_arena.h (STAGED for round 5, not product code): the scratch of a two-lane handle as two
+"""lm::LaneSlabs + lm::ScratchArena (lexicmap_amd/csrc/lm_internal.h, product code): the scratch of a two-lane handle as two
 fixed slabs cut once from the budget.  Over a fake device: two lanes carving jittered, C3-like pools concurrently never reach
 the device after the reservation (round 4's shared growing arena took three C3 steps of hipMalloc stalls to settle and halved
 batch parts under the transient pressure); a single-lane search on the same handle gets both slabs; what no slab can take goes
@@ -12,21 +12,37 @@ import threading
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-EXP = os.path.join(os.path.dirname(HERE), "experiments", "lane_arena")
-LIB = os.path.join(EXP, "liblane_arena_host.so")
+LIB = os.path.join(HERE, "libarena_host.so")
+SRC = os.path.join(HERE, "arena_host.cpp")
+HDR = os.path.join(os.path.dirname(HERE), "lexicmap_amd", "csrc", "lm_internal.h")
 MB = 1 << 20
 GB = 1 << 30
+
+
+class _Names:
+    """the la_* names of this file on the ah_* exports of tests/arena_host.cpp"""
+    MAP = {"la_arena_new": "ah_arena_new", "la_arena_delete": "ah_arena_delete", "la_alloc": "ah_arena_alloc", "la_release": "ah_arena_release",
+           "la_trim": "ah_arena_trim", "la_live_bytes": "ah_arena_live_bytes", "la_overflow_allocs": "ah_arena_slab_allocs",
+           "la_slabs_new": "ah_slabs_new", "la_slabs_delete": "ah_slabs_delete", "la_slabs_reserve": "ah_slabs_reserve",
+           "la_slabs_assign": "ah_slabs_assign", "la_slabs_unassign": "ah_slabs_unassign", "la_reset": "ah_reset",
+           "la_device_used": "ah_device_used", "la_device_mallocs": "ah_device_mallocs"}
+
+    def __init__(self, lib):
+        self._lib = lib
+
+    def __getattr__(self, k):
+        return getattr(self._lib, self.MAP[k])
 
 
 @pytest.fixture(scope="module")
 def L():
     if not os.path.isdir("/opt/rocm/include"):
         pytest.skip("HIP headers not installed")
-    srcs = [os.path.join(EXP, "lane_arena_host.cpp"), os.path.join(EXP, "lm_lane_arena.h")]
+    srcs = [SRC, HDR]
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
-                               "-o", LIB, srcs[0]])
-    lib = C.CDLL(LIB)
+                               "-o", LIB, SRC])
+    lib = _Names(C.CDLL(LIB))
     for f in ("la_arena_new", "la_alloc", "la_slabs_new"):
         getattr(lib, f).restype = C.c_void_p
     lib.la_alloc.argtypes = [C.c_void_p, C.c_size_t]
@@ -39,6 +55,7 @@ def L():
     lib.la_slabs_reserve.argtypes = [C.c_void_p, C.c_size_t]
     lib.la_slabs_assign.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     lib.la_slabs_unassign.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.la_release.restype = C.c_int
     lib.la_reset.argtypes = [C.c_size_t]
     lib.la_device_used.restype = C.c_size_t
     lib.la_device_mallocs.restype = C.c_long
@@ -95,7 +112,7 @@ def test_two_lanes_never_reach_the_device_after_the_reservation_and_one_lane_get
     assert L.la_slabs_assign(slabs, a0, a1, 2) == 0
     run_part(L, a1, budget // 2, rng, 1.0)
     assert L.la_device_mallocs() == m0
-    L.la_slabs_unassign(slabs, a0, a1)
+    assert L.la_slabs_unassign(slabs, a0, a1) == 0
     L.la_arena_delete(a0)
     L.la_arena_delete(a1)
     L.la_slabs_delete(slabs)

@@ -1,4 +1,4 @@
-"""experiments/pa_chain_bt/pa_chain_bt.h (STAGED for round 5, not product code): the backtrack of Chainer2 - regions left and
+"""lexicmap_amd/csrc/lm_pa_chain_bt_core.h + lm_pa_clear_tile.h (product headers, switch LM_PA_CHAIN_BT_WAVE): the backtrack of Chainer2 - regions left and
 right of every chain, the walk from anchor to predecessor, the chain statistics - by a wavefront (region scans by 64 lanes,
 the walk out of 64-anchor tiles in LDS) instead of one lane chasing pointers through global memory; on the host SIMT emulator
 against lm_run_chain2 (lm_algos.h): every chain, every field, the order after the sort by QBegin."""
@@ -21,7 +21,7 @@ def lib():
     if _lib is None:
         root = os.path.dirname(HERE)
         path = os.path.join(EMU, "libpa_chain_bt_emu.so")
-        srcs = [os.path.join(EMU, "pa_chain_bt_emu.cpp"), os.path.join(root, "experiments", "pa_chain_bt", "pa_chain_bt.h"),
+        srcs = [os.path.join(EMU, "pa_chain_bt_emu.cpp"), os.path.join(root, "lexicmap_amd", "csrc", "lm_pa_chain_bt_core.h"), os.path.join(root, "lexicmap_amd", "csrc", "lm_pa_clear_tile.h"),
                 os.path.join(EMU, "simt_emu.h"), os.path.join(root, "lexicmap_amd", "csrc", "lm_algos.h")]
         if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(s) for s in srcs):
             subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-o", path, srcs[0]])

@@ -1,4 +1,4 @@
-"""experiments/pa_chain_pipe/pa_chain_pipe.h (STAGED for round 5, not product code): the banded chaining DP of the
+"""lexicmap_amd/csrc/lm_pa_chain_pipe_dp.h (product header, switch LM_PA_CHAIN_PIPE): the banded chaining DP of the
 pseudo-alignment by a workgroup of 8 wavefronts pipelined over the anchors of ONE window - each wavefront evaluates the band
 of its anchor ahead of time (coordinates only), reduces the candidates whose scores are final, then takes the pending ones in
 order as the wavefronts behind it publish them - on the host SIMT emulator (tests/emu: 512 fibers, spin-waits yield) against
@@ -23,7 +23,7 @@ def lib():
     if _lib is None:
         root = os.path.dirname(HERE)
         path = os.path.join(EMU, "libpa_chain_pipe_emu.so")
-        srcs = [os.path.join(EMU, "pa_chain_pipe_emu.cpp"), os.path.join(root, "experiments", "pa_chain_pipe", "pa_chain_pipe.h"),
+        srcs = [os.path.join(EMU, "pa_chain_pipe_emu.cpp"), os.path.join(root, "lexicmap_amd", "csrc", "lm_pa_chain_pipe_dp.h"),
                 os.path.join(EMU, "simt_emu.h"), os.path.join(root, "lexicmap_amd", "csrc", "lm_algos.h")]
         if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(s) for s in srcs):
             subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-o", path, srcs[0]])

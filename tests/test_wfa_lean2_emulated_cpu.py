@@ -1,4 +1,4 @@
-"""experiments/wfa_lean2/wfa_lean2_fwd.h - the staged restructuring of k_wfa_lean's forward pass (no-wrap ring that is
+"""lexicmap_amd/csrc/lm_wfa_lean2_fwd.h (product header, switch LM_WFA_LEAN2) - the restructuring of k_wfa_lean's forward pass (no-wrap ring that is
 recentred, trimming by ballots, extension fused behind the recurrence; fewer instructions per score step) - on the host SIMT
 emulator (tests/emu) against the oracle: score, run list, coordinates and statistics; rings of 64-512 diagonals with 32- and
 16-bit cells; wavefronts that drift (the ring is recentred), that outgrow the ring (status 3) and the small cases."""
@@ -13,7 +13,7 @@ from test_device_algos_cpu import mutate, rand_seq, run_oracle_wfa
 from test_wfa_mw_emulated_cpu import with_insertion
 from test_wfa_row_emulated_cpu import EMU, EmuOut
 
-EXP = os.path.join(os.path.dirname(os.path.dirname(EMU)), "experiments", "wfa_lean2")
+EXP = os.path.join(os.path.dirname(os.path.dirname(EMU)), "lexicmap_amd", "csrc")
 _lib = None
 
 
@@ -21,7 +21,7 @@ def lib():
     global _lib
     if _lib is None:
         path = os.path.join(EMU, "libwfa_lean2_emu.so")
-        srcs = [os.path.join(EMU, f) for f in ("wfa_lean2_emu.cpp", "wfa_host_walk.h", "simt_emu.h")] + [os.path.join(EXP, "wfa_lean2_fwd.h")]
+        srcs = [os.path.join(EMU, f) for f in ("wfa_lean2_emu.cpp", "wfa_host_walk.h", "simt_emu.h")] + [os.path.join(EXP, "lm_wfa_lean2_fwd.h")]
         if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(s) for s in srcs):
             subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-o", path, srcs[0]])
         _lib = C.CDLL(path)

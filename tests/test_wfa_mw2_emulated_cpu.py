@@ -1,4 +1,4 @@
-"""experiments/wfa_lean2/wfa_mw2_fwd.h - the staged restructuring of the workgroup WFA forward pass (k_wfa_mw: four
+"""lexicmap_amd/csrc/lm_wfa_mw2_fwd.h (product header, switch LM_WFA_LEAN2) - the restructuring of the workgroup WFA forward pass (k_wfa_mw: four
 wavefronts per alignment, 256 / 512 / 1024 diagonals; three barriers per score instead of four, ballot trimming, fused
 extension, a ring without wrap that the workgroup recentres) - on the host SIMT emulator (tests/emu) against the oracle: score,
 run list, coordinates, statistics; wavefronts wider than one wavefront's 64 lanes, than 256 and 512 diagonals (long end gaps),
@@ -14,7 +14,7 @@ from test_device_algos_cpu import mutate, rand_seq, run_oracle_wfa
 from test_wfa_mw_emulated_cpu import with_insertion
 from test_wfa_row_emulated_cpu import EMU, EmuOut
 
-EXP = os.path.join(os.path.dirname(os.path.dirname(EMU)), "experiments", "wfa_lean2")
+EXP = os.path.join(os.path.dirname(os.path.dirname(EMU)), "lexicmap_amd", "csrc")
 _lib = None
 
 
@@ -22,7 +22,7 @@ def lib():
     global _lib
     if _lib is None:
         path = os.path.join(EMU, "libwfa_mw2_emu.so")
-        srcs = [os.path.join(EMU, f) for f in ("wfa_mw2_emu.cpp", "wfa_host_walk.h", "simt_emu.h")] + [os.path.join(EXP, f) for f in ("wfa_mw2_fwd.h", "wfa_lean2_fwd.h")]
+        srcs = [os.path.join(EMU, f) for f in ("wfa_mw2_emu.cpp", "wfa_host_walk.h", "simt_emu.h")] + [os.path.join(EXP, f) for f in ("lm_wfa_mw2_fwd.h", "lm_wfa_lean2_fwd.h")]
         if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(s) for s in srcs):
             subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-o", path, srcs[0]])
         _lib = C.CDLL(path)

@@ -1,8 +1,8 @@
-"""experiments/wfa_lean2/gpu_check.py - first GPU run of k_wfa_lean2 after tools/adopt_wfa_lean2.py (round 5): every
+"""wfa_lean2_gpu_check.py - the forced-path check of k_wfa_lean2 / k_wfa_mw2 (lexicmap_amd/csrc/lm_wfa_lean2.h, lm_wfa_mw2.h): every
 instantiation forced through lm_wfa_batch (la.Index.wfa) against the oracle's lmo_wfa_align, with LM_WFA_LEAN2 = 1 and = 0
-(k_wfa_lean), plus the time of either on a class-shaped batch.  Becomes tests/test_gpu_wfa_lean2.py once it passes.
+(k_wfa_lean), plus the time of either on a class-shaped batch.  tests/test_gpu_wfa_lean2.py runs main(timing=False).
 
-    python experiments/wfa_lean2/gpu_check.py            (on the GPU box, from the repository root)
+    python tests/wfa_lean2_gpu_check.py            (on the GPU box, from the repository root: with the timing batches)
 
 Pairs: gene-sized (<= 2 kb: 128 diagonals, 16-bit cells), 2-8 kb (128 / 256 diagonals, 16-bit cells up to 12 000 bases), 8-32
 kb (windowed, 256 diagonals), 32-65 kb (whole sequences, 512: workgroup passes unless LM_WFA_MW=0), beyond 65 kb (windowed);
@@ -17,8 +17,8 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import oracle as O  # noqa: E402
 import lexicmap_amd as la  # noqa: E402
 from lexicmap_amd import synth  # noqa: E402

@@ -2,7 +2,7 @@
 """isa_loops.py <file.s> <kernel-name-substring> [first-block last-block]: the basic blocks of one kernel of a hipcc -S
 listing with their instruction mix (V vector ALU, S scalar ALU, L LDS, G global / flat memory, B branches, W waits / nops),
 their branches, and the loops (backward branches).  With a block range: the listing of those blocks.
-How the per-score-step numbers of experiments/wfa_lean2/README.md were read off the assembly."""
+How the per-score-step numbers of DESIGN.md section 4 were read off the assembly."""
 import re
 import sys
 from collections import Counter

@@ -1,7 +1,7 @@
-"""experiments/wfa_lean2/stress_emu.py [seconds] [seed]: random pairs of every shape through the staged forward passes on the
+"""tools/stress_emu_wfa_lean2.py [seconds] [seed]: random pairs of every shape through the staged forward passes on the
 host SIMT emulator (single wavefront: 64-512 diagonals, 16- / 32-bit cells, whole / windowed; workgroup: 256-1024 diagonals,
 whole / windowed) against the oracle, for as long as asked.  Not part of the test suite (the suite runs fixed cases of the same
-harnesses); run before adopting:  python experiments/wfa_lean2/stress_emu.py 600"""
+harnesses); run before adopting:  python tools/stress_emu_wfa_lean2.py 600"""
 import os
 import random
 import sys
