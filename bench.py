@@ -79,6 +79,9 @@ def parse():
     p.add_argument("--no-exclusive-step", action="store_true",
                    help="skip the extra serialised step (outside the timed region) that gives the exclusive kernel durations")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
+    p.add_argument("--gather", default="c", choices=["c", "torch"],
+                   help="N > 1: the row gather through the library's lm_gather_rows (RCCL behind the C-ABI; default) or through "
+                        "torch.distributed (lexicmap_amd/merge.py)")
     p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                    help="nccl = RCCL (one GPU per rank); gloo only to exercise the N>1 logic with ranks sharing a GPU")
     p.add_argument("--builder", default=None, choices=["gpu", "oracle"],
@@ -222,10 +225,12 @@ def cpu_baseline(index_dir, queries, seconds, ncores):
         dt = time.time() - t0
     rows = sum(r[0] for r in res)
     bases = sum(r[1] for r in res)
+    chains = sum(r[3] for r in res)
     # the oracle's rows of every sample query that was searched (query i of the sample list = queries[i % n])
     oracle_rows = {i: res[i][2] for i in range(min(n, nsample))}
     return dict(value=len(sample) / dt, unit="queries/s", cores=ncores, kind="port", _oracle_rows=oracle_rows,
                 gbp_aligned_per_s=bases / dt / 1e9, rows_per_query=rows / max(len(sample), 1),
+                chains_per_query=round(chains / max(len(sample), 1), 1),
                 sample="%d searches over %d sample queries, oracle/liblmo.so (C restatement of the Go reference, RAM-resident "
                        "index = the reference's -w regime) on %d processes, %.1f s, %d HSP rows"
                        % (len(sample), n, ncores, dt, rows))
@@ -247,7 +252,7 @@ ROW_CHECK_FIELDS = ("batch_genome", "cls", "hsp", "seq_idx", "nseqs", "seq_len",
 def _cpu_one(seq):
     rows, st = _CPU_IDX.search(seq)
     compact = [tuple(r[f] for f in ROW_CHECK_FIELDS) + (r["evalue"], st["ngenomes"]) for r in rows]
-    return (len(rows), sum(r["aligned_length"] for r in rows), compact)
+    return (len(rows), sum(r["aligned_length"] for r in rows), compact, st["n_chains"])
 
 
 def rows_equal_oracle(gpu_rows, oracle_rows, bg_map=None):
@@ -361,6 +366,32 @@ def main():
         os.environ.setdefault("LM_HOST_THREADS", str(max(1, usable_cores() // world)))
     import lexicmap_amd as la
     from lexicmap_amd import merge, synth
+
+    # the row gather of the sharded search through the library's C entry point (lm_gather_rows over RCCL: what the Go host of
+    # INTEGRATION.md calls); the communicator's id travels by one torch.distributed broadcast.  A failure to set it up is
+    # reported in the line (config.gather) and the torch.distributed gather of lexicmap_amd/merge.py takes over.
+    comm = None
+    gather_kind = "none (1 rank)"
+    if world > 1:
+        gather_kind = "torch.distributed gather (lexicmap_amd/merge.py)"
+        if args.dist_backend == "nccl" and args.gather == "c":
+            try:
+                from lexicmap_amd.api import Comm, COMM_ID_BYTES
+                idt = torch.zeros(COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    idt.copy_(torch.frombuffer(bytearray(Comm.unique_id()), dtype=torch.uint8))
+                dist.broadcast(idt, src=0)
+                comm = Comm(bytes(idt.cpu().numpy().tobytes()), world, rank, local_rank)
+                gather_kind = "lm_gather_rows (C-ABI, RCCL send/recv to the merging rank)"
+            except Exception as e:  # noqa: BLE001
+                comm = None
+                gather_kind += "; lm_gather_rows unavailable: %r" % (e,)
+            ok = torch.tensor([1 if comm is not None else 0], device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # every rank or none
+            if int(ok.item()) == 0 and comm is not None:
+                comm.close()
+                comm = None
+                gather_kind = "torch.distributed gather (lexicmap_amd/merge.py); lm_gather_rows unavailable on another rank"
 
     if args.builder is None:
         args.builder = "gpu" if args.workload in ("c2", "c3", "c4", "c5", "c3mini") else "oracle"
@@ -575,7 +606,12 @@ def main():
                     rows["query"] = rows["query"] + rank * len(queries)  # every rank has its own batch
                 else:
                     rows["query"] = rows["query"] * world + rank  # local -> global query number (round-robin sharding)
-            per_rank = merge.all_gather_rows(rows, device="cuda" if args.dist_backend == "nccl" else "cpu", host_on=0)
+            if comm is not None:
+                per_rank, _cnt = comm.gather_rows(rows, root=0)
+                if per_rank is None:
+                    per_rank = [rows]
+            else:
+                per_rank = merge.all_gather_rows(rows, device="cuda" if args.dist_backend == "nccl" else "cpu", host_on=0)
             # index shards: the library's C merge (lm_merge_sharded: final order per query + global hits) on rank 0
             rows = (merge.merge_sharded_c(per_rank) if rank == 0 else per_rank[0]) if index_sharded else \
                 merge.merge_query_sharded(per_rank)
@@ -820,7 +856,7 @@ def main():
                                        ("index-shard x%d (genome g on rank g %% %d), queries broadcast, one all-gatherv of HSP rows per step" % (world, world))
                                        if index_sharded else
                                        ("q-shard x%d (index replicated), %d queries per GPU" % (world, len(my)))),
-                       "pcie_upload_s": round(upload_s, 4), "tag": args.tag,
+                       "pcie_upload_s": round(upload_s, 4), "tag": args.tag, "gather": gather_kind,
                        "go_toolchain": go or "absent (reference Go binary cannot be built; CPU baseline is the C port)"},
             "stage_ms": {k: round(v, 3) for k, v in stats.items() if k.startswith("ms_")},
             "work": {k: v for k, v in stats.items() if not k.startswith("ms_")},
@@ -873,6 +909,14 @@ def main():
             ncores = usable_cores()
             cb = cpu_baseline(index_dir, cpu_queries or queries, args.cpu_seconds, ncores)
             cb["sample"] += "; " + cpu_sample_note
+            # like for like or not: the seed chains (= windows the pseudo-alignment has to examine) per query on either side
+            cb["gpu_chains_per_query"] = round(stats.get("chains", 0) / max(len(queries), 1), 1) if stats else None
+            if cb.get("chains_per_query") and cb["gpu_chains_per_query"] and cb["gpu_chains_per_query"] > 2 * cb["chains_per_query"]:
+                cb["note"] = ("UPPER BOUND, not a like-for-like ratio: the sample index holds %.0f seed chains per query where the "
+                              "timed index holds %.0f - the chain windows of unrelated genomes (random seed matches, rejected by "
+                              "the pseudo-alignment) grow with the size of the index and are nearly absent from the sample; the "
+                              "like-for-like pair is cpu_baseline.value against gpu_on_same_sample" %
+                              (cb["chains_per_query"], cb["gpu_chains_per_query"]))
             oracle_rows = cb.pop("_oracle_rows")
             if True:
                 # the same sample (same index directory, same queries) through the HIP path: a like-for-like pair of numbers
@@ -927,6 +971,8 @@ def main():
         shutil.rmtree(tmpdir, ignore_errors=True)
     if rank == 0:
         print(json.dumps(result), flush=True)
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -204,6 +204,29 @@ typedef struct lm_stage lm_stage; /* host arrays of a stage-level call, released
  * are process-local and come back NULL.  Free with lm_result_free. */
 lm_status lm_merge_sharded(lm_index *idx, const lm_hsp *const *rows, const size_t *nrows, int nshards, lm_result **out);
 
+/* The ONE collective of the sharded search (north_star: "per-shard hit lists merged with a single RCCL all-gatherv over
+ * xGMI"), behind the C-ABI so that the Go host needs nothing else: a gatherv of lm_hsp records to the merging rank - an
+ * all-gather of the row counts (8 bytes per rank), then one group of point-to-point transfers into the root ((N-1) payloads
+ * over the root's xGMI links; the ranks that do not merge receive nothing).  What the gathered rows are merged into:
+ * lm_merge_sharded above (lib-index-search.go:2919-2921, merge-search-results.go:142-194).
+ *   lm_comm_unique_id: rank 0 makes the 128-byte id (an ncclUniqueId) and hands it to the other ranks by the host's own
+ *     means (the Go host: a file, a socket or its launcher's environment; bench.py: torch.distributed broadcast);
+ *   lm_comm_init: every rank, once per process - one process per GPU, `device` = the GPU of this rank's index handle;
+ *   lm_gather_rows: rows / n = this rank's rows (host memory, e.g. lm_result_rows).  nrows[lm_comm_size] receives every
+ *     rank's count on every rank.  On `root`, *all_rows = the rows of rank 0, 1, ... back to back (pointer columns cleared:
+ *     they are addresses of other processes; lm_merge_sharded re-attaches genome_id / seq_id), owned by the communicator
+ *     and valid until its next call; elsewhere *all_rows = NULL.  All ranks must call it, in the same order.
+ * RCCL is bound at run time (librccl.so.1; LM_RCCL_LIB overrides): a single-GPU user never loads it. */
+#define LM_COMM_ID_BYTES 128
+typedef struct lm_comm lm_comm;
+lm_status lm_comm_unique_id(uint8_t id[LM_COMM_ID_BYTES]);
+lm_status lm_comm_init(const uint8_t id[LM_COMM_ID_BYTES], int nranks, int rank, int device, lm_comm **out);
+void lm_comm_free(lm_comm *comm);
+int lm_comm_rank(const lm_comm *comm);
+int lm_comm_size(const lm_comm *comm);
+const char *lm_comm_last_error(const lm_comm *comm); /* comm == NULL: the last failed lm_comm_unique_id / lm_comm_init of this thread */
+lm_status lm_gather_rows(lm_comm *comm, const lm_hsp *rows, size_t n, int root, const lm_hsp **all_rows, size_t *nrows);
+
 /* -n/--top-n-genomes with a sharded index: the cut of lib-index-search.go:1781-1805 is over the genomes of ALL shards.
  *   1. every rank: lm_search_scores -> its candidates, per query at most top_n (query, genome, Chainer score)
  *   2. host: gather the candidates of all ranks; lm_topn_merge -> the global top-N per query (score descending, ties by

@@ -163,6 +163,15 @@ def lib():
     L.lm_tuning_reload.restype = None
     L.lm_profile_get.argtypes = [vp, C.POINTER(C.POINTER(KernelTime))]
     L.lm_profile_get.restype = C.c_size_t
+    L.lm_comm_unique_id.argtypes = [C.c_char_p]
+    L.lm_comm_init.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.lm_comm_free.argtypes = [vp]
+    L.lm_comm_free.restype = None
+    L.lm_comm_rank.argtypes = [vp]
+    L.lm_comm_size.argtypes = [vp]
+    L.lm_comm_last_error.argtypes = [vp]
+    L.lm_comm_last_error.restype = C.c_char_p
+    L.lm_gather_rows.argtypes = [vp, C.POINTER(Hsp), C.c_size_t, C.c_int, C.POINTER(C.POINTER(Hsp)), C.POINTER(C.c_size_t)]
     _lib = L
     return L
 
@@ -478,3 +487,59 @@ class Index:
         n = lib().lm_profile_get(self.h, C.byref(p))
         return [dict(name=p[i].name.decode(), launches=p[i].launches, total_ms=p[i].total_ms, bytes=p[i].bytes)
                 for i in range(n)]
+
+
+COMM_ID_BYTES = 128
+
+
+class Comm:
+    """ctypes view of lm_comm (include/lexicmap_hip.h): the RCCL communicator of the sharded search's row gather.
+    Rank 0 calls Comm.unique_id() and hands the 128 bytes to the other ranks by the host's own means (bench.py: a
+    torch.distributed broadcast); every rank then opens Comm(id, nranks, rank, device)."""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        st = lib().lm_comm_unique_id(buf)
+        if st != 0:
+            raise RuntimeError("lm_comm_unique_id failed (%d): %s" % (st, (lib().lm_comm_last_error(None) or b"").decode()))
+        return buf.raw
+
+    def __init__(self, uid, nranks, rank, device=0):
+        self.L = lib()
+        h = C.c_void_p()
+        st = self.L.lm_comm_init(bytes(uid), nranks, rank, device, C.byref(h))
+        if st != 0:
+            raise RuntimeError("lm_comm_init failed (%d): %s" % (st, (self.L.lm_comm_last_error(None) or b"").decode()))
+        self.h = h
+        self.nranks, self.rank = nranks, rank
+
+    def close(self):
+        if self.h:
+            self.L.lm_comm_free(self.h)
+            self.h = None
+
+    def gather_rows(self, arr, root=0):
+        """arr: numpy rows of merge.ROW_DTYPE (this rank's).  -> (list of per-rank row arrays on `root` - views of the
+        communicator's buffer, valid until the next call - or None elsewhere, the per-rank counts)"""
+        import numpy as np
+        from .merge import ROW_DTYPE
+        arr = np.ascontiguousarray(arr, dtype=ROW_DTYPE)
+        allp = C.POINTER(Hsp)()
+        cnt = (C.c_size_t * self.nranks)()
+        st = self.L.lm_gather_rows(self.h, arr.ctypes.data_as(C.POINTER(Hsp)), len(arr), root, C.byref(allp), cnt)
+        if st != 0:
+            raise RuntimeError("lm_gather_rows failed (%d): %s" % (st, (self.L.lm_comm_last_error(self.h) or b"").decode()))
+        counts = [int(x) for x in cnt]
+        if self.rank != root:
+            return None, counts
+        total = sum(counts)
+        if total == 0:
+            return [np.zeros(0, dtype=ROW_DTYPE) for _ in counts], counts
+        buf = (C.c_char * (total * C.sizeof(Hsp))).from_address(C.addressof(allp.contents))
+        allr = np.frombuffer(buf, dtype=ROW_DTYPE)
+        out, o = [], 0
+        for n in counts:
+            out.append(allr[o:o + n])
+            o += n
+        return out, counts

@@ -1319,8 +1319,17 @@ LM_HD uint32_t lm_pa_filter_slot(uint32_t pfx, int log) {
     return (pfx * 0x9E3779B1u) >> (32 - log);
 }
 LM_HD int lm_pa_bloom_log(int log) { return log < LM_PA_BLOOM_LOG_MAX ? log : LM_PA_BLOOM_LOG_MAX; }
+// (a 24-bit multiply: the 11-base prefix has 22 bits, and v_mul_u32_u24 issues at full rate where v_mul_lo_u32 takes four
+// passes - four of them per window position were a fifth of k_pa_filter's vector time)
+LM_HD uint32_t lm_mul24(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);
+#else
+    return (uint32_t)((uint64_t)(a & 0xffffffu) * (uint64_t)(b & 0xffffffu));
+#endif
+}
 LM_HD uint32_t lm_pa_bloom_slot(uint32_t pfx, int which, int blog) {
-    return (pfx * (which ? 0xC2B2AE35u : 0x85EBCA6Bu)) >> (32 - blog);
+    return lm_mul24(pfx, which ? 0xB2AE35u : 0xEBCA6Bu) >> (32 - blog);
 }
 LM_HD uint64_t lm_pa_bits_words(int log) {
     return 2 * ((uint64_t)1 << (log - 5)) + ((uint64_t)1 << (lm_pa_bloom_log(log) - 5)) + ((uint64_t)1 << (LM_PA_MAP9_LOG - 5));

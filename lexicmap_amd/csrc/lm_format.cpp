@@ -527,6 +527,12 @@ std::string load_index_genomes(const std::string &dir, HostIndex &out, int &stat
                 out.others.push_back(std::move(g));
                 continue;
             }
+            if ((int64_t)g.len > out.max_genome_len) {
+                // (the seed packer sized its position field from the .idx tables before this file was read: a record longer
+                // than its index entry says would have its positions packed into too few bits)
+                status = 2;
+                return std::string("genome data: a record of ") + name + " is longer than its genomes.bin.idx entry says";
+            }
             g.bits_off = (int64_t)out.gbits.size();
             out.gbits.insert(out.gbits.end(), gb.begin() + p, gb.begin() + p + nbytes);
             // pad so that 8-byte loads near the end of a genome stay inside the buffer

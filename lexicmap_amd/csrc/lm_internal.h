@@ -361,6 +361,7 @@ extern thread_local std::string g_open_error; // text of the last failed open/bu
 struct lm_index;
 void lm_fill_gap_lut(lm_index *ix);
 void lm_set_scratch_budget(lm_index *ix);
+void lm_reserve_lane_slabs(lm_index *ix);
 
 namespace lm {
 struct Work;
@@ -393,6 +394,7 @@ struct lm_tune {
     int wfa_first_nc[LM_WFA_CLASSES] = {2, 2, 4, 8, 8};
     int wfa_win[LM_WFA_CLASSES] = {0, 0, 1, 0, 1};
     int chain1_wave = 1;     // seed chaining of pairs with many anchors by a wavefront each (LM_CHAIN1_LANES=1: one lane per pair)
+    int pa_filter_roll = 1;  // k_pa_filter: a lane takes consecutive window positions (immediate funnel shifts over its own 64-base string); LM_PA_FILTER_ROLL=0: every 64th position, words passed between lanes
     int pa_seg_by_group = 1; // candidate segments by task group + XCD-local k_pa_search (LM_PA_SEG_BY_WAVE=1: by wavefront)
     int wfa_resident_pct = 100; // LM_WFA_RESIDENT_PCT: share of the CUs' wavefront slots / LDS the persistent WFA kernels take
     FILE *wfa_dump = nullptr; // LM_DEBUG_WFA_DUMP=<file>: one line per WFA problem and pass (width, status, lengths, estimate, score)
@@ -404,6 +406,7 @@ struct lm_tune {
     int wfa_defer = 0;       // LM_WFA_DEFER=1: a round's latency-bound alignments finish beside the next round's first passes (default: every round waits for them)
     int wfa_r16 = 1;         // 16-bit ring cells in the whole-sequence WFA kernels of 128 / 256 diagonals (LM_WFA_R16=0: 32-bit)
     int wfa_lean2 = 1;       // the single-wavefront WFA passes by k_wfa_lean2 (restructured forward pass); LM_WFA_LEAN2=0: k_wfa_lean
+    int wfa_l2_margin = 12;  // LM_WFA_L2_MARGIN (4, 8 or 12): k_wfa_lean2<2, int16_t>'s shrink margin (lm_wfa_lean2_fwd.h)
     int wfa_mw = 1;          // 512 / 1024-diagonal passes by a workgroup of four wavefronts per alignment (LM_WFA_MW=0: one wavefront)
     int pa_chain_pipe = 1;   // the Chainer2 DP of windows with more than pa_pipe_min anchors by a workgroup of pipelined wavefronts (LM_PA_CHAIN_PIPE=0: off)
     int pa_pipe_min = 512;   // LM_PA_PIPE_MIN
@@ -428,6 +431,7 @@ struct lm_tune {
         if (const char *e = getenv("LM_WFA_MW")) wfa_mw = atoi(e) != 0;
         if (const char *e = getenv("LM_WFA_R16")) wfa_r16 = atoi(e) != 0;
         if (const char *e = getenv("LM_WFA_LEAN2")) wfa_lean2 = atoi(e) != 0;
+        if (const char *e = getenv("LM_WFA_L2_MARGIN")) wfa_l2_margin = atoi(e) <= 4 ? 4 : (atoi(e) <= 8 ? 8 : 12);
         if (const char *e = getenv("LM_WFA_DEFER")) wfa_defer = atoi(e) != 0;
         if (const char *e = getenv("LM_LOOKUP_FLAT")) lookup_flat = atoi(e) != 0;
         if (const char *e = getenv("LM_TWO_LANES")) two_lanes = atoi(e) != 0;
@@ -439,6 +443,7 @@ struct lm_tune {
         if (const char *e = getenv("LM_PA_CHAIN_BT_WAVE")) pa_chain_bt_wave = atoi(e) & 3;
         if (getenv("LM_CHAIN1_LANES")) chain1_wave = 0;
         if (const char *e = getenv("LM_PA_SEG_BY_WAVE")) pa_seg_by_group = atoi(e) ? 0 : 1;
+        if (const char *e = getenv("LM_PA_FILTER_ROLL")) pa_filter_roll = atoi(e) != 0;
     }
 };
 

@@ -1034,6 +1034,17 @@ static_assert(PA_WAVES == LM_PA_RANGE_SEGS, "one candidate segment per wavefront
 #define PA_SLICE 1920 /* window positions a wavefront takes at a time: their 2-bit genome words are one 8-byte load per lane */
 #define PA_PEND 128 /* positions a wavefront sets aside for the global bitmap: examined whenever 64 have gathered */
 #define PA_LDS_BYTES ((1 << (LM_PA_BLOOM_LOG_MAX - 3)) + (1 << (LM_PA_MAP9_LOG - 3)) + PA_WAVES * PA_STAGE * 8 + PA_WAVES * PA_PEND * 12)
+// ROLL (K == 31): a lane takes ceil(np / 64) CONSECUTIVE positions of a slice instead of every 64th, so the 32-bit windows
+// that hold the first p bases of a k-mer and of its reverse complement are funnel shifts by IMMEDIATES over the lane's own
+// 64-base string (and its reverse complement, built once per slice) - no cross-lane traffic, no 64-bit shifts, no per-position
+// reverse complement: ~50 vector instructions per position pair where the strided form (ROLL = false, kept for K != 31) has ~100.
+#define PA_SLICE_ROLL 2048 /* 64 lanes x 32 positions */
+// reverse complement of the 16 bases of a dword (first base in the top bits)
+__device__ __forceinline__ uint32_t pa_rc16(uint32_t x) {
+    const uint32_t y = __builtin_bitreverse32(~x);
+    return ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
+}
+template <bool ROLL>
 __global__ __launch_bounds__(PA_THREADS) void k_pa_filter(DevIndexView ix, const Task *__restrict__ tasks, int64_t ntasks,
                                                            const uint8_t *__restrict__ wbuf,
                                                            const int64_t *__restrict__ posoff,
@@ -1173,7 +1184,7 @@ __global__ __launch_bounds__(PA_THREADS) void k_pa_filter(DevIndexView ix, const
                 int acc = 0;
                 for (int j = r0; j < r1; j++) {
                     s_first[j] = acc;
-                    acc += (s_npos[j] + PA_SLICE - 1) / PA_SLICE;
+                    acc += (s_npos[j] + (ROLL ? PA_SLICE_ROLL : PA_SLICE) - 1) / (ROLL ? PA_SLICE_ROLL : PA_SLICE);
                 }
                 s_first[r1] = acc;
                 s_next = 0;
@@ -1196,7 +1207,9 @@ __global__ __launch_bounds__(PA_THREADS) void k_pa_filter(DevIndexView ix, const
                 t.tBegin = s_tb[j];
                 t.wlen = s_wlen[j];
                 const int npos = s_npos[j];
-                const int p0 = (sl - s_first[j]) * PA_SLICE, p1 = p0 + PA_SLICE < npos ? p0 + PA_SLICE : npos;
+                // (ROLL: the slices of a window are equal - 64 lanes x the same number of positions, none nearly empty)
+                const int slice = ROLL ? (npos + (s_first[j + 1] - s_first[j]) - 1) / (s_first[j + 1] - s_first[j]) : PA_SLICE;
+                const int p0 = (sl - s_first[j]) * slice, p1 = p0 + slice < npos ? p0 + slice : npos;
                 const int64_t goff = s_goff[j];
                 const uint8_t *gb = goff >= 0 ? ix.gbits : nullptr;
                 const uint8_t *w = wbuf + s_woff[j];
@@ -1205,7 +1218,90 @@ __global__ __launch_bounds__(PA_THREADS) void k_pa_filter(DevIndexView ix, const
                 const bool use_bits = qbits != nullptr && p >= LM_PFX_BASES && K >= LM_PFX_BASES;
                 const bool fast_pfx = use_bits && gb != nullptr && p <= 15 && K >= 16;
                 const uint64_t rec_t = (uint64_t)(t0g + j) << 32;
-                if (fast_pfx) {
+                if (ROLL && fast_pfx && K == 31 && p1 > p0) {
+                    const int np = p1 - p0;
+                    const int bpl = (np + 63) >> 6;                                          // positions per lane, <= 32
+                    const int g0 = t.rc ? t.tBegin + t.wlen - K - (p1 - 1) : t.tBegin + p0;  // first genome position
+                    const int64_t abs0 = goff * 4 + g0;                                      // in bases from gbits
+                    const int rl0 = bpl * lane;                                              // the lane's first position (genome order)
+                    const int64_t ab = abs0 + (rl0 < np ? rl0 : 0);
+                    // the lane's string: 64 bases from its first position = dwords S0..S3 (first base in the top bits), cut
+                    // out of five consecutive dwords of the 2-bit genome; dwords past the last base the slice needs are not
+                    // read (the store is padded by one 8-byte word only): their bits belong to positions >= np
+                    const uint32_t *gd = (const uint32_t *)gb;
+                    const int64_t d0 = ab >> 4, dlast = (abs0 + np + K - 2) >> 4;
+                    uint32_t e[5];
+#pragma unroll
+                    for (int k = 0; k < 5; k++) e[k] = __builtin_bswap32(gd[d0 + k < dlast ? d0 + k : dlast]);
+                    const int ob = (int)(ab & 15) * 2;
+                    uint32_t S0, S1, S2, S3;
+                    {
+                        const uint64_t q0_ = ((uint64_t)e[0] << 32) | e[1], q1_ = ((uint64_t)e[1] << 32) | e[2];
+                        const uint64_t q2_ = ((uint64_t)e[2] << 32) | e[3], q3_ = ((uint64_t)e[3] << 32) | e[4];
+                        S0 = (uint32_t)(q0_ >> (32 - ob));
+                        S1 = (uint32_t)(q1_ >> (32 - ob));
+                        S2 = (uint32_t)(q2_ >> (32 - ob));
+                        S3 = (uint32_t)(q3_ >> (32 - ob));
+                    }
+                    // its reverse complement: base i of R = the complement of base 63 - i of S.  The reverse-complement k-mer of
+                    // position j (bases [j, j + 31) of S) starts at base 33 - j of R.
+                    uint32_t R0 = pa_rc16(S3), R1 = pa_rc16(S2), R2 = pa_rc16(S1), R3 = pa_rc16(S0);
+                    const int shp = 32 - 2 * p, sha = (p - LM_PFX_BASES) << 1;
+                    const uint32_t m9p = (1u << ((p - 9) << 1)) - 1u;
+                    const uint32_t pcode = (uint32_t)((p - LM_PFX_BASES) >> 1) << 30; // p = 11, 13 or 15
+#pragma unroll 1
+                    for (int half = 0; half < 2; half++) {
+                        // positions 16 * half + jj of the lane: windows over (S0, S1) and (R1, R2, R3) with immediate shifts
+#pragma unroll
+                        for (int jj = 0; jj < 16; jj++) {
+                            if (16 * half + jj >= bpl) break; // (wave-uniform)
+                            const int sh = 2 * jj;            // first p bases of the k-mer: bit offset sh of (S0, S1)
+                            const uint32_t xw = sh ? __builtin_amdgcn_alignbit(S0, S1, 32 - sh) : S0;
+                            const int orc = 66 - 2 * jj;      // ... of its reverse complement: bit offset orc of (R0..R3)
+                            const uint32_t Ra = (orc >> 5) == 2 ? R2 : R1, Rb = (orc >> 5) == 2 ? R3 : R2;
+                            const uint32_t yw = (orc & 31) ? __builtin_amdgcn_alignbit(Ra, Rb, 32 - (orc & 31)) : Ra;
+                            const uint32_t first = xw >> shp, rl = yw >> shp;
+                            const uint32_t pf0 = t.rc ? rl : first, pf1 = t.rc ? first : rl;
+                            const int r = rl0 + 16 * half + jj;           // position of the slice in genome order
+                            const int i = t.rc ? p1 - 1 - r : p0 + r;    // window position
+                            const bool in = r < np;
+                            bool c0, c1;
+                            const uint32_t a0 = pf0 >> sha, a1 = pf1 >> sha;
+                            const uint32_t s00 = lm_pa_bloom_slot(a0, 0, blog), s01 = lm_pa_bloom_slot(a0, 1, blog);
+                            const uint32_t s10 = lm_pa_bloom_slot(a1, 0, blog), s11 = lm_pa_bloom_slot(a1, 1, blog);
+                            const uint32_t b00 = s_bloom[s00 >> 5], b01 = s_bloom[s01 >> 5];
+                            const uint32_t b10 = s_bloom[s10 >> 5], b11 = s_bloom[s11 >> 5];
+                            const bool h0 = in && (((b00 >> (s00 & 31)) & (b01 >> (s01 & 31))) & 1u) != 0;
+                            const bool h1 = in && (((b10 >> (s10 & 31)) & (b11 >> (s11 & 31))) & 1u) != 0;
+                            const bool q0 = in && !h0 && (pf0 & m9p) == 0, q1 = in && !h1 && (pf1 & m9p) == 0;
+                            c0 = h0;
+                            c1 = h1;
+                            if (log > blog) { // long reads: the global 11-base bitmap, 64 pending positions at a time (see below)
+                                c0 = c1 = false;
+                                const uint64_t rec = rec_t | ((uint64_t)(uint32_t)i << 1);
+                                pend(h0 || q0, pf0 | pcode, rec);
+                                pend(h1 || q1, pf1 | pcode, rec | 1ull);
+                            } else if (__ballot(q0 || q1) != 0ull) { // the partial-prefix rule, all in LDS here (rare lanes)
+                                if (q0) c0 = lm_pa_candidate2(s_bloom, blog, s_map9, qbits, log, pf0, p);
+                                if (q1) c1 = lm_pa_candidate2(s_bloom, blog, s_map9, qbits, log, pf1, p);
+                            }
+                            const uint64_t m0 = __ballot(c0), m1 = __ballot(c1);
+                            if ((m0 | m1) != 0ull) {
+                                const int n0 = __popcll(m0);
+                                const uint64_t rec = rec_t | ((uint64_t)(uint32_t)i << 1);
+                                if (c0) stg[n_stg + __popcll(m0 & lt_mask)] = rec;
+                                if (c1) stg[n_stg + n0 + __popcll(m1 & lt_mask)] = rec | 1ull;
+                                n_stg += n0 + __popcll(m1);
+                                if (n_stg > PA_STAGE - 128) flush(); // LDS accesses of one wavefront complete in program order
+                            }
+                        }
+                        S0 = S1; // the second half: the same windows one dword further (and one dword earlier in R)
+                        S1 = S2;
+                        R3 = R2;
+                        R2 = R1;
+                        R1 = R0;
+                    }
+                } else if (fast_pfx) {
                     // prefixes only; the low-complexity filter (which needs the whole k-mer) is applied by k_pa_search.
                     // The 2-bit genome words of the whole slice in ONE load (lane l holds 32 bases: 64 lanes cover the
                     // slice's 1920 positions + K - 1 + the word misalignment); a position takes its two words from the
@@ -1800,6 +1896,10 @@ __global__ __launch_bounds__(64) void k_pa_chain_wave(const uint64_t *__restrict
             atomicAdd(dbg + 1, d_2 - d_1);
             atomicAdd(dbg + 2, d_3 - d_2);
             atomicAdd(dbg + 3, 1ull);
+            const int cls = n <= 8 ? 0 : (n <= 64 ? 1 : (n <= 256 ? 2 : 3)); // by anchors left after clear + trim: windows, anchors, clocks
+            atomicAdd(dbg + 4 + 3 * cls, 1ull);
+            atomicAdd(dbg + 5 + 3 * cls, (unsigned long long)n);
+            atomicAdd(dbg + 6 + 3 * cls, d_3 - d_0);
         }
     }
 }
@@ -2752,13 +2852,14 @@ __global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, i
             ihi[a] = dhi[a] = E_HI;
         }
         if (max_score < 1 || arena_cap < 1) status = 1;
-        if (R16 && (plen > 12000 || tlen > 12000)) status = 3; // (see RT above)
+        const bool r16_too_long = R16 && (plen > 12000 || tlen > 12000); // (see RT above)
+        if (r16_too_long) status = 3;
         mlo[0] = mhi[0] = 0;
         LDS_WAVE_SYNC();
         if (lane == 0) rM[0][koff & (W - 1)] = 0;
         LDS_WAVE_SYNC();
         int s = 0, ms = 0, is = 0; // ring rows of score s
-        int wide_at = 0;           // width that did not fit the ring (status 3), reported in the score field
+        int wide_at = r16_too_long ? W : 0; // width that did not fit the ring (status 3), reported in the score field (never 0 with status 3: a 0 means 'not plain ACGT' to the host)
         int alo = 0;               // first diagonal of the row of score s
         int32_t used = 1;          // backtrace bytes (the slab holds < 2^31); score 0 = one cell that is never read
         if (lane == 0) {
@@ -3228,16 +3329,18 @@ void launch_build_cmp_bits(hipStream_t st, const uint64_t *keys_cmp, const int64
 void launch_pa_filter(hipStream_t st, DevIndexView ix, const Task *tasks, int64_t ntasks, const uint8_t *wbuf,
                       const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_bits, const int64_t *bits_off,
                       const int32_t *bits_log, int K, int min_prefix, unsigned long long *seg_count, int nseg, int64_t seg_cap,
-                      uint64_t *cand, unsigned long long *group_counter, int ncu, int seg_by_group) {
+                      uint64_t *cand, unsigned long long *group_counter, int ncu, int seg_by_group, bool roll) {
     const int64_t ngroups = (ntasks + PA_GROUP - 1) / PA_GROUP;
     int g = (int)(ngroups < 1 ? 1 : (ngroups > ncu ? ncu : ngroups));
     static bool lds_set = false;
     if (!lds_set) {
-        (void)hipFuncSetAttribute((const void *)k_pa_filter, hipFuncAttributeMaxDynamicSharedMemorySize, PA_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)k_pa_filter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PA_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)k_pa_filter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PA_LDS_BYTES);
         lds_set = true;
     }
-    hipLaunchKernelGGL(k_pa_filter, dim3(g), dim3(PA_THREADS), PA_LDS_BYTES, st, ix, tasks, ntasks, wbuf, posoff, nvalid,
-                       cmp_bits, bits_off, bits_log, K, min_prefix, seg_count, nseg, seg_cap, cand, group_counter, seg_by_group);
+    hipLaunchKernelGGL(roll ? k_pa_filter<true> : k_pa_filter<false>, dim3(g), dim3(PA_THREADS), PA_LDS_BYTES, st, ix, tasks, ntasks, wbuf,
+                       posoff, nvalid, cmp_bits, bits_off, bits_log, K, min_prefix, seg_count, nseg, seg_cap, cand, group_counter,
+                       seg_by_group);
 }
 void launch_pa_search(hipStream_t st, DevIndexView ix, const Task *tasks, const uint8_t *wbuf, const uint64_t *keys_cmp,
                       const uint32_t *vals_cmp, const int64_t *posoff, const int32_t *nvalid, const uint32_t *cmp_tab,
@@ -3279,8 +3382,10 @@ void launch_pa_chain(hipStream_t st, const uint64_t *B, const int64_t *pa_off, i
     int32_t *long_tasks = stack + 2 * total + 4 * ntasks + 8;
     unsigned int *nlong = (unsigned int *)(long_tasks + ntasks);
     static const bool pa_dbg = getenv("LM_DEBUG_PA_CHAIN") != nullptr; // phase times of k_pa_chain_wave (stack holds 16 more ints)
-    unsigned long long *dbg = pa_dbg ? (unsigned long long *)(((uintptr_t)(nlong + 2) + 7) & ~(uintptr_t)7) : nullptr;
-    if (dbg) (void)hipMemsetAsync(dbg, 0, 4 * sizeof(unsigned long long), st);
+    static unsigned long long *d_pa_dbg = nullptr; // (its own small buffer: 16 counters)
+    if (pa_dbg && !d_pa_dbg && hipMalloc((void **)&d_pa_dbg, 16 * sizeof(unsigned long long)) != hipSuccess) d_pa_dbg = nullptr;
+    unsigned long long *dbg = pa_dbg ? d_pa_dbg : nullptr;
+    if (dbg) (void)hipMemsetAsync(dbg, 0, 16 * sizeof(unsigned long long), st);
     if (pipe_min > 0) (void)hipMemsetAsync(nlong, 0, sizeof(unsigned int), st);
     hipLaunchKernelGGL(ring ? k_pa_chain_wave<true> : k_pa_chain_wave<false>, dim3(g), dim3(64), 0, st, B, pa_off, ntasks, K, opt, subs, marks, msi, stack, out, out_n,
                        clr_n, qbits, tbits, pipe_min, long_tasks, nlong, bt_wave, dbg);
@@ -3288,13 +3393,15 @@ void launch_pa_chain(hipStream_t st, const uint64_t *B, const int64_t *pa_off, i
         hipLaunchKernelGGL(k_pa_chain_pipe, dim3((unsigned)(ntasks < 1024 ? (ntasks < 1 ? 1 : ntasks) : 1024)), dim3(PCP_NW * 64), 0, st, pa_off, long_tasks,
                            nlong, opt, subs, msi, stack, out, out_n, clr_n, bt_wave & 1);
     if (dbg) {
-        unsigned long long h[4] = {0, 0, 0, 0};
+        unsigned long long h[16] = {0};
         unsigned int nl = 0;
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost);
         (void)hipMemcpy(&nl, nlong, sizeof nl, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[lm] k_pa_chain: %lld windows (%llu finished by the wavefront kernel, %u handed to the workgroup kernel), wavefront-ms: clear+trim %.1f, DP %.1f, backtrack %.1f\n",
-                (long long)ntasks, h[3], pipe_min > 0 ? nl : 0u, (double)h[0] / 1e5, (double)h[1] / 1e5, (double)h[2] / 1e5);
+        fprintf(stderr, "[lm] k_pa_chain: %lld windows (%llu finished by the wavefront kernel, %u handed to the workgroup kernel), wavefront-ms: clear+trim %.1f, DP %.1f, backtrack %.1f; "
+                        "by anchors left {windows, anchors, wavefront-ms}: 2-8 {%llu, %llu, %.1f} 9-64 {%llu, %llu, %.1f} 65-256 {%llu, %llu, %.1f} 257+ {%llu, %llu, %.1f}\n",
+                (long long)ntasks, h[3], pipe_min > 0 ? nl : 0u, (double)h[0] / 1e5, (double)h[1] / 1e5, (double)h[2] / 1e5, h[4], h[5], (double)h[6] / 1e5, h[7], h[8],
+                (double)h[9] / 1e5, h[10], h[11], (double)h[12] / 1e5, h[13], h[14], (double)h[15] / 1e5);
     }
 }
 void launch_gather_chain2(hipStream_t st, const LmChain2 *in, const int64_t *pa_off, const int32_t *out_n,
@@ -3325,7 +3432,11 @@ void launch_extend(hipStream_t st, const HspIn *hsps, int64_t n, const uint8_t *
 typedef void (*WfaLeanFn)(const WfaIn *, int64_t, const int32_t *, int64_t, int32_t *, int64_t, uint8_t *, int64_t, uint64_t *,
                           unsigned int *, int, int, WfaOut *, unsigned long long *);
 // r16: 16-bit ring cells (whole-sequence kernels of 128 / 256 diagonals, sequences up to 12 000 bases: lm_kernels.h)
-static WfaLeanFn wfa_lean2_fn(int nc, bool win, bool r16) { // the restructured forward pass (lm_wfa_lean2.h)
+static WfaLeanFn wfa_lean2_fn(int nc, bool win, bool r16, int margin) { // the restructured forward pass (lm_wfa_lean2.h)
+    // (margin: free slots a 128-diagonal ring keeps on either side of the live rows when it works in ONE chunk of 64 - fewer:
+    // longer in one chunk, more recentres; the dominant instantiation exists for 4, 8 and 12)
+    if (r16 && !win && nc == 2 && margin == 4) return k_wfa_lean2<2, int16_t, false, 4>;
+    if (r16 && !win && nc == 2 && margin == 8) return k_wfa_lean2<2, int16_t, false, 8>;
     if (r16 && !win && nc == 2) return k_wfa_lean2<2, int16_t, false>;
     if (r16 && !win && nc == 4) return k_wfa_lean2<4, int16_t, false>;
     switch (nc) {
@@ -3336,8 +3447,8 @@ static WfaLeanFn wfa_lean2_fn(int nc, bool win, bool r16) { // the restructured 
     default: return win ? k_wfa_lean2<2, int32_t, true> : k_wfa_lean2<2, int32_t, false>;
     }
 }
-static WfaLeanFn wfa_lean_fn(int nc, bool win, bool r16, bool lean2 = false) {
-    if (lean2) return wfa_lean2_fn(nc, win, r16);
+static WfaLeanFn wfa_lean_fn(int nc, bool win, bool r16, int lean2 = 0) { // lean2: 0 = k_wfa_lean, else k_wfa_lean2 with that shrink margin
+    if (lean2) return wfa_lean2_fn(nc, win, r16, lean2);
     if (r16 && !win && nc == 2) return k_wfa_lean<2, false, int16_t>;
     if (r16 && !win && nc == 4) return k_wfa_lean<4, false, int16_t>;
     switch (nc) {
@@ -3352,7 +3463,7 @@ bool wfa_r16_ok(int seq_words, int nc, bool win) { return !win && (nc == 2 || nc
 static size_t wfa_dyn_lds(int seq_words, bool win) { // two packed sequences with one padding word each (+2: the predicated
     return win ? 0 : (size_t)(2 * (seq_words + 2) + 1) * sizeof(uint32_t); // extension may read one word past; k_wfa_lean2: one word in front)
 }
-int wfa_resident_blocks(int device, int seq_words, int nc, bool win, bool r16, bool lean2) {
+int wfa_resident_blocks(int device, int seq_words, int nc, bool win, bool r16, int lean2) {
     int nb = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)wfa_lean_fn(nc, win, r16, lean2), 64, wfa_dyn_lds(seq_words, win)) != hipSuccess || nb < 1)
         nb = 8;
@@ -3361,7 +3472,7 @@ int wfa_resident_blocks(int device, int seq_words, int nc, bool win, bool r16, b
 }
 void launch_wfa(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks,
                 int32_t *hdr_pool, int64_t hdr_stride, uint8_t *arena_pool, int64_t arena_stride, uint64_t *ops_pool,
-                unsigned int *queue, int seq_words, int want_ops, WfaOut *out, int nc, bool win, bool r16, unsigned long long *dbg, bool lean2) {
+                unsigned int *queue, int seq_words, int want_ops, WfaOut *out, int nc, bool win, bool r16, unsigned long long *dbg, int lean2) {
     hipLaunchKernelGGL(wfa_lean_fn(nc, win, r16, lean2), dim3(nblocks), dim3(64), wfa_dyn_lds(seq_words, win), st, in, n, todo, ntodo, hdr_pool,
                        hdr_stride, arena_pool, arena_stride, ops_pool, queue, seq_words, want_ops, out, dbg);
 }

@@ -174,6 +174,17 @@ void lm_set_scratch_budget(lm_index *ix) {
     if (getenv("LM_DEBUG"))
         fprintf(stderr, "[lm] index resident: %.2f GB, device free %.2f of %.2f GB, scratch budget %.2f GB\n",
                 (double)ix->hbm_bytes / 1e9, (double)fr / 1e9, (double)tot / 1e9, (double)ix->scratch_budget / 1e9);
+    // A production-size index cuts its lane slabs NOW, as part of opening it (hipMalloc of ~100 GB clears pages for seconds:
+    // 2.4 s of the first C3 step when it was done there); a small index (tests, stage calls, several shard handles on one
+    // device) leaves it to its first search.
+    if (ix->hbm_bytes >= ((int64_t)4 << 30)) lm_reserve_lane_slabs(ix);
+}
+void lm_reserve_lane_slabs(lm_index *ix) {
+    if (ix->tune.arena_reserve_pct <= 0 || ix->lane_slabs.asked || ix->scratch_budget <= 0) return;
+    const bool ok = ix->lane_slabs.reserve((size_t)(ix->scratch_budget / 100 * ix->tune.arena_reserve_pct));
+    if (getenv("LM_DEBUG") || getenv("LM_DEBUG_MEM"))
+        fprintf(stderr, "[lm] scratch: %d %% of the budget (%.2f GB) cut into two lane slabs: %s\n", ix->tune.arena_reserve_pct,
+                (double)ix->lane_slabs.bytes() / 1e9, ok ? "yes" : "refused (slabs on demand)");
 }
 
 namespace lm {
@@ -1217,8 +1228,18 @@ void lm_tuning_reload(lm_index *ix) {
     lm_tune fresh;
     if (ix->tune.wfa_dump) fclose(ix->tune.wfa_dump);
     if (ix->tune.wfa_waves) fclose(ix->tune.wfa_waves);
+    fresh.wfa_serial = fresh.wfa_serial || ix->tune.wfa_serial;   // (owned by lm_profile_exclusive: a reload does not undo it)
+    fresh.no_pipeline = fresh.no_pipeline || ix->tune.no_pipeline;
     ix->tune = fresh;
+    // every variant starts from the same scratch state: both lanes' buffers go back (the lane slabs stay with the handle)
+    (void)hipDeviceSynchronize();
+    delete ix->work;
+    ix->work = nullptr;
+    delete ix->work1;
+    ix->work1 = nullptr;
     lm_free_align_ctx(ix);
+    ix->arena[0].trim();
+    ix->arena[1].trim();
 }
 void lm_profile_reset(lm_index *ix) {
     prof_resolve(ix);
@@ -1576,7 +1597,7 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
             Prof p(ix, "k_pa_filter", W);
             launch_pa_filter(S(ix), ix->view, tasks_d, nt, a.wb, qb->d_posoff.p, a.w->nvalid.p, a.w->cmp_bits.p,
                              qb->d_bits_off.p, qb->d_bits_log.p, ix->host.k, 11, a.pa_count.p + 2, nseg, seg_cap, a.B1.p,
-                             a.pa_count.p + 1, device_cus(ix->device), by_group ? 1 : 0);
+                             a.pa_count.p + 1, device_cus(ix->device), by_group ? 1 : 0, ix->tune.pa_filter_roll != 0);
         }
         {
             Prof p(ix, "k_pa_search");
@@ -1932,7 +1953,7 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
         const int64_t m = (int64_t)cls[c].size();
         const int64_t smax = std::min<int64_t>(8 * cl[c] + 64, cs[c]);
         const int64_t per = (smax / 2 + 2) * 64 * first_nc[c] + 2 * cl[c] + 4096 + (smax / 2 + 4) * 16;
-        want[c] = m == 0 ? 0 : std::min<int64_t>(m, wfa_resident_blocks(ix->device, cw[c], first_nc[c], win[c], ix->tune.wfa_r16 && wfa_r16_ok(cw[c], first_nc[c], win[c]), ix->tune.wfa_lean2 != 0)) * per * 9 / 8;
+        want[c] = m == 0 ? 0 : std::min<int64_t>(m, wfa_resident_blocks(ix->device, cw[c], first_nc[c], win[c], ix->tune.wfa_r16 && wfa_r16_ok(cw[c], first_nc[c], win[c]), ix->tune.wfa_lean2 ? ix->tune.wfa_l2_margin : 0)) * per * 9 / 8;
         want_tot += want[c];
     }
     for (int c = 0; c < NCH; c++)
@@ -1948,7 +1969,7 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
         // the 512 / 1024-diagonal passes are a handful of long alignments the round waits for: a workgroup of four wavefronts each
         const bool mw = ix->tune.wfa_mw && nc >= 8;
         const bool r16 = !mw && ix->tune.wfa_r16 && wfa_r16_ok(seq_words, nc, use_win); // 16-bit ring cells: more wavefronts per CU
-        const int resident = mw ? wfa_mw_resident_blocks(ix->device, seq_words, nc, use_win, ix->tune.wfa_lean2 != 0) : wfa_resident_blocks(ix->device, seq_words, nc, use_win, r16, ix->tune.wfa_lean2 != 0);
+        const int resident = mw ? wfa_mw_resident_blocks(ix->device, seq_words, nc, use_win, ix->tune.wfa_lean2 != 0) : wfa_resident_blocks(ix->device, seq_words, nc, use_win, r16, ix->tune.wfa_lean2 ? ix->tune.wfa_l2_margin : 0);
         int nblocks = (int)std::min<int64_t>(m, std::max<int64_t>(mw ? 1 : 256, (int64_t)resident * ix->tune.wfa_resident_pct / 100));
         // private scratch per resident wave: one backtrace byte per wavefront cell + 8 bytes per even score; never
         // more than the longest problem of the class is expected to need
@@ -1985,7 +2006,7 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
                               a.ops_pool.p, lc.queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc, use_win, ix->tune.wfa_lean2 != 0);
             else
                 launch_wfa(S(ix), a.wfa_in.p, n, lc.todo.p, m, nblocks, lc.hdr_pool.p, entries * 2, (uint8_t *)lc.arena_pool.p, bytes,
-                           a.ops_pool.p, lc.queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc, use_win, r16, wave_dbg ? lc.dbg.p : nullptr, ix->tune.wfa_lean2 != 0);
+                           a.ops_pool.p, lc.queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc, use_win, r16, wave_dbg ? lc.dbg.p : nullptr, ix->tune.wfa_lean2 ? ix->tune.wfa_l2_margin : 0);
         }
         sync(ix);
         if (wave_dbg) { // where the launch's time went, wavefront by wavefront (100-MHz wall clock)
@@ -3285,12 +3306,7 @@ static void search_parts(lm_index *ix, lm_qbatch *qb, lm_result *res, const Sear
     tls_lane = 0;
     ix->active_lanes = 1;
     ix->budget_lanes = 1;
-    if (ix->tune.arena_reserve_pct > 0 && !ix->lane_slabs.asked && ix->scratch_budget > 0) { // once per handle (LaneSlabs, lm_internal.h)
-        const bool ok = ix->lane_slabs.reserve((size_t)(ix->scratch_budget / 100 * ix->tune.arena_reserve_pct));
-        if (getenv("LM_DEBUG"))
-            fprintf(stderr, "[lm] scratch: %d %% of the budget (%.2f GB) cut into two lane slabs: %s\n", ix->tune.arena_reserve_pct,
-                    (double)ix->lane_slabs.bytes() / 1e9, ok ? "yes" : "refused (slabs on demand)");
-    }
+    lm_reserve_lane_slabs(ix); // once per handle (LaneSlabs, lm_internal.h); a production-size index did it when it was opened
     if (qb->parts.empty()) {
         ix->lane_slabs.assign(ix->arena[0], ix->arena[1], 1); // (false: a block is live - the assignment stays, overflow slabs serve)
         try {

@@ -56,7 +56,7 @@ __device__ __forceinline__ int l2_sflb(unsigned long long m) {
 
 #include "lm_wfa_lean2_fwd.h"
 
-template <int NC, typename RT, bool WIN>
+template <int NC, typename RT, bool WIN, int MARGIN = L2_SHRINK_MARGIN>
 __global__ __launch_bounds__(64) void k_wfa_lean2(const WfaIn *__restrict__ in, int64_t n, const int32_t *__restrict__ todo, int64_t ntodo,
                                                    int32_t *__restrict__ hdr_pool, int64_t hdr_stride, uint8_t *__restrict__ arena_pool,
                                                    int64_t arena_stride, uint64_t *__restrict__ ops_pool, unsigned int *__restrict__ queue,
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64) void k_wfa_lean2(const WfaIn *__restrict__ in, 
             p.arena_cap = (int32_t)(arena_stride - 16); // the window copies of the walk read whole 16-byte chunks
             p.max_score = max_score;
             LDS_WAVE_SYNC();
-            wfa_lean2_forward<NC, RT, WIN>(p, (RT *)ring_raw, Q.buf, T.buf, &r);
+            wfa_lean2_forward<NC, RT, WIN, MARGIN>(p, (RT *)ring_raw, Q.buf, T.buf, &r);
             Q.w0 = r.qw0; // (WIN: bt_replay moves the windows on from where the pass left them)
             T.w0 = r.tw0;
         }

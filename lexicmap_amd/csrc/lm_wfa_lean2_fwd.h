@@ -129,7 +129,7 @@ WR_DEV void l2_win_move2(uint32_t *qbuf, const uint8_t *q, int plen, int *qw0_cu
 #endif
 // qb / tb: word 0 of the 2-bit packed sequences in LDS (one readable word in front, (len + 15) / 16 + 2 words, zero behind the
 // last base); WIN: the two windows instead (L2_WINW + 2 words each, one readable word in front), filled here from p.q / p.t
-template <int NC, typename RT, bool WIN = false>
+template <int NC, typename RT, bool WIN = false, int MARGIN = L2_SHRINK_MARGIN>
 L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint32_t *tb, L2Res *res) {
     static_assert(NC == 1 || NC == 2 || NC == 4 || NC == 8 || NC == 16, "1, 2, 4, 8 or 16 cells per lane");
     static_assert(!(WIN && sizeof(RT) == 2), "16-bit cells: whole sequences of at most 12 000 bases");
@@ -166,7 +166,10 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
     for (int c = 0; c < NC; c++) last_act[c] = -1000;
     last_act[0] = 0;
     if (p.max_score < 1 || p.arena_cap < 1) status = 1;
-    if (R16 && (plen > 12000 || tlen > 12000)) status = 3;
+    if (R16 && (plen > 12000 || tlen > 12000)) {
+        status = 3;
+        wide_at = W; // (never 0 with status 3: a 0 means 'not plain ACGT' to the host)
+    }
     int s = 0;
     // this lane's cell (chunk 0) in the ring rows, by age: pM[a] = M[s-2a] (pM[0] is also where score 0 goes), pI / pD[0] = I / D[s],
     // [1] = I / D[s-2].  Rotated with the scores: five + four cheap register moves per score instead of the index arithmetic,
@@ -319,7 +322,7 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
             // score limit; an empty row (hi < lo); the row outside the frame; scratch; more chunks than the row needs
             uint32_t rare = (EDGE ? 0u : (uint32_t)edge_m) | (uint32_t)(s_lim - 3 - s) | span | (uint32_t)(lo - kbase) | (uint32_t)(kbase + W - 1 - hi) |
                             ((uint32_t)p.arena_cap - (uint32_t)used - span - 1u);
-            if (NC > 1) rare |= (uint32_t)((int)((span + 1 + 2 * L2_SHRINK_MARGIN + 63) >> 6) - (cl - cf + 1)) & ~(uint32_t)(s + 2 - WR_UNIFORM(shrink_from));
+            if (NC > 1) rare |= (uint32_t)((int)((span + 1 + 2 * MARGIN + 63) >> 6) - (cl - cf + 1)) & ~(uint32_t)(s + 2 - WR_UNIFORM(shrink_from));
             if ((int32_t)rare < 0) break;
             // ---- a plain step ----
             s += 2;
@@ -613,7 +616,7 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
                 wide_at = uw;
                 break;
             }
-            int nch = (uw + 2 * L2_SHRINK_MARGIN + 63) >> 6; // chunks the live rows get
+            int nch = (uw + 2 * MARGIN + 63) >> 6; // chunks the live rows get
             nch = nch < NC ? nch : NC;
             const bool out = lo < kbase || hi > kbase + W - 1;
             const int touched = ((uhi - kbase) >> 6) - ((ulo - kbase) >> 6) + 1;

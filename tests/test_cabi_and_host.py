@@ -74,6 +74,13 @@ def test_no_gpu_means_loud_failure_not_fallback(tmp_path):
     assert b"no CPU path" in L.lm_last_error(None)
     with pytest.raises(RuntimeError):
         la.Index.synthetic(4, 1000, 2)
+    # the row gather (RCCL between GPUs) likewise: no device, no communicator
+    buf = C.create_string_buffer(128)
+    assert L.lm_comm_unique_id(buf) == 4
+    hc = C.c_void_p()
+    assert L.lm_comm_init(buf, 1, 0, 0, C.byref(hc)) == 4 and not hc
+    assert b"RCCL" in L.lm_comm_last_error(None)
+    assert L.lm_comm_init(buf, 2, 5, 0, C.byref(hc)) == 7  # LM_ERR_ARG: rank outside the communicator
 
 
 def test_option_defaults_match_reference_flags():

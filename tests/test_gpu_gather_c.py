@@ -1,0 +1,42 @@
+"""lm_gather_rows (include/lexicmap_hip.h): the row gather of the sharded search behind the C-ABI, over RCCL.  One GPU here,
+so the communicator has ONE rank (RCCL refuses two ranks on one device): the count all-gather runs, the root's own rows come
+back in place with the pointer columns cleared, the staging buffers are reused, and the result feeds lm_merge_sharded.  The
+multi-rank transfers are exercised by `bench.py --gpus N` on the driver's multi-GPU node; tests/test_merge_gloo.py covers the
+N > 1 merge logic on the CPU."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_single_rank_communicator_gathers_counts_and_rows_and_feeds_the_c_merge():
+    from lexicmap_amd import merge
+    from lexicmap_amd.api import Comm
+    uid = Comm.unique_id()
+    assert len(uid) == 128
+    comm = Comm(uid, 1, 0, device=0)
+    try:
+        rng = np.random.default_rng(4)
+        rows = np.zeros(5000, dtype=merge.ROW_DTYPE)
+        rows["query"] = np.sort(rng.integers(0, 50, 5000))
+        rows["batch_genome"] = rng.integers(0, 1000, 5000)
+        rows["bitscore"] = rng.integers(50, 3000, 5000)
+        rows["pident"] = rng.integers(70, 101, 5000).astype(np.float64)
+        rows["genome_id"] = 12345  # a process-local address: cleared by the gather
+        expect = rows.copy()
+        expect["genome_id"] = 0
+        for rep in range(2):   # the second call reuses the staging buffers
+            got, counts = comm.gather_rows(rows, root=0)
+            assert counts == [5000] and len(got) == 1
+            assert merge._cat([got[0]]).tobytes() == merge._cat([expect]).tobytes()
+        merged = merge.merge_sharded_c([got[0]])
+        ref = merge.merge_sharded([rows])
+        assert len(merged) == 5000
+        for f in ("query", "batch_genome", "bitscore", "hits"):
+            assert (merged[f] == ref[f]).all()
+        got, counts = comm.gather_rows(rows[:0], root=0)
+        assert counts == [0] and len(got[0]) == 0
+        with pytest.raises(RuntimeError):
+            comm.gather_rows(rows, root=3)   # no such rank: LM_ERR_ARG, nothing hangs
+    finally:
+        comm.close()
