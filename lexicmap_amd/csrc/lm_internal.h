@@ -400,13 +400,12 @@ struct lm_tune {
     FILE *wfa_dump = nullptr; // LM_DEBUG_WFA_DUMP=<file>: one line per WFA problem and pass (width, status, lengths, estimate, score)
     FILE *wfa_waves = nullptr; // LM_DEBUG_WFA_WAVES=<file>: one JSON line per k_wfa_lean launch: when its wavefronts started / ended, busy share
     int wfa_ak_margin = -1;  // LM_WFA_AK_MARGIN: a problem starts at the ring that holds |tlen - qlen| + margin diagonals (-1: at the class's width)
-    int arena_reserve_pct = 80; // LM_ARENA_RESERVE_PCT: share of the scratch budget cut into the two lane slabs at the first search (LaneSlabs; 0: slabs on demand as in round 4)
+    int arena_reserve_pct = 95; // LM_ARENA_RESERVE_PCT: share of the scratch budget cut into the two lane slabs when a production-size index is opened, else at the first search (LaneSlabs; 0: slabs on demand as in round 4)
     int two_lanes = 1;       // two parts of a batch searched side by side, each with half of the scratch budget (LM_TWO_LANES=0: one after the other)
     int lookup_flat = 1;     // anchors emitted with the lanes over the output (k_lookup_emit_flat); LM_LOOKUP_FLAT=0: one lane per lookup
     int wfa_defer = 0;       // LM_WFA_DEFER=1: a round's latency-bound alignments finish beside the next round's first passes (default: every round waits for them)
     int wfa_r16 = 1;         // 16-bit ring cells in the whole-sequence WFA kernels of 128 / 256 diagonals (LM_WFA_R16=0: 32-bit)
     int wfa_lean2 = 1;       // the single-wavefront WFA passes by k_wfa_lean2 (restructured forward pass); LM_WFA_LEAN2=0: k_wfa_lean
-    int wfa_l2_margin = 12;  // LM_WFA_L2_MARGIN (4, 8 or 12): k_wfa_lean2<2, int16_t>'s shrink margin (lm_wfa_lean2_fwd.h)
     int wfa_mw = 1;          // 512 / 1024-diagonal passes by a workgroup of four wavefronts per alignment (LM_WFA_MW=0: one wavefront)
     int pa_chain_pipe = 1;   // the Chainer2 DP of windows with more than pa_pipe_min anchors by a workgroup of pipelined wavefronts (LM_PA_CHAIN_PIPE=0: off)
     int pa_pipe_min = 512;   // LM_PA_PIPE_MIN
@@ -431,11 +430,10 @@ struct lm_tune {
         if (const char *e = getenv("LM_WFA_MW")) wfa_mw = atoi(e) != 0;
         if (const char *e = getenv("LM_WFA_R16")) wfa_r16 = atoi(e) != 0;
         if (const char *e = getenv("LM_WFA_LEAN2")) wfa_lean2 = atoi(e) != 0;
-        if (const char *e = getenv("LM_WFA_L2_MARGIN")) wfa_l2_margin = atoi(e) <= 4 ? 4 : (atoi(e) <= 8 ? 8 : 12);
         if (const char *e = getenv("LM_WFA_DEFER")) wfa_defer = atoi(e) != 0;
         if (const char *e = getenv("LM_LOOKUP_FLAT")) lookup_flat = atoi(e) != 0;
         if (const char *e = getenv("LM_TWO_LANES")) two_lanes = atoi(e) != 0;
-        if (const char *e = getenv("LM_ARENA_RESERVE_PCT")) arena_reserve_pct = std::max(0, std::min(90, atoi(e)));
+        if (const char *e = getenv("LM_ARENA_RESERVE_PCT")) arena_reserve_pct = std::max(0, std::min(100, atoi(e)));
         if (const char *e = getenv("LM_WFA_AK_MARGIN")) wfa_ak_margin = atoi(e);
         if (const char *e = getenv("LM_PA_CHAIN_RING")) pa_chain_ring = atoi(e) != 0;
         if (const char *e = getenv("LM_PA_CHAIN_PIPE")) pa_chain_pipe = atoi(e) != 0;

@@ -3432,11 +3432,9 @@ void launch_extend(hipStream_t st, const HspIn *hsps, int64_t n, const uint8_t *
 typedef void (*WfaLeanFn)(const WfaIn *, int64_t, const int32_t *, int64_t, int32_t *, int64_t, uint8_t *, int64_t, uint64_t *,
                           unsigned int *, int, int, WfaOut *, unsigned long long *);
 // r16: 16-bit ring cells (whole-sequence kernels of 128 / 256 diagonals, sequences up to 12 000 bases: lm_kernels.h)
-static WfaLeanFn wfa_lean2_fn(int nc, bool win, bool r16, int margin) { // the restructured forward pass (lm_wfa_lean2.h)
-    // (margin: free slots a 128-diagonal ring keeps on either side of the live rows when it works in ONE chunk of 64 - fewer:
-    // longer in one chunk, more recentres; the dominant instantiation exists for 4, 8 and 12)
-    if (r16 && !win && nc == 2 && margin == 4) return k_wfa_lean2<2, int16_t, false, 4>;
-    if (r16 && !win && nc == 2 && margin == 8) return k_wfa_lean2<2, int16_t, false, 8>;
+static WfaLeanFn wfa_lean2_fn(int nc, bool win, bool r16) { // the restructured forward pass (lm_wfa_lean2.h)
+    // (shrink margins 4 and 8 of the dominant instantiation - longer in ONE chunk of 64 slots, more recentres - were measured
+    // on one resident C3 index against the 12 it has: 9.67 / 9.80 s against 9.69 s per step, no difference; removed)
     if (r16 && !win && nc == 2) return k_wfa_lean2<2, int16_t, false>;
     if (r16 && !win && nc == 4) return k_wfa_lean2<4, int16_t, false>;
     switch (nc) {
@@ -3447,8 +3445,8 @@ static WfaLeanFn wfa_lean2_fn(int nc, bool win, bool r16, int margin) { // the r
     default: return win ? k_wfa_lean2<2, int32_t, true> : k_wfa_lean2<2, int32_t, false>;
     }
 }
-static WfaLeanFn wfa_lean_fn(int nc, bool win, bool r16, int lean2 = 0) { // lean2: 0 = k_wfa_lean, else k_wfa_lean2 with that shrink margin
-    if (lean2) return wfa_lean2_fn(nc, win, r16, lean2);
+static WfaLeanFn wfa_lean_fn(int nc, bool win, bool r16, bool lean2 = false) {
+    if (lean2) return wfa_lean2_fn(nc, win, r16);
     if (r16 && !win && nc == 2) return k_wfa_lean<2, false, int16_t>;
     if (r16 && !win && nc == 4) return k_wfa_lean<4, false, int16_t>;
     switch (nc) {
@@ -3463,7 +3461,7 @@ bool wfa_r16_ok(int seq_words, int nc, bool win) { return !win && (nc == 2 || nc
 static size_t wfa_dyn_lds(int seq_words, bool win) { // two packed sequences with one padding word each (+2: the predicated
     return win ? 0 : (size_t)(2 * (seq_words + 2) + 1) * sizeof(uint32_t); // extension may read one word past; k_wfa_lean2: one word in front)
 }
-int wfa_resident_blocks(int device, int seq_words, int nc, bool win, bool r16, int lean2) {
+int wfa_resident_blocks(int device, int seq_words, int nc, bool win, bool r16, bool lean2) {
     int nb = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)wfa_lean_fn(nc, win, r16, lean2), 64, wfa_dyn_lds(seq_words, win)) != hipSuccess || nb < 1)
         nb = 8;
@@ -3472,7 +3470,7 @@ int wfa_resident_blocks(int device, int seq_words, int nc, bool win, bool r16, i
 }
 void launch_wfa(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks,
                 int32_t *hdr_pool, int64_t hdr_stride, uint8_t *arena_pool, int64_t arena_stride, uint64_t *ops_pool,
-                unsigned int *queue, int seq_words, int want_ops, WfaOut *out, int nc, bool win, bool r16, unsigned long long *dbg, int lean2) {
+                unsigned int *queue, int seq_words, int want_ops, WfaOut *out, int nc, bool win, bool r16, unsigned long long *dbg, bool lean2) {
     hipLaunchKernelGGL(wfa_lean_fn(nc, win, r16, lean2), dim3(nblocks), dim3(64), wfa_dyn_lds(seq_words, win), st, in, n, todo, ntodo, hdr_pool,
                        hdr_stride, arena_pool, arena_stride, ops_pool, queue, seq_words, want_ops, out, dbg);
 }

@@ -1062,33 +1062,73 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
                 sl->c.min_file_bytes = (size_t)biggest;
                 sl->c.min_seeds = (size_t)biggest / 7 + 1;
             }
+            // Decoded seeds that stay on the device between the two passes: a file whose (k-mer, value, mask) arrays - 18 bytes
+            // per seed this shard keeps - fit beside what is still to be allocated (the packed image, the genomes) is decoded and
+            // uploaded ONCE; its second pass reads the device copy.  A shard keeps 1 / N of the seeds: all of its files stay.
+            struct Kept {
+                DBuf<uint64_t> k, v;
+                DBuf<uint16_t> m;
+                int64_t n = 0;
+            };
+            std::vector<std::unique_ptr<Kept>> kept(nf);
+            int64_t keep_budget = 0, kept_bytes = 0, files_bytes = 0;
+            {
+                for (auto &f : h.seed_files) {
+                    struct stat sb;
+                    if (stat(f.c_str(), &sb) == 0) files_bytes += (int64_t)sb.st_size;
+                }
+                size_t fr = 0, tot = 0;
+                if (hipMemGetInfo(&fr, &tot) == hipSuccess) // (image: <= ~0.55 bytes per file byte measured; 0.75 reserved)
+                    keep_budget = (int64_t)fr - files_bytes * 3 / 4 / (int64_t)std::max(1, h.shard_count) - (int64_t)h.gbits_bound - ((int64_t)6 << 30);
+                if (getenv("LM_LOADER_NO_KEEP")) keep_budget = 0;
+            }
+            int64_t n_kept_files = 0;
             for (int pass = 0; pass < 2; pass++) {
                 // declaration order matters: `fut` is destroyed FIRST when an exception unwinds this scope (a failed upload,
                 // DeviceOOM) and a std::async future joins its task in its destructor - so the decode tasks still running
                 // have finished before the slots and status entries they write into are freed
+                std::vector<size_t> files; // the files this pass decodes (pass 1: those without a device copy)
+                for (size_t i = 0; i < nf; i++)
+                    if (!kept[i]) files.push_back(i);
+                const size_t nd = files.size();
                 std::vector<int> stat(nf, 0), anch(nf, -1);
-                std::vector<std::future<std::string>> fut(nf);
-                auto launch = [&](size_t i) {
-                    fut[i] = std::async(std::launch::async, [&, i]() {
-                        return decode_seed_chunk(h.seed_files[i], h, slot[i % nslots]->c, stat[i], anch[i]);
+                std::vector<std::future<std::string>> fut(nd);
+                auto launch = [&](size_t pos) {
+                    const size_t i = files[pos];
+                    fut[pos] = std::async(std::launch::async, [&, i, pos]() {
+                        return decode_seed_chunk(h.seed_files[i], h, slot[pos % nslots]->c, stat[i], anch[i]);
                     });
                 };
-                for (size_t i = 0; i < std::min(nslots, nf); i++) launch(i);
-                for (size_t i = 0; i < nf; i++) {
+                for (size_t pos = 0; pos < std::min(nslots, nd); pos++) launch(pos);
+                if (pass == 1) { // the files with a device copy, beside the decoders of the others
+                    const double tk0 = now_ms();
+                    for (size_t i = 0; i < nf; i++) {
+                        if (!kept[i]) continue;
+                        Kept &kp = *kept[i];
+                        const int64_t slice = (int64_t)32 << 20;
+                        for (int64_t o = 0; o < kp.n; o += slice) sp.place(kp.m.p + o, kp.k.p + o, kp.v.p + o, std::min(slice, kp.n - o));
+                        sync(ix);
+                        kept[i].reset(); // (its memory goes back before the partitions are sorted)
+                    }
+                    t_pack += now_ms() - tk0;
+                }
+                for (size_t pos = 0; pos < nd; pos++) {
+                    const size_t i = files[pos];
                     const double tw0 = now_ms();
-                    const std::string e2 = fut[i].get();
+                    const std::string e2 = fut[pos].get();
                     t_wait += now_ms() - tw0;
                     if (!e2.empty()) {
-                        for (size_t j = i + 1; j < nf; j++)
+                        for (size_t j = pos + 1; j < nd; j++)
                             if (fut[j].valid()) fut[j].wait();
                         g_open_error = e2;
                         const int stt = stat[i];
+                        kept.clear();
                         slot.clear(); // (before the handle and its device context go)
                         gfut.wait();  // (the genome reader writes into the handle)
                         lm_index_close(ix);
                         return stt == 2 ? LM_ERR_FORMAT : LM_ERR_IO;
                     }
-                    Slot &sl = *slot[i % nslots];
+                    Slot &sl = *slot[pos % nslots];
                     const double tp0 = now_ms();
                     if (pin) sl.pin();
                     t_pin += now_ms() - tp0;
@@ -1096,25 +1136,57 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
                     SeedChunk &c = sl.c;
                     const int64_t cnt = (int64_t)c.n;
                     const int64_t slice = (int64_t)32 << 20;
+                    Kept *kp = nullptr;
+                    if (pass == 0 && cnt > 0 && kept_bytes + cnt * 18 <= keep_budget) {
+                        std::unique_ptr<Kept> nk(new Kept());
+                        try {
+                            nk->k.alloc_exact((size_t)cnt);
+                            nk->v.alloc_exact((size_t)cnt);
+                            nk->m.alloc_exact((size_t)cnt);
+                            nk->n = cnt;
+                            kept[i] = std::move(nk);
+                            kp = kept[i].get();
+                            kept_bytes += cnt * 18;
+                            n_kept_files++;
+                        } catch (const std::exception &) { // the device said no: this file (and the rest) are decoded twice
+                            (void)hipGetLastError();
+                            keep_budget = 0;
+                        }
+                    }
                     for (int64_t o = 0; o < cnt; o += slice) {
                         const int64_t m = std::min(slice, cnt - o);
-                        dk.ensure((size_t)m);
-                        dv.ensure((size_t)m);
-                        dm.ensure((size_t)m);
-                        HIPCHK(hipMemcpyAsync(dk.p, c.kmers.data() + o, (size_t)m * 8, hipMemcpyHostToDevice, S(ix)));
-                        HIPCHK(hipMemcpyAsync(dv.p, c.vals.data() + o, (size_t)m * 8, hipMemcpyHostToDevice, S(ix)));
-                        HIPCHK(hipMemcpyAsync(dm.p, c.masks.data() + o, (size_t)m * 2, hipMemcpyHostToDevice, S(ix)));
+                        uint64_t *pk, *pv;
+                        uint16_t *pm;
+                        if (kp) {
+                            pk = kp->k.p + o;
+                            pv = kp->v.p + o;
+                            pm = kp->m.p + o;
+                        } else {
+                            dk.ensure((size_t)m);
+                            dv.ensure((size_t)m);
+                            dm.ensure((size_t)m);
+                            pk = dk.p;
+                            pv = dv.p;
+                            pm = dm.p;
+                        }
+                        HIPCHK(hipMemcpyAsync(pk, c.kmers.data() + o, (size_t)m * 8, hipMemcpyHostToDevice, S(ix)));
+                        HIPCHK(hipMemcpyAsync(pv, c.vals.data() + o, (size_t)m * 8, hipMemcpyHostToDevice, S(ix)));
+                        HIPCHK(hipMemcpyAsync(pm, c.masks.data() + o, (size_t)m * 2, hipMemcpyHostToDevice, S(ix)));
                         if (pass == 0)
-                            sp.count(dm.p, dk.p, dv.p, m);
+                            sp.count(pm, pk, pv, m);
                         else
-                            sp.place(dm.p, dk.p, dv.p, m);
-                        sync(ix); // the staging buffers are reused
+                            sp.place(pm, pk, pv, m);
+                        if (!kp) sync(ix); // the staging buffers are reused
                     }
+                    sync(ix); // (the slot's host arrays are decoded into again)
                     t_pack += now_ms() - tk0;
-                    if (i + nslots < nf) launch(i + nslots); // this slot's next file
+                    if (pos + nslots < nd) launch(pos + nslots); // this slot's next file
                 }
                 if (pass == 0) sp.end_count();
             }
+            if (ldbg)
+                fprintf(stderr, "[lm] loader: %lld of %zu chunk files kept on the device between the passes (%.2f GB of decoded seeds; budget %.2f GB)\n",
+                        (long long)n_kept_files, nf, (double)kept_bytes / 1e9, (double)keep_budget / 1e9);
             const double tf0 = now_ms();
             sp.finish();
             if (ldbg)
@@ -1953,7 +2025,7 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
         const int64_t m = (int64_t)cls[c].size();
         const int64_t smax = std::min<int64_t>(8 * cl[c] + 64, cs[c]);
         const int64_t per = (smax / 2 + 2) * 64 * first_nc[c] + 2 * cl[c] + 4096 + (smax / 2 + 4) * 16;
-        want[c] = m == 0 ? 0 : std::min<int64_t>(m, wfa_resident_blocks(ix->device, cw[c], first_nc[c], win[c], ix->tune.wfa_r16 && wfa_r16_ok(cw[c], first_nc[c], win[c]), ix->tune.wfa_lean2 ? ix->tune.wfa_l2_margin : 0)) * per * 9 / 8;
+        want[c] = m == 0 ? 0 : std::min<int64_t>(m, wfa_resident_blocks(ix->device, cw[c], first_nc[c], win[c], ix->tune.wfa_r16 && wfa_r16_ok(cw[c], first_nc[c], win[c]), ix->tune.wfa_lean2 != 0)) * per * 9 / 8;
         want_tot += want[c];
     }
     for (int c = 0; c < NCH; c++)
@@ -1969,7 +2041,7 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
         // the 512 / 1024-diagonal passes are a handful of long alignments the round waits for: a workgroup of four wavefronts each
         const bool mw = ix->tune.wfa_mw && nc >= 8;
         const bool r16 = !mw && ix->tune.wfa_r16 && wfa_r16_ok(seq_words, nc, use_win); // 16-bit ring cells: more wavefronts per CU
-        const int resident = mw ? wfa_mw_resident_blocks(ix->device, seq_words, nc, use_win, ix->tune.wfa_lean2 != 0) : wfa_resident_blocks(ix->device, seq_words, nc, use_win, r16, ix->tune.wfa_lean2 ? ix->tune.wfa_l2_margin : 0);
+        const int resident = mw ? wfa_mw_resident_blocks(ix->device, seq_words, nc, use_win, ix->tune.wfa_lean2 != 0) : wfa_resident_blocks(ix->device, seq_words, nc, use_win, r16, ix->tune.wfa_lean2 != 0);
         int nblocks = (int)std::min<int64_t>(m, std::max<int64_t>(mw ? 1 : 256, (int64_t)resident * ix->tune.wfa_resident_pct / 100));
         // private scratch per resident wave: one backtrace byte per wavefront cell + 8 bytes per even score; never
         // more than the longest problem of the class is expected to need
@@ -2006,7 +2078,7 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
                               a.ops_pool.p, lc.queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc, use_win, ix->tune.wfa_lean2 != 0);
             else
                 launch_wfa(S(ix), a.wfa_in.p, n, lc.todo.p, m, nblocks, lc.hdr_pool.p, entries * 2, (uint8_t *)lc.arena_pool.p, bytes,
-                           a.ops_pool.p, lc.queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc, use_win, r16, wave_dbg ? lc.dbg.p : nullptr, ix->tune.wfa_lean2 ? ix->tune.wfa_l2_margin : 0);
+                           a.ops_pool.p, lc.queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc, use_win, r16, wave_dbg ? lc.dbg.p : nullptr, ix->tune.wfa_lean2 != 0);
         }
         sync(ix);
         if (wave_dbg) { // where the launch's time went, wavefront by wavefront (100-MHz wall clock)
@@ -3383,8 +3455,10 @@ static void search_parts(lm_index *ix, lm_qbatch *qb, lm_result *res, const Sear
                     search_impl(ix, it->part, &it->res, ctl);
                 } catch (const PartTooLarge &) {
                     split = true;
+                    if (getenv("LM_DEBUG_MEM")) fprintf(stderr, "[lm] lane %d: a part of %d queries is halved: its seed anchors exceed the lane's share of the budget\n", lane, it->part->nq);
                 } catch (const DeviceOOM &e) {
                     if (it->part->nq < 2) throw;
+                    if (getenv("LM_DEBUG_MEM")) fprintf(stderr, "[lm] lane %d: a part of %d queries is halved after: %s\n", lane, it->part->nq, e.what());
                     drop_scratch(ix, e.what());
                     split = true;
                 }

@@ -79,8 +79,6 @@ static long run1(const uint8_t *q, int qlen, const uint8_t *t, int tlen, int max
     return ncoll;
 }
 
-static int g_margin = L2_SHRINK_MARGIN; // the shrink margin of the <2, int16_t> instantiation (the product has 4, 8 and 12)
-extern "C" void l2_emu_set_margin(int m) { g_margin = m; }
 extern "C" long l2_emu_run(int nc, int r16, int win, const uint8_t *q, int qlen, const uint8_t *t, int tlen, int max_score, int arena_cap,
                            uint64_t *ops, int ops_cap, WrEmuOut *out, int *recentres) {
     if (win) switch (nc) {
@@ -90,8 +88,6 @@ extern "C" long l2_emu_run(int nc, int r16, int win, const uint8_t *q, int qlen,
         case 8: return run1<8, int32_t, true>(q, qlen, t, tlen, max_score, arena_cap, ops, ops_cap, out, recentres);
         default: return -1;
         }
-    if (nc == 2 && r16 && g_margin == 4) return run1<2, int16_t, false, 4>(q, qlen, t, tlen, max_score, arena_cap, ops, ops_cap, out, recentres);
-    if (nc == 2 && r16 && g_margin == 8) return run1<2, int16_t, false, 8>(q, qlen, t, tlen, max_score, arena_cap, ops, ops_cap, out, recentres);
     switch (nc * 2 + (r16 ? 1 : 0)) {
     case 2: return run1<1, int32_t>(q, qlen, t, tlen, max_score, arena_cap, ops, ops_cap, out, recentres);
     case 3: return run1<1, int16_t>(q, qlen, t, tlen, max_score, arena_cap, ops, ops_cap, out, recentres);

@@ -193,27 +193,3 @@ def test_the_first_touch_of_a_sequence_end_is_the_end():
         exp = run_oracle_wfa(q, t)
         for nc, r16, win in ((1, False, False), (2, True, False), (2, False, True), (4, True, False)):
             assert run1(q, t, nc, r16, win=win)[:2] == (0, exp)
-
-
-@pytest.mark.parametrize("margin", [4, 8])
-def test_the_other_shrink_margins_of_the_dominant_instantiation_equal_the_oracle(margin):
-    """k_wfa_lean2<2, int16_t, false, MARGIN> exists for MARGIN 4, 8 and 12 (LM_WFA_L2_MARGIN): a smaller margin keeps the
-    128-diagonal ring in ONE chunk for wider live rows and recentres more often - same alignments"""
-    rng = random.Random(40 + margin)
-    lib().l2_emu_set_margin(margin)
-    try:
-        nrec = 0
-        for n, div in ((900, 0.05), (1500, 0.10), (1800, 0.14), (1200, 0.08)):
-            q = rand_seq(rng, n)
-            t = mutate(rng, q, div, div / 4, div / 3)   # more deletions than insertions: the wavefront drifts
-            exp = run_oracle_wfa(q, t)
-            st, got, rec = run1(q, t, 2, True)
-            nrec += rec
-            if st == 3:
-                lib().l2_emu_set_margin(12)
-                st, got, _ = run1(q, t, 4, True)
-                lib().l2_emu_set_margin(margin)
-            assert st == 0 and got == exp
-        assert nrec > 0
-    finally:
-        lib().l2_emu_set_margin(12)
