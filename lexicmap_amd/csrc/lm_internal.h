@@ -405,7 +405,6 @@ struct lm_tune {
     int lookup_flat = 1;     // anchors emitted with the lanes over the output (k_lookup_emit_flat); LM_LOOKUP_FLAT=0: one lane per lookup
     int wfa_defer = 0;       // LM_WFA_DEFER=1: a round's latency-bound alignments finish beside the next round's first passes (default: every round waits for them)
     int wfa_r16 = 1;         // 16-bit ring cells in the whole-sequence WFA kernels of 128 / 256 diagonals (LM_WFA_R16=0: 32-bit)
-    int wfa_lean2 = 1;       // the single-wavefront WFA passes by k_wfa_lean2 (restructured forward pass); LM_WFA_LEAN2=0: k_wfa_lean
     int wfa_mw = 1;          // 512 / 1024-diagonal passes by a workgroup of four wavefronts per alignment (LM_WFA_MW=0: one wavefront)
     int pa_chain_pipe = 1;   // the Chainer2 DP of windows with more than pa_pipe_min anchors by a workgroup of pipelined wavefronts (LM_PA_CHAIN_PIPE=0: off)
     int pa_pipe_min = 512;   // LM_PA_PIPE_MIN
@@ -429,7 +428,6 @@ struct lm_tune {
         no_pipeline = getenv("LM_NO_PIPELINE") != nullptr;
         if (const char *e = getenv("LM_WFA_MW")) wfa_mw = atoi(e) != 0;
         if (const char *e = getenv("LM_WFA_R16")) wfa_r16 = atoi(e) != 0;
-        if (const char *e = getenv("LM_WFA_LEAN2")) wfa_lean2 = atoi(e) != 0;
         if (const char *e = getenv("LM_WFA_DEFER")) wfa_defer = atoi(e) != 0;
         if (const char *e = getenv("LM_LOOKUP_FLAT")) lookup_flat = atoi(e) != 0;
         if (const char *e = getenv("LM_TWO_LANES")) two_lanes = atoi(e) != 0;

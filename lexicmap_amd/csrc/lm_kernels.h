@@ -141,19 +141,20 @@ void launch_extend(hipStream_t st, const HspIn *hsps, int64_t n, const uint8_t *
                    const uint8_t *wbuf, const int32_t *cap, const int64_t *woff, uint16_t *subs, int32_t *msi,
                    void *rows_pool, uint32_t *rstart_pool, HspExt *out);
 // k_wfa_lean<nc>: persistent wavefronts with private scratch, <= 64 nc - 2 diagonals (status 3 beyond); nc = 2, 4, 8 or 16
-int wfa_resident_blocks(int device, int seq_words, int nc, bool win, bool r16 = false, bool lean2 = false);
+int wfa_resident_blocks(int device, int seq_words, int nc, bool win, bool r16 = false);
 // 16-bit ring cells (half the LDS per wavefront): whole-sequence kernels of 128 / 256 diagonals, sequences <= 12 000 bases
 bool wfa_r16_ok(int seq_words, int nc, bool win);
 void launch_wfa(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks,
                 int32_t *hdr_pool, int64_t hdr_stride, uint8_t *arena_pool, int64_t arena_stride, uint64_t *ops_pool,
                 unsigned int *queue, int seq_words, int want_ops, WfaOut *out, int nc, bool win, bool r16 = false,
-                unsigned long long *dbg = nullptr, bool lean2 = false); // dbg: 6 words per workgroup (LM_DEBUG_WFA_WAVES); lean2: k_wfa_lean2
+                unsigned long long *dbg = nullptr); // dbg: 6 words per workgroup (LM_DEBUG_WFA_WAVES); lean2: k_wfa_lean2
 
 // k_wfa_mw<nc / 4, win>: the same passes for nc = 8 / 16 by a workgroup of four wavefronts per alignment
-int wfa_mw_resident_blocks(int device, int seq_words, int nc, bool win, bool lean2 = false);
+int wfa_mw_resident_blocks(int device, int seq_words, int nc, bool win);
+void launch_set_occ8(bool on); // LM_OCC8 (default on): k_wfa_lean2<2, int16_t> and k_pa_chain_wave held to 64 VGPRs = 8 wavefronts per SIMD
 void launch_wfa_mw(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks, int32_t *hdr_pool,
                    int64_t hdr_stride, uint8_t *arena_pool, int64_t arena_stride, uint64_t *ops_pool, unsigned int *queue, int seq_words,
-                   int want_ops, WfaOut *out, int nc, bool win, bool lean2 = false);
+                   int want_ops, WfaOut *out, int nc, bool win);
 
 // wavefronts wider than the LDS ring (status 3 from launch_wfa): same algorithm with the ring in global memory
 void launch_wfa_wide(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int32_t *hdr_pool,

@@ -1703,8 +1703,8 @@ __device__ int lm_chain2_backtrack(const LmSub *a_, int n, const LmChain2Opt &op
 
 // RING: the DP keeps the recent anchors and scores in an LDS ring (lm_pa_chain_dp_core.h); otherwise every step goes
 // through global memory (kept for comparison: LM_PA_CHAIN_RING=0)
-template <bool RING>
-__global__ __launch_bounds__(64) void k_pa_chain_wave(const uint64_t *__restrict__ B, const int64_t *__restrict__ pa_off,
+template <bool RING, int WPE = 1> // (WPE: wavefronts per SIMD the register allocation is held to)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void k_pa_chain_wave(const uint64_t *__restrict__ B, const int64_t *__restrict__ pa_off,
                                                        int64_t ntasks, int K, LmChain2Opt opt, LmSub *__restrict__ subs_pool,
                                                        uint8_t *__restrict__ marks_pool, uint64_t *__restrict__ msi_pool,
                                                        int32_t *__restrict__ stack_pool, LmChain2 *__restrict__ out_pool,
@@ -2719,510 +2719,20 @@ __device__ __forceinline__ void bt_replay(const uint8_t *__restrict__ opseq, int
     }
 }
 
-// ---- k_wfa_lean<NC>: the LDS wavefront kernel ------------------------------------------------------------------------
-// NC cells per lane (W = 64*NC diagonals): the cell of diagonal k of every ring row lives at LDS slot (k mod W), cells
-// outside a row's valid range hold LM_NULL_OFF, so the recurrence reads its five neighbours without range tests as long
-// as a wavefront is at most W-2 diagonals wide (wider ones return status 3: NC=1 -> NC=2 -> k_wfa_wave). The valid
-// ranges of the last 9 (M) / 3 (I, D) scores are wave-uniform scalars kept in registers and rotated every score;
-// trimming and the wf-adaptive cut-off are DPP reductions of packed (first, last) positions (the scalar unit, which all
-// resident wavefronts of a CU share, has little else to do than the loop control). No global loads inside the score loop: both sequences are 2-bit
-// packed in LDS. Persistent wavefronts: each workgroup (one wave) owns a private header/arena region and pops problems
-// from a queue ordered by decreasing expected cost. Results are identical to lm_wfa_align.
-template <int NC, bool WIN, typename RT>
-__global__ __launch_bounds__(64) void k_wfa_lean(const WfaIn *__restrict__ in, int64_t n, const int32_t *__restrict__ todo,
-                                                  int64_t ntodo, int32_t *__restrict__ hdr_pool, int64_t hdr_stride,
-                                                  uint8_t *__restrict__ arena_pool, int64_t arena_stride,
-                                                  uint64_t *__restrict__ ops_pool, unsigned int *__restrict__ queue,
-                                                  int seq_words, int want_ops, WfaOut *__restrict__ out,
-                                                  unsigned long long *__restrict__ dbg) {
-    static_assert(NC == 1 || NC == 2 || NC == 4 || NC == 8 || NC == 16, "1, 2, 4, 8 or 16 cells per lane");
-    constexpr int W = 64 * NC;
-    // All penalties are even (x=4, o+e=8, e=2): only even scores have wavefronts, so the ring holds the last five even
-    // M scores (s, s-2, .. s-8) and the last two I / D scores, and the score loop steps by 2. (Odd scores are empty
-    // wavefronts in the reference and the backtrace never visits them.)
-    // ring of wavefront rows; the backtrace walk reuses the same LDS (the ring is dead by then) for its row window
-    // RT = int16_t: the ring holds 16-bit offsets - half the LDS per wavefront, and LDS is what bounds the number of resident
-    // wavefronts of the short classes (<= 8 kb: 18 -> 24 per CU) whose dependent LDS / DPP chains need them to fill the
-    // issue slots.  Valid offsets are <= tlen; the invalid ones inside a range are RNULL + j or tlen + 1 + j with j <= s / 2
-    // (an I cell grows by one per score step: I[s][k] = max(M[s-8][k-1], I[s-2][k-1]) + 1; M cells are sanitised, D cells do
-    // not grow), so with tlen <= 12000 and s < 24000 (checked below: beyond, status 3 hands the problem to the 32-bit pass)
-    // nothing wraps, every comparison has the outcome it has with 32-bit cells, and the backtrace bytes are the same.
-    constexpr bool R16 = sizeof(RT) == 2;
-    static_assert(!R16 || (NC <= 4 && !WIN), "16-bit ring: whole-sequence kernels up to 256 diagonals");
-    constexpr int RNULL = R16 ? -16384 : LM_NULL_OFF;
-    constexpr int RING_CELLS = 9 * W * (int)sizeof(RT);
-    constexpr int BW = RING_CELLS >= (int)sizeof(BtLds) ? BT_WIN : ((RING_CELLS - 512 - 32) & ~15);
-    static_assert(BW >= 2 * W, "the walk's window holds at least two rows");
-    constexpr int RING_BYTES = RING_CELLS > (int)sizeof(BtLdsT<BW>) ? RING_CELLS : (int)sizeof(BtLdsT<BW>);
-    __shared__ __attribute__((aligned(16))) uint8_t ring_raw[RING_BYTES];
-    RT(*rM)[W] = (RT(*)[W])ring_raw;
-    RT(*rI)[W] = (RT(*)[W])(ring_raw + 5 * W * sizeof(RT));
-    RT(*rD)[W] = (RT(*)[W])(ring_raw + 7 * W * sizeof(RT));
-    BtLdsT<BW> &btl = *(BtLdsT<BW> *)ring_raw;
-    __shared__ unsigned int sh_x;
-    // WIN: the two sequence windows; otherwise both whole packed sequences in dynamic LDS (seq_words + 1 words each)
-    __shared__ uint32_t qwin_buf[WIN ? WFA_WINW + 2 : 1], twin_buf[WIN ? WFA_WINW + 2 : 1];
-    extern __shared__ uint32_t seq_lds[];
-    const int lane = threadIdx.x;
-    // per resident wavefront: {first diagonal, row offset} per even score, and the backtrace bytes (one per cell)
-    int32_t *hdr2 = hdr_pool + (int64_t)blockIdx.x * hdr_stride;
-    uint8_t *bt = arena_pool + (int64_t)blockIdx.x * arena_stride;
-    const int64_t arena_cap = arena_stride - 16; // the window copies of the walk read whole 16-byte chunks
-    const int max_score = (int)(hdr_stride / 2 - 2) * 2;
-    // Work queue: lane 0 pops the next problem at the END of the loop body (inside the block that writes the result)
-    // and the index travels through LDS. Keeping lane-conditional code away from the loop header matters: with the pop
-    // at the top the compiler peels lane 0 into an outer loop and lets the other 63 lanes iterate without it.
-    // The passes of the length classes run side by side (run_wfa): the wide rings belong to the few long alignments every
-    // round waits for, so their wavefronts are issued ahead of the many short ones sharing the SIMDs
-    if (NC >= 16)
-        __builtin_amdgcn_s_setprio(3);
-    else if (NC >= 8)
-        __builtin_amdgcn_s_setprio(2);
-    else if (NC >= 4)
-        __builtin_amdgcn_s_setprio(1);
-    // LM_DEBUG_WFA_WAVES (dbg != nullptr): per resident wavefront {first pop, exit, problems, time in the score loops, longest
-    // problem, its queue position} on the 100-MHz wall clock - where a launch's tail comes from
-    unsigned long long d_t0 = 0, d_fwd = 0, d_max = 0, d_ts = 0;
-    unsigned int d_n = 0, d_maxx = 0;
-    if (dbg) d_t0 = wall_clock64();
-    if (lane == 0) sh_x = atomicAdd(queue, 1u);
-    while (true) {
-        LDS_WAVE_SYNC();
-        // made provably wave-uniform so everything derived from it stays scalar
-        const unsigned int x = (unsigned int)__builtin_amdgcn_readfirstlane((int)sh_x);
-        LDS_WAVE_SYNC();
-        if ((int64_t)x >= ntodo) break;
-        const int64_t i = todo ? todo[x] : (int64_t)x;
-        if (i < 0 || i >= n) break; // malformed work list
-        if (dbg) d_ts = wall_clock64();
-        const WfaIn w = in[i];
-        const int plen = w.qlen, tlen = w.tlen;
-        const int ak = tlen - plen;
-        // slot of diagonal k = (k + koff) mod W: the band between diagonal 0 and the final diagonal ak is centred on the
-        // first 64 slots, so that the second cell of every lane (NC == 2) is only touched when a wavefront is wide or
-        // has drifted (chunks without a valid cell are skipped with a scalar branch)
-        const int koff = 32 - (ak >= -40 && ak <= 40 ? ak / 2 : 0);
-        int status = 0;
-        LDS_WAVE_SYNC(); // the previous alignment is done with the sequence windows and the ring
-        bool bad = false;  // a non-ACGT byte was packed (checked when the alignment ends: the result is discarded)
-        WfaWin Q, T;
-        Q.buf = WIN ? qwin_buf : seq_lds;
-        Q.src = w.q;
-        Q.len = plen;
-        Q.w0 = 0;
-        T.buf = WIN ? twin_buf : seq_lds + seq_words + 1;
-        T.src = w.t;
-        T.len = tlen;
-        T.w0 = 0;
-        if (WIN) {
-            wfa_win_move2(Q, 0, T, 0, lane, &bad, true);
-        } else {
-            const int qw = (plen + 15) >> 4, tw = (tlen + 15) >> 4;
-            if (qw > seq_words || tw > seq_words) {
-                status = 3;
-            } else {
-                for (int j = lane; j < qw; j += 64) Q.buf[j] = pack16(w.q + 16 * j, plen - 16 * j, &bad);
-                for (int j = lane; j < tw; j += 64) T.buf[j] = pack16(w.t + 16 * j, tlen - 16 * j, &bad);
-                if (lane == 0) {
-                    Q.buf[qw] = 0;
-                    T.buf[tw] = 0;
-                }
-                if (__ballot(bad) != 0ull) status = 3;
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < NC; c++) {
-#pragma unroll
-            for (int r = 0; r < 5; r++) rM[r][lane + 64 * c] = RNULL;
-#pragma unroll
-            for (int r = 0; r < 2; r++) rI[r][lane + 64 * c] = rD[r][lane + 64 * c] = RNULL;
-        }
-        // valid ranges by age in even scores: mlo[a]..mhi[a] is M[s-2a]. An empty range is (E_LO, E_HI): far apart, so
-        // min / max unions and the unsigned range tests below need no "is it empty" cases
-        constexpr int E_LO = 1 << 28, E_HI = -(1 << 28);
-        int mlo[5], mhi[5], ilo[2], ihi[2], dlo[2], dhi[2];
-#pragma unroll
-        for (int a = 0; a < 5; a++) {
-            mlo[a] = E_LO;
-            mhi[a] = E_HI;
-        }
-#pragma unroll
-        for (int a = 0; a < 2; a++) {
-            ilo[a] = dlo[a] = E_LO;
-            ihi[a] = dhi[a] = E_HI;
-        }
-        if (max_score < 1 || arena_cap < 1) status = 1;
-        const bool r16_too_long = R16 && (plen > 12000 || tlen > 12000); // (see RT above)
-        if (r16_too_long) status = 3;
-        mlo[0] = mhi[0] = 0;
-        LDS_WAVE_SYNC();
-        if (lane == 0) rM[0][koff & (W - 1)] = 0;
-        LDS_WAVE_SYNC();
-        int s = 0, ms = 0, is = 0; // ring rows of score s
-        int wide_at = r16_too_long ? W : 0; // width that did not fit the ring (status 3), reported in the score field (never 0 with status 3: a 0 means 'not plain ACGT' to the host)
-        int alo = 0;               // first diagonal of the row of score s
-        int32_t used = 1;          // backtrace bytes (the slab holds < 2^31); score 0 = one cell that is never read
-        if (lane == 0) {
-            hdr2[0] = 0;
-            hdr2[1] = 0;
-            hdr2[2] = 0;
-            hdr2[3] = 1;
-        }
-        // Which of the NC chunks of 64 slots does the slot range of diagonals [lo, hi] touch (bit c) ?  Computed once per range,
-        // a dozen scalar instructions, instead of per chunk and loop: the scalar unit is what bounds this kernel (one per
-        // CU, shared by all its wavefronts), and the wide rings (8 / 16 chunks, of which a wavefront touches two to eight)
-        // spent more scalar time deciding which chunks to skip than on anything else
-        auto chunk_mask = [&](int lo_, int hi_) -> uint32_t {
-            if (NC == 1) return 1u;
-            const int s0 = (lo_ + koff) & (W - 1), s1 = s0 + (hi_ - lo_);
-            const int cf = s0 >> 6, cl = (s1 >> 6) < NC - 1 ? (s1 >> 6) : NC - 1;
-            uint32_t m = ((2u << (cl - cf)) - 1u) << cf;
-            if (s1 >= W) m |= (2u << ((s1 - W) >> 6)) - 1u;
-            return (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
-        };
-        auto chunk_on = [&](uint32_t cm, int c, int lo_, int hi_) { return NC == 1 ? true : ((cm >> c) & 1u) != 0; };
-        while (status == 0) {
-            bool done = false;
-            if (mlo[0] <= mhi[0]) {
-                const uint32_t cmx = chunk_mask(mlo[0], mhi[0]);
-                int kc[NC], jc[NC];
-                bool inr[NC];
-                int32_t off[NC];
-                bool fin = false;
-                // Extension as wave-uniform loops (ballot) with per-lane predication by arithmetic: far less exec-mask
-                // bookkeeping on the scalar unit than per-lane while loops.
-                if (!WIN) {
-#pragma unroll
-                    for (int c = 0; c < NC; c++) {
-                        const int slot = lane + 64 * c;
-                        const int j = (slot - koff - alo) & (W - 1);
-                        const int k = alo + j; // this cell's diagonal at score s
-                        kc[c] = k;
-                        jc[c] = j;
-                        inr[c] = false;
-                        off[c] = RNULL;
-                        if (!chunk_on(cmx, c, mlo[0], mhi[0])) continue;
-                        inr[c] = (uint32_t)(k - mlo[0]) <= (uint32_t)(mhi[0] - mlo[0]);
-                        int32_t o = rM[ms][slot];
-                        const bool act = inr[c] && o >= 0;
-                        int v = act ? o - k : 0, h = act ? o : 0;
-                        bool ext = act;
-                        while (__ballot(ext) != 0ull) { // 16 bases per pass from the whole packed sequences
-                            const int run = wfa_match_run<false>(Q, T, v, h);
-                            const int nm = ext ? run : 0;
-                            v += nm;
-                            h += nm;
-                            ext = nm == 16;
-                        }
-                        if (act) {
-                            o = h;
-                            rM[ms][slot] = o;
-                        }
-                        off[c] = o;
-                        fin = fin || (inr[c] && k == ak && o >= tlen);
-                    }
-                } else {
-                    uint32_t extm = 0; // bit c: this lane's cell of chunk c is still being extended
-#pragma unroll
-                    for (int c = 0; c < NC; c++) {
-                        const int slot = lane + 64 * c;
-                        const int j = (slot - koff - alo) & (W - 1);
-                        const int k = alo + j; // this cell's diagonal at score s
-                        kc[c] = k;
-                        jc[c] = j;
-                        inr[c] = false;
-                        off[c] = RNULL;
-                        if (!chunk_on(cmx, c, mlo[0], mhi[0])) continue;
-                        inr[c] = (uint32_t)(k - mlo[0]) <= (uint32_t)(mhi[0] - mlo[0]);
-                        const int32_t o = rM[ms][slot];
-                        off[c] = o;
-                        if (inr[c] && o >= 0) extm |= 1u << c;
-                    }
-                    // 32 bases per pass from the sequence windows; a cell outside a window waits, and once nobody inside
-                    // extends any more both windows move to the smallest waiting positions (rare: one move per ~2900 bases
-                    // of progress; ONE inlined copy of the move)
-                    while (true) {
-#pragma unroll
-                        for (int c = 0; c < NC; c++) {
-                            if (!chunk_on(cmx, c, mlo[0], mhi[0])) continue;
-                            bool ext = ((extm >> c) & 1u) != 0;
-                            int h = ext ? off[c] : 0, v = ext ? h - kc[c] : 0;
-                            while (true) {
-                                const bool in = wfa_win_has(Q, v) && wfa_win_has(T, h);
-                                if (__ballot(ext && in) == 0ull) break;
-                                // (read by every lane - the slots are masked, any position is a valid LDS address - so that
-                                // the compiler has no branch to build around the LDS loads)
-                                const int run = wfa_match_run<true>(Q, T, v, h);
-                                const int nm = (ext && in) ? run : 0;
-                                v += nm;
-                                h += nm;
-                                ext = ext && (!in || nm == 32);
-                            }
-                            if ((extm >> c) & 1u) off[c] = h;
-                            if (!ext) extm &= ~(1u << c);
-                        }
-                        if (__ballot(extm != 0u) == 0ull) break;
-                        int mv = 2147483647, mh = 2147483647;
-#pragma unroll
-                        for (int c = 0; c < NC; c++) {
-                            const bool wt = ((extm >> c) & 1u) != 0;
-                            const int h = off[c], v = off[c] - kc[c];
-                            mh = wt && h < mh ? h : mh;
-                            mv = wt && v < mv ? v : mv;
-                        }
-                        mv = wave_min_i32_slow(mv);
-                        mh = wave_min_i32_slow(mh);
-                        wfa_win_move2(Q, mv >> 4, T, mh >> 4, lane, &bad, false);
-                    }
-#pragma unroll
-                    for (int c = 0; c < NC; c++) {
-                        if (inr[c] && off[c] >= 0) rM[ms][lane + 64 * c] = off[c];
-                        fin = fin || (inr[c] && kc[c] == ak && off[c] >= tlen);
-                    }
-                }
-                done = __ballot(fin) != 0ull;
-                if (!done && mhi[0] - mlo[0] + 1 >= 10) { // wf-adaptive(10, 50)
-                    int dist[NC];
-                    int dm = 2147483647;
-#pragma unroll
-                    for (int c = 0; c < NC; c++) {
-                        dist[c] = inr[c] ? wf_dist(off[c], kc[c], plen, tlen) : 2147483647;
-                        dm = dist[c] < dm ? dist[c] : dm;
-                    }
-                    const int dmin = wave_min_i32(dm);
-                    // The diagonals that stay: lm_wfa_align walks up from mlo to the first kept one below `top` and down
-                    // from mhi to the last kept one above `bottom` = max(ak, new lo) - which is max(ak, mlo): the new lo
-                    // never passes ak (it stops at top <= ak) unless nothing below top is tested at all (mlo >= top).
-                    // Both ends in one packed reduction: (j, W-1-j) of the kept cells on either side, j relative to alo.
-                    const int top = ak < mhi[0] ? ak : mhi[0];
-                    const int bottom = ak > mlo[0] ? ak : mlo[0];
-                    uint32_t enc = 0xffffffffu;
-#pragma unroll
-                    for (int c = 0; c < NC; c++) {
-                        const bool keep = inr[c] && (dist[c] - dmin <= 50);
-                        const uint32_t l16 = (keep && kc[c] < top) ? (uint32_t)jc[c] : 0xffffu;
-                        const uint32_t h16 = (keep && kc[c] > bottom) ? (uint32_t)(W - 1 - jc[c]) : 0xffffu;
-                        enc = pk_min_u16(enc, l16 | (h16 << 16));
-                    }
-                    const uint32_t red = wave_pkmin_u16(enc);
-                    int nlo = mlo[0], nhi = mhi[0];
-                    if (mlo[0] < top) nlo = (red & 0xffffu) != 0xffffu ? alo + (int)(red & 0xffffu) : top;
-                    if (mhi[0] > bottom) nhi = (red >> 16) != 0xffffu ? alo + (W - 1 - (int)(red >> 16)) : bottom;
-                    if (nlo != mlo[0] || nhi != mhi[0]) {
-                        // clamp I[s] / D[s] to the reduced M range (empty stays empty: the sentinels survive max / min) and
-                        // put NULL back into the ring cells that left a range
-                        const int oil = ilo[0], odl = dlo[0];
-                        const uint32_t oisp = (uint32_t)(ihi[0] - ilo[0]), odsp = (uint32_t)(dhi[0] - dlo[0]);
-                        ilo[0] = ilo[0] > nlo ? ilo[0] : nlo;
-                        ihi[0] = ihi[0] < nhi ? ihi[0] : nhi;
-                        dlo[0] = dlo[0] > nlo ? dlo[0] : nlo;
-                        dhi[0] = dhi[0] < nhi ? dhi[0] : nhi;
-                        if (ilo[0] > ihi[0]) {
-                            ilo[0] = E_LO;
-                            ihi[0] = E_HI;
-                        }
-                        if (dlo[0] > dhi[0]) {
-                            dlo[0] = E_LO;
-                            dhi[0] = E_HI;
-                        }
-                        const uint32_t nmsp = (uint32_t)(nhi - nlo), nisp = (uint32_t)(ihi[0] - ilo[0]), ndsp = (uint32_t)(dhi[0] - dlo[0]);
-#pragma unroll
-                        for (int c = 0; c < NC; c++) {
-                            const int slot = lane + 64 * c, k = kc[c];
-                            if (inr[c] && (uint32_t)(k - nlo) > nmsp) rM[ms][slot] = RNULL;
-                            if ((uint32_t)(k - oil) <= oisp && (uint32_t)(k - ilo[0]) > nisp) rI[is][slot] = RNULL;
-                            if ((uint32_t)(k - odl) <= odsp && (uint32_t)(k - dlo[0]) > ndsp) rD[is][slot] = RNULL;
-                        }
-                        mlo[0] = nlo;
-                        mhi[0] = nhi;
-                    }
-                }
-            }
-            if (done) break;
-            s += 2;
-            if (s >= max_score) {
-                status = 1;
-                break;
-            }
-            if (R16 && s >= 24000) { // the 16-bit cells could wrap from here on: the 32-bit pass takes the problem
-                status = 3;
-                wide_at = W;
-                break;
-            }
-#pragma unroll
-            for (int a = 4; a > 0; a--) {
-                mlo[a] = mlo[a - 1];
-                mhi[a] = mhi[a - 1];
-            }
-            ilo[1] = ilo[0];
-            ihi[1] = ihi[0];
-            dlo[1] = dlo[0];
-            dhi[1] = dhi[0];
-            ms = ms == 4 ? 0 : ms + 1;
-            is ^= 1;
-            // sources: M[s-4] (mismatch), M[s-8] (gap open), I[s-2] / D[s-2] (gap extension)
-            int lo = mlo[2] < mlo[4] - 1 ? mlo[2] : mlo[4] - 1, hi = mhi[2] > mhi[4] + 1 ? mhi[2] : mhi[4] + 1;
-            {
-                const int l2 = ilo[1] + 1 < dlo[1] - 1 ? ilo[1] + 1 : dlo[1] - 1, h2 = ihi[1] + 1 > dhi[1] - 1 ? ihi[1] + 1 : dhi[1] - 1;
-                lo = l2 < lo ? l2 : lo;
-                hi = h2 > hi ? h2 : hi;
-            }
-            if (lo > hi) { // no source wavefront (all four empty)
-                mlo[0] = ilo[0] = dlo[0] = E_LO;
-                mhi[0] = ihi[0] = dhi[0] = E_HI;
-#pragma unroll
-                for (int c = 0; c < NC; c++) {
-                    rM[ms][lane + 64 * c] = RNULL;
-                    rI[is][lane + 64 * c] = RNULL;
-                    rD[is][lane + 64 * c] = RNULL;
-                }
-                alo = 0;
-                if (lane == 0) { // an empty row: same offset as the next one
-                    hdr2[s] = 0;
-                    hdr2[s + 1] = used;
-                    hdr2[s + 3] = used;
-                }
-                continue;
-            }
-            const int wd = hi - lo + 1;
-            if (wd > W - 2) {
-                status = 3;
-                wide_at = wd;
-                break;
-            }
-            if ((int64_t)used + wd > arena_cap) {
-                status = 1;
-                break;
-            }
-            const int32_t rowb = used;
-            used += wd;
-            alo = lo;
-            if (lane == 0) { // entry s/2 = {lo, row offset}; the offset of entry s/2+1 closes the row
-                hdr2[s] = lo;
-                hdr2[s + 1] = rowb;
-                hdr2[s + 3] = used;
-            }
-            const int r4 = ms >= 2 ? ms - 2 : ms + 3, r8 = ms == 4 ? 0 : ms + 1, r2 = is ^ 1; // rows of s-4, s-8, s-2
-            LDS_WAVE_SYNC(); // the neighbours' extension results are in the ring
-            const uint32_t cmr = chunk_mask(lo, hi);
-            int kk[NC];
-            bool inr[NC];
-            int32_t vins[NC], vdel[NC], vmx[NC];
-            uint32_t em = 0xffffffffu, ei = 0xffffffffu, ed = 0xffffffffu; // (first, W-1-last) cell inside the DP matrix
-#pragma unroll
-            for (int c = 0; c < NC; c++) {
-                const int slot = lane + 64 * c;
-                const int j = (slot - koff - lo) & (W - 1);
-                const int k = lo + j;
-                kk[c] = k;
-                inr[c] = false;
-                vins[c] = vdel[c] = vmx[c] = RNULL;
-                if (!chunk_on(cmr, c, lo, hi)) continue;
-                inr[c] = k <= hi;
-                const int sm1 = (slot + W - 1) & (W - 1), sp1 = (slot + 1) & (W - 1);
-                int32_t a = rM[r8][sm1], b = rI[r2][sm1];
-                const bool iext = b >= a; // equal offsets: extension (lm_wfa_backtrace tags 2 > 1)
-                const int32_t ins = (iext ? b : a) + 1;
-                a = rM[r8][sp1];
-                b = rD[r2][sp1];
-                const bool dext = b >= a; // tags 4 > 3
-                const int32_t del = dext ? b : a;
-                const int32_t mis = rM[r4][slot] + 1;
-                int32_t mx = mis > ins ? mis : ins;
-                if (del > mx) mx = del;
-                // predecessor of the M cell on equal offsets: mismatch (tag 9) > deletion (4, 3) > insertion (2, 1)
-                const uint32_t mc = (mis >= del && mis >= ins) ? 0u : (del >= ins ? 2u : 1u);
-                if ((uint32_t)mx > (uint32_t)tlen) mx = RNULL;
-                if ((uint32_t)(mx - k) > (uint32_t)plen) mx = RNULL;
-                if (inr[c]) bt[rowb + (k - lo)] = (uint8_t)(mc | (iext ? 4u : 0u) | (dext ? 8u : 0u));
-                vins[c] = ins;
-                vdel[c] = del;
-                vmx[c] = mx;
-                // trim each of the three new wavefronts to its first/last cell inside the DP matrix
-                auto okc = [&](int32_t o) {
-                    return inr[c] && (uint32_t)o <= (uint32_t)tlen && (uint32_t)(o - k) <= (uint32_t)plen;
-                };
-                const uint32_t pos = (uint32_t)j | ((uint32_t)(W - 1 - j) << 16);
-                em = pk_min_u16(em, okc(mx) ? pos : 0xffffffffu);
-                ei = pk_min_u16(ei, okc(ins) ? pos : 0xffffffffu);
-                ed = pk_min_u16(ed, okc(del) ? pos : 0xffffffffu);
-            }
-            {
-                const uint32_t rm = wave_pkmin_u16(em), ri = wave_pkmin_u16(ei), rd = wave_pkmin_u16(ed);
-                const bool hm = (rm & 0xffffu) != 0xffffu, hi_ = (ri & 0xffffu) != 0xffffu, hd = (rd & 0xffffu) != 0xffffu;
-                mlo[0] = hm ? lo + (int)(rm & 0xffffu) : E_LO;
-                mhi[0] = hm ? lo + (W - 1 - (int)(rm >> 16)) : E_HI;
-                ilo[0] = hi_ ? lo + (int)(ri & 0xffffu) : E_LO;
-                ihi[0] = hi_ ? lo + (W - 1 - (int)(ri >> 16)) : E_HI;
-                dlo[0] = hd ? lo + (int)(rd & 0xffffu) : E_LO;
-                dhi[0] = hd ? lo + (W - 1 - (int)(rd >> 16)) : E_HI;
-            }
-            LDS_WAVE_SYNC(); // every lane has read the old rows before row ms / is are overwritten
-            const uint32_t spm = (uint32_t)(mhi[0] - mlo[0]), spi = (uint32_t)(ihi[0] - ilo[0]), spd = (uint32_t)(dhi[0] - dlo[0]);
-#pragma unroll
-            for (int c = 0; c < NC; c++) { // (k - E_LO) as unsigned is above every span, also above the span of an empty range
-                const int slot = lane + 64 * c, k = kk[c];
-                rM[ms][slot] = (uint32_t)(k - mlo[0]) <= spm ? vmx[c] : RNULL;
-                rI[is][slot] = (uint32_t)(k - ilo[0]) <= spi ? vins[c] : RNULL;
-                rD[is][slot] = (uint32_t)(k - dlo[0]) <= spd ? vdel[c] : RNULL;
-            }
-        }
-        if (status == 0 && __ballot(bad) != 0ull) status = 3; // not plain ACGT: the byte-comparing kernel takes it
-        __syncthreads(); // the backtrace reads what every lane stored to global memory
-        if (dbg) d_fwd += wall_clock64() - d_ts;
-        WfaOut o;
-        o.blast_score = 0;
-        if (status != 0) {
-            o.r.status = status;
-            o.r.score = wide_at;
-            o.r.nops = 0;
-            o.r.qbegin = o.r.qend = o.r.tbegin = o.r.tend = 0;
-            o.r.align_len = o.r.matches = o.r.gaps = o.r.gap_regions = 0;
-        } else {
-            // operations (reversed) into the unused tail of this wavefront's slab, then the forward replay
-            const int nops = bt_walk(hdr2, bt, s, ak, bt + arena_stride - 16, arena_stride - 16 - ((used + 15) & ~15), &btl, lane);
-            __threadfence_block();
-            __syncthreads(); // lane 0's operation bytes are visible to the other lanes
-            if (nops < 0) {
-                o.r.status = 1;
-                o.r.score = 0;
-                o.r.nops = 0;
-                o.r.qbegin = o.r.qend = o.r.tbegin = o.r.tend = 0;
-                o.r.align_len = o.r.matches = o.r.gaps = o.r.gap_regions = 0;
-            } else {
-                bt_replay<WIN>(bt + arena_stride - 16 - nops, nops, Q, T, plen, tlen, want_ops ? ops_pool + w.ops_off : nullptr,
-                          w.ops_cap, lane, s, &o.r, &o.blast_score);
-            }
-        }
-        if (lane == 0) {
-            out[i] = o;
-            sh_x = atomicAdd(queue, 1u);
-        }
-        if (dbg) {
-            const unsigned long long dt = wall_clock64() - d_ts;
-            d_n++;
-            if (dt > d_max) {
-                d_max = dt;
-                d_maxx = x;
-            }
-        }
-    }
-    if (dbg && lane == 0) {
-        unsigned long long *d = dbg + 6 * (size_t)blockIdx.x;
-        d[0] = d_t0;
-        d[1] = wall_clock64();
-        d[2] = d_n;
-        d[3] = d_fwd;
-        d[4] = d_max;
-        d[5] = d_maxx;
-    }
-}
-
+// ---- the LDS wavefront kernels -----------------------------------------------------------------------------------------
+// k_wfa_lean2<NC, RT, WIN> (lm_wfa_lean2.h: one wavefront per alignment, 64 * NC diagonals) and k_wfa_mw2<NCW, WIN>
+// (lm_wfa_mw2.h: a workgroup of four wavefronts per long alignment).  Persistent: each workgroup owns a private header / arena
+// region and pops problems from a queue ordered by decreasing expected cost; a ring that turns out too narrow returns status 3
+// and the next width takes the problem (... -> k_wfa_wave, the global-memory ring).  Results are identical to lm_wfa_align.
+// (Their predecessors k_wfa_lean / k_wfa_mw - a wrapping ring, five DPP range reductions and three LDS hand-offs per score -
+// were measured against them on one resident C3 index in round 5, 12.1 against 9.85 s per step, and removed.)
 
 #include "lm_wfa_mw.h"
 
 // ------------------------------------------------------------------------------------------------------------
 // host-callable launchers
+static bool occ8 = getenv("LM_OCC8") ? atoi(getenv("LM_OCC8")) != 0 : true; // (A/B of the register cap; re-read by lm_tuning_reload through launch_set_occ8)
+void launch_set_occ8(bool on) { occ8 = on; }
 static inline int grid_for(int64_t n, int block, int maxb = 2048 * 8) {
     int64_t g = (n + block - 1) / block;
     if (g < 1) g = 1;
@@ -3387,7 +2897,7 @@ void launch_pa_chain(hipStream_t st, const uint64_t *B, const int64_t *pa_off, i
     unsigned long long *dbg = pa_dbg ? d_pa_dbg : nullptr;
     if (dbg) (void)hipMemsetAsync(dbg, 0, 16 * sizeof(unsigned long long), st);
     if (pipe_min > 0) (void)hipMemsetAsync(nlong, 0, sizeof(unsigned int), st);
-    hipLaunchKernelGGL(ring ? k_pa_chain_wave<true> : k_pa_chain_wave<false>, dim3(g), dim3(64), 0, st, B, pa_off, ntasks, K, opt, subs, marks, msi, stack, out, out_n,
+    hipLaunchKernelGGL(ring ? (occ8 ? k_pa_chain_wave<true, 8> : k_pa_chain_wave<true>) : k_pa_chain_wave<false>, dim3(g), dim3(64), 0, st, B, pa_off, ntasks, K, opt, subs, marks, msi, stack, out, out_n,
                        clr_n, qbits, tbits, pipe_min, long_tasks, nlong, bt_wave, dbg);
     if (pipe_min > 0) // (the number of long windows is known on the device only: a grid that fills the chip, workgroups loop)
         hipLaunchKernelGGL(k_pa_chain_pipe, dim3((unsigned)(ntasks < 1024 ? (ntasks < 1 ? 1 : ntasks) : 1024)), dim3(PCP_NW * 64), 0, st, pa_off, long_tasks,
@@ -3432,10 +2942,10 @@ void launch_extend(hipStream_t st, const HspIn *hsps, int64_t n, const uint8_t *
 typedef void (*WfaLeanFn)(const WfaIn *, int64_t, const int32_t *, int64_t, int32_t *, int64_t, uint8_t *, int64_t, uint64_t *,
                           unsigned int *, int, int, WfaOut *, unsigned long long *);
 // r16: 16-bit ring cells (whole-sequence kernels of 128 / 256 diagonals, sequences up to 12 000 bases: lm_kernels.h)
-static WfaLeanFn wfa_lean2_fn(int nc, bool win, bool r16) { // the restructured forward pass (lm_wfa_lean2.h)
+static WfaLeanFn wfa_lean_fn(int nc, bool win, bool r16) { // (lm_wfa_lean2.h)
     // (shrink margins 4 and 8 of the dominant instantiation - longer in ONE chunk of 64 slots, more recentres - were measured
     // on one resident C3 index against the 12 it has: 9.67 / 9.80 s against 9.69 s per step, no difference; removed)
-    if (r16 && !win && nc == 2) return k_wfa_lean2<2, int16_t, false>;
+    if (r16 && !win && nc == 2) return occ8 ? k_wfa_lean2<2, int16_t, false, L2_SHRINK_MARGIN, 8> : k_wfa_lean2<2, int16_t, false>;
     if (r16 && !win && nc == 4) return k_wfa_lean2<4, int16_t, false>;
     switch (nc) {
     case 16: return win ? k_wfa_lean2<16, int32_t, true> : k_wfa_lean2<16, int32_t, false>;
@@ -3445,33 +2955,22 @@ static WfaLeanFn wfa_lean2_fn(int nc, bool win, bool r16) { // the restructured 
     default: return win ? k_wfa_lean2<2, int32_t, true> : k_wfa_lean2<2, int32_t, false>;
     }
 }
-static WfaLeanFn wfa_lean_fn(int nc, bool win, bool r16, bool lean2 = false) {
-    if (lean2) return wfa_lean2_fn(nc, win, r16);
-    if (r16 && !win && nc == 2) return k_wfa_lean<2, false, int16_t>;
-    if (r16 && !win && nc == 4) return k_wfa_lean<4, false, int16_t>;
-    switch (nc) {
-    case 16: return win ? k_wfa_lean<16, true, int32_t> : k_wfa_lean<16, false, int32_t>;
-    case 8: return win ? k_wfa_lean<8, true, int32_t> : k_wfa_lean<8, false, int32_t>;
-    case 4: return win ? k_wfa_lean<4, true, int32_t> : k_wfa_lean<4, false, int32_t>;
-    case 1: return win ? k_wfa_lean<1, true, int32_t> : k_wfa_lean<1, false, int32_t>;
-    default: return win ? k_wfa_lean<2, true, int32_t> : k_wfa_lean<2, false, int32_t>;
-    }
-}
 bool wfa_r16_ok(int seq_words, int nc, bool win) { return !win && (nc == 2 || nc == 4) && seq_words <= 750; }
+
 static size_t wfa_dyn_lds(int seq_words, bool win) { // two packed sequences with one padding word each (+2: the predicated
     return win ? 0 : (size_t)(2 * (seq_words + 2) + 1) * sizeof(uint32_t); // extension may read one word past; k_wfa_lean2: one word in front)
 }
-int wfa_resident_blocks(int device, int seq_words, int nc, bool win, bool r16, bool lean2) {
+int wfa_resident_blocks(int device, int seq_words, int nc, bool win, bool r16) {
     int nb = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)wfa_lean_fn(nc, win, r16, lean2), 64, wfa_dyn_lds(seq_words, win)) != hipSuccess || nb < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)wfa_lean_fn(nc, win, r16), 64, wfa_dyn_lds(seq_words, win)) != hipSuccess || nb < 1)
         nb = 8;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
     return nb * cus;
 }
 void launch_wfa(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks,
                 int32_t *hdr_pool, int64_t hdr_stride, uint8_t *arena_pool, int64_t arena_stride, uint64_t *ops_pool,
-                unsigned int *queue, int seq_words, int want_ops, WfaOut *out, int nc, bool win, bool r16, unsigned long long *dbg, bool lean2) {
-    hipLaunchKernelGGL(wfa_lean_fn(nc, win, r16, lean2), dim3(nblocks), dim3(64), wfa_dyn_lds(seq_words, win), st, in, n, todo, ntodo, hdr_pool,
+                unsigned int *queue, int seq_words, int want_ops, WfaOut *out, int nc, bool win, bool r16, unsigned long long *dbg) {
+    hipLaunchKernelGGL(wfa_lean_fn(nc, win, r16), dim3(nblocks), dim3(64), wfa_dyn_lds(seq_words, win), st, in, n, todo, ntodo, hdr_pool,
                        hdr_stride, arena_pool, arena_stride, ops_pool, queue, seq_words, want_ops, out, dbg);
 }
 void launch_wfa_wide(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int32_t *hdr_pool,

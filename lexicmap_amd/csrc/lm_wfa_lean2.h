@@ -56,8 +56,10 @@ __device__ __forceinline__ int l2_sflb(unsigned long long m) {
 
 #include "lm_wfa_lean2_fwd.h"
 
-template <int NC, typename RT, bool WIN, int MARGIN = L2_SHRINK_MARGIN>
-__global__ __launch_bounds__(64) void k_wfa_lean2(const WfaIn *__restrict__ in, int64_t n, const int32_t *__restrict__ todo, int64_t ntodo,
+// WPE: wavefronts per SIMD the register allocation is held to (8 = at most 64 VGPRs: the instantiation of the two shortest length
+// classes, whose residency the registers bound - 69 VGPRs were 7 wavefronts per SIMD; 1 = as the compiler likes)
+template <int NC, typename RT, bool WIN, int MARGIN = L2_SHRINK_MARGIN, int WPE = 1>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void k_wfa_lean2(const WfaIn *__restrict__ in, int64_t n, const int32_t *__restrict__ todo, int64_t ntodo,
                                                    int32_t *__restrict__ hdr_pool, int64_t hdr_stride, uint8_t *__restrict__ arena_pool,
                                                    int64_t arena_stride, uint64_t *__restrict__ ops_pool, unsigned int *__restrict__ queue,
                                                    int seq_words, int want_ops, WfaOut *__restrict__ out, unsigned long long *__restrict__ dbg) {

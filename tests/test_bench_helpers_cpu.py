@@ -88,7 +88,7 @@ def test_rocprof_kernel_names_match_the_names_bench_reports():
     assert S.short("void lm::k_wfa_lean<16, (bool)1>(x)") == "k_wfa_win1024"
     assert S.short("void lm::k_wfa_lean<4, false, short>(x)") == "k_wfa_lean256"   # the 16-bit ring instantiations
     assert S.short("void lm::k_wfa_lean<2, false, int>(x)") == "k_wfa_lean"
-    # the staged restructured kernels (experiments/wfa_lean2) take the names of the kernels they replace
+    # k_wfa_lean2 / k_wfa_mw2 keep the profile names of the kernels they replaced in round 5
     assert S.short("void lm::k_wfa_lean2<2, short, false>(x)") == "k_wfa_lean"
     assert S.short("void lm::k_wfa_lean2<4, int, (bool)1>(x)") == "k_wfa_win256"
     assert S.short("void lm::k_wfa_mw2<4, true>(x)") == "k_wfa_mww1024"

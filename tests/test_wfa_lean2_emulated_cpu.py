@@ -1,4 +1,4 @@
-"""lexicmap_amd/csrc/lm_wfa_lean2_fwd.h (product header, switch LM_WFA_LEAN2) - the restructuring of k_wfa_lean's forward pass (no-wrap ring that is
+"""lexicmap_amd/csrc/lm_wfa_lean2_fwd.h (product header: the forward pass of k_wfa_lean2, the single-wavefront WFA kernel - no-wrap ring that is
 recentred, trimming by ballots, extension fused behind the recurrence; fewer instructions per score step) - on the host SIMT
 emulator (tests/emu) against the oracle: score, run list, coordinates and statistics; rings of 64-512 diagonals with 32- and
 16-bit cells; wavefronts that drift (the ring is recentred), that outgrow the ring (status 3) and the small cases."""
@@ -10,8 +10,7 @@ import subprocess
 import pytest
 
 from test_device_algos_cpu import mutate, rand_seq, run_oracle_wfa
-from test_wfa_mw_emulated_cpu import with_insertion
-from test_wfa_row_emulated_cpu import EMU, EmuOut
+from emu_common import EMU, EmuOut, with_insertion
 
 EXP = os.path.join(os.path.dirname(os.path.dirname(EMU)), "lexicmap_amd", "csrc")
 _lib = None

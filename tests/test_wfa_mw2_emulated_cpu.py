@@ -1,4 +1,4 @@
-"""lexicmap_amd/csrc/lm_wfa_mw2_fwd.h (product header, switch LM_WFA_LEAN2) - the restructuring of the workgroup WFA forward pass (k_wfa_mw: four
+"""lexicmap_amd/csrc/lm_wfa_mw2_fwd.h (product header: the forward pass of k_wfa_mw2, the workgroup WFA kernel - four
 wavefronts per alignment, 256 / 512 / 1024 diagonals; three barriers per score instead of four, ballot trimming, fused
 extension, a ring without wrap that the workgroup recentres) - on the host SIMT emulator (tests/emu) against the oracle: score,
 run list, coordinates, statistics; wavefronts wider than one wavefront's 64 lanes, than 256 and 512 diagonals (long end gaps),
@@ -11,10 +11,11 @@ import subprocess
 import pytest
 
 from test_device_algos_cpu import mutate, rand_seq, run_oracle_wfa
-from test_wfa_mw_emulated_cpu import with_insertion
-from test_wfa_row_emulated_cpu import EMU, EmuOut
+from emu_common import EMU, EmuOut, with_insertion
 
 EXP = os.path.join(os.path.dirname(os.path.dirname(EMU)), "lexicmap_amd", "csrc")
+
+
 _lib = None
 
 

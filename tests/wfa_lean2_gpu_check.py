@@ -1,6 +1,6 @@
 """wfa_lean2_gpu_check.py - the forced-path check of k_wfa_lean2 / k_wfa_mw2 (lexicmap_amd/csrc/lm_wfa_lean2.h, lm_wfa_mw2.h): every
-instantiation forced through lm_wfa_batch (la.Index.wfa) against the oracle's lmo_wfa_align, with LM_WFA_LEAN2 = 1 and = 0
-(k_wfa_lean), plus the time of either on a class-shaped batch.  tests/test_gpu_wfa_lean2.py runs main(timing=False).
+instantiation forced through lm_wfa_batch (la.Index.wfa) against the oracle's lmo_wfa_align, plus the time of two class-shaped
+batches.  tests/test_gpu_wfa_lean2.py runs main(timing=False).
 
     python tests/wfa_lean2_gpu_check.py            (on the GPU box, from the repository root: with the timing batches)
 
@@ -70,10 +70,8 @@ def main(timing=True):
               pair(rng, 36000, 0.02, 0.02, 0.02, extra=380), pair(rng, 44000, 0.02, 0.02, 0.02, extra=-640)]
     total_bad = 0
     report = {}
-    for env in ({"LM_WFA_LEAN2": "1"}, {"LM_WFA_LEAN2": "0"}, {"LM_WFA_LEAN2": "1", "LM_WFA_FIRST_NC": "1,1,1,1,1"},
-                {"LM_WFA_LEAN2": "1", "LM_WFA_MW": "0"}, {"LM_WFA_LEAN2": "1", "LM_WFA_R16": "0"},
-                {"LM_WFA_LEAN2": "1", "LM_WFA_WIN": "11111"}, {"LM_WFA_LEAN2": "1", "LM_WFA_WIN": "00000"}):
-        for k in ("LM_WFA_LEAN2", "LM_WFA_FIRST_NC", "LM_WFA_MW", "LM_WFA_R16", "LM_WFA_WIN"):
+    for env in ({}, {"LM_WFA_FIRST_NC": "1,1,1,1,1"}, {"LM_WFA_MW": "0"}, {"LM_WFA_R16": "0"}, {"LM_WFA_WIN": "11111"}, {"LM_WFA_WIN": "00000"}):
+        for k in ("LM_WFA_FIRST_NC", "LM_WFA_MW", "LM_WFA_R16", "LM_WFA_WIN"):
             os.environ.pop(k, None)
         os.environ.update(env)
         gi = la.Index(d)
@@ -85,21 +83,19 @@ def main(timing=True):
         report[json.dumps(env, sort_keys=True)] = {"different": bad, "kernels": names}
         print(env, "different:", bad, names)
         gi.close()
-    # time: 8192 gene-sized pairs and 512 5-kb pairs, k_wfa_lean2 vs k_wfa_lean
+    # time: 8192 gene-sized pairs and 512 5-kb pairs, k_wfa_lean2
     timing_s = {}
     for label, batch in () if not timing else (("genes_1500bp_x8192", [pair(rng, 1500, 0.05, 0.02, 0.02) for _ in range(256)] * 32),
                          ("reads_5kb_x512", [pair(rng, 5000, 0.03, 0.02, 0.03) for _ in range(64)] * 8)):
-        for lean2 in ("1", "0"):
-            os.environ["LM_WFA_LEAN2"] = lean2
-            for k in ("LM_WFA_FIRST_NC", "LM_WFA_MW", "LM_WFA_R16", "LM_WFA_WIN"):
-                os.environ.pop(k, None)
-            gi = la.Index(d)
-            gi.wfa(batch[:64])
-            t0 = time.time()
-            gi.wfa(batch)
-            timing_s["%s lean2=%s" % (label, lean2)] = round(time.time() - t0, 4)
-            gi.close()
-    for k in ("LM_WFA_LEAN2", "LM_WFA_FIRST_NC", "LM_WFA_MW", "LM_WFA_R16", "LM_WFA_WIN"):
+        for k in ("LM_WFA_FIRST_NC", "LM_WFA_MW", "LM_WFA_R16", "LM_WFA_WIN"):
+            os.environ.pop(k, None)
+        gi = la.Index(d)
+        gi.wfa(batch[:64])
+        t0 = time.time()
+        gi.wfa(batch)
+        timing_s[label] = round(time.time() - t0, 4)
+        gi.close()
+    for k in ("LM_WFA_FIRST_NC", "LM_WFA_MW", "LM_WFA_R16", "LM_WFA_WIN"):
         os.environ.pop(k, None)
     print(json.dumps({"report": report, "seconds": timing_s}, indent=1))
     os.makedirs("gpurun_out", exist_ok=True)
