@@ -1373,7 +1373,10 @@ LM_HD bool lm_pa_candidate2(const uint32_t *bloom, int blog, const uint32_t *map
     if (hit) return true;
     if (f & ((1u << ((p - 9) << 1)) - 1u)) return false; // bases [9, p) not all A
     if ((f & ((1u << ((p - 7) << 1)) - 1u)) == 0) return true; // bases [7, p) all A
-    if ((f >> ((p - 9) << 1)) & 3u) {
+    const uint32_t p9 = f >> ((p - LM_PFX_BASES2) << 1);
+    const bool m9 = ((map9[p9 >> 5] >> (p9 & 31)) & 1u) != 0; // (either way some k-mer shares the key's first 9 bases: the exact map)
+    if (!m9) return false;
+    if (p9 & 3u) {
         // base 8 is not A: a = p - 9, so d = 9 and L = 10 exactly: some k-mer shares the key's 10 bases and differs at
         // base 10 (an A in the key): one of the three sibling 11-base prefixes is in the set
         for (uint32_t sib = 1; sib < 4; sib++) {
@@ -1387,8 +1390,7 @@ LM_HD bool lm_pa_candidate2(const uint32_t *bloom, int blog, const uint32_t *map
         }
         return false;
     }
-    const uint32_t p9 = f >> ((p - LM_PFX_BASES2) << 1);
-    return ((map9[p9 >> 5] >> (p9 & 31)) & 1u) != 0;
+    return true; // base 8 is an A: the 9-base map was the test
 }
 
 // Same, with the two binary searches narrowed by a bucket table over the leading `tab_bits/2` bases:

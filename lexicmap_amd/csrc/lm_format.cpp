@@ -393,7 +393,11 @@ std::string load_index(const std::string &dir, int shard_rank, int shard_count, 
                 out.max_genome_len = std::max<int64_t>(out.max_genome_len, rec_len[(size_t)g]);
             }
     }
-    if (shard_count > 1) gbits_bound = gbits_bound / (size_t)shard_count + gbits_bound / (size_t)shard_count / 8 + (1 << 20);
+    if (shard_count > 1) { // exactly this shard's genomes (their lengths are in the batch indexes)
+        gbits_bound = 64;
+        for (size_t g = 0; g < rec_len.size(); g++)
+            if (out.g2local.empty() || ((size_t)g < out.g2local.size() && out.g2local[g] >= 0)) gbits_bound += ((size_t)rec_len[g] + 3) / 4 + 16;
+    }
     out.gbits_bound = gbits_bound;
     // seeds
     std::vector<std::string> files;
@@ -454,8 +458,9 @@ std::string load_index_genomes(const std::string &dir, HostIndex &out, int &stat
         status = 1;
         return "failed to read " + dir + "/genomes.map.bin";
     }
-    int64_t global = 0;
-    out.gbits.reserve(out.gbits_bound);
+    int64_t global = 0, run = 0; // run: bytes of the store so far when a sink takes the bases
+    const bool to_sink = (bool)out.gbits_sink;
+    if (!to_sink) out.gbits.reserve(out.gbits_bound);
     std::vector<uint8_t> ib, gb; // (reused: the batches are GBs each)
     for (int b = 0; b < out.genome_batches; b++) {
         char name[64];
@@ -473,6 +478,7 @@ std::string load_index_genomes(const std::string &dir, HostIndex &out, int &stat
             status = gb.empty() ? 1 : 2;
             return std::string("genome data: invalid binary format: ") + name;
         }
+        if (out.gbits_batch_begin) out.gbits_batch_begin(gb.data(), gb.size());
         for (uint32_t r = 0; r < nrec; r++, global++) {
             // a shard keeps the bases of its own genomes only, but the names and sizes of all of them: rank 0 prints the
             // merged rows of every shard (lm_merge_sharded)
@@ -533,6 +539,16 @@ std::string load_index_genomes(const std::string &dir, HostIndex &out, int &stat
                 status = 2;
                 return std::string("genome data: a record of ") + name + " is longer than its genomes.bin.idx entry says";
             }
+            if (to_sink) { // (same offsets as the host store: 8 .. 15 bytes of padding behind every genome)
+                g.bits_off = run;
+                if (!out.gbits_sink(gb.data() + p, nbytes, run)) {
+                    status = 2;
+                    return std::string("genome data: the packed bases of ") + name + " exceed what the batch indexes announced";
+                }
+                run = (run + (int64_t)nbytes + 15) & ~(int64_t)7;
+                out.genomes.push_back(std::move(g));
+                continue;
+            }
             g.bits_off = (int64_t)out.gbits.size();
             out.gbits.insert(out.gbits.end(), gb.begin() + p, gb.begin() + p + nbytes);
             // pad so that 8-byte loads near the end of a genome stay inside the buffer
@@ -540,7 +556,9 @@ std::string load_index_genomes(const std::string &dir, HostIndex &out, int &stat
             out.gbits.resize(padded, 0);
             out.genomes.push_back(std::move(g));
         }
+        if (out.gbits_batch_end) out.gbits_batch_end();
     }
+    out.gbits_total = to_sink ? run : (int64_t)out.gbits.size();
 
     return "";
 }

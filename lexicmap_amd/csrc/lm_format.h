@@ -5,6 +5,7 @@
 // list (the upstream lexichash layout is not in the reference tree; see lm_format.cpp and DESIGN.md).
 #pragma once
 #include <stdint.h>
+#include <functional>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -50,7 +51,15 @@ struct HostIndex {
     std::vector<int64_t> batch_first; // [batches+1] global dense number of the first genome of each batch
     int shard_rank = 0, shard_count = 1;
     int64_t n_local_genomes = 0, max_genome_len = 1; // from the batch .idx files (before the batches themselves are read)
-    size_t gbits_bound = 0;
+    size_t gbits_bound = 0;        // upper bound of the packed bytes (+ padding) of this shard's genomes
+    // Optional: where load_index_genomes puts the packed bases of a local genome instead of appending them to `gbits` (the
+    // loader: straight from the batch file's buffer to their place on the device).  batch_begin: a batch file was read into
+    // [buf, buf + bytes) - the sinks of its genomes point into it; batch_end: the buffer is about to be reused.  A sink that
+    // returns false stops the load (status 2).
+    std::function<void(const uint8_t *buf, size_t bytes)> gbits_batch_begin;
+    std::function<bool(const uint8_t *src, size_t nbytes, int64_t bits_off)> gbits_sink;
+    std::function<void()> gbits_batch_end;
+    int64_t gbits_total = 0;       // bytes of the store once every batch is read (= gbits.size() without a sink)
 };
 
 // Everything of the index except the seeds (info.toml, masks, genomes, id map, chunk lists) + the list of seed chunk files.

@@ -406,10 +406,6 @@ struct lm_tune {
     int wfa_defer = 0;       // LM_WFA_DEFER=1: a round's latency-bound alignments finish beside the next round's first passes (default: every round waits for them)
     int wfa_r16 = 1;         // 16-bit ring cells in the whole-sequence WFA kernels of 128 / 256 diagonals (LM_WFA_R16=0: 32-bit)
     int wfa_mw = 1;          // 512 / 1024-diagonal passes by a workgroup of four wavefronts per alignment (LM_WFA_MW=0: one wavefront)
-    int pa_chain_pipe = 1;   // the Chainer2 DP of windows with more than pa_pipe_min anchors by a workgroup of pipelined wavefronts (LM_PA_CHAIN_PIPE=0: off)
-    int pa_pipe_min = 512;   // LM_PA_PIPE_MIN
-    int pa_chain_bt_wave = 3; // LM_PA_CHAIN_BT_WAVE: bit 0 = the backtrack of Chainer2 by the wavefront (LDS tiles, 64-lane region scans; 0: lane 0), bit 1 = the marks of ClearSubstrPairs from LDS tiles (0: binary search + scan in global memory)
-    int pa_chain_ring = 1;   // Chainer2 DP with the recent anchors in an LDS ring (LM_PA_CHAIN_RING=0: through global memory)
     int wfa_serial = 0;      // LM_WFA_SERIAL=1: the WFA length classes one after the other (exclusive kernel timings)
     int no_pipeline = 0;     // LM_NO_PIPELINE=1: no pseudo-alignment producer beside extend / WFA (exclusive kernel timings)
     lm_tune() {
@@ -433,10 +429,6 @@ struct lm_tune {
         if (const char *e = getenv("LM_TWO_LANES")) two_lanes = atoi(e) != 0;
         if (const char *e = getenv("LM_ARENA_RESERVE_PCT")) arena_reserve_pct = std::max(0, std::min(100, atoi(e)));
         if (const char *e = getenv("LM_WFA_AK_MARGIN")) wfa_ak_margin = atoi(e);
-        if (const char *e = getenv("LM_PA_CHAIN_RING")) pa_chain_ring = atoi(e) != 0;
-        if (const char *e = getenv("LM_PA_CHAIN_PIPE")) pa_chain_pipe = atoi(e) != 0;
-        if (const char *e = getenv("LM_PA_PIPE_MIN")) pa_pipe_min = std::max(64, atoi(e));
-        if (const char *e = getenv("LM_PA_CHAIN_BT_WAVE")) pa_chain_bt_wave = atoi(e) & 3;
         if (getenv("LM_CHAIN1_LANES")) chain1_wave = 0;
         if (const char *e = getenv("LM_PA_SEG_BY_WAVE")) pa_seg_by_group = atoi(e) ? 0 : 1;
         if (const char *e = getenv("LM_PA_FILTER_ROLL")) pa_filter_roll = atoi(e) != 0;

@@ -130,7 +130,7 @@ void launch_pa_task_off_sorted(hipStream_t st, const uint64_t *sortedA, int shif
                                int64_t *pa_off);
 void launch_pa_chain(hipStream_t st, const uint64_t *B, const int64_t *pa_off, int64_t ntasks, int K, LmChain2Opt opt,
                      LmSub *subs, uint8_t *marks, uint64_t *msi, int32_t *stack, LmChain2 *out, int32_t *out_n,
-                     int32_t *clr_n, int qbits, int tbits, bool ring, int pipe_min = 0, int64_t total = 0, int bt_wave = 0);
+                     int32_t *clr_n, int qbits, int tbits);
 void launch_gather_chain2(hipStream_t st, const LmChain2 *in, const int64_t *pa_off, const int32_t *out_n,
                           const int64_t *res_off, int64_t ntasks, LmChain2 *out);
 void launch_extend_count(hipStream_t st, const HspIn *hsps, int64_t n, const uint8_t *qseq, const int64_t *qoff,
@@ -151,6 +151,7 @@ void launch_wfa(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo,
 
 // k_wfa_mw<nc / 4, win>: the same passes for nc = 8 / 16 by a workgroup of four wavefronts per alignment
 int wfa_mw_resident_blocks(int device, int seq_words, int nc, bool win);
+void launch_set_dp_reg(int on); // LM_PA_DP_REG (default on)
 void launch_set_occ8(bool on); // LM_OCC8 (default on): k_wfa_lean2<2, int16_t> and k_pa_chain_wave held to 64 VGPRs = 8 wavefronts per SIMD
 void launch_wfa_mw(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks, int32_t *hdr_pool,
                    int64_t hdr_stride, uint8_t *arena_pool, int64_t arena_stride, uint64_t *ops_pool, unsigned int *queue, int seq_words,

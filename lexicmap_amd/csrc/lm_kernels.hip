@@ -1044,6 +1044,31 @@ __device__ __forceinline__ uint32_t pa_rc16(uint32_t x) {
     const uint32_t y = __builtin_bitreverse32(~x);
     return ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
 }
+// lm_pa_candidate2 for the lanes `q` of a wavefront whose key f (first p bases) FAILED its own Bloom test, has bases [9, p) all
+// A and belongs to a query without a global 11-base bitmap (log <= blog); the other lanes keep `c`.  One lane in eight is such
+// a lane, so EVERY pass of a wavefront comes here, and the literal rule - three sibling prefixes, two hashes and two LDS reads
+// each, per strand - was 3/4 of the kernel's instructions (217 per window base where the common path has ~50).  Staged instead:
+// bases [7, p) all A - a candidate; otherwise the exact 9-base map must hit (a sibling shares 10 bases with the key, so its
+// 9-base prefix is the key's: one LDS read turns away >= 88 % of the lanes); base 8 an A - that is the rule; base 8 not an A -
+// the three sibling tests, entered only when some lane is left.
+__device__ __forceinline__ bool pa_partial_rule(bool q, bool c, uint32_t f, int p, int blog, const uint32_t *bloom, const uint32_t *map9) {
+    const uint32_t p9 = f >> ((p - 9) << 1);
+    const bool all7 = (f & ((1u << ((p - 7) << 1)) - 1u)) == 0;
+    const bool m9 = q && ((map9[p9 >> 5] >> (p9 & 31)) & 1u) != 0;
+    const bool need = m9 && !all7 && (p9 & 3u) != 0;
+    bool r = q ? (all7 || (m9 && (p9 & 3u) == 0)) : c;
+    if (__ballot(need) != 0ull && need) {
+        const uint32_t p11 = f >> ((p - LM_PFX_BASES) << 1);
+        bool any = false;
+#pragma unroll
+        for (uint32_t sib = 1; sib < 4; sib++) {
+            const uint32_t x = p11 | sib, sa = lm_pa_bloom_slot(x, 0, blog), sb = lm_pa_bloom_slot(x, 1, blog);
+            any = any || (((bloom[sa >> 5] >> (sa & 31)) & (bloom[sb >> 5] >> (sb & 31))) & 1u) != 0;
+        }
+        r = any;
+    }
+    return r;
+}
 template <bool ROLL>
 __global__ __launch_bounds__(PA_THREADS) void k_pa_filter(DevIndexView ix, const Task *__restrict__ tasks, int64_t ntasks,
                                                            const uint8_t *__restrict__ wbuf,
@@ -1282,8 +1307,8 @@ __global__ __launch_bounds__(PA_THREADS) void k_pa_filter(DevIndexView ix, const
                                 pend(h0 || q0, pf0 | pcode, rec);
                                 pend(h1 || q1, pf1 | pcode, rec | 1ull);
                             } else if (__ballot(q0 || q1) != 0ull) { // the partial-prefix rule, all in LDS here (rare lanes)
-                                if (q0) c0 = lm_pa_candidate2(s_bloom, blog, s_map9, qbits, log, pf0, p);
-                                if (q1) c1 = lm_pa_candidate2(s_bloom, blog, s_map9, qbits, log, pf1, p);
+                                c0 = pa_partial_rule(q0, c0, pf0, p, blog, s_bloom, s_map9); // (lm_pa_candidate2 for these lanes, in LDS)
+                                c1 = pa_partial_rule(q1, c1, pf1, p, blog, s_bloom, s_map9);
                             }
                             const uint64_t m0 = __ballot(c0), m1 = __ballot(c1);
                             if ((m0 | m1) != 0ull) {
@@ -1353,8 +1378,8 @@ __global__ __launch_bounds__(PA_THREADS) void k_pa_filter(DevIndexView ix, const
                                 pend(h1 || q1, pf1 | pcode, rec | 1ull);
                             } else if (__ballot(q0 || q1) != 0ull) {
                                 // the partial-prefix rule, all in LDS here (rare lanes)
-                                if (q0) c0 = lm_pa_candidate2(s_bloom, blog, s_map9, qbits, log, pf0, p);
-                                if (q1) c1 = lm_pa_candidate2(s_bloom, blog, s_map9, qbits, log, pf1, p);
+                                c0 = pa_partial_rule(q0, c0, pf0, p, blog, s_bloom, s_map9); // (lm_pa_candidate2 for these lanes, in LDS)
+                                c1 = pa_partial_rule(q1, c1, pf1, p, blog, s_bloom, s_map9);
                             }
                         }
                         // both strands appended with one reservation in the wavefront's strip
@@ -1577,140 +1602,16 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
     return v;
 }
 
-// Backtrack with the explicit region stack: lm_run_chain2's second half, by one thread (k_pa_chain_wave's lane 0,
-// k_pa_chain_pipe's thread 0).  msi[]: (score << 32 | predecessor) per anchor, M / Mi the best score and its anchor.
-__device__ int lm_chain2_backtrack(const LmSub *a_, int n, const LmChain2Opt &opt, const uint64_t *msi, long long M, int Mi, int32_t *stack,
-                                   LmChain2 *res) {
-    int nout = 0;
-    if (M >= (long long)opt.min_score) {
-        int sp = 0;
-        stack[sp++] = 0;
-        stack[sp++] = n;
-        int pending_Mi0 = Mi;
-        while (sp > 0) {
-            int hi = stack[--sp];
-            int lo = stack[--sp];
-            int mi;
-            if (pending_Mi0 >= 0) {
-                mi = pending_Mi0;
-                pending_Mi0 = -1;
-            } else {
-                long long bestm = 0;
-                mi = lo;
-                for (int i = lo; i < hi; i++) {
-                    long long m = (long long)(msi[i] >> 32);
-                    if (m > bestm) {
-                        bestm = m;
-                        mi = i;
-                    }
-                }
-                if (bestm < (long long)opt.min_score) continue;
-            }
-            int n_matched = 0, n_abq = 0, n_abt = 0;
-            int i = mi, j = 0;
-            int32_t qb = 0, qe = 0, tb = 0, te = 0;
-            int begin_of_next = 0;
-            bool first_anchor = true, jneg = false;
-            int n_anchors = 0;
-            while (true) {
-                j = (int)(msi[i] & 4294967295ull);
-                if (j < lo) {
-                    jneg = true;
-                    break;
-                }
-                const LmSub sub = a_[i];
-                n_anchors++;
-                if (first_anchor) {
-                    first_anchor = false;
-                    qe = sub.qbegin + (int32_t)sub.len - 1;
-                    te = sub.tbegin + (int32_t)sub.len - 1;
-                    qb = sub.qbegin;
-                    tb = sub.tbegin;
-                    n_matched += sub.len;
-                } else {
-                    qb = sub.qbegin;
-                    tb = sub.tbegin;
-                    if ((int)sub.qbegin + (int)sub.len - 1 >= begin_of_next)
-                        n_matched += begin_of_next - (int)sub.qbegin;
-                    else
-                        n_matched += sub.len;
-                }
-                begin_of_next = sub.qbegin;
-                if (i == j) {
-                    n_abq += (int)qe - (int)qb + 1;
-                    if (n_abq < opt.min_align_len) break;
-                    n_abt += (int)te - (int)tb + 1;
-                    double pident = (double)n_matched / (double)(n_abq > n_abt ? n_abq : n_abt) * 100;
-                    if (pident < opt.heuristic_pident) break;
-                    if (pident > 100) pident = 100;
-                    LmChain2 p;
-                    p.nanchors = n_anchors;
-                    p.aligned_bases_q = n_abq;
-                    p.aligned_bases_t = n_abt;
-                    p.matched_bases = n_matched;
-                    p.pident = pident;
-                    p.qbegin = qb;
-                    p.qend = qe;
-                    p.tbegin = tb;
-                    p.tend = te;
-                    res[nout++] = p;
-                    break;
-                }
-                i = j;
-            }
-            if (jneg && n_anchors > 0) {
-                n_abq += (int)qe - (int)qb + 1;
-                n_abt += (int)te - (int)tb + 1;
-                if (n_abq >= opt.min_align_len) {
-                    double pident = (double)n_matched / (double)(n_abq > n_abt ? n_abq : n_abt) * 100;
-                    if (pident >= opt.heuristic_pident) {
-                        if (pident > 100) pident = 100;
-                        LmChain2 p;
-                        p.nanchors = n_anchors;
-                        p.aligned_bases_q = n_abq;
-                        p.aligned_bases_t = n_abt;
-                        p.matched_bases = n_matched;
-                        p.pident = pident;
-                        p.qbegin = qb;
-                        p.qend = qe;
-                        p.tbegin = tb;
-                        p.tend = te;
-                        res[nout++] = p;
-                    }
-                }
-            }
-            if (i > lo) {
-                stack[sp++] = lo;
-                stack[sp++] = i;
-            }
-            if (mi != hi - 1) {
-                stack[sp++] = mi + 1;
-                stack[sp++] = hi;
-            }
-        }
-        for (int i = 1; i < nout; i++) { // stable sort by QBegin (lib-seq_compare.go:501-508)
-            LmChain2 x = res[i];
-            int j = i - 1;
-            while (j >= 0 && res[j].qbegin > x.qbegin) {
-                res[j + 1] = res[j];
-                j--;
-            }
-            res[j + 1] = x;
-        }
-    }
-    return nout;
-}
-
-// RING: the DP keeps the recent anchors and scores in an LDS ring (lm_pa_chain_dp_core.h); otherwise every step goes
-// through global memory (kept for comparison: LM_PA_CHAIN_RING=0)
-template <bool RING, int WPE = 1> // (WPE: wavefronts per SIMD the register allocation is held to)
+// (Forms measured against this one on one resident index and removed in round 5: the DP through global memory, 152 -> 130 ms per
+// C4 launch; the backtrack by lane 0 and ClearSubstrPairs by binary search in global memory, C3 9.85 -> 10.0 s, C4 shard 1.47 ->
+// 1.56 s per step; the DP of long windows pipelined over the eight wavefronts of a workgroup, C4 shard 1.47 vs 1.44 s without.)
+template <int WPE = 1, bool DPREG = true> // (WPE: wavefronts per SIMD the register allocation is held to; DPREG: pa_chain_dp_reg)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void k_pa_chain_wave(const uint64_t *__restrict__ B, const int64_t *__restrict__ pa_off,
                                                        int64_t ntasks, int K, LmChain2Opt opt, LmSub *__restrict__ subs_pool,
                                                        uint8_t *__restrict__ marks_pool, uint64_t *__restrict__ msi_pool,
                                                        int32_t *__restrict__ stack_pool, LmChain2 *__restrict__ out_pool,
                                                        int32_t *__restrict__ out_n, int32_t *__restrict__ clr_n, int qbits,
-                                                       int tbits, int pipe_min, int32_t *__restrict__ long_tasks,
-                                                       unsigned int *__restrict__ nlong, int bt_wave,
+                                                       int tbits,
                                                        unsigned long long *__restrict__ dbg) {
     const int lane = threadIdx.x;
     __shared__ PcdLds pcd_lds;
@@ -1750,33 +1651,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
         __syncthreads();
         // ---- ClearSubstrPairs (lib-index-search.go:927-972): anchor i+1 is dropped when nested in an earlier one ----
         if (n > 1) {
-            if (bt_wave & 2) pa_clear_marks_wave(sb, n, K, marks, (PccLds *)&pcd_lds);
-            for (int i = lane; i < n && !(bt_wave & 2); i += 64) {
-                uint8_t mk = 0;
-                if (i >= 1) {
-                    const LmSub v = sb[i];
-                    int32_t vqend = v.qbegin + v.len;
-                    int32_t upbound = vqend - K;
-                    if (upbound < 0) upbound = 0;
-                    int32_t vtend = v.tbegin + v.len;
-                    int lo = 0, hi = i;
-                    while (lo < hi) {
-                        int mid = (lo + hi) >> 1;
-                        if (sb[mid].qbegin < upbound)
-                            lo = mid + 1;
-                        else
-                            hi = mid;
-                    }
-                    for (int j = lo; j < i; j++) {
-                        const LmSub p = sb[j];
-                        if (vqend <= p.qbegin + p.len && v.tbegin >= p.tbegin && vtend <= p.tbegin + p.len) {
-                            mk = 1;
-                            break;
-                        }
-                    }
-                }
-                marks[i] = mk;
-            }
+            pa_clear_marks_wave(sb, n, K, marks, (PccLds *)&pcd_lds); // (lm_pa_clear_tile.h)
             __syncthreads();
             int w = 0; // ordered in-place compaction, chunk by chunk
             for (int c = 0; c < n; c += 64) {
@@ -1804,13 +1679,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
             continue;
         }
         const LmSub *a_ = sb + start;
-        if (pipe_min > 0 && n > pipe_min) { // a long window: its DP and backtrack by a workgroup (k_pa_chain_pipe)
-            if (lane == 0) {
-                out_n[ti] = start;
-                long_tasks[atomicAdd(nlong, 1u)] = (int32_t)ti;
-            }
-            continue;
-        }
         if (n == 1) {
             if (lane == 0) out_n[ti] = lm_run_chain2(a_, 1, opt, msi, stack_pool + 2 * o + 4 * ti, res);
             continue;
@@ -1819,76 +1687,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
         if (dbg) d_1 = wall_clock64();
         long long M = 0;
         int Mi = 0;
-        if (RING) {
+        if (DPREG) // (lm_pa_chain_dp_core.h: the last 64 anchors in registers / all of the recent ones in the LDS ring)
+            pa_chain_dp_reg(a_, n, opt, msi, &pcd_lds, &M, &Mi);
+        else
             pa_chain_dp_ring(a_, n, opt, msi, &pcd_lds, &M, &Mi);
-            __threadfence_block();
-        } else {
-            if (lane == 0) msi[0] = (uint64_t)a_[0].len << 32;
-            for (int i = 1; i < n; i++) {
-                __syncthreads();
-                const LmSub a = a_[i];
-                unsigned long long best = 0; // (score<<32 | ~j) of the best candidate so far, 0 = none
-                int bcount = 0;
-                bool stop = false;
-                for (int jt = i - 1; jt >= 0 && !stop; jt -= 64) {
-                    int j = jt - lane;
-                    bool inb = j >= 0;
-                    LmSub b;
-                    bool skip = true;
-                    if (inb) {
-                        b = a_[j];
-                        skip = (b.qbegin == a.qbegin || b.tbegin > a.tbegin);
-                    }
-                    unsigned long long nskip = __ballot(!skip);
-                    int cnt = bcount + __popcll(nskip & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull)));
-                    bool brk = false;
-                    if (!skip) {
-                        int32_t bbase = a.qbegin - b.qbegin - (int32_t)b.len;
-                        brk = !(bbase <= opt.band_base || cnt <= opt.band_count);
-                    }
-                    unsigned long long bm = __ballot(brk);
-                    int first_brk = bm ? (__ffsll((long long)bm) - 1) : 64;
-                    if (bm) stop = true;
-                    if (!skip && lane < first_brk) {
-                        int32_t qd = a.qbegin - b.qbegin, td = a.tbegin - b.tbegin;
-                        if (qd < 0) qd = -qd;
-                        if (td < 0) td = -td;
-                        int32_t g = qd > td ? qd - td : td - qd;
-                        if (g <= opt.max_gap) {
-                            long long s = (long long)(msi[j] >> 32) + (long long)b.len - (long long)g;
-                            if (s >= 0) {
-                                unsigned long long key = ((unsigned long long)s << 32) | (unsigned long long)(0xffffffffu - (uint32_t)j);
-                                if (key > best) best = key;
-                            }
-                        }
-                    }
-                    bcount += __popcll(nskip);
-                }
-                best = wave_max_u64(best);
-                long long m = a.len;
-                int mj = i;
-                if (best != 0) {
-                    long long s = (long long)(best >> 32);
-                    if (s >= m) {
-                        m = s;
-                        mj = (int)(0xffffffffu - (uint32_t)(best & 0xffffffffu));
-                    }
-                }
-                if (lane == 0) msi[i] = ((uint64_t)m << 32) | (uint64_t)(uint32_t)mj;
-                if (m > M) {
-                    M = m;
-                    Mi = i;
-                }
-            }
-        }
+        __threadfence_block();
         __syncthreads();
-        // ---- backtrack (lm_chain2_backtrack), or the hand-over of a long window to k_pa_chain_pipe ----
+        // ---- backtrack by the wavefront: region scans by 64 lanes, the walk out of LDS tiles (lm_pa_chain_bt.h) ----
         if (dbg) d_2 = wall_clock64();
-        if (bt_wave & 1) { // by the wavefront: region scans by 64 lanes, the walk out of LDS tiles (lm_pa_chain_bt.h)
+        {
             const int no = pa_chain_backtrack_wave(a_, n, opt, msi, M, Mi, stack_pool + 2 * o + 4 * ti, res, &pcb_lds);
             if (lane == 0) out_n[ti] = no;
-        } else if (lane == 0) {
-            out_n[ti] = lm_chain2_backtrack(a_, n, opt, msi, M, Mi, stack_pool + 2 * o + 4 * ti, res);
         }
         if (dbg && lane == 0) {
             const unsigned long long d_3 = wall_clock64();
@@ -1904,7 +1713,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
     }
 }
 
-#include "lm_pa_chain_pipe.h"
 
 __global__ void k_gather_chain2(const LmChain2 *__restrict__ in, const int64_t *__restrict__ pa_off,
                                 const int32_t *__restrict__ out_n, const int64_t *__restrict__ res_off, int64_t ntasks,
@@ -2733,6 +2541,8 @@ __device__ __forceinline__ void bt_replay(const uint8_t *__restrict__ opseq, int
 // host-callable launchers
 static bool occ8 = getenv("LM_OCC8") ? atoi(getenv("LM_OCC8")) != 0 : true; // (A/B of the register cap; re-read by lm_tuning_reload through launch_set_occ8)
 void launch_set_occ8(bool on) { occ8 = on; }
+static int dp_reg_now = -1; // LM_PA_DP_REG re-read by lm_tuning_reload (A/B): k_pa_chain_wave's DP with the last 64 anchors in registers (default) or in the LDS ring
+void launch_set_dp_reg(int on) { dp_reg_now = on; }
 static inline int grid_for(int64_t n, int block, int maxb = 2048 * 8) {
     int64_t g = (n + block - 1) / block;
     if (g < 1) g = 1;
@@ -2886,31 +2696,24 @@ void launch_pa_task_off_sorted(hipStream_t st, const uint64_t *sortedA, int shif
 }
 void launch_pa_chain(hipStream_t st, const uint64_t *B, const int64_t *pa_off, int64_t ntasks, int K, LmChain2Opt opt,
                      LmSub *subs, uint8_t *marks, uint64_t *msi, int32_t *stack, LmChain2 *out, int32_t *out_n,
-                     int32_t *clr_n, int qbits, int tbits, bool ring, int pipe_min, int64_t total, int bt_wave) {
+                     int32_t *clr_n, int qbits, int tbits) {
     int g = (int)(ntasks < 1 ? 1 : (ntasks > 262144 ? 262144 : ntasks));
-    // pipe_min > 0: the list of long windows and its counter live behind the stacks (stack holds 2 * total + 5 * ntasks + 48 ints)
-    int32_t *long_tasks = stack + 2 * total + 4 * ntasks + 8;
-    unsigned int *nlong = (unsigned int *)(long_tasks + ntasks);
-    static const bool pa_dbg = getenv("LM_DEBUG_PA_CHAIN") != nullptr; // phase times of k_pa_chain_wave (stack holds 16 more ints)
+    static const bool pa_dbg = getenv("LM_DEBUG_PA_CHAIN") != nullptr; // phase times of k_pa_chain_wave
     static unsigned long long *d_pa_dbg = nullptr; // (its own small buffer: 16 counters)
     if (pa_dbg && !d_pa_dbg && hipMalloc((void **)&d_pa_dbg, 16 * sizeof(unsigned long long)) != hipSuccess) d_pa_dbg = nullptr;
     unsigned long long *dbg = pa_dbg ? d_pa_dbg : nullptr;
     if (dbg) (void)hipMemsetAsync(dbg, 0, 16 * sizeof(unsigned long long), st);
-    if (pipe_min > 0) (void)hipMemsetAsync(nlong, 0, sizeof(unsigned int), st);
-    hipLaunchKernelGGL(ring ? (occ8 ? k_pa_chain_wave<true, 8> : k_pa_chain_wave<true>) : k_pa_chain_wave<false>, dim3(g), dim3(64), 0, st, B, pa_off, ntasks, K, opt, subs, marks, msi, stack, out, out_n,
-                       clr_n, qbits, tbits, pipe_min, long_tasks, nlong, bt_wave, dbg);
-    if (pipe_min > 0) // (the number of long windows is known on the device only: a grid that fills the chip, workgroups loop)
-        hipLaunchKernelGGL(k_pa_chain_pipe, dim3((unsigned)(ntasks < 1024 ? (ntasks < 1 ? 1 : ntasks) : 1024)), dim3(PCP_NW * 64), 0, st, pa_off, long_tasks,
-                           nlong, opt, subs, msi, stack, out, out_n, clr_n, bt_wave & 1);
+    static const bool dp_reg_env = getenv("LM_PA_DP_REG") ? atoi(getenv("LM_PA_DP_REG")) != 0 : true;
+    const bool dpr = dp_reg_now < 0 ? dp_reg_env : dp_reg_now != 0;
+    hipLaunchKernelGGL(dpr ? (occ8 ? k_pa_chain_wave<8, true> : k_pa_chain_wave<1, true>) : (occ8 ? k_pa_chain_wave<8, false> : k_pa_chain_wave<1, false>), dim3(g), dim3(64), 0, st, B, pa_off, ntasks, K, opt, subs, marks, msi, stack, out, out_n,
+                       clr_n, qbits, tbits, dbg);
     if (dbg) {
         unsigned long long h[16] = {0};
-        unsigned int nl = 0;
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost);
-        (void)hipMemcpy(&nl, nlong, sizeof nl, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[lm] k_pa_chain: %lld windows (%llu finished by the wavefront kernel, %u handed to the workgroup kernel), wavefront-ms: clear+trim %.1f, DP %.1f, backtrack %.1f; "
+        fprintf(stderr, "[lm] k_pa_chain: %lld windows (%llu with a DP), wavefront-ms: clear+trim %.1f, DP %.1f, backtrack %.1f; "
                         "by anchors left {windows, anchors, wavefront-ms}: 2-8 {%llu, %llu, %.1f} 9-64 {%llu, %llu, %.1f} 65-256 {%llu, %llu, %.1f} 257+ {%llu, %llu, %.1f}\n",
-                (long long)ntasks, h[3], pipe_min > 0 ? nl : 0u, (double)h[0] / 1e5, (double)h[1] / 1e5, (double)h[2] / 1e5, h[4], h[5], (double)h[6] / 1e5, h[7], h[8],
+                (long long)ntasks, h[3], (double)h[0] / 1e5, (double)h[1] / 1e5, (double)h[2] / 1e5, h[4], h[5], (double)h[6] / 1e5, h[7], h[8],
                 (double)h[9] / 1e5, h[10], h[11], (double)h[12] / 1e5, h[13], h[14], (double)h[15] / 1e5);
     }
 }

@@ -36,4 +36,26 @@ __device__ __forceinline__ unsigned long long pcd_wave_max_u64(unsigned long lon
 #define PCD_FFSLL(x) __ffsll((long long)(x))
 #define PCD_WAVE_MAX_U64(v) pcd_wave_max_u64(v)
 
+// one-lane wavefront shift: lane 0 <- the wave-uniform `newv`, lane l <- lane l - 1 (DPP wave_shr:1; lane 0 has no source and keeps `old`)
+__device__ __forceinline__ int pcd_shift_in(int newv, int v) { return __builtin_amdgcn_update_dpp(newv, v, 0x138, 0xf, 0xf, false); }
+#define PCD_SHIFT_IN(newv, v) pcd_shift_in((int)(newv), (int)(v))
+// signed maximum over the wavefront, in every lane (the DPP steps of wave_min_i32, lm_kernels.hip)
+__device__ __forceinline__ int pcd_wave_max_i32(int v) {
+    int x = __builtin_amdgcn_mov_dpp(v, 0xb1, 0xf, 0xf, false);
+    v = x > v ? x : v;
+    x = __builtin_amdgcn_mov_dpp(v, 0x4e, 0xf, 0xf, false);
+    v = x > v ? x : v;
+    x = __builtin_amdgcn_mov_dpp(v, 0x124, 0xf, 0xf, false);
+    v = x > v ? x : v;
+    x = __builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, false);
+    v = x > v ? x : v;
+    x = __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false);
+    v = x > v ? x : v;
+    x = __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false);
+    v = x > v ? x : v;
+    return __builtin_amdgcn_readlane(v, 63);
+}
+#define PCD_WAVE_MAX_I32(v) pcd_wave_max_i32(v)
+#define PCD_CLZLL(x) __clzll((long long)(x))
+
 #include "lm_pa_chain_dp_core.h"

@@ -532,7 +532,9 @@ static void stage_mask(Work &w) {
                 w.first_mask.p);
 }
 
-struct PartTooLarge : std::exception {};
+struct PartTooLarge : std::exception {
+    double over = 2.0; // how many times the part's seed anchors exceed what one pass may hold
+};
 struct ChunkTooLarge : std::exception {};
 
 static void stage_lookup(Work &w, lm_stage_stats &stats) {
@@ -594,7 +596,10 @@ static void stage_lookup(Work &w, lm_stage_stats &stats) {
     if (T >= (int64_t)1 << 31 || (BUDGET(ix) > 0 && T * 96 > BUDGET(ix) * 22 / 100) ||
         (dbg_max && qb->nq > 1 && T > atoll(dbg_max))) {
         if (qb->nq <= 1) throw HipError("one query yields more seed anchors than the device can hold");
-        throw PartTooLarge();
+        PartTooLarge e;
+        e.over = std::max(T >= (int64_t)1 << 31 ? (double)T / 2147483647.0 : 1.0, BUDGET(ix) > 0 ? (double)T * 96.0 / ((double)BUDGET(ix) * 0.22) : 1.0);
+        if (dbg_max) e.over = std::max(e.over, (double)T / (double)std::max<long long>(1, atoll(dbg_max)));
+        throw e;
     }
     {   // (only for a part that goes on: a part thrown back for halving is searched again as two)
         // algorithmic bytes of the lookup, SURVEY.md §8(d) as written (reference-format sizes): per ISSUED lookup one
@@ -982,6 +987,41 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
         h2d(ix, ix->d_pfx_first, pfx);
         int gstatus = 0;
         const double t_g0 = now_ms();
+        // The packed bases go from the batch file's buffer (registered with the driver while its genomes are copied) straight to
+        // their place on the device, on the reader's own stream: no host copy of the genome store (12.5 GB at C2 size: appending
+        // to it and uploading it from pageable memory afterwards was 8 s of a 9.7-s open once the seed passes took 4.3 s).
+        ix->d_gbits.alloc_exact(h.gbits_bound + 64, true, S(ix)); // zero-filled: the padding behind every genome
+        sync(ix);
+        struct GenomeSink {
+            hipStream_t st = nullptr;
+            void *reg = nullptr;
+            uint8_t *dst = nullptr;
+            size_t cap = 0;
+            ~GenomeSink() {
+                if (st) (void)hipStreamSynchronize(st);
+                if (reg) (void)hipHostUnregister(reg);
+                if (st) (void)hipStreamDestroy(st);
+            }
+        } gsink;
+        gsink.dst = ix->d_gbits.p;
+        gsink.cap = h.gbits_bound + 64;
+        HIPCHK(hipStreamCreateWithFlags(&gsink.st, hipStreamNonBlocking));
+        const int gdev = device;
+        h.gbits_batch_begin = [&gsink, gdev](const uint8_t *buf, size_t bytes) {
+            (void)hipSetDevice(gdev);
+            if (gsink.reg) (void)hipHostUnregister(gsink.reg);
+            gsink.reg = bytes && !getenv("LM_LOADER_NO_PIN") && hipHostRegister((void *)buf, bytes, hipHostRegisterDefault) == hipSuccess ? (void *)buf : nullptr;
+            if (!gsink.reg) (void)hipGetLastError(); // pageable copies then: slower, not wrong
+        };
+        h.gbits_sink = [&gsink](const uint8_t *src, size_t nbytes, int64_t off) {
+            if (off < 0 || (size_t)off + nbytes + 16 > gsink.cap) return false;
+            return hipMemcpyAsync(gsink.dst + off, src, nbytes, hipMemcpyHostToDevice, gsink.st) == hipSuccess;
+        };
+        h.gbits_batch_end = [&gsink]() {
+            (void)hipStreamSynchronize(gsink.st); // the buffer is read into again
+            if (gsink.reg) (void)hipHostUnregister(gsink.reg);
+            gsink.reg = nullptr;
+        };
         std::future<std::string> gfut = std::async(std::launch::async, [&]() { return load_index_genomes(dir, h, gstatus); });
         const int64_t max_len = h.max_genome_len;
         h2d(ix, ix->d_batch_first, h.batch_first);
@@ -1079,7 +1119,7 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
                 }
                 size_t fr = 0, tot = 0;
                 if (hipMemGetInfo(&fr, &tot) == hipSuccess) // (image: <= ~0.55 bytes per file byte measured; 0.75 reserved)
-                    keep_budget = (int64_t)fr - files_bytes * 3 / 4 / (int64_t)std::max(1, h.shard_count) - (int64_t)h.gbits_bound - ((int64_t)6 << 30);
+                    keep_budget = (int64_t)fr - files_bytes * 3 / 4 / (int64_t)std::max(1, h.shard_count) - ((int64_t)6 << 30); // (the genome store is allocated already)
                 if (getenv("LM_LOADER_NO_KEEP")) keep_budget = 0;
             }
             int64_t n_kept_files = 0;
@@ -1209,10 +1249,9 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
                 return LM_ERR_FORMAT;
             }
         }
-        ix->d_gbits.alloc_exact(h.gbits.size() + 64); // k-mer extraction reads whole aligned words past the last base
-        if (!h.gbits.empty())
-            HIPCHK(hipMemcpyAsync(ix->d_gbits.p, h.gbits.data(), h.gbits.size(), hipMemcpyHostToDevice, S(ix)));
-        HIPCHK(hipMemsetAsync(ix->d_gbits.p + h.gbits.size(), 0, 64, S(ix)));
+        h.gbits_batch_begin = nullptr; // (they refer to this frame)
+        h.gbits_sink = nullptr;
+        h.gbits_batch_end = nullptr;
         std::vector<int64_t> goff;
         std::vector<int32_t> glen;
         std::vector<uint64_t> gbg;
@@ -1230,7 +1269,7 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
         v.gbits = ix->d_gbits.p;
         v.g_off = ix->d_g_off.p;
         v.g_len = ix->d_g_len.p;
-        ix->hbm_bytes = ix->seed_bytes + (int64_t)(h.masks.size() * 8 + pfx.size() * 4 + h.gbits.size() + 64 + goff.size() * 20 +
+        ix->hbm_bytes = ix->seed_bytes + (int64_t)(h.masks.size() * 8 + pfx.size() * 4 + (size_t)h.gbits_total + 64 + goff.size() * 20 +
                                                    h.batch_first.size() * 8);
         // the host copy of the packed genomes is no longer needed
         std::vector<uint8_t>().swap(h.gbits);
@@ -1299,6 +1338,7 @@ void lm_tuning_reload(lm_index *ix) {
     std::lock_guard<std::mutex> lock(ix->mu);
     lm_tune fresh;
     launch_set_occ8(getenv("LM_OCC8") ? atoi(getenv("LM_OCC8")) != 0 : true);
+    launch_set_dp_reg(getenv("LM_PA_DP_REG") ? (atoi(getenv("LM_PA_DP_REG")) != 0 ? 1 : 0) : 1);
     if (ix->tune.wfa_dump) fclose(ix->tune.wfa_dump);
     if (ix->tune.wfa_waves) fclose(ix->tune.wfa_waves);
     fresh.wfa_serial = fresh.wfa_serial || ix->tune.wfa_serial;   // (owned by lm_profile_exclusive: a reload does not undo it)
@@ -1766,8 +1806,7 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
         {
             Prof p(ix, "k_pa_chain", TP * 32);
             launch_pa_chain(S(ix), a.B0.p, a.pa_off.p, nt, ix->host.k, o2, a.subs.p, a.marks.p, a.msi.p, a.stack.p,
-                            a.out.p, a.out_n.p, a.clr_n.p, compact ? qbits : 0, compact ? tbits : 0, ix->tune.pa_chain_ring != 0,
-                            ix->tune.pa_chain_pipe ? ix->tune.pa_pipe_min : 0, TP, ix->tune.pa_chain_bt_wave);
+                            a.out.p, a.out_n.p, a.clr_n.p, compact ? qbits : 0, compact ? tbits : 0);
         }
         a.res_off.ensure((size_t)nt + 2);
         int64_t NR = scan_to_i64<int32_t, CastI32>(ix, a.out_n.p, nt, a.res_off.p);
@@ -3335,6 +3374,42 @@ static void search_impl(lm_index *ix, lm_qbatch *qb, lm_result *res, const Searc
 } // namespace lm
 
 // two new batch parts from the host copy of the bases of `src` (a part, or the plain batch itself)
+// A part thrown back because its seed anchors are `over` times what one pass may hold is cut into ceil(1.15 x over) pieces of
+// about equal numbers of query BASES at once: halving it again and again searched the seeding stages of the same queries up to
+// three times over in the first step of a fresh C3 batch (11.3 s where the settled step takes 9.7).
+static std::vector<lm_qbatch *> split_qbatch(lm_index *ix, lm_qbatch *src, double over) {
+    const size_t nq = (size_t)src->nq;
+    if (nq < 2) throw HipError("one query yields more seed anchors than the device can hold");
+    size_t k = (size_t)std::ceil(std::max(1.0, over) * 1.15);
+    k = std::max<size_t>(2, std::min(k, nq));
+    std::vector<lm_query> qs(nq);
+    int64_t bases = 0;
+    for (size_t i = 0; i < nq; i++) {
+        qs[i].seq = src->h_seq.data() + src->h_qoff[i];
+        qs[i].len = (uint32_t)(src->h_qoff[i + 1] - src->h_qoff[i]);
+        bases += qs[i].len;
+    }
+    std::vector<lm_qbatch *> out;
+    try {
+        size_t b = 0;
+        int64_t acc = 0; // bases of the queries before b
+        for (size_t piece = 0; piece < k; piece++) {
+            size_t e = b + 1; // every piece takes at least one query and leaves one for each piece behind it
+            int64_t a2 = acc + qs[b].len;
+            const int64_t want = bases * (int64_t)(piece + 1) / (int64_t)k;
+            while (piece + 1 < k && e < nq - (k - 1 - piece) && a2 + qs[e].len / 2 <= want) a2 += qs[e++].len;
+            if (piece + 1 == k) e = nq;
+            out.push_back(upload_part(ix, qs.data() + b, e - b, src->q0 + (uint32_t)b));
+            for (size_t i = b; i < e; i++) acc += qs[i].len;
+            b = e;
+        }
+    } catch (...) {
+        for (auto *p : out) delete p;
+        throw;
+    }
+    if (getenv("LM_DEBUG")) fprintf(stderr, "[lm] batch part of %zu queries cut into %zu (seed anchors %.2f x the scratch budget's share)\n", nq, out.size(), over);
+    return out;
+}
 static std::pair<lm_qbatch *, lm_qbatch *> halve_qbatch(lm_index *ix, lm_qbatch *src) {
     const size_t nq = (size_t)src->nq, h = nq / 2;
     if (nq < 2) throw HipError("one query yields more seed anchors than the device can hold");
@@ -3382,10 +3457,12 @@ static void search_parts(lm_index *ix, lm_qbatch *qb, lm_result *res, const Sear
     lm_reserve_lane_slabs(ix); // once per handle (LaneSlabs, lm_internal.h); a production-size index did it when it was opened
     if (qb->parts.empty()) {
         ix->lane_slabs.assign(ix->arena[0], ix->arena[1], 1); // (false: a block is live - the assignment stays, overflow slabs serve)
+        double over = 0;
         try {
             search_impl(ix, qb, res, ctl);
             return;
-        } catch (const PartTooLarge &) {
+        } catch (const PartTooLarge &e) {
+            over = e.over;
         } catch (const DeviceOOM &e) { // the shares of the scratch budget are estimates: retry on half the queries
             if (qb->nq < 2) throw;
             drop_scratch(ix, e.what());
@@ -3395,8 +3472,12 @@ static void search_parts(lm_index *ix, lm_qbatch *qb, lm_result *res, const Sear
         res->strings.clear();
         res->rows.clear();
         res->stats = lm_stage_stats();
-        auto ab = halve_qbatch(ix, qb);
-        qb->parts = {ab.first, ab.second};
+        if (over > 0) {
+            qb->parts = split_qbatch(ix, qb, over);
+        } else {
+            auto ab = halve_qbatch(ix, qb);
+            qb->parts = {ab.first, ab.second};
+        }
         qb->d_seq.release(); // the plain batch's own device copy is no longer used
         qb->d_qoff.release();
         qb->d_posoff.release();
@@ -3452,10 +3533,12 @@ static void search_parts(lm_index *ix, lm_qbatch *qb, lm_result *res, const Sear
                     it->state = 1;
                 }
                 bool split = false;
+                double over = 0;
                 try {
                     search_impl(ix, it->part, &it->res, ctl);
-                } catch (const PartTooLarge &) {
+                } catch (const PartTooLarge &e) {
                     split = true;
+                    over = e.over;
                     if (getenv("LM_DEBUG_MEM")) fprintf(stderr, "[lm] lane %d: a part of %d queries is halved: its seed anchors exceed the lane's share of the budget\n", lane, it->part->nq);
                 } catch (const DeviceOOM &e) {
                     if (it->part->nq < 2) throw;
@@ -3464,18 +3547,26 @@ static void search_parts(lm_index *ix, lm_qbatch *qb, lm_result *res, const Sear
                     split = true;
                 }
                 if (split) {
-                    auto ab = halve_qbatch(ix, it->part);
+                    std::vector<lm_qbatch *> pieces;
+                    if (over > 0) {
+                        pieces = split_qbatch(ix, it->part, over);
+                    } else {
+                        auto ab = halve_qbatch(ix, it->part);
+                        pieces = {ab.first, ab.second};
+                    }
                     std::lock_guard<std::mutex> l(lm_);
                     delete it->part;
-                    it->part = ab.first; // this entry becomes the first half, the second half follows it
+                    it->part = pieces[0]; // this entry becomes the first piece, the others follow it in order
                     it->state = 0;
                     for (auto *str : it->res.strings) delete str;
                     it->res.strings.clear();
                     it->res.rows.clear();
                     auto nx = std::next(it);
-                    auto ins = todo.emplace(nx);
-                    ins->part = ab.second;
-                    ins->state = 0;
+                    for (size_t pi = 1; pi < pieces.size(); pi++) {
+                        auto ins = todo.emplace(nx);
+                        ins->part = pieces[pi];
+                        ins->state = 0;
+                    }
                 } else {
                     std::lock_guard<std::mutex> l(lm_);
                     it->state = 2;

@@ -18,8 +18,9 @@ def test_single_rank_communicator_gathers_counts_and_rows_and_feeds_the_c_merge(
     try:
         rng = np.random.default_rng(4)
         rows = np.zeros(5000, dtype=merge.ROW_DTYPE)
-        rows["query"] = np.sort(rng.integers(0, 50, 5000))
-        rows["batch_genome"] = rng.integers(0, 1000, 5000)
+        qs, gs = rng.integers(0, 50, 5000), rng.integers(0, 1000, 5000)
+        o = np.lexsort((gs, qs))   # as a search returns them: grouped by query, a genome's rows together
+        rows["query"], rows["batch_genome"] = qs[o], gs[o]
         rows["bitscore"] = rng.integers(50, 3000, 5000)
         rows["pident"] = rng.integers(70, 101, 5000).astype(np.float64)
         rows["genome_id"] = 12345  # a process-local address: cleared by the gather

@@ -130,11 +130,12 @@ def test_batch_split_into_parts_gives_the_same_rows(lr_index, lr_queries, monkey
 
 
 def test_rows_do_not_depend_on_which_device_implementation_of_a_stage_runs(lr_index, lr_queries, monkeypatch):
-    """LM_WFA_MW (512 / 1024-diagonal WFA passes: a workgroup of four wavefronts or one wavefront per alignment),
-    LM_PA_CHAIN_RING (Chainer2 DP with the recent anchors in LDS or through global memory), LM_WFA_R16 (16- or 32-bit ring
-    cells in the short WFA classes) and LM_WFA_AK_MARGIN (problems started at the ring width |tlen - qlen| predicts, or all at
-    their class's width) and LM_LOOKUP_FLAT (seed anchors emitted with the lanes over the output or over the lookups) choose
-    between device paths that must agree to the byte: the rows of the long-read fixture (equal to the oracle's by the first test) with each switch off"""
+    """LM_WFA_MW (512 / 1024-diagonal WFA passes: a workgroup of four wavefronts or one wavefront per alignment), LM_OCC8 (the
+    register cap of the two kernels it applies to), LM_WFA_R16 (16- or 32-bit ring cells in the short WFA classes),
+    LM_WFA_AK_MARGIN (problems started at the ring width |tlen - qlen| predicts, or all at their class's width), LM_LOOKUP_FLAT
+    (seed anchors emitted with the lanes over the output or over the lookups), LM_PA_FILTER_ROLL (window positions consecutive
+    per lane or strided) and LM_ARENA_RESERVE_PCT (lane slabs or slabs on demand) choose between device paths that must agree
+    to the byte: the rows of the long-read fixture (equal to the oracle's by the first test) with each switch flipped"""
     la = _la()
     d, _ = lr_index
     seqs = [q[1] for q in lr_queries]
@@ -144,7 +145,7 @@ def test_rows_do_not_depend_on_which_device_implementation_of_a_stage_runs(lr_in
     ran = {p["name"] for p in gi.profile_get() if p["launches"] > 0}
     gi.close()
     assert any(n.startswith("k_wfa_mw") for n in ran), ran   # the fixture does reach the wide passes
-    for var, off in (("LM_WFA_MW", "0"), ("LM_PA_CHAIN_PIPE", "0"), ("LM_PA_CHAIN_BT_WAVE", "0"), ("LM_PA_PIPE_MIN", "64"), ("LM_PA_CHAIN_RING", "0"), ("LM_WFA_R16", "0"), ("LM_WFA_AK_MARGIN", "40"),
+    for var, off in (("LM_WFA_MW", "0"), ("LM_OCC8", "0"), ("LM_WFA_R16", "0"), ("LM_WFA_AK_MARGIN", "40"),
                      ("LM_LOOKUP_FLAT", "0"), ("LM_PA_FILTER_ROLL", "0"), ("LM_ARENA_RESERVE_PCT", "0")):
         monkeypatch.setenv(var, off)
         gi = la.Index(d)      # the switches are read once per handle

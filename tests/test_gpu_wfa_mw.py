@@ -1,5 +1,5 @@
-"""GPU parity of the workgroup WFA passes (k_wfa_mw<2 / 4, WIN>: four wavefronts per alignment, 512 / 1024 diagonals) and of
-the switches that choose between two device implementations of one stage (LM_WFA_MW, LM_PA_CHAIN_RING): every form against
+"""GPU parity of the workgroup WFA passes (k_wfa_mw2<2 / 4, WIN>: four wavefronts per alignment, 512 / 1024 diagonals) and of
+the switch that chooses between two device implementations of the wide passes (LM_WFA_MW): either form against
 the oracle (lmo_wfa_align = the restatement of wfa v0.5.0 as lib-index-search.go:2261 calls it), and the rows of the long-read
 fixture with each switch on and off.
 

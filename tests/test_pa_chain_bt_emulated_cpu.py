@@ -1,4 +1,4 @@
-"""lexicmap_amd/csrc/lm_pa_chain_bt_core.h + lm_pa_clear_tile.h (product headers, switch LM_PA_CHAIN_BT_WAVE): the backtrack of Chainer2 - regions left and
+"""lexicmap_amd/csrc/lm_pa_chain_bt_core.h + lm_pa_clear_tile.h (product headers): the backtrack of Chainer2 - regions left and
 right of every chain, the walk from anchor to predecessor, the chain statistics - by a wavefront (region scans by 64 lanes,
 the walk out of 64-anchor tiles in LDS) instead of one lane chasing pointers through global memory; on the host SIMT emulator
 against lm_run_chain2 (lm_algos.h): every chain, every field, the order after the sort by QBegin."""
