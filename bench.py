@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PROFILE_ROUND = "r04"  # profiles/<round>_<workload>_pmc_*.json: the committed counter passes roofline.traffic is read from
+PROFILE_ROUND = "r05"  # profiles/<round>_<workload>_pmc_*.json: the committed counter passes roofline.traffic is read from
 # instruction-issue peaks of the chip (MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, a wave64 VALU instruction issues over 2
 # cycles; ONE scalar unit per CU), wave-instructions per second at 2.4 GHz
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2
@@ -393,6 +393,8 @@ def main():
                 comm = None
                 gather_kind = "torch.distributed gather (lexicmap_amd/merge.py); lm_gather_rows unavailable on another rank"
 
+    comm_box = [comm, gather_kind]  # (step() may give the C gather up at run time)
+
     if args.builder is None:
         args.builder = "gpu" if args.workload in ("c2", "c3", "c4", "c5", "c3mini") else "oracle"
     wl = dict(WORKLOADS[args.workload])
@@ -606,11 +608,18 @@ def main():
                     rows["query"] = rows["query"] + rank * len(queries)  # every rank has its own batch
                 else:
                     rows["query"] = rows["query"] * world + rank  # local -> global query number (round-robin sharding)
-            if comm is not None:
-                per_rank, _cnt = comm.gather_rows(rows, root=0)
-                if per_rank is None:
-                    per_rank = [rows]
-            else:
+            per_rank = None
+            if comm_box[0] is not None:
+                try:
+                    per_rank, _cnt = comm_box[0].gather_rows(rows, root=0)
+                    if per_rank is None:
+                        per_rank = [rows]
+                except RuntimeError as e:  # reported in the line; the torch.distributed gather takes over from here on
+                    log("[rank %d] lm_gather_rows failed (%s): torch.distributed gather from now on" % (rank, e))
+                    comm_box[0] = None
+                    comm_box[1] = "torch.distributed gather (lexicmap_amd/merge.py); lm_gather_rows failed at run time: %s" % (e,)
+                    per_rank = None
+            if per_rank is None:
                 per_rank = merge.all_gather_rows(rows, device="cuda" if args.dist_backend == "nccl" else "cpu", host_on=0)
             # index shards: the library's C merge (lm_merge_sharded: final order per query + global hits) on rank 0
             rows = (merge.merge_sharded_c(per_rank) if rank == 0 else per_rank[0]) if index_sharded else \
@@ -856,7 +865,7 @@ def main():
                                        ("index-shard x%d (genome g on rank g %% %d), queries broadcast, one all-gatherv of HSP rows per step" % (world, world))
                                        if index_sharded else
                                        ("q-shard x%d (index replicated), %d queries per GPU" % (world, len(my)))),
-                       "pcie_upload_s": round(upload_s, 4), "tag": args.tag, "gather": gather_kind,
+                       "pcie_upload_s": round(upload_s, 4), "tag": args.tag, "gather": comm_box[1],
                        "go_toolchain": go or "absent (reference Go binary cannot be built; CPU baseline is the C port)"},
             "stage_ms": {k: round(v, 3) for k, v in stats.items() if k.startswith("ms_")},
             "work": {k: v for k, v in stats.items() if not k.startswith("ms_")},

@@ -44,45 +44,43 @@ bool read_all(const std::string &path, std::vector<uint8_t> &buf) {
     buf.resize((size_t)n);
     return n == 0 || f.read(buf.data(), (size_t)n);
 }
-// a big file (the genome batches: GBs each) read by several threads with pread: one thread copies out of the page cache at
-// 2-3 GB/s, which made the genomes a third of the time the loader took
-bool read_all_mt(const std::string &path, std::vector<uint8_t> &buf) {
-    const int fd = open(path.c_str(), O_RDONLY);
-    if (fd < 0) return false;
-    struct stat sb;
-    if (fstat(fd, &sb) != 0) {
-        close(fd);
-        return false;
+struct FdGuard {
+    int fd;
+    explicit FdGuard(int f) : fd(f) {}
+    ~FdGuard() {
+        if (fd >= 0) close(fd);
     }
-    const size_t n = (size_t)sb.st_size;
-    buf.resize(n);
-    const size_t piece = (size_t)64 << 20;
+};
+bool pread_all(int fd, uint8_t *dst, size_t n, size_t off) {
+    while (n) {
+        const ssize_t r = pread(fd, dst, n, (off_t)off);
+        if (r <= 0) return false;
+        dst += r;
+        off += (size_t)r;
+        n -= (size_t)r;
+    }
+    return true;
+}
+// n bytes at `off` by up to 8 threads (one thread copies out of the page cache at 2-3 GB/s)
+bool pread_all_mt(int fd, uint8_t *dst, size_t n, size_t off) {
+    const size_t piece = (size_t)32 << 20;
     const size_t npieces = (n + piece - 1) / piece;
-    unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    if (npieces < nt) nt = (unsigned)std::max<size_t>(1, npieces);
+    if (npieces <= 1) return pread_all(fd, dst, n, off);
+    const unsigned nt = (unsigned)std::min<size_t>(npieces, std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
     std::atomic<size_t> next{0};
     std::atomic<bool> ok{true};
     auto body = [&]() {
         for (;;) {
             const size_t i = next.fetch_add(1);
             if (i >= npieces) break;
-            size_t off = i * piece, left = std::min(piece, n - off);
-            while (left) {
-                const ssize_t r = pread(fd, buf.data() + off, left, (off_t)off);
-                if (r <= 0) {
-                    ok = false;
-                    return;
-                }
-                off += (size_t)r;
-                left -= (size_t)r;
-            }
+            const size_t o = i * piece, len = std::min(piece, n - o);
+            if (!pread_all(fd, dst + o, len, off + o)) ok = false;
         }
     };
     std::vector<std::thread> th;
     for (unsigned t = 1; t < nt; t++) th.emplace_back(body);
     body();
     for (auto &t : th) t.join();
-    close(fd);
     return ok;
 }
 
@@ -461,7 +459,14 @@ std::string load_index_genomes(const std::string &dir, HostIndex &out, int &stat
     int64_t global = 0, run = 0; // run: bytes of the store so far when a sink takes the bases
     const bool to_sink = (bool)out.gbits_sink;
     if (!to_sink) out.gbits.reserve(out.gbits_bound);
-    std::vector<uint8_t> ib, gb; // (reused: the batches are GBs each)
+    // A batch file (GBs) is read in RUNS of consecutive records of at most ~256 MB into one reused buffer (the loader: pinned
+    // memory of its own, gbits_buffer) - not whole: cutting, zero-filling and faulting in a buffer of the file's size cost more
+    // than reading it.  Of a record of another shard only the head is read (names and contig table: rank 0 prints every shard's
+    // rows), so a shard reads 1 / N of the genome bytes.
+    std::vector<uint8_t> ib, own;
+    size_t RUN_MAX = (size_t)256 << 20, HEAD = (size_t)256 << 10;
+    if (const char *e = getenv("LM_LOADER_RUN_BYTES")) RUN_MAX = (size_t)std::max(1ll, atoll(e)); // (tests: runs of a few records, heads of a few bytes)
+    if (const char *e = getenv("LM_LOADER_HEAD_BYTES")) HEAD = (size_t)std::max(1ll, atoll(e));
     for (int b = 0; b < out.genome_batches; b++) {
         char name[64];
         snprintf(name, sizeof name, "/genomes/batch_%04d/genomes.bin", b);
@@ -474,89 +479,150 @@ std::string load_index_genomes(const std::string &dir, HostIndex &out, int &stat
             status = 2;
             return "genome data: the batch index changed while the index was being opened";
         }
-        if (!read_all_mt(dir + name, gb) || gb.size() < 16 || memcmp(gb.data(), ".genomes", 8) != 0 || gb[8] != 0) {
-            status = gb.empty() ? 1 : 2;
+        if (24 + (size_t)nrec * 12 > ib.size()) {
+            status = 2;
+            return "genome data: broken file (index)";
+        }
+        FdGuard fd(open((dir + name).c_str(), O_RDONLY));
+        struct stat sb;
+        uint8_t magic[16];
+        if (fd.fd < 0 || fstat(fd.fd, &sb) != 0 || sb.st_size < 16 || !pread_all(fd.fd, magic, 16, 0) || memcmp(magic, ".genomes", 8) != 0 || magic[8] != 0) {
+            status = fd.fd < 0 ? 1 : 2;
             return std::string("genome data: invalid binary format: ") + name;
         }
-        if (out.gbits_batch_begin) out.gbits_batch_begin(gb.data(), gb.size());
-        for (uint32_t r = 0; r < nrec; r++, global++) {
-            // a shard keeps the bases of its own genomes only, but the names and sizes of all of them: rank 0 prints the
-            // merged rows of every shard (lm_merge_sharded)
-            const bool local = out.g2local.empty() || out.g2local[(size_t)global] >= 0;
-            if (24 + (size_t)r * 12 + 12 > ib.size()) {
+        const size_t fsize = (size_t)sb.st_size;
+        auto rec_off = [&](uint32_t r) { return r < nrec ? (size_t)be64(&ib[24 + (size_t)r * 12]) : fsize; };
+        for (uint32_t r0 = 0; r0 < nrec;) {
+            const bool local0 = out.g2local.empty() || out.g2local[(size_t)(global)] >= 0;
+            // the run: consecutive local records up to RUN_MAX bytes (at least one), or the head of ONE record of another shard
+            uint32_t r1 = r0 + 1;
+            size_t o0 = rec_off(r0), o1 = rec_off(r1);
+            if (o0 < 16 || o1 < o0 || o1 > fsize) {
                 status = 2;
                 return "genome data: broken file (index)";
             }
-            size_t p = (size_t)be64(&ib[24 + (size_t)r * 12]);
-            HostGenome g;
-            g.bg = ((uint64_t)b << 17) | r;
-            g.global = global;
-            auto it = id_of.find(g.bg);
-            if (it != id_of.end()) g.id = it->second;
-            if (p + 2 > gb.size()) {
-                status = 2;
-                return "genome data: broken file";
+            bool head_only = false;
+            if (local0) {
+                while (r1 < nrec && (out.g2local.empty() || out.g2local[(size_t)(global + (r1 - r0))] >= 0) && rec_off(r1 + 1) >= o1 &&
+                       rec_off(r1 + 1) <= fsize && rec_off(r1 + 1) - o0 <= RUN_MAX)
+                    o1 = rec_off(++r1);
+            } else if (o1 - o0 > HEAD) {
+                head_only = true;
             }
-            uint32_t idl = be16(&gb[p]);
-            p += 2 + idl;
-            if (p + 12 > gb.size()) {
-                status = 2;
-                return "genome data: broken file";
-            }
-            g.genome_size = (int32_t)be32(&gb[p]);
-            g.len = (int32_t)be32(&gb[p + 4]);
-            g.nseqs = (int32_t)be32(&gb[p + 8]);
-            p += 12;
-            for (int s = 0; s < g.nseqs; s++) {
-                if (p + 6 > gb.size()) {
+            size_t want = head_only ? HEAD : o1 - o0;
+            uint8_t *gb = nullptr;
+            for (int attempt = 0; attempt < 2; attempt++) { // (second attempt: the head of a foreign record was not all of its head)
+                if (out.gbits_buffer) {
+                    gb = out.gbits_buffer(want + 16);
+                } else {
+                    if (own.size() < want + 16) own.resize(want + 16);
+                    gb = own.data();
+                }
+                if (!gb || !pread_all_mt(fd.fd, gb, want, o0)) {
+                    status = 1;
+                    return std::string("genome data: cannot read ") + name;
+                }
+                const size_t gbn = want;
+                bool again = false;
+                const int64_t global0 = global, run0 = run;
+                const size_t ng0 = out.genomes.size(), no0 = out.others.size();
+                for (uint32_t r = r0; r < r1 && !again; r++, global++) {
+                    const bool local = local0; // (a run is all local, or one foreign record)
+                    size_t p = rec_off(r) - o0;
+                    const size_t rend = head_only ? gbn : rec_off(r + 1) - o0;
+                    HostGenome g;
+                    g.bg = ((uint64_t)b << 17) | r;
+                    g.global = global;
+                    auto it = id_of.find(g.bg);
+                    if (it != id_of.end()) g.id = it->second;
+                    auto short_of = [&](size_t need) { // true: the record's bytes end before `need`
+                        if (need <= rend) return false;
+                        if (head_only) again = true; // (read the whole record)
+                        return true;
+                    };
+                    if (short_of(p + 2)) break;
+                    uint32_t idl = be16(&gb[p]);
+                    p += 2 + idl;
+                    if (short_of(p + 12)) break;
+                    g.genome_size = (int32_t)be32(&gb[p]);
+                    g.len = (int32_t)be32(&gb[p + 4]);
+                    g.nseqs = (int32_t)be32(&gb[p + 8]);
+                    p += 12;
+                    bool cut = false;
+                    for (int s = 0; s < g.nseqs; s++) {
+                        if (short_of(p + 6)) {
+                            cut = true;
+                            break;
+                        }
+                        g.seq_sizes.push_back((int32_t)be32(&gb[p]));
+                        uint32_t l = be16(&gb[p + 4]);
+                        p += 6;
+                        if (short_of(p + l)) {
+                            cut = true;
+                            break;
+                        }
+                        g.seq_ids.emplace_back((const char *)&gb[p], l);
+                        p += l;
+                    }
+                    if (cut || short_of(p + 8)) break;
+                    uint32_t nbytes = be32(&gb[p]);
+                    p += 8;
+                    if (!local) { // (its bases are another shard's: not read at all when the record is longer than its head)
+                        if (o0 + p + nbytes > o1) {
+                            status = 2;
+                            return "genome data: broken file";
+                        }
+                        out.other_of[g.bg] = (int)out.others.size();
+                        out.others.push_back(std::move(g));
+                        continue;
+                    }
+                    if (p + nbytes > rend) {
+                        status = 2;
+                        return "genome data: broken file";
+                    }
+                    if ((int64_t)g.len > out.max_genome_len) {
+                        // (the seed packer sized its position field from the .idx tables before this file was read: a record longer
+                        // than its index entry says would have its positions packed into too few bits)
+                        status = 2;
+                        return std::string("genome data: a record of ") + name + " is longer than its genomes.bin.idx entry says";
+                    }
+                    if (to_sink) { // (same offsets as the host store: 8 .. 15 bytes of padding behind every genome)
+                        g.bits_off = run;
+                        if (!out.gbits_sink(gb + p, nbytes, run)) {
+                            status = 2;
+                            return std::string("genome data: the packed bases of ") + name + " exceed what the batch indexes announced";
+                        }
+                        run = (run + (int64_t)nbytes + 15) & ~(int64_t)7;
+                    } else {
+                        g.bits_off = (int64_t)out.gbits.size();
+                        out.gbits.insert(out.gbits.end(), gb + p, gb + p + nbytes);
+                        // pad so that 8-byte loads near the end of a genome stay inside the buffer
+                        size_t padded = (out.gbits.size() + 15) & ~(size_t)7;
+                        out.gbits.resize(padded, 0);
+                    }
+                    out.genomes.push_back(std::move(g));
+                }
+                if (out.gbits_batch_end) out.gbits_batch_end(); // (the buffer is read into again)
+                if (!again) {
+                    if (global != global0 + (int64_t)(r1 - r0)) { // a record ended before its fields did
+                        status = 2;
+                        return "genome data: broken file";
+                    }
+                    break;
+                }
+                if (attempt == 1) {
                     status = 2;
                     return "genome data: broken file";
                 }
-                g.seq_sizes.push_back((int32_t)be32(&gb[p]));
-                uint32_t l = be16(&gb[p + 4]);
-                p += 6;
-                g.seq_ids.emplace_back((const char *)&gb[p], l);
-                p += l;
+                global = global0; // the whole record this time
+                run = run0;
+                out.genomes.resize(ng0);
+                out.others.resize(no0);
+                head_only = false;
+                want = o1 - o0;
             }
-            if (p + 8 > gb.size()) {
-                status = 2;
-                return "genome data: broken file";
-            }
-            uint32_t nbytes = be32(&gb[p]);
-            p += 8;
-            if (p + nbytes > gb.size()) {
-                status = 2;
-                return "genome data: broken file";
-            }
-            if (!local) {
-                out.other_of[g.bg] = (int)out.others.size();
-                out.others.push_back(std::move(g));
-                continue;
-            }
-            if ((int64_t)g.len > out.max_genome_len) {
-                // (the seed packer sized its position field from the .idx tables before this file was read: a record longer
-                // than its index entry says would have its positions packed into too few bits)
-                status = 2;
-                return std::string("genome data: a record of ") + name + " is longer than its genomes.bin.idx entry says";
-            }
-            if (to_sink) { // (same offsets as the host store: 8 .. 15 bytes of padding behind every genome)
-                g.bits_off = run;
-                if (!out.gbits_sink(gb.data() + p, nbytes, run)) {
-                    status = 2;
-                    return std::string("genome data: the packed bases of ") + name + " exceed what the batch indexes announced";
-                }
-                run = (run + (int64_t)nbytes + 15) & ~(int64_t)7;
-                out.genomes.push_back(std::move(g));
-                continue;
-            }
-            g.bits_off = (int64_t)out.gbits.size();
-            out.gbits.insert(out.gbits.end(), gb.begin() + p, gb.begin() + p + nbytes);
-            // pad so that 8-byte loads near the end of a genome stay inside the buffer
-            size_t padded = (out.gbits.size() + 15) & ~(size_t)7;
-            out.gbits.resize(padded, 0);
-            out.genomes.push_back(std::move(g));
+            r0 = r1;
         }
-        if (out.gbits_batch_end) out.gbits_batch_end();
     }
     out.gbits_total = to_sink ? run : (int64_t)out.gbits.size();
 

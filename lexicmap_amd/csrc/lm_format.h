@@ -53,12 +53,10 @@ struct HostIndex {
     int64_t n_local_genomes = 0, max_genome_len = 1; // from the batch .idx files (before the batches themselves are read)
     size_t gbits_bound = 0;        // upper bound of the packed bytes (+ padding) of this shard's genomes
     // Optional: where load_index_genomes puts the packed bases of a local genome instead of appending them to `gbits` (the
-    // loader: straight from the batch file's buffer to their place on the device).  batch_begin: a batch file was read into
-    // [buf, buf + bytes) - the sinks of its genomes point into it; batch_end: the buffer is about to be reused.  A sink that
-    // returns false stops the load (status 2).
-    std::function<void(const uint8_t *buf, size_t bytes)> gbits_batch_begin;
+    // loader: straight from the read buffer to their place on the device).  A sink that returns false stops the load (status 2).
+    std::function<uint8_t *(size_t bytes)> gbits_buffer; // the buffer a run of records is read into (the loader: pinned memory)
     std::function<bool(const uint8_t *src, size_t nbytes, int64_t bits_off)> gbits_sink;
-    std::function<void()> gbits_batch_end;
+    std::function<void()> gbits_batch_end;               // the buffer is about to be read into again
     int64_t gbits_total = 0;       // bytes of the store once every batch is read (= gbits.size() without a sink)
 };
 

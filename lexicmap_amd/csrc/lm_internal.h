@@ -400,7 +400,7 @@ struct lm_tune {
     FILE *wfa_dump = nullptr; // LM_DEBUG_WFA_DUMP=<file>: one line per WFA problem and pass (width, status, lengths, estimate, score)
     FILE *wfa_waves = nullptr; // LM_DEBUG_WFA_WAVES=<file>: one JSON line per k_wfa_lean launch: when its wavefronts started / ended, busy share
     int wfa_ak_margin = -1;  // LM_WFA_AK_MARGIN: a problem starts at the ring that holds |tlen - qlen| + margin diagonals (-1: at the class's width)
-    int arena_reserve_pct = 95; // LM_ARENA_RESERVE_PCT: share of the scratch budget cut into the two lane slabs when a production-size index is opened, else at the first search (LaneSlabs; 0: slabs on demand as in round 4)
+    int arena_reserve_pct = 90; // LM_ARENA_RESERVE_PCT: share of the scratch budget cut into the two lane slabs when a production-size index is opened, else at the first search (LaneSlabs; 0: slabs on demand as in round 4)
     int two_lanes = 1;       // two parts of a batch searched side by side, each with half of the scratch budget (LM_TWO_LANES=0: one after the other)
     int lookup_flat = 1;     // anchors emitted with the lanes over the output (k_lookup_emit_flat); LM_LOOKUP_FLAT=0: one lane per lookup
     int wfa_defer = 0;       // LM_WFA_DEFER=1: a round's latency-bound alignments finish beside the next round's first passes (default: every round waits for them)

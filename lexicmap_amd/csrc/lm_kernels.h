@@ -151,8 +151,6 @@ void launch_wfa(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo,
 
 // k_wfa_mw<nc / 4, win>: the same passes for nc = 8 / 16 by a workgroup of four wavefronts per alignment
 int wfa_mw_resident_blocks(int device, int seq_words, int nc, bool win);
-void launch_set_dp_reg(int on); // LM_PA_DP_REG (default on)
-void launch_set_occ8(bool on); // LM_OCC8 (default on): k_wfa_lean2<2, int16_t> and k_pa_chain_wave held to 64 VGPRs = 8 wavefronts per SIMD
 void launch_wfa_mw(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks, int32_t *hdr_pool,
                    int64_t hdr_stride, uint8_t *arena_pool, int64_t arena_stride, uint64_t *ops_pool, unsigned int *queue, int seq_words,
                    int want_ops, WfaOut *out, int nc, bool win);

@@ -1605,8 +1605,9 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 // (Forms measured against this one on one resident index and removed in round 5: the DP through global memory, 152 -> 130 ms per
 // C4 launch; the backtrack by lane 0 and ClearSubstrPairs by binary search in global memory, C3 9.85 -> 10.0 s, C4 shard 1.47 ->
 // 1.56 s per step; the DP of long windows pipelined over the eight wavefronts of a workgroup, C4 shard 1.47 vs 1.44 s without.)
-template <int WPE = 1, bool DPREG = true> // (WPE: wavefronts per SIMD the register allocation is held to; DPREG: pa_chain_dp_reg)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void k_pa_chain_wave(const uint64_t *__restrict__ B, const int64_t *__restrict__ pa_off,
+// (held to 64 VGPRs = 8 wavefronts per SIMD - the kernel is bound by the latency of a wavefront's dependent chain x windows in
+// flight; 67 VGPRs were 7: C4 shard 1.40 -> 1.33 s per step)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void k_pa_chain_wave(const uint64_t *__restrict__ B, const int64_t *__restrict__ pa_off,
                                                        int64_t ntasks, int K, LmChain2Opt opt, LmSub *__restrict__ subs_pool,
                                                        uint8_t *__restrict__ marks_pool, uint64_t *__restrict__ msi_pool,
                                                        int32_t *__restrict__ stack_pool, LmChain2 *__restrict__ out_pool,
@@ -1687,10 +1688,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void 
         if (dbg) d_1 = wall_clock64();
         long long M = 0;
         int Mi = 0;
-        if (DPREG) // (lm_pa_chain_dp_core.h: the last 64 anchors in registers / all of the recent ones in the LDS ring)
-            pa_chain_dp_reg(a_, n, opt, msi, &pcd_lds, &M, &Mi);
-        else
-            pa_chain_dp_ring(a_, n, opt, msi, &pcd_lds, &M, &Mi);
+        pa_chain_dp_reg(a_, n, opt, msi, &pcd_lds, &M, &Mi); // (lm_pa_chain_dp_core.h: the last 64 anchors in registers)
         __threadfence_block();
         __syncthreads();
         // ---- backtrack by the wavefront: region scans by 64 lanes, the walk out of LDS tiles (lm_pa_chain_bt.h) ----
@@ -2539,10 +2537,6 @@ __device__ __forceinline__ void bt_replay(const uint8_t *__restrict__ opseq, int
 
 // ------------------------------------------------------------------------------------------------------------
 // host-callable launchers
-static bool occ8 = getenv("LM_OCC8") ? atoi(getenv("LM_OCC8")) != 0 : true; // (A/B of the register cap; re-read by lm_tuning_reload through launch_set_occ8)
-void launch_set_occ8(bool on) { occ8 = on; }
-static int dp_reg_now = -1; // LM_PA_DP_REG re-read by lm_tuning_reload (A/B): k_pa_chain_wave's DP with the last 64 anchors in registers (default) or in the LDS ring
-void launch_set_dp_reg(int on) { dp_reg_now = on; }
 static inline int grid_for(int64_t n, int block, int maxb = 2048 * 8) {
     int64_t g = (n + block - 1) / block;
     if (g < 1) g = 1;
@@ -2703,9 +2697,7 @@ void launch_pa_chain(hipStream_t st, const uint64_t *B, const int64_t *pa_off, i
     if (pa_dbg && !d_pa_dbg && hipMalloc((void **)&d_pa_dbg, 16 * sizeof(unsigned long long)) != hipSuccess) d_pa_dbg = nullptr;
     unsigned long long *dbg = pa_dbg ? d_pa_dbg : nullptr;
     if (dbg) (void)hipMemsetAsync(dbg, 0, 16 * sizeof(unsigned long long), st);
-    static const bool dp_reg_env = getenv("LM_PA_DP_REG") ? atoi(getenv("LM_PA_DP_REG")) != 0 : true;
-    const bool dpr = dp_reg_now < 0 ? dp_reg_env : dp_reg_now != 0;
-    hipLaunchKernelGGL(dpr ? (occ8 ? k_pa_chain_wave<8, true> : k_pa_chain_wave<1, true>) : (occ8 ? k_pa_chain_wave<8, false> : k_pa_chain_wave<1, false>), dim3(g), dim3(64), 0, st, B, pa_off, ntasks, K, opt, subs, marks, msi, stack, out, out_n,
+    hipLaunchKernelGGL(k_pa_chain_wave, dim3(g), dim3(64), 0, st, B, pa_off, ntasks, K, opt, subs, marks, msi, stack, out, out_n,
                        clr_n, qbits, tbits, dbg);
     if (dbg) {
         unsigned long long h[16] = {0};
@@ -2748,7 +2740,7 @@ typedef void (*WfaLeanFn)(const WfaIn *, int64_t, const int32_t *, int64_t, int3
 static WfaLeanFn wfa_lean_fn(int nc, bool win, bool r16) { // (lm_wfa_lean2.h)
     // (shrink margins 4 and 8 of the dominant instantiation - longer in ONE chunk of 64 slots, more recentres - were measured
     // on one resident C3 index against the 12 it has: 9.67 / 9.80 s against 9.69 s per step, no difference; removed)
-    if (r16 && !win && nc == 2) return occ8 ? k_wfa_lean2<2, int16_t, false, L2_SHRINK_MARGIN, 8> : k_wfa_lean2<2, int16_t, false>;
+    if (r16 && !win && nc == 2) return k_wfa_lean2<2, int16_t, false, L2_SHRINK_MARGIN, 8>; // (64 VGPRs, 8 wavefronts per SIMD: no difference at C3, kept with k_pa_chain_wave's)
     if (r16 && !win && nc == 4) return k_wfa_lean2<4, int16_t, false>;
     switch (nc) {
     case 16: return win ? k_wfa_lean2<16, int32_t, true> : k_wfa_lean2<16, int32_t, false>;

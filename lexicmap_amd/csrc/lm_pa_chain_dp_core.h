@@ -20,113 +20,16 @@ struct PcdLds {
     int32_t nq[64], nt[64], nlen[64]; // the next 64 anchors
 };
 
-// a_[0..n): the cleared + trimmed anchors (n >= 2); msi[i] = score << 32 | predecessor, as lm_run_chain2 leaves it.
-// Returns the best score in *M and its anchor in *Mi (identical in all lanes).
-PCD_DEV void pa_chain_dp_ring(const LmSub *a_, int n, const LmChain2Opt &opt, uint64_t *msi, PcdLds *L, long long *Mout, int *Miout) {
-    const int lane = PCD_LANE;
-    long long M = 0;
-    int Mi = 0;
-    for (int i0 = 0; i0 < n; i0 += 64) {
-        PCD_LDS_SYNC(); // everybody is done with the previous 64 anchors
-        if (i0 + lane < n) {
-            const LmSub x = a_[i0 + lane];
-            L->nq[lane] = x.qbegin;
-            L->nt[lane] = x.tbegin;
-            L->nlen[lane] = (int32_t)x.len;
-        }
-        PCD_LDS_SYNC();
-        const int i1 = i0 + 64 < n ? i0 + 64 : n;
-        for (int i = i0; i < i1; i++) {
-            const int32_t aq = L->nq[i - i0], at = L->nt[i - i0], alen = L->nlen[i - i0];
-            long long m = alen;
-            int mj = i;
-            if (i > 0) {
-                unsigned long long best = 0; // (score << 32 | ~j) of the best candidate so far, 0 = none
-                int bcount = 0;
-                bool stop = false;
-                for (int jt = i - 1; jt >= 0 && !stop; jt -= 64) {
-                    const int j = jt - lane;
-                    const bool inb = j >= 0;
-                    int32_t bq = 0, bt = 0, blen = 0;
-                    uint32_t bs = 0;
-                    if (i - (jt - 63) <= PCD_RING) { // the whole round is in the ring (uniform)
-                        const int sl = j & (PCD_RING - 1);
-                        bq = L->q[sl];
-                        bt = L->t[sl];
-                        blen = L->len[sl];
-                        bs = L->score[sl];
-                    } else {
-                        PCD_GLOBAL_FENCE(); // lane 0's stores of the scores are visible to the loads below
-                        if (inb) {
-                            const LmSub b = a_[j];
-                            bq = b.qbegin;
-                            bt = b.tbegin;
-                            blen = (int32_t)b.len;
-                            bs = (uint32_t)(msi[j] >> 32);
-                        }
-                    }
-                    const bool skip = !inb || bq == aq || bt > at;
-                    const unsigned long long nskip = PCD_BALLOT(!skip);
-                    const int cnt = bcount + PCD_POPCLL(nskip & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull)));
-                    bool brk = false;
-                    if (!skip) {
-                        const int32_t bbase = aq - bq - blen;
-                        brk = !(bbase <= opt.band_base || cnt <= opt.band_count);
-                    }
-                    const unsigned long long bm = PCD_BALLOT(brk);
-                    const int first_brk = bm ? (PCD_FFSLL(bm) - 1) : 64;
-                    if (bm) stop = true;
-                    if (!skip && lane < first_brk) {
-                        int32_t qd = aq - bq, td = at - bt;
-                        if (qd < 0) qd = -qd;
-                        if (td < 0) td = -td;
-                        const int32_t g = qd > td ? qd - td : td - qd;
-                        if (g <= opt.max_gap) {
-                            const long long s = (long long)bs + (long long)blen - (long long)g;
-                            if (s >= 0) {
-                                const unsigned long long key = ((unsigned long long)s << 32) | (unsigned long long)(0xffffffffu - (uint32_t)j);
-                                if (key > best) best = key;
-                            }
-                        }
-                    }
-                    bcount += PCD_POPCLL(nskip);
-                }
-                best = PCD_WAVE_MAX_U64(best);
-                if (best != 0) {
-                    const long long s = (long long)(best >> 32);
-                    if (s >= m) {
-                        m = s;
-                        mj = (int)(0xffffffffu - (uint32_t)(best & 0xffffffffu));
-                    }
-                }
-            }
-            PCD_LDS_SYNC(); // every lane has read the ring slot that is about to be overwritten (anchor i - PCD_RING)
-            if (lane == 0) {
-                msi[i] = ((uint64_t)m << 32) | (uint64_t)(uint32_t)mj;
-                const int sl = i & (PCD_RING - 1);
-                L->q[sl] = aq;
-                L->t[sl] = at;
-                L->len[sl] = alen;
-                L->score[sl] = (uint32_t)m;
-            }
-            PCD_LDS_SYNC();
-            if (i > 0 && m > M) { // (the best score is sought among anchors 1.., as in lm_run_chain2)
-                M = m;
-                Mi = i;
-            }
-        }
-    }
-    *Mout = M;
-    *Miout = Mi;
-}
-
-// pa_chain_dp_reg - the same DP with the last 64 anchors and their scores in REGISTERS: lane l holds anchor i - 1 - l, so the first
+// a_[0..n): the cleared + trimmed anchors (n >= 2); msi[i] = score << 32 | predecessor, as lm_run_chain2 leaves it.  Returns the
+// best score in *M and its anchor in *Mi (identical in all lanes).
+// pa_chain_dp_reg - the DP with the last 64 anchors and their scores in REGISTERS: lane l holds anchor i - 1 - l, so the first
 // candidate round of anchor i (in nearly every window the only one: the band closes after 50 candidates or 100 bases) reads
 // nothing from LDS, and its result - the largest score, the farthest of the candidates that reach it - is a 32-bit wave maximum,
 // one ballot and a bit scan instead of the 64-bit key reduction; the finished anchor enters at lane 0 by a one-lane wavefront
-// shift of the four registers (DPP wave_shr:1).  The step of pa_chain_dp_ring is a chain of five LDS round trips and twelve
-// 64-bit DPP steps (~1 us per anchor whatever the chip does beside it); this one has none on its critical path.  The LDS ring is
-// still written (one store per anchor) for the rare further rounds, which run exactly as in pa_chain_dp_ring.
+// shift of the four registers (DPP wave_shr:1).  Its predecessor (round 4: every candidate round out of the LDS ring) was a chain of five
+// LDS round trips and twelve 64-bit DPP steps per anchor (~1 us whatever the chip does beside it; C4 shard 1.45 -> 1.33 s per
+// step with this form, k_pa_chain 1.23 -> 0.89 s of exclusive time per C3 step); this one has none on its critical path.  The
+// LDS ring is still written (one store per anchor) for the rare further rounds.
 // The includer adds PCD_SHIFT_IN(newv, v) (lane 0 <- the wave-uniform newv, lane l <- lane l - 1's v) and PCD_WAVE_MAX_I32(v).
 PCD_DEV void pa_chain_dp_reg(const LmSub *a_, int n, const LmChain2Opt &opt, uint64_t *msi, PcdLds *L, long long *Mout, int *Miout) {
     const int lane = PCD_LANE;
@@ -180,7 +83,7 @@ PCD_DEV void pa_chain_dp_reg(const LmSub *a_, int n, const LmChain2Opt &opt, uin
                         mj = i - 1 - (63 - PCD_CLZLL(eq)); // the farthest candidate with that score (the key's tie rule)
                     }
                 } else {
-                    // ---- further rounds from the LDS ring / global memory, as in pa_chain_dp_ring ----
+                    // ---- further rounds from the LDS ring / global memory ----
                     unsigned long long best = sc >= 0 ? (((unsigned long long)(uint32_t)sc << 32) | (unsigned long long)(0xffffffffu - (uint32_t)(i - 1 - lane))) : 0ull;
                     int bcount = PCD_POPCLL(nskip);
                     bool stop = false;

@@ -169,7 +169,7 @@ void lm_fill_gap_lut(lm_index *ix) {
 void lm_set_scratch_budget(lm_index *ix) {
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) != hipSuccess) return;
-    ix->scratch_budget = (int64_t)((double)fr * 0.85);
+    ix->scratch_budget = (int64_t)((double)fr * 0.80); // (0.85 until round 5: the pools' head-room and the buffers outside the arena took the device to 99 %)
     if (const char *e = getenv("LM_SCRATCH_BUDGET_MB")) ix->scratch_budget = std::max<int64_t>(64, atoll(e)) << 20;
     if (getenv("LM_DEBUG"))
         fprintf(stderr, "[lm] index resident: %.2f GB, device free %.2f of %.2f GB, scratch budget %.2f GB\n",
@@ -987,19 +987,21 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
         h2d(ix, ix->d_pfx_first, pfx);
         int gstatus = 0;
         const double t_g0 = now_ms();
-        // The packed bases go from the batch file's buffer (registered with the driver while its genomes are copied) straight to
-        // their place on the device, on the reader's own stream: no host copy of the genome store (12.5 GB at C2 size: appending
-        // to it and uploading it from pageable memory afterwards was 8 s of a 9.7-s open once the seed passes took 4.3 s).
+        // The packed bases go from the reader's buffer - pinned, a run of records of ~256 MB at a time - straight to their place on
+        // the device, on the reader's own stream: no host copy of the genome store and no buffer of a batch file's size (12.5 GB
+        // at C2 size: cutting and faulting in 6-GB buffers, appending to the store and uploading it from pageable memory
+        // afterwards was 8 s of a 9.7-s open once the seed passes took 4.3 s).
         ix->d_gbits.alloc_exact(h.gbits_bound + 64, true, S(ix)); // zero-filled: the padding behind every genome
         sync(ix);
         struct GenomeSink {
             hipStream_t st = nullptr;
-            void *reg = nullptr;
+            uint8_t *pinned = nullptr; // the reader's buffer (grow-only)
+            size_t pinned_cap = 0;
             uint8_t *dst = nullptr;
             size_t cap = 0;
             ~GenomeSink() {
                 if (st) (void)hipStreamSynchronize(st);
-                if (reg) (void)hipHostUnregister(reg);
+                if (pinned) (void)hipHostFree(pinned);
                 if (st) (void)hipStreamDestroy(st);
             }
         } gsink;
@@ -1007,21 +1009,30 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
         gsink.cap = h.gbits_bound + 64;
         HIPCHK(hipStreamCreateWithFlags(&gsink.st, hipStreamNonBlocking));
         const int gdev = device;
-        h.gbits_batch_begin = [&gsink, gdev](const uint8_t *buf, size_t bytes) {
+        h.gbits_buffer = [&gsink, gdev](size_t bytes) -> uint8_t * {
             (void)hipSetDevice(gdev);
-            if (gsink.reg) (void)hipHostUnregister(gsink.reg);
-            gsink.reg = bytes && !getenv("LM_LOADER_NO_PIN") && hipHostRegister((void *)buf, bytes, hipHostRegisterDefault) == hipSuccess ? (void *)buf : nullptr;
-            if (!gsink.reg) (void)hipGetLastError(); // pageable copies then: slower, not wrong
+            if (bytes > gsink.pinned_cap) {
+                if (gsink.pinned) {
+                    (void)hipStreamSynchronize(gsink.st);
+                    (void)hipHostFree(gsink.pinned);
+                }
+                gsink.pinned = nullptr;
+                gsink.pinned_cap = 0;
+                const size_t want = std::max<size_t>(bytes, (size_t)257 << 20);
+                if (hipHostMalloc((void **)&gsink.pinned, want, hipHostMallocDefault) != hipSuccess) {
+                    (void)hipGetLastError();
+                    gsink.pinned = nullptr;
+                    return nullptr;
+                }
+                gsink.pinned_cap = want;
+            }
+            return gsink.pinned;
         };
         h.gbits_sink = [&gsink](const uint8_t *src, size_t nbytes, int64_t off) {
             if (off < 0 || (size_t)off + nbytes + 16 > gsink.cap) return false;
             return hipMemcpyAsync(gsink.dst + off, src, nbytes, hipMemcpyHostToDevice, gsink.st) == hipSuccess;
         };
-        h.gbits_batch_end = [&gsink]() {
-            (void)hipStreamSynchronize(gsink.st); // the buffer is read into again
-            if (gsink.reg) (void)hipHostUnregister(gsink.reg);
-            gsink.reg = nullptr;
-        };
+        h.gbits_batch_end = [&gsink]() { (void)hipStreamSynchronize(gsink.st); }; // the buffer is read into again
         std::future<std::string> gfut = std::async(std::launch::async, [&]() { return load_index_genomes(dir, h, gstatus); });
         const int64_t max_len = h.max_genome_len;
         h2d(ix, ix->d_batch_first, h.batch_first);
@@ -1249,7 +1260,7 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
                 return LM_ERR_FORMAT;
             }
         }
-        h.gbits_batch_begin = nullptr; // (they refer to this frame)
+        h.gbits_buffer = nullptr; // (they refer to this frame)
         h.gbits_sink = nullptr;
         h.gbits_batch_end = nullptr;
         std::vector<int64_t> goff;
@@ -1337,8 +1348,6 @@ void lm_tuning_reload(lm_index *ix) {
     if (!ix) return;
     std::lock_guard<std::mutex> lock(ix->mu);
     lm_tune fresh;
-    launch_set_occ8(getenv("LM_OCC8") ? atoi(getenv("LM_OCC8")) != 0 : true);
-    launch_set_dp_reg(getenv("LM_PA_DP_REG") ? (atoi(getenv("LM_PA_DP_REG")) != 0 ? 1 : 0) : 1);
     if (ix->tune.wfa_dump) fclose(ix->tune.wfa_dump);
     if (ix->tune.wfa_waves) fclose(ix->tune.wfa_waves);
     fresh.wfa_serial = fresh.wfa_serial || ix->tune.wfa_serial;   // (owned by lm_profile_exclusive: a reload does not undo it)

@@ -37,8 +37,6 @@ static inline int emu_shift_in(int newv, int v, int site) { // lane 0 <- newv, l
 #include "../../lexicmap_amd/csrc/lm_pa_chain_dp_core.h"
 
 // subs: n anchors {qbegin, tbegin, len} (sorted the way the kernel gets them); returns 0 when the emulated DP equals lm_run_chain2's
-static int g_reg = 0; // 1: pa_chain_dp_reg (the last 64 anchors in registers), 0: pa_chain_dp_ring
-extern "C" void pcd_emu_use_reg(int on) { g_reg = on; }
 extern "C" int pcd_emu_check(const int32_t *qb, const int32_t *tb, const uint8_t *len, int n, int max_gap, int band_base, int band_count,
                              uint64_t *msi_out, long long *M_out, int *Mi_out) {
     std::vector<LmSub> a((size_t)n);
@@ -70,10 +68,7 @@ extern "C" int pcd_emu_check(const int32_t *qb, const int32_t *tb, const uint8_t
     memset(&lds, 0x5a, sizeof lds);
     long long M[64];
     int Mi[64];
-    if (g_reg)
-        simt::run_wave([&](int lane) { pa_chain_dp_reg(a.data(), n, opt, msi.data(), &lds, &M[lane], &Mi[lane]); });
-    else
-        simt::run_wave([&](int lane) { pa_chain_dp_ring(a.data(), n, opt, msi.data(), &lds, &M[lane], &Mi[lane]); });
+    simt::run_wave([&](int lane) { pa_chain_dp_reg(a.data(), n, opt, msi.data(), &lds, &M[lane], &Mi[lane]); });
     int bad = 0;
     for (int l = 1; l < 64; l++) bad += M[l] != M[0] || Mi[l] != Mi[0];
     // (lm_run_chain2 seeds msi[0] with predecessor 0 and M with 0: the kernel's loop starts at anchor 1 the same way)

@@ -19,6 +19,25 @@ int fh_open(const char *dir, int shard_rank, int shard_count) {
     return g_err.empty() ? 0 : st;
 }
 int fh_nfiles() { return (int)g_idx.seed_files.size(); }
+// the genome store load_index_genomes left: local genomes (bases on this shard) and the others (names and contig tables only)
+int fh_ngenomes() { return (int)g_idx.genomes.size(); }
+int fh_nothers() { return (int)g_idx.others.size(); }
+// local genome i: its key, length, contigs and the address of its packed bases (2 bits per base, first base in bits 7-6)
+const unsigned char *fh_genome(int i, unsigned long long *bg, int *len, int *nseqs, const char **id) {
+    const lm::HostGenome &g = g_idx.genomes[(size_t)i];
+    *bg = g.bg;
+    *len = g.len;
+    *nseqs = g.nseqs;
+    *id = g.id.c_str();
+    return g_idx.gbits.data() + g.bits_off;
+}
+void fh_other(int i, unsigned long long *bg, int *len, int *nseqs, const char **id) {
+    const lm::HostGenome &g = g_idx.others[(size_t)i];
+    *bg = g.bg;
+    *len = g.len;
+    *nseqs = g.nseqs;
+    *id = g.id.c_str();
+}
 const char *fh_file(int i) { return g_idx.seed_files[(size_t)i].c_str(); }
 // returns the number of seeds (>= 0) or -status; the arrays stay valid until the next call
 long long fh_decode(const char *path, const unsigned long long **kmers, const unsigned long long **vals, const unsigned short **masks) {

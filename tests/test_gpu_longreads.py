@@ -145,7 +145,7 @@ def test_rows_do_not_depend_on_which_device_implementation_of_a_stage_runs(lr_in
     ran = {p["name"] for p in gi.profile_get() if p["launches"] > 0}
     gi.close()
     assert any(n.startswith("k_wfa_mw") for n in ran), ran   # the fixture does reach the wide passes
-    for var, off in (("LM_WFA_MW", "0"), ("LM_OCC8", "0"), ("LM_WFA_R16", "0"), ("LM_WFA_AK_MARGIN", "40"),
+    for var, off in (("LM_WFA_MW", "0"), ("LM_WFA_R16", "0"), ("LM_WFA_AK_MARGIN", "40"),
                      ("LM_LOOKUP_FLAT", "0"), ("LM_PA_FILTER_ROLL", "0"), ("LM_ARENA_RESERVE_PCT", "0")):
         monkeypatch.setenv(var, off)
         gi = la.Index(d)      # the switches are read once per handle

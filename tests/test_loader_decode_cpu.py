@@ -114,3 +114,59 @@ def test_truncated_and_foreign_files_are_refused(F, index, tmp_path):
     open(bad, "wb").write(data)   # and the untouched copy decodes again (the slot survived the failures)
     n, (k, v, m) = decode(F, bad.encode())
     assert sorted(zip(m.tolist(), k.tolist(), v.tolist())) == oracle_seeds(src.encode())
+
+
+def _genomes_of(F):
+    out = {}
+    for i in range(F.fh_ngenomes()):
+        bg, ln, ns, gid = C.c_uint64(), C.c_int(), C.c_int(), C.c_char_p()
+        F.fh_genome.restype = C.POINTER(C.c_ubyte)
+        p = F.fh_genome(i, C.byref(bg), C.byref(ln), C.byref(ns), C.byref(gid))
+        packed = bytes(p[:(ln.value + 3) // 4])
+        bases = "".join("ACGT"[(packed[j >> 2] >> ((3 - (j & 3)) << 1)) & 3] for j in range(ln.value))
+        out[bg.value] = (gid.value.decode(), ln.value, ns.value, bases)
+    others = {}
+    for i in range(F.fh_nothers()):
+        bg, ln, ns, gid = C.c_uint64(), C.c_int(), C.c_int(), C.c_char_p()
+        F.fh_other(i, C.byref(bg), C.byref(ln), C.byref(ns), C.byref(gid))
+        others[bg.value] = (gid.value.decode(), ln.value, ns.value)
+    return out, others
+
+
+@pytest.mark.parametrize("run_bytes,head_bytes", [(None, None), (40000, 64), (1, 1), (20000, 100000)])
+def test_genome_batches_read_in_runs_and_a_shard_reads_only_the_heads_of_foreign_records(F, index, monkeypatch, run_bytes, head_bytes):
+    """load_index_genomes reads a batch file in runs of consecutive records (LM_LOADER_RUN_BYTES: here a few records or one
+    per run) and, of a record that belongs to another shard, only its head (LM_LOADER_HEAD_BYTES: here too short for the head,
+    so the whole record is read after all): names, lengths, contig counts and every base of every local genome equal what the
+    index was built from, whatever the run and head sizes, unsharded and on each of three shards"""
+    from lexicmap_amd import synth
+    genomes = synth.make_genomes(12, 60000, 3, seed=17, max_div=0.08, contigs=(1, 3))
+    if run_bytes is not None:
+        monkeypatch.setenv("LM_LOADER_RUN_BYTES", str(run_bytes))
+        monkeypatch.setenv("LM_LOADER_HEAD_BYTES", str(head_bytes))
+    want = {}
+    for g, (gid, contigs) in enumerate(genomes):
+        want[g] = (gid, len(contigs))
+    assert F.fh_open(index.encode(), 0, 1) == 0, F.fh_error()
+    loc, oth = _genomes_of(F)
+    assert len(loc) == 12 and not oth
+    for bg, (gid, ln, ns, bases) in loc.items():
+        g = bg & 0x1ffff
+        assert (gid, ns) == want[g]
+        seqs = [c[1].decode() if isinstance(c[1], bytes) else c[1] for c in genomes[g][1]]
+        # contigs are joined by the reference's interval of N (stored as A): the contig bases must appear in order
+        pos = 0
+        for sq in seqs:
+            k = bases.find(sq, pos)
+            assert k >= 0, (g, len(sq))
+            pos = k + len(sq)
+    whole = loc
+    for r in range(3):
+        assert F.fh_open(index.encode(), r, 3) == 0, F.fh_error()
+        loc, oth = _genomes_of(F)
+        assert sorted(bg & 0x1ffff for bg in loc) == [g for g in range(12) if g % 3 == r]
+        assert sorted(bg & 0x1ffff for bg in oth) == [g for g in range(12) if g % 3 != r]
+        for bg, v in loc.items():
+            assert v == whole[bg]
+        for bg, (gid, ln, ns) in oth.items():
+            assert (gid, ln, ns) == whole[bg][:3]

@@ -1,5 +1,5 @@
-"""lexicmap_amd/csrc/lm_pa_chain_dp_core.h - the banded chaining DP of k_pa_chain_wave<true> with the recent anchors in an LDS
-ring (one source for the device and for the host) - on the host SIMT emulator (tests/emu) against lm_run_chain2 (the CPU-checked statement of the
+"""lexicmap_amd/csrc/lm_pa_chain_dp_core.h - the banded chaining DP of k_pa_chain_wave with the last 64 anchors in registers and the LDS
+ring behind them (one source for the device and for the host) - on the host SIMT emulator (tests/emu) against lm_run_chain2 (the CPU-checked statement of the
 device logic, itself equal to the oracle's Chainer2): every score and predecessor, the best score and its anchor."""
 import ctypes as C
 import os
@@ -27,15 +27,6 @@ def lib():
 
 
 def check(anchors, max_gap=20, band_base=100, band_count=50):
-    """both forms of the DP: pa_chain_dp_ring (the recent anchors in an LDS ring) and pa_chain_dp_reg (the last 64 in registers,
-    the ring for what lies further back) against lm_run_chain2; returns the sum of their differences"""
-    bad_ring, M, Mi = check1(anchors, 0, max_gap, band_base, band_count)
-    bad_reg, M2, Mi2 = check1(anchors, 1, max_gap, band_base, band_count)
-    return bad_ring + bad_reg + int((M, Mi) != (M2, Mi2)), M, Mi
-
-
-def check1(anchors, reg, max_gap=20, band_base=100, band_count=50):
-    lib().pcd_emu_use_reg(reg)
     n = len(anchors)
     qb = (C.c_int32 * n)(*[a[0] for a in anchors])
     tb = (C.c_int32 * n)(*[a[1] for a in anchors])

@@ -5,7 +5,7 @@
 # roofline.traffic / instruction_issue of the line are filled by the run itself and nothing is refilled afterwards.
 # Every summary is stamped with the hash of the library sources (bench.py source_hash): bench.py refuses PMC passes taken
 # on other sources.   usage: tools/profile.sh <workload> [steps] [extra bench args...]
-P=r04
+P=${LM_PROFILE_PREFIX:-r05}
 W=${1:-c3}
 STEPS=${2:-2}
 shift; shift
@@ -40,5 +40,5 @@ tail -n 2 /tmp/prof_f.log /tmp/prof_w.log /tmp/prof_sq.log
 # the passes of THESE sources where bench.py looks for them, then the bench line
 cp $R/gpurun_out/${P}_${W}_pmc_fetch.json $R/gpurun_out/${P}_${W}_pmc_write.json $R/gpurun_out/${P}_${W}_pmc_sq.json $R/profiles/
 cd $R
-timeout 1500 python bench.py --workload $W --steps $STEPS --warmup 1 $EXTRA > gpurun_out/${P}_${W}_bench.json 2> gpurun_out/${P}_${W}_bench.err
+timeout 1500 python bench.py --workload $W --steps 3 --warmup 3 $EXTRA > gpurun_out/${P}_${W}_bench.json 2> gpurun_out/${P}_${W}_bench.err
 tail -2 gpurun_out/${P}_${W}_bench.err
