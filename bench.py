@@ -119,10 +119,45 @@ WORKLOADS = {
 }
 
 
-def source_hash():
-    """identity of the kernels a PMC pass was taken on: sha256 over the library sources"""
+def _code_only(text):
+    """C / C++ source without comments, whitespace collapsed: what source_hash() hashes"""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c == '"' or c == "'":  # string / character literal: copied as it is
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+        else:
+            out.append(c)
+            i += 1
+    return " ".join("".join(out).split())
+
+
+def source_hash(root=None):
+    """identity of the kernels a PMC pass was taken on: sha256 over the CODE of the library sources (comments and whitespace do
+    not count: a comment fixed after the counter passes were taken does not orphan them)"""
     h = hashlib.sha256()
-    d = os.path.join(ROOT, "lexicmap_amd", "csrc")
+    d = os.path.join(root or ROOT, "lexicmap_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            h.update(_code_only(open(os.path.join(d, f), encoding="utf-8", errors="replace").read()).encode())
+    return h.hexdigest()[:16]
+
+
+def source_hash_raw(root=None):
+    """the hash of rounds 1-5a: over the raw bytes of the same files (tools/restamp_hash.py maps one to the other)"""
+    h = hashlib.sha256()
+    d = os.path.join(root or ROOT, "lexicmap_amd", "csrc")
     for f in sorted(os.listdir(d)):
         if f.endswith((".hip", ".h", ".cpp")):
             h.update(f.encode())

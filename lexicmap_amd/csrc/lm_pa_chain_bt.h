@@ -1,6 +1,6 @@
 // lm_pa_chain_bt.h - device side of pa_chain_bt.h : the macros under which the
 // wavefront backtrack compiles inside lm_kernels.hip (namespace lm, after lm_pa_chain_dp.h: it uses pcd_wave_max_u64).
-// tools/adopt_pa_chain_pipe.py wires it into k_pa_chain_wave / k_pa_chain_pipe behind LM_PA_CHAIN_BT_WAVE.
+// k_pa_chain_wave's backtrack and ClearSubstrPairs marks since round 5 (the lane-0 / global-memory forms lost the A/B and went).
 #pragma once
 
 #define PCB_DEV __device__ __forceinline__

@@ -1,6 +1,6 @@
 // lm_pa_chain_bt_core.h - the backtrack of Chainer2 (lm_run_chain2's second half; lib-chaining2.go:309-420 as
-// restated in lm_algos.h) by a WAVEFRONT instead of one lane.  STAGED for round 5: equal to lm_run_chain2 on the host SIMT
-// emulator (tests/test_pa_chain_bt_emulated_cpu.py), compiled for gfx950; never run on a GPU.
+// restated in lm_algos.h) by a WAVEFRONT instead of one lane.  Equal to lm_run_chain2 on the host SIMT
+// emulator (tests/test_pa_chain_bt_emulated_cpu.py) and, in k_pa_chain_wave, to the oracle's rows on the GPU (round 5).
 //
 // Why: k_pa_chain_wave runs the backtrack on lane 0: a walk from anchor to predecessor with two dependent GLOBAL loads per
 // anchor (msi[i], then the anchor), and, for every region left and right of a chain, a serial scan of the region for its best

@@ -1,6 +1,6 @@
 // lm_pa_clear_tile.h - the marks of ClearSubstrPairs (lib-index-search.go:927-972 as lm_clear_sorted states
 // it: an anchor is dropped when it lies inside an EARLIER anchor of the sorted list whose QBegin is at most K - len before its
-// own) from LDS tiles.  STAGED for round 5: equal to lm_clear_sorted on the host SIMT emulator; never run on a GPU.
+// own) from LDS tiles.  Equal to lm_clear_sorted on the host SIMT emulator; product code since round 5.
 //
 // k_pa_chain_wave gives every anchor a lane that binary-searches the list in GLOBAL memory for its first candidate (~11
 // dependent loads) and then reads the candidates one by one (a 16-byte load each): ~20 dependent round trips per 64 anchors,

@@ -1,9 +1,8 @@
 // lm_wfa_lean2.h - device side of wfa_lean2_fwd.h : k_wfa_lean2<NC, RT, WIN>,
-// k_wfa_lean (persistent wavefronts over a queue; the sequences 2-bit packed in LDS, whole or through sliding windows;
-// bt_walk / bt_replay of lm_kernels.hip) with the restructured forward pass.  Same signature, scratch pools and results as
-// k_wfa_lean<NC, WIN, RT>: the integration is wfa_lean_fn() returning these + 8 * seq_words + 20 bytes of dynamic LDS for the
-// whole-sequence form.  Included inside namespace lm after lm_wfa_mw.h (whose WR_* macros it shares).  NOT run on a GPU yet:
-// compiled for gfx950 (compile_check.hip), the forward pass checked on the host SIMT emulator.
+// the single-wavefront WFA kernel (persistent wavefronts over a queue; the sequences 2-bit packed in LDS, whole or through sliding windows;
+// bt_walk / bt_replay of lm_kernels.hip) with the forward pass of lm_wfa_lean2_fwd.h.  8 * seq_words + 20 bytes of dynamic LDS for the
+// whole-sequence form.  Included by lm_wfa_mw.h (whose WR_* macros it shares) inside namespace lm.  It replaced k_wfa_lean in
+// round 5 (C3 12.1 -> 9.85 s per step on one resident index); the forward pass is also checked on the host SIMT emulator.
 #pragma once
 
 #define WR_WAVE_SYNC() LDS_WAVE_SYNC()

@@ -1,10 +1,10 @@
 // wfa_lean2_fwd.h - the forward pass of the gap-affine WFA (x=4, o=6, e=2, wf-adaptive(10,50)) by ONE
 // wavefront, restructured for fewer instructions per score step than k_wfa_lean (lexicmap_amd/csrc/lm_kernels.hip).
-// equal to the oracle on the host SIMT emulator (tests/test_wfa_lean2_emulated_cpu.py), compiled for
-// gfx950 beside the product kernels (compile_check.hip), instruction counts of the score loop in README.md; never run on a GPU.
+// Equal to the oracle on the host SIMT emulator (tests/test_wfa_lean2_emulated_cpu.py) and on the GPU (tests/test_gpu_wfa_lean2.py);
+// instruction counts of the score loop: DESIGN.md section 4.  (k_wfa_lean below = its predecessor, removed in round 5.)
 //
 // Why: k_wfa_lean is 58 % of the vector and 71 % of the scalar instructions of a C3 step (profiles/r04_c3_pmc_sq.json) and it
-// runs at its instruction roofline (experiments/README.md, valu_rate): only fewer instructions per score step make it faster.
+// runs at its instruction roofline (experiments/README.md, valu_rate; round 4): only fewer instructions per score step make it faster.
 // Its ISA spends more than half of a step on bookkeeping: the slot -> diagonal mapping of a ring that wraps (k, j, in-range
 // masks per chunk and phase, twice per score), three packed DPP reductions for the trimmed ranges and two for the cut-off
 // (6 dependent DPP stages each), the extension as a second phase that reads M back from LDS and writes it again, separate

@@ -1,8 +1,8 @@
-// lm_wfa_mw2.h - device side of wfa_mw2_fwd.h : k_wfa_mw2<NCW, WIN>, k_wfa_mw
+// lm_wfa_mw2.h - device side of wfa_mw2_fwd.h : k_wfa_mw2<NCW, WIN>, the workgroup WFA kernel
 // (a workgroup of four wavefronts per long alignment; persistent over a queue; bt_walk / bt_replay by the first wavefront)
-// with the restructured forward pass.  Same signature, scratch pools and results as k_wfa_mw<NCW, WIN>; dynamic LDS of the
-// whole-sequence form 8 * seq_words + 20 bytes.  Included inside namespace lm after lm_wfa_lean2.h.  NOT run on a GPU yet:
-// compiled for gfx950 (compile_check.hip), the forward pass checked on the host SIMT emulator.
+// with the forward pass of lm_wfa_mw2_fwd.h; dynamic LDS of the
+// whole-sequence form 8 * seq_words + 20 bytes.  Included inside namespace lm after lm_wfa_lean2.h.  It replaced k_wfa_mw in round 5;
+// forced through every instantiation on the GPU by tests/test_gpu_wfa_lean2.py / test_gpu_wfa_mw.py, and on the host SIMT emulator.
 #pragma once
 
 // the minimum over the four lanes of a quad, in each of them (two DPP quad permutations)

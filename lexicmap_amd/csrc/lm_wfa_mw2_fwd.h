@@ -1,6 +1,6 @@
 // wfa_mw2_fwd.h - the forward pass of wfa_lean2_fwd.h for a WORKGROUP of four wavefronts per alignment
-// (256 threads x NCW cells = 512 / 1024 diagonals): the restructuring of lm_wfa_mw_fwd.h (k_wfa_mw) that k_wfa_lean got.
-// equal to the oracle on the host SIMT emulator (tests/test_wfa_mw2_emulated_cpu.py); never run on a GPU.
+// (256 threads x NCW cells = 512 / 1024 diagonals): the restructuring of round 4's workgroup kernel (k_wfa_mw) that k_wfa_lean got.
+// Equal to the oracle on the host SIMT emulator (tests/test_wfa_mw2_emulated_cpu.py) and on the GPU (tests/test_gpu_wfa_mw.py).
 //
 // k_wfa_mw is latency-bound: a handful of 20-50-kb alignments per round, each a chain of score steps, every round of the C3
 // pipeline waits for them.  Its step has FOUR workgroup barriers (extension results; kept range of the cut-off; NULL-backs and

@@ -1,0 +1,33 @@
+"""Two ranks on ONE GPU (gloo: RCCL refuses two ranks on a device): `bench.py --gpus 2 --dist-backend gloo` spawns two processes,
+each opens its genome shard (g % 2) of the same small index on the same device, searches the same batch, the rows are gathered to
+rank 0 (torch.distributed: the C gather needs RCCL) and merged by lm_merge_sharded - the number of rows and of aligned bases must
+be those of the one-rank run.  (The N > 1 logic of the sharded search end to end; row-for-row equality of shards vs the unsharded
+index: tests/test_gpu_parity.py, tests/test_gpu_c4c5.py.)"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line(extra):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline", "--no-exclusive-step"] + extra, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_two_ranks_on_one_gpu_give_the_rows_of_one_rank():
+    one = _line([])
+    two = _line(["--gpus", "2", "--dist-backend", "gloo"])
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert two["rows"] == one["rows"] and one["rows"] > 0
+    assert abs(two["gbp_aligned_per_s"] * two["ms_per_step"] - one["gbp_aligned_per_s"] * one["ms_per_step"]) <= 1e-6 * max(1.0, one["gbp_aligned_per_s"] * one["ms_per_step"])
+    assert "index-shard x2" in two["config"]["parallelism"]
