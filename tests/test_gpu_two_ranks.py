@@ -1,7 +1,7 @@
 """Two ranks on ONE GPU (gloo: RCCL refuses two ranks on a device): `bench.py --gpus 2 --dist-backend gloo` spawns two processes,
 each opens its genome shard (g % 2) of the same small index on the same device, searches the same batch, the rows are gathered to
-rank 0 (torch.distributed: the C gather needs RCCL) and merged by lm_merge_sharded - the number of rows and of aligned bases must
-be those of the one-rank run.  (The N > 1 logic of the sharded search end to end; row-for-row equality of shards vs the unsharded
+rank 0 (torch.distributed: the C gather needs RCCL) and merged by lm_merge_sharded - the number of rows (and, within the rounding of the
+line's rates, of aligned bases) must be those of the one-rank run.  (The N > 1 logic of the sharded search end to end; row-for-row equality of shards vs the unsharded
 index: tests/test_gpu_parity.py, tests/test_gpu_c4c5.py.)"""
 import json
 import os
@@ -29,5 +29,6 @@ def test_two_ranks_on_one_gpu_give_the_rows_of_one_rank():
     two = _line(["--gpus", "2", "--dist-backend", "gloo"])
     assert two["n_gpus"] == 2 and one["n_gpus"] == 1
     assert two["rows"] == one["rows"] and one["rows"] > 0
-    assert abs(two["gbp_aligned_per_s"] * two["ms_per_step"] - one["gbp_aligned_per_s"] * one["ms_per_step"]) <= 1e-6 * max(1.0, one["gbp_aligned_per_s"] * one["ms_per_step"])
+    a1, a2 = one["gbp_aligned_per_s"] * one["ms_per_step"], two["gbp_aligned_per_s"] * two["ms_per_step"]  # ~ aligned bases (rounded rates)
+    assert abs(a1 - a2) <= 0.02 * max(a1, a2)
     assert "index-shard x2" in two["config"]["parallelism"]
