@@ -412,12 +412,20 @@ def main():
         if args.dist_backend == "nccl" and args.gather == "c":
             try:
                 from lexicmap_amd.api import Comm, COMM_ID_BYTES
-                idt = torch.zeros(COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
+                idt = torch.zeros(COMM_ID_BYTES + 1, dtype=torch.uint8, device="cuda")  # [0]: rank 0 has an id to offer
                 if rank == 0:
-                    idt.copy_(torch.frombuffer(bytearray(Comm.unique_id()), dtype=torch.uint8))
+                    try:
+                        uid = Comm.unique_id()
+                        idt.copy_(torch.frombuffer(bytearray(b"\x01" + uid), dtype=torch.uint8))
+                    except Exception as e:  # noqa: BLE001 (every rank learns it from the flag: nobody waits in ncclCommInitRank)
+                        gather_kind += "; lm_comm_unique_id failed on rank 0: %r" % (e,)
                 dist.broadcast(idt, src=0)
-                comm = Comm(bytes(idt.cpu().numpy().tobytes()), world, rank, local_rank)
-                gather_kind = "lm_gather_rows (C-ABI, RCCL send/recv to the merging rank)"
+                idb = bytes(idt.cpu().numpy().tobytes())
+                if idb[0] == 1:
+                    comm = Comm(idb[1:], world, rank, local_rank)
+                    gather_kind = "lm_gather_rows (C-ABI, RCCL send/recv to the merging rank)"
+                elif rank != 0:
+                    gather_kind += "; rank 0 offered no communicator id"
             except Exception as e:  # noqa: BLE001
                 comm = None
                 gather_kind += "; lm_gather_rows unavailable: %r" % (e,)

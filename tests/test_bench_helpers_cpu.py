@@ -138,3 +138,14 @@ def test_counter_passes_are_spread_over_this_runs_launches_per_step(tmp_path, mo
     assert bench.pmc_issue("k_wfa_lean", "c3", per_step_launches=400)["sq_insts_valu_per_launch"] == 1250000
     monkeypatch.setattr(bench, "source_hash", lambda: "other")   # passes of other sources are refused
     assert bench.pmc_traffic("k_wfa_lean", "c3", per_step=True)[0] is None and bench.pmc_issue("k_wfa_lean", "c3") is None
+
+
+def test_source_hash_ignores_comments_and_whitespace_but_not_code():
+    """bench.source_hash ties the committed counter passes to the library's CODE: comments and layout may change, a token may not"""
+    import bench
+    a = 'int f(int x) { // why\n    return x /* inline */ + 1; }\nconst char *s = "// not a comment";\n'
+    b = 'int f(int x) {\n  return x + 1;   }  /* new\n comment */ const char *s = "// not a comment";'
+    c = 'int f(int x) { return x + 2; }\nconst char *s = "// not a comment";'
+    assert bench._code_only(a) == bench._code_only(b) != bench._code_only(c)
+    assert '"// not a comment"' in bench._code_only(a)
+    assert len(bench.source_hash()) == 16 and bench.source_hash() != bench.source_hash_raw()

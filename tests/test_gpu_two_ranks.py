@@ -16,8 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _line(extra):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    env.pop("RANK", None)
-    env.pop("WORLD_SIZE", None)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):  # (another test of the session may have set a rendezvous up)
+        env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--steps", "1", "--warmup", "0",
                         "--no-cpu-baseline", "--no-exclusive-step"] + extra, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
