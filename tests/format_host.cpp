@@ -18,6 +18,32 @@ int fh_open(const char *dir, int shard_rank, int shard_count) {
     g_err = lm::load_index(dir, shard_rank, shard_count, g_idx, st);
     return g_err.empty() ? 0 : st;
 }
+// the same with the genome bases handed to a SINK (what the loader does: to the device) instead of appended to the host store;
+// the sink here writes them where they belong in g_sunk and counts its calls
+static std::vector<unsigned char> g_sunk;
+static long g_sink_calls = 0;
+int fh_open_sink(const char *dir, int shard_rank, int shard_count) {
+    int st = 0;
+    g_idx = lm::HostIndex();
+    g_sunk.clear();
+    g_sink_calls = 0;
+    g_err = lm::load_index(dir, shard_rank, shard_count, g_idx, st, false);
+    if (!g_err.empty()) return st;
+    g_sunk.assign(g_idx.gbits_bound + 64, 0); // (zero-filled, as the loader's device buffer is: the padding behind a genome)
+    g_idx.gbits_sink = [](const uint8_t *src, size_t n, int64_t off) {
+        if (off < 0 || (size_t)off + n > g_sunk.size()) return false;
+        memcpy(g_sunk.data() + off, src, n);
+        g_sink_calls++;
+        return true;
+    };
+    g_err = lm::load_index_genomes(dir, g_idx, st);
+    g_idx.gbits_sink = nullptr;
+    if (g_err.empty()) g_idx.gbits.assign(g_sunk.begin(), g_sunk.begin() + g_idx.gbits_total); // (fh_genome reads g_idx.gbits)
+    return g_err.empty() ? 0 : st;
+}
+long fh_sink_calls() { return g_sink_calls; }
+long long fh_store_bytes() { return (long long)g_idx.gbits.size(); }
+const unsigned char *fh_store() { return g_idx.gbits.data(); }
 int fh_nfiles() { return (int)g_idx.seed_files.size(); }
 // the genome store load_index_genomes left: local genomes (bases on this shard) and the others (names and contig tables only)
 int fh_ngenomes() { return (int)g_idx.genomes.size(); }

@@ -170,3 +170,26 @@ def test_genome_batches_read_in_runs_and_a_shard_reads_only_the_heads_of_foreign
             assert v == whole[bg]
         for bg, (gid, ln, ns) in oth.items():
             assert (gid, ln, ns) == whole[bg][:3]
+
+
+@pytest.mark.parametrize("run_bytes", [None, 40000, 1])
+def test_the_bases_handed_to_a_sink_are_the_host_store(F, index, monkeypatch, run_bytes):
+    """with a sink (the loader: the device, zero-filled beforehand) load_index_genomes hands every local genome's packed bases
+    over with the offset it has in the store: what the sink received is the host store of the sink-less reader, byte for byte,
+    on every shard, for runs of all, a few and one record"""
+    if run_bytes is not None:
+        monkeypatch.setenv("LM_LOADER_RUN_BYTES", str(run_bytes))
+    F.fh_store.restype = C.POINTER(C.c_ubyte)
+    F.fh_store_bytes.restype = C.c_longlong
+    F.fh_sink_calls.restype = C.c_long
+    for r, n in ((0, 1), (0, 3), (1, 3), (2, 3)):
+        assert F.fh_open(index.encode(), r, n) == 0, F.fh_error()
+        nb = F.fh_store_bytes()
+        host = bytes(F.fh_store()[:nb])
+        loc_h, oth_h = _genomes_of(F)
+        assert F.fh_open_sink(index.encode(), r, n) == 0, F.fh_error()
+        assert F.fh_store_bytes() == nb
+        assert bytes(F.fh_store()[:nb]) == host
+        loc_s, oth_s = _genomes_of(F)
+        assert loc_s == loc_h and oth_s == oth_h
+        assert F.fh_sink_calls() == len(loc_h)

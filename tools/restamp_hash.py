@@ -39,7 +39,7 @@ for f in files:
     if doc.get("source_hash") == code_now:
         print(f, "already stamped")
         continue
-    if doc.get("source_hash") != raw_then:
+    if doc.get("source_hash") != raw_then and doc.get("source_hash_raw_at_run") != raw_then:
         sys.exit("%s is stamped %s, not the raw hash of %s (%s) - refused" % (f, doc.get("source_hash"), commit, raw_then))
     doc["source_hash_raw_at_run"] = raw_then
     doc["source_hash"] = code_now
