@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PROFILE_ROUND = "r05"  # profiles/<round>_<workload>_pmc_*.json: the committed counter passes roofline.traffic is read from
+PROFILE_ROUND = "r06"  # profiles/<round>_<workload>_pmc_*.json: the committed counter passes roofline.traffic is read from
 # instruction-issue peaks of the chip (MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, a wave64 VALU instruction issues over 2
 # cycles; ONE scalar unit per CU), wave-instructions per second at 2.4 GHz
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2
@@ -180,17 +180,15 @@ def pmc_traffic(kernel, workload, per_step=False):
             return None, "committed PMC pass was taken on other kernel sources (%s != %s): refused" % (
                 doc.get("source_hash"), source_hash())
         pm = doc.get("pmc", {})
+        # exact name only: a kernel the pass does not list yields null, never a neighbour's totals (round 5 matched by prefix and
+        # gave the whole k_wfa_lean2 family's traffic to its 128-diagonal instantiation)
         best = (kernel, pm[kernel][ctr]) if kernel in pm and ctr in pm[kernel] else None
-        for k, v in pm.items():  # older summaries name template kernels without the bench's suffix: longest prefix
-            if best is None or best[0] != kernel:
-                if ctr in v and (kernel.startswith(k) or k.startswith(kernel)) and (best is None or len(k) > len(best[0])):
-                    best = (k, v[ctr])
         if best is None:
             return None, "kernel not in the committed PMC pass"
         # per STEP when the caller asks for it: the passes time one step (--steps 1 --warmup 0), and the number of launches a
         # step is cut into differs between runs (batch parts halved under memory pressure stay halved), so a per-launch mean of
         # one run over the per-launch bytes of another would mix granularities
-        tot += (best[1]["total"] if per_step else best[1]["mean"]) * 1024.0
+        tot += (best[1]["total"] / max(int(doc.get("window_steps", 1)), 1) if per_step else best[1]["mean"]) * 1024.0
         found = True
     return (int(tot) if found else None), ("(FETCH_SIZE+WRITE_SIZE)*1024 from profiles/%s_%s_pmc_*.json (same sources%s); "
                                            "read part is a lower bound on gfx950" %
@@ -209,17 +207,15 @@ def pmc_issue(kernel, workload, per_step_launches=0):
     if doc.get("source_hash") != source_hash():
         return None
     pm = doc.get("pmc", {})
-    best = (kernel, pm[kernel]) if kernel in pm and "SQ_INSTS_VALU" in pm[kernel] else None
-    for k, v in pm.items():
-        if best is None or best[0] != kernel:
-            if "SQ_INSTS_VALU" in v and (kernel.startswith(k) or k.startswith(kernel)) and (best is None or len(k) > len(best[0])):
-                best = (k, v)
+    best = (kernel, pm[kernel]) if kernel in pm and "SQ_INSTS_VALU" in pm[kernel] else None  # (exact name only, see pmc_traffic)
     if best is None:
         return None
     v = best[1]
-    out = {c.lower() + "_per_launch": int(v[c]["total"] / per_step_launches if per_step_launches else v[c]["mean"])
+    wsteps = max(int(doc.get("window_steps", 1)), 1)  # steps between the pass's markers (1 in the passes without markers)
+    out = {c.lower() + "_per_launch": int(v[c]["total"] / wsteps / per_step_launches if per_step_launches else v[c]["mean"])
            for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS") if c in v}
-    out["note"] = "profiles/%s_%s_pmc_sq.json (kernels serialised by the counter pass)" % (PROFILE_ROUND, workload)
+    out["note"] = "profiles/%s_%s_pmc_sq.json (kernels serialised by the counter pass%s)" % (
+        PROFILE_ROUND, workload, "; " + doc["window"] if doc.get("window") else "")
     return out
 
 
@@ -676,6 +672,7 @@ def main():
         warmup_ms.append(round((time.time() - t_s0) * 1e3, 1))
     gi.profile(True)
     gi.profile_reset()
+    gi.profile_mark(1)  # (where tools/summarize_rocprof.py cuts a rocprofv3 pass: the timed - warm - steps only)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -695,6 +692,7 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    gi.profile_mark(2)
     prof = gi.profile_get()
     gi.profile(False)
     # One more step OUTSIDE the timed region with the kernels serialised (no overlapped streams): in the timed steps the WFA
@@ -820,6 +818,12 @@ def main():
                 issue["issue_frac_valu"] = round(issue.get("sq_insts_valu_per_launch", 0) / (dur_ms * 1e-3) / VALU_ISSUE_PEAK, 4)
                 issue["issue_frac_salu"] = round(issue.get("sq_insts_salu_per_launch", 0) / (dur_ms * 1e-3) / SALU_ISSUE_PEAK, 4)
                 issue["issue_frac_valu_measured_mix"] = round(issue.get("sq_insts_valu_per_launch", 0) / (dur_ms * 1e-3) / VALU_ISSUE_PEAK_MIX, 4)
+                # a fraction above 1 of a hardware issue rate is an accounting error (round 5: a family's counters over one
+                # instantiation's launches), never a finding: refused
+                over = [k for k in ("issue_frac_valu", "issue_frac_salu") if issue[k] > 1.0]
+                if over:
+                    issue = dict(refused="%s above 1.0 (%s): the counters and the launches do not describe the same work" % (
+                        ", ".join(over), ", ".join("%s=%s" % (k, issue[k]) for k in over)), note=issue.get("note"))
             return dict(bound="hbm", kernel=pk["name"], achieved=round(ach, 3), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(ach / HBM_PEAK_GBS, 6), traffic=tr, traffic_source=tn,
                         traffic_over_algorithmic=(round(tr / alg, 2) if tr and alg else None),

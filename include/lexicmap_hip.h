@@ -316,6 +316,9 @@ void lm_profile_reset(lm_index *idx);
  * per-kernel HIP-event times are exclusive times; results are unchanged. Measurement only. */
 void lm_profile_exclusive(lm_index *idx, int exclusive);
 size_t lm_profile_get(lm_index *idx, const lm_kernel_time **out);
+/* Measurement only: waits for the device, launches the empty kernel lm::k_profile_mark(id) and waits again - a boundary a
+ * rocprofv3 trace or counter pass can be cut at (tools/summarize_rocprof.py keeps the dispatches between the first two marks). */
+void lm_profile_mark(lm_index *idx, int id);
 /* Measurement only: re-reads the LM_* experiment switches (which a handle reads once, when it is opened or built) from the
  * environment, so that one resident index can be timed under several settings (bench.py --ab).  Results are unchanged by any
  * switch; the alignment scratch of the handle is dropped so that it is re-cut under the new settings. */

@@ -159,6 +159,8 @@ def lib():
     L.lm_profile_enable.argtypes = [vp, C.c_int]
     L.lm_profile_reset.argtypes = [vp]
     L.lm_profile_exclusive.argtypes = [vp, C.c_int]
+    L.lm_profile_mark.argtypes = [vp, C.c_int]
+    L.lm_profile_mark.restype = None
     L.lm_tuning_reload.argtypes = [vp]
     L.lm_tuning_reload.restype = None
     L.lm_profile_get.argtypes = [vp, C.POINTER(C.POINTER(KernelTime))]
@@ -477,6 +479,10 @@ class Index:
     def profile_exclusive(self, on=True):
         """kernels of the following searches one after the other: exclusive per-kernel times (measurement only)"""
         lib().lm_profile_exclusive(self.h, int(on))
+
+    def profile_mark(self, ident):
+        """an empty marker kernel between idle points of the device: where a rocprofv3 pass is cut (measurement only)"""
+        lib().lm_profile_mark(self.h, int(ident))
 
     def tuning_reload(self):
         """re-read the LM_* experiment switches from the environment (measurement only: results do not depend on them)"""

@@ -2652,6 +2652,10 @@ void launch_pa_filter(hipStream_t st, DevIndexView ix, const Task *tasks, int64_
         (void)hipFuncSetAttribute((const void *)k_pa_filter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PA_LDS_BYTES);
         lds_set = true;
     }
+    // ROLL slices a window into pieces of up to PA_SLICE_ROLL = 2048 positions and takes its rolling branch only for K == 31; any
+    // other k would fall into the strided branch, whose one-load-per-lane word cache covers 64 x 32 bases = PA_SLICE positions only
+    // (the end of a 2048-position slice came out garbled and candidates were dropped): other k run the strided instantiation
+    roll = roll && K == 31;
     hipLaunchKernelGGL(roll ? k_pa_filter<true> : k_pa_filter<false>, dim3(g), dim3(PA_THREADS), PA_LDS_BYTES, st, ix, tasks, ntasks, wbuf,
                        posoff, nvalid, cmp_bits, bits_off, bits_log, K, min_prefix, seg_count, nseg, seg_cap, cand, group_counter,
                        seg_by_group);

@@ -82,21 +82,75 @@ def test_rows_equal_oracle_translates_genome_keys_between_a_sample_index_and_the
 
 def test_rocprof_kernel_names_match_the_names_bench_reports():
     import summarize_rocprof as S
-    assert S.short("void lm::k_wfa_lean<2, false>(lm::WfaIn const*, long)") == "k_wfa_lean"
-    assert S.short("void lm::k_wfa_lean<4, true>(lm::WfaIn const*, long)") == "k_wfa_win256"
-    assert S.short("void lm::k_wfa_lean<8, (bool)0>(x)") == "k_wfa_lean512"
-    assert S.short("void lm::k_wfa_lean<16, (bool)1>(x)") == "k_wfa_win1024"
-    assert S.short("void lm::k_wfa_lean<4, false, short>(x)") == "k_wfa_lean256"   # the 16-bit ring instantiations
-    assert S.short("void lm::k_wfa_lean<2, false, int>(x)") == "k_wfa_lean"
-    # k_wfa_lean2 / k_wfa_mw2 keep the profile names of the kernels they replaced in round 5
+    # k_wfa_lean2 / k_wfa_mw2 keep the profile names of the kernels they replaced in round 5; any number of trailing template
+    # arguments (round 5's pattern knew three, the kernel has five: every instantiation landed under ONE name)
     assert S.short("void lm::k_wfa_lean2<2, short, false>(x)") == "k_wfa_lean"
+    assert S.short("void lm::k_wfa_lean2<2, short, false, 12, 8>(lm::WfaIn const*, long, int const*)") == "k_wfa_lean"
+    assert S.short("void lm::k_wfa_lean2<4, short, false, 12, 1>(lm::WfaIn const*, long)") == "k_wfa_lean256"
+    assert S.short("void lm::k_wfa_lean2<4, int, true, 12, 1>(lm::WfaIn const*, long)") == "k_wfa_win256"
     assert S.short("void lm::k_wfa_lean2<4, int, (bool)1>(x)") == "k_wfa_win256"
+    assert S.short("void lm::k_wfa_lean2<1, int, false, 12, 1>(x)") == "k_wfa_lean64"
+    assert S.short("void lm::k_wfa_lean2<16, int, (bool)0, 12, 1>(x)") == "k_wfa_lean1024"
     assert S.short("void lm::k_wfa_mw2<4, true>(x)") == "k_wfa_mww1024"
-    assert S.short("void lm::k_wfa_mw<2, false>(lm::WfaIn const*, long)") == "k_wfa_mw512"
-    assert S.short("void lm::k_wfa_mw<4, (bool)1>(x)") == "k_wfa_mww1024"
+    assert S.short("void lm::k_wfa_mw2<2, false>(lm::WfaIn const*, long)") == "k_wfa_mw512"
     assert S.short("void lm::k_pa_chain_wave<true>(unsigned long const*, ...)") == "k_pa_chain"
+    assert S.short("void lm::k_pa_filter<true>(lm::DevIndexView, lm::Task const*, long)") == "k_pa_filter"
     assert S.short("lm::k_pa_search(lm::DevIndexView, ...)") == "k_pa_search"
     assert S.short("void rocprim::detail::radix_sort_onesweep_kernel<...>").startswith("rocprim:")
+
+
+def test_every_kernel_of_a_committed_trace_gets_one_summary_name_per_bench_name():
+    """the kernel names rocprofv3 printed for the round-5 C3 run: each WFA instantiation must land under the name the library's
+    profile (bench.py) reports for it, and no two instantiations under one name"""
+    import csv
+    import summarize_rocprof as S
+    names = [r["Name"] for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r05_c3_kernel_stats.csv")))]
+    wfa = [n for n in names if "k_wfa_" in n]
+    got = [S.short(n) for n in wfa]
+    assert len(wfa) >= 6 and len(set(got)) == len(wfa), got
+    bench_names = {"k_wfa_lean64", "k_wfa_lean", "k_wfa_lean256", "k_wfa_lean512", "k_wfa_lean1024", "k_wfa_win64", "k_wfa_win128",
+                   "k_wfa_win256", "k_wfa_win512", "k_wfa_win1024", "k_wfa_mw512", "k_wfa_mw1024", "k_wfa_mww512", "k_wfa_mww1024", "k_wfa_wave"}
+    assert set(got) <= bench_names, set(got) - bench_names
+    assert {"k_wfa_lean", "k_wfa_lean256", "k_wfa_win256"} <= set(got)
+
+
+def test_a_pass_is_cut_at_the_step_markers(tmp_path):
+    """counters / durations of the timed (warm) steps only: the dispatches between the two lm::k_profile_mark kernels"""
+    import csv
+    import json
+    import subprocess
+    d = tmp_path / "out"
+    d.mkdir()
+    rows = []
+    seq = ["lm::k_mask(a)"] * 3 + ["lm::k_profile_mark(int)"] + ["lm::k_mask(a)", "void lm::k_wfa_lean2<2, short, false, 12, 8>(x)"] * 2 + \
+          ["lm::k_profile_mark(int)"] + ["lm::k_mask(a)"] * 5
+    for i, n in enumerate(seq):
+        rows.append(dict(Dispatch_Id=i + 1, Kernel_Name=n, Counter_Name="SQ_INSTS_SALU", Counter_Value=10 + i))
+    with open(d / "x_counter_collection.csv", "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0]))
+        w.writeheader()
+        w.writerows(rows)
+    with open(d / "x_kernel_trace.csv", "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=["Dispatch_Id", "Kernel_Name", "Start_Timestamp", "End_Timestamp"])
+        w.writeheader()
+        for i, n in enumerate(seq):
+            w.writerow(dict(Dispatch_Id=i + 1, Kernel_Name=n, Start_Timestamp=1000 * i, End_Timestamp=1000 * i + 100 + i))
+    out = tmp_path / "s.json"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "summarize_rocprof.py"), str(d), str(out), "hash", "python bench.py --steps 2 --warmup 1"],
+                          stdout=subprocess.DEVNULL)
+    doc = json.load(open(out))
+    assert "between the two" in doc["window"] and doc["window_steps"] == 2
+    assert doc["pmc"]["k_mask"]["SQ_INSTS_SALU"]["dispatches"] == 2 and doc["pmc"]["k_wfa_lean"]["SQ_INSTS_SALU"]["dispatches"] == 2
+    assert doc["pmc"]["k_mask"]["SQ_INSTS_SALU"]["total"] == (10 + 4) + (10 + 6)
+    ks = {k["name"]: k for k in doc["kernel_stats"]}
+    assert ks["k_mask"]["calls"] == 2 and ks["k_wfa_lean"]["calls"] == 2 and "k_profile_mark" not in ks
+    # a run without markers is summed whole and carries no window
+    for f in (d / "x_counter_collection.csv", d / "x_kernel_trace.csv"):
+        f.write_text(f.read_text().replace("lm::k_profile_mark(int)", "lm::k_other(int)"))
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "summarize_rocprof.py"), str(d), str(out), "hash", "python bench.py --steps 2"],
+                          stdout=subprocess.DEVNULL)
+    doc = json.load(open(out))
+    assert "window" not in doc and "window_steps" not in doc and doc["pmc"]["k_mask"]["SQ_INSTS_SALU"]["dispatches"] == 10
 
 
 def test_workloads_name_every_baseline_config_and_the_shards_fit():
@@ -136,6 +190,13 @@ def test_counter_passes_are_spread_over_this_runs_launches_per_step(tmp_path, mo
     assert per_launch == 3000 * 1024 and per_step == 100 * 3000 * 1024 and "launches per step" in note
     assert bench.pmc_issue("k_wfa_lean", "c3")["sq_insts_valu_per_launch"] == 5000000
     assert bench.pmc_issue("k_wfa_lean", "c3", per_step_launches=400)["sq_insts_valu_per_launch"] == 1250000
+    # exact names only: a kernel the pass does not list gets nothing - never the counters of a neighbour whose name it starts
+    assert bench.pmc_traffic("k_wfa_lean256", "c3", per_step=True)[0] is None and bench.pmc_issue("k_wfa_lean256", "c3") is None
+    assert bench.pmc_traffic("k_wfa", "c3")[0] is None
+    # a pass cut at the step markers over two steps: totals are per window, the bench wants them per step
+    sq["window_steps"] = 2
+    (prof / ("%s_c3_pmc_sq.json" % bench.PROFILE_ROUND)).write_text(json.dumps(sq))
+    assert bench.pmc_issue("k_wfa_lean", "c3", per_step_launches=400)["sq_insts_valu_per_launch"] == 625000
     monkeypatch.setattr(bench, "source_hash", lambda: "other")   # passes of other sources are refused
     assert bench.pmc_traffic("k_wfa_lean", "c3", per_step=True)[0] is None and bench.pmc_issue("k_wfa_lean", "c3") is None
 

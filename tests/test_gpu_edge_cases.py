@@ -73,3 +73,29 @@ def test_whole_contig_as_query(idx):
             assert e[f] == r[f], f
     best = rows[0]
     assert best["pident"] == 100.0 and best["aligned_length"] == len(contig) and best["qcov_hsp"] == 100.0
+
+
+@pytest.mark.parametrize("k", [21, 27])
+def test_an_index_with_k_below_31_gives_the_oracle_rows_for_windows_beyond_2048_positions(tmp_path, k):
+    """k is index-defined (info.toml max-K; SURVEY section 8: 'always read it from the index').  The anchor filter's rolling form is
+    written for K == 31 and slices windows into pieces of up to 2048 positions; any other k must run the strided form with its
+    1920-position slices (lm_kernels.hip launch_pa_filter) - reads of 4-6 kb give chain windows well beyond 2048 positions"""
+    import lexicmap_amd as la
+    from lexicmap_amd import synth
+    genomes = synth.make_genomes(5, 80_000, 1, seed=13, max_div=0.05)
+    queries = synth.make_gene_queries(genomes, 6, seed=14, len_range=(4000, 6000), max_div=0.06)
+    d = str(tmp_path / ("k%d.lmi" % k))
+    O.build_index(d, genomes, O.default_build_opt(chunks=2, k=k))
+    gi, oi = la.Index(d), O.Index(d)
+    try:
+        assert gi.info()["k"] == k
+        ids, seqs = [q[0] for q in queries], [q[1] for q in queries]
+        got = gi.search_tsv(ids, seqs)
+        exp = []
+        for i, s in zip(ids, seqs):
+            exp += oi.search_tsv(i, s)
+        assert len(exp) > 10 and max(int(r.split("\t")[9]) for r in exp) > 2048   # alignments beyond 2048 bases
+        assert got == exp
+    finally:
+        gi.close()
+        oi.close()
