@@ -52,6 +52,17 @@ __device__ __forceinline__ int l2_sflb(unsigned long long m) {
 #define WR_FLB(x) l2_sflb(x)
 #define WR_READLANE(v, l) __builtin_amdgcn_readlane((v), (l)) /* `l` is wave-uniform */
 #define WR_ALIGNBIT(hi, lo, sh) __builtin_amdgcn_alignbit((hi), (lo), (sh))
+// -2 pos modulo 32 (positions are below 2^24): one full-rate v_mul_u32_u24 the compiler cannot turn back into v_mul_lo_u32
+__device__ __forceinline__ uint32_t l2_neg2(int pos) {
+#ifdef L2_NO_ASM
+    return 30u * (uint32_t)pos;
+#else
+    uint32_t r;
+    asm("v_mul_u32_u24 %0, %1, 30" : "=v"(r) : "v"(pos));
+    return r;
+#endif
+}
+#define WR_NEG2(pos) l2_neg2(pos)
 
 #include "lm_wfa_lean2_fwd.h"
 

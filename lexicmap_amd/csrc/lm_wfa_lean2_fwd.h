@@ -62,11 +62,17 @@ struct L2Res {
 // cells of the ring: nine rows (M 0-4, I 5-6, D 7-8) of 64 * NC cells + a pad cell on either side
 template <int NC> constexpr int l2_ring_cells() { return 9 * (64 * NC + 2); }
 
+// WR_NEG2(pos): a shift count equal to -2 pos modulo 32.  (Written in C - in whatever form - the compiler reduces it to
+// v_mul_lo_u32 pos, 30: the funnel shift only looks at five bits, and 30 = -2 modulo 32.  That is a quarter-rate instruction,
+// twice per extension pass and chunk; the device macro is one full-rate v_mul_u32_u24.)
+#ifndef WR_NEG2
+#define WR_NEG2(pos) (30u * (uint32_t)(pos))
+#endif
 // 16 packed bases from base `pos` (first base in the top bits of a word; seq[-1] must be readable): the two words that hold
 // the LAST of the 32 bits, funnel-shifted - one v_alignbit_b32 whatever the position, no 64-bit shift, no half swaps
 WR_DEV uint32_t l2_get16(const uint32_t *seq, int pos) {
     const uint32_t *w = seq + ((pos + 15) >> 4); // = (2 pos + 31) >> 5: the word of the last bit
-    return WR_ALIGNBIT(w[-1], w[0], ~(2u * (uint32_t)pos + 31u)); // ({w[-1], w[0]} >> (-2 pos & 31)) & 0xffffffff
+    return WR_ALIGNBIT(w[-1], w[0], WR_NEG2(pos)); // ({w[-1], w[0]} >> (-2 pos & 31)) & 0xffffffff
 }
 
 // ---- sliding 2-bit windows (the WIN form): the layout of k_wfa_lean's WfaWin - each sequence a circular window of L2_WINW
@@ -97,7 +103,7 @@ WR_DEV bool l2_win_has(int w0, int pos) { return (uint32_t)((pos >> 4) - w0) < (
 // in front of the window's first word is read and ignored when pos is a multiple of 16)
 WR_DEV void l2_win_get32(const uint32_t *buf, int pos, uint32_t *hi, uint32_t *lo) {
     const uint32_t *w = buf + ((((pos + 15) >> 4) - 1) & (L2_WINW - 1));
-    const uint32_t sh = ~(2u * (uint32_t)pos + 31u);
+    const uint32_t sh = WR_NEG2(pos);
     *hi = WR_ALIGNBIT(w[0], w[1], sh);
     *lo = WR_ALIGNBIT(w[1], w[2], sh);
 }
@@ -160,16 +166,24 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
         ilo[a] = dlo[a] = E_LO;
         ihi[a] = dhi[a] = E_HI;
     }
-    // a chunk whose cells were all NULL for the last five scores is NULL in every ring row: nothing to store while it is idle
-    int last_act[NC];
-#pragma unroll
-    for (int c = 0; c < NC; c++) last_act[c] = -1000;
-    last_act[0] = 0;
+    // FLAVOURS (round 6).  Every live row lies in chunks [0, na) of the frame - the ring rows are all NULL beyond, since the shift
+    // that last centred them rewrote every cell - and the hot loop exists in one copy per flavour NA (up to three: NA_MIN, 2 NA_MIN,
+    // 4 NA_MIN <= NC) that works on chunks 0 .. NA-1 UNCONDITIONALLY: no "does this chunk hold cells of the row" test in front of the
+    // recurrence, the extension, the cut-off and the stores of every chunk, no record of when a chunk was last active, no NULL-back
+    // stores (round 5: seven scalar instructions per test, ~55 of the 205 scalar instructions of a 128-diagonal step - on the unit
+    // that bounds the kernel).  A row that leaves the chunks of its flavour, or fits a narrower one with the margin, ends the hot
+    // loop; the frame code below shifts the rows and picks the flavour.
+    constexpr int NA_MIN = NC >= 16 ? 4 : NC >= 8 ? 2 : 1;
+    int na = NA_MIN;
     if (p.max_score < 1 || p.arena_cap < 1) status = 1;
     if (R16 && (plen > 12000 || tlen > 12000)) {
         status = 3;
         wide_at = W; // (never 0 with status 3: a 0 means 'not plain ACGT' to the host)
     }
+    // the end test as ONE compare per chunk: tlen on the lane of the final diagonal, out of reach elsewhere
+    int endk[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) endk[c] = kcol[c] == ak ? tlen : 2147483647;
     int s = 0;
     // this lane's cell (chunk 0) in the ring rows, by age: pM[a] = M[s-2a] (pM[0] is also where score 0 goes), pI / pD[0] = I / D[s],
     // [1] = I / D[s-2].  Rotated with the scores: five + four cheap register moves per score instead of the index arithmetic,
@@ -209,33 +223,37 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
         // a lane extends while h < lim; it stops by pulling lim down to h.  (The predicate is recomputed from registers every
         // pass: the wave mask of one compare is free, that of a loop-carried flag costs two vector instructions.)
         int lim = valid ? hmax : 0;
-        while (true) { // (the positions of idle lanes stay inside the sequences)
-            const bool ext = h < lim;
-            if (WR_BALLOT(ext) == 0ull) break;
-            const uint32_t d = l2_get16(qb, h - k) ^ l2_get16(tb, h);
-            const int nm = WR_CLZ(d) >> 1; // 16 when all 16 bases match
-            h += ext ? nm : 0;
-            lim = nm == 16 ? lim : h;
+        // (guard + do-while: one compare + one conditional branch back per pass, nothing else of loop control - a while (true)
+        // with a break in it came out of the compiler with two branches, a select and a mask test per pass inside the big kernel)
+        if (WR_BALLOT(h < lim) != 0ull) {
+            do { // (the positions of idle lanes stay inside the sequences)
+                const bool ext = h < lim;
+                const uint32_t d = l2_get16(qb, h - k) ^ l2_get16(tb, h);
+                const int nm = WR_CLZ(d) >> 1; // 16 when all 16 bases match
+                h += ext ? nm : 0;
+                lim = nm == 16 ? lim : h;
+            } while (WR_BALLOT(h < lim) != 0ull);
         }
-        if (!decltype(in_edge)::value) edge_m = WR_UNIFORM(edge_m | (WR_BALLOT(valid && h >= hmax) != 0ull ? -1 : 0));
+        // (an idle lane has h = 0 < hmax unless a sequence is empty - and then the EDGE copy, which is right anywhere, runs from the start)
+        if (!decltype(in_edge)::value) edge_m = WR_UNIFORM(edge_m | (WR_BALLOT(h >= hmax) != 0ull ? -1 : 0));
         return h < hmax ? h : hmax;
     };
     // WIN: the cells of all chunks of a lane, 32 bases per pass through the windows.  A cell outside a window waits; once
     // nobody inside extends any more, both windows move to the smallest waiting positions (the cell with the smallest query
     // position is then inside both: two cells of a wavefront are less than W < 4000 diagonals apart) - k_wfa_lean's scheme.
     // h[c] / k[c]: offset and diagonal of a valid cell, 0 / 0 for an idle one; on[c]: the chunk has valid cells (wave-uniform).
-    auto extend_win = [&](auto in_edge, int *h, const int *k, const bool *valid, const bool *on) {
-        int lim[NC], hmax[NC];
+    auto extend_win = [&](auto in_edge, auto na_tag, int *h, const int *k, const bool *valid) {
+        constexpr int NA = decltype(na_tag)::value;
+        int lim[NA], hmax[NA];
 #pragma unroll
-        for (int c = 0; c < NC; c++) {
+        for (int c = 0; c < NA; c++) {
             hmax[c] = tlen < plen + k[c] ? tlen : plen + k[c];
             lim[c] = valid[c] ? hmax[c] : 0;
         }
         while (true) {
             uint64_t pend = 0;
 #pragma unroll
-            for (int c = 0; c < NC; c++) {
-                if (!on[c]) continue;
+            for (int c = 0; c < NA; c++) {
                 while (true) {
                     const uint64_t go_m = WR_BALLOT(h[c] < lim[c]) & WR_BALLOT(l2_win_has(qw0, h[c] - k[c])) & WR_BALLOT(l2_win_has(tw0, h[c]));
                     if (go_m == 0ull) break;
@@ -254,8 +272,8 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
             if (pend == 0ull) break;
             int mv = 2147483647, mh = 2147483647;
 #pragma unroll
-            for (int c = 0; c < NC; c++) {
-                const bool wt = on[c] && h[c] < lim[c];
+            for (int c = 0; c < NA; c++) {
+                const bool wt = h[c] < lim[c];
                 mh = wt && h[c] < mh ? h[c] : mh;
                 mv = wt && h[c] - k[c] < mv ? h[c] - k[c] : mv;
             }
@@ -264,8 +282,8 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
             l2_win_move2(qb, p.q, plen, &qw0, mv >> 4, tb, p.t, tlen, &tw0, mh >> 4, lane, &bad, false);
         }
 #pragma unroll
-        for (int c = 0; c < NC; c++) {
-            if (!decltype(in_edge)::value && on[c]) edge_m = WR_UNIFORM(edge_m | (WR_BALLOT(valid[c] && h[c] >= hmax[c]) != 0ull ? -1 : 0));
+        for (int c = 0; c < NA; c++) {
+            if (!decltype(in_edge)::value) edge_m = WR_UNIFORM(edge_m | (WR_BALLOT(h[c] >= hmax[c]) != 0ull ? -1 : 0));
             h[c] = h[c] < hmax[c] ? h[c] : hmax[c];
         }
     };
@@ -274,16 +292,9 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
         const bool mine = kcol[0] == 0;
         int h;
         if (WIN) {
-            int h_[NC], k_[NC];
-            bool v_[NC], on_[NC];
-#pragma unroll
-            for (int c = 0; c < NC; c++) {
-                h_[c] = k_[c] = 0;
-                v_[c] = on_[c] = false;
-            }
-            v_[0] = mine;
-            on_[0] = true;
-            extend_win(std::false_type{}, h_, k_, v_, on_);
+            int h_[1] = {0}, k_[1] = {0};
+            bool v_[1] = {mine};
+            extend_win(std::false_type{}, std::integral_constant<int, 1>{}, h_, k_, v_);
             h = h_[0];
         } else {
             h = extend(std::false_type{}, mine, 0, 0);
@@ -295,17 +306,18 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
     }
     // Two loops.  The INNER one is the score step and nothing else: before a step it looks at the row the step would make
     // (from the ranges it already has) and leaves when anything but a plain step is due - the end, a limit, an empty row, a
-    // row outside the frame or in more chunks than it needs, scratch running out.  The OUTER one does that rare thing and
-    // comes back.  (With the rare paths inside the step, every variable they touch is merged on every path of every step:
-    // a fifth of the step's instructions were register copies.)
+    // row outside the chunks of the flavour or one that fits a narrower flavour, scratch running out.  The OUTER one does that
+    // rare thing and comes back.  (With the rare paths inside the step, every variable they touch is merged on every path of
+    // every step: a fifth of the step's instructions were register copies.)
     const int s_limit = R16 && p.max_score > 24000 ? 24000 : p.max_score; // (16-bit cells could wrap from s = 24000 on)
     int s_lim = s_limit; // the hot loop's copy: pulled below every score once the end is reached (one sign test covers both)
-    int shrink_from = 0; // no "fewer chunks ?" test before this score (a live row may be wider than the new one for a while)
+    int shrink_from = 0; // no "narrower flavour ?" test before this score (a live row may be wider than the new one for a while)
     int lo = 0, hi = 0; // the row of score s + 2 as the hot loop saw it when it left
     int32_t *hp = p.hdr2; // = p.hdr2 + s: carried along instead of recomputed from s (a 64-bit shift and add per score)
-    // the hot loop, in two copies: INTERIOR (leaves also at the first touch) and EDGE
-    auto hot = [&](auto in_edge) {
+    // the hot loop, in 2 x (1 to 3) copies: INTERIOR (leaves also at the first touch) and EDGE, per flavour
+    auto hot = [&](auto in_edge, auto na_tag) {
         constexpr bool EDGE = decltype(in_edge)::value;
+        constexpr int NA = decltype(na_tag)::value;
         while (true) {
             // the row of score s + 2; sources: M[s-2] (mismatch), M[s-6] (gap open), I[s] / D[s] (gap extension)
             // (two-way minima pinned to the scalar unit: a three-way one is selected as v_min3_i32 + v_readfirstlane_b32)
@@ -317,12 +329,11 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
                 hi = h2 > hi ? h2 : hi;
             }
             const uint32_t span = (uint32_t)(hi - lo); // (an empty row: far above W)
-            const int cf = (lo - kbase) >> 6, cl = (hi - kbase) >> 6; // chunks holding cells of [lo, hi]
             // every "not a plain step" condition as the sign of one word (scalar adds and ORs, one compare): the end reached; the
-            // score limit; an empty row (hi < lo); the row outside the frame; scratch; more chunks than the row needs
-            uint32_t rare = (EDGE ? 0u : (uint32_t)edge_m) | (uint32_t)(s_lim - 3 - s) | span | (uint32_t)(lo - kbase) | (uint32_t)(kbase + W - 1 - hi) |
+            // score limit; an empty row (hi < lo); the row outside the chunks of the flavour; scratch; a narrower flavour would do
+            uint32_t rare = (EDGE ? 0u : (uint32_t)edge_m) | (uint32_t)(s_lim - 3 - s) | span | (uint32_t)(lo - kbase) | (uint32_t)(kbase + 64 * NA - 1 - hi) |
                             ((uint32_t)p.arena_cap - (uint32_t)used - span - 1u);
-            if (NC > 1) rare |= (uint32_t)((int)((span + 1 + 2 * MARGIN + 63) >> 6) - (cl - cf + 1)) & ~(uint32_t)(s + 2 - WR_UNIFORM(shrink_from));
+            if (NA > NA_MIN) rare |= (uint32_t)((int)span + 2 * MARGIN - 32 * NA) & ~(uint32_t)(s + 2 - WR_UNIFORM(shrink_from));
             if ((int32_t)rare < 0) break;
             // ---- a plain step ----
             s += 2;
@@ -350,25 +361,20 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
             const LP newM = pM[0], newI = pI[0], newD = pD[0];
             const int32_t rowb = used;
             used += (int32_t)span + 1;
-            if (lane == 0) { // entry s/2 = {lo, row offset}; the offset of entry s/2+1 closes the row
-                hp[0] = lo;
-                hp[1] = rowb;
-                hp[3] = used;
-            }
+            // entry s/2 = {lo, row offset}; the offset of entry s/2+1 closes the row.  EVERY lane stores the same three words to
+            // the same addresses (one request): restricting it to lane 0 cost six scalar instructions of exec-mask traffic per score
+            hp[0] = lo;
+            hp[1] = rowb;
+            hp[3] = used;
             const LP M8 = pM[4], M4 = pM[2], I2 = pI[1], D2 = pD[1]; // rows of s-8, s-4, s-2
             const int32_t rowk = rowb - lo; // byte of diagonal k: bt[rowk + k] (never negative for a cell of the row)
-            int32_t off[NC], vins[NC], vdel[NC];
+            int32_t off[NA], vins[NA], vdel[NA];
             // first / last cell inside the DP matrix of each of the three new wavefronts, as slots: lane order is diagonal order, so
             // these are ballots + ff1 / flbit on the scalar unit (none: first = 0xffffffff, last < 0)
             uint32_t fm = 0xffffffffu, fi = 0xffffffffu, fd = 0xffffffffu;
             int lm = -1, li = -1, ld = -1;
-            uint32_t cmv = 0; // bit c: chunk c holds a valid M cell
 #pragma unroll
-            for (int c = 0; c < NC; c++) {
-                off[c] = RNULL;
-                vins[c] = vdel[c] = RNULL;
-                if (NC > 1 && (c < cf || c > cl)) continue;
-                last_act[c] = s;
+            for (int c = 0; c < NA; c++) {
                 const int k = kcol[c];
                 int32_t a = M8[64 * c], b = I2[64 * c];
                 const bool iext = b >= a; // equal offsets: extension (lm_wfa_backtrace tags 2 > 1)
@@ -407,7 +413,6 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
                 lm = l_m > lm ? l_m : lm;
                 li = l_i > li ? l_i : li;
                 ld = l_d > ld ? l_d : ld;
-                if (NC > 1) cmv |= ((uint32_t)~l_m >> 31) << c; // (l_m >= 0: the chunk has a valid M cell)
             }
             // (WR_UNIFORM: provably scalar - the ranges stay in scalar registers and so does everything derived from them)
             if (EDGE) {
@@ -434,54 +439,45 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
                 mlo[0] = m_lo; // (= lo, hi of the row: never empty here)
                 mhi[0] = m_hi;
                 lm = 0; // "there is a valid M cell"
-                if (NC > 1) {
-                    const int cf2 = (m_lo - kbase) >> 6, cl2 = (m_hi - kbase) >> 6;
-                    cmv = ((2u << cl2) - 1u) & ~((1u << cf2) - 1u);
-                }
             }
             // ---- the new M cells, still in registers: greedy extension, end test, cut-off ----
             bool cut = false;
             if (lm >= 0) {
                 if (WIN) {
-                    int h_[NC], k_[NC];
-                    bool v_[NC], on_[NC];
+                    int h_[NA], k_[NA];
+                    bool v_[NA];
 #pragma unroll
-                    for (int c = 0; c < NC; c++) {
+                    for (int c = 0; c < NA; c++) {
                         v_[c] = off[c] >= 0;
-                        on_[c] = NC == 1 || ((cmv >> c) & 1u) != 0;
                         h_[c] = v_[c] ? off[c] : 0;
                         k_[c] = v_[c] ? kcol[c] : 0;
                     }
-                    extend_win(in_edge, h_, k_, v_, on_);
+                    extend_win(in_edge, na_tag, h_, k_, v_);
 #pragma unroll
-                    for (int c = 0; c < NC; c++) off[c] = v_[c] ? h_[c] : RNULL;
+                    for (int c = 0; c < NA; c++) off[c] = v_[c] ? h_[c] : RNULL;
                 } else {
 #pragma unroll
-                    for (int c = 0; c < NC; c++) {
-                        if (NC > 1 && !((cmv >> c) & 1u)) continue; // (wave-uniform)
+                    for (int c = 0; c < NA; c++) { // (a chunk without valid cells leaves at the first ballot)
                         const bool valid = off[c] >= 0;
                         const int h = extend(in_edge, valid, valid ? off[c] : 0, valid ? kcol[c] : 0);
                         off[c] = valid ? h : RNULL;
                     }
                 }
                 // the end: the cell of the final diagonal has reached the end of the target (the cut-off and the stores below
-                // still run once: nothing reads them, and the step has no way out but its end)
-                if (ak >= mlo[0] && ak <= mhi[0]) {
-                    const int sa = ak - kbase;
-                    int32_t hak = RNULL;
+                // still run once: nothing reads them, and the step has no way out but its end).  endk is tlen on that lane only; an
+                // invalid cell is NULL, below every tlen
+                {
+                    uint64_t eb = 0ull;
 #pragma unroll
-                    for (int c = 0; c < NC; c++)
-                        if ((sa >> 6) == c) hak = WR_READLANE(off[c], sa & 63);
-                    done = hak >= tlen;
+                    for (int c = 0; c < NA; c++) eb |= WR_BALLOT(off[c] >= endk[c]);
+                    done = eb != 0ull;
                     s_lim = WR_UNIFORM(done ? -(1 << 30) : s_lim);
                 }
                 if (mhi[0] - mlo[0] + 1 >= 10) { // wf-adaptive(10, 50)
-                    int32_t dist[NC];
+                    int32_t dist[NA];
                     int32_t dm = 2147483647;
 #pragma unroll
-                    for (int c = 0; c < NC; c++) {
-                        dist[c] = 2147483647;
-                        if (NC > 1 && !((cmv >> c) & 1u)) continue;
+                    for (int c = 0; c < NA; c++) {
                         // (an invalid cell is NULL: its distance comes out beyond every valid one + 50 by itself)
                         const int32_t lv = plen - off[c] + kcol[c], lh = tlen - off[c];
                         dist[c] = lv > lh ? lv : lh;
@@ -489,24 +485,25 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
                     }
                     const int32_t dmin = WR_WAVE_MIN_I32(dm);
                     // The diagonals that stay: lm_wfa_align walks up from mlo to the first kept one below `top` and down from
-                    // mhi to the last kept one above `bottom` = max(ak, new lo) - which is max(ak, mlo) (see k_wfa_lean)
+                    // mhi to the last kept one above `bottom` = max(ak, new lo) - which is max(ak, mlo) (see k_wfa_lean).  With the
+                    // lanes from `top` on counted as kept, the first kept lane IS the new lo (a kept cell below top if there is
+                    // one, else top; never below mlo: kept cells are valid ones) - and the lanes up to `bottom` likewise for the new hi
                     const int top = ak < mhi[0] ? ak : mhi[0];
                     const int bottom = ak > mlo[0] ? ak : mlo[0];
                     uint32_t fl = 0xffffffffu;
                     int lh_ = -1;
 #pragma unroll
-                    for (int c = 0; c < NC; c++) {
-                        if (NC > 1 && !((cmv >> c) & 1u)) continue;
+                    for (int c = 0; c < NA; c++) {
                         const uint64_t keep = WR_BALLOT(dist[c] - dmin <= 50);
-                        const uint64_t kl = keep & WR_BALLOT(kcol[c] < top), kh = keep & WR_BALLOT(kcol[c] > bottom);
+                        const uint64_t kl = keep | WR_BALLOT(kcol[c] >= top), kh = keep | WR_BALLOT(kcol[c] <= bottom);
                         const uint32_t f = (uint32_t)WR_FF1(kl) | (uint32_t)(64 * c);
                         const int l = WR_FLB(kh) ^ (64 * c + 63);
                         fl = f < fl ? f : fl;
                         lh_ = l > lh_ ? l : lh_;
                     }
-                    int nlo = mlo[0], nhi = mhi[0];
-                    if (mlo[0] < top) nlo = (int)fl >= 0 ? kbase + (int)fl : top;
-                    if (mhi[0] > bottom) nhi = lh_ >= 0 ? kbase + lh_ : bottom;
+                    int nlo = kbase + (int)fl, nhi = kbase + lh_; // (top and bottom are inside the chunks of the flavour: both exist)
+                    nlo = nlo > mlo[0] ? nlo : mlo[0];
+                    nhi = nhi < mhi[0] ? nhi : mhi[0];
                     if (nlo != mlo[0] || nhi != mhi[0]) {
                         // I[s] / D[s] are clamped to the reduced M range (empty stays empty: the sentinels survive max / min)
                         cut = true;
@@ -535,11 +532,7 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
             {
                 const uint32_t spm = (uint32_t)(mhi[0] - mlo[0]), spi = (uint32_t)(ihi[0] - ilo[0]), spd = (uint32_t)(dhi[0] - dlo[0]);
 #pragma unroll
-                for (int c = 0; c < NC; c++) { // (k - E_LO) as unsigned is above every span, also above the span of an empty range
-                    if (NC > 1 && (c < cf || c > cl)) {
-                        if (s - last_act[c] <= 10) newM[64 * c + 1] = newI[64 * c + 1] = newD[64 * c + 1] = (RT)RNULL; // what this chunk held 5 / 2 scores ago
-                        continue;
-                    }
+                for (int c = 0; c < NA; c++) { // (k - E_LO) as unsigned is above every span, also above the span of an empty range
                     const int k = kcol[c];
                     int32_t m = off[c];
                     if (cut) m = (uint32_t)(k - mlo[0]) <= spm ? m : RNULL; // (without a cut the cells outside the range are NULL already)
@@ -551,11 +544,21 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
             WR_WAVE_SYNC(); // the rows of score s are in the ring
         }
     };
+    // the flavours this ring width has: NA_MIN, then twice and four times that while they fit
+    constexpr int F0 = NA_MIN, F1 = 2 * F0 <= NC ? 2 * F0 : NC, F2 = 4 * F0 <= NC ? 4 * F0 : NC;
+    auto run_hot = [&](auto in_edge) {
+        if (na == F0)
+            hot(in_edge, std::integral_constant<int, F0>{});
+        else if (F1 != F0 && na == F1)
+            hot(in_edge, std::integral_constant<int, F1>{});
+        else
+            hot(in_edge, std::integral_constant<int, F2>{});
+    };
     while (status == 0 && !done) {
         if (edge_m)
-            hot(std::true_type{});
+            run_hot(std::true_type{});
         else
-            hot(std::false_type{});
+            run_hot(std::false_type{});
         // ---- what is due instead of a plain step (lo, hi: the row of score s + 2; possibly nothing but the first touch) ----
         if (done) break;
         if (s + 2 >= s_limit) {
@@ -590,11 +593,9 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
             mhi[0] = ihi[0] = dhi[0] = E_HI;
 #pragma unroll
             for (int c = 0; c < NC; c++) pM[0][64 * c + 1] = pI[0][64 * c + 1] = pD[0][64 * c + 1] = (RT)RNULL;
-            if (lane == 0) { // same offset as the next row
-                hp[0] = 0;
-                hp[1] = used;
-                hp[3] = used;
-            }
+            hp[0] = 0; // same offset as the next row
+            hp[1] = used;
+            hp[3] = used;
             WR_WAVE_SYNC();
             continue;
         }
@@ -603,7 +604,7 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
             break;
         }
         // The frame.  Every live row - M[s] .. M[s-6], I / D[s] (I may start at lo - 1, D may end at hi + 1) - and the new one
-        // must be inside slots [0, W); with fewer chunks than they touch now if they fit with a margin.
+        // must be inside the chunks of the flavour; the flavour is the narrowest that holds them with the margin.
         {
             int ulo = lo < mlo[0] ? lo : mlo[0], uhi = hi > mhi[0] ? hi : mhi[0];
             ulo = mlo[2] < ulo ? mlo[2] : ulo;
@@ -616,16 +617,16 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
                 wide_at = uw;
                 break;
             }
-            int nch = (uw + 2 * MARGIN + 63) >> 6; // chunks the live rows get
-            nch = nch < NC ? nch : NC;
-            const bool out = lo < kbase || hi > kbase + W - 1;
-            const int touched = ((uhi - kbase) >> 6) - ((ulo - kbase) >> 6) + 1;
-            if (!out && nch >= touched) { // the new row asks for fewer chunks, the live rows do not allow it yet
+            int f = NA_MIN; // the flavour the live rows get (NC when the margin does not fit anywhere: uw <= W)
+            while (f < NC && 64 * f < uw + 2 * MARGIN) f *= 2;
+            const bool out = lo < kbase || hi > kbase + 64 * na - 1;
+            if (!out && f >= na) { // the new row asks for a narrower flavour, the live rows do not allow it yet (or: the first touch)
                 shrink_from = WR_UNIFORM(s + 2 + 8);
                 continue;
             }
-            // shift the nine rows: the live rows centred on the first nch chunks
-            const int nk = WR_UNIFORM(ulo - (64 * nch - uw) / 2);
+            // shift the nine rows: the live rows centred on the chunks of the flavour (every cell of every row is rewritten:
+            // what lies outside the live rows becomes NULL)
+            const int nk = WR_UNIFORM(ulo - (64 * f - uw) / 2);
             const int delta = nk - kbase; // new slot i <- old slot i + delta
 #pragma unroll 1
             for (int r = 0; r < 9; r++) {
@@ -641,10 +642,12 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
             }
             WR_WAVE_SYNC();
             kbase = nk;
+            na = WR_UNIFORM(f);
+            shrink_from = WR_UNIFORM(s + 2 + 8);
 #pragma unroll
             for (int c = 0; c < NC; c++) {
                 kcol[c] = nk + lane + 64 * c;
-                last_act[c] = s; // (anything may have moved anywhere)
+                endk[c] = kcol[c] == ak ? tlen : 2147483647;
             }
             nrec++;
         }

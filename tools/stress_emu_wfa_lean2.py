@@ -7,7 +7,7 @@ import random
 import sys
 import time
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 from test_device_algos_cpu import mutate, rand_seq, run_oracle_wfa  # noqa: E402
 import test_wfa_lean2_emulated_cpu as L2  # noqa: E402
 import test_wfa_mw2_emulated_cpu as M2  # noqa: E402
