@@ -2742,14 +2742,8 @@ typedef void (*WfaLeanFn)(const WfaIn *, int64_t, const int32_t *, int64_t, int3
                           unsigned int *, int, int, WfaOut *, unsigned long long *);
 // r16: 16-bit ring cells (whole-sequence kernels of 128 / 256 diagonals, sequences up to 12 000 bases: lm_kernels.h)
 static WfaLeanFn wfa_lean_fn(int nc, bool win, bool r16) { // (lm_wfa_lean2.h)
-    // (shrink margins 4 and 8 of the dominant instantiation - longer in ONE chunk of 64 slots, more recentres - were measured
-    // on one resident C3 index against the 12 it has: 9.67 / 9.80 s against 9.69 s per step, no difference; removed)
-    if (const char *e = getenv("LM_WFA_MARGIN")) { // (round-6 A/B of the flavour margin on the dominant instantiation; removed once decided)
-        const int m = atoi(e);
-        if (r16 && !win && nc == 2 && m == 4) return k_wfa_lean2<2, int16_t, false, 4, 8>;
-        if (r16 && !win && nc == 2 && m == 8) return k_wfa_lean2<2, int16_t, false, 8, 8>;
-        if (r16 && !win && nc == 2 && m == 2) return k_wfa_lean2<2, int16_t, false, 2, 8>;
-    }
+    // (flavour margins 2 / 4 / 8 / 12 of the dominant instantiation - the free slots either side when the live rows are centred
+    // on the chunks of a flavour - measured on one resident c3mini index: 321 / 318 / 315 / 321 ms per step; 8 kept)
     if (r16 && !win && nc == 2) return k_wfa_lean2<2, int16_t, false, L2_SHRINK_MARGIN, 8>; // (64 VGPRs, 8 wavefronts per SIMD: no difference at C3, kept with k_pa_chain_wave's)
     if (r16 && !win && nc == 4) return k_wfa_lean2<4, int16_t, false>;
     switch (nc) {

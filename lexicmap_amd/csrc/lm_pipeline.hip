@@ -181,10 +181,22 @@ void lm_set_scratch_budget(lm_index *ix) {
 }
 void lm_reserve_lane_slabs(lm_index *ix) {
     if (ix->tune.arena_reserve_pct <= 0 || ix->lane_slabs.asked || ix->scratch_budget <= 0) return;
-    const bool ok = ix->lane_slabs.reserve((size_t)(ix->scratch_budget / 100 * ix->tune.arena_reserve_pct));
+    int64_t want = ix->scratch_budget / 100 * ix->tune.arena_reserve_pct;
+    if (ix->hbm_bytes < ((int64_t)4 << 30)) {
+        // A small index (tests, stage calls, shard handles sharing a device, a host that embeds the library beside other users of
+        // the GPU) reaches this at its first search, possibly long after it was opened: the budget is taken from what is free NOW
+        // (another handle's slabs may have appeared since), and the slabs it keeps until it is closed are capped - 72 % of the
+        // device held by every 60-kb test index starved whatever came next (a second process got a budget too small for one
+        // chunk of pseudo-alignment anchors).  What a large batch needs beyond the cap comes as overflow slabs, handed back by trim().
+        size_t fr = 0, tot = 0;
+        if (!getenv("LM_SCRATCH_BUDGET_MB") && hipMemGetInfo(&fr, &tot) == hipSuccess)
+            ix->scratch_budget = std::min<int64_t>(ix->scratch_budget, (int64_t)((double)fr * 0.80));
+        want = std::min<int64_t>(ix->scratch_budget / 100 * ix->tune.arena_reserve_pct, (int64_t)8 << 30);
+    }
+    const bool ok = ix->lane_slabs.reserve((size_t)want);
     if (getenv("LM_DEBUG") || getenv("LM_DEBUG_MEM"))
-        fprintf(stderr, "[lm] scratch: %d %% of the budget (%.2f GB) cut into two lane slabs: %s\n", ix->tune.arena_reserve_pct,
-                (double)ix->lane_slabs.bytes() / 1e9, ok ? "yes" : "refused (slabs on demand)");
+        fprintf(stderr, "[lm] scratch: %.2f GB of the %.2f-GB budget cut into two lane slabs: %s\n", (double)ix->lane_slabs.bytes() / 1e9,
+                (double)ix->scratch_budget / 1e9, ok ? "yes" : "refused (slabs on demand)");
 }
 
 namespace lm {

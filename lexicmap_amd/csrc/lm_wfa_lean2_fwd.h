@@ -40,7 +40,7 @@
 #define WR_NULL_OFF (-1073741824) /* = LM_NULL_OFF */
 #endif
 #ifndef L2_SHRINK_MARGIN
-#define L2_SHRINK_MARGIN 12 /* recentre into fewer chunks only when the live rows fit with this many free slots on either side */
+#define L2_SHRINK_MARGIN 8 /* a narrower flavour only when the live rows fit its chunks with this many free slots on either side */
 #endif
 
 struct L2Prob {        // one alignment (wave-uniform)
@@ -429,15 +429,13 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
                 // M[s-4], I[s] or D[s] has one.  (Empty ranges are sentinels +- a few: they lose every minimum / maximum.)
                 const int i_lo = WR_UNIFORM((mlo[4] < ilo[1] ? mlo[4] : ilo[1]) + 1), i_hi = WR_UNIFORM((mhi[4] > ihi[1] ? mhi[4] : ihi[1]) + 1);
                 const int d_lo = WR_UNIFORM((mlo[4] < dlo[1] ? mlo[4] : dlo[1]) - 1), d_hi = WR_UNIFORM((mhi[4] > dhi[1] ? mhi[4] : dhi[1]) - 1);
-                int m_lo = WR_UNIFORM(i_lo < d_lo ? i_lo : d_lo), m_hi = WR_UNIFORM(i_hi > d_hi ? i_hi : d_hi);
-                m_lo = mlo[2] < m_lo ? mlo[2] : m_lo;
-                m_hi = mhi[2] > m_hi ? mhi[2] : m_hi;
                 ilo[0] = i_lo <= i_hi ? i_lo : E_LO;
                 ihi[0] = i_lo <= i_hi ? i_hi : E_HI;
                 dlo[0] = d_lo <= d_hi ? d_lo : E_LO;
                 dhi[0] = d_lo <= d_hi ? d_hi : E_HI;
-                mlo[0] = m_lo; // (= lo, hi of the row: never empty here)
-                mhi[0] = m_hi;
+                // M[s] = the row: min(M[s-4].lo, I[s].lo, D[s].lo) is the `lo` of the top of this step term by term (never empty here)
+                mlo[0] = lo;
+                mhi[0] = hi;
                 lm = 0; // "there is a valid M cell"
             }
             // ---- the new M cells, still in registers: greedy extension, end test, cut-off ----
@@ -504,8 +502,12 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
                     int nlo = kbase + (int)fl, nhi = kbase + lh_; // (top and bottom are inside the chunks of the flavour: both exist)
                     nlo = nlo > mlo[0] ? nlo : mlo[0];
                     nhi = nhi < mhi[0] ? nhi : mhi[0];
-                    if (nlo != mlo[0] || nhi != mhi[0]) {
-                        // I[s] / D[s] are clamped to the reduced M range (empty stays empty: the sentinels survive max / min)
+                    // I[s] / D[s] are clamped to the reduced M range (empty stays empty: the sentinels survive max / min).  INTERIOR:
+                    // their ranges lie inside M's (a cell with a valid I or D source has a valid M), so without a cut the clamps
+                    // change nothing - applied without asking (ten scalar instructions; the test and its branch were eight, the
+                    // clamps fourteen more on most steps of a wavefront in steady state).  EDGE: an M cell may be outside the
+                    // matrix where its I / D cell is inside, so the ranges are only touched by a real cut.
+                    if (!EDGE || nlo != mlo[0] || nhi != mhi[0]) {
                         cut = true;
                         ilo[0] = ilo[0] > nlo ? ilo[0] : nlo;
                         ihi[0] = ihi[0] < nhi ? ihi[0] : nhi;
