@@ -405,10 +405,29 @@ def main():
     gather_kind = "none (1 rank)"
     if world > 1:
         gather_kind = "torch.distributed gather (lexicmap_amd/merge.py)"
-        if args.dist_backend == "nccl" and args.gather == "c":
+        # (gloo = ranks sharing a GPU, which RCCL refuses: the C gather only with a stand-in behind LM_RCCL_LIB - tests/fake_rccl.c)
+        if args.gather == "c" and (args.dist_backend == "nccl" or os.environ.get("LM_RCCL_LIB")):
+            cdev = "cuda" if args.dist_backend == "nccl" else "cpu"
             try:
                 from lexicmap_amd.api import Comm, COMM_ID_BYTES
-                idt = torch.zeros(COMM_ID_BYTES + 1, dtype=torch.uint8, device="cuda")  # [0]: rank 0 has an id to offer
+                # every rank must be able to bind an RCCL before ANY rank enters ncclCommInitRank (a rank that failed there would
+                # leave the others waiting inside it): agree on a "loadable" flag first
+                import ctypes
+                loadable = 0
+                for name in (os.environ.get("LM_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"):
+                    if not name:
+                        continue
+                    try:
+                        ctypes.CDLL(name, mode=ctypes.RTLD_GLOBAL)
+                        loadable = 1
+                        break
+                    except OSError:
+                        pass
+                okl = torch.tensor([loadable], device=cdev)
+                dist.all_reduce(okl, op=dist.ReduceOp.MIN)
+                if int(okl.item()) == 0:
+                    raise RuntimeError("no RCCL library could be loaded on some rank")
+                idt = torch.zeros(COMM_ID_BYTES + 1, dtype=torch.uint8, device=cdev)  # [0]: rank 0 has an id to offer
                 if rank == 0:
                     try:
                         uid = Comm.unique_id()
@@ -419,18 +438,18 @@ def main():
                 idb = bytes(idt.cpu().numpy().tobytes())
                 if idb[0] == 1:
                     comm = Comm(idb[1:], world, rank, local_rank)
-                    gather_kind = "lm_gather_rows (C-ABI, RCCL send/recv to the merging rank)"
+                    gather_kind = "lm_gather_merge_rows (C-ABI: RCCL send/recv into the merging rank, merge on its device)"
                 elif rank != 0:
                     gather_kind += "; rank 0 offered no communicator id"
             except Exception as e:  # noqa: BLE001
                 comm = None
-                gather_kind += "; lm_gather_rows unavailable: %r" % (e,)
-            ok = torch.tensor([1 if comm is not None else 0], device="cuda")
+                gather_kind += "; lm_gather_merge_rows unavailable: %r" % (e,)
+            ok = torch.tensor([1 if comm is not None else 0], device=cdev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # every rank or none
             if int(ok.item()) == 0 and comm is not None:
                 comm.close()
                 comm = None
-                gather_kind = "torch.distributed gather (lexicmap_amd/merge.py); lm_gather_rows unavailable on another rank"
+                gather_kind = "torch.distributed gather (lexicmap_amd/merge.py); the C gather is unavailable on another rank"
 
     comm_box = [comm, gather_kind]  # (step() may give the C gather up at run time)
 
@@ -647,17 +666,17 @@ def main():
                     rows["query"] = rows["query"] + rank * len(queries)  # every rank has its own batch
                 else:
                     rows["query"] = rows["query"] * world + rank  # local -> global query number (round-robin sharding)
+            if comm_box[0] is not None and index_sharded:
+                # the gather and the merge behind the C-ABI in one call (lm_gather_merge_rows).  A failure here is fatal for the
+                # whole job: the ranks cannot agree on another path in the middle of a collective (one that switched alone would
+                # leave the others blocked in their receives)
+                merged = comm_box[0].gather_merge_rows(rows, root=0, index=gi)
+                return (merged if rank == 0 else rows), st
             per_rank = None
             if comm_box[0] is not None:
-                try:
-                    per_rank, _cnt = comm_box[0].gather_rows(rows, root=0)
-                    if per_rank is None:
-                        per_rank = [rows]
-                except RuntimeError as e:  # reported in the line; the torch.distributed gather takes over from here on
-                    log("[rank %d] lm_gather_rows failed (%s): torch.distributed gather from now on" % (rank, e))
-                    comm_box[0] = None
-                    comm_box[1] = "torch.distributed gather (lexicmap_amd/merge.py); lm_gather_rows failed at run time: %s" % (e,)
-                    per_rank = None
+                per_rank, _cnt = comm_box[0].gather_rows(rows, root=0)  # (a failure raises: fatal, see above)
+                if per_rank is None:
+                    per_rank = [rows]
             if per_rank is None:
                 per_rank = merge.all_gather_rows(rows, device="cuda" if args.dist_backend == "nccl" else "cpu", host_on=0)
             # index shards: the library's C merge (lm_merge_sharded: final order per query + global hits) on rank 0
@@ -749,20 +768,45 @@ def main():
             per_rank.append(c)
         t_m = time.time()
         merged = merge.merge_sharded_c(per_rank)
-        merge_s = time.time() - t_m
+        merge_host_s = time.time() - t_m
+        # ... and by what the N-GPU run does (lm_gather_merge_rows): the rows where the receives put them - in device memory, rank
+        # order - merged on the device, downloaded once, names re-attached (lm_merge_sharded_device on a single-rank communicator;
+        # the second call: the first sizes the buffers).  Rows must equal the host merge's.
+        merge_s, merge_kind = merge_host_s, "lm_merge_sharded (host threads)"
+        try:
+            from lexicmap_amd.api import Comm
+            cm = Comm(Comm.unique_id(), 1, 0, local_rank)
+            cat = np.concatenate([c_.view(np.uint8).reshape(-1) for c_ in per_rank]) if len(base) else np.zeros(0, np.uint8)
+            dev = torch.from_numpy(cat).cuda()
+            torch.cuda.synchronize()
+            counts_ = [len(c_) for c_ in per_rank]
+            cm.merge_sharded_device(dev.data_ptr(), counts_, index=gi)
+            t_m = time.time()
+            md = cm.merge_sharded_device(dev.data_ptr(), counts_, index=gi)
+            merge_s = time.time() - t_m
+            strip = lambda a: [a[f].tobytes() for f in merge.ROW_DTYPE.names if f not in merge.PTR_FIELDS]  # noqa: E731
+            if strip(md) != strip(merged):
+                raise SystemExit("bench.py: the device merge and lm_merge_sharded disagree")
+            merge_kind = "lm_merge_sharded_device (device merge + one download + names); rows equal lm_merge_sharded's"
+            del md, dev, cat
+            cm.close()
+        except (RuntimeError, OSError) as e:
+            merge_kind += "; device merge unavailable: %r" % (e,)
         row_bytes = int(base.dtype.itemsize) * len(base)
-        # gather to rank 0 over xGMI: (N-1) shards' rows into one GPU, ~153 GB/s per link (MI355X_MICROARCH.md), + D2H
-        gather_s = (shard_of - 1) * row_bytes / 153e9 + shard_of * row_bytes / 50e9
+        # gather to rank 0 over xGMI: (N-1) shards' rows into one GPU, ~153 GB/s per link (MI355X_MICROARCH.md); the download of
+        # the merged rows is inside the timed device merge
+        gather_s = (shard_of - 1) * row_bytes / 153e9
         step_s0 = dt / args.steps
         fe_ms = sum(v for k, v in stats.items() if k in ("ms_mask", "ms_lookup"))
         shard_model = dict(shards=shard_of, shard_rank=args.shard_rank, shard_step_ms=round(step_s0 * 1e3, 3),
                            replicated_front_end_ms=round(fe_ms, 3),
                            rows_this_shard=int(len(base)), rows_merged=int(len(merged)), row_bytes_per_shard=row_bytes,
-                           merge_ms_host=round(merge_s * 1e3, 3), gather_ms_estimated=round(gather_s * 1e3, 3),
+                           merge_ms=round(merge_s * 1e3, 3), merge_kind=merge_kind, merge_ms_host=round(merge_host_s * 1e3, 3),
+                           gather_ms_estimated=round(gather_s * 1e3, 3),
                            predicted_step_ms=round((step_s0 + merge_s + gather_s) * 1e3, 3),
                            predicted_queries_per_s=round(len(queries) / (step_s0 + merge_s + gather_s), 3),
                            note="one shard measured on one GPU; predicted N-GPU step = this shard's step + gather (estimated "
-                                "from the row bytes) + host-timed lm_merge_sharded over N shards' worth of rows; the efficiency "
+                                "from the row bytes) + the timed merge (merge_kind) over N shards' worth of rows; the efficiency "
                                 "against the 1-GPU line is computed in DESIGN.md section 8, not here")
         del merged, per_rank, base
     rows_total, aligned_total = int(len(rows_np)), int(rows_np["aligned_length"].sum())

@@ -226,6 +226,18 @@ int lm_comm_rank(const lm_comm *comm);
 int lm_comm_size(const lm_comm *comm);
 const char *lm_comm_last_error(const lm_comm *comm); /* comm == NULL: the last failed lm_comm_unique_id / lm_comm_init of this thread */
 lm_status lm_gather_rows(lm_comm *comm, const lm_hsp *rows, size_t n, int root, const lm_hsp **all_rows, size_t *nrows);
+/* lm_gather_rows + lm_merge_sharded in one call, the merge on the DEVICE: the other ranks' rows are received into device memory
+ * in rank order, the root's own are uploaded beside them, the final order (the reference's, as lm_merge_sharded makes it) and the
+ * global `hits` are computed there and downloaded once.  On `root`: *merged = `*total` rows in output order with genome_id /
+ * seq_id re-attached from idx (the root's handle; NULL: left NULL), owned by the communicator and valid until its next call;
+ * elsewhere *merged = NULL and *total = 0.  All ranks must call it, in the same order. */
+lm_status lm_gather_merge_rows(lm_comm *comm, lm_index *idx, const lm_hsp *rows, size_t n, int root, const lm_hsp **merged,
+                               size_t *total);
+/* The merging rank's part of lm_gather_merge_rows by itself: d_rows = the rows of shard 0, 1, ... back to back in DEVICE memory
+ * (nrows[r] each), merged on the device on the communicator's stream (a single-rank communicator will do), downloaded once,
+ * names re-attached.  *merged / *total as above.  (How bench.py times the merge of N shards' rows on one GPU.) */
+lm_status lm_merge_sharded_device(lm_comm *comm, lm_index *idx, const void *d_rows, const size_t *nrows, int nshards,
+                                  const lm_hsp **merged, size_t *total);
 
 /* -n/--top-n-genomes with a sharded index: the cut of lib-index-search.go:1781-1805 is over the genomes of ALL shards.
  *   1. every rank: lm_search_scores -> its candidates, per query at most top_n (query, genome, Chainer score)

@@ -174,6 +174,8 @@ def lib():
     L.lm_comm_last_error.argtypes = [vp]
     L.lm_comm_last_error.restype = C.c_char_p
     L.lm_gather_rows.argtypes = [vp, C.POINTER(Hsp), C.c_size_t, C.c_int, C.POINTER(C.POINTER(Hsp)), C.POINTER(C.c_size_t)]
+    L.lm_gather_merge_rows.argtypes = [vp, vp, C.POINTER(Hsp), C.c_size_t, C.c_int, C.POINTER(C.POINTER(Hsp)), C.POINTER(C.c_size_t)]
+    L.lm_merge_sharded_device.argtypes = [vp, vp, vp, C.POINTER(C.c_size_t), C.c_int, C.POINTER(C.POINTER(Hsp)), C.POINTER(C.c_size_t)]
     _lib = L
     return L
 
@@ -495,6 +497,15 @@ class Index:
                 for i in range(n)]
 
 
+def row_names(rows, i):
+    """(genome_id, seq_id) of row i of a numpy row array (merge.ROW_DTYPE) whose pointer columns are live in THIS process"""
+    out = []
+    for f in ("genome_id", "seq_id"):
+        a = int(rows[f][i])
+        out.append(C.string_at(a).decode() if a else None)
+    return tuple(out)
+
+
 COMM_ID_BYTES = 128
 
 
@@ -549,3 +560,40 @@ class Comm:
             out.append(allr[o:o + n])
             o += n
         return out, counts
+
+    def merge_sharded_device(self, dev_ptr, counts, index=None):
+        """lm_merge_sharded_device: rows of shard 0, 1, ... back to back in device memory at address dev_ptr (counts[r] rows each)
+        -> the merged rows (a view of the communicator's pinned buffer, valid until its next call)"""
+        import numpy as np
+        from .merge import ROW_DTYPE
+        outp = C.POINTER(Hsp)()
+        total = C.c_size_t(0)
+        cnt = (C.c_size_t * len(counts))(*[int(x) for x in counts])
+        st = self.L.lm_merge_sharded_device(self.h, index.h if index is not None else None, C.c_void_p(int(dev_ptr)), cnt, len(counts),
+                                            C.byref(outp), C.byref(total))
+        if st != 0:
+            raise RuntimeError("lm_merge_sharded_device failed (%d): %s" % (st, (self.L.lm_comm_last_error(self.h) or b"").decode()))
+        if total.value == 0:
+            return np.zeros(0, dtype=ROW_DTYPE)
+        buf = (C.c_char * (total.value * C.sizeof(Hsp))).from_address(C.addressof(outp.contents))
+        return np.frombuffer(buf, dtype=ROW_DTYPE)
+
+    def gather_merge_rows(self, arr, root=0, index=None):
+        """lm_gather_merge_rows: the gather and the merge (on the device) in one call.  -> on `root` the merged rows of all ranks
+        in output order (a view of the communicator's pinned buffer, valid until its next call), None elsewhere.  index: the
+        root's Index (names are re-attached from it) or None."""
+        import numpy as np
+        from .merge import ROW_DTYPE
+        arr = np.ascontiguousarray(arr, dtype=ROW_DTYPE)
+        outp = C.POINTER(Hsp)()
+        total = C.c_size_t(0)
+        st = self.L.lm_gather_merge_rows(self.h, index.h if index is not None else None, arr.ctypes.data_as(C.POINTER(Hsp)), len(arr), root,
+                                         C.byref(outp), C.byref(total))
+        if st != 0:
+            raise RuntimeError("lm_gather_merge_rows failed (%d): %s" % (st, (self.L.lm_comm_last_error(self.h) or b"").decode()))
+        if self.rank != root:
+            return None
+        if total.value == 0:
+            return np.zeros(0, dtype=ROW_DTYPE)
+        buf = (C.c_char * (total.value * C.sizeof(Hsp))).from_address(C.addressof(outp.contents))
+        return np.frombuffer(buf, dtype=ROW_DTYPE)

@@ -9,14 +9,25 @@
 // carries its own copy) keeps using that ONE instance, and a single-GPU user of the library needs no RCCL at all.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/lexicmap_hip.h"
+#include "lm_merge.h"
+
+// The few RCCL types and constants this file needs, declared here (values of rccl.h / nccl.h, stable since NCCL 2.0): the
+// library is bound with dlopen, so the single-GPU build must not need the RCCL headers either.  lm_comm_* check ncclGetVersion
+// after binding (point-to-point transfers exist since 2.7).
+typedef struct ncclComm *ncclComm_t;
+typedef struct {
+    char internal[128];
+} ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclUint8 = 1, ncclUint64 = 5 } ncclDataType_t;
 
 extern thread_local std::string g_open_error; // text of the last failure without a handle (lm_last_error(NULL))
 
@@ -32,6 +43,8 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
+    int version = 0;
     std::string err;
     bool ok = false;
 };
@@ -64,7 +77,13 @@ Rccl &rccl() {
         LM_SYM(GroupStart, "ncclGroupStart")
         LM_SYM(GroupEnd, "ncclGroupEnd")
         LM_SYM(GetErrorString, "ncclGetErrorString")
+        LM_SYM(GetVersion, "ncclGetVersion")
 #undef LM_SYM
+        // 2.7.0 is 2700 in the old numbering (major * 1000 + minor * 100 + patch), 2.9+ count major * 10000: both are >= 2700
+        if (r.GetVersion(&r.version) != ncclSuccess || r.version < 2700) {
+            r.err = "the RCCL that was found is older than 2.7 (no ncclSend / ncclRecv): version code " + std::to_string(r.version);
+            return;
+        }
         r.ok = true;
     });
     return r;
@@ -80,6 +99,10 @@ struct lm_comm {
     size_t send_cap = 0, recv_cap = 0, hrecv_cap = 0, hsend_cap = 0;
     unsigned long long *d_counts = nullptr; // [nranks + 1]: the gathered counts, then this rank's own
     std::vector<size_t> counts;
+    // lm_gather_merge_rows: all ranks' rows in rank order, the merged rows, their pinned host mirror, the merge's scratch
+    void *d_all = nullptr, *d_merged = nullptr, *h_merged = nullptr;
+    size_t all_cap = 0, merged_cap = 0, hmerged_cap = 0;
+    lm::MergeScratch ms;
     std::string err;
     std::mutex mu;
 };
@@ -181,6 +204,10 @@ void lm_comm_free(lm_comm *c) {
     if (c->d_counts) (void)hipFree(c->d_counts);
     if (c->h_recv) (void)hipHostFree(c->h_recv);
     if (c->h_send) (void)hipHostFree(c->h_send);
+    if (c->d_all) (void)hipFree(c->d_all);
+    if (c->d_merged) (void)hipFree(c->d_merged);
+    if (c->h_merged) (void)hipHostFree(c->h_merged);
+    c->ms.release();
     if (c->st) (void)hipStreamDestroy(c->st);
     delete c;
 }
@@ -291,6 +318,99 @@ lm_status lm_gather_rows(lm_comm *c, const lm_hsp *rows, size_t n, int root, con
     }
     *all_rows = all;
     return LM_OK;
+}
+
+// rows of all shards in device memory, rank order -> the final order in the communicator's pinned buffer (lm_merge.hip + one
+// download + the names); the caller holds c->mu
+static lm_status merge_on_device(lm_comm *c, lm_index *idx, const lm_hsp *d_rows, const int64_t *off, int N, const lm_hsp **merged, size_t *total_out) {
+    const size_t total = (size_t)off[N], item = sizeof(lm_hsp);
+    lm_status s = grow_dev(c, &c->d_merged, &c->merged_cap, total * item);
+    if (s != LM_OK) return s;
+    s = grow_host(c, &c->h_merged, &c->hmerged_cap, total * item);
+    if (s != LM_OK) return s;
+    CK_HIP(c, lm::merge_rows_device(c->st, d_rows, total, off, N, (lm_hsp *)c->d_merged, c->ms));
+    CK_HIP(c, hipMemcpyAsync(c->h_merged, c->d_merged, total * item, hipMemcpyDeviceToHost, c->st));
+    CK_HIP(c, hipStreamSynchronize(c->st));
+    lm_attach_names(idx, (lm_hsp *)c->h_merged, total);
+    *merged = (const lm_hsp *)c->h_merged;
+    *total_out = total;
+    return LM_OK;
+}
+
+// The gather and the merge in one call: the rows of the other ranks are received into device memory at their place in rank order,
+// this rank's own rows are uploaded beside them, the final order is made on the device (lm_merge.hip) and downloaded ONCE into
+// the communicator's pinned buffer; the names are re-attached by the host threads.  Same rows, same order, same `hits` as
+// lm_gather_rows + lm_merge_sharded.  On `root`: *merged / *total; elsewhere *merged = NULL, *total = 0.  idx (may be NULL:
+// names stay NULL) is the root's index handle.  All ranks call it, in the same order as their other collective calls.
+lm_status lm_gather_merge_rows(lm_comm *c, lm_index *idx, const lm_hsp *rows, size_t n, int root, const lm_hsp **merged, size_t *total_out) {
+    if (!c || !merged || !total_out || (n > 0 && !rows) || root < 0 || root >= c->nranks) return LM_ERR_ARG;
+    *merged = nullptr;
+    *total_out = 0;
+    std::lock_guard<std::mutex> lock(c->mu);
+    Rccl &r = rccl();
+    CK_HIP(c, hipSetDevice(c->device));
+    const int N = c->nranks;
+    unsigned long long mine = (unsigned long long)n;
+    CK_HIP(c, hipMemcpyAsync(c->d_counts + N, &mine, sizeof mine, hipMemcpyHostToDevice, c->st));
+    CK_NCCL(c, r.AllGather(c->d_counts + N, c->d_counts, 1, ncclUint64, c->comm, c->st));
+    std::vector<unsigned long long> cnt((size_t)N);
+    CK_HIP(c, hipMemcpyAsync(cnt.data(), c->d_counts, sizeof(unsigned long long) * (size_t)N, hipMemcpyDeviceToHost, c->st));
+    CK_HIP(c, hipStreamSynchronize(c->st));
+    std::vector<int64_t> off((size_t)N + 1, 0);
+    for (int i = 0; i < N; i++) off[(size_t)i + 1] = off[(size_t)i] + (int64_t)cnt[(size_t)i];
+    const size_t total = (size_t)off[(size_t)N], item = sizeof(lm_hsp);
+    lm_status s = LM_OK;
+    if (n > 0) { // this rank's rows to the device through the pinned mirror (one DMA): the payload of a send, or the root's own block
+        s = grow_host(c, &c->h_send, &c->hsend_cap, n * item);
+        if (s != LM_OK) return s;
+        memcpy(c->h_send, rows, n * item);
+    }
+    if (c->rank != root) {
+        if (n > 0) {
+            s = grow_dev(c, &c->d_send, &c->send_cap, n * item);
+            if (s != LM_OK) return s;
+            CK_HIP(c, hipMemcpyAsync(c->d_send, c->h_send, n * item, hipMemcpyHostToDevice, c->st));
+            CK_NCCL(c, r.Send(c->d_send, n * item, ncclUint8, root, c->comm, c->st));
+        }
+        CK_HIP(c, hipStreamSynchronize(c->st));
+        return LM_OK;
+    }
+    if (total == 0) return LM_OK;
+    s = grow_dev(c, &c->d_all, &c->all_cap, total * item);
+    if (s != LM_OK) return s;
+    if (n > 0) CK_HIP(c, hipMemcpyAsync((char *)c->d_all + (size_t)off[(size_t)root] * item, c->h_send, n * item, hipMemcpyHostToDevice, c->st));
+    if (total > n) {
+        CK_NCCL(c, r.GroupStart());
+        for (int i = 0; i < N; i++) {
+            if (i == root || cnt[(size_t)i] == 0) continue;
+            ncclResult_t e = r.Recv((char *)c->d_all + (size_t)off[(size_t)i] * item, (size_t)cnt[(size_t)i] * item, ncclUint8, i, c->comm, c->st);
+            if (e != ncclSuccess) {
+                (void)r.GroupEnd();
+                c->err = std::string("ncclRecv: ") + r.GetErrorString(e);
+                return LM_ERR_HIP;
+            }
+        }
+        CK_NCCL(c, r.GroupEnd());
+    }
+    return merge_on_device(c, idx, (const lm_hsp *)c->d_all, off.data(), N, merged, total_out);
+}
+
+// What the merging rank does once the rows have arrived, by itself: `d_rows` = the rows of shard 0, 1, ... back to back IN DEVICE
+// MEMORY (nrows[r] of each; each block grouped by query ascending, a genome's rows together), merged on the device on the
+// communicator's stream (a single-rank communicator will do), downloaded once, names re-attached from idx.  *merged as in
+// lm_gather_merge_rows.  (bench.py times the merge of N shards' worth of rows on one GPU with it.)
+lm_status lm_merge_sharded_device(lm_comm *c, lm_index *idx, const void *d_rows, const size_t *nrows, int nshards, const lm_hsp **merged,
+                                  size_t *total_out) {
+    if (!c || !merged || !total_out || !nrows || nshards < 1) return LM_ERR_ARG;
+    *merged = nullptr;
+    *total_out = 0;
+    std::lock_guard<std::mutex> lock(c->mu);
+    CK_HIP(c, hipSetDevice(c->device));
+    std::vector<int64_t> off((size_t)nshards + 1, 0);
+    for (int i = 0; i < nshards; i++) off[(size_t)i + 1] = off[(size_t)i] + (int64_t)nrows[i];
+    if (off[(size_t)nshards] == 0) return LM_OK;
+    if (!d_rows) return LM_ERR_ARG;
+    return merge_on_device(c, idx, (const lm_hsp *)d_rows, off.data(), nshards, merged, total_out);
 }
 
 } // extern "C"

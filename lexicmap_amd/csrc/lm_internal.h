@@ -8,7 +8,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <deque>
 #include <mutex>
+#include <shared_mutex>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -480,5 +482,10 @@ struct lm_index {
     std::vector<Pending> pending;
     // genome lookup
     std::unordered_map<uint64_t, int> bg2local;
+    // names of a synthetic set (a function of the genome number), made on first use and kept with the handle: ONE copy per genome
+    // (lm_merge_sharded made two strings per ROW: ten million allocations per C3 step on the merging rank)
+    std::shared_mutex syn_mu;
+    std::unordered_map<uint64_t, std::pair<const char *, const char *>> syn_names;
+    std::deque<std::string> syn_store;
 };
 

@@ -4020,6 +4020,63 @@ lm_status lm_wfa_batch(lm_index *ix, const lm_query *q, const lm_query *t, size_
 }
 
 
+// genome_id / seq_id of a row that came from another process: every shard holds the names of all genomes (this shard's in
+// host.genomes, the others' in host.others); the names of a synthetic set are a function of the genome number, made once per
+// genome and kept with the handle
+static void attach_name(lm_index *ix, lm_hsp &h) {
+    const HostIndex &H = ix->host;
+    auto it = ix->bg2local.find(h.batch_genome);
+    const HostGenome *G = nullptr;
+    if (it != ix->bg2local.end()) {
+        G = &H.genomes[it->second];
+    } else {
+        auto io = H.other_of.find(h.batch_genome);
+        if (io != H.other_of.end()) G = &H.others[io->second];
+    }
+    if (G) {
+        h.genome_id = G->id.c_str();
+        if (h.seq_idx >= 0 && h.seq_idx < (int)G->seq_ids.size()) h.seq_id = G->seq_ids[h.seq_idx].c_str();
+        return;
+    }
+    if (!H.synthetic) return;
+    {
+        std::shared_lock<std::shared_mutex> rl(ix->syn_mu);
+        auto is = ix->syn_names.find(h.batch_genome);
+        if (is != ix->syn_names.end()) {
+            h.genome_id = is->second.first;
+            h.seq_id = is->second.second;
+            return;
+        }
+    }
+    std::unique_lock<std::shared_mutex> wl(ix->syn_mu);
+    auto is = ix->syn_names.find(h.batch_genome);
+    if (is == ix->syn_names.end()) {
+        const long long g = (long long)((h.batch_genome >> 17) * 5000 + (h.batch_genome & 0x1ffff));
+        char nm[64];
+        snprintf(nm, sizeof nm, "SYN_%09lld.1", g);
+        ix->syn_store.emplace_back(nm);
+        const char *a = ix->syn_store.back().c_str();
+        snprintf(nm, sizeof nm, "syn%09lld_c1", g);
+        ix->syn_store.emplace_back(nm);
+        is = ix->syn_names.emplace(h.batch_genome, std::make_pair(a, ix->syn_store.back().c_str())).first;
+    }
+    h.genome_id = is->second.first;
+    h.seq_id = is->second.second;
+}
+void lm_attach_names(lm_index *ix, lm_hsp *rows, size_t n) {
+    if (!ix || n == 0) return;
+    parallel_for((int64_t)n, 4096, [&](int64_t a, int64_t b) {
+        for (int64_t i = a; i < b; i++) {
+            if (i > a && rows[i].batch_genome == rows[i - 1].batch_genome && rows[i].seq_idx == rows[i - 1].seq_idx) { // a genome's rows are together
+                rows[i].genome_id = rows[i - 1].genome_id;
+                rows[i].seq_id = rows[i - 1].seq_id;
+                continue;
+            }
+            attach_name(ix, rows[i]);
+        }
+    });
+}
+
 // ---- merging the rows of genome shards ------------------------------------------------------------
 // Host-only: no device work, callable without a GPU (idx may be NULL: names are then left NULL).
 lm_status lm_merge_sharded(lm_index *ix, const lm_hsp *const *rows, const size_t *nrows, int nshards, lm_result **out) {
@@ -4077,7 +4134,6 @@ lm_status lm_merge_sharded(lm_index *ix, const lm_hsp *const *rows, const size_t
             }
         }
         res->rows.resize(total);
-        std::mutex smu;
         parallel_for((int64_t)jobs.size(), 16, [&](int64_t j0, int64_t j1) {
             struct Grp {
                 int rank;
@@ -4086,7 +4142,6 @@ lm_status lm_merge_sharded(lm_index *ix, const lm_hsp *const *rows, const size_t
                 double best;
             };
             std::vector<Grp> grps;
-            std::vector<std::string *> mine;
             for (int64_t ji = j0; ji < j1; ji++) {
                 const QJob &job = jobs[(size_t)ji];
                 grps.clear();
@@ -4116,36 +4171,9 @@ lm_status lm_merge_sharded(lm_index *ix, const lm_hsp *const *rows, const size_t
                         h.hits = (uint32_t)grps.size(); // search.go:463,494: subject genomes of the query, over all shards
                         h.genome_id = h.seq_id = nullptr;
                         h.cigar = h.qseq = h.sseq = h.align = nullptr; // process-local addresses of another rank
-                        if (ix) {
-                            const HostIndex &H = ix->host;
-                            auto it = ix->bg2local.find(h.batch_genome);
-                            const HostGenome *G = nullptr;
-                            if (it != ix->bg2local.end()) {
-                                G = &H.genomes[it->second];
-                            } else {
-                                auto io = H.other_of.find(h.batch_genome);
-                                if (io != H.other_of.end()) G = &H.others[io->second];
-                            }
-                            if (G) {
-                                h.genome_id = G->id.c_str();
-                                if (h.seq_idx >= 0 && h.seq_idx < (int)G->seq_ids.size()) h.seq_id = G->seq_ids[h.seq_idx].c_str();
-                            } else if (H.synthetic) { // names of the synthetic set are a function of the genome number
-                                const long long g = (long long)((h.batch_genome >> 17) * 5000 + (h.batch_genome & 0x1ffff));
-                                char nm[64];
-                                snprintf(nm, sizeof nm, "SYN_%09lld.1", g);
-                                mine.push_back(new std::string(nm));
-                                h.genome_id = mine.back()->c_str();
-                                snprintf(nm, sizeof nm, "syn%09lld_c1", g);
-                                mine.push_back(new std::string(nm));
-                                h.seq_id = mine.back()->c_str();
-                            }
-                        }
+                        if (ix) attach_name(ix, h);
                         res->rows[w++] = h;
                     }
-            }
-            if (!mine.empty()) {
-                std::lock_guard<std::mutex> l(smu);
-                res->strings.insert(res->strings.end(), mine.begin(), mine.end());
             }
         });
         res->stats.rows = (int64_t)res->rows.size();

@@ -42,3 +42,40 @@ def test_single_rank_communicator_gathers_counts_and_rows_and_feeds_the_c_merge(
             comm.gather_rows(rows, root=3)   # no such rank: LM_ERR_ARG, nothing hangs
     finally:
         comm.close()
+
+
+def test_device_merge_of_four_shards_equals_the_host_merge():
+    """lm_merge_sharded_device (lm_merge.hip: heads, scan, group keys, rocPRIM merge sort, emit) against lm_merge_sharded on the
+    same rows: four shards, 200 queries, genomes with several rows, equal similarities (ties go by genome key), a shard without
+    rows, queries that only some shards hit"""
+    import torch
+    from lexicmap_amd import merge
+    from lexicmap_amd.api import Comm
+    rng = np.random.default_rng(11)
+    shards = []
+    for r in range(4):
+        n = 0 if r == 2 else 20000
+        qs = rng.integers(0, 200, n) * (1 if r != 3 else 2)         # shard 3 only hits even queries
+        gs = rng.integers(0, 3000, n) * 4 + r                         # a genome lives in ONE shard
+        o = np.lexsort((gs, qs))
+        a = np.zeros(n, dtype=merge.ROW_DTYPE)
+        a["query"], a["batch_genome"] = qs[o], gs[o]
+        a["bitscore"] = rng.integers(1, 40, n) * 50                   # few distinct values: many equal similarities
+        a["pident"] = rng.integers(8, 11, n).astype(np.float64) * 10.0
+        a["hsp"] = np.arange(n)                                       # tells the rows of a genome apart: their order must be kept
+        a["genome_id"] = 777
+        shards.append(a)
+    want = merge.merge_sharded_c(shards)
+    comm = Comm(Comm.unique_id(), 1, 0, device=0)
+    try:
+        cat = np.concatenate([s.view(np.uint8).reshape(-1) for s in shards])
+        dev = torch.from_numpy(cat).cuda()
+        torch.cuda.synchronize()
+        for _ in range(2):   # the second call reuses every buffer
+            got = comm.merge_sharded_device(dev.data_ptr(), [len(s) for s in shards])
+            assert len(got) == len(want) == 60000
+            for f in merge.ROW_DTYPE.names:
+                assert got[f].tobytes() == want[f].tobytes(), f
+        assert len(comm.merge_sharded_device(0, [0, 0])) == 0
+    finally:
+        comm.close()
