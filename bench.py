@@ -89,6 +89,10 @@ def parse():
     p.add_argument("--cpu-sample-genomes", type=int, default=0,
                    help="genomes of the CPU-baseline sample index (default: one whole family + 16 genomes of other families)")
     p.add_argument("--cpu-sample-queries", type=int, default=0)
+    p.add_argument("--cpu-subsets", default="auto",
+                   help="CPU baseline on comparable work: genome counts of the subset indexes (GPU-built with the workload's own "
+                        "generator, written by lm_index_save, opened by the oracle RAM-resident), e.g. 1250,5000; auto: two sizes "
+                        "whose RAM-resident seeds fit the host; 0: skip")
     p.add_argument("--ab", default="", help="development: after the timed steps, time the same resident batch under other "
                    "experiment switches, e.g. 'LM_WFA_R16=0|LM_WFA_MW=0 LM_WFA_R16=0' (variants separated by |, one warm-up + "
                    "--ab-steps steps each; reported under 'ab', not part of the metric)")
@@ -713,6 +717,29 @@ def main():
         dt = float(tt.item())
     gi.profile_mark(2)
     prof = gi.profile_get()
+    # the printer (search.go:437-533: one writer goroutine) on the rows of the last timed step: lm_format_rows (host threads, one
+    # buffer) + one write to /dev/null - what the reference's queries/s includes and the timed region above does not
+    host_e2e = None
+    if rank == 0 and world == 1 and rows_np is not None and len(rows_np):
+        try:
+            ids_ = [q[0] for q in my]
+            lens_ = [len(q[1]) for q in my]
+            text_, fmt_s = la.api.format_rows(rows_np, ids_, lens_)
+            t_w = time.time()
+            with open(os.devnull, "wb") as fh:
+                fh.write(text_)
+            wr_s = time.time() - t_w
+            st_s = dt / args.steps
+            host_e2e = dict(format_rows_s=round(fmt_s, 4), write_devnull_s=round(wr_s, 4), tsv_bytes=len(text_),
+                            rows_per_s_formatted=round(len(rows_np) / max(fmt_s, 1e-9)),
+                            share_of_step=round((fmt_s + wr_s) / st_s, 4),
+                            queries_per_s_with_printer=round(len(my) / (st_s + fmt_s + wr_s), 3),
+                            note="lm_format_rows + one write after the step (serial: the reference prints beside its searches); "
+                                 "the host PROGRAM (tests/cabi_shim.c as its own process) is timed on a subset index: "
+                                 "cpu_baseline.subsets[].host_program")
+            del text_
+        except Exception as e:  # noqa: BLE001
+            host_e2e = dict(failed=repr(e))
     gi.profile(False)
     # One more step OUTSIDE the timed region with the kernels serialised (no overlapped streams): in the timed steps the WFA
     # length classes, the anchor kernels of the next chunk and the fallback share the chip, so a kernel's HIP-event time there
@@ -958,6 +985,7 @@ def main():
                                        ("q-shard x%d (index replicated), %d queries per GPU" % (world, len(my)))),
                        "pcie_upload_s": round(upload_s, 4), "tag": args.tag, "gather": comm_box[1],
                        "go_toolchain": go or "absent (reference Go binary cannot be built; CPU baseline is the C port)"},
+            "host_end_to_end": host_e2e,
             "stage_ms": {k: round(v, 3) for k, v in stats.items() if k.startswith("ms_")},
             "work": {k: v for k, v in stats.items() if not k.startswith("ms_")},
             "rows": rows_total,
@@ -1003,6 +1031,117 @@ def main():
     gi.close()
     gi = None
     sample_mismatch = None
+
+    def shim_leg(sdir, S):
+        """the whole host program as its own process (tests/cabi_shim.c = the Go host's call sequence in C99): opens the subset
+        index from disk, reads >= 1000 reads from a FASTA file, searches in batches, formats with lm_format_rows, writes /dev/null"""
+        import re
+        import subprocess
+        try:
+            d0 = tempfile.mkdtemp(prefix="lm_shim_")
+            exe = os.path.join(d0, "cabi_shim")
+            subprocess.check_call(["gcc", "-std=c99", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cabi_shim.c"),
+                                   "-L", os.path.dirname(la.LIB_PATH), "-llexicmap_hip", "-Wl,-rpath," + os.path.dirname(la.LIB_PATH), "-o", exe])
+            sub2 = la.Index(sdir, device=local_rank)
+            nrd = 1000 if wl["kind"] == "reads" else 4000
+            fa = os.path.join(d0, "reads.fa")
+            with open(fa, "wb") as fh:
+                for i in range(nrd):
+                    rng = np.random.default_rng([2003, S, i])
+                    g = int(rng.integers(0, S))
+                    L = min(qlen_of(rng), wl["genome_len"])
+                    st = int(rng.integers(0, wl["genome_len"] - L + 1))
+                    src = np.frombuffer(sub2.fetch(g, st, L), dtype=np.uint8)
+                    fh.write(b">r%05d\n" % i + draw_query(np, synth, rng, src, wl) + b"\n")
+            sub2.close()
+            r = subprocess.run([exe, "-d", sdir, "-o", os.devnull, fa],  # (one batch: up to 4096 records / 64 Mb by default)
+                               capture_output=True, text=True, timeout=900)
+            shutil.rmtree(d0, ignore_errors=True)
+            if r.returncode != 0:
+                return dict(failed=r.stderr[-500:])
+            m = re.search(r"timing: (.*)", r.stderr)
+            t = {k: float(v) for k, v in (x.split("=") for x in m.group(1).split())}
+            return dict(program="tests/cabi_shim.c (C99 restatement of the Go host: reader loop, lm_search_batch, lm_format_rows, one writer)",
+                        reads=int(t["queries"]), index_genomes=S, open_s=t["open_s"], search_s=t["search_s"], format_s=t["format_s"],
+                        write_s=t["write_s"], rows=int(t["rows"]), tsv_bytes=int(t["tsv_bytes"]),
+                        queries_per_s_search_only=round(t["queries"] / max(t["search_s"], 1e-9), 2),
+                        queries_per_s_search_format_write=round(t["queries"] / max(t["search_s"] + t["format_s"] + t["write_s"], 1e-9), 2),
+                        printer_share=round((t["format_s"] + t["write_s"]) / max(t["search_s"] + t["format_s"] + t["write_s"], 1e-9), 4))
+        except Exception as e:  # noqa: BLE001
+            return dict(failed=repr(e))
+
+    def cpu_subset_legs():
+        """a CPU number beside the GPU number ON THE SAME WORK.  A subset index of S genomes is built on the GPU
+        with the workload's generator (same genome length, same ~members per family, same masks parameters), written in the
+        reference's on-disk format by lm_index_save and opened RAM-resident by the oracle (= the reference's -w regime,
+        kv/kv-searcher2.go:52-88); the same sample reads are searched by both, rows compared, at two sizes."""
+        import psutil
+        out = []
+        per_genome_seeds = 2.0 * (20000 + wl["genome_len"] / 77.0)   # captures + desert seeds, reversed twins
+        if args.cpu_subsets == "auto":
+            smax = int(8e9 / 16 / per_genome_seeds)                   # <= 8 GB of RAM-resident seeds per oracle process
+            sizes = [max(200, smax // 4 // 50 * 50), max(400, smax // 50 * 50)]
+            if args.workload == "c3mini":
+                sizes = [400, 1600]
+        else:
+            sizes = [int(x) for x in args.cpu_subsets.split(",") if int(x) > 0]
+        members = max(1, wl["genomes"] // wl["families"])
+        for S in sizes:
+            rec = dict(genomes=S, genome_len=wl["genome_len"])
+            sdir = None
+            try:
+                t_b = time.time()
+                sub = la.Index.synthetic(S, wl["genome_len"], max(1, S // members), seed=1000, max_div=0.10, device=local_rank)
+                nsq = args.cpu_sample_queries or (64 if wl["kind"] == "reads" else 512)
+                qs = []
+                for i in range(nsq):
+                    rng = np.random.default_rng([2002, S, i])
+                    g = int(rng.integers(0, S))
+                    L = min(qlen_of(rng), wl["genome_len"])
+                    st = int(rng.integers(0, wl["genome_len"] - L + 1))
+                    src = np.frombuffer(sub.fetch(g, st, L), dtype=np.uint8)
+                    qs.append(("u%05d" % i, draw_query(np, synth, rng, src, wl)))
+                sdir = os.path.join(tempfile.mkdtemp(prefix="lm_cpu_subset_"), "subset.lmi")
+                sub.save(sdir, chunks=8)
+                inf = sub.info()
+                rec.update(seeds=int(inf["seeds"]), index_files_GB=round(sum(os.path.getsize(os.path.join(r_, f_)) for r_, _d, fs in os.walk(sdir) for f_ in fs) / 1e9, 2),
+                           build_and_save_s=round(time.time() - t_b, 1))
+                # the HIP path on the subset (its own handle: the index it built)
+                qb3 = sub.upload([q[1] for q in qs])
+                sub.search_resident_np(qb3)
+                torch.cuda.synchronize()
+                t1 = time.time()
+                reps = 3
+                for _ in range(reps):
+                    r3, st3 = sub.search_resident_np(qb3)
+                torch.cuda.synchronize()
+                rec["gpu_queries_per_s"] = round(nsq * reps / (time.time() - t1), 2)
+                rec["gpu_chains_per_query"] = round(st3.get("chains", 0) / nsq, 1)
+                r3 = r3.copy()
+                sub.free_batch(qb3)
+                sub.close()
+                if S == max(sizes):
+                    rec["host_program"] = shim_leg(sdir, S)
+                # the oracle on the host cores, as many processes as the host's free memory holds copies of the RAM-resident index
+                rss = inf["seeds"] * 16 + S * wl["genome_len"] * 1.3
+                nproc = int(max(1, min(usable_cores(), psutil.virtual_memory().available * 0.6 / rss)))
+                c3_ = cpu_baseline(sdir, qs, max(5.0, args.cpu_seconds / 2), nproc)
+                orows = c3_.pop("_oracle_rows")
+                eq, ncmp, diff = rows_equal_oracle(r3, orows)
+                rec.update(cpu_queries_per_s=float(round(c3_["value"], 3)), cores=nproc, cpu_chains_per_query=c3_["chains_per_query"],
+                           rows_per_query=round(c3_["rows_per_query"], 1), gpu_over_cpu=round(rec["gpu_queries_per_s"] / max(c3_["value"], 1e-9), 1),
+                           rows_equal=bool(eq), rows_compared=int(ncmp), sample=c3_["sample"])
+                if not eq:
+                    rec["first_difference"] = diff
+            except Exception as e:  # noqa: BLE001 (reported in the line)
+                rec["failed"] = repr(e)
+            finally:
+                if sdir:
+                    shutil.rmtree(os.path.dirname(sdir), ignore_errors=True)
+            log("[rank 0] CPU / GPU on a subset index: %s" % {k: v for k, v in rec.items() if k != "sample"})
+            out.append(rec)
+        return out
+
     # CPU baseline on rank 0, N=1 only
     if rank == 0 and world == 1 and not args.no_cpu_baseline and index_dir:
         try:
@@ -1062,6 +1201,16 @@ def main():
                 except Exception as e:
                     cb["gpu_on_same_sample"] = "failed: %r" % (e,)
                     cb["sample_rows_equal"] = None
+            if gpu_built and args.cpu_subsets != "0" and args.workload in ("c2", "c3", "c3mini"):
+                cb["subsets"] = cpu_subset_legs()
+                ok_pairs = [x for x in cb["subsets"] if isinstance(x.get("cpu_queries_per_s"), float)]
+                if ok_pairs:
+                    cb["note_subsets"] = ("LIKE-FOR-LIKE pairs: the same reads on the same index (a subset of the workload's genome set: "
+                                          "same generator, same family size) by the oracle on the host cores and by the HIP path, at two "
+                                          "index sizes - chains per query are equal on both sides by construction; rows compared")
+                    for x in ok_pairs:
+                        if x.get("rows_equal") is False:
+                            sample_mismatch = sample_mismatch or ("subset of %d genomes: %s" % (x["genomes"], x.get("first_difference")))
             result["cpu_baseline"] = cb
         except Exception as e:  # the baseline must not kill the bench line
             result["cpu_baseline"] = dict(value=None, unit="queries/s", cores=0, kind="port", sample="failed: %r" % (e,))

@@ -188,6 +188,11 @@ int lm_format_row(const lm_hsp *row, const char *query_id, uint32_t qlen, int mo
 #define LM_ROW_ALL 1
 #define LM_ROW_SSEQ_IDX 2
 int lm_format_row_ex(const lm_hsp *row, const char *query_id, uint32_t qlen, int flags, char *buf, size_t buflen);
+/* The printer's loop over a batch (search.go:468-523; one writer goroutine in the reference): every row as lm_format_row_ex
+ * writes it, a newline after each, in row order, formatted by the host threads into ONE buffer (*text, *len bytes, released
+ * with lm_free).  query_ids / query_lens: the id and length of batch query i at [i], nq of them (rows[].query indexes them). */
+lm_status lm_format_rows(const lm_hsp *rows, size_t n, const char *const *query_ids, const uint32_t *query_lens, size_t nq,
+                         int flags, char **text, size_t *len);
 /* the header line of the TSV (search.go:426-430), no newline; more_columns as in lm_format_row */
 const char *lm_tsv_header(int more_columns);
 

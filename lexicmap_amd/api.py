@@ -159,6 +159,10 @@ def lib():
     L.lm_profile_enable.argtypes = [vp, C.c_int]
     L.lm_profile_reset.argtypes = [vp]
     L.lm_profile_exclusive.argtypes = [vp, C.c_int]
+    L.lm_format_rows.argtypes = [C.POINTER(Hsp), C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.c_size_t, C.c_int,
+                                 C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.lm_free.argtypes = [vp]
+    L.lm_free.restype = None
     L.lm_profile_mark.argtypes = [vp, C.c_int]
     L.lm_profile_mark.restype = None
     L.lm_tuning_reload.argtypes = [vp]
@@ -495,6 +499,27 @@ class Index:
         n = lib().lm_profile_get(self.h, C.byref(p))
         return [dict(name=p[i].name.decode(), launches=p[i].launches, total_ms=p[i].total_ms, bytes=p[i].bytes)
                 for i in range(n)]
+
+
+def format_rows(rows, ids, lens, flags=0, want_text=True):
+    """lm_format_rows: the TSV text (bytes) of a numpy row array (merge.ROW_DTYPE, pointer columns live in this process); ids /
+    lens: id and length of every batch query.  want_text=False: only (bytes, seconds) - the text is released unseen."""
+    import time
+    import numpy as np
+    from .merge import ROW_DTYPE
+    L = lib()
+    arr = np.ascontiguousarray(rows, dtype=ROW_DTYPE)
+    idarr = (C.c_char_p * len(ids))(*[i if isinstance(i, bytes) else str(i).encode() for i in ids])
+    lnarr = (C.c_uint32 * len(lens))(*[int(x) for x in lens])
+    text, n = C.c_void_p(), C.c_size_t(0)
+    t0 = time.time()
+    st = L.lm_format_rows(arr.ctypes.data_as(C.POINTER(Hsp)), len(arr), idarr, lnarr, len(ids), flags, C.byref(text), C.byref(n))
+    dt = time.time() - t0
+    if st != 0:
+        raise RuntimeError("lm_format_rows failed (%d)" % st)
+    out = C.string_at(text, n.value) if want_text else None
+    L.lm_free(text)
+    return (out if want_text else n.value), dt
 
 
 def row_names(rows, i):

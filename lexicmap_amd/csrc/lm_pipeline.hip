@@ -3775,6 +3775,53 @@ int lm_format_row_ex(const lm_hsp *h, const char *query_id, uint32_t qlen, int f
 int lm_format_row(const lm_hsp *h, const char *query_id, uint32_t qlen, int more_columns, char *buf, size_t buflen) {
     return lm_format_row_ex(h, query_id, qlen, more_columns ? LM_ROW_ALL : 0, buf, buflen);
 }
+// The printer's loop over a whole batch (search.go:468-523 is one writer goroutine; a C3 step emits 5 M rows = 0.7 GB of text):
+// every row formatted as by lm_format_row_ex + a newline, by the host threads into ONE buffer, in row order.
+lm_status lm_format_rows(const lm_hsp *rows, size_t n, const char *const *query_ids, const uint32_t *query_lens, size_t nq, int flags, char **text,
+                         size_t *len) {
+    if (!text || !len || (n > 0 && (!rows || !query_ids || !query_lens))) return LM_ERR_ARG;
+    *text = nullptr;
+    *len = 0;
+    for (size_t i = 0; i < n; i++)
+        if (rows[i].query >= nq) return LM_ERR_ARG;
+    const int64_t grain = 8192;
+    const int64_t nparts = ((int64_t)n + grain - 1) / grain;
+    std::vector<std::string> parts((size_t)nparts);
+    try {
+        parallel_for(nparts, 1, [&](int64_t p0, int64_t p1) {
+            std::vector<char> line((size_t)1 << 16);
+            for (int64_t p = p0; p < p1; p++) {
+                std::string &out = parts[(size_t)p];
+                const size_t b = (size_t)(p * grain), e = std::min(n, (size_t)((p + 1) * grain));
+                out.reserve((e - b) * 192);
+                for (size_t i = b; i < e; i++) {
+                    const uint32_t q = rows[i].query;
+                    int need = lm_format_row_ex(&rows[i], query_ids[q] ? query_ids[q] : "", query_lens[q], flags, line.data(), line.size());
+                    if (need < 0) need = 0;
+                    if ((size_t)need >= line.size()) { // (-a rows carry the aligned sequences: as long as the HSP)
+                        line.resize((size_t)need + 1);
+                        need = lm_format_row_ex(&rows[i], query_ids[q] ? query_ids[q] : "", query_lens[q], flags, line.data(), line.size());
+                    }
+                    out.append(line.data(), (size_t)need);
+                    out.push_back('\n');
+                }
+            }
+        });
+        std::vector<size_t> off((size_t)nparts + 1, 0);
+        for (int64_t p = 0; p < nparts; p++) off[(size_t)p + 1] = off[(size_t)p] + parts[(size_t)p].size();
+        char *buf = (char *)malloc(off[(size_t)nparts] + 1);
+        if (!buf) return LM_ERR_NOMEM;
+        parallel_for(nparts, 1, [&](int64_t p0, int64_t p1) {
+            for (int64_t p = p0; p < p1; p++) memcpy(buf + off[(size_t)p], parts[(size_t)p].data(), parts[(size_t)p].size());
+        });
+        buf[off[(size_t)nparts]] = 0;
+        *text = buf;
+        *len = off[(size_t)nparts];
+    } catch (const std::exception &) {
+        return LM_ERR_NOMEM;
+    }
+    return LM_OK;
+}
 const char *lm_tsv_header(int more_columns) {
     return more_columns ? "query\tqlen\thits\tsgenome\tsseqid\tqcovGnm\tcls\thsp\tqcovHSP\talenHSP\tpident\tgaps\tqstart\tqend\tsstart\tsend\tsstr\tslen\tevalue\tbitscore\tcigar\tqseq\tsseq\talign"
                         : "query\tqlen\thits\tsgenome\tsseqid\tqcovGnm\tcls\thsp\tqcovHSP\talenHSP\tpident\tgaps\tqstart\tqend\tsstart\tsend\tsstr\tslen\tevalue\tbitscore";

@@ -17,6 +17,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "lexicmap_hip.h"
 
@@ -60,44 +61,68 @@ typedef struct {
     lm_index *h;
     FILE *out;
     int row_flags;
-    unsigned long long total, matched, rows;
+    unsigned long long total, matched, rows, bases, text_bytes;
     int flushes;
+    double t_search, t_format, t_write;
 } ctx;
 
-/* SearchBatch + printResult for every record of the batch, in input order (search.go:437-533) */
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* SearchBatch + printResult for every record of the batch, in input order (search.go:437-533): the rows of the batch are
+ * formatted by ONE call (lm_format_rows: the host threads, one buffer) and written with one fwrite */
 static void flush(ctx *c, batch *b) {
-    static char buf[1 << 20];
     if (b->n == 0) return;
     lm_query *qs = (lm_query *)malloc(b->n * sizeof *qs);
-    if (!qs) die("out of memory");
+    const char **ids = (const char **)malloc(b->n * sizeof *ids);
+    uint32_t *lens = (uint32_t *)malloc(b->n * sizeof *lens);
+    if (!qs || !ids || !lens) die("out of memory");
     for (size_t i = 0; i < b->n; i++) {
         qs[i].seq = (const uint8_t *)b->r[i].seq;
         qs[i].len = (uint32_t)b->r[i].len;
+        ids[i] = b->r[i].id;
+        lens[i] = (uint32_t)b->r[i].len;
     }
     lm_result *res = NULL;
+    double t0 = now_s();
     if (lm_search_batch(c->h, qs, b->n, &res) != LM_OK) die(lm_last_error(c->h));
+    double t1 = now_s();
     const lm_hsp *rows = NULL;
     const size_t m = lm_result_rows(res, &rows); /* grouped by query in batch order; within a query in final order */
     size_t j = 0;
-    for (size_t i = 0; i < b->n; i++) {
+    for (size_t i = 0; i < b->n; i++) { /* search.go:439-446: a query without rows is counted and prints nothing */
         c->total++;
         size_t k = j;
         while (k < m && rows[k].query == (uint32_t)i) k++;
-        if (k > j) c->matched++; /* search.go:439-446: a query without rows is counted and prints nothing */
-        for (; j < k; j++) {
-            int need = lm_format_row_ex(&rows[j], b->r[i].id, (uint32_t)b->r[i].len, c->row_flags, buf, sizeof buf);
-            if (need < 0 || (size_t)need >= sizeof buf) die("row longer than the line buffer");
-            fputs(buf, c->out);
-            fputc('\n', c->out);
-            c->rows++;
-        }
-        fflush(c->out); /* outfh.Flush() per query (search.go:527) */
+        if (k > j) c->matched++;
+        j = k;
+    }
+    if (j != m) die("rows of a query number outside the batch");
+    char *text = NULL;
+    size_t len = 0;
+    if (lm_format_rows(rows, m, ids, lens, b->n, c->row_flags, &text, &len) != LM_OK) die("lm_format_rows failed");
+    double t2 = now_s();
+    if (len && fwrite(text, 1, len, c->out) != len) die("write failed");
+    fflush(c->out); /* outfh.Flush() (search.go:527) */
+    double t3 = now_s();
+    c->rows += m;
+    c->bases += b->bases;
+    c->text_bytes += len;
+    c->t_search += t1 - t0;
+    c->t_format += t2 - t1;
+    c->t_write += t3 - t2;
+    lm_free(text);
+    for (size_t i = 0; i < b->n; i++) {
         free(b->r[i].id);
         free(b->r[i].seq);
     }
-    if (j != m) die("rows of a query number outside the batch");
     lm_result_free(res); /* RecycleSearchResults */
     free(qs);
+    free(ids);
+    free(lens);
     b->n = 0;
     b->bases = 0;
     c->flushes++;
@@ -247,7 +272,9 @@ int main(int argc, char **argv) {
 
     ctx c;
     memset(&c, 0, sizeof c);
+    const double t_open0 = now_s();
     if (lm_index_open(dir, &o, 0, &c.h) != LM_OK) die(lm_last_error(NULL)); /* NewIndexSearcher */
+    const double t_open = now_s() - t_open0, t_run0 = now_s();
     lm_index_info info;
     lm_index_get_info(c.h, &info);
     c.out = strcmp(out_path, "-") == 0 ? stdout : fopen(out_path, "w");
@@ -265,6 +292,9 @@ int main(int argc, char **argv) {
     fprintf(stderr, "processed queries: %llu\n", c.total);
     fprintf(stderr, "%.4f%% (%llu/%llu) queries matched\n", c.total ? (double)c.matched / (double)c.total * 100 : 0.0, c.matched, c.total);
     fprintf(stderr, "k=%d masks=%d rows=%llu batches=%d\n", info.k, info.masks, c.rows, c.flushes);
+    /* where the host program's time went (bench.py reads this line: host_end_to_end) */
+    fprintf(stderr, "timing: open_s=%.3f run_s=%.3f search_s=%.3f format_s=%.3f write_s=%.3f queries=%llu query_bases=%llu rows=%llu tsv_bytes=%llu\n", t_open,
+            now_s() - t_run0, c.t_search, c.t_format, c.t_write, c.total, c.bases, c.rows, c.text_bytes);
     if (c.out != stdout) fclose(c.out);
     free(b.r);
     free((void *)files);
