@@ -133,6 +133,9 @@ WR_DEV void l2_win_move2(uint32_t *qbuf, const uint8_t *q, int plen, int *qw0_cu
 #ifndef L2_FWD_ATTR
 #define L2_FWD_ATTR WR_DEV
 #endif
+#ifndef L2_COUNT
+#define L2_COUNT(what, n) /* the emulator harness counts score steps per flavour, extension passes and cut-offs */
+#endif
 // qb / tb: word 0 of the 2-bit packed sequences in LDS (one readable word in front, (len + 15) / 16 + 2 words, zero behind the
 // last base); WIN: the two windows instead (L2_WINW + 2 words each, one readable word in front), filled here from p.q / p.t
 template <int NC, typename RT, bool WIN = false, int MARGIN = L2_SHRINK_MARGIN>
@@ -227,6 +230,7 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
         // with a break in it came out of the compiler with two branches, a select and a mask test per pass inside the big kernel)
         if (WR_BALLOT(h < lim) != 0ull) {
             do { // (the positions of idle lanes stay inside the sequences)
+                L2_COUNT(ext_pass, 1);
                 const bool ext = h < lim;
                 const uint32_t d = l2_get16(qb, h - k) ^ l2_get16(tb, h);
                 const int nm = WR_CLZ(d) >> 1; // 16 when all 16 bases match
@@ -336,6 +340,8 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
             if (NA > NA_MIN) rare |= (uint32_t)((int)span + 2 * MARGIN - 32 * NA) & ~(uint32_t)(s + 2 - WR_UNIFORM(shrink_from));
             if ((int32_t)rare < 0) break;
             // ---- a plain step ----
+            L2_COUNT(step[EDGE ? 1 : 0][NA > 4 ? 4 : NA], 1);
+            L2_COUNT(width, (int)span + 1);
             s += 2;
             hp += 2;
 #pragma unroll
@@ -472,6 +478,7 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
                     s_lim = WR_UNIFORM(done ? -(1 << 30) : s_lim);
                 }
                 if (mhi[0] - mlo[0] + 1 >= 10) { // wf-adaptive(10, 50)
+                    L2_COUNT(cutoff, 1);
                     int32_t dist[NA];
                     int32_t dm = 2147483647;
 #pragma unroll

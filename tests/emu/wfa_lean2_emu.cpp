@@ -23,6 +23,17 @@
 #define WR_WAVE_MIN_I32(v) \
     ((int32_t)simt::wave_reduce((uint32_t)(v), __LINE__, [](uint32_t a, uint32_t b) { return (uint32_t)((int32_t)a < (int32_t)b ? (int32_t)a : (int32_t)b); }))
 
+// dynamic counts of the forward pass (lane 0 counts; l2_emu_counts reads and clears): steps per (edge, flavour), extension
+// passes, cut-offs, the sum of the row widths
+struct L2Counts {
+    long step[2][5];
+    long ext_pass, cutoff, width;
+};
+static L2Counts g_cnt;
+#define L2_COUNT(what, n) \
+    do {                  \
+        if (simt::tid() == 0) g_cnt.what += (n); \
+    } while (0)
 #include "../../lexicmap_amd/csrc/lm_wfa_lean2_fwd.h"
 #include "wfa_host_walk.h"
 
@@ -79,6 +90,10 @@ static long run1(const uint8_t *q, int qlen, const uint8_t *t, int tlen, int max
     return ncoll;
 }
 
+extern "C" void l2_emu_counts(long *out) { // 13 longs
+    memcpy(out, &g_cnt, sizeof g_cnt);
+    memset(&g_cnt, 0, sizeof g_cnt);
+}
 extern "C" long l2_emu_run(int nc, int r16, int win, const uint8_t *q, int qlen, const uint8_t *t, int tlen, int max_score, int arena_cap,
                            uint64_t *ops, int ops_cap, WrEmuOut *out, int *recentres) {
     if (win) switch (nc) {
