@@ -677,7 +677,7 @@ lm_status lm_index_build_synthetic(const lm_synth_spec *spec, const lm_options *
         }
         for (int w = 1; w < nwords; w++) dcnt[w] = dcnt[w - 1] + (uint32_t)__builtin_popcountll(dmap[w - 1]);
         const size_t lds_bytes = (size_t)M * 8 + (size_t)nwords * 12 + 64;
-        if (lds_bytes > 160 * 1024 || getenv("LM_BUILDER_GLOBAL_CAPTURE")) lds_capture = false;
+        if (lds_bytes > 160 * 1024) lds_capture = false;
         DBuf<uint64_t> dbl_map;
         DBuf<uint32_t> dbl_cnt;
         copy_up(dbl_map, dmap);

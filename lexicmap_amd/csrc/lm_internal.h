@@ -395,26 +395,18 @@ struct lm_tune {
     // LDS (0; impossible beyond 65 kb).  LM_WFA_FIRST_NC="2,2,4,8,8", LM_WFA_WIN="00101" override.
     int wfa_first_nc[LM_WFA_CLASSES] = {2, 2, 4, 8, 8};
     int wfa_win[LM_WFA_CLASSES] = {0, 0, 1, 0, 1};
-    int chain1_wave = 1;     // seed chaining of pairs with many anchors by a wavefront each (LM_CHAIN1_LANES=1: one lane per pair)
+    int chain1_wave = 1;     // seed chaining of pairs with many anchors by a wavefront each
     int pa_filter_roll = 1;  // k_pa_filter: a lane takes consecutive window positions (immediate funnel shifts over its own 64-base string); LM_PA_FILTER_ROLL=0: every 64th position, words passed between lanes
-    int pa_seg_by_group = 1; // candidate segments by task group + XCD-local k_pa_search (LM_PA_SEG_BY_WAVE=1: by wavefront)
-    int wfa_resident_pct = 100; // LM_WFA_RESIDENT_PCT: share of the CUs' wavefront slots / LDS the persistent WFA kernels take
-    FILE *wfa_dump = nullptr; // LM_DEBUG_WFA_DUMP=<file>: one line per WFA problem and pass (width, status, lengths, estimate, score)
-    FILE *wfa_waves = nullptr; // LM_DEBUG_WFA_WAVES=<file>: one JSON line per k_wfa_lean launch: when its wavefronts started / ended, busy share
-    int wfa_ak_margin = -1;  // LM_WFA_AK_MARGIN: a problem starts at the ring that holds |tlen - qlen| + margin diagonals (-1: at the class's width)
+    int pa_seg_by_group = 1; // candidate segments by task group + XCD-local k_pa_search
+    int wfa_resident_pct = 100; // share of the CUs' wavefront slots / LDS the persistent WFA kernels take (75 / 50 % measured in round 3: no gain / -20 %)
     int arena_reserve_pct = 90; // LM_ARENA_RESERVE_PCT: share of the scratch budget cut into the two lane slabs when a production-size index is opened, else at the first search (LaneSlabs; 0: slabs on demand as in round 4)
     int two_lanes = 1;       // two parts of a batch searched side by side, each with half of the scratch budget (LM_TWO_LANES=0: one after the other)
     int lookup_flat = 1;     // anchors emitted with the lanes over the output (k_lookup_emit_flat); LM_LOOKUP_FLAT=0: one lane per lookup
-    int wfa_defer = 0;       // LM_WFA_DEFER=1: a round's latency-bound alignments finish beside the next round's first passes (default: every round waits for them)
     int wfa_r16 = 1;         // 16-bit ring cells in the whole-sequence WFA kernels of 128 / 256 diagonals (LM_WFA_R16=0: 32-bit)
     int wfa_mw = 1;          // 512 / 1024-diagonal passes by a workgroup of four wavefronts per alignment (LM_WFA_MW=0: one wavefront)
-    int wfa_serial = 0;      // LM_WFA_SERIAL=1: the WFA length classes one after the other (exclusive kernel timings)
-    int no_pipeline = 0;     // LM_NO_PIPELINE=1: no pseudo-alignment producer beside extend / WFA (exclusive kernel timings)
+    int wfa_serial = 0;      // the WFA length classes one after the other (lm_profile_exclusive: exclusive kernel timings)
+    int no_pipeline = 0;     // no pseudo-alignment producer beside extend / WFA (lm_profile_exclusive)
     lm_tune() {
-        wfa_serial = getenv("LM_WFA_SERIAL") != nullptr;
-        if (const char *e = getenv("LM_DEBUG_WFA_DUMP")) wfa_dump = fopen(e, "a");
-        if (const char *e = getenv("LM_DEBUG_WFA_WAVES")) wfa_waves = fopen(e, "a");
-        if (const char *e = getenv("LM_WFA_RESIDENT_PCT")) wfa_resident_pct = std::max(5, std::min(100, atoi(e)));
         if (const char *e = getenv("LM_WFA_FIRST_NC")) {
             int v[LM_WFA_CLASSES];
             if (sscanf(e, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]) == LM_WFA_CLASSES)
@@ -423,16 +415,11 @@ struct lm_tune {
         }
         if (const char *e = getenv("LM_WFA_WIN"))
             for (int c = 0; c < LM_WFA_CLASSES && e[c]; c++) wfa_win[c] = e[c] == '1';
-        no_pipeline = getenv("LM_NO_PIPELINE") != nullptr;
         if (const char *e = getenv("LM_WFA_MW")) wfa_mw = atoi(e) != 0;
         if (const char *e = getenv("LM_WFA_R16")) wfa_r16 = atoi(e) != 0;
-        if (const char *e = getenv("LM_WFA_DEFER")) wfa_defer = atoi(e) != 0;
         if (const char *e = getenv("LM_LOOKUP_FLAT")) lookup_flat = atoi(e) != 0;
         if (const char *e = getenv("LM_TWO_LANES")) two_lanes = atoi(e) != 0;
         if (const char *e = getenv("LM_ARENA_RESERVE_PCT")) arena_reserve_pct = std::max(0, std::min(100, atoi(e)));
-        if (const char *e = getenv("LM_WFA_AK_MARGIN")) wfa_ak_margin = atoi(e);
-        if (getenv("LM_CHAIN1_LANES")) chain1_wave = 0;
-        if (const char *e = getenv("LM_PA_SEG_BY_WAVE")) pa_seg_by_group = atoi(e) ? 0 : 1;
         if (const char *e = getenv("LM_PA_FILTER_ROLL")) pa_filter_roll = atoi(e) != 0;
     }
 };

@@ -1090,7 +1090,6 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
                 }
                 const int64_t per_slot = biggest * 36 / 10 + (1 << 20);
                 nslots = (size_t)std::max<int64_t>(std::min<int64_t>(2, (int64_t)nf), std::min<int64_t>((int64_t)nslots, avail / 3 / per_slot));
-                if (const char *e = getenv("LM_LOADER_SLOTS")) nslots = (size_t)std::max(1, std::min((int)nf, atoi(e)));
                 if (nslots < 1) nslots = 1;
             }
             struct Slot {
@@ -1113,7 +1112,7 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
             };
             DBuf<uint64_t> dk, dv;
             DBuf<uint16_t> dm;
-            const bool pin = !getenv("LM_LOADER_NO_PIN");
+            const bool pin = true; // (decoded chunks are registered with the driver: the upload is one DMA)
             const bool ldbg = getenv("LM_DEBUG") != nullptr;
             double t_wait = 0, t_pin = 0, t_pack = 0;
             const double t_seeds0 = now_ms();
@@ -1366,15 +1365,13 @@ void lm_profile_mark(lm_index *ix, int id) {
 void lm_profile_exclusive(lm_index *ix, int exclusive) {
     if (!ix) return;
     std::lock_guard<std::mutex> lock(ix->mu);
-    ix->tune.wfa_serial = exclusive != 0 || getenv("LM_WFA_SERIAL") != nullptr;
-    ix->tune.no_pipeline = exclusive != 0 || getenv("LM_NO_PIPELINE") != nullptr;
+    ix->tune.wfa_serial = exclusive != 0;
+    ix->tune.no_pipeline = exclusive != 0;
 }
 void lm_tuning_reload(lm_index *ix) {
     if (!ix) return;
     std::lock_guard<std::mutex> lock(ix->mu);
     lm_tune fresh;
-    if (ix->tune.wfa_dump) fclose(ix->tune.wfa_dump);
-    if (ix->tune.wfa_waves) fclose(ix->tune.wfa_waves);
     fresh.wfa_serial = fresh.wfa_serial || ix->tune.wfa_serial;   // (owned by lm_profile_exclusive: a reload does not undo it)
     fresh.no_pipeline = fresh.no_pipeline || ix->tune.no_pipeline;
     ix->tune = fresh;
@@ -1462,7 +1459,7 @@ static lm_qbatch *upload_part(lm_index *ix, const lm_query *queries, size_t nq, 
 }
 
 // Limits of one pass: slot numbers (query, mask, direction) and k-mer numbers travel as 32-bit values, and the arrays
-// sized by them must fit the device memory left beside the index (LM_MAX_PART_KMERS / LM_MAX_PART_SLOTS override).
+// sized by them must fit the device memory left beside the index (LM_MAX_PART_KMERS overrides: tests).
 static void part_limits(lm_index *ix, int64_t *max_pos, int64_t *max_qm) {
     int64_t pos = ((int64_t)1 << 30) - 1, qm = ((int64_t)1 << 31) - 1;
     // ~104 B per k-mer position (two sorted k-mer arrays with their double buffers, capture marks) and ~80 B per
@@ -1473,7 +1470,6 @@ static void part_limits(lm_index *ix, int64_t *max_pos, int64_t *max_qm) {
         qm = std::min<int64_t>(qm, std::max<int64_t>(b / 2 / 80, (int64_t)ix->host.M));
     }
     if (const char *e = getenv("LM_MAX_PART_KMERS")) pos = std::max<int64_t>(1, std::min<int64_t>(pos, atoll(e)));
-    if (const char *e = getenv("LM_MAX_PART_SLOTS")) qm = std::max<int64_t>(ix->host.M, std::min<int64_t>(qm, atoll(e)));
     *max_pos = pos;
     *max_qm = qm;
 }
@@ -1564,9 +1560,7 @@ struct AlignCtx {
     DBuf<int64_t> woff;
     DBuf<uint8_t> wbuf;
     // windows of the tasks with chains, compact, gathered over the chunks of one extendMatch / WFA round
-    DBuf<uint8_t> gwbuf, gwbuf2; // the round's compact window buffer; two alternate while a round's tail is still aligning
-    hipStream_t tail_st = nullptr; // (on the context the tail thread aligns with)
-    DBuf<uint8_t> tail_tmp;
+    DBuf<uint8_t> gwbuf; // the round's compact window buffer
     DBuf<int32_t> gw_idx;
     DBuf<int64_t> gw_dest;
     DBuf<unsigned long long> pa_count;
@@ -1597,7 +1591,6 @@ struct AlignCtx {
         hipStream_t st = nullptr;
         DBuf<int32_t> todo, hdr_pool, arena_pool;
         DBuf<unsigned int> queue;
-        DBuf<unsigned long long> dbg; // LM_DEBUG_WFA_WAVES
         DBuf<uint8_t> tmp;
         ~LeanCtx() {
             if (st) (void)hipStreamDestroy(st);
@@ -1619,10 +1612,9 @@ struct AlignCtx {
         for_each_phase([](auto &b) { b.phase = true; });
     }
     ~AlignCtx() {
-        if (tail_st) (void)hipStreamDestroy(tail_st);
     }
     template <class F> void for_each_phase(F f) {
-        f(wlen); f(woff); f(wbuf); f(gwbuf); f(gwbuf2); f(tail_tmp); f(gw_idx); f(gw_dest); f(pa_off); f(A0); f(B0); f(A1); f(B1); f(subs);
+        f(wlen); f(woff); f(wbuf); f(gwbuf); f(gw_idx); f(gw_dest); f(pa_off); f(A0); f(B0); f(A1); f(B1); f(subs);
         f(marks); f(msi); f(stack); f(out_n); f(clr_n); f(out); f(out_compact); f(res_off); f(tasks); f(hsp_in);
         f(hsp_ext); f(ext_cap); f(ext_wcap); f(ext_msi); f(ext_off); f(ext_subs); f(ext_rows); f(ext_rstart);
         f(wfa_in); f(wfa_out);  f(ops_pool);
@@ -1723,6 +1715,7 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
         for (int q = 0; q < qb->nq; q++) maxq = std::max<int64_t>(maxq, qb->h_qoff[q + 1] - qb->h_qoff[q]);
         if (maxq < 8192) by_group = false;
     }
+    bool nseg_stale = false; // the layout changed (task-group ranges -> per wavefront): count the segments again
     for (int attempt = 0;; attempt++) {
         if (!compact) a.A0.ensure((size_t)a.pa_cap);
         a.B0.ensure((size_t)a.pa_cap);
@@ -1731,7 +1724,12 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
         // task group: never more segments than groups, and a re-run after an overflow keeps the number of segments (the
         // measured fullest segment then sizes the next attempt exactly)
         if (!by_group) {
-            nseg = (int)std::max<int64_t>(1, std::min<int64_t>(1024, a.pa_cap / 4096));
+            // (once per layout: a re-run after an overflow keeps the number of segments, so that the capacity of a segment grows
+            // with the buffer.  Recomputed every attempt it stayed at ~4096 entries while the buffer grew - a chunk whose busiest
+            // wavefront found a few more than that overflowed five times in a row and the search failed, depending on which
+            // wavefront happened to take which slices: round 6, seen once in three runs of the test suite)
+            if (attempt == 0 || nseg_stale) nseg = (int)std::max<int64_t>(1, std::min<int64_t>(1024, a.pa_cap / 4096));
+            nseg_stale = false;
         } else if (attempt == 0) { // ranges of task groups x LM_PA_RANGE_SEGS segments each
             const int64_t ngroups = (nt + LM_PA_GROUP - 1) / LM_PA_GROUP;
             const int64_t ranges = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(LM_PA_MAX_SEGS / LM_PA_RANGE_SEGS, ngroups),
@@ -1780,13 +1778,17 @@ static void run_pseudo(AlignCtx &a, TaskSpan ht, std::vector<int64_t> &res_off_h
         // candidates and anchors share the estimate; a segment that overflowed dropped candidates: size for the fullest
         int64_t need = std::max<int64_t>(seg_max > seg_cap ? seg_max * nseg + seg_max * nseg / 8 : ncand, TP);
         if (need <= a.pa_cap && seg_max <= seg_cap) break;
-        if (attempt > 4) throw HipError("pseudo-alignment anchor buffer keeps overflowing");
+        if (attempt > 4)
+            throw HipError("pseudo-alignment anchor buffer keeps overflowing (windows " + std::to_string(nt) + ", window bases " + std::to_string(W) +
+                           ", candidates " + std::to_string(ncand) + ", fullest of " + std::to_string(nseg) + " segments " + std::to_string(seg_max) + " of " +
+                           std::to_string(seg_cap) + ", anchors " + std::to_string(TP) + ", capacity " + std::to_string(a.pa_cap) + ")");
         if (by_group && seg_max > seg_cap && seg_max * nseg > 3 * std::max<int64_t>(std::max(ncand, TP), 1)) {
             // Segments by task-group range are as uneven as the batch: one 200-kb plasmid query among genes (or the reads of a
             // mixed batch) fills its range with 10-50 x the mean, and a uniform segment capacity sized for the fullest range
             // would blow the whole list - and the anchor buffers that share its size - up by that factor (an out-of-memory
             // or a halved chunk exactly on the mixed workloads).  Such a chunk takes the balanced per-wavefront layout.
             by_group = false;
+            nseg_stale = true;
             need = std::max<int64_t>(ncand + ncand / 8, TP);
             if (getenv("LM_DEBUG")) fprintf(stderr, "[lm] pseudo-alignment: uneven ranges (fullest %lld x %d segments vs %lld candidates): per-wavefront segments for this chunk\n",
                                             (long long)seg_max, nseg, (long long)ncand);
@@ -1896,18 +1898,8 @@ static double div_from_pseudo_pident(double pid) { // table over integer percent
     return lut[i]; // floor of the identity => slightly over-estimated divergence
 }
 
-// `defer` (the search's rounds): only the FIRST pass of the classes up to 32 kb runs here - the throughput-bound launches that
-// fill the chip; what they leave (status 3 / 1), what is predicted wider than its class's ring and everything of the long
-// classes (a handful of alignments per round at single-problem latency: k_wfa_mw) is listed in `defer` with the ring width
-// it should start at, its record left at status -1: the caller aligns those in a second call (`min_nc` = those widths) on
-// another context BESIDE the next round's first passes instead of making every round wait for them.
-struct WfaDefer {
-    std::vector<int32_t> idx;
-    std::vector<int8_t> min_nc;
-};
 static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &out, std::vector<uint64_t> &ops_h,
-                    std::vector<int64_t> &ops_off_h, bool want_ops, const std::vector<float> *est_div = nullptr,
-                    WfaDefer *defer = nullptr, const std::vector<int8_t> *min_nc = nullptr, double budget_frac = 1.0) {
+                    std::vector<int64_t> &ops_off_h, bool want_ops, const std::vector<float> *est_div = nullptr) {
     lm_index *ix = a.ix;
     const int lane = tls_lane;
     int64_t n = (int64_t)in.size();
@@ -1916,8 +1908,8 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
     ops_h.clear();
     if (n == 0) return;
     // scratch: the LDS passes and the global-memory fallback run at the same time
-    const int64_t lean_budget = (int64_t)(budget_frac * (double)(BUDGET(ix) > 0 ? std::min<int64_t>(a.wfa_budget, BUDGET(ix) * 26 / 100) : a.wfa_budget));
-    const int64_t wide_budget = (int64_t)(budget_frac * (double)(BUDGET(ix) > 0 ? std::min<int64_t>((int64_t)72 << 30, BUDGET(ix) * 10 / 100) : (int64_t)72 << 30));
+    const int64_t lean_budget = BUDGET(ix) > 0 ? std::min<int64_t>(a.wfa_budget, BUDGET(ix) * 26 / 100) : a.wfa_budget;
+    const int64_t wide_budget = BUDGET(ix) > 0 ? std::min<int64_t>((int64_t)72 << 30, BUDGET(ix) * 10 / 100) : (int64_t)72 << 30;
     a.wfa_out.ensure((size_t)n);
     a.wfa_in.ensure((size_t)n);
     std::vector<std::vector<uint64_t>> ops_keep(want_ops ? n : 0);
@@ -2035,17 +2027,12 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
     // the whole packed sequences in LDS or reads them through sliding windows (lm_tune::wfa_win), and keep the few long
     // alignments of a round off the queue of the many short ones.  The last class (beyond 65 kb: what the whole-sequence
     // kernel cannot hold) is open-ended and always windowed.  Within a class the queue keeps the longest-expected-first order
-    // Every class has up to TWO chains of passes running side by side: chain c starts all its problems at the class's ring width;
-    // chain NCLS + c holds the problems PREDICTED to outgrow that width and starts each at the width predicted for it.  The
-    // wavefront of a global alignment must span from where the alignment is to its final diagonal tlen - qlen (lm_wfa_align
-    // keeps the range open towards it), so a problem with |tlen - qlen| + ~40 diagonals above a ring's W - 2 fails there with
-    // status 3 after a few hundred scores whatever its divergence (measured: of 78 000 c3-shaped problems exactly those with
-    // |tlen - qlen| >= 210..260 outgrew 254 diagonals).  Left to the retry pass they are a tail the round waits for (1 % of
-    // the 2-8-kb class: a 46-ms second pass behind a 250-ms first one); started at their width at once they run beside it.
-    constexpr int NCLS = LM_WFA_CLASSES, NCH = 2 * LM_WFA_CLASSES;
+    // (Measured in round 4 and removed in round 6: a second chain of passes per class for the problems |tlen - qlen| predicts to
+    // outgrow the class's ring, started at the predicted width - the retry passes leave the critical chain, but the round is
+    // bound by the sum of the work: C3 22.6 s against 13.0 s per step.)
+    constexpr int NCLS = LM_WFA_CLASSES, NCH = LM_WFA_CLASSES;
     const int bounds[NCLS - 1] = {128, 512, 2048, 4096};
     std::vector<int32_t> cls[NCH];
-    std::vector<int8_t> start_nc(n, 0);
     int cw[NCH];
     int64_t cl[NCH], cs[NCH];
     for (int c = 0; c < NCH; c++) {
@@ -2057,31 +2044,12 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
     bool win[NCH];
     for (int c = 0; c < NCLS; c++) {
         first_nc[c] = ix->tune.wfa_first_nc[c];
-        first_nc[NCLS + c] = 16; // lowered to the narrowest predicted width of its members below
-        win[c] = win[NCLS + c] = ix->tune.wfa_win[c] != 0 || c == NCLS - 1;
+        win[c] = ix->tune.wfa_win[c] != 0 || c == NCLS - 1;
     }
-    const int ak_margin = ix->tune.wfa_ak_margin; // < 0: no prediction
     for (int32_t i : order) {
         const int wds = (std::max(in[i].qlen, in[i].tlen) + 15) / 16;
         int c = 0;
         while (c < NCLS - 1 && wds > bounds[c]) c++;
-        int snc = first_nc[c];
-        if (ak_margin >= 0) {
-            const int need = std::abs(in[i].tlen - in[i].qlen) + ak_margin;
-            while (snc < 16 && need > 64 * snc - 2) snc *= 2;
-        }
-        if (min_nc) snc = std::max(snc, std::min(16, (int)(*min_nc)[i]));
-        start_nc[i] = (int8_t)snc;
-        if (defer && (c >= 3 || snc > first_nc[c])) { // the latency-bound ones: the caller's second call
-            defer->idx.push_back(i);
-            defer->min_nc.push_back((int8_t)snc);
-            out[i].r.status = -1;
-            continue;
-        }
-        if (snc > first_nc[c]) {
-            c += NCLS;
-            first_nc[c] = std::min(first_nc[c], snc);
-        }
         cls[c].push_back(i);
         cw[c] = std::max(cw[c], wds);
         const int64_t L = (int64_t)in[i].qlen + in[i].tlen;
@@ -2133,12 +2101,6 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
         lc.arena_pool.ensure((size_t)(bytes / 4) * nblocks + 16);
         lc.todo.ensure((size_t)m);
         lc.queue.ensure(1);
-        const bool wave_dbg = ix->tune.wfa_waves != nullptr && !mw;
-        auto items_at = [&](long long x) { return items[(size_t)x]; };
-        if (wave_dbg) {
-            lc.dbg.ensure((size_t)nblocks * 6);
-            HIPCHK(hipMemsetAsync(lc.dbg.p, 0, sizeof(unsigned long long) * 6 * nblocks, S(ix)));
-        }
         HIPCHK(hipMemcpyAsync(lc.todo.p, items.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice, S(ix)));
         HIPCHK(hipMemsetAsync(lc.queue.p, 0, sizeof(unsigned int), S(ix)));
         {
@@ -2152,51 +2114,9 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
                               a.ops_pool.p, lc.queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc, use_win);
             else
                 launch_wfa(S(ix), a.wfa_in.p, n, lc.todo.p, m, nblocks, lc.hdr_pool.p, entries * 2, (uint8_t *)lc.arena_pool.p, bytes,
-                           a.ops_pool.p, lc.queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc, use_win, r16, wave_dbg ? lc.dbg.p : nullptr);
+                           a.ops_pool.p, lc.queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc, use_win, r16, nullptr);
         }
         sync(ix);
-        if (wave_dbg) { // where the launch's time went, wavefront by wavefront (100-MHz wall clock)
-            std::vector<unsigned long long> d;
-            d2h(ix, d, lc.dbg.p, (size_t)nblocks * 6);
-            sync(ix);
-            unsigned long long t_first = ~0ull, t_last = 0;
-            for (int b = 0; b < nblocks; b++)
-                if (d[6 * b + 1]) {
-                    t_first = std::min(t_first, d[6 * b]);
-                    t_last = std::max(t_last, d[6 * b + 1]);
-                }
-            std::vector<double> ends, starts;
-            double busy = 0, fwd = 0, worst = 0;
-            long long items = 0, worst_x = -1;
-            for (int b = 0; b < nblocks; b++) {
-                if (!d[6 * b + 1]) continue;
-                starts.push_back((double)(d[6 * b] - t_first) * 1e-5);
-                ends.push_back((double)(d[6 * b + 1] - t_first) * 1e-5);
-                busy += (double)(d[6 * b + 1] - d[6 * b]) * 1e-5;
-                fwd += (double)d[6 * b + 3] * 1e-5;
-                items += (long long)d[6 * b + 2];
-                if ((double)d[6 * b + 4] * 1e-5 > worst) {
-                    worst = (double)d[6 * b + 4] * 1e-5;
-                    worst_x = (long long)d[6 * b + 5];
-                }
-            }
-            std::sort(ends.begin(), ends.end());
-            std::sort(starts.begin(), starts.end());
-            const size_t nw = ends.size();
-            auto pct = [&](const std::vector<double> &v, double q) { return v.empty() ? 0.0 : v[std::min(v.size() - 1, (size_t)(q * (double)v.size()))]; };
-            const double span = nw ? (double)(t_last - t_first) * 1e-5 : 0;
-            std::lock_guard<std::mutex> l(fb_mu);
-            fprintf(ix->tune.wfa_waves, "{\"diagonals\": %d, \"win\": %d, \"serial\": %d, \"problems\": %lld, \"waves_launched\": %d, \"waves_ran\": %zu, \"span_ms\": %.3f, "
-                    "\"mean_busy_ms\": %.3f, \"busy_over_span\": %.3f, \"fwd_share\": %.3f, \"start_p50\": %.3f, \"start_p99\": %.3f, \"start_max\": %.3f, "
-                    "\"end_p10\": %.3f, \"end_p50\": %.3f, \"end_p90\": %.3f, \"end_p99\": %.3f, \"longest_problem_ms\": %.3f, \"its_queue_pos\": %lld, "
-                    "\"its_qlen\": %d, \"its_tlen\": %d, \"its_div\": %.3f, \"problems_done\": %lld}\n",
-                    64 * nc, use_win ? 1 : 0, ix->tune.wfa_serial ? 1 : 0, (long long)m, nblocks, nw, span, nw ? busy / (double)nw : 0.0, span > 0 ? busy / ((double)nw * span) : 0.0,
-                    busy > 0 ? fwd / busy : 0.0, pct(starts, 0.5), pct(starts, 0.99), starts.empty() ? 0.0 : starts.back(), pct(ends, 0.1), pct(ends, 0.5),
-                    pct(ends, 0.9), pct(ends, 0.99), worst, worst_x, worst_x >= 0 && worst_x < m ? in[items_at(worst_x)].qlen : 0,
-                    worst_x >= 0 && worst_x < m ? in[items_at(worst_x)].tlen : 0,
-                    worst_x >= 0 && worst_x < m && est_div ? (double)(*est_div)[items_at(worst_x)] : -1.0, items);
-            fflush(ix->tune.wfa_waves);
-        }
         // this pass's results: the records of its items (other classes write theirs into the same array meanwhile)
         std::vector<WfaOut> tmp;
         d2h(ix, tmp, a.wfa_out.p, (size_t)n);
@@ -2204,13 +2124,6 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
         if (want_ops) d2h(ix, ops_tmp, a.ops_pool.p, (size_t)ops_tot);
         sync(ix);
         int64_t n3 = 0, n1 = 0;
-        if (ix->tune.wfa_dump) { // experiment log: what predicts the ring width a problem needs
-            std::lock_guard<std::mutex> l(fb_mu);
-            for (int32_t i : items)
-                fprintf(ix->tune.wfa_dump, "%d %d %d %d %.4f %d %d\n", 64 * nc, tmp[i].r.status, in[i].qlen, in[i].tlen,
-                        est_div ? (double)(*est_div)[i] : -1.0, tmp[i].r.score, (int)tmp[i].r.gaps);
-            fflush(ix->tune.wfa_dump);
-        }
         for (int32_t i : items) {
             int stt = tmp[i].r.status;
             n3 += stt == 3;
@@ -2245,34 +2158,11 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
     // rings are slower per score and their LDS keeps the anchor filter's workgroups off the CUs.)
     auto class_chain = [&](int c) {
         AlignCtx::LeanCtx &lc = a.lean[c];
-        std::vector<int32_t> cur, next, later = cls[c];
-        for (int nc = first_nc[c]; nc <= 16 && (!cur.empty() || !later.empty()); nc *= 2) {
-            // what the narrower pass left (status 3) + the members that start at this width, in the queue's cost order
-            if (!later.empty()) {
-                std::vector<int32_t> keep;
-                for (int32_t i : later) (start_nc[i] <= nc ? cur : keep).push_back(i);
-                later.swap(keep);
-            }
+        std::vector<int32_t> cur = cls[c], next;
+        for (int nc = first_nc[c]; nc <= 16 && !cur.empty(); nc *= 2) { // what a pass leaves (status 3) goes to the next width
             next.clear();
             persistent_pass(lc, share[c], cur, cw[c], win[c], cl[c], cs[c], next, nc);
             cur.swap(next);
-            if (defer) { // first pass only: what outgrew this ring starts at the next width in the caller's second call
-                std::lock_guard<std::mutex> l(fb_mu);
-                for (int32_t i : cur) {
-                    defer->idx.push_back(i);
-                    defer->min_nc.push_back((int8_t)std::min(16, 2 * nc));
-                    out[i].r.status = -1;
-                }
-                for (size_t j = 0; j < fb_items.size(); j++) { // scratch overflows of this pass: same width again, own scratch there
-                    defer->idx.push_back(fb_items[j]);
-                    defer->min_nc.push_back((int8_t)nc);
-                    out[fb_items[j]].r.status = -1;
-                }
-                fb_items.clear();
-                fb_level.clear();
-                cur.clear();
-                break;
-            }
         }
         std::lock_guard<std::mutex> l(fb_mu);
         for (int32_t i : cur) { // the hard ones: generous scratch at once instead of an overflow and a second launch
@@ -2315,12 +2205,9 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
     std::thread cth[NCH];
     std::exception_ptr cerr[NCH];
     const bool serial = ix->tune.wfa_serial; // exclusive kernel timings: one class after the other
-    // start order: the predicted-wide chains and the long classes first (latency-bound: resident from the start)
+    // start order: the long classes first (latency-bound: resident from the start)
     int start_order[NCH];
-    for (int c = 0; c < NCLS; c++) {
-        start_order[c] = 2 * NCLS - 1 - c;      // chains NCLS + 4 .. NCLS + 0
-        start_order[NCLS + c] = NCLS - 1 - c;   // chains 4 .. 0
-    }
+    for (int c = 0; c < NCLS; c++) start_order[c] = NCLS - 1 - c;
     for (int oi = 0; oi < NCH; oi++) {
         const int c = start_order[oi];
         if (c == 0 || cls[c].empty()) continue;
@@ -2589,10 +2476,10 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
             if (t.joinable()) t.join();
         }
     } joiner{prod_thread, pm, pcv, cons_abort};
-    // ---- rounds.  The HSPs gathered from one or more chunks go through extendMatch / WFA / finalisation together.  A round's
-    // state lives in a Round object because its latency-bound alignments (the long classes and whatever outgrew the first
-    // pass's ring: a few hundred problems that keep a handful of CUs busy for ~100 ms) finish on a second context BESIDE
-    // the next round's first passes (run_wfa's `defer`): the tail thread aligns them and then finalises the round's genomes.
+    // ---- rounds.  The HSPs gathered from one or more chunks go through extendMatch / WFA / finalisation together.  (Round 4
+    // let a round's latency-bound alignments - the long classes and whatever outgrew its first pass's ring - finish on a third
+    // context beside the NEXT round's first passes; the consumer then waited for the pseudo-alignment producer instead: C3 14.3
+    // against 13.0 s per step.  Removed in round 6.)
     struct Round {
         std::vector<HspMeta> hsps;
         std::vector<HGenome> genomes; // of this round, in task order
@@ -2600,51 +2487,17 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
         std::vector<uint64_t> ops_h;
         std::vector<int64_t> ops_off_h;
         std::vector<uint8_t> wbuf_h;
-        // the deferred part
-        WfaDefer defer;
-        std::vector<int32_t> tail_of; // HSP -> index among the deferred ones, or -1
-        std::vector<WfaIn> in_t;
-        std::vector<float> est_t;
-        std::vector<WfaOut> wout_t;
-        std::vector<uint64_t> ops_h_t;
-        std::vector<int64_t> ops_off_t;
-        lm_stage_stats st_t;
-        int buf = 0; // which of the two window buffers holds this round's windows
     };
     std::vector<std::unique_ptr<Round>> rounds_done; // in round order: their genomes are appended to `genomes` at the end
     std::unique_ptr<Round> cur(new Round());
-    std::thread tail_thread;
-    std::exception_ptr tail_err;
-    std::mutex st_mu; // the stage statistics both threads add to
+    std::mutex st_mu; // the stage statistics (the finalisation is threaded)
     int round_no = 0;
-    auto gwb = [&](int b) -> DBuf<uint8_t> & { return b ? a.gwbuf2 : a.gwbuf; };
-    const bool defer_tails = pipelined && ix->tune.wfa_defer && !ix->tune.wfa_serial && ix->active_lanes == 1; // (two lanes + tails: too many queues)
-    AlignCtx *a_tail = defer_tails ? &get_actx(ix, qb, &w, &st, 2) : nullptr;
+    auto gwb = [&]() -> DBuf<uint8_t> & { return a.gwbuf; };
     int64_t gw_used = 0;        // bytes of the round's window buffer in use
     const int64_t gw_target = BUDGET(ix) > 0 ? std::min<int64_t>((int64_t)6 << 30, std::max<int64_t>((int64_t)64 << 20, BUDGET(ix) * 3 / 100)) : (int64_t)1 << 30;
     const int64_t round_hsps = getenv("LM_DEBUG_ROUND_HSPS") ? atoll(getenv("LM_DEBUG_ROUND_HSPS")) : 330000;
     const int64_t min_round_hsps = getenv("LM_DEBUG_MIN_ROUND_HSPS") ? atoll(getenv("LM_DEBUG_MIN_ROUND_HSPS")) : 150000;
-    struct TailJoiner { // the tail thread never outlives this frame
-        std::thread &t;
-        ~TailJoiner() {
-            if (t.joinable()) t.join();
-        }
-    } tail_joiner{tail_thread};
-    Round *tail_round = nullptr; // the round whose tail is (or was last) running
-    auto join_tail = [&]() {
-        if (tail_thread.joinable()) tail_thread.join();
-        if (tail_round) {
-            st.wfa_retries += tail_round->st_t.wfa_retries;
-            tail_round = nullptr;
-        }
-        if (tail_err) {
-            std::exception_ptr e = tail_err;
-            tail_err = nullptr;
-            std::rethrow_exception(e);
-        }
-    };
-    // ---- finalisation of a round's genomes (:2266-2357 / :2533-2626, then :2684-2749); on the consumer's thread, or on the
-    // tail thread once the round's deferred alignments are in
+    // ---- finalisation of a round's genomes (:2266-2357 / :2533-2626, then :2684-2749); on the consumer's thread
     auto finalize_round = [&](Round &R) {
         const double td = now_ms();
         parallel_for((int64_t)R.genomes.size(), 128, [&](int64_t gb0, int64_t gb1) {
@@ -2660,8 +2513,7 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
                         continue;
                     }
                     const HspMeta &h = R.hsps[c.hsp];
-                    const int32_t tj = R.tail_of.empty() ? -1 : R.tail_of[c.hsp]; // aligned by the tail call ?
-                    const WfaOut &wo = tj >= 0 ? R.wout_t[tj] : R.wout[c.hsp];
+                    const WfaOut &wo = R.wout[c.hsp];
                     const LmWfaOut &cg = wo.r;
                     int lq = h.ext.qe - h.ext.qs, lt = h.ext.te - h.ext.ts;
                     c.score = wo.blast_score;
@@ -2704,8 +2556,7 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
                         continue;
                     }
                     if (want_seq) {
-                        std::vector<uint64_t> ops = tj >= 0 ? std::vector<uint64_t>(R.ops_h_t.begin() + R.ops_off_t[tj], R.ops_h_t.begin() + R.ops_off_t[tj + 1])
-                                                            : std::vector<uint64_t>(R.ops_h.begin() + R.ops_off_h[c.hsp], R.ops_h.begin() + R.ops_off_h[c.hsp + 1]);
+                        std::vector<uint64_t> ops(R.ops_h.begin() + R.ops_off_h[c.hsp], R.ops_h.begin() + R.ops_off_h[c.hsp + 1]);
                         c.cigar = fmt_cigar(ops);
                         c.qseq = new std::string();
                         c.tseq = new std::string();
@@ -2756,10 +2607,8 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
         }
         janitor().dispose(std::move(R.hsps));
         janitor().dispose(std::move(R.wout));
-        janitor().dispose(std::move(R.wout_t));
         R.hsps = std::vector<HspMeta>();
         R.ops_h = std::vector<uint64_t>();
-        R.ops_h_t = std::vector<uint64_t>();
         R.wbuf_h = std::vector<uint8_t>();
     };
     auto flush_round = [&]() {
@@ -2769,7 +2618,7 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
         }
         Round &R = *cur;
         std::vector<HspMeta> &hsps = R.hsps;
-        DBuf<uint8_t> &gwbuf = gwb(R.buf);
+        DBuf<uint8_t> &gwbuf = gwb();
         double tc = now_ms();
         int64_t NH = (int64_t)hsps.size();
         st.hsps_aligned += NH;
@@ -2818,65 +2667,24 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
             }
             std::vector<float> est(NH);
             for (int64_t i = 0; i < NH; i++) est[i] = hsps[i].est_div;
-            run_wfa(a, win, R.wout, R.ops_h, R.ops_off_h, want_seq, &est, defer_tails ? &R.defer : nullptr, nullptr, defer_tails ? 0.6 : 1.0);
+            run_wfa(a, win, R.wout, R.ops_h, R.ops_off_h, want_seq, &est);
             if (want_seq) {
                 d2h(ix, R.wbuf_h, gwbuf.p, (size_t)gw_used);
                 sync(ix);
-            }
-            if (!R.defer.idx.empty()) { // the deferred problems as a batch of their own
-                const size_t nt = R.defer.idx.size();
-                R.tail_of.assign((size_t)NH, -1);
-                R.in_t.resize(nt);
-                R.est_t.resize(nt);
-                for (size_t j = 0; j < nt; j++) {
-                    const int32_t i = R.defer.idx[j];
-                    R.tail_of[i] = (int32_t)j;
-                    R.in_t[j] = win[i];
-                    R.est_t[j] = est[i];
-                }
             }
         }
         {
             std::lock_guard<std::mutex> l(st_mu);
             st.ms_extend_wfa += now_ms() - tc;
         }
-        dbg_stamp("first WFA passes of the round done");
-        // one tail at a time: the previous round's has had this round's first passes to finish (and its window buffer is the
-        // one the NEXT round's glue will fill)
-        join_tail();
+        dbg_stamp("WFA passes of the round done");
         std::unique_ptr<Round> done = std::move(cur);
         cur.reset(new Round());
         round_no++;
-        cur->buf = defer_tails ? (round_no & 1) : 0;
         gw_used = 0;
         Round *Rp = done.get();
         rounds_done.push_back(std::move(done));
-        if (Rp->defer.idx.empty()) {
-            finalize_round(*Rp);
-            return;
-        }
-        if (getenv("LM_DEBUG"))
-            fprintf(stderr, "[lm +%.1f ms] %zu of the round's %lld alignments deferred to the tail (long classes / wider rings)\n", now_ms() - g_dbg_t0,
-                    Rp->defer.idx.size(), (long long)NH);
-        if (!a_tail->tail_st) HIPCHK(hipStreamCreate(&a_tail->tail_st));
-        memset(&Rp->st_t, 0, sizeof Rp->st_t);
-        a_tail->stats = &Rp->st_t;
-        tail_round = Rp;
-        tail_thread = std::thread([&, Rp]() {
-            try {
-                HIPCHK(hipSetDevice(ix->device));
-                tls_lane = lane;
-                tls_stream = a_tail->tail_st;
-                tls_tmp = &a_tail->tail_tmp;
-                tls_arena = &ix->arena[tls_lane];
-                run_wfa(*a_tail, Rp->in_t, Rp->wout_t, Rp->ops_h_t, Rp->ops_off_t, want_seq, &Rp->est_t, nullptr, &Rp->defer.min_nc, 0.4);
-                finalize_round(*Rp);
-            } catch (...) {
-                tail_err = std::current_exception();
-            }
-            tls_stream = nullptr;
-            tls_tmp = nullptr;
-        });
+        finalize_round(*Rp);
     };
     int64_t np_tpos = r0; // unpipelined: next chunk start
     while (true) {
@@ -2912,8 +2720,8 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
             int64_t need = 0;
             for (size_t t = 0; t < ht.size(); t++)
                 if (res_off[t + 1] > res_off[t]) need += ((int64_t)ht[t].wlen + 15) & ~(int64_t)15;
-            if (gw_used > 0 && (gw_used + need > (int64_t)gwb(cur->buf).cap - 64 || (int64_t)cur->hsps.size() >= round_hsps)) flush_round();
-            if (gw_used == 0) gwb(cur->buf).ensure((size_t)std::max<int64_t>(need, gw_target) + 64);
+            if (gw_used > 0 && (gw_used + need > (int64_t)gwb().cap - 64 || (int64_t)cur->hsps.size() >= round_hsps)) flush_round();
+            if (gw_used == 0) gwb().ensure((size_t)std::max<int64_t>(need, gw_target) + 64);
         }
         double tb = now_ms();
         dbg_stamp("glue of a chunk starts");
@@ -3043,7 +2851,7 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
                 HIPCHK(hipMemcpyAsync(a.gw_idx.p, widx.data(), widx.size() * sizeof(int32_t), hipMemcpyHostToDevice, S(ix)));
                 HIPCHK(hipMemcpyAsync(a.gw_dest.p, wdest.data(), wdest.size() * sizeof(int64_t), hipMemcpyHostToDevice, S(ix)));
                 Prof p(ix, "k_extract_windows", (gw_used - wdest[0]) * 5 / 4);
-                launch_extract_windows_at(S(ix), ix->view, w.tasks.p + tpos, a.gw_idx.p, a.gw_dest.p, (int64_t)widx.size(), gwb(cur->buf).p);
+                launch_extract_windows_at(S(ix), ix->view, w.tasks.p + tpos, a.gw_idx.p, a.gw_dest.p, (int64_t)widx.size(), gwb().p);
                 sync(ix); // the host lists go out of scope
             }
             cur->genomes.reserve(cur->genomes.size() + (size_t)ns);
@@ -3071,7 +2879,6 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
         if (idle && (int64_t)cur->hsps.size() >= min_round_hsps) flush_round();
     }
     flush_round();
-    join_tail();
     {
         size_t total = genomes.size();
         for (auto &r : rounds_done) total += r->genomes.size();

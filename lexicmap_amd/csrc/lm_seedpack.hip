@@ -391,7 +391,7 @@ void SeedPacker::finish() {
     nbig.alloc_exact(1, true, ix->st);
     if (n_main > 0) {
         const int64_t nparts = nmd * (P1 - 1);
-        const int dbg_mode = getenv("LM_SP_DEBUG_MODE") ? atoi(getenv("LM_SP_DEBUG_MODE")) : 0; // timing experiments only
+        const int dbg_mode = 0; // (the kernel's timing-experiment modes are not reachable any more)
         const double t0 = now_ms();
         hipLaunchKernelGGL(k_sp_sort_parts, dim3((unsigned)std::min<int64_t>(nparts, (int64_t)1 << 22)), dim3(64), 0, ix->st,
                            ix->d_part_tab.p, ix->d_md_off.p, P1, nmd, key_bits, val_bits, ix->d_pk_keys.p, ix->d_pk_vals.p,

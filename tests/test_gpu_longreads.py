@@ -131,8 +131,7 @@ def test_batch_split_into_parts_gives_the_same_rows(lr_index, lr_queries, monkey
 
 def test_rows_do_not_depend_on_which_device_implementation_of_a_stage_runs(lr_index, lr_queries, monkeypatch):
     """LM_WFA_MW (512 / 1024-diagonal WFA passes: a workgroup of four wavefronts or one wavefront per alignment), LM_OCC8 (the
-    register cap of the two kernels it applies to), LM_WFA_R16 (16- or 32-bit ring cells in the short WFA classes),
-    LM_WFA_AK_MARGIN (problems started at the ring width |tlen - qlen| predicts, or all at their class's width), LM_LOOKUP_FLAT
+    register cap of the two kernels it applies to), LM_WFA_R16 (16- or 32-bit ring cells in the short WFA classes), LM_LOOKUP_FLAT
     (seed anchors emitted with the lanes over the output or over the lookups), LM_PA_FILTER_ROLL (window positions consecutive
     per lane or strided) and LM_ARENA_RESERVE_PCT (lane slabs or slabs on demand) choose between device paths that must agree
     to the byte: the rows of the long-read fixture (equal to the oracle's by the first test) with each switch flipped"""
@@ -145,7 +144,7 @@ def test_rows_do_not_depend_on_which_device_implementation_of_a_stage_runs(lr_in
     ran = {p["name"] for p in gi.profile_get() if p["launches"] > 0}
     gi.close()
     assert any(n.startswith("k_wfa_mw") for n in ran), ran   # the fixture does reach the wide passes
-    for var, off in (("LM_WFA_MW", "0"), ("LM_WFA_R16", "0"), ("LM_WFA_AK_MARGIN", "40"),
+    for var, off in (("LM_WFA_MW", "0"), ("LM_WFA_R16", "0"),
                      ("LM_LOOKUP_FLAT", "0"), ("LM_PA_FILTER_ROLL", "0"), ("LM_ARENA_RESERVE_PCT", "0")):
         monkeypatch.setenv(var, off)
         gi = la.Index(d)      # the switches are read once per handle
@@ -160,11 +159,9 @@ def test_rows_do_not_depend_on_which_device_implementation_of_a_stage_runs(lr_in
             assert not any(n.startswith("k_wfa_mw") for n in ran1), ran1
 
 
-def test_rounds_whose_long_alignments_finish_beside_the_next_round_give_the_same_rows(lr_index, lr_queries, monkeypatch):
-    """With the alignment half in chunks (forced here: several chunks, a round every few HSPs) a round's latency-bound
-    alignments - the classes above 32 kb and whatever outgrew the first pass's ring - are aligned by a second context while
-    the next round's first passes run, and the round is finalised by that thread (run_wfa `defer`, LM_WFA_DEFER).  Rows,
-    CIGAR / alignment strings included, must be those of the single-round run, with the switch on and off."""
+def test_many_small_rounds_give_the_rows_of_one_round(lr_index, lr_queries, monkeypatch):
+    """With the alignment half in chunks (forced here: several chunks, a round of extendMatch / WFA / finalisation every few
+    HSPs) the rows, CIGAR / alignment strings included, must be those of the single-round run."""
     la = _la()
     d, _ = lr_index
     seqs = [q[1] for q in lr_queries]
@@ -176,12 +173,10 @@ def test_rounds_whose_long_alignments_finish_beside_the_next_round_give_the_same
     monkeypatch.setenv("LM_DEBUG_MAX_WINDOW_BYTES", "150000")   # a few chain windows per chunk
     monkeypatch.setenv("LM_DEBUG_ROUND_HSPS", "4")              # a round every few HSPs
     monkeypatch.setenv("LM_DEBUG_MIN_ROUND_HSPS", "1")
-    for defer in ("1", "0"):
-        monkeypatch.setenv("LM_WFA_DEFER", defer)
-        gi = la.Index(d, la.api.default_options(**opt))
-        got, st1 = gi.search(seqs)
-        gi.close()
-        assert got == base, defer
-        assert st0["rows"] == st1["rows"] and st0["hsps_aligned"] == st1["hsps_aligned"]
-    for v in ("LM_WFA_DEFER", "LM_DEBUG_MAX_WINDOW_BYTES", "LM_DEBUG_ROUND_HSPS", "LM_DEBUG_MIN_ROUND_HSPS"):
+    gi = la.Index(d, la.api.default_options(**opt))
+    got, st1 = gi.search(seqs)
+    gi.close()
+    assert got == base
+    assert st0["rows"] == st1["rows"] and st0["hsps_aligned"] == st1["hsps_aligned"]
+    for v in ("LM_DEBUG_MAX_WINDOW_BYTES", "LM_DEBUG_ROUND_HSPS", "LM_DEBUG_MIN_ROUND_HSPS"):
         monkeypatch.delenv(v)

@@ -39,7 +39,10 @@ def demo15(tmp_path_factory):
 
 def run(exe, args):
     r = subprocess.run([exe] + args, capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr
+    if r.returncode != 0:   # (what the device looked like to the other process: a failure here has been a starved scratch budget)
+        import torch
+        free, total = torch.cuda.mem_get_info()
+        raise AssertionError("%s\n[device memory seen from the test process: %.1f of %.1f GB free]" % (r.stderr, free / 1e9, total / 1e9))
     return r.stdout, r.stderr
 
 
