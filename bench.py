@@ -791,7 +791,11 @@ def main():
         per_rank = []
         for r in range(shard_of):
             c = base.copy()
-            c["batch_genome"] = c["batch_genome"] + (np.uint64(r) << np.uint64(40))  # distinct genomes per emulated shard
+            # the genomes shard r holds are those with number = r modulo N: this shard's genome g stands for its neighbour g + r
+            # (a real genome of the set: its names resolve as they would on the merging rank)
+            gnum = ((c["batch_genome"] >> np.uint64(17)) * np.uint64(5000) + (c["batch_genome"] & np.uint64(0x1ffff))).astype(np.int64)
+            gnum = np.clip(gnum - args.shard_rank + r, 0, wl["genomes"] - 1).astype(np.uint64)
+            c["batch_genome"] = ((gnum // np.uint64(5000)) << np.uint64(17)) | (gnum % np.uint64(5000))
             per_rank.append(c)
         t_m = time.time()
         merged = merge.merge_sharded_c(per_rank)

@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -328,10 +330,19 @@ static lm_status merge_on_device(lm_comm *c, lm_index *idx, const lm_hsp *d_rows
     if (s != LM_OK) return s;
     s = grow_host(c, &c->h_merged, &c->hmerged_cap, total * item);
     if (s != LM_OK) return s;
+    const bool dbg = getenv("LM_DEBUG") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     CK_HIP(c, lm::merge_rows_device(c->st, d_rows, total, off, N, (lm_hsp *)c->d_merged, c->ms));
+    if (dbg) CK_HIP(c, hipStreamSynchronize(c->st));
+    const double t1 = now();
     CK_HIP(c, hipMemcpyAsync(c->h_merged, c->d_merged, total * item, hipMemcpyDeviceToHost, c->st));
     CK_HIP(c, hipStreamSynchronize(c->st));
+    const double t2 = now();
     lm_attach_names(idx, (lm_hsp *)c->h_merged, total);
+    if (dbg)
+        fprintf(stderr, "[lm] device merge of %zu rows: order %.1f ms, download %.1f ms (%.1f GB/s), names %.1f ms\n", total, t1 - t0, t2 - t1,
+                (double)(total * item) / 1e6 / std::max(t2 - t1, 1e-3), now() - t2);
     *merged = (const lm_hsp *)c->h_merged;
     *total_out = total;
     return LM_OK;

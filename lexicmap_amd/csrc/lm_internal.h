@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <memory>
 #include <deque>
 #include <mutex>
 #include <shared_mutex>
@@ -472,7 +473,8 @@ struct lm_index {
     // names of a synthetic set (a function of the genome number), made on first use and kept with the handle: ONE copy per genome
     // (lm_merge_sharded made two strings per ROW: ten million allocations per C3 step on the merging rank)
     std::shared_mutex syn_mu;
-    std::unordered_map<uint64_t, std::pair<const char *, const char *>> syn_names;
+    std::unordered_map<uint64_t, std::pair<const char *, const char *>> syn_names; // (genome numbers beyond the set: bench.py's emulated shards)
+    std::unique_ptr<std::atomic<const char *>[]> syn_dense;                         // [2 * synth_genomes]: id, sequence id; NULL until first use
     std::deque<std::string> syn_store;
 };
 

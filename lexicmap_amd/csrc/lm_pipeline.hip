@@ -3893,6 +3893,33 @@ static void attach_name(lm_index *ix, lm_hsp &h) {
         return;
     }
     if (!H.synthetic) return;
+    const long long g = (long long)((h.batch_genome >> 17) * 5000 + (h.batch_genome & 0x1ffff));
+    auto make = [&](const char **a, const char **b) { // (under the unique lock)
+        char nm[64];
+        snprintf(nm, sizeof nm, "SYN_%09lld.1", g);
+        ix->syn_store.emplace_back(nm);
+        *a = ix->syn_store.back().c_str();
+        snprintf(nm, sizeof nm, "syn%09lld_c1", g);
+        ix->syn_store.emplace_back(nm);
+        *b = ix->syn_store.back().c_str();
+    };
+    if (g >= 0 && g < H.synth_genomes && ix->syn_dense) { // one load per name once a genome has been seen (4.7 M rows per C3 step)
+        std::atomic<const char *> *e = ix->syn_dense.get() + 2 * g;
+        const char *b = e[1].load(std::memory_order_acquire); // (the sequence id is published last)
+        if (!b) {
+            std::unique_lock<std::shared_mutex> wl(ix->syn_mu);
+            b = e[1].load(std::memory_order_relaxed);
+            if (!b) {
+                const char *a = nullptr;
+                make(&a, &b);
+                e[0].store(a, std::memory_order_relaxed);
+                e[1].store(b, std::memory_order_release);
+            }
+        }
+        h.genome_id = e[0].load(std::memory_order_relaxed);
+        h.seq_id = b;
+        return;
+    }
     {
         std::shared_lock<std::shared_mutex> rl(ix->syn_mu);
         auto is = ix->syn_names.find(h.batch_genome);
@@ -3905,20 +3932,23 @@ static void attach_name(lm_index *ix, lm_hsp &h) {
     std::unique_lock<std::shared_mutex> wl(ix->syn_mu);
     auto is = ix->syn_names.find(h.batch_genome);
     if (is == ix->syn_names.end()) {
-        const long long g = (long long)((h.batch_genome >> 17) * 5000 + (h.batch_genome & 0x1ffff));
-        char nm[64];
-        snprintf(nm, sizeof nm, "SYN_%09lld.1", g);
-        ix->syn_store.emplace_back(nm);
-        const char *a = ix->syn_store.back().c_str();
-        snprintf(nm, sizeof nm, "syn%09lld_c1", g);
-        ix->syn_store.emplace_back(nm);
-        is = ix->syn_names.emplace(h.batch_genome, std::make_pair(a, ix->syn_store.back().c_str())).first;
+        const char *a = nullptr, *b = nullptr;
+        make(&a, &b);
+        is = ix->syn_names.emplace(h.batch_genome, std::make_pair(a, b)).first;
     }
     h.genome_id = is->second.first;
     h.seq_id = is->second.second;
 }
 void lm_attach_names(lm_index *ix, lm_hsp *rows, size_t n) {
     if (!ix || n == 0) return;
+    if (ix->host.synthetic && !ix->syn_dense && ix->host.synth_genomes > 0) {
+        std::unique_lock<std::shared_mutex> wl(ix->syn_mu);
+        if (!ix->syn_dense) {
+            const size_t m = 2 * (size_t)ix->host.synth_genomes;
+            ix->syn_dense.reset(new std::atomic<const char *>[m]);
+            for (size_t i = 0; i < m; i++) ix->syn_dense[i].store(nullptr, std::memory_order_relaxed);
+        }
+    }
     parallel_for((int64_t)n, 4096, [&](int64_t a, int64_t b) {
         for (int64_t i = a; i < b; i++) {
             if (i > a && rows[i].batch_genome == rows[i - 1].batch_genome && rows[i].seq_idx == rows[i - 1].seq_idx) { // a genome's rows are together

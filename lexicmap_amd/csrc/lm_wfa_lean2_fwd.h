@@ -367,13 +367,13 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
             const LP newM = pM[0], newI = pI[0], newD = pD[0];
             const int32_t rowb = used;
             used += (int32_t)span + 1;
-            // entry s/2 = {lo, row offset}; the offset of entry s/2+1 closes the row.  EVERY lane stores the same three words to
-            // the same addresses (one request): restricting it to lane 0 cost six scalar instructions of exec-mask traffic per score
+            // entry s/2 = {lo, row offset}; the offset of entry s/2+1 closes the row - the next step writes it as ITS row offset,
+            // the last row's is written once after the loops.  EVERY lane stores the same two words to the same addresses (one
+            // request): restricting it to lane 0 cost six scalar instructions of exec-mask traffic per score
             hp[0] = lo;
             hp[1] = rowb;
-            hp[3] = used;
             const LP M8 = pM[4], M4 = pM[2], I2 = pI[1], D2 = pD[1]; // rows of s-8, s-4, s-2
-            const int32_t rowk = rowb - lo; // byte of diagonal k: bt[rowk + k] (never negative for a cell of the row)
+            const int32_t rowk = WR_UNIFORM(rowb - lo); // byte of diagonal k: bt[rowk + k] (never negative for a cell of the row)
             int32_t off[NA], vins[NA], vdel[NA];
             // first / last cell inside the DP matrix of each of the three new wavefronts, as slots: lane order is diagonal order, so
             // these are ballots + ff1 / flbit on the scalar unit (none: first = 0xffffffff, last < 0)
@@ -604,7 +604,6 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
             for (int c = 0; c < NC; c++) pM[0][64 * c + 1] = pI[0][64 * c + 1] = pD[0][64 * c + 1] = (RT)RNULL;
             hp[0] = 0; // same offset as the next row
             hp[1] = used;
-            hp[3] = used;
             WR_WAVE_SYNC();
             continue;
         }
@@ -661,6 +660,7 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
             nrec++;
         }
     }
+    hp[3] = used; // the last row's closing offset (score 0: written above)
     if (WIN && status == 0 && WR_BALLOT(bad) != 0ull) status = 3; // not plain ACGT: the result is discarded
     res->qw0 = qw0;
     res->tw0 = tw0;
