@@ -380,6 +380,13 @@ def draw_query(np, synth, rng, seq, wl, as_read=False):
 def main():
     args = parse()
     maybe_spawn(args)
+    # ONE JSON line on stdout, whatever the libraries print: RCCL writes a version banner to stdout when a communicator is made
+    # (lm_comm_init on every rank of an N-GPU run; the single-rank communicator of the shard model).  Everything written to file
+    # descriptor 1 from here on goes to stderr; the line is written to the real stdout at the end.  (After maybe_spawn: the
+    # ranks it starts must inherit the real stdout.)
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -1223,7 +1230,7 @@ def main():
     if tmpdir and gpu_built:
         shutil.rmtree(tmpdir, ignore_errors=True)
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        print(json.dumps(result), file=real_stdout, flush=True)
     if comm is not None:
         comm.close()
     if world > 1:
