@@ -1,6 +1,7 @@
 // lm_format.cpp — see lm_format.h
 #include "lm_format.h"
 
+#include <chrono>
 #include <algorithm>
 #include <atomic>
 #include <thread>
@@ -457,6 +458,10 @@ std::string load_index_genomes(const std::string &dir, HostIndex &out, int &stat
         return "failed to read " + dir + "/genomes.map.bin";
     }
     int64_t global = 0, run = 0; // run: bytes of the store so far when a sink takes the bases
+    // (LM_DEBUG: where the reader's time goes - the reads into its buffer, the records handed to the sink, the waits for the sink)
+    const bool rdbg = getenv("LM_DEBUG") != nullptr;
+    double t_read = 0, t_sink = 0, t_end = 0, t_idx = 0;
+    auto nowms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const bool to_sink = (bool)out.gbits_sink;
     if (!to_sink) out.gbits.reserve(out.gbits_bound);
     // A batch file (GBs) is read in RUNS of consecutive records of at most ~256 MB into one reused buffer (the loader: pinned
@@ -518,7 +523,10 @@ std::string load_index_genomes(const std::string &dir, HostIndex &out, int &stat
                     if (own.size() < want + 16) own.resize(want + 16);
                     gb = own.data();
                 }
-                if (!gb || !pread_all_mt(fd.fd, gb, want, o0)) {
+                const double tr0 = nowms();
+                const bool read_ok = gb && pread_all_mt(fd.fd, gb, want, o0);
+                t_read += nowms() - tr0;
+                if (!read_ok) {
                     status = 1;
                     return std::string("genome data: cannot read ") + name;
                 }
@@ -588,7 +596,10 @@ std::string load_index_genomes(const std::string &dir, HostIndex &out, int &stat
                     }
                     if (to_sink) { // (same offsets as the host store: 8 .. 15 bytes of padding behind every genome)
                         g.bits_off = run;
-                        if (!out.gbits_sink(gb + p, nbytes, run)) {
+                        const double ts0 = rdbg ? nowms() : 0;
+                        const bool sunk = out.gbits_sink(gb + p, nbytes, run);
+                        if (rdbg) t_sink += nowms() - ts0;
+                        if (!sunk) {
                             status = 2;
                             return std::string("genome data: the packed bases of ") + name + " exceed what the batch indexes announced";
                         }
@@ -602,7 +613,11 @@ std::string load_index_genomes(const std::string &dir, HostIndex &out, int &stat
                     }
                     out.genomes.push_back(std::move(g));
                 }
-                if (out.gbits_batch_end) out.gbits_batch_end(); // (the buffer is read into again)
+                {
+                    const double te0 = nowms();
+                    if (out.gbits_batch_end) out.gbits_batch_end(); // (the buffer is read into again)
+                    t_end += nowms() - te0;
+                }
                 if (!again) {
                     if (global != global0 + (int64_t)(r1 - r0)) { // a record ended before its fields did
                         status = 2;
@@ -624,6 +639,10 @@ std::string load_index_genomes(const std::string &dir, HostIndex &out, int &stat
             r0 = r1;
         }
     }
+    if (rdbg)
+        fprintf(stderr, "[lm] genome reader: %.0f ms reading runs into the buffer, %.0f ms handing %zu records to the sink, %.0f ms waiting for the sink at the end of a run\n",
+                t_read, t_sink, out.genomes.size(), t_end);
+    (void)t_idx;
     out.gbits_total = to_sink ? run : (int64_t)out.gbits.size();
 
     return "";

@@ -177,7 +177,11 @@ void lm_set_scratch_budget(lm_index *ix) {
     // A production-size index cuts its lane slabs NOW, as part of opening it (hipMalloc of ~100 GB clears pages for seconds:
     // 2.4 s of the first C3 step when it was done there); a small index (tests, stage calls, several shard handles on one
     // device) leaves it to its first search.
-    if (ix->hbm_bytes >= ((int64_t)4 << 30)) lm_reserve_lane_slabs(ix);
+    if (ix->hbm_bytes >= ((int64_t)4 << 30)) {
+        const double t0 = lm::now_ms();
+        lm_reserve_lane_slabs(ix);
+        if (getenv("LM_DEBUG")) fprintf(stderr, "[lm] the lane slabs were cut in %.0f ms (part of opening a production-size index)\n", lm::now_ms() - t0);
+    }
 }
 void lm_reserve_lane_slabs(lm_index *ix) {
     if (ix->tune.arena_reserve_pct <= 0 || ix->lane_slabs.asked || ix->scratch_budget <= 0) return;
@@ -1005,6 +1009,7 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
         // afterwards was 8 s of a 9.7-s open once the seed passes took 4.3 s).
         ix->d_gbits.alloc_exact(h.gbits_bound + 64, true, S(ix)); // zero-filled: the padding behind every genome
         sync(ix);
+        if (getenv("LM_DEBUG")) fprintf(stderr, "[lm] loader: the genome store (%.1f GB, zero-filled) was allocated in %.0f ms\n", (double)h.gbits_bound / 1e9, now_ms() - t_g0);
         struct GenomeSink {
             hipStream_t st = nullptr;
             uint8_t *pinned = nullptr; // the reader's buffer (grow-only)
@@ -1116,6 +1121,7 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
             const bool ldbg = getenv("LM_DEBUG") != nullptr;
             double t_wait = 0, t_pin = 0, t_pack = 0;
             const double t_seeds0 = now_ms();
+            if (ldbg) fprintf(stderr, "[lm] loader: the seed passes start %.0f ms after the genome reader\n", t_seeds0 - t_g0);
             std::vector<std::unique_ptr<Slot>> slot(nslots); // (both passes use the same slots: warm pages, registered once)
             for (auto &sl : slot) {
                 sl.reset(new Slot());
@@ -1297,6 +1303,7 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
         std::vector<uint8_t>().swap(h.gbits);
         ix->tmp.release();
         lm_set_scratch_budget(ix);
+        if (getenv("LM_DEBUG")) fprintf(stderr, "[lm] loader: done %.0f ms after the genome reader started\n", now_ms() - t_g0);
     } catch (const std::exception &e) {
         g_open_error = e.what();
         lm_index_close(ix);
