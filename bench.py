@@ -94,7 +94,7 @@ def parse():
                         "generator, written by lm_index_save, opened by the oracle RAM-resident), e.g. 1250,5000; auto: two sizes "
                         "whose RAM-resident seeds fit the host; 0: skip")
     p.add_argument("--ab", default="", help="development: after the timed steps, time the same resident batch under other "
-                   "experiment switches, e.g. 'LM_WFA_R16=0|LM_WFA_MW=0 LM_WFA_R16=0' (variants separated by |, one warm-up + "
+                   "experiment switches, e.g. 'LM_WFA_R16=0|LM_TWO_LANES=0 LM_WFA_R16=0' (variants separated by |, one warm-up + "
                    "--ab-steps steps each; reported under 'ab', not part of the metric)")
     p.add_argument("--ab-steps", type=int, default=2)
     return p.parse_args()

@@ -404,7 +404,6 @@ struct lm_tune {
     int two_lanes = 1;       // two parts of a batch searched side by side, each with half of the scratch budget (LM_TWO_LANES=0: one after the other)
     int lookup_flat = 1;     // anchors emitted with the lanes over the output (k_lookup_emit_flat); LM_LOOKUP_FLAT=0: one lane per lookup
     int wfa_r16 = 1;         // 16-bit ring cells in the whole-sequence WFA kernels of 128 / 256 diagonals (LM_WFA_R16=0: 32-bit)
-    int wfa_mw = 1;          // 512 / 1024-diagonal passes by a workgroup of four wavefronts per alignment (LM_WFA_MW=0: one wavefront)
     int wfa_serial = 0;      // the WFA length classes one after the other (lm_profile_exclusive: exclusive kernel timings)
     int no_pipeline = 0;     // no pseudo-alignment producer beside extend / WFA (lm_profile_exclusive)
     lm_tune() {
@@ -416,7 +415,6 @@ struct lm_tune {
         }
         if (const char *e = getenv("LM_WFA_WIN"))
             for (int c = 0; c < LM_WFA_CLASSES && e[c]; c++) wfa_win[c] = e[c] == '1';
-        if (const char *e = getenv("LM_WFA_MW")) wfa_mw = atoi(e) != 0;
         if (const char *e = getenv("LM_WFA_R16")) wfa_r16 = atoi(e) != 0;
         if (const char *e = getenv("LM_LOOKUP_FLAT")) lookup_flat = atoi(e) != 0;
         if (const char *e = getenv("LM_TWO_LANES")) two_lanes = atoi(e) != 0;

@@ -147,13 +147,7 @@ bool wfa_r16_ok(int seq_words, int nc, bool win);
 void launch_wfa(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks,
                 int32_t *hdr_pool, int64_t hdr_stride, uint8_t *arena_pool, int64_t arena_stride, uint64_t *ops_pool,
                 unsigned int *queue, int seq_words, int want_ops, WfaOut *out, int nc, bool win, bool r16 = false,
-                unsigned long long *dbg = nullptr); // dbg: 6 words per workgroup (LM_DEBUG_WFA_WAVES); lean2: k_wfa_lean2
-
-// k_wfa_mw<nc / 4, win>: the same passes for nc = 8 / 16 by a workgroup of four wavefronts per alignment
-int wfa_mw_resident_blocks(int device, int seq_words, int nc, bool win);
-void launch_wfa_mw(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int nblocks, int32_t *hdr_pool,
-                   int64_t hdr_stride, uint8_t *arena_pool, int64_t arena_stride, uint64_t *ops_pool, unsigned int *queue, int seq_words,
-                   int want_ops, WfaOut *out, int nc, bool win);
+                unsigned long long *dbg = nullptr); // (dbg: unused)
 
 // wavefronts wider than the LDS ring (status 3 from launch_wfa): same algorithm with the ring in global memory
 void launch_wfa_wide(hipStream_t st, const WfaIn *in, int64_t n, const int32_t *todo, int64_t ntodo, int32_t *hdr_pool,

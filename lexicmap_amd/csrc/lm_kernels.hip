@@ -2526,14 +2526,13 @@ __device__ __forceinline__ void bt_replay(const uint8_t *__restrict__ opseq, int
 }
 
 // ---- the LDS wavefront kernels -----------------------------------------------------------------------------------------
-// k_wfa_lean2<NC, RT, WIN> (lm_wfa_lean2.h: one wavefront per alignment, 64 * NC diagonals) and k_wfa_mw2<NCW, WIN>
-// (lm_wfa_mw2.h: a workgroup of four wavefronts per long alignment).  Persistent: each workgroup owns a private header / arena
-// region and pops problems from a queue ordered by decreasing expected cost; a ring that turns out too narrow returns status 3
-// and the next width takes the problem (... -> k_wfa_wave, the global-memory ring).  Results are identical to lm_wfa_align.
-// (Their predecessors k_wfa_lean / k_wfa_mw - a wrapping ring, five DPP range reductions and three LDS hand-offs per score -
-// were measured against them on one resident C3 index in round 5, 12.1 against 9.85 s per step, and removed.)
+// k_wfa_lean2<NC, RT, WIN> (lm_wfa_lean2.h: one wavefront per alignment, 64 * NC diagonals).  Persistent: each wavefront owns a
+// private header / arena region and pops problems from a queue ordered by decreasing expected cost; a ring that turns out too
+// narrow returns status 3 and the next width takes the problem (... -> k_wfa_wave, the global-memory ring).  Results are
+// identical to lm_wfa_align.  (Removed after their A/B: k_wfa_lean / k_wfa_mw - a wrapping ring, five DPP range reductions and
+// three LDS hand-offs per score - in round 5; k_wfa_mw2, four wavefronts per long alignment, in round 6: lm_wfa_dev.h.)
 
-#include "lm_wfa_mw.h"
+#include "lm_wfa_dev.h"
 
 // ------------------------------------------------------------------------------------------------------------
 // host-callable launchers

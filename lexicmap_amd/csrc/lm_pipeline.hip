@@ -2087,11 +2087,9 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
                                int64_t lmax, int64_t s_expect, std::vector<int32_t> &too_wide, int nc) {
         const int64_t m = (int64_t)items.size();
         if (m == 0) return;
-        // the 512 / 1024-diagonal passes are a handful of long alignments the round waits for: a workgroup of four wavefronts each
-        const bool mw = ix->tune.wfa_mw && nc >= 8;
-        const bool r16 = !mw && ix->tune.wfa_r16 && wfa_r16_ok(seq_words, nc, use_win); // 16-bit ring cells: more wavefronts per CU
-        const int resident = mw ? wfa_mw_resident_blocks(ix->device, seq_words, nc, use_win) : wfa_resident_blocks(ix->device, seq_words, nc, use_win, r16);
-        int nblocks = (int)std::min<int64_t>(m, std::max<int64_t>(mw ? 1 : 256, (int64_t)resident * ix->tune.wfa_resident_pct / 100));
+        const bool r16 = ix->tune.wfa_r16 && wfa_r16_ok(seq_words, nc, use_win); // 16-bit ring cells: more wavefronts per CU
+        const int resident = wfa_resident_blocks(ix->device, seq_words, nc, use_win, r16);
+        int nblocks = (int)std::min<int64_t>(m, std::max<int64_t>(256, (int64_t)resident * ix->tune.wfa_resident_pct / 100));
         // private scratch per resident wave: one backtrace byte per wavefront cell + 8 bytes per even score; never
         // more than the longest problem of the class is expected to need
         const int64_t smax = std::min<int64_t>(8 * lmax + 64, s_expect); // a global alignment never exceeds 8 per base
@@ -2111,17 +2109,11 @@ static void run_wfa(AlignCtx &a, std::vector<WfaIn> &in, std::vector<WfaOut> &ou
         HIPCHK(hipMemcpyAsync(lc.todo.p, items.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice, S(ix)));
         HIPCHK(hipMemsetAsync(lc.queue.p, 0, sizeof(unsigned int), S(ix)));
         {
-            static const char *const names[4][5] = {{"k_wfa_lean64", "k_wfa_lean", "k_wfa_lean256", "k_wfa_lean512", "k_wfa_lean1024"},
-                                                    {"k_wfa_win64", "k_wfa_win128", "k_wfa_win256", "k_wfa_win512", "k_wfa_win1024"},
-                                                    {"", "", "", "k_wfa_mw512", "k_wfa_mw1024"},
-                                                    {"", "", "", "k_wfa_mww512", "k_wfa_mww1024"}};
-            Prof p(ix, names[mw ? (use_win ? 3 : 2) : use_win ? 1 : 0][nc == 16 ? 4 : nc == 8 ? 3 : nc == 4 ? 2 : nc == 1 ? 0 : 1], wfa_bytes(in, items));
-            if (mw)
-                launch_wfa_mw(S(ix), a.wfa_in.p, n, lc.todo.p, m, nblocks, lc.hdr_pool.p, entries * 2, (uint8_t *)lc.arena_pool.p, bytes,
-                              a.ops_pool.p, lc.queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc, use_win);
-            else
-                launch_wfa(S(ix), a.wfa_in.p, n, lc.todo.p, m, nblocks, lc.hdr_pool.p, entries * 2, (uint8_t *)lc.arena_pool.p, bytes,
-                           a.ops_pool.p, lc.queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc, use_win, r16, nullptr);
+            static const char *const names[2][5] = {{"k_wfa_lean64", "k_wfa_lean", "k_wfa_lean256", "k_wfa_lean512", "k_wfa_lean1024"},
+                                                    {"k_wfa_win64", "k_wfa_win128", "k_wfa_win256", "k_wfa_win512", "k_wfa_win1024"}};
+            Prof p(ix, names[use_win ? 1 : 0][nc == 16 ? 4 : nc == 8 ? 3 : nc == 4 ? 2 : nc == 1 ? 0 : 1], wfa_bytes(in, items));
+            launch_wfa(S(ix), a.wfa_in.p, n, lc.todo.p, m, nblocks, lc.hdr_pool.p, entries * 2, (uint8_t *)lc.arena_pool.p, bytes,
+                       a.ops_pool.p, lc.queue.p, seq_words, want_ops ? 1 : 0, a.wfa_out.p, nc, use_win, r16, nullptr);
         }
         sync(ix);
         // this pass's results: the records of its items (other classes write theirs into the same array meanwhile)

@@ -1,7 +1,7 @@
 // lm_wfa_lean2.h - device side of wfa_lean2_fwd.h : k_wfa_lean2<NC, RT, WIN>,
 // the single-wavefront WFA kernel (persistent wavefronts over a queue; the sequences 2-bit packed in LDS, whole or through sliding windows;
 // bt_walk / bt_replay of lm_kernels.hip) with the forward pass of lm_wfa_lean2_fwd.h.  8 * seq_words + 20 bytes of dynamic LDS for the
-// whole-sequence form.  Included by lm_wfa_mw.h (whose WR_* macros it shares) inside namespace lm.  It replaced k_wfa_lean in
+// whole-sequence form.  Included by lm_wfa_dev.h (whose WR_* macros it uses) inside namespace lm.  It replaced k_wfa_lean in
 // round 5 (C3 12.1 -> 9.85 s per step on one resident index); the forward pass is also checked on the host SIMT emulator.
 #pragma once
 

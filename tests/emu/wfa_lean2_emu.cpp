@@ -101,6 +101,7 @@ extern "C" long l2_emu_run(int nc, int r16, int win, const uint8_t *q, int qlen,
         case 2: return run1<2, int32_t, true>(q, qlen, t, tlen, max_score, arena_cap, ops, ops_cap, out, recentres);
         case 4: return run1<4, int32_t, true>(q, qlen, t, tlen, max_score, arena_cap, ops, ops_cap, out, recentres);
         case 8: return run1<8, int32_t, true>(q, qlen, t, tlen, max_score, arena_cap, ops, ops_cap, out, recentres);
+        case 16: return run1<16, int32_t, true>(q, qlen, t, tlen, max_score, arena_cap, ops, ops_cap, out, recentres);
         default: return -1;
         }
     switch (nc * 2 + (r16 ? 1 : 0)) {
@@ -111,6 +112,7 @@ extern "C" long l2_emu_run(int nc, int r16, int win, const uint8_t *q, int qlen,
     case 8: return run1<4, int32_t>(q, qlen, t, tlen, max_score, arena_cap, ops, ops_cap, out, recentres);
     case 9: return run1<4, int16_t>(q, qlen, t, tlen, max_score, arena_cap, ops, ops_cap, out, recentres);
     case 16: return run1<8, int32_t>(q, qlen, t, tlen, max_score, arena_cap, ops, ops_cap, out, recentres);
+    case 32: return run1<16, int32_t>(q, qlen, t, tlen, max_score, arena_cap, ops, ops_cap, out, recentres);
     }
     return -1;
 }

@@ -130,8 +130,7 @@ def test_batch_split_into_parts_gives_the_same_rows(lr_index, lr_queries, monkey
 
 
 def test_rows_do_not_depend_on_which_device_implementation_of_a_stage_runs(lr_index, lr_queries, monkeypatch):
-    """LM_WFA_MW (512 / 1024-diagonal WFA passes: a workgroup of four wavefronts or one wavefront per alignment), LM_OCC8 (the
-    register cap of the two kernels it applies to), LM_WFA_R16 (16- or 32-bit ring cells in the short WFA classes), LM_LOOKUP_FLAT
+    """LM_WFA_R16 (16- or 32-bit ring cells in the short WFA classes), LM_LOOKUP_FLAT
     (seed anchors emitted with the lanes over the output or over the lookups), LM_PA_FILTER_ROLL (window positions consecutive
     per lane or strided) and LM_ARENA_RESERVE_PCT (lane slabs or slabs on demand) choose between device paths that must agree
     to the byte: the rows of the long-read fixture (equal to the oracle's by the first test) with each switch flipped"""
@@ -143,8 +142,8 @@ def test_rows_do_not_depend_on_which_device_implementation_of_a_stage_runs(lr_in
     base, st0 = gi.search(seqs)
     ran = {p["name"] for p in gi.profile_get() if p["launches"] > 0}
     gi.close()
-    assert any(n.startswith("k_wfa_mw") for n in ran), ran   # the fixture does reach the wide passes
-    for var, off in (("LM_WFA_MW", "0"), ("LM_WFA_R16", "0"),
+    assert any(n in ("k_wfa_lean512", "k_wfa_win512", "k_wfa_lean1024", "k_wfa_win1024") for n in ran), ran   # the fixture does reach the wide passes
+    for var, off in (("LM_WFA_R16", "0"), ("LM_SCRATCH_BUDGET_MB", "3072"),
                      ("LM_LOOKUP_FLAT", "0"), ("LM_PA_FILTER_ROLL", "0"), ("LM_ARENA_RESERVE_PCT", "0")):
         monkeypatch.setenv(var, off)
         gi = la.Index(d)      # the switches are read once per handle
@@ -155,8 +154,6 @@ def test_rows_do_not_depend_on_which_device_implementation_of_a_stage_runs(lr_in
         monkeypatch.delenv(var)
         assert got == base, var
         assert st0["rows"] == st1["rows"] and st0["chains"] == st1["chains"] and st0["pa_anchors"] == st1["pa_anchors"]
-        if var == "LM_WFA_MW":
-            assert not any(n.startswith("k_wfa_mw") for n in ran1), ran1
 
 
 def test_many_small_rounds_give_the_rows_of_one_round(lr_index, lr_queries, monkeypatch):

@@ -1,4 +1,4 @@
-"""GPU parity of k_wfa_lean2 / k_wfa_mw2 (the LDS wavefront kernels): every instantiation forced through lm_wfa_batch against
+"""GPU parity of k_wfa_lean2 (the LDS wavefront kernel): every instantiation forced through lm_wfa_batch against
 the oracle's lmo_wfa_align - ring widths 64-1024 diagonals, 16- and 32-bit cells, whole sequences and sliding windows, drifting
 wavefronts (the ring is recentred), pairs that outgrow a ring.  The pairs and the checks: tests/wfa_lean2_gpu_check.py."""
 import importlib.util

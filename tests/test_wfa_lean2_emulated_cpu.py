@@ -192,3 +192,24 @@ def test_the_first_touch_of_a_sequence_end_is_the_end():
         exp = run_oracle_wfa(q, t)
         for nc, r16, win in ((1, False, False), (2, True, False), (2, False, True), (4, True, False)):
             assert run1(q, t, nc, r16, win=win)[:2] == (0, exp)
+
+
+@pytest.mark.parametrize("nc,win,n,extra,seed", [(8, False, 3000, 330, 41), (8, True, 5000, -400, 42), (16, False, 2500, 700, 43), (16, True, 6000, -820, 44),
+                                                  (8, False, 2500, 0, 45), (16, True, 2200, 30, 46)])
+def test_wide_rings_run_in_their_flavours(nc, win, n, extra, seed):
+    """512 / 1024 diagonals by one wavefront (round 6: the workgroup kernels are gone).  The hot loop exists per flavour - chunks
+    0 .. NA-1 of the frame, NA in {2, 4, 8} / {4, 8, 16} - and the rows move between them as the wavefront widens towards a far
+    final diagonal (|tlen - qlen| of 330-820) and narrows again behind it; narrow pairs stay in the smallest flavour."""
+    rng = random.Random(seed)
+    q = rand_seq(rng, n)
+    t = mutate(rng, q, 0.03, 0.01, 0.01)
+    if extra > 0:
+        t = t + rand_seq(rng, extra)
+    elif extra < 0:
+        q = q + rand_seq(rng, -extra)
+    exp = run_oracle_wfa(q, t)
+    assert exp[0] == 0
+    st, got, nrec = run1(q, t, nc, False, win=win, max_score=40000)
+    assert st == 0 and got == exp
+    if abs(extra) > 128 * (nc // 8):
+        assert nrec >= 1   # the frame was re-cut at least once on the way

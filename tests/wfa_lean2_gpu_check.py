@@ -1,11 +1,11 @@
-"""wfa_lean2_gpu_check.py - the forced-path check of k_wfa_lean2 / k_wfa_mw2 (lexicmap_amd/csrc/lm_wfa_lean2.h, lm_wfa_mw2.h): every
+"""wfa_lean2_gpu_check.py - the forced-path check of k_wfa_lean2 (lexicmap_amd/csrc/lm_wfa_lean2.h): every
 instantiation forced through lm_wfa_batch (la.Index.wfa) against the oracle's lmo_wfa_align, plus the time of two class-shaped
 batches.  tests/test_gpu_wfa_lean2.py runs main(timing=False).
 
     python tests/wfa_lean2_gpu_check.py            (on the GPU box, from the repository root: with the timing batches)
 
 Pairs: gene-sized (<= 2 kb: 128 diagonals, 16-bit cells), 2-8 kb (128 / 256 diagonals, 16-bit cells up to 12 000 bases), 8-32
-kb (windowed, 256 diagonals), 32-65 kb (whole sequences, 512: workgroup passes unless LM_WFA_MW=0), beyond 65 kb (windowed);
+kb (windowed, 256 diagonals), 32-65 kb (whole sequences, 512 / 1024 diagonals), beyond 65 kb (windowed);
 divergence 1-15 %; one-sided indels (the ring is recentred); length differences that outgrow 128 / 256 diagonals (status 3 ->
 next width); LM_WFA_FIRST_NC=1,1,1,1,1 to run the 64-diagonal kernels too."""
 import ctypes as C
@@ -65,13 +65,13 @@ def main(timing=True):
     pairs += [pair(rng, 3000, 0.05, 0.02, 0.02, extra=150), pair(rng, 3000, 0.05, 0.02, 0.02, extra=-300)]            # outgrow 128 / 256
     pairs += [pair(rng, 12000, 0.02, 0.02, 0.03), pair(rng, 25000, 0.02, 0.02, 0.03), pair(rng, 30000, 0.03, 0.01, 0.05)]  # windowed
     pairs += [pair(rng, 40000, 0.02, 0.02, 0.03), pair(rng, 70000, 0.02, 0.02, 0.03)]
-    # the workgroup passes (k_wfa_mw2): final diagonals 300-700 away - 512 / 1024 diagonals, windowed (8-32 kb) and whole (32-65 kb)
+    # the wide passes: final diagonals 300-700 away - 512 / 1024 diagonals, windowed (8-32 kb) and whole (32-65 kb)
     pairs += [pair(rng, 20000, 0.02, 0.02, 0.02, extra=400), pair(rng, 26000, 0.02, 0.02, 0.02, extra=-450), pair(rng, 30000, 0.02, 0.02, 0.02, extra=650),
               pair(rng, 36000, 0.02, 0.02, 0.02, extra=380), pair(rng, 44000, 0.02, 0.02, 0.02, extra=-640)]
     total_bad = 0
     report = {}
-    for env in ({}, {"LM_WFA_FIRST_NC": "1,1,1,1,1"}, {"LM_WFA_MW": "0"}, {"LM_WFA_R16": "0"}, {"LM_WFA_WIN": "11111"}, {"LM_WFA_WIN": "00000"}):
-        for k in ("LM_WFA_FIRST_NC", "LM_WFA_MW", "LM_WFA_R16", "LM_WFA_WIN"):
+    for env in ({}, {"LM_WFA_FIRST_NC": "1,1,1,1,1"}, {"LM_WFA_R16": "0"}, {"LM_WFA_WIN": "11111"}, {"LM_WFA_WIN": "00000"}):
+        for k in ("LM_WFA_FIRST_NC", "LM_WFA_R16", "LM_WFA_WIN"):
             os.environ.pop(k, None)
         os.environ.update(env)
         gi = la.Index(d)
@@ -87,7 +87,7 @@ def main(timing=True):
     timing_s = {}
     for label, batch in () if not timing else (("genes_1500bp_x8192", [pair(rng, 1500, 0.05, 0.02, 0.02) for _ in range(256)] * 32),
                          ("reads_5kb_x512", [pair(rng, 5000, 0.03, 0.02, 0.03) for _ in range(64)] * 8)):
-        for k in ("LM_WFA_FIRST_NC", "LM_WFA_MW", "LM_WFA_R16", "LM_WFA_WIN"):
+        for k in ("LM_WFA_FIRST_NC", "LM_WFA_R16", "LM_WFA_WIN"):
             os.environ.pop(k, None)
         gi = la.Index(d)
         gi.wfa(batch[:64])
@@ -95,11 +95,11 @@ def main(timing=True):
         gi.wfa(batch)
         timing_s[label] = round(time.time() - t0, 4)
         gi.close()
-    for k in ("LM_WFA_FIRST_NC", "LM_WFA_MW", "LM_WFA_R16", "LM_WFA_WIN"):
+    for k in ("LM_WFA_FIRST_NC", "LM_WFA_R16", "LM_WFA_WIN"):
         os.environ.pop(k, None)
     print(json.dumps({"report": report, "seconds": timing_s}, indent=1))
     os.makedirs("gpurun_out", exist_ok=True)
-    json.dump({"report": report, "seconds": timing_s}, open("gpurun_out/r05_wfa_lean2_check.json", "w"), indent=1)
+    json.dump({"report": report, "seconds": timing_s}, open("gpurun_out/r06_wfa_lean2_check.json", "w"), indent=1)
     return total_bad, report
 
 
