@@ -21,8 +21,8 @@ H=$(python -c "import bench; print(bench.source_hash())")
 echo "workload $W, sources $H"
 cd /tmp
 rm -rf /tmp/prof_ks /tmp/prof_f /tmp/prof_w /tmp/prof_sq
-timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -o ks -- python $R/bench.py --workload $W --steps $STEPS --warmup 1 --no-cpu-baseline --no-exclusive-step $EXTRA > /tmp/prof_ks.log 2>&1
-python $R/tools/summarize_rocprof.py /tmp/prof_ks $R/gpurun_out/${P}_${W}_kernel_stats.json $H "rocprofv3 --kernel-trace --stats -- python bench.py --workload $W --steps $STEPS --warmup 1 --no-cpu-baseline --no-exclusive-step $EXTRA"
+timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -o ks -- python $R/bench.py --workload $W --steps $STEPS --warmup 2 --no-cpu-baseline --no-exclusive-step $EXTRA > /tmp/prof_ks.log 2>&1
+python $R/tools/summarize_rocprof.py /tmp/prof_ks $R/gpurun_out/${P}_${W}_kernel_stats.json $H "rocprofv3 --kernel-trace --stats -- python bench.py --workload $W --steps $STEPS --warmup 2 --no-cpu-baseline --no-exclusive-step $EXTRA"
 for f in $(find /tmp/prof_ks -name "*kernel_stats.csv"); do python - "$f" "$R/gpurun_out/${P}_${W}_kernel_stats.csv" <<'PY'
 import csv, sys
 rows = list(csv.reader(open(sys.argv[1])))
@@ -32,12 +32,12 @@ for r in rows:
     w.writerow(r)
 PY
 done
-timeout 1500 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_f -o f -- python $R/bench.py --workload $W --steps 1 --warmup 1 --no-cpu-baseline --no-exclusive-step $EXTRA > /tmp/prof_f.log 2>&1
-python $R/tools/summarize_rocprof.py /tmp/prof_f $R/gpurun_out/${P}_${W}_pmc_fetch.json $H "rocprofv3 --pmc FETCH_SIZE -- python bench.py --workload $W --steps 1 --warmup 1 --no-cpu-baseline --no-exclusive-step $EXTRA" | tail -12
-timeout 1500 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_w -o w -- python $R/bench.py --workload $W --steps 1 --warmup 1 --no-cpu-baseline --no-exclusive-step $EXTRA > /tmp/prof_w.log 2>&1
-python $R/tools/summarize_rocprof.py /tmp/prof_w $R/gpurun_out/${P}_${W}_pmc_write.json $H "rocprofv3 --pmc WRITE_SIZE -- python bench.py --workload $W --steps 1 --warmup 1 --no-cpu-baseline --no-exclusive-step $EXTRA" | tail -12
-timeout 1500 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d /tmp/prof_sq -o sq -- python $R/bench.py --workload $W --steps 1 --warmup 1 --no-cpu-baseline --no-exclusive-step $EXTRA > /tmp/prof_sq.log 2>&1
-python $R/tools/summarize_rocprof.py /tmp/prof_sq $R/gpurun_out/${P}_${W}_pmc_sq.json $H "rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -- python bench.py --workload $W --steps 1 --warmup 1 --no-cpu-baseline --no-exclusive-step $EXTRA" | grep -E "^k_(wfa|pa_|extend|lookup|chain)"
+timeout 1500 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_f -o f -- python $R/bench.py --workload $W --steps 1 --warmup 2 --no-cpu-baseline --no-exclusive-step $EXTRA > /tmp/prof_f.log 2>&1
+python $R/tools/summarize_rocprof.py /tmp/prof_f $R/gpurun_out/${P}_${W}_pmc_fetch.json $H "rocprofv3 --pmc FETCH_SIZE -- python bench.py --workload $W --steps 1 --warmup 2 --no-cpu-baseline --no-exclusive-step $EXTRA" | tail -12
+timeout 1500 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_w -o w -- python $R/bench.py --workload $W --steps 1 --warmup 2 --no-cpu-baseline --no-exclusive-step $EXTRA > /tmp/prof_w.log 2>&1
+python $R/tools/summarize_rocprof.py /tmp/prof_w $R/gpurun_out/${P}_${W}_pmc_write.json $H "rocprofv3 --pmc WRITE_SIZE -- python bench.py --workload $W --steps 1 --warmup 2 --no-cpu-baseline --no-exclusive-step $EXTRA" | tail -12
+timeout 1500 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d /tmp/prof_sq -o sq -- python $R/bench.py --workload $W --steps 1 --warmup 2 --no-cpu-baseline --no-exclusive-step $EXTRA > /tmp/prof_sq.log 2>&1
+python $R/tools/summarize_rocprof.py /tmp/prof_sq $R/gpurun_out/${P}_${W}_pmc_sq.json $H "rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -- python bench.py --workload $W --steps 1 --warmup 2 --no-cpu-baseline --no-exclusive-step $EXTRA" | grep -E "^k_(wfa|pa_|extend|lookup|chain)"
 tail -n 2 /tmp/prof_f.log /tmp/prof_w.log /tmp/prof_sq.log
 # the passes of THESE sources where bench.py looks for them, then the bench line
 cp $R/gpurun_out/${P}_${W}_pmc_fetch.json $R/gpurun_out/${P}_${W}_pmc_write.json $R/gpurun_out/${P}_${W}_pmc_sq.json $R/profiles/
