@@ -322,22 +322,47 @@ lm_status lm_gather_rows(lm_comm *c, const lm_hsp *rows, size_t n, int root, con
     return LM_OK;
 }
 
+// the handle's idle scratch slabs as the allocator of one merge (lm_merge.h)
+static void *borrow_cb(void *ctx, size_t bytes) { return lm_scratch_borrow((lm_index *)ctx, bytes); }
+static void return_cb(void *ctx, void *p) { lm_scratch_return((lm_index *)ctx, p); }
+
 // rows of all shards in device memory, rank order -> the final order in the communicator's pinned buffer (lm_merge.hip + one
-// download + the names); the caller holds c->mu
+// download + the names); the caller holds c->mu and, when idx is given, the handle's scratch session (the buffers of the merge
+// are then borrowed from the handle's scratch slabs)
 static lm_status merge_on_device(lm_comm *c, lm_index *idx, const lm_hsp *d_rows, const int64_t *off, int N, const lm_hsp **merged, size_t *total_out) {
     const size_t total = (size_t)off[N], item = sizeof(lm_hsp);
-    lm_status s = grow_dev(c, &c->d_merged, &c->merged_cap, total * item);
+    lm_status s = grow_host(c, &c->h_merged, &c->hmerged_cap, total * item);
     if (s != LM_OK) return s;
-    s = grow_host(c, &c->h_merged, &c->hmerged_cap, total * item);
-    if (s != LM_OK) return s;
+    lm_hsp *d_out = nullptr;
+    if (idx) {
+        c->ms.borrow = borrow_cb;
+        c->ms.give_back = return_cb;
+        c->ms.ctx = idx;
+        d_out = (lm_hsp *)c->ms.take(total * item);
+        if (!d_out) {
+            c->ms.end_call();
+            c->err = "the merge's buffers do not fit the index handle's scratch";
+            return LM_ERR_NOMEM;
+        }
+    } else {
+        s = grow_dev(c, &c->d_merged, &c->merged_cap, total * item);
+        if (s != LM_OK) return s;
+        d_out = (lm_hsp *)c->d_merged;
+    }
     const bool dbg = getenv("LM_DEBUG") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
-    CK_HIP(c, lm::merge_rows_device(c->st, d_rows, total, off, N, (lm_hsp *)c->d_merged, c->ms));
-    if (dbg) CK_HIP(c, hipStreamSynchronize(c->st));
+    hipError_t e = lm::merge_rows_device(c->st, d_rows, total, off, N, d_out, c->ms);
+    if (e == hipSuccess && dbg) e = hipStreamSynchronize(c->st);
     const double t1 = now();
-    CK_HIP(c, hipMemcpyAsync(c->h_merged, c->d_merged, total * item, hipMemcpyDeviceToHost, c->st));
-    CK_HIP(c, hipStreamSynchronize(c->st));
+    if (e == hipSuccess) e = hipMemcpyAsync(c->h_merged, d_out, total * item, hipMemcpyDeviceToHost, c->st);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->st);
+    else (void)hipStreamSynchronize(c->st);
+    c->ms.end_call(); // (borrowed buffers go back to the handle whatever happened)
+    if (e != hipSuccess) {
+        c->err = std::string("device merge: ") + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? LM_ERR_NOMEM : LM_ERR_HIP;
+    }
     const double t2 = now();
     lm_attach_names(idx, (lm_hsp *)c->h_merged, total);
     if (dbg)
@@ -387,14 +412,36 @@ lm_status lm_gather_merge_rows(lm_comm *c, lm_index *idx, const lm_hsp *rows, si
         return LM_OK;
     }
     if (total == 0) return LM_OK;
-    s = grow_dev(c, &c->d_all, &c->all_cap, total * item);
-    if (s != LM_OK) return s;
-    if (n > 0) CK_HIP(c, hipMemcpyAsync((char *)c->d_all + (size_t)off[(size_t)root] * item, c->h_send, n * item, hipMemcpyHostToDevice, c->st));
+    // the gathered rows: in the handle's scratch when there is one (idle between two searches), else in a buffer of the communicator
+    struct Session {
+        lm_index *ix;
+        void *blk = nullptr;
+        explicit Session(lm_index *i) : ix(i) {
+            if (ix) lm_scratch_session_begin(ix);
+        }
+        ~Session() {
+            if (ix && blk) lm_scratch_return(ix, blk);
+            if (ix) lm_scratch_session_end(ix);
+        }
+    } session(idx);
+    if (idx) {
+        session.blk = lm_scratch_borrow(idx, total * item);
+        if (!session.blk) {
+            c->err = "the gathered rows do not fit the index handle's scratch";
+            // (the other ranks are sending: receive into nothing is not possible - the job fails, as any error inside a collective)
+            return LM_ERR_NOMEM;
+        }
+    } else {
+        s = grow_dev(c, &c->d_all, &c->all_cap, total * item);
+        if (s != LM_OK) return s;
+    }
+    char *const d_all = idx ? (char *)session.blk : (char *)c->d_all;
+    if (n > 0) CK_HIP(c, hipMemcpyAsync(d_all + (size_t)off[(size_t)root] * item, c->h_send, n * item, hipMemcpyHostToDevice, c->st));
     if (total > n) {
         CK_NCCL(c, r.GroupStart());
         for (int i = 0; i < N; i++) {
             if (i == root || cnt[(size_t)i] == 0) continue;
-            ncclResult_t e = r.Recv((char *)c->d_all + (size_t)off[(size_t)i] * item, (size_t)cnt[(size_t)i] * item, ncclUint8, i, c->comm, c->st);
+            ncclResult_t e = r.Recv(d_all + (size_t)off[(size_t)i] * item, (size_t)cnt[(size_t)i] * item, ncclUint8, i, c->comm, c->st);
             if (e != ncclSuccess) {
                 (void)r.GroupEnd();
                 c->err = std::string("ncclRecv: ") + r.GetErrorString(e);
@@ -403,7 +450,7 @@ lm_status lm_gather_merge_rows(lm_comm *c, lm_index *idx, const lm_hsp *rows, si
         }
         CK_NCCL(c, r.GroupEnd());
     }
-    return merge_on_device(c, idx, (const lm_hsp *)c->d_all, off.data(), N, merged, total_out);
+    return merge_on_device(c, idx, (const lm_hsp *)d_all, off.data(), N, merged, total_out);
 }
 
 // What the merging rank does once the rows have arrived, by itself: `d_rows` = the rows of shard 0, 1, ... back to back IN DEVICE
@@ -421,7 +468,10 @@ lm_status lm_merge_sharded_device(lm_comm *c, lm_index *idx, const void *d_rows,
     for (int i = 0; i < nshards; i++) off[(size_t)i + 1] = off[(size_t)i] + (int64_t)nrows[i];
     if (off[(size_t)nshards] == 0) return LM_OK;
     if (!d_rows) return LM_ERR_ARG;
-    return merge_on_device(c, idx, (const lm_hsp *)d_rows, off.data(), nshards, merged, total_out);
+    if (idx) lm_scratch_session_begin(idx);
+    const lm_status st = merge_on_device(c, idx, (const lm_hsp *)d_rows, off.data(), nshards, merged, total_out);
+    if (idx) lm_scratch_session_end(idx);
+    return st;
 }
 
 } // extern "C"

@@ -115,7 +115,30 @@ __global__ void k_mg_emit(const lm_hsp *__restrict__ rows, int64_t n, const MgKe
         if (e_ != hipSuccess) return e_;    \
     } while (0)
 
-static hipError_t mg_grow(void **p, size_t *cap, size_t need) {
+void *MergeScratch::take(size_t bytes) {
+    if (!borrow || nborrowed >= 16) return nullptr;
+    void *p = borrow(ctx, bytes);
+    if (p) borrowed[nborrowed++] = p;
+    return p;
+}
+void MergeScratch::end_call() {
+    if (!borrow) return;
+    for (int i = 0; i < nborrowed; i++) give_back(ctx, borrowed[i]);
+    nborrowed = 0;
+    void **ps[] = {&head, &gid, &sim, &keys, &keys2, &first, &cnt, &sizes, &hits, &outpos, &tmp, &off};
+    for (void **p : ps) *p = nullptr;
+    for (size_t &c : cap) c = 0;
+    borrow = nullptr;
+    give_back = nullptr;
+    ctx = nullptr;
+}
+static hipError_t mg_grow(MergeScratch &S, void **p, size_t *cap, size_t need) {
+    if (S.borrow) { // (one exact block per buffer and call; a buffer that must grow within the call - tmp - gets a new one)
+        if (need <= *cap && *p) return hipSuccess;
+        *p = S.take(need + 256);
+        *cap = *p ? need + 256 : 0;
+        return *p ? hipSuccess : hipErrorOutOfMemory;
+    }
     if (need <= *cap && *p) return hipSuccess;
     if (*p) (void)hipFree(*p);
     *p = nullptr;
@@ -127,6 +150,10 @@ static hipError_t mg_grow(void **p, size_t *cap, size_t need) {
 }
 
 void MergeScratch::release() {
+    if (borrow) {
+        end_call();
+        return;
+    }
     void **ps[] = {&head, &gid, &sim, &keys, &keys2, &first, &cnt, &sizes, &hits, &outpos, &tmp, &off};
     for (void **p : ps) {
         if (*p) (void)hipFree(*p);
@@ -141,34 +168,34 @@ hipError_t merge_rows_device(hipStream_t st, const lm_hsp *d_rows, size_t n, con
     if (n == 0) return hipSuccess;
     if (n >= ((size_t)1 << 32)) return hipErrorInvalidValue;
     const int64_t N = (int64_t)n;
-    MG_HIP(mg_grow(&S.head, &S.cap[0], n * 4));
-    MG_HIP(mg_grow(&S.gid, &S.cap[1], n * 4));
-    MG_HIP(mg_grow(&S.sim, &S.cap[2], n * 8));
-    MG_HIP(mg_grow(&S.off, &S.cap[11], (size_t)(nranks + 1) * 8));
+    MG_HIP(mg_grow(S, &S.head, &S.cap[0], n * 4));
+    MG_HIP(mg_grow(S, &S.gid, &S.cap[1], n * 4));
+    MG_HIP(mg_grow(S, &S.sim, &S.cap[2], n * 8));
+    MG_HIP(mg_grow(S, &S.off, &S.cap[11], (size_t)(nranks + 1) * 8));
     MG_HIP(hipMemcpyAsync(S.off, off_host, (size_t)(nranks + 1) * 8, hipMemcpyHostToDevice, st));
     const int B = 256;
     const unsigned gb = (unsigned)((n + B - 1) / B);
     hipLaunchKernelGGL(k_mg_heads, dim3(gb), dim3(B), 0, st, d_rows, N, (const int64_t *)S.off, nranks, (uint32_t *)S.head, (double *)S.sim);
     size_t bytes = 0;
     MG_HIP(rocprim::inclusive_scan(nullptr, bytes, (uint32_t *)S.head, (uint32_t *)S.gid, n, rocprim::plus<uint32_t>(), st));
-    MG_HIP(mg_grow(&S.tmp, &S.cap[10], bytes));
+    MG_HIP(mg_grow(S, &S.tmp, &S.cap[10], bytes));
     MG_HIP(rocprim::inclusive_scan(S.tmp, bytes, (uint32_t *)S.head, (uint32_t *)S.gid, n, rocprim::plus<uint32_t>(), st));
     uint32_t ng32 = 0;
     MG_HIP(hipMemcpyAsync(&ng32, (uint32_t *)S.gid + (n - 1), 4, hipMemcpyDeviceToHost, st));
     MG_HIP(hipStreamSynchronize(st)); // (the number of groups sizes what follows)
     const size_t ng = ng32;
-    MG_HIP(mg_grow(&S.keys, &S.cap[3], ng * sizeof(MgKey)));
-    MG_HIP(mg_grow(&S.keys2, &S.cap[4], ng * sizeof(MgKey)));
-    MG_HIP(mg_grow(&S.first, &S.cap[5], ng * 4));
-    MG_HIP(mg_grow(&S.cnt, &S.cap[6], ng * 4));
-    MG_HIP(mg_grow(&S.sizes, &S.cap[7], ng * 4));
-    MG_HIP(mg_grow(&S.hits, &S.cap[8], ng * 4));
-    MG_HIP(mg_grow(&S.outpos, &S.cap[9], (ng + 1) * 8));
+    MG_HIP(mg_grow(S, &S.keys, &S.cap[3], ng * sizeof(MgKey)));
+    MG_HIP(mg_grow(S, &S.keys2, &S.cap[4], ng * sizeof(MgKey)));
+    MG_HIP(mg_grow(S, &S.first, &S.cap[5], ng * 4));
+    MG_HIP(mg_grow(S, &S.cnt, &S.cap[6], ng * 4));
+    MG_HIP(mg_grow(S, &S.sizes, &S.cap[7], ng * 4));
+    MG_HIP(mg_grow(S, &S.hits, &S.cap[8], ng * 4));
+    MG_HIP(mg_grow(S, &S.outpos, &S.cap[9], (ng + 1) * 8));
     hipLaunchKernelGGL(k_mg_groups, dim3(gb), dim3(B), 0, st, d_rows, N, (const uint32_t *)S.head, (const uint32_t *)S.gid, (const double *)S.sim,
                        (MgKey *)S.keys, (uint32_t *)S.first, (uint32_t *)S.cnt);
     bytes = 0;
     MG_HIP(rocprim::merge_sort(nullptr, bytes, (MgKey *)S.keys, (MgKey *)S.keys2, ng, MgLess(), st));
-    MG_HIP(mg_grow(&S.tmp, &S.cap[10], bytes));
+    MG_HIP(mg_grow(S, &S.tmp, &S.cap[10], bytes));
     MG_HIP(rocprim::merge_sort(S.tmp, bytes, (MgKey *)S.keys, (MgKey *)S.keys2, ng, MgLess(), st));
     const unsigned gg = (unsigned)((ng + B - 1) / B);
     hipLaunchKernelGGL(k_mg_qruns, dim3(gg), dim3(B), 0, st, (const MgKey *)S.keys2, (int64_t)ng, (const uint32_t *)S.cnt, (uint32_t *)S.sizes,
@@ -176,7 +203,7 @@ hipError_t merge_rows_device(hipStream_t st, const lm_hsp *d_rows, size_t n, con
     auto it = rocprim::make_transform_iterator((const uint32_t *)S.sizes, MgToI64());
     bytes = 0;
     MG_HIP(rocprim::exclusive_scan(nullptr, bytes, it, (int64_t *)S.outpos, (int64_t)0, ng, rocprim::plus<int64_t>(), st));
-    MG_HIP(mg_grow(&S.tmp, &S.cap[10], bytes));
+    MG_HIP(mg_grow(S, &S.tmp, &S.cap[10], bytes));
     MG_HIP(rocprim::exclusive_scan(S.tmp, bytes, it, (int64_t *)S.outpos, (int64_t)0, ng, rocprim::plus<int64_t>(), st));
     hipLaunchKernelGGL(k_mg_emit, dim3(gb), dim3(B), 0, st, d_rows, N, (const MgKey *)S.keys2, (int64_t)ng, (const uint32_t *)S.first,
                        (const int64_t *)S.outpos, (const uint32_t *)S.hits, d_out);

@@ -3938,6 +3938,27 @@ static void attach_name(lm_index *ix, lm_hsp &h) {
     h.genome_id = is->second.first;
     h.seq_id = is->second.second;
 }
+// the handle's scratch slabs lent to the shard merge between two searches (lm_merge.h)
+void lm_scratch_session_begin(lm_index *ix) {
+    if (!ix) return;
+    ix->mu.lock();
+    (void)hipSetDevice(ix->device);
+}
+void lm_scratch_session_end(lm_index *ix) {
+    if (ix) ix->mu.unlock();
+}
+void *lm_scratch_borrow(lm_index *ix, size_t bytes) {
+    if (!ix || bytes == 0) return nullptr;
+    try {
+        return ix->arena[0].alloc(bytes);
+    } catch (const std::exception &e) {
+        ix->err = e.what();
+        return nullptr;
+    }
+}
+void lm_scratch_return(lm_index *ix, void *p) {
+    if (ix && p) (void)ix->arena[0].release(p);
+}
 void lm_attach_names(lm_index *ix, lm_hsp *rows, size_t n) {
     if (!ix || n == 0) return;
     if (ix->host.synthetic && !ix->syn_dense && ix->host.synth_genomes > 0) {
