@@ -40,6 +40,20 @@ struct DeviceOOM : HipError {
 };
 inline std::atomic<int64_t> g_dbuf_bytes{0}; // device bytes held by all DBufs of the process (index image + scratch)
 
+// hipMalloc that leaves the device a reserve.  The runtime allocates device memory of its own while a search runs (kernel
+// arguments, scratch, signals); with the index, the lane slabs and the overflow slabs a C3 handle held 274 of 288 GB, and one run
+// in round 6 ended in "HSA_STATUS_ERROR_OUT_OF_RESOURCES ... Queue aborting" during its warm-up steps - not an error the library
+// can catch.  A large request that would leave less than 6 GB free is refused here instead (the callers trim their empty slabs,
+// retry, and then halve the batch part: DeviceOOM), on production-size devices only.
+static inline hipError_t lm_guarded_malloc(void **p, size_t n) {
+    if (n >= ((size_t)16 << 20)) {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot >= ((size_t)64 << 30) && fr < n + ((size_t)6 << 30)) return hipErrorOutOfMemory;
+    }
+    return hipMalloc(p, n);
+}
+
+
 // Scratch of one index handle that comes and goes with the halves of a search (seeding / alignment): carved
 // out of a few large device allocations ("slabs") that stay with the handle, because hipMalloc / hipFree of tens of GB per
 // batch part cost seconds (the driver clears the pages).  First fit by address inside a slab, free neighbours coalesce; at
@@ -121,15 +135,15 @@ struct ScratchArena {
             if (pass == 1) break;
             char *base = nullptr;
             size_t got = own;
-            hipError_t e = hipMalloc((void **)&base, got);
+            hipError_t e = lm_guarded_malloc((void **)&base, got);
             if (e != hipSuccess) {
                 (void)hipGetLastError();
                 trim_locked();
-                e = hipMalloc((void **)&base, got);
+                e = lm_guarded_malloc((void **)&base, got);
                 if (e != hipSuccess && got > bytes) { // (the head-room of the grid is a convenience, not a need)
                     (void)hipGetLastError();
                     got = bytes;
-                    e = hipMalloc((void **)&base, got);
+                    e = lm_guarded_malloc((void **)&base, got);
                 }
             }
             if (e != hipSuccess) {
@@ -278,13 +292,13 @@ template <typename T> struct DBuf {
             p = (T *)tls_arena->alloc(want * sizeof(T));
             arena = tls_arena;
         } else {
-            hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+            hipError_t e = lm_guarded_malloc((void **)&p, want * sizeof(T));
             if (e != hipSuccess) {
                 p = nullptr;
                 (void)hipGetLastError();
                 if (tls_arena) { // memory parked in empty slabs
                     tls_arena->trim();
-                    e = hipMalloc((void **)&p, want * sizeof(T));
+                    e = lm_guarded_malloc((void **)&p, want * sizeof(T));
                 }
             }
             if (e != hipSuccess) {
