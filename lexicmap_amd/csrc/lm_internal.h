@@ -318,7 +318,15 @@ template <typename T> struct DBuf {
     void alloc_exact(size_t n, bool zero = false, hipStream_t st = nullptr) {
         release();
         size_t want = std::max<size_t>(n, 1);
-        HIPCHK(hipMalloc((void **)&p, want * sizeof(T)));
+        {
+            const hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+            if (e == hipErrorOutOfMemory) { // (its own type: the loader retries without its kept copies)
+                p = nullptr;
+                (void)hipGetLastError();
+                throw DeviceOOM("device allocation of " + std::to_string(want * sizeof(T) >> 20) + " MB failed: out of memory");
+            }
+            HIPCHK(e);
+        }
         cap = want;
         g_dbuf_bytes += (int64_t)bytes();
         if (zero) HIPCHK(hipMemsetAsync(p, 0, want * sizeof(T), st));

@@ -1068,6 +1068,10 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
         v.ngenomes = h.n_local_genomes;
         v.shard_rank = h.shard_rank;
         v.shard_count = h.shard_count;
+        // (A device allocation that fails inside the passes - the keep budget is an estimate of what the packed image and its
+        // sort scratch leave - makes the passes start over WITHOUT the kept copies, every file decoded twice, instead of failing the open.)
+        bool loader_keep = getenv("LM_LOADER_NO_KEEP") == nullptr;
+        for (int load_try = 0;; load_try++) try
         {   // packed seed image: every chunk file is decoded and shown to the packer twice (count, then place).  Files are
             // decoded by the host threads ahead of the upload into a small pool of REUSED chunk slots (after the first files
             // no decode touches fresh pages: faulting in and zero-filling 18 B per seed of new memory per file cost more than
@@ -1148,7 +1152,7 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
                 size_t fr = 0, tot = 0;
                 if (hipMemGetInfo(&fr, &tot) == hipSuccess) // (image: <= ~0.55 bytes per file byte measured; 0.75 reserved)
                     keep_budget = (int64_t)fr - files_bytes * 3 / 4 / (int64_t)std::max(1, h.shard_count) - ((int64_t)6 << 30); // (the genome store is allocated already)
-                if (getenv("LM_LOADER_NO_KEEP")) keep_budget = 0;
+                if (!loader_keep) keep_budget = 0;
             }
             int64_t n_kept_files = 0;
             for (int pass = 0; pass < 2; pass++) {
@@ -1256,11 +1260,18 @@ lm_status lm_index_open(const char *dir, const lm_options *opt, int device, lm_i
                 fprintf(stderr, "[lm] loader: %lld of %zu chunk files kept on the device between the passes (%.2f GB of decoded seeds; budget %.2f GB)\n",
                         (long long)n_kept_files, nf, (double)kept_bytes / 1e9, (double)keep_budget / 1e9);
             const double tf0 = now_ms();
+            if (load_try == 0 && loader_keep && getenv("LM_DEBUG_LOADER_OOM")) throw DeviceOOM("test hook: out of memory at the end of the seed passes");
             sp.finish();
             if (ldbg)
                 fprintf(stderr, "[lm] loader: %zu chunk files through %zu slots, two passes in %.0f ms: %.0f ms waiting for the decoders, %.0f ms "
                                 "registering the slots, %.0f ms uploading + packing, %.0f ms sorting the partitions\n",
                         nf, nslots, now_ms() - t_seeds0, t_wait, t_pin, t_pack, now_ms() - tf0);
+            break;
+        } catch (const DeviceOOM &e) {
+            if (!loader_keep || load_try > 0) throw;
+            loader_keep = false;
+            (void)hipDeviceSynchronize();
+            if (getenv("LM_DEBUG")) fprintf(stderr, "[lm] loader: %s - the seed passes start over without device copies of the decoded seeds\n", e.what());
         }
         // ---- the genomes (read meanwhile): bases and tables to the device
         {

@@ -18,7 +18,9 @@
 #include <errno.h>
 #include <sys/stat.h>
 
+#include <algorithm>
 #include <atomic>
+#include <map>
 #include <thread>
 
 namespace lm {
@@ -717,6 +719,20 @@ extern "C" lm_status lm_index_save(lm_index *ix, const char *dir_c, int chunks) 
                 if (fg.bad || fi.bad) throw HipError("lm_index_save: write failed (genomes)");
             }
             if (fmap.bad) throw HipError("lm_index_save: write failed (genomes.map.bin)");
+        }
+        // ---- genomes.chunks.bin (lib-index-build.go:1787-1808): per split genome the number of its chunks and their keys, in
+        // chunk order; written (empty when no genome was split) so that the saved index is complete for the reference's reader
+        {
+            std::map<int, std::vector<std::pair<int, uint64_t>>> lists; // list number -> (chunk index, key)
+            for (const auto &kv : h.chunk_of) lists[kv.second.list].emplace_back(kv.second.idx, kv.first);
+            OutFile fc(dir + "/genomes.chunks.bin");
+            for (auto &li : lists) {
+                if (li.second.size() <= 1) continue;
+                std::sort(li.second.begin(), li.second.end());
+                fc.be((uint64_t)li.second.size(), 8);
+                for (const auto &e : li.second) fc.be(e.second, 8);
+            }
+            if (fc.bad) throw HipError("lm_index_save: write failed (genomes.chunks.bin)");
         }
         // ---- seeds: masks split evenly over the chunk files (lib-index-build.go:1861-1889)
         std::vector<int64_t> md_off((size_t)2 * M + 1), out_off((size_t)2 * M + 1);

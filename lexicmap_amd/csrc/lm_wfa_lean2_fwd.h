@@ -435,10 +435,12 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
                 // M[s-4], I[s] or D[s] has one.  (Empty ranges are sentinels +- a few: they lose every minimum / maximum.)
                 const int i_lo = WR_UNIFORM((mlo[4] < ilo[1] ? mlo[4] : ilo[1]) + 1), i_hi = WR_UNIFORM((mhi[4] > ihi[1] ? mhi[4] : ihi[1]) + 1);
                 const int d_lo = WR_UNIFORM((mlo[4] < dlo[1] ? mlo[4] : dlo[1]) - 1), d_hi = WR_UNIFORM((mhi[4] > dhi[1] ? mhi[4] : dhi[1]) - 1);
-                ilo[0] = i_lo <= i_hi ? i_lo : E_LO;
-                ihi[0] = i_lo <= i_hi ? i_hi : E_HI;
-                dlo[0] = d_lo <= d_hi ? d_lo : E_LO;
-                dhi[0] = d_lo <= d_hi ? d_hi : E_HI;
+                // (raw: an empty range is lo > hi here; the cut-off's clamps keep it empty and put the sentinels in, a row too
+                // narrow for the cut-off does so itself below - one normalisation per step instead of two)
+                ilo[0] = i_lo;
+                ihi[0] = i_hi;
+                dlo[0] = d_lo;
+                dhi[0] = d_hi;
                 // M[s] = the row: min(M[s-4].lo, I[s].lo, D[s].lo) is the `lo` of the top of this step term by term (never empty here)
                 mlo[0] = lo;
                 mhi[0] = hi;
@@ -534,6 +536,15 @@ L2_FWD_ATTR void wfa_lean2_forward(const L2Prob &p, RT *ring, uint32_t *qb, uint
                         ihi[0] = WR_UNIFORM(ihi[0]);
                         dlo[0] = WR_UNIFORM(dlo[0]);
                         dhi[0] = WR_UNIFORM(dhi[0]);
+                    }
+                } else if (!EDGE) { // (no cut-off on a row of fewer than ten cells: the interior ranges get their sentinels here)
+                    if (ilo[0] > ihi[0]) {
+                        ilo[0] = E_LO;
+                        ihi[0] = E_HI;
+                    }
+                    if (dlo[0] > dhi[0]) {
+                        dlo[0] = E_LO;
+                        dhi[0] = E_HI;
                     }
                 }
             }

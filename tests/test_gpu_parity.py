@@ -757,3 +757,64 @@ def test_prophage_golden_rows_through_the_hip_stages(small_index):
                     "%.3f" % (100.0 * r["matches"] / r["align_len"]), r["gaps"], "%.2e" % ev.value, bits.value))
     want = [as_row(gold[i]) for _g, _rc, _q, _t, rows in wins for i in rows]
     assert got == want
+
+
+def test_a_saved_index_keeps_its_genome_chunk_lists(tmp_path):
+    """lm_index_save writes genomes.chunks.bin (lib-index-build.go:1787-1808: per split genome the number of its chunks and their
+    keys in chunk order): the file of an index with split genomes comes back byte for byte, the saved index gives the rows of
+    the original through the HIP path and through the oracle; an index without split genomes gets an empty file"""
+    la = _la()
+    from lexicmap_amd import synth
+    genomes = _split_genomes()
+    qs = synth.make_gene_queries(genomes, 12, seed=53, len_range=(500, 3000), max_div=0.08)
+    ids, seqs = [q[0] for q in qs], [q[1] for q in qs]
+    d0, d1, d2 = str(tmp_path / "split.lmi"), str(tmp_path / "saved.lmi"), str(tmp_path / "plain_saved.lmi")
+    O.build_index(d0, genomes, O.default_build_opt(chunks=2, max_genome=70000))
+    gi = la.Index(d0)
+    want = gi.search_tsv(ids, seqs)
+    gi.save(d1, chunks=3)
+    gi.close()
+    assert open(os.path.join(d1, "genomes.chunks.bin"), "rb").read() == open(os.path.join(d0, "genomes.chunks.bin"), "rb").read()
+    g1, o1 = la.Index(d1), O.Index(d1)
+    got = g1.search_tsv(ids, seqs)
+    exp = []
+    for i, s in zip(ids, seqs):
+        exp += o1.search_tsv(i, s)
+    g1.close()
+    o1.close()
+    assert len(want) > 0 and got == want == exp
+    d3 = str(tmp_path / "plain.lmi")
+    O.build_index(d3, genomes[:3], O.default_build_opt(chunks=2))
+    g3 = la.Index(d3)
+    g3.save(d2, chunks=2)
+    g3.close()
+    assert os.path.getsize(os.path.join(d2, "genomes.chunks.bin")) == 0
+
+
+def test_an_allocation_failure_inside_the_loader_starts_the_seed_passes_over_without_kept_copies(tmp_path, monkeypatch):
+    """the loader keeps the decoded seeds of a chunk file on the device between its count and place passes while an ESTIMATE of
+    what the packed image will need leaves room; when an allocation fails all the same, the passes start over without the kept
+    copies (every file decoded twice) instead of failing the open (LM_DEBUG_LOADER_OOM: the failure injected once, at the end of
+    the first attempt).  Same image, same rows."""
+    la = _la()
+    from lexicmap_amd import synth
+    genomes = synth.make_genomes(5, 70_000, 2, seed=61, max_div=0.05)
+    qs = synth.make_gene_queries(genomes, 8, seed=62, len_range=(500, 2000), max_div=0.06)
+    ids, seqs = [q[0] for q in qs], [q[1] for q in qs]
+    d = str(tmp_path / "oom.lmi")
+    O.build_index(d, genomes, O.default_build_opt(chunks=3))
+    gi = la.Index(d)
+    want, info0 = gi.search_tsv(ids, seqs), gi.info()
+    seeds0 = [gi.mask_seeds(m) for m in (0, 7, 99)]
+    gi.close()
+    monkeypatch.setenv("LM_DEBUG_LOADER_OOM", "1")
+    gi = la.Index(d)
+    monkeypatch.delenv("LM_DEBUG_LOADER_OOM")
+    try:
+        assert gi.info() == info0
+        for m, s0 in zip((0, 7, 99), seeds0):
+            s1 = gi.mask_seeds(m)
+            assert all(np.array_equal(a, b) for a, b in zip(s0, s1))
+        assert len(want) > 0 and gi.search_tsv(ids, seqs) == want
+    finally:
+        gi.close()
