@@ -102,14 +102,14 @@ lm_status lm_index_build_synthetic(const lm_synth_spec *spec, const lm_options *
 /* bases [start, start+len) of local genome `local_genome` as ASCII (used to derive synthetic queries) */
 lm_status lm_index_fetch(lm_index *idx, int64_t local_genome, int64_t start, int64_t len, uint8_t *out);
 /* Writes the resident (unsharded) index to `dir`: info.toml, seeds/chunk_NNN.bin (+ .idx, kv/kv-data.go:126-602) in at most
- * `chunks` files, genomes/batch_NNNN/genomes.bin (+ .idx, genome/genome.go:217-357) and genomes.map.bin in the reference's
+ * `chunks` files, genomes/batch_NNNN/genomes.bin (+ .idx, genome/genome.go:217-357), genomes.map.bin and genomes.chunks.bin in the reference's
  * on-disk format; masks.bin in THIS build's own layout (LMMASKS1: lexichash's file layout is not in the reference tree), so
  * lm_index_open and the oracle read the result back, the reference's Go binary does not.  info.toml carries the format
  * version, k, masks, chunk files, partitions, genome counts, input bases and the contig interval; the build-time settings it
  * does not know (rand-seed, the seed-distance settings, soft-masking, max-kmer-freq) are written as the reference's defaults
  * and are not read by a search.  Used to time the loader at benchmark scale on GPU-built sets.
- * Not written: genomes.chunks.bin (the chunk lists of genomes split at --max-genome) - an index with split genomes saved this
- * way reports its chunks as separate genomes; a shard (shard_count > 1) is refused. */
+ * genomes.chunks.bin (the chunk lists of genomes split at --max-genome, lib-index-build.go:1787-1808) is written too - empty
+ * when no genome was split.  A shard (shard_count > 1) is refused. */
 lm_status lm_index_save(lm_index *idx, const char *dir, int chunks);
 /* Replaces (*Index).Close (lib-index-search.go:760) */
 void lm_index_close(lm_index *idx);
