@@ -43,12 +43,14 @@ inline std::atomic<int64_t> g_dbuf_bytes{0}; // device bytes held by all DBufs o
 // hipMalloc that leaves the device a reserve.  The runtime allocates device memory of its own while a search runs (kernel
 // arguments, scratch, signals); with the index, the lane slabs and the overflow slabs a C3 handle held 274 of 288 GB, and one run
 // in round 6 ended in "HSA_STATUS_ERROR_OUT_OF_RESOURCES ... Queue aborting" during its warm-up steps - not an error the library
-// can catch.  A large request that would leave less than 6 GB free is refused here instead (the callers trim their empty slabs,
-// retry, and then halve the batch part: DeviceOOM), on production-size devices only.
+// can catch.  A large request that would leave less than 3 GB free is refused here instead (the callers trim their empty slabs,
+// retry, and then halve the batch part: DeviceOOM), on production-size devices only.  (A reserve of 6 GB refused so many overflow
+// slabs in one of two C3 runs that the halved parts - they stay halved - made 29 lookup launches per step instead of 17: 8.7
+// instead of 8.2 s.  With 3 GB two runs ended at 16 and 18 parts, profiles/r06_c3_reserve3_mem.log.)
 static inline hipError_t lm_guarded_malloc(void **p, size_t n) {
     if (n >= ((size_t)16 << 20)) {
         size_t fr = 0, tot = 0;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot >= ((size_t)64 << 30) && fr < n + ((size_t)6 << 30)) return hipErrorOutOfMemory;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot >= ((size_t)64 << 30) && fr < n + ((size_t)3 << 30)) return hipErrorOutOfMemory;
     }
     return hipMalloc(p, n);
 }

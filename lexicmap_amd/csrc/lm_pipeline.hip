@@ -169,7 +169,10 @@ void lm_fill_gap_lut(lm_index *ix) {
 void lm_set_scratch_budget(lm_index *ix) {
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) != hipSuccess) return;
-    ix->scratch_budget = (int64_t)((double)fr * 0.80); // (0.85 until round 5: the pools' head-room and the buffers outside the arena took the device to 99 %)
+    // (0.85 until round 5: the pools' head-room and the buffers outside the arena took the device to 99 %.  Round 6 tried 0.76:
+    // the parts and therefore the demand stay the same - lane slabs + overflow slabs 148 GB instead of 145, the smaller slabs
+    // push more into overflow slabs that are sized on a grid - and 6.5 GB were left free instead of 15.7: kept at 0.80.)
+    ix->scratch_budget = (int64_t)((double)fr * 0.80);
     if (const char *e = getenv("LM_SCRATCH_BUDGET_MB")) ix->scratch_budget = std::max<int64_t>(64, atoll(e)) << 20;
     if (getenv("LM_DEBUG"))
         fprintf(stderr, "[lm] index resident: %.2f GB, device free %.2f of %.2f GB, scratch budget %.2f GB\n",
