@@ -2509,7 +2509,11 @@ static void align_range(lm_index *ix, lm_qbatch *qb, Work &w, AlignCtx &a, TaskS
     int64_t gw_used = 0;        // bytes of the round's window buffer in use
     const int64_t gw_target = BUDGET(ix) > 0 ? std::min<int64_t>((int64_t)6 << 30, std::max<int64_t>((int64_t)64 << 20, BUDGET(ix) * 3 / 100)) : (int64_t)1 << 30;
     const int64_t round_hsps = getenv("LM_DEBUG_ROUND_HSPS") ? atoll(getenv("LM_DEBUG_ROUND_HSPS")) : 330000;
-    const int64_t min_round_hsps = getenv("LM_DEBUG_MIN_ROUND_HSPS") ? atoll(getenv("LM_DEBUG_MIN_ROUND_HSPS")) : 150000;
+    // what an idle consumer aligns instead of waiting for the producer.  150 000 until the end of round 6: every round ends in the
+    // latency-bound 512 / 1024-diagonal passes of a few long alignments (~130 ms per round at C3), and the idle rule made ~32
+    // rounds per C3 step out of what ~20 full ones hold: 8.0 s per step against 7.54 with a full round only, 8.68 with 80 000
+    // (profiles/r06_c3_ab_rounds.json, one index) - and a step whose number of rounds depended on thread timing.
+    const int64_t min_round_hsps = getenv("LM_DEBUG_MIN_ROUND_HSPS") ? atoll(getenv("LM_DEBUG_MIN_ROUND_HSPS")) : round_hsps;
     // ---- finalisation of a round's genomes (:2266-2357 / :2533-2626, then :2684-2749); on the consumer's thread
     auto finalize_round = [&](Round &R) {
         const double td = now_ms();
